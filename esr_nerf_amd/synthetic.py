@@ -1,0 +1,106 @@
+"""Synthetic "slab" scenes of SURVEY.md section 8(d) / BASELINE.md section 2.
+
+The reference's sampler draws ``ceil((t_max - t_min) * |d| / (0.5 * voxel))`` steps
+per ray (app/utils/base/cuda/render_utils_kernel.cu:53).  In a box
+``(-1,-1,-z) .. (1,1,z)`` with ``voxel = 2/256`` an axis-parallel ray therefore
+gets exactly ``256 * z * 2`` samples, which pins BASELINE.json's
+"4096 rays x 128 samples" (z = 0.25) and "x 192 samples" (z = 0.375) on the
+reference's own arithmetic.  Everything is seeded and generated on CPU, then
+moved to the requested device, so the CPU oracle and the HIP path see identical
+bits.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict
+
+import torch
+
+# name -> (n_rays, z half-extent, voxels along x)   [z-extent in voxels = res * z]
+CONFIGS = {
+    "C1": dict(n_rays=512, z=1.0 / 3.0, res=96),      # coarse plumbing size, ~64 samples
+    "C2": dict(n_rays=4096, z=0.25, res=256),         # fine, 128 samples (north star)
+    "C3": dict(n_rays=4096, z=0.375, res=256),        # fine, 192 samples
+    "tiny": dict(n_rays=64, z=0.25, res=64),          # 32 samples, golden-vector size
+    "small": dict(n_rays=512, z=0.25, res=128),       # 64 samples
+    "g16": dict(n_rays=48, z=0.25, res=32),           # 16 samples, committed golden fixtures
+}
+
+
+@dataclass
+class SlabScene:
+    name: str
+    n_rays: int
+    xyz_min: torch.Tensor
+    xyz_max: torch.Tensor
+    num_voxels: int
+    near: float
+    far: float
+    mask_density: torch.Tensor        # [1,1,32,32,32]
+    mask_alpha_init: float
+    s_val: float
+    batch: Dict[str, torch.Tensor] = field(default_factory=dict)   # rays_o, rays_d, viewdirs, em_modes, rgbs
+    sdf_fn: object = None
+
+
+def slab_scene(name: str = "C2", s_val: float = 20.0, seed: int = 0, n_rays: int | None = None,
+               oblique: bool = False) -> SlabScene:
+    """Build inputs for one of the BASELINE configs.
+
+    ``oblique=True`` tilts and jitters the ray directions (un-normalised ``rays_d``)
+    so rays get ragged step counts and clip the box faces: the edge-case variant
+    used by the parity tests; the bench uses the axis-parallel default.
+    """
+    c = CONFIGS[name]
+    n = int(n_rays if n_rays is not None else c["n_rays"])
+    z, res = float(c["z"]), int(c["res"])
+    g = torch.Generator().manual_seed(seed)
+    xyz_min = torch.tensor([-1.0, -1.0, -z])
+    xyz_max = torch.tensor([1.0, 1.0, z])
+    num_voxels = res * res * int(round(res * z))
+    xy = (torch.rand(n, 2, generator=g) * 2 - 1) * 0.9
+    rays_o = torch.cat([xy, torch.full((n, 1), 2.0)], -1)
+    rays_d = torch.tensor([0.0, 0.0, -1.0]).repeat(n, 1)
+    if oblique:
+        tilt = (torch.rand(n, 2, generator=g) * 2 - 1) * 0.35
+        rays_d = torch.cat([tilt, -torch.ones(n, 1)], -1)
+        rays_d = rays_d * (0.5 + torch.rand(n, 1, generator=g))        # un-normalised on purpose
+        rays_d[::17, 0] = 0.0                                           # exercise the d==0 branch
+    viewdirs = rays_d / rays_d.norm(dim=-1, keepdim=True)
+    em_modes = (torch.arange(n) % 2).long()
+    rgbs = torch.rand(n, 3, generator=g)
+    rgbs[::13] = 1.0                                                    # exercise the rgbs>=1 branch of the loss
+    return SlabScene(
+        name=name, n_rays=n, xyz_min=xyz_min, xyz_max=xyz_max, num_voxels=num_voxels,
+        near=0.05, far=6.0, mask_density=torch.full((1, 1, 32, 32, 32), 30.0),
+        mask_alpha_init=1e-6, s_val=float(s_val),
+        batch=dict(rays_o=rays_o.contiguous(), rays_d=rays_d.contiguous(),
+                   viewdirs=viewdirs.contiguous(), em_modes=em_modes, rgbs=rgbs),
+    )
+
+
+def analytic_sdf(world_size, xyz_min, xyz_max) -> torch.Tensor:
+    """SDF = z + 0.05 sin(3x) cos(3y) sampled on the grid nodes -> [1,1,X,Y,Z]."""
+    X, Y, Z = [int(v) for v in world_size]
+    xs = torch.linspace(float(xyz_min[0]), float(xyz_max[0]), X)
+    ys = torch.linspace(float(xyz_min[1]), float(xyz_max[1]), Y)
+    zs = torch.linspace(float(xyz_min[2]), float(xyz_max[2]), Z)
+    gx, gy, gz = torch.meshgrid(xs, ys, zs, indexing="ij")
+    return (gz + 0.05 * torch.sin(3 * gx) * torch.cos(3 * gy))[None, None].contiguous()
+
+
+@torch.no_grad()
+def init_slab_model(model, scene: SlabScene, seed: int = 0):
+    """Overwrite grids of a VoxurfF-compatible model (reference or ours) with the
+    slab content: analytic SDF, N(0, 0.1) colour grids.  MLPs keep their default
+    nn.Linear init (drawn by the caller under ``torch.manual_seed``)."""
+    g = torch.Generator().manual_seed(seed + 1)
+    ws = [int(v) for v in model.world_size]
+    dev = model.sdf.grid.device
+    model.sdf.grid.data.copy_(analytic_sdf(ws, scene.xyz_min, scene.xyz_max).to(dev))
+    for name in ("off_color", "emo_color"):
+        grid = getattr(model, name).grid
+        vals = torch.randn(tuple(grid.shape), generator=g) * 0.1
+        grid.data.copy_(vals.to(dev))
+    model.sdf_random_init = False
+    return model

@@ -1,0 +1,158 @@
+"""ctypes front-end of the C oracle (oracle/esr_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; the product package (esr_nerf_amd) never imports it.
+
+Every function mirrors one op of the reference's pybind modules
+(app/utils/base/cuda/render_utils.cpp:170-184, total_variation.cpp:29-32) on
+CPU torch tensors, so it can also be plugged into the imported reference
+(oracle/gen_golden.py) in place of the CUDA extension.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libesr_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the C oracle with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(
+        os.path.join(_HERE, "esr_oracle.c")
+    ):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+    return _lib
+
+
+def _p(t: torch.Tensor):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _f32(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def sample_pts_on_rays(rays_o, rays_d, xyz_min, xyz_max, near, far, stepdist):
+    """-> [ray_pts, mask_outbbox, ray_id, step_id, N_steps, t_min, t_max]
+    (render_utils_kernel.cu:196-242)."""
+    rays_o, rays_d = _f32(rays_o), _f32(rays_d)
+    xyz_min, xyz_max = _f32(xyz_min), _f32(xyz_max)
+    n = rays_o.shape[0]
+    t_min = torch.empty(n, dtype=torch.float32)
+    t_max = torch.empty(n, dtype=torch.float32)
+    n_steps = torch.empty(n, dtype=torch.int64)
+    L = lib()
+    L.esr_oracle_sample_count(
+        _p(rays_o), _p(rays_d), _p(xyz_min), _p(xyz_max),
+        ctypes.c_float(float(near)), ctypes.c_float(float(far)),
+        ctypes.c_float(float(stepdist)), ctypes.c_int64(n),
+        _p(t_min), _p(t_max), _p(n_steps),
+    )
+    total = int(n_steps.sum().item())
+    ray_pts = torch.empty(total, 3, dtype=torch.float32)
+    mask = torch.empty(total, dtype=torch.uint8)
+    ray_id = torch.empty(total, dtype=torch.int64)
+    step_id = torch.empty(total, dtype=torch.int64)
+    L.esr_oracle_sample_fill(
+        _p(rays_o), _p(rays_d), _p(xyz_min), _p(xyz_max), _p(t_min), _p(n_steps),
+        ctypes.c_float(float(stepdist)), ctypes.c_int64(n),
+        _p(ray_pts), _p(mask), _p(ray_id), _p(step_id),
+    )
+    return [ray_pts, mask.bool(), ray_id, step_id, n_steps, t_min, t_max]
+
+
+def alpha2weight(alpha, ray_id, n_rays):
+    """-> [weight, T, alphainv_last, i_start, i_end] (render_utils_kernel.cu:619-651)."""
+    alpha = _f32(alpha)
+    ray_id = ray_id.to(torch.int64).contiguous()
+    m = alpha.shape[0]
+    weight = torch.empty(m, dtype=torch.float32)
+    T = torch.empty(m, dtype=torch.float32)
+    last = torch.empty(n_rays, dtype=torch.float32)
+    i_s = torch.empty(n_rays, dtype=torch.int64)
+    i_e = torch.empty(n_rays, dtype=torch.int64)
+    lib().esr_oracle_alpha2weight(
+        _p(alpha), _p(ray_id), ctypes.c_int64(m), ctypes.c_int64(int(n_rays)),
+        _p(weight), _p(T), _p(last), _p(i_s), _p(i_e),
+    )
+    return [weight, T, last, i_s, i_e]
+
+
+def alpha2weight_backward(alpha, weight, T, alphainv_last, i_start, i_end, n_rays,
+                          grad_weights, grad_last):
+    """-> grad wrt alpha (render_utils_kernel.cu:679-707)."""
+    alpha, weight, T = _f32(alpha), _f32(weight), _f32(T)
+    alphainv_last = _f32(alphainv_last)
+    gw, gl = _f32(grad_weights), _f32(grad_last)
+    m = alpha.shape[0]
+    grad = torch.empty(m, dtype=torch.float32)
+    lib().esr_oracle_alpha2weight_backward(
+        _p(alpha), _p(weight), _p(T), _p(alphainv_last),
+        _p(i_start.contiguous()), _p(i_end.contiguous()),
+        ctypes.c_int64(m), ctypes.c_int64(int(n_rays)), _p(gw), _p(gl), _p(grad),
+    )
+    return grad
+
+
+def total_variation_add_grad(param, grad, wx, wy, wz, dense_mode):
+    """In-place on `grad` (total_variation_kernel.cu:68-98)."""
+    assert param.is_contiguous() and grad.is_contiguous()
+    assert param.dtype == torch.float32 and grad.dtype == torch.float32
+    lib().esr_oracle_tv_add_grad(
+        _p(param.detach()), _p(grad),
+        ctypes.c_float(float(wx)), ctypes.c_float(float(wy)), ctypes.c_float(float(wz)),
+        ctypes.c_int64(param.shape[2]), ctypes.c_int64(param.shape[3]),
+        ctypes.c_int64(param.shape[4]), ctypes.c_int64(param.numel()),
+        ctypes.c_int(1 if dense_mode else 0),
+    )
+
+
+def segment_sum(src, index, out):
+    """torch_scatter.segment_coo(src, index, out=out, reduce='sum') for sorted index."""
+    src = _f32(src)
+    index = index.to(torch.int64).contiguous()
+    assert out.is_contiguous() and out.dtype == torch.float32
+    c = 1 if src.dim() == 1 else src.shape[1]
+    lib().esr_oracle_segment_sum(
+        _p(src), _p(index), ctypes.c_int64(src.shape[0]), ctypes.c_int64(c), _p(out)
+    )
+    return out
+
+
+class _Namespace:
+    """Stand-in for the pybind module object the reference imports."""
+
+
+def as_render_utils_module():
+    m = _Namespace()
+    m.sample_pts_on_rays = sample_pts_on_rays
+    m.alpha2weight = alpha2weight
+    m.alpha2weight_backward = alpha2weight_backward
+    return m
+
+
+def as_total_variation_module():
+    m = _Namespace()
+    m.total_variation_add_grad = total_variation_add_grad
+    return m
+
+
+__all__ = [
+    "build", "sample_pts_on_rays", "alpha2weight", "alpha2weight_backward",
+    "total_variation_add_grad", "segment_sum",
+    "as_render_utils_module", "as_total_variation_module",
+]
+_ = np  # numpy kept importable for callers that pass arrays through torch.from_numpy

@@ -1,0 +1,42 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_npz(name):
+    with np.load(os.path.join(GOLDEN, name), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def golden_params():
+    z = load_npz("fine_g16_params.npz")
+    meta = {k: z.pop(k) for k in list(z) if k.startswith("__")}
+    return {k: torch.from_numpy(v) for k, v in z.items()}, meta
+
+
+@pytest.fixture(scope="session", params=["fine_g16_axis", "fine_g16_oblique"])
+def golden_case(request):
+    z = load_npz(request.param + ".npz")
+    return request.param, {k: torch.from_numpy(np.asarray(v)) for k, v in z.items()}
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    """SURVEY.md 8(d) parity metric: max|a-b| / max(|b|) (rel-to-max-norm)."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    if b.numel() == 0:
+        return 0.0 if a.numel() == 0 else float("inf")
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
