@@ -1,0 +1,98 @@
+"""ctypes binding of libesr_hip.so (include/esr_hip.h).
+
+The library is the product: if it is missing or fails to load, everything that
+needs it raises -- there is no CPU or PyTorch fallback on the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libesr_hip.so")
+ABI_VERSION = 1
+_lib = None
+
+
+class EsrScene(C.Structure):
+    _fields_ = [
+        ("xyz_min", C.c_float * 3), ("xyz_max", C.c_float * 3),
+        ("mask_min", C.c_float * 3), ("mask_max", C.c_float * 3),
+        ("gx", C.c_int32), ("gy", C.c_int32), ("gz", C.c_int32),
+        ("mx", C.c_int32), ("my", C.c_int32), ("mz", C.c_int32),
+        ("near_", C.c_float), ("stepdist", C.c_float), ("voxel_size", C.c_float),
+        ("act_shift", C.c_float), ("mask_thres", C.c_float), ("fast_thres", C.c_float),
+        ("s_val", C.c_float), ("max_steps", C.c_int32), ("grad_feat", C.c_float * 4),
+    ]
+
+
+class EsrPlan(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("n_on", "n_off", "tiles_on", "tiles_all", "m0", "m1", "m2", "overflow")]
+
+
+class EsrMlpWeights(C.Structure):
+    _fields_ = [("w", C.c_void_p * 4), ("b", C.c_void_p * 4)]
+
+
+# every exported symbol of include/esr_hip.h (checked by tests/test_abi.py)
+EXPORTS = [
+    "esr_abi_version", "esr_build_info",
+    "esr_sample_count", "esr_sample_fill", "esr_alpha2weight_fwd", "esr_alpha2weight_bwd",
+    "esr_tv_add_grad", "esr_segment_sum",
+    "esr_fine_march_count", "esr_fine_plan_begin", "esr_fine_plan", "esr_fine_march_fill",
+    "esr_fine_march_bwd", "esr_fine_feat_fwd", "esr_fine_feat_bwd",
+    "esr_mlp_packed_floats", "esr_mlp_pack", "esr_mlp_fwd", "esr_mlp_dgrad", "esr_mlp_wgrad",
+    "esr_fine_tone_in_fwd", "esr_fine_composite_fwd", "esr_fine_composite_bwd",
+    "esr_fine_tone_in_bwd", "esr_fine_loss_fwd_bwd",
+]
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library; raises (never falls back) when it is unavailable."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m esr_nerf_amd.build` "
+                "(there is no CPU fallback for the HIP path)")
+        L = C.CDLL(LIB_PATH)
+        L.esr_abi_version.restype = C.c_int
+        L.esr_build_info.restype = C.c_char_p
+        if hasattr(L, "esr_mlp_packed_floats"):
+            L.esr_mlp_packed_floats.restype = C.c_int64
+        if L.esr_abi_version() != ABI_VERSION:
+            raise RuntimeError("libesr_hip.so ABI version mismatch: rebuild")
+        _lib = L
+    return _lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise RuntimeError(f"{what} failed with code {code}" +
+                           (" (hipError)" if code > 0 else " (bad argument)"))
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA(HIP) tensor (or NULL for None)."""
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise RuntimeError("esr_hip ops need device tensors (got a CPU tensor)")
+    if not t.is_contiguous():
+        raise RuntimeError("esr_hip ops need contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr_array(tensors, n=None):
+    n = n or len(tensors)
+    arr = (C.c_void_p * n)()
+    for i, t in enumerate(tensors):
+        arr[i] = 0 if t is None else t.data_ptr()
+    return arr

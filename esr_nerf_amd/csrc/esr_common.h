@@ -1,0 +1,205 @@
+// Shared device helpers for libesr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/esr_hip.h"
+
+#define ESR_API extern "C" __attribute__((visibility("default")))
+
+#define ESR_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return (int)e__;              \
+    } while (0)
+
+#define ESR_WAVE 64
+
+static inline hipStream_t esr_stream(void *s) { return (hipStream_t)s; }
+
+static inline int esr_grid_for(int64_t n, int block, int cap = 256 * 8)
+{
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------------------
+// Ray / box geometry.  Every operation here is a separately rounded binary32
+// op (contraction off) so sample positions and the integer outputs derived
+// from them are bit-identical to oracle/esr_oracle.c.
+// ---------------------------------------------------------------------------
+struct RayGeom {
+    float start[3];
+    float dir[3];
+    float t_min, t_max;
+    int n_steps;
+};
+
+__device__ __forceinline__ float esr_ray_norm(const float d[3])
+{
+#pragma clang fp contract(off)
+    float s = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    return sqrtf(s);   // correctly rounded (NOT __fsqrt_rn: that lowers to bare v_sqrt_f32, ~1 ulp)
+}
+
+__device__ __forceinline__ void esr_ray_trange(const float o[3], const float d[3],
+                                               const float bmin[3], const float bmax[3],
+                                               float near_, float far_, float &tmin, float &tmax)
+{
+#pragma clang fp contract(off)
+    float lo = 0.f, hi = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float v = (d[a] == 0.0f) ? (float)1e-6 : d[a];
+        float ta = __fdiv_rn(bmax[a] - o[a], v);
+        float tb = __fdiv_rn(bmin[a] - o[a], v);
+        float mn = fminf(ta, tb), mx = fmaxf(ta, tb);
+        if (a == 0) { lo = mn; hi = mx; }
+        else        { lo = fmaxf(lo, mn); hi = fminf(hi, mx); }
+    }
+    tmin = fmaxf(fminf(lo, far_), near_);
+    tmax = fmaxf(fminf(hi, far_), near_);
+}
+
+__device__ __forceinline__ int64_t esr_ray_nsteps(float tmin, float tmax, float nrm, float stepdist)
+{
+#pragma clang fp contract(off)
+    float len = __fdiv_rn((tmax - tmin) * nrm, stepdist);
+    double c = (double)ceilf(len);
+    return (int64_t)(c > 1.0 ? c : 1.0);
+}
+
+__device__ __forceinline__ void esr_ray_start_dir(const float o[3], const float d[3], float tmin,
+                                                  float nrm, float start[3], float dir[3])
+{
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        start[a] = o[a] + d[a] * tmin;
+        dir[a] = __fdiv_rn(d[a], nrm);
+    }
+}
+
+__device__ __forceinline__ void esr_ray_point(const float start[3], const float dir[3],
+                                              float stepdist, int step, float p[3])
+{
+#pragma clang fp contract(off)
+    float dist = stepdist * (float)step;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) p[a] = start[a] + dir[a] * dist;
+}
+
+__device__ __forceinline__ bool esr_out_of_box(const float p[3], const float bmin[3], const float bmax[3])
+{
+    return (bmin[0] > p[0]) | (bmin[1] > p[1]) | (bmin[2] > p[2]) |
+           (bmax[0] < p[0]) | (bmax[1] < p[1]) | (bmax[2] < p[2]);
+}
+
+__device__ __forceinline__ RayGeom esr_ray_geom(const float *rays_o, const float *rays_d, int r,
+                                                const float bmin[3], const float bmax[3],
+                                                float near_, float far_, float stepdist)
+{
+    RayGeom g;
+    float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+    float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+    esr_ray_trange(o, d, bmin, bmax, near_, far_, g.t_min, g.t_max);
+    float nrm = esr_ray_norm(d);
+    g.n_steps = (int)esr_ray_nsteps(g.t_min, g.t_max, nrm, stepdist);
+    esr_ray_start_dir(o, d, g.t_min, nrm, g.start, g.dir);
+    return g;
+}
+
+// ---------------------------------------------------------------------------
+// Trilinear lookup with the arithmetic of F.grid_sample(mode="bilinear",
+// align_corners=True, padding_mode="zeros") on a [X,Y,Z] volume, as the
+// reference calls it (app/utils/base/module.py:24-35): world x -> slowest axis.
+// ---------------------------------------------------------------------------
+struct Tri {
+    int i0[3];      // floor index per GRID axis (0 = X slowest, 2 = Z fastest)
+    float f[3];     // fractional part per grid axis
+};
+
+// world point -> continuous grid index per grid axis, replicating
+// ((p-min)/(max-min))*2-1 followed by ((n+1)/2)*(size-1)
+__device__ __forceinline__ void esr_world_to_index(const float p[3], const float bmin[3],
+                                                   const float bmax[3], const int dims[3], float idx[3])
+{
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float u = __fdiv_rn(p[a] - bmin[a], bmax[a] - bmin[a]);
+        float n = u * 2.0f - 1.0f;
+        idx[a] = __fdiv_rn(n + 1.0f, 2.0f) * (float)(dims[a] - 1);
+    }
+}
+
+__device__ __forceinline__ Tri esr_tri_setup(const float idx[3])
+{
+    Tri t;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float fl = floorf(idx[a]);
+        t.i0[a] = (int)fl;
+        t.f[a] = idx[a] - fl;
+    }
+    return t;
+}
+
+// corner weight in ATen's spelling: (x1 - ix) for the low corner, (ix - x0) for the high one
+__device__ __forceinline__ float esr_corner_w(const Tri &t, const float idx[3], int cx, int cy, int cz)
+{
+    float wx = cx ? (idx[0] - (float)t.i0[0]) : ((float)(t.i0[0] + 1) - idx[0]);
+    float wy = cy ? (idx[1] - (float)t.i0[1]) : ((float)(t.i0[1] + 1) - idx[1]);
+    float wz = cz ? (idx[2] - (float)t.i0[2]) : ((float)(t.i0[2] + 1) - idx[2]);
+    // ATen multiplies fastest-axis weight first: (wz * wy) * wx
+    return (wz * wy) * wx;
+}
+
+// 1-channel fetch with zero padding
+__device__ __forceinline__ float esr_tri_fetch1(const float *__restrict__ g, const int dims[3],
+                                                const float idx[3])
+{
+    Tri t = esr_tri_setup(idx);
+    float acc = 0.f;
+#pragma unroll
+    for (int cx = 0; cx < 2; ++cx)
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+            for (int cz = 0; cz < 2; ++cz) {
+                int x = t.i0[0] + cx, y = t.i0[1] + cy, z = t.i0[2] + cz;
+                bool inb = (x >= 0) & (x < dims[0]) & (y >= 0) & (y < dims[1]) & (z >= 0) & (z < dims[2]);
+                float w = esr_corner_w(t, idx, cx, cy, cz);
+                if (inb) acc += g[((int64_t)x * dims[1] + y) * dims[2] + z] * w;
+            }
+    return acc;
+}
+
+// scatter-add of one value through the same 8 corners
+__device__ __forceinline__ void esr_tri_scatter1(float *__restrict__ g, const int dims[3],
+                                                 const float idx[3], float v)
+{
+    Tri t = esr_tri_setup(idx);
+#pragma unroll
+    for (int cx = 0; cx < 2; ++cx)
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+            for (int cz = 0; cz < 2; ++cz) {
+                int x = t.i0[0] + cx, y = t.i0[1] + cy, z = t.i0[2] + cz;
+                bool inb = (x >= 0) & (x < dims[0]) & (y >= 0) & (y < dims[1]) & (z >= 0) & (z < dims[2]);
+                float w = esr_corner_w(t, idx, cx, cy, cz);
+                if (inb && w != 0.f) atomicAdd(&g[((int64_t)x * dims[1] + y) * dims[2] + z], v * w);
+            }
+}
+
+__device__ __forceinline__ float esr_softplus(float x)
+{
+    // F.softplus(beta=1, threshold=20)
+    return x > 20.f ? x : log1pf(expf(x));
+}
+__device__ __forceinline__ float esr_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ __forceinline__ int esr_lane() { return (int)(threadIdx.x & 63); }

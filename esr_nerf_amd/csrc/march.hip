@@ -1,0 +1,354 @@
+// Fused ray march of the fine stage: sampler -> in-box test -> mask cache ->
+// SDF tap -> NeuS "interp" alpha -> alpha>thres -> front-to-back transmittance
+// with the early stop -> weight>thres, and its backward.
+//
+// Reference algorithm (paths under the reference tree):
+//   app/fine/model/voxurff.py:186-213 (forward_training, up to "app mask 1")
+//   app/fine/model/voxurff.py:623-654 + render_utils_kernel.cu:12-79,167-194 (sample_ray)
+//   app/utils/base/module.py:104-114 (MaskCache.forward)
+//   app/utils/base/functions.py:72-105 (neus_alpha_from_sdf_scatter_interp)
+//   render_utils_kernel.cu:577-605,654-677 (alpha2weight fwd/bwd)
+//
+// MI355X design: ONE 64-lane wavefront per ray.  The reference materialises M0,
+// M1, M2 sized tensors in HBM between ~25 launches, compacts with boolean masks
+// (host syncs) and composites with one thread per ray.  Here a ray's samples live
+// in lanes/LDS: compaction is ballot + mbcnt, the NeuS neighbour exchange is an
+// LDS read, the transmittance recurrence is a v_readlane loop in the reference's
+// serial order (so the early stop is bit-identical), and nothing but the final
+// survivors (16 B each) touches HBM.  Three instantiations: COUNT (sizes), FILL
+// (records) and BWD (recompute + reverse scan + trilinear atomic scatter).
+#include "esr_common.h"
+
+namespace {
+
+enum { MARCH_COUNT = 0, MARCH_FILL = 1, MARCH_BWD = 2 };
+
+struct MarchParams {
+    esr_scene_t sc;
+    const float *rays_o, *rays_d, *mask_density, *sdf;
+    int n_rays;
+    int cap;                 // per-wave LDS capacity in samples (multiple of 64)
+    // COUNT
+    int32_t *cnt3;
+    float *alphainv_last;
+    esr_plan_t *plan;
+    // FILL / BWD
+    const int32_t *off3;
+    int32_t *rec_ray, *rec_step;
+    float *rec_w, *rec_sdf;
+    // BWD
+    const float *dweight, *dlast;
+    float *grad_sdf;
+};
+
+__device__ __forceinline__ float neus_alpha(float pc, float nc)
+{
+    float r = (fmaxf(pc - nc, 0.f) + 1e-5f) / (pc + 1e-5f);
+    return fminf(fmaxf(r, 0.f), 1.f);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) march_kernel(MarchParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = esr_lane();
+    const int wave_in_blk = threadIdx.x >> 6;
+    const int waves_per_blk = blockDim.x >> 6;
+    const int r = blockIdx.x * waves_per_blk + wave_in_blk;
+    if (r >= P.n_rays) return;                        // whole wave leaves together
+
+    constexpr int NARR = (MODE == MARCH_BWD) ? 5 : 2;
+    float *base = reinterpret_cast<float *>(smem_raw) + (size_t)wave_in_blk * NARR * P.cap;
+    float *sdf1 = base;                                // SDF of mask-cache survivors
+    int *step1 = reinterpret_cast<int *>(base + P.cap);
+    float *alpha1 = (MODE == MARCH_BWD) ? base + 2 * P.cap : nullptr;   // later: d/d prev-midpoint
+    float *T1 = (MODE == MARCH_BWD) ? base + 3 * P.cap : nullptr;       // later: d/d next-midpoint
+    int *info1 = (MODE == MARCH_BWD) ? reinterpret_cast<int *>(base + 4 * P.cap) : nullptr;
+
+    const esr_scene_t &sc = P.sc;
+    const int gdims[3] = {sc.gx, sc.gy, sc.gz};
+    const int mdims[3] = {sc.mx, sc.my, sc.mz};
+    const RayGeom g = esr_ray_geom(P.rays_o, P.rays_d, r, sc.xyz_min, sc.xyz_max, sc.near_, 1e9f,
+                                   sc.stepdist);
+    if (g.n_steps > P.cap) {
+        if (MODE == MARCH_COUNT && lane == 0) {
+            atomicOr(&P.plan->overflow, 1);
+            P.cnt3[r] = 0;
+            P.alphainv_last[r] = 1.f;
+        }
+        return;
+    }
+
+    // ---- phase 1: walk the ray, keep in-box & mask-cache survivors in LDS ----
+    int n0 = 0, n1 = 0;
+    for (int c0 = 0; c0 < g.n_steps; c0 += 64) {
+        const int step = c0 + lane;
+        bool ok = step < g.n_steps;
+        float p[3], idx[3], s = 0.f;
+        esr_ray_point(g.start, g.dir, sc.stepdist, step, p);
+        ok = ok && !esr_out_of_box(p, sc.xyz_min, sc.xyz_max);
+        n0 += __popcll(__ballot(ok));
+        if (ok) {
+            esr_world_to_index(p, sc.mask_min, sc.mask_max, mdims, idx);
+            const float dens = esr_tri_fetch1(P.mask_density, mdims, idx);
+            const float a = 1.f - expf(-esr_softplus(dens + sc.act_shift));
+            ok = a >= sc.mask_thres;
+        }
+        if (ok) {
+            esr_world_to_index(p, sc.xyz_min, sc.xyz_max, gdims, idx);
+            s = esr_tri_fetch1(P.sdf, gdims, idx);
+        }
+        const unsigned long long b = __ballot(ok);
+        if (ok) {
+            const int pos = n1 + __popcll(b & ((1ull << lane) - 1ull));
+            sdf1[pos] = s;
+            step1[pos] = step;
+        }
+        n1 += __popcll(b);
+    }
+    __threadfence_block();
+
+    // ---- phase 2: alpha, thresholds, transmittance in serial order ----------
+    float tc = 1.f;
+    bool stopped = false;
+    int n2 = 0, n3 = 0;
+    const int out_base = (MODE != MARCH_COUNT) ? P.off3[r] : 0;
+    for (int c0 = 0; c0 < n1; c0 += 64) {
+        const int j = c0 + lane;
+        const bool ok = j < n1;
+        float s = 0.f, alpha = 0.f;
+        if (ok) {
+            s = sdf1[j];
+            const float prv = (j > 0) ? (sdf1[j - 1] + s) * 0.5f : s;
+            const float nxt = (j < n1 - 1) ? (s + sdf1[j + 1]) * 0.5f : s;
+            alpha = neus_alpha(esr_sigmoid(prv * sc.s_val), esr_sigmoid(nxt * sc.s_val));
+        }
+        const bool v2 = ok && alpha > sc.fast_thres;
+        const unsigned long long b2 = __ballot(v2);
+        n2 += __popcll(b2);
+        float myT = 1.f;
+        bool proc = false;
+        if (!stopped) {
+            unsigned long long rem = b2;
+            while (rem) {
+                const int i = __ffsll((long long)rem) - 1;
+                rem &= rem - 1;
+                const float ai = __shfl(alpha, i);
+                if (lane == i) { myT = tc; proc = true; }
+                tc = (float)((double)tc * (1.0 - (double)ai));
+                if ((double)tc < 1e-3) { stopped = true; break; }
+            }
+        }
+        const float w = proc ? myT * alpha : 0.f;
+        const bool v3 = proc && w > sc.fast_thres;
+        const unsigned long long b3 = __ballot(v3);
+        const int rank = n3 + __popcll(b3 & ((1ull << lane) - 1ull));
+        if (MODE == MARCH_FILL && v3) {
+            const int o = out_base + rank;
+            P.rec_ray[o] = r;
+            P.rec_step[o] = step1[j];
+            P.rec_w[o] = w;
+            P.rec_sdf[o] = s;
+        }
+        if (MODE == MARCH_BWD && ok) {
+            alpha1[j] = alpha;
+            T1[j] = myT;
+            info1[j] = (v2 ? 1 : 0) | (proc ? 2 : 0) | (v3 ? ((rank + 1) << 8) : 0);
+        }
+        n3 += __popcll(b3);
+    }
+
+    if (MODE == MARCH_COUNT) {
+        if (lane == 0) {
+            P.cnt3[r] = n3;
+            P.alphainv_last[r] = tc;
+            atomicAdd(&P.plan->m0, n0);
+            atomicAdd(&P.plan->m1, n1);
+            atomicAdd(&P.plan->m2, n2);
+        }
+        return;
+    }
+    if (MODE != MARCH_BWD) return;
+
+    // ---- backward: reverse scan over the processed samples -------------------
+    __threadfence_block();
+    float back = P.dlast[r] * tc;
+    const int nchunk = (n1 + 63) >> 6;
+    for (int c = nchunk - 1; c >= 0; --c) {
+        const int j = c * 64 + lane;
+        const bool ok = j < n1;
+        const int info = ok ? info1[j] : 0;
+        const bool proc = info & 2;
+        const float alpha = ok ? alpha1[j] : 0.f;
+        const float T = ok ? T1[j] : 1.f;
+        const float gw = (info >> 8) ? P.dweight[out_base + (info >> 8) - 1] : 0.f;
+        const float x = proc ? gw * (T * alpha) : 0.f;
+        float v = x;                                  // inclusive suffix sum over lanes >= lane
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float u = __shfl_down(v, off);
+            if (lane + off < 64) v += u;
+        }
+        const float myback = back + (v - x);
+        back += __shfl(v, 0);
+        float dprev = 0.f, dnext = 0.f;
+        if (proc) {
+            const float dalpha =
+                (float)((double)(gw * T) - (double)myback / ((double)(1.0f - alpha) + 1e-10));
+            const float s = sdf1[j];
+            const float prv = (j > 0) ? (sdf1[j - 1] + s) * 0.5f : s;
+            const float nxt = (j < n1 - 1) ? (s + sdf1[j + 1]) * 0.5f : s;
+            const float pc = esr_sigmoid(prv * sc.s_val), nc = esr_sigmoid(nxt * sc.s_val);
+            const float num = fmaxf(pc - nc, 0.f) + 1e-5f, den = pc + 1e-5f;
+            const float ratio = num / den;
+            if (ratio >= 0.f && ratio <= 1.f) {       // clip passes the gradient on [0,1]
+                const float pos = (pc - nc > 0.f) ? 1.f : 0.f;   // relu'
+                const float dr_dpc = (pos * den - num) / (den * den);
+                const float dr_dnc = -pos / den;
+                dprev = dalpha * dr_dpc * sc.s_val * pc * (1.f - pc);
+                dnext = dalpha * dr_dnc * sc.s_val * nc * (1.f - nc);
+            }
+        }
+        if (ok) { alpha1[j] = dprev; T1[j] = dnext; }
+    }
+    __threadfence_block();
+    for (int c0 = 0; c0 < n1; c0 += 64) {
+        const int j = c0 + lane;
+        if (j >= n1) continue;
+        float ds = alpha1[j] * ((j > 0) ? 0.5f : 1.f) + T1[j] * ((j < n1 - 1) ? 0.5f : 1.f);
+        if (j + 1 < n1) ds += 0.5f * alpha1[j + 1];
+        if (j > 0) ds += 0.5f * T1[j - 1];
+        if (ds != 0.f) {
+            float p[3], idx[3];
+            esr_ray_point(g.start, g.dir, sc.stepdist, step1[j], p);
+            esr_world_to_index(p, sc.xyz_min, sc.xyz_max, gdims, idx);
+            esr_tri_scatter1(P.grad_sdf, gdims, idx, ds);
+        }
+    }
+}
+
+// One workgroup: exclusive offsets, emissive-on rays first, off rays from the
+// next multiple of 32.
+__global__ void __launch_bounds__(1024) plan_kernel(const int32_t *__restrict__ cnt3,
+                                                    const int64_t *__restrict__ em_modes, int n_rays,
+                                                    int32_t *__restrict__ off3, esr_plan_t *plan)
+{
+    __shared__ int part[1024];
+    __shared__ int total_on;
+    const int tid = threadIdx.x;
+    const int per = (n_rays + 1023) / 1024;
+    const int b = tid * per, e = (b + per < n_rays) ? b + per : n_rays;
+    int base = 0;
+    for (int pass = 0; pass < 2; ++pass) {           // pass 0: on rays, pass 1: off rays
+        int s = 0;
+        for (int i = b; i < e; ++i)
+            if ((em_modes[i] == 1) == (pass == 0)) s += cnt3[i];
+        part[tid] = s;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            int v = (tid >= off) ? part[tid - off] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        int run = base + part[tid] - s;
+        for (int i = b; i < e; ++i)
+            if ((em_modes[i] == 1) == (pass == 0)) {
+                off3[i] = run;
+                run += cnt3[i];
+            }
+        const int tot = part[1023];
+        __syncthreads();
+        if (pass == 0) {
+            if (tid == 0) {
+                total_on = tot;
+                plan->n_on = tot;
+                plan->tiles_on = (tot + 31) / 32;
+            }
+            base = ((tot + 31) / 32) * 32;
+        } else if (tid == 0) {
+            plan->n_off = tot;
+            plan->tiles_all = (total_on + 31) / 32 + (tot + 31) / 32;
+        }
+        __syncthreads();
+    }
+}
+
+int march_cap(const esr_scene_t *sc) { return ((sc->max_steps + 63) / 64) * 64; }
+
+template <int MODE>
+int launch_march(MarchParams &P, hipStream_t s)
+{
+    if (P.n_rays == 0) return 0;
+    constexpr int NARR = (MODE == MARCH_BWD) ? 5 : 2;
+    const size_t per_wave = (size_t)NARR * P.cap * sizeof(float);
+    int wpb = 4;
+    while (wpb > 1 && per_wave * wpb > 64 * 1024) wpb >>= 1;
+    if (per_wave * wpb > 160 * 1024) return ESR_ECAP;
+    const int grid = (P.n_rays + wpb - 1) / wpb;
+    march_kernel<MODE><<<grid, wpb * 64, per_wave * wpb, s>>>(P);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+ESR_API int esr_fine_plan_begin(esr_plan_t *plan, void *stream)
+{
+    if (!plan) return ESR_EINVAL;
+    return (int)hipMemsetAsync(plan, 0, sizeof(esr_plan_t), esr_stream(stream));
+}
+
+ESR_API int esr_fine_march_count(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                                 const float *mask_density, const float *sdf, int32_t n_rays,
+                                 int32_t *cnt3, float *alphainv_last, esr_plan_t *plan, void *stream)
+{
+    if (!scene || n_rays < 0 || !plan) return ESR_EINVAL;
+    if (n_rays && (!rays_o || !rays_d || !mask_density || !sdf || !cnt3 || !alphainv_last)) return ESR_EINVAL;
+    MarchParams P = {};
+    P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d; P.mask_density = mask_density; P.sdf = sdf;
+    P.n_rays = n_rays; P.cap = march_cap(scene); P.cnt3 = cnt3; P.alphainv_last = alphainv_last;
+    P.plan = plan;
+    return launch_march<MARCH_COUNT>(P, esr_stream(stream));
+}
+
+ESR_API int esr_fine_plan(const int32_t *cnt3, const int64_t *em_modes, int32_t n_rays, int32_t *off3,
+                          esr_plan_t *plan, void *stream)
+{
+    if (n_rays < 0 || !plan) return ESR_EINVAL;
+    if (n_rays && (!cnt3 || !em_modes || !off3)) return ESR_EINVAL;
+    plan_kernel<<<1, 1024, 0, esr_stream(stream)>>>(cnt3, em_modes, n_rays, off3, plan);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_fine_march_fill(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                                const float *mask_density, const float *sdf, int32_t n_rays,
+                                const int32_t *off3, int32_t *rec_ray, int32_t *rec_step, float *rec_w,
+                                float *rec_sdf, void *stream)
+{
+    if (!scene || n_rays < 0) return ESR_EINVAL;
+    if (n_rays && (!rays_o || !rays_d || !mask_density || !sdf || !off3 || !rec_ray || !rec_step ||
+                   !rec_w || !rec_sdf))
+        return ESR_EINVAL;
+    MarchParams P = {};
+    P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d; P.mask_density = mask_density; P.sdf = sdf;
+    P.n_rays = n_rays; P.cap = march_cap(scene); P.off3 = off3; P.rec_ray = rec_ray;
+    P.rec_step = rec_step; P.rec_w = rec_w; P.rec_sdf = rec_sdf;
+    return launch_march<MARCH_FILL>(P, esr_stream(stream));
+}
+
+ESR_API int esr_fine_march_bwd(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                               const float *mask_density, const float *sdf, int32_t n_rays,
+                               const int32_t *off3, const float *dweight, const float *dlast,
+                               float *grad_sdf, void *stream)
+{
+    if (!scene || n_rays < 0) return ESR_EINVAL;
+    if (n_rays && (!rays_o || !rays_d || !mask_density || !sdf || !off3 || !dweight || !dlast || !grad_sdf))
+        return ESR_EINVAL;
+    MarchParams P = {};
+    P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d; P.mask_density = mask_density; P.sdf = sdf;
+    P.n_rays = n_rays; P.cap = march_cap(scene); P.off3 = off3; P.dweight = dweight; P.dlast = dlast;
+    P.grad_sdf = grad_sdf;
+    return launch_march<MARCH_BWD>(P, esr_stream(stream));
+}

@@ -1,0 +1,598 @@
+// Tiny-MLP engine on the f32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Reference: app/utils/pbr/module.py:6-39 (RadianceNet 85-192-192-192-3 + softplus,
+// TonemapNet 33-192-3 + sigmoid) evaluated per surviving sample in
+// app/fine/model/voxurff.py:243-256, and torch autograd for the backward.
+//
+// MI355X design (not a GEMM-library call, not a warp-shaped tiling):
+//  * "Transposed" formulation  H_l^T = W_l . H_{l-1}^T : the weight matrix is the MFMA
+//    A operand, a tile of 32 SAMPLES is the N dimension.  The 32x32 accumulator of
+//    layer l then has the sample on the lane and the feature in the register --
+//    exactly the B-operand layout layer l+1 needs (B[k][n]: lane = n + 32*(k&1)).
+//    The whole 4-layer chain therefore runs out of registers: no LDS round trip, no
+//    transposes, no barriers; one 64-lane wave owns 32 samples end to end.  The k
+//    index a register stands for is a fixed permutation of the feature index; it is
+//    folded into the weight packing (esr_mlp_pack), which also bakes in the column
+//    permutation between the reference's 85-d input order and the X tile rows.
+//  * Weights are pre-packed so that the A operand of 4 consecutive k-steps is one
+//    coalesced 16-B-per-lane load (1 KiB per wave instruction) served by L1/L2: the
+//    MFMA rate needs only 16 B/clk/CU of weights.
+//  * fp32 MFMA is bit-for-bit a k-ordered fmaf chain, so results stay within 1e-6 of
+//    the CPU oracle; there is no reduced-precision path on gfx950 for f32 inputs.
+//  * Hidden activations are saved tile-major [tile][feature][32] (each store = two
+//    full 128-B lines) and re-read by the backward instead of being recomputed: the
+//    f32 matrix rate (157 TF) is the binding roof, HBM (8 TB/s) has headroom.
+//  * Weight gradients contract over SAMPLES; both operands are read straight from the
+//    tile-major buffers with 16-B loads along the sample axis, each wave keeps a
+//    96x96 block of dW in 144 accumulator registers across its whole tile range and
+//    flushes it with 128-B-contiguous float atomics once.
+#include "esr_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int HID_TILES = 6;          // 192 hidden features
+constexpr int HID = 192;
+constexpr int HKP = 96;               // k-pairs of a 192-wide hidden layer
+
+// feature index a (k-pair p, lane half h) register slot stands for in a hidden layer
+__host__ __device__ constexpr int hid_feature(int p, int h)
+{
+    return 32 * (p >> 4) + ((p & 15) & 3) + 8 * ((p & 15) >> 2) + 4 * h;
+}
+// row of a 32x32 accumulator tile held by register r of lane half h
+__host__ __device__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- network descriptions ---------------------------------------------------
+struct NetDesc {
+    int n_layers;           // linear layers (hidden + output)
+    int in_dim, in_kp;      // reference input width, k-pairs of the first layer (multiple of 4)
+    int xrows;              // rows of the input tile
+    int out_dim;
+};
+__host__ __device__ constexpr NetDesc net_desc(int kind)
+{
+    return kind == ESR_MLP_RADIANCE ? NetDesc{4, 85, 48, 96, 3} : NetDesc{2, 33, 24, 48, 3};
+}
+
+// X-tile row -> column of the reference's first-layer weight (-1: no column)
+__host__ __device__ inline int in_colmap(int kind, int row)
+{
+    if (kind == ESR_MLP_TONEMAP) return row < 33 ? row : -1;
+    if (row < 6) return row;                 // colour
+    if (row == 6) return 48;                 // sdf
+    if (row < 31) return 49 + (row - 7);     // feat24
+    if (row < 43) return 73 + (row - 31);    // normal12
+    if (row < 46) return 6 + (row - 43);     // xyz
+    if (row < 61) return 9 + (row - 46);     // sin
+    if (row < 76) return 24 + (row - 61);    // cos
+    if (row < 85) return 39 + (row - 76);    // viewdir, sin, cos
+    return -1;
+}
+
+// Packed buffer layout (floats).  Forward part per layer l:
+//   Wf_l [tiles_out][kp/4][64 lanes][4]   bias Bf_l [tiles_out][2 halves][16]
+// Backward part per layer l: Wb_l [tiles_in][kpo/4][64][4]   (tiles_in: rows of the layer INPUT)
+struct PackLayout {
+    int n_layers;
+    int kp[4], tiles_out[4], in_dim[4], out_dim[4];
+    int kpo[4], tiles_in[4];
+    int64_t off_wf[4], off_bf[4], off_wb[4];
+    int64_t total;
+};
+__host__ __device__ constexpr PackLayout pack_layout(int kind)
+{
+    const NetDesc d = net_desc(kind);
+    PackLayout L = {};
+    L.n_layers = d.n_layers;
+    int64_t o = 0;
+    for (int l = 0; l < d.n_layers; ++l) {
+        const bool first = l == 0, last = l == d.n_layers - 1;
+        L.kp[l] = first ? d.in_kp : HKP;
+        L.in_dim[l] = first ? d.in_dim : HID;
+        L.out_dim[l] = last ? d.out_dim : HID;
+        L.tiles_out[l] = last ? 1 : HID_TILES;
+        L.kpo[l] = last ? 4 : HKP;                       // contraction pairs of the transposed product
+        L.tiles_in[l] = first ? 2 : HID_TILES;           // dX: rows 0..63 only
+        L.off_wf[l] = o; o += (int64_t)L.tiles_out[l] * L.kp[l] * 64;
+        L.off_bf[l] = o; o += (int64_t)L.tiles_out[l] * 32;
+        L.off_wb[l] = o; o += (int64_t)L.tiles_in[l] * L.kpo[l] * 64;
+    }
+    L.total = o;
+    return L;
+}
+
+struct PackArgs {
+    int kind;
+    const float *w[4], *b[4];
+    float *out;
+};
+
+__global__ void __launch_bounds__(256) pack_kernel(PackArgs A)
+{
+    const PackLayout L = pack_layout(A.kind);
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < L.total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        int l = 0;
+        while (l + 1 < L.n_layers && e >= L.off_wf[l + 1]) ++l;
+        const bool first = l == 0, last = l == L.n_layers - 1;
+        const float *W = A.w[l];
+        const int ind = L.in_dim[l], outd = L.out_dim[l];
+        float v = 0.f;
+        if (e < L.off_bf[l]) {                               // forward weights
+            int64_t i = e - L.off_wf[l];
+            const int sub = i & 3; i >>= 2;
+            const int lane = i & 63; i >>= 6;
+            const int q = (int)(i % (L.kp[l] / 4)), it = (int)(i / (L.kp[l] / 4));
+            const int p = 4 * q + sub, h = lane >> 5;
+            const int row = 32 * it + (lane & 31);
+            const int col = first ? in_colmap(A.kind, 2 * p + h) : hid_feature(p, h);
+            if (row < outd && col >= 0 && col < ind) v = W[(int64_t)row * ind + col];
+        } else if (e < L.off_wb[l]) {                        // bias in accumulator order
+            int64_t i = e - L.off_bf[l];
+            const int r = i & 15, h = (i >> 4) & 1, it = (int)(i >> 5);
+            const int row = 32 * it + acc_row(r, h);
+            if (row < outd) v = A.b[l][row];
+        } else {                                             // transposed weights for dgrad
+            int64_t i = e - L.off_wb[l];
+            const int sub = i & 3; i >>= 2;
+            const int lane = i & 63; i >>= 6;
+            const int q = (int)(i % (L.kpo[l] / 4)), it = (int)(i / (L.kpo[l] / 4));
+            const int p = 4 * q + sub, h = lane >> 5;
+            const int orow = last ? (2 * p + h) : hid_feature(p, h);          // output feature of layer l
+            const int irow = 32 * it + (lane & 31);                           // input feature / X row
+            const int col = first ? in_colmap(A.kind, irow) : irow;
+            if (orow < outd && col >= 0 && col < ind) v = W[(int64_t)orow * ind + col];
+        }
+        A.out[e] = v;
+    }
+}
+
+// ---- MFMA building blocks ------------------------------------------------------
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// Buffer addressing (SGPR descriptor + per-lane 32-bit offset + scalar constant offset):
+// with plain pointers hipcc materialises ~100 loop-invariant 64-bit addresses per kernel
+// (one per store/load slot) and spills kilobytes per lane.  Out-of-range accesses are
+// dropped by the hardware range check instead of faulting.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 bload4(rsrc_t r, int voff, int soff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float bload1(rsrc_t r, int voff, int soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore1(rsrc_t r, float v, int voff, int soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+
+// acc[n / KP4] += (packed weight quad n) . B-quad (n % KP4), n = 0 .. NT*KP4-1.
+// The weight stream (byte offset `woff` in the packed buffer) is explicitly
+// double-buffered in groups of G 16-B loads (16 MFMAs = ~1k cycles of matrix work per
+// group) with a scheduling barrier per group so the loads stay one group ahead.
+template <int KP4, int NT, typename BF>
+__device__ __forceinline__ void stream_layer(rsrc_t W, int woff, BF bget, f32x16 (&acc)[NT], int lane)
+{
+    constexpr int NTOT = NT * KP4, G = 4, NG = (NTOT + G - 1) / G;
+    const int voff = lane * 16;
+    float4 buf[2][G];
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+        if (i < NTOT) buf[0][i] = bload4(W, voff, woff + i * 1024);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int n = (g + 1) * G + i;
+            if (n < NTOT) buf[(g + 1) & 1][i] = bload4(W, voff, woff + n * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int n = g * G + i;
+            if (n < NTOT) {
+                const int it = n / KP4, q = n % KP4;
+                const float4 a = buf[g & 1][i];
+                acc[it] = mfma32(a.x, bget(4 * q + 0), acc[it]);
+                acc[it] = mfma32(a.y, bget(4 * q + 1), acc[it]);
+                acc[it] = mfma32(a.z, bget(4 * q + 2), acc[it]);
+                acc[it] = mfma32(a.w, bget(4 * q + 3), acc[it]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// acc[it] += Wp[it] . B      B given as KP per-lane registers
+template <int KP, int NT>
+__device__ __forceinline__ void layer_from_regs(rsrc_t W, int woff, const float (&B)[KP],
+                                                f32x16 (&acc)[NT], int lane)
+{
+    static_assert(KP % 4 == 0, "k-pairs come in quads");
+    stream_layer<KP / 4, NT>(W, woff, [&](int k) { return B[k]; }, acc, lane);
+}
+
+// acc[it] += Wp[it] . prev    prev = accumulator tiles of the previous layer (192 features)
+template <int NT>
+__device__ __forceinline__ void layer_from_acc(rsrc_t W, int woff, const f32x16 (&prev)[HID_TILES],
+                                               f32x16 (&acc)[NT], int lane)
+{
+    stream_layer<HKP / 4, NT>(W, woff, [&](int k) { return prev[k >> 4][k & 15]; }, acc, lane);
+}
+
+// bias (packed in accumulator order at byte offset boff)
+template <int NT>
+__device__ __forceinline__ void load_bias(rsrc_t W, int boff, f32x16 (&acc)[NT], int lane)
+{
+    const int voff = (lane >> 5) * 64;
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = bload4(W, voff, boff + it * 128 + q * 16);
+            acc[it][4 * q + 0] = v.x; acc[it][4 * q + 1] = v.y;
+            acc[it][4 * q + 2] = v.z; acc[it][4 * q + 3] = v.w;
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void relu_tiles(f32x16 (&acc)[NT])
+{
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[it][r] = fmaxf(acc[it][r], 0.f);
+}
+
+// per-lane byte offset inside a tile-major tile: row 4h, sample s
+__device__ __forceinline__ int tile_voff(int lane) { return ((lane >> 5) * 4 * 32 + (lane & 31)) * 4; }
+// scalar byte offset of accumulator register r of tile `it` (row = 32it + (r&3) + 8(r>>2))
+__host__ __device__ constexpr int tile_soff(int it, int r) { return (32 * it + (r & 3) + 8 * (r >> 2)) * 128; }
+
+// tile-major store of NT accumulator tiles through descriptor T (based at the tile)
+template <int NT>
+__device__ __forceinline__ void store_tiles(rsrc_t T, const f32x16 (&acc)[NT], int lane)
+{
+    const int voff = tile_voff(lane);
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bstore1(T, acc[it][r], voff, tile_soff(it, r));
+}
+
+// acc = (saved activation > 0) ? acc : 0
+template <int NT>
+__device__ __forceinline__ void mask_by_saved(rsrc_t T, f32x16 (&acc)[NT], int lane)
+{
+    const int voff = tile_voff(lane);
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float a = bload1(T, voff, tile_soff(it, r));
+            acc[it][r] = a > 0.f ? acc[it][r] : 0.f;
+        }
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_tiles(f32x16 (&acc)[NT])
+{
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[it][r] = 0.f;
+}
+
+constexpr unsigned HID_TILE_BYTES = HID * 32 * 4;
+
+struct FwdArgs {
+    const float *packed, *X;
+    int t0, t1;
+    float *H[3];
+    int save, alt;
+    float *zout;
+};
+
+template <int KIND>
+__global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
+{
+    constexpr NetDesc D = net_desc(KIND);
+    constexpr int NHID = D.n_layers - 1;
+    constexpr int KP1 = D.in_kp;
+    constexpr PackLayout L = pack_layout(KIND);
+    const int lane = esr_lane();
+    const int h = lane >> 5, s = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const rsrc_t W = make_rsrc(A.packed, (unsigned)(L.total * 4));
+    for (int t = A.t0 + wave; t < A.t1; t += nwaves) {
+        const rsrc_t RX = make_rsrc(A.X + (size_t)t * D.xrows * 32, D.xrows * 32 * 4);
+        const int xvoff = (h * 32 + s) * 4;
+        const int alt_off = (KIND == ESR_MLP_RADIANCE && A.alt) ? 88 * 128 : 0;
+        float B1[KP1];
+#pragma unroll
+        for (int p = 0; p < KP1; ++p)
+            B1[p] = bload1(RX, xvoff, 2 * p * 128 + ((2 * p < 6) ? alt_off : 0));
+        f32x16 cur[HID_TILES];
+        load_bias<HID_TILES>(W, (int)L.off_bf[0] * 4, cur, lane);
+        layer_from_regs<KP1, HID_TILES>(W, (int)L.off_wf[0] * 4, B1, cur, lane);
+        relu_tiles<HID_TILES>(cur);
+        if (A.save) store_tiles<HID_TILES>(make_rsrc(A.H[0] + (size_t)t * HID * 32, HID_TILE_BYTES), cur, lane);
+#pragma unroll
+        for (int l = 1; l < NHID; ++l) {
+            f32x16 nxt[HID_TILES];
+            load_bias<HID_TILES>(W, (int)L.off_bf[l] * 4, nxt, lane);
+            layer_from_acc<HID_TILES>(W, (int)L.off_wf[l] * 4, cur, nxt, lane);
+            relu_tiles<HID_TILES>(nxt);
+            if (A.save) store_tiles<HID_TILES>(make_rsrc(A.H[l] + (size_t)t * HID * 32, HID_TILE_BYTES), nxt, lane);
+#pragma unroll
+            for (int it = 0; it < HID_TILES; ++it) cur[it] = nxt[it];
+        }
+        f32x16 out[1];
+        load_bias<1>(W, (int)L.off_bf[NHID] * 4, out, lane);
+        layer_from_acc<1>(W, (int)L.off_wf[NHID] * 4, cur, out, lane);
+        if (h == 0) {                       // rows 0..3 of the output tile live in lanes 0-31, regs 0-3
+            float *z = A.zout + (size_t)t * 4 * 32 + s;
+            z[0] = out[0][0]; z[32] = out[0][1]; z[64] = out[0][2]; z[96] = 0.f;
+        }
+    }
+}
+
+struct DgradArgs {
+    const float *packed, *dz;
+    int t0, t1;
+    const float *H[3];
+    float *dZ[3];
+    float *dX;
+};
+
+template <int KIND>
+__global__ void __launch_bounds__(256, 2) mlp_dgrad_kernel(DgradArgs A)
+{
+    constexpr NetDesc D = net_desc(KIND);
+    constexpr int NHID = D.n_layers - 1;
+    constexpr PackLayout L = pack_layout(KIND);
+    const int lane = esr_lane();
+    const int h = lane >> 5, s = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const rsrc_t W = make_rsrc(A.packed, (unsigned)(L.total * 4));
+    for (int t = A.t0 + wave; t < A.t1; t += nwaves) {
+        const float *dzt = A.dz + (size_t)t * 4 * 32 + s;
+        float B0[4] = {dzt[(0 + h) * 32], dzt[(2 + h) * 32], 0.f, 0.f};   // pair p <-> rows 2p, 2p+1
+        f32x16 cur[HID_TILES];
+        zero_tiles<HID_TILES>(cur);
+        layer_from_regs<4, HID_TILES>(W, (int)L.off_wb[NHID] * 4, B0, cur, lane);
+        mask_by_saved<HID_TILES>(make_rsrc(A.H[NHID - 1] + (size_t)t * HID * 32, HID_TILE_BYTES), cur, lane);
+        store_tiles<HID_TILES>(make_rsrc(A.dZ[NHID - 1] + (size_t)t * HID * 32, HID_TILE_BYTES), cur, lane);
+#pragma unroll
+        for (int l = NHID - 1; l >= 1; --l) {
+            f32x16 nxt[HID_TILES];
+            zero_tiles<HID_TILES>(nxt);
+            layer_from_acc<HID_TILES>(W, (int)L.off_wb[l] * 4, cur, nxt, lane);
+            mask_by_saved<HID_TILES>(make_rsrc(A.H[l - 1] + (size_t)t * HID * 32, HID_TILE_BYTES), nxt, lane);
+            store_tiles<HID_TILES>(make_rsrc(A.dZ[l - 1] + (size_t)t * HID * 32, HID_TILE_BYTES), nxt, lane);
+#pragma unroll
+            for (int it = 0; it < HID_TILES; ++it) cur[it] = nxt[it];
+        }
+        f32x16 dx[2];
+        zero_tiles<2>(dx);
+        layer_from_acc<2>(W, (int)L.off_wb[0] * 4, cur, dx, lane);
+        store_tiles<2>(make_rsrc(A.dX + (size_t)t * 64 * 32, 64 * 32 * 4), dx, lane);
+    }
+}
+
+// dW[rowA][col(rowB)] += sum_samples A[rowA][s] * B[rowB][s];  db[rowA] += sum_s A[rowA][s]
+struct WgradArgs {
+    const float *A; int RA;      // [tiles][RA][32]
+    const float *B; int RB;      // [tiles][RB][32]
+    int t0, t1;
+    float *gw; int ld; int out_rows;
+    int kind; int first;         // column map: first layer uses in_colmap(kind, row)
+    float *gb;
+    int blocks_n;                // column blocks
+};
+
+template <int MI, int NJ>
+__global__ void __launch_bounds__(256, 2) mlp_wgrad_kernel(WgradArgs W)
+{
+    const int lane = esr_lane();
+    const int h = lane >> 5, rl = lane & 31;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int nblk = ((W.RA + 32 * MI - 1) / (32 * MI)) * W.blocks_n;
+    const int blk = wave % nblk, split = wave / nblk, nsplit = nwaves / nblk;
+    if (split >= nsplit) return;
+    const int bm = blk / W.blocks_n, bn = blk % W.blocks_n;
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) zero_tiles<NJ>(acc[i]);
+    float bsum[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) bsum[i] = 0.f;
+    int rowA[MI], rowB[NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) rowA[i] = 32 * (MI * bm + i) + rl;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) rowB[j] = 32 * (NJ * bn + j) + rl;
+    for (int t = W.t0 + split; t < W.t1; t += nsplit) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float4 a[MI], b[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                a[i] = rowA[i] < W.RA
+                           ? *reinterpret_cast<const float4 *>(W.A + ((size_t)t * W.RA + rowA[i]) * 32 + 8 * u + 4 * h)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                b[j] = rowB[j] < W.RB
+                           ? *reinterpret_cast<const float4 *>(W.B + ((size_t)t * W.RB + rowB[j]) * 32 + 8 * u + 4 * h)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                bsum[i] += (a[i].x + a[i].y) + (a[i].z + a[i].w);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc[i][j] = mfma32(a[i].x, b[j].x, acc[i][j]);
+                    acc[i][j] = mfma32(a[i].y, b[j].y, acc[i][j]);
+                    acc[i][j] = mfma32(a[i].z, b[j].z, acc[i][j]);
+                    acc[i][j] = mfma32(a[i].w, b[j].w, acc[i][j]);
+                }
+            }
+        }
+    }
+    // flush: accumulator column = B row (lane), accumulator row = A row (register)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int rb = rowB[j];
+        const int col = (rb < W.RB) ? (W.first ? in_colmap(W.kind, rb) : rb) : -1;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ra = 32 * (MI * bm + i) + acc_row(r, h);
+                if (col >= 0 && col < W.ld && ra < W.out_rows) atomicAdd(&W.gw[(size_t)ra * W.ld + col], acc[i][j][r]);
+            }
+    }
+    if (W.gb && bn == 0) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const float tot = bsum[i] + __shfl_xor(bsum[i], 32);
+            if (h == 0 && rowA[i] < W.out_rows) atomicAdd(&W.gb[rowA[i]], tot);
+        }
+    }
+}
+
+int mlp_grid(int n_tiles)
+{
+    // 2 workgroups (8 waves) per CU resident; one tile per wave per trip
+    int wg = (n_tiles + 3) / 4;
+    if (wg > 512) wg = 512;
+    if (wg < 1) wg = 1;
+    return wg;
+}
+
+template <int MI, int NJ>
+int launch_wgrad(WgradArgs W, hipStream_t s)
+{
+    const int n_tiles = W.t1 - W.t0;
+    if (n_tiles <= 0) return 0;
+    const int blocks_m = (W.RA + 32 * MI - 1) / (32 * MI);
+    W.blocks_n = (W.RB + 32 * NJ - 1) / (32 * NJ);
+    const int nblk = blocks_m * W.blocks_n;
+    int nsplit = 2048 / nblk;
+    if (nsplit > n_tiles) nsplit = n_tiles;
+    if (nsplit < 1) nsplit = 1;
+    const int waves = nblk * nsplit;
+    mlp_wgrad_kernel<MI, NJ><<<(waves + 3) / 4, 256, 0, s>>>(W);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+ESR_API int64_t esr_mlp_packed_floats(int kind)
+{
+    if (kind != ESR_MLP_RADIANCE && kind != ESR_MLP_TONEMAP) return ESR_EINVAL;
+    return pack_layout(kind).total;
+}
+
+ESR_API int esr_mlp_pack(int kind, const esr_mlp_weights_t *w, float *packed, void *stream)
+{
+    if ((kind != ESR_MLP_RADIANCE && kind != ESR_MLP_TONEMAP) || !w || !packed) return ESR_EINVAL;
+    PackArgs A = {};
+    A.kind = kind;
+    const int nl = net_desc(kind).n_layers;
+    for (int l = 0; l < nl; ++l) {
+        if (!w->w[l] || !w->b[l]) return ESR_EINVAL;
+        A.w[l] = w->w[l];
+        A.b[l] = w->b[l];
+    }
+    A.out = packed;
+    pack_kernel<<<esr_grid_for(pack_layout(kind).total, 256, 1024), 256, 0, esr_stream(stream)>>>(A);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_mlp_fwd(int kind, const float *packed, const float *X, int32_t t0, int32_t t1,
+                        float *const *H, int save, int alt_color, float *zout, void *stream)
+{
+    if ((kind != ESR_MLP_RADIANCE && kind != ESR_MLP_TONEMAP) || t0 < 0 || t1 < t0) return ESR_EINVAL;
+    if (t1 == t0) return 0;
+    if (!packed || !X || !zout) return ESR_EINVAL;
+    const int nhid = net_desc(kind).n_layers - 1;
+    FwdArgs A = {};
+    A.packed = packed; A.X = X; A.t0 = t0; A.t1 = t1; A.save = save ? 1 : 0; A.alt = alt_color ? 1 : 0;
+    A.zout = zout;
+    if (save) {
+        if (!H) return ESR_EINVAL;
+        for (int l = 0; l < nhid; ++l) { if (!H[l]) return ESR_EINVAL; A.H[l] = H[l]; }
+    }
+    const int grid = mlp_grid(t1 - t0);
+    if (kind == ESR_MLP_RADIANCE) mlp_fwd_kernel<ESR_MLP_RADIANCE><<<grid, 256, 0, esr_stream(stream)>>>(A);
+    else mlp_fwd_kernel<ESR_MLP_TONEMAP><<<grid, 256, 0, esr_stream(stream)>>>(A);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_mlp_dgrad(int kind, const float *packed, const float *dz, int32_t t0, int32_t t1,
+                          const float *const *H, float *const *dZ, float *dX, void *stream)
+{
+    if ((kind != ESR_MLP_RADIANCE && kind != ESR_MLP_TONEMAP) || t0 < 0 || t1 < t0) return ESR_EINVAL;
+    if (t1 == t0) return 0;
+    if (!packed || !dz || !H || !dZ || !dX) return ESR_EINVAL;
+    const int nhid = net_desc(kind).n_layers - 1;
+    DgradArgs A = {};
+    A.packed = packed; A.dz = dz; A.t0 = t0; A.t1 = t1; A.dX = dX;
+    for (int l = 0; l < nhid; ++l) {
+        if (!H[l] || !dZ[l]) return ESR_EINVAL;
+        A.H[l] = H[l]; A.dZ[l] = dZ[l];
+    }
+    const int grid = mlp_grid(t1 - t0);
+    if (kind == ESR_MLP_RADIANCE) mlp_dgrad_kernel<ESR_MLP_RADIANCE><<<grid, 256, 0, esr_stream(stream)>>>(A);
+    else mlp_dgrad_kernel<ESR_MLP_TONEMAP><<<grid, 256, 0, esr_stream(stream)>>>(A);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_mlp_wgrad(int kind, const float *X, int alt_color, const float *const *H,
+                          const float *const *dZ, const float *dz, int32_t t0, int32_t t1,
+                          float *const *gw, float *const *gb, void *stream)
+{
+    (void)alt_color;   // gradients only ever flow through the main colour rows
+    if ((kind != ESR_MLP_RADIANCE && kind != ESR_MLP_TONEMAP) || t0 < 0 || t1 < t0) return ESR_EINVAL;
+    if (t1 == t0) return 0;
+    if (!X || !H || !dZ || !dz || !gw || !gb) return ESR_EINVAL;
+    const NetDesc D = net_desc(kind);
+    const int nhid = D.n_layers - 1;
+    hipStream_t s = esr_stream(stream);
+    for (int l = 0; l < D.n_layers; ++l) {
+        const bool first = l == 0, last = l == D.n_layers - 1;
+        WgradArgs W = {};
+        W.A = last ? dz : dZ[l];          W.RA = last ? 4 : HID;
+        W.B = first ? X : H[l - 1];       W.RB = first ? D.xrows : HID;
+        W.t0 = t0; W.t1 = t1;
+        W.gw = gw[l]; W.ld = first ? D.in_dim : HID; W.out_rows = last ? D.out_dim : HID;
+        W.kind = kind; W.first = first ? 1 : 0; W.gb = gb[l];
+        if (!W.A || !W.B || !W.gw || !W.gb) return ESR_EINVAL;
+        int rc = last ? launch_wgrad<1, 3>(W, s) : launch_wgrad<3, 3>(W, s);
+        if (rc) return rc;
+    }
+    (void)nhid;
+    return 0;
+}

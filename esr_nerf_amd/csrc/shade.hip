@@ -1,0 +1,287 @@
+// Element-wise stages between the MLP passes, compositing, and the trainer loss.
+//
+// Reference algorithm (paths under the reference tree):
+//   app/fine/model/voxurff.py:243-256  lin_rgb = softplus(emo) + softplus(off).detach() | softplus(off)
+//   app/fine/model/voxurff.py:783-788  tonemapper input [lin, sin(lin*2^i), cos(lin*2^i)]
+//   app/fine/model/voxurff.py:258-272  weights * rgb -> segment_coo(sum) per ray
+//   app/fine/fine.py:355-382 + utils2/image.py:14-26   loss of one training step
+//
+// All buffers are tile-major [tile][row][32 samples]: consecutive lanes touch
+// consecutive addresses on every access.  Compositing reduces inside the wave with a
+// segmented shuffle scan (samples are sorted by ray) and issues one float atomic per
+// (ray segment, channel) -- the MI355X replacement of torch_scatter.segment_coo.
+#include "esr_common.h"
+
+namespace {
+
+constexpr int XT_ROWS = 48;
+
+__device__ __forceinline__ float softplus_grad(float z) { return z > 20.f ? 1.f : esr_sigmoid(z); }
+
+__global__ void __launch_bounds__(256) tone_in_fwd_kernel(const float *__restrict__ z_off,
+                                                          const float *__restrict__ z_emo, int tiles_on,
+                                                          int tiles_all, float *__restrict__ lin,
+                                                          float *__restrict__ Xt)
+{
+    const int total = tiles_all * 32;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+        const int t = j >> 5, s = j & 31;
+        const size_t z4 = (size_t)t * 4 * 32 + s;
+        float *X = Xt + (size_t)t * XT_ROWS * 32 + s;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = esr_softplus(z_off[z4 + c * 32]);
+            if (t < tiles_on) v = esr_softplus(z_emo[z4 + c * 32]) + v;
+            lin[z4 + c * 32] = v;
+            X[c * 32] = v;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const float a = v * (float)(1 << i);
+                X[(3 + c * 5 + i) * 32] = sinf(a);
+                X[(18 + c * 5 + i) * 32] = cosf(a);
+            }
+        }
+        lin[z4 + 96] = 0.f;
+        for (int r = 33; r < XT_ROWS; ++r) X[r * 32] = 0.f;
+    }
+}
+
+// segmented inclusive scan over the 64 lanes (segments = runs of equal key)
+__device__ __forceinline__ float seg_scan(float v, int key, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float u = __shfl_up(v, off);
+        const int ku = __shfl_up(key, off);
+        if (lane >= off && ku == key) v += u;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(256) composite_fwd_kernel(const float *__restrict__ zt,
+                                                            const float *__restrict__ lin,
+                                                            const int32_t *__restrict__ rec_ray,
+                                                            const float *__restrict__ rec_w, int tiles_all,
+                                                            float *__restrict__ rgb,
+                                                            float *__restrict__ srgb_marched,
+                                                            float *__restrict__ lin_marched)
+{
+    const int lane = esr_lane();
+    const int total = tiles_all * 32;                     // multiple of 32; waves cover 64
+    const int stride = gridDim.x * blockDim.x;
+    for (int j0 = (blockIdx.x * blockDim.x + threadIdx.x) - lane; j0 < total; j0 += stride) {
+        const int j = j0 + lane;
+        const bool in = j < total;
+        const int t = j >> 5, s = j & 31;
+        const size_t z4 = (size_t)t * 4 * 32 + s;
+        const int ray = in ? rec_ray[j] : -1;
+        const float w = (in && ray >= 0) ? rec_w[j] : 0.f;
+        const int ray_next = __shfl_down(ray, 1);
+        const bool tail = ray >= 0 && (lane == 63 || ray_next != ray);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float col = 0.f, l = 0.f;
+            if (in) {
+                col = esr_sigmoid(zt[z4 + c * 32]);
+                rgb[z4 + c * 32] = col;
+                l = lin[z4 + c * 32];
+            }
+            const float a = seg_scan(w * col, ray, lane);
+            const float b = seg_scan(w * l, ray, lane);
+            if (tail) {
+                atomicAdd(&srgb_marched[3 * ray + c], a);
+                atomicAdd(&lin_marched[3 * ray + c], b);
+            }
+        }
+        if (in) rgb[z4 + 96] = 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256) composite_bwd_kernel(const float *__restrict__ g_srgb,
+                                                            const float *__restrict__ g_lin,
+                                                            const float *__restrict__ rgb,
+                                                            const float *__restrict__ lin,
+                                                            const int32_t *__restrict__ rec_ray,
+                                                            const float *__restrict__ rec_w, int tiles_all,
+                                                            float *__restrict__ dweight,
+                                                            float *__restrict__ dzt)
+{
+    const int total = tiles_all * 32;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+        const int t = j >> 5, s = j & 31;
+        const size_t z4 = (size_t)t * 4 * 32 + s;
+        const int ray = rec_ray[j];
+        float dw = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float d = 0.f;
+            if (ray >= 0) {
+                const float col = rgb[z4 + c * 32];
+                const float gs = g_srgb[3 * ray + c];
+                dw += gs * col + g_lin[3 * ray + c] * lin[z4 + c * 32];
+                d = rec_w[j] * gs * col * (1.f - col);
+            }
+            dzt[z4 + c * 32] = d;
+        }
+        dzt[z4 + 96] = 0.f;
+        dweight[j] = dw;
+    }
+}
+
+__global__ void __launch_bounds__(256) tone_in_bwd_kernel(
+    const float *__restrict__ dXt, const float *__restrict__ g_lin, const float *__restrict__ lin,
+    const float *__restrict__ z_off, const float *__restrict__ z_emo, const int32_t *__restrict__ rec_ray,
+    const float *__restrict__ rec_w, int tiles_on, int tiles_all, float *__restrict__ dz)
+{
+    const int total = tiles_all * 32;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+        const int t = j >> 5, s = j & 31;
+        const size_t z4 = (size_t)t * 4 * 32 + s;
+        const float *dX = dXt + (size_t)t * 64 * 32 + s;
+        const int ray = rec_ray[j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float d = 0.f;
+            if (ray >= 0) {
+                const float v = lin[z4 + c * 32];
+                d = rec_w[j] * g_lin[3 * ray + c] + dX[c * 32];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const float f = (float)(1 << i), a = v * f;
+                    d += f * (dX[(3 + c * 5 + i) * 32] * cosf(a) - dX[(18 + c * 5 + i) * 32] * sinf(a));
+                }
+                const float z = (t < tiles_on) ? z_emo[z4 + c * 32] : z_off[z4 + c * 32];
+                d *= softplus_grad(z);
+            }
+            dz[z4 + c * 32] = d;
+        }
+        dz[z4 + 96] = 0.f;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) loss_kernel(const float *__restrict__ srgb_m,
+                                                   const float *__restrict__ lin_m,
+                                                   const float *__restrict__ last,
+                                                   const float *__restrict__ rgbs, int n_rays, float white_bg,
+                                                   float w_lin, float w_ent, float *__restrict__ loss,
+                                                   float *__restrict__ g_srgb, float *__restrict__ g_lin,
+                                                   float *__restrict__ g_last)
+{
+    const float inv = 1.f / (3.f * (float)n_rays);
+    float acc = 0.f;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += gridDim.x * blockDim.x) {
+        const float al = last[r];
+        const float bg = al * white_bg;
+        float gl = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float gt = rgbs[3 * r + c];
+            // srgb term
+            const float ps = srgb_m[3 * r + c] + bg;
+            const float xs = fminf(fmaxf(ps, 0.f), 1.f);
+            acc += (xs - gt) * (xs - gt) * inv;
+            const float gs = (ps >= 0.f && ps <= 1.f) ? 2.f * (xs - gt) * inv : 0.f;
+            g_srgb[3 * r + c] = gs;
+            // linear term through the sRGB transfer curve
+            const float pl = lin_m[3 * r + c] + bg;
+            const float l0 = fmaxf(pl, 0.f);
+            const bool sat = gt >= 1.f;
+            const float x = sat ? fminf(l0, 1.f) : l0;
+            const bool low = x <= 0.0031308f;
+            const float y = low ? 12.92f * x : 1.055f * powf(x, 1.f / 2.4f) - 0.055f;
+            acc += w_lin * (y - gt) * (y - gt) * inv;
+            float g = w_lin * 2.f * (y - gt) * inv;
+            g *= low ? 12.92f : 1.055f * (1.f / 2.4f) * powf(x, 1.f / 2.4f - 1.f);
+            if (sat && !(l0 <= 1.f)) g = 0.f;       // clamp(max=1) passes the gradient for l0 <= 1
+            if (!(pl >= 0.f)) g = 0.f;              // clamp(min=0)
+            g_lin[3 * r + c] = g;
+            gl += (gs + g) * white_bg;
+        }
+        if (r == n_rays - 1) {                      // reference quirk: entropy of the LAST ray only
+            const float p = fminf(fmaxf(al, 1e-6f), 1.f - 1e-6f);
+            acc += w_ent * -(p * logf(p) + (1.f - p) * logf(1.f - p));
+            if (al >= 1e-6f && al <= 1.f - 1e-6f) gl += w_ent * -(logf(p) - logf(1.f - p));
+        }
+        g_last[r] = gl;
+    }
+    acc = wave_sum(acc);
+    if (esr_lane() == 0 && acc != 0.f) atomicAdd(loss, acc);
+}
+
+}  // namespace
+
+ESR_API int esr_fine_tone_in_fwd(const float *z_off, const float *z_emo, int32_t tiles_on,
+                                 int32_t tiles_all, float *lin, float *Xt, void *stream)
+{
+    if (tiles_all < 0 || tiles_on < 0 || tiles_on > tiles_all) return ESR_EINVAL;
+    if (tiles_all == 0) return 0;
+    if (!z_off || (tiles_on && !z_emo) || !lin || !Xt) return ESR_EINVAL;
+    tone_in_fwd_kernel<<<esr_grid_for((int64_t)tiles_all * 32, 256), 256, 0, esr_stream(stream)>>>(
+        z_off, z_emo, tiles_on, tiles_all, lin, Xt);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_fine_composite_fwd(const float *zt, const float *lin, const int32_t *rec_ray,
+                                   const float *rec_w, int32_t tiles_all, float *rgb, float *srgb_marched,
+                                   float *lin_marched, void *stream)
+{
+    if (tiles_all < 0) return ESR_EINVAL;
+    if (tiles_all == 0) return 0;
+    if (!zt || !lin || !rec_ray || !rec_w || !rgb || !srgb_marched || !lin_marched) return ESR_EINVAL;
+    composite_fwd_kernel<<<esr_grid_for(((int64_t)tiles_all * 32 + 63) / 64 * 64, 256), 256, 0,
+                           esr_stream(stream)>>>(zt, lin, rec_ray, rec_w, tiles_all, rgb, srgb_marched,
+                                                 lin_marched);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_fine_composite_bwd(const float *g_srgb, const float *g_lin, const float *rgb,
+                                   const float *lin, const int32_t *rec_ray, const float *rec_w,
+                                   int32_t tiles_all, float *dweight, float *dzt, void *stream)
+{
+    if (tiles_all < 0) return ESR_EINVAL;
+    if (tiles_all == 0) return 0;
+    if (!g_srgb || !g_lin || !rgb || !lin || !rec_ray || !rec_w || !dweight || !dzt) return ESR_EINVAL;
+    composite_bwd_kernel<<<esr_grid_for((int64_t)tiles_all * 32, 256), 256, 0, esr_stream(stream)>>>(
+        g_srgb, g_lin, rgb, lin, rec_ray, rec_w, tiles_all, dweight, dzt);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_fine_tone_in_bwd(const float *dXt, const float *g_lin, const float *lin,
+                                 const float *z_off, const float *z_emo, const int32_t *rec_ray,
+                                 const float *rec_w, int32_t tiles_on, int32_t tiles_all, float *dz,
+                                 void *stream)
+{
+    if (tiles_all < 0 || tiles_on < 0 || tiles_on > tiles_all) return ESR_EINVAL;
+    if (tiles_all == 0) return 0;
+    if (!dXt || !g_lin || !lin || !z_off || (tiles_on && !z_emo) || !rec_ray || !rec_w || !dz) return ESR_EINVAL;
+    tone_in_bwd_kernel<<<esr_grid_for((int64_t)tiles_all * 32, 256), 256, 0, esr_stream(stream)>>>(
+        dXt, g_lin, lin, z_off, z_emo, rec_ray, rec_w, tiles_on, tiles_all, dz);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_fine_loss_fwd_bwd(const float *srgb_marched, const float *lin_marched,
+                                  const float *alphainv_last, const float *rgbs, int32_t n_rays,
+                                  float white_bg, float weight_linear, float weight_entropy_last,
+                                  float *loss, float *g_srgb, float *g_lin, float *g_last, void *stream)
+{
+    if (n_rays < 0) return ESR_EINVAL;
+    if (n_rays == 0) return 0;
+    if (!srgb_marched || !lin_marched || !alphainv_last || !rgbs || !loss || !g_srgb || !g_lin || !g_last)
+        return ESR_EINVAL;
+    loss_kernel<<<esr_grid_for(n_rays, 256), 256, 0, esr_stream(stream)>>>(
+        srgb_marched, lin_marched, alphainv_last, rgbs, n_rays, white_bg, weight_linear,
+        weight_entropy_last, loss, g_srgb, g_lin, g_last);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}

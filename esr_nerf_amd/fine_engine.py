@@ -1,0 +1,246 @@
+"""Host driver of the fused fine-stage path: enqueues the HIP kernels of
+libesr_hip.so (include/esr_hip.h, section B) for one training step of
+``VoxurfF.forward_training`` (reference: app/fine/model/voxurff.py:177-278) and
+its backward.
+
+PyTorch is plumbing here: it owns the device memory (a grow-only workspace),
+the stream, and the autograd edge to the parameters.  Every arithmetic step on
+the path is a HIP kernel behind the C ABI; there is no torch fallback -- if the
+library is missing, `_lib.lib()` raises.
+
+One host<->device sync per forward (the 32-byte plan header that sizes the
+activation workspace); the reference has >= 8 (item() in the sampler, one per
+boolean-mask compaction).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+
+KIND_RADIANCE, KIND_TONEMAP = 0, 1
+HID = 192
+X_ROWS, DX_ROWS, XT_ROWS = 96, 64, 48
+
+
+def make_scene(xyz_min, xyz_max, mask_min, mask_max, world_size, mask_size, near, stepdist,
+               voxel_size, act_shift, mask_thres, fast_thres, s_val, grad_feat) -> _lib.EsrScene:
+    sc = _lib.EsrScene()
+    for i in range(3):
+        sc.xyz_min[i], sc.xyz_max[i] = float(xyz_min[i]), float(xyz_max[i])
+        sc.mask_min[i], sc.mask_max[i] = float(mask_min[i]), float(mask_max[i])
+    sc.gx, sc.gy, sc.gz = [int(v) for v in world_size]
+    sc.mx, sc.my, sc.mz = [int(v) for v in mask_size]
+    sc.near_, sc.stepdist, sc.voxel_size = float(near), float(stepdist), float(voxel_size)
+    sc.act_shift, sc.mask_thres, sc.fast_thres = float(act_shift), float(mask_thres), float(fast_thres)
+    sc.s_val = float(s_val)
+    # longest chord of the box in steps (+ slack for the ceil and the >=1 rule)
+    diag = math.sqrt(sum((float(xyz_max[i]) - float(xyz_min[i])) ** 2 for i in range(3)))
+    sc.max_steps = int(diag / float(stepdist)) + 4
+    if len(grad_feat) != 4:
+        raise NotImplementedError("the HIP feature kernel is built for 4 stencil radii (cfg grad_feat)")
+    for i in range(4):
+        sc.grad_feat[i] = float(grad_feat[i])
+    return sc
+
+
+@dataclass
+class FineCtx:
+    """What the backward needs from the forward of one step."""
+    scene: _lib.EsrScene
+    n_rays: int
+    tiles_on: int
+    tiles_all: int
+    counts: Dict[str, int]
+    rays_o: torch.Tensor
+    rays_d: torch.Tensor
+    off3: torch.Tensor
+    mask_density: torch.Tensor
+    sdf: torch.Tensor
+
+
+class _Workspace:
+    """Grow-only device buffers, tile-major [tiles, rows, 32] fp32."""
+
+    def __init__(self, device):
+        self.device = device
+        self.cap_tiles = 0
+        self.buf: Dict[str, torch.Tensor] = {}
+
+    ROWS = dict(X=X_ROWS, gnorm=4, H0=HID, H1=HID, H2=HID, z_off=4, z_emo=4, lin=4, Xt=XT_ROWS, Ht=HID,
+                zt=4, rgb=4, dzt=4, dZt=HID, dXt=DX_ROWS, dz=4, dZ0=HID, dZ1=HID, dZ2=HID, dX=DX_ROWS,
+                dweight=1, rec_w=1, rec_sdf=1)
+
+    def ensure(self, tiles: int):
+        if tiles <= self.cap_tiles:
+            return
+        cap = max(tiles, int(self.cap_tiles * 1.25) + 64)
+        self.buf = {k: torch.empty(cap * r * 32, dtype=torch.float32, device=self.device)
+                    for k, r in self.ROWS.items()}
+        self.buf["rec_ray"] = torch.empty(cap * 32, dtype=torch.int32, device=self.device)
+        self.buf["rec_step"] = torch.empty(cap * 32, dtype=torch.int32, device=self.device)
+        self.cap_tiles = cap
+
+    def __getitem__(self, k):
+        return self.buf[k]
+
+
+class FineEngine:
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.L = _lib.lib()
+        self.ws = _Workspace(self.device)
+        self.plan_dev = torch.zeros(8, dtype=torch.int32, device=self.device)
+        self.plan_host = torch.zeros(8, dtype=torch.int32).pin_memory()
+        self.packed = {
+            k: torch.empty(self.L.esr_mlp_packed_floats(kind), dtype=torch.float32, device=self.device)
+            for k, kind in (("off", KIND_RADIANCE), ("emo", KIND_RADIANCE), ("tone", KIND_TONEMAP))}
+        self.ray_bufs: Dict[int, Dict[str, torch.Tensor]] = {}
+
+    # -- helpers ---------------------------------------------------------------
+    def _s(self):
+        return _lib.stream_ptr(self.device)
+
+    def _ray_buf(self, n):
+        if n not in self.ray_bufs:
+            self.ray_bufs[n] = dict(
+                cnt3=torch.empty(n, dtype=torch.int32, device=self.device),
+                off3=torch.empty(n, dtype=torch.int32, device=self.device))
+        return self.ray_bufs[n]
+
+    def pack(self, which: str, kind: int, weights: List[torch.Tensor], biases: List[torch.Tensor]):
+        w = _lib.EsrMlpWeights()
+        for i, (a, b) in enumerate(zip(weights, biases)):
+            if not (a.is_cuda and a.is_contiguous() and b.is_contiguous() and a.dtype == torch.float32):
+                raise RuntimeError("MLP parameters must be contiguous fp32 device tensors")
+            w.w[i], w.b[i] = a.data_ptr(), b.data_ptr()
+        _lib.check(self.L.esr_mlp_pack(kind, C.byref(w), _lib.ptr(self.packed[which]), self._s()), "esr_mlp_pack")
+
+    def _H(self, names):
+        return _lib.ptr_array([self.ws[n] for n in names])
+
+    # -- forward -----------------------------------------------------------------
+    def forward(self, scene, rays_o, rays_d, viewdirs, em_modes, mask_density, sdf, off_color, emo_color):
+        """-> (ctx, alphainv_last [N], srgb_marched [N,3], lin_marched [N,3]).
+        sdf [X,Y,Z], off_color/emo_color [X,Y,Z,6], mask_density [mx,my,mz]: contiguous fp32."""
+        L, s, ws = self.L, self._s(), self.ws
+        n = rays_o.shape[0]
+        for t in (rays_o, rays_d, viewdirs):
+            if t.dtype != torch.float32:
+                raise RuntimeError("rays must be fp32")
+        if em_modes.dtype != torch.int64:
+            raise RuntimeError("em_modes must be int64")
+        rb = self._ray_buf(n)
+        last = torch.empty(n, dtype=torch.float32, device=self.device)
+        srgb = torch.zeros(n, 3, dtype=torch.float32, device=self.device)
+        lin = torch.zeros(n, 3, dtype=torch.float32, device=self.device)
+        sp = C.byref(scene)
+        _lib.check(L.esr_fine_plan_begin(_lib.ptr(self.plan_dev), s), "plan_begin")
+        _lib.check(L.esr_fine_march_count(sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(mask_density),
+                                          _lib.ptr(sdf), n, _lib.ptr(rb["cnt3"]), _lib.ptr(last),
+                                          _lib.ptr(self.plan_dev), s), "march_count")
+        _lib.check(L.esr_fine_plan(_lib.ptr(rb["cnt3"]), _lib.ptr(em_modes), n, _lib.ptr(rb["off3"]),
+                                   _lib.ptr(self.plan_dev), s), "plan")
+        self.plan_host.copy_(self.plan_dev, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()        # the one sync of the step
+        n_on, n_off, tiles_on, tiles_all, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
+        if overflow:
+            raise RuntimeError("a ray exceeded scene.max_steps; the LDS bound of the march kernel is wrong")
+        ctx = FineCtx(scene=scene, n_rays=n, tiles_on=tiles_on, tiles_all=tiles_all,
+                      counts=dict(m0=m0, m1=m1, m2=m2, m3=n_on + n_off, n_on=n_on, n_off=n_off),
+                      rays_o=rays_o, rays_d=rays_d, off3=rb["off3"], mask_density=mask_density, sdf=sdf)
+        if tiles_all == 0:
+            return ctx, last, srgb, lin
+        ws.ensure(tiles_all)
+        ws["rec_ray"][: tiles_all * 32].fill_(-1)
+        _lib.check(L.esr_fine_march_fill(sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(mask_density),
+                                         _lib.ptr(sdf), n, _lib.ptr(rb["off3"]), _lib.ptr(ws["rec_ray"]),
+                                         _lib.ptr(ws["rec_step"]), _lib.ptr(ws["rec_w"]),
+                                         _lib.ptr(ws["rec_sdf"]), s), "march_fill")
+        _lib.check(L.esr_fine_feat_fwd(sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(viewdirs),
+                                       _lib.ptr(sdf), _lib.ptr(off_color), _lib.ptr(emo_color),
+                                       _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_step"]),
+                                       _lib.ptr(ws["rec_sdf"]), tiles_on, tiles_all, _lib.ptr(ws["X"]),
+                                       _lib.ptr(ws["gnorm"]), s), "feat_fwd")
+        H = self._H(["H0", "H1", "H2"])
+        # off net: detached pass on the on-tiles (alt colour rows, nothing saved), saved pass on the off-tiles
+        _lib.check(L.esr_mlp_fwd(KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), 0, tiles_on,
+                                 H, 0, 1, _lib.ptr(ws["z_off"]), s), "mlp_fwd(off|on-tiles)")
+        _lib.check(L.esr_mlp_fwd(KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), tiles_on,
+                                 tiles_all, H, 1, 0, _lib.ptr(ws["z_off"]), s), "mlp_fwd(off)")
+        _lib.check(L.esr_mlp_fwd(KIND_RADIANCE, _lib.ptr(self.packed["emo"]), _lib.ptr(ws["X"]), 0, tiles_on,
+                                 H, 1, 0, _lib.ptr(ws["z_emo"]), s), "mlp_fwd(emo)")
+        _lib.check(L.esr_fine_tone_in_fwd(_lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), tiles_on, tiles_all,
+                                          _lib.ptr(ws["lin"]), _lib.ptr(ws["Xt"]), s), "tone_in_fwd")
+        _lib.check(L.esr_mlp_fwd(KIND_TONEMAP, _lib.ptr(self.packed["tone"]), _lib.ptr(ws["Xt"]), 0, tiles_all,
+                                 self._H(["Ht"]), 1, 0, _lib.ptr(ws["zt"]), s), "mlp_fwd(tone)")
+        _lib.check(L.esr_fine_composite_fwd(_lib.ptr(ws["zt"]), _lib.ptr(ws["lin"]), _lib.ptr(ws["rec_ray"]),
+                                            _lib.ptr(ws["rec_w"]), tiles_all, _lib.ptr(ws["rgb"]),
+                                            _lib.ptr(srgb), _lib.ptr(lin), s), "composite_fwd")
+        return ctx, last, srgb, lin
+
+    # -- backward ----------------------------------------------------------------
+    def backward(self, ctx: FineCtx, g_last, g_srgb, g_lin, grads: Dict[str, Optional[torch.Tensor]]):
+        """Accumulates into the (zero-initialised, reference-layout) tensors of ``grads``:
+        sdf [X,Y,Z], off_color/emo_color [X,Y,Z,6], off_w/off_b/emo_w/emo_b (lists of 4),
+        tone_w/tone_b (lists of 2)."""
+        L, s, ws = self.L, self._s(), self.ws
+        sp = C.byref(ctx.scene)
+        to, ta = ctx.tiles_on, ctx.tiles_all
+        g_last, g_srgb, g_lin = g_last.contiguous(), g_srgb.contiguous(), g_lin.contiguous()
+        if ta > 0:
+            _lib.check(L.esr_fine_composite_bwd(_lib.ptr(g_srgb), _lib.ptr(g_lin), _lib.ptr(ws["rgb"]),
+                                                _lib.ptr(ws["lin"]), _lib.ptr(ws["rec_ray"]),
+                                                _lib.ptr(ws["rec_w"]), ta, _lib.ptr(ws["dweight"]),
+                                                _lib.ptr(ws["dzt"]), s), "composite_bwd")
+            _lib.check(L.esr_mlp_dgrad(KIND_TONEMAP, _lib.ptr(self.packed["tone"]), _lib.ptr(ws["dzt"]), 0, ta,
+                                       self._H(["Ht"]), self._H(["dZt"]), _lib.ptr(ws["dXt"]), s),
+                       "mlp_dgrad(tone)")
+            _lib.check(L.esr_fine_tone_in_bwd(_lib.ptr(ws["dXt"]), _lib.ptr(g_lin), _lib.ptr(ws["lin"]),
+                                              _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]),
+                                              _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), to, ta,
+                                              _lib.ptr(ws["dz"]), s), "tone_in_bwd")
+            H, dZ = self._H(["H0", "H1", "H2"]), self._H(["dZ0", "dZ1", "dZ2"])
+            _lib.check(L.esr_mlp_dgrad(KIND_RADIANCE, _lib.ptr(self.packed["emo"]), _lib.ptr(ws["dz"]), 0, to,
+                                       H, dZ, _lib.ptr(ws["dX"]), s), "mlp_dgrad(emo)")
+            _lib.check(L.esr_mlp_dgrad(KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["dz"]), to, ta,
+                                       H, dZ, _lib.ptr(ws["dX"]), s), "mlp_dgrad(off)")
+            _lib.check(L.esr_mlp_wgrad(KIND_TONEMAP, _lib.ptr(ws["Xt"]), 0, self._H(["Ht"]), self._H(["dZt"]),
+                                       _lib.ptr(ws["dzt"]), 0, ta, _lib.ptr_array(grads["tone_w"]),
+                                       _lib.ptr_array(grads["tone_b"]), s), "mlp_wgrad(tone)")
+            _lib.check(L.esr_mlp_wgrad(KIND_RADIANCE, _lib.ptr(ws["X"]), 0, H, dZ, _lib.ptr(ws["dz"]), 0, to,
+                                       _lib.ptr_array(grads["emo_w"]), _lib.ptr_array(grads["emo_b"]), s),
+                       "mlp_wgrad(emo)")
+            _lib.check(L.esr_mlp_wgrad(KIND_RADIANCE, _lib.ptr(ws["X"]), 0, H, dZ, _lib.ptr(ws["dz"]), to, ta,
+                                       _lib.ptr_array(grads["off_w"]), _lib.ptr_array(grads["off_b"]), s),
+                       "mlp_wgrad(off)")
+            _lib.check(L.esr_fine_feat_bwd(sp, _lib.ptr(ctx.rays_o), _lib.ptr(ctx.rays_d),
+                                           _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_step"]), _lib.ptr(ws["X"]),
+                                           _lib.ptr(ws["gnorm"]), _lib.ptr(ws["dX"]), to, ta,
+                                           _lib.ptr(grads["sdf"]), _lib.ptr(grads["off_color"]),
+                                           _lib.ptr(grads["emo_color"]), s), "feat_bwd")
+            dweight = ws["dweight"]
+        else:
+            dweight = torch.zeros(32, dtype=torch.float32, device=self.device)
+        _lib.check(L.esr_fine_march_bwd(sp, _lib.ptr(ctx.rays_o), _lib.ptr(ctx.rays_d),
+                                        _lib.ptr(ctx.mask_density), _lib.ptr(ctx.sdf), ctx.n_rays,
+                                        _lib.ptr(ctx.off3), _lib.ptr(dweight), _lib.ptr(g_last),
+                                        _lib.ptr(grads["sdf"]), s), "march_bwd")
+
+    # -- fused trainer-step loss (app/fine/fine.py:355-382) ------------------------
+    def loss_fwd_bwd(self, last, srgb, lin, rgbs, white_bg=True, weight_linear=0.1, weight_entropy_last=0.001):
+        n = last.shape[0]
+        loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        g_srgb = torch.empty_like(srgb)
+        g_lin = torch.empty_like(lin)
+        g_last = torch.empty_like(last)
+        _lib.check(self.L.esr_fine_loss_fwd_bwd(
+            _lib.ptr(srgb), _lib.ptr(lin), _lib.ptr(last), _lib.ptr(rgbs.contiguous()), n,
+            C.c_float(1.0 if white_bg else 0.0), C.c_float(weight_linear), C.c_float(weight_entropy_last),
+            _lib.ptr(loss), _lib.ptr(g_srgb), _lib.ptr(g_lin), _lib.ptr(g_last), self._s()), "loss")
+        return loss, g_last, g_srgb, g_lin

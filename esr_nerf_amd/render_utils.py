@@ -1,0 +1,122 @@
+"""Drop-in for the reference's two pybind extension modules.
+
+Same function names, argument order and return lists as
+``render_utils_cuda`` (app/utils/base/cuda/render_utils.cpp:170-184) and
+``total_variation_cuda`` (app/utils/base/cuda/total_variation.cpp:29-32), so the
+reference's ``app/utils/base/module.py`` / ``voxurff.py`` call sites run on it
+unchanged; the bodies call the C ABI of libesr_hip.so.  Errors surface as
+RuntimeError like the reference's TORCH_CHECK(is_cuda / is_contiguous).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_i64 = torch.int64
+_f32 = torch.float32
+
+
+def _chk(t: torch.Tensor, name: str, dtype=None):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}")
+
+
+def sample_pts_on_rays(rays_o, rays_d, xyz_min, xyz_max, near, far, stepdist):
+    """-> [ray_pts, mask_outbbox, ray_id, step_id, N_steps, t_min, t_max]."""
+    for t, n in ((rays_o, "rays_o"), (rays_d, "rays_d"), (xyz_min, "xyz_min"), (xyz_max, "xyz_max")):
+        _chk(t, n, _f32)
+    L = _lib.lib()
+    dev = rays_o.device
+    n = rays_o.shape[0]
+    t_min = torch.empty(n, dtype=_f32, device=dev)
+    t_max = torch.empty(n, dtype=_f32, device=dev)
+    n_steps = torch.empty(n, dtype=_i64, device=dev)
+    cumsum = torch.empty(n, dtype=_i64, device=dev)
+    total = torch.empty(1, dtype=_i64, device=dev)
+    s = _lib.stream_ptr(dev)
+    _lib.check(L.esr_sample_count(
+        _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(xyz_min), _lib.ptr(xyz_max),
+        C.c_float(float(near)), C.c_float(float(far)), C.c_float(float(stepdist)), C.c_int64(n),
+        _lib.ptr(t_min), _lib.ptr(t_max), _lib.ptr(n_steps), _lib.ptr(cumsum), _lib.ptr(total), s),
+        "esr_sample_count")
+    m = int(total.item())          # same device->host sync as the reference (kernel.cu:212)
+    ray_pts = torch.empty(m, 3, dtype=_f32, device=dev)
+    mask = torch.empty(m, dtype=torch.bool, device=dev)
+    ray_id = torch.empty(m, dtype=_i64, device=dev)
+    step_id = torch.empty(m, dtype=_i64, device=dev)
+    _lib.check(L.esr_sample_fill(
+        _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(xyz_min), _lib.ptr(xyz_max), _lib.ptr(t_min),
+        _lib.ptr(cumsum), C.c_float(float(stepdist)), C.c_int64(n), C.c_int64(m),
+        _lib.ptr(ray_pts), _lib.ptr(mask), _lib.ptr(ray_id), _lib.ptr(step_id), s),
+        "esr_sample_fill")
+    return [ray_pts, mask, ray_id, step_id, n_steps, t_min, t_max]
+
+
+def alpha2weight(alpha, ray_id, n_rays):
+    """-> [weight, T, alphainv_last, i_start, i_end]."""
+    _chk(alpha, "alpha", _f32)
+    _chk(ray_id, "ray_id", _i64)
+    L = _lib.lib()
+    dev = alpha.device
+    m, n_rays = alpha.shape[0], int(n_rays)
+    weight = torch.empty_like(alpha)
+    T = torch.empty_like(alpha)
+    last = torch.empty(n_rays, dtype=_f32, device=dev)
+    i_s = torch.empty(n_rays, dtype=_i64, device=dev)
+    i_e = torch.empty(n_rays, dtype=_i64, device=dev)
+    _lib.check(L.esr_alpha2weight_fwd(
+        _lib.ptr(alpha), _lib.ptr(ray_id), C.c_int64(m), C.c_int64(n_rays), _lib.ptr(weight),
+        _lib.ptr(T), _lib.ptr(last), _lib.ptr(i_s), _lib.ptr(i_e), _lib.stream_ptr(dev)),
+        "esr_alpha2weight_fwd")
+    return [weight, T, last, i_s, i_e]
+
+
+def alpha2weight_backward(alpha, weight, T, alphainv_last, i_start, i_end, n_rays,
+                          grad_weights, grad_last):
+    for t, n in ((alpha, "alpha"), (weight, "weight"), (T, "T"), (alphainv_last, "alphainv_last"),
+                 (grad_weights, "grad_weights"), (grad_last, "grad_last")):
+        _chk(t, n, _f32)
+    L = _lib.lib()
+    grad = torch.empty_like(alpha)
+    _lib.check(L.esr_alpha2weight_bwd(
+        _lib.ptr(alpha), _lib.ptr(weight), _lib.ptr(T), _lib.ptr(alphainv_last), _lib.ptr(i_start),
+        _lib.ptr(i_end), C.c_int64(alpha.shape[0]), C.c_int64(int(n_rays)), _lib.ptr(grad_weights),
+        _lib.ptr(grad_last), _lib.ptr(grad), _lib.stream_ptr(alpha.device)),
+        "esr_alpha2weight_bwd")
+    return grad
+
+
+def total_variation_add_grad(param, grad, wx, wy, wz, dense_mode):
+    """In place on ``grad`` ([1,C,X,Y,Z] like ``param``)."""
+    _chk(param, "param", _f32)
+    _chk(grad, "grad", _f32)
+    L = _lib.lib()
+    _lib.check(L.esr_tv_add_grad(
+        _lib.ptr(param), _lib.ptr(grad), C.c_float(float(wx)), C.c_float(float(wy)),
+        C.c_float(float(wz)), C.c_int64(param.shape[2]), C.c_int64(param.shape[3]),
+        C.c_int64(param.shape[4]), C.c_int64(param.numel()), C.c_int(1 if dense_mode else 0),
+        _lib.stream_ptr(param.device)), "esr_tv_add_grad")
+
+
+def segment_coo(src, index, out=None, dim_size=None, reduce="sum"):
+    """torch_scatter.segment_coo(src, index, out, reduce='sum') for a sorted index."""
+    if reduce != "sum":
+        raise NotImplementedError("only reduce='sum' is on the path")
+    _chk(index, "index", _i64)
+    src = src.contiguous()
+    _chk(src, "src", _f32)
+    if out is None:
+        out = torch.zeros((int(dim_size),) + tuple(src.shape[1:]), dtype=_f32, device=src.device)
+    _chk(out, "out", _f32)
+    c = 1 if src.dim() == 1 else src.shape[1]
+    _lib.check(_lib.lib().esr_segment_sum(
+        _lib.ptr(src), _lib.ptr(index), C.c_int64(src.shape[0]), C.c_int64(c), _lib.ptr(out),
+        C.c_int64(out.shape[0]), _lib.stream_ptr(src.device)), "esr_segment_sum")
+    return out

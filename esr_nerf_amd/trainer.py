@@ -1,0 +1,127 @@
+"""One training step of the fine stage on the HIP path, without autograd in the
+loop: forward kernels -> fused loss+gradient kernel -> backward kernels.
+
+It reproduces the body of the reference trainer's hot loop
+(app/fine/fine.py:346-395: renderer call, white-background add + clamps, MSE on
+sRGB, MSE on gamma-encoded linear colour, entropy of alphainv_last, backward)
+for ``bench.py`` and for data-parallel runs; ``VoxurfF.forward`` + a torch loss +
+``loss.backward()`` (the drop-in route used by the reference's ``Fine.learn``)
+enqueues exactly the same renderer kernels and is tested to give the same
+numbers.  The optimizer step is outside the named path and not
+part of this class.
+
+Data parallelism: rays are independent, so every rank runs the
+same step on its contiguous shard of the global batch and the parameter
+gradients are summed with ONE flat all-reduce (RCCL over xGMI when the process
+group is NCCL).  Losses are normalised by the GLOBAL ray count so the reduced
+gradient equals the single-process gradient of the full batch.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from .fine_engine import KIND_RADIANCE, KIND_TONEMAP
+
+
+def shard_batch(batch: Dict[str, torch.Tensor], rank: int, world: int) -> Dict[str, torch.Tensor]:
+    """Contiguous ray shard of a global batch (last rank takes the remainder)."""
+    n = next(iter(batch.values())).shape[0]
+    per = n // world
+    lo = rank * per
+    hi = n if rank == world - 1 else lo + per
+    return {k: v[lo:hi].contiguous() for k, v in batch.items()}
+
+
+class FineStep:
+    def __init__(self, model, white_bg: bool = True, weight_linear: float = 0.1,
+                 weight_entropy_last: float = 0.001, process_group=None):
+        self.model = model
+        self.white_bg = white_bg
+        self.weight_linear = weight_linear
+        self.weight_entropy_last = weight_entropy_last
+        self.pg = process_group
+        self._names = None
+        self._flat = None
+
+    # names follow state_dict / named_parameters of the renderer
+    def _param_names(self):
+        if self._names is None:
+            names = []
+            for net in ("off_rgbnet", "emo_rgbnet", "tonemapper"):
+                seq = "linear" if net != "tonemapper" else "srgb"
+                mod = getattr(getattr(self.model, net), seq)
+                for key, sub in mod.named_modules():
+                    if isinstance(sub, torch.nn.Linear):
+                        names += [f"{net}.{seq}.{key}.weight", f"{net}.{seq}.{key}.bias"]
+            self._names = names
+        return self._names
+
+    def _alloc_grads(self, dev):
+        """One flat zero buffer holding every gradient (a single memset, a single all-reduce)."""
+        m = self.model
+        X, Y, Z = [int(v) for v in m.world_size]
+        shapes = [("sdf.grid", (1, 1, X, Y, Z)), ("off_color.grid", (1, X, Y, Z, 6)),
+                  ("emo_color.grid", (1, X, Y, Z, 6))]
+        shapes += [(n, tuple(p.shape)) for n, p in zip(self._param_names(), m._mlp_params())]
+        total = sum(int(torch.Size(s).numel()) for _, s in shapes)
+        if self._flat is None or self._flat.numel() != total:
+            self._flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self._flat.zero_()
+        out, o = {}, 0
+        for n, s in shapes:
+            k = int(torch.Size(s).numel())
+            out[n] = self._flat[o:o + k].view(s)
+            o += k
+        return out
+
+    @torch.no_grad()
+    def forward_loss_backward(self, batch: Dict[str, torch.Tensor], s_val: float,
+                              global_rays: Optional[int] = None,
+                              entropy_owner: bool = True) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """``global_rays``: size of the whole batch when ``batch`` is one rank's shard.
+        ``entropy_owner``: the reference's entropy term looks at the LAST ray of the batch only
+        (fine.py:378), so under sharding exactly one rank -- the one holding the global last ray --
+        must add it."""
+        m = self.model
+        eng = m.engine
+        m.s_val = s_val
+        ps = m._mlp_params()
+        eng.pack("off", KIND_RADIANCE, list(ps[0:8:2]), list(ps[1:8:2]))
+        eng.pack("emo", KIND_RADIANCE, list(ps[8:16:2]), list(ps[9:16:2]))
+        eng.pack("tone", KIND_TONEMAP, list(ps[16:20:2]), list(ps[17:20:2]))
+        ctx, last, srgb, lin = eng.forward(
+            m.scene_struct(), batch["rays_o"], batch["rays_d"], batch["viewdirs"], batch["em_modes"],
+            m.mask_cache.density.view(*m.mask_cache.density.shape[2:]),
+            m.sdf.device_view(), m.off_color.device_view(), m.emo_color.device_view())
+        m.last_counts = ctx.counts
+        n_local = last.shape[0]
+        scale = 1.0 if global_rays is None else n_local / float(global_rays)
+        # the MSE terms are means over the GLOBAL batch (rescaled below); the entropy term is not a
+        # mean, so it is pre-divided by the same factor on the one rank that owns it
+        w_ent = (self.weight_entropy_last / scale) if entropy_owner else 0.0
+        loss, g_last, g_srgb, g_lin = eng.loss_fwd_bwd(last, srgb, lin, batch["rgbs"], self.white_bg,
+                                                       self.weight_linear, w_ent)
+        if scale != 1.0:
+            loss, g_last, g_srgb, g_lin = loss * scale, g_last * scale, g_srgb * scale, g_lin * scale
+        g = self._alloc_grads(last.device)
+        names = self._param_names()
+        grads = dict(sdf=g["sdf.grid"], off_color=g["off_color.grid"], emo_color=g["emo_color.grid"],
+                     off_w=[g[n] for n in names[0:8:2]], off_b=[g[n] for n in names[1:8:2]],
+                     emo_w=[g[n] for n in names[8:16:2]], emo_b=[g[n] for n in names[9:16:2]],
+                     tone_w=[g[n] for n in names[16:20:2]], tone_b=[g[n] for n in names[17:20:2]])
+        eng.backward(ctx, g_last, g_srgb, g_lin, grads)
+        if self.pg is not None:
+            import torch.distributed as dist
+            dist.all_reduce(self._flat, group=self.pg)
+            dist.all_reduce(loss, group=self.pg)
+        g["off_color.grid"] = g["off_color.grid"].permute(0, 4, 1, 2, 3)     # logical [1,6,X,Y,Z]
+        g["emo_color.grid"] = g["emo_color.grid"].permute(0, 4, 1, 2, 3)
+        return loss, g
+
+    def assign_grads(self, grads: Dict[str, torch.Tensor]):
+        """Expose the step's gradients as ``param.grad`` (for a torch optimizer)."""
+        for n, p in self.model.named_parameters():
+            if n in grads:
+                p.grad = grads[n]

@@ -1,0 +1,288 @@
+/*
+ * esr_hip.h -- C ABI of libesr_hip.so, the MI355X (gfx950) implementation of
+ * ESR-NeRF's volumetric-rendering hot path.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - every pointer is CALLER-OWNED DEVICE memory, contiguous, unless marked
+ *     [host]; outputs are never allocated inside the library.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every
+ *     kernel is enqueued on it, nothing synchronises the device.
+ *   - return value: 0 on success, otherwise the (positive) hipError_t of the
+ *     failing runtime call, or a negative ESR_E* argument error.  Nothing throws
+ *     across the ABI.  The Python shim re-raises non-zero codes as RuntimeError,
+ *     which is what the reference's TORCH_CHECK failures surface as
+ *     (app/utils/base/cuda/render_utils.cpp:46-48).
+ *   - re-entrant; no global state.
+ *
+ * Reference interfaces replaced (paths relative to the reference tree):
+ *   app/utils/base/cuda/render_utils.cpp:170-184  pybind module render_utils_cuda
+ *   app/utils/base/cuda/total_variation.cpp:29-32 pybind module total_variation_cuda
+ *   torch_scatter.segment_coo (third party; call sites app/fine/model/voxurff.py:260-272)
+ *   and, for the fused fine-stage ops, the torch-level body of
+ *   VoxurfF.forward_training (app/fine/model/voxurff.py:177-278).
+ */
+#ifndef ESR_HIP_H
+#define ESR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESR_EINVAL (-1)   /* bad argument (null pointer, negative size, bad dims) */
+#define ESR_ECAP   (-2)   /* a capacity limit of the kernels is exceeded          */
+
+#define ESR_TILE 32       /* samples per tile of the tile-major activation layout  */
+
+int esr_abi_version(void);          /* bumps whenever a signature below changes */
+const char *esr_build_info(void);   /* "gfx950 <date>"                         */
+
+/* ------------------------------------------------------------------------- *
+ * A. Drop-in replacements of the reference's native ops (same arithmetic,
+ *    same outputs, caller allocates).
+ * ------------------------------------------------------------------------- */
+
+/*
+ * sample_pts_on_rays, phase 1 -- replaces infer_t_minmax + infer_n_samples +
+ * N_steps.cumsum + N_steps.sum (render_utils_kernel.cu:12-55,204-212).
+ * rays_o, rays_d [n_rays,3] f32; xyz_min, xyz_max [3] f32 (device, as in the
+ * reference).  Outputs: t_min, t_max [n_rays] f32; n_steps, cumsum [n_rays] i64
+ * (inclusive scan); total [1] i64 (device).  The caller reads `total` back to
+ * size phase 2 -- the same device->host sync the reference performs at
+ * render_utils_kernel.cu:212.
+ */
+int esr_sample_count(const float *rays_o, const float *rays_d, const float *xyz_min,
+                     const float *xyz_max, float near_, float far_, float stepdist,
+                     int64_t n_rays, float *t_min, float *t_max, int64_t *n_steps,
+                     int64_t *cumsum, int64_t *total, void *stream);
+
+/*
+ * sample_pts_on_rays, phase 2 -- replaces __set_1_at_ray_seg_start + cumsum_ +
+ * __set_step_id + infer_ray_start_dir + sample_pts_on_rays_cuda_kernel
+ * (render_utils_kernel.cu:58-79,144-194,213-241).  Outputs have `total` rows:
+ * ray_pts [total,3] f32, mask_outbbox [total] u8 (bool), ray_id, step_id [total] i64.
+ */
+int esr_sample_fill(const float *rays_o, const float *rays_d, const float *xyz_min,
+                    const float *xyz_max, const float *t_min, const int64_t *cumsum,
+                    float stepdist, int64_t n_rays, int64_t total, float *ray_pts,
+                    uint8_t *mask_outbbox, int64_t *ray_id, int64_t *step_id, void *stream);
+
+/*
+ * alpha2weight -- replaces render_utils_kernel.cu:577-651.  alpha [n_pts] f32,
+ * ray_id [n_pts] i64 sorted.  Writes weight, T [n_pts]; alphainv_last [n_rays];
+ * i_start, i_end [n_rays] i64 -- all fully initialised here (0/1/1/0/0 defaults).
+ */
+int esr_alpha2weight_fwd(const float *alpha, const int64_t *ray_id, int64_t n_pts,
+                         int64_t n_rays, float *weight, float *T, float *alphainv_last,
+                         int64_t *i_start, int64_t *i_end, void *stream);
+
+/* alpha2weight_backward -- replaces render_utils_kernel.cu:654-707. grad [n_pts]. */
+int esr_alpha2weight_bwd(const float *alpha, const float *weight, const float *T,
+                         const float *alphainv_last, const int64_t *i_start,
+                         const int64_t *i_end, int64_t n_pts, int64_t n_rays,
+                         const float *grad_weights, const float *grad_last, float *grad,
+                         void *stream);
+
+/*
+ * total_variation_add_grad -- replaces total_variation_kernel.cu:13-35,68-98.
+ * In place on grad; param/grad have n elements laid out [..., sz_i, sz_j, sz_k].
+ * Keeps the reference's quirk: the i and k axes both use wz, wx is unused.
+ */
+int esr_tv_add_grad(const float *param, float *grad, float wx, float wy, float wz,
+                    int64_t sz_i, int64_t sz_j, int64_t sz_k, int64_t n, int dense_mode,
+                    void *stream);
+
+/*
+ * Sorted segment sum -- replaces torch_scatter.segment_coo(src, index, out,
+ * reduce="sum") (voxurff.py:260-272).  out [n_seg,c] is accumulated into
+ * (caller zero-fills); index [n] i64 non-decreasing.
+ */
+int esr_segment_sum(const float *src, const int64_t *index, int64_t n, int64_t c,
+                    float *out, int64_t n_seg, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * B. Fused fine-stage path (VoxurfF.forward_training and its backward).
+ * ------------------------------------------------------------------------- */
+
+/* Scene constants, host struct passed by pointer [host] and copied by value. */
+typedef struct esr_scene {
+    float xyz_min[3], xyz_max[3];     /* sampler box == sdf/colour grid box          */
+    float mask_min[3], mask_max[3];   /* mask-cache box                              */
+    int32_t gx, gy, gz;               /* sdf / colour grid nodes [X,Y,Z]             */
+    int32_t mx, my, mz;               /* mask-cache grid nodes                       */
+    float near_, stepdist, voxel_size;
+    float act_shift, mask_thres;      /* mask cache: 1-exp(-softplus(d+shift)) >= thres */
+    float fast_thres;                 /* alpha > thres, then weight > thres          */
+    float s_val;
+    int32_t max_steps;                /* upper bound of per-ray step count (LDS sizing) */
+    float grad_feat[4];               /* stencil radii of the 24-tap SDF feature (voxels) */
+} esr_scene_t;
+
+/*
+ * Header the planner leaves in device memory (and the caller reads back once per
+ * iteration to size the activation workspace).
+ */
+typedef struct esr_plan {
+    int32_t n_on;        /* surviving samples on emissive-on rays   */
+    int32_t n_off;       /* surviving samples on emissive-off rays  */
+    int32_t tiles_on;    /* ceil(n_on / 32)                         */
+    int32_t tiles_all;   /* tiles_on + ceil(n_off / 32)             */
+    int32_t m0, m1, m2;  /* survivors after in-box / mask-cache / alpha>thres */
+    int32_t overflow;    /* !=0: a ray exceeded scene.max_steps     */
+} esr_plan_t;
+
+/*
+ * march, counting pass: per ray (one wavefront each) sampler -> mask cache ->
+ * SDF tap -> NeuS-interp alpha -> alpha>thres -> transmittance with the early
+ * stop -> weight>thres (voxurff.py:186-213, functions.py:72-105,
+ * render_utils_kernel.cu:577-605).  mask_density [mx,my,mz] (max-pooled),
+ * sdf [gx,gy,gz].  Writes cnt3 [n_rays] i32 and alphainv_last [n_rays] f32 and
+ * accumulates the m0/m1/m2 counters of *plan (zeroed by esr_fine_plan_begin).
+ */
+int esr_fine_march_count(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                         const float *mask_density, const float *sdf, int32_t n_rays,
+                         int32_t *cnt3, float *alphainv_last, esr_plan_t *plan, void *stream);
+
+int esr_fine_plan_begin(esr_plan_t *plan, void *stream);
+
+/*
+ * plan: exclusive offsets of every ray's survivors in the compact sample list.
+ * Emissive-on rays (em_modes==1) first, then -- starting at the next multiple of
+ * 32 -- the off rays, both in ray order, so every 32-sample tile is on-only or
+ * off-only.  off3 [n_rays] i32; *plan (device) gets the totals.
+ */
+int esr_fine_plan(const int32_t *cnt3, const int64_t *em_modes, int32_t n_rays,
+                  int32_t *off3, esr_plan_t *plan, void *stream);
+
+/*
+ * march, fill pass: recomputes the march and writes one record per surviving
+ * sample at off3[ray] + rank: rec_ray, rec_step (i32), rec_w, rec_sdf (f32).
+ * Padding entries must have been set to rec_ray = -1 by the caller.
+ */
+int esr_fine_march_fill(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                        const float *mask_density, const float *sdf, int32_t n_rays,
+                        const int32_t *off3, int32_t *rec_ray, int32_t *rec_step,
+                        float *rec_w, float *rec_sdf, void *stream);
+
+/*
+ * march backward: d(weights), d(alphainv_last) -> atomic scatter into grad_sdf
+ * [gx,gy,gz] through the compositing scan, the alpha formula and the trilinear
+ * tap.  dweight [n_tiles*32] is indexed like the records.
+ */
+int esr_fine_march_bwd(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                       const float *mask_density, const float *sdf, int32_t n_rays,
+                       const int32_t *off3, const float *dweight, const float *dlast,
+                       float *grad_sdf, void *stream);
+
+/*
+ * Per-sample feature assembly (voxurff.py:219-254 + :678-721 + module.py:24-35).
+ * Colour grids are channel-last [gx,gy,gz,6] (torch.channels_last_3d storage of
+ * the reference's [1,6,X,Y,Z] parameter).  X [n_tiles,96,32] f32, rows:
+ *   0-5 colour (emo grid on on-tiles, off grid on off-tiles) | 6 sdf | 7-30 feat24
+ *   | 31-42 normal12 | 43-45 xyz | 46-60 sin | 61-75 cos | 76-84 viewdir PE
+ *   | 85-87 zero | 88-93 off colour (on-tiles only) | 94-95 zero
+ * gnorm [n_tiles,4,32]: |grad| per stencil radius, kept for the backward.
+ */
+int esr_fine_feat_fwd(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                      const float *viewdirs, const float *sdf, const float *off_color,
+                      const float *emo_color, const int32_t *rec_ray, const int32_t *rec_step,
+                      const float *rec_sdf, int32_t tiles_on, int32_t tiles_all, float *X,
+                      float *gnorm, void *stream);
+
+/* Backward of the above: dX [n_tiles,64,32] (rows 0-42 used) -> grid gradients. */
+int esr_fine_feat_bwd(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                      const int32_t *rec_ray, const int32_t *rec_step, const float *X,
+                      const float *gnorm, const float *dX, int32_t tiles_on, int32_t tiles_all,
+                      float *grad_sdf, float *grad_off_color, float *grad_emo_color,
+                      void *stream);
+
+/*
+ * Tiny-MLP engine (RadianceNet 85-192-192-192-3, TonemapNet 33-192-3;
+ * app/utils/pbr/module.py:6-39) on f32 MFMA.  `kind`: 0 radiance, 1 tonemap.
+ * Weights are the reference's nn.Linear tensors ([out,in] row-major) packed by
+ * esr_mlp_pack into MFMA operand order.
+ */
+#define ESR_MLP_RADIANCE 0
+#define ESR_MLP_TONEMAP  1
+#define ESR_MLP_MAX_LAYERS 4
+
+typedef struct esr_mlp_weights {       /* [host] struct of device pointers */
+    const float *w[ESR_MLP_MAX_LAYERS];   /* [out,in] */
+    const float *b[ESR_MLP_MAX_LAYERS];   /* [out]    */
+} esr_mlp_weights_t;
+
+int64_t esr_mlp_packed_floats(int kind);     /* size of the packed buffer */
+int esr_mlp_pack(int kind, const esr_mlp_weights_t *w, float *packed, void *stream);
+
+/*
+ * Forward over tiles [t0,t1).  X: layer-1 input, tile-major [tiles,xrows,32].
+ * H: NHID saved hidden activations, each [tiles,192,32] (NULL or save=0: not kept).
+ * zout [tiles,4,32]: pre-activation outputs (row 3 = 0).  alt_color != 0 makes the
+ * radiance net read rows 88-93 instead of 0-5 (off net on emissive-on tiles).
+ */
+int esr_mlp_fwd(int kind, const float *packed, const float *X, int32_t t0, int32_t t1,
+                float *const *H, int save, int alt_color, float *zout, void *stream);
+
+/*
+ * Input/hidden gradients over tiles [t0,t1).  dz [tiles,4,32] -> dZ[l] (each
+ * [tiles,192,32], pre-activation grads of hidden layer l) and dX [tiles,64,32].
+ */
+int esr_mlp_dgrad(int kind, const float *packed, const float *dz, int32_t t0, int32_t t1,
+                  const float *const *H, float *const *dZ, float *dX, void *stream);
+
+/*
+ * Weight/bias gradients accumulated (atomics) into the reference-layout tensors
+ * gw[l] [out,in], gb[l] [out] over tiles [t0,t1).
+ */
+int esr_mlp_wgrad(int kind, const float *X, int alt_color, const float *const *H,
+                  const float *const *dZ, const float *dz, int32_t t0, int32_t t1,
+                  float *const *gw, float *const *gb, void *stream);
+
+/*
+ * Between the nets: lin = softplus(z_off) (+ softplus(z_emo) on on-tiles);
+ * Xt [tiles,48,32] = [lin3 | sin15 | cos15 | 0...] (voxurff.py:783-788).
+ */
+int esr_fine_tone_in_fwd(const float *z_off, const float *z_emo, int32_t tiles_on,
+                         int32_t tiles_all, float *lin, float *Xt, void *stream);
+
+/*
+ * rgb = sigmoid(zt); srgb_marched[ray] += w*rgb; lin_marched[ray] += w*lin
+ * (segmented wave reduction + one atomic per ray segment; voxurff.py:258-272).
+ * rgb [tiles,4,32] kept for the backward.  Outputs [n_rays,3] are accumulated
+ * into (caller zero-fills).
+ */
+int esr_fine_composite_fwd(const float *zt, const float *lin, const int32_t *rec_ray,
+                           const float *rec_w, int32_t tiles_all, float *rgb,
+                           float *srgb_marched, float *lin_marched, void *stream);
+
+/* d(srgb_marched), d(lin_marched) [n_rays,3] -> dweight [tiles*32], dzt [tiles,4,32]. */
+int esr_fine_composite_bwd(const float *g_srgb, const float *g_lin, const float *rgb,
+                           const float *lin, const int32_t *rec_ray, const float *rec_w,
+                           int32_t tiles_all, float *dweight, float *dzt, void *stream);
+
+/*
+ * dXt [tiles,64,32] (tonemap input grads) + g_lin -> dz [tiles,4,32] (grad of the
+ * radiance pre-activations: emo net on on-tiles, off net on off-tiles).
+ */
+int esr_fine_tone_in_bwd(const float *dXt, const float *g_lin, const float *lin,
+                         const float *z_off, const float *z_emo, const int32_t *rec_ray,
+                         const float *rec_w, int32_t tiles_on, int32_t tiles_all, float *dz,
+                         void *stream);
+
+/*
+ * Trainer-step loss of the fine stage (app/fine/fine.py:355-382) and its
+ * gradient w.r.t. the three renderer outputs, one launch.  loss [1] f32 is
+ * accumulated into (caller zero-fills).
+ */
+int esr_fine_loss_fwd_bwd(const float *srgb_marched, const float *lin_marched,
+                          const float *alphainv_last, const float *rgbs, int32_t n_rays,
+                          float white_bg, float weight_linear, float weight_entropy_last,
+                          float *loss, float *g_srgb, float *g_lin, float *g_last,
+                          void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESR_HIP_H */

@@ -1,0 +1,272 @@
+"""Fused HIP fine-stage path vs the CPU oracle (oracle/fine_path.py) and vs the
+golden vectors recorded from the imported reference.  Everything goes through
+the C ABI of libesr_hip.so (esr_nerf_amd.fine_engine / VoxurfF).
+
+Tolerance: north_star's 1e-4 relative fp32, measured rel-to-max-norm
+(SURVEY.md section 8(d)); discrete outputs (survivor counts) must match exactly.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+# --------------------------------------------------------------------------- helpers
+def build_gpu_model(scene, seed=0, grid_seed=0):
+    from esr_nerf_amd.config import fine_cfg
+    from esr_nerf_amd.synthetic import init_slab_model
+    from esr_nerf_amd.voxurff import VoxurfF
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    m = VoxurfF(fine_cfg("cuda:0"), scene.near, scene.far, scene.xyz_min, scene.xyz_max, scene.xyz_min,
+                scene.xyz_max, scene.mask_alpha_init, scene.mask_density, scene.s_val, scene.num_voxels)
+    init_slab_model(m, scene, seed=grid_seed)
+    m.train()
+    return m
+
+
+def oracle_for(model, scene):
+    from esr_nerf_amd.config import fine_cfg
+    from oracle import fine_path as fp
+    cfg = fine_cfg("cpu")
+    c = fp.make_consts(cfg.app.model, scene.xyz_min, scene.xyz_max, scene.xyz_min, scene.xyz_max,
+                       scene.mask_alpha_init, scene.mask_density, scene.near, scene.num_voxels)
+    P = fp.params_from_state_dict({k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()})
+    return fp, c, P
+
+
+def gpu_batch(scene):
+    return {k: v.cuda() for k, v in scene.batch.items()}
+
+
+def run_gpu(model, scene, s_val, loss="torch"):
+    from oracle import fine_path as fp
+    b = gpu_batch(scene)
+    model.zero_grad(set_to_none=True)
+    res = model(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=b["em_modes"], s_val=s_val)
+    out = {k: v.detach().clone() for k, v in res.items()}
+    l, _ = fp.fine_loss(res, b["rgbs"])          # torch autograd on the device: the trainer's loss lines
+    l.backward()
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    return out, float(l), grads
+
+
+def run_oracle(fp, c, P, scene, s_val):
+    keep = {}
+    res = fp.forward_training(P, c, scene.batch, s_val, keep=keep)
+    l, _ = fp.fine_loss(res, scene.batch["rgbs"])
+    l.backward()
+    grads = {k: v.grad for k, v in P.items() if v.grad is not None}
+    return {k: v.detach() for k, v in res.items()}, float(l), grads, keep
+
+
+def compare(out, loss, grads, o_out, o_loss, o_grads, tol=TOL):
+    for k in o_out:
+        assert rel_err(out[k], o_out[k]) < tol, (k, rel_err(out[k], o_out[k]))
+    assert abs(loss - o_loss) < tol * max(1.0, abs(o_loss))
+    bad = {}
+    for k, g in o_grads.items():
+        e = rel_err(grads[k], g)
+        if not e < tol:
+            bad[k] = e
+    assert not bad, bad
+    assert set(grads) == set(o_grads)
+
+
+# --------------------------------------------------------------------------- MLP engine alone
+def _in_colmap(kind, row):
+    if kind == 1:
+        return row if row < 33 else -1
+    if row < 6: return row
+    if row == 6: return 48
+    if row < 31: return 49 + row - 7
+    if row < 43: return 73 + row - 31
+    if row < 46: return 6 + row - 43
+    if row < 61: return 9 + row - 46
+    if row < 76: return 24 + row - 61
+    if row < 85: return 39 + row - 76
+    return -1
+
+
+@pytest.mark.parametrize("kind,tiles", [(0, 1), (0, 37), (1, 5), (1, 64)])
+def test_mlp_engine_fwd_dgrad_wgrad_vs_torch(kind, tiles):
+    """Random tile-major inputs; reference = plain fp32 torch Linear/ReLU chain + autograd on CPU."""
+    from esr_nerf_amd import _lib
+    from esr_nerf_amd.fine_engine import FineEngine
+    eng = FineEngine("cuda:0")
+    L = eng.L
+    g = torch.Generator().manual_seed(kind * 100 + tiles)
+    in_dim, xrows, nl = (85, 96, 4) if kind == 0 else (33, 48, 2)
+    dims = [in_dim] + [192] * (nl - 1) + [3]
+    Ws = [(torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5).requires_grad_() for i in range(nl)]
+    Bs = [(torch.randn(dims[i + 1], generator=g) * 0.1).requires_grad_() for i in range(nl)]
+    X = torch.randn(tiles, xrows, 32, generator=g)
+    rows = [r for r in range(xrows) if _in_colmap(kind, r) >= 0]
+    cols = [_in_colmap(kind, r) for r in rows]
+    x_ref = torch.zeros(tiles * 32, in_dim)
+    x_ref[:, cols] = X[:, rows, :].permute(0, 2, 1).reshape(tiles * 32, len(rows))
+    x_ref.requires_grad_()
+    h, hs = x_ref, []
+    for i in range(nl):
+        h = torch.nn.functional.linear(h, Ws[i], Bs[i])
+        if i + 1 < nl:
+            h = torch.relu(h)
+            hs.append(h)
+    dz = torch.randn(tiles * 32, 3, generator=g)
+    h.backward(dz)
+
+    def tm(t, rows_):        # [tiles*32, rows] -> tile-major [tiles, rows, 32]
+        return t.reshape(tiles, 32, rows_).permute(0, 2, 1).contiguous()
+
+    which = "off" if kind == 0 else "tone"
+    eng.pack(which, kind, [w.detach().cuda().contiguous() for w in Ws], [b.detach().cuda().contiguous() for b in Bs])
+    Xd = X.cuda().contiguous()
+    Hd = [torch.zeros(tiles, 192, 32, device="cuda") for _ in range(nl - 1)]
+    zout = torch.full((tiles, 4, 32), 7.0, device="cuda")
+    s = _lib.stream_ptr("cuda:0")
+    _lib.check(L.esr_mlp_fwd(kind, _lib.ptr(eng.packed[which]), _lib.ptr(Xd), 0, tiles, _lib.ptr_array(Hd), 1, 0,
+                             _lib.ptr(zout), s), "fwd")
+    assert rel_err(zout[:, :3], tm(h.detach(), 3)) < 1e-5
+    assert float(zout[:, 3].abs().max()) == 0.0
+    for a, b in zip(Hd, hs):
+        assert rel_err(a, tm(b.detach(), 192)) < 1e-5
+    # dgrad
+    dzd = torch.zeros(tiles, 4, 32, device="cuda")
+    dzd[:, :3] = tm(dz, 3).cuda()
+    dZd = [torch.zeros(tiles, 192, 32, device="cuda") for _ in range(nl - 1)]
+    dXd = torch.zeros(tiles, 64, 32, device="cuda")
+    _lib.check(L.esr_mlp_dgrad(kind, _lib.ptr(eng.packed[which]), _lib.ptr(dzd), 0, tiles, _lib.ptr_array(Hd),
+                               _lib.ptr_array(dZd), _lib.ptr(dXd), s), "dgrad")
+    dx_ref = tm(x_ref.grad, in_dim)
+    rows64 = [r for r in rows if r < 64]
+    assert rel_err(dXd[:, rows64].cpu(), dx_ref[:, [_in_colmap(kind, r) for r in rows64]]) < 1e-5
+    # wgrad
+    gw = [torch.zeros_like(w).cuda() for w in Ws]
+    gb = [torch.zeros_like(b).cuda() for b in Bs]
+    _lib.check(L.esr_mlp_wgrad(kind, _lib.ptr(Xd), 0, _lib.ptr_array(Hd), _lib.ptr_array(dZd), _lib.ptr(dzd), 0,
+                               tiles, _lib.ptr_array(gw), _lib.ptr_array(gb), s), "wgrad")
+    for i in range(nl):
+        assert rel_err(gw[i], Ws[i].grad) < 2e-5, ("gw", i, rel_err(gw[i], Ws[i].grad))
+        assert rel_err(gb[i], Bs[i].grad) < 2e-5, ("gb", i)
+
+
+def test_loss_kernel_matches_trainer_loss():
+    from esr_nerf_amd.fine_engine import FineEngine
+    from oracle import fine_path as fp
+    eng = FineEngine("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    n = 777
+    res = {"etc/alphainv_cum": torch.rand(n, generator=g).requires_grad_(),
+           "srgb/rgb": (torch.rand(n, 3, generator=g) * 1.3 - 0.1).requires_grad_(),
+           "lin/rgb": (torch.rand(n, 3, generator=g) * 1.6 - 0.2).requires_grad_()}
+    res["etc/white_bg"] = res["etc/alphainv_cum"][..., None]
+    rgbs = torch.rand(n, 3, generator=g)
+    rgbs[::7] = 1.0
+    l, _ = fp.fine_loss(res, rgbs)
+    l.backward()
+    loss, g_last, g_srgb, g_lin = eng.loss_fwd_bwd(res["etc/alphainv_cum"].detach().cuda(),
+                                                   res["srgb/rgb"].detach().cuda().contiguous(),
+                                                   res["lin/rgb"].detach().cuda().contiguous(), rgbs.cuda())
+    assert abs(float(loss) - float(l)) < 1e-6
+    assert rel_err(g_srgb, res["srgb/rgb"].grad) < 1e-5
+    assert rel_err(g_lin, res["lin/rgb"].grad) < 1e-5
+    assert rel_err(g_last, res["etc/alphainv_cum"].grad) < 1e-5
+
+
+# --------------------------------------------------------------------------- end to end
+def test_golden_reference_vectors(golden_case, golden_params):
+    """Fixtures generated by the IMPORTED reference: outputs, loss and all 23 gradients."""
+    from esr_nerf_amd.synthetic import slab_scene
+    name, z = golden_case
+    sd, _ = golden_params
+    sc = slab_scene("g16", oblique=name.endswith("oblique"), s_val=float(z["in/s_val"]))
+    for k in ("rays_o", "rays_d", "viewdirs", "em_modes", "rgbs"):
+        assert torch.equal(sc.batch[k], z["in/" + k]), k            # the generator is deterministic
+    m = build_gpu_model(sc)
+    m.load_state_dict({k: v.cuda() for k, v in sd.items()})
+    assert m.off_color.grid.is_contiguous(memory_format=torch.channels_last_3d)
+    out, loss, grads = run_gpu(m, sc, float(z["in/s_val"]))
+    for k in out:
+        assert rel_err(out[k], z["out/" + k]) < TOL, (k, rel_err(out[k], z["out/" + k]))
+    assert abs(loss - float(z["loss"])) < 1e-5
+    bad = {k[5:]: rel_err(grads[k[5:]], v) for k, v in z.items()
+           if k.startswith("grad/") and not rel_err(grads[k[5:]], v) < TOL}
+    assert not bad, bad
+    # discrete: survivors after the in-box test and before compositing
+    assert m.last_counts["m0"] == int((~z["native/sample/mask_outbbox"]).sum())
+    assert m.last_counts["m2"] == z["native/a2w/alpha"].numel()
+
+
+@pytest.mark.parametrize("name,oblique,s_val,n_rays", [
+    ("tiny", False, 20.0, None), ("tiny", True, 90.0, 200), ("small", False, 220.0, None),
+    ("small", True, 45.0, 300), ("tiny", True, 400.0, 1),
+])
+def test_fused_path_vs_oracle(name, oblique, s_val, n_rays):
+    from esr_nerf_amd.synthetic import slab_scene
+    sc = slab_scene(name, s_val=s_val, oblique=oblique, n_rays=n_rays, seed=3)
+    m = build_gpu_model(sc, seed=1, grid_seed=2)
+    fp, c, P = oracle_for(m, sc)
+    out, loss, grads = run_gpu(m, sc, s_val)
+    o_out, o_loss, o_grads, keep = run_oracle(fp, c, P, sc, s_val)
+    n0, n1, n2, n3 = keep["counts"]
+    lc = m.last_counts
+    assert (lc["m0"], lc["m1"], lc["m2"], lc["m3"]) == (n0, n1, n2, n3)
+    compare(out, loss, grads, o_out, o_loss, o_grads)
+
+
+def test_all_rays_miss_or_empty():
+    """Degenerate batches: rays that never enter the box -> zero colour, alphainv_last = 1, zero grads."""
+    from esr_nerf_amd.synthetic import slab_scene
+    sc = slab_scene("tiny", n_rays=16)
+    sc.batch["rays_o"] = sc.batch["rays_o"] + torch.tensor([10.0, 0.0, 0.0])
+    m = build_gpu_model(sc)
+    out, loss, grads = run_gpu(m, sc, 20.0)
+    assert torch.equal(out["etc/alphainv_cum"].cpu(), torch.ones(16))
+    assert float(out["srgb/rgb"].abs().max()) == 0.0 and m.last_counts["m3"] == 0
+    assert float(grads["sdf.grid"].abs().max()) == 0.0
+
+
+def test_fused_loss_path_equals_autograd_path():
+    """bench.py drives engine.loss_fwd_bwd + engine.backward directly; same numbers as autograd."""
+    from esr_nerf_amd.synthetic import slab_scene
+    from esr_nerf_amd.trainer import FineStep
+    sc = slab_scene("small", s_val=60.0, oblique=True, n_rays=256)
+    m = build_gpu_model(sc)
+    out, loss, grads = run_gpu(m, sc, 60.0)
+    step = FineStep(m)
+    b = gpu_batch(sc)
+    loss2, grads2 = step.forward_loss_backward(b, 60.0)
+    assert abs(float(loss2) - loss) < 1e-6
+    for k, g in grads.items():
+        assert rel_err(grads2[k], g) < 1e-5, k
+
+
+def test_c2_full_size_properties():
+    """BASELINE config C2 (4096 rays x 128 samples): size-independent properties.
+    (a) the slab gives exactly 128 samples per ray and, at s_val=20, all survive;
+    (b) rays are independent: a 48-ray subset evaluated ALONE by the CPU oracle matches the
+        same rays inside the full GPU batch;
+    (c) two runs agree (float atomics only reorder last bits)."""
+    from esr_nerf_amd.synthetic import slab_scene
+    sc = slab_scene("C2", s_val=20.0)
+    m = build_gpu_model(sc)
+    out, loss, grads = run_gpu(m, sc, 20.0)
+    lc = m.last_counts
+    assert lc["m0"] == lc["m1"] == lc["m2"] == lc["m3"] == 4096 * 128
+    out2, loss2, grads2 = run_gpu(m, sc, 20.0)
+    assert rel_err(out2["srgb/rgb"], out["srgb/rgb"]) < 1e-6 and abs(loss - loss2) < 1e-6
+    assert rel_err(grads2["sdf.grid"], grads["sdf.grid"]) < 1e-5
+    idx = torch.arange(0, 4096, 4096 // 48)[:48]
+    sub = slab_scene("C2", s_val=20.0)
+    sub.batch = {k: v[idx].contiguous() for k, v in sc.batch.items()}
+    fp, c, P = oracle_for(m, sub)
+    with torch.no_grad():
+        res = fp.forward_training(P, c, sub.batch, 20.0)
+    for k in ("etc/alphainv_cum", "srgb/rgb", "lin/rgb"):
+        assert rel_err(out[k][idx.cuda()], res[k]) < TOL, k

@@ -1,0 +1,142 @@
+"""HIP drop-ins of the reference's native ops vs the C oracle -- through the
+C ABI (esr_nerf_amd.render_utils -> libesr_hip.so).  Integer / index outputs and
+the sampler's float outputs must be BIT-EXACT; float compositing outputs are
+bit-exact too because the kernels keep the reference's serial order."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ru():
+    from esr_nerf_amd import render_utils
+    return render_utils
+
+
+@pytest.fixture(scope="module")
+def native():
+    from oracle import native
+    return native
+
+
+def _rays(n, seed):
+    g = np.random.default_rng(seed)
+    o = g.uniform(-2.5, 2.5, (n, 3)).astype(np.float32)
+    d = g.normal(size=(n, 3)).astype(np.float32) * g.uniform(0.2, 3, (n, 1)).astype(np.float32)
+    if n > 4:
+        d[::5, g.integers(0, 3)] = 0.0
+    return torch.from_numpy(o), torch.from_numpy(d)
+
+
+@pytest.mark.parametrize("n,seed", [(1, 0), (7, 1), (300, 2), (4096, 3), (20000, 4)])
+def test_sampler_bit_exact(ru, native, n, seed):
+    o, d = _rays(n, seed)
+    bmin = torch.tensor([-1, -0.8, -0.5])
+    bmax = torch.tensor([1, 0.9, 0.25])
+    near, far, sd = 0.05, 1e9, 0.0123 if n < 10000 else 0.03
+    ref = native.sample_pts_on_rays(o, d, bmin, bmax, near, far, sd)
+    got = ru.sample_pts_on_rays(o.cuda(), d.cuda(), bmin.cuda(), bmax.cuda(), near, far, sd)
+    for nm, r, g in zip(["pts", "mask", "ray_id", "step_id", "n_steps", "t_min", "t_max"], ref, got):
+        assert r.dtype == g.dtype, nm
+        assert torch.equal(r, g.cpu()), nm
+
+
+def test_sampler_slab_c2_exactly_128(ru):
+    """the C2 slab gives every ray exactly 128 in-box samples."""
+    from esr_nerf_amd.synthetic import slab_scene
+    sc = slab_scene("C2")
+    b = sc.batch
+    out = ru.sample_pts_on_rays(b["rays_o"].cuda(), b["rays_d"].cuda(), sc.xyz_min.cuda(),
+                                sc.xyz_max.cuda(), sc.near, 1e9, 0.5 * 2 / 256)
+    inb = ~out[1]
+    per_ray = torch.bincount(out[2][inb], minlength=4096)
+    assert int(per_ray.min()) == int(per_ray.max()) == 128
+
+
+def test_sampler_empty_and_errors(ru):
+    e = torch.zeros(0, 3, device="cuda")
+    b = torch.tensor([-1.0, -1, -1], device="cuda")
+    out = ru.sample_pts_on_rays(e, e, b, -b, 0.1, 1e9, 0.01)
+    assert out[0].shape == (0, 3) and out[4].numel() == 0
+    with pytest.raises(RuntimeError):
+        ru.sample_pts_on_rays(torch.zeros(3, 3), torch.zeros(3, 3), b, -b, 0.1, 1e9, 0.01)   # CPU tensor
+    with pytest.raises(RuntimeError):
+        ru.sample_pts_on_rays(torch.zeros(3, 6, device="cuda")[:, ::2], torch.zeros(3, 3, device="cuda"),
+                              b, -b, 0.1, 1e9, 0.01)                                          # non-contiguous
+
+
+@pytest.mark.parametrize("seed,n_rays,maxc", [(0, 40, 30), (1, 500, 200), (2, 4096, 128)])
+def test_alpha2weight_fwd_bwd_bit_exact(ru, native, seed, n_rays, maxc):
+    g = np.random.default_rng(seed)
+    counts = g.integers(0, maxc, n_rays)
+    counts[3] = 0
+    counts[-1] = 0
+    ray_id = torch.from_numpy(np.repeat(np.arange(n_rays), counts))
+    alpha = g.uniform(0, 1, len(ray_id)).astype(np.float32) ** 3
+    alpha[g.uniform(size=len(alpha)) < 0.05] = 0.9999
+    alpha = torch.from_numpy(alpha)
+    ref = native.alpha2weight(alpha, ray_id, n_rays)
+    got = ru.alpha2weight(alpha.cuda(), ray_id.cuda(), n_rays)
+    for nm, r, t in zip(["weight", "T", "last", "i_start", "i_end"], ref, got):
+        assert torch.equal(r, t.cpu()), nm
+    gw = torch.from_numpy(g.normal(size=len(alpha)).astype(np.float32))
+    gl = torch.from_numpy(g.normal(size=n_rays).astype(np.float32))
+    gref = native.alpha2weight_backward(alpha, *ref, n_rays, gw, gl)
+    ggot = ru.alpha2weight_backward(alpha.cuda(), *got, n_rays, gw.cuda(), gl.cuda())
+    assert torch.equal(gref, ggot.cpu())
+
+
+def test_alpha2weight_empty(ru):
+    out = ru.alpha2weight(torch.zeros(0, device="cuda"), torch.zeros(0, dtype=torch.int64, device="cuda"), 5)
+    assert out[0].numel() == 0 and torch.equal(out[2].cpu(), torch.ones(5))
+
+
+def test_golden_native_traffic(ru, golden_case):
+    """Vectors recorded from the imported reference run (tests/golden)."""
+    from esr_nerf_amd.synthetic import slab_scene
+    name, z = golden_case
+    sc = slab_scene("g16")
+    got = ru.sample_pts_on_rays(z["in/rays_o"].cuda(), z["in/rays_d"].cuda(), sc.xyz_min.cuda(),
+                                sc.xyz_max.cuda(), float(z["native/sample/near"]), 1e9,
+                                float(z["native/sample/stepdist"]))
+    for nm, t in zip(["ray_pts", "mask_outbbox", "ray_id", "step_id", "N_steps", "t_min", "t_max"], got):
+        assert torch.equal(t.cpu(), z["native/sample/" + nm]), nm
+    n = z["in/rays_o"].shape[0]
+    out = ru.alpha2weight(z["native/a2w/alpha"].cuda(), z["native/a2w/ray_id"].cuda(), n)
+    for nm, t in zip(["weight", "T", "alphainv_last", "i_start", "i_end"], out):
+        assert torch.equal(t.cpu(), z["native/a2w/" + nm]), nm
+    gr = ru.alpha2weight_backward(z["native/a2w/alpha"].cuda(), *out, n,
+                                  z["native/a2wb/grad_weights"].cuda(), z["native/a2wb/grad_last"].cuda())
+    assert torch.equal(gr.cpu(), z["native/a2wb/grad"])
+
+
+@pytest.mark.parametrize("dense", [True, False])
+@pytest.mark.parametrize("shape", [(1, 1, 7, 6, 5), (1, 1, 64, 48, 33), (1, 3, 16, 8, 9)])
+def test_tv_add_grad(ru, native, dense, shape):
+    g = torch.Generator().manual_seed(5)
+    param = torch.randn(shape, generator=g) * 1.5
+    grad = torch.randn(shape, generator=g)
+    grad[torch.rand(shape, generator=g) < 0.4] = 0
+    exp = grad.clone()
+    native.total_variation_add_grad(param, exp, 9.0, 0.3, 0.7, dense)
+    got = grad.clone().cuda()
+    ru.total_variation_add_grad(param.cuda(), got, 9.0, 0.3, 0.7, dense)
+    assert torch.allclose(got.cpu(), exp, rtol=1e-6, atol=1e-6)
+    if not dense:
+        assert torch.equal(got.cpu()[grad == 0], grad[grad == 0])
+
+
+@pytest.mark.parametrize("n,c", [(50, 3), (100000, 3), (777, 1)])
+def test_segment_sum(ru, native, n, c):
+    g = torch.Generator().manual_seed(n)
+    idx = torch.sort(torch.randint(0, max(2, n // 20), (n,), generator=g)).values
+    src = torch.randn(n, c, generator=g) if c > 1 else torch.randn(n, generator=g)
+    nseg = int(idx.max()) + 2
+    exp = torch.zeros((nseg, c) if c > 1 else (nseg,))
+    native.segment_sum(src, idx, exp)
+    got = ru.segment_coo(src.cuda(), idx.cuda(), out=torch.zeros_like(exp).cuda())
+    assert rel_err(got, exp) < 1e-5
