@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Benchmark of the fine-stage hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A *step* = one pass of the hot path over one batch of synthetic input: renderer
+forward (ray march, feature gather, radiance/tonemap MLPs, compositing), the
+trainer's loss, and the full backward -- BASELINE.json config C2 ("giftbox_w fine
+stage, 4096 rays x 128 samples, fp32") on the slab scene of SURVEY.md section 8(d),
+inputs resident in HBM before the timed region.  The optimizer step is outside
+the named path (reported separately, not here).  With N > 1 every rank
+runs the same step on its own 4096 rays (weak scaling) and the gradients are
+all-reduced over RCCL inside the timed region.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel, algorithmic FLOPs / HIP-event time vs the f32 MFMA peak
+  cpu_baseline  oracle/fine_path.py (the CPU port of the reference path) timed on
+                the host cores on a bounded ray sample of the same scene (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TF = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, Peak FP32 (matrix)
+RAD_MAC = 85 * 192 + 192 * 192 * 2 + 192 * 3          # RadianceNet MACs per sample (pbr/module.py:6-21)
+TONE_MAC = 33 * 192 + 192 * 3                          # TonemapNet MACs per sample
+DGRAD_RAD_MAC = 3 * 192 + 192 * 192 * 2 + 192 * 43     # dX needs only the 43 grid-fed columns
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="C2", choices=["C2", "C3", "small", "tiny"])
+    ap.add_argument("--s-val", type=float, default=20.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=1024)
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    return ap.parse_args()
+
+
+def algorithmic_flops(name, counts):
+    """Algorithmic FLOPs of one launch of a named MLP kernel (padding and the
+    detached-pass bookkeeping excluded): 2 * MACs * samples it processes."""
+    n_on, n_off = counts["n_on"], counts["n_off"]
+    table = {
+        "mlp_fwd(off|on-tiles)": 2 * RAD_MAC * n_on,
+        "mlp_fwd(off)": 2 * RAD_MAC * n_off,
+        "mlp_fwd(emo)": 2 * RAD_MAC * n_on,
+        "mlp_fwd(tone)": 2 * TONE_MAC * (n_on + n_off),
+        "mlp_dgrad(emo)": 2 * DGRAD_RAD_MAC * n_on,
+        "mlp_dgrad(off)": 2 * DGRAD_RAD_MAC * n_off,
+        "mlp_dgrad(tone)": 2 * (3 * 192 + 192 * 33) * (n_on + n_off),
+        "mlp_wgrad(emo)": 2 * RAD_MAC * n_on,
+        "mlp_wgrad(off)": 2 * RAD_MAC * n_off,
+        "mlp_wgrad(tone)": 2 * TONE_MAC * (n_on + n_off),
+    }
+    return table.get(name)
+
+
+def cpu_baseline(model, scene, s_val, n_rays, iters):
+    """The CPU port of the reference path (checker code) on a bounded sample."""
+    from esr_nerf_amd.config import fine_cfg
+    from oracle import fine_path as fp
+    cfg = fine_cfg("cpu")
+    c = fp.make_consts(cfg.app.model, scene.xyz_min, scene.xyz_max, scene.xyz_min, scene.xyz_max,
+                       scene.mask_alpha_init, scene.mask_density, scene.near, scene.num_voxels)
+    P = fp.params_from_state_dict({k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()})
+    batch = {k: v[:n_rays].contiguous() for k, v in scene.batch.items()}
+    times = []
+    for i in range(iters + 1):
+        for v in P.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        res = fp.forward_training(P, c, batch, s_val)
+        loss, _ = fp.fine_loss(res, batch["rgbs"])
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+    t = sum(times[1:]) / iters
+    return dict(value=n_rays / t, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n_rays} of the {scene.n_rays} rays of the same scene (full grid), fwd+loss+bwd, "
+                       f"{iters} iterations after 1 warm-up, {t:.2f} s/iter, torch {torch.__version__} CPU ops "
+                       f"+ oracle/esr_oracle.c")
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))     # nccl == RCCL on ROCm
+        pg = dist.group.WORLD
+
+    import numpy as np
+    from esr_nerf_amd.config import fine_cfg
+    from esr_nerf_amd.synthetic import CONFIGS, init_slab_model, slab_scene
+    from esr_nerf_amd.trainer import FineStep
+    from esr_nerf_amd.voxurff import VoxurfF
+
+    # identical parameters on every rank (seed 0), different rays per rank (weak scaling)
+    scene = slab_scene(a.config, s_val=a.s_val, seed=rank)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = VoxurfF(fine_cfg(dev), scene.near, scene.far, scene.xyz_min, scene.xyz_max, scene.xyz_min,
+                        scene.xyz_max, scene.mask_alpha_init, scene.mask_density, scene.s_val, scene.num_voxels)
+    init_slab_model(model, scene)
+    model.train()
+    step = FineStep(model, process_group=pg)
+    batch = {k: v.to(dev) for k, v in scene.batch.items()}
+    n_rays = scene.n_rays
+    eng = model.engine
+
+    def one():
+        return step.forward_loss_backward(batch, a.s_val)
+
+    for _ in range(a.warmup):
+        one()
+    torch.cuda.synchronize()
+    eng.enable_timing(True)                 # HIP events on the launch stream around every kernel
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss, _ = one()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern = eng.timing_summary()             # name -> (launches, total ms)
+    eng.enable_timing(False)
+    counts = dict(model.last_counts)
+
+    if rank == 0:
+        value = n_rays * world * a.steps / dt
+        c = CONFIGS[a.config]
+        samples = int(round(c["res"] * c["z"] * 2))
+        out = {
+            "metric": "training rays/sec at 4096 rays x 128 samples (fine stage)" if a.config == "C2"
+                      else f"training rays/sec, config {a.config}",
+            "value": value, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{a.config}: giftbox_w fine stage on the slab scene, {n_rays} rays x {samples} "
+                            f"samples per GPU, grid {'x'.join(str(int(v)) for v in model.world_size.tolist())}, "
+                            f"s_val={a.s_val:g}, forward + trainer loss + backward (no optimizer step)",
+                "rays_per_gpu": n_rays, "samples_per_ray": samples, "surviving_samples": counts.get("m3"),
+                "parallelism": f"dp{world}",
+            },
+            "loss": float(loss),
+        }
+        # dominant kernel by HIP-event time
+        total_ms = sum(ms for _, ms in kern.values()) or 1.0
+        mlp = {k: v for k, v in kern.items() if algorithmic_flops(k, counts)}
+        if mlp:
+            name = max(mlp, key=lambda k: mlp[k][1])
+            launches, ms = mlp[name]
+            avg_s = ms / launches * 1e-3
+            flops = algorithmic_flops(name, counts)
+            ach = flops / avg_s / 1e12
+            traffic = None
+            side = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(side):
+                with open(side) as f:
+                    traffic = json.load(f).get(name)
+            out["roofline"] = {
+                "bound": "mfma", "kernel": name, "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                "frac": ach / MFMA_F32_PEAK_TF, "traffic": traffic,
+                "avg_launch_ms": ms / launches, "algorithmic_gflop_per_launch": flops / 1e9,
+                "share_of_kernel_time": ms / total_ms,
+            }
+            # the whole MLP engine (all 10 launches per step) against the same roof
+            mf = sum(algorithmic_flops(k, counts) * v[0] for k, v in mlp.items())
+            mt = sum(v[1] for v in mlp.values()) * 1e-3
+            out["roofline"]["all_mlp_kernels"] = {"achieved": mf / mt / 1e12, "frac": mf / mt / 1e12 / MFMA_F32_PEAK_TF,
+                                                  "share_of_kernel_time": mt * 1e3 / total_ms}
+        out["kernel_ms_per_step"] = {k: round(v[1] / a.steps, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, scene, a.s_val, min(a.cpu_rays, n_rays), a.cpu_iters)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

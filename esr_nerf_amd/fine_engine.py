@@ -101,10 +101,39 @@ class FineEngine:
             k: torch.empty(self.L.esr_mlp_packed_floats(kind), dtype=torch.float32, device=self.device)
             for k, kind in (("off", KIND_RADIANCE), ("emo", KIND_RADIANCE), ("tone", KIND_TONEMAP))}
         self.ray_bufs: Dict[int, Dict[str, torch.Tensor]] = {}
+        self._timing = False
+        self._events = []
 
     # -- helpers ---------------------------------------------------------------
     def _s(self):
         return _lib.stream_ptr(self.device)
+
+    def _run(self, name, fn, *args):
+        """Enqueue one C-ABI call; with timing on, bracket it with HIP events recorded on the
+        stream the kernel is launched on (torch's current stream == the `stream` argument)."""
+        if self._timing:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            self._events.append((name, e0, e1))
+        else:
+            rc = fn(*args)
+        _lib.check(rc, name)
+
+    def enable_timing(self, on: bool):
+        self._timing = bool(on)
+        self._events = []
+
+    def timing_summary(self):
+        """name -> (launches, total milliseconds) over everything recorded since enable_timing(True)."""
+        torch.cuda.synchronize(self.device)
+        out = {}
+        for name, e0, e1 in self._events:
+            n, ms = out.get(name, (0, 0.0))
+            out[name] = (n + 1, ms + e0.elapsed_time(e1))
+        return out
 
     def _ray_buf(self, n):
         if n not in self.ray_bufs:
@@ -119,7 +148,7 @@ class FineEngine:
             if not (a.is_cuda and a.is_contiguous() and b.is_contiguous() and a.dtype == torch.float32):
                 raise RuntimeError("MLP parameters must be contiguous fp32 device tensors")
             w.w[i], w.b[i] = a.data_ptr(), b.data_ptr()
-        _lib.check(self.L.esr_mlp_pack(kind, C.byref(w), _lib.ptr(self.packed[which]), self._s()), "esr_mlp_pack")
+        self._run(f"mlp_pack({which})", self.L.esr_mlp_pack, kind, C.byref(w), _lib.ptr(self.packed[which]), self._s())
 
     def _H(self, names):
         return _lib.ptr_array([self.ws[n] for n in names])
@@ -140,12 +169,12 @@ class FineEngine:
         srgb = torch.zeros(n, 3, dtype=torch.float32, device=self.device)
         lin = torch.zeros(n, 3, dtype=torch.float32, device=self.device)
         sp = C.byref(scene)
-        _lib.check(L.esr_fine_plan_begin(_lib.ptr(self.plan_dev), s), "plan_begin")
-        _lib.check(L.esr_fine_march_count(sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(mask_density),
+        self._run("plan_begin", L.esr_fine_plan_begin, _lib.ptr(self.plan_dev), s)
+        self._run("march_count", L.esr_fine_march_count, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(mask_density),
                                           _lib.ptr(sdf), n, _lib.ptr(rb["cnt3"]), _lib.ptr(last),
-                                          _lib.ptr(self.plan_dev), s), "march_count")
-        _lib.check(L.esr_fine_plan(_lib.ptr(rb["cnt3"]), _lib.ptr(em_modes), n, _lib.ptr(rb["off3"]),
-                                   _lib.ptr(self.plan_dev), s), "plan")
+                                          _lib.ptr(self.plan_dev), s)
+        self._run("plan", L.esr_fine_plan, _lib.ptr(rb["cnt3"]), _lib.ptr(em_modes), n, _lib.ptr(rb["off3"]),
+                                   _lib.ptr(self.plan_dev), s)
         self.plan_host.copy_(self.plan_dev, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()        # the one sync of the step
         n_on, n_off, tiles_on, tiles_all, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
@@ -158,30 +187,30 @@ class FineEngine:
             return ctx, last, srgb, lin
         ws.ensure(tiles_all)
         ws["rec_ray"][: tiles_all * 32].fill_(-1)
-        _lib.check(L.esr_fine_march_fill(sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(mask_density),
+        self._run("march_fill", L.esr_fine_march_fill, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(mask_density),
                                          _lib.ptr(sdf), n, _lib.ptr(rb["off3"]), _lib.ptr(ws["rec_ray"]),
                                          _lib.ptr(ws["rec_step"]), _lib.ptr(ws["rec_w"]),
-                                         _lib.ptr(ws["rec_sdf"]), s), "march_fill")
-        _lib.check(L.esr_fine_feat_fwd(sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(viewdirs),
+                                         _lib.ptr(ws["rec_sdf"]), s)
+        self._run("feat_fwd", L.esr_fine_feat_fwd, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(viewdirs),
                                        _lib.ptr(sdf), _lib.ptr(off_color), _lib.ptr(emo_color),
                                        _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_step"]),
                                        _lib.ptr(ws["rec_sdf"]), tiles_on, tiles_all, _lib.ptr(ws["X"]),
-                                       _lib.ptr(ws["gnorm"]), s), "feat_fwd")
+                                       _lib.ptr(ws["gnorm"]), s)
         H = self._H(["H0", "H1", "H2"])
         # off net: detached pass on the on-tiles (alt colour rows, nothing saved), saved pass on the off-tiles
-        _lib.check(L.esr_mlp_fwd(KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), 0, tiles_on,
-                                 H, 0, 1, _lib.ptr(ws["z_off"]), s), "mlp_fwd(off|on-tiles)")
-        _lib.check(L.esr_mlp_fwd(KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), tiles_on,
-                                 tiles_all, H, 1, 0, _lib.ptr(ws["z_off"]), s), "mlp_fwd(off)")
-        _lib.check(L.esr_mlp_fwd(KIND_RADIANCE, _lib.ptr(self.packed["emo"]), _lib.ptr(ws["X"]), 0, tiles_on,
-                                 H, 1, 0, _lib.ptr(ws["z_emo"]), s), "mlp_fwd(emo)")
-        _lib.check(L.esr_fine_tone_in_fwd(_lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), tiles_on, tiles_all,
-                                          _lib.ptr(ws["lin"]), _lib.ptr(ws["Xt"]), s), "tone_in_fwd")
-        _lib.check(L.esr_mlp_fwd(KIND_TONEMAP, _lib.ptr(self.packed["tone"]), _lib.ptr(ws["Xt"]), 0, tiles_all,
-                                 self._H(["Ht"]), 1, 0, _lib.ptr(ws["zt"]), s), "mlp_fwd(tone)")
-        _lib.check(L.esr_fine_composite_fwd(_lib.ptr(ws["zt"]), _lib.ptr(ws["lin"]), _lib.ptr(ws["rec_ray"]),
+        self._run("mlp_fwd(off|on-tiles)", L.esr_mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), 0, tiles_on,
+                                 H, 0, 1, _lib.ptr(ws["z_off"]), s)
+        self._run("mlp_fwd(off)", L.esr_mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), tiles_on,
+                                 tiles_all, H, 1, 0, _lib.ptr(ws["z_off"]), s)
+        self._run("mlp_fwd(emo)", L.esr_mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["emo"]), _lib.ptr(ws["X"]), 0, tiles_on,
+                                 H, 1, 0, _lib.ptr(ws["z_emo"]), s)
+        self._run("tone_in_fwd", L.esr_fine_tone_in_fwd, _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), tiles_on, tiles_all,
+                                          _lib.ptr(ws["lin"]), _lib.ptr(ws["Xt"]), s)
+        self._run("mlp_fwd(tone)", L.esr_mlp_fwd, KIND_TONEMAP, _lib.ptr(self.packed["tone"]), _lib.ptr(ws["Xt"]), 0, tiles_all,
+                                 self._H(["Ht"]), 1, 0, _lib.ptr(ws["zt"]), s)
+        self._run("composite_fwd", L.esr_fine_composite_fwd, _lib.ptr(ws["zt"]), _lib.ptr(ws["lin"]), _lib.ptr(ws["rec_ray"]),
                                             _lib.ptr(ws["rec_w"]), tiles_all, _lib.ptr(ws["rgb"]),
-                                            _lib.ptr(srgb), _lib.ptr(lin), s), "composite_fwd")
+                                            _lib.ptr(srgb), _lib.ptr(lin), s)
         return ctx, last, srgb, lin
 
     # -- backward ----------------------------------------------------------------
@@ -194,43 +223,40 @@ class FineEngine:
         to, ta = ctx.tiles_on, ctx.tiles_all
         g_last, g_srgb, g_lin = g_last.contiguous(), g_srgb.contiguous(), g_lin.contiguous()
         if ta > 0:
-            _lib.check(L.esr_fine_composite_bwd(_lib.ptr(g_srgb), _lib.ptr(g_lin), _lib.ptr(ws["rgb"]),
+            self._run("composite_bwd", L.esr_fine_composite_bwd, _lib.ptr(g_srgb), _lib.ptr(g_lin), _lib.ptr(ws["rgb"]),
                                                 _lib.ptr(ws["lin"]), _lib.ptr(ws["rec_ray"]),
                                                 _lib.ptr(ws["rec_w"]), ta, _lib.ptr(ws["dweight"]),
-                                                _lib.ptr(ws["dzt"]), s), "composite_bwd")
-            _lib.check(L.esr_mlp_dgrad(KIND_TONEMAP, _lib.ptr(self.packed["tone"]), _lib.ptr(ws["dzt"]), 0, ta,
-                                       self._H(["Ht"]), self._H(["dZt"]), _lib.ptr(ws["dXt"]), s),
-                       "mlp_dgrad(tone)")
-            _lib.check(L.esr_fine_tone_in_bwd(_lib.ptr(ws["dXt"]), _lib.ptr(g_lin), _lib.ptr(ws["lin"]),
+                                                _lib.ptr(ws["dzt"]), s)
+            self._run("mlp_dgrad(tone)", L.esr_mlp_dgrad, KIND_TONEMAP, _lib.ptr(self.packed["tone"]), _lib.ptr(ws["dzt"]), 0, ta,
+                                       self._H(["Ht"]), self._H(["dZt"]), _lib.ptr(ws["dXt"]), s)
+            self._run("tone_in_bwd", L.esr_fine_tone_in_bwd, _lib.ptr(ws["dXt"]), _lib.ptr(g_lin), _lib.ptr(ws["lin"]),
                                               _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]),
                                               _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), to, ta,
-                                              _lib.ptr(ws["dz"]), s), "tone_in_bwd")
+                                              _lib.ptr(ws["dz"]), s)
             H, dZ = self._H(["H0", "H1", "H2"]), self._H(["dZ0", "dZ1", "dZ2"])
-            _lib.check(L.esr_mlp_dgrad(KIND_RADIANCE, _lib.ptr(self.packed["emo"]), _lib.ptr(ws["dz"]), 0, to,
-                                       H, dZ, _lib.ptr(ws["dX"]), s), "mlp_dgrad(emo)")
-            _lib.check(L.esr_mlp_dgrad(KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["dz"]), to, ta,
-                                       H, dZ, _lib.ptr(ws["dX"]), s), "mlp_dgrad(off)")
-            _lib.check(L.esr_mlp_wgrad(KIND_TONEMAP, _lib.ptr(ws["Xt"]), 0, self._H(["Ht"]), self._H(["dZt"]),
+            self._run("mlp_dgrad(emo)", L.esr_mlp_dgrad, KIND_RADIANCE, _lib.ptr(self.packed["emo"]), _lib.ptr(ws["dz"]), 0, to,
+                                       H, dZ, _lib.ptr(ws["dX"]), s)
+            self._run("mlp_dgrad(off)", L.esr_mlp_dgrad, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["dz"]), to, ta,
+                                       H, dZ, _lib.ptr(ws["dX"]), s)
+            self._run("mlp_wgrad(tone)", L.esr_mlp_wgrad, KIND_TONEMAP, _lib.ptr(ws["Xt"]), 0, self._H(["Ht"]), self._H(["dZt"]),
                                        _lib.ptr(ws["dzt"]), 0, ta, _lib.ptr_array(grads["tone_w"]),
-                                       _lib.ptr_array(grads["tone_b"]), s), "mlp_wgrad(tone)")
-            _lib.check(L.esr_mlp_wgrad(KIND_RADIANCE, _lib.ptr(ws["X"]), 0, H, dZ, _lib.ptr(ws["dz"]), 0, to,
-                                       _lib.ptr_array(grads["emo_w"]), _lib.ptr_array(grads["emo_b"]), s),
-                       "mlp_wgrad(emo)")
-            _lib.check(L.esr_mlp_wgrad(KIND_RADIANCE, _lib.ptr(ws["X"]), 0, H, dZ, _lib.ptr(ws["dz"]), to, ta,
-                                       _lib.ptr_array(grads["off_w"]), _lib.ptr_array(grads["off_b"]), s),
-                       "mlp_wgrad(off)")
-            _lib.check(L.esr_fine_feat_bwd(sp, _lib.ptr(ctx.rays_o), _lib.ptr(ctx.rays_d),
+                                       _lib.ptr_array(grads["tone_b"]), s)
+            self._run("mlp_wgrad(emo)", L.esr_mlp_wgrad, KIND_RADIANCE, _lib.ptr(ws["X"]), 0, H, dZ, _lib.ptr(ws["dz"]), 0, to,
+                                       _lib.ptr_array(grads["emo_w"]), _lib.ptr_array(grads["emo_b"]), s)
+            self._run("mlp_wgrad(off)", L.esr_mlp_wgrad, KIND_RADIANCE, _lib.ptr(ws["X"]), 0, H, dZ, _lib.ptr(ws["dz"]), to, ta,
+                                       _lib.ptr_array(grads["off_w"]), _lib.ptr_array(grads["off_b"]), s)
+            self._run("feat_bwd", L.esr_fine_feat_bwd, sp, _lib.ptr(ctx.rays_o), _lib.ptr(ctx.rays_d),
                                            _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_step"]), _lib.ptr(ws["X"]),
                                            _lib.ptr(ws["gnorm"]), _lib.ptr(ws["dX"]), to, ta,
                                            _lib.ptr(grads["sdf"]), _lib.ptr(grads["off_color"]),
-                                           _lib.ptr(grads["emo_color"]), s), "feat_bwd")
+                                           _lib.ptr(grads["emo_color"]), s)
             dweight = ws["dweight"]
         else:
             dweight = torch.zeros(32, dtype=torch.float32, device=self.device)
-        _lib.check(L.esr_fine_march_bwd(sp, _lib.ptr(ctx.rays_o), _lib.ptr(ctx.rays_d),
+        self._run("march_bwd", L.esr_fine_march_bwd, sp, _lib.ptr(ctx.rays_o), _lib.ptr(ctx.rays_d),
                                         _lib.ptr(ctx.mask_density), _lib.ptr(ctx.sdf), ctx.n_rays,
                                         _lib.ptr(ctx.off3), _lib.ptr(dweight), _lib.ptr(g_last),
-                                        _lib.ptr(grads["sdf"]), s), "march_bwd")
+                                        _lib.ptr(grads["sdf"]), s)
 
     # -- fused trainer-step loss (app/fine/fine.py:355-382) ------------------------
     def loss_fwd_bwd(self, last, srgb, lin, rgbs, white_bg=True, weight_linear=0.1, weight_entropy_last=0.001):
@@ -239,8 +265,8 @@ class FineEngine:
         g_srgb = torch.empty_like(srgb)
         g_lin = torch.empty_like(lin)
         g_last = torch.empty_like(last)
-        _lib.check(self.L.esr_fine_loss_fwd_bwd(
-            _lib.ptr(srgb), _lib.ptr(lin), _lib.ptr(last), _lib.ptr(rgbs.contiguous()), n,
-            C.c_float(1.0 if white_bg else 0.0), C.c_float(weight_linear), C.c_float(weight_entropy_last),
-            _lib.ptr(loss), _lib.ptr(g_srgb), _lib.ptr(g_lin), _lib.ptr(g_last), self._s()), "loss")
+        self._run("loss", self.L.esr_fine_loss_fwd_bwd,
+                  _lib.ptr(srgb), _lib.ptr(lin), _lib.ptr(last), _lib.ptr(rgbs.contiguous()), n,
+                  C.c_float(1.0 if white_bg else 0.0), C.c_float(weight_linear), C.c_float(weight_entropy_last),
+                  _lib.ptr(loss), _lib.ptr(g_srgb), _lib.ptr(g_lin), _lib.ptr(g_last), self._s())
         return loss, g_last, g_srgb, g_lin
