@@ -34,6 +34,16 @@ def shard_batch(batch: Dict[str, torch.Tensor], rank: int, world: int) -> Dict[s
     return {k: v[lo:hi].contiguous() for k, v in batch.items()}
 
 
+def dp_loss_weights(n_local: int, global_rays, entropy_owner: bool, weight_entropy_last: float):
+    """(scale, w_ent) for one rank's shard.  The two MSE terms are means over the batch, so a
+    shard's mean-normalised loss/gradients are multiplied by ``scale = n_local / n_global``; the
+    entropy term (last ray only, fine.py:378) is not a mean: it is added by the owning rank only
+    and pre-divided by ``scale`` so that the common rescale leaves it at ``weight_entropy_last``."""
+    scale = 1.0 if global_rays is None else n_local / float(global_rays)
+    w_ent = (weight_entropy_last / scale) if entropy_owner else 0.0
+    return scale, w_ent
+
+
 class FineStep:
     def __init__(self, model, white_bg: bool = True, weight_linear: float = 0.1,
                  weight_entropy_last: float = 0.001, process_group=None):
@@ -96,11 +106,7 @@ class FineStep:
             m.mask_cache.density.view(*m.mask_cache.density.shape[2:]),
             m.sdf.device_view(), m.off_color.device_view(), m.emo_color.device_view())
         m.last_counts = ctx.counts
-        n_local = last.shape[0]
-        scale = 1.0 if global_rays is None else n_local / float(global_rays)
-        # the MSE terms are means over the GLOBAL batch (rescaled below); the entropy term is not a
-        # mean, so it is pre-divided by the same factor on the one rank that owns it
-        w_ent = (self.weight_entropy_last / scale) if entropy_owner else 0.0
+        scale, w_ent = dp_loss_weights(last.shape[0], global_rays, entropy_owner, self.weight_entropy_last)
         loss, g_last, g_srgb, g_lin = eng.loss_fwd_bwd(last, srgb, lin, batch["rgbs"], self.white_bg,
                                                        self.weight_linear, w_ent)
         if scale != 1.0:
