@@ -213,6 +213,11 @@ struct Window {
     int ch;                               // channels per cell
 };
 
+// Ordering of one wave's own LDS accesses: the hardware executes a wave's DS instructions in
+// order, so waiting for lgkmcnt (and stopping compiler motion) is enough.  __threadfence_block()
+// would also wait vmcnt(0), i.e. drain the global atomics of the previous flush (~us each).
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ int wave_min_i(int v)
 {
 #pragma unroll
@@ -329,7 +334,7 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
         // ---- phase 1: SDF grid (value tap + 24 stencil taps, split between the two lanes of a sample)
         window_setup(w, i0, valid, gdims, 2, 3, 1);
         window_zero(w, lane);
-        __threadfence_block();
+        lds_fence();
         if (valid) {
             if (h == 0) tri_scatter_win(w, P.grad_sdf, gdims, ind, dXt[ROW_SDF * 32]);
 #pragma unroll 1
@@ -362,14 +367,14 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
                 }
             }
         }
-        __threadfence_block();
+        lds_fence();
         window_flush(w, P.grad_sdf, gdims, lane);
-        __threadfence_block();
+        lds_fence();
         // ---- phase 2: colour grid of this tile's net (3 channels per lane half)
         float *gcol = on_tile ? P.grad_emo : P.grad_off;
         window_setup(w, i0, valid, gdims, 0, 1, 6);
         window_zero(w, lane);
-        __threadfence_block();
+        lds_fence();
         if (valid) {
             float d3[3];
 #pragma unroll
@@ -390,9 +395,9 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
                         }
                     }
         }
-        __threadfence_block();
+        lds_fence();
         window_flush(w, gcol, gdims, lane);
-        __threadfence_block();
+        lds_fence();
     }
 }
 

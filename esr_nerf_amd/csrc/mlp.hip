@@ -404,45 +404,97 @@ struct WgradArgs {
     float *gw; int ld; int out_rows;
     int kind; int first;         // column map: first layer uses in_colmap(kind, row)
     float *gb;
-    int blocks_n;                // column blocks
 };
 
-template <int MI, int NJ>
-__global__ void __launch_bounds__(256, 2) mlp_wgrad_kernel(WgradArgs W)
+// Cooperative weight-gradient kernel.  One workgroup covers the WHOLE dW of a layer:
+// wave (wm, wn, wk) owns the MI x NJ block of 32x32 output tiles at (wm, wn) and the
+// wk-th share of each tile's 32 samples.  Per sample tile the workgroup stages A (dZ)
+// and B (H / X) ONCE from HBM with fully coalesced 16-B loads into LDS (row stride 36
+// floats: the 16 lanes of a ds_read_b128 group then hit 16 distinct 4-bank groups), and
+// every wave reads its MFMA operands from LDS.  Global loads of tile t+1 are in flight
+// while tile t is multiplied (register-staged, write-after-compute, one barrier per
+// tile).  The predecessor of this kernel let every wave fetch its operand rows straight
+// from global memory with a 128-B lane stride: 2x redundant traffic and 64 cache lines
+// per load instruction -- 49 TF.  Accumulators (up to 144 registers) live across the
+// whole tile range and are flushed once with 128-B-contiguous float atomics.
+constexpr int LDS_STRIDE = 36;        // floats per staged row (32 samples + 4 pad)
+
+template <int MI, int NJ, int WM, int WN, int WK>
+__global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradArgs W)
 {
-    const int lane = esr_lane();
-    const int h = lane >> 5, rl = lane & 31;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const int nblk = ((W.RA + 32 * MI - 1) / (32 * MI)) * W.blocks_n;
-    const int blk = wave % nblk, split = wave / nblk, nsplit = nwaves / nblk;
-    if (split >= nsplit) return;
-    const int bm = blk / W.blocks_n, bn = blk % W.blocks_n;
+    constexpr int NW = WM * WN * WK, NT = 64 * NW;
+    constexpr int RAP = WM * MI * 32, RBP = WN * NJ * 32;          // staged rows (padded to tiles)
+    constexpr int BUF = (RAP + RBP) * LDS_STRIDE;                  // floats per LDS buffer
+    constexpr int LA = (RAP * 8 + NT - 1) / NT, LB = (RBP * 8 + NT - 1) / NT;   // float4 loads per thread
+    constexpr int NU = 4 / WK;                                     // 8-sample groups per wave per tile
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, rl = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = w % WK, wn = (w / WK) % WN, wm = w / (WK * WN);
+    const int nsplit = gridDim.x, split = blockIdx.x;
+
+    // rows of a short A (the 4-row dz of an output layer) never get staged: zero both buffers once
+    for (int i = tid; i < 2 * BUF; i += NT) lds[i] = 0.f;
+    __syncthreads();
+
     f32x16 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i) zero_tiles<NJ>(acc[i]);
     float bsum[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) bsum[i] = 0.f;
-    int rowA[MI], rowB[NJ];
+
+    float4 ga[LA], gb[LB];
+    auto issue = [&](int t) {
+        const float4 *At = reinterpret_cast<const float4 *>(W.A + (size_t)t * W.RA * 32);
+        const float4 *Bt = reinterpret_cast<const float4 *>(W.B + (size_t)t * W.RB * 32);
 #pragma unroll
-    for (int i = 0; i < MI; ++i) rowA[i] = 32 * (MI * bm + i) + rl;
+        for (int k = 0; k < LA; ++k) {
+            const int q = tid + k * NT;
+            ga[k] = (q < W.RA * 8) ? At[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) rowB[j] = 32 * (NJ * bn + j) + rl;
-    for (int t = W.t0 + split; t < W.t1; t += nsplit) {
+        for (int k = 0; k < LB; ++k) {
+            const int q = tid + k * NT;
+            gb[k] = (q < W.RB * 8) ? Bt[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&](int buf) {
+        float *La = lds + buf * BUF, *Lb = La + RAP * LDS_STRIDE;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int k = 0; k < LA; ++k) {
+            const int q = tid + k * NT;
+            if (q < W.RA * 8) *reinterpret_cast<float4 *>(La + (q >> 3) * LDS_STRIDE + (q & 7) * 4) = ga[k];
+        }
+#pragma unroll
+        for (int k = 0; k < LB; ++k) {
+            const int q = tid + k * NT;
+            if (q < W.RB * 8) *reinterpret_cast<float4 *>(Lb + (q >> 3) * LDS_STRIDE + (q & 7) * 4) = gb[k];
+        }
+    };
+
+    int t = W.t0 + split;
+    int cur = 0;
+    if (t < W.t1) {
+        issue(t);
+        commit(0);
+    }
+    __syncthreads();
+    for (; t < W.t1; t += nsplit) {
+        const int tn = t + nsplit;
+        if (tn < W.t1) issue(tn);                              // next tile's HBM loads fly under the MFMAs
+        const float *La = lds + cur * BUF + (wm * MI * 32 + rl) * LDS_STRIDE + 4 * h;
+        const float *Lb = lds + cur * BUF + (RAP + wn * NJ * 32 + rl) * LDS_STRIDE + 4 * h;
+#pragma unroll
+        for (int uu = 0; uu < NU; ++uu) {
+            const int u = wk * NU + uu;
             float4 a[MI], b[NJ];
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                a[i] = rowA[i] < W.RA
-                           ? *reinterpret_cast<const float4 *>(W.A + ((size_t)t * W.RA + rowA[i]) * 32 + 8 * u + 4 * h)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                a[i] = *reinterpret_cast<const float4 *>(La + i * 32 * LDS_STRIDE + 8 * u);
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                b[j] = rowB[j] < W.RB
-                           ? *reinterpret_cast<const float4 *>(W.B + ((size_t)t * W.RB + rowB[j]) * 32 + 8 * u + 4 * h)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                b[j] = *reinterpret_cast<const float4 *>(Lb + j * 32 * LDS_STRIDE + 8 * u);
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 bsum[i] += (a[i].x + a[i].y) + (a[i].z + a[i].w);
@@ -455,25 +507,29 @@ __global__ void __launch_bounds__(256, 2) mlp_wgrad_kernel(WgradArgs W)
                 }
             }
         }
+        if (tn < W.t1) commit(cur ^ 1);                        // the other buffer was last read a barrier ago
+        __syncthreads();
+        cur ^= 1;
     }
     // flush: accumulator column = B row (lane), accumulator row = A row (register)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int rb = rowB[j];
+        const int rb = 32 * (NJ * wn + j) + rl;
         const int col = (rb < W.RB) ? (W.first ? in_colmap(W.kind, rb) : rb) : -1;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ra = 32 * (MI * bm + i) + acc_row(r, h);
+                const int ra = 32 * (MI * wm + i) + acc_row(r, h);
                 if (col >= 0 && col < W.ld && ra < W.out_rows) atomicAdd(&W.gw[(size_t)ra * W.ld + col], acc[i][j][r]);
             }
     }
-    if (W.gb && bn == 0) {
+    if (W.gb && wn == 0) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
+            const int ra = 32 * (MI * wm + i) + rl;
             const float tot = bsum[i] + __shfl_xor(bsum[i], 32);
-            if (h == 0 && rowA[i] < W.out_rows) atomicAdd(&W.gb[rowA[i]], tot);
+            if (h == 0 && ra < W.out_rows) atomicAdd(&W.gb[ra], tot);
         }
     }
 }
@@ -487,19 +543,24 @@ int mlp_grid(int n_tiles)
     return wg;
 }
 
-template <int MI, int NJ>
-int launch_wgrad(WgradArgs W, hipStream_t s)
+template <int MI, int NJ, int WM, int WN, int WK>
+int launch_wgrad(const WgradArgs &W, hipStream_t s)
 {
     const int n_tiles = W.t1 - W.t0;
     if (n_tiles <= 0) return 0;
-    const int blocks_m = (W.RA + 32 * MI - 1) / (32 * MI);
-    W.blocks_n = (W.RB + 32 * NJ - 1) / (32 * NJ);
-    const int nblk = blocks_m * W.blocks_n;
-    int nsplit = 2048 / nblk;
-    if (nsplit > n_tiles) nsplit = n_tiles;
-    if (nsplit < 1) nsplit = 1;
-    const int waves = nblk * nsplit;
-    mlp_wgrad_kernel<MI, NJ><<<(waves + 3) / 4, 256, 0, s>>>(W);
+    if (W.RA > WM * MI * 32 || W.RB > WN * NJ * 32) return ESR_ECAP;
+    constexpr int NT = 64 * WM * WN * WK;
+    constexpr size_t lds_bytes = 2 * (size_t)(WM * MI * 32 + WN * NJ * 32) * LDS_STRIDE * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {       // > 64 KB of dynamic LDS needs the opt-in
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_kernel<MI, NJ, WM, WN, WK>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    int grid = 256;        // one workgroup per CU (LDS-bound residency)
+    if (grid > n_tiles) grid = n_tiles;
+    mlp_wgrad_kernel<MI, NJ, WM, WN, WK><<<grid, NT, lds_bytes, s>>>(W);
     ESR_CHECK_LAUNCH();
     return 0;
 }
@@ -590,7 +651,12 @@ ESR_API int esr_mlp_wgrad(int kind, const float *X, int alt_color, const float *
         W.gw = gw[l]; W.ld = first ? D.in_dim : HID; W.out_rows = last ? D.out_dim : HID;
         W.kind = kind; W.first = first ? 1 : 0; W.gb = gb[l];
         if (!W.A || !W.B || !W.gw || !W.gb) return ESR_EINVAL;
-        int rc = last ? launch_wgrad<1, 3>(W, s) : launch_wgrad<3, 3>(W, s);
+        // waves per workgroup (wm x wn x wk): 192x192 -> 2x2x2, 192x<=96 (first layer) -> 2x1x4,
+        // 4x192 (output layer) -> 1x2x4; always 8 waves = 2 per SIMD
+        int rc;
+        if (last) rc = launch_wgrad<1, 3, 1, 2, 2>(W, s);
+        else if (first) rc = launch_wgrad<3, 3, 2, 1, 2>(W, s);     // input tiles have <= 96 rows
+        else rc = launch_wgrad<3, 3, 2, 2, 1>(W, s);
         if (rc) return rc;
     }
     (void)nhid;
