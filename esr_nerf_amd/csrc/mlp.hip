@@ -288,6 +288,37 @@ __device__ __forceinline__ void mask_by_saved(rsrc_t T, f32x16 (&acc)[NT], int l
         }
 }
 
+// ReLU sign bits of NT accumulator tiles, 16 bits per tile, two tiles per word.  The backward
+// needs only (h > 0): 3 words per lane instead of re-reading 96 floats (24 KB per tile).
+template <int NT>
+__device__ __forceinline__ void store_relu_mask(rsrc_t T, const f32x16 (&acc)[NT], int lane)
+{
+    static_assert(NT % 2 == 0, "two tiles per mask word");
+#pragma unroll
+    for (int wd = 0; wd < NT / 2; ++wd) {
+        unsigned m = 0;
+#pragma unroll
+        for (int b = 0; b < 32; ++b) m |= (acc[2 * wd + (b >> 4)][b & 15] > 0.f) ? (1u << b) : 0u;
+        __builtin_amdgcn_raw_buffer_store_b32(m, T, lane * 4, wd * 256, 0);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void load_relu_mask(rsrc_t T, unsigned (&m)[NT / 2], int lane)
+{
+#pragma unroll
+    for (int wd = 0; wd < NT / 2; ++wd) m[wd] = __builtin_amdgcn_raw_buffer_load_b32(T, lane * 4, wd * 256, 0);
+}
+template <int NT>
+__device__ __forceinline__ void apply_relu_mask(const unsigned (&m)[NT / 2], f32x16 (&acc)[NT])
+{
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[it][r] = ((m[it >> 1] >> ((it & 1) * 16 + r)) & 1u) ? acc[it][r] : 0.f;
+}
+constexpr unsigned MASK_TILE_BYTES = (HID_TILES / 2) * 64 * 4;     // per tile per layer
+
 template <int NT>
 __device__ __forceinline__ void zero_tiles(f32x16 (&acc)[NT])
 {
@@ -303,6 +334,7 @@ struct FwdArgs {
     const float *packed, *X;
     int t0, t1;
     float *H[3];
+    unsigned *M[3];
     int save, alt;
     float *zout;
 };
@@ -331,14 +363,20 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
         load_bias<HID_TILES>(W, (int)L.off_bf[0] * 4, cur, lane);
         layer_from_regs<KP1, HID_TILES>(W, (int)L.off_wf[0] * 4, B1, cur, lane);
         relu_tiles<HID_TILES>(cur);
-        if (A.save) store_tiles<HID_TILES>(make_rsrc(A.H[0] + (size_t)t * HID * 32, HID_TILE_BYTES), cur, lane);
+        if (A.save) {
+            store_tiles<HID_TILES>(make_rsrc(A.H[0] + (size_t)t * HID * 32, HID_TILE_BYTES), cur, lane);
+            store_relu_mask<HID_TILES>(make_rsrc(A.M[0] + (size_t)t * (MASK_TILE_BYTES / 4), MASK_TILE_BYTES), cur, lane);
+        }
 #pragma unroll
         for (int l = 1; l < NHID; ++l) {
             f32x16 nxt[HID_TILES];
             load_bias<HID_TILES>(W, (int)L.off_bf[l] * 4, nxt, lane);
             layer_from_acc<HID_TILES>(W, (int)L.off_wf[l] * 4, cur, nxt, lane);
             relu_tiles<HID_TILES>(nxt);
-            if (A.save) store_tiles<HID_TILES>(make_rsrc(A.H[l] + (size_t)t * HID * 32, HID_TILE_BYTES), nxt, lane);
+            if (A.save) {
+                store_tiles<HID_TILES>(make_rsrc(A.H[l] + (size_t)t * HID * 32, HID_TILE_BYTES), nxt, lane);
+                store_relu_mask<HID_TILES>(make_rsrc(A.M[l] + (size_t)t * (MASK_TILE_BYTES / 4), MASK_TILE_BYTES), nxt, lane);
+            }
 #pragma unroll
             for (int it = 0; it < HID_TILES; ++it) cur[it] = nxt[it];
         }
@@ -355,7 +393,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
 struct DgradArgs {
     const float *packed, *dz;
     int t0, t1;
-    const float *H[3];
+    const unsigned *M[3];
     float *dZ[3];
     float *dX;
 };
@@ -374,17 +412,21 @@ __global__ void __launch_bounds__(256, 2) mlp_dgrad_kernel(DgradArgs A)
     for (int t = A.t0 + wave; t < A.t1; t += nwaves) {
         const float *dzt = A.dz + (size_t)t * 4 * 32 + s;
         float B0[4] = {dzt[(0 + h) * 32], dzt[(2 + h) * 32], 0.f, 0.f};   // pair p <-> rows 2p, 2p+1
+        unsigned msk[NHID][HID_TILES / 2];                                   // all layers' ReLU masks up front
+#pragma unroll
+        for (int l = 0; l < NHID; ++l)
+            load_relu_mask<HID_TILES>(make_rsrc(A.M[l] + (size_t)t * (MASK_TILE_BYTES / 4), MASK_TILE_BYTES), msk[l], lane);
         f32x16 cur[HID_TILES];
         zero_tiles<HID_TILES>(cur);
         layer_from_regs<4, HID_TILES>(W, (int)L.off_wb[NHID] * 4, B0, cur, lane);
-        mask_by_saved<HID_TILES>(make_rsrc(A.H[NHID - 1] + (size_t)t * HID * 32, HID_TILE_BYTES), cur, lane);
+        apply_relu_mask<HID_TILES>(msk[NHID - 1], cur);
         store_tiles<HID_TILES>(make_rsrc(A.dZ[NHID - 1] + (size_t)t * HID * 32, HID_TILE_BYTES), cur, lane);
 #pragma unroll
         for (int l = NHID - 1; l >= 1; --l) {
             f32x16 nxt[HID_TILES];
             zero_tiles<HID_TILES>(nxt);
             layer_from_acc<HID_TILES>(W, (int)L.off_wb[l] * 4, cur, nxt, lane);
-            mask_by_saved<HID_TILES>(make_rsrc(A.H[l - 1] + (size_t)t * HID * 32, HID_TILE_BYTES), nxt, lane);
+            apply_relu_mask<HID_TILES>(msk[l - 1], nxt);
             store_tiles<HID_TILES>(make_rsrc(A.dZ[l - 1] + (size_t)t * HID * 32, HID_TILE_BYTES), nxt, lane);
 #pragma unroll
             for (int it = 0; it < HID_TILES; ++it) cur[it] = nxt[it];
@@ -591,7 +633,8 @@ ESR_API int esr_mlp_pack(int kind, const esr_mlp_weights_t *w, float *packed, vo
 }
 
 ESR_API int esr_mlp_fwd(int kind, const float *packed, const float *X, int32_t t0, int32_t t1,
-                        float *const *H, int save, int alt_color, float *zout, void *stream)
+                        float *const *H, uint32_t *const *M, int save, int alt_color, float *zout,
+                        void *stream)
 {
     if ((kind != ESR_MLP_RADIANCE && kind != ESR_MLP_TONEMAP) || t0 < 0 || t1 < t0) return ESR_EINVAL;
     if (t1 == t0) return 0;
@@ -601,8 +644,12 @@ ESR_API int esr_mlp_fwd(int kind, const float *packed, const float *X, int32_t t
     A.packed = packed; A.X = X; A.t0 = t0; A.t1 = t1; A.save = save ? 1 : 0; A.alt = alt_color ? 1 : 0;
     A.zout = zout;
     if (save) {
-        if (!H) return ESR_EINVAL;
-        for (int l = 0; l < nhid; ++l) { if (!H[l]) return ESR_EINVAL; A.H[l] = H[l]; }
+        if (!H || !M) return ESR_EINVAL;
+        for (int l = 0; l < nhid; ++l) {
+            if (!H[l] || !M[l]) return ESR_EINVAL;
+            A.H[l] = H[l];
+            A.M[l] = M[l];
+        }
     }
     const int grid = mlp_grid(t1 - t0);
     if (kind == ESR_MLP_RADIANCE) mlp_fwd_kernel<ESR_MLP_RADIANCE><<<grid, 256, 0, esr_stream(stream)>>>(A);
@@ -612,17 +659,17 @@ ESR_API int esr_mlp_fwd(int kind, const float *packed, const float *X, int32_t t
 }
 
 ESR_API int esr_mlp_dgrad(int kind, const float *packed, const float *dz, int32_t t0, int32_t t1,
-                          const float *const *H, float *const *dZ, float *dX, void *stream)
+                          const uint32_t *const *M, float *const *dZ, float *dX, void *stream)
 {
     if ((kind != ESR_MLP_RADIANCE && kind != ESR_MLP_TONEMAP) || t0 < 0 || t1 < t0) return ESR_EINVAL;
     if (t1 == t0) return 0;
-    if (!packed || !dz || !H || !dZ || !dX) return ESR_EINVAL;
+    if (!packed || !dz || !M || !dZ || !dX) return ESR_EINVAL;
     const int nhid = net_desc(kind).n_layers - 1;
     DgradArgs A = {};
     A.packed = packed; A.dz = dz; A.t0 = t0; A.t1 = t1; A.dX = dX;
     for (int l = 0; l < nhid; ++l) {
-        if (!H[l] || !dZ[l]) return ESR_EINVAL;
-        A.H[l] = H[l]; A.dZ[l] = dZ[l];
+        if (!M[l] || !dZ[l]) return ESR_EINVAL;
+        A.M[l] = M[l]; A.dZ[l] = dZ[l];
     }
     const int grid = mlp_grid(t1 - t0);
     if (kind == ESR_MLP_RADIANCE) mlp_dgrad_kernel<ESR_MLP_RADIANCE><<<grid, 256, 0, esr_stream(stream)>>>(A);

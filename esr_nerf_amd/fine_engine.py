@@ -82,6 +82,8 @@ class _Workspace:
         cap = max(tiles, int(self.cap_tiles * 1.25) + 64)
         self.buf = {k: torch.empty(cap * r * 32, dtype=torch.float32, device=self.device)
                     for k, r in self.ROWS.items()}
+        for k in ("M0", "M1", "M2", "Mt"):          # ReLU sign bits, [tiles, 3, 64] u32
+            self.buf[k] = torch.empty(cap * 3 * 64, dtype=torch.int32, device=self.device)
         self.buf["rec_ray"] = torch.empty(cap * 32, dtype=torch.int32, device=self.device)
         self.buf["rec_step"] = torch.empty(cap * 32, dtype=torch.int32, device=self.device)
         self.cap_tiles = cap
@@ -201,18 +203,18 @@ class FineEngine:
                                        _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_step"]),
                                        _lib.ptr(ws["rec_sdf"]), tiles_on, tiles_all, _lib.ptr(ws["X"]),
                                        _lib.ptr(ws["gnorm"]), s)
-        H = self._H(["H0", "H1", "H2"])
+        H, M = self._H(["H0", "H1", "H2"]), self._H(["M0", "M1", "M2"])
         # off net: detached pass on the on-tiles (alt colour rows, nothing saved), saved pass on the off-tiles
         self._run("mlp_fwd(off|on-tiles)", L.esr_mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), 0, tiles_on,
-                                 H, 0, 1, _lib.ptr(ws["z_off"]), s)
+                                 H, M, 0, 1, _lib.ptr(ws["z_off"]), s)
         self._run("mlp_fwd(off)", L.esr_mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), tiles_on,
-                                 tiles_all, H, 1, 0, _lib.ptr(ws["z_off"]), s)
+                                 tiles_all, H, M, 1, 0, _lib.ptr(ws["z_off"]), s)
         self._run("mlp_fwd(emo)", L.esr_mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["emo"]), _lib.ptr(ws["X"]), 0, tiles_on,
-                                 H, 1, 0, _lib.ptr(ws["z_emo"]), s)
+                                 H, M, 1, 0, _lib.ptr(ws["z_emo"]), s)
         self._run("tone_in_fwd", L.esr_fine_tone_in_fwd, _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), tiles_on, tiles_all,
                                           _lib.ptr(ws["lin"]), _lib.ptr(ws["Xt"]), s)
         self._run("mlp_fwd(tone)", L.esr_mlp_fwd, KIND_TONEMAP, _lib.ptr(self.packed["tone"]), _lib.ptr(ws["Xt"]), 0, tiles_all,
-                                 self._H(["Ht"]), 1, 0, _lib.ptr(ws["zt"]), s)
+                                 self._H(["Ht"]), self._H(["Mt"]), 1, 0, _lib.ptr(ws["zt"]), s)
         self._run("composite_fwd", L.esr_fine_composite_fwd, _lib.ptr(ws["zt"]), _lib.ptr(ws["lin"]), _lib.ptr(ws["rec_ray"]),
                                             _lib.ptr(ws["rec_w"]), tiles_all, _lib.ptr(ws["rgb"]),
                                             _lib.ptr(srgb), _lib.ptr(lin), s)
@@ -233,16 +235,17 @@ class FineEngine:
                                                 _lib.ptr(ws["rec_w"]), ta, _lib.ptr(ws["dweight"]),
                                                 _lib.ptr(ws["dzt"]), s)
             self._run("mlp_dgrad(tone)", L.esr_mlp_dgrad, KIND_TONEMAP, _lib.ptr(self.packed["tone"]), _lib.ptr(ws["dzt"]), 0, ta,
-                                       self._H(["Ht"]), self._H(["dZt"]), _lib.ptr(ws["dXt"]), s)
+                                       self._H(["Mt"]), self._H(["dZt"]), _lib.ptr(ws["dXt"]), s)
             self._run("tone_in_bwd", L.esr_fine_tone_in_bwd, _lib.ptr(ws["dXt"]), _lib.ptr(g_lin), _lib.ptr(ws["lin"]),
                                               _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]),
                                               _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), to, ta,
                                               _lib.ptr(ws["dz"]), s)
             H, dZ = self._H(["H0", "H1", "H2"]), self._H(["dZ0", "dZ1", "dZ2"])
+            M = self._H(["M0", "M1", "M2"])
             self._run("mlp_dgrad(emo)", L.esr_mlp_dgrad, KIND_RADIANCE, _lib.ptr(self.packed["emo"]), _lib.ptr(ws["dz"]), 0, to,
-                                       H, dZ, _lib.ptr(ws["dX"]), s)
+                                       M, dZ, _lib.ptr(ws["dX"]), s)
             self._run("mlp_dgrad(off)", L.esr_mlp_dgrad, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["dz"]), to, ta,
-                                       H, dZ, _lib.ptr(ws["dX"]), s)
+                                       M, dZ, _lib.ptr(ws["dX"]), s)
             self._run("mlp_wgrad(tone)", L.esr_mlp_wgrad, KIND_TONEMAP, _lib.ptr(ws["Xt"]), 0, self._H(["Ht"]), self._H(["dZt"]),
                                        _lib.ptr(ws["dzt"]), 0, ta, _lib.ptr_array(grads["tone_w"]),
                                        _lib.ptr_array(grads["tone_b"]), s)

@@ -218,19 +218,22 @@ int esr_mlp_pack(int kind, const esr_mlp_weights_t *w, float *packed, void *stre
 
 /*
  * Forward over tiles [t0,t1).  X: layer-1 input, tile-major [tiles,xrows,32].
- * H: NHID saved hidden activations, each [tiles,192,32] (NULL or save=0: not kept).
- * zout [tiles,4,32]: pre-activation outputs (row 3 = 0).  alt_color != 0 makes the
- * radiance net read rows 88-93 instead of 0-5 (off net on emissive-on tiles).
+ * With save != 0 every hidden layer l keeps H[l] [tiles,192,32] (read by the weight
+ * gradient) and its ReLU sign bits M[l] [tiles,3,64] u32 (read by the input gradient:
+ * 768 B per tile instead of 24 KB).  zout [tiles,4,32]: pre-activation outputs
+ * (row 3 = 0).  alt_color != 0 makes the radiance net read rows 88-93 instead of 0-5
+ * (off net on emissive-on tiles).
  */
 int esr_mlp_fwd(int kind, const float *packed, const float *X, int32_t t0, int32_t t1,
-                float *const *H, int save, int alt_color, float *zout, void *stream);
+                float *const *H, uint32_t *const *M, int save, int alt_color, float *zout,
+                void *stream);
 
 /*
  * Input/hidden gradients over tiles [t0,t1).  dz [tiles,4,32] -> dZ[l] (each
  * [tiles,192,32], pre-activation grads of hidden layer l) and dX [tiles,64,32].
  */
 int esr_mlp_dgrad(int kind, const float *packed, const float *dz, int32_t t0, int32_t t1,
-                  const float *const *H, float *const *dZ, float *dX, void *stream);
+                  const uint32_t *const *M, float *const *dZ, float *dX, void *stream);
 
 /*
  * Weight/bias gradients accumulated (atomics) into the reference-layout tensors

@@ -128,9 +128,10 @@ def test_mlp_engine_fwd_dgrad_wgrad_vs_torch(kind, tiles):
     eng.pack(which, kind, [w.detach().cuda().contiguous() for w in Ws], [b.detach().cuda().contiguous() for b in Bs])
     Xd = X.cuda().contiguous()
     Hd = [torch.zeros(tiles, 192, 32, device="cuda") for _ in range(nl - 1)]
+    Md = [torch.zeros(tiles, 3, 64, dtype=torch.int32, device="cuda") for _ in range(nl - 1)]
     zout = torch.full((tiles, 4, 32), 7.0, device="cuda")
     s = _lib.stream_ptr("cuda:0")
-    _lib.check(L.esr_mlp_fwd(kind, _lib.ptr(eng.packed[which]), _lib.ptr(Xd), 0, tiles, _lib.ptr_array(Hd), 1, 0,
+    _lib.check(L.esr_mlp_fwd(kind, _lib.ptr(eng.packed[which]), _lib.ptr(Xd), 0, tiles, _lib.ptr_array(Hd), _lib.ptr_array(Md), 1, 0,
                              _lib.ptr(zout), s), "fwd")
     assert rel_err(zout[:, :3], tm(h.detach(), 3)) < 1e-5
     assert float(zout[:, 3].abs().max()) == 0.0
@@ -141,7 +142,7 @@ def test_mlp_engine_fwd_dgrad_wgrad_vs_torch(kind, tiles):
     dzd[:, :3] = tm(dz, 3).cuda()
     dZd = [torch.zeros(tiles, 192, 32, device="cuda") for _ in range(nl - 1)]
     dXd = torch.zeros(tiles, 64, 32, device="cuda")
-    _lib.check(L.esr_mlp_dgrad(kind, _lib.ptr(eng.packed[which]), _lib.ptr(dzd), 0, tiles, _lib.ptr_array(Hd),
+    _lib.check(L.esr_mlp_dgrad(kind, _lib.ptr(eng.packed[which]), _lib.ptr(dzd), 0, tiles, _lib.ptr_array(Md),
                                _lib.ptr_array(dZd), _lib.ptr(dXd), s), "dgrad")
     dx_ref = tm(x_ref.grad, in_dim)
     rows64 = [r for r in rows if r < 64]
