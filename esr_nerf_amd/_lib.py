@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libesr_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 
@@ -45,6 +45,7 @@ EXPORTS = [
     "esr_fine_march_count", "esr_fine_plan_begin", "esr_fine_plan", "esr_fine_march_fill",
     "esr_fine_march_bwd", "esr_fine_feat_fwd", "esr_fine_feat_bwd",
     "esr_mlp_packed_floats", "esr_mlp_pack", "esr_mlp_fwd", "esr_mlp_dgrad", "esr_mlp_wgrad",
+    "esr_mlp_wgrad_scratch_floats",
     "esr_fine_tone_in_fwd", "esr_fine_composite_fwd", "esr_fine_composite_bwd",
     "esr_fine_tone_in_bwd", "esr_fine_loss_fwd_bwd",
 ]
@@ -63,6 +64,7 @@ def lib() -> C.CDLL:
         L.esr_build_info.restype = C.c_char_p
         if hasattr(L, "esr_mlp_packed_floats"):
             L.esr_mlp_packed_floats.restype = C.c_int64
+            L.esr_mlp_wgrad_scratch_floats.restype = C.c_int64
         if L.esr_abi_version() != ABI_VERSION:
             raise RuntimeError("libesr_hip.so ABI version mismatch: rebuild")
         _lib = L

@@ -446,6 +446,7 @@ struct WgradArgs {
     float *gw; int ld; int out_rows;
     int kind; int first;         // column map: first layer uses in_colmap(kind, row)
     float *gb;
+    float *slab;                 // [gridDim.x * WK][out_rows][ld] partial sums
 };
 
 // Cooperative weight-gradient kernel.  One workgroup covers the WHOLE dW of a layer:
@@ -467,17 +468,13 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradAr
     constexpr int NW = WM * WN * WK, NT = 64 * NW;
     constexpr int RAP = WM * MI * 32, RBP = WN * NJ * 32;          // staged rows (padded to tiles)
     constexpr int BUF = (RAP + RBP) * LDS_STRIDE;                  // floats per LDS buffer
-    constexpr int LA = (RAP * 8 + NT - 1) / NT, LB = (RBP * 8 + NT - 1) / NT;   // float4 loads per thread
+    constexpr int LA = RAP * 8 / NT, LB = RBP * 8 / NT;            // float4 loads per thread
     constexpr int NU = 4 / WK;                                     // 8-sample groups per wave per tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, rl = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = w % WK, wn = (w / WK) % WN, wm = w / (WK * WN);
     const int nsplit = gridDim.x, split = blockIdx.x;
-
-    // rows of a short A (the 4-row dz of an output layer) never get staged: zero both buffers once
-    for (int i = tid; i < 2 * BUF; i += NT) lds[i] = 0.f;
-    __syncthreads();
 
     f32x16 acc[MI][NJ];
 #pragma unroll
@@ -486,45 +483,42 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradAr
 #pragma unroll
     for (int i = 0; i < MI; ++i) bsum[i] = 0.f;
 
-    float4 ga[LA], gb[LB];
-    auto issue = [&](int t) {
-        const float4 *At = reinterpret_cast<const float4 *>(W.A + (size_t)t * W.RA * 32);
-        const float4 *Bt = reinterpret_cast<const float4 *>(W.B + (size_t)t * W.RB * 32);
+    // Three-stage pipeline: tile t is multiplied out of LDS while tile t+1 sits in registers waiting
+    // to be committed and tile t+2's HBM loads are in flight (two register sets, static names).  With
+    // one tile of prefetch the 192x96 and 4x192 layers were latency-bound: their MFMA work per tile
+    // (<= 4.6k cycles) is shorter than an HBM round trip under load.
+    float4 ga[2][LA], gb[2][LB];
+    // Staging loads are range-checked BUFFER loads (out-of-range rows of a short operand read as
+    // zero): no per-load branches, so the whole step is one basic block and hipcc keeps a COUNTED
+    // vmcnt at the commit (with predicated plain loads it fell back to vmcnt(0) and drained the
+    // prefetch every iteration).
+    static_assert(LA * NT == RAP * 8 && LB * NT == RBP * 8, "staging covers the padded tiles exactly");
+    // Past the end of the tile range the descriptor gets ZERO records: the loads still issue (so the
+    // vmcnt arithmetic is the same on every trip) but touch no memory and return zeros.
+    auto issue = [&](int t, float4 (&ra)[LA], float4 (&rb_)[LB]) {
+        const bool live = t < W.t1;
+        const int tc = live ? t : W.t0;
+        const rsrc_t SA = make_rsrc(W.A + (size_t)tc * W.RA * 32, live ? (unsigned)W.RA * 128u : 0u);
+        const rsrc_t SB = make_rsrc(W.B + (size_t)tc * W.RB * 32, live ? (unsigned)W.RB * 128u : 0u);
 #pragma unroll
-        for (int k = 0; k < LA; ++k) {
-            const int q = tid + k * NT;
-            ga[k] = (q < W.RA * 8) ? At[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int k = 0; k < LA; ++k) ra[k] = bload4(SA, (tid + k * NT) * 16, 0);
 #pragma unroll
-        for (int k = 0; k < LB; ++k) {
-            const int q = tid + k * NT;
-            gb[k] = (q < W.RB * 8) ? Bt[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int k = 0; k < LB; ++k) rb_[k] = bload4(SB, (tid + k * NT) * 16, 0);
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int buf, const float4 (&ra)[LA], const float4 (&rb_)[LB]) {
         float *La = lds + buf * BUF, *Lb = La + RAP * LDS_STRIDE;
 #pragma unroll
         for (int k = 0; k < LA; ++k) {
             const int q = tid + k * NT;
-            if (q < W.RA * 8) *reinterpret_cast<float4 *>(La + (q >> 3) * LDS_STRIDE + (q & 7) * 4) = ga[k];
+            *reinterpret_cast<float4 *>(La + (q >> 3) * LDS_STRIDE + (q & 7) * 4) = ra[k];
         }
 #pragma unroll
         for (int k = 0; k < LB; ++k) {
             const int q = tid + k * NT;
-            if (q < W.RB * 8) *reinterpret_cast<float4 *>(Lb + (q >> 3) * LDS_STRIDE + (q & 7) * 4) = gb[k];
+            *reinterpret_cast<float4 *>(Lb + (q >> 3) * LDS_STRIDE + (q & 7) * 4) = rb_[k];
         }
     };
-
-    int t = W.t0 + split;
-    int cur = 0;
-    if (t < W.t1) {
-        issue(t);
-        commit(0);
-    }
-    __syncthreads();
-    for (; t < W.t1; t += nsplit) {
-        const int tn = t + nsplit;
-        if (tn < W.t1) issue(tn);                              // next tile's HBM loads fly under the MFMAs
+    auto compute = [&](int cur) {
         const float *La = lds + cur * BUF + (wm * MI * 32 + rl) * LDS_STRIDE + 4 * h;
         const float *Lb = lds + cur * BUF + (RAP + wn * NJ * 32 + rl) * LDS_STRIDE + 4 * h;
 #pragma unroll
@@ -549,11 +543,33 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradAr
                 }
             }
         }
-        if (tn < W.t1) commit(cur ^ 1);                        // the other buffer was last read a barrier ago
-        __syncthreads();
-        cur ^= 1;
+    };
+
+    int t = W.t0 + split;
+    issue(t, ga[0], gb[0]);
+    commit(0, ga[0], gb[0]);
+    issue(t + nsplit, ga[1], gb[1]);                                 // tile t+1 -> register set 1
+    __syncthreads();
+    // invariant at the top of a step on tile t: LDS buffer `cur` holds t, register set `nx` holds t+1
+    for (int cur = 0; t < W.t1;) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {                       // unrolled by 2: static register sets
+            if (t < W.t1) {
+                const int nx = half ^ 1, fr = half;                  // set holding t+1 / set free for t+2
+                issue(t + 2 * nsplit, ga[fr], gb[fr]);               // unconditional: counted vmcnt below
+                compute(cur);
+                commit(cur ^ 1, ga[nx], gb[nx]);                     // (zeros past the end: never read)
+                __syncthreads();
+                cur ^= 1;
+                t += nsplit;
+            }
+        }
     }
-    // flush: accumulator column = B row (lane), accumulator row = A row (register)
+    // flush: accumulator column = B row (lane), accumulator row = A row (register).  Every wave
+    // stores its block into its workgroup's private slab with plain 128-B-contiguous stores; a
+    // second tiny kernel sums the slabs.  (1024 waves atomically adding into the same 147 KB at
+    // kernel end ran at a fraction of the atomic rate: same-address contention.)
+    float *S = W.slab + (size_t)(blockIdx.x * WK + wk) * W.out_rows * W.ld;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int rb = 32 * (NJ * wn + j) + rl;
@@ -563,7 +579,7 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradAr
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ra = 32 * (MI * wm + i) + acc_row(r, h);
-                if (col >= 0 && col < W.ld && ra < W.out_rows) atomicAdd(&W.gw[(size_t)ra * W.ld + col], acc[i][j][r]);
+                if (col >= 0 && col < W.ld && ra < W.out_rows) S[(size_t)ra * W.ld + col] = acc[i][j][r];
             }
     }
     if (W.gb && wn == 0) {
@@ -573,6 +589,23 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradAr
             const float tot = bsum[i] + __shfl_xor(bsum[i], 32);
             if (h == 0 && ra < W.out_rows) atomicAdd(&W.gb[ra], tot);
         }
+    }
+}
+
+// gw[e] += sum over partial slabs; 32 slabs per thread, groups combined with one atomic each
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ slab, int n_partials,
+                                                           int n_elems, float *__restrict__ gw)
+{
+    constexpr int PG = 32;
+    const int groups = (n_partials + PG - 1) / PG;
+    const int64_t total = (int64_t)n_elems * groups;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i % n_elems), g = (int)(i / n_elems);
+        const int p1 = min((g + 1) * PG, n_partials);
+        float acc = 0.f;
+        for (int p = g * PG; p < p1; ++p) acc += slab[(size_t)p * n_elems + e];
+        atomicAdd(&gw[e], acc);
     }
 }
 
@@ -586,7 +619,7 @@ int mlp_grid(int n_tiles)
 }
 
 template <int MI, int NJ, int WM, int WN, int WK>
-int launch_wgrad(const WgradArgs &W, hipStream_t s)
+int launch_wgrad(const WgradArgs &W, int64_t slab_floats, hipStream_t s)
 {
     const int n_tiles = W.t1 - W.t0;
     if (n_tiles <= 0) return 0;
@@ -602,7 +635,13 @@ int launch_wgrad(const WgradArgs &W, hipStream_t s)
     }
     int grid = 256;        // one workgroup per CU (LDS-bound residency)
     if (grid > n_tiles) grid = n_tiles;
+    const int n_elems = W.out_rows * W.ld;
+    if ((int64_t)grid * WK * n_elems > slab_floats) return ESR_ECAP;
     mlp_wgrad_kernel<MI, NJ, WM, WN, WK><<<grid, NT, lds_bytes, s>>>(W);
+    ESR_CHECK_LAUNCH();
+    const int groups = (grid * WK + 31) / 32;
+    wgrad_reduce_kernel<<<esr_grid_for((int64_t)n_elems * groups, 256, 2048), 256, 0, s>>>(W.slab, grid * WK,
+                                                                                         n_elems, W.gw);
     ESR_CHECK_LAUNCH();
     return 0;
 }
@@ -678,14 +717,17 @@ ESR_API int esr_mlp_dgrad(int kind, const float *packed, const float *dz, int32_
     return 0;
 }
 
+ESR_API int64_t esr_mlp_wgrad_scratch_floats(void) { return (int64_t)256 * 2 * HID * HID; }
+
 ESR_API int esr_mlp_wgrad(int kind, const float *X, int alt_color, const float *const *H,
                           const float *const *dZ, const float *dz, int32_t t0, int32_t t1,
-                          float *const *gw, float *const *gb, void *stream)
+                          float *const *gw, float *const *gb, float *scratch, int64_t scratch_floats,
+                          void *stream)
 {
     (void)alt_color;   // gradients only ever flow through the main colour rows
     if ((kind != ESR_MLP_RADIANCE && kind != ESR_MLP_TONEMAP) || t0 < 0 || t1 < t0) return ESR_EINVAL;
     if (t1 == t0) return 0;
-    if (!X || !H || !dZ || !dz || !gw || !gb) return ESR_EINVAL;
+    if (!X || !H || !dZ || !dz || !gw || !gb || !scratch) return ESR_EINVAL;
     const NetDesc D = net_desc(kind);
     const int nhid = D.n_layers - 1;
     hipStream_t s = esr_stream(stream);
@@ -696,14 +738,14 @@ ESR_API int esr_mlp_wgrad(int kind, const float *X, int alt_color, const float *
         W.B = first ? X : H[l - 1];       W.RB = first ? D.xrows : HID;
         W.t0 = t0; W.t1 = t1;
         W.gw = gw[l]; W.ld = first ? D.in_dim : HID; W.out_rows = last ? D.out_dim : HID;
-        W.kind = kind; W.first = first ? 1 : 0; W.gb = gb[l];
+        W.kind = kind; W.first = first ? 1 : 0; W.gb = gb[l]; W.slab = scratch;
         if (!W.A || !W.B || !W.gw || !W.gb) return ESR_EINVAL;
         // waves per workgroup (wm x wn x wk): 192x192 -> 2x2x2, 192x<=96 (first layer) -> 2x1x4,
         // 4x192 (output layer) -> 1x2x4; always 8 waves = 2 per SIMD
         int rc;
-        if (last) rc = launch_wgrad<1, 3, 1, 2, 2>(W, s);
-        else if (first) rc = launch_wgrad<3, 3, 2, 1, 2>(W, s);     // input tiles have <= 96 rows
-        else rc = launch_wgrad<3, 3, 2, 2, 1>(W, s);
+        if (last) rc = launch_wgrad<1, 3, 1, 2, 2>(W, scratch_floats, s);
+        else if (first) rc = launch_wgrad<3, 3, 2, 1, 2>(W, scratch_floats, s);     // input tiles have <= 96 rows
+        else rc = launch_wgrad<3, 3, 2, 2, 1>(W, scratch_floats, s);
         if (rc) return rc;
     }
     (void)nhid;

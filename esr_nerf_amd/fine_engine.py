@@ -103,6 +103,8 @@ class FineEngine:
             k: torch.empty(self.L.esr_mlp_packed_floats(kind), dtype=torch.float32, device=self.device)
             for k, kind in (("off", KIND_RADIANCE), ("emo", KIND_RADIANCE), ("tone", KIND_TONEMAP))}
         self.ray_bufs: Dict[int, Dict[str, torch.Tensor]] = {}
+        self.wgrad_scratch = torch.empty(self.L.esr_mlp_wgrad_scratch_floats(), dtype=torch.float32,
+                                         device=self.device)
         self._timing = False
         self._only = None
         self._events = []
@@ -242,17 +244,18 @@ class FineEngine:
                                               _lib.ptr(ws["dz"]), s)
             H, dZ = self._H(["H0", "H1", "H2"]), self._H(["dZ0", "dZ1", "dZ2"])
             M = self._H(["M0", "M1", "M2"])
+            sc = (_lib.ptr(self.wgrad_scratch), C.c_int64(self.wgrad_scratch.numel()))
             self._run("mlp_dgrad(emo)", L.esr_mlp_dgrad, KIND_RADIANCE, _lib.ptr(self.packed["emo"]), _lib.ptr(ws["dz"]), 0, to,
                                        M, dZ, _lib.ptr(ws["dX"]), s)
             self._run("mlp_dgrad(off)", L.esr_mlp_dgrad, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["dz"]), to, ta,
                                        M, dZ, _lib.ptr(ws["dX"]), s)
             self._run("mlp_wgrad(tone)", L.esr_mlp_wgrad, KIND_TONEMAP, _lib.ptr(ws["Xt"]), 0, self._H(["Ht"]), self._H(["dZt"]),
                                        _lib.ptr(ws["dzt"]), 0, ta, _lib.ptr_array(grads["tone_w"]),
-                                       _lib.ptr_array(grads["tone_b"]), s)
+                                       _lib.ptr_array(grads["tone_b"]), *sc, s)
             self._run("mlp_wgrad(emo)", L.esr_mlp_wgrad, KIND_RADIANCE, _lib.ptr(ws["X"]), 0, H, dZ, _lib.ptr(ws["dz"]), 0, to,
-                                       _lib.ptr_array(grads["emo_w"]), _lib.ptr_array(grads["emo_b"]), s)
+                                       _lib.ptr_array(grads["emo_w"]), _lib.ptr_array(grads["emo_b"]), *sc, s)
             self._run("mlp_wgrad(off)", L.esr_mlp_wgrad, KIND_RADIANCE, _lib.ptr(ws["X"]), 0, H, dZ, _lib.ptr(ws["dz"]), to, ta,
-                                       _lib.ptr_array(grads["off_w"]), _lib.ptr_array(grads["off_b"]), s)
+                                       _lib.ptr_array(grads["off_w"]), _lib.ptr_array(grads["off_b"]), *sc, s)
             self._run("feat_bwd", L.esr_fine_feat_bwd, sp, _lib.ptr(ctx.rays_o), _lib.ptr(ctx.rays_d),
                                            _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_step"]), _lib.ptr(ws["X"]),
                                            _lib.ptr(ws["gnorm"]), _lib.ptr(ws["dX"]), to, ta,

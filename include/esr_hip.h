@@ -236,12 +236,15 @@ int esr_mlp_dgrad(int kind, const float *packed, const float *dz, int32_t t0, in
                   const uint32_t *const *M, float *const *dZ, float *dX, void *stream);
 
 /*
- * Weight/bias gradients accumulated (atomics) into the reference-layout tensors
- * gw[l] [out,in], gb[l] [out] over tiles [t0,t1).
+ * Weight/bias gradients accumulated into the reference-layout tensors gw[l] [out,in],
+ * gb[l] [out] over tiles [t0,t1).  scratch: >= esr_mlp_wgrad_scratch_floats() floats of
+ * device workspace for the per-workgroup partial slabs (summed by a second kernel).
  */
+int64_t esr_mlp_wgrad_scratch_floats(void);
 int esr_mlp_wgrad(int kind, const float *X, int alt_color, const float *const *H,
                   const float *const *dZ, const float *dz, int32_t t0, int32_t t1,
-                  float *const *gw, float *const *gb, void *stream);
+                  float *const *gw, float *const *gb, float *scratch, int64_t scratch_floats,
+                  void *stream);
 
 /*
  * Between the nets: lin = softplus(z_off) (+ softplus(z_emo) on on-tiles);

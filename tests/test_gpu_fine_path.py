@@ -151,7 +151,8 @@ def test_mlp_engine_fwd_dgrad_wgrad_vs_torch(kind, tiles):
     gw = [torch.zeros_like(w).cuda() for w in Ws]
     gb = [torch.zeros_like(b).cuda() for b in Bs]
     _lib.check(L.esr_mlp_wgrad(kind, _lib.ptr(Xd), 0, _lib.ptr_array(Hd), _lib.ptr_array(dZd), _lib.ptr(dzd), 0,
-                               tiles, _lib.ptr_array(gw), _lib.ptr_array(gb), s), "wgrad")
+                               tiles, _lib.ptr_array(gw), _lib.ptr_array(gb), _lib.ptr(eng.wgrad_scratch),
+                               C.c_int64(eng.wgrad_scratch.numel()), s), "wgrad")
     for i in range(nl):
         assert rel_err(gw[i], Ws[i].grad) < 2e-5, ("gw", i, rel_err(gw[i], Ws[i].grad))
         assert rel_err(gb[i], Bs[i].grad) < 2e-5, ("gb", i)
