@@ -148,7 +148,9 @@ def main():
     eng = model.engine
 
     def one():
-        return step.forward_loss_backward(batch, a.s_val)
+        # N > 1: this rank's 4096 rays are one shard of a global batch of 4096 * N rays
+        return step.forward_loss_backward(batch, a.s_val, global_rays=n_rays * world if world > 1 else None,
+                                          entropy_owner=(rank == world - 1))
 
     # warm-up; its last steps carry HIP events around EVERY kernel (full breakdown + which kernel
     # dominates).  Bracketing everything costs ~2 ms/step, so it is kept out of the timed region.
@@ -169,7 +171,9 @@ def main():
             if call in breakdown:
                 by_kernel[kname] = by_kernel.get(kname, 0.0) + breakdown[call][1]
         dominant = max(by_kernel, key=by_kernel.get) if by_kernel else None
-    dom_calls = [c for c, k in KERNEL_OF.items() if k == dominant]
+    dom_calls = [c for c, k in KERNEL_OF.items() if k == dominant and c in breakdown]
+    # one launch of that kernel per step is bracketed (each event pair costs ~40-80 us of wall time)
+    dom_calls = sorted(dom_calls, key=lambda c: -breakdown[c][1])[:1]
     # timed region: exactly K steps, events only around the dominant kernel's launches (on their stream)
     eng.enable_timing(dominant is not None, only=dom_calls if dominant else None)
     if world > 1:

@@ -223,10 +223,16 @@ class FineEngine:
         return ctx, last, srgb, lin
 
     # -- backward ----------------------------------------------------------------
-    def backward(self, ctx: FineCtx, g_last, g_srgb, g_lin, grads: Dict[str, Optional[torch.Tensor]]):
+    def backward(self, ctx: FineCtx, g_last, g_srgb, g_lin, grads: Dict[str, Optional[torch.Tensor]],
+                 after_grids=None):
         """Accumulates into the (zero-initialised, reference-layout) tensors of ``grads``:
         sdf [X,Y,Z], off_color/emo_color [X,Y,Z,6], off_w/off_b/emo_w/emo_b (lists of 4),
-        tone_w/tone_b (lists of 2)."""
+        tone_w/tone_b (lists of 2).
+
+        Order: input-gradient chain -> grid scatters (feat_bwd, march_bwd) -> weight gradients.
+        ``after_grids()`` is called once the grid gradients are complete in stream order and before
+        the three wgrad calls are enqueued: the data-parallel step starts the (large) grid all-reduce
+        there so that it overlaps ~1.4 ms of matrix work."""
         L, s, ws = self.L, self._s(), self.ws
         sp = C.byref(ctx.scene)
         to, ta = ctx.tiles_on, ctx.tiles_all
@@ -249,13 +255,6 @@ class FineEngine:
                                        M, dZ, _lib.ptr(ws["dX"]), s)
             self._run("mlp_dgrad(off)", L.esr_mlp_dgrad, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["dz"]), to, ta,
                                        M, dZ, _lib.ptr(ws["dX"]), s)
-            self._run("mlp_wgrad(tone)", L.esr_mlp_wgrad, KIND_TONEMAP, _lib.ptr(ws["Xt"]), 0, self._H(["Ht"]), self._H(["dZt"]),
-                                       _lib.ptr(ws["dzt"]), 0, ta, _lib.ptr_array(grads["tone_w"]),
-                                       _lib.ptr_array(grads["tone_b"]), *sc, s)
-            self._run("mlp_wgrad(emo)", L.esr_mlp_wgrad, KIND_RADIANCE, _lib.ptr(ws["X"]), 0, H, dZ, _lib.ptr(ws["dz"]), 0, to,
-                                       _lib.ptr_array(grads["emo_w"]), _lib.ptr_array(grads["emo_b"]), *sc, s)
-            self._run("mlp_wgrad(off)", L.esr_mlp_wgrad, KIND_RADIANCE, _lib.ptr(ws["X"]), 0, H, dZ, _lib.ptr(ws["dz"]), to, ta,
-                                       _lib.ptr_array(grads["off_w"]), _lib.ptr_array(grads["off_b"]), *sc, s)
             self._run("feat_bwd", L.esr_fine_feat_bwd, sp, _lib.ptr(ctx.rays_o), _lib.ptr(ctx.rays_d),
                                            _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_step"]), _lib.ptr(ws["X"]),
                                            _lib.ptr(ws["gnorm"]), _lib.ptr(ws["dX"]), to, ta,
@@ -268,6 +267,17 @@ class FineEngine:
                                         _lib.ptr(ctx.mask_density), _lib.ptr(ctx.sdf), ctx.n_rays,
                                         _lib.ptr(ctx.off3), _lib.ptr(dweight), _lib.ptr(g_last),
                                         _lib.ptr(grads["sdf"]), s)
+
+        if after_grids is not None:
+            after_grids()
+        if ta > 0:
+            self._run("mlp_wgrad(tone)", L.esr_mlp_wgrad, KIND_TONEMAP, _lib.ptr(ws["Xt"]), 0, self._H(["Ht"]), self._H(["dZt"]),
+                                       _lib.ptr(ws["dzt"]), 0, ta, _lib.ptr_array(grads["tone_w"]),
+                                       _lib.ptr_array(grads["tone_b"]), *sc, s)
+            self._run("mlp_wgrad(emo)", L.esr_mlp_wgrad, KIND_RADIANCE, _lib.ptr(ws["X"]), 0, H, dZ, _lib.ptr(ws["dz"]), 0, to,
+                                       _lib.ptr_array(grads["emo_w"]), _lib.ptr_array(grads["emo_b"]), *sc, s)
+            self._run("mlp_wgrad(off)", L.esr_mlp_wgrad, KIND_RADIANCE, _lib.ptr(ws["X"]), 0, H, dZ, _lib.ptr(ws["dz"]), to, ta,
+                                       _lib.ptr_array(grads["off_w"]), _lib.ptr_array(grads["off_b"]), *sc, s)
 
     # -- fused trainer-step loss (app/fine/fine.py:355-382) ------------------------
     def loss_fwd_bwd(self, last, srgb, lin, rgbs, white_bg=True, weight_linear=0.1, weight_entropy_last=0.001):

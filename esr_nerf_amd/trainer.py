@@ -12,8 +12,9 @@ part of this class.
 
 Data parallelism: rays are independent, so every rank runs the
 same step on its contiguous shard of the global batch and the parameter
-gradients are summed with ONE flat all-reduce (RCCL over xGMI when the process
-group is NCCL).  Losses are normalised by the GLOBAL ray count so the reduced
+gradients live in ONE flat buffer that is summed with two all-reduces (RCCL over
+xGMI when the process group is NCCL): the dense-grid part as soon as the grid scatters are
+done -- overlapped with the weight-gradient kernels -- and the small MLP part at the end.  Losses are normalised by the GLOBAL ray count so the reduced
 gradient equals the single-process gradient of the full batch.
 """
 from __future__ import annotations
@@ -80,10 +81,12 @@ class FineStep:
             self._flat = torch.empty(total, dtype=torch.float32, device=dev)
         self._flat.zero_()
         out, o = {}, 0
-        for n, s in shapes:
+        for i, (n, s) in enumerate(shapes):
             k = int(torch.Size(s).numel())
             out[n] = self._flat[o:o + k].view(s)
             o += k
+            if i == 2:
+                self._n_grid = o          # [0, _n_grid): the three dense grids; the rest: MLP tensors
         return out
 
     @torch.no_grad()
@@ -117,11 +120,22 @@ class FineStep:
                      off_w=[g[n] for n in names[0:8:2]], off_b=[g[n] for n in names[1:8:2]],
                      emo_w=[g[n] for n in names[8:16:2]], emo_b=[g[n] for n in names[9:16:2]],
                      tone_w=[g[n] for n in names[16:20:2]], tone_b=[g[n] for n in names[17:20:2]])
-        eng.backward(ctx, g_last, g_srgb, g_lin, grads)
+        works = []
         if self.pg is not None:
             import torch.distributed as dist
-            dist.all_reduce(self._flat, group=self.pg)
-            dist.all_reduce(loss, group=self.pg)
+
+            def after_grids():
+                # grid gradients (218 MB at C2, >99 % of the payload) are final here: their all-reduce
+                # runs on RCCL's stream underneath the wgrad kernels that the engine enqueues next
+                works.append(dist.all_reduce(self._flat[: self._n_grid], group=self.pg, async_op=True))
+        else:
+            after_grids = None
+        eng.backward(ctx, g_last, g_srgb, g_lin, grads, after_grids=after_grids)
+        if self.pg is not None:
+            works.append(dist.all_reduce(self._flat[self._n_grid:], group=self.pg, async_op=True))
+            works.append(dist.all_reduce(loss, group=self.pg, async_op=True))
+            for w in works:
+                w.wait()                  # stream-level wait: the caller's stream sees reduced gradients
         g["off_color.grid"] = g["off_color.grid"].permute(0, 4, 1, 2, 3)     # logical [1,6,X,Y,Z]
         g["emo_color.grid"] = g["emo_color.grid"].permute(0, 4, 1, 2, 3)
         return loss, g
