@@ -55,6 +55,24 @@ FINE_TRAINER = dict(
 )
 
 
+# /root/reference/cfg/app/lts.yaml:12-41 (model) and :83-89 (loss weights)
+LTS_MODEL = dict(FINE_MODEL, brdfnet_width=128, brdfnet_depth=4, env_sg=48, env_activation="softplus",
+                 ray_sampling="random", num_2ndrays=256, num_ltspts=100, lts_near=1e-5)
+LTS_TRAINER = dict(weight_entropy_last=0.001, weight_tv_density=0.01, weight_linear=10.0, weight_lts=0.01,
+                   weight_normal_smooth=0.001, normal_eps=0.01, emit_eps=0.001, s_start=220.0)
+
+
+def lts_cfg(device: str = "cpu", **model_over) -> AttrDict:
+    m = dict(LTS_MODEL)
+    m.update(model_over)
+    return AttrDict(
+        system=dict(device=device, debug=True, seed=0, tqdm_iters=10),
+        app=dict(model=m, trainer=dict(LTS_TRAINER)),
+        data=dict(white_bg=True),
+        global_step=0,
+    )
+
+
 def fine_cfg(device: str = "cpu") -> AttrDict:
     return AttrDict(
         system=dict(device=device, debug=True, seed=0, tqdm_iters=10),

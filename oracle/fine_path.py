@@ -136,7 +136,7 @@ def mask_cache(c: FineConsts, pts: Tensor) -> Tensor:
     return alpha >= c.maskcache_thres
 
 
-def sdf_stencil(c: FineConsts, sdf_grid: Tensor, pts: Tensor, displace: Tensor, eps: float = 0.0):
+def sdf_stencil(c: FineConsts, sdf_grid: Tensor, pts: Tensor, displace: Tensor, diff_eps: float = 0.0):
     """Clamped +-displace taps along the three grid axes.
 
     Returns feat [M,6K] (tap order: -ax0,+ax0,-ax1,+ax1,-ax2,+ax2 with ax0 = world z,
@@ -154,8 +154,9 @@ def sdf_stencil(c: FineConsts, sdf_grid: Tensor, pts: Tensor, displace: Tensor, 
     feat = sample_grid(sdf_grid, tap_norm.reshape(-1, 3))[:, 0].reshape(M, 6, K)
     taps = taps.reshape(M, 6, K, 3)
     diff = (taps[:, 1::2] - taps[:, 0::2]).max(dim=-1).values                    # [M,3,K]
-    grad = (feat[:, 1::2] - feat[:, 0::2]) / diff / c.voxel_size
-    normal = F.normalize(grad + eps, dim=1) if eps else F.normalize(grad, dim=1)
+    # the LTS renderer guards the division: diff + 1e-12 (esrnerf.py:1560); the fine renderer does not
+    grad = (feat[:, 1::2] - feat[:, 0::2]) / ((diff + diff_eps) if diff_eps else diff) / c.voxel_size
+    normal = F.normalize(grad, dim=1)
     return feat.reshape(M, 6 * K), grad.reshape(M, 3 * K), normal.reshape(M, 3 * K)
 
 

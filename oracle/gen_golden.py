@@ -128,6 +128,86 @@ def main():
               {k: tuple(v.shape) for k, v in res_raw.items()})
 
     ru.sample_pts_on_rays, ru.alpha2weight, ru.alpha2weight_backward = real_sample, real_a2w, real_a2w_b
+    gen_lts(ns)
+
+
+def lts_reference_loss(ns, results, rgbs, cfg):
+    """Arithmetic of app/fine/lts.py:337-379 (no TV) with the reference's apply_gamma_curve."""
+    tr = cfg.app.trainer
+    loss = reference_loss(ns, results, rgbs, cfg)          # same first three terms, lts weights
+    loss = loss + tr.weight_lts * F.mse_loss(results["lin/pbr/off"], results["lin/pbr/off_hat"])
+    loss = loss + tr.weight_lts * F.mse_loss(results["lin/pbr/emo"], results["lin/pbr/emo_hat"])
+    loss = loss + tr.weight_normal_smooth * F.l1_loss(results["etc/normal"], results["etc/normal_eps"])
+    return loss
+
+
+def gen_lts(ns):
+    """ESRNeRF.forward_training (lts and pdra mode) on the small oblique slab, with every random draw
+    of the reference recorded so that restatements can be fed the same numbers."""
+    from esr_nerf_amd.config import lts_cfg
+    cfg = lts_cfg("cpu", num_2ndrays=8, num_ltspts=12)
+    sc = slab_scene("g16", s_val=60.0, oblique=True)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = ns.ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max,
+                       sc.mask_alpha_init, sc.mask_density, sc.s_val, sc.num_voxels)
+    init_slab_model(model, sc)
+    with torch.no_grad():
+        model.brdf.grid.data.copy_(torch.randn(model.brdf.grid.shape, generator=torch.Generator().manual_seed(9)) * 0.1)
+    model.train()
+    np.savez_compressed(os.path.join(OUT, "lts_g16_params.npz"),
+                        **{k: v.detach().numpy() for k, v in model.state_dict().items()})
+    b = dict(sc.batch)
+    b["uncert_masks"] = (torch.arange(sc.n_rays) % 3 == 0)
+    for mode in ("lts", "pdra"):
+        model.pdra_mode = mode == "pdra"
+        model.zero_grad(set_to_none=True)
+        rec = {"randn": [], "randn_like": []}
+        r_randn, r_like, r_choice = torch.randn, torch.randn_like, np.random.choice
+
+        def p_randn(*a, **k):
+            t = r_randn(*a, **k)
+            rec["randn"].append(t.clone())
+            return t
+
+        def p_like(x, **k):
+            t = r_like(x, **k)
+            rec["randn_like"].append(t.clone())
+            return t
+
+        def p_choice(*a, **k):
+            v = r_choice(*a, **k)
+            rec["idx"] = np.array(v)
+            return v
+
+        torch.manual_seed(5)
+        np.random.seed(5)
+        torch.randn, torch.randn_like, np.random.choice = p_randn, p_like, p_choice
+        try:
+            res = model(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=b["em_modes"],
+                        uncert_masks=b["uncert_masks"], s_val=60.0, normal_eps=cfg.app.trainer.normal_eps,
+                        emit_eps=cfg.app.trainer.emit_eps)
+        finally:
+            torch.randn, torch.randn_like, np.random.choice = r_randn, r_like, r_choice
+        res_raw = {k: v.detach().clone() for k, v in res.items()}
+        loss = lts_reference_loss(ns, dict(res), b["rgbs"], cfg)
+        loss.backward()
+        out = {"in/" + k: v.numpy() for k, v in b.items()}
+        out["in/s_val"] = np.float32(60.0)
+        out["draw/idx"] = rec["idx"].astype(np.int64)
+        out["draw/dirs"] = rec["randn"][0].numpy()
+        out["draw/noise_normal"] = rec["randn_like"][0].numpy()
+        out["draw/noise_emit"] = rec["randn_like"][1].numpy()
+        assert len(rec["randn"]) == 1 and len(rec["randn_like"]) == 2
+        for k, v in res_raw.items():
+            out["out/" + k] = v.numpy()
+        out["loss"] = loss.detach().numpy()
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                out["grad/" + k] = p.grad.detach().numpy()
+        np.savez_compressed(os.path.join(OUT, f"lts_g16_{mode}.npz"), **out)
+        print("lts", mode, "loss", float(loss), "M3", res_raw["etc/normal"].shape[0],
+              "grads", sum(1 for k in out if k.startswith("grad/")))
 
 
 if __name__ == "__main__":

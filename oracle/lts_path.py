@@ -1,0 +1,268 @@
+"""CPU restatement of the LTS-stage training path -- TEST INFRASTRUCTURE ONLY.
+
+Functional torch-CPU statement of ``ESRNeRF.forward_training`` with
+``pdra_mode`` off/on and of the ``LTS.learn`` loss,
+written from the algorithm.  Checker for the LTS kernels; never imported by the
+product package.
+
+Reference lines restated (relative to /root/reference):
+  primary pass ..................... app/fine/model/esrnerf.py:681-788
+  exact trilinear SDF gradient ..... app/fine/model/esrnerf.py:1572-1605, app/utils/base/functions.py:142-309
+  stencil with the +1e-12 guard .... app/fine/model/esrnerf.py:1527-1570
+  light-transport segment .......... app/fine/model/esrnerf.py:487-679
+  hemisphere directions ............ app/utils/pbr/functions.py:10-18
+  Disney reflection ................ app/utils/pbr/functions.py:108-173
+  BRDF / emission / SG env nets .... app/utils/pbr/module.py:42-143
+  perturbed re-evaluations ......... app/fine/model/esrnerf.py:807-830
+  loss ............................. app/fine/lts.py:337-379
+
+Randomness.  The reference draws, in this order: ``np.random.choice`` (which
+surviving samples host a light-transport segment), ``torch.randn`` for the
+hemisphere directions, two ``torch.randn_like`` for the perturbations.  Here the
+draws are explicit inputs (``Draws``) so that the imported reference, this
+restatement and the HIP path can be fed identical numbers.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from oracle import fine_path as fp
+from oracle import native
+
+Tensor = torch.Tensor
+BRDF_KEYS = ("brdfnet.0", "brdfnet.2.0", "brdfnet.3.0", "brdfnet.4")
+
+
+@dataclass
+class Draws:
+    idx: Tensor          # [P] int64, indices into the surviving primary samples
+    dirs: Tensor         # [P, R+1, 3] standard normal (before normalisation / hemisphere flip)
+    noise_normal: Tensor  # [M3, 3] standard normal
+    noise_emit: Tensor    # [M3, 3] standard normal
+
+
+def trilinear_xyz(c: fp.FineConsts, grid: Tensor, pts: Tensor) -> Tensor:
+    """1-channel trilinear interpolant as a differentiable function of the WORLD point
+    (weights before clamping, border-replicated indices: functions.py:153-260)."""
+    g = grid[0, 0]
+    size = [g.shape[0], g.shape[1], g.shape[2]]
+    u = (pts - c.xyz_min) / (c.xyz_max - c.xyz_min)
+    n = u * 2 - 1
+    ix = [((n[:, a] + 1) / 2) * (size[a] - 1) for a in range(3)]
+    with torch.no_grad():
+        i0 = [torch.floor(v) for v in ix]
+    out = 0
+    for dx in (0, 1):
+        for dy in (0, 1):
+            for dz in (0, 1):
+                d = (dx, dy, dz)
+                w = 1
+                idx = []
+                for a in range(3):
+                    w = w * ((ix[a] - i0[a]) if d[a] else ((i0[a] + 1) - ix[a]))
+                    idx.append((i0[a] + d[a]).clamp(0, size[a] - 1).long())
+                out = out + g[idx[0], idx[1], idx[2]] * w
+    return out
+
+
+def sdf_expgrad(c: fp.FineConsts, grid: Tensor, pts: Tensor):
+    """SDF value and its exact spatial gradient (differentiable w.r.t. the grid)."""
+    with torch.enable_grad():
+        p = pts.detach().clone().requires_grad_(True)
+        sdf = trilinear_xyz(c, grid, p)
+        (g,) = torch.autograd.grad(sdf.sum(), p, create_graph=True)
+    return sdf, g
+
+
+def hemisphere_dirs(normal: Tensor, raw: Tensor) -> Tensor:
+    d = F.normalize(raw, dim=-1)
+    flip = (d * normal.unsqueeze(-2)).sum(-1) < 0
+    return torch.where(flip[..., None], -d, d)
+
+
+def disney_reflection(albedo, roughness, metallic, normal, win, wout):
+    eps = 1e-7
+    dot = lambda a, b: (a * b).sum(-1, keepdim=True)
+    h = F.normalize(win + wout, dim=-1)
+    noh, ooh = dot(normal, h).clamp(min=0), dot(wout, h).clamp(min=0)
+    ion, oon = dot(win, normal).clamp(min=0), dot(wout, normal).clamp(min=0)
+    fd = (1 - metallic) * albedo / torch.pi
+    r2 = (roughness * roughness).clamp(min=eps)
+    D = 1 / (r2 * torch.pi) * torch.exp(2 / r2 * (noh - 1))
+    f0 = 0.04 * (1 - metallic) + albedo * metallic
+    Fr = f0 + (1.0 - f0) * ((1.0 - ooh) ** 5)
+
+    def v(cos):
+        k = ((1 + roughness) ** 2) / 8
+        return 0.5 / (cos * (1 - k) + k).clamp(min=eps)
+
+    fs = D * Fr * (v(ion) * v(oon))
+    return (fd + fs) * ion * torch.pi * 2
+
+
+def sg_envmap(P: Dict[str, Tensor], dirs: Tensor) -> Tensor:
+    lobes = F.normalize(P["envmap.lobes"], dim=-1)
+    lam = P["envmap.lambdas"].abs()
+    e = torch.exp(lam * ((dirs.unsqueeze(-2) * lobes).sum(-1, keepdim=True) - 1.0))
+    return F.softplus((P["envmap.mus"] * e).sum(-2))
+
+
+def brdf_net(P, x):
+    o = torch.sigmoid(fp.mlp(P, [f"brdfnet.{k}" for k in BRDF_KEYS], x))
+    return o[:, 0:3], o[:, 3:4], o[:, 4:5]
+
+
+def emit_net(P, x):
+    return F.softplus(fp.mlp(P, [f"emitnet.{k}" for k in BRDF_KEYS], x))
+
+
+def _pe(c: fp.FineConsts, pts: Tensor) -> Tensor:
+    unit = (pts - c.xyz_min) / (c.xyz_max - c.xyz_min)
+    freq = torch.tensor([2.0 ** i for i in range(c.posbase_pe)])
+    e = (unit.unsqueeze(-1) * freq).flatten(-2)
+    return torch.cat([unit, e.sin(), e.cos()], -1)
+
+
+def _view_pe(c: fp.FineConsts, v: Tensor) -> Tensor:
+    freq = torch.tensor([2.0 ** i for i in range(c.viewbase_pe)])
+    e = (v.unsqueeze(-1) * freq).flatten(-2)
+    return torch.cat([e, e.sin(), e.cos()], -1)
+
+
+def _march(P, c: fp.FineConsts, rays_o, rays_d, near, s_val):
+    """sampler -> mask cache -> SDF -> alpha -> thresholds -> weights (voxurff/esrnerf common part)."""
+    N = rays_o.shape[0]
+    stepdist = c.stepsize * c.voxel_size
+    pts, out_box, ray_id = native.sample_pts_on_rays(rays_o.contiguous(), rays_d.contiguous(), c.xyz_min,
+                                                      c.xyz_max, near, 1e9, float(stepdist))[:3]
+    inb = ~out_box
+    pts, ray_id = pts[inb], ray_id[inb]
+    m = fp.mask_cache(c, pts)
+    return N, pts[m], ray_id[m]
+
+
+def _stencil(c, grid, pts):
+    return fp.sdf_stencil(c, grid, pts, c.grad_feat, diff_eps=1e-12)
+
+
+def forward_training(P: Dict[str, Tensor], c: fp.FineConsts, batch: Dict[str, Tensor], s_val: float,
+                     draws: Draws, normal_eps: float, emit_eps: float, num_2ndrays: int, lts_near: float,
+                     pdra_mode: bool = False, keep: Optional[dict] = None) -> Dict[str, Tensor]:
+    rays_o, rays_d, viewdirs = batch["rays_o"], batch["rays_d"], batch["viewdirs"]
+    em_modes, uncert = batch["em_modes"], batch["uncert_masks"]
+    N, pts, ray_id = _march(P, c, rays_o, rays_d, c.near, s_val)
+    sdf, expg = sdf_expgrad(c, P["sdf.grid"], pts)
+    alpha = fp.neus_alpha_interp(sdf, ray_id, s_val)
+    m = alpha > c.fastcolor_thres
+    alpha, pts, ray_id, sdf, expg = alpha[m], pts[m], ray_id[m], sdf[m], expg[m]
+    weights, alphainv_last = fp._Composite.apply(alpha, ray_id, N)
+    m = weights > c.fastcolor_thres
+    weights, pts, ray_id, sdf, expg = weights[m], pts[m], ray_id[m], sdf[m], expg[m]
+
+    on = em_modes[ray_id] == 1
+    feat, _, nrm = _stencil(c, P["sdf.grid"], pts)
+    xyz_pe = _pe(c, pts)
+    vpe = _view_pe(c, viewdirs)[ray_id]
+    common = torch.cat([xyz_pe, vpe, sdf[:, None], feat, nrm], -1)
+    gpts = fp.to_norm(pts, c.xyz_min, c.xyz_max)
+    lin = torch.zeros_like(pts)
+    lin[on] = fp.radiance(P, "emo_rgbnet", torch.cat([fp.sample_grid(P["emo_color.grid"], gpts[on]), common[on]], -1))
+    lin = lin + fp.radiance(P, "off_rgbnet", torch.cat([fp.sample_grid(P["off_color.grid"], gpts), common], -1))
+    rgb = fp.tonemap(P, c, lin)
+    bfeat = torch.cat([xyz_pe, sdf[:, None], feat, nrm], -1)
+    base, rough, metal = brdf_net(P, torch.cat([fp.sample_grid(P["brdf.grid"], gpts), bfeat], -1))
+    emit = emit_net(P, torch.cat([fp.sample_grid(P["emo_color.grid"], gpts), bfeat], -1))
+    w = weights.unsqueeze(-1)
+    zeros = lambda: torch.zeros(N, 3)
+    rgb_m = zeros().index_add(0, ray_id, w * rgb)
+    lin_m = zeros().index_add(0, ray_id, w * lin)
+    emit_m = zeros().index_add(0, ray_id, w * emit)
+    normal = F.normalize(expg.detach(), dim=-1)
+
+    idx = draws.idx
+    lts = light_transport_segment(P, c, pts[idx], viewdirs[ray_id][idx], normal[idx], sdf[idx], base[idx],
+                                  rough[idx], metal[idx], emit[idx], uncert[ray_id][idx], draws.dirs,
+                                  s_val, num_2ndrays, lts_near, pdra_mode)
+    _, expg_eps = sdf_expgrad(c, P["sdf.grid"], pts + draws.noise_normal * normal_eps)
+    pts2 = pts + draws.noise_emit * emit_eps
+    gp2 = fp.to_norm(pts2, c.xyz_min, c.xyz_max)
+    sdf2 = fp.sample_grid(P["sdf.grid"], gp2)[:, 0]
+    feat2, _, nrm2 = _stencil(c, P["sdf.grid"], pts2)
+    bfeat2 = torch.cat([_pe(c, pts2), sdf2[:, None], feat2, nrm2], -1)
+    emit2 = emit_net(P, torch.cat([fp.sample_grid(P["emo_color.grid"], gp2), bfeat2], -1))
+    base2, rough2, metal2 = brdf_net(P, torch.cat([fp.sample_grid(P["brdf.grid"], gp2), bfeat2], -1))
+    if keep is not None:
+        keep.update(m3=pts.shape[0], ray_id=ray_id, pts=pts)
+    return {
+        "etc/alphainv_cum": alphainv_last, "etc/white_bg": alphainv_last[..., None],
+        "srgb/rgb": rgb_m, "lin/rgb": lin_m,
+        "lin/pbr/off": lts["off"], "lin/pbr/off_hat": lts["off_hat"],
+        "lin/pbr/emo": lts["emo"], "lin/pbr/emo_hat": lts["emo_hat"],
+        "etc/emit_uncert": emit_m[uncert], "etc/emit_cert": emit_m[~uncert],
+        "etc/normal": expg, "etc/normal_eps": expg_eps, "etc/emit": emit, "etc/emit_eps": emit2,
+        "etc/brdf": torch.cat([base, rough, metal], -1), "etc/brdf_eps": torch.cat([base2, rough2, metal2], -1),
+    }
+
+
+def light_transport_segment(P, c, pts, viewdirs, normal, sdf, base, rough, metal, emission, umask, raw_dirs,
+                            s_val, R, lts_near, pdra_mode):
+    """Outgoing radiance of P surface points predicted by the radiance nets ("off", "emo", for the
+    camera direction and one random direction) against the rendering equation evaluated with R
+    secondary rays per point ("off_hat", "emo_hat")."""
+    Pn = pts.shape[0]
+    dirs_all = hemisphere_dirs(normal, raw_dirs)
+    v_rand = -dirs_all[:, -1]
+    dirs = dirs_all[:, :-1]
+    feat, _, nrm = _stencil(c, P["sdf.grid"], pts)
+    xyz_pe = _pe(c, pts)
+    vpe = _view_pe(c, torch.cat([viewdirs, v_rand], 0))
+    rep = lambda t: t.repeat([2] + [1] * (t.dim() - 1))
+    common = torch.cat([rep(xyz_pe), vpe, rep(sdf[:, None]), rep(feat), rep(nrm)], -1)
+    gp = fp.to_norm(pts, c.xyz_min, c.xyz_max)
+    off = fp.radiance(P, "off_rgbnet", torch.cat([rep(fp.sample_grid(P["off_color.grid"], gp)), common], -1))
+    emo = fp.radiance(P, "emo_rgbnet", torch.cat([rep(fp.sample_grid(P["emo_color.grid"], gp)), common], -1))
+
+    ex = lambda t: t.view(Pn, 1, -1).expand(Pn, R, t.shape[-1]).flatten(0, 1)
+    o2, v2, vr2, n2 = ex(pts), ex(viewdirs), ex(v_rand), ex(normal)
+    d2 = dirs.flatten(0, 1)
+    Rf = disney_reflection(rep(ex(base)), rep(ex(rough)), rep(ex(metal)), rep(n2), rep(d2),
+                           torch.cat([-v2, -vr2], 0))
+    # incoming radiance along the secondary rays
+    N2, p2, rid = _march(P, c, o2, d2, lts_near, s_val)
+    s2 = fp.sample_grid(P["sdf.grid"], fp.to_norm(p2, c.xyz_min, c.xyz_max))[:, 0]
+    a2 = fp.neus_alpha_interp(s2, rid, s_val) if s2.numel() > 1 else s2.new_zeros(s2.shape)
+    m = a2 > c.fastcolor_thres
+    a2, p2, rid, s2 = a2[m], p2[m], rid[m], s2[m]
+    w2, last2 = fp._Composite.apply(a2, rid, N2)
+    m = w2 > c.fastcolor_thres
+    w2, p2, rid, s2 = w2[m], p2[m], rid[m], s2[m]
+    f2, _, nr2 = _stencil(c, P["sdf.grid"], p2)
+    feat2 = torch.cat([_pe(c, p2), _view_pe(c, d2)[rid], s2[:, None], f2, nr2], -1)
+    g2 = fp.to_norm(p2, c.xyz_min, c.xyz_max)
+    loff = fp.radiance(P, "off_rgbnet", torch.cat([fp.sample_grid(P["off_color.grid"], g2), feat2], -1))
+    lemo = fp.radiance(P, "emo_rgbnet", torch.cat([fp.sample_grid(P["emo_color.grid"], g2), feat2], -1))
+    off_m = torch.zeros(N2, 3).index_add(0, rid, w2[:, None] * loff)
+    emo_m = torch.zeros(N2, 3).index_add(0, rid, w2[:, None] * lemo)
+    env = sg_envmap(P, d2) * last2.unsqueeze(-1)
+    off_hat = (rep(off_m + env) * Rf).view(-1, R, 3).mean(-2)
+    reflect = (rep(emo_m) * Rf).view(-1, R, 3).mean(-2)
+    if pdra_mode:
+        um = rep(umask)
+        emo_hat = torch.where(um[:, None], rep(emission) + reflect.detach(), reflect)
+    else:
+        emo_hat = rep(emission) + reflect
+    return dict(off=off, emo=emo, off_hat=off_hat, emo_hat=emo_hat)
+
+
+def lts_loss(results: Dict[str, Tensor], rgbs: Tensor, white_bg: bool = True, weight_linear: float = 10.0,
+             weight_lts: float = 0.01, weight_entropy_last: float = 0.001, weight_normal_smooth: float = 0.001):
+    """app/fine/lts.py:337-379 (TV terms excluded, as in fine_loss)."""
+    base, aux = fp.fine_loss(results, rgbs, white_bg, weight_linear, weight_entropy_last)
+    l_off = F.mse_loss(results["lin/pbr/off"], results["lin/pbr/off_hat"])
+    l_emo = F.mse_loss(results["lin/pbr/emo"], results["lin/pbr/emo_hat"])
+    l_n = F.l1_loss(results["etc/normal"], results["etc/normal_eps"])
+    return base + weight_lts * (l_off + l_emo) + weight_normal_smooth * l_n, aux
