@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int XROWS = 96;   // rows of an X tile
+constexpr int XROWS = 104;  // rows of an X tile (96 + third colour group at 96-101)
 constexpr int DXROWS = 64;  // rows of a dX tile (0..42 used)
 constexpr int ROW_COL = 0, ROW_SDF = 6, ROW_FEAT = 7, ROW_NRM = 31, ROW_XYZ = 43, ROW_SIN = 46,
               ROW_COS = 61, ROW_VD = 76, ROW_VSIN = 79, ROW_VCOS = 82, ROW_ALT = 88;
@@ -147,6 +147,8 @@ __global__ void __launch_bounds__(256) feat_fwd_kernel(FeatParams P)
         Xt[(ROW_ALT + 6) * 32] = 0.f;
         Xt[(ROW_ALT + 7) * 32] = 0.f;
         Xt[85 * 32] = 0.f; Xt[86 * 32] = 0.f; Xt[87 * 32] = 0.f;
+#pragma unroll
+        for (int r = 96; r < XROWS; ++r) Xt[r * 32] = 0.f;      // third colour group: unused by the fine stage
         Xt[ROW_SDF * 32] = P.rec_sdf[j];
         // 24-tap SDF stencil: reference axis order is (z, y, x) = grid axes (2, 1, 0)
         float grad[3][4];

@@ -32,9 +32,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int HID_TILES = 6;          // 192 hidden features
-constexpr int HID = 192;
-constexpr int HKP = 96;               // k-pairs of a 192-wide hidden layer
+constexpr int MAX_HID_TILES = 6;      // widest hidden layer: 192 features
 
 // feature index a (k-pair p, lane half h) register slot stands for in a hidden layer
 __host__ __device__ constexpr int hid_feature(int p, int h)
@@ -50,16 +48,34 @@ struct NetDesc {
     int in_dim, in_kp;      // reference input width, k-pairs of the first layer (multiple of 4)
     int xrows;              // rows of the input tile
     int out_dim;
+    int hid_tiles;          // hidden width / 32
+    int zrows;              // rows of the output / output-gradient tile (4 or 8)
 };
+constexpr int X_ROWS = 104; // feature tile: 96 rows + a third colour group (rows 96-101)
 __host__ __device__ constexpr NetDesc net_desc(int kind)
 {
-    return kind == ESR_MLP_RADIANCE ? NetDesc{4, 85, 48, 96, 3} : NetDesc{2, 33, 24, 48, 3};
+    return kind == ESR_MLP_RADIANCE ? NetDesc{4, 85, 48, X_ROWS, 3, 6, 4}      // pbr/module.py:6-21
+         : kind == ESR_MLP_TONEMAP  ? NetDesc{2, 33, 24, 48, 3, 6, 4}          // pbr/module.py:24-39
+         : kind == ESR_MLP_BRDF     ? NetDesc{4, 76, 40, X_ROWS, 5, 4, 8}      // pbr/module.py:42-65
+         :                            NetDesc{4, 76, 40, X_ROWS, 3, 4, 4};     // EmissionNet, pbr/module.py:68-83
 }
+__host__ __device__ constexpr bool kind_ok(int kind) { return kind >= 0 && kind <= ESR_MLP_EMIT; }
 
 // X-tile row -> column of the reference's first-layer weight (-1: no column)
 __host__ __device__ inline int in_colmap(int kind, int row)
 {
     if (kind == ESR_MLP_TONEMAP) return row < 33 ? row : -1;
+    if (kind == ESR_MLP_BRDF || kind == ESR_MLP_EMIT) {
+        // reference order (esrnerf.py:761-765): colour6 | xyz3 sin15 cos15 | sdf | feat24 | normal12
+        if (row < 6) return row;
+        if (row == 6) return 39;
+        if (row < 31) return 40 + (row - 7);
+        if (row < 43) return 64 + (row - 31);
+        if (row < 46) return 6 + (row - 43);
+        if (row < 61) return 9 + (row - 46);
+        if (row < 76) return 24 + (row - 61);
+        return -1;                           // no view-direction input
+    }
     if (row < 6) return row;                 // colour
     if (row == 6) return 48;                 // sdf
     if (row < 31) return 49 + (row - 7);     // feat24
@@ -89,12 +105,13 @@ __host__ __device__ constexpr PackLayout pack_layout(int kind)
     int64_t o = 0;
     for (int l = 0; l < d.n_layers; ++l) {
         const bool first = l == 0, last = l == d.n_layers - 1;
-        L.kp[l] = first ? d.in_kp : HKP;
-        L.in_dim[l] = first ? d.in_dim : HID;
-        L.out_dim[l] = last ? d.out_dim : HID;
-        L.tiles_out[l] = last ? 1 : HID_TILES;
-        L.kpo[l] = last ? 4 : HKP;                       // contraction pairs of the transposed product
-        L.tiles_in[l] = first ? 2 : HID_TILES;           // dX: rows 0..63 only
+        const int hkp = 16 * d.hid_tiles, hid = 32 * d.hid_tiles;
+        L.kp[l] = first ? d.in_kp : hkp;
+        L.in_dim[l] = first ? d.in_dim : hid;
+        L.out_dim[l] = last ? d.out_dim : hid;
+        L.tiles_out[l] = last ? 1 : d.hid_tiles;
+        L.kpo[l] = last ? 4 : hkp;                       // contraction pairs of the transposed product
+        L.tiles_in[l] = first ? 2 : d.hid_tiles;         // dX: rows 0..63 only
         L.off_wf[l] = o; o += (int64_t)L.tiles_out[l] * L.kp[l] * 64;
         L.off_bf[l] = o; o += (int64_t)L.tiles_out[l] * 32;
         L.off_wb[l] = o; o += (int64_t)L.tiles_in[l] * L.kpo[l] * 64;
@@ -225,12 +242,12 @@ __device__ __forceinline__ void layer_from_regs(rsrc_t W, int woff, const float 
     stream_layer<KP / 4, NT>(W, woff, [&](int k) { return B[k]; }, acc, lane);
 }
 
-// acc[it] += Wp[it] . prev    prev = accumulator tiles of the previous layer (192 features)
-template <int NT>
-__device__ __forceinline__ void layer_from_acc(rsrc_t W, int woff, const f32x16 (&prev)[HID_TILES],
+// acc[it] += Wp[it] . prev    prev = NP accumulator tiles of the previous layer (32*NP features)
+template <int NP, int NT>
+__device__ __forceinline__ void layer_from_acc(rsrc_t W, int woff, const f32x16 (&prev)[NP],
                                                f32x16 (&acc)[NT], int lane)
 {
-    stream_layer<HKP / 4, NT>(W, woff, [&](int k) { return prev[k >> 4][k & 15]; }, acc, lane);
+    stream_layer<NP * 4, NT>(W, woff, [&](int k) { return prev[k >> 4][k & 15]; }, acc, lane);
 }
 
 // bias (packed in accumulator order at byte offset boff)
@@ -317,7 +334,6 @@ __device__ __forceinline__ void apply_relu_mask(const unsigned (&m)[NT / 2], f32
         for (int r = 0; r < 16; ++r)
             acc[it][r] = ((m[it >> 1] >> ((it & 1) * 16 + r)) & 1u) ? acc[it][r] : 0.f;
 }
-constexpr unsigned MASK_TILE_BYTES = (HID_TILES / 2) * 64 * 4;     // per tile per layer
 
 template <int NT>
 __device__ __forceinline__ void zero_tiles(f32x16 (&acc)[NT])
@@ -328,14 +344,12 @@ __device__ __forceinline__ void zero_tiles(f32x16 (&acc)[NT])
         for (int r = 0; r < 16; ++r) acc[it][r] = 0.f;
 }
 
-constexpr unsigned HID_TILE_BYTES = HID * 32 * 4;
-
 struct FwdArgs {
     const float *packed, *X;
     int t0, t1;
     float *H[3];
     unsigned *M[3];
-    int save, alt;
+    int save, crow;            // crow: X row of the 6-row colour group this net reads (0, 88 or 96)
     float *zout;
 };
 
@@ -345,6 +359,8 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
     constexpr NetDesc D = net_desc(KIND);
     constexpr int NHID = D.n_layers - 1;
     constexpr int KP1 = D.in_kp;
+    constexpr int HT = D.hid_tiles;
+    constexpr unsigned HBYTES = HT * 32 * 32 * 4, MBYTES = (HT / 2) * 256;
     constexpr PackLayout L = pack_layout(KIND);
     const int lane = esr_lane();
     const int h = lane >> 5, s = lane & 31;
@@ -354,37 +370,41 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
     for (int t = A.t0 + wave; t < A.t1; t += nwaves) {
         const rsrc_t RX = make_rsrc(A.X + (size_t)t * D.xrows * 32, D.xrows * 32 * 4);
         const int xvoff = (h * 32 + s) * 4;
-        const int alt_off = (KIND == ESR_MLP_RADIANCE && A.alt) ? 88 * 128 : 0;
+        const int coff = A.crow * 128;
         float B1[KP1];
 #pragma unroll
         for (int p = 0; p < KP1; ++p)
-            B1[p] = bload1(RX, xvoff, 2 * p * 128 + ((2 * p < 6) ? alt_off : 0));
-        f32x16 cur[HID_TILES];
-        load_bias<HID_TILES>(W, (int)L.off_bf[0] * 4, cur, lane);
-        layer_from_regs<KP1, HID_TILES>(W, (int)L.off_wf[0] * 4, B1, cur, lane);
-        relu_tiles<HID_TILES>(cur);
+            B1[p] = bload1(RX, xvoff, 2 * p * 128 + ((2 * p < 6) ? coff : 0));
+        f32x16 cur[HT];
+        load_bias<HT>(W, (int)L.off_bf[0] * 4, cur, lane);
+        layer_from_regs<KP1, HT>(W, (int)L.off_wf[0] * 4, B1, cur, lane);
+        relu_tiles<HT>(cur);
         if (A.save) {
-            store_tiles<HID_TILES>(make_rsrc(A.H[0] + (size_t)t * HID * 32, HID_TILE_BYTES), cur, lane);
-            store_relu_mask<HID_TILES>(make_rsrc(A.M[0] + (size_t)t * (MASK_TILE_BYTES / 4), MASK_TILE_BYTES), cur, lane);
+            store_tiles<HT>(make_rsrc(A.H[0] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
+            store_relu_mask<HT>(make_rsrc(A.M[0] + (size_t)t * (MBYTES / 4), MBYTES), cur, lane);
         }
 #pragma unroll
         for (int l = 1; l < NHID; ++l) {
-            f32x16 nxt[HID_TILES];
-            load_bias<HID_TILES>(W, (int)L.off_bf[l] * 4, nxt, lane);
-            layer_from_acc<HID_TILES>(W, (int)L.off_wf[l] * 4, cur, nxt, lane);
-            relu_tiles<HID_TILES>(nxt);
+            f32x16 nxt[HT];
+            load_bias<HT>(W, (int)L.off_bf[l] * 4, nxt, lane);
+            layer_from_acc<HT, HT>(W, (int)L.off_wf[l] * 4, cur, nxt, lane);
+            relu_tiles<HT>(nxt);
             if (A.save) {
-                store_tiles<HID_TILES>(make_rsrc(A.H[l] + (size_t)t * HID * 32, HID_TILE_BYTES), nxt, lane);
-                store_relu_mask<HID_TILES>(make_rsrc(A.M[l] + (size_t)t * (MASK_TILE_BYTES / 4), MASK_TILE_BYTES), nxt, lane);
+                store_tiles<HT>(make_rsrc(A.H[l] + (size_t)t * (HBYTES / 4), HBYTES), nxt, lane);
+                store_relu_mask<HT>(make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), nxt, lane);
             }
 #pragma unroll
-            for (int it = 0; it < HID_TILES; ++it) cur[it] = nxt[it];
+            for (int it = 0; it < HT; ++it) cur[it] = nxt[it];
         }
         f32x16 out[1];
         load_bias<1>(W, (int)L.off_bf[NHID] * 4, out, lane);
-        layer_from_acc<1>(W, (int)L.off_wf[NHID] * 4, cur, out, lane);
-        if (h == 0) {                       // rows 0..3 of the output tile live in lanes 0-31, regs 0-3
-            float *z = A.zout + (size_t)t * 4 * 32 + s;
+        layer_from_acc<HT, 1>(W, (int)L.off_wf[NHID] * 4, cur, out, lane);
+        // output rows 0-3 live in lanes 0-31 (regs 0-3), rows 4-7 in lanes 32-63 (regs 0-3)
+        float *z = A.zout + (size_t)t * D.zrows * 32 + s;
+        if (D.zrows == 8) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[(4 * h + r) * 32] = out[0][r];
+        } else if (h == 0) {
             z[0] = out[0][0]; z[32] = out[0][1]; z[64] = out[0][2]; z[96] = 0.f;
         }
     }
@@ -403,6 +423,8 @@ __global__ void __launch_bounds__(256, 2) mlp_dgrad_kernel(DgradArgs A)
 {
     constexpr NetDesc D = net_desc(KIND);
     constexpr int NHID = D.n_layers - 1;
+    constexpr int HT = D.hid_tiles;
+    constexpr unsigned HBYTES = HT * 32 * 32 * 4, MBYTES = (HT / 2) * 256;
     constexpr PackLayout L = pack_layout(KIND);
     const int lane = esr_lane();
     const int h = lane >> 5, s = lane & 31;
@@ -410,30 +432,32 @@ __global__ void __launch_bounds__(256, 2) mlp_dgrad_kernel(DgradArgs A)
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const rsrc_t W = make_rsrc(A.packed, (unsigned)(L.total * 4));
     for (int t = A.t0 + wave; t < A.t1; t += nwaves) {
-        const float *dzt = A.dz + (size_t)t * 4 * 32 + s;
-        float B0[4] = {dzt[(0 + h) * 32], dzt[(2 + h) * 32], 0.f, 0.f};   // pair p <-> rows 2p, 2p+1
-        unsigned msk[NHID][HID_TILES / 2];                                   // all layers' ReLU masks up front
+        const float *dzt = A.dz + (size_t)t * D.zrows * 32 + s;
+        float B0[4];                                                         // pair p <-> rows 2p, 2p+1
+#pragma unroll
+        for (int p = 0; p < 4; ++p) B0[p] = (2 * p < D.zrows) ? dzt[(2 * p + h) * 32] : 0.f;
+        unsigned msk[NHID][HT / 2];                                          // all layers' ReLU masks up front
 #pragma unroll
         for (int l = 0; l < NHID; ++l)
-            load_relu_mask<HID_TILES>(make_rsrc(A.M[l] + (size_t)t * (MASK_TILE_BYTES / 4), MASK_TILE_BYTES), msk[l], lane);
-        f32x16 cur[HID_TILES];
-        zero_tiles<HID_TILES>(cur);
-        layer_from_regs<4, HID_TILES>(W, (int)L.off_wb[NHID] * 4, B0, cur, lane);
-        apply_relu_mask<HID_TILES>(msk[NHID - 1], cur);
-        store_tiles<HID_TILES>(make_rsrc(A.dZ[NHID - 1] + (size_t)t * HID * 32, HID_TILE_BYTES), cur, lane);
+            load_relu_mask<HT>(make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), msk[l], lane);
+        f32x16 cur[HT];
+        zero_tiles<HT>(cur);
+        layer_from_regs<4, HT>(W, (int)L.off_wb[NHID] * 4, B0, cur, lane);
+        apply_relu_mask<HT>(msk[NHID - 1], cur);
+        store_tiles<HT>(make_rsrc(A.dZ[NHID - 1] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
 #pragma unroll
         for (int l = NHID - 1; l >= 1; --l) {
-            f32x16 nxt[HID_TILES];
-            zero_tiles<HID_TILES>(nxt);
-            layer_from_acc<HID_TILES>(W, (int)L.off_wb[l] * 4, cur, nxt, lane);
-            apply_relu_mask<HID_TILES>(msk[l - 1], nxt);
-            store_tiles<HID_TILES>(make_rsrc(A.dZ[l - 1] + (size_t)t * HID * 32, HID_TILE_BYTES), nxt, lane);
+            f32x16 nxt[HT];
+            zero_tiles<HT>(nxt);
+            layer_from_acc<HT, HT>(W, (int)L.off_wb[l] * 4, cur, nxt, lane);
+            apply_relu_mask<HT>(msk[l - 1], nxt);
+            store_tiles<HT>(make_rsrc(A.dZ[l - 1] + (size_t)t * (HBYTES / 4), HBYTES), nxt, lane);
 #pragma unroll
-            for (int it = 0; it < HID_TILES; ++it) cur[it] = nxt[it];
+            for (int it = 0; it < HT; ++it) cur[it] = nxt[it];
         }
         f32x16 dx[2];
         zero_tiles<2>(dx);
-        layer_from_acc<2>(W, (int)L.off_wb[0] * 4, cur, dx, lane);
+        layer_from_acc<HT, 2>(W, (int)L.off_wb[0] * 4, cur, dx, lane);
         store_tiles<2>(make_rsrc(A.dX + (size_t)t * 64 * 32, 64 * 32 * 4), dx, lane);
     }
 }
@@ -447,6 +471,8 @@ struct WgradArgs {
     int kind; int first;         // column map: first layer uses in_colmap(kind, row)
     float *gb;
     float *slab;                 // [gridDim.x * WK][out_rows][ld] partial sums
+    int b_tile_rows;             // rows per B tile in memory (>= RB; the X tile has extra colour rows)
+    int crow;                    // first layer: B rows 0-5 are read from X rows crow..crow+5
 };
 
 // Cooperative weight-gradient kernel.  One workgroup covers the WHOLE dW of a layer:
@@ -499,11 +525,16 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradAr
         const bool live = t < W.t1;
         const int tc = live ? t : W.t0;
         const rsrc_t SA = make_rsrc(W.A + (size_t)tc * W.RA * 32, live ? (unsigned)W.RA * 128u : 0u);
-        const rsrc_t SB = make_rsrc(W.B + (size_t)tc * W.RB * 32, live ? (unsigned)W.RB * 128u : 0u);
+        const rsrc_t SB = make_rsrc(W.B + (size_t)tc * W.b_tile_rows * 32, live ? (unsigned)W.b_tile_rows * 128u : 0u);
 #pragma unroll
         for (int k = 0; k < LA; ++k) ra[k] = bload4(SA, (tid + k * NT) * 16, 0);
 #pragma unroll
-        for (int k = 0; k < LB; ++k) rb_[k] = bload4(SB, (tid + k * NT) * 16, 0);
+        for (int k = 0; k < LB; ++k) {
+            const int q = tid + k * NT;                                  // float4 index: row q/8
+            // rows 0-5 of a first layer come from the net's colour group of the X tile
+            const int src = (q < 48) ? q + W.crow * 8 : q;
+            rb_[k] = bload4(SB, src * 16, 0);       // (tiles shorter than the staged block read as zero)
+        }
     };
     auto commit = [&](int buf, const float4 (&ra)[LA], const float4 (&rb_)[LB]) {
         float *La = lds + buf * BUF, *Lb = La + RAP * LDS_STRIDE;
@@ -650,13 +681,13 @@ int launch_wgrad(const WgradArgs &W, int64_t slab_floats, hipStream_t s)
 
 ESR_API int64_t esr_mlp_packed_floats(int kind)
 {
-    if (kind != ESR_MLP_RADIANCE && kind != ESR_MLP_TONEMAP) return ESR_EINVAL;
+    if (!kind_ok(kind)) return ESR_EINVAL;
     return pack_layout(kind).total;
 }
 
 ESR_API int esr_mlp_pack(int kind, const esr_mlp_weights_t *w, float *packed, void *stream)
 {
-    if ((kind != ESR_MLP_RADIANCE && kind != ESR_MLP_TONEMAP) || !w || !packed) return ESR_EINVAL;
+    if (!kind_ok(kind) || !w || !packed) return ESR_EINVAL;
     PackArgs A = {};
     A.kind = kind;
     const int nl = net_desc(kind).n_layers;
@@ -672,15 +703,16 @@ ESR_API int esr_mlp_pack(int kind, const esr_mlp_weights_t *w, float *packed, vo
 }
 
 ESR_API int esr_mlp_fwd(int kind, const float *packed, const float *X, int32_t t0, int32_t t1,
-                        float *const *H, uint32_t *const *M, int save, int alt_color, float *zout,
+                        float *const *H, uint32_t *const *M, int save, int color_row0, float *zout,
                         void *stream)
 {
-    if ((kind != ESR_MLP_RADIANCE && kind != ESR_MLP_TONEMAP) || t0 < 0 || t1 < t0) return ESR_EINVAL;
+    if (!kind_ok(kind) || t0 < 0 || t1 < t0) return ESR_EINVAL;
+    if (color_row0 != 0 && color_row0 != 88 && color_row0 != 96) return ESR_EINVAL;
     if (t1 == t0) return 0;
     if (!packed || !X || !zout) return ESR_EINVAL;
     const int nhid = net_desc(kind).n_layers - 1;
     FwdArgs A = {};
-    A.packed = packed; A.X = X; A.t0 = t0; A.t1 = t1; A.save = save ? 1 : 0; A.alt = alt_color ? 1 : 0;
+    A.packed = packed; A.X = X; A.t0 = t0; A.t1 = t1; A.save = save ? 1 : 0; A.crow = color_row0;
     A.zout = zout;
     if (save) {
         if (!H || !M) return ESR_EINVAL;
@@ -691,8 +723,13 @@ ESR_API int esr_mlp_fwd(int kind, const float *packed, const float *X, int32_t t
         }
     }
     const int grid = mlp_grid(t1 - t0);
-    if (kind == ESR_MLP_RADIANCE) mlp_fwd_kernel<ESR_MLP_RADIANCE><<<grid, 256, 0, esr_stream(stream)>>>(A);
-    else mlp_fwd_kernel<ESR_MLP_TONEMAP><<<grid, 256, 0, esr_stream(stream)>>>(A);
+    hipStream_t s = esr_stream(stream);
+    switch (kind) {
+    case ESR_MLP_RADIANCE: mlp_fwd_kernel<ESR_MLP_RADIANCE><<<grid, 256, 0, s>>>(A); break;
+    case ESR_MLP_TONEMAP:  mlp_fwd_kernel<ESR_MLP_TONEMAP><<<grid, 256, 0, s>>>(A); break;
+    case ESR_MLP_BRDF:     mlp_fwd_kernel<ESR_MLP_BRDF><<<grid, 256, 0, s>>>(A); break;
+    default:               mlp_fwd_kernel<ESR_MLP_EMIT><<<grid, 256, 0, s>>>(A); break;
+    }
     ESR_CHECK_LAUNCH();
     return 0;
 }
@@ -700,7 +737,7 @@ ESR_API int esr_mlp_fwd(int kind, const float *packed, const float *X, int32_t t
 ESR_API int esr_mlp_dgrad(int kind, const float *packed, const float *dz, int32_t t0, int32_t t1,
                           const uint32_t *const *M, float *const *dZ, float *dX, void *stream)
 {
-    if ((kind != ESR_MLP_RADIANCE && kind != ESR_MLP_TONEMAP) || t0 < 0 || t1 < t0) return ESR_EINVAL;
+    if (!kind_ok(kind) || t0 < 0 || t1 < t0) return ESR_EINVAL;
     if (t1 == t0) return 0;
     if (!packed || !dz || !M || !dZ || !dX) return ESR_EINVAL;
     const int nhid = net_desc(kind).n_layers - 1;
@@ -711,43 +748,56 @@ ESR_API int esr_mlp_dgrad(int kind, const float *packed, const float *dz, int32_
         A.M[l] = M[l]; A.dZ[l] = dZ[l];
     }
     const int grid = mlp_grid(t1 - t0);
-    if (kind == ESR_MLP_RADIANCE) mlp_dgrad_kernel<ESR_MLP_RADIANCE><<<grid, 256, 0, esr_stream(stream)>>>(A);
-    else mlp_dgrad_kernel<ESR_MLP_TONEMAP><<<grid, 256, 0, esr_stream(stream)>>>(A);
+    hipStream_t s = esr_stream(stream);
+    switch (kind) {
+    case ESR_MLP_RADIANCE: mlp_dgrad_kernel<ESR_MLP_RADIANCE><<<grid, 256, 0, s>>>(A); break;
+    case ESR_MLP_TONEMAP:  mlp_dgrad_kernel<ESR_MLP_TONEMAP><<<grid, 256, 0, s>>>(A); break;
+    case ESR_MLP_BRDF:     mlp_dgrad_kernel<ESR_MLP_BRDF><<<grid, 256, 0, s>>>(A); break;
+    default:               mlp_dgrad_kernel<ESR_MLP_EMIT><<<grid, 256, 0, s>>>(A); break;
+    }
     ESR_CHECK_LAUNCH();
     return 0;
 }
 
-ESR_API int64_t esr_mlp_wgrad_scratch_floats(void) { return (int64_t)256 * 2 * HID * HID; }
+ESR_API int64_t esr_mlp_wgrad_scratch_floats(void) { return (int64_t)256 * 2 * 192 * 192; }
 
-ESR_API int esr_mlp_wgrad(int kind, const float *X, int alt_color, const float *const *H,
+ESR_API int esr_mlp_wgrad(int kind, const float *X, int color_row0, const float *const *H,
                           const float *const *dZ, const float *dz, int32_t t0, int32_t t1,
                           float *const *gw, float *const *gb, float *scratch, int64_t scratch_floats,
                           void *stream)
 {
-    (void)alt_color;   // gradients only ever flow through the main colour rows
-    if ((kind != ESR_MLP_RADIANCE && kind != ESR_MLP_TONEMAP) || t0 < 0 || t1 < t0) return ESR_EINVAL;
+    if (!kind_ok(kind) || t0 < 0 || t1 < t0) return ESR_EINVAL;
+    if (color_row0 != 0 && color_row0 != 88 && color_row0 != 96) return ESR_EINVAL;
     if (t1 == t0) return 0;
     if (!X || !H || !dZ || !dz || !gw || !gb || !scratch) return ESR_EINVAL;
     const NetDesc D = net_desc(kind);
-    const int nhid = D.n_layers - 1;
+    const int hid = 32 * D.hid_tiles;
     hipStream_t s = esr_stream(stream);
     for (int l = 0; l < D.n_layers; ++l) {
         const bool first = l == 0, last = l == D.n_layers - 1;
         WgradArgs W = {};
-        W.A = last ? dz : dZ[l];          W.RA = last ? 4 : HID;
-        W.B = first ? X : H[l - 1];       W.RB = first ? D.xrows : HID;
+        W.A = last ? dz : dZ[l];          W.RA = last ? D.zrows : hid;
+        W.B = first ? X : H[l - 1];       W.RB = first ? (D.xrows < 96 ? D.xrows : 96) : hid;
+        W.b_tile_rows = first ? D.xrows : hid;
+        W.crow = first ? color_row0 : 0;
         W.t0 = t0; W.t1 = t1;
-        W.gw = gw[l]; W.ld = first ? D.in_dim : HID; W.out_rows = last ? D.out_dim : HID;
+        W.gw = gw[l]; W.ld = first ? D.in_dim : hid; W.out_rows = last ? D.out_dim : hid;
         W.kind = kind; W.first = first ? 1 : 0; W.gb = gb[l]; W.slab = scratch;
         if (!W.A || !W.B || !W.gw || !W.gb) return ESR_EINVAL;
-        // waves per workgroup (wm x wn x wk): 192x192 -> 2x2x2, 192x<=96 (first layer) -> 2x1x4,
-        // 4x192 (output layer) -> 1x2x4; always 8 waves = 2 per SIMD
+        // waves per workgroup (wm x wn x wk), always 4 waves = 1 per SIMD:
+        //   192-wide nets: 192x192 -> 2x2x1, 192x<=96 (first layer) -> 2x1x2, zrows x 192 (output) -> 1x2x2
+        //   128-wide nets: 128x128 -> 2x2x1, 128x96 -> 2x1x2, 8x128 -> 1x2x2
         int rc;
-        if (last) rc = launch_wgrad<1, 3, 1, 2, 2>(W, scratch_floats, s);
-        else if (first) rc = launch_wgrad<3, 3, 2, 1, 2>(W, scratch_floats, s);     // input tiles have <= 96 rows
-        else rc = launch_wgrad<3, 3, 2, 2, 1>(W, scratch_floats, s);
+        if (D.hid_tiles == 6) {
+            if (last) rc = launch_wgrad<1, 3, 1, 2, 2>(W, scratch_floats, s);
+            else if (first) rc = launch_wgrad<3, 3, 2, 1, 2>(W, scratch_floats, s);
+            else rc = launch_wgrad<3, 3, 2, 2, 1>(W, scratch_floats, s);
+        } else {
+            if (last) rc = launch_wgrad<1, 2, 1, 2, 2>(W, scratch_floats, s);
+            else if (first) rc = launch_wgrad<2, 3, 2, 1, 2>(W, scratch_floats, s);
+            else rc = launch_wgrad<2, 2, 2, 2, 1>(W, scratch_floats, s);
+        }
         if (rc) return rc;
     }
-    (void)nhid;
     return 0;
 }

@@ -25,7 +25,7 @@ from . import _lib
 
 KIND_RADIANCE, KIND_TONEMAP = 0, 1
 HID = 192
-X_ROWS, DX_ROWS, XT_ROWS = 96, 64, 48
+X_ROWS, DX_ROWS, XT_ROWS = 104, 64, 48
 
 
 def make_scene(xyz_min, xyz_max, mask_min, mask_max, world_size, mask_size, near, stepdist,
@@ -208,7 +208,7 @@ class FineEngine:
         H, M = self._H(["H0", "H1", "H2"]), self._H(["M0", "M1", "M2"])
         # off net: detached pass on the on-tiles (alt colour rows, nothing saved), saved pass on the off-tiles
         self._run("mlp_fwd(off|on-tiles)", L.esr_mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), 0, tiles_on,
-                                 H, M, 0, 1, _lib.ptr(ws["z_off"]), s)
+                                 H, M, 0, 88, _lib.ptr(ws["z_off"]), s)
         self._run("mlp_fwd(off)", L.esr_mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), tiles_on,
                                  tiles_all, H, M, 1, 0, _lib.ptr(ws["z_off"]), s)
         self._run("mlp_fwd(emo)", L.esr_mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["emo"]), _lib.ptr(ws["X"]), 0, tiles_on,

@@ -179,10 +179,11 @@ int esr_fine_march_bwd(const esr_scene_t *scene, const float *rays_o, const floa
 /*
  * Per-sample feature assembly (voxurff.py:219-254 + :678-721 + module.py:24-35).
  * Colour grids are channel-last [gx,gy,gz,6] (torch.channels_last_3d storage of
- * the reference's [1,6,X,Y,Z] parameter).  X [n_tiles,96,32] f32, rows:
+ * the reference's [1,6,X,Y,Z] parameter).  X [n_tiles,104,32] f32, rows:
  *   0-5 colour (emo grid on on-tiles, off grid on off-tiles) | 6 sdf | 7-30 feat24
  *   | 31-42 normal12 | 43-45 xyz | 46-60 sin | 61-75 cos | 76-84 viewdir PE
  *   | 85-87 zero | 88-93 off colour (on-tiles only) | 94-95 zero
+ * Tiles have 104 rows: rows 96-101 are a third colour group (BRDF grid of the LTS stage).
  * gnorm [n_tiles,4,32]: |grad| per stencil radius, kept for the backward.
  */
 int esr_fine_feat_fwd(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
@@ -204,8 +205,10 @@ int esr_fine_feat_bwd(const esr_scene_t *scene, const float *rays_o, const float
  * Weights are the reference's nn.Linear tensors ([out,in] row-major) packed by
  * esr_mlp_pack into MFMA operand order.
  */
-#define ESR_MLP_RADIANCE 0
-#define ESR_MLP_TONEMAP  1
+#define ESR_MLP_RADIANCE 0   /* 85-192-192-192-3, softplus applied by the caller kernels   */
+#define ESR_MLP_TONEMAP  1   /* 33-192-3                                                  */
+#define ESR_MLP_BRDF     2   /* BRDFNet 76-128-128-128-5 (app/utils/pbr/module.py:42-65)  */
+#define ESR_MLP_EMIT     3   /* EmissionNet 76-128-128-128-3 (app/utils/pbr/module.py:68-83) */
 #define ESR_MLP_MAX_LAYERS 4
 
 typedef struct esr_mlp_weights {       /* [host] struct of device pointers */
@@ -221,11 +224,12 @@ int esr_mlp_pack(int kind, const esr_mlp_weights_t *w, float *packed, void *stre
  * With save != 0 every hidden layer l keeps H[l] [tiles,192,32] (read by the weight
  * gradient) and its ReLU sign bits M[l] [tiles,3,64] u32 (read by the input gradient:
  * 768 B per tile instead of 24 KB).  zout [tiles,4,32]: pre-activation outputs
- * (row 3 = 0).  alt_color != 0 makes the radiance net read rows 88-93 instead of 0-5
- * (off net on emissive-on tiles).
+ * (row 3 = 0; [tiles,8,32] for the 5-output BRDF net).  Hidden tiles are [tiles,128,32]
+ * and masks [tiles,2,64] for the 128-wide nets.  color_row0 (0, 88 or 96) selects which
+ * 6-row colour group of the X tile feeds the first 6 inputs.
  */
 int esr_mlp_fwd(int kind, const float *packed, const float *X, int32_t t0, int32_t t1,
-                float *const *H, uint32_t *const *M, int save, int alt_color, float *zout,
+                float *const *H, uint32_t *const *M, int save, int color_row0, float *zout,
                 void *stream);
 
 /*
@@ -241,7 +245,7 @@ int esr_mlp_dgrad(int kind, const float *packed, const float *dz, int32_t t0, in
  * device workspace for the per-workgroup partial slabs (summed by a second kernel).
  */
 int64_t esr_mlp_wgrad_scratch_floats(void);
-int esr_mlp_wgrad(int kind, const float *X, int alt_color, const float *const *H,
+int esr_mlp_wgrad(int kind, const float *X, int color_row0, const float *const *H,
                   const float *const *dZ, const float *dz, int32_t t0, int32_t t1,
                   float *const *gw, float *const *gb, float *scratch, int64_t scratch_floats,
                   void *stream);
