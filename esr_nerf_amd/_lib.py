@@ -33,6 +33,17 @@ class EsrPlan(C.Structure):
                 ("n_on", "n_off", "tiles_on", "tiles_all", "m0", "m1", "m2", "overflow")]
 
 
+class EsrLtsArgs(C.Structure):
+    _fields_ = [("n_pts", C.c_int32), ("n_rays", C.c_int32), ("n_sg", C.c_int32), ("pdra_mode", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("base", "rough", "metal", "normal", "view", "dirs", "off_m", "emo_m",
+                                          "last2", "mus", "lambdas", "lobes", "emission", "umask")]
+
+
+class EsrLtsGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("d_off_m", "d_emo_m", "d_last2", "d_base", "d_rough", "d_metal",
+                                          "d_emission", "d_mus", "d_lambdas", "d_lobes")]
+
+
 class EsrMlpWeights(C.Structure):
     _fields_ = [("w", C.c_void_p * 4), ("b", C.c_void_p * 4)]
 
@@ -48,6 +59,7 @@ EXPORTS = [
     "esr_mlp_wgrad_scratch_floats",
     "esr_fine_tone_in_fwd", "esr_fine_composite_fwd", "esr_fine_composite_bwd",
     "esr_fine_tone_in_bwd", "esr_fine_loss_fwd_bwd",
+    "esr_expgrad_fwd", "esr_expgrad_bwd", "esr_lts_dirs", "esr_lts_combine_fwd", "esr_lts_combine_bwd",
 ]
 
 

@@ -292,6 +292,65 @@ int esr_fine_loss_fwd_bwd(const float *srgb_marched, const float *lin_marched,
                           float *loss, float *g_srgb, float *g_lin, float *g_last,
                           void *stream);
 
+/* ------------------------------------------------------------------------- *
+ * C. Light-transport-segment (LTS / PDRA) stage ops
+ *    (ESRNeRF.forward_training, app/fine/model/esrnerf.py:486-851).
+ * ------------------------------------------------------------------------- */
+
+/*
+ * Exact spatial gradient of the trilinear SDF interpolant -- replaces sample_sdf_expgrad
+ * (esrnerf.py:1572-1596: autograd through differentiable_grid_sample,
+ * app/utils/base/functions.py:142-309) by its closed form.  Points are either the
+ * march records (rec_ray/rec_step, pts == NULL; padding records give zeros) or explicit
+ * pts [n,3]; optional noise [n,3] * eps is added (the *_eps re-evaluations,
+ * esrnerf.py:807-810).  out [n,4] = (sdf, d/dx, d/dy, d/dz) in WORLD xyz order.
+ */
+int esr_expgrad_fwd(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                    const int32_t *rec_ray, const int32_t *rec_step, const float *pts,
+                    const float *noise, float eps, const float *sdf, int32_t n, float *out,
+                    void *stream);
+/* g [n,4] -> atomic scatter into grad_sdf [gx,gy,gz] (the op is linear in the grid). */
+int esr_expgrad_bwd(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                    const int32_t *rec_ray, const int32_t *rec_step, const float *pts,
+                    const float *noise, float eps, const float *g, int32_t n, float *grad_sdf,
+                    void *stream);
+
+/*
+ * Hemisphere directions -- replaces diffuse_scattering (app/utils/pbr/functions.py:10-18)
+ * given the standard-normal draws: normalise, flip into the hemisphere of `normal`.
+ * raw, dirs [n_pts, rays_plus_one, 3]; normal [n_pts,3].
+ */
+int esr_lts_dirs(const float *raw, const float *normal, int32_t n_pts, int32_t rays_plus_one,
+                 float *dirs, void *stream);
+
+/*
+ * Rendering-equation estimate at n_pts surface points with n_rays secondary rays each
+ * (esrnerf.py:565-572 disney_reflection, :653-677 env term, means, emo_hat; pbr/module.py:133-143
+ * spherical-Gaussian env map; pbr/functions.py:108-173).  The two "copies" are the camera view
+ * direction and the random one (-dirs[:, n_rays]).  All arrays row-major device memory.
+ */
+typedef struct esr_lts_args {
+    int32_t n_pts, n_rays, n_sg, pdra_mode;
+    const float *base, *rough, *metal;      /* [P,3] [P] [P]  BRDF parameters at the points      */
+    const float *normal, *view;             /* [P,3] unit normal (detached), [P,3] view direction */
+    const float *dirs;                      /* [P, n_rays+1, 3] from esr_lts_dirs                 */
+    const float *off_m, *emo_m, *last2;     /* [P*R,3] [P*R,3] [P*R] marched secondary rays       */
+    const float *mus, *lambdas, *lobes;     /* [J,3] [J] [J,3] envmap parameters (J <= 64)        */
+    const float *emission;                  /* [P,3]                                              */
+    const uint8_t *umask;                   /* [P] uncertain-ray flags (pdra) or NULL             */
+} esr_lts_args_t;
+
+typedef struct esr_lts_grads {
+    float *d_off_m, *d_emo_m, *d_last2;     /* [P*R,3] [P*R,3] [P*R]  written                     */
+    float *d_base, *d_rough, *d_metal, *d_emission;   /* [P,3] [P] [P] [P,3]  written             */
+    float *d_mus, *d_lambdas, *d_lobes;     /* accumulated into (caller zero-fills)               */
+} esr_lts_grads_t;
+
+/* off_hat, emo_hat [2P,3]: rows [0,P) camera direction, [P,2P) random direction. */
+int esr_lts_combine_fwd(const esr_lts_args_t *args, float *off_hat, float *emo_hat, void *stream);
+int esr_lts_combine_bwd(const esr_lts_args_t *args, const float *g_off_hat, const float *g_emo_hat,
+                        const esr_lts_grads_t *grads, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,156 @@
+"""LTS-stage kernels (include/esr_hip.h section C) vs the CPU oracle (oracle/lts_path.py), forward
+and backward (torch autograd through the oracle functions), through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene_and_consts(name="tiny"):
+    from esr_nerf_amd.config import lts_cfg
+    from esr_nerf_amd.fine_engine import make_scene
+    from esr_nerf_amd.synthetic import analytic_sdf, slab_scene
+    from oracle import fine_path as fp
+    sc = slab_scene(name)
+    cfg = lts_cfg("cpu")
+    c = fp.make_consts(cfg.app.model, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max, sc.mask_alpha_init,
+                       sc.mask_density, sc.near, sc.num_voxels)
+    g = torch.Generator().manual_seed(1)
+    grid = analytic_sdf(c.world_size.tolist(), sc.xyz_min, sc.xyz_max) + 0.02 * torch.randn(
+        1, 1, *c.world_size.tolist(), generator=g)
+    scene = make_scene(sc.xyz_min.tolist(), sc.xyz_max.tolist(), sc.xyz_min.tolist(), sc.xyz_max.tolist(),
+                       c.world_size.tolist(), [32, 32, 32], sc.near, float(c.stepsize * c.voxel_size),
+                       float(c.voxel_size), c.act_shift, c.maskcache_thres, c.fastcolor_thres, 20.0,
+                       c.grad_feat.tolist())
+    return sc, c, grid, scene
+
+
+@pytest.mark.parametrize("with_noise", [False, True])
+def test_expgrad_fwd_bwd(with_noise):
+    from esr_nerf_amd import _lib
+    from oracle import lts_path as lp
+    L = _lib.lib()
+    sc, c, grid, scene = _scene_and_consts()
+    g = torch.Generator().manual_seed(2)
+    n = 5000
+    pts = sc.xyz_min + (sc.xyz_max - sc.xyz_min) * torch.rand(n, 3, generator=g)
+    pts[:50] = sc.xyz_max                      # exactly on the upper faces
+    pts[50:100, 0] = sc.xyz_min[0]
+    noise = torch.randn(n, 3, generator=g) if with_noise else None
+    eps = 0.003
+    grid_r = grid.clone().requires_grad_()
+    q = pts + noise * eps if with_noise else pts
+    q = torch.maximum(torch.minimum(q, sc.xyz_max), sc.xyz_min)
+    if with_noise:                                   # keep the perturbed points inside the box
+        noise = (q - pts) / eps
+    sdf, gr = lp.sdf_expgrad(c, grid_r, q)
+    gout = torch.randn(n, 4, generator=g)
+    (sdf * gout[:, 0]).sum().add((gr * gout[:, 1:]).sum()).backward()
+    out = torch.empty(n, 4, device="cuda")
+    s = _lib.stream_ptr("cuda:0")
+    gd = grid[0, 0].contiguous().cuda()
+    nz = noise.cuda().contiguous() if with_noise else None
+    pd = pts.cuda().contiguous()
+    _lib.check(L.esr_expgrad_fwd(C.byref(scene), None, None, None, None, _lib.ptr(pd), _lib.ptr(nz), C.c_float(eps),
+                                 _lib.ptr(gd), n, _lib.ptr(out), s), "expgrad_fwd")
+    assert rel_err(out[:, 0], sdf.detach()) < 1e-5
+    assert rel_err(out[:, 1:], gr.detach()) < 1e-5
+    gs = torch.zeros_like(gd)
+    gout_d = gout.cuda().contiguous()
+    _lib.check(L.esr_expgrad_bwd(C.byref(scene), None, None, None, None, _lib.ptr(pd), _lib.ptr(nz), C.c_float(eps),
+                                 _lib.ptr(gout_d), n, _lib.ptr(gs), s), "expgrad_bwd")
+    assert rel_err(gs, grid_r.grad[0, 0]) < 1e-5
+
+
+def test_lts_dirs():
+    from esr_nerf_amd import _lib
+    from oracle import lts_path as lp
+    g = torch.Generator().manual_seed(3)
+    P, R1 = 37, 65
+    nrm = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)
+    raw = torch.randn(P, R1, 3, generator=g)
+    ref = lp.hemisphere_dirs(nrm, raw)
+    out = torch.empty(P, R1, 3, device="cuda")
+    raw_d, nrm_d = raw.cuda(), nrm.cuda()            # keep the device copies alive across the async launch
+    _lib.check(_lib.lib().esr_lts_dirs(_lib.ptr(raw_d), _lib.ptr(nrm_d), P, R1, _lib.ptr(out),
+                                       _lib.stream_ptr("cuda:0")), "dirs")
+    assert rel_err(out, ref) < 1e-6
+    assert bool(((out.cpu() * nrm[:, None]).sum(-1) >= -1e-7).all())
+
+
+@pytest.mark.parametrize("pdra,P,R", [(0, 10, 8), (1, 10, 8), (0, 100, 256), (1, 7, 300)])
+def test_lts_combine_fwd_bwd(pdra, P, R):
+    """env map + Disney reflection + hemisphere means + emo_hat assembly, against the oracle formulas."""
+    from esr_nerf_amd import _lib
+    from oracle import lts_path as lp
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(10 + P + R)
+    rnd = lambda *s: torch.rand(*s, generator=g)
+    base, rough, metal = rnd(P, 3).requires_grad_(), rnd(P, 1).requires_grad_(), rnd(P, 1).requires_grad_()
+    if P > 5:
+        with torch.no_grad():
+            rough[0] = 1e-5       # exercises the r^2 clamp
+    nrm = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)
+    view = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)
+    dirs_all = lp.hemisphere_dirs(nrm, torch.randn(P, R + 1, 3, generator=g))
+    off_m = (rnd(P * R, 3) * 2).requires_grad_()
+    emo_m = (rnd(P * R, 3) * 2).requires_grad_()
+    last2 = rnd(P * R).requires_grad_()
+    emission = rnd(P, 3).requires_grad_()
+    umask = (torch.arange(P) % 3 == 0)
+    J = 48
+    Pm = {"envmap.mus": (torch.randn(J, 3, generator=g) * 0.3).requires_grad_(),
+          "envmap.lambdas": (10 + 20 * torch.randn(J, 1, generator=g)).requires_grad_(),
+          "envmap.lobes": torch.randn(J, 3, generator=g).requires_grad_()}
+    # oracle, with the reference's tensor plumbing (esrnerf.py:553-572,653-677)
+    rep = lambda t: t.repeat([2] + [1] * (t.dim() - 1))
+    ex = lambda t: t.view(P, 1, -1).expand(P, R, t.shape[-1]).flatten(0, 1)
+    d2 = dirs_all[:, :-1].flatten(0, 1)
+    v_rand = -dirs_all[:, -1]
+    Rf = lp.disney_reflection(rep(ex(base)), rep(ex(rough)), rep(ex(metal)), rep(ex(nrm)), rep(d2),
+                              torch.cat([-ex(view), -ex(v_rand)], 0))
+    env = lp.sg_envmap(Pm, d2) * last2.unsqueeze(-1)
+    off_hat = (rep(off_m + env) * Rf).view(-1, R, 3).mean(-2)
+    reflect = (rep(emo_m) * Rf).view(-1, R, 3).mean(-2)
+    if pdra:
+        um = rep(umask)
+        emo_hat = torch.where(um[:, None], rep(emission) + reflect.detach(), reflect)
+    else:
+        emo_hat = rep(emission) + reflect
+    g1, g2 = torch.randn(2 * P, 3, generator=g), torch.randn(2 * P, 3, generator=g)
+    ((off_hat * g1).sum() + (emo_hat * g2).sum()).backward()
+
+    dev = lambda t: t.detach().cuda().contiguous()
+    keep = dict(base=dev(base), rough=dev(rough[:, 0]), metal=dev(metal[:, 0]), normal=dev(nrm), view=dev(view),
+                dirs=dev(dirs_all), off_m=dev(off_m), emo_m=dev(emo_m), last2=dev(last2), mus=dev(Pm["envmap.mus"]),
+                lambdas=dev(Pm["envmap.lambdas"][:, 0]), lobes=dev(Pm["envmap.lobes"]), emission=dev(emission),
+                umask=umask.to(torch.uint8).cuda())
+    a = _lib.EsrLtsArgs()
+    a.n_pts, a.n_rays, a.n_sg, a.pdra_mode = P, R, J, pdra
+    for k, v in keep.items():
+        setattr(a, k, v.data_ptr())
+    oh = torch.empty(2 * P, 3, device="cuda")
+    eh = torch.empty(2 * P, 3, device="cuda")
+    s = _lib.stream_ptr("cuda:0")
+    _lib.check(L.esr_lts_combine_fwd(C.byref(a), _lib.ptr(oh), _lib.ptr(eh), s), "combine_fwd")
+    assert rel_err(oh, off_hat.detach()) < 2e-5
+    assert rel_err(eh, emo_hat.detach()) < 2e-5
+    z = lambda *sh: torch.zeros(*sh, device="cuda")
+    gr = dict(d_off_m=z(P * R, 3), d_emo_m=z(P * R, 3), d_last2=z(P * R), d_base=z(P, 3), d_rough=z(P), d_metal=z(P),
+              d_emission=z(P, 3), d_mus=z(J, 3), d_lambdas=z(J), d_lobes=z(J, 3))
+    gs = _lib.EsrLtsGrads()
+    for k, v in gr.items():
+        setattr(gs, k, v.data_ptr())
+    g1d, g2d = g1.cuda(), g2.cuda()
+    _lib.check(L.esr_lts_combine_bwd(C.byref(a), _lib.ptr(g1d), _lib.ptr(g2d), C.byref(gs), s), "combine_bwd")
+    zero = lambda t: torch.zeros_like(t) if t.grad is None else t.grad
+    exp = dict(d_off_m=off_m.grad, d_emo_m=zero(emo_m), d_last2=last2.grad, d_base=base.grad, d_rough=rough.grad[:, 0],
+               d_metal=metal.grad[:, 0], d_emission=zero(emission), d_mus=Pm["envmap.mus"].grad,
+               d_lambdas=Pm["envmap.lambdas"].grad[:, 0], d_lobes=Pm["envmap.lobes"].grad)
+    bad = {k: rel_err(gr[k], v) for k, v in exp.items() if not rel_err(gr[k], v) < 1e-4}
+    assert not bad, bad
