@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libesr_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 
@@ -31,6 +31,18 @@ class EsrScene(C.Structure):
 class EsrPlan(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("n_on", "n_off", "tiles_on", "tiles_all", "m0", "m1", "m2", "overflow")]
+
+
+class EsrFeatArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("rays_o", "rays_d", "viewdirs", "rec_ray", "rec_step", "rec_sdf",
+                                          "pts", "pt_viewdirs", "pt_sdf")] + \
+               [("n_pts", C.c_int32), ("sdf", C.c_void_p), ("color_on", C.c_void_p * 3),
+                ("color_off", C.c_void_p * 3), ("tiles_on", C.c_int32), ("tiles_all", C.c_int32)]
+
+
+class EsrFeatBwdSrc(C.Structure):
+    _fields_ = [("dX", C.c_void_p), ("grad_color_on", C.c_void_p), ("grad_color_off", C.c_void_p),
+                ("t0", C.c_int32), ("t1", C.c_int32)]
 
 
 class EsrLtsArgs(C.Structure):

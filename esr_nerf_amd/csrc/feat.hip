@@ -23,17 +23,51 @@ constexpr int DXROWS = 64;  // rows of a dX tile (0..42 used)
 constexpr int ROW_COL = 0, ROW_SDF = 6, ROW_FEAT = 7, ROW_NRM = 31, ROW_XYZ = 43, ROW_SIN = 46,
               ROW_COS = 61, ROW_VD = 76, ROW_VSIN = 79, ROW_VCOS = 82, ROW_ALT = 88;
 
+constexpr int MAX_SRC = 4;
+constexpr int COLOR_ROW[3] = {0, 88, 96};          // first row of the three 6-row colour groups
+
 struct FeatParams {
     esr_scene_t sc;
-    const float *rays_o, *rays_d, *viewdirs, *sdf, *off_color, *emo_color;
+    // sample positions: march records (pts == nullptr) or explicit points
+    const float *rays_o, *rays_d, *viewdirs;
     const int32_t *rec_ray, *rec_step;
     const float *rec_sdf;
+    const float *pts, *pt_viewdirs, *pt_sdf;
+    int n_pts;
+    const float *sdf;
+    const float *color_on[3], *color_off[3];         // grid per colour group on on-tiles / off-tiles
     int tiles_on, tiles_all;
     float *X, *gnorm;
     // backward
-    const float *dX;
-    float *grad_sdf, *grad_off, *grad_emo;
+    int n_src;
+    const float *dX[MAX_SRC];
+    float *gcol_on[MAX_SRC], *gcol_off[MAX_SRC];
+    int src_t0[MAX_SRC], src_t1[MAX_SRC];
+    const float *dsdf_extra;                          // [tiles*32] added to the SDF-value row, or null
+    float *dsdf_out;                                  // explicit mode: gradient w.r.t. pt_sdf
+    float *grad_sdf;
 };
+
+// position, view direction and SDF value of sample j; false for padding lanes
+__device__ __forceinline__ bool sample_inputs(const FeatParams &P, int j, float p[3], float vd[3], float &sdfv)
+{
+    if (P.pts) {
+        if (j >= P.n_pts) return false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { p[a] = P.pts[3 * j + a]; vd[a] = P.pt_viewdirs[3 * j + a]; }
+        sdfv = P.pt_sdf[j];
+        return true;
+    }
+    const int ray = P.rec_ray[j];
+    if (ray < 0) return false;
+    const RayGeom g = esr_ray_geom(P.rays_o, P.rays_d, ray, P.sc.xyz_min, P.sc.xyz_max, P.sc.near_, 1e9f,
+                                   P.sc.stepdist);
+    esr_ray_point(g.start, g.dir, P.sc.stepdist, P.rec_step[j], p);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) vd[a] = P.viewdirs[3 * ray + a];
+    sdfv = P.rec_sdf[j];
+    return true;
+}
 
 __device__ __forceinline__ void tri_fetch6(const float *__restrict__ g, const int dims[3],
                                            const float idx[3], float out[6])
@@ -100,13 +134,6 @@ __device__ __forceinline__ float tap_index(const float ind[3], const int dims[3]
     return along;
 }
 
-__device__ __forceinline__ void sample_point(const FeatParams &P, int ray, int step, float p[3])
-{
-    const RayGeom g = esr_ray_geom(P.rays_o, P.rays_d, ray, P.sc.xyz_min, P.sc.xyz_max, P.sc.near_,
-                                   1e9f, P.sc.stepdist);
-    esr_ray_point(g.start, g.dir, P.sc.stepdist, step, p);
-}
-
 __global__ void __launch_bounds__(256) feat_fwd_kernel(FeatParams P)
 {
     const esr_scene_t &sc = P.sc;
@@ -116,40 +143,31 @@ __global__ void __launch_bounds__(256) feat_fwd_kernel(FeatParams P)
         const int t = j >> 5, s = j & 31;
         float *Xt = P.X + (size_t)t * XROWS * 32 + s;
         float *Gn = P.gnorm + (size_t)t * 4 * 32 + s;
-        const int ray = P.rec_ray[j];
-        if (ray < 0) {                                   // padding lane: inert zeros
+        float p[3], ind[3], unit[3], vdir[3], sdfv;
+        if (!sample_inputs(P, j, p, vdir, sdfv)) {       // padding lane: inert zeros
             for (int r = 0; r < XROWS; ++r) Xt[r * 32] = 0.f;
             for (int k = 0; k < 4; ++k) Gn[k * 32] = 0.f;
             continue;
         }
         const bool on_tile = t < P.tiles_on;
-        float p[3], ind[3], unit[3];
-        sample_point(P, ray, P.rec_step[j], p);
         esr_world_to_index(p, sc.xyz_min, sc.xyz_max, gdims, ind);
         {
 #pragma clang fp contract(off)
 #pragma unroll
             for (int a = 0; a < 3; ++a) unit[a] = __fdiv_rn(p[a] - sc.xyz_min[a], sc.xyz_max[a] - sc.xyz_min[a]);
         }
-        // colour grids
-        float col[6];
-        tri_fetch6(on_tile ? P.emo_color : P.off_color, gdims, ind, col);
+        // colour groups (rows 0-5, 88-93, 96-101): each fed by the grid configured for this tile type
 #pragma unroll
-        for (int c = 0; c < 6; ++c) Xt[(ROW_COL + c) * 32] = col[c];
-        if (on_tile) {
-            tri_fetch6(P.off_color, gdims, ind, col);
+        for (int gi = 0; gi < 3; ++gi) {
+            const float *grid = on_tile ? P.color_on[gi] : P.color_off[gi];
+            float col[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (grid) tri_fetch6(grid, gdims, ind, col);
 #pragma unroll
-            for (int c = 0; c < 6; ++c) Xt[(ROW_ALT + c) * 32] = col[c];
-        } else {
-#pragma unroll
-            for (int c = 0; c < 6; ++c) Xt[(ROW_ALT + c) * 32] = 0.f;
+            for (int c = 0; c < 6; ++c) Xt[(COLOR_ROW[gi] + c) * 32] = col[c];
         }
-        Xt[(ROW_ALT + 6) * 32] = 0.f;
-        Xt[(ROW_ALT + 7) * 32] = 0.f;
+        Xt[94 * 32] = 0.f; Xt[95 * 32] = 0.f; Xt[102 * 32] = 0.f; Xt[103 * 32] = 0.f;
         Xt[85 * 32] = 0.f; Xt[86 * 32] = 0.f; Xt[87 * 32] = 0.f;
-#pragma unroll
-        for (int r = 96; r < XROWS; ++r) Xt[r * 32] = 0.f;      // third colour group: unused by the fine stage
-        Xt[ROW_SDF * 32] = P.rec_sdf[j];
+        Xt[ROW_SDF * 32] = sdfv;
         // 24-tap SDF stencil: reference axis order is (z, y, x) = grid axes (2, 1, 0)
         float grad[3][4];
 #pragma unroll
@@ -185,7 +203,7 @@ __global__ void __launch_bounds__(256) feat_fwd_kernel(FeatParams P)
                 Xt[(ROW_SIN + c * 5 + i) * 32] = sinf(a);
                 Xt[(ROW_COS + c * 5 + i) * 32] = cosf(a);
             }
-            const float v = P.viewdirs[3 * ray + c];
+            const float v = vdir[c];
             Xt[(ROW_VD + c) * 32] = v;
             Xt[(ROW_VSIN + c) * 32] = sinf(v);
             Xt[(ROW_VCOS + c) * 32] = cosf(v);
@@ -319,16 +337,21 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
     w.lds = (lds_float *)(win_all + (threadIdx.x >> 6) * WIN_FLOATS);
     for (int t = wave; t < P.tiles_all; t += nwaves) {
         const int j = t * 32 + s;
-        const int ray = P.rec_ray[j];
-        const bool valid = ray >= 0;
         const float *Xt = P.X + (size_t)t * XROWS * 32 + s;
-        const float *dXt = P.dX + (size_t)t * DXROWS * 32 + s;
         const float *Gn = P.gnorm + (size_t)t * 4 * 32 + s;
         const bool on_tile = t < P.tiles_on;
-        float p[3] = {0.f, 0.f, 0.f}, ind[3] = {0.f, 0.f, 0.f};
+        float p[3] = {0.f, 0.f, 0.f}, ind[3] = {0.f, 0.f, 0.f}, vdir_[3], sdfv_;
         int i0[3] = {0, 0, 0};
+        const bool valid = sample_inputs(P, j, p, vdir_, sdfv_);
+        // gradient rows of this sample: sum over the nets that consumed the tile (rows 6-42 are shared)
+        auto dxrow = [&](int row) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAX_SRC; ++k)
+                if (k < P.n_src && t >= P.src_t0[k] && t < P.src_t1[k]) v += P.dX[k][((size_t)t * DXROWS + row) * 32 + s];
+            return v;
+        };
         if (valid) {
-            sample_point(P, ray, P.rec_step[j], p);
             esr_world_to_index(p, sc.xyz_min, sc.xyz_max, gdims, ind);
 #pragma unroll
             for (int a = 0; a < 3; ++a) i0[a] = (int)floorf(ind[a]);
@@ -352,7 +375,7 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
 #pragma unroll
                 for (int ar = 0; ar < 3; ++ar) {
                     n[ar] = Xt[(ROW_NRM + ar * 4 + k) * 32];
-                    dn[ar] = dXt[(ROW_NRM + ar * 4 + k) * 32];
+                    dn[ar] = dxrow(ROW_NRM + ar * 4 + k);
                     dot += n[ar] * dn[ar];
                 }
 #pragma unroll
@@ -366,7 +389,11 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
                 wc[a][0] = (float)(i0[a] + 1) - ind[a];
                 wc[a][1] = ind[a] - (float)i0[a];
             }
-            const float d_sdf = dXt[ROW_SDF * 32];
+            float d_sdf = dxrow(ROW_SDF) + (P.dsdf_extra ? P.dsdf_extra[j] : 0.f);
+            if (P.dsdf_out) {                 // explicit points: the SDF value is an input, not a grid tap
+                if (h == 0) P.dsdf_out[j] = d_sdf;
+                d_sdf = 0.f;
+            }
 #pragma unroll
             for (int bar = 0; bar < 2; ++bar) {
                 // bar 0: z (h=0) or y (h=1); bar 1: x, split between the halves.  ar: reference axis order
@@ -397,8 +424,8 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
                     }
                     const float thr = (ar == 0 ? through[0][k] : (ar == 1 ? through[1][k] : through[2][k])) /
                                       (cp - cm) / sc.voxel_size;
-                    const float dfm = dXt[(ROW_FEAT + (2 * ar) * 4 + k) * 32] - thr;
-                    const float dfp = dXt[(ROW_FEAT + (2 * ar + 1) * 4 + k) * 32] + thr;
+                    const float dfm = dxrow(ROW_FEAT + (2 * ar) * 4 + k) - thr;
+                    const float dfp = dxrow(ROW_FEAT + (2 * ar + 1) * 4 + k) + thr;
                     deposit(ixm, dfm);
                     deposit(ixp, dfp);
                 }
@@ -429,76 +456,92 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
         lds_fence();
         window_flush(w, P.grad_sdf, gdims, lane);
         lds_fence();
-        // ---- phase 2: colour grid of this tile's net (3 channels per lane half)
-        float *gcol = on_tile ? P.grad_emo : P.grad_off;
-        window_setup(w, i0, valid, gdims, 0, 1, 6);
-        window_zero(w, lane);
-        lds_fence();
-        if (valid) {
-            float d3[3];
+        // ---- phase 2: colour grids, one pass per net that read a colour group (3 channels per lane half)
+        for (int k = 0; k < P.n_src; ++k) {
+            float *gcol = on_tile ? P.gcol_on[k] : P.gcol_off[k];
+            if (!gcol || t < P.src_t0[k] || t >= P.src_t1[k]) continue;       // wave-uniform
+            const float *dXt = P.dX[k] + (size_t)t * DXROWS * 32 + s;
+            window_setup(w, i0, valid, gdims, 0, 1, 6);
+            window_zero(w, lane);
+            lds_fence();
+            if (valid) {
+                float d3[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) d3[c] = dXt[(ROW_COL + 3 * h + c) * 32];
-            Tri tr = esr_tri_setup(ind);
+                for (int c = 0; c < 3; ++c) d3[c] = dXt[(ROW_COL + 3 * h + c) * 32];
+                Tri tr = esr_tri_setup(ind);
 #pragma unroll
-            for (int cx = 0; cx < 2; ++cx)
+                for (int cx = 0; cx < 2; ++cx)
 #pragma unroll
-                for (int cy = 0; cy < 2; ++cy)
+                    for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
-                    for (int cz = 0; cz < 2; ++cz) {
-                        int x = tr.i0[0] + cx, y = tr.i0[1] + cy, z = tr.i0[2] + cz;
-                        bool inb = (x >= 0) & (x < gdims[0]) & (y >= 0) & (y < gdims[1]) & (z >= 0) & (z < gdims[2]);
-                        float wgt = esr_corner_w(tr, ind, cx, cy, cz);
-                        if (inb && wgt != 0.f) {
+                        for (int cz = 0; cz < 2; ++cz) {
+                            int x = tr.i0[0] + cx, y = tr.i0[1] + cy, z = tr.i0[2] + cz;
+                            bool inb = (x >= 0) & (x < gdims[0]) & (y >= 0) & (y < gdims[1]) & (z >= 0) & (z < gdims[2]);
+                            float wgt = esr_corner_w(tr, ind, cx, cy, cz);
+                            if (inb && wgt != 0.f) {
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) window_add(w, gcol, gdims, x, y, z, 3 * h + c, d3[c] * wgt);
+                                for (int c = 0; c < 3; ++c) window_add(w, gcol, gdims, x, y, z, 3 * h + c, d3[c] * wgt);
+                            }
                         }
-                    }
+            }
+            lds_fence();
+            window_flush(w, gcol, gdims, lane);
+            lds_fence();
         }
-        lds_fence();
-        window_flush(w, gcol, gdims, lane);
-        lds_fence();
     }
 }
 
 }  // namespace
 
-ESR_API int esr_fine_feat_fwd(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
-                              const float *viewdirs, const float *sdf, const float *off_color,
-                              const float *emo_color, const int32_t *rec_ray, const int32_t *rec_step,
-                              const float *rec_sdf, int32_t tiles_on, int32_t tiles_all, float *X,
-                              float *gnorm, void *stream)
+static int feat_common(const esr_scene_t *scene, const esr_feat_args_t *a, FeatParams &P)
 {
-    if (!scene || tiles_all < 0 || tiles_on < 0 || tiles_on > tiles_all) return ESR_EINVAL;
-    if (tiles_all == 0) return 0;
-    if (!rays_o || !rays_d || !viewdirs || !sdf || !off_color || !emo_color || !rec_ray || !rec_step ||
-        !rec_sdf || !X || !gnorm)
+    if (!scene || !a || a->tiles_all < 0 || a->tiles_on < 0 || a->tiles_on > a->tiles_all) return ESR_EINVAL;
+    if (a->tiles_all == 0) return 0;
+    if (!a->sdf) return ESR_EINVAL;
+    if (a->pts) {
+        if (!a->pt_viewdirs || !a->pt_sdf || a->n_pts < 0 || a->n_pts > a->tiles_all * 32) return ESR_EINVAL;
+    } else if (!a->rays_o || !a->rays_d || !a->viewdirs || !a->rec_ray || !a->rec_step || !a->rec_sdf) {
         return ESR_EINVAL;
+    }
+    P.sc = *scene; P.rays_o = a->rays_o; P.rays_d = a->rays_d; P.viewdirs = a->viewdirs;
+    P.rec_ray = a->rec_ray; P.rec_step = a->rec_step; P.rec_sdf = a->rec_sdf;
+    P.pts = a->pts; P.pt_viewdirs = a->pt_viewdirs; P.pt_sdf = a->pt_sdf; P.n_pts = a->n_pts;
+    P.sdf = a->sdf; P.tiles_on = a->tiles_on; P.tiles_all = a->tiles_all;
+    for (int g = 0; g < 3; ++g) { P.color_on[g] = a->color_on[g]; P.color_off[g] = a->color_off[g]; }
+    return 1;
+}
+
+ESR_API int esr_fine_feat_fwd(const esr_scene_t *scene, const esr_feat_args_t *args, float *X, float *gnorm,
+                              void *stream)
+{
     FeatParams P = {};
-    P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d; P.viewdirs = viewdirs; P.sdf = sdf;
-    P.off_color = off_color; P.emo_color = emo_color; P.rec_ray = rec_ray; P.rec_step = rec_step;
-    P.rec_sdf = rec_sdf; P.tiles_on = tiles_on; P.tiles_all = tiles_all; P.X = X; P.gnorm = gnorm;
-    feat_fwd_kernel<<<esr_grid_for((int64_t)tiles_all * 32, 256, 256 * 16), 256, 0, esr_stream(stream)>>>(P);
+    const int c = feat_common(scene, args, P);
+    if (c <= 0) return c;
+    if (!X || !gnorm) return ESR_EINVAL;
+    P.X = X; P.gnorm = gnorm;
+    feat_fwd_kernel<<<esr_grid_for((int64_t)P.tiles_all * 32, 256, 256 * 16), 256, 0, esr_stream(stream)>>>(P);
     ESR_CHECK_LAUNCH();
     return 0;
 }
 
-ESR_API int esr_fine_feat_bwd(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
-                              const int32_t *rec_ray, const int32_t *rec_step, const float *X,
-                              const float *gnorm, const float *dX, int32_t tiles_on, int32_t tiles_all,
-                              float *grad_sdf, float *grad_off_color, float *grad_emo_color, void *stream)
+ESR_API int esr_fine_feat_bwd(const esr_scene_t *scene, const esr_feat_args_t *args, const float *X,
+                              const float *gnorm, const esr_feat_bwd_src_t *src, int32_t n_src,
+                              const float *dsdf_extra, float *grad_sdf, float *dsdf_out, void *stream)
 {
-    if (!scene || tiles_all < 0 || tiles_on < 0 || tiles_on > tiles_all) return ESR_EINVAL;
-    if (tiles_all == 0) return 0;
-    if (!rays_o || !rays_d || !rec_ray || !rec_step || !X || !gnorm || !dX || !grad_sdf ||
-        !grad_off_color || !grad_emo_color)
-        return ESR_EINVAL;
     FeatParams P = {};
-    P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d; P.rec_ray = rec_ray; P.rec_step = rec_step;
-    P.tiles_on = tiles_on; P.tiles_all = tiles_all; P.X = const_cast<float *>(X);
-    P.gnorm = const_cast<float *>(gnorm); P.dX = dX; P.grad_sdf = grad_sdf; P.grad_off = grad_off_color;
-    P.grad_emo = grad_emo_color;
+    const int c = feat_common(scene, args, P);
+    if (c <= 0) return c;
+    if (!X || !gnorm || !src || n_src < 1 || n_src > MAX_SRC || !grad_sdf) return ESR_EINVAL;
+    P.X = const_cast<float *>(X); P.gnorm = const_cast<float *>(gnorm);
+    P.n_src = n_src;
+    for (int k = 0; k < n_src; ++k) {
+        if (!src[k].dX) return ESR_EINVAL;
+        P.dX[k] = src[k].dX; P.gcol_on[k] = src[k].grad_color_on; P.gcol_off[k] = src[k].grad_color_off;
+        P.src_t0[k] = src[k].t0; P.src_t1[k] = src[k].t1;
+    }
+    P.dsdf_extra = dsdf_extra; P.dsdf_out = dsdf_out; P.grad_sdf = grad_sdf;
     // one wave per tile, 4 waves (4 x 16 KB LDS windows) per workgroup
-    feat_bwd_kernel<<<esr_grid_for((int64_t)tiles_all * 64, 256, 256 * 2), 256,
+    feat_bwd_kernel<<<esr_grid_for((int64_t)P.tiles_all * 64, 256, 256 * 2), 256,
                       4 * WIN_FLOATS * sizeof(float), esr_stream(stream)>>>(P);
     ESR_CHECK_LAUNCH();
     return 0;

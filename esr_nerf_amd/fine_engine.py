@@ -62,6 +62,7 @@ class FineCtx:
     off3: torch.Tensor
     mask_density: torch.Tensor
     sdf: torch.Tensor
+    feat_args: object = None
 
 
 class _Workspace:
@@ -162,6 +163,19 @@ class FineEngine:
     def _H(self, names):
         return _lib.ptr_array([self.ws[n] for n in names])
 
+    def feat_args(self, rays_o, rays_d, viewdirs, sdf, tiles_on, tiles_all, color_on, color_off, ws=None):
+        """esr_feat_args_t for march-record sampling (the tensors must outlive the launches)."""
+        ws = ws or self.ws
+        fa = _lib.EsrFeatArgs()
+        fa.rays_o, fa.rays_d, fa.viewdirs = rays_o.data_ptr(), rays_d.data_ptr(), viewdirs.data_ptr()
+        fa.rec_ray, fa.rec_step, fa.rec_sdf = ws["rec_ray"].data_ptr(), ws["rec_step"].data_ptr(), ws["rec_sdf"].data_ptr()
+        fa.sdf = sdf.data_ptr()
+        for g in range(3):
+            fa.color_on[g] = color_on[g].data_ptr() if color_on[g] is not None else None
+            fa.color_off[g] = color_off[g].data_ptr() if color_off[g] is not None else None
+        fa.tiles_on, fa.tiles_all = tiles_on, tiles_all
+        return fa
+
     # -- forward -----------------------------------------------------------------
     def forward(self, scene, rays_o, rays_d, viewdirs, em_modes, mask_density, sdf, off_color, emo_color):
         """-> (ctx, alphainv_last [N], srgb_marched [N,3], lin_marched [N,3]).
@@ -200,11 +214,10 @@ class FineEngine:
                                          _lib.ptr(sdf), n, _lib.ptr(rb["off3"]), _lib.ptr(ws["rec_ray"]),
                                          _lib.ptr(ws["rec_step"]), _lib.ptr(ws["rec_w"]),
                                          _lib.ptr(ws["rec_sdf"]), s)
-        self._run("feat_fwd", L.esr_fine_feat_fwd, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(viewdirs),
-                                       _lib.ptr(sdf), _lib.ptr(off_color), _lib.ptr(emo_color),
-                                       _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_step"]),
-                                       _lib.ptr(ws["rec_sdf"]), tiles_on, tiles_all, _lib.ptr(ws["X"]),
-                                       _lib.ptr(ws["gnorm"]), s)
+        fa = self.feat_args(rays_o, rays_d, viewdirs, sdf, tiles_on, tiles_all,
+                            color_on=(emo_color, off_color, None), color_off=(off_color, None, None))
+        self._run("feat_fwd", L.esr_fine_feat_fwd, sp, C.byref(fa), _lib.ptr(ws["X"]), _lib.ptr(ws["gnorm"]), s)
+        ctx.feat_args = fa
         H, M = self._H(["H0", "H1", "H2"]), self._H(["M0", "M1", "M2"])
         # off net: detached pass on the on-tiles (alt colour rows, nothing saved), saved pass on the off-tiles
         self._run("mlp_fwd(off|on-tiles)", L.esr_mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), 0, tiles_on,
@@ -255,11 +268,13 @@ class FineEngine:
                                        M, dZ, _lib.ptr(ws["dX"]), s)
             self._run("mlp_dgrad(off)", L.esr_mlp_dgrad, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["dz"]), to, ta,
                                        M, dZ, _lib.ptr(ws["dX"]), s)
-            self._run("feat_bwd", L.esr_fine_feat_bwd, sp, _lib.ptr(ctx.rays_o), _lib.ptr(ctx.rays_d),
-                                           _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_step"]), _lib.ptr(ws["X"]),
-                                           _lib.ptr(ws["gnorm"]), _lib.ptr(ws["dX"]), to, ta,
-                                           _lib.ptr(grads["sdf"]), _lib.ptr(grads["off_color"]),
-                                           _lib.ptr(grads["emo_color"]), s)
+            src = (_lib.EsrFeatBwdSrc * 1)()
+            src[0].dX = ws["dX"].data_ptr()
+            src[0].grad_color_on = grads["emo_color"].data_ptr()      # on-tiles carry the emo net's gradient
+            src[0].grad_color_off = grads["off_color"].data_ptr()
+            src[0].t0, src[0].t1 = 0, ta
+            self._run("feat_bwd", L.esr_fine_feat_bwd, sp, C.byref(ctx.feat_args), _lib.ptr(ws["X"]),
+                      _lib.ptr(ws["gnorm"]), src, 1, None, _lib.ptr(grads["sdf"]), None, s)
             dweight = ws["dweight"]
         else:
             dweight = torch.zeros(32, dtype=torch.float32, device=self.device)

@@ -177,27 +177,48 @@ int esr_fine_march_bwd(const esr_scene_t *scene, const float *rays_o, const floa
                        float *grad_sdf, void *stream);
 
 /*
- * Per-sample feature assembly (voxurff.py:219-254 + :678-721 + module.py:24-35).
- * Colour grids are channel-last [gx,gy,gz,6] (torch.channels_last_3d storage of
- * the reference's [1,6,X,Y,Z] parameter).  X [n_tiles,104,32] f32, rows:
- *   0-5 colour (emo grid on on-tiles, off grid on off-tiles) | 6 sdf | 7-30 feat24
- *   | 31-42 normal12 | 43-45 xyz | 46-60 sin | 61-75 cos | 76-84 viewdir PE
- *   | 85-87 zero | 88-93 off colour (on-tiles only) | 94-95 zero
- * Tiles have 104 rows: rows 96-101 are a third colour group (BRDF grid of the LTS stage).
+ * Per-sample feature assembly (voxurff.py:219-254 + :678-721 + module.py:24-35; the LTS renderer's
+ * esrnerf.py:728-765 uses the same features with three colour grids).
+ * Colour grids are channel-last [gx,gy,gz,6] (torch.channels_last_3d storage of the reference's
+ * [1,6,X,Y,Z] parameter).  X [n_tiles,104,32] f32, rows:
+ *   0-5 colour group 0 | 6 sdf | 7-30 feat24 | 31-42 normal12 | 43-45 xyz | 46-60 sin | 61-75 cos
+ *   | 76-84 viewdir PE | 85-87 zero | 88-93 colour group 1 | 94-95 zero | 96-101 colour group 2 | zero
  * gnorm [n_tiles,4,32]: |grad| per stencil radius, kept for the backward.
  */
-int esr_fine_feat_fwd(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
-                      const float *viewdirs, const float *sdf, const float *off_color,
-                      const float *emo_color, const int32_t *rec_ray, const int32_t *rec_step,
-                      const float *rec_sdf, int32_t tiles_on, int32_t tiles_all, float *X,
-                      float *gnorm, void *stream);
+typedef struct esr_feat_args {
+    /* sample positions: either the march records ... */
+    const float *rays_o, *rays_d, *viewdirs;        /* [N,3] each; viewdirs per RAY                 */
+    const int32_t *rec_ray, *rec_step;              /* [tiles*32]                                   */
+    const float *rec_sdf;
+    /* ... or explicit points (pts != NULL): per-sample arrays, n_pts valid samples, the rest padding */
+    const float *pts, *pt_viewdirs, *pt_sdf;        /* [n_pts,3] [n_pts,3] [n_pts]                  */
+    int32_t n_pts;
+    const float *sdf;                               /* SDF grid [gx,gy,gz]                          */
+    /* grid feeding colour group g on emissive-on tiles / on the other tiles (NULL: zeros).
+       fine stage: group0 = {emo, off}, group1 = {off, NULL}; LTS stage: {off,off} {emo,emo} {brdf,brdf} */
+    const float *color_on[3], *color_off[3];
+    int32_t tiles_on, tiles_all;
+} esr_feat_args_t;
 
-/* Backward of the above: dX [n_tiles,64,32] (rows 0-42 used) -> grid gradients. */
-int esr_fine_feat_bwd(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
-                      const int32_t *rec_ray, const int32_t *rec_step, const float *X,
-                      const float *gnorm, const float *dX, int32_t tiles_on, int32_t tiles_all,
-                      float *grad_sdf, float *grad_off_color, float *grad_emo_color,
+int esr_fine_feat_fwd(const esr_scene_t *scene, const esr_feat_args_t *args, float *X, float *gnorm,
                       void *stream);
+
+/*
+ * Backward.  Every net that consumed the tiles contributes a dX [n_tiles,64,32] (rows 0-42 used)
+ * over its tile range: rows 6-42 (sdf value, stencil features, normals) are summed over the sources,
+ * rows 0-5 go to that source's colour grid.  dsdf_extra [tiles*32] (optional) is added to the
+ * SDF-value row.  With explicit points the SDF-value gradient is returned in dsdf_out [tiles*32]
+ * instead of being scattered.  Scatter = LDS accumulation window + z-contiguous float atomics.
+ */
+typedef struct esr_feat_bwd_src {
+    const float *dX;
+    float *grad_color_on, *grad_color_off;          /* colour grid gradient on on-tiles / other tiles (NULL: none) */
+    int32_t t0, t1;
+} esr_feat_bwd_src_t;
+
+int esr_fine_feat_bwd(const esr_scene_t *scene, const esr_feat_args_t *args, const float *X,
+                      const float *gnorm, const esr_feat_bwd_src_t *src, int32_t n_src,
+                      const float *dsdf_extra, float *grad_sdf, float *dsdf_out, void *stream);
 
 /*
  * Tiny-MLP engine (RadianceNet 85-192-192-192-3, TonemapNet 33-192-3;
