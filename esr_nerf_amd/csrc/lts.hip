@@ -31,7 +31,7 @@ struct ExpGradParams {
     const float *noise;                  // optional [n,3]
     float eps;
     const float *sdf;
-    int n;
+    int n, zero_pad;
     float *out;                          // [n,4]: sdf value, d/dx, d/dy, d/dz
     const float *g;                      // backward: [n,4] (component 0 = grad w.r.t. the value)
     float *grad_sdf;
@@ -100,7 +100,9 @@ __global__ void __launch_bounds__(256) expgrad_kernel(ExpGradParams P)
                     const float c1 = sx * w[1][cy] * w[2][cz], c2 = w[0][cx] * sy * w[2][cz],
                                 c3 = w[0][cx] * w[1][cy] * sz;
                     if (!BWD) {
-                        const float gcell = P.sdf[cell];
+                        const bool inb = (i0[0] + cx >= 0) & (i0[0] + cx < dims[0]) & (i0[1] + cy >= 0) &
+                                         (i0[1] + cy < dims[1]) & (i0[2] + cz >= 0) & (i0[2] + cz < dims[2]);
+                        const float gcell = (P.zero_pad && !inb) ? 0.f : P.sdf[cell];
                         val += gcell * c0; d[0] += gcell * c1; d[1] += gcell * c2; d[2] += gcell * c3;
                     } else {
                         const float t = gv * c0 + gd[0] * c1 + gd[1] * c2 + gd[2] * c3;
@@ -369,15 +371,15 @@ __global__ void __launch_bounds__(256) lts_combine_kernel(LtsParams L)
 
 ESR_API int esr_expgrad_fwd(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
                             const int32_t *rec_ray, const int32_t *rec_step, const float *pts,
-                            const float *noise, float eps, const float *sdf, int32_t n, float *out,
-                            void *stream)
+                            const float *noise, float eps, const float *sdf, int32_t n, int zero_pad,
+                            float *out, void *stream)
 {
     if (!scene || n < 0) return ESR_EINVAL;
     if (n == 0) return 0;
     if (!sdf || !out || (!pts && (!rays_o || !rays_d || !rec_ray || !rec_step))) return ESR_EINVAL;
     ExpGradParams P = {};
     P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d; P.rec_ray = rec_ray; P.rec_step = rec_step;
-    P.pts = pts; P.noise = noise; P.eps = eps; P.sdf = sdf; P.n = n; P.out = out;
+    P.pts = pts; P.noise = noise; P.eps = eps; P.sdf = sdf; P.n = n; P.out = out; P.zero_pad = zero_pad;
     expgrad_kernel<false><<<esr_grid_for(n, 256), 256, 0, esr_stream(stream)>>>(P);
     ESR_CHECK_LAUNCH();
     return 0;

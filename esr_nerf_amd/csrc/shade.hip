@@ -215,6 +215,134 @@ __global__ void __launch_bounds__(256) loss_kernel(const float *__restrict__ srg
     if (esr_lane() == 0 && acc != 0.f) atomicAdd(loss, acc);
 }
 
+// ---- LTS-stage helpers ------------------------------------------------------------------------
+// out = act(z) on the first n_ch rows of [tiles, rows, 32] tiles (act 0: softplus, 1: sigmoid);
+// backward: dz = g * act'(z)
+template <bool BWD>
+__global__ void __launch_bounds__(256) act_kernel(const float *__restrict__ z, const float *__restrict__ g,
+                                                  int tiles, int rows, int n_ch, int act, float *__restrict__ out)
+{
+    const int64_t total = (int64_t)tiles * rows * 32;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)((i >> 5) % rows);
+        float v = 0.f;
+        if (row < n_ch) {
+            const float x = z[i];
+            if (!BWD) v = act ? esr_sigmoid(x) : esr_softplus(x);
+            else {
+                const float sg = esr_sigmoid(x);
+                v = g[i] * (act ? sg * (1.f - sg) : (x > 20.f ? 1.f : sg));
+            }
+        }
+        out[i] = v;
+    }
+}
+
+// out[ray, c] += w * v[c] for a 3-channel tile-major quantity (segmented wave reduction)
+__global__ void __launch_bounds__(256) composite3_fwd_kernel(const float *__restrict__ v, int rows,
+                                                             const int32_t *__restrict__ rec_ray,
+                                                             const float *__restrict__ rec_w, int tiles,
+                                                             float *__restrict__ out)
+{
+    const int lane = esr_lane();
+    const int total = tiles * 32;
+    const int stride = gridDim.x * blockDim.x;
+    for (int j0 = (blockIdx.x * blockDim.x + threadIdx.x) - lane; j0 < total; j0 += stride) {
+        const int j = j0 + lane;
+        const bool in = j < total;
+        const int t = j >> 5, s = j & 31;
+        const int ray = in ? rec_ray[j] : -1;
+        const float w = (in && ray >= 0) ? rec_w[j] : 0.f;
+        const int ray_next = __shfl_down(ray, 1);
+        const bool tail = ray >= 0 && (lane == 63 || ray_next != ray);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float x = in ? v[((size_t)t * rows + c) * 32 + s] : 0.f;
+            const float a = seg_scan(w * x, ray, lane);
+            if (tail) atomicAdd(&out[3 * ray + c], a);
+        }
+    }
+}
+
+// dv[c] (+)= w * g[ray, c];  dweight (+)= sum_c g[ray, c] * v[c]
+__global__ void __launch_bounds__(256) composite3_bwd_kernel(const float *__restrict__ g,
+                                                             const float *__restrict__ v, int rows,
+                                                             const int32_t *__restrict__ rec_ray,
+                                                             const float *__restrict__ rec_w, int tiles,
+                                                             int accumulate, float *__restrict__ dv,
+                                                             float *__restrict__ dweight)
+{
+    const int total = tiles * 32;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+        const int t = j >> 5, s = j & 31;
+        const int ray = rec_ray[j];
+        float dw = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const size_t i = ((size_t)t * rows + c) * 32 + s;
+            float d = 0.f;
+            if (ray >= 0) {
+                d = rec_w[j] * g[3 * ray + c];
+                dw += g[3 * ray + c] * v[i];
+            }
+            dv[i] = (accumulate & 1) ? dv[i] + d : d;
+        }
+        dweight[j] = (accumulate & 2) ? dweight[j] + dw : dw;
+    }
+}
+
+// LTS renderer: lin = softplus(z_off) + [on] softplus(z_emo) with NO detach (esrnerf.py:751-757):
+// dz_off on every tile, dz_emo on the on-tiles.  dlin_extra [tiles,4,32] (optional) is added.
+__global__ void __launch_bounds__(256) lts_tone_in_bwd_kernel(
+    const float *__restrict__ dXt, const float *__restrict__ g_lin, const float *__restrict__ lin,
+    const float *__restrict__ z_off, const float *__restrict__ z_emo, const int32_t *__restrict__ rec_ray,
+    const float *__restrict__ rec_w, int tiles_on, int tiles_all, float *__restrict__ dz_off,
+    float *__restrict__ dz_emo)
+{
+    const int total = tiles_all * 32;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+        const int t = j >> 5, s = j & 31;
+        const size_t z4 = (size_t)t * 4 * 32 + s;
+        const float *dX = dXt + (size_t)t * 64 * 32 + s;
+        const int ray = rec_ray[j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float d = 0.f;
+            if (ray >= 0) {
+                const float v = lin[z4 + c * 32];
+                d = rec_w[j] * g_lin[3 * ray + c] + dX[c * 32];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const float f = (float)(1 << i), a = v * f;
+                    d += f * (dX[(3 + c * 5 + i) * 32] * cosf(a) - dX[(18 + c * 5 + i) * 32] * sinf(a));
+                }
+            }
+            dz_off[z4 + c * 32] = d * softplus_grad(z_off[z4 + c * 32]);
+            if (t < tiles_on) dz_emo[z4 + c * 32] = d * softplus_grad(z_emo[z4 + c * 32]);
+        }
+        dz_off[z4 + 96] = 0.f;
+        if (t < tiles_on) dz_emo[z4 + 96] = 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256) sample_points_kernel(esr_scene_t sc, const float *__restrict__ rays_o,
+                                                            const float *__restrict__ rays_d,
+                                                            const int32_t *__restrict__ rec_ray,
+                                                            const int32_t *__restrict__ rec_step, int n,
+                                                            float *__restrict__ pts)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int ray = rec_ray[i];
+        float p[3] = {0.f, 0.f, 0.f};
+        if (ray >= 0) {
+            const RayGeom g = esr_ray_geom(rays_o, rays_d, ray, sc.xyz_min, sc.xyz_max, sc.near_, 1e9f, sc.stepdist);
+            esr_ray_point(g.start, g.dir, sc.stepdist, rec_step[i], p);
+        }
+        pts[3 * i] = p[0]; pts[3 * i + 1] = p[1]; pts[3 * i + 2] = p[2];
+    }
+}
+
 }  // namespace
 
 ESR_API int esr_fine_tone_in_fwd(const float *z_off, const float *z_emo, int32_t tiles_on,
@@ -282,6 +410,82 @@ ESR_API int esr_fine_loss_fwd_bwd(const float *srgb_marched, const float *lin_ma
     loss_kernel<<<esr_grid_for(n_rays, 256), 256, 0, esr_stream(stream)>>>(
         srgb_marched, lin_marched, alphainv_last, rgbs, n_rays, white_bg, weight_linear,
         weight_entropy_last, loss, g_srgb, g_lin, g_last);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_act_fwd(const float *z, int32_t tiles, int32_t rows, int32_t n_ch, int act, float *out,
+                        void *stream)
+{
+    if (tiles < 0 || rows < 1 || n_ch < 0 || n_ch > rows || (act != 0 && act != 1)) return ESR_EINVAL;
+    if (tiles == 0) return 0;
+    if (!z || !out) return ESR_EINVAL;
+    act_kernel<false><<<esr_grid_for((int64_t)tiles * rows * 32, 256), 256, 0, esr_stream(stream)>>>(
+        z, nullptr, tiles, rows, n_ch, act, out);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_act_bwd(const float *z, const float *g, int32_t tiles, int32_t rows, int32_t n_ch, int act,
+                        float *dz, void *stream)
+{
+    if (tiles < 0 || rows < 1 || n_ch < 0 || n_ch > rows || (act != 0 && act != 1)) return ESR_EINVAL;
+    if (tiles == 0) return 0;
+    if (!z || !g || !dz) return ESR_EINVAL;
+    act_kernel<true><<<esr_grid_for((int64_t)tiles * rows * 32, 256), 256, 0, esr_stream(stream)>>>(
+        z, g, tiles, rows, n_ch, act, dz);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_composite3_fwd(const float *v, int32_t rows, const int32_t *rec_ray, const float *rec_w,
+                               int32_t tiles, float *out, void *stream)
+{
+    if (tiles < 0 || rows < 3) return ESR_EINVAL;
+    if (tiles == 0) return 0;
+    if (!v || !rec_ray || !rec_w || !out) return ESR_EINVAL;
+    composite3_fwd_kernel<<<esr_grid_for(((int64_t)tiles * 32 + 63) / 64 * 64, 256), 256, 0, esr_stream(stream)>>>(
+        v, rows, rec_ray, rec_w, tiles, out);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_composite3_bwd(const float *g, const float *v, int32_t rows, const int32_t *rec_ray,
+                               const float *rec_w, int32_t tiles, int accumulate, float *dv, float *dweight,
+                               void *stream)
+{
+    if (tiles < 0 || rows < 3) return ESR_EINVAL;
+    if (tiles == 0) return 0;
+    if (!g || !v || !rec_ray || !rec_w || !dv || !dweight) return ESR_EINVAL;
+    composite3_bwd_kernel<<<esr_grid_for((int64_t)tiles * 32, 256), 256, 0, esr_stream(stream)>>>(
+        g, v, rows, rec_ray, rec_w, tiles, accumulate, dv, dweight);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_lts_tone_in_bwd(const float *dXt, const float *g_lin, const float *lin, const float *z_off,
+                                const float *z_emo, const int32_t *rec_ray, const float *rec_w,
+                                int32_t tiles_on, int32_t tiles_all, float *dz_off, float *dz_emo, void *stream)
+{
+    if (tiles_all < 0 || tiles_on < 0 || tiles_on > tiles_all) return ESR_EINVAL;
+    if (tiles_all == 0) return 0;
+    if (!dXt || !g_lin || !lin || !z_off || (tiles_on && (!z_emo || !dz_emo)) || !rec_ray || !rec_w || !dz_off)
+        return ESR_EINVAL;
+    lts_tone_in_bwd_kernel<<<esr_grid_for((int64_t)tiles_all * 32, 256), 256, 0, esr_stream(stream)>>>(
+        dXt, g_lin, lin, z_off, z_emo, rec_ray, rec_w, tiles_on, tiles_all, dz_off, dz_emo);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_sample_points(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                              const int32_t *rec_ray, const int32_t *rec_step, int32_t n, float *pts,
+                              void *stream)
+{
+    if (!scene || n < 0) return ESR_EINVAL;
+    if (n == 0) return 0;
+    if (!rays_o || !rays_d || !rec_ray || !rec_step || !pts) return ESR_EINVAL;
+    sample_points_kernel<<<esr_grid_for(n, 256), 256, 0, esr_stream(stream)>>>(*scene, rays_o, rays_d, rec_ray,
+                                                                               rec_step, n, pts);
     ESR_CHECK_LAUNCH();
     return 0;
 }

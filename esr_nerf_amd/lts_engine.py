@@ -1,0 +1,504 @@
+"""Host driver of the LTS / PDRA renderer (``ESRNeRF.forward_training``, reference:
+app/fine/model/esrnerf.py:486-851) on the kernels of libesr_hip.so.
+
+Three sampling passes share one set of kernels:
+  primary   the camera rays (march records)        -> srgb/lin/emit composites, per-sample heads
+  points    the P chosen surface samples, twice    -> "lin/pbr/off", "lin/pbr/emo" (explicit points)
+  secondary P x R hemisphere rays (march records)  -> incoming radiance for the rendering equation
+and ``esr_lts_combine_*`` ties them together (env map, Disney reflection, hemisphere means).
+
+Arithmetic is in HIP kernels; torch is used for memory, for re-ordering per-sample tensors
+between the kernels' compact tile order and the reference's ray-sorted order (index_select /
+index_add on small arrays), for the random draws (``torch.randn`` / ``np.random.choice`` exactly
+where the reference draws them) and for the autograd edge.  The perturbed re-evaluations
+("etc/emit_eps", "etc/brdf_eps", used by the PDRA trainer only) are forward-only this round.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .fine_engine import DX_ROWS, KIND_RADIANCE, KIND_TONEMAP, X_ROWS, XT_ROWS, FineEngine
+
+KIND_BRDF, KIND_EMIT = 2, 3
+ACT_SOFTPLUS, ACT_SIGMOID = 0, 1
+
+
+class Pass:
+    """Records + tile-major workspace of one sampling pass (grow-only)."""
+
+    def __init__(self, device, name):
+        self.device, self.name = device, name
+        self.cap = 0
+        self.bufs: Dict[str, torch.Tensor] = {}
+        self.rows: Dict[str, int] = {}
+        self.tiles_on = self.tiles_all = 0
+        self.n_rays = 0
+        self.counts: Dict[str, int] = {}
+        self.fa = None            # esr_feat_args_t
+        self.keep: List[torch.Tensor] = []   # tensors referenced by raw pointers
+
+    def ensure(self, tiles):
+        if tiles > self.cap:
+            self.cap = max(tiles, int(self.cap * 1.25) + 16)
+            self.bufs = {}
+
+    def buf(self, name, rows=1, dtype=torch.float32):
+        t = self.bufs.get(name)
+        if t is None:
+            t = torch.empty(self.cap * rows * 32, dtype=dtype, device=self.device)
+            self.bufs[name] = t
+            self.rows[name] = rows
+        return t
+
+    def rowmajor(self, name, tiles=None):
+        """[tiles*32, rows] copy of a tile-major buffer."""
+        tiles = self.tiles_all if tiles is None else tiles
+        r = self.rows[name]
+        return self.bufs[name][: tiles * r * 32].view(tiles, r, 32).permute(0, 2, 1).reshape(tiles * 32, r)
+
+    def from_rowmajor(self, name, rows, x):
+        """write a [tiles*32, c<=rows] row-major tensor into a tile-major buffer (rest zero)."""
+        tiles = x.shape[0] // 32
+        t = self.buf(name, rows)
+        v = t[: tiles * rows * 32].view(tiles, rows, 32)
+        v.zero_()
+        v[:, : x.shape[1], :] = x.view(tiles, 32, x.shape[1]).permute(0, 2, 1)
+        return t
+
+
+@dataclass
+class LtsCtx:
+    scene: object
+    scene2: object
+    batch: Dict[str, torch.Tensor]
+    perm: torch.Tensor                 # compact index of every surviving sample, in reference order
+    jp: torch.Tensor                   # compact indices of the LTS points
+    n_pts: int
+    n_2nd: int
+    pdra: bool
+    t: Dict[str, torch.Tensor] = field(default_factory=dict)
+    eps: Dict[str, float] = field(default_factory=dict)
+
+
+class LtsEngine(FineEngine):
+    def __init__(self, device):
+        super().__init__(device)
+        self.prim = Pass(self.device, "primary")
+        self.pts = Pass(self.device, "points")
+        self.sec = Pass(self.device, "secondary")
+        self.epsp = Pass(self.device, "eps")
+        for k, kind in (("brdf", KIND_BRDF), ("emit", KIND_EMIT)):
+            self.packed[k] = torch.empty(self.L.esr_mlp_packed_floats(kind), dtype=torch.float32,
+                                         device=self.device)
+
+    # ------------------------------------------------------------------ building blocks
+    def _march(self, P: Pass, scene, rays_o, rays_d, em_modes, mask_density, sdf):
+        L, s = self.L, self._s()
+        n = rays_o.shape[0]
+        P.n_rays = n
+        cnt3 = torch.empty(n, dtype=torch.int32, device=self.device)
+        off3 = torch.empty(n, dtype=torch.int32, device=self.device)
+        last = torch.empty(n, dtype=torch.float32, device=self.device)
+        sp = C.byref(scene)
+        self._run("plan_begin", L.esr_fine_plan_begin, _lib.ptr(self.plan_dev), s)
+        self._run(f"march_count[{P.name}]", L.esr_fine_march_count, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
+                  _lib.ptr(mask_density), _lib.ptr(sdf), n, _lib.ptr(cnt3), _lib.ptr(last), _lib.ptr(self.plan_dev), s)
+        self._run("plan", L.esr_fine_plan, _lib.ptr(cnt3), _lib.ptr(em_modes), n, _lib.ptr(off3),
+                  _lib.ptr(self.plan_dev), s)
+        self.plan_host.copy_(self.plan_dev, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        n_on, n_off, tiles_on, tiles_all, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
+        if overflow:
+            raise RuntimeError("a ray exceeded scene.max_steps; the LDS bound of the march kernel is wrong")
+        P.tiles_on, P.tiles_all = tiles_on, tiles_all
+        P.counts = dict(m0=m0, m1=m1, m2=m2, m3=n_on + n_off, n_on=n_on, n_off=n_off)
+        P.ensure(max(tiles_all, 1))
+        rec_ray = P.buf("rec_ray", 1, torch.int32)
+        rec_ray[: max(tiles_all, 1) * 32].fill_(-1)
+        if tiles_all:
+            self._run(f"march_fill[{P.name}]", L.esr_fine_march_fill, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
+                      _lib.ptr(mask_density), _lib.ptr(sdf), n, _lib.ptr(off3), _lib.ptr(rec_ray),
+                      _lib.ptr(P.buf("rec_step", 1, torch.int32)), _lib.ptr(P.buf("rec_w")),
+                      _lib.ptr(P.buf("rec_sdf")), s)
+        P.keep = [rays_o, rays_d, em_modes, cnt3, off3, last]
+        return cnt3, off3, last
+
+    def _feat_args_records(self, P: Pass, rays_o, rays_d, viewdirs, sdf, color_on, color_off):
+        fa = _lib.EsrFeatArgs()
+        fa.rays_o, fa.rays_d, fa.viewdirs = rays_o.data_ptr(), rays_d.data_ptr(), viewdirs.data_ptr()
+        fa.rec_ray, fa.rec_step = P.bufs["rec_ray"].data_ptr(), P.bufs["rec_step"].data_ptr()
+        fa.rec_sdf = P.bufs["rec_sdf"].data_ptr()
+        fa.sdf = sdf.data_ptr()
+        for g in range(3):
+            fa.color_on[g] = color_on[g].data_ptr() if color_on[g] is not None else None
+            fa.color_off[g] = color_off[g].data_ptr() if color_off[g] is not None else None
+        fa.tiles_on, fa.tiles_all = P.tiles_on, P.tiles_all
+        P.fa = fa
+        P.keep += [viewdirs]
+        return fa
+
+    def _feat_args_points(self, P: Pass, pts, vd, sdfv, sdf, colors):
+        n = pts.shape[0]
+        tiles = (n + 31) // 32
+        P.tiles_on, P.tiles_all = 0, tiles
+        P.ensure(tiles)
+        fa = _lib.EsrFeatArgs()
+        fa.pts, fa.pt_viewdirs, fa.pt_sdf, fa.n_pts = pts.data_ptr(), vd.data_ptr(), sdfv.data_ptr(), n
+        fa.sdf = sdf.data_ptr()
+        for g in range(3):
+            fa.color_on[g] = None
+            fa.color_off[g] = colors[g].data_ptr() if colors[g] is not None else None
+        fa.tiles_on, fa.tiles_all = 0, tiles
+        P.fa = fa
+        P.keep = [pts, vd, sdfv]
+        return fa
+
+    def _features(self, P: Pass, scene):
+        if P.tiles_all:
+            self._run(f"feat_fwd[{P.name}]", self.L.esr_fine_feat_fwd, C.byref(scene), C.byref(P.fa),
+                      _lib.ptr(P.buf("X", X_ROWS)), _lib.ptr(P.buf("gnorm", 4)), self._s())
+
+    def _net_fwd(self, P: Pass, net, kind, crow, t0, t1, save=True):
+        hid, nh, zrows = ((192, 3, 4) if kind == KIND_RADIANCE else (192, 1, 4) if kind == KIND_TONEMAP
+                          else (128, 3, 8) if kind == KIND_BRDF else (128, 3, 4))
+        H = [P.buf(f"{net}.H{l}", hid) for l in range(nh)]
+        M = [P.buf(f"{net}.M{l}", hid // 32 // 2 * 2, torch.int32) for l in range(nh)]
+        z = P.buf(f"{net}.z", zrows)
+        x = P.bufs["Xt"] if kind == KIND_TONEMAP else P.bufs["X"]
+        if t1 > t0:
+            self._run(f"mlp_fwd({net})[{P.name}]", self.L.esr_mlp_fwd, kind, _lib.ptr(self.packed[net]),
+                      _lib.ptr(x), t0, t1, _lib.ptr_array(H), _lib.ptr_array(M), 1 if save else 0, crow,
+                      _lib.ptr(z), self._s())
+        return z
+
+    def _net_bwd(self, P: Pass, net, kind, crow, t0, t1, dz, gw, gb):
+        """dgrad + wgrad of one net over tiles [t0,t1); returns its dX buffer."""
+        hid, nh = ((192, 3) if kind == KIND_RADIANCE else (192, 1) if kind == KIND_TONEMAP else (128, 3))
+        H = [P.bufs[f"{net}.H{l}"] for l in range(nh)]
+        M = [P.bufs[f"{net}.M{l}"] for l in range(nh)]
+        dZ = [P.buf(f"{net}.dZ{l}", hid) for l in range(nh)]
+        dX = P.buf(f"{net}.dX", DX_ROWS)
+        x = P.bufs["Xt"] if kind == KIND_TONEMAP else P.bufs["X"]
+        if t1 > t0:
+            s = self._s()
+            self._run(f"mlp_dgrad({net})[{P.name}]", self.L.esr_mlp_dgrad, kind, _lib.ptr(self.packed[net]),
+                      _lib.ptr(dz), t0, t1, _lib.ptr_array(M), _lib.ptr_array(dZ), _lib.ptr(dX), s)
+            self._run(f"mlp_wgrad({net})[{P.name}]", self.L.esr_mlp_wgrad, kind, _lib.ptr(x), crow,
+                      _lib.ptr_array(H), _lib.ptr_array(dZ), _lib.ptr(dz), t0, t1, _lib.ptr_array(gw),
+                      _lib.ptr_array(gb), _lib.ptr(self.wgrad_scratch), C.c_int64(self.wgrad_scratch.numel()), s)
+        return dX
+
+    def _act(self, P, zname, out, rows, n_ch, act, bwd_g=None, tiles=None):
+        tiles = P.tiles_all if tiles is None else tiles
+        o = P.buf(out, rows)
+        if tiles:
+            if bwd_g is None:
+                self._run("act_fwd", self.L.esr_act_fwd, _lib.ptr(P.bufs[zname]), tiles, rows, n_ch, act, _lib.ptr(o), self._s())
+            else:
+                self._run("act_bwd", self.L.esr_act_bwd, _lib.ptr(P.bufs[zname]), _lib.ptr(bwd_g), tiles, rows, n_ch, act,
+                          _lib.ptr(o), self._s())
+        return o
+
+    def _feat_bwd(self, P: Pass, scene, sources, grad_sdf, dsdf_extra=None, dsdf_out=None):
+        if not P.tiles_all:
+            return
+        src = (_lib.EsrFeatBwdSrc * len(sources))()
+        for i, (dX, gon, goff, t0, t1) in enumerate(sources):
+            src[i].dX = dX.data_ptr()
+            src[i].grad_color_on = gon.data_ptr() if gon is not None else None
+            src[i].grad_color_off = goff.data_ptr() if goff is not None else None
+            src[i].t0, src[i].t1 = t0, t1
+        self._run(f"feat_bwd[{P.name}]", self.L.esr_fine_feat_bwd, C.byref(scene), C.byref(P.fa),
+                  _lib.ptr(P.bufs["X"]), _lib.ptr(P.bufs["gnorm"]), src, len(sources), _lib.ptr(dsdf_extra),
+                  _lib.ptr(grad_sdf), _lib.ptr(dsdf_out), self._s())
+
+    # ------------------------------------------------------------------ forward
+    def lts_forward(self, scene, scene2, batch, grids, envmap, cfg, draws=None):
+        """grids: dict sdf [X,Y,Z], off/emo/brdf [X,Y,Z,6], mask [mx,my,mz].  cfg: num_2ndrays, num_ltspts,
+        normal_eps, emit_eps, pdra.  draws (optional): dict idx, dirs, noise_normal, noise_emit -- when
+        absent they are drawn exactly where the reference draws them."""
+        L, s, dev = self.L, self._s(), self.device
+        sdf, offg, emog, brdfg = grids["sdf"], grids["off"], grids["emo"], grids["brdf"]
+        rays_o, rays_d, viewdirs = batch["rays_o"], batch["rays_d"], batch["viewdirs"]
+        N = rays_o.shape[0]
+        P0 = self.prim
+        cnt3, off3, last = self._march(P0, scene, rays_o, rays_d, batch["em_modes"], grids["mask"], sdf)
+        T, Ton = P0.tiles_all, P0.tiles_on
+        srgb = torch.zeros(N, 3, device=dev)
+        lin_m = torch.zeros(N, 3, device=dev)
+        emit_m = torch.zeros(N, 3, device=dev)
+        ctx = LtsCtx(scene=scene, scene2=scene2, batch=batch, perm=None, jp=None, n_pts=0,
+                     n_2nd=int(cfg["num_2ndrays"]), pdra=bool(cfg["pdra"]))
+        ctx.t.update(cnt3=cnt3, off3=off3, last=last, grids=grids, envmap=envmap)
+        ctx.eps = dict(normal=float(cfg["normal_eps"]), emit=float(cfg["emit_eps"]))
+        m3 = P0.counts["m3"]
+        if T == 0:
+            raise RuntimeError("LTS step with no surviving sample (degenerate batch)")
+        sp = C.byref(scene)
+        self._feat_args_records(P0, rays_o, rays_d, viewdirs, sdf, (offg, emog, brdfg), (offg, emog, brdfg))
+        self._features(P0, scene)
+        # exact normals (+ positions) of every surviving sample
+        eg = torch.empty(T * 32, 4, device=dev)
+        self._run("expgrad_fwd", L.esr_expgrad_fwd, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(P0.bufs["rec_ray"]),
+                  _lib.ptr(P0.bufs["rec_step"]), None, None, C.c_float(0.0), _lib.ptr(sdf), T * 32, 0, _lib.ptr(eg), s)
+        pts_all = torch.empty(T * 32, 3, device=dev)
+        self._run("sample_points", L.esr_sample_points, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
+                  _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(P0.bufs["rec_step"]), T * 32, _lib.ptr(pts_all), s)
+        # radiance heads: off on every tile, emo on the on-tiles (both carry gradients, esrnerf.py:751-757)
+        self._net_fwd(P0, "off", KIND_RADIANCE, 0, 0, T)
+        self._net_fwd(P0, "emo", KIND_RADIANCE, 88, 0, Ton)
+        self._run("tone_in_fwd", L.esr_fine_tone_in_fwd, _lib.ptr(P0.bufs["off.z"]), _lib.ptr(P0.bufs["emo.z"]), Ton, T,
+                  _lib.ptr(P0.buf("lin", 4)), _lib.ptr(P0.buf("Xt", XT_ROWS)), s)
+        self._net_fwd(P0, "tone", KIND_TONEMAP, 0, 0, T)
+        self._run("composite_fwd", L.esr_fine_composite_fwd, _lib.ptr(P0.bufs["tone.z"]), _lib.ptr(P0.bufs["lin"]),
+                  _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(P0.bufs["rec_w"]), T, _lib.ptr(P0.buf("rgb", 4)),
+                  _lib.ptr(srgb), _lib.ptr(lin_m), s)
+        # material heads on every sample
+        self._net_fwd(P0, "brdf", KIND_BRDF, 96, 0, T)
+        self._net_fwd(P0, "emit", KIND_EMIT, 88, 0, T)
+        self._act(P0, "brdf.z", "brdf.a", 8, 5, ACT_SIGMOID)
+        self._act(P0, "emit.z", "emit.a", 4, 3, ACT_SOFTPLUS)
+        self._run("composite3_fwd(emit)", L.esr_composite3_fwd, _lib.ptr(P0.bufs["emit.a"]), 4,
+                  _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(P0.bufs["rec_w"]), T, _lib.ptr(emit_m), s)
+
+        # ---- compact order <-> the reference's ray-sorted order
+        n_on, n_off = P0.counts["n_on"], P0.counts["n_off"]
+        jidx = torch.cat([torch.arange(n_on, device=dev), Ton * 32 + torch.arange(n_off, device=dev)])
+        rec_ray = P0.bufs["rec_ray"][: T * 32].long()
+        ray_j = rec_ray[jidx]
+        ref_off = torch.cumsum(cnt3.long(), 0) - cnt3.long()
+        ref_pos = ref_off[ray_j] + (jidx - off3.long()[ray_j])
+        perm = torch.empty(m3, dtype=torch.long, device=dev)
+        perm[ref_pos] = jidx
+        ctx.perm = perm
+        brdf_rm = P0.rowmajor("brdf.a")            # [T*32, 8]
+        emit_rm = P0.rowmajor("emit.a")            # [T*32, 4]
+
+        # ---- light-transport segment
+        if draws is None:
+            idx_ref = torch.from_numpy(np.random.choice(m3, min(int(cfg["num_ltspts"]), m3), replace=False)).to(dev)
+        else:
+            idx_ref = draws["idx"].to(dev)
+        Pn, R = idx_ref.numel(), ctx.n_2nd
+        ctx.n_pts = Pn
+        jp = perm[idx_ref]
+        ctx.jp = jp
+        pts_p = pts_all[jp].contiguous()
+        ray_p = rec_ray[jp]
+        view_p = viewdirs[ray_p].contiguous()
+        normal_p = torch.nn.functional.normalize(eg[jp, 1:4], dim=-1).contiguous()      # detached normals
+        sdf_p = P0.bufs["rec_sdf"][: T * 32][jp].contiguous()
+        base_p, rough_p, metal_p = (brdf_rm[jp, 0:3].contiguous(), brdf_rm[jp, 3].contiguous(),
+                                    brdf_rm[jp, 4].contiguous())
+        emis_p = emit_rm[jp, 0:3].contiguous()
+        umask_p = batch["uncert_masks"][ray_p].to(torch.uint8).contiguous()
+        raw = torch.randn(Pn, R + 1, 3, device=dev) if draws is None else draws["dirs"].to(dev).contiguous()
+        dirs_all = torch.empty(Pn, R + 1, 3, device=dev)
+        self._run("lts_dirs", L.esr_lts_dirs, _lib.ptr(raw), _lib.ptr(normal_p), Pn, R + 1, _lib.ptr(dirs_all), s)
+        v_rand = (-dirs_all[:, R]).contiguous()
+        # (a) radiance predicted by the nets at the points, camera direction and random direction
+        P1 = self.pts
+        pts2 = torch.cat([pts_p, pts_p]).contiguous()
+        vd2 = torch.cat([view_p, v_rand]).contiguous()
+        sdf2 = torch.cat([sdf_p, sdf_p]).contiguous()
+        self._feat_args_points(P1, pts2, vd2, sdf2, sdf, (offg, emog, None))
+        self._features(P1, scene)
+        T1 = P1.tiles_all
+        self._net_fwd(P1, "off", KIND_RADIANCE, 0, 0, T1)
+        self._net_fwd(P1, "emo", KIND_RADIANCE, 88, 0, T1)
+        self._act(P1, "off.z", "off.a", 4, 3, ACT_SOFTPLUS)
+        self._act(P1, "emo.z", "emo.a", 4, 3, ACT_SOFTPLUS)
+        off_pt = P1.rowmajor("off.a")[: 2 * Pn, :3].contiguous()
+        emo_pt = P1.rowmajor("emo.a")[: 2 * Pn, :3].contiguous()
+        # (b) incoming radiance along the secondary rays
+        P2 = self.sec
+        o2 = pts_p.repeat_interleave(R, 0).contiguous()
+        d2 = dirs_all[:, :R].reshape(Pn * R, 3).contiguous()
+        em2 = torch.zeros(Pn * R, dtype=torch.int64, device=dev)
+        _, off3_2, last2 = self._march(P2, scene2, o2, d2, em2, grids["mask"], sdf)
+        T2 = P2.tiles_all
+        off_m = torch.zeros(Pn * R, 3, device=dev)
+        emo_m = torch.zeros(Pn * R, 3, device=dev)
+        if T2:
+            self._feat_args_records(P2, o2, d2, d2, sdf, (offg, emog, None), (offg, emog, None))
+            self._features(P2, scene2)
+            self._net_fwd(P2, "off", KIND_RADIANCE, 0, 0, T2)
+            self._net_fwd(P2, "emo", KIND_RADIANCE, 88, 0, T2)
+            self._act(P2, "off.z", "off.a", 4, 3, ACT_SOFTPLUS)
+            self._act(P2, "emo.z", "emo.a", 4, 3, ACT_SOFTPLUS)
+            for nm, dst in (("off.a", off_m), ("emo.a", emo_m)):
+                self._run("composite3_fwd", L.esr_composite3_fwd, _lib.ptr(P2.bufs[nm]), 4, _lib.ptr(P2.bufs["rec_ray"]),
+                          _lib.ptr(P2.bufs["rec_w"]), T2, _lib.ptr(dst), s)
+        # (c) rendering equation
+        a = _lib.EsrLtsArgs()
+        a.n_pts, a.n_rays, a.n_sg, a.pdra_mode = Pn, R, envmap["mus"].shape[0], 1 if ctx.pdra else 0
+        lam = envmap["lambdas"].reshape(-1).contiguous()
+        held = dict(base=base_p, rough=rough_p, metal=metal_p, normal=normal_p, view=view_p, dirs=dirs_all,
+                    off_m=off_m, emo_m=emo_m, last2=last2, mus=envmap["mus"].contiguous(), lambdas=lam,
+                    lobes=envmap["lobes"].contiguous(), emission=emis_p, umask=umask_p)
+        for k, v in held.items():
+            setattr(a, k, v.data_ptr())
+        off_hat = torch.empty(2 * Pn, 3, device=dev)
+        emo_hat = torch.empty(2 * Pn, 3, device=dev)
+        self._run("lts_combine_fwd", L.esr_lts_combine_fwd, C.byref(a), _lib.ptr(off_hat), _lib.ptr(emo_hat), s)
+        ctx.t.update(held=held, lts_args=a, off3_2=off3_2, o2=o2, d2=d2, eg=eg, pts_all=pts_all)
+
+        # ---- perturbed re-evaluations (esrnerf.py:807-830)
+        nn_ = torch.randn(m3, 3, device=dev) if draws is None else draws["noise_normal"].to(dev)
+        ne_ = torch.randn(m3, 3, device=dev) if draws is None else draws["noise_emit"].to(dev)
+        noise_n = torch.zeros(T * 32, 3, device=dev)
+        noise_n[perm] = nn_
+        eg_eps = torch.empty(T * 32, 4, device=dev)
+        self._run("expgrad_fwd(eps)", L.esr_expgrad_fwd, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(P0.bufs["rec_ray"]),
+                  _lib.ptr(P0.bufs["rec_step"]), None, _lib.ptr(noise_n), C.c_float(ctx.eps["normal"]), _lib.ptr(sdf),
+                  T * 32, 0, _lib.ptr(eg_eps), s)
+        ctx.t.update(noise_n=noise_n)
+        # emit_eps / brdf_eps: forward only (explicit points in reference order)
+        P3 = self.epsp
+        pts_e = (pts_all[perm] + ne_ * ctx.eps["emit"]).contiguous()
+        sv = torch.empty(m3, 4, device=dev)
+        self._run("expgrad_fwd(pts)", L.esr_expgrad_fwd, sp, None, None, None, None, _lib.ptr(pts_e), None, C.c_float(0.0),
+                  _lib.ptr(sdf), m3, 1, _lib.ptr(sv), s)
+        sdf_e = sv[:, 0].contiguous()
+        vd_e = torch.zeros(m3, 3, device=dev)
+        self._feat_args_points(P3, pts_e, vd_e, sdf_e, sdf, (None, emog, brdfg))
+        self._features(P3, scene)
+        T3 = P3.tiles_all
+        self._net_fwd(P3, "emit", KIND_EMIT, 88, 0, T3, save=False)
+        self._net_fwd(P3, "brdf", KIND_BRDF, 96, 0, T3, save=False)
+        self._act(P3, "emit.z", "emit.a", 4, 3, ACT_SOFTPLUS)
+        self._act(P3, "brdf.z", "brdf.a", 8, 5, ACT_SIGMOID)
+        emit_eps = P3.rowmajor("emit.a")[:m3, :3].contiguous()
+        brdf_eps = P3.rowmajor("brdf.a")[:m3, :5].contiguous()
+
+        um = batch["uncert_masks"]
+        out = {
+            "etc/alphainv_cum": last, "srgb/rgb": srgb, "lin/rgb": lin_m,
+            "lin/pbr/off": off_pt, "lin/pbr/off_hat": off_hat, "lin/pbr/emo": emo_pt, "lin/pbr/emo_hat": emo_hat,
+            "emit_marched": emit_m,
+            "etc/normal": eg[perm, 1:4].contiguous(), "etc/normal_eps": eg_eps[perm, 1:4].contiguous(),
+            "etc/emit": emit_rm[perm, :3].contiguous(), "etc/emit_eps": emit_eps,
+            "etc/brdf": brdf_rm[perm, :5].contiguous(), "etc/brdf_eps": brdf_eps,
+        }
+        ctx.t["um"] = um
+        return ctx, out
+
+    # ------------------------------------------------------------------ backward
+    def lts_backward(self, ctx: LtsCtx, g: Dict[str, Optional[torch.Tensor]], grads):
+        """g: gradients w.r.t. the tensors of lts_forward's dict (None = zero).  grads: zero-initialised
+        dict: sdf, off, emo, brdf grids; {off,emo,tone,brdf,emit}_{w,b} lists; mus, lambdas, lobes."""
+        L, s, dev = self.L, self._s(), self.device
+        P0, P1, P2 = self.prim, self.pts, self.sec
+        T, Ton = P0.tiles_all, P0.tiles_on
+        Pn, R = ctx.n_pts, ctx.n_2nd
+        perm, jp = ctx.perm, ctx.jp
+        zero = lambda k, shape: g[k].contiguous() if g.get(k) is not None else torch.zeros(shape, device=dev)
+        sp, sp2 = C.byref(ctx.scene), C.byref(ctx.scene2)
+        b = ctx.batch
+        grid_g = grads
+
+        # ---- rendering equation
+        g_oh, g_eh = zero("lin/pbr/off_hat", (2 * Pn, 3)), zero("lin/pbr/emo_hat", (2 * Pn, 3))
+        z = lambda *sh: torch.zeros(*sh, device=dev)
+        d = dict(d_off_m=z(Pn * R, 3), d_emo_m=z(Pn * R, 3), d_last2=z(Pn * R), d_base=z(Pn, 3), d_rough=z(Pn),
+                 d_metal=z(Pn), d_emission=z(Pn, 3), d_mus=grads["mus"], d_lambdas=grads["lambdas"].view(-1),
+                 d_lobes=grads["lobes"])
+        gs = _lib.EsrLtsGrads()
+        for k, v in d.items():
+            setattr(gs, k, v.data_ptr())
+        self._run("lts_combine_bwd", L.esr_lts_combine_bwd, C.byref(ctx.t["lts_args"]), _lib.ptr(g_oh), _lib.ptr(g_eh),
+                  C.byref(gs), s)
+
+        # ---- secondary rays
+        T2 = P2.tiles_all
+        if T2:
+            dw2 = P2.buf("dweight")
+            for i, (nm, gm) in enumerate((("off", d["d_off_m"]), ("emo", d["d_emo_m"]))):
+                da = P2.buf(f"{nm}.da", 4)
+                self._run("composite3_bwd", L.esr_composite3_bwd, _lib.ptr(gm), _lib.ptr(P2.bufs[f"{nm}.a"]), 4,
+                          _lib.ptr(P2.bufs["rec_ray"]), _lib.ptr(P2.bufs["rec_w"]), T2, 2 if i else 0, _lib.ptr(da),
+                          _lib.ptr(dw2), s)      # (second call: fresh dv, accumulated dweight)
+            src = []
+            for nm, crow, gon in (("off", 0, grads["off"]), ("emo", 88, grads["emo"])):
+                dz = self._act(P2, f"{nm}.z", f"{nm}.dz", 4, 3, ACT_SOFTPLUS, bwd_g=P2.bufs[f"{nm}.da"])
+                dX = self._net_bwd(P2, nm, KIND_RADIANCE, crow, 0, T2, dz, grads[f"{nm}_w"], grads[f"{nm}_b"])
+                src.append((dX, None, gon, 0, T2))
+            self._feat_bwd(P2, ctx.scene2, src, grads["sdf"])
+            dweight2 = dw2
+        else:
+            dweight2 = z(32)
+        self._run("march_bwd[secondary]", L.esr_fine_march_bwd, sp2, _lib.ptr(ctx.t["o2"]), _lib.ptr(ctx.t["d2"]),
+                  _lib.ptr(ctx.t["grids"]["mask"]), _lib.ptr(ctx.t["grids"]["sdf"]), Pn * R, _lib.ptr(ctx.t["off3_2"]),
+                  _lib.ptr(dweight2), _lib.ptr(d["d_last2"]), _lib.ptr(grads["sdf"]), s)
+
+        # ---- radiance at the points
+        T1 = P1.tiles_all
+        src = []
+        for nm, crow, key, gon in (("off", 0, "lin/pbr/off", grads["off"]), ("emo", 88, "lin/pbr/emo", grads["emo"])):
+            ga = torch.zeros(T1 * 32, 3, device=dev)
+            ga[: 2 * Pn] = zero(key, (2 * Pn, 3))
+            gt = P1.from_rowmajor(f"{nm}.ga", 4, ga)
+            dz = self._act(P1, f"{nm}.z", f"{nm}.dz", 4, 3, ACT_SOFTPLUS, bwd_g=gt)
+            dX = self._net_bwd(P1, nm, KIND_RADIANCE, crow, 0, T1, dz, grads[f"{nm}_w"], grads[f"{nm}_b"])
+            src.append((dX, None, gon, 0, T1))
+        dsdf_pts = torch.zeros(T1 * 32, device=dev)
+        self._feat_bwd(P1, ctx.scene, src, grads["sdf"], dsdf_out=dsdf_pts)
+
+        # ---- primary pass: assemble per-sample head gradients in compact order
+        def to_compact(key, c):
+            out = torch.zeros(T * 32, c, device=dev)
+            if g.get(key) is not None:
+                out[perm] = g[key]
+            return out
+        d_brdf = to_compact("etc/brdf", 5)
+        d_brdf.index_add_(0, jp, torch.cat([d["d_base"], d["d_rough"][:, None], d["d_metal"][:, None]], 1))
+        d_emit = to_compact("etc/emit", 3)
+        d_emit.index_add_(0, jp, d["d_emission"])
+        dsdf_extra = torch.zeros(T * 32, device=dev)
+        dsdf_extra.index_add_(0, jp, dsdf_pts[:Pn] + dsdf_pts[Pn: 2 * Pn])
+        # composites
+        g_srgb, g_lin = zero("srgb/rgb", (P0.n_rays, 3)), zero("lin/rgb", (P0.n_rays, 3))
+        g_em = zero("emit_marched", (P0.n_rays, 3))
+        g_last = zero("etc/alphainv_cum", (P0.n_rays,))
+        dweight = P0.buf("dweight")
+        self._run("composite_bwd", L.esr_fine_composite_bwd, _lib.ptr(g_srgb), _lib.ptr(g_lin), _lib.ptr(P0.bufs["rgb"]),
+                  _lib.ptr(P0.bufs["lin"]), _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(P0.bufs["rec_w"]), T, _lib.ptr(dweight),
+                  _lib.ptr(P0.buf("tone.dz", 4)), s)
+        d_emit_t = P0.from_rowmajor("emit.da", 4, d_emit)
+        self._run("composite3_bwd(emit)", L.esr_composite3_bwd, _lib.ptr(g_em), _lib.ptr(P0.bufs["emit.a"]), 4,
+                  _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(P0.bufs["rec_w"]), T, 3, _lib.ptr(d_emit_t), _lib.ptr(dweight), s)
+        d_brdf_t = P0.from_rowmajor("brdf.da", 8, d_brdf)
+        # tonemapper -> radiance heads
+        dXt = self._net_bwd(P0, "tone", KIND_TONEMAP, 0, 0, T, P0.bufs["tone.dz"], grads["tone_w"], grads["tone_b"])
+        self._run("lts_tone_in_bwd", L.esr_lts_tone_in_bwd, _lib.ptr(dXt), _lib.ptr(g_lin), _lib.ptr(P0.bufs["lin"]),
+                  _lib.ptr(P0.bufs["off.z"]), _lib.ptr(P0.bufs["emo.z"]), _lib.ptr(P0.bufs["rec_ray"]),
+                  _lib.ptr(P0.bufs["rec_w"]), Ton, T, _lib.ptr(P0.buf("off.dz", 4)), _lib.ptr(P0.buf("emo.dz", 4)), s)
+        src = [(self._net_bwd(P0, "off", KIND_RADIANCE, 0, 0, T, P0.bufs["off.dz"], grads["off_w"], grads["off_b"]),
+                grads["off"], grads["off"], 0, T),
+               (self._net_bwd(P0, "emo", KIND_RADIANCE, 88, 0, Ton, P0.bufs["emo.dz"], grads["emo_w"], grads["emo_b"]),
+                grads["emo"], grads["emo"], 0, Ton)]
+        dzb = self._act(P0, "brdf.z", "brdf.dz", 8, 5, ACT_SIGMOID, bwd_g=d_brdf_t)
+        dze = self._act(P0, "emit.z", "emit.dz", 4, 3, ACT_SOFTPLUS, bwd_g=d_emit_t)
+        src.append((self._net_bwd(P0, "brdf", KIND_BRDF, 96, 0, T, dzb, grads["brdf_w"], grads["brdf_b"]),
+                    grads["brdf"], grads["brdf"], 0, T))
+        src.append((self._net_bwd(P0, "emit", KIND_EMIT, 88, 0, T, dze, grads["emit_w"], grads["emit_b"]),
+                    grads["emo"], grads["emo"], 0, T))
+        self._feat_bwd(P0, ctx.scene, src, grads["sdf"], dsdf_extra=dsdf_extra)
+        self._run("march_bwd", L.esr_fine_march_bwd, sp, _lib.ptr(b["rays_o"]), _lib.ptr(b["rays_d"]),
+                  _lib.ptr(ctx.t["grids"]["mask"]), _lib.ptr(ctx.t["grids"]["sdf"]), P0.n_rays, _lib.ptr(ctx.t["off3"]),
+                  _lib.ptr(dweight), _lib.ptr(g_last), _lib.ptr(grads["sdf"]), s)
+        # exact normals (linear in the grid): etc/normal and etc/normal_eps
+        for key, noise, eps in (("etc/normal", None, 0.0), ("etc/normal_eps", ctx.t["noise_n"], ctx.eps["normal"])):
+            if g.get(key) is None:
+                continue
+            g4 = torch.zeros(T * 32, 4, device=dev)
+            g4[perm, 1:4] = g[key]
+            self._run("expgrad_bwd", L.esr_expgrad_bwd, sp, _lib.ptr(b["rays_o"]), _lib.ptr(b["rays_d"]),
+                      _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(P0.bufs["rec_step"]), None, _lib.ptr(noise), C.c_float(eps),
+                      _lib.ptr(g4), T * 32, _lib.ptr(grads["sdf"]), s)

@@ -325,11 +325,13 @@ int esr_fine_loss_fwd_bwd(const float *srgb_marched, const float *lin_marched,
  * march records (rec_ray/rec_step, pts == NULL; padding records give zeros) or explicit
  * pts [n,3]; optional noise [n,3] * eps is added (the *_eps re-evaluations,
  * esrnerf.py:807-810).  out [n,4] = (sdf, d/dx, d/dy, d/dz) in WORLD xyz order.
+ * zero_pad != 0: corners outside the grid contribute zero instead of being border-replicated
+ * (F.grid_sample semantics of sample_sdf_grad, used for the perturbed emit/brdf evaluation).
  */
 int esr_expgrad_fwd(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
                     const int32_t *rec_ray, const int32_t *rec_step, const float *pts,
-                    const float *noise, float eps, const float *sdf, int32_t n, float *out,
-                    void *stream);
+                    const float *noise, float eps, const float *sdf, int32_t n, int zero_pad,
+                    float *out, void *stream);
 /* g [n,4] -> atomic scatter into grad_sdf [gx,gy,gz] (the op is linear in the grid). */
 int esr_expgrad_bwd(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
                     const int32_t *rec_ray, const int32_t *rec_step, const float *pts,
@@ -371,6 +373,30 @@ typedef struct esr_lts_grads {
 int esr_lts_combine_fwd(const esr_lts_args_t *args, float *off_hat, float *emo_hat, void *stream);
 int esr_lts_combine_bwd(const esr_lts_args_t *args, const float *g_off_hat, const float *g_emo_hat,
                         const esr_lts_grads_t *grads, void *stream);
+
+/*
+ * Small tile-major helpers of the LTS renderer.
+ *  esr_act_*: out = act(z) on the first n_ch rows of [tiles,rows,32] tiles, rest zero
+ *     (act 0 softplus: radiance / emission heads, 1 sigmoid: BRDF head; pbr/module.py:21,64,83).
+ *  esr_composite3_*: out[ray,c] += w * v[c] (segment sum over sorted rays, esrnerf.py:639-651,783-788)
+ *     and its backward (accumulate bit 0: add into dv, bit 1: add into dweight).
+ *  esr_lts_tone_in_bwd: as esr_fine_tone_in_bwd for lin = off + emo WITHOUT the detach
+ *     (esrnerf.py:751-757): dz_off on all tiles, dz_emo on the on-tiles.
+ *  esr_sample_points: world positions of the march records (padding -> 0).
+ */
+int esr_act_fwd(const float *z, int32_t tiles, int32_t rows, int32_t n_ch, int act, float *out, void *stream);
+int esr_act_bwd(const float *z, const float *g, int32_t tiles, int32_t rows, int32_t n_ch, int act,
+                float *dz, void *stream);
+int esr_composite3_fwd(const float *v, int32_t rows, const int32_t *rec_ray, const float *rec_w,
+                       int32_t tiles, float *out, void *stream);
+int esr_composite3_bwd(const float *g, const float *v, int32_t rows, const int32_t *rec_ray,
+                       const float *rec_w, int32_t tiles, int accumulate, float *dv, float *dweight,
+                       void *stream);
+int esr_lts_tone_in_bwd(const float *dXt, const float *g_lin, const float *lin, const float *z_off,
+                        const float *z_emo, const int32_t *rec_ray, const float *rec_w, int32_t tiles_on,
+                        int32_t tiles_all, float *dz_off, float *dz_emo, void *stream);
+int esr_sample_points(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                      const int32_t *rec_ray, const int32_t *rec_step, int32_t n, float *pts, void *stream);
 
 #ifdef __cplusplus
 }

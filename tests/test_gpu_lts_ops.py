@@ -57,7 +57,7 @@ def test_expgrad_fwd_bwd(with_noise):
     nz = noise.cuda().contiguous() if with_noise else None
     pd = pts.cuda().contiguous()
     _lib.check(L.esr_expgrad_fwd(C.byref(scene), None, None, None, None, _lib.ptr(pd), _lib.ptr(nz), C.c_float(eps),
-                                 _lib.ptr(gd), n, _lib.ptr(out), s), "expgrad_fwd")
+                                 _lib.ptr(gd), n, 0, _lib.ptr(out), s), "expgrad_fwd")
     assert rel_err(out[:, 0], sdf.detach()) < 1e-5
     assert rel_err(out[:, 1:], gr.detach()) < 1e-5
     gs = torch.zeros_like(gd)
