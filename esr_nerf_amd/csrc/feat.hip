@@ -182,7 +182,9 @@ __global__ void __launch_bounds__(256) feat_fwd_kernel(FeatParams P)
                 const float fp = esr_tri_fetch1(P.sdf, gdims, ixp);
                 Xt[(ROW_FEAT + (2 * ar) * 4 + k) * 32] = fm;
                 Xt[(ROW_FEAT + (2 * ar + 1) * 4 + k) * 32] = fp;
-                grad[ar][k] = (fp - fm) / (cp - cm) / sc.voxel_size;
+                // + 1e-12: the LTS renderer's guard (esrnerf.py:1560) for taps that clamp onto each other
+                // (points pushed outside the box); a no-op in fp32 for in-box samples, where cp - cm >= 0.5
+                grad[ar][k] = (fp - fm) / ((cp - cm) + 1e-12f) / sc.voxel_size;
             }
         }
 #pragma unroll
@@ -362,7 +364,19 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
         // corners -- 72 LDS atomics per sample instead of 200 (LDS float atomics retire ~1 lane per 1.5
         // clocks and were 59 % of this kernel's wave time).  Lane half 0 owns the z bar and the lower half
         // of the x bar, lane half 1 the y bar and the upper half of the x bar.
-        window_setup(w, i0, valid, gdims, 2, 3, 1);
+        // The reference clamps every coordinate of a tap to the grid (not only the displaced one), which
+        // matters for explicit points that a perturbation pushed outside the box: the bars are anchored
+        // at the clamped position (identical to `ind` for in-box samples).
+        float indc[3] = {0.f, 0.f, 0.f};
+        int i0c[3] = {0, 0, 0};
+        if (valid) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                indc[a] = fminf(fmaxf(ind[a], 0.f), (float)(gdims[a] - 1));
+                i0c[a] = (int)floorf(indc[a]);
+            }
+        }
+        window_setup(w, i0c, valid, gdims, 2, 3, 1);
         window_zero(w, lane);
         lds_fence();
         if (valid) {
@@ -386,8 +400,8 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
             float wc[3][2];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                wc[a][0] = (float)(i0[a] + 1) - ind[a];
-                wc[a][1] = ind[a] - (float)i0[a];
+                wc[a][0] = (float)(i0c[a] + 1) - indc[a];
+                wc[a][1] = indc[a] - (float)i0c[a];
             }
             float d_sdf = dxrow(ROW_SDF) + (P.dsdf_extra ? P.dsdf_extra[j] : 0.f);
             if (P.dsdf_out) {                 // explicit points: the SDF value is an input, not a grid tap
@@ -399,7 +413,7 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
                 // bar 0: z (h=0) or y (h=1); bar 1: x, split between the halves.  ar: reference axis order
                 const int ar = bar == 0 ? h : 2;
                 const int axis = 2 - ar;
-                const int iA = axis == 0 ? i0[0] : (axis == 1 ? i0[1] : i0[2]);
+                const int iA = axis == 0 ? i0c[0] : (axis == 1 ? i0c[1] : i0c[2]);
                 const int dimA = axis == 0 ? gdims[0] : (axis == 1 ? gdims[1] : gdims[2]);
                 const float indA = axis == 0 ? ind[0] : (axis == 1 ? ind[1] : ind[2]);
                 float acc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -423,7 +437,7 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
                         ixp = __fdiv_rn((__fdiv_rn(cp, top) * 2.0f - 1.0f) + 1.0f, 2.0f) * top;
                     }
                     const float thr = (ar == 0 ? through[0][k] : (ar == 1 ? through[1][k] : through[2][k])) /
-                                      (cp - cm) / sc.voxel_size;
+                                      ((cp - cm) + 1e-12f) / sc.voxel_size;
                     const float dfm = dxrow(ROW_FEAT + (2 * ar) * 4 + k) - thr;
                     const float dfp = dxrow(ROW_FEAT + (2 * ar + 1) * 4 + k) + thr;
                     deposit(ixm, dfm);
@@ -444,8 +458,8 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
                             const float wgt = (pb == 0 ? wc[0][b] : wc[1][b]) * (pc == 1 ? wc[1][c] : wc[2][c]);
                             int xyz[3];
                             xyz[axis] = cA;
-                            xyz[pb] = (pb == 0 ? i0[0] : i0[1]) + b;
-                            xyz[pc] = (pc == 1 ? i0[1] : i0[2]) + c;
+                            xyz[pb] = (pb == 0 ? i0c[0] : i0c[1]) + b;
+                            xyz[pc] = (pc == 1 ? i0c[1] : i0c[2]) + c;
                             const bool inb = (xyz[pb] < (pb == 0 ? gdims[0] : gdims[1])) &
                                              (xyz[pc] < (pc == 1 ? gdims[1] : gdims[2]));
                             if (inb && wgt != 0.f) window_add(w, P.grad_sdf, gdims, xyz[0], xyz[1], xyz[2], 0, acc6[o] * wgt);

@@ -99,14 +99,15 @@ __global__ void __launch_bounds__(256) expgrad_kernel(ExpGradParams P)
                     const float c0 = w[0][cx] * w[1][cy] * w[2][cz];
                     const float c1 = sx * w[1][cy] * w[2][cz], c2 = w[0][cx] * sy * w[2][cz],
                                 c3 = w[0][cx] * w[1][cy] * sz;
+                    const bool inb = (i0[0] + cx >= 0) & (i0[0] + cx < dims[0]) & (i0[1] + cy >= 0) &
+                                     (i0[1] + cy < dims[1]) & (i0[2] + cz >= 0) & (i0[2] + cz < dims[2]);
+                    const bool dropped = P.zero_pad && !inb;        // F.grid_sample zero padding
                     if (!BWD) {
-                        const bool inb = (i0[0] + cx >= 0) & (i0[0] + cx < dims[0]) & (i0[1] + cy >= 0) &
-                                         (i0[1] + cy < dims[1]) & (i0[2] + cz >= 0) & (i0[2] + cz < dims[2]);
-                        const float gcell = (P.zero_pad && !inb) ? 0.f : P.sdf[cell];
+                        const float gcell = dropped ? 0.f : P.sdf[cell];
                         val += gcell * c0; d[0] += gcell * c1; d[1] += gcell * c2; d[2] += gcell * c3;
                     } else {
                         const float t = gv * c0 + gd[0] * c1 + gd[1] * c2 + gd[2] * c3;
-                        if (t != 0.f) atomicAdd(&P.grad_sdf[cell], t);
+                        if (t != 0.f && !dropped) atomicAdd(&P.grad_sdf[cell], t);
                     }
                 }
         if (!BWD) {
@@ -387,15 +388,15 @@ ESR_API int esr_expgrad_fwd(const esr_scene_t *scene, const float *rays_o, const
 
 ESR_API int esr_expgrad_bwd(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
                             const int32_t *rec_ray, const int32_t *rec_step, const float *pts,
-                            const float *noise, float eps, const float *g, int32_t n, float *grad_sdf,
-                            void *stream)
+                            const float *noise, float eps, const float *g, int32_t n, int zero_pad,
+                            float *grad_sdf, void *stream)
 {
     if (!scene || n < 0) return ESR_EINVAL;
     if (n == 0) return 0;
     if (!g || !grad_sdf || (!pts && (!rays_o || !rays_d || !rec_ray || !rec_step))) return ESR_EINVAL;
     ExpGradParams P = {};
     P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d; P.rec_ray = rec_ray; P.rec_step = rec_step;
-    P.pts = pts; P.noise = noise; P.eps = eps; P.n = n; P.g = g; P.grad_sdf = grad_sdf;
+    P.pts = pts; P.noise = noise; P.eps = eps; P.n = n; P.g = g; P.grad_sdf = grad_sdf; P.zero_pad = zero_pad;
     expgrad_kernel<true><<<esr_grid_for(n, 256), 256, 0, esr_stream(stream)>>>(P);
     ESR_CHECK_LAUNCH();
     return 0;

@@ -8,8 +8,7 @@ name, cfg/app/lts.yaml:61-71) and ``state_dict`` keys.  ``forward_training`` is 
 node over the kernels of libesr_hip.so (esr_nerf_amd/lts_engine.py).
 
 Not yet provided: ``forward_evaluate``, ``forward_finetune``, ``eval_emit``, ``eval_esp``,
-``render_envmap``; gradients of "etc/emit_eps" / "etc/brdf_eps" (only the
-PDRA trainer's loss reads them) are not propagated.
+``render_envmap``.
 """
 from __future__ import annotations
 
@@ -27,7 +26,6 @@ from .voxurff import VoxurfF
 OUT_KEYS = ("etc/alphainv_cum", "srgb/rgb", "lin/rgb", "lin/pbr/off", "lin/pbr/off_hat", "lin/pbr/emo",
             "lin/pbr/emo_hat", "emit_marched", "etc/normal", "etc/normal_eps", "etc/emit", "etc/emit_eps",
             "etc/brdf", "etc/brdf_eps")
-NONDIFF = ("etc/emit_eps", "etc/brdf_eps")
 
 
 class BRDFNet(nn.Module):
@@ -105,17 +103,16 @@ class _LtsRender(torch.autograd.Function):
                    emit_eps=batch["emit_eps"], pdra=model.pdra_mode)
         lctx, out = eng.lts_forward(scene, scene2, batch, grids, env, cfg, draws)
         ctx.lctx, ctx.model = lctx, model
+        ctx.set_materialize_grads(False)         # unused result tensors arrive as None and cost nothing
         ctx.shapes = [tuple(p.shape) for p in mlp_params]
         model.last_counts = dict(eng.prim.counts)
-        outs = tuple(out[k] for k in OUT_KEYS)
-        ctx.mark_non_differentiable(*[out[k] for k in NONDIFF])
-        return outs
+        return tuple(out[k] for k in OUT_KEYS)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, *gout):
         model = ctx.model
-        dev = gout[0].device
+        dev = model.sdf.grid.device
         z = lambda shape: torch.zeros(shape, dtype=torch.float32, device=dev)
         X, Y, Z = [int(v) for v in model.world_size]
         g_sdf = z((1, 1, X, Y, Z))
@@ -126,7 +123,7 @@ class _LtsRender(torch.autograd.Function):
                      off_w=mg[0:8:2], off_b=mg[1:8:2], emo_w=mg[8:16:2], emo_b=mg[9:16:2],
                      tone_w=mg[16:20:2], tone_b=mg[17:20:2], brdf_w=mg[20:28:2], brdf_b=mg[21:28:2],
                      emit_w=mg[28:36:2], emit_b=mg[29:36:2])
-        g = {k: (None if k in NONDIFF else gv) for k, gv in zip(OUT_KEYS, gout)}
+        g = dict(zip(OUT_KEYS, gout))
         model.engine.lts_backward(ctx.lctx, g, grads)
         perm5 = lambda t: t.permute(0, 4, 1, 2, 3)
         return (None, None, None, g_sdf, perm5(g_off), perm5(g_emo), perm5(g_brdf), grads["mus"], grads["lambdas"],

@@ -10,8 +10,7 @@ and ``esr_lts_combine_*`` ties them together (env map, Disney reflection, hemisp
 Arithmetic is in HIP kernels; torch is used for memory, for re-ordering per-sample tensors
 between the kernels' compact tile order and the reference's ray-sorted order (index_select /
 index_add on small arrays), for the random draws (``torch.randn`` / ``np.random.choice`` exactly
-where the reference draws them) and for the autograd edge.  The perturbed re-evaluations
-("etc/emit_eps", "etc/brdf_eps", used by the PDRA trainer only) are forward-only this round.
+where the reference draws them) and for the autograd edge.
 """
 from __future__ import annotations
 
@@ -370,8 +369,9 @@ class LtsEngine(FineEngine):
         self._feat_args_points(P3, pts_e, vd_e, sdf_e, sdf, (None, emog, brdfg))
         self._features(P3, scene)
         T3 = P3.tiles_all
-        self._net_fwd(P3, "emit", KIND_EMIT, 88, 0, T3, save=False)
-        self._net_fwd(P3, "brdf", KIND_BRDF, 96, 0, T3, save=False)
+        eps_grads = bool(cfg.get("eps_grads", True))      # keep activations for d/d(emit_eps, brdf_eps)
+        self._net_fwd(P3, "emit", KIND_EMIT, 88, 0, T3, save=eps_grads)
+        self._net_fwd(P3, "brdf", KIND_BRDF, 96, 0, T3, save=eps_grads)
         self._act(P3, "emit.z", "emit.a", 4, 3, ACT_SOFTPLUS)
         self._act(P3, "brdf.z", "brdf.a", 8, 5, ACT_SIGMOID)
         emit_eps = P3.rowmajor("emit.a")[:m3, :3].contiguous()
@@ -386,7 +386,7 @@ class LtsEngine(FineEngine):
             "etc/emit": emit_rm[perm, :3].contiguous(), "etc/emit_eps": emit_eps,
             "etc/brdf": brdf_rm[perm, :5].contiguous(), "etc/brdf_eps": brdf_eps,
         }
-        ctx.t["um"] = um
+        ctx.t.update(um=um, pts_e=pts_e, eps_grads=eps_grads, m3=m3)
         return ctx, out
 
     # ------------------------------------------------------------------ backward
@@ -501,4 +501,29 @@ class LtsEngine(FineEngine):
             g4[perm, 1:4] = g[key]
             self._run("expgrad_bwd", L.esr_expgrad_bwd, sp, _lib.ptr(b["rays_o"]), _lib.ptr(b["rays_d"]),
                       _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(P0.bufs["rec_step"]), None, _lib.ptr(noise), C.c_float(eps),
-                      _lib.ptr(g4), T * 32, _lib.ptr(grads["sdf"]), s)
+                      _lib.ptr(g4), T * 32, 0, _lib.ptr(grads["sdf"]), s)
+
+        # ---- perturbed material heads ("etc/emit_eps": PDRA's emission-smoothness loss, pdra.py:455-457)
+        P3, m3 = self.epsp, ctx.t["m3"]
+        T3 = P3.tiles_all
+        src = []
+        for key, nm, kind, crow, rows, nch, act, ggrid in (
+                ("etc/emit_eps", "emit", KIND_EMIT, 88, 4, 3, ACT_SOFTPLUS, grads["emo"]),
+                ("etc/brdf_eps", "brdf", KIND_BRDF, 96, 8, 5, ACT_SIGMOID, grads["brdf"])):
+            if g.get(key) is None:
+                continue
+            if not ctx.t["eps_grads"]:
+                raise RuntimeError(f"gradient of {key} requested but the forward ran with eps_grads=False")
+            ga = torch.zeros(T3 * 32, nch, device=dev)
+            ga[:m3] = g[key]
+            gt = P3.from_rowmajor(f"{nm}.ga", rows, ga)
+            dz = self._act(P3, f"{nm}.z", f"{nm}.dz", rows, nch, act, bwd_g=gt)
+            dX = self._net_bwd(P3, nm, kind, crow, 0, T3, dz, grads[f"{nm}_w"], grads[f"{nm}_b"])
+            src.append((dX, None, ggrid, 0, T3))
+        if src:
+            g4e = torch.zeros(T3 * 32, 4, device=dev)
+            dsdf_e = torch.zeros(T3 * 32, device=dev)
+            self._feat_bwd(P3, ctx.scene, src, grads["sdf"], dsdf_out=dsdf_e)
+            g4e[:, 0] = dsdf_e
+            self._run("expgrad_bwd(pts)", L.esr_expgrad_bwd, sp, None, None, None, None, _lib.ptr(ctx.t["pts_e"]), None,
+                      C.c_float(0.0), _lib.ptr(g4e), m3, 1, _lib.ptr(grads["sdf"]), s)

@@ -335,8 +335,8 @@ int esr_expgrad_fwd(const esr_scene_t *scene, const float *rays_o, const float *
 /* g [n,4] -> atomic scatter into grad_sdf [gx,gy,gz] (the op is linear in the grid). */
 int esr_expgrad_bwd(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
                     const int32_t *rec_ray, const int32_t *rec_step, const float *pts,
-                    const float *noise, float eps, const float *g, int32_t n, float *grad_sdf,
-                    void *stream);
+                    const float *noise, float eps, const float *g, int32_t n, int zero_pad,
+                    float *grad_sdf, void *stream);
 
 /*
  * Hemisphere directions -- replaces diffuse_scattering (app/utils/pbr/functions.py:10-18)

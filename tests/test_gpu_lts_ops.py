@@ -63,7 +63,7 @@ def test_expgrad_fwd_bwd(with_noise):
     gs = torch.zeros_like(gd)
     gout_d = gout.cuda().contiguous()
     _lib.check(L.esr_expgrad_bwd(C.byref(scene), None, None, None, None, _lib.ptr(pd), _lib.ptr(nz), C.c_float(eps),
-                                 _lib.ptr(gout_d), n, _lib.ptr(gs), s), "expgrad_bwd")
+                                 _lib.ptr(gout_d), n, 0, _lib.ptr(gs), s), "expgrad_bwd")
     assert rel_err(gs, grid_r.grad[0, 0]) < 1e-5
 
 
@@ -154,3 +154,80 @@ def test_lts_combine_fwd_bwd(pdra, P, R):
                d_lambdas=Pm["envmap.lambdas"].grad[:, 0], d_lobes=Pm["envmap.lobes"].grad)
     bad = {k: rel_err(gr[k], v) for k, v in exp.items() if not rel_err(gr[k], v) < 1e-4}
     assert not bad, bad
+
+
+def test_feat_kernels_explicit_points_straddling_the_box():
+    """esr_fine_feat_fwd / _bwd in explicit-point mode with points up to ~1 voxel OUTSIDE the box (the
+    perturbed emit/brdf re-evaluation of esrnerf.py:807-830 produces them): every tap coordinate is clamped to
+    the grid (voxurff.py:697-699), colour taps are zero-padded.  Forward rows and the scatter into the SDF /
+    colour gradients against the oracle's stencil."""
+    import ctypes as C
+    from esr_nerf_amd import _lib
+    from esr_nerf_amd.config import lts_cfg
+    from esr_nerf_amd.fine_engine import make_scene
+    from esr_nerf_amd.synthetic import slab_scene
+    from oracle import fine_path as fp
+    L = _lib.lib()
+    sc = slab_scene("tiny", s_val=40.0)
+    cfg = lts_cfg("cpu")
+    c = fp.make_consts(cfg.app.model, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max, sc.mask_alpha_init,
+                       sc.mask_density, sc.near, sc.num_voxels)
+    ws = [int(v) for v in c.world_size]
+    g = torch.Generator().manual_seed(5)
+    sdf = torch.randn(1, 1, *ws, generator=g).requires_grad_(True)
+    col = (torch.randn(1, 6, *ws, generator=g) * 0.3).requires_grad_(True)
+    n = 200
+    lo, hi = sc.xyz_min, sc.xyz_max
+    vox = float(c.voxel_size)
+    pts = lo + (hi - lo) * torch.rand(n, 3, generator=g)
+    face = torch.randint(0, 3, (n,), generator=g)
+    side = torch.randint(0, 2, (n,), generator=g).bool()
+    off = (torch.rand(n, generator=g) * 2 - 1) * 0.45 * vox             # +-0.45 voxel around a face
+    for i in range(n // 2):                                             # half of the points hug a face
+        a = int(face[i])
+        pts[i, a] = (hi[a] if side[i] else lo[a]) + off[i]
+    pts[0] = lo - 0.3 * vox                                             # outside on all three axes (corner)
+    pts[1] = hi + 0.3 * vox
+    pts[2] = lo - 1.2 * vox      # beyond the smallest tap radius: +- taps clamp onto each other (diff = 0 -> the
+    pts[3, 0] = hi[0] + 0.8 * vox  # 1e-12 guard); forward only, the reference's own gradient is 0/1e-12 noise there
+    sdfv = torch.randn(n, generator=g)
+    feat, _, nrm = fp.sdf_stencil(c, sdf, pts, c.grad_feat, diff_eps=1e-12)
+    colv = fp.sample_grid(col, fp.to_norm(pts, lo, hi))
+    scene = make_scene(lo.tolist(), hi.tolist(), lo.tolist(), hi.tolist(), ws, [32, 32, 32], sc.near,
+                       float(c.stepsize * c.voxel_size), vox, 0.0, 1e-3, 1e-4, 40.0, [float(v) for v in c.grad_feat])
+    tiles = (n + 31) // 32
+    dev = "cuda"
+    pd, vd, sv = pts.cuda().contiguous(), torch.zeros(n, 3, device=dev), sdfv.cuda().contiguous()
+    sdf_d = sdf.detach()[0, 0].contiguous().cuda()
+    col_d = col.detach()[0].permute(1, 2, 3, 0).contiguous().cuda()
+    fa = _lib.EsrFeatArgs()
+    fa.pts, fa.pt_viewdirs, fa.pt_sdf, fa.n_pts = pd.data_ptr(), vd.data_ptr(), sv.data_ptr(), n
+    fa.sdf = sdf_d.data_ptr()
+    fa.color_off[0] = col_d.data_ptr()
+    fa.tiles_on, fa.tiles_all = 0, tiles
+    X = torch.empty(tiles * 104 * 32, device=dev)
+    gn = torch.empty(tiles * 4 * 32, device=dev)
+    s = _lib.stream_ptr("cuda:0")
+    _lib.check(L.esr_fine_feat_fwd(C.byref(scene), C.byref(fa), _lib.ptr(X), _lib.ptr(gn), s), "feat_fwd")
+    Xr = X.view(tiles, 104, 32).permute(0, 2, 1).reshape(tiles * 32, 104)[:n].cpu()
+    assert rel_err(Xr[:, 0:6], colv) < 1e-5
+    assert torch.equal(Xr[:, 6], sdfv)
+    assert rel_err(Xr[:, 7:31], feat) < 1e-5
+    assert rel_err(Xr[:, 31:43], nrm) < 1e-4, rel_err(Xr[:, 31:43], nrm)
+    # backward: random dX on the 43 grid-fed rows
+    dXr = torch.randn(n, 43, generator=g)
+    dXr[2:4] = 0.0
+    (colv * dXr[:, 0:6]).sum().add((feat * dXr[:, 7:31]).sum()).add((nrm * dXr[:, 31:43]).sum()).backward()
+    dXt = torch.zeros(tiles * 32, 64)
+    dXt[:n, :43] = dXr
+    dX = dXt.view(tiles, 32, 64).permute(0, 2, 1).contiguous().cuda()
+    g_sdf, g_col = torch.zeros_like(sdf_d), torch.zeros_like(col_d)
+    dsdf_out = torch.zeros(tiles * 32, device=dev)
+    src = (_lib.EsrFeatBwdSrc * 1)()
+    src[0].dX, src[0].grad_color_on, src[0].grad_color_off = dX.data_ptr(), None, g_col.data_ptr()
+    src[0].t0, src[0].t1 = 0, tiles
+    _lib.check(L.esr_fine_feat_bwd(C.byref(scene), C.byref(fa), _lib.ptr(X), _lib.ptr(gn), src, 1, None,
+                                   _lib.ptr(g_sdf), _lib.ptr(dsdf_out), s), "feat_bwd")
+    assert rel_err(g_sdf, sdf.grad[0, 0]) < 1e-4, rel_err(g_sdf, sdf.grad[0, 0])
+    assert rel_err(g_col.permute(3, 0, 1, 2), col.grad[0]) < 2e-5
+    assert rel_err(dsdf_out[:n], dXr[:, 6]) < 1e-6

@@ -45,6 +45,8 @@ TERMS = {
                                   + (r["etc/normal_eps"] * torch.linspace(2, -1, r["etc/normal"].numel(), device=r["etc/normal"].device).view_as(r["etc/normal"])).sum(),
     "emit": lambda r, rgbs: (r["etc/emit"] ** 2).mean() + (r["etc/emit_uncert"] ** 2).mean() + r["etc/emit_cert"].mean(),
     "brdf": lambda r, rgbs: (r["etc/brdf"] ** 2).mean(),
+    "emit_eps": lambda r, rgbs: ((r["etc/emit"] - r["etc/emit_eps"]) ** 2).mean(),
+    "brdf_eps": lambda r, rgbs: ((r["etc/brdf"] - 2 * r["etc/brdf_eps"]) ** 2).mean(),
 }
 for name, fn in TERMS.items():
     P = fp.params_from_state_dict(sd)
