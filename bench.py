@@ -40,8 +40,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="C2", choices=["C2", "C3", "small", "tiny"])
-    ap.add_argument("--s-val", type=float, default=20.0)
+    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "small", "tiny"])
+    ap.add_argument("--stage", default=None, choices=["fine", "lts", "pdra"],
+                    help="trainer step to run (default: fine; C4 defaults to lts)")
+    ap.add_argument("--s-val", type=float, default=None, help="default 20 (fine.yaml:45) / 220 (lts.yaml:52)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--cpu-iters", type=int, default=3)
@@ -104,8 +106,81 @@ def cpu_baseline(model, scene, s_val, n_rays, iters):
                        f"+ oracle/esr_oracle.c")
 
 
+def lts_mlp_flops(breakdown, eng, n_prof):
+    """Algorithmic FLOPs and milliseconds per step of every MLP launch of an LTS/PDRA step (names
+    ``mlp_<op>(<net>)[<pass>]``; samples per pass from the engine's survivor counts)."""
+    rad, tone = RAD_MAC, TONE_MAC
+    head = lambda o: 76 * 128 + 128 * 128 * 2 + 128 * o
+    mac = {"off": rad, "emo": rad, "tone": tone, "brdf": head(5), "emit": head(3)}
+    dg = {"off": DGRAD_RAD_MAC, "emo": DGRAD_RAD_MAC, "tone": 3 * 192 + 192 * 33,
+          "brdf": 5 * 128 + 128 * 128 * 2 + 128 * 43, "emit": 3 * 128 + 128 * 128 * 2 + 128 * 43}
+    pc = eng.prim.counts
+    n_of = {"primary": {"off": pc["m3"], "emo": pc["n_on"], "tone": pc["m3"], "brdf": pc["m3"], "emit": pc["m3"]},
+            "points": dict.fromkeys(mac, eng.pts.tiles_all * 32), "secondary": dict.fromkeys(mac, eng.sec.counts.get("m3", 0)),
+            "eps": dict.fromkeys(mac, pc["m3"])}
+    fl = ms = 0.0
+    for name, (n, t) in breakdown.items():
+        if not name.startswith("mlp_") or "pack" in name:
+            continue
+        op, rest = name[4:].split("(", 1)
+        net, pas = rest.split(")[")
+        pas = pas.rstrip("]")
+        k = dg[net] if op == "dgrad" else mac[net]
+        fl += 2.0 * k * n_of[pas][net]
+        ms += t / max(n_prof, 1)
+    return fl, ms
+
+
+def cpu_baseline_lts(model, scene, s_val, n_rays, iters, stage, tr):
+    """LTS / PDRA step of the CPU port on a proportionally scaled sample: n_rays primary rays and
+    num_ltspts * n_rays / N surface points with the full 256 secondary rays each."""
+    import numpy as np
+    from esr_nerf_amd.config import lts_cfg
+    from oracle import fine_path as fp
+    from oracle import lts_path as lp
+    cfg = lts_cfg("cpu")
+    R = model.num_2ndrays
+    Pn = max(1, int(round(model.num_ltspts * n_rays / scene.n_rays)))
+    c = fp.make_consts(cfg.app.model, scene.xyz_min, scene.xyz_max, scene.xyz_min, scene.xyz_max,
+                       scene.mask_alpha_init, scene.mask_density, scene.near, scene.num_voxels)
+    P = fp.params_from_state_dict({k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()})
+    batch = {k: v[:n_rays].contiguous() for k, v in scene.batch.items()}
+    batch["uncert_masks"] = torch.arange(n_rays) % 3 == 0
+    keep = {}
+    fp.forward_training(fp.params_from_state_dict({k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}),
+                        c, batch, s_val, keep=keep)
+    m3 = keep["counts"][3]
+    g = torch.Generator().manual_seed(0)
+    draws = lp.Draws(idx=torch.randperm(m3, generator=g)[:Pn], dirs=torch.randn(Pn, R + 1, 3, generator=g),
+                     noise_normal=torch.randn(m3, 3, generator=g), noise_emit=torch.randn(m3, 3, generator=g))
+    times = []
+    for i in range(iters + 1):
+        for v in P.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        res = lp.forward_training(P, c, batch, s_val, draws, tr.normal_eps, tr.emit_eps, R, cfg.app.model.lts_near,
+                                  pdra_mode=(stage == "pdra"))
+        if stage == "pdra":
+            loss, _ = lp.pdra_loss(res, batch["rgbs"], True, tr.weight_linear, tr.weight_lts, tr.weight_entropy_last,
+                                   tr.weight_normal_smooth, tr.weight_emit_smooth, tr.weight_lts_l, tr.weight_lts_r,
+                                   tr.weight_emit_supp)
+        else:
+            loss, _ = lp.lts_loss(res, batch["rgbs"], True, tr.weight_linear, tr.weight_lts, tr.weight_entropy_last,
+                                  tr.weight_normal_smooth)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+    t = sum(times[1:]) / iters
+    return dict(value=n_rays / t, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n_rays} of the {scene.n_rays} primary rays + {Pn} surface points x {R} secondary rays "
+                       f"(same ratio as the full step), fwd+loss+bwd, {iters} iterations after 1 warm-up, "
+                       f"{t:.2f} s/iter, torch {torch.__version__} CPU ops + oracle/esr_oracle.c")
+
+
 def main():
     a = parse()
+    stage = a.stage or ("lts" if a.config == "C4" else "fine")
+    if a.s_val is None:
+        a.s_val = 20.0 if stage == "fine" else 220.0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -126,9 +201,10 @@ def main():
         pg = dist.group.WORLD
 
     import numpy as np
-    from esr_nerf_amd.config import fine_cfg
+    from esr_nerf_amd.config import fine_cfg, lts_cfg
+    from esr_nerf_amd.esrnerf import ESRNeRF
     from esr_nerf_amd.synthetic import CONFIGS, init_slab_model, slab_scene
-    from esr_nerf_amd.trainer import FineStep
+    from esr_nerf_amd.trainer import FineStep, LtsStep
     from esr_nerf_amd.voxurff import VoxurfF
 
     # identical parameters on every rank (seed 0), different rays per rank (weak scaling)
@@ -137,20 +213,29 @@ def main():
     np.random.seed(0)
     import contextlib
     import io
+    cfg = fine_cfg(dev) if stage == "fine" else lts_cfg(dev)
     with contextlib.redirect_stdout(io.StringIO()):
-        model = VoxurfF(fine_cfg(dev), scene.near, scene.far, scene.xyz_min, scene.xyz_max, scene.xyz_min,
-                        scene.xyz_max, scene.mask_alpha_init, scene.mask_density, scene.s_val, scene.num_voxels)
+        model = (VoxurfF if stage == "fine" else ESRNeRF)(
+            cfg, scene.near, scene.far, scene.xyz_min, scene.xyz_max, scene.xyz_min,
+            scene.xyz_max, scene.mask_alpha_init, scene.mask_density, scene.s_val, scene.num_voxels)
     init_slab_model(model, scene)
     model.train()
-    step = FineStep(model, process_group=pg)
     batch = {k: v.to(dev) for k, v in scene.batch.items()}
     n_rays = scene.n_rays
+    if stage == "fine":
+        step = FineStep(model, process_group=pg)
+    else:
+        model.pdra_mode = stage == "pdra"
+        with torch.no_grad():
+            model.brdf.grid.normal_(0.0, 0.1)
+        batch["uncert_masks"] = (torch.arange(n_rays, device=dev) % 3 == 0)
+        step = LtsStep(model, cfg.app.trainer, stage=stage, process_group=pg)
     eng = model.engine
 
     def one():
-        # N > 1: this rank's 4096 rays are one shard of a global batch of 4096 * N rays
+        # N > 1: this rank's rays are one shard of a global batch of n_rays * N rays
         return step.forward_loss_backward(batch, a.s_val, global_rays=n_rays * world if world > 1 else None,
-                                          entropy_owner=(rank == world - 1))
+                                          entropy_owner=(rank == world - 1))[:2]
 
     # warm-up; its last steps carry HIP events around EVERY kernel (full breakdown + which kernel
     # dominates).  Bracketing everything costs ~2 ms/step, so it is kept out of the timed region.
@@ -201,15 +286,17 @@ def main():
         c = CONFIGS[a.config]
         samples = int(round(c["res"] * c["z"] * 2))
         out = {
-            "metric": "training rays/sec at 4096 rays x 128 samples (fine stage)" if a.config == "C2"
-                      else f"training rays/sec, config {a.config}",
+            "metric": "training rays/sec at 4096 rays x 128 samples (fine stage)" if (a.config, stage) == ("C2", "fine")
+                      else f"training rays/sec, config {a.config}, {stage} stage",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"{a.config}: giftbox_w fine stage on the slab scene, {n_rays} rays x {samples} "
+                "workload": f"{a.config}: giftbox_w {stage} stage on the slab scene, {n_rays} rays x {samples} "
                             f"samples per GPU, grid {'x'.join(str(int(v)) for v in model.world_size.tolist())}, "
-                            f"s_val={a.s_val:g}, forward + trainer loss + backward (no optimizer step)",
+                            f"s_val={a.s_val:g}, forward + trainer loss + backward (no optimizer step)"
+                            + ("" if stage == "fine" else f"; + {model.num_ltspts} surface points x {model.num_2ndrays} "
+                               f"secondary rays per GPU ({eng.sec.counts.get('m3')} surviving secondary samples)"),
                 "rays_per_gpu": n_rays, "samples_per_ray": samples, "surviving_samples": counts.get("m3"),
                 "parallelism": f"dp{world}",
             },
@@ -244,8 +331,24 @@ def main():
                                                   "share_of_kernel_time": mt * 1e3 / total_ms}
             out["kernel_ms_per_step_warmup"] = {k: round(v[1] / v[0], 4) for k, v in
                                                 sorted(breakdown.items(), key=lambda kv: -kv[1][1])}
+        if breakdown and "kernel_ms_per_step_warmup" not in out:
+            out["kernel_ms_per_step_warmup"] = {k: round(v[1] / max(n_prof, 1), 4) for k, v in
+                                                sorted(breakdown.items(), key=lambda kv: -kv[1][1])}
+        if breakdown and stage != "fine":
+            fl, ms_mlp = lts_mlp_flops(breakdown, eng, n_prof)
+            total_ms = sum(ms_ for _, ms_ in breakdown.values()) / max(n_prof, 1)
+            out["roofline"] = {
+                "bound": "mfma", "kernel": "all mlp_fwd/dgrad/wgrad launches of the step (HIP events, instrumented "
+                                           "warm-up steps)", "achieved": fl / (ms_mlp * 1e-3) / 1e12,
+                "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": fl / (ms_mlp * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
+                "traffic": None, "mlp_ms_per_step": ms_mlp, "share_of_kernel_time": ms_mlp / total_ms,
+                "kernel_ms_per_step": total_ms}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, scene, a.s_val, min(a.cpu_rays, n_rays), a.cpu_iters)
+            if stage == "fine":
+                out["cpu_baseline"] = cpu_baseline(model, scene, a.s_val, min(a.cpu_rays, n_rays), a.cpu_iters)
+            else:
+                out["cpu_baseline"] = cpu_baseline_lts(model, scene, a.s_val, min(a.cpu_rays, n_rays), a.cpu_iters,
+                                                       stage, cfg.app.trainer)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

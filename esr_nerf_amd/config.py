@@ -62,12 +62,16 @@ LTS_TRAINER = dict(weight_entropy_last=0.001, weight_tv_density=0.01, weight_lin
                    weight_normal_smooth=0.001, normal_eps=0.01, emit_eps=0.001, s_start=220.0)
 
 
+# /root/reference/cfg/app/pdra.yaml:88-98
+PDRA_TRAINER = dict(LTS_TRAINER, weight_emit_smooth=0.1, weight_lts_l=50.0, weight_lts_r=1.0, weight_emit_supp=0.1)
+
+
 def lts_cfg(device: str = "cpu", **model_over) -> AttrDict:
     m = dict(LTS_MODEL)
     m.update(model_over)
     return AttrDict(
         system=dict(device=device, debug=True, seed=0, tqdm_iters=10),
-        app=dict(model=m, trainer=dict(LTS_TRAINER)),
+        app=dict(model=m, trainer=dict(PDRA_TRAINER)),      # superset of the lts keys
         data=dict(white_bg=True),
         global_step=0,
     )

@@ -215,6 +215,33 @@ __global__ void __launch_bounds__(256) loss_kernel(const float *__restrict__ srg
     if (esr_lane() == 0 && acc != 0.f) atomicAdd(loss, acc);
 }
 
+// One mean-reduced two-operand term of the LTS / PDRA trainer losses (lts.py:362-379, pdra.py:408-457)
+// with its gradients; rows selected by row_mask == mask_value, b == nullptr stands for zeros.
+__global__ void __launch_bounds__(256) pair_loss_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                        int64_t rows, int cols, const uint8_t *__restrict__ row_mask,
+                                                        int mask_value, const int32_t *__restrict__ count_dev, int kind,
+                                                        float w_value, float w_a, float w_b, float *__restrict__ loss,
+                                                        float *__restrict__ ga, float *__restrict__ gb)
+{
+    const int64_t total = rows * cols;
+    const int64_t n_sel = count_dev ? (int64_t)count_dev[0] * cols : total;
+    const float inv = n_sel > 0 ? 1.f / (float)n_sel : 0.f;
+    float acc = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool sel = !row_mask || (int)row_mask[i / cols] == mask_value;
+        float g = 0.f;
+        if (sel) {
+            const float d = a[i] - (b ? b[i] : 0.f);
+            if (kind == 0) { acc += d * d * inv; g = 2.f * d * inv; }
+            else { acc += fabsf(d) * inv; g = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv; }
+        }
+        if (ga) ga[i] = w_a * g;
+        if (gb) gb[i] = -w_b * g;
+    }
+    acc = wave_sum(acc) * w_value;
+    if (esr_lane() == 0 && acc != 0.f) atomicAdd(loss, acc);
+}
+
 // ---- LTS-stage helpers ------------------------------------------------------------------------
 // out = act(z) on the first n_ch rows of [tiles, rows, 32] tiles (act 0: softplus, 1: sigmoid);
 // backward: dz = g * act'(z)
@@ -410,6 +437,20 @@ ESR_API int esr_fine_loss_fwd_bwd(const float *srgb_marched, const float *lin_ma
     loss_kernel<<<esr_grid_for(n_rays, 256), 256, 0, esr_stream(stream)>>>(
         srgb_marched, lin_marched, alphainv_last, rgbs, n_rays, white_bg, weight_linear,
         weight_entropy_last, loss, g_srgb, g_lin, g_last);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_pair_loss_fwd_bwd(const float *a, const float *b, int64_t rows, int32_t cols,
+                                  const uint8_t *row_mask, int mask_value, const int32_t *count_dev, int kind,
+                                  float w_value, float w_a, float w_b, float *loss, float *ga, float *gb,
+                                  void *stream)
+{
+    if (rows < 0 || cols < 1 || (kind != 0 && kind != 1)) return ESR_EINVAL;
+    if (rows == 0) return 0;
+    if (!a || !loss) return ESR_EINVAL;
+    pair_loss_kernel<<<esr_grid_for(rows * cols, 256), 256, 0, esr_stream(stream)>>>(
+        a, b, rows, cols, row_mask, mask_value, count_dev, kind, w_value, w_a, w_b, loss, ga, gb);
     ESR_CHECK_LAUNCH();
     return 0;
 }

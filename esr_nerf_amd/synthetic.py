@@ -21,6 +21,7 @@ CONFIGS = {
     "C1": dict(n_rays=512, z=1.0 / 3.0, res=96),      # coarse plumbing size, ~64 samples
     "C2": dict(n_rays=4096, z=0.25, res=256),         # fine, 128 samples (north star)
     "C3": dict(n_rays=4096, z=0.375, res=256),        # fine, 192 samples
+    "C4": dict(n_rays=8192, z=0.25, res=256),         # lts / pdra stages: 8192 primary rays (+100x256 secondary)
     "tiny": dict(n_rays=64, z=0.25, res=64),          # 32 samples, golden-vector size
     "small": dict(n_rays=512, z=0.25, res=128),       # 64 samples
     "g16": dict(n_rays=48, z=0.25, res=32),           # 16 samples, committed golden fixtures

@@ -145,3 +145,142 @@ class FineStep:
         for n, p in self.model.named_parameters():
             if n in grads:
                 p.grad = grads[n]
+
+
+class LtsStep:
+    """One training step of the LTS stage (``stage="lts"``, app/fine/lts.py:327-397) or the PDRA stage
+    (``stage="pdra"``, app/fine/pdra.py:374-475) on the HIP path, without autograd in the loop:
+    ``LtsEngine.lts_forward`` -> loss kernels (the fine-stage image loss plus one
+    ``esr_pair_loss_fwd_bwd`` launch per LTS/PDRA term) -> ``LtsEngine.lts_backward``.
+
+    Data parallelism as in ``FineStep``: every rank renders its own ray shard and its own
+    ``num_ltspts`` surface points (per process, as in the reference), every loss term is scaled by
+    ``n_local / n_global`` and ONE flat gradient buffer is summed over the ranks."""
+
+    NETS = (("off_rgbnet", "linear"), ("emo_rgbnet", "linear"), ("tonemapper", "srgb"), ("brdfnet", "brdfnet"),
+            ("emitnet", "brdfnet"))
+
+    def __init__(self, model, trainer_cfg, stage: str = "lts", white_bg: bool = True, process_group=None):
+        if stage not in ("lts", "pdra"):
+            raise ValueError("stage must be 'lts' or 'pdra'")
+        self.model, self.t, self.stage, self.white_bg, self.pg = model, trainer_cfg, stage, white_bg, process_group
+        self._names = None
+        self._flat = None
+
+    def _param_names(self):
+        if self._names is None:
+            names = []
+            for net, seq in self.NETS:
+                for key, sub in getattr(getattr(self.model, net), seq).named_modules():
+                    if isinstance(sub, torch.nn.Linear):
+                        names += [f"{net}.{seq}.{key}.weight", f"{net}.{seq}.{key}.bias"]
+            self._names = names
+        return self._names
+
+    def _alloc_grads(self, dev):
+        m = self.model
+        X, Y, Z = [int(v) for v in m.world_size]
+        J = m.envmap.mus.shape[0]
+        shapes = [("sdf.grid", (1, 1, X, Y, Z)), ("off_color.grid", (1, X, Y, Z, 6)), ("emo_color.grid", (1, X, Y, Z, 6)),
+                  ("brdf.grid", (1, X, Y, Z, 6))]
+        shapes += [(n, tuple(p.shape)) for n, p in zip(self._param_names(), m._mlp_params())]
+        shapes += [("envmap.mus", (J, 3)), ("envmap.lambdas", (J, 1)), ("envmap.lobes", (J, 3))]
+        total = sum(int(torch.Size(s).numel()) for _, s in shapes)
+        if self._flat is None or self._flat.numel() != total:
+            self._flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self._flat.zero_()
+        out, o = {}, 0
+        for n, s in shapes:
+            k = int(torch.Size(s).numel())
+            out[n] = self._flat[o:o + k].view(s)
+            o += k
+        return out
+
+    def _pair(self, eng, loss, a, b, kind, w_value, w_a, w_b, scale, want_gb=True, row_mask=None, mask_value=0,
+              count=None):
+        import ctypes as C
+        from . import _lib
+        a = a.contiguous()
+        ga = torch.empty_like(a)
+        gb = torch.empty_like(a) if (b is not None and want_gb) else None
+        rows = a.shape[0]
+        cols = a.numel() // max(rows, 1)
+        if rows:
+            eng._run("pair_loss", eng.L.esr_pair_loss_fwd_bwd, _lib.ptr(a), _lib.ptr(b.contiguous() if b is not None else None),
+                     C.c_int64(rows), cols, _lib.ptr(row_mask), mask_value, _lib.ptr(count), kind,
+                     C.c_float(w_value * scale), C.c_float(w_a * scale), C.c_float(w_b * scale), _lib.ptr(loss),
+                     _lib.ptr(ga), _lib.ptr(gb), eng._s())
+        return ga, gb
+
+    @torch.no_grad()
+    def forward_loss_backward(self, batch: Dict[str, torch.Tensor], s_val: float, global_rays: Optional[int] = None,
+                              entropy_owner: bool = True, draws=None):
+        m, t = self.model, self.t
+        eng = m.engine
+        m.s_val = s_val
+        ps = m._mlp_params()
+        from .fine_engine import KIND_RADIANCE as KR, KIND_TONEMAP as KT
+        from .lts_engine import KIND_BRDF as KB, KIND_EMIT as KE
+        o = 0
+        for name, kind, n in (("off", KR, 8), ("emo", KR, 8), ("tone", KT, 4), ("brdf", KB, 8), ("emit", KE, 8)):
+            eng.pack(name, kind, list(ps[o:o + n:2]), list(ps[o + 1:o + n:2]))
+            o += n
+        grids = dict(sdf=m.sdf.device_view(), off=m.off_color.device_view(), emo=m.emo_color.device_view(),
+                     brdf=m.brdf.device_view(), mask=m.mask_cache.density.view(*m.mask_cache.density.shape[2:]))
+        env = dict(mus=m.envmap.mus.detach(), lambdas=m.envmap.lambdas.detach(), lobes=m.envmap.lobes.detach())
+        pdra = self.stage == "pdra"
+        cfg = dict(num_2ndrays=m.num_2ndrays, num_ltspts=m.num_ltspts, normal_eps=t.normal_eps, emit_eps=t.emit_eps,
+                   pdra=m.pdra_mode, eps_grads=pdra)
+        ctx, out = eng.lts_forward(m.scene_struct(), m.scene_struct(near=m.lts_near), batch, grids, env, cfg, draws)
+        m.last_counts = dict(eng.prim.counts)
+        last = out["etc/alphainv_cum"]
+        scale, w_ent = dp_loss_weights(last.shape[0], global_rays, entropy_owner, t.weight_entropy_last)
+        loss, g_last, g_srgb, g_lin = eng.loss_fwd_bwd(last, out["srgb/rgb"], out["lin/rgb"], batch["rgbs"],
+                                                       self.white_bg, t.weight_linear, w_ent)
+        if scale != 1.0:
+            loss, g_last, g_srgb, g_lin = loss * scale, g_last * scale, g_srgb * scale, g_lin * scale
+        g = {"etc/alphainv_cum": g_last, "srgb/rgb": g_srgb, "lin/rgb": g_lin}
+        wl = t.weight_lts
+        if not pdra:
+            g["lin/pbr/off"], g["lin/pbr/off_hat"] = self._pair(eng, loss, out["lin/pbr/off"], out["lin/pbr/off_hat"],
+                                                                0, wl, wl, wl, scale)
+            g["lin/pbr/emo"], g["lin/pbr/emo_hat"] = self._pair(eng, loss, out["lin/pbr/emo"], out["lin/pbr/emo_hat"],
+                                                                0, wl, wl, wl, scale)
+        else:
+            g["lin/pbr/off"], g["lin/pbr/off_hat"] = self._pair(eng, loss, out["lin/pbr/off"], out["lin/pbr/off_hat"],
+                                                                1, wl, wl, wl, scale)
+            wL, wR = t.weight_lts_l, t.weight_lts_r
+            g["lin/pbr/emo"], g["lin/pbr/emo_hat"] = self._pair(eng, loss, out["lin/pbr/emo"], out["lin/pbr/emo_hat"],
+                                                                1, wl * (wL + wR), wl * wR, wl * wL, scale)
+            um8 = batch["uncert_masks"].view(torch.uint8)
+            n_cert = (um8 == 0).sum(dtype=torch.int32).view(1)
+            g["emit_marched"], _ = self._pair(eng, loss, out["emit_marched"], None, 0, t.weight_emit_supp,
+                                              t.weight_emit_supp, 0.0, scale, row_mask=um8, mask_value=0, count=n_cert)
+            ws = t.weight_emit_smooth
+            g["etc/emit"], g["etc/emit_eps"] = self._pair(eng, loss, out["etc/emit"], out["etc/emit_eps"], 1, ws, ws, ws,
+                                                          scale)
+        wn = t.weight_normal_smooth
+        g["etc/normal"], g["etc/normal_eps"] = self._pair(eng, loss, out["etc/normal"], out["etc/normal_eps"], 1, wn, wn,
+                                                          wn, scale)
+        G = self._alloc_grads(last.device)
+        names = self._param_names()
+        pick = lambda lo, hi: ([G[n] for n in names[lo:hi:2]], [G[n] for n in names[lo + 1:hi:2]])
+        (ow, ob), (ew, eb), (tw, tb), (bw, bb), (mw, mb) = pick(0, 8), pick(8, 16), pick(16, 20), pick(20, 28), pick(28, 36)
+        grads = dict(sdf=G["sdf.grid"], off=G["off_color.grid"], emo=G["emo_color.grid"], brdf=G["brdf.grid"],
+                     off_w=ow, off_b=ob, emo_w=ew, emo_b=eb, tone_w=tw, tone_b=tb, brdf_w=bw, brdf_b=bb,
+                     emit_w=mw, emit_b=mb, mus=G["envmap.mus"], lambdas=G["envmap.lambdas"], lobes=G["envmap.lobes"])
+        eng.lts_backward(ctx, g, grads)
+        if self.pg is not None:
+            import torch.distributed as dist
+            works = [dist.all_reduce(self._flat, group=self.pg, async_op=True),
+                     dist.all_reduce(loss, group=self.pg, async_op=True)]
+            for w in works:
+                w.wait()
+        for k in ("off_color.grid", "emo_color.grid", "brdf.grid"):
+            G[k] = G[k].permute(0, 4, 1, 2, 3)
+        return loss, G, out
+
+    def assign_grads(self, grads: Dict[str, torch.Tensor]):
+        for n, p in self.model.named_parameters():
+            if n in grads:
+                p.grad = grads[n]

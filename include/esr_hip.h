@@ -313,6 +313,22 @@ int esr_fine_loss_fwd_bwd(const float *srgb_marched, const float *lin_marched,
                           float *loss, float *g_srgb, float *g_lin, float *g_last,
                           void *stream);
 
+/*
+ * One mean-reduced two-operand term of the LTS / PDRA trainer losses and its gradients
+ * (app/fine/lts.py:362-379: MSE(off, off_hat), MSE(emo, emo_hat), L1(normal, normal_eps);
+ * app/fine/pdra.py:408-457: the L1 variants with separate weights for the two sides, the
+ * emission suppression mean(emit_cert^2), L1(emit, emit_eps)).
+ *   kind 0: mean((a-b)^2), kind 1: mean(|a-b|) over the elements of the rows with
+ *   row_mask[row] == mask_value (row_mask NULL: all rows); b NULL stands for zeros.
+ *   count_dev (device, optional): number of selected rows, so that a data-dependent
+ *   selection (emit_cert = emit_marched[~uncert]) needs no host sync; 0 rows -> term 0.
+ * loss[0] += w_value * term;  ga = w_a * d(term)/d(a);  gb = w_b * d(term)/d(b)  (NULL: skip).
+ */
+int esr_pair_loss_fwd_bwd(const float *a, const float *b, int64_t rows, int32_t cols,
+                          const uint8_t *row_mask, int mask_value, const int32_t *count_dev,
+                          int kind, float w_value, float w_a, float w_b, float *loss, float *ga,
+                          float *gb, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * C. Light-transport-segment (LTS / PDRA) stage ops
  *    (ESRNeRF.forward_training, app/fine/model/esrnerf.py:486-851).

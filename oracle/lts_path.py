@@ -266,3 +266,21 @@ def lts_loss(results: Dict[str, Tensor], rgbs: Tensor, white_bg: bool = True, we
     l_emo = F.mse_loss(results["lin/pbr/emo"], results["lin/pbr/emo_hat"])
     l_n = F.l1_loss(results["etc/normal"], results["etc/normal_eps"])
     return base + weight_lts * (l_off + l_emo) + weight_normal_smooth * l_n, aux
+
+
+def pdra_loss(results: Dict[str, Tensor], rgbs: Tensor, white_bg: bool = True, weight_linear: float = 10.0,
+              weight_lts: float = 0.01, weight_entropy_last: float = 0.001, weight_normal_smooth: float = 0.001,
+              weight_emit_smooth: float = 0.1, weight_lts_l: float = 50.0, weight_lts_r: float = 1.0,
+              weight_emit_supp: float = 0.1):
+    """app/fine/pdra.py:383-457 (TV terms excluded, as in fine_loss)."""
+    base, aux = fp.fine_loss(results, rgbs, white_bg, weight_linear, weight_entropy_last)
+    l_off = F.l1_loss(results["lin/pbr/off"], results["lin/pbr/off_hat"])
+    l_emo_l = F.l1_loss(results["lin/pbr/emo"].detach(), results["lin/pbr/emo_hat"])
+    l_emo_r = F.l1_loss(results["lin/pbr/emo"], results["lin/pbr/emo_hat"].detach())
+    loss = base + weight_lts * l_off + weight_lts * (weight_lts_l * l_emo_l + weight_lts_r * l_emo_r)
+    emc = results["etc/emit_cert"]
+    if len(emc):
+        loss = loss + weight_emit_supp * torch.pow(emc, 2).mean()
+    loss = loss + weight_normal_smooth * F.l1_loss(results["etc/normal"], results["etc/normal_eps"])
+    loss = loss + weight_emit_smooth * F.l1_loss(results["etc/emit"], results["etc/emit_eps"])
+    return loss, aux

@@ -178,3 +178,51 @@ def test_lts_path_vs_oracle_linear_functional(mode, scene_name, n_rays, s_val):
         if not e < TOL:
             bad[k] = e
     assert not bad, str(bad)
+
+
+@pytest.mark.parametrize("stage", ["lts", "pdra"])
+def test_lts_step_equals_autograd_route(stage):
+    """LtsStep (loss kernels, no autograd: what bench.py and the DP runs use) against the drop-in route
+    (ESRNeRF.forward + the trainer's loss lines in torch + loss.backward()) on identical draws."""
+    from esr_nerf_amd.synthetic import init_slab_model, slab_scene
+    from esr_nerf_amd.trainer import LtsStep
+    from oracle import lts_path as lp
+    s_val, n_rays, R, Pn = 70.0, 256, 16, 24
+    sc = slab_scene("small", s_val=s_val, oblique=True, n_rays=n_rays, seed=2)
+    m, cfg = build_lts_model(sc, num_2ndrays=R, num_ltspts=Pn)
+    init_slab_model(m, sc, seed=3)
+    with torch.no_grad():
+        m.brdf.grid.normal_(0.0, 0.3)
+    m.pdra_mode = stage == "pdra"
+    tr = cfg.app.trainer
+    b = {k: v.cuda() for k, v in sc.batch.items()}
+    g = torch.Generator().manual_seed(1)
+    b["uncert_masks"] = (torch.rand(n_rays, generator=g) < 0.5).cuda()
+    # first pass with internal draws just to learn M3, then fixed draws for both routes
+    step = LtsStep(m, tr, stage=stage)
+    step.forward_loss_backward(b, s_val)
+    m3 = m.last_counts["m3"]
+    draws = dict(idx=torch.randperm(m3, generator=g)[:Pn].cuda(), dirs=torch.randn(Pn, R + 1, 3, generator=g).cuda(),
+                 noise_normal=torch.randn(m3, 3, generator=g).cuda(), noise_emit=torch.randn(m3, 3, generator=g).cuda())
+    loss_s, G, _ = step.forward_loss_backward(b, s_val, draws=draws)
+    G = {k: v.clone() for k, v in G.items()}
+    m.zero_grad(set_to_none=True)
+    res = m(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=b["em_modes"],
+            uncert_masks=b["uncert_masks"], s_val=s_val, normal_eps=tr.normal_eps, emit_eps=tr.emit_eps, draws=draws)
+    if stage == "lts":
+        loss_a, _ = lp.lts_loss(res, b["rgbs"], True, tr.weight_linear, tr.weight_lts, tr.weight_entropy_last,
+                                tr.weight_normal_smooth)
+    else:
+        loss_a, _ = lp.pdra_loss(res, b["rgbs"], True, tr.weight_linear, tr.weight_lts, tr.weight_entropy_last,
+                                 tr.weight_normal_smooth, tr.weight_emit_smooth, tr.weight_lts_l, tr.weight_lts_r,
+                                 tr.weight_emit_supp)
+    loss_a.backward()
+    assert abs(float(loss_s) - float(loss_a)) < 1e-5 * max(1.0, abs(float(loss_a)))
+    bad = {}
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        e = rel_err(G[k], p.grad)
+        if not e < 2e-5:
+            bad[k] = e
+    assert not bad, str(bad)
