@@ -312,7 +312,9 @@ def main():
             if os.path.exists(side):
                 with open(side) as f:
                     tj = json.load(f)
-                vals = [tj[c] for c in dom_calls if c in tj]
+                wl = tj.get("_workload", {})
+                same = (wl.get("config"), wl.get("stage"), wl.get("s_val")) == (a.config, stage, float(a.s_val))
+                vals = [tj[c] for c in dom_calls if c in tj] if same else []     # counters are per workload
                 traffic = sum(vals) / len(vals) if vals else None
             total_ms = sum(ms_ for _, ms_ in breakdown.values()) or 1.0
             out["roofline"] = {
