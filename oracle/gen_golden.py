@@ -129,6 +129,7 @@ def main():
 
     ru.sample_pts_on_rays, ru.alpha2weight, ru.alpha2weight_backward = real_sample, real_a2w, real_a2w_b
     gen_lts(ns)
+    gen_finetune(ns)
 
 
 def lts_reference_loss(ns, results, rgbs, cfg):
@@ -210,5 +211,80 @@ def gen_lts(ns):
               "grads", sum(1 for k in out if k.startswith("grad/")))
 
 
+def gen_finetune(ns):
+    """ESRNeRF.forward_finetune (re-lighting fine-tune, esrnerf.py:241-484) + the loss line of
+    pdra.py:1090-1093 on the same small slab; parameters = lts_g16_params.npz with emo_color perturbed after
+    train(finetune=True) froze its copy emit_color (so the two grids differ, as they do during fine-tuning)."""
+    from esr_nerf_amd.config import lts_cfg
+    cfg = lts_cfg("cpu", num_2ndrays=8, num_ltspts=12)
+    sc = slab_scene("g16", s_val=60.0, oblique=True)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = ns.ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max,
+                       sc.mask_alpha_init, sc.mask_density, sc.s_val, sc.num_voxels)
+    init_slab_model(model, sc)
+    with torch.no_grad():
+        model.brdf.grid.data.copy_(torch.randn(model.brdf.grid.shape, generator=torch.Generator().manual_seed(9)) * 0.1)
+    with np.load(os.path.join(OUT, "lts_g16_params.npz")) as z:
+        for k, v in model.state_dict().items():
+            assert np.array_equal(z[k], v.detach().numpy()), k        # same parameters as the lts fixtures
+    for p_ in model.parameters():
+        p_.requires_grad_(False)
+    for p_ in list(model.emo_color.parameters()) + list(model.emo_rgbnet.parameters()):
+        p_.requires_grad_(True)
+    model.s_val = 60.0
+    model.train(True, finetune=True)
+    g = torch.Generator().manual_seed(21)
+    with torch.no_grad():
+        model.emo_color.grid.add_(torch.randn(model.emo_color.grid.shape, generator=g) * 0.05)
+    n = sc.n_rays
+    b = dict(rays_o=sc.batch["rays_o"], rays_d=sc.batch["rays_d"], viewdirs=sc.batch["viewdirs"],
+             em_modes=(torch.arange(n) % 5).long(), em_intensities=0.25 + 2.0 * torch.rand(n, generator=g),
+             em_colors=torch.rand(n, 2, generator=g))
+    rec = {}
+    r_randn, r_choice = torch.randn, np.random.choice
+
+    def p_randn(*a, **k):
+        t = r_randn(*a, **k)
+        rec.setdefault("randn", []).append(t.clone())
+        return t
+
+    def p_choice(*a, **k):
+        v = r_choice(*a, **k)
+        rec["idx"] = np.array(v)
+        return v
+
+    torch.manual_seed(6)
+    np.random.seed(6)
+    torch.randn, np.random.choice = p_randn, p_choice
+    try:
+        res = model(**b)
+    finally:
+        torch.randn, np.random.choice = r_randn, r_choice
+    assert len(rec["randn"]) == 1
+    w = 0.5                                                      # cfg/app/pdra.yaml:138 (eval.weight_lts)
+    loss = w * F.mse_loss(res["lin/pbr/emo"], res["lin/pbr/emo_hat"])
+    loss.backward()
+    out = {"in/" + k: v.numpy() for k, v in b.items()}
+    out["in/s_val"] = np.float32(60.0)
+    out["in/weight_lts"] = np.float32(w)
+    out["param/emo_color.grid"] = model.emo_color.grid.detach().numpy()
+    out["param/emit_color.grid"] = model.emit_color.grid.detach().numpy()
+    out["draw/idx"] = rec["idx"].astype(np.int64)
+    out["draw/dirs"] = rec["randn"][0].numpy()
+    for k, v in res.items():
+        out["out/" + k] = v.detach().numpy()
+    out["loss"] = loss.detach().numpy()
+    for k, p_ in model.named_parameters():
+        if p_.grad is not None:
+            out["grad/" + k] = p_.grad.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "lts_g16_finetune.npz"), **out)
+    print("finetune loss", float(loss), "grads", sorted(k for k in out if k.startswith("grad/")))
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "finetune":
+        gen_finetune(ref_import.load())
+    else:
+        main()

@@ -284,3 +284,98 @@ def pdra_loss(results: Dict[str, Tensor], rgbs: Tensor, white_bg: bool = True, w
     loss = loss + weight_normal_smooth * F.l1_loss(results["etc/normal"], results["etc/normal_eps"])
     loss = loss + weight_emit_smooth * F.l1_loss(results["etc/emit"], results["etc/emit_eps"])
     return loss, aux
+
+
+# ------------------------------------------------------------------ re-lighting fine-tune (A16)
+def rgb_to_hsv(rgb: Tensor, eps: float = 1e-8) -> Tensor:
+    """app/utils/pbr/functions.py:214-236: hue in [0,1), saturation = delta / (max + eps), value = max."""
+    mx, arg = rgb.max(-1)
+    mn = rgb.min(-1).values
+    delta = mx - mn
+    s = delta / (mx + eps)
+    d = torch.where(delta == 0, torch.ones_like(delta), delta)
+    rc, gc, bc = (mx.unsqueeze(-1) - rgb).unbind(-1)
+    cand = torch.stack([bc - gc, (rc - bc) + 2.0 * d, (gc - rc) + 4.0 * d], -1) / d.unsqueeze(-1)
+    h = cand.gather(-1, arg.unsqueeze(-1)).squeeze(-1)
+    return torch.stack([(h / 6.0) % 1.0, s, mx], -1)
+
+
+def hsv_to_rgb(hsv: Tensor) -> Tensor:
+    """app/utils/pbr/functions.py:239-255 (sector table v,q,p,p,t,v / t,v,v,q,p,p / p,p,t,v,v,q)."""
+    h, s, v = hsv.unbind(-1)
+    sector = torch.floor(h * 6) % 6
+    f = ((h * 6) % 6) - sector
+    p, q, t = v * (1 - s), v * (1 - f * s), v * (1 - (1 - f) * s)
+    k = sector.long().unsqueeze(-1)
+    r = torch.stack([v, q, p, p, t, v], -1).gather(-1, k)
+    g = torch.stack([t, v, v, q, p, p], -1).gather(-1, k)
+    b = torch.stack([p, p, t, v, v, q], -1).gather(-1, k)
+    return torch.cat([r, g, b], -1)
+
+
+def edit_emission(emit: Tensor, em_modes: Tensor, em_intensities: Tensor, em_colors: Tensor) -> Tensor:
+    """esrnerf.py:432-441: mode 0 off, 2/4 intensity scale, 3/4 hue+saturation replaced."""
+    emit = emit.clone()
+    emit[em_modes == 0] = 0
+    im = (em_modes == 2) | (em_modes == 4)
+    emit[im] = emit[im] * em_intensities[im][..., None]
+    cm = (em_modes == 3) | (em_modes == 4)
+    hsv = rgb_to_hsv(emit[cm])
+    hsv[..., :-1] = em_colors[cm]
+    emit[cm] = hsv_to_rgb(hsv)
+    return emit
+
+
+def forward_finetune(P: Dict[str, Tensor], c: fp.FineConsts, batch: Dict[str, Tensor], s_val: float, idx: Tensor,
+                     raw_dirs: Tensor, num_2ndrays: int, lts_near: float) -> Dict[str, Tensor]:
+    """ESRNeRF.forward_finetune (esrnerf.py:241-484).  P["emit_color.grid"] is the frozen copy of the emo
+    colour grid that feeds the emission head; only emo_color.grid / emo_rgbnet.* receive gradients (the
+    reference evaluates everything else under no_grad)."""
+    rays_o, rays_d, viewdirs = batch["rays_o"], batch["rays_d"], batch["viewdirs"]
+    R = num_2ndrays
+    with torch.no_grad():
+        N, pts, ray_id = _march(P, c, rays_o, rays_d, c.near, s_val)
+        sdf = fp.sample_grid(P["sdf.grid"], fp.to_norm(pts, c.xyz_min, c.xyz_max))[:, 0]
+        alpha = fp.neus_alpha_interp(sdf, ray_id, s_val)
+        m = alpha > c.fastcolor_thres
+        alpha, pts, ray_id = alpha[m], pts[m], ray_id[m]
+        weights, _ = fp._Composite.apply(alpha, ray_id, N)
+        m = weights > c.fastcolor_thres
+        pts, ray_id = pts[m], ray_id[m]
+        p, vd = pts[idx], viewdirs[ray_id][idx]
+        modes, inten, cols = batch["em_modes"][ray_id][idx], batch["em_intensities"][ray_id][idx], batch["em_colors"][ray_id][idx]
+        Pn = p.shape[0]
+        sdf_p, expg = sdf_expgrad(c, P["sdf.grid"], p)
+        sdf_p, normal = sdf_p.detach(), F.normalize(expg.detach(), dim=-1)
+        dirs_all = hemisphere_dirs(normal, raw_dirs)
+        v_rand, dirs = -dirs_all[:, -1], dirs_all[:, :-1]
+        feat, _, nrm = _stencil(c, P["sdf.grid"], p)
+        xyz_pe = _pe(c, p)
+        rep = lambda t: t.repeat([2] + [1] * (t.dim() - 1))
+        common = torch.cat([rep(xyz_pe), _view_pe(c, torch.cat([vd, v_rand], 0)), rep(sdf_p[:, None]), rep(feat), rep(nrm)], -1)
+        gp = fp.to_norm(p, c.xyz_min, c.xyz_max)
+        bfeat = torch.cat([xyz_pe, sdf_p[:, None], feat, nrm], -1)
+        base, rough, metal = brdf_net(P, torch.cat([fp.sample_grid(P["brdf.grid"], gp), bfeat], -1))
+        emit = emit_net(P, torch.cat([fp.sample_grid(P["emit_color.grid"], gp), bfeat], -1))
+    emo = fp.radiance(P, "emo_rgbnet", torch.cat([rep(fp.sample_grid(P["emo_color.grid"], gp)), common.detach()], -1))
+    with torch.no_grad():
+        ex = lambda t: t.view(Pn, 1, -1).expand(Pn, R, t.shape[-1]).flatten(0, 1)
+        o2, d2 = ex(p), dirs.flatten(0, 1)
+        Rf = disney_reflection(rep(ex(base)), rep(ex(rough)), rep(ex(metal)), rep(ex(normal)), rep(d2),
+                               torch.cat([-ex(vd), -ex(v_rand)], 0))
+        N2, p2, rid = _march(P, c, o2, d2, lts_near, s_val)
+        s2 = fp.sample_grid(P["sdf.grid"], fp.to_norm(p2, c.xyz_min, c.xyz_max))[:, 0]
+        a2 = fp.neus_alpha_interp(s2, rid, s_val) if s2.numel() > 1 else s2.new_zeros(s2.shape)
+        m = a2 > c.fastcolor_thres
+        a2, p2, rid, s2 = a2[m], p2[m], rid[m], s2[m]
+        w2, _ = fp._Composite.apply(a2, rid, N2)
+        m = w2 > c.fastcolor_thres
+        w2, p2, rid, s2 = w2[m], p2[m], rid[m], s2[m]
+        f2, _, nr2 = _stencil(c, P["sdf.grid"], p2)
+        feat2 = torch.cat([_pe(c, p2), _view_pe(c, d2)[rid], s2[:, None], f2, nr2], -1)
+        lemo = fp.radiance(P, "emo_rgbnet", torch.cat([fp.sample_grid(P["emo_color.grid"], fp.to_norm(p2, c.xyz_min, c.xyz_max)), feat2], -1))
+        emo_m = torch.zeros(N2, 3).index_add(0, rid, w2[:, None] * lemo)
+        emit = edit_emission(emit, modes, inten, cols)
+        reflect = (rep(emo_m) * Rf).view(-1, R, 3).mean(-2)
+        emo_hat = rep(emit) + reflect
+    return {"lin/pbr/emo": emo, "lin/pbr/emo_hat": emo_hat}
