@@ -364,6 +364,7 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
         // corners -- 72 LDS atomics per sample instead of 200 (LDS float atomics retire ~1 lane per 1.5
         // clocks and were 59 % of this kernel's wave time).  Lane half 0 owns the z bar and the lower half
         // of the x bar, lane half 1 the y bar and the upper half of the x bar.
+        if (P.grad_sdf) {       // null: the SDF grid is frozen (re-lighting fine-tune), colour phase only
         // The reference clamps every coordinate of a tap to the grid (not only the displaced one), which
         // matters for explicit points that a perturbation pushed outside the box: the bars are anchored
         // at the clamped position (identical to `ind` for in-box samples).
@@ -470,6 +471,7 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
         lds_fence();
         window_flush(w, P.grad_sdf, gdims, lane);
         lds_fence();
+        }
         // ---- phase 2: colour grids, one pass per net that read a colour group (3 channels per lane half)
         for (int k = 0; k < P.n_src; ++k) {
             float *gcol = on_tile ? P.gcol_on[k] : P.gcol_off[k];
@@ -545,7 +547,7 @@ ESR_API int esr_fine_feat_bwd(const esr_scene_t *scene, const esr_feat_args_t *a
     FeatParams P = {};
     const int c = feat_common(scene, args, P);
     if (c <= 0) return c;
-    if (!X || !gnorm || !src || n_src < 1 || n_src > MAX_SRC || !grad_sdf) return ESR_EINVAL;
+    if (!X || !gnorm || !src || n_src < 1 || n_src > MAX_SRC) return ESR_EINVAL;
     P.X = const_cast<float *>(X); P.gnorm = const_cast<float *>(gnorm);
     P.n_src = n_src;
     for (int k = 0; k < n_src; ++k) {

@@ -137,6 +137,38 @@ __global__ void __launch_bounds__(256) lts_dirs_kernel(const float *__restrict__
     }
 }
 
+// ---- emission edit of the re-lighting fine-tune (esrnerf.py:427-441, pbr/functions.py:214-255) --------
+// mode 0: off; 2, 4: intensity scale; 3, 4: hue and saturation replaced (value kept) through the
+// reference's rgb<->hsv pair.  `%` below is torch's remainder (result in [0, divisor)).
+__device__ __forceinline__ float esr_rem(float a, float b) { return a - floorf(a / b) * b; }
+
+__global__ void __launch_bounds__(256) emit_edit_kernel(float *__restrict__ emit, const int64_t *__restrict__ modes,
+                                                        const float *__restrict__ inten,
+                                                        const float *__restrict__ colors, int n)
+{
+#pragma clang fp contract(off)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int64_t m = modes[i];
+        float r = emit[3 * i], g = emit[3 * i + 1], b = emit[3 * i + 2];
+        if (m == 0) { r = g = b = 0.f; }
+        if (m == 2 || m == 4) { const float k = inten[i]; r = r * k; g = g * k; b = b * k; }
+        if (m == 3 || m == 4) {
+            // rgb -> hsv: only v survives (h, s come from the edit), hsv -> rgb
+            const float v = fmaxf(r, fmaxf(g, b));
+            const float h = colors[2 * i], sat = colors[2 * i + 1];
+            const float h6 = h * 6.f;
+            const float sector = esr_rem(floorf(h6), 6.f);
+            const float f = esr_rem(h6, 6.f) - sector;
+            const float p = v * (1.f - sat), q = v * (1.f - f * sat), t = v * (1.f - (1.f - f) * sat);
+            const int k = (int)sector;
+            r = k == 0 ? v : k == 1 ? q : k == 2 ? p : k == 3 ? p : k == 4 ? t : v;
+            g = k == 0 ? t : k == 1 ? v : k == 2 ? v : k == 3 ? q : k == 4 ? p : p;
+            b = k == 0 ? p : k == 1 ? p : k == 2 ? t : k == 3 ? v : k == 4 ? v : q;
+        }
+        emit[3 * i] = r; emit[3 * i + 1] = g; emit[3 * i + 2] = b;
+    }
+}
+
 // ---- light-transport combine ----------------------------------------------------------------
 struct LtsParams {
     int n_pts, n_rays, n_sg, pdra;            // R = n_rays secondary rays per point
@@ -410,6 +442,18 @@ ESR_API int esr_lts_dirs(const float *raw, const float *normal, int32_t n_pts, i
     if (!raw || !normal || !dirs) return ESR_EINVAL;
     lts_dirs_kernel<<<esr_grid_for((int64_t)n_pts * rays_plus_one, 256), 256, 0, esr_stream(stream)>>>(
         raw, normal, n_pts, rays_plus_one, dirs);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_emit_edit(float *emit, const int64_t *em_modes, const float *em_intensities,
+                          const float *em_colors, int32_t n, void *stream)
+{
+    if (n < 0) return ESR_EINVAL;
+    if (n == 0) return 0;
+    if (!emit || !em_modes || !em_intensities || !em_colors) return ESR_EINVAL;
+    emit_edit_kernel<<<esr_grid_for(n, 256), 256, 0, esr_stream(stream)>>>(emit, em_modes, em_intensities,
+                                                                          em_colors, n);
     ESR_CHECK_LAUNCH();
     return 0;
 }

@@ -7,8 +7,8 @@ Same constructor, ``train()`` / ``forward(**kwargs)`` protocol, the 16 result ke
 name, cfg/app/lts.yaml:61-71) and ``state_dict`` keys.  ``forward_training`` is one autograd
 node over the kernels of libesr_hip.so (esr_nerf_amd/lts_engine.py).
 
-Not yet provided: ``forward_evaluate``, ``forward_finetune``, ``eval_emit``, ``eval_esp``,
-``render_envmap``.
+``forward_finetune`` (re-lighting fine-tune target, esrnerf.py:241-484) runs on the same kernels.
+Not yet provided: ``forward_evaluate``, ``eval_emit``, ``eval_esp``, ``render_envmap``.
 """
 from __future__ import annotations
 
@@ -130,6 +130,40 @@ class _LtsRender(torch.autograd.Function):
                 grads["lobes"], *mg)
 
 
+class _FinetuneRender(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, batch, draws, emo_color, *emo_params):
+        eng: LtsEngine = model.engine
+        eng.pack("emo", KIND_RADIANCE, list(emo_params[0::2]), list(emo_params[1::2]))
+        for name, kind, net in (("brdf", KIND_BRDF, model.brdfnet), ("emit", KIND_EMIT, model.emitnet)):
+            lins = net.layers()
+            eng.pack(name, kind, [l.weight.detach() for l in lins], [l.bias.detach() for l in lins])
+        grids = dict(sdf=model.sdf.device_view(), emo=model.emo_color.device_view(), brdf=model.brdf.device_view(),
+                     emit=model.emit_color.device_view(),
+                     mask=model.mask_cache.density.view(*model.mask_cache.density.shape[2:]))
+        cfg = dict(num_2ndrays=model.num_2ndrays, num_ltspts=model.num_ltspts)
+        fctx, out = eng.finetune_forward(model.scene_struct(), model.scene_struct(near=model.lts_near), batch, grids,
+                                         cfg, draws)
+        ctx.fctx, ctx.model = fctx, model
+        ctx.shapes = [tuple(p.shape) for p in emo_params]
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(out["lin/pbr/emo_hat"])
+        model.last_counts = dict(eng.prim.counts)
+        return out["lin/pbr/emo"], out["lin/pbr/emo_hat"]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_emo, _g_hat):
+        model = ctx.model
+        dev = model.sdf.grid.device
+        X, Y, Z = [int(v) for v in model.world_size]
+        g_grid = torch.zeros((1, X, Y, Z, 6), dtype=torch.float32, device=dev)
+        mg = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.shapes]
+        if g_emo is not None:
+            model.engine.finetune_backward(ctx.fctx, g_emo.contiguous(), dict(emo=g_grid, emo_w=mg[0::2], emo_b=mg[1::2]))
+        return (None, None, None, g_grid.permute(0, 4, 1, 2, 3), *mg)
+
+
 class ESRNeRF(VoxurfF):
     def __init__(self, cfg, near, far, xyz_min, xyz_max, mask_xyz_min, mask_xyz_max, mask_alpha_init,
                  mask_density, s_val, num_voxles):
@@ -171,8 +205,19 @@ class ESRNeRF(VoxurfF):
         return sc
 
     def train(self, mode=True, finetune=False):
-        if finetune:
-            raise NotImplementedError("forward_finetune (re-lighting) is a 'next' row of SURVEY.md section 8")
+        """esrnerf.py:218-239: fine-tune mode renders through ``forward_finetune`` and freezes a copy of the emo
+        colour grid (``emit_color``) for the emission head; leaving it deletes the copy again."""
+        if mode and finetune:
+            ret = nn.Module.train(self, mode)
+            self.forward = self.forward_finetune
+            self.emit_color = DenseGrid(channels=self.color_dim, world_size=self.world_size, xyz_min=self.xyz_min,
+                                        xyz_max=self.xyz_max).to(self.device)
+            self.emit_color.load_state_dict(self.emo_color.state_dict())
+            for p in self.emit_color.parameters():
+                p.requires_grad_(False)
+            return ret
+        if mode and hasattr(self, "emit_color"):
+            del self.emit_color
         return super().train(mode)
 
     def _mlp_params(self) -> List[torch.Tensor]:
@@ -206,6 +251,15 @@ class ESRNeRF(VoxurfF):
             "etc/emit": r["etc/emit"], "etc/emit_eps": r["etc/emit_eps"],
             "etc/brdf": r["etc/brdf"], "etc/brdf_eps": r["etc/brdf_eps"],
         }
+
+    def forward_finetune(self, draws=None, **kwargs):
+        """Re-lighting fine-tune target (esrnerf.py:241-484): {"lin/pbr/emo" (differentiable w.r.t. emo_color and
+        emo_rgbnet only), "lin/pbr/emo_hat" (constant)}.  Uses ``self.s_val`` like the reference."""
+        batch = {k: kwargs[k].contiguous() for k in ("rays_o", "rays_d", "viewdirs", "em_modes", "em_intensities",
+                                                      "em_colors")}
+        ps = [t for lin in self.emo_rgbnet.layers() for t in (lin.weight, lin.bias)]
+        emo, emo_hat = _FinetuneRender.apply(self, batch, draws, self.emo_color.grid, *ps)
+        return {"lin/pbr/emo": emo, "lin/pbr/emo_hat": emo_hat}
 
     @torch.no_grad()
     def scale_volume_grid(self, num_voxels):

@@ -217,6 +217,119 @@ class LtsEngine(FineEngine):
                   _lib.ptr(P.bufs["X"]), _lib.ptr(P.bufs["gnorm"]), src, len(sources), _lib.ptr(dsdf_extra),
                   _lib.ptr(grad_sdf), _lib.ptr(dsdf_out), self._s())
 
+    def _ref_order(self, P0: Pass, cnt3, off3):
+        """perm[k] = compact (tile-order) index of the k-th surviving sample in the reference's ray-sorted
+        order; also the int64 ray id of every compact slot."""
+        dev = self.device
+        T, Ton = P0.tiles_all, P0.tiles_on
+        n_on, n_off = P0.counts["n_on"], P0.counts["n_off"]
+        jidx = torch.cat([torch.arange(n_on, device=dev), Ton * 32 + torch.arange(n_off, device=dev)])
+        rec_ray = P0.bufs["rec_ray"][: T * 32].long()
+        ray_j = rec_ray[jidx]
+        ref_off = torch.cumsum(cnt3.long(), 0) - cnt3.long()
+        ref_pos = ref_off[ray_j] + (jidx - off3.long()[ray_j])
+        perm = torch.empty(n_on + n_off, dtype=torch.long, device=dev)
+        perm[ref_pos] = jidx
+        return perm, rec_ray
+
+    # ------------------------------------------------------------------ re-lighting fine-tune (A16)
+    def finetune_forward(self, scene, scene2, batch, grids, cfg, draws=None):
+        """``ESRNeRF.forward_finetune`` (esrnerf.py:241-484): the emo net's prediction at ``num_ltspts`` surface
+        points (camera + one random direction) against edited emission + reflected emo radiance gathered over
+        ``num_2ndrays`` secondary rays.  grids: sdf, emo, brdf, emit (the frozen copy feeding the emission head),
+        mask.  Only the emo colour grid and the emo net receive gradients (finetune_backward)."""
+        L, s, dev = self.L, self._s(), self.device
+        sdf, emog, brdfg, emitg = grids["sdf"], grids["emo"], grids["brdf"], grids["emit"]
+        rays_o, rays_d, viewdirs = batch["rays_o"], batch["rays_d"], batch["viewdirs"]
+        N = rays_o.shape[0]
+        P0, P1, P2 = self.prim, self.pts, self.sec
+        cnt3, off3, _ = self._march(P0, scene, rays_o, rays_d, torch.zeros(N, dtype=torch.int64, device=dev),
+                                    grids["mask"], sdf)
+        T, m3 = P0.tiles_all, P0.counts["m3"]
+        if T == 0:
+            raise RuntimeError("fine-tune step with no surviving sample (degenerate batch)")
+        sp = C.byref(scene)
+        eg = torch.empty(T * 32, 4, device=dev)
+        self._run("expgrad_fwd", L.esr_expgrad_fwd, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(P0.bufs["rec_ray"]),
+                  _lib.ptr(P0.bufs["rec_step"]), None, None, C.c_float(0.0), _lib.ptr(sdf), T * 32, 0, _lib.ptr(eg), s)
+        pts_all = torch.empty(T * 32, 3, device=dev)
+        self._run("sample_points", L.esr_sample_points, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
+                  _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(P0.bufs["rec_step"]), T * 32, _lib.ptr(pts_all), s)
+        perm, rec_ray = self._ref_order(P0, cnt3, off3)
+        if draws is None:
+            idx_ref = torch.from_numpy(np.random.choice(m3, min(int(cfg["num_ltspts"]), m3), replace=False)).to(dev)
+        else:
+            idx_ref = draws["idx"].to(dev)
+        Pn, R = idx_ref.numel(), int(cfg["num_2ndrays"])
+        jp = perm[idx_ref]
+        ray_p = rec_ray[jp]
+        pts_p = pts_all[jp].contiguous()
+        view_p = viewdirs[ray_p].contiguous()
+        normal_p = torch.nn.functional.normalize(eg[jp, 1:4], dim=-1).contiguous()
+        sdf_p = P0.bufs["rec_sdf"][: T * 32][jp].contiguous()
+        raw = torch.randn(Pn, R + 1, 3, device=dev) if draws is None else draws["dirs"].to(dev).contiguous()
+        dirs_all = torch.empty(Pn, R + 1, 3, device=dev)
+        self._run("lts_dirs", L.esr_lts_dirs, _lib.ptr(raw), _lib.ptr(normal_p), Pn, R + 1, _lib.ptr(dirs_all), s)
+        v_rand = (-dirs_all[:, R]).contiguous()
+        # heads at the points: colour group rows 0 / 88 / 96 <- emit_color / emo_color / brdf
+        pts2, vd2, sdf2 = torch.cat([pts_p, pts_p]).contiguous(), torch.cat([view_p, v_rand]).contiguous(), \
+            torch.cat([sdf_p, sdf_p]).contiguous()
+        self._feat_args_points(P1, pts2, vd2, sdf2, sdf, (emitg, emog, brdfg))
+        self._features(P1, scene)
+        T1 = P1.tiles_all
+        self._net_fwd(P1, "emo", KIND_RADIANCE, 88, 0, T1)
+        self._net_fwd(P1, "brdf", KIND_BRDF, 96, 0, T1, save=False)
+        self._net_fwd(P1, "emit", KIND_EMIT, 0, 0, T1, save=False)
+        self._act(P1, "emo.z", "emo.a", 4, 3, ACT_SOFTPLUS)
+        self._act(P1, "brdf.z", "brdf.a", 8, 5, ACT_SIGMOID)
+        self._act(P1, "emit.z", "emit.a", 4, 3, ACT_SOFTPLUS)
+        emo_pt = P1.rowmajor("emo.a")[: 2 * Pn, :3].contiguous()
+        brdf_rm = P1.rowmajor("brdf.a")[:Pn]
+        base_p, rough_p, metal_p = brdf_rm[:, 0:3].contiguous(), brdf_rm[:, 3].contiguous(), brdf_rm[:, 4].contiguous()
+        emis_p = P1.rowmajor("emit.a")[:Pn, :3].contiguous()
+        modes_p = batch["em_modes"][ray_p].contiguous()
+        inten_p = batch["em_intensities"][ray_p].contiguous()
+        cols_p = batch["em_colors"][ray_p].contiguous()
+        self._run("emit_edit", L.esr_emit_edit, _lib.ptr(emis_p), _lib.ptr(modes_p), _lib.ptr(inten_p), _lib.ptr(cols_p), Pn, s)
+        # incoming emo radiance along the secondary rays (no gradient: esrnerf.py:241 no_grad)
+        o2 = pts_p.repeat_interleave(R, 0).contiguous()
+        d2 = dirs_all[:, :R].reshape(Pn * R, 3).contiguous()
+        _, _, last2 = self._march(P2, scene2, o2, d2, torch.zeros(Pn * R, dtype=torch.int64, device=dev), grids["mask"], sdf)
+        T2 = P2.tiles_all
+        emo_m = torch.zeros(Pn * R, 3, device=dev)
+        if T2:
+            self._feat_args_records(P2, o2, d2, d2, sdf, (None, emog, None), (None, emog, None))
+            self._features(P2, scene2)
+            self._net_fwd(P2, "emo", KIND_RADIANCE, 88, 0, T2, save=False)
+            self._act(P2, "emo.z", "emo.a", 4, 3, ACT_SOFTPLUS)
+            self._run("composite3_fwd", L.esr_composite3_fwd, _lib.ptr(P2.bufs["emo.a"]), 4, _lib.ptr(P2.bufs["rec_ray"]),
+                      _lib.ptr(P2.bufs["rec_w"]), T2, _lib.ptr(emo_m), s)
+        a = _lib.EsrLtsArgs()
+        a.n_pts, a.n_rays, a.n_sg, a.pdra_mode = Pn, R, 1, 0
+        zero3 = torch.zeros(1, 3, device=dev)
+        held = dict(base=base_p, rough=rough_p, metal=metal_p, normal=normal_p, view=view_p, dirs=dirs_all,
+                    off_m=torch.zeros(Pn * R, 3, device=dev), emo_m=emo_m, last2=torch.zeros(Pn * R, device=dev),
+                    mus=zero3, lambdas=torch.ones(1, device=dev), lobes=torch.ones(1, 3, device=dev), emission=emis_p,
+                    umask=torch.zeros(Pn, dtype=torch.uint8, device=dev))
+        for k, v in held.items():
+            setattr(a, k, v.data_ptr())
+        off_hat = torch.empty(2 * Pn, 3, device=dev)          # the off half of the combine is unused here
+        emo_hat = torch.empty(2 * Pn, 3, device=dev)
+        self._run("lts_combine_fwd", L.esr_lts_combine_fwd, C.byref(a), _lib.ptr(off_hat), _lib.ptr(emo_hat), s)
+        ctx = dict(scene=scene, n_pts=Pn, held=held, keep=(pts2, vd2, sdf2, last2))
+        return ctx, {"lin/pbr/emo": emo_pt, "lin/pbr/emo_hat": emo_hat}
+
+    def finetune_backward(self, ctx, g_emo, grads):
+        """g_emo [2*P,3] -> grads["emo"] (colour grid, channels-last), grads["emo_w"], grads["emo_b"]."""
+        P1, dev = self.pts, self.device
+        T1, Pn = P1.tiles_all, ctx["n_pts"]
+        ga = torch.zeros(T1 * 32, 3, device=dev)
+        ga[: 2 * Pn] = g_emo
+        gt = P1.from_rowmajor("emo.ga", 4, ga)
+        dz = self._act(P1, "emo.z", "emo.dz", 4, 3, ACT_SOFTPLUS, bwd_g=gt)
+        dX = self._net_bwd(P1, "emo", KIND_RADIANCE, 88, 0, T1, dz, grads["emo_w"], grads["emo_b"])
+        self._feat_bwd(P1, ctx["scene"], [(dX, None, grads["emo"], 0, T1)], None)
+
     # ------------------------------------------------------------------ forward
     def lts_forward(self, scene, scene2, batch, grids, envmap, cfg, draws=None):
         """grids: dict sdf [X,Y,Z], off/emo/brdf [X,Y,Z,6], mask [mx,my,mz].  cfg: num_2ndrays, num_ltspts,
@@ -267,14 +380,7 @@ class LtsEngine(FineEngine):
                   _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(P0.bufs["rec_w"]), T, _lib.ptr(emit_m), s)
 
         # ---- compact order <-> the reference's ray-sorted order
-        n_on, n_off = P0.counts["n_on"], P0.counts["n_off"]
-        jidx = torch.cat([torch.arange(n_on, device=dev), Ton * 32 + torch.arange(n_off, device=dev)])
-        rec_ray = P0.bufs["rec_ray"][: T * 32].long()
-        ray_j = rec_ray[jidx]
-        ref_off = torch.cumsum(cnt3.long(), 0) - cnt3.long()
-        ref_pos = ref_off[ray_j] + (jidx - off3.long()[ray_j])
-        perm = torch.empty(m3, dtype=torch.long, device=dev)
-        perm[ref_pos] = jidx
+        perm, rec_ray = self._ref_order(P0, cnt3, off3)
         ctx.perm = perm
         brdf_rm = P0.rowmajor("brdf.a")            # [T*32, 8]
         emit_rm = P0.rowmajor("emit.a")            # [T*32, 4]

@@ -208,7 +208,8 @@ int esr_fine_feat_fwd(const esr_scene_t *scene, const esr_feat_args_t *args, flo
  * over its tile range: rows 6-42 (sdf value, stencil features, normals) are summed over the sources,
  * rows 0-5 go to that source's colour grid.  dsdf_extra [tiles*32] (optional) is added to the
  * SDF-value row.  With explicit points the SDF-value gradient is returned in dsdf_out [tiles*32]
- * instead of being scattered.  Scatter = LDS accumulation window + z-contiguous float atomics.
+ * instead of being scattered.  grad_sdf NULL: the SDF grid is frozen, only the colour grids receive
+ * gradients (re-lighting fine-tune).  Scatter = LDS accumulation window + z-contiguous float atomics.
  */
 typedef struct esr_feat_bwd_src {
     const float *dX;
@@ -389,6 +390,16 @@ typedef struct esr_lts_grads {
 int esr_lts_combine_fwd(const esr_lts_args_t *args, float *off_hat, float *emo_hat, void *stream);
 int esr_lts_combine_bwd(const esr_lts_args_t *args, const float *g_off_hat, const float *g_emo_hat,
                         const esr_lts_grads_t *grads, void *stream);
+
+/*
+ * Emission edit of the re-lighting fine-tune, in place on emit [n,3] -- replaces
+ * app/fine/model/esrnerf.py:427-441 with rgb_to_hsv / hsv_to_rgb of
+ * app/utils/pbr/functions.py:214-255.  em_modes int64 [n]: 0 emission off, 1 unchanged,
+ * 2 scaled by em_intensities [n], 3 hue/saturation replaced by em_colors [n,2] (value kept),
+ * 4 both.
+ */
+int esr_emit_edit(float *emit, const int64_t *em_modes, const float *em_intensities,
+                  const float *em_colors, int32_t n, void *stream);
 
 /*
  * Small tile-major helpers of the LTS renderer.

@@ -231,3 +231,22 @@ def test_feat_kernels_explicit_points_straddling_the_box():
     assert rel_err(g_sdf, sdf.grad[0, 0]) < 1e-4, rel_err(g_sdf, sdf.grad[0, 0])
     assert rel_err(g_col.permute(3, 0, 1, 2), col.grad[0]) < 2e-5
     assert rel_err(dsdf_out[:n], dXr[:, 6]) < 1e-6
+
+
+def test_emit_edit_kernel_all_modes():
+    """esr_emit_edit against the oracle's restatement of esrnerf.py:427-441 + the reference's hsv pair."""
+    from esr_nerf_amd import _lib
+    from oracle import lts_path as lp
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(4)
+    n = 5000
+    emit = torch.rand(n, 3, generator=g) * 4.0 + 1e-3
+    emit[:50] = emit[:50, :1]                                  # grey: delta == 0 branch of rgb_to_hsv
+    modes = torch.randint(0, 5, (n,), generator=g)
+    inten = torch.rand(n, generator=g) * 3.0
+    cols = torch.rand(n, 2, generator=g)
+    cols[100:120, 0] = torch.tensor([0.0, 1.0 / 6, 2.0 / 6, 0.5, 4.0 / 6, 5.0 / 6, 0.999999, 1.0, 0.25, 0.75] * 2)
+    ref = lp.edit_emission(emit, modes, inten, cols)
+    e, m, i, c = emit.cuda().contiguous(), modes.cuda(), inten.cuda(), cols.cuda().contiguous()
+    _lib.check(L.esr_emit_edit(_lib.ptr(e), _lib.ptr(m), _lib.ptr(i), _lib.ptr(c), n, _lib.stream_ptr("cuda:0")), "emit_edit")
+    assert rel_err(e, ref) < 1e-6

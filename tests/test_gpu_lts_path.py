@@ -226,3 +226,40 @@ def test_lts_step_equals_autograd_route(stage):
         if not e < 2e-5:
             bad[k] = e
     assert not bad, str(bad)
+
+
+def test_finetune_golden_reference_vectors():
+    """ESRNeRF.forward_finetune (A16) on the HIP path against the reference-generated fixture: both outputs,
+    the loss of pdra.py:1090-1093 and the 9 gradients (emo colour grid + emo net); nothing else gets one."""
+    from esr_nerf_amd.synthetic import slab_scene
+    z = {k: torch.from_numpy(np.asarray(v)) for k, v in load_npz("lts_g16_finetune.npz").items()}
+    sd = {k: torch.from_numpy(v) for k, v in load_npz("lts_g16_params.npz").items()}
+    sc = slab_scene("g16", s_val=60.0, oblique=True)
+    m, cfg = build_lts_model(sc, num_2ndrays=8, num_ltspts=12)
+    m.load_state_dict({k: v.cuda() for k, v in sd.items()})
+    for p in m.parameters():
+        p.requires_grad_(False)
+    for p in list(m.emo_color.parameters()) + list(m.emo_rgbnet.parameters()):
+        p.requires_grad_(True)
+    m.s_val = 60.0
+    m.train(True, finetune=True)
+    assert "emit_color.grid" in m.state_dict() and not m.emit_color.grid.requires_grad
+    with torch.no_grad():
+        m.emo_color.grid.copy_(z["param/emo_color.grid"].cuda())
+    assert rel_err(m.emit_color.grid, z["param/emit_color.grid"]) == 0.0
+    b = {k[3:]: v.cuda() for k, v in z.items() if k.startswith("in/") and k not in ("in/s_val", "in/weight_lts")}
+    res = m(draws=dict(idx=z["draw/idx"].cuda(), dirs=z["draw/dirs"].cuda()), **b)
+    for k in ("lin/pbr/emo", "lin/pbr/emo_hat"):
+        assert res[k].shape == z["out/" + k].shape
+        assert rel_err(res[k], z["out/" + k]) < TOL, (k, rel_err(res[k], z["out/" + k]))
+    assert not res["lin/pbr/emo_hat"].requires_grad
+    loss = float(z["in/weight_lts"]) * torch.nn.functional.mse_loss(res["lin/pbr/emo"], res["lin/pbr/emo_hat"])
+    assert abs(float(loss.detach()) - float(z["loss"])) < 1e-6
+    loss.backward()
+    got = {k for k, p in m.named_parameters() if p.grad is not None}
+    want = {k[5:] for k in z if k.startswith("grad/")}
+    assert got == want
+    bad = {k: rel_err(dict(m.named_parameters())[k].grad, z["grad/" + k]) for k in want}
+    assert all(e < TOL for e in bad.values()), str(bad)
+    m.train(True)                      # leaving fine-tune mode drops the frozen copy (esrnerf.py:222-223)
+    assert not hasattr(m, "emit_color")
