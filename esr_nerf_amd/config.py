@@ -66,6 +66,25 @@ LTS_TRAINER = dict(weight_entropy_last=0.001, weight_tv_density=0.01, weight_lin
 PDRA_TRAINER = dict(LTS_TRAINER, weight_emit_smooth=0.1, weight_lts_l=50.0, weight_lts_r=1.0, weight_emit_supp=0.1)
 
 
+# /root/reference/cfg/app/coarse.yaml:12-32 (model), :75-77 (loss weights)
+COARSE_MODEL = dict(mask_ks=3, maskcache_thres=0.001, fastcolor_thres=0.0001, stepsize=0.5, num_voxels=884736,
+                    color_dim=12, rgbnet_width=128, rgbnet_depth=3, posbase_pe=5, viewbase_pe=1, smooth_ksize=5,
+                    smooth_sigma=0.8, neus_alpha="interp")
+COARSE_TRAINER = dict(weight_entropy_last=0.001, weight_tv_density=0.001, weight_tv_color=0.01,
+                      tvs=dict(sdf=0.1, smooth_grad=0.05), s_start=5.0, s_inv_ratio=50.0)
+
+
+def coarse_cfg(device: str = "cpu", **model_over) -> AttrDict:
+    m = dict(COARSE_MODEL)
+    m.update(model_over)
+    return AttrDict(
+        system=dict(device=device, debug=True, seed=0, tqdm_iters=10),
+        app=dict(model=m, trainer=dict(COARSE_TRAINER)),
+        data=dict(white_bg=True),
+        global_step=0,
+    )
+
+
 def lts_cfg(device: str = "cpu", **model_over) -> AttrDict:
     m = dict(LTS_MODEL)
     m.update(model_over)

@@ -130,6 +130,7 @@ def main():
     ru.sample_pts_on_rays, ru.alpha2weight, ru.alpha2weight_backward = real_sample, real_a2w, real_a2w_b
     gen_lts(ns)
     gen_finetune(ns)
+    gen_coarse(ns)
 
 
 def lts_reference_loss(ns, results, rgbs, cfg):
@@ -282,8 +283,51 @@ def gen_finetune(ns):
     print("finetune loss", float(loss), "grads", sorted(k for k in out if k.startswith("grad/")))
 
 
+def gen_coarse(ns):
+    """VoxurfC.forward_training + the loss lines of coarse.py:341-352 on the small oblique slab (A17)."""
+    from esr_nerf_amd.config import coarse_cfg
+    from esr_nerf_amd.synthetic import analytic_sdf
+    sc = slab_scene("g16", s_val=8.0, oblique=True)
+    cfg = coarse_cfg("cpu", num_voxels=sc.num_voxels)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = ns.VoxurfC(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max,
+                       sc.mask_alpha_init, sc.mask_density, 8.0)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        model.sdf.grid.copy_(analytic_sdf([int(v) for v in model.world_size], sc.xyz_min, sc.xyz_max))
+        model.off_color.grid.copy_(torch.randn(model.off_color.grid.shape, generator=g) * 0.1)
+        model.emo_color.grid.copy_(torch.randn(model.emo_color.grid.shape, generator=g) * 0.1)
+    model.train()
+    np.savez_compressed(os.path.join(OUT, "coarse_g16_params.npz"),
+                        **{k: v.detach().numpy() for k, v in model.state_dict().items()})
+    b = sc.batch
+    for s_val in (8.0, 40.0):
+        model.zero_grad(set_to_none=True)
+        res = model(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=b["em_modes"], s_val=s_val)
+        raw = {k: v.detach().clone() for k, v in res.items()}
+        srgb = (res["srgb/rgb"] + res["etc/white_bg"] * 1.0).clamp(min=0.0, max=1.0)
+        loss = F.mse_loss(srgb, b["rgbs"])
+        pout = res["etc/alphainv_cum"][..., -1].clamp(1e-6, 1 - 1e-6)
+        loss = loss + cfg.app.trainer.weight_entropy_last * -(pout * torch.log(pout) + (1 - pout) * torch.log(1 - pout)).mean()
+        loss.backward()
+        out = {"in/" + k: v.numpy() for k, v in b.items()}
+        out["in/s_val"] = np.float32(s_val)
+        for k, v in raw.items():
+            out["out/" + k] = v.numpy()
+        out["loss"] = loss.detach().numpy()
+        for k, p_ in model.named_parameters():
+            if p_.grad is not None:
+                out["grad/" + k] = p_.grad.detach().numpy()
+        np.savez_compressed(os.path.join(OUT, f"coarse_g16_s{int(s_val)}.npz"), **out)
+        print("coarse s_val", s_val, "loss", float(loss), "grads", sum(1 for k in out if k.startswith("grad/")))
+
+
 if __name__ == "__main__":
     import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "coarse":
+        gen_coarse(ref_import.load())
+        raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "finetune":
         gen_finetune(ref_import.load())
     else:
