@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libesr_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 _lib = None
 
 
@@ -74,6 +74,7 @@ EXPORTS = [
     "esr_expgrad_fwd", "esr_expgrad_bwd", "esr_lts_dirs", "esr_lts_combine_fwd", "esr_lts_combine_bwd",
     "esr_act_fwd", "esr_act_bwd", "esr_composite3_fwd", "esr_composite3_bwd", "esr_lts_tone_in_bwd",
     "esr_sample_points", "esr_pair_loss_fwd_bwd", "esr_emit_edit",
+    "esr_gauss3d_fwd", "esr_gauss3d_bwd", "esr_central_grad_fwd", "esr_central_grad_bwd",
 ]
 
 

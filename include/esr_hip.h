@@ -425,6 +425,32 @@ int esr_lts_tone_in_bwd(const float *dXt, const float *g_lin, const float *lin, 
 int esr_sample_points(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
                       const int32_t *rec_ray, const int32_t *rec_step, int32_t n, float *pts, void *stream);
 
+/* ------------------------------------------------------------------------- *
+ * D. Coarse stage (VoxurfC) -- dense whole-grid operators
+ * ------------------------------------------------------------------------- */
+
+/*
+ * Gaussian smoothing of the SDF grid -- replaces Gaussian3DConv.forward
+ * (app/utils/base/module.py:145-177: nn.Conv3d(1,1,k, padding=k//2, padding_mode="replicate"),
+ * called on every forward at app/coarse/model/voxurfc.py:202).  in/out [gx,gy,gz];
+ * weights_host: k*k*k floats in HOST memory in Conv3d order (they travel as a kernel argument).
+ * _bwd is the exact adjoint (a gather, no atomics): gin += conv^T(gout).
+ */
+int esr_gauss3d_fwd(const float *in, const float *weights_host, int ksize, int32_t gx, int32_t gy,
+                    int32_t gz, float *out, void *stream);
+int esr_gauss3d_bwd(const float *gout, const float *weights_host, int ksize, int32_t gx, int32_t gy,
+                    int32_t gz, float *gin, void *stream);
+
+/*
+ * Dense central-difference gradient of the SDF grid -- replaces VoxurfC.neus_sdf_gradient
+ * (app/coarse/model/voxurfc.py:597-616).  grad is channels-last [gx,gy,gz,3] (component a =
+ * d/d grid axis a = world x,y,z), zero on the boundary layer of each axis.  _bwd: gsdf += adjoint.
+ */
+int esr_central_grad_fwd(const float *sdf, int32_t gx, int32_t gy, int32_t gz, float voxel_size,
+                         float *grad, void *stream);
+int esr_central_grad_bwd(const float *ggrad, int32_t gx, int32_t gy, int32_t gz, float voxel_size,
+                         float *gsdf, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
