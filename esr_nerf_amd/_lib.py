@@ -75,6 +75,7 @@ EXPORTS = [
     "esr_act_fwd", "esr_act_bwd", "esr_composite3_fwd", "esr_composite3_bwd", "esr_lts_tone_in_bwd",
     "esr_sample_points", "esr_pair_loss_fwd_bwd", "esr_emit_edit",
     "esr_gauss3d_fwd", "esr_gauss3d_bwd", "esr_central_grad_fwd", "esr_central_grad_bwd",
+    "esr_coarse_march_count", "esr_coarse_march_fill", "esr_coarse_march_bwd",
 ]
 
 

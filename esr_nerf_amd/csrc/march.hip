@@ -31,6 +31,7 @@ struct MarchParams {
     // COUNT
     int32_t *cnt3;
     float *alphainv_last;
+    float *cumw;             // coarse: per-ray sum of the final weights (white_bg = 1 - cumw)
     esr_plan_t *plan;
     // FILL / BWD
     const int32_t *off3;
@@ -47,7 +48,9 @@ __device__ __forceinline__ float neus_alpha(float pc, float nc)
     return fminf(fmaxf(r, 0.f), 1.f);
 }
 
-template <int MODE>
+// COARSE (VoxurfC.forward_training, voxurfc.py:207-219): no alpha threshold, and alpha2weight runs a SECOND
+// time over the weight > thres survivors of the first pass; weights and alphainv_last come from that pass.
+template <int MODE, bool COARSE>
 __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -109,8 +112,8 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
     __threadfence_block();
 
     // ---- phase 2: alpha, thresholds, transmittance in serial order ----------
-    float tc = 1.f;
-    bool stopped = false;
+    float tc = 1.f, tc2 = 1.f, wsum = 0.f;
+    bool stopped = false, stopped2 = false;
     int n2 = 0, n3 = 0;
     const int out_base = (MODE != MARCH_COUNT) ? P.off3[r] : 0;
     for (int c0 = 0; c0 < n1; c0 += 64) {
@@ -123,7 +126,7 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
             const float nxt = (j < n1 - 1) ? (s + sdf1[j + 1]) * 0.5f : s;
             alpha = neus_alpha(esr_sigmoid(prv * sc.s_val), esr_sigmoid(nxt * sc.s_val));
         }
-        const bool v2 = ok && alpha > sc.fast_thres;
+        const bool v2 = ok && (COARSE || alpha > sc.fast_thres);
         const unsigned long long b2 = __ballot(v2);
         n2 += __popcll(b2);
         float myT = 1.f;
@@ -139,10 +142,27 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
                 if ((double)tc < 1e-3) { stopped = true; break; }
             }
         }
-        const float w = proc ? myT * alpha : 0.f;
+        float w = proc ? myT * alpha : 0.f;
         const bool v3 = proc && w > sc.fast_thres;
         const unsigned long long b3 = __ballot(v3);
         const int rank = n3 + __popcll(b3 & ((1ull << lane) - 1ull));
+        if (COARSE) {                     // second transmittance pass over the survivors, same serial order
+            myT = 1.f;
+            proc = false;
+            if (!stopped2) {
+                unsigned long long rem = b3;
+                while (rem) {
+                    const int i = __ffsll((long long)rem) - 1;
+                    rem &= rem - 1;
+                    const float ai = __shfl(alpha, i);
+                    if (lane == i) { myT = tc2; proc = true; }
+                    tc2 = (float)((double)tc2 * (1.0 - (double)ai));
+                    if ((double)tc2 < 1e-3) { stopped2 = true; break; }
+                }
+            }
+            w = proc ? myT * alpha : 0.f;
+            wsum += v3 ? w : 0.f;
+        }
         if (MODE == MARCH_FILL && v3) {
             const int o = out_base + rank;
             P.rec_ray[o] = r;
@@ -159,9 +179,14 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
     }
 
     if (MODE == MARCH_COUNT) {
+        if (COARSE && P.cumw) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) wsum += __shfl_xor(wsum, off);
+        }
         if (lane == 0) {
             P.cnt3[r] = n3;
-            P.alphainv_last[r] = tc;
+            P.alphainv_last[r] = COARSE ? tc2 : tc;
+            if (COARSE && P.cumw) P.cumw[r] = wsum;
             atomicAdd(&P.plan->m0, n0);
             atomicAdd(&P.plan->m1, n1);
             atomicAdd(&P.plan->m2, n2);
@@ -172,7 +197,7 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
 
     // ---- backward: reverse scan over the processed samples -------------------
     __threadfence_block();
-    float back = P.dlast[r] * tc;
+    float back = P.dlast[r] * (COARSE ? tc2 : tc);
     const int nchunk = (n1 + 63) >> 6;
     for (int c = nchunk - 1; c >= 0; --c) {
         const int j = c * 64 + lane;
@@ -276,7 +301,7 @@ __global__ void __launch_bounds__(1024) plan_kernel(const int32_t *__restrict__ 
 
 int march_cap(const esr_scene_t *sc) { return ((sc->max_steps + 63) / 64) * 64; }
 
-template <int MODE>
+template <int MODE, bool COARSE = false>
 int launch_march(MarchParams &P, hipStream_t s)
 {
     if (P.n_rays == 0) return 0;
@@ -286,7 +311,7 @@ int launch_march(MarchParams &P, hipStream_t s)
     while (wpb > 1 && per_wave * wpb > 64 * 1024) wpb >>= 1;
     if (per_wave * wpb > 160 * 1024) return ESR_ECAP;
     const int grid = (P.n_rays + wpb - 1) / wpb;
-    march_kernel<MODE><<<grid, wpb * 64, per_wave * wpb, s>>>(P);
+    march_kernel<MODE, COARSE><<<grid, wpb * 64, per_wave * wpb, s>>>(P);
     ESR_CHECK_LAUNCH();
     return 0;
 }
@@ -351,4 +376,52 @@ ESR_API int esr_fine_march_bwd(const esr_scene_t *scene, const float *rays_o, co
     P.n_rays = n_rays; P.cap = march_cap(scene); P.off3 = off3; P.dweight = dweight; P.dlast = dlast;
     P.grad_sdf = grad_sdf;
     return launch_march<MARCH_BWD>(P, esr_stream(stream));
+}
+
+// ---- coarse stage (VoxurfC): same march on the SMOOTHED sdf grid, two transmittance passes -------------
+ESR_API int esr_coarse_march_count(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                                   const float *mask_density, const float *sdf_smooth, int32_t n_rays,
+                                   int32_t *cnt3, float *alphainv_last, float *cum_weights, esr_plan_t *plan,
+                                   void *stream)
+{
+    if (!scene || n_rays < 0 || !plan) return ESR_EINVAL;
+    if (n_rays && (!rays_o || !rays_d || !mask_density || !sdf_smooth || !cnt3 || !alphainv_last || !cum_weights))
+        return ESR_EINVAL;
+    MarchParams P = {};
+    P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d; P.mask_density = mask_density; P.sdf = sdf_smooth;
+    P.n_rays = n_rays; P.cap = march_cap(scene); P.cnt3 = cnt3; P.alphainv_last = alphainv_last;
+    P.cumw = cum_weights; P.plan = plan;
+    return launch_march<MARCH_COUNT, true>(P, esr_stream(stream));
+}
+
+ESR_API int esr_coarse_march_fill(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                                  const float *mask_density, const float *sdf_smooth, int32_t n_rays,
+                                  const int32_t *off3, int32_t *rec_ray, int32_t *rec_step, float *rec_w,
+                                  float *rec_sdf, void *stream)
+{
+    if (!scene || n_rays < 0) return ESR_EINVAL;
+    if (n_rays && (!rays_o || !rays_d || !mask_density || !sdf_smooth || !off3 || !rec_ray || !rec_step ||
+                   !rec_w || !rec_sdf))
+        return ESR_EINVAL;
+    MarchParams P = {};
+    P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d; P.mask_density = mask_density; P.sdf = sdf_smooth;
+    P.n_rays = n_rays; P.cap = march_cap(scene); P.off3 = off3; P.rec_ray = rec_ray;
+    P.rec_step = rec_step; P.rec_w = rec_w; P.rec_sdf = rec_sdf;
+    return launch_march<MARCH_FILL, true>(P, esr_stream(stream));
+}
+
+ESR_API int esr_coarse_march_bwd(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                                 const float *mask_density, const float *sdf_smooth, int32_t n_rays,
+                                 const int32_t *off3, const float *dweight, const float *dlast,
+                                 float *grad_sdf_smooth, void *stream)
+{
+    if (!scene || n_rays < 0) return ESR_EINVAL;
+    if (n_rays && (!rays_o || !rays_d || !mask_density || !sdf_smooth || !off3 || !dweight || !dlast ||
+                   !grad_sdf_smooth))
+        return ESR_EINVAL;
+    MarchParams P = {};
+    P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d; P.mask_density = mask_density; P.sdf = sdf_smooth;
+    P.n_rays = n_rays; P.cap = march_cap(scene); P.off3 = off3; P.dweight = dweight; P.dlast = dlast;
+    P.grad_sdf = grad_sdf_smooth;
+    return launch_march<MARCH_BWD, true>(P, esr_stream(stream));
 }

@@ -50,21 +50,35 @@ struct NetDesc {
     int out_dim;
     int hid_tiles;          // hidden width / 32
     int zrows;              // rows of the output / output-gradient tile (4 or 8)
+    int cw;                 // rows of the colour group at the head of the input tile (re-targetable, see crow)
 };
+constexpr int XC_ROWS = 72; // coarse feature tile: 12 colour | 12 alt colour | normal3 | xyz3 sin15 cos15 | view 9 | pad
 constexpr int X_ROWS = 104; // feature tile: 96 rows + a third colour group (rows 96-101)
 __host__ __device__ constexpr NetDesc net_desc(int kind)
 {
-    return kind == ESR_MLP_RADIANCE ? NetDesc{4, 85, 48, X_ROWS, 3, 6, 4}      // pbr/module.py:6-21
-         : kind == ESR_MLP_TONEMAP  ? NetDesc{2, 33, 24, 48, 3, 6, 4}          // pbr/module.py:24-39
-         : kind == ESR_MLP_BRDF     ? NetDesc{4, 76, 40, X_ROWS, 5, 4, 8}      // pbr/module.py:42-65
-         :                            NetDesc{4, 76, 40, X_ROWS, 3, 4, 4};     // EmissionNet, pbr/module.py:68-83
+    return kind == ESR_MLP_RADIANCE ? NetDesc{4, 85, 48, X_ROWS, 3, 6, 4, 6}   // pbr/module.py:6-21
+         : kind == ESR_MLP_TONEMAP  ? NetDesc{2, 33, 24, 48, 3, 6, 4, 6}       // pbr/module.py:24-39
+         : kind == ESR_MLP_BRDF     ? NetDesc{4, 76, 40, X_ROWS, 5, 4, 8, 6}   // pbr/module.py:42-65
+         : kind == ESR_MLP_EMIT     ? NetDesc{4, 76, 40, X_ROWS, 3, 4, 4, 6}   // EmissionNet, pbr/module.py:68-83
+         :                            NetDesc{3, 57, 36, XC_ROWS, 3, 4, 4, 12}; // coarse rgbnet, voxurfc.py:134-149
 }
-__host__ __device__ constexpr bool kind_ok(int kind) { return kind >= 0 && kind <= ESR_MLP_EMIT; }
+__host__ __device__ constexpr bool kind_ok(int kind) { return kind >= 0 && kind <= ESR_MLP_COARSE; }
 
 // X-tile row -> column of the reference's first-layer weight (-1: no column)
 __host__ __device__ inline int in_colmap(int kind, int row)
 {
     if (kind == ESR_MLP_TONEMAP) return row < 33 ? row : -1;
+    if (kind == ESR_MLP_COARSE) {
+        // reference order (voxurfc.py:228-250): colour12 | xyz3 sin15 cos15 | vd3 sin3 cos3 | normal3
+        if (row < 12) return row;
+        if (row < 24) return -1;                 // the other net's colour group
+        if (row < 27) return 54 + (row - 24);    // normal
+        if (row < 30) return 12 + (row - 27);    // xyz
+        if (row < 45) return 15 + (row - 30);    // sin
+        if (row < 60) return 30 + (row - 45);    // cos
+        if (row < 69) return 45 + (row - 60);    // viewdir, sin, cos
+        return -1;
+    }
     if (kind == ESR_MLP_BRDF || kind == ESR_MLP_EMIT) {
         // reference order (esrnerf.py:761-765): colour6 | xyz3 sin15 cos15 | sdf | feat24 | normal12
         if (row < 6) return row;
@@ -374,7 +388,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
         float B1[KP1];
 #pragma unroll
         for (int p = 0; p < KP1; ++p)
-            B1[p] = bload1(RX, xvoff, 2 * p * 128 + ((2 * p < 6) ? coff : 0));
+            B1[p] = bload1(RX, xvoff, 2 * p * 128 + ((2 * p < D.cw) ? coff : 0));
         f32x16 cur[HT];
         load_bias<HT>(W, (int)L.off_bf[0] * 4, cur, lane);
         layer_from_regs<KP1, HT>(W, (int)L.off_wf[0] * 4, B1, cur, lane);
@@ -472,7 +486,8 @@ struct WgradArgs {
     float *gb;
     float *slab;                 // [gridDim.x * WK][out_rows][ld] partial sums
     int b_tile_rows;             // rows per B tile in memory (>= RB; the X tile has extra colour rows)
-    int crow;                    // first layer: B rows 0-5 are read from X rows crow..crow+5
+    int crow;                    // first layer: B rows 0..cw-1 are read from X rows crow..crow+cw-1
+    int cw8;                     // colour-group rows x 8 (float4 units per row)
 };
 
 // Cooperative weight-gradient kernel.  One workgroup covers the WHOLE dW of a layer:
@@ -532,7 +547,7 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradAr
         for (int k = 0; k < LB; ++k) {
             const int q = tid + k * NT;                                  // float4 index: row q/8
             // rows 0-5 of a first layer come from the net's colour group of the X tile
-            const int src = (q < 48) ? q + W.crow * 8 : q;
+            const int src = (q < W.cw8) ? q + W.crow * 8 : q;
             rb_[k] = bload4(SB, src * 16, 0);       // (tiles shorter than the staged block read as zero)
         }
     };
@@ -702,12 +717,17 @@ ESR_API int esr_mlp_pack(int kind, const esr_mlp_weights_t *w, float *packed, vo
     return 0;
 }
 
+static bool color_row_ok(int kind, int crow)
+{
+    return kind == ESR_MLP_COARSE ? (crow == 0 || crow == 12) : (crow == 0 || crow == 88 || crow == 96);
+}
+
 ESR_API int esr_mlp_fwd(int kind, const float *packed, const float *X, int32_t t0, int32_t t1,
                         float *const *H, uint32_t *const *M, int save, int color_row0, float *zout,
                         void *stream)
 {
     if (!kind_ok(kind) || t0 < 0 || t1 < t0) return ESR_EINVAL;
-    if (color_row0 != 0 && color_row0 != 88 && color_row0 != 96) return ESR_EINVAL;
+    if (!color_row_ok(kind, color_row0)) return ESR_EINVAL;
     if (t1 == t0) return 0;
     if (!packed || !X || !zout) return ESR_EINVAL;
     const int nhid = net_desc(kind).n_layers - 1;
@@ -728,7 +748,8 @@ ESR_API int esr_mlp_fwd(int kind, const float *packed, const float *X, int32_t t
     case ESR_MLP_RADIANCE: mlp_fwd_kernel<ESR_MLP_RADIANCE><<<grid, 256, 0, s>>>(A); break;
     case ESR_MLP_TONEMAP:  mlp_fwd_kernel<ESR_MLP_TONEMAP><<<grid, 256, 0, s>>>(A); break;
     case ESR_MLP_BRDF:     mlp_fwd_kernel<ESR_MLP_BRDF><<<grid, 256, 0, s>>>(A); break;
-    default:               mlp_fwd_kernel<ESR_MLP_EMIT><<<grid, 256, 0, s>>>(A); break;
+    case ESR_MLP_EMIT:     mlp_fwd_kernel<ESR_MLP_EMIT><<<grid, 256, 0, s>>>(A); break;
+    default:               mlp_fwd_kernel<ESR_MLP_COARSE><<<grid, 256, 0, s>>>(A); break;
     }
     ESR_CHECK_LAUNCH();
     return 0;
@@ -753,7 +774,8 @@ ESR_API int esr_mlp_dgrad(int kind, const float *packed, const float *dz, int32_
     case ESR_MLP_RADIANCE: mlp_dgrad_kernel<ESR_MLP_RADIANCE><<<grid, 256, 0, s>>>(A); break;
     case ESR_MLP_TONEMAP:  mlp_dgrad_kernel<ESR_MLP_TONEMAP><<<grid, 256, 0, s>>>(A); break;
     case ESR_MLP_BRDF:     mlp_dgrad_kernel<ESR_MLP_BRDF><<<grid, 256, 0, s>>>(A); break;
-    default:               mlp_dgrad_kernel<ESR_MLP_EMIT><<<grid, 256, 0, s>>>(A); break;
+    case ESR_MLP_EMIT:     mlp_dgrad_kernel<ESR_MLP_EMIT><<<grid, 256, 0, s>>>(A); break;
+    default:               mlp_dgrad_kernel<ESR_MLP_COARSE><<<grid, 256, 0, s>>>(A); break;
     }
     ESR_CHECK_LAUNCH();
     return 0;
@@ -767,7 +789,7 @@ ESR_API int esr_mlp_wgrad(int kind, const float *X, int color_row0, const float 
                           void *stream)
 {
     if (!kind_ok(kind) || t0 < 0 || t1 < t0) return ESR_EINVAL;
-    if (color_row0 != 0 && color_row0 != 88 && color_row0 != 96) return ESR_EINVAL;
+    if (!color_row_ok(kind, color_row0)) return ESR_EINVAL;
     if (t1 == t0) return 0;
     if (!X || !H || !dZ || !dz || !gw || !gb || !scratch) return ESR_EINVAL;
     const NetDesc D = net_desc(kind);
@@ -780,6 +802,7 @@ ESR_API int esr_mlp_wgrad(int kind, const float *X, int color_row0, const float 
         W.B = first ? X : H[l - 1];       W.RB = first ? (D.xrows < 96 ? D.xrows : 96) : hid;
         W.b_tile_rows = first ? D.xrows : hid;
         W.crow = first ? color_row0 : 0;
+        W.cw8 = D.cw * 8;
         W.t0 = t0; W.t1 = t1;
         W.gw = gw[l]; W.ld = first ? D.in_dim : hid; W.out_rows = last ? D.out_dim : hid;
         W.kind = kind; W.first = first ? 1 : 0; W.gb = gb[l]; W.slab = scratch;

@@ -231,6 +231,7 @@ int esr_fine_feat_bwd(const esr_scene_t *scene, const esr_feat_args_t *args, con
 #define ESR_MLP_TONEMAP  1   /* 33-192-3                                                  */
 #define ESR_MLP_BRDF     2   /* BRDFNet 76-128-128-128-5 (app/utils/pbr/module.py:42-65)  */
 #define ESR_MLP_EMIT     3   /* EmissionNet 76-128-128-128-3 (app/utils/pbr/module.py:68-83) */
+#define ESR_MLP_COARSE   4   /* coarse rgbnet 57-128-128-3 (app/coarse/model/voxurfc.py:134-149), 72-row input tile */
 #define ESR_MLP_MAX_LAYERS 4
 
 typedef struct esr_mlp_weights {       /* [host] struct of device pointers */
@@ -450,6 +451,26 @@ int esr_central_grad_fwd(const float *sdf, int32_t gx, int32_t gy, int32_t gz, f
                          float *grad, void *stream);
 int esr_central_grad_bwd(const float *ggrad, int32_t gx, int32_t gy, int32_t gz, float voxel_size,
                          float *gsdf, void *stream);
+
+/*
+ * Fused march of the coarse renderer (app/coarse/model/voxurfc.py:186-219): sampler -> in-box ->
+ * mask cache -> SDF tap of the SMOOTHED grid -> NeuS "interp" alpha -> alpha2weight over ALL
+ * mask-cache survivors -> weight > thres -> alpha2weight AGAIN over the survivors (weights,
+ * alphainv_last and cum_weights = sum of weights come from this second pass).  Same three-call
+ * protocol and record layout as esr_fine_march_*; plan.m2 == plan.m1 (there is no alpha mask).
+ */
+int esr_coarse_march_count(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                           const float *mask_density, const float *sdf_smooth, int32_t n_rays,
+                           int32_t *cnt3, float *alphainv_last, float *cum_weights, esr_plan_t *plan,
+                           void *stream);
+int esr_coarse_march_fill(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                          const float *mask_density, const float *sdf_smooth, int32_t n_rays,
+                          const int32_t *off3, int32_t *rec_ray, int32_t *rec_step, float *rec_w,
+                          float *rec_sdf, void *stream);
+int esr_coarse_march_bwd(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                         const float *mask_density, const float *sdf_smooth, int32_t n_rays,
+                         const int32_t *off3, const float *dweight, const float *dlast,
+                         float *grad_sdf_smooth, void *stream);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,15 @@ def compare(out, loss, grads, o_out, o_loss, o_grads, tol=TOL):
 def _in_colmap(kind, row):
     if kind == 1:
         return row if row < 33 else -1
+    if kind == 4:               # coarse rgbnet: colour12 | xyz PE 33 | view PE 9 | normal3 on a 72-row tile
+        if row < 12: return row
+        if row < 24: return -1
+        if row < 27: return 54 + row - 24
+        if row < 30: return 12 + row - 27
+        if row < 45: return 15 + row - 30
+        if row < 60: return 30 + row - 45
+        if row < 69: return 45 + row - 60
+        return -1
     if kind in (2, 3):          # BRDF / emission nets: colour6 | xyz PE 33 | sdf | feat24 | normal12
         if row < 6: return row
         if row == 6: return 39
@@ -106,11 +115,12 @@ def _in_colmap(kind, row):
 NET = {0: dict(in_dim=85, xrows=104, nl=4, hid=192, out=3, zrows=4),
        1: dict(in_dim=33, xrows=48, nl=2, hid=192, out=3, zrows=4),
        2: dict(in_dim=76, xrows=104, nl=4, hid=128, out=5, zrows=8),
-       3: dict(in_dim=76, xrows=104, nl=4, hid=128, out=3, zrows=4)}
+       3: dict(in_dim=76, xrows=104, nl=4, hid=128, out=3, zrows=4),
+       4: dict(in_dim=57, xrows=72, nl=3, hid=128, out=3, zrows=4, cw=12)}
 
 
 @pytest.mark.parametrize("kind,tiles,crow", [(0, 1, 0), (0, 37, 88), (1, 5, 0), (1, 64, 0), (2, 9, 96), (2, 300, 0),
-                                             (3, 33, 88), (0, 700, 96)])
+                                             (3, 33, 88), (0, 700, 96), (4, 3, 0), (4, 130, 12)])
 def test_mlp_engine_fwd_dgrad_wgrad_vs_torch(kind, tiles, crow):
     """Random tile-major inputs; reference = plain fp32 torch Linear/ReLU chain + autograd on CPU.
     Covers RadianceNet, TonemapNet, BRDFNet (5 outputs, 128 wide) and EmissionNet, and the three
@@ -128,7 +138,8 @@ def test_mlp_engine_fwd_dgrad_wgrad_vs_torch(kind, tiles, crow):
     X = torch.randn(tiles, xrows, 32, generator=g)
     rows = [r for r in range(min(xrows, 96)) if _in_colmap(kind, r) >= 0]
     cols = [_in_colmap(kind, r) for r in rows]
-    src_rows = [r + crow if r < 6 else r for r in rows]           # colour group actually read
+    cw = n.get("cw", 6)
+    src_rows = [r + crow if r < cw else r for r in rows]          # colour group actually read
     x_ref = torch.zeros(tiles * 32, in_dim)
     x_ref[:, cols] = X[:, src_rows, :].permute(0, 2, 1).reshape(tiles * 32, len(rows))
     x_ref.requires_grad_()
