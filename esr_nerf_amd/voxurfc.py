@@ -1,0 +1,334 @@
+"""Drop-in for the reference's coarse-stage renderer ``app.coarse.model.VoxurfC``
+(reference: app/coarse/model/voxurfc.py) -- training forward.
+
+Same constructor (no ``num_voxels`` argument: it comes from ``cfg.app.model``), ``train()`` /
+``forward(**kwargs)`` protocol, result keys {"etc/alphainv_cum", "etc/white_bg", "srgb/rgb"}, sub-module
+names (``sdf, off_color, off_rgbnet, emo_color, emo_rgbnet`` -- the coarse optimizer addresses them by name,
+cfg/app/coarse.yaml:51-56) and ``state_dict`` keys (``off_rgbnet.{0,2.0,3}.*``, the frozen
+``smooth_conv.m.*`` / ``tv_smooth_conv.m.*``).  ``forward_training`` is one autograd node over
+libesr_hip.so: dense Gaussian smoothing + dense central differences of the SDF grid, the two-pass coarse
+march, 57-128-128-3 MLPs on f32 MFMA, sigmoid-sum shading and compositing, and the whole backward.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib, render_utils
+from .fine_engine import DX_ROWS, FineEngine, make_scene
+from .modules import DenseGrid, Gaussian3DConv, GradientConv, MaskCache, _linears, _mlp_stack
+
+KIND_COARSE = 4
+XC_ROWS, HID = 72, 128
+
+
+class CoarseEngine(FineEngine):
+    """Kernel driver of one coarse training step (grow-only tile-major workspace, one host sync)."""
+
+    def __init__(self, device):
+        super().__init__(device)
+        for k in ("off", "emo"):
+            self.packed[k] = torch.empty(self.L.esr_mlp_packed_floats(KIND_COARSE), dtype=torch.float32,
+                                         device=self.device)
+        self.cap = 0
+        self.b: Dict[str, torch.Tensor] = {}
+
+    ROWS = dict(X=XC_ROWS, gnorm=1, rec_w=1, rec_sdf=1, rgb=4, dweight=1,
+                **{f"{n}.{k}": r for n in ("off", "emo") for k, r in
+                   (("H0", HID), ("H1", HID), ("z", 4), ("dz", 4), ("dZ0", HID), ("dZ1", HID), ("dX", DX_ROWS))})
+
+    def _ensure(self, tiles):
+        if tiles <= self.cap:
+            return
+        cap = max(tiles, int(self.cap * 1.25) + 16)
+        dev = self.device
+        self.b = {k: torch.empty(cap * r * 32, dtype=torch.float32, device=dev) for k, r in self.ROWS.items()}
+        for n in ("off", "emo"):
+            for l in (0, 1):
+                self.b[f"{n}.M{l}"] = torch.empty(cap * 4 * 32, dtype=torch.int32, device=dev)
+        self.b["rec_ray"] = torch.empty(cap * 32, dtype=torch.int32, device=dev)
+        self.b["rec_step"] = torch.empty(cap * 32, dtype=torch.int32, device=dev)
+        self.cap = cap
+
+    def forward(self, scene, batch, sdf, kernel_w, ksize, voxel_size, mask_density, off_color, emo_color):
+        """sdf [X,Y,Z]; off/emo_color [X,Y,Z,12]; kernel_w: ctypes float array (k^3, host).
+        -> (ctx, alphainv_last [N], white_bg [N,1], srgb [N,3])"""
+        L, s, dev, b = self.L, self._s(), self.device, self.b
+        rays_o, rays_d, viewdirs, em_modes = batch["rays_o"], batch["rays_d"], batch["viewdirs"], batch["em_modes"]
+        n = rays_o.shape[0]
+        dims = [int(v) for v in sdf.shape]
+        sm = torch.empty_like(sdf)
+        gg = torch.empty(*dims, 3, dtype=torch.float32, device=dev)
+        self._run("gauss3d_fwd", L.esr_gauss3d_fwd, _lib.ptr(sdf), kernel_w, ksize, *dims, _lib.ptr(sm), s)
+        self._run("central_grad_fwd", L.esr_central_grad_fwd, _lib.ptr(sdf), *dims, C.c_float(voxel_size),
+                  _lib.ptr(gg), s)
+        cnt3 = torch.empty(n, dtype=torch.int32, device=dev)
+        off3 = torch.empty(n, dtype=torch.int32, device=dev)
+        last = torch.empty(n, dtype=torch.float32, device=dev)
+        cumw = torch.empty(n, dtype=torch.float32, device=dev)
+        srgb = torch.zeros(n, 3, dtype=torch.float32, device=dev)
+        sp = C.byref(scene)
+        self._run("plan_begin", L.esr_fine_plan_begin, _lib.ptr(self.plan_dev), s)
+        self._run("march_count", L.esr_coarse_march_count, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
+                  _lib.ptr(mask_density), _lib.ptr(sm), n, _lib.ptr(cnt3), _lib.ptr(last), _lib.ptr(cumw),
+                  _lib.ptr(self.plan_dev), s)
+        self._run("plan", L.esr_fine_plan, _lib.ptr(cnt3), _lib.ptr(em_modes), n, _lib.ptr(off3),
+                  _lib.ptr(self.plan_dev), s)
+        self.plan_host.copy_(self.plan_dev, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        n_on, n_off, tiles_on, tiles_all, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
+        if overflow:
+            raise RuntimeError("a ray exceeded scene.max_steps; the LDS bound of the march kernel is wrong")
+        ctx = dict(scene=scene, batch=batch, n=n, T=tiles_all, Ton=tiles_on, sm=sm, gg=gg, off3=off3, dims=dims,
+                   mask_density=mask_density, kernel_w=kernel_w, ksize=ksize, voxel=voxel_size,
+                   counts=dict(m0=m0, m1=m1, m2=m2, m3=n_on + n_off, n_on=n_on, n_off=n_off))
+        white_bg = (1.0 - cumw).unsqueeze(-1)
+        if tiles_all == 0:
+            return ctx, last, white_bg, srgb
+        self._ensure(tiles_all)
+        b = self.b
+        T, Ton = tiles_all, tiles_on
+        b["rec_ray"][: T * 32].fill_(-1)
+        self._run("march_fill", L.esr_coarse_march_fill, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
+                  _lib.ptr(mask_density), _lib.ptr(sm), n, _lib.ptr(off3), _lib.ptr(b["rec_ray"]),
+                  _lib.ptr(b["rec_step"]), _lib.ptr(b["rec_w"]), _lib.ptr(b["rec_sdf"]), s)
+        self._run("feat_fwd", L.esr_coarse_feat_fwd, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(viewdirs),
+                  _lib.ptr(b["rec_ray"]), _lib.ptr(b["rec_step"]), Ton, T, _lib.ptr(gg), _lib.ptr(off_color),
+                  _lib.ptr(emo_color), _lib.ptr(b["X"]), _lib.ptr(b["gnorm"]), s)
+        for net, crow, t1 in (("off", 0, T), ("emo", 12, Ton)):
+            if t1:
+                self._run(f"mlp_fwd({net})", L.esr_mlp_fwd, KIND_COARSE, _lib.ptr(self.packed[net]), _lib.ptr(b["X"]),
+                          0, t1, _lib.ptr_array([b[f"{net}.H0"], b[f"{net}.H1"]]),
+                          _lib.ptr_array([b[f"{net}.M0"], b[f"{net}.M1"]]), 1, crow, _lib.ptr(b[f"{net}.z"]), s)
+        self._run("shade_fwd", L.esr_coarse_shade_fwd, _lib.ptr(b["off.z"]), _lib.ptr(b["emo.z"]),
+                  _lib.ptr(b["rec_ray"]), _lib.ptr(b["rec_w"]), Ton, T, _lib.ptr(b["rgb"]), _lib.ptr(srgb), s)
+        return ctx, last, white_bg, srgb
+
+    def backward(self, ctx, g_last, g_wbg, g_srgb, grads):
+        """grads (zero-initialised): sdf [X,Y,Z], off_color / emo_color [X,Y,Z,12], off_w/off_b/emo_w/emo_b (3 each)."""
+        L, s, dev, b = self.L, self._s(), self.device, self.b
+        T, Ton, n, dims = ctx["T"], ctx["Ton"], ctx["n"], ctx["dims"]
+        sp = C.byref(ctx["scene"])
+        bt = ctx["batch"]
+        z = lambda *sh: torch.zeros(*sh, dtype=torch.float32, device=dev)
+        g_last = g_last.contiguous() if g_last is not None else z(n)
+        g_wbg = g_wbg.reshape(-1).contiguous() if g_wbg is not None else z(n)
+        g_srgb = g_srgb.contiguous() if g_srgb is not None else z(n, 3)
+        g_sm, g_gg = z(*dims), z(*dims, 3)
+        if T:
+            self._run("shade_bwd", L.esr_coarse_shade_bwd, _lib.ptr(g_srgb), _lib.ptr(g_wbg), _lib.ptr(b["rgb"]),
+                      _lib.ptr(b["off.z"]), _lib.ptr(b["emo.z"]), _lib.ptr(b["rec_ray"]), _lib.ptr(b["rec_w"]), Ton, T,
+                      _lib.ptr(b["off.dz"]), _lib.ptr(b["emo.dz"]), _lib.ptr(b["dweight"]), s)
+            for net, crow, t1 in (("off", 0, T), ("emo", 12, Ton)):
+                if not t1:
+                    continue
+                H = _lib.ptr_array([b[f"{net}.H0"], b[f"{net}.H1"]])
+                M = _lib.ptr_array([b[f"{net}.M0"], b[f"{net}.M1"]])
+                dZ = _lib.ptr_array([b[f"{net}.dZ0"], b[f"{net}.dZ1"]])
+                self._run(f"mlp_dgrad({net})", L.esr_mlp_dgrad, KIND_COARSE, _lib.ptr(self.packed[net]),
+                          _lib.ptr(b[f"{net}.dz"]), 0, t1, M, dZ, _lib.ptr(b[f"{net}.dX"]), s)
+                self._run(f"mlp_wgrad({net})", L.esr_mlp_wgrad, KIND_COARSE, _lib.ptr(b["X"]), crow, H, dZ,
+                          _lib.ptr(b[f"{net}.dz"]), 0, t1, _lib.ptr_array(grads[f"{net}_w"]),
+                          _lib.ptr_array(grads[f"{net}_b"]), _lib.ptr(self.wgrad_scratch),
+                          C.c_int64(self.wgrad_scratch.numel()), s)
+            self._run("feat_bwd", L.esr_coarse_feat_bwd, sp, _lib.ptr(bt["rays_o"]), _lib.ptr(bt["rays_d"]),
+                      _lib.ptr(bt["viewdirs"]), _lib.ptr(b["rec_ray"]), _lib.ptr(b["rec_step"]), Ton, T, _lib.ptr(b["X"]),
+                      _lib.ptr(b["gnorm"]), _lib.ptr(b["off.dX"]), _lib.ptr(b["emo.dX"]), _lib.ptr(g_gg),
+                      _lib.ptr(grads["off_color"]), _lib.ptr(grads["emo_color"]), s)
+            dweight = b["dweight"]
+        else:
+            dweight = z(32)
+        # alphainv_last and the weights depend on the SMOOTHED grid; white_bg's dependence rides in dweight
+        self._run("march_bwd", L.esr_coarse_march_bwd, sp, _lib.ptr(bt["rays_o"]), _lib.ptr(bt["rays_d"]),
+                  _lib.ptr(ctx["mask_density"]), _lib.ptr(ctx["sm"]), n, _lib.ptr(ctx["off3"]), _lib.ptr(dweight),
+                  _lib.ptr(g_last), _lib.ptr(g_sm), s)
+        self._run("gauss3d_bwd", L.esr_gauss3d_bwd, _lib.ptr(g_sm), ctx["kernel_w"], ctx["ksize"], *dims,
+                  _lib.ptr(grads["sdf"]), s)
+        self._run("central_grad_bwd", L.esr_central_grad_bwd, _lib.ptr(g_gg), *dims, C.c_float(ctx["voxel"]),
+                  _lib.ptr(grads["sdf"]), s)
+
+
+class _CoarseRender(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, batch, sdf, off_color, emo_color, *mlp_params):
+        eng: CoarseEngine = model.engine
+        eng.pack("off", KIND_COARSE, list(mlp_params[0:6:2]), list(mlp_params[1:6:2]))
+        eng.pack("emo", KIND_COARSE, list(mlp_params[6:12:2]), list(mlp_params[7:12:2]))
+        fctx, last, wbg, srgb = eng.forward(
+            model.scene_struct(), batch, model.sdf.device_view(), model._kernel_w, model.smooth_ksize,
+            model._voxel_size_f, model.mask_cache.density.view(*model.mask_cache.density.shape[2:]),
+            model.off_color.device_view(), model.emo_color.device_view())
+        ctx.fctx, ctx.model = fctx, model
+        ctx.shapes = [tuple(p.shape) for p in mlp_params]
+        ctx.set_materialize_grads(False)
+        model.last_counts = fctx["counts"]
+        return last, wbg, srgb
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_last, g_wbg, g_srgb):
+        model = ctx.model
+        dev = model.sdf.grid.device
+        X, Y, Z = [int(v) for v in model.world_size]
+        z = lambda shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+        g_sdf, g_off, g_emo = z((1, 1, X, Y, Z)), z((1, X, Y, Z, 12)), z((1, X, Y, Z, 12))
+        mg = [z(s) for s in ctx.shapes]
+        grads = dict(sdf=g_sdf, off_color=g_off, emo_color=g_emo, off_w=mg[0:6:2], off_b=mg[1:6:2],
+                     emo_w=mg[6:12:2], emo_b=mg[7:12:2])
+        model.engine.backward(ctx.fctx, g_last, g_wbg, g_srgb, grads)
+        return (None, None, g_sdf, g_off.permute(0, 4, 1, 2, 3), g_emo.permute(0, 4, 1, 2, 3), *mg)
+
+
+class VoxurfC(nn.Module):
+    def __init__(self, cfg, near: float, far: float, xyz_min: torch.Tensor, xyz_max: torch.Tensor,
+                 mask_xyz_min: torch.Tensor, mask_xyz_max: torch.Tensor, mask_alpha_init: float,
+                 mask_density: torch.Tensor, s_val: float):
+        super().__init__()
+        self.cfg = cfg
+        self.device = cfg.system.device
+        m = cfg.app.model
+        self.near, self.far = near, far
+        self.xyz_min, self.xyz_max = xyz_min.to(self.device), xyz_max.to(self.device)
+        self.mask_xyz_min, self.mask_xyz_max = mask_xyz_min.to(self.device), mask_xyz_max.to(self.device)
+        self.mask_alpha_init = mask_alpha_init
+        self.mask_density = mask_density.to(self.device)
+        self.s_val = s_val
+        self.mask_ks, self.maskcache_thres, self.fastcolor_thres = m.mask_ks, m.maskcache_thres, m.fastcolor_thres
+        self.stepsize, self.num_voxels = m.stepsize, m.num_voxels
+        self.color_dim, self.rgbnet_width, self.rgbnet_depth = m.color_dim, m.rgbnet_width, m.rgbnet_depth
+        self.posbase_pe, self.viewbase_pe = m.posbase_pe, m.viewbase_pe
+        self.smooth_ksize, self.smooth_sigma = m.smooth_ksize, m.smooth_sigma
+        self.neus_alpha = m.neus_alpha
+        want = dict(color_dim=12, rgbnet_width=128, rgbnet_depth=3, posbase_pe=5, viewbase_pe=1)
+        for k, v in want.items():
+            if getattr(self, k) != v:
+                raise NotImplementedError(f"libesr_hip kernels are built for {k}={v}, got {getattr(self, k)}")
+        if self.neus_alpha != "interp":
+            raise NotImplementedError("only neus_alpha='interp' (cfg/app/coarse.yaml:30) is on the HIP path")
+        if self.smooth_ksize > 7 or self.smooth_ksize % 2 == 0:
+            raise NotImplementedError("esr_gauss3d_* support odd kernel sizes up to 7")
+
+        # construction order = the reference's (voxurfc.py:78-178): it fixes the RNG draws of the default inits
+        self.set_grid_resolution(self.num_voxels)
+        grid_args = dict(world_size=self.world_size, xyz_min=self.xyz_min, xyz_max=self.xyz_max)
+        self.sdf = DenseGrid(channels=1, **grid_args)
+        ax = [np.linspace(-1.0, 1.0, int(n)) for n in self.world_size]
+        gx, gy, gz = np.meshgrid(*ax, indexing="ij")
+        self.sdf.grid.data = torch.from_numpy((gx ** 2 + gy ** 2 + gz ** 2) ** 0.5 - 1).float()[None, None]
+        self.smooth_conv = Gaussian3DConv(self.smooth_ksize, self.smooth_sigma)
+        self.tv_smooth_conv = GradientConv()
+        self.mask_cache = MaskCache(self.mask_xyz_min, self.mask_xyz_max, self.mask_density, self.mask_alpha_init,
+                                    self.maskcache_thres, self.mask_ks)
+        self.off_color = DenseGrid(channels=self.color_dim, **grid_args)
+        dim0 = (3 + 3 * self.posbase_pe * 2) + (3 * self.viewbase_pe * 3) + self.color_dim + 3
+        self.off_rgbnet = _mlp_stack(dim0, self.rgbnet_width, self.rgbnet_depth, 3)
+        nn.init.constant_(self.off_rgbnet[-1].bias, 0)
+        self.emo_color = DenseGrid(channels=self.color_dim, **grid_args)
+        self.emo_rgbnet = _mlp_stack(dim0, self.rgbnet_width, self.rgbnet_depth, 3)
+        nn.init.constant_(self.emo_rgbnet[-1].bias, 0)
+        self.to(self.device)
+        self.set_nonempty_mask()
+        self._kernel_w = (C.c_float * self.smooth_ksize ** 3)(*self.smooth_conv.m.weight.detach().flatten().tolist())
+        self._engine = None
+        self.last_counts: Dict[str, int] = {}
+        self.gradient = None
+
+    @property
+    def engine(self) -> CoarseEngine:
+        if self._engine is None:
+            if not str(self.device).startswith("cuda"):
+                raise RuntimeError("VoxurfC.forward_training runs on libesr_hip.so and needs a GPU device "
+                                   "(there is no CPU fallback)")
+            self._engine = CoarseEngine(self.device)
+        return self._engine
+
+    def scene_struct(self):
+        return make_scene(self._xyz_cache[0], self._xyz_cache[1], self.mask_xyz_min.tolist(), self.mask_xyz_max.tolist(),
+                          self._world_size_l, list(self.mask_cache.density.shape[2:]), self.near, self._stepdist,
+                          self._voxel_size_f, self.mask_cache.act_shift, self.maskcache_thres, self.fastcolor_thres,
+                          self.s_val, [0.5, 1.0, 1.5, 2.0])
+
+    def train(self, mode=True):
+        self.forward = self.forward_training if mode else self.forward_evaluate
+        return super().train(mode)
+
+    def _mlp_params(self) -> List[torch.Tensor]:
+        return [t for net in (self.off_rgbnet, self.emo_rgbnet) for lin in _linears(net) for t in (lin.weight, lin.bias)]
+
+    def forward_training(self, **kwargs):
+        self.s_val = kwargs["s_val"]
+        batch = dict(rays_o=kwargs["rays_o"].contiguous(), rays_d=kwargs["rays_d"].contiguous(),
+                     viewdirs=kwargs["viewdirs"].contiguous(), em_modes=kwargs["em_modes"].contiguous())
+        last, wbg, srgb = _CoarseRender.apply(self, batch, self.sdf.grid, self.off_color.grid, self.emo_color.grid,
+                                              *self._mlp_params())
+        return {"etc/alphainv_cum": last, "etc/white_bg": wbg, "srgb/rgb": srgb}
+
+    def forward_evaluate(self, **kwargs):
+        raise NotImplementedError("image rendering (forward_evaluate) is a 'next' row of SURVEY.md section 8(f)")
+
+    # ------------------------------------------------------------------ geometry / regularisers
+    def set_grid_resolution(self, num_voxels: int):
+        """voxurfc.py:483-489, evaluated on the host in fp32 (same bits as the CPU oracle, see VoxurfF)."""
+        self.num_voxels = num_voxels
+        lo, hi = self.xyz_min.detach().cpu(), self.xyz_max.detach().cpu()
+        voxel_size = ((hi - lo).prod() / num_voxels).pow(1 / 3)
+        world_size = ((hi - lo) / voxel_size).long()
+        self.voxel_size, self.world_size = voxel_size.to(self.xyz_min.device), world_size.to(self.xyz_min.device)
+        self._voxel_size_f = float(voxel_size)
+        self._stepdist = float(self.stepsize * voxel_size)
+        self._xyz_cache = (lo.tolist(), hi.tolist())
+        self._world_size_l = [int(v) for v in world_size]
+        print("voxel_size       {}".format(self.voxel_size))
+        print("world_size       {}".format(self.world_size))
+
+    @torch.no_grad()
+    def set_nonempty_mask(self):
+        lin = [torch.linspace(float(self.xyz_min[i]), float(self.xyz_max[i]), self.sdf.grid.shape[2 + i],
+                              device=self.xyz_min.device) for i in range(3)]
+        pts = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)
+        self.nonempty_mask = self.mask_cache(pts)[None, None].contiguous()
+        self.sdf.grid[~self.nonempty_mask] = 1
+
+    def neus_sdf_gradient(self):
+        """Dense central differences in the reference's [1,3,X,Y,Z] layout (only the TV term reads it here)."""
+        g = self.sdf.grid
+        out = torch.zeros([1, 3, *g.shape[-3:]], device=g.device)
+        out[:, 0, 1:-1] = (g[:, 0, 2:] - g[:, 0, :-2]) / 2 / self.voxel_size
+        out[:, 1, :, 1:-1] = (g[:, 0, :, 2:] - g[:, 0, :, :-2]) / 2 / self.voxel_size
+        out[:, 2, :, :, 1:-1] = (g[:, 0, :, :, 2:] - g[:, 0, :, :, :-2]) / 2 / self.voxel_size
+        return out
+
+    @staticmethod
+    def _tv(v, mask):
+        parts = []
+        for d in (2, 3, 4):
+            lo, hi = [slice(None)] * 5, [slice(None)] * 5
+            lo[d], hi[d] = slice(None, -1), slice(1, None)
+            parts.append(v.diff(dim=d).abs()[mask[tuple(lo)] & mask[tuple(hi)]].mean())
+        return sum(parts) / 3
+
+    def density_total_variation(self, sdf_tv: float = 0, smooth_grad_tv: float = 0):
+        tv = 0
+        if sdf_tv > 0:
+            tv = tv + self._tv(self.sdf.grid, self.nonempty_mask) / 2 / self.voxel_size * sdf_tv
+        if smooth_grad_tv > 0:
+            self.gradient = self.neus_sdf_gradient()
+            gr = self.gradient.permute(1, 0, 2, 3, 4)
+            err = self.tv_smooth_conv(gr).detach() - gr
+            tv = tv + (err[self.nonempty_mask.repeat(3, 1, 1, 1, 1)] ** 2).mean() * smooth_grad_tv
+        return tv
+
+    def color_total_variation(self):
+        m = self.nonempty_mask.repeat(1, self.color_dim, 1, 1, 1)
+        return self._tv(self.off_color.grid, m) + self._tv(self.emo_color.grid, m)
+
+    def sample_ray(self, rays_o: torch.Tensor, rays_d: torch.Tensor):
+        stepdist = self.stepsize * self.voxel_size
+        pts, out_box, ray_id, step_id = render_utils.sample_pts_on_rays(
+            rays_o.contiguous(), rays_d.contiguous(), self.xyz_min, self.xyz_max, self.near, 1e9, stepdist)[:4]
+        keep = ~out_box
+        return pts[keep], ray_id[keep], step_id[keep]

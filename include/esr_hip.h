@@ -472,6 +472,38 @@ int esr_coarse_march_bwd(const esr_scene_t *scene, const float *rays_o, const fl
                          const int32_t *off3, const float *dweight, const float *dlast,
                          float *grad_sdf_smooth, void *stream);
 
+/*
+ * Per-sample features of the coarse renderer (app/coarse/model/voxurfc.py:221-250) on the march
+ * records.  grad_grid [gx,gy,gz,3] (esr_central_grad_fwd), off_color / emo_color [gx,gy,gz,12]
+ * channels-last.  X [tiles,72,32] rows: 0-11 off colour | 12-23 emo colour (on-tiles) | 24-26 normal
+ * = g/(|g|+1e-5) | 27-29 xyz | 30-44 sin | 45-59 cos | 60-68 view PE | 69-71 zero; gnorm [tiles*32] = |g|.
+ * _bwd: dX_off (all tiles) / dX_emo (on-tiles) [tiles,64,32] from esr_mlp_dgrad(ESR_MLP_COARSE) ->
+ * atomic scatters into the colour-grid gradients and into g_grad_grid [gx,gy,gz,3].
+ */
+int esr_coarse_feat_fwd(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                        const float *viewdirs, const int32_t *rec_ray, const int32_t *rec_step,
+                        int32_t tiles_on, int32_t tiles_all, const float *grad_grid,
+                        const float *off_color, const float *emo_color, float *X, float *gnorm,
+                        void *stream);
+int esr_coarse_feat_bwd(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                        const float *viewdirs, const int32_t *rec_ray, const int32_t *rec_step,
+                        int32_t tiles_on, int32_t tiles_all, const float *X, const float *gnorm,
+                        const float *dX_off, const float *dX_emo, float *g_grad_grid,
+                        float *g_off_color, float *g_emo_color, void *stream);
+
+/*
+ * rgb = sigmoid(z_off) + [on-tiles] sigmoid(z_emo) and its weighted segment sum per ray
+ * (voxurfc.py:240-258; srgb_marched [n_rays,3] accumulated into, caller zero-fills); backward
+ * with white_bg = 1 - sum of weights folded in: dweight = g_srgb[ray].rgb - g_white_bg[ray].
+ */
+int esr_coarse_shade_fwd(const float *z_off, const float *z_emo, const int32_t *rec_ray,
+                         const float *rec_w, int32_t tiles_on, int32_t tiles_all, float *rgb,
+                         float *srgb_marched, void *stream);
+int esr_coarse_shade_bwd(const float *g_srgb, const float *g_white_bg, const float *rgb,
+                         const float *z_off, const float *z_emo, const int32_t *rec_ray,
+                         const float *rec_w, int32_t tiles_on, int32_t tiles_all, float *dz_off,
+                         float *dz_emo, float *dweight, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
