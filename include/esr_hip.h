@@ -504,6 +504,20 @@ int esr_coarse_shade_bwd(const float *g_srgb, const float *g_white_bg, const flo
                          const float *rec_w, int32_t tiles_on, int32_t tiles_all, float *dz_off,
                          float *dz_emo, float *dweight, void *stream);
 
+/* ------------------------------------------------------------------------- *
+ * E. Optimizer
+ * ------------------------------------------------------------------------- */
+
+/*
+ * One fused Adam update of a parameter tensor, in place -- replaces `adam`
+ * (app/utils/optimizer.py:183-228; betas (0.9, 0.99) at :60, optional per-voxel lr :98-100).
+ * step >= 1 is the value AFTER the increment (bias corrections 1 - beta^step).  All pointers:
+ * n contiguous fp32 device values; per_lr NULL or [n].
+ */
+int esr_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                  const float *per_lr, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int32_t step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

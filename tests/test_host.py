@@ -181,3 +181,25 @@ def test_data_parallel_sharding_is_exact_gloo_world2():
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("DPRESULT")][0].split()
     assert float(line[1]) < 1e-5 and float(line[2]) < 1e-6, line
+
+
+def test_optimizer_groups_freeze_and_no_cpu_fallback():
+    """create_optimizer_or_freeze_model (app/utils/optimizer.py:11-60): one group per named attribute with
+    lr > 0, lr == 0 freezes; the fused step refuses CPU parameters instead of falling back."""
+    import torch.nn as nn
+    from esr_nerf_amd.optimizer import create_optimizer_or_freeze_model
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Linear(3, 2)
+            self.b = nn.Parameter(torch.zeros(4))
+            self.c = nn.Linear(2, 2)
+    m = M()
+    opt = create_optimizer_or_freeze_model(m, a=0.1, b=0.01, c=0.0, missing=1.0)
+    assert set(opt.name2pg) == {"a", "b"} and opt.name2pg["a"]["lr"] == 0.1
+    assert opt.defaults["betas"] == (0.9, 0.99)
+    assert not any(p.requires_grad for p in m.c.parameters()) and m.b.requires_grad
+    m.b.grad = torch.ones(4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        opt.step()
