@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libesr_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 _lib = None
 
 
@@ -77,7 +77,7 @@ EXPORTS = [
     "esr_gauss3d_fwd", "esr_gauss3d_bwd", "esr_central_grad_fwd", "esr_central_grad_bwd",
     "esr_coarse_march_count", "esr_coarse_march_fill", "esr_coarse_march_bwd",
     "esr_coarse_feat_fwd", "esr_coarse_feat_bwd", "esr_coarse_shade_fwd", "esr_coarse_shade_bwd",
-    "esr_adam_step",
+    "esr_adam_step", "esr_eval_aux", "esr_eval_disp",
 ]
 
 

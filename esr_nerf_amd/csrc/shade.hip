@@ -242,6 +242,50 @@ __global__ void __launch_bounds__(256) pair_loss_kernel(const float *__restrict_
     if (esr_lane() == 0 && acc != 0.f) atomicAdd(loss, acc);
 }
 
+// ---- image rendering (forward_evaluate) helpers --------------------------------------------------
+// aux [tiles,8,32]: rows 0-2 camera-space normal colour ((normalize(g) @ pos_rt) * (1,-1,-1) + 1) / 2 with g the
+// radius-1 finite difference (voxurff.py:431-435; its normalised components are X rows 31 + axis*4 + 1 in
+// the reference's (z,y,x) order), row 4: step_id * stepdist (depth integrand, voxurff.py:437-441), rest 0.
+struct EvalAux {
+    const float *X;
+    const int32_t *rec_ray, *rec_step;
+    int tiles, xrows;
+    float rt[9], stepdist;
+    float *aux;
+};
+__global__ void __launch_bounds__(256) eval_aux_kernel(EvalAux A)
+{
+    const int total = A.tiles * 32;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+        const int t = j >> 5, s = j & 31;
+        float *o = A.aux + (size_t)t * 8 * 32 + s;
+        const bool ok = A.rec_ray[j] >= 0;
+        const float *X = A.X + (size_t)t * A.xrows * 32 + s;
+        float n[3] = {0.f, 0.f, 0.f};
+        if (ok) { n[0] = X[(31 + 2 * 4 + 1) * 32]; n[1] = X[(31 + 1 * 4 + 1) * 32]; n[2] = X[(31 + 0 * 4 + 1) * 32]; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = n[0] * A.rt[0 * 3 + c] + n[1] * A.rt[1 * 3 + c] + n[2] * A.rt[2 * 3 + c];
+            v = (v * (c == 0 ? 1.f : -1.f) + 1.f) / 2.f;
+            o[c * 32] = ok ? v : 0.f;
+        }
+        o[3 * 32] = 0.f;
+        o[4 * 32] = ok ? (float)A.rec_step[j] * A.stepdist : 0.f;
+        o[5 * 32] = 0.f; o[6 * 32] = 0.f; o[7 * 32] = 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256) eval_disp_kernel(const float *__restrict__ depth3, const float *__restrict__ last,
+                                                        float far_, int n, float *__restrict__ depth,
+                                                        float *__restrict__ disp)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float d = depth3[3 * i];
+        depth[i] = d;
+        disp[i] = 1.f / (d + last[i] * far_);
+    }
+}
+
 // ---- LTS-stage helpers ------------------------------------------------------------------------
 // out = act(z) on the first n_ch rows of [tiles, rows, 32] tiles (act 0: softplus, 1: sigmoid);
 // backward: dz = g * act'(z)
@@ -437,6 +481,33 @@ ESR_API int esr_fine_loss_fwd_bwd(const float *srgb_marched, const float *lin_ma
     loss_kernel<<<esr_grid_for(n_rays, 256), 256, 0, esr_stream(stream)>>>(
         srgb_marched, lin_marched, alphainv_last, rgbs, n_rays, white_bg, weight_linear,
         weight_entropy_last, loss, g_srgb, g_lin, g_last);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_eval_aux(const float *X, int32_t xrows, const int32_t *rec_ray, const int32_t *rec_step,
+                         int32_t tiles, const float *pos_rt_host, float stepdist, float *aux, void *stream)
+{
+    if (tiles < 0 || xrows < 43) return ESR_EINVAL;
+    if (tiles == 0) return 0;
+    if (!X || !rec_ray || !rec_step || !pos_rt_host || !aux) return ESR_EINVAL;
+    EvalAux A = {};
+    A.X = X; A.rec_ray = rec_ray; A.rec_step = rec_step; A.tiles = tiles; A.xrows = xrows; A.stepdist = stepdist;
+    A.aux = aux;
+    for (int i = 0; i < 9; ++i) A.rt[i] = pos_rt_host[i];
+    eval_aux_kernel<<<esr_grid_for((int64_t)tiles * 32, 256), 256, 0, esr_stream(stream)>>>(A);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_eval_disp(const float *depth3, const float *alphainv_last, float far_, int32_t n_rays,
+                          float *depth, float *disp, void *stream)
+{
+    if (n_rays < 0) return ESR_EINVAL;
+    if (n_rays == 0) return 0;
+    if (!depth3 || !alphainv_last || !depth || !disp) return ESR_EINVAL;
+    eval_disp_kernel<<<esr_grid_for(n_rays, 256), 256, 0, esr_stream(stream)>>>(depth3, alphainv_last, far_, n_rays,
+                                                                                depth, disp);
     ESR_CHECK_LAUNCH();
     return 0;
 }

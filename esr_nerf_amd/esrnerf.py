@@ -261,6 +261,11 @@ class ESRNeRF(VoxurfF):
         emo, emo_hat = _FinetuneRender.apply(self, batch, draws, self.emo_color.grid, *ps)
         return {"lin/pbr/emo": emo, "lin/pbr/emo_hat": emo_hat}
 
+    def forward_evaluate(self, **kwargs):
+        raise NotImplementedError("ESRNeRF.forward_evaluate (esrnerf.py:853-1297, per-sample light transport and 30 "
+                                  "result keys) is a 'next' row of SURVEY.md section 8(f); the fine-stage image "
+                                  "renderer is VoxurfF.forward_evaluate")
+
     @torch.no_grad()
     def scale_volume_grid(self, num_voxels):
         super().scale_volume_grid(num_voxels)

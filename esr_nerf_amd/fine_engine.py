@@ -235,6 +235,70 @@ class FineEngine:
                                             _lib.ptr(srgb), _lib.ptr(lin), s)
         return ctx, last, srgb, lin
 
+    # -- image rendering ---------------------------------------------------------
+    @torch.no_grad()
+    def evaluate(self, scene, rays_o, rays_d, viewdirs, mask_density, sdf, off_color, emo_color, pos_rt, far,
+                 em_mode: int):
+        """``VoxurfF.forward_evaluate`` (voxurff.py:280-461), forward only: the off / emo / on radiance variants
+        tone-mapped separately, depth, disparity and camera-space normals.  Returns the reference's 12 keys."""
+        L, s, ws, dev = self.L, self._s(), self.ws, self.device
+        n = rays_o.shape[0]
+        rb = self._ray_buf(n)
+        last = torch.empty(n, dtype=torch.float32, device=dev)
+        sp = C.byref(scene)
+        em0 = torch.zeros(n, dtype=torch.int64, device=dev)            # tile partition only: every tile "off"
+        self._run("plan_begin", L.esr_fine_plan_begin, _lib.ptr(self.plan_dev), s)
+        self._run("march_count", L.esr_fine_march_count, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(mask_density),
+                  _lib.ptr(sdf), n, _lib.ptr(rb["cnt3"]), _lib.ptr(last), _lib.ptr(self.plan_dev), s)
+        self._run("plan", L.esr_fine_plan, _lib.ptr(rb["cnt3"]), _lib.ptr(em0), n, _lib.ptr(rb["off3"]),
+                  _lib.ptr(self.plan_dev), s)
+        self.plan_host.copy_(self.plan_dev, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        _, _, _, T, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
+        if overflow:
+            raise RuntimeError("a ray exceeded scene.max_steps; the LDS bound of the march kernel is wrong")
+        z3 = lambda: torch.zeros(n, 3, dtype=torch.float32, device=dev)
+        out = {f"{sp_}/{v}_rgb": z3() for v in ("off", "on", "emo") for sp_ in ("srgb", "lin")}
+        normal_m, depth3 = z3(), z3()
+        depth = torch.zeros(n, dtype=torch.float32, device=dev)
+        disp = torch.empty(n, dtype=torch.float32, device=dev)
+        if T:
+            ws.ensure(T)
+            ws["rec_ray"][: T * 32].fill_(-1)
+            self._run("march_fill", L.esr_fine_march_fill, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(mask_density),
+                      _lib.ptr(sdf), n, _lib.ptr(rb["off3"]), _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_step"]),
+                      _lib.ptr(ws["rec_w"]), _lib.ptr(ws["rec_sdf"]), s)
+            fa = self.feat_args(rays_o, rays_d, viewdirs, sdf, 0, T, color_on=(None, None, None),
+                                color_off=(off_color, emo_color, None))
+            self._run("feat_fwd", L.esr_fine_feat_fwd, sp, C.byref(fa), _lib.ptr(ws["X"]), _lib.ptr(ws["gnorm"]), s)
+            H, M = self._H(["H0", "H1", "H2"]), self._H(["M0", "M1", "M2"])
+            for net, crow, z in (("off", 0, "z_off"), ("emo", 88, "z_emo")):
+                self._run(f"mlp_fwd({net})", L.esr_mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed[net]), _lib.ptr(ws["X"]), 0, T,
+                          H, M, 0, crow, _lib.ptr(ws[z]), s)
+            for name, za, zb, ton in (("off", "z_off", "z_emo", 0), ("emo", "z_emo", "z_emo", 0), ("on", "z_off", "z_emo", T)):
+                self._run("tone_in_fwd", L.esr_fine_tone_in_fwd, _lib.ptr(ws[za]), _lib.ptr(ws[zb]), ton, T,
+                          _lib.ptr(ws["lin"]), _lib.ptr(ws["Xt"]), s)
+                self._run("mlp_fwd(tone)", L.esr_mlp_fwd, KIND_TONEMAP, _lib.ptr(self.packed["tone"]), _lib.ptr(ws["Xt"]), 0, T,
+                          self._H(["Ht"]), self._H(["Mt"]), 0, 0, _lib.ptr(ws["zt"]), s)
+                self._run("composite_fwd", L.esr_fine_composite_fwd, _lib.ptr(ws["zt"]), _lib.ptr(ws["lin"]),
+                          _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), T, _lib.ptr(ws["rgb"]),
+                          _lib.ptr(out[f"srgb/{name}_rgb"]), _lib.ptr(out[f"lin/{name}_rgb"]), s)
+            aux = torch.empty(T * 8 * 32, dtype=torch.float32, device=dev)
+            rt = (C.c_float * 9)(*[float(v) for v in pos_rt.detach().cpu().reshape(-1).tolist()])
+            self._run("eval_aux", L.esr_eval_aux, _lib.ptr(ws["X"]), X_ROWS, _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_step"]),
+                      T, rt, C.c_float(scene.stepdist), _lib.ptr(aux), s)
+            self._run("composite3_fwd(normal)", L.esr_composite3_fwd, _lib.ptr(aux), 8, _lib.ptr(ws["rec_ray"]),
+                      _lib.ptr(ws["rec_w"]), T, _lib.ptr(normal_m), s)
+            self._run("composite3_fwd(depth)", L.esr_composite3_fwd, C.c_void_p(aux.data_ptr() + 4 * 32 * 4), 8,
+                      _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), T, _lib.ptr(depth3), s)
+        self._run("eval_disp", L.esr_eval_disp, _lib.ptr(depth3), _lib.ptr(last), C.c_float(far), n, _lib.ptr(depth),
+                  _lib.ptr(disp), s)
+        out.update({"etc/depth": depth, "etc/disp": disp, "etc/normal": normal_m, "etc/white_bg": last.unsqueeze(-1)})
+        pick = "off" if int(em_mode) == 0 else "on"
+        out["srgb/rgb"], out["lin/rgb"] = out[f"srgb/{pick}_rgb"], out[f"lin/{pick}_rgb"]
+        self.last_eval_counts = dict(m0=m0, m1=m1, m2=m2, tiles=T)
+        return out
+
     # -- backward ----------------------------------------------------------------
     def backward(self, ctx: FineCtx, g_last, g_srgb, g_lin, grads: Dict[str, Optional[torch.Tensor]],
                  after_grids=None):

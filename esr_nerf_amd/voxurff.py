@@ -176,10 +176,21 @@ class VoxurfF(nn.Module):
             "lin/rgb": lin,
         }
 
+    @torch.no_grad()
     def forward_evaluate(self, **kwargs):
-        raise NotImplementedError(
-            "image rendering (forward_evaluate) is a 'next' row of SURVEY.md section 8(f); "
-            "round 1 covers forward_training")
+        """Image rendering (voxurff.py:280-461): kwargs rays_o, rays_d, viewdirs [N,3], em_modes (one scalar),
+        pos_rt [3,3]; uses ``self.s_val``.  Returns the reference's 12 result keys."""
+        eng = self.engine
+        for name, kind, net in (("off", KIND_RADIANCE, self.off_rgbnet), ("emo", KIND_RADIANCE, self.emo_rgbnet),
+                                ("tone", KIND_TONEMAP, self.tonemapper)):
+            lins = net.layers()
+            eng.pack(name, kind, [l.weight.detach() for l in lins], [l.bias.detach() for l in lins])
+        em = kwargs["em_modes"]
+        em = int(em.reshape(-1)[0]) if torch.is_tensor(em) else int(em)
+        return eng.evaluate(self.scene_struct(), kwargs["rays_o"].contiguous(), kwargs["rays_d"].contiguous(),
+                            kwargs["viewdirs"].contiguous(),
+                            self.mask_cache.density.view(*self.mask_cache.density.shape[2:]), self.sdf.device_view(),
+                            self.off_color.device_view(), self.emo_color.device_view(), kwargs["pos_rt"], self.far, em)
 
     # ------------------------------------------------------------------ geometry
     def set_grid_resolution(self, num_voxels: int):

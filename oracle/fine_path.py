@@ -278,6 +278,59 @@ def forward_training(P: Dict[str, Tensor], c: FineConsts, batch: Dict[str, Tenso
     }
 
 
+@torch.no_grad()
+def forward_evaluate(P: Dict[str, Tensor], c: FineConsts, batch: Dict[str, Tensor], s_val: float, far: float,
+                     em_mode: int, pos_rt: Tensor) -> Dict[str, Tensor]:
+    """VoxurfF.forward_evaluate (voxurff.py:280-461): image rendering -- the three radiance variants (off, emo,
+    on = off + emo) tone-mapped separately, depth / disparity, camera-space normals from the radius-1 finite
+    differences.  ``em_mode`` is one scalar per call (fine.py:549)."""
+    rays_o, rays_d, viewdirs = batch["rays_o"].contiguous(), batch["rays_d"].contiguous(), batch["viewdirs"]
+    N = rays_o.shape[0]
+    stepdist = c.stepsize * c.voxel_size
+    pts, out_box, ray_id, step_id = native.sample_pts_on_rays(rays_o, rays_d, c.xyz_min, c.xyz_max, c.near, 1e9,
+                                                              float(stepdist))[:4]
+    inb = ~out_box
+    pts, ray_id, step_id = pts[inb], ray_id[inb], step_id[inb]
+    m = mask_cache(c, pts)
+    pts, ray_id, step_id = pts[m], ray_id[m], step_id[m]
+    sdf = sample_grid(P["sdf.grid"], to_norm(pts, c.xyz_min, c.xyz_max))[:, 0]
+    alpha = neus_alpha_interp(sdf, ray_id, s_val)
+    m = alpha > c.fastcolor_thres
+    alpha, pts, ray_id, step_id, sdf = alpha[m], pts[m], ray_id[m], step_id[m], sdf[m]
+    zeros = torch.zeros(N, 3)
+    weights, alphainv_last = _Composite.apply(alpha, ray_id, N)
+    m = weights > c.fastcolor_thres
+    weights, pts, ray_id, step_id, sdf = weights[m], pts[m], ray_id[m], step_id[m], sdf[m]
+    _, g1, _ = sdf_stencil(c, P["sdf.grid"], pts, torch.tensor([1.0]))
+    grad = torch.cat([g1[:, [2]], g1[:, [1]], g1[:, [0]]], -1)
+    feat, _, normal12 = sdf_stencil(c, P["sdf.grid"], pts, c.grad_feat)
+    unit = (pts - c.xyz_min) / (c.xyz_max - c.xyz_min)
+    pfreq = torch.tensor([2.0 ** i for i in range(c.posbase_pe)])
+    vfreq = torch.tensor([2.0 ** i for i in range(c.viewbase_pe)])
+    pe = (unit.unsqueeze(-1) * pfreq).flatten(-2)
+    ve = (viewdirs.unsqueeze(-1) * vfreq).flatten(-2)
+    common = torch.cat([unit, pe.sin(), pe.cos(), ve[ray_id], ve.sin()[ray_id], ve.cos()[ray_id], sdf[:, None], feat,
+                        normal12], -1)
+    npts = to_norm(pts, c.xyz_min, c.xyz_max)
+    lin_off = radiance(P, "off_rgbnet", torch.cat([sample_grid(P["off_color.grid"], npts), common], -1))
+    lin_emo = radiance(P, "emo_rgbnet", torch.cat([sample_grid(P["emo_color.grid"], npts), common], -1))
+    lin_on = lin_off + lin_emo
+    w = weights.unsqueeze(-1)
+    comp = lambda x: zeros.clone().index_add(0, ray_id, w * x)
+    out = {}
+    for name, lin in (("off", lin_off), ("on", lin_on), ("emo", lin_emo)):
+        out[f"srgb/{name}_rgb"] = comp(tonemap(P, c, lin))
+        out[f"lin/{name}_rgb"] = comp(lin)
+    nrm = F.normalize(grad, dim=-1) @ pos_rt
+    nrm = (nrm * torch.tensor([1.0, -1.0, -1.0]) + 1.0) / 2.0
+    depth = torch.zeros(N).index_add(0, ray_id, weights * step_id * stepdist)
+    out.update({"etc/depth": depth, "etc/disp": 1 / (depth + alphainv_last * far), "etc/normal": comp(nrm),
+                "etc/white_bg": alphainv_last.unsqueeze(-1)})
+    pick = "off" if em_mode == 0 else "on"
+    out["srgb/rgb"], out["lin/rgb"] = out[f"srgb/{pick}_rgb"], out[f"lin/{pick}_rgb"]
+    return out
+
+
 # --------------------------------------------------------------------------- #
 # trainer-step loss
 # --------------------------------------------------------------------------- #

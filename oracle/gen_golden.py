@@ -131,6 +131,7 @@ def main():
     gen_lts(ns)
     gen_finetune(ns)
     gen_coarse(ns)
+    gen_eval(ns)
 
 
 def lts_reference_loss(ns, results, rgbs, cfg):
@@ -323,8 +324,40 @@ def gen_coarse(ns):
         print("coarse s_val", s_val, "loss", float(loss), "grads", sum(1 for k in out if k.startswith("grad/")))
 
 
+def gen_eval(ns):
+    """VoxurfF.forward_evaluate (image rendering, voxurff.py:280-461) for em_modes 0 and 1 on the oblique slab,
+    parameters = fine_g16_params.npz."""
+    cfg = fine_cfg("cpu")
+    sc = slab_scene("g16", s_val=60.0, oblique=True)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = ns.VoxurfF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max, sc.mask_alpha_init,
+                       sc.mask_density, 60.0, sc.num_voxels)
+    init_slab_model(model, sc)
+    with np.load(os.path.join(OUT, "fine_g16_params.npz")) as z:
+        for k, v in model.state_dict().items():
+            assert np.array_equal(z[k], v.detach().numpy()), k
+    model.eval()
+    b = sc.batch
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(2)))
+    out = {"in/" + k: b[k].numpy() for k in ("rays_o", "rays_d", "viewdirs")}
+    out["in/pos_rt"] = q.numpy()
+    out["in/s_val"] = np.float32(60.0)
+    out["in/far"] = np.float32(sc.far)
+    for em in (0, 1):
+        with torch.no_grad():
+            res = model(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=em, pos_rt=q)
+        for k, v in res.items():
+            out[f"out{em}/{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "fine_g16_eval.npz"), **out)
+    print("eval keys", sorted(k for k in out if k.startswith("out0/")))
+
+
 if __name__ == "__main__":
     import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "eval":
+        gen_eval(ref_import.load())
+        raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "coarse":
         gen_coarse(ref_import.load())
         raise SystemExit(0)

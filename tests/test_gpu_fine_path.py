@@ -312,3 +312,43 @@ def test_c2_full_size_properties():
         res = fp.forward_training(P, c, sub.batch, 20.0)
     for k in ("etc/alphainv_cum", "srgb/rgb", "lin/rgb"):
         assert rel_err(out[k][idx.cuda()], res[k]) < TOL, k
+
+
+def test_forward_evaluate_golden_and_psnr():
+    """Image rendering (VoxurfF.forward_evaluate) against the reference-generated fixture, all 12 result keys
+    for both emissive modes; PSNR between the two renderings of the slab 'image' far beyond the 0.1 dB bar."""
+    from conftest import load_npz
+    from esr_nerf_amd.synthetic import slab_scene
+    z = {k: torch.from_numpy(np.asarray(v)) for k, v in load_npz("fine_g16_eval.npz").items()}
+    sd = {k: torch.from_numpy(v) for k, v in load_npz("fine_g16_params.npz").items() if not k.startswith("__")}
+    sc = slab_scene("g16", s_val=60.0, oblique=True)
+    m = build_gpu_model(sc)
+    m.load_state_dict({k: v.cuda() for k, v in sd.items()})
+    m.s_val = 60.0
+    m.eval()
+    for em in (0, 1):
+        res = m(rays_o=z["in/rays_o"].cuda(), rays_d=z["in/rays_d"].cuda(), viewdirs=z["in/viewdirs"].cuda(),
+                em_modes=em, pos_rt=z["in/pos_rt"].cuda())
+        keys = [k[5:] for k in z if k.startswith(f"out{em}/")]
+        assert set(keys) == set(res) and len(keys) == 12
+        for k in keys:
+            assert res[k].shape == z[f"out{em}/{k}"].shape, k
+            assert rel_err(res[k], z[f"out{em}/{k}"]) < TOL, (em, k, rel_err(res[k], z[f"out{em}/{k}"]))
+        ref = (z[f"out{em}/srgb/rgb"] + z[f"out{em}/etc/white_bg"]).clamp(0, 1)
+        got = (res["srgb/rgb"].cpu() + res["etc/white_bg"].cpu()).clamp(0, 1)
+        mse = float(((ref - got) ** 2).mean())
+        assert mse < 1e-10                                           # PSNR > 100 dB between the two renderings
+    m.train()
+    assert m.forward == m.forward_training
+
+
+def test_forward_evaluate_all_miss():
+    from esr_nerf_amd.synthetic import slab_scene
+    sc = slab_scene("tiny", n_rays=16)
+    m = build_gpu_model(sc)
+    m.eval()
+    o = (sc.batch["rays_o"] + torch.tensor([10.0, 0.0, 0.0])).cuda()
+    res = m(rays_o=o, rays_d=sc.batch["rays_d"].cuda(), viewdirs=sc.batch["viewdirs"].cuda(), em_modes=1,
+            pos_rt=torch.eye(3).cuda())
+    assert float(res["srgb/rgb"].abs().max()) == 0.0 and torch.equal(res["etc/white_bg"].cpu(), torch.ones(16, 1))
+    assert rel_err(res["etc/disp"], torch.full((16,), 1.0 / sc.far)) < 1e-6
