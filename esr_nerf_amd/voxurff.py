@@ -137,7 +137,7 @@ class VoxurfF(nn.Module):
     def engine(self) -> FineEngine:
         if self._engine is None:
             if not str(self.device).startswith("cuda"):
-                raise RuntimeError("VoxurfF.forward_training runs on libesr_hip.so and needs a GPU device "
+                raise RuntimeError("VoxurfF renders through libesr_hip.so and needs a GPU device "
                                    "(there is no CPU fallback)")
             self._engine = FineEngine(self.device)
         return self._engine

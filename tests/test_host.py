@@ -91,9 +91,9 @@ def test_no_cpu_fallback_and_loud_config_errors():
         _cpu_model(rgbnet_width=128)
     with pytest.raises(NotImplementedError):
         _cpu_model(neus_alpha="grad")
-    m.eval()
-    with pytest.raises(NotImplementedError):
-        m(rays_o=b["rays_o"])
+    m.eval()                                   # image rendering is on the HIP path too: no CPU fallback either
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=0, pos_rt=torch.eye(3))
     from esr_nerf_amd import render_utils
     z = torch.zeros(3, 3)
     with pytest.raises(RuntimeError):
