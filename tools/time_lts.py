@@ -1,4 +1,4 @@
-"""Wall time + per-call HIP-event breakdown of one LTS training step (autograd route) at C4 size."""
+"""Wall time + per-call HIP-event breakdown of one LTS training step (LtsStep, no autograd) at C4 size."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,7 +7,7 @@ import torch
 from esr_nerf_amd.config import lts_cfg
 from esr_nerf_amd.esrnerf import ESRNeRF
 from esr_nerf_amd.synthetic import init_slab_model, slab_scene
-from oracle import lts_path as lp      # loss lines only (torch ops on the device)
+from esr_nerf_amd.trainer import LtsStep
 
 n_rays = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 s_val = float(sys.argv[2]) if len(sys.argv) > 2 else 220.0
@@ -19,16 +19,11 @@ m = ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max
 m.train()
 init_slab_model(m, sc, seed=1)
 b = {k: v.cuda() for k, v in sc.batch.items()}
-um = torch.zeros(n_rays, dtype=torch.bool, device="cuda"); um[::3] = True
-tr = cfg.app.trainer
+b["uncert_masks"] = torch.arange(n_rays, device="cuda") % 3 == 0
+runner = LtsStep(m, cfg.app.trainer, stage=sys.argv[3] if len(sys.argv) > 3 else "lts")
 
 def step():
-    m.zero_grad(set_to_none=True)
-    res = m(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=b["em_modes"],
-            uncert_masks=um, s_val=s_val, normal_eps=tr.normal_eps, emit_eps=tr.emit_eps)
-    loss, _ = lp.lts_loss(res, b["rgbs"], True, tr.weight_linear, tr.weight_lts, tr.weight_entropy_last, tr.weight_normal_smooth)
-    loss.backward()
-    return loss
+    return runner.forward_loss_backward(b, s_val)[0]
 
 for _ in range(3):
     step()
