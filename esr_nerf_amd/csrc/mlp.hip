@@ -813,6 +813,7 @@ ESR_API int esr_mlp_wgrad(int kind, const float *X, int color_row0, const float 
         int rc;
         if (D.hid_tiles == 6) {
             if (last) rc = launch_wgrad<1, 3, 1, 2, 2>(W, scratch_floats, s);
+            else if (first && W.RB <= 64) rc = launch_wgrad<3, 2, 2, 1, 2>(W, scratch_floats, s);   // tone mapper: 48 input rows
             else if (first) rc = launch_wgrad<3, 3, 2, 1, 2>(W, scratch_floats, s);
             else rc = launch_wgrad<3, 3, 2, 2, 1>(W, scratch_floats, s);
         } else {
