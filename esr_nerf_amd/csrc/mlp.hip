@@ -29,6 +29,9 @@
 #include "esr_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef ESR_NT_AUX
+#define ESR_NT_AUX 2          // gfx940+ buffer cache-policy bits: 1 = sc0, 2 = nt, 16 = sc1
+#endif
 
 namespace {
 
@@ -210,6 +213,12 @@ __device__ __forceinline__ void bstore1(rsrc_t r, float v, int voff, int soff)
 {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
 }
+// streaming store (nt): saved activations / gradients are written once and read by a later kernel; keeping
+// them out of the L2's working set leaves it to the packed weights that every wave re-reads
+__device__ __forceinline__ void bstore1_nt(rsrc_t r, float v, int voff, int soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, ESR_NT_AUX);
+}
 
 // acc[n / KP4] += (packed weight quad n) . B-quad (n % KP4), n = 0 .. NT*KP4-1.
 // The weight stream (byte offset `woff` in the packed buffer) is explicitly
@@ -302,7 +311,7 @@ __device__ __forceinline__ void store_tiles(rsrc_t T, const f32x16 (&acc)[NT], i
 #pragma unroll
     for (int it = 0; it < NT; ++it)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bstore1(T, acc[it][r], voff, tile_soff(it, r));
+        for (int r = 0; r < 16; ++r) bstore1_nt(T, acc[it][r], voff, tile_soff(it, r));
 }
 
 // acc = (saved activation > 0) ? acc : 0
