@@ -1,0 +1,21 @@
+#!/bin/bash
+# rocprofv3 evidence for bench.py's default workload (C2, fine stage), run on the GPU box:
+#   gpurun -- 'bash tools/profile_c2.sh r01_d'
+# 1. --kernel-trace --stats  -> gpurun_out/<tag>_stats/   (per-kernel time)
+# 2. --pmc FETCH_SIZE        -> gpurun_out/<tag>_fetch/   (separate pass per counter, as the guide prescribes)
+# 3. --pmc WRITE_SIZE        -> gpurun_out/<tag>_write/
+# The program goes directly after `--` (no env/bash wrappers under the profiler).
+TAG=${1:-prof}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+ARGS="--no-cpu-baseline --no-optimizer --no-kernel-timing"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats" -o run -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 $ARGS > "$OUT/${TAG}_stats.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${TAG}_fetch" -o run -- python3 "$ROOT/bench.py" --steps 3 --warmup 2 $ARGS > "$OUT/${TAG}_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${TAG}_write" -o run -- python3 "$ROOT/bench.py" --steps 3 --warmup 2 $ARGS > "$OUT/${TAG}_write.log" 2>&1
+for w in stats fetch write; do echo "== $w"; tail -n 2 "$OUT/${TAG}_$w.log" | cut -c1-300; done
+# keep the csv summaries only (gpurun copies back at most 64 MiB)
+find "$OUT" -path "*${TAG}_*" -type f ! -name "*.csv" ! -name "*.log" -delete
+find "$OUT" -path "*${TAG}_*" -name "*.csv" -size +20M -delete
+du -sh "$OUT"; find "$OUT" -path "*${TAG}_*" -name "*.csv" | head -20
