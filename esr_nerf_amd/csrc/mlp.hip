@@ -28,344 +28,9 @@
 //    flushes it with 128-B-contiguous float atomics once.
 #include "esr_common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-#ifndef ESR_NT_AUX
-#define ESR_NT_AUX 2          // gfx940+ buffer cache-policy bits: 1 = sc0, 2 = nt, 16 = sc1
-#endif
+#include "mlp_common.h"
 
 namespace {
-
-constexpr int MAX_HID_TILES = 6;      // widest hidden layer: 192 features
-
-// feature index a (k-pair p, lane half h) register slot stands for in a hidden layer
-__host__ __device__ constexpr int hid_feature(int p, int h)
-{
-    return 32 * (p >> 4) + ((p & 15) & 3) + 8 * ((p & 15) >> 2) + 4 * h;
-}
-// row of a 32x32 accumulator tile held by register r of lane half h
-__host__ __device__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-// ---- network descriptions ---------------------------------------------------
-struct NetDesc {
-    int n_layers;           // linear layers (hidden + output)
-    int in_dim, in_kp;      // reference input width, k-pairs of the first layer (multiple of 4)
-    int xrows;              // rows of the input tile
-    int out_dim;
-    int hid_tiles;          // hidden width / 32
-    int zrows;              // rows of the output / output-gradient tile (4 or 8)
-    int cw;                 // rows of the colour group at the head of the input tile (re-targetable, see crow)
-};
-constexpr int XC_ROWS = 72; // coarse feature tile: 12 colour | 12 alt colour | normal3 | xyz3 sin15 cos15 | view 9 | pad
-constexpr int X_ROWS = 104; // feature tile: 96 rows + a third colour group (rows 96-101)
-__host__ __device__ constexpr NetDesc net_desc(int kind)
-{
-    return kind == ESR_MLP_RADIANCE ? NetDesc{4, 85, 48, X_ROWS, 3, 6, 4, 6}   // pbr/module.py:6-21
-         : kind == ESR_MLP_TONEMAP  ? NetDesc{2, 33, 24, 48, 3, 6, 4, 6}       // pbr/module.py:24-39
-         : kind == ESR_MLP_BRDF     ? NetDesc{4, 76, 40, X_ROWS, 5, 4, 8, 6}   // pbr/module.py:42-65
-         : kind == ESR_MLP_EMIT     ? NetDesc{4, 76, 40, X_ROWS, 3, 4, 4, 6}   // EmissionNet, pbr/module.py:68-83
-         :                            NetDesc{3, 57, 36, XC_ROWS, 3, 4, 4, 12}; // coarse rgbnet, voxurfc.py:134-149
-}
-__host__ __device__ constexpr bool kind_ok(int kind) { return kind >= 0 && kind <= ESR_MLP_COARSE; }
-
-// X-tile row -> column of the reference's first-layer weight (-1: no column)
-__host__ __device__ inline int in_colmap(int kind, int row)
-{
-    if (kind == ESR_MLP_TONEMAP) return row < 33 ? row : -1;
-    if (kind == ESR_MLP_COARSE) {
-        // reference order (voxurfc.py:228-250): colour12 | xyz3 sin15 cos15 | vd3 sin3 cos3 | normal3
-        if (row < 12) return row;
-        if (row < 24) return -1;                 // the other net's colour group
-        if (row < 27) return 54 + (row - 24);    // normal
-        if (row < 30) return 12 + (row - 27);    // xyz
-        if (row < 45) return 15 + (row - 30);    // sin
-        if (row < 60) return 30 + (row - 45);    // cos
-        if (row < 69) return 45 + (row - 60);    // viewdir, sin, cos
-        return -1;
-    }
-    if (kind == ESR_MLP_BRDF || kind == ESR_MLP_EMIT) {
-        // reference order (esrnerf.py:761-765): colour6 | xyz3 sin15 cos15 | sdf | feat24 | normal12
-        if (row < 6) return row;
-        if (row == 6) return 39;
-        if (row < 31) return 40 + (row - 7);
-        if (row < 43) return 64 + (row - 31);
-        if (row < 46) return 6 + (row - 43);
-        if (row < 61) return 9 + (row - 46);
-        if (row < 76) return 24 + (row - 61);
-        return -1;                           // no view-direction input
-    }
-    if (row < 6) return row;                 // colour
-    if (row == 6) return 48;                 // sdf
-    if (row < 31) return 49 + (row - 7);     // feat24
-    if (row < 43) return 73 + (row - 31);    // normal12
-    if (row < 46) return 6 + (row - 43);     // xyz
-    if (row < 61) return 9 + (row - 46);     // sin
-    if (row < 76) return 24 + (row - 61);    // cos
-    if (row < 85) return 39 + (row - 76);    // viewdir, sin, cos
-    return -1;
-}
-
-// Packed buffer layout (floats).  Forward part per layer l:
-//   Wf_l [tiles_out][kp/4][64 lanes][4]   bias Bf_l [tiles_out][2 halves][16]
-// Backward part per layer l: Wb_l [tiles_in][kpo/4][64][4]   (tiles_in: rows of the layer INPUT)
-struct PackLayout {
-    int n_layers;
-    int kp[4], tiles_out[4], in_dim[4], out_dim[4];
-    int kpo[4], tiles_in[4];
-    int64_t off_wf[4], off_bf[4], off_wb[4];
-    int64_t total;
-};
-__host__ __device__ constexpr PackLayout pack_layout(int kind)
-{
-    const NetDesc d = net_desc(kind);
-    PackLayout L = {};
-    L.n_layers = d.n_layers;
-    int64_t o = 0;
-    for (int l = 0; l < d.n_layers; ++l) {
-        const bool first = l == 0, last = l == d.n_layers - 1;
-        const int hkp = 16 * d.hid_tiles, hid = 32 * d.hid_tiles;
-        L.kp[l] = first ? d.in_kp : hkp;
-        L.in_dim[l] = first ? d.in_dim : hid;
-        L.out_dim[l] = last ? d.out_dim : hid;
-        L.tiles_out[l] = last ? 1 : d.hid_tiles;
-        L.kpo[l] = last ? 4 : hkp;                       // contraction pairs of the transposed product
-        L.tiles_in[l] = first ? 2 : d.hid_tiles;         // dX: rows 0..63 only
-        L.off_wf[l] = o; o += (int64_t)L.tiles_out[l] * L.kp[l] * 64;
-        L.off_bf[l] = o; o += (int64_t)L.tiles_out[l] * 32;
-        L.off_wb[l] = o; o += (int64_t)L.tiles_in[l] * L.kpo[l] * 64;
-    }
-    L.total = o;
-    return L;
-}
-
-struct PackArgs {
-    int kind;
-    const float *w[4], *b[4];
-    float *out;
-};
-
-__global__ void __launch_bounds__(256) pack_kernel(PackArgs A)
-{
-    const PackLayout L = pack_layout(A.kind);
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < L.total;
-         e += (int64_t)gridDim.x * blockDim.x) {
-        int l = 0;
-        while (l + 1 < L.n_layers && e >= L.off_wf[l + 1]) ++l;
-        const bool first = l == 0, last = l == L.n_layers - 1;
-        const float *W = A.w[l];
-        const int ind = L.in_dim[l], outd = L.out_dim[l];
-        float v = 0.f;
-        if (e < L.off_bf[l]) {                               // forward weights
-            int64_t i = e - L.off_wf[l];
-            const int sub = i & 3; i >>= 2;
-            const int lane = i & 63; i >>= 6;
-            const int q = (int)(i % (L.kp[l] / 4)), it = (int)(i / (L.kp[l] / 4));
-            const int p = 4 * q + sub, h = lane >> 5;
-            const int row = 32 * it + (lane & 31);
-            const int col = first ? in_colmap(A.kind, 2 * p + h) : hid_feature(p, h);
-            if (row < outd && col >= 0 && col < ind) v = W[(int64_t)row * ind + col];
-        } else if (e < L.off_wb[l]) {                        // bias in accumulator order
-            int64_t i = e - L.off_bf[l];
-            const int r = i & 15, h = (i >> 4) & 1, it = (int)(i >> 5);
-            const int row = 32 * it + acc_row(r, h);
-            if (row < outd) v = A.b[l][row];
-        } else {                                             // transposed weights for dgrad
-            int64_t i = e - L.off_wb[l];
-            const int sub = i & 3; i >>= 2;
-            const int lane = i & 63; i >>= 6;
-            const int q = (int)(i % (L.kpo[l] / 4)), it = (int)(i / (L.kpo[l] / 4));
-            const int p = 4 * q + sub, h = lane >> 5;
-            const int orow = last ? (2 * p + h) : hid_feature(p, h);          // output feature of layer l
-            const int irow = 32 * it + (lane & 31);                           // input feature / X row
-            const int col = first ? in_colmap(A.kind, irow) : irow;
-            if (orow < outd && col >= 0 && col < ind) v = W[(int64_t)orow * ind + col];
-        }
-        A.out[e] = v;
-    }
-}
-
-// ---- MFMA building blocks ------------------------------------------------------
-__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-// Buffer addressing (SGPR descriptor + per-lane 32-bit offset + scalar constant offset):
-// with plain pointers hipcc materialises ~100 loop-invariant 64-bit addresses per kernel
-// (one per store/load slot) and spills kilobytes per lane.  Out-of-range accesses are
-// dropped by the hardware range check instead of faulting.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-
-__device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 bload4(rsrc_t r, int voff, int soff)
-{
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-__device__ __forceinline__ float bload1(rsrc_t r, int voff, int soff)
-{
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
-__device__ __forceinline__ void bstore1(rsrc_t r, float v, int voff, int soff)
-{
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
-}
-// streaming store (nt): saved activations / gradients are written once and read by a later kernel; keeping
-// them out of the L2's working set leaves it to the packed weights that every wave re-reads
-__device__ __forceinline__ void bstore1_nt(rsrc_t r, float v, int voff, int soff)
-{
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, ESR_NT_AUX);
-}
-
-// acc[n / KP4] += (packed weight quad n) . B-quad (n % KP4), n = 0 .. NT*KP4-1.
-// The weight stream (byte offset `woff` in the packed buffer) is explicitly
-// double-buffered in groups of G 16-B loads (16 MFMAs = ~1k cycles of matrix work per
-// group) with a scheduling barrier per group so the loads stay one group ahead.
-template <int KP4, int NT, typename BF>
-__device__ __forceinline__ void stream_layer(rsrc_t W, int woff, BF bget, f32x16 (&acc)[NT], int lane)
-{
-    constexpr int NTOT = NT * KP4, G = 4, NG = (NTOT + G - 1) / G;
-    const int voff = lane * 16;
-    float4 buf[2][G];
-#pragma unroll
-    for (int i = 0; i < G; ++i)
-        if (i < NTOT) buf[0][i] = bload4(W, voff, woff + i * 1024);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int n = (g + 1) * G + i;
-            if (n < NTOT) buf[(g + 1) & 1][i] = bload4(W, voff, woff + n * 1024);
-        }
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int n = g * G + i;
-            if (n < NTOT) {
-                const int it = n / KP4, q = n % KP4;
-                const float4 a = buf[g & 1][i];
-                acc[it] = mfma32(a.x, bget(4 * q + 0), acc[it]);
-                acc[it] = mfma32(a.y, bget(4 * q + 1), acc[it]);
-                acc[it] = mfma32(a.z, bget(4 * q + 2), acc[it]);
-                acc[it] = mfma32(a.w, bget(4 * q + 3), acc[it]);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// acc[it] += Wp[it] . B      B given as KP per-lane registers
-template <int KP, int NT>
-__device__ __forceinline__ void layer_from_regs(rsrc_t W, int woff, const float (&B)[KP],
-                                                f32x16 (&acc)[NT], int lane)
-{
-    static_assert(KP % 4 == 0, "k-pairs come in quads");
-    stream_layer<KP / 4, NT>(W, woff, [&](int k) { return B[k]; }, acc, lane);
-}
-
-// acc[it] += Wp[it] . prev    prev = NP accumulator tiles of the previous layer (32*NP features)
-template <int NP, int NT>
-__device__ __forceinline__ void layer_from_acc(rsrc_t W, int woff, const f32x16 (&prev)[NP],
-                                               f32x16 (&acc)[NT], int lane)
-{
-    stream_layer<NP * 4, NT>(W, woff, [&](int k) { return prev[k >> 4][k & 15]; }, acc, lane);
-}
-
-// bias (packed in accumulator order at byte offset boff)
-template <int NT>
-__device__ __forceinline__ void load_bias(rsrc_t W, int boff, f32x16 (&acc)[NT], int lane)
-{
-    const int voff = (lane >> 5) * 64;
-#pragma unroll
-    for (int it = 0; it < NT; ++it) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 v = bload4(W, voff, boff + it * 128 + q * 16);
-            acc[it][4 * q + 0] = v.x; acc[it][4 * q + 1] = v.y;
-            acc[it][4 * q + 2] = v.z; acc[it][4 * q + 3] = v.w;
-        }
-    }
-}
-
-template <int NT>
-__device__ __forceinline__ void relu_tiles(f32x16 (&acc)[NT])
-{
-#pragma unroll
-    for (int it = 0; it < NT; ++it)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[it][r] = fmaxf(acc[it][r], 0.f);
-}
-
-// per-lane byte offset inside a tile-major tile: row 4h, sample s
-__device__ __forceinline__ int tile_voff(int lane) { return ((lane >> 5) * 4 * 32 + (lane & 31)) * 4; }
-// scalar byte offset of accumulator register r of tile `it` (row = 32it + (r&3) + 8(r>>2))
-__host__ __device__ constexpr int tile_soff(int it, int r) { return (32 * it + (r & 3) + 8 * (r >> 2)) * 128; }
-
-// tile-major store of NT accumulator tiles through descriptor T (based at the tile)
-template <int NT>
-__device__ __forceinline__ void store_tiles(rsrc_t T, const f32x16 (&acc)[NT], int lane)
-{
-    const int voff = tile_voff(lane);
-#pragma unroll
-    for (int it = 0; it < NT; ++it)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bstore1_nt(T, acc[it][r], voff, tile_soff(it, r));
-}
-
-// acc = (saved activation > 0) ? acc : 0
-template <int NT>
-__device__ __forceinline__ void mask_by_saved(rsrc_t T, f32x16 (&acc)[NT], int lane)
-{
-    const int voff = tile_voff(lane);
-#pragma unroll
-    for (int it = 0; it < NT; ++it)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float a = bload1(T, voff, tile_soff(it, r));
-            acc[it][r] = a > 0.f ? acc[it][r] : 0.f;
-        }
-}
-
-// ReLU sign bits of NT accumulator tiles, 16 bits per tile, two tiles per word.  The backward
-// needs only (h > 0): 3 words per lane instead of re-reading 96 floats (24 KB per tile).
-template <int NT>
-__device__ __forceinline__ void store_relu_mask(rsrc_t T, const f32x16 (&acc)[NT], int lane)
-{
-    static_assert(NT % 2 == 0, "two tiles per mask word");
-#pragma unroll
-    for (int wd = 0; wd < NT / 2; ++wd) {
-        unsigned m = 0;
-#pragma unroll
-        for (int b = 0; b < 32; ++b) m |= (acc[2 * wd + (b >> 4)][b & 15] > 0.f) ? (1u << b) : 0u;
-        __builtin_amdgcn_raw_buffer_store_b32(m, T, lane * 4, wd * 256, 0);
-    }
-}
-template <int NT>
-__device__ __forceinline__ void load_relu_mask(rsrc_t T, unsigned (&m)[NT / 2], int lane)
-{
-#pragma unroll
-    for (int wd = 0; wd < NT / 2; ++wd) m[wd] = __builtin_amdgcn_raw_buffer_load_b32(T, lane * 4, wd * 256, 0);
-}
-template <int NT>
-__device__ __forceinline__ void apply_relu_mask(const unsigned (&m)[NT / 2], f32x16 (&acc)[NT])
-{
-#pragma unroll
-    for (int it = 0; it < NT; ++it)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            acc[it][r] = ((m[it >> 1] >> ((it & 1) * 16 + r)) & 1u) ? acc[it][r] : 0.f;
-}
-
-template <int NT>
-__device__ __forceinline__ void zero_tiles(f32x16 (&acc)[NT])
-{
-#pragma unroll
-    for (int it = 0; it < NT; ++it)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[it][r] = 0.f;
-}
 
 struct FwdArgs {
     const float *packed, *X;

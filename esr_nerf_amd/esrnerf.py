@@ -8,7 +8,8 @@ name, cfg/app/lts.yaml:61-71) and ``state_dict`` keys.  ``forward_training`` is 
 node over the kernels of libesr_hip.so (esr_nerf_amd/lts_engine.py).
 
 ``forward_finetune`` (re-lighting fine-tune target, esrnerf.py:241-484) runs on the same kernels.
-Not yet provided: ``forward_evaluate``, ``eval_emit``, ``eval_esp``, ``render_envmap``.
+``eval_emit`` / ``eval_esp`` (the PDRA trainer's regrouping queries) are forward-only passes over the same kernels.
+Not yet provided: ``forward_evaluate``, ``render_envmap``.
 """
 from __future__ import annotations
 
@@ -204,22 +205,6 @@ class ESRNeRF(VoxurfF):
             sc.near_ = float(near)
         return sc
 
-    def train(self, mode=True, finetune=False):
-        """esrnerf.py:218-239: fine-tune mode renders through ``forward_finetune`` and freezes a copy of the emo
-        colour grid (``emit_color``) for the emission head; leaving it deletes the copy again."""
-        if mode and finetune:
-            ret = nn.Module.train(self, mode)
-            self.forward = self.forward_finetune
-            self.emit_color = DenseGrid(channels=self.color_dim, world_size=self.world_size, xyz_min=self.xyz_min,
-                                        xyz_max=self.xyz_max).to(self.device)
-            self.emit_color.load_state_dict(self.emo_color.state_dict())
-            for p in self.emit_color.parameters():
-                p.requires_grad_(False)
-            return ret
-        if mode and hasattr(self, "emit_color"):
-            del self.emit_color
-        return super().train(mode)
-
     def _mlp_params(self) -> List[torch.Tensor]:
         ps = []
         for net in (self.off_rgbnet, self.emo_rgbnet, self.tonemapper, self.brdfnet, self.emitnet):
@@ -260,6 +245,47 @@ class ESRNeRF(VoxurfF):
         ps = [t for lin in self.emo_rgbnet.layers() for t in (lin.weight, lin.bias)]
         emo, emo_hat = _FinetuneRender.apply(self, batch, draws, self.emo_color.grid, *ps)
         return {"lin/pbr/emo": emo, "lin/pbr/emo_hat": emo_hat}
+
+    def train(self, mode=True, finetune=False):
+        """esrnerf.py:218-239: fine-tune mode renders through ``forward_finetune`` and freezes a copy of the emo
+        colour grid (``emit_color``) for the emission head; plain training drops the copy again; evaluation aliases
+        ``emit_color`` to ``emo_color`` when no copy exists."""
+        if mode and finetune:
+            ret = nn.Module.train(self, mode)
+            self.forward = self.forward_finetune
+            self.emit_color = DenseGrid(channels=self.color_dim, world_size=self.world_size, xyz_min=self.xyz_min,
+                                        xyz_max=self.xyz_max).to(self.device)
+            self.emit_color.load_state_dict(self.emo_color.state_dict())
+            for p in self.emit_color.parameters():
+                p.requires_grad_(False)
+            return ret
+        if mode and hasattr(self, "emit_color"):
+            del self.emit_color
+        ret = super().train(mode)
+        if not mode and not hasattr(self, "emit_color"):
+            self.emit_color = self.emo_color
+        return ret
+
+    def _eval_query(self, what, **kwargs):
+        eng = self.engine
+        if what == "emit":
+            lins = self.emitnet.layers()
+            eng.pack("emit", KIND_EMIT, [l.weight.detach() for l in lins], [l.bias.detach() for l in lins])
+        grid = getattr(self, "emit_color", self.emo_color)
+        return eng.eval_query(self.scene_struct(), kwargs["rays_o"].contiguous(), kwargs["rays_d"].contiguous(),
+                              kwargs["viewdirs"].contiguous(),
+                              self.mask_cache.density.view(*self.mask_cache.density.shape[2:]), self.sdf.device_view(),
+                              grid.device_view(), what)
+
+    @torch.no_grad()
+    def eval_emit(self, **kwargs):
+        """Composited emission per ray (esrnerf.py:1299-1358; PDRA's ray regrouping, pdra.py:882-932)."""
+        return self._eval_query("emit", **kwargs)
+
+    @torch.no_grad()
+    def eval_esp(self, **kwargs):
+        """Weight-composited sample position per ray (esrnerf.py:1360-1407)."""
+        return self._eval_query("esp", **kwargs)
 
     def forward_evaluate(self, **kwargs):
         raise NotImplementedError("ESRNeRF.forward_evaluate (esrnerf.py:853-1297, per-sample light transport and 30 "

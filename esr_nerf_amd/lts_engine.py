@@ -232,6 +232,34 @@ class LtsEngine(FineEngine):
         perm[ref_pos] = jidx
         return perm, rec_ray
 
+    # ------------------------------------------------------------------ PDRA regrouping queries
+    @torch.no_grad()
+    def eval_query(self, scene, rays_o, rays_d, viewdirs, mask_density, sdf, emit_grid, what: str):
+        """``ESRNeRF.eval_emit`` (what="emit", esrnerf.py:1299-1358: composited emission) or ``eval_esp``
+        (what="esp", :1360-1407: composited sample position) per ray, forward only -> [N,3]."""
+        L, s, dev = self.L, self._s(), self.device
+        n = rays_o.shape[0]
+        P0 = self.prim
+        self._march(P0, scene, rays_o, rays_d, torch.zeros(n, dtype=torch.int64, device=dev), mask_density, sdf)
+        T = P0.tiles_all
+        out = torch.zeros(n, 3, dtype=torch.float32, device=dev)
+        if T == 0:
+            return out
+        sp = C.byref(scene)
+        if what == "emit":
+            self._feat_args_records(P0, rays_o, rays_d, viewdirs, sdf, (emit_grid, None, None), (emit_grid, None, None))
+            self._features(P0, scene)
+            self._net_fwd(P0, "emit", KIND_EMIT, 0, 0, T, save=False)
+            v = self._act(P0, "emit.z", "emit.a", 4, 3, ACT_SOFTPLUS)
+        else:
+            pts = torch.empty(T * 32, 3, device=dev)
+            self._run("sample_points", L.esr_sample_points, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
+                      _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(P0.bufs["rec_step"]), T * 32, _lib.ptr(pts), s)
+            v = P0.from_rowmajor("pts.t", 4, pts)
+        self._run(f"composite3_fwd({what})", L.esr_composite3_fwd, _lib.ptr(v), 4, _lib.ptr(P0.bufs["rec_ray"]),
+                  _lib.ptr(P0.bufs["rec_w"]), T, _lib.ptr(out), s)
+        return out
+
     # ------------------------------------------------------------------ re-lighting fine-tune (A16)
     def finetune_forward(self, scene, scene2, batch, grids, cfg, draws=None):
         """``ESRNeRF.forward_finetune`` (esrnerf.py:241-484): the emo net's prediction at ``num_ltspts`` surface

@@ -132,6 +132,7 @@ def main():
     gen_finetune(ns)
     gen_coarse(ns)
     gen_eval(ns)
+    gen_lts_evals(ns)
 
 
 def lts_reference_loss(ns, results, rgbs, cfg):
@@ -284,6 +285,32 @@ def gen_finetune(ns):
     print("finetune loss", float(loss), "grads", sorted(k for k in out if k.startswith("grad/")))
 
 
+def gen_lts_evals(ns):
+    """ESRNeRF.eval_emit / eval_esp (PDRA regrouping queries, esrnerf.py:1299-1407) in eval mode on the oblique
+    slab, parameters = lts_g16_params.npz, inputs = the rays of lts_g16_lts.npz."""
+    from esr_nerf_amd.config import lts_cfg
+    cfg = lts_cfg("cpu", num_2ndrays=8, num_ltspts=12)
+    sc = slab_scene("g16", s_val=60.0, oblique=True)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = ns.ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max,
+                       sc.mask_alpha_init, sc.mask_density, sc.s_val, sc.num_voxels)
+    init_slab_model(model, sc)
+    with torch.no_grad():
+        model.brdf.grid.data.copy_(torch.randn(model.brdf.grid.shape, generator=torch.Generator().manual_seed(9)) * 0.1)
+    with np.load(os.path.join(OUT, "lts_g16_params.npz")) as z:
+        for k, v in model.state_dict().items():
+            assert np.array_equal(z[k], v.detach().numpy()), k
+    model.s_val = 60.0
+    model.eval()
+    b = sc.batch
+    with torch.no_grad():
+        e = model.eval_emit(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"])
+        p_ = model.eval_esp(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"])
+    np.savez_compressed(os.path.join(OUT, "lts_g16_evals.npz"), **{"out/eval_emit": e.numpy(), "out/eval_esp": p_.numpy()})
+    print("lts evals", float(e.abs().max()), float(p_.abs().max()))
+
+
 def gen_coarse(ns):
     """VoxurfC.forward_training + the loss lines of coarse.py:341-352 on the small oblique slab (A17)."""
     from esr_nerf_amd.config import coarse_cfg
@@ -355,6 +382,9 @@ def gen_eval(ns):
 
 if __name__ == "__main__":
     import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "lts_evals":
+        gen_lts_evals(ref_import.load())
+        raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "eval":
         gen_eval(ref_import.load())
         raise SystemExit(0)

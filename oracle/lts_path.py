@@ -379,3 +379,35 @@ def forward_finetune(P: Dict[str, Tensor], c: fp.FineConsts, batch: Dict[str, Te
         reflect = (rep(emo_m) * Rf).view(-1, R, 3).mean(-2)
         emo_hat = rep(emit) + reflect
     return {"lin/pbr/emo": emo, "lin/pbr/emo_hat": emo_hat}
+
+
+# ------------------------------------------------------------------ PDRA regrouping queries
+@torch.no_grad()
+def _primary_survivors(P, c, batch, s_val):
+    rays_o, rays_d = batch["rays_o"], batch["rays_d"]
+    N, pts, ray_id = _march(P, c, rays_o, rays_d, c.near, s_val)
+    sdf = fp.sample_grid(P["sdf.grid"], fp.to_norm(pts, c.xyz_min, c.xyz_max))[:, 0]
+    alpha = fp.neus_alpha_interp(sdf, ray_id, s_val)
+    m = alpha > c.fastcolor_thres
+    alpha, pts, ray_id, sdf = alpha[m], pts[m], ray_id[m], sdf[m]
+    weights, _ = fp._Composite.apply(alpha, ray_id, N)
+    m = weights > c.fastcolor_thres
+    return N, weights[m], pts[m], ray_id[m], sdf[m]
+
+
+@torch.no_grad()
+def eval_emit(P, c, batch, s_val, emit_grid_key: str = "emo_color.grid") -> Tensor:
+    """ESRNeRF.eval_emit (esrnerf.py:1299-1358): composited emission per ray, [N,3].  In eval mode the emission
+    head reads ``emit_color``, which is ``emo_color`` unless a fine-tune froze a copy (esrnerf.py:236-238)."""
+    N, w, pts, ray_id, sdf = _primary_survivors(P, c, batch, s_val)
+    feat, _, nrm = _stencil(c, P["sdf.grid"], pts)
+    bfeat = torch.cat([_pe(c, pts), sdf[:, None], feat, nrm], -1)
+    emit = emit_net(P, torch.cat([fp.sample_grid(P[emit_grid_key], fp.to_norm(pts, c.xyz_min, c.xyz_max)), bfeat], -1))
+    return torch.zeros(N, 3).index_add(0, ray_id, w[:, None] * emit)
+
+
+@torch.no_grad()
+def eval_esp(P, c, batch, s_val) -> Tensor:
+    """ESRNeRF.eval_esp (esrnerf.py:1360-1407): weight-composited sample position per ray, [N,3]."""
+    N, w, pts, ray_id, _ = _primary_survivors(P, c, batch, s_val)
+    return torch.zeros(N, 3).index_add(0, ray_id, w[:, None] * pts)

@@ -263,3 +263,21 @@ def test_finetune_golden_reference_vectors():
     assert all(e < TOL for e in bad.values()), str(bad)
     m.train(True)                      # leaving fine-tune mode drops the frozen copy (esrnerf.py:222-223)
     assert not hasattr(m, "emit_color")
+
+
+def test_eval_emit_and_esp_golden():
+    """PDRA regrouping queries on the HIP path against the reference-generated fixture."""
+    from esr_nerf_amd.synthetic import slab_scene
+    z = {k: torch.from_numpy(np.asarray(v)) for k, v in load_npz("lts_g16_evals.npz").items()}
+    sd = {k: torch.from_numpy(v) for k, v in load_npz("lts_g16_params.npz").items()}
+    sc = slab_scene("g16", s_val=60.0, oblique=True)
+    m, _ = build_lts_model(sc, num_2ndrays=8, num_ltspts=12)
+    m.load_state_dict({k: v.cuda() for k, v in sd.items()})
+    m.s_val = 60.0
+    m.eval()
+    assert m.emit_color is m.emo_color
+    b = {k: sc.batch[k].cuda() for k in ("rays_o", "rays_d", "viewdirs")}
+    assert rel_err(m.eval_emit(**b), z["out/eval_emit"]) < TOL
+    assert rel_err(m.eval_esp(**b), z["out/eval_esp"]) < TOL
+    miss = dict(b, rays_o=b["rays_o"] + torch.tensor([10.0, 0.0, 0.0], device="cuda"))
+    assert float(m.eval_emit(**miss).abs().max()) == 0.0
