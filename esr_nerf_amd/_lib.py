@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libesr_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 _lib = None
 
 
@@ -78,6 +78,7 @@ EXPORTS = [
     "esr_coarse_march_count", "esr_coarse_march_fill", "esr_coarse_march_bwd",
     "esr_coarse_feat_fwd", "esr_coarse_feat_bwd", "esr_coarse_shade_fwd", "esr_coarse_shade_bwd",
     "esr_adam_step", "esr_eval_aux", "esr_eval_disp",
+    "esr_mlp_packed_bf16_elems", "esr_mlp_pack_bf16", "esr_mlp_fwd_bf16", "esr_mlp_dgrad_bf16", "esr_mlp_wgrad_bf16",
 ]
 
 
@@ -95,6 +96,8 @@ def lib() -> C.CDLL:
         if hasattr(L, "esr_mlp_packed_floats"):
             L.esr_mlp_packed_floats.restype = C.c_int64
             L.esr_mlp_wgrad_scratch_floats.restype = C.c_int64
+        if hasattr(L, "esr_mlp_packed_bf16_elems"):
+            L.esr_mlp_packed_bf16_elems.restype = C.c_int64
         if L.esr_abi_version() != ABI_VERSION:
             raise RuntimeError("libesr_hip.so ABI version mismatch: rebuild")
         _lib = L

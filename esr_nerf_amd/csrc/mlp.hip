@@ -177,7 +177,9 @@ struct WgradArgs {
 // whole tile range and are flushed once with 128-B-contiguous float atomics.
 constexpr int LDS_STRIDE = 36;        // floats per staged row (32 samples + 4 pad)
 
-template <int MI, int NJ, int WM, int WN, int WK>
+// BF: bf16 operands (v_mfma_f32_32x32x16_bf16, 16 samples per k-step, values rounded on the way from LDS to the
+// operand registers), fp32 accumulation and fp32 staging -- the weight-gradient kernel of the bf16 configurations.
+template <int MI, int NJ, int WM, int WN, int WK, bool BF>
 __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradArgs W)
 {
     constexpr int NW = WM * WN * WK, NT = 64 * NW;
@@ -239,6 +241,33 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradAr
         }
     };
     auto compute = [&](int cur) {
+        if constexpr (BF) {
+            static_assert(WK <= 2, "a tile has two 16-sample k-steps");
+            constexpr int NU16 = 2 / WK;
+            const float *La = lds + cur * BUF + (wm * MI * 32 + rl) * LDS_STRIDE + 8 * h;
+            const float *Lb = lds + cur * BUF + (RAP + wn * NJ * 32 + rl) * LDS_STRIDE + 8 * h;
+#pragma unroll
+            for (int uu = 0; uu < NU16; ++uu) {
+                const int u = wk * NU16 + uu;
+                bf16x8 a[MI], b[NJ];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const float4 lo = *reinterpret_cast<const float4 *>(La + i * 32 * LDS_STRIDE + 16 * u);
+                    const float4 hi = *reinterpret_cast<const float4 *>(La + i * 32 * LDS_STRIDE + 16 * u + 4);
+                    bsum[i] += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
+                    a[i] = pack8(lo, hi);
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    b[j] = pack8(*reinterpret_cast<const float4 *>(Lb + j * 32 * LDS_STRIDE + 16 * u),
+                                 *reinterpret_cast<const float4 *>(Lb + j * 32 * LDS_STRIDE + 16 * u + 4));
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+            }
+            return;
+        }
         const float *La = lds + cur * BUF + (wm * MI * 32 + rl) * LDS_STRIDE + 4 * h;
         const float *Lb = lds + cur * BUF + (RAP + wn * NJ * 32 + rl) * LDS_STRIDE + 4 * h;
 #pragma unroll
@@ -338,7 +367,7 @@ int mlp_grid(int n_tiles)
     return wg;
 }
 
-template <int MI, int NJ, int WM, int WN, int WK>
+template <int MI, int NJ, int WM, int WN, int WK, bool BF = false>
 int launch_wgrad(const WgradArgs &W, int64_t slab_floats, hipStream_t s)
 {
     const int n_tiles = W.t1 - W.t0;
@@ -348,7 +377,7 @@ int launch_wgrad(const WgradArgs &W, int64_t slab_floats, hipStream_t s)
     constexpr size_t lds_bytes = 2 * (size_t)(WM * MI * 32 + WN * NJ * 32) * LDS_STRIDE * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {       // > 64 KB of dynamic LDS needs the opt-in
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_kernel<MI, NJ, WM, WN, WK>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_kernel<MI, NJ, WM, WN, WK, BF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -357,7 +386,7 @@ int launch_wgrad(const WgradArgs &W, int64_t slab_floats, hipStream_t s)
     if (grid > n_tiles) grid = n_tiles;
     const int n_elems = W.out_rows * W.ld;
     if ((int64_t)grid * WK * n_elems > slab_floats) return ESR_ECAP;
-    mlp_wgrad_kernel<MI, NJ, WM, WN, WK><<<grid, NT, lds_bytes, s>>>(W);
+    mlp_wgrad_kernel<MI, NJ, WM, WN, WK, BF><<<grid, NT, lds_bytes, s>>>(W);
     ESR_CHECK_LAUNCH();
     const int groups = (grid * WK + 31) / 32;
     wgrad_reduce_kernel<<<esr_grid_for((int64_t)n_elems * groups, 256, 2048), 256, 0, s>>>(W.slab, grid * WK,
@@ -457,10 +486,11 @@ ESR_API int esr_mlp_dgrad(int kind, const float *packed, const float *dz, int32_
 
 ESR_API int64_t esr_mlp_wgrad_scratch_floats(void) { return (int64_t)256 * 2 * 192 * 192; }
 
-ESR_API int esr_mlp_wgrad(int kind, const float *X, int color_row0, const float *const *H,
-                          const float *const *dZ, const float *dz, int32_t t0, int32_t t1,
-                          float *const *gw, float *const *gb, float *scratch, int64_t scratch_floats,
-                          void *stream)
+template <bool BF>
+static int wgrad_all(int kind, const float *X, int color_row0, const float *const *H,
+                     const float *const *dZ, const float *dz, int32_t t0, int32_t t1,
+                     float *const *gw, float *const *gb, float *scratch, int64_t scratch_floats,
+                     void *stream)
 {
     if (!kind_ok(kind) || t0 < 0 || t1 < t0) return ESR_EINVAL;
     if (!color_row_ok(kind, color_row0)) return ESR_EINVAL;
@@ -486,16 +516,32 @@ ESR_API int esr_mlp_wgrad(int kind, const float *X, int color_row0, const float 
         //   128-wide nets: 128x128 -> 2x2x1, 128x96 -> 2x1x2, 8x128 -> 1x2x2
         int rc;
         if (D.hid_tiles == 6) {
-            if (last) rc = launch_wgrad<1, 3, 1, 2, 2>(W, scratch_floats, s);
-            else if (first && W.RB <= 64) rc = launch_wgrad<3, 2, 2, 1, 2>(W, scratch_floats, s);   // tone mapper: 48 input rows
-            else if (first) rc = launch_wgrad<3, 3, 2, 1, 2>(W, scratch_floats, s);
-            else rc = launch_wgrad<3, 3, 2, 2, 1>(W, scratch_floats, s);
+            if (last) rc = launch_wgrad<1, 3, 1, 2, 2, BF>(W, scratch_floats, s);
+            else if (first && W.RB <= 64) rc = launch_wgrad<3, 2, 2, 1, 2, BF>(W, scratch_floats, s);   // tone mapper: 48 input rows
+            else if (first) rc = launch_wgrad<3, 3, 2, 1, 2, BF>(W, scratch_floats, s);
+            else rc = launch_wgrad<3, 3, 2, 2, 1, BF>(W, scratch_floats, s);
         } else {
-            if (last) rc = launch_wgrad<1, 2, 1, 2, 2>(W, scratch_floats, s);
-            else if (first) rc = launch_wgrad<2, 3, 2, 1, 2>(W, scratch_floats, s);
-            else rc = launch_wgrad<2, 2, 2, 2, 1>(W, scratch_floats, s);
+            if (last) rc = launch_wgrad<1, 2, 1, 2, 2, BF>(W, scratch_floats, s);
+            else if (first) rc = launch_wgrad<2, 3, 2, 1, 2, BF>(W, scratch_floats, s);
+            else rc = launch_wgrad<2, 2, 2, 2, 1, BF>(W, scratch_floats, s);
         }
         if (rc) return rc;
     }
     return 0;
+}
+
+ESR_API int esr_mlp_wgrad(int kind, const float *X, int color_row0, const float *const *H,
+                          const float *const *dZ, const float *dz, int32_t t0, int32_t t1,
+                          float *const *gw, float *const *gb, float *scratch, int64_t scratch_floats,
+                          void *stream)
+{
+    return wgrad_all<false>(kind, X, color_row0, H, dZ, dz, t0, t1, gw, gb, scratch, scratch_floats, stream);
+}
+
+ESR_API int esr_mlp_wgrad_bf16(int kind, const float *X, int color_row0, const float *const *H,
+                               const float *const *dZ, const float *dz, int32_t t0, int32_t t1,
+                               float *const *gw, float *const *gb, float *scratch, int64_t scratch_floats,
+                               void *stream)
+{
+    return wgrad_all<true>(kind, X, color_row0, H, dZ, dz, t0, t1, gw, gb, scratch, scratch_floats, stream);
 }

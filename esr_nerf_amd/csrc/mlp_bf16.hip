@@ -1,0 +1,360 @@
+// Tiny-MLP engine on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16) -- the build-side precision choice of
+// BASELINE.json's bf16 configurations (C3, C5; the reference itself is fp32 everywhere).
+//
+// Same networks, same "transposed" chain as mlp.hip (one wave owns 32 samples end to end, the accumulator of
+// layer l is the B operand of layer l+1), with bf16 OPERANDS and fp32 ACCUMULATION: weights are rounded to bf16
+// by esr_mlp_pack_bf16, activations are rounded when they become an MFMA operand (v_cvt_pk_bf16_f32), biases,
+// accumulators, saved activations, ReLU masks and every gradient buffer stay fp32 -- so the feature kernels,
+// the shading kernels and the buffers of the fp32 path are shared unchanged.
+//
+// A 32x32x16 bf16 MFMA takes 8 consecutive k values per lane (k block = lane >> 5).  Accumulator register r
+// of lane-half h holds row (r & 3) + 8 (r >> 2) + 4 h, so the 16 rows 16 jj .. 16 jj + 15 of a 32-row tile are
+// exactly registers 8 jj .. 8 jj + 7 of both halves: k-step j = 2 * tile + jj, slot i of half h <-> feature
+// 32 (j >> 1) + 16 (j & 1) + 4 h + (i & 3) + 8 (i >> 2).  That permutation is folded into the weight packing.
+//
+// Matrix time drops 16x against the f32 cores, so these kernels are bound by the activation traffic (reading
+// X, writing the saved H / dZ tiles) and by the L2 -> L1 weight stream, not by the MFMA pipe.
+#include "mlp_common.h"
+
+namespace {
+
+__host__ __device__ constexpr int kfeat16(int j, int h, int i)
+{
+    return 32 * (j >> 1) + 16 * (j & 1) + 4 * h + (i & 3) + 8 * (i >> 2);
+}
+
+// Packed bf16 buffer (elements).  Forward part of layer l: [ks][tiles_out][64 lanes][8]; transposed part
+// (dgrad): [kso][tiles_in][64][8].  Biases are read from the fp32 packed buffer of esr_mlp_pack.
+struct Pack16Layout {
+    int n_layers;
+    int ks[4], tiles_out[4], kso[4], tiles_in[4], in_dim[4], out_dim[4];
+    int64_t off_wf[4], off_wb[4];
+    int64_t total;
+};
+__host__ __device__ constexpr Pack16Layout pack16_layout(int kind)
+{
+    const NetDesc d = net_desc(kind);
+    Pack16Layout L = {};
+    L.n_layers = d.n_layers;
+    int64_t o = 0;
+    for (int l = 0; l < d.n_layers; ++l) {
+        const bool first = l == 0, last = l == d.n_layers - 1;
+        const int hid = 32 * d.hid_tiles;
+        L.ks[l] = first ? (2 * d.in_kp + 15) / 16 : hid / 16;
+        L.in_dim[l] = first ? d.in_dim : hid;
+        L.out_dim[l] = last ? d.out_dim : hid;
+        L.tiles_out[l] = last ? 1 : d.hid_tiles;
+        L.kso[l] = last ? 1 : hid / 16;
+        L.tiles_in[l] = first ? 2 : d.hid_tiles;
+        L.off_wf[l] = o; o += (int64_t)L.ks[l] * L.tiles_out[l] * 512;
+        L.off_wb[l] = o; o += (int64_t)L.kso[l] * L.tiles_in[l] * 512;
+    }
+    L.total = o;
+    return L;
+}
+
+struct Pack16Args {
+    int kind;
+    const float *w[4];
+    __bf16 *out;
+};
+
+__global__ void __launch_bounds__(256) pack16_kernel(Pack16Args A)
+{
+    const Pack16Layout L = pack16_layout(A.kind);
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < L.total; e += (int64_t)gridDim.x * blockDim.x) {
+        int l = 0;
+        while (l + 1 < L.n_layers && e >= L.off_wf[l + 1]) ++l;
+        const bool first = l == 0, last = l == L.n_layers - 1;
+        const float *W = A.w[l];
+        const int ind = L.in_dim[l], outd = L.out_dim[l];
+        float v = 0.f;
+        if (e < L.off_wb[l]) {                               // forward weights, order [k-step][out tile]
+            int64_t i = e - L.off_wf[l];
+            const int slot = i & 7; i >>= 3;
+            const int lane = i & 63; i >>= 6;
+            const int it = (int)(i % L.tiles_out[l]), j = (int)(i / L.tiles_out[l]);
+            const int h = lane >> 5, row = 32 * it + (lane & 31);
+            const int col = first ? in_colmap(A.kind, 16 * j + 8 * h + slot) : kfeat16(j, h, slot);
+            if (row < outd && col >= 0 && col < ind) v = W[(int64_t)row * ind + col];
+        } else {                                             // transposed weights, order [k-step][in tile]
+            int64_t i = e - L.off_wb[l];
+            const int slot = i & 7; i >>= 3;
+            const int lane = i & 63; i >>= 6;
+            const int it = (int)(i % L.tiles_in[l]), j = (int)(i / L.tiles_in[l]);
+            const int h = lane >> 5;
+            const int orow = last ? (8 * h + slot) : kfeat16(j, h, slot);      // output feature of layer l
+            const int irow = 32 * it + (lane & 31);                            // input feature / X row
+            const int col = first ? in_colmap(A.kind, irow) : irow;
+            if (orow < outd && col >= 0 && col < ind) v = W[(int64_t)orow * ind + col];
+        }
+        A.out[e] = (__bf16)v;
+    }
+}
+
+// registers 8 jj .. 8 jj + 7 of an accumulator tile, rounded to bf16: the B operand of k-step 2 * tile + jj
+__device__ __forceinline__ bf16x8 acc_to_b(const f32x16 &t, int jj)
+{
+    bf16x8 b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = (__bf16)t[8 * jj + i];
+    return b;
+}
+
+// acc[it] += W16[j][it] . B(j) for j < KS, it < NT.  One 16-B-per-lane load per MFMA, streamed G loads ahead.
+template <int KS, int NT, typename BF>
+__device__ __forceinline__ void stream_layer16(rsrc_t W, int woff, BF bget, f32x16 (&acc)[NT], int lane)
+{
+    constexpr int NTOT = KS * NT, G = 8, NG = (NTOT + G - 1) / G;
+    const int voff = lane * 16;
+    u32x4 buf[2][G];
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+        if (i < NTOT) buf[0][i] = __builtin_amdgcn_raw_buffer_load_b128(W, voff, woff + i * 1024, 0);
+    bf16x8 b = {};
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int n = (g + 1) * G + i;
+            if (n < NTOT) buf[(g + 1) & 1][i] = __builtin_amdgcn_raw_buffer_load_b128(W, voff, woff + n * 1024, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int n = g * G + i;
+            if (n < NTOT) {
+                const int j = n / NT, it = n % NT;
+                if (it == 0) b = bget(j);
+                acc[it] = mfma16(__builtin_bit_cast(bf16x8, buf[g & 1][i]), b, acc[it]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int NP, int NT>
+__device__ __forceinline__ void layer16_from_acc(rsrc_t W, int woff, const f32x16 (&prev)[NP], f32x16 (&acc)[NT], int lane)
+{
+    stream_layer16<2 * NP, NT>(W, woff, [&](int j) { return acc_to_b(prev[j >> 1], j & 1); }, acc, lane);
+}
+
+struct Fwd16Args {
+    const float *packed32;     // esr_mlp_pack buffer (biases)
+    const __bf16 *packed16;
+    const float *X;
+    int t0, t1;
+    float *H[3];
+    unsigned *M[3];
+    int save, crow;
+    float *zout;
+};
+
+template <int KIND>
+__global__ void __launch_bounds__(256, 2) mlp_fwd16_kernel(Fwd16Args A)
+{
+    constexpr NetDesc D = net_desc(KIND);
+    constexpr int NHID = D.n_layers - 1;
+    constexpr int HT = D.hid_tiles;
+    constexpr unsigned HBYTES = HT * 32 * 32 * 4, MBYTES = (HT / 2) * 256;
+    constexpr PackLayout L32 = pack_layout(KIND);
+    constexpr Pack16Layout L = pack16_layout(KIND);
+    constexpr int KS1 = L.ks[0];
+    const int lane = esr_lane();
+    const int h = lane >> 5, s = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const rsrc_t W32 = make_rsrc(A.packed32, (unsigned)(L32.total * 4));
+    const rsrc_t W16 = make_rsrc(A.packed16, (unsigned)(L.total * 2));
+    for (int t = A.t0 + wave; t < A.t1; t += nwaves) {
+        const rsrc_t RX = make_rsrc(A.X + (size_t)t * D.xrows * 32, D.xrows * 32 * 4);
+        const int xvoff = (h * 8 * 32 + s) * 4;
+        const int coff = A.crow * 128;
+        bf16x8 B1[KS1];
+#pragma unroll
+        for (int j = 0; j < KS1; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = 16 * j + 8 * h + i;                 // the net's colour group feeds rows < cw
+                B1[j][i] = (__bf16)bload1(RX, xvoff + (row < D.cw ? coff : 0), (16 * j + i) * 128);
+            }
+        f32x16 cur[HT];
+        load_bias<HT>(W32, (int)L32.off_bf[0] * 4, cur, lane);
+        stream_layer16<KS1, HT>(W16, (int)L.off_wf[0] * 2, [&](int j) { return B1[j]; }, cur, lane);
+        relu_tiles<HT>(cur);
+        if (A.save) {
+            store_tiles<HT>(make_rsrc(A.H[0] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
+            store_relu_mask<HT>(make_rsrc(A.M[0] + (size_t)t * (MBYTES / 4), MBYTES), cur, lane);
+        }
+#pragma unroll
+        for (int l = 1; l < NHID; ++l) {
+            f32x16 nxt[HT];
+            load_bias<HT>(W32, (int)L32.off_bf[l] * 4, nxt, lane);
+            layer16_from_acc<HT, HT>(W16, (int)L.off_wf[l] * 2, cur, nxt, lane);
+            relu_tiles<HT>(nxt);
+            if (A.save) {
+                store_tiles<HT>(make_rsrc(A.H[l] + (size_t)t * (HBYTES / 4), HBYTES), nxt, lane);
+                store_relu_mask<HT>(make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), nxt, lane);
+            }
+#pragma unroll
+            for (int it = 0; it < HT; ++it) cur[it] = nxt[it];
+        }
+        f32x16 out[1];
+        load_bias<1>(W32, (int)L32.off_bf[NHID] * 4, out, lane);
+        layer16_from_acc<HT, 1>(W16, (int)L.off_wf[NHID] * 2, cur, out, lane);
+        float *z = A.zout + (size_t)t * D.zrows * 32 + s;
+        if (D.zrows == 8) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[(4 * h + r) * 32] = out[0][r];
+        } else if (h == 0) {
+            z[0] = out[0][0]; z[32] = out[0][1]; z[64] = out[0][2]; z[96] = 0.f;
+        }
+    }
+}
+
+struct Dgrad16Args {
+    const __bf16 *packed16;
+    const float *dz;
+    int t0, t1;
+    const unsigned *M[3];
+    float *dZ[3];
+    float *dX;
+};
+
+template <int KIND>
+__global__ void __launch_bounds__(256, 2) mlp_dgrad16_kernel(Dgrad16Args A)
+{
+    constexpr NetDesc D = net_desc(KIND);
+    constexpr int NHID = D.n_layers - 1;
+    constexpr int HT = D.hid_tiles;
+    constexpr unsigned HBYTES = HT * 32 * 32 * 4, MBYTES = (HT / 2) * 256;
+    constexpr Pack16Layout L = pack16_layout(KIND);
+    const int lane = esr_lane();
+    const int h = lane >> 5, s = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const rsrc_t W16 = make_rsrc(A.packed16, (unsigned)(L.total * 2));
+    for (int t = A.t0 + wave; t < A.t1; t += nwaves) {
+        const float *dzt = A.dz + (size_t)t * D.zrows * 32 + s;
+        bf16x8 B0;                                                           // slot i of half h <-> dz row 8 h + i
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 8 * h + i;
+            B0[i] = (__bf16)((row < D.zrows) ? dzt[row * 32] : 0.f);
+        }
+        unsigned msk[NHID][HT / 2];
+#pragma unroll
+        for (int l = 0; l < NHID; ++l)
+            load_relu_mask<HT>(make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), msk[l], lane);
+        f32x16 cur[HT];
+        zero_tiles<HT>(cur);
+        stream_layer16<1, HT>(W16, (int)L.off_wb[NHID] * 2, [&](int) { return B0; }, cur, lane);
+        apply_relu_mask<HT>(msk[NHID - 1], cur);
+        store_tiles<HT>(make_rsrc(A.dZ[NHID - 1] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
+#pragma unroll
+        for (int l = NHID - 1; l >= 1; --l) {
+            f32x16 nxt[HT];
+            zero_tiles<HT>(nxt);
+            layer16_from_acc<HT, HT>(W16, (int)L.off_wb[l] * 2, cur, nxt, lane);
+            apply_relu_mask<HT>(msk[l - 1], nxt);
+            store_tiles<HT>(make_rsrc(A.dZ[l - 1] + (size_t)t * (HBYTES / 4), HBYTES), nxt, lane);
+#pragma unroll
+            for (int it = 0; it < HT; ++it) cur[it] = nxt[it];
+        }
+        f32x16 dx[2];
+        zero_tiles<2>(dx);
+        layer16_from_acc<HT, 2>(W16, (int)L.off_wb[0] * 2, cur, dx, lane);
+        store_tiles<2>(make_rsrc(A.dX + (size_t)t * 64 * 32, 64 * 32 * 4), dx, lane);
+    }
+}
+
+bool crow_ok(int kind, int crow)
+{
+    return kind == ESR_MLP_COARSE ? (crow == 0 || crow == 12) : (crow == 0 || crow == 88 || crow == 96);
+}
+
+int grid16(int n_tiles)
+{
+    int wg = (n_tiles + 3) / 4;
+    if (wg > 512) wg = 512;
+    return wg < 1 ? 1 : wg;
+}
+
+}  // namespace
+
+ESR_API int64_t esr_mlp_packed_bf16_elems(int kind)
+{
+    if (!kind_ok(kind)) return ESR_EINVAL;
+    return pack16_layout(kind).total;
+}
+
+ESR_API int esr_mlp_pack_bf16(int kind, const esr_mlp_weights_t *w, void *packed16, void *stream)
+{
+    if (!kind_ok(kind) || !w || !packed16) return ESR_EINVAL;
+    Pack16Args A = {};
+    A.kind = kind;
+    A.out = static_cast<__bf16 *>(packed16);
+    for (int l = 0; l < net_desc(kind).n_layers; ++l) {
+        if (!w->w[l]) return ESR_EINVAL;
+        A.w[l] = w->w[l];
+    }
+    pack16_kernel<<<esr_grid_for(pack16_layout(kind).total, 256, 1024), 256, 0, esr_stream(stream)>>>(A);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_mlp_fwd_bf16(int kind, const float *packed32, const void *packed16, const float *X, int32_t t0,
+                             int32_t t1, float *const *H, uint32_t *const *M, int save, int color_row0,
+                             float *zout, void *stream)
+{
+    if (!kind_ok(kind) || t0 < 0 || t1 < t0 || !crow_ok(kind, color_row0)) return ESR_EINVAL;
+    if (t1 == t0) return 0;
+    if (!packed32 || !packed16 || !X || !zout) return ESR_EINVAL;
+    const int nhid = net_desc(kind).n_layers - 1;
+    Fwd16Args A = {};
+    A.packed32 = packed32; A.packed16 = static_cast<const __bf16 *>(packed16); A.X = X; A.t0 = t0; A.t1 = t1;
+    A.save = save ? 1 : 0; A.crow = color_row0; A.zout = zout;
+    if (save) {
+        if (!H || !M) return ESR_EINVAL;
+        for (int l = 0; l < nhid; ++l) {
+            if (!H[l] || !M[l]) return ESR_EINVAL;
+            A.H[l] = H[l]; A.M[l] = M[l];
+        }
+    }
+    const int grid = grid16(t1 - t0);
+    hipStream_t s = esr_stream(stream);
+    switch (kind) {
+    case ESR_MLP_RADIANCE: mlp_fwd16_kernel<ESR_MLP_RADIANCE><<<grid, 256, 0, s>>>(A); break;
+    case ESR_MLP_TONEMAP:  mlp_fwd16_kernel<ESR_MLP_TONEMAP><<<grid, 256, 0, s>>>(A); break;
+    case ESR_MLP_BRDF:     mlp_fwd16_kernel<ESR_MLP_BRDF><<<grid, 256, 0, s>>>(A); break;
+    case ESR_MLP_EMIT:     mlp_fwd16_kernel<ESR_MLP_EMIT><<<grid, 256, 0, s>>>(A); break;
+    default:               mlp_fwd16_kernel<ESR_MLP_COARSE><<<grid, 256, 0, s>>>(A); break;
+    }
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_mlp_dgrad_bf16(int kind, const void *packed16, const float *dz, int32_t t0, int32_t t1,
+                               const uint32_t *const *M, float *const *dZ, float *dX, void *stream)
+{
+    if (!kind_ok(kind) || t0 < 0 || t1 < t0) return ESR_EINVAL;
+    if (t1 == t0) return 0;
+    if (!packed16 || !dz || !M || !dZ || !dX) return ESR_EINVAL;
+    const int nhid = net_desc(kind).n_layers - 1;
+    Dgrad16Args A = {};
+    A.packed16 = static_cast<const __bf16 *>(packed16); A.dz = dz; A.t0 = t0; A.t1 = t1; A.dX = dX;
+    for (int l = 0; l < nhid; ++l) {
+        if (!M[l] || !dZ[l]) return ESR_EINVAL;
+        A.M[l] = M[l]; A.dZ[l] = dZ[l];
+    }
+    const int grid = grid16(t1 - t0);
+    hipStream_t s = esr_stream(stream);
+    switch (kind) {
+    case ESR_MLP_RADIANCE: mlp_dgrad16_kernel<ESR_MLP_RADIANCE><<<grid, 256, 0, s>>>(A); break;
+    case ESR_MLP_TONEMAP:  mlp_dgrad16_kernel<ESR_MLP_TONEMAP><<<grid, 256, 0, s>>>(A); break;
+    case ESR_MLP_BRDF:     mlp_dgrad16_kernel<ESR_MLP_BRDF><<<grid, 256, 0, s>>>(A); break;
+    case ESR_MLP_EMIT:     mlp_dgrad16_kernel<ESR_MLP_EMIT><<<grid, 256, 0, s>>>(A); break;
+    default:               mlp_dgrad16_kernel<ESR_MLP_COARSE><<<grid, 256, 0, s>>>(A); break;
+    }
+    ESR_CHECK_LAUNCH();
+    return 0;
+}

@@ -343,4 +343,18 @@ __device__ __forceinline__ void zero_tiles(f32x16 (&acc)[NT])
         for (int r = 0; r < 16; ++r) acc[it][r] = 0.f;
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8 pack8(float4 lo, float4 hi)
+{
+    bf16x8 v;
+    v[0] = (__bf16)lo.x; v[1] = (__bf16)lo.y; v[2] = (__bf16)lo.z; v[3] = (__bf16)lo.w;
+    v[4] = (__bf16)hi.x; v[5] = (__bf16)hi.y; v[6] = (__bf16)hi.z; v[7] = (__bf16)hi.w;
+    return v;
+}
+
 }  // namespace

@@ -274,6 +274,25 @@ int esr_mlp_wgrad(int kind, const float *X, int color_row0, const float *const *
                   void *stream);
 
 /*
+ * bf16 variants of the MLP engine for BASELINE.json's bf16 configurations (a build-side precision choice:
+ * the reference is fp32 everywhere): bf16 MFMA OPERANDS (v_mfma_f32_32x32x16_bf16), fp32 accumulation;
+ * weights are rounded by esr_mlp_pack_bf16, activations when they become an operand; biases (read from
+ * the esr_mlp_pack buffer), saved activations H, masks M and all gradient buffers stay fp32 with the layouts
+ * above, so the feature / shading kernels are shared.  packed16: esr_mlp_packed_bf16_elems(kind) bf16 values.
+ */
+int64_t esr_mlp_packed_bf16_elems(int kind);
+int esr_mlp_pack_bf16(int kind, const esr_mlp_weights_t *w, void *packed16, void *stream);
+int esr_mlp_fwd_bf16(int kind, const float *packed32, const void *packed16, const float *X, int32_t t0,
+                     int32_t t1, float *const *H, uint32_t *const *M, int save, int color_row0,
+                     float *zout, void *stream);
+int esr_mlp_dgrad_bf16(int kind, const void *packed16, const float *dz, int32_t t0, int32_t t1,
+                       const uint32_t *const *M, float *const *dZ, float *dX, void *stream);
+int esr_mlp_wgrad_bf16(int kind, const float *X, int color_row0, const float *const *H,
+                       const float *const *dZ, const float *dz, int32_t t0, int32_t t1,
+                       float *const *gw, float *const *gb, float *scratch, int64_t scratch_floats,
+                       void *stream);
+
+/*
  * Between the nets: lin = softplus(z_off) (+ softplus(z_emo) on on-tiles);
  * Xt [tiles,48,32] = [lin3 | sin15 | cos15 | 0...] (voxurff.py:783-788).
  */

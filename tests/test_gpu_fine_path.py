@@ -352,3 +352,97 @@ def test_forward_evaluate_all_miss():
             pos_rt=torch.eye(3).cuda())
     assert float(res["srgb/rgb"].abs().max()) == 0.0 and torch.equal(res["etc/white_bg"].cpu(), torch.ones(16, 1))
     assert rel_err(res["etc/disp"], torch.full((16,), 1.0 / sc.far)) < 1e-6
+
+
+@pytest.mark.parametrize("kind,tiles,crow", [(0, 5, 0), (0, 300, 88), (1, 70, 0), (2, 33, 96), (3, 9, 88), (4, 40, 12)])
+def test_mlp_engine_bf16_vs_emulation(kind, tiles, crow):
+    """bf16-operand / fp32-accumulate MLP kernels (fwd, dgrad, wgrad) against a torch emulation of exactly that
+    arithmetic: weights rounded to bf16 once, activations / gradients rounded where they become an MFMA operand,
+    sums in fp32.  Tolerance 2e-3 of the max-norm (a value that sits on a bf16 rounding boundary may round the
+    other way under a different fp32 summation order)."""
+    from esr_nerf_amd import _lib
+    from esr_nerf_amd.fine_engine import FineEngine
+    eng = FineEngine("cuda:0")
+    L = eng.L
+    g = torch.Generator().manual_seed(kind * 77 + tiles)
+    n = NET[kind]
+    in_dim, xrows, nl, hid, nout, zrows = n["in_dim"], n["xrows"], n["nl"], n["hid"], n["out"], n["zrows"]
+    cw = n.get("cw", 6)
+    dims = [in_dim] + [hid] * (nl - 1) + [nout]
+    Ws = [torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5 for i in range(nl)]
+    Bs = [torch.randn(dims[i + 1], generator=g) * 0.1 for i in range(nl)]
+    X = torch.randn(tiles, xrows, 32, generator=g)
+    rows = [r for r in range(min(xrows, 96)) if _in_colmap(kind, r) >= 0]
+    cols = [_in_colmap(kind, r) for r in rows]
+    src_rows = [r + crow if r < cw else r for r in rows]
+    x = torch.zeros(tiles * 32, in_dim)
+    x[:, cols] = X[:, src_rows, :].permute(0, 2, 1).reshape(tiles * 32, len(rows))
+    bf = lambda t: t.bfloat16().float()
+    Wb = [bf(w) for w in Ws]
+    hs, pre, a = [], [], x
+    for i in range(nl):
+        zz = bf(a) @ Wb[i].T + Bs[i]
+        if i + 1 < nl:
+            pre.append(zz)
+            a = torch.relu(zz)
+            hs.append(a)
+    z_ref = zz
+    dz = torch.randn(tiles * 32, nout, generator=g)
+    knife = torch.zeros(tiles * 32, dtype=torch.bool)
+    for p_ in pre:
+        knife |= (p_.abs() < 1e-4).any(-1)
+    dz[knife] = 0
+    # backward emulation
+    gW, gB, dA = [None] * nl, [None] * nl, dz
+    dZs = [None] * (nl - 1)
+    for i in range(nl - 1, -1, -1):
+        inp = x if i == 0 else hs[i - 1]
+        gW[i] = bf(dA).T @ bf(inp)
+        gB[i] = dA.sum(0)
+        d_in = bf(dA) @ Wb[i]
+        if i > 0:
+            dA = d_in * (pre[i - 1] > 0)
+            dZs[i - 1] = dA
+        else:
+            dx_ref = d_in
+
+    def tm(t, rows_):
+        return t.reshape(tiles, 32, rows_).permute(0, 2, 1).contiguous()
+
+    s = _lib.stream_ptr("cuda:0")
+    packed = torch.empty(L.esr_mlp_packed_floats(kind), device="cuda")
+    packed16 = torch.empty(L.esr_mlp_packed_bf16_elems(kind), dtype=torch.bfloat16, device="cuda")
+    w = _lib.EsrMlpWeights()
+    keep = [(a_.cuda().contiguous(), b_.cuda().contiguous()) for a_, b_ in zip(Ws, Bs)]
+    for i, (a_, b_) in enumerate(keep):
+        w.w[i], w.b[i] = a_.data_ptr(), b_.data_ptr()
+    _lib.check(L.esr_mlp_pack(kind, C.byref(w), _lib.ptr(packed), s), "pack")
+    _lib.check(L.esr_mlp_pack_bf16(kind, C.byref(w), _lib.ptr(packed16), s), "pack16")
+    Xd = X.cuda().contiguous()
+    Hd = [torch.zeros(tiles, hid, 32, device="cuda") for _ in range(nl - 1)]
+    Md = [torch.zeros(tiles, hid // 64, 64, dtype=torch.int32, device="cuda") for _ in range(nl - 1)]
+    zout = torch.full((tiles, zrows, 32), 7.0, device="cuda")
+    _lib.check(L.esr_mlp_fwd_bf16(kind, _lib.ptr(packed), _lib.ptr(packed16), _lib.ptr(Xd), 0, tiles, _lib.ptr_array(Hd),
+                                  _lib.ptr_array(Md), 1, crow, _lib.ptr(zout), s), "fwd16")
+    T16 = 2e-3
+    assert rel_err(zout[:, :nout], tm(z_ref, nout)) < T16
+    for a_, b_ in zip(Hd, hs):
+        assert rel_err(a_, tm(b_, hid)) < T16
+    dzd = torch.zeros(tiles, zrows, 32, device="cuda")
+    dzd[:, :nout] = tm(dz, nout).cuda()
+    dZd = [torch.zeros(tiles, hid, 32, device="cuda") for _ in range(nl - 1)]
+    dXd = torch.zeros(tiles, 64, 32, device="cuda")
+    _lib.check(L.esr_mlp_dgrad_bf16(kind, _lib.ptr(packed16), _lib.ptr(dzd), 0, tiles, _lib.ptr_array(Md),
+                                    _lib.ptr_array(dZd), _lib.ptr(dXd), s), "dgrad16")
+    for a_, b_ in zip(dZd, dZs):
+        assert rel_err(a_, tm(b_, hid)) < T16
+    rows64 = [r for r in rows if r < 64]
+    assert rel_err(dXd[:, rows64].cpu(), tm(dx_ref, in_dim)[:, [_in_colmap(kind, r) for r in rows64]]) < T16
+    gw = [torch.zeros_like(w_).cuda() for w_ in Ws]
+    gb = [torch.zeros_like(b_).cuda() for b_ in Bs]
+    _lib.check(L.esr_mlp_wgrad_bf16(kind, _lib.ptr(Xd), crow, _lib.ptr_array(Hd), _lib.ptr_array(dZd), _lib.ptr(dzd), 0,
+                                    tiles, _lib.ptr_array(gw), _lib.ptr_array(gb), _lib.ptr(eng.wgrad_scratch),
+                                    C.c_int64(eng.wgrad_scratch.numel()), s), "wgrad16")
+    for i in range(nl):
+        assert rel_err(gw[i], gW[i]) < T16, ("gw", i, rel_err(gw[i], gW[i]))
+        assert rel_err(gb[i], gB[i]) < 1e-4, ("gb", i)
