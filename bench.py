@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TF = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, Peak FP32 (matrix)
+MFMA_BF16_PEAK_TF = 2500.0        # same guide, dense BF16 MFMA
 RAD_MAC = 85 * 192 + 192 * 192 * 2 + 192 * 3          # RadianceNet MACs per sample (pbr/module.py:6-21)
 TONE_MAC = 33 * 192 + 192 * 3                          # TonemapNet MACs per sample
 DGRAD_RAD_MAC = 3 * 192 + 192 * 192 * 2 + 192 * 43     # dX needs only the 43 grid-fed columns
@@ -47,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="MLP operand type: f32 (f32 matrix cores, the headline) or bf16 (bf16 operands, fp32 accumulation)")
     ap.add_argument("--no-optimizer", action="store_true", help="skip the separately reported fused-Adam timing")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not bracket kernels with HIP events (drops the roofline object)")
@@ -68,6 +71,24 @@ def algorithmic_flops(name, counts):
         "mlp_wgrad(emo)": 2 * RAD_MAC * n_on,
         "mlp_wgrad(off)": 2 * RAD_MAC * n_off,
         "mlp_wgrad(tone)": 2 * TONE_MAC * (n_on + n_off),
+    }
+    return table.get(name)
+
+
+def algorithmic_bytes(name, counts):
+    """Algorithmic HBM bytes of one launch of a named MLP kernel in bf16 mode, where the matrix work is 16x cheaper
+    and the activation traffic binds: inputs read + saved activations / gradients written (fp32 storage), per
+    surviving sample, padding excluded."""
+    n_on, n_off = counts["n_on"], counts["n_off"]
+    H3 = 3 * 192 * 4
+    table = {
+        "mlp_fwd(off|on-tiles)": (85 * 4 + 12) * n_on,
+        "mlp_fwd(off)": (85 * 4 + H3 + 12) * n_off,
+        "mlp_fwd(emo)": (85 * 4 + H3 + 12) * n_on,
+        "mlp_fwd(tone)": (33 * 4 + 192 * 4 + 12) * (n_on + n_off),
+        "mlp_dgrad(emo)": (12 + H3 + 43 * 4) * n_on,
+        "mlp_dgrad(off)": (12 + H3 + 43 * 4) * n_off,
+        "mlp_dgrad(tone)": (12 + 192 * 4 + 3 * 4) * (n_on + n_off),
     }
     return table.get(name)
 
@@ -220,6 +241,7 @@ def main():
             cfg, scene.near, scene.far, scene.xyz_min, scene.xyz_max, scene.xyz_min,
             scene.xyz_max, scene.mask_alpha_init, scene.mask_density, scene.s_val, scene.num_voxels)
     init_slab_model(model, scene)
+    model.mlp_dtype = a.dtype
     model.train()
     batch = {k: v.to(dev) for k, v in scene.batch.items()}
     n_rays = scene.n_rays
@@ -306,11 +328,11 @@ def main():
         c = CONFIGS[a.config]
         samples = int(round(c["res"] * c["z"] * 2))
         out = {
-            "metric": "training rays/sec at 4096 rays x 128 samples (fine stage)" if (a.config, stage) == ("C2", "fine")
-                      else f"training rays/sec, config {a.config}, {stage} stage",
+            "metric": "training rays/sec at 4096 rays x 128 samples (fine stage)" if (a.config, stage, a.dtype) == ("C2", "fine", "f32")
+                      else f"training rays/sec, config {a.config}, {stage} stage, {a.dtype} MLPs",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {
                 "workload": f"{a.config}: giftbox_w {stage} stage on the slab scene, {n_rays} rays x {samples} "
                             f"samples per GPU, grid {'x'.join(str(int(v)) for v in model.world_size.tolist())}, "
@@ -331,6 +353,7 @@ def main():
             ms = sum(kern[c][1] for c in dom_calls if c in kern)
             flops_total = sum(algorithmic_flops(c, counts) * kern[c][0] for c in dom_calls if c in kern)
             ach = flops_total / (ms * 1e-3) / 1e12
+            bytes_total = sum((algorithmic_bytes(c, counts) or 0) * kern[c][0] for c in dom_calls if c in kern)
             traffic = None
             side = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(side):
@@ -349,6 +372,11 @@ def main():
                 "algorithmic_gflop_per_launch": flops_total / launches / 1e9,
                 "share_of_kernel_time": sum(breakdown[c][1] for c in dom_calls if c in breakdown) / total_ms,
             }
+            if a.dtype == "bf16":                  # bf16 operands: the activation traffic, not the MFMA pipe, binds
+                gbs = bytes_total / (ms * 1e-3) / 1e9
+                out["roofline"].update({"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                                        "algorithmic_mb_per_launch": bytes_total / launches / 1e6,
+                                        "mfma_tflops": ach, "mfma_frac_of_bf16_peak": ach / MFMA_BF16_PEAK_TF})
             # the whole MLP engine (all 10 calls per step), from the instrumented warm-up steps
             mlp = {k: v for k, v in breakdown.items() if algorithmic_flops(k, counts)}
             mf = sum(algorithmic_flops(k, counts) * v[0] for k, v in mlp.items())

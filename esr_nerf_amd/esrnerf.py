@@ -196,7 +196,7 @@ class ESRNeRF(VoxurfF):
             if not str(self.device).startswith("cuda"):
                 raise RuntimeError("ESRNeRF.forward_training runs on libesr_hip.so and needs a GPU device "
                                    "(there is no CPU fallback)")
-            self._engine = LtsEngine(self.device)
+            self._engine = LtsEngine(self.device, getattr(self, "mlp_dtype", "f32"))
         return self._engine
 
     def scene_struct(self, near=None):

@@ -94,8 +94,15 @@ class _Workspace:
 
 
 class FineEngine:
-    def __init__(self, device):
+    def __init__(self, device, mlp_dtype: str = "f32"):
+        """``mlp_dtype``: "f32" (f32 matrix cores; BASELINE configs C2, C4) or "bf16" (bf16 MFMA operands with fp32
+        accumulation for the MLPs only -- the build-side precision choice of C3 / C5; everything else stays fp32)."""
+        if mlp_dtype not in ("f32", "bf16"):
+            raise ValueError("mlp_dtype must be 'f32' or 'bf16'")
         self.device = torch.device(device)
+        self.bf16 = mlp_dtype == "bf16"
+        self.packed16: Dict[str, torch.Tensor] = {}
+        self._p16: Dict[int, C.c_void_p] = {}
         self.L = _lib.lib()
         self.ws = _Workspace(self.device)
         self.plan_dev = torch.zeros(8, dtype=torch.int32, device=self.device)
@@ -159,6 +166,27 @@ class FineEngine:
                 raise RuntimeError("MLP parameters must be contiguous fp32 device tensors")
             w.w[i], w.b[i] = a.data_ptr(), b.data_ptr()
         self._run(f"mlp_pack({which})", self.L.esr_mlp_pack, kind, C.byref(w), _lib.ptr(self.packed[which]), self._s())
+        if self.bf16:
+            n16 = self.L.esr_mlp_packed_bf16_elems(kind)
+            if which not in self.packed16 or self.packed16[which].numel() != n16:
+                self.packed16[which] = torch.empty(n16, dtype=torch.bfloat16, device=self.device)
+            self._p16[self.packed[which].data_ptr()] = _lib.ptr(self.packed16[which])
+            self._run(f"mlp_pack16({which})", self.L.esr_mlp_pack_bf16, kind, C.byref(w), _lib.ptr(self.packed16[which]),
+                      self._s())
+
+    # the three MLP entry points with the fp32 signatures; in bf16 mode the packed fp32 pointer selects its bf16 twin
+    def mlp_fwd(self, kind, packed, *rest):
+        if not self.bf16:
+            return self.L.esr_mlp_fwd(kind, packed, *rest)
+        return self.L.esr_mlp_fwd_bf16(kind, packed, self._p16[packed.value], *rest)
+
+    def mlp_dgrad(self, kind, packed, *rest):
+        if not self.bf16:
+            return self.L.esr_mlp_dgrad(kind, packed, *rest)
+        return self.L.esr_mlp_dgrad_bf16(kind, self._p16[packed.value], *rest)
+
+    def mlp_wgrad(self, *args):
+        return (self.L.esr_mlp_wgrad_bf16 if self.bf16 else self.L.esr_mlp_wgrad)(*args)
 
     def _H(self, names):
         return _lib.ptr_array([self.ws[n] for n in names])
@@ -220,15 +248,15 @@ class FineEngine:
         ctx.feat_args = fa
         H, M = self._H(["H0", "H1", "H2"]), self._H(["M0", "M1", "M2"])
         # off net: detached pass on the on-tiles (alt colour rows, nothing saved), saved pass on the off-tiles
-        self._run("mlp_fwd(off|on-tiles)", L.esr_mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), 0, tiles_on,
+        self._run("mlp_fwd(off|on-tiles)", self.mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), 0, tiles_on,
                                  H, M, 0, 88, _lib.ptr(ws["z_off"]), s)
-        self._run("mlp_fwd(off)", L.esr_mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), tiles_on,
+        self._run("mlp_fwd(off)", self.mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), tiles_on,
                                  tiles_all, H, M, 1, 0, _lib.ptr(ws["z_off"]), s)
-        self._run("mlp_fwd(emo)", L.esr_mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["emo"]), _lib.ptr(ws["X"]), 0, tiles_on,
+        self._run("mlp_fwd(emo)", self.mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["emo"]), _lib.ptr(ws["X"]), 0, tiles_on,
                                  H, M, 1, 0, _lib.ptr(ws["z_emo"]), s)
         self._run("tone_in_fwd", L.esr_fine_tone_in_fwd, _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), tiles_on, tiles_all,
                                           _lib.ptr(ws["lin"]), _lib.ptr(ws["Xt"]), s)
-        self._run("mlp_fwd(tone)", L.esr_mlp_fwd, KIND_TONEMAP, _lib.ptr(self.packed["tone"]), _lib.ptr(ws["Xt"]), 0, tiles_all,
+        self._run("mlp_fwd(tone)", self.mlp_fwd, KIND_TONEMAP, _lib.ptr(self.packed["tone"]), _lib.ptr(ws["Xt"]), 0, tiles_all,
                                  self._H(["Ht"]), self._H(["Mt"]), 1, 0, _lib.ptr(ws["zt"]), s)
         self._run("composite_fwd", L.esr_fine_composite_fwd, _lib.ptr(ws["zt"]), _lib.ptr(ws["lin"]), _lib.ptr(ws["rec_ray"]),
                                             _lib.ptr(ws["rec_w"]), tiles_all, _lib.ptr(ws["rgb"]),
@@ -273,12 +301,12 @@ class FineEngine:
             self._run("feat_fwd", L.esr_fine_feat_fwd, sp, C.byref(fa), _lib.ptr(ws["X"]), _lib.ptr(ws["gnorm"]), s)
             H, M = self._H(["H0", "H1", "H2"]), self._H(["M0", "M1", "M2"])
             for net, crow, z in (("off", 0, "z_off"), ("emo", 88, "z_emo")):
-                self._run(f"mlp_fwd({net})", L.esr_mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed[net]), _lib.ptr(ws["X"]), 0, T,
+                self._run(f"mlp_fwd({net})", self.mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed[net]), _lib.ptr(ws["X"]), 0, T,
                           H, M, 0, crow, _lib.ptr(ws[z]), s)
             for name, za, zb, ton in (("off", "z_off", "z_emo", 0), ("emo", "z_emo", "z_emo", 0), ("on", "z_off", "z_emo", T)):
                 self._run("tone_in_fwd", L.esr_fine_tone_in_fwd, _lib.ptr(ws[za]), _lib.ptr(ws[zb]), ton, T,
                           _lib.ptr(ws["lin"]), _lib.ptr(ws["Xt"]), s)
-                self._run("mlp_fwd(tone)", L.esr_mlp_fwd, KIND_TONEMAP, _lib.ptr(self.packed["tone"]), _lib.ptr(ws["Xt"]), 0, T,
+                self._run("mlp_fwd(tone)", self.mlp_fwd, KIND_TONEMAP, _lib.ptr(self.packed["tone"]), _lib.ptr(ws["Xt"]), 0, T,
                           self._H(["Ht"]), self._H(["Mt"]), 0, 0, _lib.ptr(ws["zt"]), s)
                 self._run("composite_fwd", L.esr_fine_composite_fwd, _lib.ptr(ws["zt"]), _lib.ptr(ws["lin"]),
                           _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), T, _lib.ptr(ws["rgb"]),
@@ -319,7 +347,7 @@ class FineEngine:
                                                 _lib.ptr(ws["lin"]), _lib.ptr(ws["rec_ray"]),
                                                 _lib.ptr(ws["rec_w"]), ta, _lib.ptr(ws["dweight"]),
                                                 _lib.ptr(ws["dzt"]), s)
-            self._run("mlp_dgrad(tone)", L.esr_mlp_dgrad, KIND_TONEMAP, _lib.ptr(self.packed["tone"]), _lib.ptr(ws["dzt"]), 0, ta,
+            self._run("mlp_dgrad(tone)", self.mlp_dgrad, KIND_TONEMAP, _lib.ptr(self.packed["tone"]), _lib.ptr(ws["dzt"]), 0, ta,
                                        self._H(["Mt"]), self._H(["dZt"]), _lib.ptr(ws["dXt"]), s)
             self._run("tone_in_bwd", L.esr_fine_tone_in_bwd, _lib.ptr(ws["dXt"]), _lib.ptr(g_lin), _lib.ptr(ws["lin"]),
                                               _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]),
@@ -328,9 +356,9 @@ class FineEngine:
             H, dZ = self._H(["H0", "H1", "H2"]), self._H(["dZ0", "dZ1", "dZ2"])
             M = self._H(["M0", "M1", "M2"])
             sc = (_lib.ptr(self.wgrad_scratch), C.c_int64(self.wgrad_scratch.numel()))
-            self._run("mlp_dgrad(emo)", L.esr_mlp_dgrad, KIND_RADIANCE, _lib.ptr(self.packed["emo"]), _lib.ptr(ws["dz"]), 0, to,
+            self._run("mlp_dgrad(emo)", self.mlp_dgrad, KIND_RADIANCE, _lib.ptr(self.packed["emo"]), _lib.ptr(ws["dz"]), 0, to,
                                        M, dZ, _lib.ptr(ws["dX"]), s)
-            self._run("mlp_dgrad(off)", L.esr_mlp_dgrad, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["dz"]), to, ta,
+            self._run("mlp_dgrad(off)", self.mlp_dgrad, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["dz"]), to, ta,
                                        M, dZ, _lib.ptr(ws["dX"]), s)
             src = (_lib.EsrFeatBwdSrc * 1)()
             src[0].dX = ws["dX"].data_ptr()
@@ -350,12 +378,12 @@ class FineEngine:
         if after_grids is not None:
             after_grids()
         if ta > 0:
-            self._run("mlp_wgrad(tone)", L.esr_mlp_wgrad, KIND_TONEMAP, _lib.ptr(ws["Xt"]), 0, self._H(["Ht"]), self._H(["dZt"]),
+            self._run("mlp_wgrad(tone)", self.mlp_wgrad, KIND_TONEMAP, _lib.ptr(ws["Xt"]), 0, self._H(["Ht"]), self._H(["dZt"]),
                                        _lib.ptr(ws["dzt"]), 0, ta, _lib.ptr_array(grads["tone_w"]),
                                        _lib.ptr_array(grads["tone_b"]), *sc, s)
-            self._run("mlp_wgrad(emo)", L.esr_mlp_wgrad, KIND_RADIANCE, _lib.ptr(ws["X"]), 0, H, dZ, _lib.ptr(ws["dz"]), 0, to,
+            self._run("mlp_wgrad(emo)", self.mlp_wgrad, KIND_RADIANCE, _lib.ptr(ws["X"]), 0, H, dZ, _lib.ptr(ws["dz"]), 0, to,
                                        _lib.ptr_array(grads["emo_w"]), _lib.ptr_array(grads["emo_b"]), *sc, s)
-            self._run("mlp_wgrad(off)", L.esr_mlp_wgrad, KIND_RADIANCE, _lib.ptr(ws["X"]), 0, H, dZ, _lib.ptr(ws["dz"]), to, ta,
+            self._run("mlp_wgrad(off)", self.mlp_wgrad, KIND_RADIANCE, _lib.ptr(ws["X"]), 0, H, dZ, _lib.ptr(ws["dz"]), to, ta,
                                        _lib.ptr_array(grads["off_w"]), _lib.ptr_array(grads["off_b"]), *sc, s)
 
     # -- fused trainer-step loss (app/fine/fine.py:355-382) ------------------------

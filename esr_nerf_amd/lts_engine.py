@@ -86,8 +86,8 @@ class LtsCtx:
 
 
 class LtsEngine(FineEngine):
-    def __init__(self, device):
-        super().__init__(device)
+    def __init__(self, device, mlp_dtype: str = "f32"):
+        super().__init__(device, mlp_dtype)
         self.prim = Pass(self.device, "primary")
         self.pts = Pass(self.device, "points")
         self.sec = Pass(self.device, "secondary")
@@ -171,7 +171,7 @@ class LtsEngine(FineEngine):
         z = P.buf(f"{net}.z", zrows)
         x = P.bufs["Xt"] if kind == KIND_TONEMAP else P.bufs["X"]
         if t1 > t0:
-            self._run(f"mlp_fwd({net})[{P.name}]", self.L.esr_mlp_fwd, kind, _lib.ptr(self.packed[net]),
+            self._run(f"mlp_fwd({net})[{P.name}]", self.mlp_fwd, kind, _lib.ptr(self.packed[net]),
                       _lib.ptr(x), t0, t1, _lib.ptr_array(H), _lib.ptr_array(M), 1 if save else 0, crow,
                       _lib.ptr(z), self._s())
         return z
@@ -186,9 +186,9 @@ class LtsEngine(FineEngine):
         x = P.bufs["Xt"] if kind == KIND_TONEMAP else P.bufs["X"]
         if t1 > t0:
             s = self._s()
-            self._run(f"mlp_dgrad({net})[{P.name}]", self.L.esr_mlp_dgrad, kind, _lib.ptr(self.packed[net]),
+            self._run(f"mlp_dgrad({net})[{P.name}]", self.mlp_dgrad, kind, _lib.ptr(self.packed[net]),
                       _lib.ptr(dz), t0, t1, _lib.ptr_array(M), _lib.ptr_array(dZ), _lib.ptr(dX), s)
-            self._run(f"mlp_wgrad({net})[{P.name}]", self.L.esr_mlp_wgrad, kind, _lib.ptr(x), crow,
+            self._run(f"mlp_wgrad({net})[{P.name}]", self.mlp_wgrad, kind, _lib.ptr(x), crow,
                       _lib.ptr_array(H), _lib.ptr_array(dZ), _lib.ptr(dz), t0, t1, _lib.ptr_array(gw),
                       _lib.ptr_array(gb), _lib.ptr(self.wgrad_scratch), C.c_int64(self.wgrad_scratch.numel()), s)
         return dX

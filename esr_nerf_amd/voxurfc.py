@@ -29,8 +29,8 @@ XC_ROWS, HID = 72, 128
 class CoarseEngine(FineEngine):
     """Kernel driver of one coarse training step (grow-only tile-major workspace, one host sync)."""
 
-    def __init__(self, device):
-        super().__init__(device)
+    def __init__(self, device, mlp_dtype: str = "f32"):
+        super().__init__(device, mlp_dtype)
         for k in ("off", "emo"):
             self.packed[k] = torch.empty(self.L.esr_mlp_packed_floats(KIND_COARSE), dtype=torch.float32,
                                          device=self.device)
@@ -101,7 +101,7 @@ class CoarseEngine(FineEngine):
                   _lib.ptr(emo_color), _lib.ptr(b["X"]), _lib.ptr(b["gnorm"]), s)
         for net, crow, t1 in (("off", 0, T), ("emo", 12, Ton)):
             if t1:
-                self._run(f"mlp_fwd({net})", L.esr_mlp_fwd, KIND_COARSE, _lib.ptr(self.packed[net]), _lib.ptr(b["X"]),
+                self._run(f"mlp_fwd({net})", self.mlp_fwd, KIND_COARSE, _lib.ptr(self.packed[net]), _lib.ptr(b["X"]),
                           0, t1, _lib.ptr_array([b[f"{net}.H0"], b[f"{net}.H1"]]),
                           _lib.ptr_array([b[f"{net}.M0"], b[f"{net}.M1"]]), 1, crow, _lib.ptr(b[f"{net}.z"]), s)
         self._run("shade_fwd", L.esr_coarse_shade_fwd, _lib.ptr(b["off.z"]), _lib.ptr(b["emo.z"]),
@@ -129,9 +129,9 @@ class CoarseEngine(FineEngine):
                 H = _lib.ptr_array([b[f"{net}.H0"], b[f"{net}.H1"]])
                 M = _lib.ptr_array([b[f"{net}.M0"], b[f"{net}.M1"]])
                 dZ = _lib.ptr_array([b[f"{net}.dZ0"], b[f"{net}.dZ1"]])
-                self._run(f"mlp_dgrad({net})", L.esr_mlp_dgrad, KIND_COARSE, _lib.ptr(self.packed[net]),
+                self._run(f"mlp_dgrad({net})", self.mlp_dgrad, KIND_COARSE, _lib.ptr(self.packed[net]),
                           _lib.ptr(b[f"{net}.dz"]), 0, t1, M, dZ, _lib.ptr(b[f"{net}.dX"]), s)
-                self._run(f"mlp_wgrad({net})", L.esr_mlp_wgrad, KIND_COARSE, _lib.ptr(b["X"]), crow, H, dZ,
+                self._run(f"mlp_wgrad({net})", self.mlp_wgrad, KIND_COARSE, _lib.ptr(b["X"]), crow, H, dZ,
                           _lib.ptr(b[f"{net}.dz"]), 0, t1, _lib.ptr_array(grads[f"{net}_w"]),
                           _lib.ptr_array(grads[f"{net}_b"]), _lib.ptr(self.wgrad_scratch),
                           C.c_int64(self.wgrad_scratch.numel()), s)
@@ -243,7 +243,7 @@ class VoxurfC(nn.Module):
             if not str(self.device).startswith("cuda"):
                 raise RuntimeError("VoxurfC.forward_training runs on libesr_hip.so and needs a GPU device "
                                    "(there is no CPU fallback)")
-            self._engine = CoarseEngine(self.device)
+            self._engine = CoarseEngine(self.device, getattr(self, "mlp_dtype", "f32"))
         return self._engine
 
     def scene_struct(self):

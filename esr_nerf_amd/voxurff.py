@@ -139,7 +139,7 @@ class VoxurfF(nn.Module):
             if not str(self.device).startswith("cuda"):
                 raise RuntimeError("VoxurfF renders through libesr_hip.so and needs a GPU device "
                                    "(there is no CPU fallback)")
-            self._engine = FineEngine(self.device)
+            self._engine = FineEngine(self.device, getattr(self, "mlp_dtype", "f32"))
         return self._engine
 
     def scene_struct(self):

@@ -446,3 +446,38 @@ def test_mlp_engine_bf16_vs_emulation(kind, tiles, crow):
     for i in range(nl):
         assert rel_err(gw[i], gW[i]) < T16, ("gw", i, rel_err(gw[i], gW[i]))
         assert rel_err(gb[i], gB[i]) < 1e-4, ("gb", i)
+
+
+def test_bf16_mode_end_to_end_close_to_fp32_and_psnr():
+    """mlp_dtype="bf16" (bf16 MFMA operands in the MLPs, everything else fp32): training outputs / loss /
+    gradients stay close to the fp32 path, and the rendered image agrees with the fp32 rendering far inside the
+    0.1 dB PSNR bar BASELINE.json sets for the bf16 configurations."""
+    import math
+    from esr_nerf_amd.synthetic import slab_scene
+    sc = slab_scene("small", s_val=60.0, oblique=True, n_rays=512, seed=9)
+    m32 = build_gpu_model(sc, seed=1, grid_seed=2)
+    m16 = build_gpu_model(sc, seed=1, grid_seed=2)
+    m16.mlp_dtype = "bf16"
+    out32, loss32, g32 = run_gpu(m32, sc, 60.0)
+    out16, loss16, g16 = run_gpu(m16, sc, 60.0)
+    assert m16.engine.bf16 and not m32.engine.bf16
+    assert m16.last_counts == m32.last_counts                      # the march is fp32 in both
+    for k in out32:
+        assert rel_err(out16[k], out32[k]) < 1e-2, (k, rel_err(out16[k], out32[k]))
+    assert abs(loss16 - loss32) < 2e-3 * max(1.0, abs(loss32))
+    for k in g32:        # bf16 operands flip ReLU units whose pre-activation is within ~1e-3 of zero: per-element
+        a_, b_ = g16[k].flatten().double(), g32[k].flatten().double()        # noise of a few %, same direction
+        cos = float((a_ * b_).sum() / (a_.norm() * b_.norm()).clamp_min(1e-30))
+        assert cos > 0.995 and rel_err(g16[k], g32[k]) < 0.2, (k, cos, rel_err(g16[k], g32[k]))
+    b = gpu_batch(sc)
+    for m in (m32, m16):
+        m.s_val = 60.0
+        m.eval()
+    kw = dict(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=1, pos_rt=torch.eye(3).cuda())
+    r32, r16 = m32(**kw), m16(**kw)
+    img = lambda r: (r["srgb/rgb"] + r["etc/white_bg"]).clamp(0, 1)
+    gt = b["rgbs"]
+    psnr = lambda x: -10.0 * math.log10(float(((x - gt) ** 2).mean()))
+    assert abs(psnr(img(r32)) - psnr(img(r16))) < 0.1
+    mse = float(((img(r32) - img(r16)) ** 2).mean())
+    assert -10.0 * math.log10(max(mse, 1e-12)) > 45.0               # bf16 vs fp32 rendering: > 45 dB

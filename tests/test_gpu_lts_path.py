@@ -281,3 +281,33 @@ def test_eval_emit_and_esp_golden():
     assert rel_err(m.eval_esp(**b), z["out/eval_esp"]) < TOL
     miss = dict(b, rays_o=b["rays_o"] + torch.tensor([10.0, 0.0, 0.0], device="cuda"))
     assert float(m.eval_emit(**miss).abs().max()) == 0.0
+
+
+def test_lts_step_bf16_mode_tracks_fp32():
+    """The LTS step with bf16 MLP operands: same survivor counts, loss within 1 % of the fp32 step, finite grads."""
+    from esr_nerf_amd.synthetic import init_slab_model, slab_scene
+    from esr_nerf_amd.trainer import LtsStep
+    s_val, n_rays, R, Pn = 70.0, 256, 16, 24
+    sc = slab_scene("small", s_val=s_val, oblique=True, n_rays=n_rays, seed=2)
+    b = {k: v.cuda() for k, v in sc.batch.items()}
+    b["uncert_masks"] = (torch.arange(n_rays) % 3 == 0).cuda()
+    g = torch.Generator().manual_seed(1)
+    res = {}
+    draws = None
+    for dt in ("f32", "bf16"):
+        m, cfg = build_lts_model(sc, num_2ndrays=R, num_ltspts=Pn)
+        init_slab_model(m, sc, seed=3)
+        m.mlp_dtype = dt
+        step = LtsStep(m, cfg.app.trainer, stage="pdra")
+        if draws is None:
+            step.forward_loss_backward(b, s_val)
+            m3 = m.last_counts["m3"]
+            draws = dict(idx=torch.randperm(m3, generator=g)[:Pn].cuda(), dirs=torch.randn(Pn, R + 1, 3, generator=g).cuda(),
+                         noise_normal=torch.randn(m3, 3, generator=g).cuda(), noise_emit=torch.randn(m3, 3, generator=g).cuda())
+        loss, G, _ = step.forward_loss_backward(b, s_val, draws=draws)
+        res[dt] = (float(loss), dict(m.last_counts), {k: v.clone() for k, v in G.items()})
+        assert m.engine.bf16 == (dt == "bf16")
+    assert res["f32"][1] == res["bf16"][1]
+    assert abs(res["f32"][0] - res["bf16"][0]) < 1e-2 * abs(res["f32"][0])
+    for k, v in res["bf16"][2].items():
+        assert bool(torch.isfinite(v).all()), k
