@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="MLP operand type: f32 (f32 matrix cores, the headline) or bf16 (bf16 operands, fp32 accumulation)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the gradient all-reduces even with one rank (self-test)")
     ap.add_argument("--no-optimizer", action="store_true", help="skip the separately reported fused-Adam timing")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not bracket kernels with HIP events (drops the roofline object)")
@@ -216,9 +218,12 @@ def main():
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     pg = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(dev))     # nccl == RCCL on ROCm
         pg = dist.group.WORLD
 
@@ -257,7 +262,7 @@ def main():
 
     def one():
         # N > 1: this rank's rays are one shard of a global batch of n_rays * N rays
-        return step.forward_loss_backward(batch, a.s_val, global_rays=n_rays * world if world > 1 else None,
+        return step.forward_loss_backward(batch, a.s_val, global_rays=n_rays * world if pg is not None else None,
                                           entropy_owner=(rank == world - 1))[:2]
 
     # warm-up; its last steps carry HIP events around EVERY kernel (full breakdown + which kernel
@@ -284,7 +289,7 @@ def main():
     dom_calls = sorted(dom_calls, key=lambda c: -breakdown[c][1])[:1]
     # timed region: exactly K steps, events only around the dominant kernel's launches (on their stream)
     eng.enable_timing(dominant is not None, only=dom_calls if dominant else None)
-    if world > 1:
+    if pg is not None:
         import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize()
@@ -292,11 +297,11 @@ def main():
     for _ in range(a.steps):
         loss, _ = one()
     torch.cuda.synchronize()
-    if world > 1:
+    if pg is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if pg is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -403,9 +408,12 @@ def main():
             else:
                 out["cpu_baseline"] = cpu_baseline_lts(model, scene, a.s_val, min(a.cpu_rays, n_rays), a.cpu_iters,
                                                        stage, cfg.app.trainer)
-        print(json.dumps(out))
-    if world > 1:
+        line = json.dumps(out)
+    if pg is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(line, flush=True)              # the ONE JSON line, last on stdout (RCCL may print banners before)
 
 
 if __name__ == "__main__":
