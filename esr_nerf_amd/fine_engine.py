@@ -156,7 +156,8 @@ class FineEngine:
         if n not in self.ray_bufs:
             self.ray_bufs[n] = dict(
                 cnt3=torch.empty(n, dtype=torch.int32, device=self.device),
-                off3=torch.empty(n, dtype=torch.int32, device=self.device))
+                off3=torch.empty(n, dtype=torch.int32, device=self.device),
+                stats=torch.empty(n * 3, dtype=torch.int32, device=self.device))
         return self.ray_bufs[n]
 
     def pack(self, which: str, kind: int, weights: List[torch.Tensor], biases: List[torch.Tensor]):
@@ -223,8 +224,8 @@ class FineEngine:
         self._run("plan_begin", L.esr_fine_plan_begin, _lib.ptr(self.plan_dev), s)
         self._run("march_count", L.esr_fine_march_count, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(mask_density),
                                           _lib.ptr(sdf), n, _lib.ptr(rb["cnt3"]), _lib.ptr(last),
-                                          _lib.ptr(self.plan_dev), s)
-        self._run("plan", L.esr_fine_plan, _lib.ptr(rb["cnt3"]), _lib.ptr(em_modes), n, _lib.ptr(rb["off3"]),
+                                          _lib.ptr(rb["stats"]), _lib.ptr(self.plan_dev), s)
+        self._run("plan", L.esr_fine_plan, _lib.ptr(rb["cnt3"]), _lib.ptr(em_modes), _lib.ptr(rb["stats"]), n, _lib.ptr(rb["off3"]),
                                    _lib.ptr(self.plan_dev), s)
         self.plan_host.copy_(self.plan_dev, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()        # the one sync of the step
@@ -277,8 +278,8 @@ class FineEngine:
         em0 = torch.zeros(n, dtype=torch.int64, device=dev)            # tile partition only: every tile "off"
         self._run("plan_begin", L.esr_fine_plan_begin, _lib.ptr(self.plan_dev), s)
         self._run("march_count", L.esr_fine_march_count, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(mask_density),
-                  _lib.ptr(sdf), n, _lib.ptr(rb["cnt3"]), _lib.ptr(last), _lib.ptr(self.plan_dev), s)
-        self._run("plan", L.esr_fine_plan, _lib.ptr(rb["cnt3"]), _lib.ptr(em0), n, _lib.ptr(rb["off3"]),
+                  _lib.ptr(sdf), n, _lib.ptr(rb["cnt3"]), _lib.ptr(last), _lib.ptr(rb["stats"]), _lib.ptr(self.plan_dev), s)
+        self._run("plan", L.esr_fine_plan, _lib.ptr(rb["cnt3"]), _lib.ptr(em0), _lib.ptr(rb["stats"]), n, _lib.ptr(rb["off3"]),
                   _lib.ptr(self.plan_dev), s)
         self.plan_host.copy_(self.plan_dev, non_blocking=True)
         torch.cuda.current_stream(dev).synchronize()

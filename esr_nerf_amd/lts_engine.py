@@ -104,11 +104,13 @@ class LtsEngine(FineEngine):
         cnt3 = torch.empty(n, dtype=torch.int32, device=self.device)
         off3 = torch.empty(n, dtype=torch.int32, device=self.device)
         last = torch.empty(n, dtype=torch.float32, device=self.device)
+        stats = torch.empty(n * 3, dtype=torch.int32, device=self.device)
         sp = C.byref(scene)
         self._run("plan_begin", L.esr_fine_plan_begin, _lib.ptr(self.plan_dev), s)
         self._run(f"march_count[{P.name}]", L.esr_fine_march_count, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
-                  _lib.ptr(mask_density), _lib.ptr(sdf), n, _lib.ptr(cnt3), _lib.ptr(last), _lib.ptr(self.plan_dev), s)
-        self._run("plan", L.esr_fine_plan, _lib.ptr(cnt3), _lib.ptr(em_modes), n, _lib.ptr(off3),
+                  _lib.ptr(mask_density), _lib.ptr(sdf), n, _lib.ptr(cnt3), _lib.ptr(last), _lib.ptr(stats),
+                  _lib.ptr(self.plan_dev), s)
+        self._run("plan", L.esr_fine_plan, _lib.ptr(cnt3), _lib.ptr(em_modes), _lib.ptr(stats), n, _lib.ptr(off3),
                   _lib.ptr(self.plan_dev), s)
         self.plan_host.copy_(self.plan_dev, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()

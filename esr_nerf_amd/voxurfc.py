@@ -70,13 +70,14 @@ class CoarseEngine(FineEngine):
         off3 = torch.empty(n, dtype=torch.int32, device=dev)
         last = torch.empty(n, dtype=torch.float32, device=dev)
         cumw = torch.empty(n, dtype=torch.float32, device=dev)
+        stats = torch.empty(n * 3, dtype=torch.int32, device=dev)
         srgb = torch.zeros(n, 3, dtype=torch.float32, device=dev)
         sp = C.byref(scene)
         self._run("plan_begin", L.esr_fine_plan_begin, _lib.ptr(self.plan_dev), s)
         self._run("march_count", L.esr_coarse_march_count, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
                   _lib.ptr(mask_density), _lib.ptr(sm), n, _lib.ptr(cnt3), _lib.ptr(last), _lib.ptr(cumw),
-                  _lib.ptr(self.plan_dev), s)
-        self._run("plan", L.esr_fine_plan, _lib.ptr(cnt3), _lib.ptr(em_modes), n, _lib.ptr(off3),
+                  _lib.ptr(stats), _lib.ptr(self.plan_dev), s)
+        self._run("plan", L.esr_fine_plan, _lib.ptr(cnt3), _lib.ptr(em_modes), _lib.ptr(stats), n, _lib.ptr(off3),
                   _lib.ptr(self.plan_dev), s)
         self.plan_host.copy_(self.plan_dev, non_blocking=True)
         torch.cuda.current_stream(dev).synchronize()

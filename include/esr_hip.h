@@ -138,12 +138,14 @@ typedef struct esr_plan {
  * SDF tap -> NeuS-interp alpha -> alpha>thres -> transmittance with the early
  * stop -> weight>thres (voxurff.py:186-213, functions.py:72-105,
  * render_utils_kernel.cu:577-605).  mask_density [mx,my,mz] (max-pooled),
- * sdf [gx,gy,gz].  Writes cnt3 [n_rays] i32 and alphainv_last [n_rays] f32 and
- * accumulates the m0/m1/m2 counters of *plan (zeroed by esr_fine_plan_begin).
+ * sdf [gx,gy,gz].  Writes cnt3 [n_rays] i32, alphainv_last [n_rays] f32 and ray_stats
+ * [n_rays,3] i32 (in-box / mask-cache / alpha>thres survivors of the ray; esr_fine_plan sums
+ * them into m0/m1/m2); sets plan->overflow (plan zeroed by esr_fine_plan_begin).
  */
 int esr_fine_march_count(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
                          const float *mask_density, const float *sdf, int32_t n_rays,
-                         int32_t *cnt3, float *alphainv_last, esr_plan_t *plan, void *stream);
+                         int32_t *cnt3, float *alphainv_last, int32_t *ray_stats, esr_plan_t *plan,
+                         void *stream);
 
 int esr_fine_plan_begin(esr_plan_t *plan, void *stream);
 
@@ -153,8 +155,8 @@ int esr_fine_plan_begin(esr_plan_t *plan, void *stream);
  * 32 -- the off rays, both in ray order, so every 32-sample tile is on-only or
  * off-only.  off3 [n_rays] i32; *plan (device) gets the totals.
  */
-int esr_fine_plan(const int32_t *cnt3, const int64_t *em_modes, int32_t n_rays,
-                  int32_t *off3, esr_plan_t *plan, void *stream);
+int esr_fine_plan(const int32_t *cnt3, const int64_t *em_modes, const int32_t *ray_stats,
+                  int32_t n_rays, int32_t *off3, esr_plan_t *plan, void *stream);
 
 /*
  * march, fill pass: recomputes the march and writes one record per surviving
@@ -480,8 +482,8 @@ int esr_central_grad_bwd(const float *ggrad, int32_t gx, int32_t gy, int32_t gz,
  */
 int esr_coarse_march_count(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
                            const float *mask_density, const float *sdf_smooth, int32_t n_rays,
-                           int32_t *cnt3, float *alphainv_last, float *cum_weights, esr_plan_t *plan,
-                           void *stream);
+                           int32_t *cnt3, float *alphainv_last, float *cum_weights, int32_t *ray_stats,
+                           esr_plan_t *plan, void *stream);
 int esr_coarse_march_fill(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
                           const float *mask_density, const float *sdf_smooth, int32_t n_rays,
                           const int32_t *off3, int32_t *rec_ray, int32_t *rec_step, float *rec_w,
