@@ -295,9 +295,14 @@ __global__ void __launch_bounds__(256) lts_combine_kernel(LtsParams L)
                 geh[c][k] = (L.pdra && um) ? 0.f : L.g_emo_hat[3 * (c * P + p) + k] / (float)R;
             }
     }
-    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+    for (int r0 = 0; r0 < R; r0 += blockDim.x) {
+        const int r = r0 + (int)threadIdx.x;
+        const bool active = r < R;
+        float denv_pre[3] = {0.f, 0.f, 0.f};                  // BWD: d loss / d (pre-softplus env colour) of this ray
+        float wi[3] = {0.f, 0.f, 0.f};
+        if (active) {
         const size_t s2 = (size_t)p * R + r;
-        const float wi[3] = {dl[3 * r], dl[3 * r + 1], dl[3 * r + 2]};
+        wi[0] = dl[3 * r]; wi[1] = dl[3 * r + 1]; wi[2] = dl[3 * r + 2];
         // environment map along the secondary ray
         float pre[3] = {0.f, 0.f, 0.f};
         for (int j = 0; j < J; ++j) {
@@ -322,7 +327,7 @@ __global__ void __launch_bounds__(256) lts_combine_kernel(LtsParams L)
                 s_ref[0][k] += inc_emo[k] * d0.R[k]; s_ref[1][k] += inc_emo[k] * d1.R[k];
             }
         } else {
-            float d_inc_off[3], denv_pre[3];
+            float d_inc_off[3];
             float dlast = 0.f;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -338,21 +343,41 @@ __global__ void __launch_bounds__(256) lts_combine_kernel(LtsParams L)
                 g_m += dR0 * d0.dR_dm[k] + dR1 * d1.dR_dm[k];
             }
             L.d_last2[s2] = dlast;
-            if (denv_pre[0] != 0.f || denv_pre[1] != 0.f || denv_pre[2] != 0.f) {
+        }
+        }   // active
+        if (BWD) {
+            // environment-map parameter gradients: every lane holds one ray's (denv_pre, wi); the 7 sums per
+            // lobe are reduced over the wave with shuffles and added to LDS by one lane (256 threads adding to
+            // the same 7 x 48 LDS words serialised: 0.66 ms for 100 workgroups)
+            const bool any = __any(denv_pre[0] != 0.f || denv_pre[1] != 0.f || denv_pre[2] != 0.f);
+            if (any) {
+                const int lane = esr_lane();
                 for (int j = 0; j < J; ++j) {
                     const float dtl = wi[0] * sg_lobe[3 * j] + wi[1] * sg_lobe[3 * j + 1] + wi[2] * sg_lobe[3 * j + 2];
                     const float e = expf(sg_lam[j] * (dtl - 1.f));
+                    float v[7];
                     float de = 0.f;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        atomicAdd(&acc_mu[3 * j + k], denv_pre[k] * e);
+                        v[k] = denv_pre[k] * e;
                         de += denv_pre[k] * sg_mu[3 * j + k];
                     }
                     de *= e;
-                    atomicAdd(&acc_lam[j], de * (dtl - 1.f));
+                    v[3] = de * (dtl - 1.f);
                     const float dd = de * sg_lam[j];               // d / d (wi . lobe_unit)
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) atomicAdd(&acc_lobe[3 * j + k], dd * wi[k]);
+                    for (int k = 0; k < 3; ++k) v[4 + k] = dd * wi[k];
+#pragma unroll
+                    for (int q = 0; q < 7; ++q)
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) v[q] += __shfl_xor(v[q], off);
+                    if (lane == 0) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) atomicAdd(&acc_mu[3 * j + k], v[k]);
+                        atomicAdd(&acc_lam[j], v[3]);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) atomicAdd(&acc_lobe[3 * j + k], v[4 + k]);
+                    }
                 }
             }
         }
