@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libesr_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 _lib = None
 
 

@@ -243,13 +243,15 @@ __global__ void __launch_bounds__(256) pair_loss_kernel(const float *__restrict_
 }
 
 // ---- image rendering (forward_evaluate) helpers --------------------------------------------------
-// aux [tiles,8,32]: rows 0-2 camera-space normal colour ((normalize(g) @ pos_rt) * (1,-1,-1) + 1) / 2 with g the
-// radius-1 finite difference (voxurff.py:431-435; its normalised components are X rows 31 + axis*4 + 1 in
-// the reference's (z,y,x) order), row 4: step_id * stepdist (depth integrand, voxurff.py:437-441), rest 0.
+// aux [tiles,8,32]: rows 0-2 camera-space normal colour ((n @ pos_rt) * (1,-1,-1) + 1) / 2 with n the unit
+// normal the feature tile already holds (fine: the radius-1 finite difference, X rows 31 + axis*4 + 1 in the
+// reference's (z,y,x) order, voxurff.py:431-435; coarse: rows 24-26, voxurfc.py:395-397), row 4: step_id *
+// stepdist (depth integrand, voxurff.py:437-441), rest 0.
 struct EvalAux {
     const float *X;
     const int32_t *rec_ray, *rec_step;
     int tiles, xrows;
+    int nrow[3];               // X rows holding the unit normal's world x, y, z components
     float rt[9], stepdist;
     float *aux;
 };
@@ -262,7 +264,7 @@ __global__ void __launch_bounds__(256) eval_aux_kernel(EvalAux A)
         const bool ok = A.rec_ray[j] >= 0;
         const float *X = A.X + (size_t)t * A.xrows * 32 + s;
         float n[3] = {0.f, 0.f, 0.f};
-        if (ok) { n[0] = X[(31 + 2 * 4 + 1) * 32]; n[1] = X[(31 + 1 * 4 + 1) * 32]; n[2] = X[(31 + 0 * 4 + 1) * 32]; }
+        if (ok) { n[0] = X[A.nrow[0] * 32]; n[1] = X[A.nrow[1] * 32]; n[2] = X[A.nrow[2] * 32]; }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float v = n[0] * A.rt[0 * 3 + c] + n[1] * A.rt[1 * 3 + c] + n[2] * A.rt[2 * 3 + c];
@@ -485,15 +487,18 @@ ESR_API int esr_fine_loss_fwd_bwd(const float *srgb_marched, const float *lin_ma
     return 0;
 }
 
-ESR_API int esr_eval_aux(const float *X, int32_t xrows, const int32_t *rec_ray, const int32_t *rec_step,
-                         int32_t tiles, const float *pos_rt_host, float stepdist, float *aux, void *stream)
+ESR_API int esr_eval_aux(const float *X, int32_t xrows, int32_t row_nx, int32_t row_ny, int32_t row_nz,
+                         const int32_t *rec_ray, const int32_t *rec_step, int32_t tiles,
+                         const float *pos_rt_host, float stepdist, float *aux, void *stream)
 {
-    if (tiles < 0 || xrows < 43) return ESR_EINVAL;
+    if (tiles < 0 || xrows < 1 || row_nx < 0 || row_ny < 0 || row_nz < 0 || row_nx >= xrows || row_ny >= xrows ||
+        row_nz >= xrows)
+        return ESR_EINVAL;
     if (tiles == 0) return 0;
     if (!X || !rec_ray || !rec_step || !pos_rt_host || !aux) return ESR_EINVAL;
     EvalAux A = {};
     A.X = X; A.rec_ray = rec_ray; A.rec_step = rec_step; A.tiles = tiles; A.xrows = xrows; A.stepdist = stepdist;
-    A.aux = aux;
+    A.aux = aux; A.nrow[0] = row_nx; A.nrow[1] = row_ny; A.nrow[2] = row_nz;
     for (int i = 0; i < 9; ++i) A.rt[i] = pos_rt_host[i];
     eval_aux_kernel<<<esr_grid_for((int64_t)tiles * 32, 256), 256, 0, esr_stream(stream)>>>(A);
     ESR_CHECK_LAUNCH();

@@ -314,8 +314,8 @@ class FineEngine:
                           _lib.ptr(out[f"srgb/{name}_rgb"]), _lib.ptr(out[f"lin/{name}_rgb"]), s)
             aux = torch.empty(T * 8 * 32, dtype=torch.float32, device=dev)
             rt = (C.c_float * 9)(*[float(v) for v in pos_rt.detach().cpu().reshape(-1).tolist()])
-            self._run("eval_aux", L.esr_eval_aux, _lib.ptr(ws["X"]), X_ROWS, _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_step"]),
-                      T, rt, C.c_float(scene.stepdist), _lib.ptr(aux), s)
+            self._run("eval_aux", L.esr_eval_aux, _lib.ptr(ws["X"]), X_ROWS, 40, 36, 32, _lib.ptr(ws["rec_ray"]),
+                      _lib.ptr(ws["rec_step"]), T, rt, C.c_float(scene.stepdist), _lib.ptr(aux), s)
             self._run("composite3_fwd(normal)", L.esr_composite3_fwd, _lib.ptr(aux), 8, _lib.ptr(ws["rec_ray"]),
                       _lib.ptr(ws["rec_w"]), T, _lib.ptr(normal_m), s)
             self._run("composite3_fwd(depth)", L.esr_composite3_fwd, C.c_void_p(aux.data_ptr() + 4 * 32 * 4), 8,

@@ -109,6 +109,43 @@ class CoarseEngine(FineEngine):
                   _lib.ptr(b["rec_ray"]), _lib.ptr(b["rec_w"]), Ton, T, _lib.ptr(b["rgb"]), _lib.ptr(srgb), s)
         return ctx, last, white_bg, srgb
 
+    @torch.no_grad()
+    def evaluate(self, scene, rays_o, rays_d, viewdirs, sdf, kernel_w, ksize, voxel_size, mask_density, off_color,
+                 emo_color, pos_rt, far, em_mode: int):
+        """``VoxurfC.forward_evaluate`` (voxurfc.py:273-422), forward only -> the reference's 8 result keys."""
+        L, s, dev = self.L, self._s(), self.device
+        n = rays_o.shape[0]
+        batch = dict(rays_o=rays_o, rays_d=rays_d, viewdirs=viewdirs,
+                     em_modes=torch.ones(n, dtype=torch.int64, device=dev))          # every tile carries both colour groups
+        ctx, _, white_bg, _ = self.forward(scene, batch, sdf, kernel_w, ksize, voxel_size, mask_density, off_color,
+                                           emo_color)
+        T, b = ctx["T"], self.b
+        z3 = lambda: torch.zeros(n, 3, dtype=torch.float32, device=dev)
+        out = {"srgb/off_rgb": z3(), "srgb/emo_rgb": z3()}
+        normal_m, depth3 = z3(), z3()
+        depth, disp = torch.zeros(n, device=dev), torch.empty(n, device=dev)
+        if T:
+            act = torch.empty(T * 4 * 32, dtype=torch.float32, device=dev)
+            for net in ("off", "emo"):
+                self._run("act_fwd", L.esr_act_fwd, _lib.ptr(b[f"{net}.z"]), T, 4, 3, 1, _lib.ptr(act), s)
+                self._run(f"composite3_fwd({net})", L.esr_composite3_fwd, _lib.ptr(act), 4, _lib.ptr(b["rec_ray"]),
+                          _lib.ptr(b["rec_w"]), T, _lib.ptr(out[f"srgb/{net}_rgb"]), s)
+            aux = torch.empty(T * 8 * 32, dtype=torch.float32, device=dev)
+            rt = (C.c_float * 9)(*[float(v) for v in pos_rt.detach().cpu().reshape(-1).tolist()])
+            self._run("eval_aux", L.esr_eval_aux, _lib.ptr(b["X"]), XC_ROWS, 24, 25, 26, _lib.ptr(b["rec_ray"]),
+                      _lib.ptr(b["rec_step"]), T, rt, C.c_float(scene.stepdist), _lib.ptr(aux), s)
+            self._run("composite3_fwd(normal)", L.esr_composite3_fwd, _lib.ptr(aux), 8, _lib.ptr(b["rec_ray"]),
+                      _lib.ptr(b["rec_w"]), T, _lib.ptr(normal_m), s)
+            self._run("composite3_fwd(depth)", L.esr_composite3_fwd, C.c_void_p(aux.data_ptr() + 4 * 32 * 4), 8,
+                      _lib.ptr(b["rec_ray"]), _lib.ptr(b["rec_w"]), T, _lib.ptr(depth3), s)
+        bg = white_bg.reshape(-1).contiguous()
+        self._run("eval_disp", L.esr_eval_disp, _lib.ptr(depth3), _lib.ptr(bg), C.c_float(far), n, _lib.ptr(depth),
+                  _lib.ptr(disp), s)
+        out["srgb/on_rgb"] = out["srgb/off_rgb"] + out["srgb/emo_rgb"]          # segment sums are linear
+        out.update({"etc/depth": depth, "etc/disp": disp, "etc/normal": normal_m, "etc/white_bg": white_bg})
+        out["srgb/rgb"] = out["srgb/off_rgb"] if int(em_mode) == 0 else out["srgb/on_rgb"]
+        return out
+
     def backward(self, ctx, g_last, g_wbg, g_srgb, grads):
         """grads (zero-initialised): sdf [X,Y,Z], off_color / emo_color [X,Y,Z,12], off_w/off_b/emo_w/emo_b (3 each)."""
         L, s, dev, b = self.L, self._s(), self.device, self.b
@@ -268,8 +305,20 @@ class VoxurfC(nn.Module):
                                               *self._mlp_params())
         return {"etc/alphainv_cum": last, "etc/white_bg": wbg, "srgb/rgb": srgb}
 
+    @torch.no_grad()
     def forward_evaluate(self, **kwargs):
-        raise NotImplementedError("image rendering (forward_evaluate) is a 'next' row of SURVEY.md section 8(f)")
+        """Image rendering (voxurfc.py:273-422): kwargs rays_o, rays_d, viewdirs [N,3], em_modes (one scalar), pos_rt
+        [3,3]; uses ``self.s_val``.  Returns the reference's 8 result keys."""
+        eng = self.engine
+        for name, net in (("off", self.off_rgbnet), ("emo", self.emo_rgbnet)):
+            lins = _linears(net)
+            eng.pack(name, KIND_COARSE, [l.weight.detach() for l in lins], [l.bias.detach() for l in lins])
+        em = kwargs["em_modes"]
+        em = int(em.reshape(-1)[0]) if torch.is_tensor(em) else int(em)
+        return eng.evaluate(self.scene_struct(), kwargs["rays_o"].contiguous(), kwargs["rays_d"].contiguous(),
+                            kwargs["viewdirs"].contiguous(), self.sdf.device_view(), self._kernel_w, self.smooth_ksize,
+                            self._voxel_size_f, self.mask_cache.density.view(*self.mask_cache.density.shape[2:]),
+                            self.off_color.device_view(), self.emo_color.device_view(), kwargs["pos_rt"], self.far, em)
 
     # ------------------------------------------------------------------ geometry / regularisers
     def set_grid_resolution(self, num_voxels: int):

@@ -530,15 +530,17 @@ int esr_coarse_shade_bwd(const float *g_srgb, const float *g_white_bg, const flo
  * ------------------------------------------------------------------------- */
 
 /*
- * Per-sample auxiliaries of VoxurfF.forward_evaluate (app/fine/model/voxurff.py:431-443) from the feature
- * tile X [tiles,xrows,32] of esr_fine_feat_fwd: aux [tiles,8,32] rows 0-2 = camera-space normal colour
- * ((normalize(grad_radius1) @ pos_rt) * (1,-1,-1) + 1) / 2, row 4 = step_id * stepdist, other rows 0.
+ * Per-sample auxiliaries of forward_evaluate (app/fine/model/voxurff.py:431-443, app/coarse/model/voxurfc.py:
+ * 395-412) from a feature tile X [tiles,xrows,32] whose rows row_nx/ny/nz hold the unit normal (fine tile:
+ * 40, 36, 32 = the radius-1 finite difference; coarse tile: 24, 25, 26): aux [tiles,8,32] rows 0-2 =
+ * camera-space normal colour ((n @ pos_rt) * (1,-1,-1) + 1) / 2, row 4 = step_id * stepdist, other rows 0.
  * pos_rt_host: 3x3 row-major in HOST memory.  Composite with esr_composite3_fwd(aux, 8, ...) and
  * esr_composite3_fwd(aux + 4*32, 8, ...) (column 0 of the second result is the depth).
  * esr_eval_disp: depth[i] = depth3[3i]; disp[i] = 1 / (depth + alphainv_last * far).
  */
-int esr_eval_aux(const float *X, int32_t xrows, const int32_t *rec_ray, const int32_t *rec_step,
-                 int32_t tiles, const float *pos_rt_host, float stepdist, float *aux, void *stream);
+int esr_eval_aux(const float *X, int32_t xrows, int32_t row_nx, int32_t row_ny, int32_t row_nz,
+                 const int32_t *rec_ray, const int32_t *rec_step, int32_t tiles,
+                 const float *pos_rt_host, float stepdist, float *aux, void *stream);
 int esr_eval_disp(const float *depth3, const float *alphainv_last, float far_, int32_t n_rays,
                   float *depth, float *disp, void *stream);
 

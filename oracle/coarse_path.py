@@ -115,3 +115,44 @@ def coarse_loss(results: Dict[str, Tensor], rgbs: Tensor, white_bg: bool = True,
     pout = results["etc/alphainv_cum"][..., -1].clamp(1e-6, 1 - 1e-6)
     ent = -(pout * torch.log(pout) + (1 - pout) * torch.log(1 - pout)).mean()
     return loss + weight_entropy_last * ent, dict(mse=float(loss.detach()))
+
+
+@torch.no_grad()
+def forward_evaluate(P: Dict[str, Tensor], c: fp.FineConsts, batch: Dict[str, Tensor], s_val: float, far: float,
+                     em_mode: int, pos_rt: Tensor, ksize: int = 5, sigma: float = 0.8) -> Dict[str, Tensor]:
+    """VoxurfC.forward_evaluate (voxurfc.py:273-422): image rendering of the coarse stage."""
+    rays_o, rays_d, viewdirs = batch["rays_o"], batch["rays_d"], batch["viewdirs"]
+    N = rays_o.shape[0]
+    stepdist = c.stepsize * c.voxel_size
+    pts, out_box, ray_id, step_id = native.sample_pts_on_rays(rays_o.contiguous(), rays_d.contiguous(), c.xyz_min, c.xyz_max,
+                                                              c.near, 1e9, float(stepdist))[:4]
+    inb = ~out_box
+    pts, ray_id, step_id = pts[inb], ray_id[inb], step_id[inb]
+    m = fp.mask_cache(c, pts)
+    pts, ray_id, step_id = pts[m], ray_id[m], step_id[m]
+    norm = fp.to_norm(pts, c.xyz_min, c.xyz_max)
+    sdf = fp.sample_grid(smooth_grid(P["sdf.grid"], gaussian_kernel(ksize, sigma)), norm)[:, 0]
+    grad = fp.sample_grid(dense_gradient(P["sdf.grid"], c.voxel_size), norm)
+    alpha = fp.neus_alpha_interp(sdf, ray_id, s_val)
+    weights, _ = fp._Composite.apply(alpha, ray_id, N)
+    m = weights > c.fastcolor_thres
+    pts, ray_id, step_id, alpha, grad, norm = pts[m], ray_id[m], step_id[m], alpha[m], grad[m], norm[m]
+    weights, _ = fp._Composite.apply(alpha, ray_id, N)
+    unit = (pts - c.xyz_min) / (c.xyz_max - c.xyz_min)
+    pf = torch.tensor([2.0 ** i for i in range(c.posbase_pe)])
+    vf = torch.tensor([2.0 ** i for i in range(c.viewbase_pe)])
+    xe = (unit.unsqueeze(-1) * pf).flatten(-2)
+    ve = (viewdirs.unsqueeze(-1) * vf).flatten(-2)
+    normal = grad / (grad.norm(dim=-1, keepdim=True) + 1e-5)
+    feat = torch.cat([unit, xe.sin(), xe.cos(), ve[ray_id], ve.sin()[ray_id], ve.cos()[ray_id], normal], -1)
+    off = torch.sigmoid(fp.mlp(P, [f"off_rgbnet.{k}" for k in RGB_KEYS], torch.cat([fp.sample_grid(P["off_color.grid"], norm), feat], -1)))
+    emo = torch.sigmoid(fp.mlp(P, [f"emo_rgbnet.{k}" for k in RGB_KEYS], torch.cat([fp.sample_grid(P["emo_color.grid"], norm), feat], -1)))
+    w = weights.unsqueeze(-1)
+    comp = lambda x: torch.zeros(N, x.shape[-1]).index_add(0, ray_id, w * x)
+    out = {"srgb/off_rgb": comp(off), "srgb/emo_rgb": comp(emo), "srgb/on_rgb": comp(off + emo)}
+    bg = 1 - comp(torch.ones_like(w))
+    nrm = ((normal @ pos_rt) * torch.tensor([1.0, -1.0, -1.0]) + 1.0) / 2.0
+    depth = torch.zeros(N).index_add(0, ray_id, weights * step_id * stepdist)
+    out.update({"etc/depth": depth, "etc/disp": 1 / (depth + bg[..., -1] * far), "etc/normal": comp(nrm), "etc/white_bg": bg})
+    out["srgb/rgb"] = out["srgb/off_rgb"] if em_mode == 0 else out["srgb/on_rgb"]
+    return out

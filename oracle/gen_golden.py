@@ -133,6 +133,7 @@ def main():
     gen_coarse(ns)
     gen_eval(ns)
     gen_lts_evals(ns)
+    gen_coarse_eval(ns)
 
 
 def lts_reference_loss(ns, results, rgbs, cfg):
@@ -351,6 +352,38 @@ def gen_coarse(ns):
         print("coarse s_val", s_val, "loss", float(loss), "grads", sum(1 for k in out if k.startswith("grad/")))
 
 
+def gen_coarse_eval(ns):
+    """VoxurfC.forward_evaluate for em_modes 0 and 1, parameters = coarse_g16_params.npz."""
+    from esr_nerf_amd.config import coarse_cfg
+    from esr_nerf_amd.synthetic import analytic_sdf
+    sc = slab_scene("g16", s_val=8.0, oblique=True)
+    cfg = coarse_cfg("cpu", num_voxels=sc.num_voxels)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = ns.VoxurfC(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max,
+                       sc.mask_alpha_init, sc.mask_density, 8.0)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        model.sdf.grid.copy_(analytic_sdf([int(v) for v in model.world_size], sc.xyz_min, sc.xyz_max))
+        model.off_color.grid.copy_(torch.randn(model.off_color.grid.shape, generator=g) * 0.1)
+        model.emo_color.grid.copy_(torch.randn(model.emo_color.grid.shape, generator=g) * 0.1)
+    with np.load(os.path.join(OUT, "coarse_g16_params.npz")) as z:
+        for k, v in model.state_dict().items():
+            assert np.array_equal(z[k], v.detach().numpy()), k
+    model.s_val = 40.0
+    model.eval()
+    b = sc.batch
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(2)))
+    out = {"in/pos_rt": q.numpy(), "in/s_val": np.float32(40.0), "in/far": np.float32(sc.far)}
+    for em in (0, 1):
+        with torch.no_grad():
+            res = model(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=em, pos_rt=q)
+        for k, v in res.items():
+            out[f"out{em}/{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "coarse_g16_eval.npz"), **out)
+    print("coarse eval keys", sorted(k for k in out if k.startswith("out0/")))
+
+
 def gen_eval(ns):
     """VoxurfF.forward_evaluate (image rendering, voxurff.py:280-461) for em_modes 0 and 1 on the oblique slab,
     parameters = fine_g16_params.npz."""
@@ -382,6 +415,9 @@ def gen_eval(ns):
 
 if __name__ == "__main__":
     import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "coarse_eval":
+        gen_coarse_eval(ref_import.load())
+        raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lts_evals":
         gen_lts_evals(ref_import.load())
         raise SystemExit(0)
