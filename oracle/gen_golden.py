@@ -134,6 +134,7 @@ def main():
     gen_eval(ns)
     gen_lts_evals(ns)
     gen_coarse_eval(ns)
+    gen_lts_eval(ns)
 
 
 def lts_reference_loss(ns, results, rgbs, cfg):
@@ -312,6 +313,56 @@ def gen_lts_evals(ns):
     print("lts evals", float(e.abs().max()), float(p_.abs().max()))
 
 
+def gen_lts_eval(ns):
+    """ESRNeRF.forward_evaluate: em_modes 1 with render_pbr (per-sample light transport, scattering draws
+    recorded per chunk) and em_modes 0 without; parameters = lts_g16_params.npz."""
+    from esr_nerf_amd.config import lts_cfg
+    cfg = lts_cfg("cpu", num_2ndrays=8, num_ltspts=12)
+    sc = slab_scene("g16", s_val=60.0, oblique=True)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = ns.ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max,
+                       sc.mask_alpha_init, sc.mask_density, sc.s_val, sc.num_voxels)
+    init_slab_model(model, sc)
+    with torch.no_grad():
+        model.brdf.grid.data.copy_(torch.randn(model.brdf.grid.shape, generator=torch.Generator().manual_seed(9)) * 0.1)
+    with np.load(os.path.join(OUT, "lts_g16_params.npz")) as z:
+        for k, v in model.state_dict().items():
+            assert np.array_equal(z[k], v.detach().numpy()), k
+    model.s_val = 60.0
+    model.eval()
+    b = sc.batch
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(2)))
+    rec = []
+    r_randn = torch.randn
+
+    def p_randn(*a, **k):
+        t = r_randn(*a, **k)
+        rec.append(t.clone())
+        return t
+
+    torch.manual_seed(4)
+    torch.randn = p_randn
+    try:
+        with torch.no_grad():
+            res1 = model(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=1, pos_rt=q,
+                         render_pbr=True, chunk_sz=150)
+    finally:
+        torch.randn = r_randn
+    with torch.no_grad():
+        res0 = model(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=0, pos_rt=q,
+                     render_pbr=False, chunk_sz=150)
+    out = {"in/pos_rt": q.numpy(), "in/s_val": np.float32(60.0), "in/far": np.float32(sc.far), "in/chunk_sz": np.int64(150)}
+    for i, t in enumerate(rec):
+        out[f"draw/dirs{i}"] = t.numpy()
+    for k, v in res1.items():
+        out["out1/" + k] = v.numpy()
+    for k, v in res0.items():
+        out["out0/" + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "lts_g16_eval.npz"), **out)
+    print("lts eval: chunks", len(rec), "keys", len(res1), len(res0))
+
+
 def gen_coarse(ns):
     """VoxurfC.forward_training + the loss lines of coarse.py:341-352 on the small oblique slab (A17)."""
     from esr_nerf_amd.config import coarse_cfg
@@ -415,6 +466,9 @@ def gen_eval(ns):
 
 if __name__ == "__main__":
     import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "lts_eval":
+        gen_lts_eval(ref_import.load())
+        raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "coarse_eval":
         gen_coarse_eval(ref_import.load())
         raise SystemExit(0)

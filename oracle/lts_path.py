@@ -411,3 +411,98 @@ def eval_esp(P, c, batch, s_val) -> Tensor:
     """ESRNeRF.eval_esp (esrnerf.py:1360-1407): weight-composited sample position per ray, [N,3]."""
     N, w, pts, ray_id, _ = _primary_survivors(P, c, batch, s_val)
     return torch.zeros(N, 3).index_add(0, ray_id, w[:, None] * pts)
+
+
+# ------------------------------------------------------------------ image rendering (esrnerf.py:853-1297)
+@torch.no_grad()
+def _evaluate_lts(P, c, pts, viewdirs, normal, base, rough, metal, emit, raw_dirs, s_val, R, lts_near):
+    """The per-sample light-transport decomposition of forward_evaluate (esrnerf.py:854-1001) for one chunk."""
+    n = pts.shape[0]
+    dirs = hemisphere_dirs(normal, raw_dirs)
+    ex = lambda t: t.view(n, 1, -1).expand(n, R, t.shape[-1]).flatten(0, 1)
+    d2 = dirs.flatten(0, 1)
+    Rf = disney_reflection(ex(base), ex(rough), ex(metal), ex(normal), d2, -ex(viewdirs))
+    N2, p2, rid = _march(P, c, ex(pts), d2, lts_near, s_val)
+    s2 = fp.sample_grid(P["sdf.grid"], fp.to_norm(p2, c.xyz_min, c.xyz_max))[:, 0]
+    a2 = fp.neus_alpha_interp(s2, rid, s_val) if s2.numel() > 1 else s2.new_zeros(s2.shape)
+    m = a2 > c.fastcolor_thres
+    a2, p2, rid, s2 = a2[m], p2[m], rid[m], s2[m]
+    w2, last2 = fp._Composite.apply(a2, rid, N2)
+    m = w2 > c.fastcolor_thres
+    w2, p2, rid, s2 = w2[m], p2[m], rid[m], s2[m]
+    f2, _, nr2 = _stencil(c, P["sdf.grid"], p2)
+    feat2 = torch.cat([_pe(c, p2), _view_pe(c, d2)[rid], s2[:, None], f2, nr2], -1)
+    g2 = fp.to_norm(p2, c.xyz_min, c.xyz_max)
+    loff = fp.radiance(P, "off_rgbnet", torch.cat([fp.sample_grid(P["off_color.grid"], g2), feat2], -1))
+    lemo = fp.radiance(P, "emo_rgbnet", torch.cat([fp.sample_grid(P["emo_color.grid"], g2), feat2], -1))
+    off_m = torch.zeros(N2, 3).index_add(0, rid, w2[:, None] * loff)
+    emo_m = torch.zeros(N2, 3).index_add(0, rid, w2[:, None] * lemo)
+    env = sg_envmap(P, d2) * last2.unsqueeze(-1)
+    mean = lambda t: t.view(-1, R, 3).mean(-2)
+    out = {"lin/env_dir": mean(env * Rf), "lin/env_indir": mean(off_m * Rf), "lin/emit_(in)dir": mean(emo_m * Rf)}
+    out["lin/env_effects"] = out["lin/env_dir"] + out["lin/env_indir"]
+    out["lin/emit_effects"] = emit + out["lin/emit_(in)dir"]
+    return out
+
+
+@torch.no_grad()
+def forward_evaluate(P, c, batch, s_val, far, em_mode, pos_rt, render_pbr, chunk_sz, raw_dirs_chunks, num_2ndrays,
+                     lts_near, emit_grid_key: str = "emo_color.grid") -> Dict[str, Tensor]:
+    """ESRNeRF.forward_evaluate (esrnerf.py:853-1297).  ``raw_dirs_chunks``: the standard-normal draws of
+    diffuse_scattering, one [chunk, R, 3] tensor per chunk of ``chunk_sz`` surviving samples (render_pbr only)."""
+    rays_o, rays_d, viewdirs = batch["rays_o"].contiguous(), batch["rays_d"].contiguous(), batch["viewdirs"]
+    N = rays_o.shape[0]
+    stepdist = c.stepsize * c.voxel_size
+    pts, out_box, ray_id, step_id = native.sample_pts_on_rays(rays_o, rays_d, c.xyz_min, c.xyz_max, c.near, 1e9,
+                                                              float(stepdist))[:4]
+    inb = ~out_box
+    pts, ray_id, step_id = pts[inb], ray_id[inb], step_id[inb]
+    m = fp.mask_cache(c, pts)
+    pts, ray_id, step_id = pts[m], ray_id[m], step_id[m]
+    sdf, expg = sdf_expgrad(c, P["sdf.grid"], pts)
+    sdf, expg = sdf.detach(), expg.detach()
+    alpha = fp.neus_alpha_interp(sdf, ray_id, s_val)
+    m = alpha > c.fastcolor_thres
+    alpha, pts, ray_id, step_id, sdf, expg = alpha[m], pts[m], ray_id[m], step_id[m], sdf[m], expg[m]
+    weights, alphainv_last = fp._Composite.apply(alpha, ray_id, N)
+    m = weights > c.fastcolor_thres
+    weights, pts, ray_id, step_id, sdf, expg = weights[m], pts[m], ray_id[m], step_id[m], sdf[m], expg[m]
+    _, g1, _ = fp.sdf_stencil(c, P["sdf.grid"], pts, torch.tensor([1.0]), diff_eps=1e-12)
+    grad = torch.cat([g1[:, [2]], g1[:, [1]], g1[:, [0]]], -1)
+    feat, _, nrm12 = _stencil(c, P["sdf.grid"], pts)
+    xyz_pe = _pe(c, pts)
+    common = torch.cat([xyz_pe, _view_pe(c, viewdirs)[ray_id], sdf[:, None], feat, nrm12], -1)
+    gp = fp.to_norm(pts, c.xyz_min, c.xyz_max)
+    lin_off = fp.radiance(P, "off_rgbnet", torch.cat([fp.sample_grid(P["off_color.grid"], gp), common], -1))
+    lin_emo = fp.radiance(P, "emo_rgbnet", torch.cat([fp.sample_grid(P["emo_color.grid"], gp), common], -1))
+    lin_on = lin_off + lin_emo
+    bfeat = torch.cat([xyz_pe, sdf[:, None], feat, nrm12], -1)
+    base, rough, metal = brdf_net(P, torch.cat([fp.sample_grid(P["brdf.grid"], gp), bfeat], -1))
+    emit = emit_net(P, torch.cat([fp.sample_grid(P[emit_grid_key], gp), bfeat], -1))
+    w = weights.unsqueeze(-1)
+    comp3 = lambda x: torch.zeros(N, 3).index_add(0, ray_id, w * x)
+    comp1 = lambda x: torch.zeros(N).index_add(0, ray_id, weights * x)
+    out = {}
+    for name, lin in (("off", lin_off), ("on", lin_on), ("emo", lin_emo)):
+        out[f"srgb/{name}_rgb"] = comp3(fp.tonemap(P, c, lin))
+        out[f"lin/{name}_rgb"] = comp3(lin)
+    out.update({"lin/basecolor": comp3(base), "lin/roughness": comp1(rough.squeeze(-1)),
+                "lin/metallic": comp1(metal.squeeze(-1)), "lin/emit": comp3(emit)})
+    nrm = ((F.normalize(grad, dim=-1) @ pos_rt) * torch.tensor([1.0, -1.0, -1.0]) + 1.0) / 2.0
+    depth = torch.zeros(N).index_add(0, ray_id, weights * step_id * stepdist)
+    out.update({"etc/depth": depth, "etc/disp": 1 / (depth + alphainv_last * far), "etc/normal": comp3(nrm),
+                "etc/white_bg": alphainv_last.unsqueeze(-1)})
+    if render_pbr:
+        vd = viewdirs[ray_id]
+        normal = F.normalize(expg, dim=-1)
+        parts: Dict[str, list] = {}
+        for ci, idx in enumerate(torch.arange(pts.shape[0]).split(chunk_sz)):
+            r = _evaluate_lts(P, c, pts[idx], vd[idx], normal[idx], base[idx], rough[idx], metal[idx], emit[idx],
+                              raw_dirs_chunks[ci], s_val, num_2ndrays, lts_near)
+            for k, v in r.items():
+                parts.setdefault(k, []).append(v)
+        for k, v in parts.items():
+            out[k] = comp3(torch.cat(v, 0))
+    pick = "off" if em_mode == 0 else "on"
+    out["srgb/rgb"], out["lin/rgb"] = out[f"srgb/{pick}_rgb"], out[f"lin/{pick}_rgb"]
+    return out
