@@ -9,7 +9,8 @@ node over the kernels of libesr_hip.so (esr_nerf_amd/lts_engine.py).
 
 ``forward_finetune`` (re-lighting fine-tune target, esrnerf.py:241-484) runs on the same kernels.
 ``eval_emit`` / ``eval_esp`` (the PDRA trainer's regrouping queries) are forward-only passes over the same kernels.
-Not yet provided: ``forward_evaluate``, ``render_envmap``.
+``forward_evaluate`` renders images incl. the per-sample light-transport decomposition.  Not provided: ``render_envmap``,
+``extract_geometry``.
 """
 from __future__ import annotations
 
@@ -287,10 +288,32 @@ class ESRNeRF(VoxurfF):
         """Weight-composited sample position per ray (esrnerf.py:1360-1407)."""
         return self._eval_query("esp", **kwargs)
 
-    def forward_evaluate(self, **kwargs):
-        raise NotImplementedError("ESRNeRF.forward_evaluate (esrnerf.py:853-1297, per-sample light transport and 30 "
-                                  "result keys) is a 'next' row of SURVEY.md section 8(f); the fine-stage image "
-                                  "renderer is VoxurfF.forward_evaluate")
+    @torch.no_grad()
+    def forward_evaluate(self, draws=None, **kwargs):
+        """Image rendering (esrnerf.py:853-1297): kwargs rays_o, rays_d, viewdirs [N,3], em_modes (one scalar), pos_rt
+        [3,3], render_pbr (bool), chunk_sz (samples per light-transport chunk); uses ``self.s_val``.  Returns the
+        reference's 16 result keys, 21 with ``render_pbr``.  ``draws`` (optional): list of [chunk, num_2ndrays, 3]
+        standard-normal tensors replacing the internal scattering draws (parity tests)."""
+        eng = self.engine
+        for name, kind, net in (("off", KIND_RADIANCE, self.off_rgbnet), ("emo", KIND_RADIANCE, self.emo_rgbnet),
+                                ("tone", KIND_TONEMAP, self.tonemapper), ("brdf", KIND_BRDF, self.brdfnet),
+                                ("emit", KIND_EMIT, self.emitnet)):
+            lins = net.layers()
+            eng.pack(name, kind, [l.weight.detach() for l in lins], [l.bias.detach() for l in lins])
+        emit_grid = getattr(self, "emit_color", self.emo_color)
+        grids = dict(sdf=self.sdf.device_view(), off=self.off_color.device_view(), emo=self.emo_color.device_view(),
+                     brdf=self.brdf.device_view(),
+                     emit=self.emo_color.device_view() if emit_grid is self.emo_color else emit_grid.device_view(),
+                     mask=self.mask_cache.density.view(*self.mask_cache.density.shape[2:]))
+        if emit_grid is self.emo_color:
+            grids["emit"] = grids["emo"]
+        env = dict(mus=self.envmap.mus.detach(), lambdas=self.envmap.lambdas.detach(), lobes=self.envmap.lobes.detach())
+        em = kwargs["em_modes"]
+        em = int(em.reshape(-1)[0]) if torch.is_tensor(em) else int(em)
+        return eng.evaluate(self.scene_struct(), self.scene_struct(near=self.lts_near), kwargs["rays_o"].contiguous(),
+                            kwargs["rays_d"].contiguous(), kwargs["viewdirs"].contiguous(), grids, env, kwargs["pos_rt"],
+                            self.far, em, bool(kwargs.get("render_pbr", False)), int(kwargs.get("chunk_sz", 4096)),
+                            self.num_2ndrays, draws)
 
     @torch.no_grad()
     def scale_volume_grid(self, num_voxels):

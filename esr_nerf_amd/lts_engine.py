@@ -234,6 +234,139 @@ class LtsEngine(FineEngine):
         perm[ref_pos] = jidx
         return perm, rec_ray
 
+    # ------------------------------------------------------------------ image rendering
+    @torch.no_grad()
+    def evaluate(self, scene, scene2, rays_o, rays_d, viewdirs, grids, envmap, pos_rt, far, em_mode, render_pbr, chunk_sz,
+                 num_2ndrays, draws=None):
+        """``ESRNeRF.forward_evaluate`` (esrnerf.py:853-1297), forward only: the 12 image keys of the fine renderer,
+        the composited material heads (lin/emit, lin/basecolor, lin/roughness, lin/metallic) and, with ``render_pbr``,
+        the light-transport decomposition of EVERY surviving sample (lin/env_dir, lin/env_indir, lin/env_effects,
+        lin/emit_(in)dir, lin/emit_effects) evaluated in chunks of ``chunk_sz`` samples x ``num_2ndrays`` secondary rays.
+        grids: sdf, off, emo, brdf, emit, mask.  draws: optional list of [chunk, R, 3] standard-normal tensors."""
+        L, s, dev = self.L, self._s(), self.device
+        sdf, offg, emog, brdfg, emitg = grids["sdf"], grids["off"], grids["emo"], grids["brdf"], grids["emit"]
+        n = rays_o.shape[0]
+        P0 = self.prim
+        cnt3, off3, last = self._march(P0, scene, rays_o, rays_d, torch.zeros(n, dtype=torch.int64, device=dev),
+                                       grids["mask"], sdf)
+        T, m3 = P0.tiles_all, P0.counts["m3"]
+        z3 = lambda: torch.zeros(n, 3, dtype=torch.float32, device=dev)
+        out = {f"{sp_}/{v}_rgb": z3() for v in ("off", "on", "emo") for sp_ in ("srgb", "lin")}
+        out.update({"lin/emit": z3(), "lin/basecolor": z3(), "etc/normal": z3()})
+        rm3, depth3 = z3(), z3()
+        depth = torch.zeros(n, dtype=torch.float32, device=dev)
+        disp = torch.empty(n, dtype=torch.float32, device=dev)
+        pbr_keys = ("lin/env_dir", "lin/env_indir", "lin/env_effects", "lin/emit_(in)dir", "lin/emit_effects")
+        if render_pbr:
+            out.update({k: z3() for k in pbr_keys})
+        sp = C.byref(scene)
+        comp = lambda src, rows, dst, name: self._run(f"composite3_fwd({name})", L.esr_composite3_fwd, src, rows,
+                                                      _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(P0.bufs["rec_w"]), T, _lib.ptr(dst), s)
+        if T:
+            self._feat_args_records(P0, rays_o, rays_d, viewdirs, sdf, (offg, emog, brdfg), (offg, emog, brdfg))
+            self._features(P0, scene)
+            self._net_fwd(P0, "off", KIND_RADIANCE, 0, 0, T, save=False)
+            self._net_fwd(P0, "emo", KIND_RADIANCE, 88, 0, T, save=False)
+            self._net_fwd(P0, "brdf", KIND_BRDF, 96, 0, T, save=False)
+            for name, za, zb, ton in (("off", "off.z", "emo.z", 0), ("emo", "emo.z", "emo.z", 0), ("on", "off.z", "emo.z", T)):
+                self._run("tone_in_fwd", L.esr_fine_tone_in_fwd, _lib.ptr(P0.bufs[za]), _lib.ptr(P0.bufs[zb]), ton, T,
+                          _lib.ptr(P0.buf("lin", 4)), _lib.ptr(P0.buf("Xt", XT_ROWS)), s)
+                self._net_fwd(P0, "tone", KIND_TONEMAP, 0, 0, T, save=False)
+                self._run("composite_fwd", L.esr_fine_composite_fwd, _lib.ptr(P0.bufs["tone.z"]), _lib.ptr(P0.bufs["lin"]),
+                          _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(P0.bufs["rec_w"]), T, _lib.ptr(P0.buf("rgb", 4)),
+                          _lib.ptr(out[f"srgb/{name}_rgb"]), _lib.ptr(out[f"lin/{name}_rgb"]), s)
+            aux = torch.empty(T * 8 * 32, dtype=torch.float32, device=dev)
+            rt = (C.c_float * 9)(*[float(v) for v in pos_rt.detach().cpu().reshape(-1).tolist()])
+            self._run("eval_aux", L.esr_eval_aux, _lib.ptr(P0.bufs["X"]), X_ROWS, 40, 36, 32, _lib.ptr(P0.bufs["rec_ray"]),
+                      _lib.ptr(P0.bufs["rec_step"]), T, rt, C.c_float(scene.stepdist), _lib.ptr(aux), s)
+            comp(_lib.ptr(aux), 8, out["etc/normal"], "normal")
+            comp(C.c_void_p(aux.data_ptr() + 4 * 32 * 4), 8, depth3, "depth")
+            # material heads; the emission head reads emit_color, which may be a frozen copy distinct from emo_color
+            self._act(P0, "brdf.z", "brdf.a", 8, 5, ACT_SIGMOID)
+            comp(_lib.ptr(P0.bufs["brdf.a"]), 8, out["lin/basecolor"], "basecolor")
+            comp(C.c_void_p(P0.bufs["brdf.a"].data_ptr() + 3 * 32 * 4), 8, rm3, "rough/metal")
+            if emitg.data_ptr() == emog.data_ptr():
+                self._net_fwd(P0, "emit", KIND_EMIT, 88, 0, T, save=False)
+            else:
+                keep_x, keep_g = P0.bufs["X"], P0.bufs["gnorm"]
+                P0.bufs["X"], P0.bufs["gnorm"] = P0.buf("X.emit", X_ROWS), P0.buf("gnorm.emit", 4)
+                self._feat_args_records(P0, rays_o, rays_d, viewdirs, sdf, (emitg, None, None), (emitg, None, None))
+                self._features(P0, scene)
+                self._net_fwd(P0, "emit", KIND_EMIT, 0, 0, T, save=False)
+                P0.bufs["X"], P0.bufs["gnorm"] = keep_x, keep_g
+            self._act(P0, "emit.z", "emit.a", 4, 3, ACT_SOFTPLUS)
+            comp(_lib.ptr(P0.bufs["emit.a"]), 4, out["lin/emit"], "emit")
+        self._run("eval_disp", L.esr_eval_disp, _lib.ptr(depth3), _lib.ptr(last), C.c_float(far), n, _lib.ptr(depth),
+                  _lib.ptr(disp), s)
+        out.update({"etc/depth": depth, "etc/disp": disp, "etc/white_bg": last.unsqueeze(-1),
+                    "lin/roughness": rm3[:, 0].contiguous(), "lin/metallic": rm3[:, 1].contiguous()})
+        if render_pbr and T:
+            R = int(num_2ndrays)
+            perm, rec_ray = self._ref_order(P0, cnt3, off3)
+            eg = torch.empty(T * 32, 4, device=dev)
+            self._run("expgrad_fwd", L.esr_expgrad_fwd, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(P0.bufs["rec_ray"]),
+                      _lib.ptr(P0.bufs["rec_step"]), None, None, C.c_float(0.0), _lib.ptr(sdf), T * 32, 0, _lib.ptr(eg), s)
+            pts_all = torch.empty(T * 32, 3, device=dev)
+            self._run("sample_points", L.esr_sample_points, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
+                      _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(P0.bufs["rec_step"]), T * 32, _lib.ptr(pts_all), s)
+            brdf_rm, emit_rm = P0.rowmajor("brdf.a"), P0.rowmajor("emit.a")
+            per = {k: torch.zeros(T * 32, 3, device=dev) for k in pbr_keys}
+            P2 = self.sec
+            mus, lam, lobes = envmap["mus"].contiguous(), envmap["lambdas"].reshape(-1).contiguous(), envmap["lobes"].contiguous()
+            for ci, idx in enumerate(torch.arange(m3, device=dev).split(int(chunk_sz))):
+                jc = perm[idx]
+                nc = jc.numel()
+                pts_c = pts_all[jc].contiguous()
+                view_c = viewdirs[rec_ray[jc]].contiguous()
+                normal_c = torch.nn.functional.normalize(eg[jc, 1:4], dim=-1).contiguous()
+                base_c, rough_c, metal_c = brdf_rm[jc, 0:3].contiguous(), brdf_rm[jc, 3].contiguous(), brdf_rm[jc, 4].contiguous()
+                emit_c = emit_rm[jc, 0:3].contiguous()
+                raw = torch.randn(nc, R, 3, device=dev) if draws is None else draws[ci].to(dev).contiguous()
+                raw1 = torch.cat([raw, torch.ones(nc, 1, 3, device=dev)], 1).contiguous()       # slot R: unused second view
+                dirs_all = torch.empty(nc, R + 1, 3, device=dev)
+                self._run("lts_dirs", L.esr_lts_dirs, _lib.ptr(raw1), _lib.ptr(normal_c), nc, R + 1, _lib.ptr(dirs_all), s)
+                o2 = pts_c.repeat_interleave(R, 0).contiguous()
+                d2 = dirs_all[:, :R].reshape(nc * R, 3).contiguous()
+                _, _, last2 = self._march(P2, scene2, o2, d2, torch.zeros(nc * R, dtype=torch.int64, device=dev),
+                                          grids["mask"], sdf)
+                T2 = P2.tiles_all
+                off_m, emo_m = torch.zeros(nc * R, 3, device=dev), torch.zeros(nc * R, 3, device=dev)
+                if T2:
+                    self._feat_args_records(P2, o2, d2, d2, sdf, (offg, emog, None), (offg, emog, None))
+                    self._features(P2, scene2)
+                    self._net_fwd(P2, "off", KIND_RADIANCE, 0, 0, T2, save=False)
+                    self._net_fwd(P2, "emo", KIND_RADIANCE, 88, 0, T2, save=False)
+                    for nm, dst in (("off", off_m), ("emo", emo_m)):
+                        self._act(P2, f"{nm}.z", f"{nm}.a", 4, 3, ACT_SOFTPLUS)
+                        self._run("composite3_fwd", L.esr_composite3_fwd, _lib.ptr(P2.bufs[f"{nm}.a"]), 4,
+                                  _lib.ptr(P2.bufs["rec_ray"]), _lib.ptr(P2.bufs["rec_w"]), T2, _lib.ptr(dst), s)
+                zeros3, zeros1 = torch.zeros(nc * R, 3, device=dev), torch.zeros(nc * R, device=dev)
+                zero_e = torch.zeros(nc, 3, device=dev)
+                um = torch.zeros(nc, dtype=torch.uint8, device=dev)
+
+                def combine(off_in, last_in, emission_in):
+                    a = _lib.EsrLtsArgs()
+                    a.n_pts, a.n_rays, a.n_sg, a.pdra_mode = nc, R, mus.shape[0], 0
+                    held = dict(base=base_c, rough=rough_c, metal=metal_c, normal=normal_c, view=view_c, dirs=dirs_all,
+                                off_m=off_in, emo_m=emo_m, last2=last_in, mus=mus, lambdas=lam, lobes=lobes,
+                                emission=emission_in, umask=um)
+                    for k, v in held.items():
+                        setattr(a, k, v.data_ptr())
+                    oh, eh = torch.empty(2 * nc, 3, device=dev), torch.empty(2 * nc, 3, device=dev)
+                    self._run("lts_combine_fwd", L.esr_lts_combine_fwd, C.byref(a), _lib.ptr(oh), _lib.ptr(eh), s)
+                    return oh[:nc], eh[:nc]             # copy 0 = the camera direction
+                env_eff, emit_eff = combine(off_m, last2, emit_c)
+                env_dir, emit_ind = combine(zeros3, last2, zero_e)
+                env_ind, _ = combine(off_m, zeros1, zero_e)
+                for k, v in (("lin/env_dir", env_dir), ("lin/env_indir", env_ind), ("lin/env_effects", env_eff),
+                             ("lin/emit_(in)dir", emit_ind), ("lin/emit_effects", emit_eff)):
+                    per[k][jc] = v
+            for k in pbr_keys:
+                comp(_lib.ptr(P0.from_rowmajor("pbr.t", 4, per[k])), 4, out[k], k)
+        pick = "off" if int(em_mode) == 0 else "on"
+        out["srgb/rgb"], out["lin/rgb"] = out[f"srgb/{pick}_rgb"], out[f"lin/{pick}_rgb"]
+        return out
+
     # ------------------------------------------------------------------ PDRA regrouping queries
     @torch.no_grad()
     def eval_query(self, scene, rays_o, rays_d, viewdirs, mask_density, sdf, emit_grid, what: str):

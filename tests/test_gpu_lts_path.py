@@ -311,3 +311,64 @@ def test_lts_step_bf16_mode_tracks_fp32():
     assert abs(res["f32"][0] - res["bf16"][0]) < 1e-2 * abs(res["f32"][0])
     for k, v in res["bf16"][2].items():
         assert bool(torch.isfinite(v).all()), k
+
+
+def test_forward_evaluate_golden():
+    """ESRNeRF.forward_evaluate on the HIP path against the reference-generated fixture: 21 keys with render_pbr
+    (recorded scattering draws, three chunks) and 16 without."""
+    from esr_nerf_amd.synthetic import slab_scene
+    z = {k: torch.from_numpy(np.asarray(v)) for k, v in load_npz("lts_g16_eval.npz").items()}
+    sd = {k: torch.from_numpy(v) for k, v in load_npz("lts_g16_params.npz").items()}
+    sc = slab_scene("g16", s_val=60.0, oblique=True)
+    m, _ = build_lts_model(sc, num_2ndrays=8, num_ltspts=12)
+    m.load_state_dict({k: v.cuda() for k, v in sd.items()})
+    m.s_val = 60.0
+    m.eval()
+    b = {k: sc.batch[k].cuda() for k in ("rays_o", "rays_d", "viewdirs")}
+    dirs = [z[f"draw/dirs{i}"].cuda() for i in range(sum(1 for k in z if k.startswith("draw/dirs")))]
+    for em, pbr, nkeys in ((1, True, 21), (0, False, 16)):
+        res = m(em_modes=em, pos_rt=z["in/pos_rt"].cuda(), render_pbr=pbr, chunk_sz=int(z["in/chunk_sz"]), draws=dirs, **b)
+        keys = [k[5:] for k in z if k.startswith(f"out{em}/")]
+        assert set(keys) == set(res) and len(keys) == nkeys, (sorted(set(keys) ^ set(res)))
+        bad = {}
+        for k in keys:
+            assert res[k].shape == z[f"out{em}/{k}"].shape, (k, res[k].shape)
+            e = rel_err(res[k], z[f"out{em}/{k}"])
+            if not e < TOL:
+                bad[k] = e
+        assert not bad, str(bad)
+    res = m(em_modes=1, pos_rt=torch.eye(3).cuda(), render_pbr=True, chunk_sz=64, **b)       # internal draws
+    assert all(bool(torch.isfinite(v).all()) for v in res.values())
+
+
+def test_evaluate_reads_the_frozen_emit_color_after_finetune():
+    """After a fine-tune froze ``emit_color`` (esrnerf.py:226-234) evaluation keeps reading that copy for the emission
+    head although ``emo_color`` moved on: lin/emit and eval_emit against the oracle with the copy as the emit grid."""
+    from esr_nerf_amd.config import lts_cfg
+    from esr_nerf_amd.synthetic import slab_scene
+    from oracle import fine_path as fp
+    from oracle import lts_path as lp
+    z = {k: torch.from_numpy(np.asarray(v)) for k, v in load_npz("lts_g16_finetune.npz").items()}
+    sd = {k: torch.from_numpy(v) for k, v in load_npz("lts_g16_params.npz").items()}
+    sc = slab_scene("g16", s_val=60.0, oblique=True)
+    m, _ = build_lts_model(sc, num_2ndrays=8, num_ltspts=12)
+    m.load_state_dict({k: v.cuda() for k, v in sd.items()})
+    m.s_val = 60.0
+    m.train(True, finetune=True)
+    with torch.no_grad():
+        m.emo_color.grid.copy_(z["param/emo_color.grid"].cuda())
+    m.eval()
+    assert m.emit_color is not m.emo_color
+    ccfg = lts_cfg("cpu", num_2ndrays=8, num_ltspts=12)
+    c = fp.make_consts(ccfg.app.model, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max, sc.mask_alpha_init,
+                       sc.mask_density, sc.near, sc.num_voxels)
+    sd2 = dict(sd)
+    sd2["emo_color.grid"], sd2["emit_color.grid"] = z["param/emo_color.grid"], z["param/emit_color.grid"]
+    P = fp.params_from_state_dict(sd2, requires_grad=False)
+    b = {k: sc.batch[k].cuda() for k in ("rays_o", "rays_d", "viewdirs")}
+    res = m(em_modes=1, pos_rt=torch.eye(3).cuda(), render_pbr=False, chunk_sz=64, **b)
+    ro = lp.forward_evaluate(P, c, sc.batch, 60.0, sc.far, 1, torch.eye(3), False, 64, [], 8, ccfg.app.model.lts_near,
+                             emit_grid_key="emit_color.grid")
+    for k in ro:
+        assert rel_err(res[k], ro[k]) < TOL, (k, rel_err(res[k], ro[k]))
+    assert rel_err(m.eval_emit(**b), lp.eval_emit(P, c, sc.batch, 60.0, emit_grid_key="emit_color.grid")) < TOL
