@@ -271,6 +271,13 @@ def main():
     for _ in range(a.warmup - n_prof):
         one()
     torch.cuda.synchronize()
+    # A generation-2 pass of Python's cyclic GC over this process (torch modules, thousands of tensors) takes
+    # 50-110 ms -- twenty steps' worth of GPU idle when it lands inside a launch sequence (seen as a "112 ms
+    # feat_bwd").  Collect now, park the survivors, and keep the collector off while kernels are being timed.
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     breakdown, dominant = {}, None
     if n_prof:
         eng.enable_timing(True)
@@ -307,6 +314,7 @@ def main():
         dt = float(t.item())
     kern = eng.timing_summary() if dominant else {}      # dominant kernel only: name -> (launches, total ms)
     eng.enable_timing(False)
+    gc.enable()
     counts = dict(model.last_counts)
 
     # optimizer step, reported separately (outside the named path, never part of `value`)

@@ -229,10 +229,24 @@ constexpr int WIN_FLOATS = 4096;          // 16 KB per wave
 // branch of window_add into one flat_atomic_add_f32 on a selected address
 typedef __attribute__((address_space(3))) float lds_float;
 
-struct Window {
+// Up to four ray-local windows per tile.  At the start of training a tile is 32 consecutive samples of ONE ray;
+// later (large s_val) a ray keeps ~20 samples and a tile holds pieces of 2-3 rays that can sit anywhere in the
+// grid: one bounding box over all of them is mostly empty (the zero / flush loops walked 4096 words per
+// phase) and its clipped remainder sent the other rays' samples to global atomics.  Each of the first four rays
+// of a tile now gets its own tight window (WIN_FLOATS / n_windows words each); a fifth ray goes to global atomics.
+constexpr int MAX_WIN = 4;
+struct WinSet {                        // wave-uniform
+    int nw;                            // windows in use
+    int mn[MAX_WIN][3], mx[MAX_WIN][3];    // bounds of the (clamped) base cells of the window's lanes
+    int lo[MAX_WIN][3], wd[MAX_WIN][3];    // current phase: origin and extent in cells (x, y, z); z fastest
+    int base[MAX_WIN];                 // first LDS word of the window
+    int ch;
+};
+struct LaneWin {                       // the window of THIS lane's sample
     lds_float *lds;
-    int lo[3], wd[3];                     // origin and extent in cells (x, y, z); z fastest
-    int ch;                               // channels per cell
+    int lo[3], wd[3];
+    int ch;
+    bool has;
 };
 
 // Ordering of one wave's own LDS accesses: the hardware executes a wave's DS instructions in
@@ -253,37 +267,88 @@ __device__ __forceinline__ int wave_max_i(int v)
     return v;
 }
 
-// bbox of [i0-below, i0+above] over the valid lanes, clipped to the grid and to WIN_FLOATS/ch cells
-__device__ __forceinline__ void window_setup(Window &w, const int i0[3], bool valid, const int dims[3],
-                                             int below, int above, int ch)
+// window id of every lane (key = ray id of the lane's sample, ascending inside a tile; invalid lanes: none)
+// and the raw cell bounds of each window
+__device__ __forceinline__ int winset_init(WinSet &W, int key, bool valid, const int i0[3])
 {
-    w.ch = ch;
-    int hi[3];
+    constexpr int NONE = 0x7fffffff;
+    const int k0 = valid ? key : NONE;
+    int wid = -1, lower = -1;
+    W.nw = 0;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const int mn = wave_min_i(valid ? i0[a] : 0x3fffffff);
-        const int mx = wave_max_i(valid ? i0[a] : -0x3fffffff);
-        w.lo[a] = max(mn - below, 0);
-        hi[a] = min(mx + above, dims[a] - 1);
-        w.wd[a] = max(hi[a] - w.lo[a] + 1, 0);
+    for (int k = 0; k < MAX_WIN; ++k) {
+        const int c = (k == W.nw) ? wave_min_i(k0 > lower ? k0 : NONE) : NONE;   // k-th smallest distinct key
+        const bool live = c != NONE;                             // wave-uniform
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { W.mn[k][a] = 0x3fffffff; W.mx[k][a] = -0x3fffffff; }
+        if (live) {                                              // (single-ray tiles pay for one window only)
+            W.nw = k + 1;
+            lower = c;
+            const bool mine = k0 == c;
+            if (mine) wid = k;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                W.mn[k][a] = wave_min_i(mine ? i0[a] : 0x3fffffff);
+                W.mx[k][a] = wave_max_i(mine ? i0[a] : -0x3fffffff);
+            }
+        }
     }
-    const int cap = WIN_FLOATS / ch;
-    // too large: shave the longest extent until it fits (the rest goes straight to global memory)
-    // (explicit branches: a runtime index into w.wd[] would push the struct to scratch)
-    while ((long long)w.wd[0] * w.wd[1] * w.wd[2] > cap) {
-        if (w.wd[0] >= w.wd[1] && w.wd[0] >= w.wd[2]) w.wd[0] = (w.wd[0] + 1) >> 1;
-        else if (w.wd[1] >= w.wd[2]) w.wd[1] = (w.wd[1] + 1) >> 1;
-        else w.wd[2] = (w.wd[2] + 1) >> 1;
-    }
+    return wid;
 }
 
-__device__ __forceinline__ void window_zero(const Window &w, int lane)
+// windows of one phase: [mn - below, mx + above] clipped to the grid and to its share of the LDS budget
+__device__ __forceinline__ void winset_phase(WinSet &W, const int dims[3], int below, int above, int ch)
 {
-    const int n = w.wd[0] * w.wd[1] * w.wd[2] * w.ch;
-    for (int i = lane; i < n; i += 64) w.lds[i] = 0.f;
+    W.ch = ch;
+    const int share = WIN_FLOATS / (W.nw > 0 ? W.nw : 1);
+    const int cap = share / ch;
+#pragma unroll
+    for (int k = 0; k < MAX_WIN; ++k) {
+        W.base[k] = k * share;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            W.lo[k][a] = max(W.mn[k][a] - below, 0);
+            const int hi = min(W.mx[k][a] + above, dims[a] - 1);
+            W.wd[k][a] = (k < W.nw) ? max(hi - W.lo[k][a] + 1, 0) : 0;
+        }
+        // too large: shave the longest extent until it fits (the rest goes straight to global memory)
+        while ((long long)W.wd[k][0] * W.wd[k][1] * W.wd[k][2] > cap) {
+            if (W.wd[k][0] >= W.wd[k][1] && W.wd[k][0] >= W.wd[k][2]) W.wd[k][0] = (W.wd[k][0] + 1) >> 1;
+            else if (W.wd[k][1] >= W.wd[k][2]) W.wd[k][1] = (W.wd[k][1] + 1) >> 1;
+            else W.wd[k][2] = (W.wd[k][2] + 1) >> 1;
+        }
+    }
 }
 
-__device__ __forceinline__ void window_add(const Window &w, float *__restrict__ g, const int dims[3],
+__device__ __forceinline__ LaneWin lane_view(const WinSet &W, int wid, lds_float *lds)
+{
+    LaneWin w;
+    w.ch = W.ch;
+    w.has = wid >= 0;
+    int base = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { w.lo[a] = 0; w.wd[a] = 0; }
+#pragma unroll
+    for (int k = 0; k < MAX_WIN; ++k)
+        if (wid == k) {
+            base = W.base[k];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { w.lo[a] = W.lo[k][a]; w.wd[a] = W.wd[k][a]; }
+        }
+    w.lds = lds + base;
+    return w;
+}
+
+__device__ __forceinline__ void winset_zero(const WinSet &W, lds_float *lds, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < MAX_WIN; ++k) {
+        const int n = W.wd[k][0] * W.wd[k][1] * W.wd[k][2] * W.ch;
+        for (int i = lane; i < n; i += 64) lds[W.base[k] + i] = 0.f;
+    }
+}
+
+__device__ __forceinline__ void window_add(const LaneWin &w, float *__restrict__ g, const int dims[3],
                                            int x, int y, int z, int c, float v)
 {
     const int wx = x - w.lo[0], wy = y - w.lo[1], wz = z - w.lo[2];
@@ -294,36 +359,22 @@ __device__ __forceinline__ void window_add(const Window &w, float *__restrict__ 
         atomicAdd(&g[(((int64_t)x * dims[1] + y) * dims[2] + z) * w.ch + c], v);
 }
 
-__device__ __forceinline__ void window_flush(const Window &w, float *__restrict__ g, const int dims[3],
+__device__ __forceinline__ void winset_flush(const WinSet &W, lds_float *lds, float *__restrict__ g, const int dims[3],
                                              int lane)
 {
-    const int row = w.wd[2] * w.ch;                   // floats per (x,y) column, contiguous in memory too
-    const int n = w.wd[0] * w.wd[1] * row;
-    for (int i = lane; i < n; i += 64) {
-        const float v = w.lds[i];
-        if (v != 0.f) {
-            const int xy = i / row, r = i - xy * row;
-            const int wx = xy / w.wd[1], wy = xy - wx * w.wd[1];
-            atomicAdd(&g[(((int64_t)(w.lo[0] + wx) * dims[1] + (w.lo[1] + wy)) * dims[2] + w.lo[2]) * w.ch + r], v);
+#pragma unroll
+    for (int k = 0; k < MAX_WIN; ++k) {
+        const int row = W.wd[k][2] * W.ch;                // floats per (x,y) column, contiguous in memory too
+        const int n = W.wd[k][0] * W.wd[k][1] * row;
+        for (int i = lane; i < n; i += 64) {
+            const float v = lds[W.base[k] + i];
+            if (v != 0.f) {
+                const int xy = i / row, r = i - xy * row;
+                const int wx = xy / W.wd[k][1], wy = xy - wx * W.wd[k][1];
+                atomicAdd(&g[(((int64_t)(W.lo[k][0] + wx) * dims[1] + (W.lo[k][1] + wy)) * dims[2] + W.lo[k][2]) * W.ch + r], v);
+            }
         }
     }
-}
-
-__device__ __forceinline__ void tri_scatter_win(const Window &w, float *__restrict__ g, const int dims[3],
-                                                const float idx[3], float v)
-{
-    Tri t = esr_tri_setup(idx);
-#pragma unroll
-    for (int cx = 0; cx < 2; ++cx)
-#pragma unroll
-        for (int cy = 0; cy < 2; ++cy)
-#pragma unroll
-            for (int cz = 0; cz < 2; ++cz) {
-                int x = t.i0[0] + cx, y = t.i0[1] + cy, z = t.i0[2] + cz;
-                bool inb = (x >= 0) & (x < dims[0]) & (y >= 0) & (y < dims[1]) & (z >= 0) & (z < dims[2]);
-                float wgt = esr_corner_w(t, idx, cx, cy, cz);
-                if (inb && wgt != 0.f) window_add(w, g, dims, x, y, z, 0, v * wgt);
-            }
 }
 
 __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
@@ -335,8 +386,8 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
     const int s = lane & 31, h = lane >> 5;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    Window w;
-    w.lds = (lds_float *)(win_all + (threadIdx.x >> 6) * WIN_FLOATS);
+    lds_float *const lds = (lds_float *)(win_all + (threadIdx.x >> 6) * WIN_FLOATS);
+    WinSet WS;
     for (int t = wave; t < P.tiles_all; t += nwaves) {
         const int j = t * 32 + s;
         const float *Xt = P.X + (size_t)t * XROWS * 32 + s;
@@ -358,13 +409,6 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
 #pragma unroll
             for (int a = 0; a < 3; ++a) i0[a] = (int)floorf(ind[a]);
         }
-        // ---- phase 1: SDF grid.  The value tap and the 24 stencil taps of a sample touch only three
-        // 6x2x2 "bars" of cells (one per axis, sharing the central 2x2x2): the taps of an axis are first
-        // reduced in registers onto the 6 cells along that axis, then spread over the 2x2 perpendicular
-        // corners -- 72 LDS atomics per sample instead of 200 (LDS float atomics retire ~1 lane per 1.5
-        // clocks and were 59 % of this kernel's wave time).  Lane half 0 owns the z bar and the lower half
-        // of the x bar, lane half 1 the y bar and the upper half of the x bar.
-        if (P.grad_sdf) {       // null: the SDF grid is frozen (re-lighting fine-tune), colour phase only
         // The reference clamps every coordinate of a tap to the grid (not only the displaced one), which
         // matters for explicit points that a perturbation pushed outside the box: the bars are anchored
         // at the clamped position (identical to `ind` for in-box samples).
@@ -377,8 +421,18 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
                 i0c[a] = (int)floorf(indc[a]);
             }
         }
-        window_setup(w, i0c, valid, gdims, 2, 3, 1);
-        window_zero(w, lane);
+        // one accumulation window per ray of the tile (explicit points: a single window)
+        const int wid = winset_init(WS, P.pts ? 0 : (valid ? P.rec_ray[j] : 0), valid, i0c);
+        // ---- phase 1: SDF grid.  The value tap and the 24 stencil taps of a sample touch only three
+        // 6x2x2 "bars" of cells (one per axis, sharing the central 2x2x2): the taps of an axis are first
+        // reduced in registers onto the 6 cells along that axis, then spread over the 2x2 perpendicular
+        // corners -- 72 LDS atomics per sample instead of 200 (LDS float atomics retire ~1 lane per 1.5
+        // clocks and were 59 % of this kernel's wave time).  Lane half 0 owns the z bar and the lower half
+        // of the x bar, lane half 1 the y bar and the upper half of the x bar.
+        if (P.grad_sdf) {       // null: the SDF grid is frozen (re-lighting fine-tune), colour phase only
+        winset_phase(WS, gdims, 2, 3, 1);
+        LaneWin w = lane_view(WS, wid, lds);
+        winset_zero(WS, lds, lane);
         lds_fence();
         if (valid) {
             // gradient w.r.t. the finite-difference vectors (through F.normalize), all 3 axes x 4 radii
@@ -469,7 +523,7 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
             }
         }
         lds_fence();
-        window_flush(w, P.grad_sdf, gdims, lane);
+        winset_flush(WS, lds, P.grad_sdf, gdims, lane);
         lds_fence();
         }
         // ---- phase 2: colour grids, one pass per net that read a colour group (3 channels per lane half)
@@ -477,8 +531,9 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
             float *gcol = on_tile ? P.gcol_on[k] : P.gcol_off[k];
             if (!gcol || t < P.src_t0[k] || t >= P.src_t1[k]) continue;       // wave-uniform
             const float *dXt = P.dX[k] + (size_t)t * DXROWS * 32 + s;
-            window_setup(w, i0, valid, gdims, 0, 1, 6);
-            window_zero(w, lane);
+            winset_phase(WS, gdims, 0, 1, 6);
+            const LaneWin w = lane_view(WS, wid, lds);
+            winset_zero(WS, lds, lane);
             lds_fence();
             if (valid) {
                 float d3[3];
@@ -501,7 +556,7 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
                         }
             }
             lds_fence();
-            window_flush(w, gcol, gdims, lane);
+            winset_flush(WS, lds, gcol, gdims, lane);
             lds_fence();
         }
     }
