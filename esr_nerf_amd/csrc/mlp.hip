@@ -22,10 +22,10 @@
 //  * Hidden activations are saved tile-major [tile][feature][32] (each store = two
 //    full 128-B lines) and re-read by the backward instead of being recomputed: the
 //    f32 matrix rate (157 TF) is the binding roof, HBM (8 TB/s) has headroom.
-//  * Weight gradients contract over SAMPLES; both operands are read straight from the
-//    tile-major buffers with 16-B loads along the sample axis, each wave keeps a
-//    96x96 block of dW in 144 accumulator registers across its whole tile range and
-//    flushes it with 128-B-contiguous float atomics once.
+//  * Weight gradients contract over SAMPLES: a workgroup stages the two operand tiles of a
+//    sample tile through a 3-stage LDS ring (coalesced 16-B buffer loads), its four waves
+//    keep the whole dW block of a layer in accumulator registers across the workgroup's tile
+//    range, and the partial blocks go to per-workgroup slabs that a second kernel sums.
 #include "esr_common.h"
 
 #include "mlp_common.h"
@@ -174,7 +174,7 @@ struct WgradArgs {
 // tile).  The predecessor of this kernel let every wave fetch its operand rows straight
 // from global memory with a 128-B lane stride: 2x redundant traffic and 64 cache lines
 // per load instruction -- 49 TF.  Accumulators (up to 144 registers) live across the
-// whole tile range and are flushed once with 128-B-contiguous float atomics.
+// whole tile range and are written once to the workgroup's slab (see the flush below).
 constexpr int LDS_STRIDE = 36;        // floats per staged row (32 samples + 4 pad)
 
 // BF: bf16 operands (v_mfma_f32_32x32x16_bf16, 16 samples per k-step, values rounded on the way from LDS to the

@@ -9,13 +9,13 @@ node over the kernels of libesr_hip.so (esr_nerf_amd/lts_engine.py).
 
 ``forward_finetune`` (re-lighting fine-tune target, esrnerf.py:241-484) runs on the same kernels.
 ``eval_emit`` / ``eval_esp`` (the PDRA trainer's regrouping queries) are forward-only passes over the same kernels.
-``forward_evaluate`` renders images incl. the per-sample light-transport decomposition.  Not provided: ``render_envmap``,
-``extract_geometry``.
+``forward_evaluate`` renders images incl. the per-sample light-transport decomposition.  ``render_envmap`` / ``extract_geometry`` are torch utilities outside the path.
 """
 from __future__ import annotations
 
 from typing import Dict, List
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -314,6 +314,14 @@ class ESRNeRF(VoxurfF):
                             kwargs["rays_d"].contiguous(), kwargs["viewdirs"].contiguous(), grids, env, kwargs["pos_rt"],
                             self.far, em, bool(kwargs.get("render_pbr", False)), int(kwargs.get("chunk_sz", 4096)),
                             self.num_2ndrays, draws)
+
+    @torch.no_grad()
+    def render_envmap(self, H, W):
+        """Lat-long image [H,W,3] of the spherical-Gaussian environment map (esrnerf.py:1675-1691); a logging utility."""
+        phi, theta = torch.meshgrid([torch.linspace(0.0, np.pi, H, device=self.device),
+                                     torch.linspace(1.0 * np.pi, -1.0 * np.pi, W, device=self.device)], indexing="ij")
+        dirs = torch.stack([torch.cos(theta) * torch.sin(phi), torch.sin(theta) * torch.sin(phi), torch.cos(phi)], -1)
+        return self.envmap(dirs.view(-1, 3)).view(H, W, 3)
 
     @torch.no_grad()
     def scale_volume_grid(self, num_voxels):

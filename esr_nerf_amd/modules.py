@@ -219,3 +219,40 @@ class TonemapNet(nn.Module):
 
     def forward(self, x):
         return torch.sigmoid(self.srgb(x))
+
+
+def extract_sdf_field(model, resolution=512, batch_size=64, smooth=True, sigma=0.5) -> torch.Tensor:
+    """``-sdf`` on a resolution^3 lattice of the bounding box (extract_fields + the query of extract_geometry,
+    app/utils/base/functions.py:108-139, voxurff.py:745-770).  A mesh-export utility outside the rendering path:
+    plain torch ``grid_sample`` in ``batch_size``^3 blocks."""
+    lo, hi = model.xyz_min.float(), model.xyz_max.float()
+    grid = model.sdf.grid
+    if smooth:
+        grid = Gaussian3DConv(sigma=sigma).to(grid.device)(grid)
+    if resolution is None:
+        resolution = int(model.world_size[0])
+    axes = [torch.linspace(float(lo[i]), float(hi[i]), resolution, device=grid.device) for i in range(3)]
+    u = torch.zeros([resolution] * 3, device=grid.device)
+    with torch.no_grad():
+        for xi, xs in enumerate(axes[0].split(batch_size)):
+            for yi, ys in enumerate(axes[1].split(batch_size)):
+                for zi, zs in enumerate(axes[2].split(batch_size)):
+                    pts = torch.stack(torch.meshgrid(xs, ys, zs, indexing="ij"), -1).reshape(1, 1, 1, -1, 3)
+                    norm = ((pts - lo) / (hi - lo)).flip((-1,)) * 2 - 1
+                    val = F.grid_sample(-grid, norm, mode="bilinear", align_corners=True).reshape(len(xs), len(ys), len(zs))
+                    u[xi * batch_size: xi * batch_size + len(xs), yi * batch_size: yi * batch_size + len(ys),
+                      zi * batch_size: zi * batch_size + len(zs)] = val
+    return u
+
+
+def extract_geometry(model, resolution=512, threshold=0.0, batch_size=64, smooth=True, sigma=0.5):
+    """(vertices, triangles) of the zero level set, as the reference's ``extract_geometry`` (needs PyMCubes)."""
+    try:
+        import mcubes
+    except ImportError as e:                                         # not in this image; the reference requires it too
+        raise ImportError("extract_geometry needs PyMCubes (`mcubes`), as the reference does (requirements.txt)") from e
+    u = extract_sdf_field(model, resolution, batch_size, smooth, sigma).cpu().numpy()
+    vertices, triangles = mcubes.marching_cubes(u, threshold)
+    lo, hi = model.xyz_min.float().cpu().numpy(), model.xyz_max.float().cpu().numpy()
+    res = u.shape[0]
+    return vertices / (res - 1.0) * (hi - lo)[None, :] + lo[None, :], triangles

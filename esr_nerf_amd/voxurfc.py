@@ -382,3 +382,9 @@ class VoxurfC(nn.Module):
             rays_o.contiguous(), rays_d.contiguous(), self.xyz_min, self.xyz_max, self.near, 1e9, stepdist)[:4]
         keep = ~out_box
         return pts[keep], ray_id[keep], step_id[keep]
+
+    def extract_geometry(self, resolution: int = 512, threshold: float = 0.0, batch_size: int = 64, smooth: bool = True,
+                         sigma: float = 0.5):
+        """Mesh export (marching cubes over -sdf); a utility outside the rendering path, see modules.extract_geometry."""
+        from .modules import extract_geometry
+        return extract_geometry(self, resolution, threshold, batch_size, smooth, sigma)

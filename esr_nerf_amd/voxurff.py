@@ -285,3 +285,9 @@ class VoxurfF(nn.Module):
             hit[ray_id[self.mask_cache(pts)]] = True
             hit_all[idx] = hit
         return hit_all
+
+    def extract_geometry(self, resolution: int = 512, threshold: float = 0.0, batch_size: int = 64, smooth: bool = True,
+                         sigma: float = 0.5):
+        """Mesh export (marching cubes over -sdf); a utility outside the rendering path, see modules.extract_geometry."""
+        from .modules import extract_geometry
+        return extract_geometry(self, resolution, threshold, batch_size, smooth, sigma)

@@ -203,3 +203,32 @@ def test_optimizer_groups_freeze_and_no_cpu_fallback():
     m.b.grad = torch.ones(4)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         opt.step()
+
+
+def test_mesh_and_envmap_utilities():
+    """extract_geometry's field sampler reproduces -sdf at the grid nodes; render_envmap matches the oracle's SG
+    evaluation; without PyMCubes extract_geometry says so."""
+    from esr_nerf_amd.config import lts_cfg
+    from esr_nerf_amd.esrnerf import ESRNeRF
+    from esr_nerf_amd.modules import extract_sdf_field
+    from esr_nerf_amd.synthetic import init_slab_model, slab_scene
+    from oracle import lts_path as lp
+    sc = slab_scene("g16")
+    torch.manual_seed(0)
+    m = ESRNeRF(lts_cfg("cpu"), sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max, sc.mask_alpha_init,
+                sc.mask_density, sc.s_val, sc.num_voxels)
+    init_slab_model(m, sc)
+    u = extract_sdf_field(m, resolution=9, batch_size=4, smooth=False)
+    assert u.shape == (9, 9, 9)
+    corner = float(-m.sdf.grid[0, 0, 0, 0, 0])
+    assert abs(float(u[0, 0, 0]) - corner) < 1e-6 and abs(float(u[-1, -1, -1]) + float(m.sdf.grid[0, 0, -1, -1, -1])) < 1e-6
+    img = m.render_envmap(6, 8)
+    assert img.shape == (6, 8, 3)
+    P = {"envmap.mus": m.envmap.mus.detach(), "envmap.lambdas": m.envmap.lambdas.detach(), "envmap.lobes": m.envmap.lobes.detach()}
+    d = torch.tensor([[0.0, 0.0, 1.0]])                               # phi = 0: the first image row looks along +z
+    assert rel_err(img[0, 0], lp.sg_envmap(P, d)[0]) < 1e-5
+    try:
+        import mcubes  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match="PyMCubes"):
+            m.extract_geometry(resolution=8)
