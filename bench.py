@@ -420,8 +420,10 @@ def main():
     if pg is not None:
         dist.destroy_process_group()
     if rank == 0:
+        import ctypes
         sys.stdout.flush()
-        print(line, flush=True)              # the ONE JSON line, last on stdout (RCCL may print banners before)
+        ctypes.CDLL(None).fflush(None)       # RCCL's version banner sits in the C stdio buffer until exit: push it out first
+        print(line, flush=True)              # the ONE JSON line, last on stdout
 
 
 if __name__ == "__main__":

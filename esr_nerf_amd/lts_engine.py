@@ -92,6 +92,7 @@ class LtsEngine(FineEngine):
         self.pts = Pass(self.device, "points")
         self.sec = Pass(self.device, "secondary")
         self.epsp = Pass(self.device, "eps")
+        self._deferred = None
         for k, kind in (("brdf", KIND_BRDF), ("emit", KIND_EMIT)):
             self.packed[k] = torch.empty(self.L.esr_mlp_packed_floats(kind), dtype=torch.float32,
                                          device=self.device)
@@ -190,9 +191,16 @@ class LtsEngine(FineEngine):
             s = self._s()
             self._run(f"mlp_dgrad({net})[{P.name}]", self.mlp_dgrad, kind, _lib.ptr(self.packed[net]),
                       _lib.ptr(dz), t0, t1, _lib.ptr_array(M), _lib.ptr_array(dZ), _lib.ptr(dX), s)
-            self._run(f"mlp_wgrad({net})[{P.name}]", self.mlp_wgrad, kind, _lib.ptr(x), crow,
-                      _lib.ptr_array(H), _lib.ptr_array(dZ), _lib.ptr(dz), t0, t1, _lib.ptr_array(gw),
-                      _lib.ptr_array(gb), _lib.ptr(self.wgrad_scratch), C.c_int64(self.wgrad_scratch.numel()), s)
+            def wgrad():
+                self._run(f"mlp_wgrad({net})[{P.name}]", self.mlp_wgrad, kind, _lib.ptr(x), crow,
+                          _lib.ptr_array(H), _lib.ptr_array(dZ), _lib.ptr(dz), t0, t1, _lib.ptr_array(gw),
+                          _lib.ptr_array(gb), _lib.ptr(self.wgrad_scratch), C.c_int64(self.wgrad_scratch.numel()), self._s())
+            # lts_backward defers the weight-gradient launches to the end of the step so that the dense-grid
+            # gradients are complete (and their all-reduce can start) before ~2.5 ms of matrix work
+            if self._deferred is not None:
+                self._deferred.append(wgrad)
+            else:
+                wgrad()
         return dX
 
     def _act(self, P, zname, out, rows, n_ch, act, bwd_g=None, tiles=None):
@@ -659,9 +667,22 @@ class LtsEngine(FineEngine):
         return ctx, out
 
     # ------------------------------------------------------------------ backward
-    def lts_backward(self, ctx: LtsCtx, g: Dict[str, Optional[torch.Tensor]], grads):
+    def lts_backward(self, ctx: LtsCtx, g: Dict[str, Optional[torch.Tensor]], grads, after_grids=None):
         """g: gradients w.r.t. the tensors of lts_forward's dict (None = zero).  grads: zero-initialised
-        dict: sdf, off, emo, brdf grids; {off,emo,tone,brdf,emit}_{w,b} lists; mus, lambdas, lobes."""
+        dict: sdf, off, emo, brdf grids; {off,emo,tone,brdf,emit}_{w,b} lists; mus, lambdas, lobes.
+        Order: every input-gradient chain and grid scatter first, then ``after_grids()`` (the data-parallel step
+        starts the dense-grid all-reduce there), then the deferred weight-gradient launches."""
+        self._deferred = []
+        try:
+            self._lts_backward(ctx, g, grads)
+            if after_grids is not None:
+                after_grids()
+            for w in self._deferred:
+                w()
+        finally:
+            self._deferred = None
+
+    def _lts_backward(self, ctx: LtsCtx, g: Dict[str, Optional[torch.Tensor]], grads):
         L, s, dev = self.L, self._s(), self.device
         P0, P1, P2 = self.prim, self.pts, self.sec
         T, Ton = P0.tiles_all, P0.tiles_on

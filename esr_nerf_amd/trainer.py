@@ -155,7 +155,8 @@ class LtsStep:
 
     Data parallelism as in ``FineStep``: every rank renders its own ray shard and its own
     ``num_ltspts`` surface points (per process, as in the reference), every loss term is scaled by
-    ``n_local / n_global`` and ONE flat gradient buffer is summed over the ranks."""
+    ``n_local / n_global`` and ONE flat gradient buffer is summed over the ranks -- the dense-grid part
+    asynchronously as soon as the scatters are done, underneath the weight-gradient kernels."""
 
     NETS = (("off_rgbnet", "linear"), ("emo_rgbnet", "linear"), ("tonemapper", "srgb"), ("brdfnet", "brdfnet"),
             ("emitnet", "brdfnet"))
@@ -190,10 +191,12 @@ class LtsStep:
             self._flat = torch.empty(total, dtype=torch.float32, device=dev)
         self._flat.zero_()
         out, o = {}, 0
-        for n, s in shapes:
+        for i, (n, s) in enumerate(shapes):
             k = int(torch.Size(s).numel())
             out[n] = self._flat[o:o + k].view(s)
             o += k
+            if i == 3:
+                self._n_grid = o          # [0, _n_grid): the four dense grids; the rest: MLP + env-map tensors
         return out
 
     def _pair(self, eng, loss, a, b, kind, w_value, w_a, w_b, scale, want_gb=True, row_mask=None, mask_value=0,
@@ -269,11 +272,20 @@ class LtsStep:
         grads = dict(sdf=G["sdf.grid"], off=G["off_color.grid"], emo=G["emo_color.grid"], brdf=G["brdf.grid"],
                      off_w=ow, off_b=ob, emo_w=ew, emo_b=eb, tone_w=tw, tone_b=tb, brdf_w=bw, brdf_b=bb,
                      emit_w=mw, emit_b=mb, mus=G["envmap.mus"], lambdas=G["envmap.lambdas"], lobes=G["envmap.lobes"])
-        eng.lts_backward(ctx, g, grads)
+        works = []
         if self.pg is not None:
             import torch.distributed as dist
-            works = [dist.all_reduce(self._flat, group=self.pg, async_op=True),
-                     dist.all_reduce(loss, group=self.pg, async_op=True)]
+
+            def after_grids():
+                # the four grid gradients (> 99 % of the payload) are final here: their all-reduce runs on RCCL's
+                # stream underneath the deferred weight-gradient kernels
+                works.append(dist.all_reduce(self._flat[: self._n_grid], group=self.pg, async_op=True))
+        else:
+            after_grids = None
+        eng.lts_backward(ctx, g, grads, after_grids=after_grids)
+        if self.pg is not None:
+            works.append(dist.all_reduce(self._flat[self._n_grid:], group=self.pg, async_op=True))
+            works.append(dist.all_reduce(loss, group=self.pg, async_op=True))
             for w in works:
                 w.wait()
         for k in ("off_color.grid", "emo_color.grid", "brdf.grid"):
