@@ -41,14 +41,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "small", "tiny"])
+    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5", "small", "tiny"],
+                    help="BASELINE.json configs: C2 fine fp32 (headline), C3 fine 192 samples, C4 lts, C5 = C4 scene, pdra stage, "
+                         "bf16 MLPs")
     ap.add_argument("--stage", default=None, choices=["fine", "lts", "pdra"],
                     help="trainer step to run (default: fine; C4 defaults to lts)")
     ap.add_argument("--s-val", type=float, default=None, help="default 20 (fine.yaml:45) / 220 (lts.yaml:52)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--cpu-iters", type=int, default=3)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
                     help="MLP operand type: f32 (f32 matrix cores, the headline) or bf16 (bf16 operands, fp32 accumulation)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the gradient all-reduces even with one rank (self-test)")
@@ -202,6 +204,9 @@ def cpu_baseline_lts(model, scene, s_val, n_rays, iters, stage, tr):
 
 def main():
     a = parse()
+    if a.config == "C5":
+        a.config, a.stage, a.dtype = "C4", a.stage or "pdra", a.dtype or "bf16"
+    a.dtype = a.dtype or "f32"
     stage = a.stage or ("lts" if a.config == "C4" else "fine")
     if a.s_val is None:
         a.s_val = 20.0 if stage == "fine" else 220.0
