@@ -177,15 +177,21 @@ struct WgradArgs {
 // whole tile range and are written once to the workgroup's slab (see the flush below).
 constexpr int LDS_STRIDE = 36;        // floats per staged row (32 samples + 4 pad)
 
-// BF: bf16 operands (v_mfma_f32_32x32x16_bf16, 16 samples per k-step, values rounded on the way from LDS to the
-// operand registers), fp32 accumulation and fp32 staging -- the weight-gradient kernel of the bf16 configurations.
-template <int MI, int NJ, int WM, int WN, int WK, bool BF>
+// MODE 0: f32 matrix cores.  MODE 1-3: bf16 operands (v_mfma_f32_32x32x16_bf16, 16 samples per k-step), fp32
+// accumulation -- the weight-gradient kernel of the bf16 configurations, where the saved hidden tiles (H, dZ) are
+// bf16 [row][32] (64-B rows, staged as they are and read from LDS as ready-made 8-element operands) while the
+// network input X and the output gradient dz are fp32 (rounded on the way from LDS to the operand registers):
+//   1 = output layer (A = dz fp32, B = H bf16), 2 = hidden layer (both bf16), 3 = first layer (A = dZ bf16, B = X fp32).
+template <int MI, int NJ, int WM, int WN, int WK, int MODE>
 __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradArgs W)
 {
+    constexpr bool BF = MODE != 0;
+    constexpr bool A16 = MODE == 2 || MODE == 3, B16 = MODE == 1 || MODE == 2;
     constexpr int NW = WM * WN * WK, NT = 64 * NW;
     constexpr int RAP = WM * MI * 32, RBP = WN * NJ * 32;          // staged rows (padded to tiles)
     constexpr int BUF = (RAP + RBP) * LDS_STRIDE;                  // floats per LDS buffer
-    constexpr int LA = RAP * 8 / NT, LB = RBP * 8 / NT;            // float4 loads per thread
+    constexpr int STRIDE16 = 20;                                   // floats per staged bf16 row (64 B + 16 B pad)
+    constexpr int LA = RAP * (A16 ? 4 : 8) / NT, LB = RBP * (B16 ? 4 : 8) / NT;   // 16-B loads per thread
     constexpr int NU = 4 / WK;                                     // 8-sample groups per wave per tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, rl = lane & 31;
@@ -209,58 +215,79 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradAr
     // zero): no per-load branches, so the whole step is one basic block and hipcc keeps a COUNTED
     // vmcnt at the commit (with predicated plain loads it fell back to vmcnt(0) and drained the
     // prefetch every iteration).
-    static_assert(LA * NT == RAP * 8 && LB * NT == RBP * 8, "staging covers the padded tiles exactly");
+    static_assert(LA * NT == RAP * (A16 ? 4 : 8) && LB * NT == RBP * (B16 ? 4 : 8),
+                  "staging covers the padded tiles exactly");
     // Past the end of the tile range the descriptor gets ZERO records: the loads still issue (so the
     // vmcnt arithmetic is the same on every trip) but touch no memory and return zeros.
     auto issue = [&](int t, float4 (&ra)[LA], float4 (&rb_)[LB]) {
         const bool live = t < W.t1;
         const int tc = live ? t : W.t0;
-        const rsrc_t SA = make_rsrc(W.A + (size_t)tc * W.RA * 32, live ? (unsigned)W.RA * 128u : 0u);
-        const rsrc_t SB = make_rsrc(W.B + (size_t)tc * W.b_tile_rows * 32, live ? (unsigned)W.b_tile_rows * 128u : 0u);
+        constexpr unsigned RBA = A16 ? 64u : 128u, RBB = B16 ? 64u : 128u;          // bytes per stored row
+        const rsrc_t SA = make_rsrc(reinterpret_cast<const char *>(W.A) + (size_t)tc * W.RA * RBA,
+                                    live ? (unsigned)W.RA * RBA : 0u);
+        const rsrc_t SB = make_rsrc(reinterpret_cast<const char *>(W.B) + (size_t)tc * W.b_tile_rows * RBB,
+                                    live ? (unsigned)W.b_tile_rows * RBB : 0u);
 #pragma unroll
         for (int k = 0; k < LA; ++k) ra[k] = bload4(SA, (tid + k * NT) * 16, 0);
 #pragma unroll
         for (int k = 0; k < LB; ++k) {
             const int q = tid + k * NT;                                  // float4 index: row q/8
             // rows 0-5 of a first layer come from the net's colour group of the X tile
-            const int src = (q < W.cw8) ? q + W.crow * 8 : q;
+            const int src = (!B16 && q < W.cw8) ? q + W.crow * 8 : q;
             rb_[k] = bload4(SB, src * 16, 0);       // (tiles shorter than the staged block read as zero)
         }
     };
     auto commit = [&](int buf, const float4 (&ra)[LA], const float4 (&rb_)[LB]) {
-        float *La = lds + buf * BUF, *Lb = La + RAP * LDS_STRIDE;
+        float *La = lds + buf * BUF, *Lb = La + RAP * (A16 ? STRIDE16 : LDS_STRIDE);
 #pragma unroll
         for (int k = 0; k < LA; ++k) {
             const int q = tid + k * NT;
-            *reinterpret_cast<float4 *>(La + (q >> 3) * LDS_STRIDE + (q & 7) * 4) = ra[k];
+            if (A16) *reinterpret_cast<float4 *>(La + (q >> 2) * STRIDE16 + (q & 3) * 4) = ra[k];
+            else *reinterpret_cast<float4 *>(La + (q >> 3) * LDS_STRIDE + (q & 7) * 4) = ra[k];
         }
 #pragma unroll
         for (int k = 0; k < LB; ++k) {
             const int q = tid + k * NT;
-            *reinterpret_cast<float4 *>(Lb + (q >> 3) * LDS_STRIDE + (q & 7) * 4) = rb_[k];
+            if (B16) *reinterpret_cast<float4 *>(Lb + (q >> 2) * STRIDE16 + (q & 3) * 4) = rb_[k];
+            else *reinterpret_cast<float4 *>(Lb + (q >> 3) * LDS_STRIDE + (q & 7) * 4) = rb_[k];
         }
     };
     auto compute = [&](int cur) {
         if constexpr (BF) {
             static_assert(WK <= 2, "a tile has two 16-sample k-steps");
             constexpr int NU16 = 2 / WK;
-            const float *La = lds + cur * BUF + (wm * MI * 32 + rl) * LDS_STRIDE + 8 * h;
-            const float *Lb = lds + cur * BUF + (RAP + wn * NJ * 32 + rl) * LDS_STRIDE + 8 * h;
+            // fp32-staged operand: row stride LDS_STRIDE floats, 8 samples = two float4; bf16-staged: STRIDE16
+            // floats per row, 8 samples = one 16-B read that IS the MFMA operand
+            constexpr int SA_ = A16 ? STRIDE16 : LDS_STRIDE, SB_ = B16 ? STRIDE16 : LDS_STRIDE;
+            const float *La = lds + cur * BUF + (wm * MI * 32 + rl) * SA_ + (A16 ? 4 : 8) * h;
+            const float *Lb = lds + cur * BUF + RAP * SA_ + (wn * NJ * 32 + rl) * SB_ + (B16 ? 4 : 8) * h;
 #pragma unroll
             for (int uu = 0; uu < NU16; ++uu) {
                 const int u = wk * NU16 + uu;
                 bf16x8 a[MI], b[NJ];
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
-                    const float4 lo = *reinterpret_cast<const float4 *>(La + i * 32 * LDS_STRIDE + 16 * u);
-                    const float4 hi = *reinterpret_cast<const float4 *>(La + i * 32 * LDS_STRIDE + 16 * u + 4);
-                    bsum[i] += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
-                    a[i] = pack8(lo, hi);
+                    if (A16) {
+                        a[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(La + i * 32 * SA_ + 8 * u));
+                        float t8 = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) t8 += (float)a[i][e];
+                        bsum[i] += t8;
+                    } else {
+                        const float4 lo = *reinterpret_cast<const float4 *>(La + i * 32 * SA_ + 16 * u);
+                        const float4 hi = *reinterpret_cast<const float4 *>(La + i * 32 * SA_ + 16 * u + 4);
+                        bsum[i] += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
+                        a[i] = pack8(lo, hi);
+                    }
                 }
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    b[j] = pack8(*reinterpret_cast<const float4 *>(Lb + j * 32 * LDS_STRIDE + 16 * u),
-                                 *reinterpret_cast<const float4 *>(Lb + j * 32 * LDS_STRIDE + 16 * u + 4));
+                for (int j = 0; j < NJ; ++j) {
+                    if (B16)
+                        b[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(Lb + j * 32 * SB_ + 8 * u));
+                    else
+                        b[j] = pack8(*reinterpret_cast<const float4 *>(Lb + j * 32 * SB_ + 16 * u),
+                                     *reinterpret_cast<const float4 *>(Lb + j * 32 * SB_ + 16 * u + 4));
+                }
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -367,7 +394,7 @@ int mlp_grid(int n_tiles)
     return wg;
 }
 
-template <int MI, int NJ, int WM, int WN, int WK, bool BF = false>
+template <int MI, int NJ, int WM, int WN, int WK, int MODE = 0>
 int launch_wgrad(const WgradArgs &W, int64_t slab_floats, hipStream_t s)
 {
     const int n_tiles = W.t1 - W.t0;
@@ -377,7 +404,7 @@ int launch_wgrad(const WgradArgs &W, int64_t slab_floats, hipStream_t s)
     constexpr size_t lds_bytes = 2 * (size_t)(WM * MI * 32 + WN * NJ * 32) * LDS_STRIDE * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {       // > 64 KB of dynamic LDS needs the opt-in
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_kernel<MI, NJ, WM, WN, WK, BF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_kernel<MI, NJ, WM, WN, WK, MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -386,7 +413,7 @@ int launch_wgrad(const WgradArgs &W, int64_t slab_floats, hipStream_t s)
     if (grid > n_tiles) grid = n_tiles;
     const int n_elems = W.out_rows * W.ld;
     if ((int64_t)grid * WK * n_elems > slab_floats) return ESR_ECAP;
-    mlp_wgrad_kernel<MI, NJ, WM, WN, WK, BF><<<grid, NT, lds_bytes, s>>>(W);
+    mlp_wgrad_kernel<MI, NJ, WM, WN, WK, MODE><<<grid, NT, lds_bytes, s>>>(W);
     ESR_CHECK_LAUNCH();
     const int groups = (grid * WK + 31) / 32;
     wgrad_reduce_kernel<<<esr_grid_for((int64_t)n_elems * groups, 256, 2048), 256, 0, s>>>(W.slab, grid * WK,
@@ -516,14 +543,14 @@ static int wgrad_all(int kind, const float *X, int color_row0, const float *cons
         //   128-wide nets: 128x128 -> 2x2x1, 128x96 -> 2x1x2, 8x128 -> 1x2x2
         int rc;
         if (D.hid_tiles == 6) {
-            if (last) rc = launch_wgrad<1, 3, 1, 2, 2, BF>(W, scratch_floats, s);
-            else if (first && W.RB <= 64) rc = launch_wgrad<3, 2, 2, 1, 2, BF>(W, scratch_floats, s);   // tone mapper: 48 input rows
-            else if (first) rc = launch_wgrad<3, 3, 2, 1, 2, BF>(W, scratch_floats, s);
-            else rc = launch_wgrad<3, 3, 2, 2, 1, BF>(W, scratch_floats, s);
+            if (last) rc = launch_wgrad<1, 3, 1, 2, 2, BF ? 1 : 0>(W, scratch_floats, s);
+            else if (first && W.RB <= 64) rc = launch_wgrad<3, 2, 2, 1, 2, BF ? 3 : 0>(W, scratch_floats, s);   // tone mapper: 48 input rows
+            else if (first) rc = launch_wgrad<3, 3, 2, 1, 2, BF ? 3 : 0>(W, scratch_floats, s);
+            else rc = launch_wgrad<3, 3, 2, 2, 1, BF ? 2 : 0>(W, scratch_floats, s);
         } else {
-            if (last) rc = launch_wgrad<1, 2, 1, 2, 2, BF>(W, scratch_floats, s);
-            else if (first) rc = launch_wgrad<2, 3, 2, 1, 2, BF>(W, scratch_floats, s);
-            else rc = launch_wgrad<2, 2, 2, 2, 1, BF>(W, scratch_floats, s);
+            if (last) rc = launch_wgrad<1, 2, 1, 2, 2, BF ? 1 : 0>(W, scratch_floats, s);
+            else if (first) rc = launch_wgrad<2, 3, 2, 1, 2, BF ? 3 : 0>(W, scratch_floats, s);
+            else rc = launch_wgrad<2, 2, 2, 2, 1, BF ? 2 : 0>(W, scratch_floats, s);
         }
         if (rc) return rc;
     }

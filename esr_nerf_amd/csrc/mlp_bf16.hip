@@ -3,9 +3,11 @@
 //
 // Same networks, same "transposed" chain as mlp.hip (one wave owns 32 samples end to end, the accumulator of
 // layer l is the B operand of layer l+1), with bf16 OPERANDS and fp32 ACCUMULATION: weights are rounded to bf16
-// by esr_mlp_pack_bf16, activations are rounded when they become an MFMA operand (v_cvt_pk_bf16_f32), biases,
-// accumulators, saved activations, ReLU masks and every gradient buffer stay fp32 -- so the feature kernels,
-// the shading kernels and the buffers of the fp32 path are shared unchanged.
+// by esr_mlp_pack_bf16, activations are rounded when they become an MFMA operand (v_cvt_pk_bf16_f32); biases and
+// accumulators are fp32; the tiles saved for the backward (hidden activations H, hidden gradients dZ) are stored as
+// bf16 -- they are only ever read back as bf16 operands of the weight-gradient kernel, and they are most of this
+// engine's HBM traffic; the network inputs X, outputs z / dz and the input gradient dX stay fp32, so the feature and
+// shading kernels of the fp32 path are shared unchanged.
 //
 // A 32x32x16 bf16 MFMA takes 8 consecutive k values per lane (k block = lane >> 5).  Accumulator register r
 // of lane-half h holds row (r & 3) + 8 (r >> 2) + 4 h, so the 16 rows 16 jj .. 16 jj + 15 of a 32-row tile are
@@ -155,7 +157,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd16_kernel(Fwd16Args A)
     constexpr NetDesc D = net_desc(KIND);
     constexpr int NHID = D.n_layers - 1;
     constexpr int HT = D.hid_tiles;
-    constexpr unsigned HBYTES = HT * 32 * 32 * 4, MBYTES = (HT / 2) * 256;
+    constexpr unsigned HBYTES = HT * 32 * 32 * 2, MBYTES = (HT / 2) * 256;      // saved tiles are bf16
     constexpr PackLayout L32 = pack_layout(KIND);
     constexpr Pack16Layout L = pack16_layout(KIND);
     constexpr int KS1 = L.ks[0];
@@ -182,7 +184,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd16_kernel(Fwd16Args A)
         stream_layer16<KS1, HT>(W16, (int)L.off_wf[0] * 2, [&](int j) { return B1[j]; }, cur, lane);
         relu_tiles<HT>(cur);
         if (A.save) {
-            store_tiles<HT>(make_rsrc(A.H[0] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
+            store_tiles_bf16<HT>(make_rsrc(A.H[0] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
             store_relu_mask<HT>(make_rsrc(A.M[0] + (size_t)t * (MBYTES / 4), MBYTES), cur, lane);
         }
 #pragma unroll
@@ -192,7 +194,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd16_kernel(Fwd16Args A)
             layer16_from_acc<HT, HT>(W16, (int)L.off_wf[l] * 2, cur, nxt, lane);
             relu_tiles<HT>(nxt);
             if (A.save) {
-                store_tiles<HT>(make_rsrc(A.H[l] + (size_t)t * (HBYTES / 4), HBYTES), nxt, lane);
+                store_tiles_bf16<HT>(make_rsrc(A.H[l] + (size_t)t * (HBYTES / 4), HBYTES), nxt, lane);
                 store_relu_mask<HT>(make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), nxt, lane);
             }
 #pragma unroll
@@ -226,7 +228,7 @@ __global__ void __launch_bounds__(256, 2) mlp_dgrad16_kernel(Dgrad16Args A)
     constexpr NetDesc D = net_desc(KIND);
     constexpr int NHID = D.n_layers - 1;
     constexpr int HT = D.hid_tiles;
-    constexpr unsigned HBYTES = HT * 32 * 32 * 4, MBYTES = (HT / 2) * 256;
+    constexpr unsigned HBYTES = HT * 32 * 32 * 2, MBYTES = (HT / 2) * 256;      // dZ tiles are bf16
     constexpr Pack16Layout L = pack16_layout(KIND);
     const int lane = esr_lane();
     const int h = lane >> 5, s = lane & 31;
@@ -249,14 +251,14 @@ __global__ void __launch_bounds__(256, 2) mlp_dgrad16_kernel(Dgrad16Args A)
         zero_tiles<HT>(cur);
         stream_layer16<1, HT>(W16, (int)L.off_wb[NHID] * 2, [&](int) { return B0; }, cur, lane);
         apply_relu_mask<HT>(msk[NHID - 1], cur);
-        store_tiles<HT>(make_rsrc(A.dZ[NHID - 1] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
+        store_tiles_bf16<HT>(make_rsrc(A.dZ[NHID - 1] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
 #pragma unroll
         for (int l = NHID - 1; l >= 1; --l) {
             f32x16 nxt[HT];
             zero_tiles<HT>(nxt);
             layer16_from_acc<HT, HT>(W16, (int)L.off_wb[l] * 2, cur, nxt, lane);
             apply_relu_mask<HT>(msk[l - 1], nxt);
-            store_tiles<HT>(make_rsrc(A.dZ[l - 1] + (size_t)t * (HBYTES / 4), HBYTES), nxt, lane);
+            store_tiles_bf16<HT>(make_rsrc(A.dZ[l - 1] + (size_t)t * (HBYTES / 4), HBYTES), nxt, lane);
 #pragma unroll
             for (int it = 0; it < HT; ++it) cur[it] = nxt[it];
         }

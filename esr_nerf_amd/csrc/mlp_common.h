@@ -345,6 +345,21 @@ __device__ __forceinline__ void zero_tiles(f32x16 (&acc)[NT])
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// bf16 tile-major store [row][32 samples] (64 B per row, streaming): what the bf16 engine saves for its backward
+template <int NT>
+__device__ __forceinline__ void store_tiles_bf16(rsrc_t T, const f32x16 (&acc)[NT], int lane)
+{
+    const int voff = ((lane >> 5) * 4 * 32 + (lane & 31)) * 2;
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const __bf16 v = (__bf16)acc[it][r];
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), T, voff,
+                                                  (32 * it + (r & 3) + 8 * (r >> 2)) * 64, ESR_NT_AUX);
+        }
+}
+
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c)
 {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);

@@ -278,9 +278,11 @@ int esr_mlp_wgrad(int kind, const float *X, int color_row0, const float *const *
 /*
  * bf16 variants of the MLP engine for BASELINE.json's bf16 configurations (a build-side precision choice:
  * the reference is fp32 everywhere): bf16 MFMA OPERANDS (v_mfma_f32_32x32x16_bf16), fp32 accumulation;
- * weights are rounded by esr_mlp_pack_bf16, activations when they become an operand; biases (read from
- * the esr_mlp_pack buffer), saved activations H, masks M and all gradient buffers stay fp32 with the layouts
- * above, so the feature / shading kernels are shared.  packed16: esr_mlp_packed_bf16_elems(kind) bf16 values.
+ * weights are rounded by esr_mlp_pack_bf16, activations when they become an operand; biases are read from
+ * the esr_mlp_pack buffer.  The tiles saved for the backward -- H[l] and dZ[l] -- are bf16 [tiles,hid,32]
+ * (half the bytes of the fp32 engine's; they are only read back as bf16 operands by esr_mlp_wgrad_bf16);
+ * X, zout, dz, dX, the masks M and the weight / bias gradients are fp32 with the layouts above, so the
+ * feature / shading kernels are shared.  packed16: esr_mlp_packed_bf16_elems(kind) bf16 values.
  */
 int64_t esr_mlp_packed_bf16_elems(int kind);
 int esr_mlp_pack_bf16(int kind, const esr_mlp_weights_t *w, void *packed16, void *stream);
