@@ -425,6 +425,12 @@ def main():
                 "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": fl / (ms_mlp * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
                 "traffic": None, "mlp_ms_per_step": ms_mlp, "share_of_kernel_time": ms_mlp / total_ms,
                 "kernel_ms_per_step": total_ms}
+        sync = getattr(step, "_sync", None)
+        if sync is not None:
+            # data-parallel exchange of the dense-grid gradients (esr_nerf_amd/grad_sync.py), last step of rank 0
+            out["grad_exchange"] = dict(sync.last, brick_bytes=sync.brick * 4,
+                                        dense_grid_mb=round(step._n_grid * 4 / 1e6, 1),
+                                        sent_mb=round(sync.last["sent"] * sync.brick * 4 / 1e6, 1))
         if world == 1 and not a.no_cpu_baseline:
             if stage == "fine":
                 out["cpu_baseline"] = cpu_baseline(model, scene, a.s_val, min(a.cpu_rays, n_rays), a.cpu_iters)

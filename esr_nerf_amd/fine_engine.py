@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
@@ -116,6 +117,8 @@ class FineEngine:
         self._timing = False
         self._only = None
         self._events = []
+        self.overlap_wgrad = os.environ.get("ESR_OVERLAP_WGRAD", "1") != "0"
+        self._side = None
 
     # -- helpers ---------------------------------------------------------------
     def _s(self):
@@ -335,14 +338,17 @@ class FineEngine:
         sdf [X,Y,Z], off_color/emo_color [X,Y,Z,6], off_w/off_b/emo_w/emo_b (lists of 4),
         tone_w/tone_b (lists of 2).
 
-        Order: input-gradient chain -> grid scatters (feat_bwd, march_bwd) -> weight gradients.
-        ``after_grids()`` is called once the grid gradients are complete in stream order and before
-        the three wgrad calls are enqueued: the data-parallel step starts the (large) grid all-reduce
-        there so that it overlaps ~1.4 ms of matrix work."""
-        L, s, ws = self.L, self._s(), self.ws
+        Order: input-gradient chain, then two independent branches -- the grid scatters (feat_bwd,
+        march_bwd: LDS / L2 atomics) and the weight gradients (matrix cores).  With ``overlap_wgrad``
+        the weight gradients run on a second HIP stream beside the scatters and are joined at the end.
+        ``after_grids()`` is called once the grid gradients are complete in stream order: the
+        data-parallel step starts the (large) grid all-reduce there, underneath the wgrad kernels."""
+        L, ws = self.L, self.ws
         sp = C.byref(ctx.scene)
         to, ta = ctx.tiles_on, ctx.tiles_all
         g_last, g_srgb, g_lin = g_last.contiguous(), g_srgb.contiguous(), g_lin.contiguous()
+        main = torch.cuda.current_stream(self.device)
+        s = self._s()
         if ta > 0:
             self._run("composite_bwd", L.esr_fine_composite_bwd, _lib.ptr(g_srgb), _lib.ptr(g_lin), _lib.ptr(ws["rgb"]),
                                                 _lib.ptr(ws["lin"]), _lib.ptr(ws["rec_ray"]),
@@ -354,31 +360,34 @@ class FineEngine:
                                               _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]),
                                               _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), to, ta,
                                               _lib.ptr(ws["dz"]), s)
-            H, dZ = self._H(["H0", "H1", "H2"]), self._H(["dZ0", "dZ1", "dZ2"])
-            M = self._H(["M0", "M1", "M2"])
-            sc = (_lib.ptr(self.wgrad_scratch), C.c_int64(self.wgrad_scratch.numel()))
+            M, dZ = self._H(["M0", "M1", "M2"]), self._H(["dZ0", "dZ1", "dZ2"])
             self._run("mlp_dgrad(emo)", self.mlp_dgrad, KIND_RADIANCE, _lib.ptr(self.packed["emo"]), _lib.ptr(ws["dz"]), 0, to,
                                        M, dZ, _lib.ptr(ws["dX"]), s)
             self._run("mlp_dgrad(off)", self.mlp_dgrad, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["dz"]), to, ta,
                                        M, dZ, _lib.ptr(ws["dX"]), s)
-            src = (_lib.EsrFeatBwdSrc * 1)()
-            src[0].dX = ws["dX"].data_ptr()
-            src[0].grad_color_on = grads["emo_color"].data_ptr()      # on-tiles carry the emo net's gradient
-            src[0].grad_color_off = grads["off_color"].data_ptr()
-            src[0].t0, src[0].t1 = 0, ta
-            self._run("feat_bwd", L.esr_fine_feat_bwd, sp, C.byref(ctx.feat_args), _lib.ptr(ws["X"]),
-                      _lib.ptr(ws["gnorm"]), src, 1, None, _lib.ptr(grads["sdf"]), None, s)
             dweight = ws["dweight"]
         else:
             dweight = torch.zeros(32, dtype=torch.float32, device=self.device)
-        self._run("march_bwd", L.esr_fine_march_bwd, sp, _lib.ptr(ctx.rays_o), _lib.ptr(ctx.rays_d),
-                                        _lib.ptr(ctx.mask_density), _lib.ptr(ctx.sdf), ctx.n_rays,
-                                        _lib.ptr(ctx.off3), _lib.ptr(dweight), _lib.ptr(g_last),
-                                        _lib.ptr(grads["sdf"]), s)
 
-        if after_grids is not None:
-            after_grids()
-        if ta > 0:
+        def scatters(s):
+            if ta > 0:
+                src = (_lib.EsrFeatBwdSrc * 1)()
+                src[0].dX = ws["dX"].data_ptr()
+                src[0].grad_color_on = grads["emo_color"].data_ptr()      # on-tiles carry the emo net's gradient
+                src[0].grad_color_off = grads["off_color"].data_ptr()
+                src[0].t0, src[0].t1 = 0, ta
+                self._run("feat_bwd", L.esr_fine_feat_bwd, sp, C.byref(ctx.feat_args), _lib.ptr(ws["X"]),
+                          _lib.ptr(ws["gnorm"]), src, 1, None, _lib.ptr(grads["sdf"]), None, s)
+            self._run("march_bwd", L.esr_fine_march_bwd, sp, _lib.ptr(ctx.rays_o), _lib.ptr(ctx.rays_d),
+                                            _lib.ptr(ctx.mask_density), _lib.ptr(ctx.sdf), ctx.n_rays,
+                                            _lib.ptr(ctx.off3), _lib.ptr(dweight), _lib.ptr(g_last),
+                                            _lib.ptr(grads["sdf"]), s)
+            if after_grids is not None:
+                after_grids()
+
+        def wgrads(s):
+            H, dZ = self._H(["H0", "H1", "H2"]), self._H(["dZ0", "dZ1", "dZ2"])
+            sc = (_lib.ptr(self.wgrad_scratch), C.c_int64(self.wgrad_scratch.numel()))
             self._run("mlp_wgrad(tone)", self.mlp_wgrad, KIND_TONEMAP, _lib.ptr(ws["Xt"]), 0, self._H(["Ht"]), self._H(["dZt"]),
                                        _lib.ptr(ws["dzt"]), 0, ta, _lib.ptr_array(grads["tone_w"]),
                                        _lib.ptr_array(grads["tone_b"]), *sc, s)
@@ -386,6 +395,28 @@ class FineEngine:
                                        _lib.ptr_array(grads["emo_w"]), _lib.ptr_array(grads["emo_b"]), *sc, s)
             self._run("mlp_wgrad(off)", self.mlp_wgrad, KIND_RADIANCE, _lib.ptr(ws["X"]), 0, H, dZ, _lib.ptr(ws["dz"]), to, ta,
                                        _lib.ptr_array(grads["off_w"]), _lib.ptr_array(grads["off_b"]), *sc, s)
+
+        if ta == 0:
+            scatters(s)
+        elif not self.overlap_wgrad:
+            scatters(s)
+            wgrads(s)
+        else:
+            side = self._side_stream()
+            fork = torch.cuda.Event()
+            fork.record(main)
+            side.wait_event(fork)
+            with torch.cuda.stream(side):
+                wgrads(self._s())
+                join = torch.cuda.Event()
+                join.record(side)
+            scatters(s)
+            main.wait_event(join)
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        return self._side
 
     # -- fused trainer-step loss (app/fine/fine.py:355-382) ------------------------
     def loss_fwd_bwd(self, last, srgb, lin, rgbs, white_bg=True, weight_linear=0.1, weight_entropy_last=0.001):

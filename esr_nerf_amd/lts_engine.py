@@ -93,6 +93,7 @@ class LtsEngine(FineEngine):
         self.sec = Pass(self.device, "secondary")
         self.epsp = Pass(self.device, "eps")
         self._deferred = None
+        self._wgrad_side = None
         for k, kind in (("brdf", KIND_BRDF), ("emit", KIND_EMIT)):
             self.packed[k] = torch.empty(self.L.esr_mlp_packed_floats(kind), dtype=torch.float32,
                                          device=self.device)
@@ -195,9 +196,19 @@ class LtsEngine(FineEngine):
                 self._run(f"mlp_wgrad({net})[{P.name}]", self.mlp_wgrad, kind, _lib.ptr(x), crow,
                           _lib.ptr_array(H), _lib.ptr_array(dZ), _lib.ptr(dz), t0, t1, _lib.ptr_array(gw),
                           _lib.ptr_array(gb), _lib.ptr(self.wgrad_scratch), C.c_int64(self.wgrad_scratch.numel()), self._s())
-            # lts_backward defers the weight-gradient launches to the end of the step so that the dense-grid
-            # gradients are complete (and their all-reduce can start) before ~2.5 ms of matrix work
-            if self._deferred is not None:
+            # Inside lts_backward the weight-gradient launches leave the main stream: with ``overlap_wgrad`` each one
+            # goes to a second HIP stream right behind its dgrad (matrix work beside the many small / atomic-bound
+            # kernels of the LTS backward); otherwise they are deferred to the end of the step.  Either way the
+            # dense-grid gradients are complete, and their exchange can start, without waiting for ~2.5 ms of wgrad.
+            if self._wgrad_side is not None:
+                main, side = torch.cuda.current_stream(self.device), self._wgrad_side
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                dz.record_stream(side)          # may be a transient torch allocation of the main stream
+                with torch.cuda.stream(side):
+                    wgrad()
+            elif self._deferred is not None:
                 self._deferred.append(wgrad)
             else:
                 wgrad()
@@ -670,17 +681,23 @@ class LtsEngine(FineEngine):
     def lts_backward(self, ctx: LtsCtx, g: Dict[str, Optional[torch.Tensor]], grads, after_grids=None):
         """g: gradients w.r.t. the tensors of lts_forward's dict (None = zero).  grads: zero-initialised
         dict: sdf, off, emo, brdf grids; {off,emo,tone,brdf,emit}_{w,b} lists; mus, lambdas, lobes.
-        Order: every input-gradient chain and grid scatter first, then ``after_grids()`` (the data-parallel step
-        starts the dense-grid all-reduce there), then the deferred weight-gradient launches."""
+        Order on the main stream: every input-gradient chain and grid scatter, then ``after_grids()`` (the
+        data-parallel step exchanges the dense-grid gradients there); the weight-gradient launches run beside it on
+        a second stream (or, without ``overlap_wgrad``, after it) and are joined at the end."""
+        main = torch.cuda.current_stream(self.device)
         self._deferred = []
+        self._wgrad_side = self._side_stream() if self.overlap_wgrad else None
         try:
             self._lts_backward(ctx, g, grads)
             if after_grids is not None:
                 after_grids()
             for w in self._deferred:
                 w()
+            if self._wgrad_side is not None:
+                main.wait_stream(self._wgrad_side)
         finally:
             self._deferred = None
+            self._wgrad_side = None
 
     def _lts_backward(self, ctx: LtsCtx, g: Dict[str, Optional[torch.Tensor]], grads):
         L, s, dev = self.L, self._s(), self.device

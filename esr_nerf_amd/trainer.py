@@ -45,6 +45,25 @@ def dp_loss_weights(n_local: int, global_rays, entropy_owner: bool, weight_entro
     return scale, w_ent
 
 
+def _grid_sync(step, eng):
+    """after_grids callback of a data-parallel step.  With the weight gradients on their own stream
+    (already enqueued when this runs) the dense-grid gradients go through the brick-sparse exchange,
+    whose host sync then costs nothing; otherwise one dense asynchronous all-reduce."""
+    import torch.distributed as dist
+    works = []
+    if getattr(eng, "overlap_wgrad", False):
+        from .grad_sync import GridGradSync
+        if step._sync is None:
+            step._sync = GridGradSync(step.pg)
+
+        def after_grids():
+            step._sync.reduce(step._flat[: step._n_grid])
+    else:
+        def after_grids():
+            works.append(dist.all_reduce(step._flat[: step._n_grid], group=step.pg, async_op=True))
+    return after_grids, works
+
+
 class FineStep:
     def __init__(self, model, white_bg: bool = True, weight_linear: float = 0.1,
                  weight_entropy_last: float = 0.001, process_group=None):
@@ -55,6 +74,7 @@ class FineStep:
         self.pg = process_group
         self._names = None
         self._flat = None
+        self._sync = None
 
     # names follow state_dict / named_parameters of the renderer
     def _param_names(self):
@@ -123,11 +143,9 @@ class FineStep:
         works = []
         if self.pg is not None:
             import torch.distributed as dist
-
-            def after_grids():
-                # grid gradients (218 MB at C2, >99 % of the payload) are final here: their all-reduce
-                # runs on RCCL's stream underneath the wgrad kernels that the engine enqueues next
-                works.append(dist.all_reduce(self._flat[: self._n_grid], group=self.pg, async_op=True))
+            # grid gradients (218 MB at C2, >99 % of the payload) are final when the engine calls this:
+            # their exchange runs underneath the wgrad kernels
+            after_grids, works = _grid_sync(self, eng)
         else:
             after_grids = None
         eng.backward(ctx, g_last, g_srgb, g_lin, grads, after_grids=after_grids)
@@ -167,6 +185,7 @@ class LtsStep:
         self.model, self.t, self.stage, self.white_bg, self.pg = model, trainer_cfg, stage, white_bg, process_group
         self._names = None
         self._flat = None
+        self._sync = None
 
     def _param_names(self):
         if self._names is None:
@@ -275,11 +294,9 @@ class LtsStep:
         works = []
         if self.pg is not None:
             import torch.distributed as dist
-
-            def after_grids():
-                # the four grid gradients (> 99 % of the payload) are final here: their all-reduce runs on RCCL's
-                # stream underneath the deferred weight-gradient kernels
-                works.append(dist.all_reduce(self._flat[: self._n_grid], group=self.pg, async_op=True))
+            # the four grid gradients (> 99 % of the payload) are final when the engine calls this: their exchange
+            # runs underneath the weight-gradient kernels
+            after_grids, works = _grid_sync(self, eng)
         else:
             after_grids = None
         eng.lts_backward(ctx, g, grads, after_grids=after_grids)

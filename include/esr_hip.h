@@ -560,6 +560,26 @@ int esr_adam_step(float *param, const float *grad, float *exp_avg, float *exp_av
                   const float *per_lr, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int32_t step, void *stream);
 
+/* ------------------------------------------------------------------------- *
+ * F. Data-parallel gradient exchange (no reference counterpart: the reference is single-process,
+ *    SURVEY 2a / 8(e); the sum over ranks itself is torch.distributed = RCCL)
+ * ------------------------------------------------------------------------- */
+
+/*
+ * Brick-sparse view of a flat fp32 gradient buffer (16-byte aligned, n values): bricks of
+ * esr_brick_floats() (= 128) consecutive values; the last brick may be ragged.
+ *   esr_brick_flags:  flags[b] = 1 if any value of brick b is non-zero, else 0  (ceil(n/128) bytes)
+ *   esr_brick_pack:   packed[k*128 .. ] = brick brick_idx[k] (ragged tail zero-filled), k < n_idx
+ *   esr_brick_unpack: the inverse scatter (values past n are dropped)
+ * brick_idx: int64 device array, strictly increasing brick numbers < ceil(n/128).
+ */
+int esr_brick_floats(void);
+int esr_brick_flags(const float *buf, int64_t n, uint8_t *flags, void *stream);
+int esr_brick_pack(const float *buf, int64_t n, const int64_t *brick_idx, int64_t n_idx, float *packed,
+                   void *stream);
+int esr_brick_unpack(const float *packed, const int64_t *brick_idx, int64_t n_idx, float *buf, int64_t n,
+                     void *stream);
+
 #ifdef __cplusplus
 }
 #endif
