@@ -289,9 +289,11 @@ def main():
     if n_prof:
         torch.cuda.synchronize()
         eng.enable_timing(True)
+        overlap, eng.overlap_wgrad = eng.overlap_wgrad, False    # one kernel at a time while each is being timed
         for _ in range(n_prof):
             one()
         breakdown = {k: (n, ms) for k, (n, ms) in eng.timing_summary().items()}
+        eng.overlap_wgrad = overlap
         eng.enable_timing(False)
     for _ in range(a.warmup - n_prof - n_lead):
         one()

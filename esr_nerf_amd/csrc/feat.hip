@@ -223,17 +223,21 @@ __global__ void __launch_bounds__(256) feat_fwd_kernel(FeatParams P)
 // atomics, better shaped.  Cells outside the window (ray changes inside a tile, long
 // diagonal tiles) fall back to direct global atomics, so the result never depends on
 // the window fitting.
-constexpr int WIN_FLOATS = 4096;          // 16 KB per wave
+// The window cells are DOUBLES: ds_add_f32 retires ~1 lane per 3 clocks on gfx950 (80 ns per wave
+// instruction, tools/ubench/lds_atomic.hip) while ds_add_f64 runs at the integer-atomic rate, 8x faster; the
+// f32 form kept the LDS pipe 60 % busy for the whole kernel (SQ_LDS_IDX_ACTIVE).  As a side effect the
+// in-window sum is exact to ~2^-52 and rounded to fp32 once at the flush.
+constexpr int WIN_CELLS = 2560;           // 20 KB of doubles per wave (2 workgroups x 4 waves x 20 KB per CU)
 
 // explicit LDS address space: with a generic pointer hipcc merges the LDS and the global
 // branch of window_add into one flat_atomic_add_f32 on a selected address
-typedef __attribute__((address_space(3))) float lds_float;
+typedef __attribute__((address_space(3))) double lds_cell;
 
 // Up to four ray-local windows per tile.  At the start of training a tile is 32 consecutive samples of ONE ray;
 // later (large s_val) a ray keeps ~20 samples and a tile holds pieces of 2-3 rays that can sit anywhere in the
 // grid: one bounding box over all of them is mostly empty (the zero / flush loops walked 4096 words per
 // phase) and its clipped remainder sent the other rays' samples to global atomics.  Each of the first four rays
-// of a tile now gets its own tight window (WIN_FLOATS / n_windows words each); a fifth ray goes to global atomics.
+// of a tile now gets its own tight window (WIN_CELLS / n_windows cells each); a fifth ray goes to global atomics.
 constexpr int MAX_WIN = 4;
 struct WinSet {                        // wave-uniform
     int nw;                            // windows in use
@@ -243,7 +247,7 @@ struct WinSet {                        // wave-uniform
     int ch;
 };
 struct LaneWin {                       // the window of THIS lane's sample
-    lds_float *lds;
+    lds_cell *lds;
     int lo[3], wd[3];
     int ch;
     bool has;
@@ -300,7 +304,7 @@ __device__ __forceinline__ int winset_init(WinSet &W, int key, bool valid, const
 __device__ __forceinline__ void winset_phase(WinSet &W, const int dims[3], int below, int above, int ch)
 {
     W.ch = ch;
-    const int share = WIN_FLOATS / (W.nw > 0 ? W.nw : 1);
+    const int share = WIN_CELLS / (W.nw > 0 ? W.nw : 1);
     const int cap = share / ch;
 #pragma unroll
     for (int k = 0; k < MAX_WIN; ++k) {
@@ -320,7 +324,7 @@ __device__ __forceinline__ void winset_phase(WinSet &W, const int dims[3], int b
     }
 }
 
-__device__ __forceinline__ LaneWin lane_view(const WinSet &W, int wid, lds_float *lds)
+__device__ __forceinline__ LaneWin lane_view(const WinSet &W, int wid, lds_cell *lds)
 {
     LaneWin w;
     w.ch = W.ch;
@@ -339,12 +343,12 @@ __device__ __forceinline__ LaneWin lane_view(const WinSet &W, int wid, lds_float
     return w;
 }
 
-__device__ __forceinline__ void winset_zero(const WinSet &W, lds_float *lds, int lane)
+__device__ __forceinline__ void winset_zero(const WinSet &W, lds_cell *lds, int lane)
 {
 #pragma unroll
     for (int k = 0; k < MAX_WIN; ++k) {
         const int n = W.wd[k][0] * W.wd[k][1] * W.wd[k][2] * W.ch;
-        for (int i = lane; i < n; i += 64) lds[W.base[k] + i] = 0.f;
+        for (int i = lane; i < n; i += 64) lds[W.base[k] + i] = 0.0;
     }
 }
 
@@ -353,13 +357,13 @@ __device__ __forceinline__ void window_add(const LaneWin &w, float *__restrict__
 {
     const int wx = x - w.lo[0], wy = y - w.lo[1], wz = z - w.lo[2];
     if ((unsigned)wx < (unsigned)w.wd[0] && (unsigned)wy < (unsigned)w.wd[1] && (unsigned)wz < (unsigned)w.wd[2])
-        __hip_atomic_fetch_add(&w.lds[((wx * w.wd[1] + wy) * w.wd[2] + wz) * w.ch + c], v, __ATOMIC_RELAXED,
+        __hip_atomic_fetch_add(&w.lds[((wx * w.wd[1] + wy) * w.wd[2] + wz) * w.ch + c], (double)v, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
     else
         atomicAdd(&g[(((int64_t)x * dims[1] + y) * dims[2] + z) * w.ch + c], v);
 }
 
-__device__ __forceinline__ void winset_flush(const WinSet &W, lds_float *lds, float *__restrict__ g, const int dims[3],
+__device__ __forceinline__ void winset_flush(const WinSet &W, lds_cell *lds, float *__restrict__ g, const int dims[3],
                                              int lane)
 {
 #pragma unroll
@@ -367,7 +371,7 @@ __device__ __forceinline__ void winset_flush(const WinSet &W, lds_float *lds, fl
         const int row = W.wd[k][2] * W.ch;                // floats per (x,y) column, contiguous in memory too
         const int n = W.wd[k][0] * W.wd[k][1] * row;
         for (int i = lane; i < n; i += 64) {
-            const float v = lds[W.base[k] + i];
+            const float v = (float)lds[W.base[k] + i];
             if (v != 0.f) {
                 const int xy = i / row, r = i - xy * row;
                 const int wx = xy / W.wd[k][1], wy = xy - wx * W.wd[k][1];
@@ -379,14 +383,14 @@ __device__ __forceinline__ void winset_flush(const WinSet &W, lds_float *lds, fl
 
 __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
 {
-    extern __shared__ __attribute__((aligned(16))) float win_all[];
+    extern __shared__ __attribute__((aligned(16))) double win_all[];
     const esr_scene_t &sc = P.sc;
     const int gdims[3] = {sc.gx, sc.gy, sc.gz};
     const int lane = esr_lane();
     const int s = lane & 31, h = lane >> 5;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    lds_float *const lds = (lds_float *)(win_all + (threadIdx.x >> 6) * WIN_FLOATS);
+    lds_cell *const lds = (lds_cell *)(win_all + (threadIdx.x >> 6) * WIN_CELLS);
     WinSet WS;
     for (int t = wave; t < P.tiles_all; t += nwaves) {
         const int j = t * 32 + s;
@@ -611,9 +615,9 @@ ESR_API int esr_fine_feat_bwd(const esr_scene_t *scene, const esr_feat_args_t *a
         P.src_t0[k] = src[k].t0; P.src_t1[k] = src[k].t1;
     }
     P.dsdf_extra = dsdf_extra; P.dsdf_out = dsdf_out; P.grad_sdf = grad_sdf;
-    // one wave per tile, 4 waves (4 x 16 KB LDS windows) per workgroup
+    // one wave per tile, 4 waves (4 x 20 KB LDS windows) per workgroup
     feat_bwd_kernel<<<esr_grid_for((int64_t)P.tiles_all * 64, 256, 256 * 2), 256,
-                      4 * WIN_FLOATS * sizeof(float), esr_stream(stream)>>>(P);
+                      4 * WIN_CELLS * sizeof(double), esr_stream(stream)>>>(P);
     ESR_CHECK_LAUNCH();
     return 0;
 }
