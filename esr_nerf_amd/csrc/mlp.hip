@@ -22,10 +22,13 @@
 //  * Hidden activations are saved tile-major [tile][feature][32] (each store = two
 //    full 128-B lines) and re-read by the backward instead of being recomputed: the
 //    f32 matrix rate (157 TF) is the binding roof, HBM (8 TB/s) has headroom.
-//  * Weight gradients contract over SAMPLES: a workgroup stages the two operand tiles of a
-//    sample tile through a 3-stage LDS ring (coalesced 16-B buffer loads), its four waves
-//    keep the whole dW block of a layer in accumulator registers across the workgroup's tile
-//    range, and the partial blocks go to per-workgroup slabs that a second kernel sums.
+//  * Weight gradients contract over SAMPLES: a workgroup keeps the whole dW block of a layer in
+//    the accumulator registers of its four compute waves across its tile range; a fifth LOADER
+//    wave streams the two operand tiles of every sample tile HBM -> LDS by LDS-DMA into a
+//    3-buffer ring (mlp_wgrad_dma_kernel); partial blocks go to per-workgroup slabs that a
+//    second kernel sums.  (bf16 operand modes: the register-staged mlp_wgrad_kernel.)
+#include <cstdlib>
+
 #include "esr_common.h"
 
 #include "mlp_common.h"
@@ -162,6 +165,7 @@ struct WgradArgs {
     int b_tile_rows;             // rows per B tile in memory (>= RB; the X tile has extra colour rows)
     int crow;                    // first layer: B rows 0..cw-1 are read from X rows crow..crow+cw-1
     int cw8;                     // colour-group rows x 8 (float4 units per row)
+    int dbg;                     // timing experiments only (ESR_WGRAD_DBG): 1 = DMA through empty descriptors
 };
 
 // Cooperative weight-gradient kernel.  One workgroup covers the WHOLE dW of a layer:
@@ -177,7 +181,7 @@ struct WgradArgs {
 // whole tile range and are written once to the workgroup's slab (see the flush below).
 constexpr int LDS_STRIDE = 36;        // floats per staged row (32 samples + 4 pad)
 
-// MODE 0: f32 matrix cores.  MODE 1-3: bf16 operands (v_mfma_f32_32x32x16_bf16, 16 samples per k-step), fp32
+// (f32 operands: mlp_wgrad_dma_kernel below.)  MODE 1-3: bf16 operands (v_mfma_f32_32x32x16_bf16, 16 samples per k-step), fp32
 // accumulation -- the weight-gradient kernel of the bf16 configurations, where the saved hidden tiles (H, dZ) are
 // bf16 [row][32] (64-B rows, staged as they are and read from LDS as ready-made 8-element operands) while the
 // network input X and the output gradient dz are fp32 (rounded on the way from LDS to the operand registers):
@@ -185,7 +189,7 @@ constexpr int LDS_STRIDE = 36;        // floats per staged row (32 samples + 4 p
 template <int MI, int NJ, int WM, int WN, int WK, int MODE>
 __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradArgs W)
 {
-    constexpr bool BF = MODE != 0;
+    static_assert(MODE >= 1 && MODE <= 3, "f32 operands: mlp_wgrad_dma_kernel");
     constexpr bool A16 = MODE == 2 || MODE == 3, B16 = MODE == 1 || MODE == 2;
     constexpr int NW = WM * WN * WK, NT = 64 * NW;
     constexpr int RAP = WM * MI * 32, RBP = WN * NJ * 32;          // staged rows (padded to tiles)
@@ -253,7 +257,7 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradAr
         }
     };
     auto compute = [&](int cur) {
-        if constexpr (BF) {
+        {
             static_assert(WK <= 2, "a tile has two 16-sample k-steps");
             constexpr int NU16 = 2 / WK;
             // fp32-staged operand: row stride LDS_STRIDE floats, 8 samples = two float4; bf16-staged: STRIDE16
@@ -293,31 +297,6 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradAr
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
             }
-            return;
-        }
-        const float *La = lds + cur * BUF + (wm * MI * 32 + rl) * LDS_STRIDE + 4 * h;
-        const float *Lb = lds + cur * BUF + (RAP + wn * NJ * 32 + rl) * LDS_STRIDE + 4 * h;
-#pragma unroll
-        for (int uu = 0; uu < NU; ++uu) {
-            const int u = wk * NU + uu;
-            float4 a[MI], b[NJ];
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-                a[i] = *reinterpret_cast<const float4 *>(La + i * 32 * LDS_STRIDE + 8 * u);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                b[j] = *reinterpret_cast<const float4 *>(Lb + j * 32 * LDS_STRIDE + 8 * u);
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                bsum[i] += (a[i].x + a[i].y) + (a[i].z + a[i].w);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    acc[i][j] = mfma32(a[i].x, b[j].x, acc[i][j]);
-                    acc[i][j] = mfma32(a[i].y, b[j].y, acc[i][j]);
-                    acc[i][j] = mfma32(a[i].z, b[j].z, acc[i][j]);
-                    acc[i][j] = mfma32(a[i].w, b[j].w, acc[i][j]);
-                }
-            }
         }
     };
 
@@ -345,6 +324,178 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradAr
     // stores its block into its workgroup's private slab with plain 128-B-contiguous stores; a
     // second tiny kernel sums the slabs.  (1024 waves atomically adding into the same 147 KB at
     // kernel end ran at a fraction of the atomic rate: same-address contention.)
+    float *S = W.slab + (size_t)(blockIdx.x * WK + wk) * W.out_rows * W.ld;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int rb = 32 * (NJ * wn + j) + rl;
+        const int col = (rb < W.RB) ? (W.first ? in_colmap(W.kind, rb) : rb) : -1;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ra = 32 * (MI * wm + i) + acc_row(r, h);
+                if (col >= 0 && col < W.ld && ra < W.out_rows) S[(size_t)ra * W.ld + col] = acc[i][j][r];
+            }
+    }
+    if (W.gb && wn == 0) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int ra = 32 * (MI * wm + i) + rl;
+            const float tot = bsum[i] + __shfl_xor(bsum[i], 32);
+            if (h == 0 && ra < W.out_rows) atomicAdd(&W.gb[ra], tot);
+        }
+    }
+}
+
+// ---- f32 weight gradients, operands staged by LDS-DMA -------------------------------------------------
+// Same decomposition as mlp_wgrad_kernel (one workgroup = the whole dW of a layer over a tile range, wave
+// (wm, wn, wk) owns an MI x NJ block of 32x32 accumulators), but the two operand tiles of a sample tile go
+// from HBM straight into LDS (`buffer_load_dwordx4 ... lds`, 1 KiB = 8 rows per wave instruction) instead of
+// through staging registers.  Why: in the register-staged kernel hipcc re-used the staging registers of the
+// tile in flight for LDS-read operands and had to wait for those loads first (`s_waitcnt vmcnt(11..8)` at
+// the top of every step, i.e. a prefetch distance of half a tile instead of two): 68 % matrix-core busy at
+// 352 VGPRs.  Here nothing in the loop has a VGPR destination in memory, the waits are counted by hand
+// (cdna_hip_programming.md: LDS-DMA + counted vmcnt + raw s_barrier), and 96 staging registers are gone.
+//
+// LDS image: 3 buffers x (RAP + RBP) rows x 128 B, unpadded (an LDS-DMA piece is lane-linear).  Bank
+// conflicts of the row-per-lane ds_read_b128 are removed by an XOR swizzle applied on the SOURCE side:
+// 16-B chunk c of row r is stored at chunk position c ^ ((r >> 1) & 7), so 16 consecutive rows read at the
+// same logical chunk hit 16 distinct 4-bank groups.
+// Three buffers, one barrier per tile in the MIDDLE of the tile (schedule: comment above the main loop).
+constexpr int wait_vm_lgkm0(int n) { return (n & 15) | 0x70 | ((n >> 4) << 14); }           // vmcnt(n) lgkmcnt(0)
+constexpr int wait_vm(int n) { return (n & 15) | 0x70 | (15 << 8) | ((n >> 4) << 14); }     // vmcnt(n)
+
+// The DMA is issued from inline asm on purpose: hipcc orders every later ds_read behind a compiler-visible
+// LDS-DMA with `s_waitcnt vmcnt(0)` (it cannot tell the buffers apart), which drains the prefetch every step.
+// An asm load is absent from its bookkeeping; its completion is counted by hand below.  M0 (the LDS
+// destination base, wide enough for all 160 KB: tools/ubench/lds_dma_m0.hip) is compiler-reserved, so it is
+// saved and restored inside the statement that uses it.
+__device__ __forceinline__ u32x4 raw_rsrc(const void *p, unsigned bytes)
+{
+    const uint64_t a = (uint64_t)(uintptr_t)p;
+    return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned lds_byte, int voff)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_byte), "s"(rsrc) : "memory");
+}
+
+template <int MI, int NJ, int WM, int WN, int WK>
+__global__ void __launch_bounds__(64 * (WM * WN * WK + 1), 1) mlp_wgrad_dma_kernel(WgradArgs W)
+{
+    constexpr int NW = WM * WN * WK;                 // compute waves (one per SIMD); wave NW is the loader
+    constexpr int RAP = WM * MI * 32, RBP = WN * NJ * 32, ROWS = RAP + RBP;
+    constexpr int PIECES = ROWS / 8;                 // 1-KiB pieces (8 rows x 128 B) per tile
+    static_assert(PIECES <= 60, "the loader counts a whole tile on vmcnt");
+    constexpr int BUF = ROWS * 32;                   // floats per LDS buffer
+    constexpr int NU = 4 / WK;                       // 8-sample groups per compute wave per tile
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, rl = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = w % WK, wn = (w / WK) % WN, wm = w / (WK * WN);
+    const int nsplit = gridDim.x, split = blockIdx.x;
+
+    // rows that no DMA ever fills (operands shorter than the staged block) must not hold NaN patterns
+    for (int i = tid; i < 3 * BUF; i += 64 * (NW + 1)) lds[i] = 0.f;
+    __syncthreads();
+
+    // Barrier schedule, identical in every wave: one before the first tile, then one in the MIDDLE of every tile.
+    //   barrier before tile 0:   tile 0 has landed
+    //   barrier inside tile i:   tile i+1 has landed (the loader waited for it) and every compute wave is done with
+    //                            tile i-1, whose buffer the loader refills with tile i+2 right after the barrier
+    if (w == NW) {
+        // ---- loader wave: streams whole tiles HBM -> LDS, nothing else.  A compute wave that issued its own pieces
+        // paid 60-180 cycles of matrix-pipe idle per LDS-DMA instruction (in-order issue: the next MFMA waits behind
+        // it); from a wave of its own the same instructions interleave with the MFMAs of the SIMD's compute wave.
+        const unsigned lds0 = (unsigned)(uintptr_t)(lds_void *)lds;
+        const int cw = W.cw8 / 8;
+        auto load_tile = [&](int t_next, int fb) {
+            const bool live = t_next < W.t1 && !(W.dbg & 1);     // past the range: zero records, no memory touched
+            const int tc = t_next < W.t1 ? t_next : W.t0;
+            const u32x4 SA = raw_rsrc(reinterpret_cast<const char *>(W.A) + (size_t)tc * W.RA * 128u,
+                                      live ? (unsigned)W.RA * 128u : 0u);
+            const u32x4 SB = raw_rsrc(reinterpret_cast<const char *>(W.B) + (size_t)tc * W.b_tile_rows * 128u,
+                                      live ? (unsigned)W.b_tile_rows * 128u : 0u);
+#pragma unroll
+            for (int p = 0; p < PIECES; ++p) {
+                const int R = 8 * p + (lane >> 3);                       // row of the staged image
+                const int c = (lane & 7) ^ ((R >> 1) & 7);               // source chunk of this LDS slot
+                int row = R;                                             // A rows >= RA fail the range check
+                if (8 * p >= RAP) row = (R - RAP < cw) ? R - RAP + W.crow : R - RAP;   // first layer: colour rows
+                lds_dma16(8 * p < RAP ? SA : SB, lds0 + (unsigned)(fb * BUF + p * 256) * 4u, row * 128 + c * 16);
+            }
+        };
+        int t = W.t0 + split;
+        load_tile(t, 0);
+        load_tile(t + nsplit, 1);
+        __builtin_amdgcn_s_waitcnt(wait_vm(PIECES));
+        __builtin_amdgcn_s_barrier();
+        for (int fb = 2; t < W.t1; t += nsplit) {
+            __builtin_amdgcn_s_waitcnt(wait_vm(0));
+            __builtin_amdgcn_s_barrier();
+            load_tile(t + 2 * nsplit, fb);
+            fb = fb == 2 ? 0 : fb + 1;
+        }
+        __builtin_amdgcn_s_waitcnt(wait_vm(0));          // nothing may land in LDS after the workgroup is gone
+        return;
+    }
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) zero_tiles<NJ>(acc[i]);
+    float bsum[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) bsum[i] = 0.f;
+    // operand reads of one 8-sample group: row (wm*MI*32 + i*32 + rl), logical chunk 2u + h, swizzled by the row
+    const int swz = (rl >> 1) & 7;
+    const int a_row = (wm * MI * 32 + rl) * 32, b_row = (RAP + wn * NJ * 32 + rl) * 32;
+    auto lds_read = [&](int buf, int uu, float4 (&a)[MI], float4 (&b)[NJ]) {
+        const int ch = ((2 * (wk * NU + uu) + h) ^ swz) * 4;
+        const float *La = lds + buf * BUF + a_row + ch, *Lb = lds + buf * BUF + b_row + ch;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const float4 *>(La + i * 32 * 32);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const float4 *>(Lb + j * 32 * 32);
+    };
+    // Operands are register double-buffered by group; the last group of a tile reads the first group of the next
+    // tile (readable since the mid-tile barrier), so no LDS latency is exposed at the tile seam.
+    static_assert(NU == 2 || NU == 4, "two halves of whole groups");
+    float4 a0[MI], b0[NJ], a1[MI], b1[NJ];
+    __builtin_amdgcn_s_barrier();
+    lds_read(0, 0, a0, b0);
+    int t = W.t0 + split;
+    for (int buf = 0; t < W.t1; t += nsplit) {
+        const int nb = buf == 2 ? 0 : buf + 1;
+#pragma unroll
+        for (int uu = 0; uu < NU; ++uu) {
+            float4 (&a)[MI] = (uu & 1) ? a1 : a0;
+            float4 (&b)[NJ] = (uu & 1) ? b1 : b0;
+            float4 (&an)[MI] = (uu & 1) ? a0 : a1;
+            float4 (&bn)[NJ] = (uu & 1) ? b0 : b1;
+            if (uu == NU / 2) __builtin_amdgcn_s_barrier();
+            if (uu + 1 < NU) lds_read(buf, uu + 1, an, bn);
+            else lds_read(nb, 0, an, bn);                 // (stale but unused after the last tile)
+            __builtin_amdgcn_sched_barrier(0);            // or hipcc sinks the reads next to their first use
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                bsum[i] += (a[i].x + a[i].y) + (a[i].z + a[i].w);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc[i][j] = mfma32(a[i].x, b[j].x, acc[i][j]);
+                    acc[i][j] = mfma32(a[i].y, b[j].y, acc[i][j]);
+                    acc[i][j] = mfma32(a[i].z, b[j].z, acc[i][j]);
+                    acc[i][j] = mfma32(a[i].w, b[j].w, acc[i][j]);
+                }
+            }
+        }
+        buf = nb;
+    }
+    __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(0));
+
     float *S = W.slab + (size_t)(blockIdx.x * WK + wk) * W.out_rows * W.ld;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -420,6 +571,46 @@ int launch_wgrad(const WgradArgs &W, int64_t slab_floats, hipStream_t s)
                                                                                          n_elems, W.gw);
     ESR_CHECK_LAUNCH();
     return 0;
+}
+
+template <int MI, int NJ, int WM, int WN, int WK>
+int launch_wgrad_dma(const WgradArgs &W, int64_t slab_floats, hipStream_t s)
+{
+    const int n_tiles = W.t1 - W.t0;
+    if (n_tiles <= 0) return 0;
+    if (W.RA > WM * MI * 32 || W.RB > WN * NJ * 32) return ESR_ECAP;
+    constexpr int NT = 64 * (WM * WN * WK + 1);           // compute waves + the loader wave
+    constexpr size_t lds_bytes = 3 * (size_t)(WM * MI * 32 + WN * NJ * 32) * 32 * sizeof(float);
+    static_assert(lds_bytes <= 160 * 1024, "three staged tiles must fit the CU's LDS");
+    static bool attr_set = false;
+    if (!attr_set) {       // > 64 KB of dynamic LDS needs the opt-in
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_dma_kernel<MI, NJ, WM, WN, WK>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    int grid = 256;        // one workgroup per CU (LDS-bound residency)
+    if (grid > n_tiles) grid = n_tiles;
+    const int n_elems = W.out_rows * W.ld;
+    if ((int64_t)grid * WK * n_elems > slab_floats) return ESR_ECAP;
+    static const int dbg = getenv("ESR_WGRAD_DBG") ? atoi(getenv("ESR_WGRAD_DBG")) : 0;
+    WgradArgs Wd = W;
+    Wd.dbg = dbg;
+    mlp_wgrad_dma_kernel<MI, NJ, WM, WN, WK><<<grid, NT, lds_bytes, s>>>(Wd);
+    ESR_CHECK_LAUNCH();
+    const int groups = (grid * WK + 31) / 32;
+    wgrad_reduce_kernel<<<esr_grid_for((int64_t)n_elems * groups, 256, 2048), 256, 0, s>>>(W.slab, grid * WK,
+                                                                                         n_elems, W.gw);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+// f32: LDS-DMA staging; bf16 operand modes: the register-staged kernel
+template <int MI, int NJ, int WM, int WN, int WK, int MODE>
+int launch_wgrad_any(const WgradArgs &W, int64_t slab_floats, hipStream_t s)
+{
+    if constexpr (MODE == 0) return launch_wgrad_dma<MI, NJ, WM, WN, WK>(W, slab_floats, s);
+    else return launch_wgrad<MI, NJ, WM, WN, WK, MODE>(W, slab_floats, s);
 }
 
 }  // namespace
@@ -543,14 +734,14 @@ static int wgrad_all(int kind, const float *X, int color_row0, const float *cons
         //   128-wide nets: 128x128 -> 2x2x1, 128x96 -> 2x1x2, 8x128 -> 1x2x2
         int rc;
         if (D.hid_tiles == 6) {
-            if (last) rc = launch_wgrad<1, 3, 1, 2, 2, BF ? 1 : 0>(W, scratch_floats, s);
-            else if (first && W.RB <= 64) rc = launch_wgrad<3, 2, 2, 1, 2, BF ? 3 : 0>(W, scratch_floats, s);   // tone mapper: 48 input rows
-            else if (first) rc = launch_wgrad<3, 3, 2, 1, 2, BF ? 3 : 0>(W, scratch_floats, s);
-            else rc = launch_wgrad<3, 3, 2, 2, 1, BF ? 2 : 0>(W, scratch_floats, s);
+            if (last) rc = launch_wgrad_any<1, 3, 1, 2, 2, BF ? 1 : 0>(W, scratch_floats, s);
+            else if (first && W.RB <= 64) rc = launch_wgrad_any<3, 2, 2, 1, 2, BF ? 3 : 0>(W, scratch_floats, s);   // tone mapper: 48 input rows
+            else if (first) rc = launch_wgrad_any<3, 3, 2, 1, 2, BF ? 3 : 0>(W, scratch_floats, s);
+            else rc = launch_wgrad_any<3, 3, 2, 2, 1, BF ? 2 : 0>(W, scratch_floats, s);
         } else {
-            if (last) rc = launch_wgrad<1, 2, 1, 2, 2, BF ? 1 : 0>(W, scratch_floats, s);
-            else if (first) rc = launch_wgrad<2, 3, 2, 1, 2, BF ? 3 : 0>(W, scratch_floats, s);
-            else rc = launch_wgrad<2, 2, 2, 2, 1, BF ? 2 : 0>(W, scratch_floats, s);
+            if (last) rc = launch_wgrad_any<1, 2, 1, 2, 2, BF ? 1 : 0>(W, scratch_floats, s);
+            else if (first) rc = launch_wgrad_any<2, 3, 2, 1, 2, BF ? 3 : 0>(W, scratch_floats, s);
+            else rc = launch_wgrad_any<2, 2, 2, 2, 1, BF ? 2 : 0>(W, scratch_floats, s);
         }
         if (rc) return rc;
     }
