@@ -196,7 +196,6 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradAr
     constexpr int BUF = (RAP + RBP) * LDS_STRIDE;                  // floats per LDS buffer
     constexpr int STRIDE16 = 20;                                   // floats per staged bf16 row (64 B + 16 B pad)
     constexpr int LA = RAP * (A16 ? 4 : 8) / NT, LB = RBP * (B16 ? 4 : 8) / NT;   // 16-B loads per thread
-    constexpr int NU = 4 / WK;                                     // 8-sample groups per wave per tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, rl = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
