@@ -392,6 +392,18 @@ def main():
                 same = (wl.get("config"), wl.get("stage"), wl.get("s_val")) == (a.config, stage, float(a.s_val))
                 vals = [tj[c] for c in dom_calls if c in tj] if same else []     # counters are per workload
                 traffic = sum(vals) / len(vals) if vals else None
+            # matrix-pipe utilisation and effective clock of the same kernel from the committed counter pass
+            # (tools/profile_mfma.sh -> profiles/*_mfma_util.csv; C2 fp32 only -- counters are per workload)
+            pmc_mfma = None
+            import csv
+            import glob
+            utils = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_mfma_util.csv")))
+            if utils and (a.config, stage, a.dtype, float(a.s_val)) == ("C2", "fine", "f32", 20.0):
+                for r in csv.DictReader(open(utils[-1])):
+                    if r["kernel"] == dominant:
+                        pmc_mfma = {"source": os.path.relpath(utils[-1], ROOT), "mfma_busy_frac": float(r["mfma_busy_frac"]),
+                                    "clock_ghz": float(r["clock_ghz"]),
+                                    "issued_gflop_per_launch": float(r["mfma_issued_gflop_per_launch"])}
             total_ms = sum(ms_ for _, ms_ in breakdown.values()) or 1.0
             out["roofline"] = {
                 "bound": "mfma", "kernel": dominant, "calls": dom_calls, "achieved": ach,
@@ -400,6 +412,7 @@ def main():
                 "avg_launch_ms": ms / launches, "launches_timed": launches,
                 "algorithmic_gflop_per_launch": flops_total / launches / 1e9,
                 "share_of_kernel_time": sum(breakdown[c][1] for c in dom_calls if c in breakdown) / total_ms,
+                "pmc": pmc_mfma,
             }
             if a.dtype == "bf16":                  # bf16 operands: the activation traffic, not the MFMA pipe, binds
                 gbs = bytes_total / (ms * 1e-3) / 1e9
