@@ -35,8 +35,8 @@ constexpr int XC_ROWS = 72; // coarse feature tile: 12 colour | 12 alt colour | 
 constexpr int X_ROWS = 104; // feature tile: 96 rows + a third colour group (rows 96-101)
 __host__ __device__ constexpr NetDesc net_desc(int kind)
 {
-    return kind == ESR_MLP_RADIANCE ? NetDesc{4, 85, 48, X_ROWS, 3, 6, 4, 6}   // pbr/module.py:6-21
-         : kind == ESR_MLP_TONEMAP  ? NetDesc{2, 33, 24, 48, 3, 6, 4, 6}       // pbr/module.py:24-39
+    return kind == ESR_MLP_RADIANCE ? NetDesc{4, 85, 44, X_ROWS, 3, 6, 4, 6}   // pbr/module.py:6-21
+         : kind == ESR_MLP_TONEMAP  ? NetDesc{2, 33, 20, 48, 3, 6, 4, 6}       // pbr/module.py:24-39
          : kind == ESR_MLP_BRDF     ? NetDesc{4, 76, 40, X_ROWS, 5, 4, 8, 6}   // pbr/module.py:42-65
          : kind == ESR_MLP_EMIT     ? NetDesc{4, 76, 40, X_ROWS, 3, 4, 4, 6}   // EmissionNet, pbr/module.py:68-83
          :                            NetDesc{3, 57, 36, XC_ROWS, 3, 4, 4, 12}; // coarse rgbnet, voxurfc.py:134-149
