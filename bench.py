@@ -351,6 +351,19 @@ def main():
         torch.cuda.synchronize()
         opt_ms = (time.perf_counter() - t1) / 5 * 1e3
         n_params = sum(p.numel() for g_ in opt.param_groups for p in g_["params"])
+    # the trainer's every-third-iteration TV lines (fine.py:383-400), reported separately like the optimizer
+    tv_ms = None
+    if rank == 0 and not a.no_optimizer and stage == "fine":
+        l_tv, g_tv = one()
+        tvs = dict(sdf=0.1, smooth_grad=0.05)
+        for _ in range(2):
+            step.add_regularisers(l_tv, g_tv, n_rays * world, 0.01, tvs, True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            step.add_regularisers(l_tv, g_tv, n_rays * world, 0.01, tvs, True)
+        torch.cuda.synchronize()
+        tv_ms = (time.perf_counter() - t1) / 5 * 1e3
 
     if rank == 0:
         value = n_rays * world * a.steps / dt
@@ -377,6 +390,9 @@ def main():
             out["optimizer_step"] = {"ms": opt_ms, "parameters": n_params, "kernel": "esr_adam_step (fused Adam, 28 B/param)",
                                      "hbm_gbs": n_params * 28 / (opt_ms * 1e-3) / 1e9,
                                      "note": "reported separately, not part of value / ms_per_step"}
+        if tv_ms is not None:
+            out["tv_terms"] = {"ms": tv_ms, "every": 3, "kernels": "esr_smooth_grad_tv_fwd/bwd + esr_tv_add_grad",
+                               "note": "do_tv lines of the trainer (fine.py:383-400), reported separately"}
         if dominant:
             launches = sum(kern[c][0] for c in dom_calls if c in kern)
             ms = sum(kern[c][1] for c in dom_calls if c in kern)

@@ -21,7 +21,7 @@ namespace {
 constexpr int XROWS = 104;  // rows of an X tile (96 + third colour group at 96-101)
 constexpr int DXROWS = 64;  // rows of a dX tile (0..42 used)
 constexpr int ROW_COL = 0, ROW_SDF = 6, ROW_FEAT = 7, ROW_NRM = 31, ROW_XYZ = 43, ROW_SIN = 46,
-              ROW_COS = 61, ROW_VD = 76, ROW_VSIN = 79, ROW_VCOS = 82, ROW_ALT = 88;
+              ROW_COS = 61, ROW_VD = 76, ROW_VSIN = 79, ROW_VCOS = 82;
 
 constexpr int MAX_SRC = 4;
 constexpr int COLOR_ROW[3] = {0, 88, 96};          // first row of the three 6-row colour groups

@@ -56,3 +56,141 @@ ESR_API int esr_tv_add_grad(const float *param, float *grad, float wx, float wy,
     ESR_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Smoothed-gradient TV term of the fine / lts trainers, forward AND backward:
+//   gradient = neus_sdf_gradient()                       (app/fine/model/voxurff.py:723-742, interior central differences)
+//   err      = tv_smooth_conv(gradient).detach() - gradient        (voxurff.py:611-613; 3x3x3 replicate-padded conv,
+//                                                                    app/utils/base/module.py:180-211)
+//   loss     = mean(err[nonempty_mask x 3]^2) * smooth_grad_tv      (voxurff.py:614-617), every tv_every-th iteration
+// The reference runs this as ~15 dense torch kernels over three-channel copies of the grid plus their autograd
+// twins.  Here: pass 1 writes the gradient field, pass 2 the masked error field and the loss (block reduction + one
+// atomic), pass 3 gathers d loss / d sdf through the central differences (the conv branch is detached, so the
+// adjoint is the difference stencil only) -- three streaming stencil passes, z on consecutive lanes.
+namespace {
+
+struct TvGrid { int gx, gy, gz; float voxel_size; };
+
+__device__ __forceinline__ float central(const float *__restrict__ s, const TvGrid G, int x, int y, int z, int c)
+{
+#pragma clang fp contract(off)
+    const int64_t i = ((int64_t)x * G.gy + y) * G.gz + z;
+    const int64_t st = c == 0 ? (int64_t)G.gy * G.gz : (c == 1 ? G.gz : 1);
+    const int p = c == 0 ? x : (c == 1 ? y : z), n = c == 0 ? G.gx : (c == 1 ? G.gy : G.gz);
+    if (p < 1 || p > n - 2) return 0.f;
+    return __fdiv_rn(__fdiv_rn(s[i + st] - s[i - st], 2.0f), G.voxel_size);
+}
+
+__global__ void __launch_bounds__(256) tv_gradient_kernel(const float *__restrict__ sdf, TvGrid G, float *__restrict__ g)
+{
+    const int64_t n = (int64_t)G.gx * G.gy * G.gz;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int z = (int)(i % G.gz), y = (int)(i / G.gz % G.gy), x = (int)(i / ((int64_t)G.gz * G.gy));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g[c * n + i] = central(sdf, G, x, y, z, c);
+    }
+}
+
+struct Conv27 { float w[27]; float bias; };
+
+__global__ void __launch_bounds__(256) tv_error_kernel(const float *__restrict__ g, const uint8_t *__restrict__ mask,
+                                                       TvGrid G, Conv27 K, float *__restrict__ err,
+                                                       float inv_count, float *__restrict__ loss)
+{
+    const int64_t n = (int64_t)G.gx * G.gy * G.gz;
+    float part = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int z = (int)(i % G.gz), y = (int)(i / G.gz % G.gy), x = (int)(i / ((int64_t)G.gz * G.gy));
+        const bool m = mask[i] != 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float e = 0.f;
+            if (m) {
+                float s = K.bias;
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+                    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                        for (int dz = -1; dz <= 1; ++dz) {
+                            const int xx = min(max(x + dx, 0), G.gx - 1), yy = min(max(y + dy, 0), G.gy - 1),
+                                      zz = min(max(z + dz, 0), G.gz - 1);
+                            s += K.w[(dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)] * g[c * n + ((int64_t)xx * G.gy + yy) * G.gz + zz];
+                        }
+                e = s - g[c * n + i];
+                part += e * e;
+            }
+            err[c * n + i] = e;                      // zero outside the mask: pass 3 needs no mask
+        }
+    }
+    // block sum -> one atomic
+    __shared__ float red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, ((red[0] + red[1]) + (red[2] + red[3])) * inv_count);
+}
+
+// d loss / d gradient_c = -2 * err_c * scale / count (conv branch detached); gradient_c[p] = (s[p+e_c] - s[p-e_c]) / 2 / vs
+// for interior p, so  d loss / d s[q] = (dg_c[q - e_c] - dg_c[q + e_c]) / 2 / vs  summed over c, interior sources only.
+__global__ void __launch_bounds__(256) tv_error_bwd_kernel(const float *__restrict__ err, TvGrid G, float coeff,
+                                                           const float *__restrict__ grad_out,
+                                                           float *__restrict__ grad_sdf)
+{
+    const int64_t n = (int64_t)G.gx * G.gy * G.gz;
+    if (grad_out) coeff *= grad_out[0];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int z = (int)(i % G.gz), y = (int)(i / G.gz % G.gy), x = (int)(i / ((int64_t)G.gz * G.gy));
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int64_t st = c == 0 ? (int64_t)G.gy * G.gz : (c == 1 ? G.gz : 1);
+            const int p = c == 0 ? x : (c == 1 ? y : z), m = c == 0 ? G.gx : (c == 1 ? G.gy : G.gz);
+            if (p - 1 >= 1 && p - 1 <= m - 2) acc += err[c * n + i - st];
+            if (p + 1 >= 1 && p + 1 <= m - 2) acc -= err[c * n + i + st];
+        }
+        grad_sdf[i] += coeff * acc;
+    }
+}
+
+}  // namespace
+
+ESR_API int esr_smooth_grad_tv_fwd(const float *sdf, const uint8_t *mask, const float *conv_w27, float conv_bias,
+                                   int32_t gx, int32_t gy, int32_t gz, float voxel_size, int64_t masked_cells,
+                                   float weight, float *work6, float *loss, void *stream)
+{
+    if (gx < 1 || gy < 1 || gz < 1 || masked_cells < 0) return ESR_EINVAL;
+    if (!sdf || !mask || !conv_w27 || !work6 || !loss) return ESR_EINVAL;
+    const int64_t n = (int64_t)gx * gy * gz;
+    TvGrid G = {gx, gy, gz, voxel_size};
+    Conv27 K;
+    for (int i = 0; i < 27; ++i) K.w[i] = conv_w27[i];          // host array
+    K.bias = conv_bias;
+    const int grid = esr_grid_for(n, 256, 256 * 16);
+    hipStream_t s = esr_stream(stream);
+    tv_gradient_kernel<<<grid, 256, 0, s>>>(sdf, G, work6);
+    ESR_CHECK_LAUNCH();
+    // mean over the 3 * masked_cells selected elements, times the term's weight (an empty mask gives NaN in torch;
+    // here it contributes nothing)
+    const float inv = masked_cells > 0 ? weight / (3.0f * (float)masked_cells) : 0.f;
+    tv_error_kernel<<<grid, 256, 0, s>>>(work6, mask, G, K, work6 + 3 * n, inv, loss);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_smooth_grad_tv_bwd(const float *work6, int32_t gx, int32_t gy, int32_t gz, float voxel_size,
+                                   int64_t masked_cells, float weight, const float *grad_out, float *grad_sdf,
+                                   void *stream)
+{
+    if (gx < 1 || gy < 1 || gz < 1 || masked_cells < 0) return ESR_EINVAL;
+    if (!work6 || !grad_sdf) return ESR_EINVAL;
+    if (masked_cells == 0) return 0;
+    const int64_t n = (int64_t)gx * gy * gz;
+    TvGrid G = {gx, gy, gz, voxel_size};
+    const float coeff = -2.0f * weight / (3.0f * (float)masked_cells) / 2.0f / voxel_size;
+    tv_error_bwd_kernel<<<esr_grid_for(n, 256, 256 * 16), 256, 0, esr_stream(stream)>>>(work6 + 3 * n, G, coeff, grad_out,
+                                                                                         grad_sdf);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}

@@ -158,6 +158,23 @@ class FineStep:
         g["emo_color.grid"] = g["emo_color.grid"].permute(0, 4, 1, 2, 3)
         return loss, g
 
+    @torch.no_grad()
+    def add_regularisers(self, loss: torch.Tensor, grads: Dict[str, torch.Tensor], n_rays_global: int,
+                         weight_tv_density: float, tvs: Dict[str, float], dense_mode: bool):
+        """The ``do_tv`` lines of the trainer (fine.py:383-400, every ``tv_every``-th iteration) without autograd:
+        ``loss += w * smoothed-gradient TV`` with its SDF gradient (csrc/tv.hip, fused forward + backward), then the
+        in-place 6-neighbour TV gradient (``sdf_total_variation_add_grad``).  Dense-grid work on replicated
+        parameters: under data parallelism call it AFTER the exchange, identically on every rank."""
+        from . import render_utils
+        m = self.model
+        w = weight_tv_density * tvs["smooth_grad"]
+        loss1 = loss.reshape(1)
+        m.smooth_grad_tv_fwd(w, loss1)
+        m.smooth_grad_tv_bwd(w, grads["sdf.grid"])
+        wt = weight_tv_density * tvs["sdf"] / n_rays_global * float(m.world_size.max()) / 128
+        render_utils.total_variation_add_grad(m.sdf.grid.detach(), grads["sdf.grid"], wt, wt, wt, dense_mode)
+        return loss
+
     def assign_grads(self, grads: Dict[str, torch.Tensor]):
         """Expose the step's gradients as ``param.grad`` (for a torch optimizer)."""
         for n, p in self.model.named_parameters():

@@ -64,6 +64,26 @@ class _FineRender(torch.autograd.Function):
         return (None, None, g_sdf, g_off.permute(0, 4, 1, 2, 3), g_emo.permute(0, 4, 1, 2, 3), *mlp_grads)
 
 
+class _SmoothGradTV(torch.autograd.Function):
+    """Smoothed-gradient TV term (voxurff.py:609-617) as one differentiable op on the HIP path."""
+
+    @staticmethod
+    def forward(ctx, model, sdf_grid, weight):
+        if not sdf_grid.is_cuda:
+            raise RuntimeError("the TV term runs on the HIP path (no CPU fallback)")
+        loss = torch.zeros(1, dtype=torch.float32, device=sdf_grid.device)
+        model.smooth_grad_tv_fwd(weight, loss)
+        ctx.model, ctx.weight = model, weight
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        m = ctx.model
+        grad = torch.zeros_like(m.sdf.grid)
+        m.smooth_grad_tv_bwd(ctx.weight, grad, g.reshape(1).float().contiguous())
+        return None, grad, None
+
+
 class VoxurfF(nn.Module):
     def __init__(self, cfg, near: float, far: float, xyz_min: torch.Tensor, xyz_max: torch.Tensor,
                  mask_xyz_min: torch.Tensor, mask_xyz_max: torch.Tensor, mask_alpha_init: float,
@@ -254,11 +274,45 @@ class VoxurfF(nn.Module):
                 parts.append(diff[m[tuple(lo)] & m[tuple(hi)]].mean())
             tv = tv + sum(parts) / 3 / 2 / self.voxel_size * sdf_tv
         if smooth_grad_tv > 0:
-            self.gradient = self.neus_sdf_gradient()
-            gr = self.gradient.permute(1, 0, 2, 3, 4)
-            err = self.tv_smooth_conv(gr).detach() - gr
-            tv = tv + (err[self.nonempty_mask.repeat(3, 1, 1, 1, 1)] ** 2).mean() * smooth_grad_tv
+            # fused HIP kernels (csrc/tv.hip): gradient field, detached 3x3x3 smoothing, masked mean of squares and,
+            # in the backward, the adjoint of the central differences -- no dense torch chain, no CPU fallback
+            tv = tv + _SmoothGradTV.apply(self, self.sdf.grid, float(smooth_grad_tv))
         return tv
+
+    def _tv_state(self):
+        """Host-side constants of the smoothed-gradient TV term: mask bytes + count, conv taps, workspace."""
+        st = getattr(self, "_tv_cache", None)
+        key = (self.nonempty_mask.data_ptr(), tuple(self.sdf.grid.shape))
+        if st is None or st["key"] != key:
+            import ctypes as C
+            mask = self.nonempty_mask.contiguous().view(torch.uint8)
+            w = self.tv_smooth_conv.m.weight.detach().float().cpu().reshape(-1).tolist()
+            st = dict(key=key, mask=mask, count=int(self.nonempty_mask.sum()), w27=(C.c_float * 27)(*w),
+                      bias=float(self.tv_smooth_conv.m.bias.detach().cpu()),
+                      work=torch.empty(6 * self.sdf.grid.numel(), dtype=torch.float32, device=self.sdf.grid.device))
+            self._tv_cache = st
+        return st
+
+    def smooth_grad_tv_fwd(self, weight: float, loss_out: torch.Tensor):
+        """loss_out[0] += weight * smoothed-gradient TV term; leaves the error field for smooth_grad_tv_bwd."""
+        import ctypes as C
+        from . import _lib
+        st, g = self._tv_state(), self.sdf.grid
+        X, Y, Z = g.shape[2:]
+        _lib.check(_lib.lib().esr_smooth_grad_tv_fwd(
+            _lib.ptr(g.detach()), _lib.ptr(st["mask"]), st["w27"], C.c_float(st["bias"]), X, Y, Z,
+            C.c_float(self._voxel_size_f), C.c_int64(st["count"]), C.c_float(weight), _lib.ptr(st["work"]),
+            _lib.ptr(loss_out), _lib.stream_ptr(g.device)), "esr_smooth_grad_tv_fwd")
+
+    def smooth_grad_tv_bwd(self, weight: float, grad_sdf: torch.Tensor, grad_out: Optional[torch.Tensor] = None):
+        """grad_sdf (+)= grad_out * d(term)/d(sdf.grid), from the error field of the last smooth_grad_tv_fwd."""
+        import ctypes as C
+        from . import _lib
+        st = self._tv_state()
+        X, Y, Z = self.sdf.grid.shape[2:]
+        _lib.check(_lib.lib().esr_smooth_grad_tv_bwd(
+            _lib.ptr(st["work"]), X, Y, Z, C.c_float(self._voxel_size_f), C.c_int64(st["count"]), C.c_float(weight),
+            _lib.ptr(grad_out), _lib.ptr(grad_sdf), _lib.stream_ptr(grad_sdf.device)), "esr_smooth_grad_tv_bwd")
 
     def sdf_total_variation_add_grad(self, weight: float, dense_mode: bool):
         w = weight * self.world_size.max() / 128

@@ -560,6 +560,22 @@ int esr_adam_step(float *param, const float *grad, float *exp_avg, float *exp_av
                   const float *per_lr, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int32_t step, void *stream);
 
+/*
+ * Smoothed-gradient TV term of the fine / lts trainers, forward and backward -- replaces the dense torch chain
+ * neus_sdf_gradient (app/fine/model/voxurff.py:723-742) -> GradientConv (app/utils/base/module.py:180-211, 3x3x3,
+ * replicate padding; the conv branch is detached) -> masked mean of squares (voxurff.py:609-617).
+ *   fwd: loss[0] += weight * mean_{c, p in mask} (conv(g_c)[p] - g_c[p])^2 ;  work6 [6, X, Y, Z] keeps g and err
+ *   bwd: grad_sdf += grad_out * d loss / d sdf  (from the err planes left in work6 by fwd)
+ * sdf [X,Y,Z]; mask [X,Y,Z] bytes (nonempty_mask); conv_w27: HOST array, kernel order [dx][dy][dz];
+ * masked_cells = number of set mask bytes (the mean runs over 3 * masked_cells values).
+ */
+int esr_smooth_grad_tv_fwd(const float *sdf, const uint8_t *mask, const float *conv_w27, float conv_bias,
+                           int32_t gx, int32_t gy, int32_t gz, float voxel_size, int64_t masked_cells,
+                           float weight, float *work6, float *loss, void *stream);
+int esr_smooth_grad_tv_bwd(const float *work6, int32_t gx, int32_t gy, int32_t gz, float voxel_size,
+                           int64_t masked_cells, float weight, const float *grad_out /* device scalar or NULL = 1 */,
+                           float *grad_sdf, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * F. Data-parallel gradient exchange (no reference counterpart: the reference is single-process,
  *    SURVEY 2a / 8(e); the sum over ranks itself is torch.distributed = RCCL)

@@ -102,23 +102,17 @@ def test_no_cpu_fallback_and_loud_config_errors():
         render_utils.alpha2weight(torch.zeros(3), torch.zeros(3, dtype=torch.int64), 2)
 
 
-def test_tv_regulariser_matches_oracle_formula():
-    """density_total_variation(smooth_grad) uses the on-demand dense gradient (voxurff.py:600-617,723-742)."""
+def test_tv_regulariser_host_side():
+    """density_total_variation: the plain SDF-TV branch (functions.py:34-42) is host-side torch; the smoothed-gradient
+    branch is a HIP kernel pair and refuses CPU tensors (its parity test: tests/test_gpu_native_ops.py)."""
     m, _ = _cpu_model()
-    tv = m.density_total_variation(sdf_tv=0.1, smooth_grad_tv=0.05)
-    g = m.sdf.grid
-    vs = m.voxel_size
-    grad = torch.zeros(1, 3, *g.shape[2:])
-    grad[:, 0, 1:-1] = (g[:, 0, 2:] - g[:, 0, :-2]) / 2 / vs
-    grad[:, 1, :, 1:-1] = (g[:, 0, :, 2:] - g[:, 0, :, :-2]) / 2 / vs
-    grad[:, 2, :, :, 1:-1] = (g[:, 0, :, :, 2:] - g[:, 0, :, :, :-2]) / 2 / vs
-    gp = grad.permute(1, 0, 2, 3, 4)
-    err = (m.tv_smooth_conv(gp).detach() - gp)[m.nonempty_mask.repeat(3, 1, 1, 1, 1)] ** 2
-    mask = m.nonempty_mask
+    tv = m.density_total_variation(sdf_tv=0.1, smooth_grad_tv=0)
+    g, vs, mask = m.sdf.grid, m.voxel_size, m.nonempty_mask
     tv_sdf = sum(g.diff(dim=d).abs()[mask.narrow(d, 0, mask.shape[d] - 1) & mask.narrow(d, 1, mask.shape[d] - 1)].mean()
                  for d in (2, 3, 4)) / 3
-    expect = tv_sdf / 2 / vs * 0.1 + err.mean() * 0.05
-    assert rel_err(tv.detach(), expect.detach()) < 1e-6
+    assert rel_err(tv.detach(), (tv_sdf / 2 / vs * 0.1).detach()) < 1e-6
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.density_total_variation(sdf_tv=0, smooth_grad_tv=0.05)
 
 
 def test_shard_batch_partitions():
