@@ -255,61 +255,78 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
 }
 
 // One workgroup: exclusive offsets, emissive-on rays first, off rays from the
-// next multiple of 32.
+// next multiple of 32.  Rays are walked in chunks of 1024 with COALESCED loads (the first version gave every thread
+// a contiguous run of rays: lane-strided dependent loads, 0.43 ms per LTS step for its 8 k + 25.6 k rays); both
+// classes are scanned at once (two counters per thread), each ray first gets the offset inside its class, and the
+// off rays are shifted by the padded on-total in a second coalesced sweep.
+__device__ __forceinline__ int2 block_scan2(int2 v, int2 *wave_tot, int tid)   // exclusive scan over 1024 threads
+{
+    int2 inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int ax = __shfl_up(inc.x, off), ay = __shfl_up(inc.y, off);
+        if ((tid & 63) >= off) { inc.x += ax; inc.y += ay; }
+    }
+    if ((tid & 63) == 63) wave_tot[tid >> 6] = inc;
+    __syncthreads();
+    if (tid < 64) {
+        int2 t = tid < 16 ? wave_tot[tid] : make_int2(0, 0);
+        int2 ti = t;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const int ax = __shfl_up(ti.x, off), ay = __shfl_up(ti.y, off);
+            if (tid >= off) { ti.x += ax; ti.y += ay; }
+        }
+        if (tid < 16) wave_tot[tid] = make_int2(ti.x - t.x, ti.y - t.y);       // exclusive wave bases
+        if (tid == 15) wave_tot[16] = ti;                                       // chunk totals
+    }
+    __syncthreads();
+    const int2 wb = wave_tot[tid >> 6];
+    return make_int2(wb.x + inc.x - v.x, wb.y + inc.y - v.y);
+}
+
 __global__ void __launch_bounds__(1024) plan_kernel(const int32_t *__restrict__ cnt3,
                                                     const int64_t *__restrict__ em_modes,
                                                     const int32_t *__restrict__ stats, int n_rays,
                                                     int32_t *__restrict__ off3, esr_plan_t *plan)
 {
-    __shared__ int part[1024];
-    __shared__ int total_on;
+    __shared__ int2 wave_tot[17];
     const int tid = threadIdx.x;
-    const int per = (n_rays + 1023) / 1024;
-    const int b = tid * per, e = (b + per < n_rays) ? b + per : n_rays;
-    {   // survivor statistics m0, m1, m2 = sums of the per-ray counts
-        int s0 = 0, s1 = 0, s2 = 0;
-        for (int i = b; i < e; ++i) { s0 += stats[3 * i]; s1 += stats[3 * i + 1]; s2 += stats[3 * i + 2]; }
+    {   // survivor statistics m0, m1, m2 = sums of the per-ray counts (element j of stats is of class j % 3)
+        int s[3] = {0, 0, 0};
+        for (int j = tid; j < 3 * n_rays; j += 1024) {
+            const int v = stats[j], c = j % 3;
+            s[0] += c == 0 ? v : 0; s[1] += c == 1 ? v : 0; s[2] += c == 2 ? v : 0;
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off);
+            s[0] += __shfl_xor(s[0], off); s[1] += __shfl_xor(s[1], off); s[2] += __shfl_xor(s[2], off);
         }
-        if ((tid & 63) == 0 && (s0 | s1 | s2)) {
-            atomicAdd(&plan->m0, s0); atomicAdd(&plan->m1, s1); atomicAdd(&plan->m2, s2);
+        if ((tid & 63) == 0 && (s[0] | s[1] | s[2])) {
+            atomicAdd(&plan->m0, s[0]); atomicAdd(&plan->m1, s[1]); atomicAdd(&plan->m2, s[2]);
         }
     }
-    int base = 0;
-    for (int pass = 0; pass < 2; ++pass) {           // pass 0: on rays, pass 1: off rays
-        int s = 0;
-        for (int i = b; i < e; ++i)
-            if ((em_modes[i] == 1) == (pass == 0)) s += cnt3[i];
-        part[tid] = s;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            int v = (tid >= off) ? part[tid - off] : 0;
-            __syncthreads();
-            part[tid] += v;
-            __syncthreads();
-        }
-        int run = base + part[tid] - s;
-        for (int i = b; i < e; ++i)
-            if ((em_modes[i] == 1) == (pass == 0)) {
-                off3[i] = run;
-                run += cnt3[i];
-            }
-        const int tot = part[1023];
-        __syncthreads();
-        if (pass == 0) {
-            if (tid == 0) {
-                total_on = tot;
-                plan->n_on = tot;
-                plan->tiles_on = (tot + 31) / 32;
-            }
-            base = ((tot + 31) / 32) * 32;
-        } else if (tid == 0) {
-            plan->n_off = tot;
-            plan->tiles_all = (total_on + 31) / 32 + (tot + 31) / 32;
-        }
-        __syncthreads();
+    int2 run = make_int2(0, 0);                        // totals of the chunks before this one (on, off)
+    for (int c0 = 0; c0 < n_rays; c0 += 1024) {
+        const int i = c0 + tid;
+        const bool live = i < n_rays;
+        const int cnt = live ? cnt3[i] : 0;
+        const bool on = live && em_modes[i] == 1;
+        const int2 v = make_int2(on ? cnt : 0, (live && !on) ? cnt : 0);
+        const int2 ex = block_scan2(v, wave_tot, tid);
+        if (live) off3[i] = on ? run.x + ex.x : run.y + ex.y;
+        const int2 tot = wave_tot[16];
+        run.x += tot.x; run.y += tot.y;
+        __syncthreads();                               // wave_tot is rewritten by the next chunk
+    }
+    const int base = ((run.x + 31) / 32) * 32;
+    for (int i = tid; i < n_rays; i += 1024)
+        if (em_modes[i] != 1) off3[i] += base;
+    if (tid == 0) {
+        plan->n_on = run.x;
+        plan->tiles_on = (run.x + 31) / 32;
+        plan->n_off = run.y;
+        plan->tiles_all = (run.x + 31) / 32 + (run.y + 31) / 32;
     }
 }
 
