@@ -12,10 +12,11 @@ part of this class.
 
 Data parallelism: rays are independent, so every rank runs the
 same step on its contiguous shard of the global batch and the parameter
-gradients live in ONE flat buffer that is summed with two all-reduces (RCCL over
-xGMI when the process group is NCCL): the dense-grid part as soon as the grid scatters are
-done -- overlapped with the weight-gradient kernels -- and the small MLP part at the end.  Losses are normalised by the GLOBAL ray count so the reduced
-gradient equals the single-process gradient of the full batch.
+gradients live in ONE flat buffer.  Its dense-grid part (> 99 % of the bytes) is exchanged
+brick-sparsely over RCCL / xGMI as soon as the grid scatters are done (grad_sync.GridGradSync),
+underneath the weight-gradient kernels that run on a second HIP stream; the small MLP part and
+the loss follow as plain all-reduces.  Losses are normalised by the GLOBAL ray count so the
+reduced gradient equals the single-process gradient of the full batch.
 """
 from __future__ import annotations
 
@@ -90,7 +91,7 @@ class FineStep:
         return self._names
 
     def _alloc_grads(self, dev):
-        """One flat zero buffer holding every gradient (a single memset, a single all-reduce)."""
+        """One flat zero buffer holding every gradient (a single memset; grids first, then the MLP tensors)."""
         m = self.model
         X, Y, Z = [int(v) for v in m.world_size]
         shapes = [("sdf.grid", (1, 1, X, Y, Z)), ("off_color.grid", (1, X, Y, Z, 6)),
