@@ -220,6 +220,12 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    # Rehearsal of the N > 1 flow on a ONE-GPU box (ESR_BENCH_REHEARSAL=1): every rank uses device 0 and the ranks
+    # talk over gloo, because RCCL refuses two ranks on one device.  Exercises the launch / barrier / max-over-ranks /
+    # gradient-exchange code with real ranks; its numbers are NOT a measurement (two processes share one GPU).
+    rehearsal = os.environ.get("ESR_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     pg = None
@@ -229,7 +235,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))     # nccl == RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))     # nccl == RCCL on ROCm
         pg = dist.group.WORLD
 
     import numpy as np
@@ -335,7 +344,7 @@ def main():
 
     # optimizer step, reported separately (outside the named path, never part of `value`)
     opt_ms = None
-    if rank == 0 and not a.no_optimizer:
+    if not a.no_optimizer:         # every rank: one() is a collective step when N > 1 (rank 0 reports)
         from esr_nerf_amd.optimizer import create_optimizer_or_freeze_model
         lrs = dict(off_color=0.1, off_rgbnet=0.003, emo_color=0.1, emo_rgbnet=0.003, sdf=0.005, tonemapper=0.003,
                    brdf=0.1, brdfnet=0.003, emitnet=0.003, envmap=0.003)
@@ -353,7 +362,7 @@ def main():
         n_params = sum(p.numel() for g_ in opt.param_groups for p in g_["params"])
     # the trainer's every-third-iteration TV lines (fine.py:383-400), reported separately like the optimizer
     tv_ms = None
-    if rank == 0 and not a.no_optimizer and stage == "fine":
+    if not a.no_optimizer and stage == "fine":
         l_tv, g_tv = one()
         tvs = dict(sdf=0.1, smooth_grad=0.05)
         for _ in range(2):
@@ -374,7 +383,8 @@ def main():
                       else f"training rays/sec, config {a.config}, {stage} stage, {a.dtype} MLPs",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": a.dtype,
+            "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)",
             "config": {
                 "workload": f"{a.config}: giftbox_w {stage} stage on the slab scene, {n_rays} rays x {samples} "
                             f"samples per GPU, grid {'x'.join(str(int(v)) for v in model.world_size.tolist())}, "

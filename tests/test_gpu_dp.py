@@ -70,3 +70,22 @@ def test_two_rank_step_equals_full_batch_step():
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     line = [l for l in out.stdout.splitlines() if l.startswith("DPGPU")][0].split()
     assert float(line[1]) < 1e-5
+
+
+def test_bench_flow_with_two_ranks_rehearsal():
+    """bench.py's N > 1 flow (launch under torch.distributed.run, barriers, max-over-ranks time, gradient exchange, the
+    separately timed optimizer / TV sections on every rank, one JSON line from rank 0) with two real ranks sharing the
+    test box's single GPU over gloo (ESR_BENCH_REHEARSAL=1; RCCL refuses two ranks per device)."""
+    import json
+    env = dict(os.environ, ESR_BENCH_REHEARSAL="1", OMP_NUM_THREADS="2")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", "29537", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2",
+         "--config", "small"],
+        env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["grad_exchange"]["mode"] in ("sparse", "dense") and d["grad_exchange"]["bricks"] > 0
+    assert "REHEARSAL" in d["data"]
