@@ -472,6 +472,9 @@ def main():
             out["grad_exchange"] = dict(sync.last, brick_bytes=sync.brick * 4,
                                         dense_grid_mb=round(step._n_grid * 4 / 1e6, 1),
                                         sent_mb=round(sync.last["sent"] * sync.brick * 4 / 1e6, 1))
+        elif pg is not None:
+            out["grad_exchange"] = dict(mode="dense-async", dense_grid_mb=round(step._n_grid * 4 / 1e6, 1),
+                                        sent_mb=round(step._n_grid * 4 / 1e6, 1))
         if world == 1 and not a.no_cpu_baseline:
             if stage == "fine":
                 out["cpu_baseline"] = cpu_baseline(model, scene, a.s_val, min(a.cpu_rays, n_rays), a.cpu_iters)

@@ -116,7 +116,7 @@ class _LtsRender(torch.autograd.Function):
         model = ctx.model
         dev = model.sdf.grid.device
         z = lambda shape: torch.zeros(shape, dtype=torch.float32, device=dev)
-        X, Y, Z = [int(v) for v in model.world_size]
+        X, Y, Z = model._world_size_l           # host copy: int(device scalar) is a sync each
         g_sdf = z((1, 1, X, Y, Z))
         g_off, g_emo, g_brdf = z((1, X, Y, Z, 6)), z((1, X, Y, Z, 6)), z((1, X, Y, Z, 6))
         mg = [z(s) for s in ctx.shapes]
@@ -158,7 +158,7 @@ class _FinetuneRender(torch.autograd.Function):
     def backward(ctx, g_emo, _g_hat):
         model = ctx.model
         dev = model.sdf.grid.device
-        X, Y, Z = [int(v) for v in model.world_size]
+        X, Y, Z = model._world_size_l           # host copy: int(device scalar) is a sync each
         g_grid = torch.zeros((1, X, Y, Z, 6), dtype=torch.float32, device=dev)
         mg = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.shapes]
         if g_emo is not None:

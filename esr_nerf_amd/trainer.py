@@ -47,12 +47,24 @@ def dp_loss_weights(n_local: int, global_rays, entropy_owner: bool, weight_entro
 
 
 def _grid_sync(step, eng):
-    """after_grids callback of a data-parallel step.  With the weight gradients on their own stream
-    (already enqueued when this runs) the dense-grid gradients go through the brick-sparse exchange,
-    whose host sync then costs nothing; otherwise one dense asynchronous all-reduce."""
+    """after_grids callback of a data-parallel step: how the dense-grid gradients are summed over ranks.
+
+    * ``sparse`` -- grad_sync.GridGradSync: brick flags, union, ONE all-reduce of the packed union (C2: 35 MB per
+      rank instead of 218 MB).  Costs one host sync and two more collective launches on the critical path of the
+      exchange (measured with one rank: +0.35 ms per step, against +0.1 ms for the dense form), so it pays when
+      the wire time dominates: few ranks = few usable xGMI links (one at N = 2).
+    * ``dense`` -- one asynchronous all-reduce of the whole grid part, no host sync; underneath the weight-gradient
+      kernels.  With all 7 links per GPU in play (N = 8) a ring moves 218 MB in about a millisecond, which the
+      ~1.3 ms of wgrad work hides.
+    ``ESR_GRAD_SYNC=sparse|dense`` forces either; the default picks sparse for 2-4 ranks (link arithmetic, to be
+    replaced by the driver's multi-GPU measurements)."""
+    import os
     import torch.distributed as dist
     works = []
-    if getattr(eng, "overlap_wgrad", False):
+    mode = os.environ.get("ESR_GRAD_SYNC", "auto")
+    if mode == "auto":
+        mode = "sparse" if 2 <= dist.get_world_size(step.pg) <= 4 else "dense"
+    if mode == "sparse" and getattr(eng, "overlap_wgrad", False):   # the sync is free only with wgrad on its own stream
         from .grad_sync import GridGradSync
         if step._sync is None:
             step._sync = GridGradSync(step.pg)
@@ -93,7 +105,7 @@ class FineStep:
     def _alloc_grads(self, dev):
         """One flat zero buffer holding every gradient (a single memset; grids first, then the MLP tensors)."""
         m = self.model
-        X, Y, Z = [int(v) for v in m.world_size]
+        X, Y, Z = m._world_size_l                   # host copy: int(device scalar) is a sync each
         shapes = [("sdf.grid", (1, 1, X, Y, Z)), ("off_color.grid", (1, X, Y, Z, 6)),
                   ("emo_color.grid", (1, X, Y, Z, 6))]
         shapes += [(n, tuple(p.shape)) for n, p in zip(self._param_names(), m._mlp_params())]
@@ -172,7 +184,7 @@ class FineStep:
         loss1 = loss.reshape(1)
         m.smooth_grad_tv_fwd(w, loss1)
         m.smooth_grad_tv_bwd(w, grads["sdf.grid"])
-        wt = weight_tv_density * tvs["sdf"] / n_rays_global * float(m.world_size.max()) / 128
+        wt = weight_tv_density * tvs["sdf"] / n_rays_global * max(m._world_size_l) / 128
         render_utils.total_variation_add_grad(m.sdf.grid.detach(), grads["sdf.grid"], wt, wt, wt, dense_mode)
         return loss
 
@@ -217,7 +229,7 @@ class LtsStep:
 
     def _alloc_grads(self, dev):
         m = self.model
-        X, Y, Z = [int(v) for v in m.world_size]
+        X, Y, Z = m._world_size_l                   # host copy: int(device scalar) is a sync each
         J = m.envmap.mus.shape[0]
         shapes = [("sdf.grid", (1, 1, X, Y, Z)), ("off_color.grid", (1, X, Y, Z, 6)), ("emo_color.grid", (1, X, Y, Z, 6)),
                   ("brdf.grid", (1, X, Y, Z, 6))]

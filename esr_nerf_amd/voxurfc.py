@@ -211,7 +211,7 @@ class _CoarseRender(torch.autograd.Function):
     def backward(ctx, g_last, g_wbg, g_srgb):
         model = ctx.model
         dev = model.sdf.grid.device
-        X, Y, Z = [int(v) for v in model.world_size]
+        X, Y, Z = model._world_size_l           # host copy: int(device scalar) is a sync each
         z = lambda shape: torch.zeros(shape, dtype=torch.float32, device=dev)
         g_sdf, g_off, g_emo = z((1, 1, X, Y, Z)), z((1, X, Y, Z, 12)), z((1, X, Y, Z, 12))
         mg = [z(s) for s in ctx.shapes]

@@ -50,7 +50,7 @@ class _FineRender(torch.autograd.Function):
         model = ctx.model
         dev = g_last.device
         z = lambda shape: torch.zeros(shape, dtype=torch.float32, device=dev)
-        X, Y, Z = [int(v) for v in model.world_size]
+        X, Y, Z = model._world_size_l           # host copy: int(device scalar) is a sync each
         g_sdf = z((1, 1, X, Y, Z))
         g_off = z((1, X, Y, Z, 6))
         g_emo = z((1, X, Y, Z, 6))
@@ -315,7 +315,7 @@ class VoxurfF(nn.Module):
             _lib.ptr(grad_out), _lib.ptr(grad_sdf), _lib.stream_ptr(grad_sdf.device)), "esr_smooth_grad_tv_bwd")
 
     def sdf_total_variation_add_grad(self, weight: float, dense_mode: bool):
-        w = weight * self.world_size.max() / 128
+        w = weight * max(self._world_size_l) / 128
         self.sdf.total_variation_add_grad(w, w, w, dense_mode)
 
     # ------------------------------------------------------------------ data filtering
