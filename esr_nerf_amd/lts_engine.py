@@ -85,6 +85,40 @@ class LtsCtx:
     eps: Dict[str, float] = field(default_factory=dict)
 
 
+class _PointDraw:
+    """``np.random.choice(n, k, replace=False)`` of numpy's GLOBAL legacy generator (the surface-point draw of
+    esrnerf.py:792), started on a worker thread as soon as ``n`` -- the survivor count -- is known and collected where
+    the reference draws it.  The draw is a full shuffle of range(n) on the host (1.3-1.6 ms at C4, 12 ms at 600 k
+    survivors) and the light-transport pass cannot be enqueued without it; beside the enqueueing of the primary pass
+    it is free.  ``esr_host_choice_noreplace`` is numpy's algorithm on numpy's state, bit for bit, called through
+    ctypes (no GIL).  The global state is checked out here and written back in ``result()``: nothing else may draw
+    from ``np.random`` in between (nothing on this path does)."""
+
+    def __init__(self, n: int, k: int):
+        import threading
+        st = np.random.get_state()
+        if st[0] != "MT19937":
+            raise RuntimeError("numpy's global generator is not the legacy MT19937")
+        self._st = st
+        self._key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+        self._pos = C.c_int32(int(st[2]))
+        self._out = np.empty(k, dtype=np.int64)
+        self._rc = None
+        L = _lib.lib()
+
+        def run():
+            self._rc = L.esr_host_choice_noreplace(self._key.ctypes.data_as(C.c_void_p), C.byref(self._pos),
+                                                   C.c_int64(n), C.c_int64(k), self._out.ctypes.data_as(C.c_void_p))
+        self._th = threading.Thread(target=run)
+        self._th.start()
+
+    def result(self) -> torch.Tensor:
+        self._th.join()
+        _lib.check(self._rc, "esr_host_choice_noreplace")
+        np.random.set_state((self._st[0], self._key, int(self._pos.value), self._st[3], self._st[4]))
+        return torch.from_numpy(self._out)
+
+
 class LtsEngine(FineEngine):
     def __init__(self, device, mlp_dtype: str = "f32"):
         super().__init__(device, mlp_dtype)
@@ -534,6 +568,7 @@ class LtsEngine(FineEngine):
         m3 = P0.counts["m3"]
         if T == 0:
             raise RuntimeError("LTS step with no surviving sample (degenerate batch)")
+        point_draw = _PointDraw(m3, min(int(cfg["num_ltspts"]), m3)) if draws is None else None
         sp = C.byref(scene)
         self._feat_args_records(P0, rays_o, rays_d, viewdirs, sdf, (offg, emog, brdfg), (offg, emog, brdfg))
         self._features(P0, scene)
@@ -568,10 +603,9 @@ class LtsEngine(FineEngine):
         emit_rm = P0.rowmajor("emit.a")            # [T*32, 4]
 
         # ---- light-transport segment
-        if draws is None:
-            idx_ref = torch.from_numpy(np.random.choice(m3, min(int(cfg["num_ltspts"]), m3), replace=False)).to(dev)
-        else:
-            idx_ref = draws["idx"].to(dev)
+        idx_host = point_draw.result() if draws is None else draws["idx"]
+        self.last_point_idx = idx_host
+        idx_ref = idx_host.to(dev)
         Pn, R = idx_ref.numel(), ctx.n_2nd
         ctx.n_pts = Pn
         jp = perm[idx_ref]

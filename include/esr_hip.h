@@ -576,6 +576,14 @@ int esr_smooth_grad_tv_bwd(const float *work6, int32_t gx, int32_t gy, int32_t g
                            int64_t masked_cells, float weight, const float *grad_out /* device scalar or NULL = 1 */,
                            float *grad_sdf, void *stream);
 
+/*
+ * HOST helper (no device work, no stream): out[0..k) = np.random.choice(n, k, replace=False) of numpy's legacy
+ * RandomState (the surface-point draw of app/fine/model/esrnerf.py:792 / :470), bit for bit, on the MT19937 state
+ * passed in (key: 624 words, *pos: 0..624; both updated).  Exists so that the draw can run on a worker thread
+ * without the GIL while the primary pass is being enqueued.
+ */
+int esr_host_choice_noreplace(uint32_t *key, int32_t *pos, int64_t n, int64_t k, int64_t *out);
+
 /* ------------------------------------------------------------------------- *
  * F. Data-parallel gradient exchange (no reference counterpart: the reference is single-process,
  *    SURVEY 2a / 8(e); the sum over ranks itself is torch.distributed = RCCL)

@@ -111,6 +111,19 @@ def test_lts_internal_draws_run_and_are_finite():
         if k.startswith("tv_smooth_conv"):
             continue
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+    # the surface points are drawn on a worker thread from numpy's global generator: same indices, same state after
+    # the step as the reference's inline np.random.choice (esrnerf.py:792)
+    import numpy as np
+    m3 = m.last_counts["m3"]
+    np.random.seed(11)
+    want = np.random.choice(m3, 40, replace=False)
+    after = np.random.random()
+    np.random.seed(11)
+    with torch.no_grad():
+        m(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=b["em_modes"],
+          uncert_masks=um, s_val=60.0, normal_eps=tr.normal_eps, emit_eps=tr.emit_eps)
+    assert np.random.random() == after
+    assert m.engine.last_point_idx.tolist() == want.tolist()
 
 
 @pytest.mark.parametrize("mode,scene_name,n_rays,s_val", [("lts", "tiny", 96, 45.0), ("pdra", "tiny", 64, 90.0)])

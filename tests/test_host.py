@@ -241,3 +241,30 @@ def test_mesh_and_envmap_utilities():
     except ImportError:
         with pytest.raises(ImportError, match="PyMCubes"):
             m.extract_geometry(resolution=8)
+
+
+def test_host_point_draw_equals_numpy_choice():
+    """esr_host_choice_noreplace == np.random.choice(n, k, replace=False) of the legacy global generator, including
+    the generator state it leaves behind (esrnerf.py:792 draws from that stream every step)."""
+    import ctypes as C
+    from esr_nerf_amd import _lib
+    L = _lib.lib()
+
+    def ours(n, k):
+        st = np.random.get_state()
+        key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+        pos = C.c_int32(int(st[2]))
+        out = np.empty(k, dtype=np.int64)
+        assert L.esr_host_choice_noreplace(key.ctypes.data_as(C.c_void_p), C.byref(pos), C.c_int64(n), C.c_int64(k),
+                                           out.ctypes.data_as(C.c_void_p)) == 0
+        np.random.set_state((st[0], key, pos.value, st[3], st[4]))
+        return out
+
+    for seed in range(4):
+        for n, k in [(1, 1), (5, 3), (100, 100), (1000, 100), (80000, 100), (70001, 64)]:
+            np.random.seed(seed); np.random.random(seed * 7)
+            a = np.random.choice(n, k, replace=False); ra = np.random.random()
+            np.random.seed(seed); np.random.random(seed * 7)
+            b = ours(n, k); rb = np.random.random()
+            assert np.array_equal(a, b) and ra == rb, (seed, n, k)
+    assert L.esr_host_choice_noreplace(None, None, C.c_int64(3), C.c_int64(5), None) < 0
