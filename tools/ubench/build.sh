@@ -2,7 +2,7 @@
 # Build the micro-benchmarks for gfx950 (hipcc cross-compiles without a GPU); run them with
 #   gpurun -- './tools/ubench/lds_atomic'   etc.
 cd "$(dirname "$0")"
-for f in lds_atomic lds_dma_m0 mfma_f32_loop; do
+for f in lds_atomic lds_dma_m0 mfma_f32_loop mfma_vmem_mix; do
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o $f $f.hip 2>&1 | grep -E "error" 
 done
 ls -la
