@@ -271,7 +271,8 @@ __device__ __forceinline__ void relu_tiles(f32x16 (&acc)[NT])
 #pragma unroll
     for (int it = 0; it < NT; ++it)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[it][r] = fmaxf(acc[it][r], 0.f);
+        for (int r = 0; r < 16; ++r)      // one v_max_f32 (fmaxf on an MFMA result compiles to a canonicalising max + the max)
+            asm("v_max_f32 %0, %1, 0" : "=v"(acc[it][r]) : "v"(acc[it][r]));
 }
 
 // per-lane byte offset inside a tile-major tile: row 4h, sample s
@@ -312,9 +313,16 @@ __device__ __forceinline__ void store_relu_mask(rsrc_t T, const f32x16 (&acc)[NT
     static_assert(NT % 2 == 0, "two tiles per mask word");
 #pragma unroll
     for (int wd = 0; wd < NT / 2; ++wd) {
+        // (x > 0) as an integer clamp of the float's bits to [0, 1] (v_med3_i32: +0, -0 and negatives give 0) shifted
+        // into place with v_lshl_or_b32: two VALU instructions per element and no VCC round trip (the compare /
+        // select / or form compiled to ~3.5 instructions plus hazard nops)
         unsigned m = 0;
 #pragma unroll
-        for (int b = 0; b < 32; ++b) m |= (acc[2 * wd + (b >> 4)][b & 15] > 0.f) ? (1u << b) : 0u;
+        for (int b = 0; b < 32; ++b) {
+            int one;                     // (asm: hipcc folds the C form back into compare + select)
+            asm("v_med3_i32 %0, %1, 0, 1" : "=v"(one) : "v"(__float_as_int(acc[2 * wd + (b >> 4)][b & 15])));
+            m |= (unsigned)one << b;
+        }
         __builtin_amdgcn_raw_buffer_store_b32(m, T, lane * 4, wd * 256, 0);
     }
 }
@@ -330,8 +338,11 @@ __device__ __forceinline__ void apply_relu_mask(const unsigned (&m)[NT / 2], f32
 #pragma unroll
     for (int it = 0; it < NT; ++it)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            acc[it][r] = ((m[it >> 1] >> ((it & 1) * 16 + r)) & 1u) ? acc[it][r] : 0.f;
+        for (int r = 0; r < 16; ++r) {
+            // sign-extended one-bit field (v_bfe_i32: 0 or -1) ANDed onto the value: two instructions, no VCC
+            const int keep = ((int)(m[it >> 1] << (31 - ((it & 1) * 16 + r)))) >> 31;
+            acc[it][r] = __int_as_float(__float_as_int(acc[it][r]) & keep);
+        }
 }
 
 template <int NT>
