@@ -66,30 +66,38 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
 #pragma unroll
         for (int p = 0; p < KP1; ++p)
             B1[p] = bload1(RX, xvoff, 2 * p * 128 + ((2 * p < D.cw) ? coff : 0));
-        f32x16 cur[HT];
-        load_bias<HT>(W, (int)L.off_bf[0] * 4, cur, lane);
-        layer_from_regs<KP1, HT>(W, (int)L.off_wf[0] * 4, B1, cur, lane);
-        relu_tiles<HT>(cur);
-        if (A.save) {
-            store_tiles<HT>(make_rsrc(A.H[0] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
-            store_relu_mask<HT>(make_rsrc(A.M[0] + (size_t)t * (MBYTES / 4), MBYTES), cur, lane);
-        }
-#pragma unroll
-        for (int l = 1; l < NHID; ++l) {
-            f32x16 nxt[HT];
-            load_bias<HT>(W, (int)L.off_bf[l] * 4, nxt, lane);
-            layer_from_acc<HT, HT>(W, (int)L.off_wf[l] * 4, cur, nxt, lane);
-            relu_tiles<HT>(nxt);
-            if (A.save) {
-                store_tiles<HT>(make_rsrc(A.H[l] + (size_t)t * (HBYTES / 4), HBYTES), nxt, lane);
-                store_relu_mask<HT>(make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), nxt, lane);
-            }
-#pragma unroll
-            for (int it = 0; it < HT; ++it) cur[it] = nxt[it];
-        }
+        // Two accumulator sets used alternately: set (l & 1) receives layer l.  The bias and the first weight
+        // group of layer l+1 are requested right after the last MFMA of layer l, before its epilogue (see
+        // stream_prefetch): the other set is dead at that point (it was layer l's input).
+        f32x16 acc2[2][HT];
+        load_bias<HT>(W, (int)L.off_bf[0] * 4, acc2[0], lane);
+        StreamPre pre = stream_prefetch<HT * (KP1 / 4)>(W, (int)L.off_wf[0] * 4, lane);
+        stream_layer_pre<KP1 / 4, HT>(W, (int)L.off_wf[0] * 4, pre, [&](int k) { return B1[k]; }, acc2[0], lane);
         f32x16 out[1];
-        load_bias<1>(W, (int)L.off_bf[NHID] * 4, out, lane);
-        layer_from_acc<HT, 1>(W, (int)L.off_wf[NHID] * 4, cur, out, lane);
+#pragma unroll
+        for (int l = 0; l < NHID; ++l) {
+            f32x16 (&cur)[HT] = acc2[l & 1];
+            f32x16 (&nxt)[HT] = acc2[(l + 1) & 1];
+            if (l + 1 < NHID) {
+                load_bias<HT>(W, (int)L.off_bf[l + 1] * 4, nxt, lane);
+                pre = stream_prefetch<HT * HT * 4>(W, (int)L.off_wf[l + 1] * 4, lane);
+            } else {
+                load_bias<1>(W, (int)L.off_bf[NHID] * 4, out, lane);
+                pre = stream_prefetch<HT * 4>(W, (int)L.off_wf[NHID] * 4, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);            // keep the requests in front of the epilogue's stores
+            relu_tiles<HT>(cur);
+            if (A.save) {
+                store_tiles<HT>(make_rsrc(A.H[l] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
+                store_relu_mask<HT>(make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), cur, lane);
+            }
+            if (l + 1 < NHID)
+                stream_layer_pre<HT * 4, HT>(W, (int)L.off_wf[l + 1] * 4, pre,
+                                             [&](int k) { return cur[k >> 4][k & 15]; }, nxt, lane);
+            else
+                stream_layer_pre<HT * 4, 1>(W, (int)L.off_wf[NHID] * 4, pre,
+                                            [&](int k) { return cur[k >> 4][k & 15]; }, out, lane);
+        }
         // output rows 0-3 live in lanes 0-31 (regs 0-3), rows 4-7 in lanes 32-63 (regs 0-3)
         float *z = A.zout + (size_t)t * D.zrows * 32 + s;
         if (D.zrows == 8) {

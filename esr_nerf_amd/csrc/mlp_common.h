@@ -249,6 +249,52 @@ __device__ __forceinline__ void layer_from_acc(rsrc_t W, int woff, const f32x16 
     stream_layer<NP * 4, NT>(W, woff, [&](int k) { return prev[k >> 4][k & 15]; }, acc, lane);
 }
 
+// The same stream with its FIRST group of weight quads already in registers (`pre`, issued by stream_prefetch).  The
+// forward kernel issues that group -- and the next layer's bias -- right after the last MFMA of the previous layer,
+// BEFORE that layer's epilogue (ReLU, mask words, ~100 stores): the L2 round trips run under the epilogue instead of
+// after it, and because the loads are then OLDER than the epilogue's stores the counted vmcnt wait in front of the
+// first MFMA does not drain those stores (vmcnt retires in order and counts stores on gfx950).
+constexpr int STREAM_G = 4;
+struct StreamPre { float4 q[STREAM_G]; };
+template <int NTOT>
+__device__ __forceinline__ StreamPre stream_prefetch(rsrc_t W, int woff, int lane)
+{
+    StreamPre P;
+#pragma unroll
+    for (int i = 0; i < STREAM_G; ++i) P.q[i] = (i < NTOT) ? bload4(W, lane * 16, woff + i * 1024) : make_float4(0.f, 0.f, 0.f, 0.f);
+    return P;
+}
+template <int KP4, int NT, typename BF>
+__device__ __forceinline__ void stream_layer_pre(rsrc_t W, int woff, const StreamPre &pre, BF bget, f32x16 (&acc)[NT], int lane)
+{
+    constexpr int NTOT = NT * KP4, G = STREAM_G, NG = (NTOT + G - 1) / G;
+    const int voff = lane * 16;
+    float4 buf[2][G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) buf[0][i] = pre.q[i];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int n = (g + 1) * G + i;
+            if (n < NTOT) buf[(g + 1) & 1][i] = bload4(W, voff, woff + n * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int n = g * G + i;
+            if (n < NTOT) {
+                const int it = n / KP4, q = n % KP4;
+                const float4 a = buf[g & 1][i];
+                acc[it] = mfma32(a.x, bget(4 * q + 0), acc[it]);
+                acc[it] = mfma32(a.y, bget(4 * q + 1), acc[it]);
+                acc[it] = mfma32(a.z, bget(4 * q + 2), acc[it]);
+                acc[it] = mfma32(a.w, bget(4 * q + 3), acc[it]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // bias (packed in accumulator order at byte offset boff)
 template <int NT>
 __device__ __forceinline__ void load_bias(rsrc_t W, int boff, f32x16 (&acc)[NT], int lane)
