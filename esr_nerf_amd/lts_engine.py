@@ -94,8 +94,12 @@ class _PointDraw:
     ctypes (no GIL).  The global state is checked out here and written back in ``result()``: nothing else may draw
     from ``np.random`` in between (nothing on this path does)."""
 
+    _pool = None           # one persistent worker: creating a thread per step costs ~0.1 ms of host time
+
     def __init__(self, n: int, k: int):
-        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        if _PointDraw._pool is None:
+            _PointDraw._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="esr-point-draw")
         st = np.random.get_state()
         if st[0] != "MT19937":
             raise RuntimeError("numpy's global generator is not the legacy MT19937")
@@ -109,11 +113,10 @@ class _PointDraw:
         def run():
             self._rc = L.esr_host_choice_noreplace(self._key.ctypes.data_as(C.c_void_p), C.byref(self._pos),
                                                    C.c_int64(n), C.c_int64(k), self._out.ctypes.data_as(C.c_void_p))
-        self._th = threading.Thread(target=run)
-        self._th.start()
+        self._fut = _PointDraw._pool.submit(run)
 
     def result(self) -> torch.Tensor:
-        self._th.join()
+        self._fut.result()
         _lib.check(self._rc, "esr_host_choice_noreplace")
         np.random.set_state((self._st[0], self._key, int(self._pos.value), self._st[3], self._st[4]))
         return torch.from_numpy(self._out)
