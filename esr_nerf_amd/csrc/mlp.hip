@@ -33,6 +33,12 @@
 
 #include "mlp_common.h"
 
+// In-kernel time stamps: nothing in the product build; tools/ubench/fwd_stamps.hip defines ESR_STAMP before including
+// this file to record s_memtime at the layer seams of one traced wave per SIMD.
+#ifndef ESR_STAMP
+#define ESR_STAMP(i)
+#endif
+
 namespace {
 
 struct FwdArgs {
@@ -62,6 +68,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
         const rsrc_t RX = make_rsrc(A.X + (size_t)t * D.xrows * 32, D.xrows * 32 * 4);
         const int xvoff = (h * 32 + s) * 4;
         const int coff = A.crow * 128;
+        ESR_STAMP(0);
         float B1[KP1];
 #pragma unroll
         for (int p = 0; p < KP1; ++p)
@@ -73,6 +80,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
         load_bias<HT>(W, (int)L.off_bf[0] * 4, acc2[0], lane);
         StreamPre pre = stream_prefetch<HT * (KP1 / 4)>(W, (int)L.off_wf[0] * 4, lane);
         stream_layer_pre<KP1 / 4, HT>(W, (int)L.off_wf[0] * 4, pre, [&](int k) { return B1[k]; }, acc2[0], lane);
+        ESR_STAMP(1);
         f32x16 out[1];
 #pragma unroll
         for (int l = 0; l < NHID; ++l) {
@@ -86,17 +94,21 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
                 pre = stream_prefetch<HT * 4>(W, (int)L.off_wf[NHID] * 4, lane);
             }
             __builtin_amdgcn_sched_barrier(0);            // keep the requests in front of the epilogue's stores
+            __builtin_amdgcn_s_setprio(3);                // (see the note on wave priorities above the kernel)
             relu_tiles<HT>(cur);
             if (A.save) {
                 store_tiles<HT>(make_rsrc(A.H[l] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
                 store_relu_mask<HT>(make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), cur, lane);
             }
+            __builtin_amdgcn_s_setprio(0);
+            ESR_STAMP(2 + 2 * l);
             if (l + 1 < NHID)
                 stream_layer_pre<HT * 4, HT>(W, (int)L.off_wf[l + 1] * 4, pre,
                                              [&](int k) { return cur[k >> 4][k & 15]; }, nxt, lane);
             else
                 stream_layer_pre<HT * 4, 1>(W, (int)L.off_wf[NHID] * 4, pre,
                                             [&](int k) { return cur[k >> 4][k & 15]; }, out, lane);
+            ESR_STAMP(3 + 2 * l);
         }
         // output rows 0-3 live in lanes 0-31 (regs 0-3), rows 4-7 in lanes 32-63 (regs 0-3)
         float *z = A.zout + (size_t)t * D.zrows * 32 + s;
@@ -142,15 +154,19 @@ __global__ void __launch_bounds__(256, 2) mlp_dgrad_kernel(DgradArgs A)
         f32x16 cur[HT];
         zero_tiles<HT>(cur);
         layer_from_regs<4, HT>(W, (int)L.off_wb[NHID] * 4, B0, cur, lane);
+        __builtin_amdgcn_s_setprio(3);
         apply_relu_mask<HT>(msk[NHID - 1], cur);
         store_tiles<HT>(make_rsrc(A.dZ[NHID - 1] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
+        __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int l = NHID - 1; l >= 1; --l) {
             f32x16 nxt[HT];
             zero_tiles<HT>(nxt);
             layer_from_acc<HT, HT>(W, (int)L.off_wb[l] * 4, cur, nxt, lane);
+            __builtin_amdgcn_s_setprio(3);
             apply_relu_mask<HT>(msk[l - 1], nxt);
             store_tiles<HT>(make_rsrc(A.dZ[l - 1] + (size_t)t * (HBYTES / 4), HBYTES), nxt, lane);
+            __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int it = 0; it < HT; ++it) cur[it] = nxt[it];
         }
