@@ -1,0 +1,83 @@
+"""The pieces around the renderer working together as the fine-stage trainer's loop (app/fine/fine.py:346-403):
+BatchSampler -> FineStep (forward, loss, backward) -> every third step the TV lines -> fused Adam; the loss goes down,
+and a run resumed from a reference-layout checkpoint (renderer record, optimizer state, sampler position) continues
+exactly where the uninterrupted run went."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from esr_nerf_amd.config import AttrDict, fine_cfg
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ["rays_o", "rays_d", "viewdirs", "em_modes", "rgbs"]
+LRS = dict(off_color=0.1, off_rgbnet=0.003, emo_color=0.1, emo_rgbnet=0.003, sdf=0.005, tonemapper=0.003)
+TVS = dict(sdf=0.1, smooth_grad=0.05)
+
+
+def _fresh():
+    from esr_nerf_amd.synthetic import init_slab_model, slab_scene
+    from esr_nerf_amd.voxurff import VoxurfF
+    sc = slab_scene("small", s_val=40.0, oblique=True, n_rays=2048, seed=3)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    m = VoxurfF(fine_cfg("cuda:0"), sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max, sc.mask_alpha_init,
+                sc.mask_density, sc.s_val, sc.num_voxels)
+    init_slab_model(m, sc)
+    m.set_nonempty_mask()
+    m.train()
+    return m, sc
+
+
+def _loop(m, sampler, opt, first_step, n_steps, losses):
+    from esr_nerf_amd.trainer import FineStep
+    step = FineStep(m)
+    for it in range(first_step, first_step + n_steps):
+        batch = sampler.sample()
+        loss, grads = step.forward_loss_backward(batch, 40.0)
+        if it % 3 == 0:                                             # do_tv (fine.py:383-400)
+            step.add_regularisers(loss, grads, batch["rgbs"].shape[0], 0.01, TVS, True)
+        step.assign_grads(grads)
+        opt.step()
+        losses.append(float(loss))
+
+
+def test_training_loop_learns_and_resumes_from_a_checkpoint(tmp_path):
+    from esr_nerf_amd import checkpoint as ck
+    from esr_nerf_amd.data import BatchSampler
+    from esr_nerf_amd.optimizer import create_optimizer_or_freeze_model
+    from esr_nerf_amd.voxurff import VoxurfF
+    cfg_sys = AttrDict(system=dict(device="cuda:0", data_preload="cuda"))
+
+    # uninterrupted: 12 + 6 steps
+    m, sc = _fresh()
+    torch.manual_seed(7)
+    sampler = BatchSampler(cfg_sys, dict(sc.batch), KEYS, 512)
+    sampler.shuffle()
+    opt = create_optimizer_or_freeze_model(m, **LRS)
+    losses = []
+    _loop(m, sampler, opt, 0, 12, losses)
+    p = str(tmp_path / "last.ckpt")
+    ck.save_checkpoint(p, m, 11, sampler=sampler, optimizer=opt)
+    rng = torch.get_rng_state(), torch.cuda.get_rng_state()
+    _loop(m, sampler, opt, 12, 6, losses)
+    assert np.mean(losses[-4:]) < 0.97 * np.mean(losses[:4]), losses         # it learns (random targets: slow memorisation)
+    assert all(np.isfinite(losses))
+    want = {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    # resumed from the file (fine.py:215-262): renderer, optimizer state, sampler position
+    z = ck.load_checkpoint(p, "cuda:0")
+    m2 = ck.build_renderer(VoxurfF, fine_cfg("cuda:0"), z["renderer"], "cuda:0")
+    m2.set_nonempty_mask()
+    m2.train()
+    opt2 = create_optimizer_or_freeze_model(m2, **LRS)
+    opt2.load_state_dict(z["trainer"]["optimizer"])
+    sampler2 = BatchSampler(cfg_sys, dict(sc.batch), KEYS, 512, z["trainer"]["batch_st"], z["trainer"]["data_idxs"])
+    torch.set_rng_state(rng[0]); torch.cuda.set_rng_state(rng[1])
+    losses2 = []
+    _loop(m2, sampler2, opt2, z["trainer"]["global_step"] + 1, 6, losses2)
+    for a, b in zip(losses[12:], losses2):
+        assert abs(a - b) < 1e-4 * max(abs(a), 1e-3), (losses[12:], losses2)
+    for k, v in m2.state_dict().items():
+        assert rel_err(v, want[k]) < 1e-2, k          # float-atomic ordering noise, amplified by Adam where v ~ 0 (step = lr * sign)
