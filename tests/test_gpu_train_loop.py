@@ -81,3 +81,45 @@ def test_training_loop_learns_and_resumes_from_a_checkpoint(tmp_path):
         assert abs(a - b) < 1e-4 * max(abs(a), 1e-3), (losses[12:], losses2)
     for k, v in m2.state_dict().items():
         assert rel_err(v, want[k]) < 1e-2, k          # float-atomic ordering noise, amplified by Adam where v ~ 0 (step = lr * sign)
+
+
+def test_pdra_loop_with_ray_groups():
+    """pdra.py's loop shape: RayGroupManager batches (uncertain + certain rays, `uncert_masks`) through LtsStep in pdra
+    mode with the fused optimizer; a regrouping (`filter`) in the middle.  Finite losses, parameters move."""
+    from esr_nerf_amd.config import lts_cfg
+    from esr_nerf_amd.data import RayGroupManager
+    from esr_nerf_amd.esrnerf import ESRNeRF
+    from esr_nerf_amd.optimizer import create_optimizer_or_freeze_model
+    from esr_nerf_amd.synthetic import init_slab_model, slab_scene
+    from esr_nerf_amd.trainer import LtsStep
+    sc = slab_scene("small", s_val=60.0, oblique=True, n_rays=1536, seed=4)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cfg = lts_cfg("cuda:0", num_2ndrays=16, num_ltspts=24)
+    m = ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max, sc.mask_alpha_init,
+                sc.mask_density, sc.s_val, sc.num_voxels)
+    init_slab_model(m, sc, seed=1)
+    with torch.no_grad():
+        m.brdf.grid.normal_(0.0, 0.1)
+    m.train()
+    m.pdra_mode = True
+    cfg_sys = AttrDict(system=dict(device="cuda:0", data_preload="cuda"))
+    torch.manual_seed(5)
+    groups = RayGroupManager(cfg_sys, dict(sc.batch), KEYS, 256, 128)
+    groups.filter(torch.arange(1536, device="cuda:0") % 3 != 0)          # a third of the rays start out certain
+    groups.shuffle()
+    opt = create_optimizer_or_freeze_model(m, **dict(LRS, brdf=0.1, brdfnet=0.003, emitnet=0.003, envmap=0.003))
+    step = LtsStep(m, cfg.app.trainer, stage="pdra")
+    before = m.emitnet.brdfnet[0].weight.detach().clone()
+    for it in range(5):
+        if it == 3:
+            groups.filter(torch.rand(groups.uncert_data_num, device="cuda:0") < 0.8)
+            groups.shuffle()
+        batch = groups.sample()
+        assert int(batch["uncert_masks"].sum()) == 256 and batch["uncert_masks"].numel() == 384
+        loss, grads, _ = step.forward_loss_backward(batch, 60.0)
+        step.assign_grads(grads)
+        opt.step()
+        assert np.isfinite(float(loss))
+    assert float((m.emitnet.brdfnet[0].weight.detach() - before).abs().max()) > 0
+    assert groups.stats()["total"] == 1536
