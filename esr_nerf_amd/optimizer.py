@@ -5,11 +5,16 @@ HIP kernel per parameter tensor (``esr_adam_step``) instead of ~10 dense torch p
 Same state layout as the reference (``state[p] = {"step", "exp_avg", "exp_avg_sq"}``) so checkpoints of the
 optimizer interchange.  amsgrad is not provided (the reference never enables it).  Parameters stored
 channels-last (colour grids) are updated in their storage order -- Adam is elementwise, any consistent
-order gives the same values.
+order gives the same values; moments restored from a reference checkpoint arrive contiguous
+(``Optimizer.load_state_dict`` keeps the loaded strides) and are brought into the parameter's order first.
+
+``CosineLR`` is the trainers' learning-rate schedule (optimizer.py:231-275): warm-up then half cosine, handed
+out as the multiplicative step-to-step factor the trainers apply to every group's lr.
 """
 from __future__ import annotations
 
 import ctypes as C
+import math
 
 import torch
 import torch.nn as nn
@@ -36,6 +41,18 @@ def create_optimizer_or_freeze_model(model: nn.Module, **lrates: float):
     return Adam(groups, betas=(0.9, 0.99))
 
 
+def _same_layout(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """Equal strides over the dimensions that have more than one element (a size-1 dimension's stride is free)."""
+    return a.shape == b.shape and all(sa == sb for n, sa, sb in zip(a.shape, a.stride(), b.stride()) if n > 1)
+
+
+def _like_param(p: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    """``src`` re-stored in the memory order of ``p`` (no copy when it already is)."""
+    if _same_layout(src, p) and src.dtype == p.dtype and src.device == p.device:
+        return src
+    return torch.empty_like(p, memory_format=torch.preserve_format).copy_(src)
+
+
 def _flat_storage(t: torch.Tensor) -> torch.Tensor:
     """1-D view over the tensor's memory (dense in SOME dimension order: contiguous or channels-last)."""
     if t.is_contiguous():
@@ -53,12 +70,34 @@ class Adam(torch.optim.Optimizer):
                 or not 0.0 <= weight_decay:
             raise ValueError("invalid Adam hyper-parameter")
         self.per_lr = None
+        self._per_lr_for = {}            # id(param) -> per_lr in that parameter's storage order (built once)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
         self.name2pg = {pg["name"]: pg for pg in self.param_groups if "name" in pg}
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        for group in self.param_groups:
+            group.setdefault("amsgrad", False)
+        self.__dict__.setdefault("per_lr", None)
+        self._per_lr_for = {}
 
     def set_pervoxel_lr(self, count):
         assert self.param_groups[0]["params"][0].shape == count.shape
         self.per_lr = count.float() / count.max()
+        self._per_lr_for = {}
+
+    def load_state_dict(self, state_dict):
+        """torch keeps the strides of the LOADED moments; a checkpoint written by the reference (fine.py:254-255)
+        holds them contiguous while the colour grids live channels-last here.  Bring both moments into each
+        parameter's storage order so the flat views of step() pair element i of p, g, m and v."""
+        super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st:
+                    for k in ("exp_avg", "exp_avg_sq"):
+                        if k in st:
+                            st[k] = _like_param(p, st[k])
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -79,13 +118,17 @@ class Adam(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                else:                                   # state injected without load_state_dict (tests, hand-made resumes)
+                    for k in ("exp_avg", "exp_avg_sq"):
+                        if not _same_layout(st[k], p):
+                            st[k] = _like_param(p, st[k])
                 st["step"] += 1
-                g = p.grad
-                if g.stride() != p.stride():            # bring the gradient into the parameter's storage order
-                    g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
+                g = _like_param(p, p.grad)              # the gradient in the parameter's storage order (usually a no-op)
                 plr = None
                 if self.per_lr is not None and p.shape == self.per_lr.shape:
-                    plr = torch.empty_like(p, memory_format=torch.preserve_format).copy_(self.per_lr)
+                    plr = self._per_lr_for.get(id(p))
+                    if plr is None:
+                        plr = self._per_lr_for[id(p)] = _like_param(p, self.per_lr.to(device=p.device, dtype=p.dtype))
                 pf, gf, mf, vf = _flat_storage(p), _flat_storage(g), _flat_storage(st["exp_avg"]), _flat_storage(st["exp_avg_sq"])
                 rc = L.esr_adam_step(_lib.ptr(pf), _lib.ptr(gf), _lib.ptr(mf), _lib.ptr(vf),
                                      _lib.ptr(_flat_storage(plr)) if plr is not None else None,
@@ -94,3 +137,41 @@ class Adam(torch.optim.Optimizer):
                                      _lib.stream_ptr(p.device))
                 _lib.check(rc, "esr_adam_step")
         return loss
+
+
+class CosineLR:
+    """optimizer.py:231-275.  ``ratio(i)``: linear warm-up from ``warm_up_min_ratio`` to 1 over ``warm_up_iters``
+    steps (held at the minimum with ``const_warm_up``), then a half cosine from 1 down to ``cos_min_ratio`` at
+    ``n_iters``; ``warm_up_iters == -1`` means "warm up for the whole run".  The trainers multiply every group's lr
+    by ``decay_factor`` once per step (fine.py:410-415): the ratio of this step's schedule value to the previous
+    step's, which is what reading the property returns (and advances).  A run resumed at ``cur_step`` continues the
+    same sequence of factors."""
+
+    def __init__(self, cfg, cur_step: int = 0):
+        tr = cfg.app.trainer
+        self.cfg = cfg
+        self.cur_step = cur_step
+        self.n_iters = tr.n_iters
+        self.warm_up_iters = tr.n_iters if tr.warm_up_iters == -1 else tr.warm_up_iters
+        self.warm_up_min_ratio = tr.warm_up_min_ratio
+        self.const_warm_up = tr.const_warm_up
+        self.cos_min_ratio = tr.cos_min_ratio
+        self.pre_decay_factor = 1.0 if cur_step == 0 else self.cosine_lr_func(cur_step - 1)
+        self.pos_decay_factor = self.cosine_lr_func(cur_step)
+
+    def cosine_lr_func(self, iter: int) -> float:
+        w = self.warm_up_iters
+        if iter < w:
+            if self.const_warm_up:
+                return self.warm_up_min_ratio
+            return self.warm_up_min_ratio + (1 - self.warm_up_min_ratio) * (iter / w)
+        phase = (iter - w) / (self.n_iters - w) * math.pi
+        return (1 + math.cos(phase)) * 0.5 * (1 - self.cos_min_ratio) + self.cos_min_ratio
+
+    @property
+    def decay_factor(self) -> float:
+        now = self.cosine_lr_func(self.cur_step)
+        factor = now / self.pre_decay_factor
+        self.pre_decay_factor = now
+        self.cur_step += 1
+        return factor

@@ -40,13 +40,40 @@ class SlabScene:
     mask_density: torch.Tensor        # [1,1,32,32,32]
     mask_alpha_init: float
     s_val: float
+    mask_xyz_min: torch.Tensor = None  # box of the mask cache (fine.py:149-184 takes it from the coarse stage's alpha mask)
+    mask_xyz_max: torch.Tensor = None
     batch: Dict[str, torch.Tensor] = field(default_factory=dict)   # rays_o, rays_d, viewdirs, em_modes, rgbs
     sdf_fn: object = None
 
 
+def prune_mask(xyz_min: torch.Tensor, xyz_max: torch.Tensor, seed: int = 0):
+    """A mask cache that prunes: box strictly inside the scene box (samples between the two
+    boxes read zero padding), a smooth random density field that crosses the occupancy threshold
+    (alpha >= 1e-3  <=>  density >= 6.908 at mask_alpha_init = 1e-6) at non-grid positions, an EMPTY z-slab just in
+    front of the surface (a ray's survivors are non-contiguous steps: the NeuS neighbour rule of functions.py:80-98
+    pairs the samples either side of the gap), and a sub-threshold column (whole rays without a survivor).
+    Returns (mask_density [1,1,32,32,32], mask_xyz_min, mask_xyz_max); the model constructor max-pools the density
+    with mask_ks = 3 (module.py:95-100), so every feature is at least 5 cells wide."""
+    g = torch.Generator().manual_seed(seed + 77)
+    ext = xyz_max - xyz_min
+    lo = xyz_min + ext * torch.tensor([0.06, 0.03, 0.08])
+    hi = xyz_max - ext * torch.tensor([0.04, 0.07, 0.05])
+    coarse = 2.0 + 12.0 * torch.rand(1, 1, 5, 5, 5, generator=g)
+    dens = torch.nn.functional.interpolate(coarse, size=(32, 32, 32), mode="trilinear", align_corners=True)
+    ax = [torch.linspace(float(lo[a]), float(hi[a]), 32) for a in range(3)]
+    gx, gy, gz = torch.meshgrid(*ax, indexing="ij")
+    zh = float(xyz_max[2])
+    dens[0, 0][(gz > 0.08 * zh) & (gz < 0.48 * zh)] = 0.0                     # empty slab in front of the surface
+    dens[0, 0][((gx - 0.3) ** 2 + (gy + 0.2) ** 2) < 0.25 ** 2] = 5.0         # occupied-looking but below threshold
+    return dens.contiguous(), lo, hi
+
+
 def slab_scene(name: str = "C2", s_val: float = 20.0, seed: int = 0, n_rays: int | None = None,
-               oblique: bool = False) -> SlabScene:
+               oblique: bool = False, mask: str = "full") -> SlabScene:
     """Build inputs for one of the BASELINE configs.
+
+    ``mask="prune"`` replaces the all-occupied mask cache by ``prune_mask`` (non-uniform density, mask box strictly
+    inside the scene box).
 
     ``oblique=True`` tilts and jitters the ray directions (un-normalised ``rays_d``)
     so rays get ragged step counts and clip the box faces: the edge-case variant
@@ -71,9 +98,14 @@ def slab_scene(name: str = "C2", s_val: float = 20.0, seed: int = 0, n_rays: int
     em_modes = (torch.arange(n) % 2).long()
     rgbs = torch.rand(n, 3, generator=g)
     rgbs[::13] = 1.0                                                    # exercise the rgbs>=1 branch of the loss
+    if mask == "prune":
+        mask_density, mlo, mhi = prune_mask(xyz_min, xyz_max, seed)
+    else:
+        assert mask == "full", mask
+        mask_density, mlo, mhi = torch.full((1, 1, 32, 32, 32), 30.0), xyz_min.clone(), xyz_max.clone()
     return SlabScene(
         name=name, n_rays=n, xyz_min=xyz_min, xyz_max=xyz_max, num_voxels=num_voxels,
-        near=0.05, far=6.0, mask_density=torch.full((1, 1, 32, 32, 32), 30.0),
+        near=0.05, far=6.0, mask_density=mask_density, mask_xyz_min=mlo, mask_xyz_max=mhi,
         mask_alpha_init=1e-6, s_val=float(s_val),
         batch=dict(rays_o=rays_o.contiguous(), rays_d=rays_d.contiguous(),
                    viewdirs=viewdirs.contiguous(), em_modes=em_modes, rgbs=rgbs),

@@ -11,7 +11,7 @@ is evaluated by torch ops.
 """
 from __future__ import annotations
 
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import numpy as np
 import torch
@@ -327,18 +327,46 @@ class VoxurfF(nn.Module):
         keep = ~out_box
         return pts[keep], ray_id[keep], step_id[keep]
 
+    def sample_ray_ori(self, rays_o: torch.Tensor, rays_d: torch.Tensor, is_train: bool = False):
+        """Fixed-count sampler of the random-init set-up path (voxurff.py:505-537): every ray gets the same
+        ``N = int(|grid_shape + 1| / stepsize) + 1`` steps of ``stepsize * voxel`` starting at its box entry, with the
+        t-range clamped to [near, far] (the march sampler uses far = 1e9).  Returns (pts [N,S,3], out-of-box [N,S],
+        step lengths).  One-time data filtering, torch ops on the rays' device."""
+        n_samples = int(np.linalg.norm(np.array(self.sdf.grid.shape[2:]) + 1) / self.stepsize) + 1
+        d_safe = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
+        ta, tb = (self.xyz_max - rays_o) / d_safe, (self.xyz_min - rays_o) / d_safe
+        t_min = torch.minimum(ta, tb).amax(-1).clamp(min=self.near, max=self.far)
+        t_max = torch.maximum(ta, tb).amin(-1).clamp(min=self.near, max=self.far)
+        miss = t_max <= t_min
+        k = torch.arange(n_samples, device=rays_o.device)[None].float()
+        if is_train:
+            k = k.repeat(rays_d.shape[-2], 1)
+            k += torch.rand_like(k[:, [0]])
+        step = self.stepsize * self.voxel_size * k
+        t = t_min[..., None] + step / rays_d.norm(dim=-1, keepdim=True)
+        pts = rays_o[..., None, :] + rays_d[..., None, :] * t[..., None]
+        out = miss[..., None] | ((self.xyz_min > pts) | (pts > self.xyz_max)).any(dim=-1)
+        return pts, out, step
+
     @torch.no_grad()
     def filter_training_rays_in_maskcache_sampling(self, rays_o, rays_d, chunk_size: int):
-        """True for rays with at least one in-box sample inside the mask cache (voxurff.py:463-502,
-        the non-random-init branch; the random-init branch uses the same criterion on a fixed grid
-        of steps and is served by the same code)."""
-        hit_all = torch.zeros(len(rays_o), dtype=torch.bool, device=rays_o.device)
-        for idx in torch.arange(len(rays_o), device=rays_o.device).split(chunk_size):
-            pts, ray_id, _ = self.sample_ray(rays_o[idx], rays_d[idx])
-            hit = torch.zeros(len(idx), dtype=torch.bool, device=rays_o.device)
-            hit[ray_id[self.mask_cache(pts)]] = True
-            hit_all[idx] = hit
-        return hit_all
+        """True for rays with at least one in-box sample inside the mask cache (voxurff.py:463-502).  Two branches, as
+        in the reference: with ``sdf_random_init`` the fixed-count sampler ``sample_ray_ori`` (t-range clamped to
+        near/far), otherwise the march sampler with far = 1e9; they keep different ray sets."""
+        dev = rays_o.device
+        keep_all = torch.ones(len(rays_o), dtype=torch.bool, device=dev)
+        for idx in torch.arange(len(rays_o), device=dev).split(chunk_size):
+            if self.sdf_random_init:
+                pts, out, _ = self.sample_ray_ori(rays_o[idx], rays_d[idx])
+                inside = ~out
+                inside[inside.clone()] = self.mask_cache(pts[inside])
+                keep_all[idx] &= inside.any(-1)
+            else:
+                pts, ray_id, _ = self.sample_ray(rays_o[idx], rays_d[idx])
+                hit = torch.zeros(len(idx), dtype=torch.bool, device=dev)
+                hit[ray_id[self.mask_cache(pts)]] = True
+                keep_all[idx] = hit
+        return keep_all
 
     def extract_geometry(self, resolution: int = 512, threshold: float = 0.0, batch_size: int = 64, smooth: bool = True,
                          sigma: float = 0.5):

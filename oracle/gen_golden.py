@@ -24,7 +24,16 @@ CASES = {
     # name: (scene kwargs, s_val)
     "fine_g16_axis": (dict(name="g16", oblique=False), 20.0),
     "fine_g16_oblique": (dict(name="g16", oblique=True), 60.0),
+    # pruning mask cache (synthetic.prune_mask): M0 > M1 > M2 > M3, non-contiguous survivors
+    "fine_g16_prune_axis": (dict(name="g16", oblique=False, mask="prune"), 20.0),
+    "fine_g16_prune_oblique": (dict(name="g16", oblique=True, mask="prune"), 60.0),
+    # data.white_bg = False (the dtu configs, cfg/data/dtu.yaml): the loss adds no background term
+    "fine_g16_prune_oblique_nobg": (dict(name="g16", oblique=True, mask="prune"), 60.0),
 }
+
+
+def _sfx(mask):
+    return "" if mask == "full" else "_" + mask
 
 
 def reference_loss(ns, results, rgbs, cfg):
@@ -48,15 +57,21 @@ def main():
     ns = ref_import.load()
     cfg = fine_cfg("cpu")
 
-    torch.manual_seed(0)
-    np.random.seed(0)
-    base = slab_scene("g16")
-    model = ns.VoxurfF(cfg, base.near, base.far, base.xyz_min, base.xyz_max, base.xyz_min,
-                       base.xyz_max, base.mask_alpha_init, base.mask_density, base.s_val,
-                       base.num_voxels)
-    init_slab_model(model, base)
-    model.train()
-    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    models = {}
+    for mask in ("full", "prune"):
+        torch.manual_seed(0)
+        np.random.seed(0)
+        base = slab_scene("g16", mask=mask)
+        model = ns.VoxurfF(cfg, base.near, base.far, base.xyz_min, base.xyz_max, base.mask_xyz_min,
+                           base.mask_xyz_max, base.mask_alpha_init, base.mask_density, base.s_val,
+                           base.num_voxels)
+        init_slab_model(model, base)
+        model.train()
+        models[mask] = model
+    sd = {k: v.detach().clone() for k, v in models["full"].state_dict().items()}
+    for k, v in models["prune"].state_dict().items():
+        assert torch.equal(v, sd[k]), k            # the mask cache is not a parameter: one parameter file serves both
+    model = models["full"]
     np.savez_compressed(
         os.path.join(OUT, "fine_g16_params.npz"),
         **{k: v.numpy() for k, v in sd.items()},
@@ -91,17 +106,22 @@ def main():
     for case, (skw, s_val) in CASES.items():
         sc = slab_scene(s_val=s_val, **skw)
         b = sc.batch
+        model = models[skw.get("mask", "full")]
         model.zero_grad(set_to_none=True)
         rec.clear()
+        hook = model.mask_cache.register_forward_hook(lambda mod, a, out: rec.__setitem__("mask_keep", out.clone()))
         res = model(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"],
                     em_modes=b["em_modes"], s_val=s_val)
+        hook.remove()
         res_raw = {k: v.detach().clone() for k, v in res.items()}
         for v in res.values():
             v.retain_grad()
-        loss = reference_loss(ns, dict(res), b["rgbs"], cfg)
+        cfg_case = fine_cfg("cpu")
+        cfg_case.data.white_bg = not case.endswith("_nobg")
+        loss = reference_loss(ns, dict(res), b["rgbs"], cfg_case)
         loss.backward()
         grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
-        out = {}
+        out = {"in/white_bg": np.bool_(cfg_case.data.white_bg)}
         for k, v in b.items():
             out["in/" + k] = v.numpy()
         out["in/s_val"] = np.float32(s_val)
@@ -123,18 +143,21 @@ def main():
         out["native/a2wb/grad_weights"] = rec["a2wb_grads"][0].numpy()
         out["native/a2wb/grad_last"] = rec["a2wb_grads"][1].numpy()
         out["native/a2wb/grad"] = rec["a2wb_out"].numpy()
+        out["native/mask_keep"] = rec["mask_keep"].numpy()          # MaskCache.forward output over the M0 in-box samples
         np.savez_compressed(os.path.join(OUT, case + ".npz"), **out)
-        print(case, "loss", float(loss), "M0", len(rec["sample_out"][0]), "M2", len(rec["a2w_in"][0]),
+        print(case, "loss", float(loss), "M0", len(rec["sample_out"][0]), "M1", int(rec["mask_keep"].sum()),
+              "M2", len(rec["a2w_in"][0]),
               {k: tuple(v.shape) for k, v in res_raw.items()})
 
     ru.sample_pts_on_rays, ru.alpha2weight, ru.alpha2weight_backward = real_sample, real_a2w, real_a2w_b
-    gen_lts(ns)
-    gen_finetune(ns)
-    gen_coarse(ns)
-    gen_eval(ns)
-    gen_lts_evals(ns)
-    gen_coarse_eval(ns)
-    gen_lts_eval(ns)
+    for mask in ("full", "prune"):
+        gen_lts(ns, mask)
+        gen_finetune(ns, mask)
+        gen_coarse(ns, mask)
+        gen_eval(ns, mask)
+        gen_lts_evals(ns, mask)
+        gen_coarse_eval(ns, mask)
+        gen_lts_eval(ns, mask)
 
 
 def lts_reference_loss(ns, results, rgbs, cfg):
@@ -147,22 +170,27 @@ def lts_reference_loss(ns, results, rgbs, cfg):
     return loss
 
 
-def gen_lts(ns):
+def gen_lts(ns, mask="full"):
     """ESRNeRF.forward_training (lts and pdra mode) on the small oblique slab, with every random draw
     of the reference recorded so that restatements can be fed the same numbers."""
     from esr_nerf_amd.config import lts_cfg
     cfg = lts_cfg("cpu", num_2ndrays=8, num_ltspts=12)
-    sc = slab_scene("g16", s_val=60.0, oblique=True)
+    sc = slab_scene("g16", s_val=60.0, oblique=True, mask=mask)
     torch.manual_seed(0)
     np.random.seed(0)
-    model = ns.ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max,
+    model = ns.ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max,
                        sc.mask_alpha_init, sc.mask_density, sc.s_val, sc.num_voxels)
     init_slab_model(model, sc)
     with torch.no_grad():
         model.brdf.grid.data.copy_(torch.randn(model.brdf.grid.shape, generator=torch.Generator().manual_seed(9)) * 0.1)
     model.train()
-    np.savez_compressed(os.path.join(OUT, "lts_g16_params.npz"),
-                        **{k: v.detach().numpy() for k, v in model.state_dict().items()})
+    if mask == "full":
+        np.savez_compressed(os.path.join(OUT, "lts_g16_params.npz"),
+                            **{k: v.detach().numpy() for k, v in model.state_dict().items()})
+    else:
+        with np.load(os.path.join(OUT, "lts_g16_params.npz")) as z:
+            for k, v in model.state_dict().items():
+                assert np.array_equal(z[k], v.detach().numpy()), k     # same parameters under every mask variant
     b = dict(sc.batch)
     b["uncert_masks"] = (torch.arange(sc.n_rays) % 3 == 0)
     for mode in ("lts", "pdra"):
@@ -211,21 +239,21 @@ def gen_lts(ns):
         for k, p in model.named_parameters():
             if p.grad is not None:
                 out["grad/" + k] = p.grad.detach().numpy()
-        np.savez_compressed(os.path.join(OUT, f"lts_g16_{mode}.npz"), **out)
+        np.savez_compressed(os.path.join(OUT, f"lts_g16_{mode}{_sfx(mask)}.npz"), **out)
         print("lts", mode, "loss", float(loss), "M3", res_raw["etc/normal"].shape[0],
               "grads", sum(1 for k in out if k.startswith("grad/")))
 
 
-def gen_finetune(ns):
+def gen_finetune(ns, mask="full"):
     """ESRNeRF.forward_finetune (re-lighting fine-tune, esrnerf.py:241-484) + the loss line of
     pdra.py:1090-1093 on the same small slab; parameters = lts_g16_params.npz with emo_color perturbed after
     train(finetune=True) froze its copy emit_color (so the two grids differ, as they do during fine-tuning)."""
     from esr_nerf_amd.config import lts_cfg
     cfg = lts_cfg("cpu", num_2ndrays=8, num_ltspts=12)
-    sc = slab_scene("g16", s_val=60.0, oblique=True)
+    sc = slab_scene("g16", s_val=60.0, oblique=True, mask=mask)
     torch.manual_seed(0)
     np.random.seed(0)
-    model = ns.ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max,
+    model = ns.ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max,
                        sc.mask_alpha_init, sc.mask_density, sc.s_val, sc.num_voxels)
     init_slab_model(model, sc)
     with torch.no_grad():
@@ -283,19 +311,19 @@ def gen_finetune(ns):
     for k, p_ in model.named_parameters():
         if p_.grad is not None:
             out["grad/" + k] = p_.grad.detach().numpy()
-    np.savez_compressed(os.path.join(OUT, "lts_g16_finetune.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"lts_g16_finetune{_sfx(mask)}.npz"), **out)
     print("finetune loss", float(loss), "grads", sorted(k for k in out if k.startswith("grad/")))
 
 
-def gen_lts_evals(ns):
+def gen_lts_evals(ns, mask="full"):
     """ESRNeRF.eval_emit / eval_esp (PDRA regrouping queries, esrnerf.py:1299-1407) in eval mode on the oblique
     slab, parameters = lts_g16_params.npz, inputs = the rays of lts_g16_lts.npz."""
     from esr_nerf_amd.config import lts_cfg
     cfg = lts_cfg("cpu", num_2ndrays=8, num_ltspts=12)
-    sc = slab_scene("g16", s_val=60.0, oblique=True)
+    sc = slab_scene("g16", s_val=60.0, oblique=True, mask=mask)
     torch.manual_seed(0)
     np.random.seed(0)
-    model = ns.ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max,
+    model = ns.ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max,
                        sc.mask_alpha_init, sc.mask_density, sc.s_val, sc.num_voxels)
     init_slab_model(model, sc)
     with torch.no_grad():
@@ -309,19 +337,19 @@ def gen_lts_evals(ns):
     with torch.no_grad():
         e = model.eval_emit(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"])
         p_ = model.eval_esp(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"])
-    np.savez_compressed(os.path.join(OUT, "lts_g16_evals.npz"), **{"out/eval_emit": e.numpy(), "out/eval_esp": p_.numpy()})
+    np.savez_compressed(os.path.join(OUT, f"lts_g16_evals{_sfx(mask)}.npz"), **{"out/eval_emit": e.numpy(), "out/eval_esp": p_.numpy()})
     print("lts evals", float(e.abs().max()), float(p_.abs().max()))
 
 
-def gen_lts_eval(ns):
+def gen_lts_eval(ns, mask="full"):
     """ESRNeRF.forward_evaluate: em_modes 1 with render_pbr (per-sample light transport, scattering draws
     recorded per chunk) and em_modes 0 without; parameters = lts_g16_params.npz."""
     from esr_nerf_amd.config import lts_cfg
     cfg = lts_cfg("cpu", num_2ndrays=8, num_ltspts=12)
-    sc = slab_scene("g16", s_val=60.0, oblique=True)
+    sc = slab_scene("g16", s_val=60.0, oblique=True, mask=mask)
     torch.manual_seed(0)
     np.random.seed(0)
-    model = ns.ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max,
+    model = ns.ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max,
                        sc.mask_alpha_init, sc.mask_density, sc.s_val, sc.num_voxels)
     init_slab_model(model, sc)
     with torch.no_grad():
@@ -359,19 +387,19 @@ def gen_lts_eval(ns):
         out["out1/" + k] = v.numpy()
     for k, v in res0.items():
         out["out0/" + k] = v.numpy()
-    np.savez_compressed(os.path.join(OUT, "lts_g16_eval.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"lts_g16_eval{_sfx(mask)}.npz"), **out)
     print("lts eval: chunks", len(rec), "keys", len(res1), len(res0))
 
 
-def gen_coarse(ns):
+def gen_coarse(ns, mask="full"):
     """VoxurfC.forward_training + the loss lines of coarse.py:341-352 on the small oblique slab (A17)."""
     from esr_nerf_amd.config import coarse_cfg
     from esr_nerf_amd.synthetic import analytic_sdf
-    sc = slab_scene("g16", s_val=8.0, oblique=True)
+    sc = slab_scene("g16", s_val=8.0, oblique=True, mask=mask)
     cfg = coarse_cfg("cpu", num_voxels=sc.num_voxels)
     torch.manual_seed(0)
     np.random.seed(0)
-    model = ns.VoxurfC(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max,
+    model = ns.VoxurfC(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max,
                        sc.mask_alpha_init, sc.mask_density, 8.0)
     g = torch.Generator().manual_seed(3)
     with torch.no_grad():
@@ -379,8 +407,13 @@ def gen_coarse(ns):
         model.off_color.grid.copy_(torch.randn(model.off_color.grid.shape, generator=g) * 0.1)
         model.emo_color.grid.copy_(torch.randn(model.emo_color.grid.shape, generator=g) * 0.1)
     model.train()
-    np.savez_compressed(os.path.join(OUT, "coarse_g16_params.npz"),
-                        **{k: v.detach().numpy() for k, v in model.state_dict().items()})
+    if mask == "full":
+        np.savez_compressed(os.path.join(OUT, "coarse_g16_params.npz"),
+                            **{k: v.detach().numpy() for k, v in model.state_dict().items()})
+    else:
+        with np.load(os.path.join(OUT, "coarse_g16_params.npz")) as z:
+            for k, v in model.state_dict().items():
+                assert np.array_equal(z[k], v.detach().numpy()), k
     b = sc.batch
     for s_val in (8.0, 40.0):
         model.zero_grad(set_to_none=True)
@@ -399,19 +432,19 @@ def gen_coarse(ns):
         for k, p_ in model.named_parameters():
             if p_.grad is not None:
                 out["grad/" + k] = p_.grad.detach().numpy()
-        np.savez_compressed(os.path.join(OUT, f"coarse_g16_s{int(s_val)}.npz"), **out)
+        np.savez_compressed(os.path.join(OUT, f"coarse_g16_s{int(s_val)}{_sfx(mask)}.npz"), **out)
         print("coarse s_val", s_val, "loss", float(loss), "grads", sum(1 for k in out if k.startswith("grad/")))
 
 
-def gen_coarse_eval(ns):
+def gen_coarse_eval(ns, mask="full"):
     """VoxurfC.forward_evaluate for em_modes 0 and 1, parameters = coarse_g16_params.npz."""
     from esr_nerf_amd.config import coarse_cfg
     from esr_nerf_amd.synthetic import analytic_sdf
-    sc = slab_scene("g16", s_val=8.0, oblique=True)
+    sc = slab_scene("g16", s_val=8.0, oblique=True, mask=mask)
     cfg = coarse_cfg("cpu", num_voxels=sc.num_voxels)
     torch.manual_seed(0)
     np.random.seed(0)
-    model = ns.VoxurfC(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max,
+    model = ns.VoxurfC(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max,
                        sc.mask_alpha_init, sc.mask_density, 8.0)
     g = torch.Generator().manual_seed(3)
     with torch.no_grad():
@@ -431,18 +464,18 @@ def gen_coarse_eval(ns):
             res = model(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=em, pos_rt=q)
         for k, v in res.items():
             out[f"out{em}/{k}"] = v.numpy()
-    np.savez_compressed(os.path.join(OUT, "coarse_g16_eval.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"coarse_g16_eval{_sfx(mask)}.npz"), **out)
     print("coarse eval keys", sorted(k for k in out if k.startswith("out0/")))
 
 
-def gen_eval(ns):
+def gen_eval(ns, mask="full"):
     """VoxurfF.forward_evaluate (image rendering, voxurff.py:280-461) for em_modes 0 and 1 on the oblique slab,
     parameters = fine_g16_params.npz."""
     cfg = fine_cfg("cpu")
-    sc = slab_scene("g16", s_val=60.0, oblique=True)
+    sc = slab_scene("g16", s_val=60.0, oblique=True, mask=mask)
     torch.manual_seed(0)
     np.random.seed(0)
-    model = ns.VoxurfF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max, sc.mask_alpha_init,
+    model = ns.VoxurfF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max, sc.mask_alpha_init,
                        sc.mask_density, 60.0, sc.num_voxels)
     init_slab_model(model, sc)
     with np.load(os.path.join(OUT, "fine_g16_params.npz")) as z:
@@ -460,7 +493,7 @@ def gen_eval(ns):
             res = model(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=em, pos_rt=q)
         for k, v in res.items():
             out[f"out{em}/{k}"] = v.numpy()
-    np.savez_compressed(os.path.join(OUT, "fine_g16_eval.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"fine_g16_eval{_sfx(mask)}.npz"), **out)
     print("eval keys", sorted(k for k in out if k.startswith("out0/")))
 
 

@@ -28,10 +28,18 @@ def golden_params():
     return {k: torch.from_numpy(v) for k, v in z.items()}, meta
 
 
-@pytest.fixture(scope="session", params=["fine_g16_axis", "fine_g16_oblique"])
+@pytest.fixture(scope="session", params=["fine_g16_axis", "fine_g16_oblique", "fine_g16_prune_axis", "fine_g16_prune_oblique",
+                                        "fine_g16_prune_oblique_nobg"])
 def golden_case(request):
     z = load_npz(request.param + ".npz")
     return request.param, {k: torch.from_numpy(np.asarray(v)) for k, v in z.items()}
+
+
+def golden_scene(name, z):
+    """The slab scene a fine_g16_* fixture was generated on (oracle/gen_golden.py CASES)."""
+    from esr_nerf_amd.synthetic import slab_scene
+    return slab_scene("g16", oblique="oblique" in name, s_val=float(z["in/s_val"]),
+                      mask="prune" if "_prune" in name else "full")
 
 
 def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:

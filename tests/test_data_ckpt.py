@@ -131,7 +131,7 @@ def _cpu_model():
     sc = slab_scene("g16", s_val=20.0)
     torch.manual_seed(0)
     np.random.seed(0)
-    m = VoxurfF(fine_cfg("cpu"), sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max, sc.mask_alpha_init,
+    m = VoxurfF(fine_cfg("cpu"), sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max, sc.mask_alpha_init,
                 sc.mask_density, sc.s_val, sc.num_voxels)
     return init_slab_model(m, sc), sc
 

@@ -28,7 +28,7 @@ dist.init_process_group("gloo")
 torch.cuda.set_device(0)
 sc = slab_scene("tiny", s_val=40.0, oblique=True)
 torch.manual_seed(0); np.random.seed(0)
-m = VoxurfF(fine_cfg("cuda:0"), sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max,
+m = VoxurfF(fine_cfg("cuda:0"), sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max,
             sc.mask_alpha_init, sc.mask_density, sc.s_val, sc.num_voxels)
 init_slab_model(m, sc)
 m.train()

@@ -18,7 +18,7 @@ def _scene_and_consts(name="tiny"):
     from oracle import fine_path as fp
     sc = slab_scene(name)
     cfg = lts_cfg("cpu")
-    c = fp.make_consts(cfg.app.model, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max, sc.mask_alpha_init,
+    c = fp.make_consts(cfg.app.model, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max, sc.mask_alpha_init,
                        sc.mask_density, sc.near, sc.num_voxels)
     g = torch.Generator().manual_seed(1)
     grid = analytic_sdf(c.world_size.tolist(), sc.xyz_min, sc.xyz_max) + 0.02 * torch.randn(
@@ -170,7 +170,7 @@ def test_feat_kernels_explicit_points_straddling_the_box():
     L = _lib.lib()
     sc = slab_scene("tiny", s_val=40.0)
     cfg = lts_cfg("cpu")
-    c = fp.make_consts(cfg.app.model, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max, sc.mask_alpha_init,
+    c = fp.make_consts(cfg.app.model, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max, sc.mask_alpha_init,
                        sc.mask_density, sc.near, sc.num_voxels)
     ws = [int(v) for v in c.world_size]
     g = torch.Generator().manual_seed(5)

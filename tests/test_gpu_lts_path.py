@@ -10,6 +10,11 @@ from conftest import load_npz, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+MASKS = ["full", "prune"]     # "prune": synthetic.prune_mask -- the mask cache removes > 40 % of the in-box samples
+
+
+def sfx(mask):
+    return "" if mask == "full" else "_" + mask
 
 
 def build_lts_model(scene, **over):
@@ -18,19 +23,20 @@ def build_lts_model(scene, **over):
     torch.manual_seed(0)
     np.random.seed(0)
     cfg = lts_cfg("cuda:0", **over)
-    m = ESRNeRF(cfg, scene.near, scene.far, scene.xyz_min, scene.xyz_max, scene.xyz_min, scene.xyz_max,
+    m = ESRNeRF(cfg, scene.near, scene.far, scene.xyz_min, scene.xyz_max, scene.mask_xyz_min, scene.mask_xyz_max,
                 scene.mask_alpha_init, scene.mask_density, scene.s_val, scene.num_voxels)
     m.train()
     return m, cfg
 
 
+@pytest.mark.parametrize("mask", MASKS)
 @pytest.mark.parametrize("mode", ["lts", "pdra"])
-def test_lts_golden_reference_vectors(mode):
+def test_lts_golden_reference_vectors(mode, mask):
     from esr_nerf_amd.synthetic import slab_scene
     from oracle import lts_path as lp
-    z = {k: torch.from_numpy(np.asarray(v)) for k, v in load_npz(f"lts_g16_{mode}.npz").items()}
+    z = {k: torch.from_numpy(np.asarray(v)) for k, v in load_npz(f"lts_g16_{mode}{sfx(mask)}.npz").items()}
     sd = {k: torch.from_numpy(v) for k, v in load_npz("lts_g16_params.npz").items()}
-    sc = slab_scene("g16", s_val=60.0, oblique=True)
+    sc = slab_scene("g16", s_val=60.0, oblique=True, mask=mask)
     m, cfg = build_lts_model(sc, num_2ndrays=8, num_ltspts=12)
     m.load_state_dict({k: v.cuda() for k, v in sd.items()})
     m.pdra_mode = (mode == "pdra")
@@ -126,8 +132,9 @@ def test_lts_internal_draws_run_and_are_finite():
     assert m.engine.last_point_idx.tolist() == want.tolist()
 
 
-@pytest.mark.parametrize("mode,scene_name,n_rays,s_val", [("lts", "tiny", 96, 45.0), ("pdra", "tiny", 64, 90.0)])
-def test_lts_path_vs_oracle_linear_functional(mode, scene_name, n_rays, s_val):
+@pytest.mark.parametrize("mode,scene_name,n_rays,s_val,mask", [("lts", "tiny", 96, 45.0, "full"), ("pdra", "tiny", 64, 90.0, "full"),
+                                                                ("lts", "tiny", 160, 45.0, "prune"), ("pdra", "tiny", 128, 90.0, "prune")])
+def test_lts_path_vs_oracle_linear_functional(mode, scene_name, n_rays, s_val, mask):
     """Every result tensor and every gradient against oracle/lts_path.py on scenes other than the fixture's.
     The scalar is a fixed random LINEAR functional of all 16 results, so each backward edge of the path
     (including d/d emit_eps and d/d brdf_eps, which no golden loss exercises) is weighted and no
@@ -142,14 +149,14 @@ def test_lts_path_vs_oracle_linear_functional(mode, scene_name, n_rays, s_val):
     from oracle import fine_path as fp
     from oracle import lts_path as lp
     R, Pn = 16, 20
-    sc = slab_scene(scene_name, s_val=s_val, oblique=True, n_rays=n_rays, seed=11)
+    sc = slab_scene(scene_name, s_val=s_val, oblique=True, n_rays=n_rays, seed=11, mask=mask)
     m, cfg = build_lts_model(sc, num_2ndrays=R, num_ltspts=Pn)
     init_slab_model(m, sc, seed=4)
     with torch.no_grad():
         m.brdf.grid.normal_(0.0, 0.3, generator=None)
     m.pdra_mode = (mode == "pdra")
     ccfg = lts_cfg("cpu", num_2ndrays=R, num_ltspts=Pn)
-    c = fp.make_consts(ccfg.app.model, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max, sc.mask_alpha_init,
+    c = fp.make_consts(ccfg.app.model, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max, sc.mask_alpha_init,
                        sc.mask_density, sc.near, sc.num_voxels)
     sd = {k: v.detach().cpu().contiguous() for k, v in m.state_dict().items()}
     P = fp.params_from_state_dict(sd)
@@ -169,6 +176,10 @@ def test_lts_path_vs_oracle_linear_functional(mode, scene_name, n_rays, s_val):
            uncert_masks=b["uncert_masks"], s_val=s_val, normal_eps=tr.normal_eps, emit_eps=tr.emit_eps,
            draws={k: v.cuda() for k, v in draws.items()})
     assert m.last_counts["m3"] == m3
+    lc = m.last_counts
+    assert (lc["m0"], lc["m1"], lc["m2"], lc["m3"]) == tuple(keep["counts"])
+    if mask == "prune":
+        assert lc["m0"] > lc["m1"] > lc["m2"] > lc["m3"] and lc["m1"] < 0.7 * lc["m0"]
     bad = {}
     lo = lg = 0.0
     for k in sorted(ro):
@@ -241,13 +252,14 @@ def test_lts_step_equals_autograd_route(stage):
     assert not bad, str(bad)
 
 
-def test_finetune_golden_reference_vectors():
+@pytest.mark.parametrize("mask", MASKS)
+def test_finetune_golden_reference_vectors(mask):
     """ESRNeRF.forward_finetune (A16) on the HIP path against the reference-generated fixture: both outputs,
     the loss of pdra.py:1090-1093 and the 9 gradients (emo colour grid + emo net); nothing else gets one."""
     from esr_nerf_amd.synthetic import slab_scene
-    z = {k: torch.from_numpy(np.asarray(v)) for k, v in load_npz("lts_g16_finetune.npz").items()}
+    z = {k: torch.from_numpy(np.asarray(v)) for k, v in load_npz(f"lts_g16_finetune{sfx(mask)}.npz").items()}
     sd = {k: torch.from_numpy(v) for k, v in load_npz("lts_g16_params.npz").items()}
-    sc = slab_scene("g16", s_val=60.0, oblique=True)
+    sc = slab_scene("g16", s_val=60.0, oblique=True, mask=mask)
     m, cfg = build_lts_model(sc, num_2ndrays=8, num_ltspts=12)
     m.load_state_dict({k: v.cuda() for k, v in sd.items()})
     for p in m.parameters():
@@ -278,12 +290,13 @@ def test_finetune_golden_reference_vectors():
     assert not hasattr(m, "emit_color")
 
 
-def test_eval_emit_and_esp_golden():
+@pytest.mark.parametrize("mask", MASKS)
+def test_eval_emit_and_esp_golden(mask):
     """PDRA regrouping queries on the HIP path against the reference-generated fixture."""
     from esr_nerf_amd.synthetic import slab_scene
-    z = {k: torch.from_numpy(np.asarray(v)) for k, v in load_npz("lts_g16_evals.npz").items()}
+    z = {k: torch.from_numpy(np.asarray(v)) for k, v in load_npz(f"lts_g16_evals{sfx(mask)}.npz").items()}
     sd = {k: torch.from_numpy(v) for k, v in load_npz("lts_g16_params.npz").items()}
-    sc = slab_scene("g16", s_val=60.0, oblique=True)
+    sc = slab_scene("g16", s_val=60.0, oblique=True, mask=mask)
     m, _ = build_lts_model(sc, num_2ndrays=8, num_ltspts=12)
     m.load_state_dict({k: v.cuda() for k, v in sd.items()})
     m.s_val = 60.0
@@ -326,13 +339,14 @@ def test_lts_step_bf16_mode_tracks_fp32():
         assert bool(torch.isfinite(v).all()), k
 
 
-def test_forward_evaluate_golden():
+@pytest.mark.parametrize("mask", MASKS)
+def test_forward_evaluate_golden(mask):
     """ESRNeRF.forward_evaluate on the HIP path against the reference-generated fixture: 21 keys with render_pbr
     (recorded scattering draws, three chunks) and 16 without."""
     from esr_nerf_amd.synthetic import slab_scene
-    z = {k: torch.from_numpy(np.asarray(v)) for k, v in load_npz("lts_g16_eval.npz").items()}
+    z = {k: torch.from_numpy(np.asarray(v)) for k, v in load_npz(f"lts_g16_eval{sfx(mask)}.npz").items()}
     sd = {k: torch.from_numpy(v) for k, v in load_npz("lts_g16_params.npz").items()}
-    sc = slab_scene("g16", s_val=60.0, oblique=True)
+    sc = slab_scene("g16", s_val=60.0, oblique=True, mask=mask)
     m, _ = build_lts_model(sc, num_2ndrays=8, num_ltspts=12)
     m.load_state_dict({k: v.cuda() for k, v in sd.items()})
     m.s_val = 60.0
@@ -373,7 +387,7 @@ def test_evaluate_reads_the_frozen_emit_color_after_finetune():
     m.eval()
     assert m.emit_color is not m.emo_color
     ccfg = lts_cfg("cpu", num_2ndrays=8, num_ltspts=12)
-    c = fp.make_consts(ccfg.app.model, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max, sc.mask_alpha_init,
+    c = fp.make_consts(ccfg.app.model, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max, sc.mask_alpha_init,
                        sc.mask_density, sc.near, sc.num_voxels)
     sd2 = dict(sd)
     sd2["emo_color.grid"], sd2["emit_color.grid"] = z["param/emo_color.grid"], z["param/emit_color.grid"]

@@ -153,7 +153,7 @@ def test_smooth_gradient_tv_term_matches_torch_chain():
     sc = slab_scene("g16", s_val=20.0)
     torch.manual_seed(0)
     np.random.seed(0)
-    m = VoxurfF(fine_cfg("cuda:0"), sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max,
+    m = VoxurfF(fine_cfg("cuda:0"), sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max,
                 sc.mask_alpha_init, sc.mask_density, sc.s_val, sc.num_voxels)
     init_slab_model(m, sc)
     with torch.no_grad():

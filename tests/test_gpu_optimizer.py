@@ -62,7 +62,7 @@ def test_short_training_run_reduces_loss_and_tracks_torch_adam():
     def build():
         torch.manual_seed(0)
         np.random.seed(0)
-        m = VoxurfF(fine_cfg("cuda:0"), sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max,
+        m = VoxurfF(fine_cfg("cuda:0"), sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max,
                     sc.mask_alpha_init, sc.mask_density, sc.s_val, sc.num_voxels)
         init_slab_model(m, sc, seed=1)
         m.train()

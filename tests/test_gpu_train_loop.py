@@ -22,7 +22,7 @@ def _fresh():
     sc = slab_scene("small", s_val=40.0, oblique=True, n_rays=2048, seed=3)
     torch.manual_seed(0)
     np.random.seed(0)
-    m = VoxurfF(fine_cfg("cuda:0"), sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max, sc.mask_alpha_init,
+    m = VoxurfF(fine_cfg("cuda:0"), sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max, sc.mask_alpha_init,
                 sc.mask_density, sc.s_val, sc.num_voxels)
     init_slab_model(m, sc)
     m.set_nonempty_mask()
@@ -96,7 +96,7 @@ def test_pdra_loop_with_ray_groups():
     torch.manual_seed(0)
     np.random.seed(0)
     cfg = lts_cfg("cuda:0", num_2ndrays=16, num_ltspts=24)
-    m = ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max, sc.mask_alpha_init,
+    m = ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max, sc.mask_alpha_init,
                 sc.mask_density, sc.s_val, sc.num_voxels)
     init_slab_model(m, sc, seed=1)
     with torch.no_grad():

@@ -58,7 +58,7 @@ def _cpu_model(**model_over):
     cfg.app.model.update(model_over)
     torch.manual_seed(0)
     np.random.seed(0)
-    m = VoxurfF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max, sc.mask_alpha_init,
+    m = VoxurfF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max, sc.mask_alpha_init,
                 sc.mask_density, sc.s_val, sc.num_voxels)
     return init_slab_model(m, sc), sc
 
@@ -137,7 +137,7 @@ sc = slab_scene("g16", s_val=60.0, oblique=True)
 z = np.load(os.path.join(sys.argv[1], "tests", "golden", "fine_g16_params.npz"))
 sd = {k: torch.from_numpy(z[k]) for k in z.files if not k.startswith("__")}
 cfg = fine_cfg("cpu")
-c = fp.make_consts(cfg.app.model, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max, sc.mask_alpha_init,
+c = fp.make_consts(cfg.app.model, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max, sc.mask_alpha_init,
                    sc.mask_density, sc.near, sc.num_voxels)
 def grads_of(batch, scale, w_ent):
     P = fp.params_from_state_dict(sd)
@@ -224,7 +224,7 @@ def test_mesh_and_envmap_utilities():
     from oracle import lts_path as lp
     sc = slab_scene("g16")
     torch.manual_seed(0)
-    m = ESRNeRF(lts_cfg("cpu"), sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max, sc.mask_alpha_init,
+    m = ESRNeRF(lts_cfg("cpu"), sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max, sc.mask_alpha_init,
                 sc.mask_density, sc.s_val, sc.num_voxels)
     init_slab_model(m, sc)
     u = extract_sdf_field(m, resolution=9, batch_size=4, smooth=False)

@@ -14,7 +14,7 @@ s_val = float(sys.argv[2]) if len(sys.argv) > 2 else 220.0
 sc = slab_scene("C2", s_val=s_val, n_rays=n_rays)
 torch.manual_seed(0); np.random.seed(0)
 cfg = lts_cfg("cuda:0")
-m = ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.xyz_min, sc.xyz_max, sc.mask_alpha_init,
+m = ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max, sc.mask_alpha_init,
             sc.mask_density, sc.s_val, sc.num_voxels)
 m.train()
 init_slab_model(m, sc, seed=1)
