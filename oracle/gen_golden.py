@@ -150,6 +150,7 @@ def main():
               {k: tuple(v.shape) for k, v in res_raw.items()})
 
     ru.sample_pts_on_rays, ru.alpha2weight, ru.alpha2weight_backward = real_sample, real_a2w, real_a2w_b
+    gen_host(ns)
     for mask in ("full", "prune"):
         gen_lts(ns, mask)
         gen_finetune(ns, mask)
@@ -158,6 +159,125 @@ def main():
         gen_lts_evals(ns, mask)
         gen_coarse_eval(ns, mask)
         gen_lts_eval(ns, mask)
+
+
+def gen_host(ns):
+    """Reference-pinned fixtures for the rows around the renderer: the imported
+    app/utils/optimizer.py (Adam incl. per-voxel lr and CosineLR decay, 10 steps), and the imported VoxurfF's
+    density_total_variation (+ autograd gradient), sdf_total_variation_add_grad, scale_volume_grid and
+    filter_training_rays_in_maskcache_sampling in both sdf_random_init branches."""
+    from esr_nerf_amd.config import AttrDict
+    opt_mod = ns.optimizer
+    out = {}
+    # ---- CosineLR: factor sequences for the trainers' settings and the branches of cosine_lr_func
+    sched = {"fine": dict(n_iters=200, warm_up_iters=20, warm_up_min_ratio=0.1, const_warm_up=False, cos_min_ratio=0.05),
+             "const": dict(n_iters=120, warm_up_iters=30, warm_up_min_ratio=0.3, const_warm_up=True, cos_min_ratio=0.2),
+             "allwarm": dict(n_iters=64, warm_up_iters=-1, warm_up_min_ratio=0.5, const_warm_up=False, cos_min_ratio=0.0)}
+    for name, tr in sched.items():
+        for start in (0, 37):
+            c = opt_mod.CosineLR(AttrDict(app=dict(trainer=tr)), cur_step=start)
+            out[f"cos/{name}/{start}"] = np.array([c.decay_factor for _ in range(tr["n_iters"] - start)], np.float64)
+        out[f"cos/{name}/cfg"] = np.array([tr["n_iters"], tr["warm_up_iters"], tr["warm_up_min_ratio"],
+                                           float(tr["const_warm_up"]), tr["cos_min_ratio"]], np.float64)
+    # ---- Adam: three groups, the first (a 1-channel grid) with a per-voxel lr; lr decayed by CosineLR every step
+    g = torch.Generator().manual_seed(31)
+    shapes = {"grid1": (1, 1, 6, 5, 4), "grid6": (1, 6, 6, 5, 4), "w": (7, 5)}
+    lrs = {"grid1": 0.1, "grid6": 0.05, "w": 0.003}
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            for k, shp in shapes.items():
+                setattr(self, k, torch.nn.Parameter(torch.randn(shp, generator=torch.Generator().manual_seed(len(k))) * 0.3))
+
+    torch.manual_seed(0)
+    m = Holder()
+    for k in shapes:
+        out[f"adam/p0/{k}"] = getattr(m, k).detach().numpy().copy()
+    opt = opt_mod.create_optimizer_or_freeze_model(m, **lrs)
+    count = torch.randint(0, 9, shapes["grid1"], generator=g)
+    opt.set_pervoxel_lr(count)
+    out["adam/count"] = count.numpy()
+    cos = opt_mod.CosineLR(AttrDict(app=dict(trainer=sched["fine"])), cur_step=0)
+    for step in range(10):
+        for k in shapes:
+            gr = torch.randn(shapes[k], generator=g) * (0.5 if step % 3 else 2.0)
+            if k == "grid6" and step == 4:
+                gr.zero_()                                           # an all-zero gradient step
+            getattr(m, k).grad = gr
+            out[f"adam/g{step}/{k}"] = gr.numpy().copy()
+        opt.step()
+        f = cos.decay_factor
+        for pg in opt.param_groups:
+            pg["lr"] = pg["lr"] * f
+        for k in shapes:
+            out[f"adam/p{step + 1}/{k}"] = getattr(m, k).detach().numpy().copy()
+    for k in shapes:
+        st = opt.state[getattr(m, k)]
+        out[f"adam/m/{k}"], out[f"adam/v/{k}"] = st["exp_avg"].numpy().copy(), st["exp_avg_sq"].numpy().copy()
+    out["adam/lr_final"] = np.array([pg["lr"] for pg in opt.param_groups], np.float64)
+    np.savez_compressed(os.path.join(OUT, "host_optimizer.npz"), **out)
+    print("host optimizer fixture:", len(out), "arrays")
+
+    # ---- dense-grid rows on a small prune-mask scene
+    cfg = fine_cfg("cpu")
+    sc = slab_scene("g16", mask="prune")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = ns.VoxurfF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max,
+                       sc.mask_alpha_init, sc.mask_density, sc.s_val, sc.num_voxels)
+    init_slab_model(model, sc)
+    with torch.no_grad():
+        model.sdf.grid.add_(torch.randn(model.sdf.grid.shape, generator=torch.Generator().manual_seed(4)) * 0.02)
+    model.set_nonempty_mask()
+    model.train()
+    o = {"sdf": model.sdf.grid.detach().numpy().copy(), "nonempty_mask": model.nonempty_mask.numpy().copy()}
+    # density_total_variation (fine.py:384-393 weights): needs self.gradient as forward_training leaves it
+    model.gradient = model.neus_sdf_gradient()
+    for key, kw in (("tv_sdf", dict(sdf_tv=0.1)), ("tv_smooth", dict(smooth_grad_tv=0.05)), ("tv_both", dict(sdf_tv=0.1, smooth_grad_tv=0.05))):
+        model.zero_grad(set_to_none=True)
+        model.gradient = model.neus_sdf_gradient()
+        tv = model.density_total_variation(**kw)
+        tv.backward()
+        o[key + "/value"] = tv.detach().numpy()
+        o[key + "/grad_sdf"] = model.sdf.grid.grad.numpy().copy()
+    # sdf_total_variation_add_grad (fine.py:397-401): dense and sparse mode on a half-empty gradient
+    for dense in (True, False):
+        gr = torch.randn(model.sdf.grid.shape, generator=torch.Generator().manual_seed(6)) * 1e-3
+        gr[..., ::2, :] = 0.0
+        model.sdf.grid.grad = gr.clone()
+        model.sdf_total_variation_add_grad(0.1 / 3, dense)
+        o[f"tv_add_grad/{int(dense)}/in"] = gr.numpy()
+        o[f"tv_add_grad/{int(dense)}/out"] = model.sdf.grid.grad.numpy().copy()
+    # filter_training_rays_in_maskcache_sampling, both branches, on rays that partly miss the box / the mask
+    gg = torch.Generator().manual_seed(12)
+    n = 300
+    ro = torch.cat([(torch.rand(n, 2, generator=gg) * 2 - 1) * 1.3, torch.full((n, 1), 2.0)], -1)
+    rd = torch.cat([(torch.rand(n, 2, generator=gg) * 2 - 1) * 0.4, -torch.ones(n, 1)], -1) * (0.5 + torch.rand(n, 1, generator=gg))
+    rd[::19, 1] = 0.0
+    o["filter/rays_o"], o["filter/rays_d"] = ro.numpy(), rd.numpy()
+    far0 = model.far
+    model.far = 2.6          # cuts the t-range of the slow rays: only the random-init sampler clamps to far (voxurff.py:520-525)
+    o["filter/far"] = np.float32(model.far)
+    for rnd in (False, True):
+        model.sdf_random_init = rnd
+        o[f"filter/keep/{int(rnd)}"] = model.filter_training_rays_in_maskcache_sampling(ro, rd, 128).numpy()
+    model.sdf_random_init = False
+    model.far = far0
+    # scale_volume_grid: [32,32,8] -> the resolution of 4.096x the voxels (fine.yaml pg_scale)
+    model.zero_grad(set_to_none=True)
+    o["scale/off_color_in"] = model.off_color.grid.detach().numpy().copy()
+    nv = int(sc.num_voxels * 4.096)
+    model.scale_volume_grid(nv)
+    o["scale/num_voxels"] = np.int64(nv)
+    o["scale/world_size"] = model.world_size.numpy()
+    o["scale/voxel_size"] = model.voxel_size.numpy()
+    o["scale/sdf"] = model.sdf.grid.detach().numpy().copy()
+    o["scale/off_color"] = model.off_color.grid.detach().numpy().copy()
+    o["scale/nonempty_mask"] = model.nonempty_mask.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "host_dense_rows.npz"), **o)
+    print("dense rows fixture:", {k: (tuple(v.shape) if hasattr(v, "shape") else v) for k, v in o.items() if "value" in k or "keep" in k},
+          "kept", int(o["filter/keep/0"].sum()), int(o["filter/keep/1"].sum()), "world", o["scale/world_size"])
 
 
 def lts_reference_loss(ns, results, rgbs, cfg):
@@ -499,6 +619,9 @@ def gen_eval(ns, mask="full"):
 
 if __name__ == "__main__":
     import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "host":
+        gen_host(ref_import.load())
+        raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lts_eval":
         gen_lts_eval(ref_import.load())
         raise SystemExit(0)

@@ -111,13 +111,23 @@ def sg_envmap(P: Dict[str, Tensor], dirs: Tensor) -> Tensor:
     return F.softplus((P["envmap.mus"] * e).sum(-2))
 
 
-def brdf_net(P, x):
-    o = torch.sigmoid(fp.mlp(P, [f"brdfnet.{k}" for k in BRDF_KEYS], x))
+def brdf_net(P, x, knife=None):
+    o = torch.sigmoid(fp.mlp(P, [f"brdfnet.{k}" for k in BRDF_KEYS], x, knife))
     return o[:, 0:3], o[:, 3:4], o[:, 4:5]
 
 
-def emit_net(P, x):
-    return F.softplus(fp.mlp(P, [f"emitnet.{k}" for k in BRDF_KEYS], x))
+def emit_net(P, x, knife=None):
+    return F.softplus(fp.mlp(P, [f"emitnet.{k}" for k in BRDF_KEYS], x, knife))
+
+
+def _knife(keep, pts):
+    """With ``keep``: a per-row record of the smallest |hidden pre-activation| over every net evaluated on ``pts``
+    (fp.mlp), registered under keep["knife_sets"] as (positions, record) -- test bookkeeping, not arithmetic."""
+    if keep is None:
+        return None
+    k = torch.full((pts.shape[0],), float("inf"))
+    keep.setdefault("knife_sets", []).append((pts.detach(), k))
+    return k
 
 
 def _pe(c: fp.FineConsts, pts: Tensor) -> Tensor:
@@ -133,15 +143,18 @@ def _view_pe(c: fp.FineConsts, v: Tensor) -> Tensor:
     return torch.cat([e, e.sin(), e.cos()], -1)
 
 
-def _march(P, c: fp.FineConsts, rays_o, rays_d, near, s_val):
-    """sampler -> mask cache -> SDF -> alpha -> thresholds -> weights (voxurff/esrnerf common part)."""
+def _march(P, c: fp.FineConsts, rays_o, rays_d, near, s_val, counts: Optional[list] = None):
+    """sampler -> mask cache -> SDF -> alpha -> thresholds -> weights (voxurff/esrnerf common part).
+    ``counts`` (a list) receives the in-box and mask-cache survivor counts M0, M1."""
     N = rays_o.shape[0]
     stepdist = c.stepsize * c.voxel_size
-    pts, out_box, ray_id = native.sample_pts_on_rays(rays_o.contiguous(), rays_d.contiguous(), c.xyz_min,
-                                                      c.xyz_max, near, 1e9, float(stepdist))[:3]
+    pts, out_box, ray_id, step_id = native.sample_pts_on_rays(rays_o.contiguous(), rays_d.contiguous(), c.xyz_min,
+                                                               c.xyz_max, near, 1e9, float(stepdist))[:4]
     inb = ~out_box
-    pts, ray_id = pts[inb], ray_id[inb]
+    pts, ray_id, step_id = pts[inb], ray_id[inb], step_id[inb]
     m = fp.mask_cache(c, pts)
+    if counts is not None:
+        counts += [int(pts.shape[0]), int(m.sum()), step_id[m]]
     return N, pts[m], ray_id[m]
 
 
@@ -154,11 +167,14 @@ def forward_training(P: Dict[str, Tensor], c: fp.FineConsts, batch: Dict[str, Te
                      pdra_mode: bool = False, keep: Optional[dict] = None) -> Dict[str, Tensor]:
     rays_o, rays_d, viewdirs = batch["rays_o"], batch["rays_d"], batch["viewdirs"]
     em_modes, uncert = batch["em_modes"], batch["uncert_masks"]
-    N, pts, ray_id = _march(P, c, rays_o, rays_d, c.near, s_val)
+    prim_counts: list = []
+    N, pts, ray_id = _march(P, c, rays_o, rays_d, c.near, s_val, prim_counts)
+    prim_counts.pop()
     sdf, expg = sdf_expgrad(c, P["sdf.grid"], pts)
     alpha = fp.neus_alpha_interp(sdf, ray_id, s_val)
     m = alpha > c.fastcolor_thres
     alpha, pts, ray_id, sdf, expg = alpha[m], pts[m], ray_id[m], sdf[m], expg[m]
+    prim_counts.append(int(pts.shape[0]))
     weights, alphainv_last = fp._Composite.apply(alpha, ray_id, N)
     m = weights > c.fastcolor_thres
     weights, pts, ray_id, sdf, expg = weights[m], pts[m], ray_id[m], sdf[m], expg[m]
@@ -170,12 +186,16 @@ def forward_training(P: Dict[str, Tensor], c: fp.FineConsts, batch: Dict[str, Te
     common = torch.cat([xyz_pe, vpe, sdf[:, None], feat, nrm], -1)
     gpts = fp.to_norm(pts, c.xyz_min, c.xyz_max)
     lin = torch.zeros_like(pts)
-    lin[on] = fp.radiance(P, "emo_rgbnet", torch.cat([fp.sample_grid(P["emo_color.grid"], gpts[on]), common[on]], -1))
-    lin = lin + fp.radiance(P, "off_rgbnet", torch.cat([fp.sample_grid(P["off_color.grid"], gpts), common], -1))
-    rgb = fp.tonemap(P, c, lin)
+    kn = _knife(keep, pts)
+    kn_on = kn[on] if kn is not None else None
+    lin[on] = fp.radiance(P, "emo_rgbnet", torch.cat([fp.sample_grid(P["emo_color.grid"], gpts[on]), common[on]], -1), kn_on)
+    if kn is not None:
+        kn[on] = kn_on
+    lin = lin + fp.radiance(P, "off_rgbnet", torch.cat([fp.sample_grid(P["off_color.grid"], gpts), common], -1), kn)
+    rgb = fp.tonemap(P, c, lin, kn)
     bfeat = torch.cat([xyz_pe, sdf[:, None], feat, nrm], -1)
-    base, rough, metal = brdf_net(P, torch.cat([fp.sample_grid(P["brdf.grid"], gpts), bfeat], -1))
-    emit = emit_net(P, torch.cat([fp.sample_grid(P["emo_color.grid"], gpts), bfeat], -1))
+    base, rough, metal = brdf_net(P, torch.cat([fp.sample_grid(P["brdf.grid"], gpts), bfeat], -1), kn)
+    emit = emit_net(P, torch.cat([fp.sample_grid(P["emo_color.grid"], gpts), bfeat], -1), kn)
     w = weights.unsqueeze(-1)
     zeros = lambda: torch.zeros(N, 3)
     rgb_m = zeros().index_add(0, ray_id, w * rgb)
@@ -186,17 +206,18 @@ def forward_training(P: Dict[str, Tensor], c: fp.FineConsts, batch: Dict[str, Te
     idx = draws.idx
     lts = light_transport_segment(P, c, pts[idx], viewdirs[ray_id][idx], normal[idx], sdf[idx], base[idx],
                                   rough[idx], metal[idx], emit[idx], uncert[ray_id][idx], draws.dirs,
-                                  s_val, num_2ndrays, lts_near, pdra_mode)
+                                  s_val, num_2ndrays, lts_near, pdra_mode, keep=keep)
     _, expg_eps = sdf_expgrad(c, P["sdf.grid"], pts + draws.noise_normal * normal_eps)
     pts2 = pts + draws.noise_emit * emit_eps
     gp2 = fp.to_norm(pts2, c.xyz_min, c.xyz_max)
     sdf2 = fp.sample_grid(P["sdf.grid"], gp2)[:, 0]
     feat2, _, nrm2 = _stencil(c, P["sdf.grid"], pts2)
     bfeat2 = torch.cat([_pe(c, pts2), sdf2[:, None], feat2, nrm2], -1)
-    emit2 = emit_net(P, torch.cat([fp.sample_grid(P["emo_color.grid"], gp2), bfeat2], -1))
-    base2, rough2, metal2 = brdf_net(P, torch.cat([fp.sample_grid(P["brdf.grid"], gp2), bfeat2], -1))
+    kn2 = _knife(keep, pts2)
+    emit2 = emit_net(P, torch.cat([fp.sample_grid(P["emo_color.grid"], gp2), bfeat2], -1), kn2)
+    base2, rough2, metal2 = brdf_net(P, torch.cat([fp.sample_grid(P["brdf.grid"], gp2), bfeat2], -1), kn2)
     if keep is not None:
-        keep.update(m3=pts.shape[0], ray_id=ray_id, pts=pts)
+        keep.update(m3=pts.shape[0], ray_id=ray_id, pts=pts, counts=tuple(prim_counts + [int(pts.shape[0])]))
     return {
         "etc/alphainv_cum": alphainv_last, "etc/white_bg": alphainv_last[..., None],
         "srgb/rgb": rgb_m, "lin/rgb": lin_m,
@@ -209,7 +230,7 @@ def forward_training(P: Dict[str, Tensor], c: fp.FineConsts, batch: Dict[str, Te
 
 
 def light_transport_segment(P, c, pts, viewdirs, normal, sdf, base, rough, metal, emission, umask, raw_dirs,
-                            s_val, R, lts_near, pdra_mode):
+                            s_val, R, lts_near, pdra_mode, keep: Optional[dict] = None):
     """Outgoing radiance of P surface points predicted by the radiance nets ("off", "emo", for the
     camera direction and one random direction) against the rendering equation evaluated with R
     secondary rays per point ("off_hat", "emo_hat")."""
@@ -223,8 +244,9 @@ def light_transport_segment(P, c, pts, viewdirs, normal, sdf, base, rough, metal
     rep = lambda t: t.repeat([2] + [1] * (t.dim() - 1))
     common = torch.cat([rep(xyz_pe), vpe, rep(sdf[:, None]), rep(feat), rep(nrm)], -1)
     gp = fp.to_norm(pts, c.xyz_min, c.xyz_max)
-    off = fp.radiance(P, "off_rgbnet", torch.cat([rep(fp.sample_grid(P["off_color.grid"], gp)), common], -1))
-    emo = fp.radiance(P, "emo_rgbnet", torch.cat([rep(fp.sample_grid(P["emo_color.grid"], gp)), common], -1))
+    knp = _knife(keep, rep(pts))
+    off = fp.radiance(P, "off_rgbnet", torch.cat([rep(fp.sample_grid(P["off_color.grid"], gp)), common], -1), knp)
+    emo = fp.radiance(P, "emo_rgbnet", torch.cat([rep(fp.sample_grid(P["emo_color.grid"], gp)), common], -1), knp)
 
     ex = lambda t: t.view(Pn, 1, -1).expand(Pn, R, t.shape[-1]).flatten(0, 1)
     o2, v2, vr2, n2 = ex(pts), ex(viewdirs), ex(v_rand), ex(normal)
@@ -232,19 +254,26 @@ def light_transport_segment(P, c, pts, viewdirs, normal, sdf, base, rough, metal
     Rf = disney_reflection(rep(ex(base)), rep(ex(rough)), rep(ex(metal)), rep(n2), rep(d2),
                            torch.cat([-v2, -vr2], 0))
     # incoming radiance along the secondary rays
-    N2, p2, rid = _march(P, c, o2, d2, lts_near, s_val)
+    sec_counts: list = []
+    N2, p2, rid = _march(P, c, o2, d2, lts_near, s_val, sec_counts)
+    sid2 = sec_counts.pop()                                   # step ids of the mask-cache survivors (bookkeeping)
     s2 = fp.sample_grid(P["sdf.grid"], fp.to_norm(p2, c.xyz_min, c.xyz_max))[:, 0]
     a2 = fp.neus_alpha_interp(s2, rid, s_val) if s2.numel() > 1 else s2.new_zeros(s2.shape)
     m = a2 > c.fastcolor_thres
-    a2, p2, rid, s2 = a2[m], p2[m], rid[m], s2[m]
+    a2, p2, rid, s2, sid2 = a2[m], p2[m], rid[m], s2[m], sid2[m]
+    sec_counts.append(int(p2.shape[0]))
     w2, last2 = fp._Composite.apply(a2, rid, N2)
     m = w2 > c.fastcolor_thres
-    w2, p2, rid, s2 = w2[m], p2[m], rid[m], s2[m]
+    w2, p2, rid, s2, sid2 = w2[m], p2[m], rid[m], s2[m], sid2[m]
+    if keep is not None:
+        keep["sec_counts"] = tuple(sec_counts + [int(p2.shape[0])])
+        keep["sec"] = dict(ray_id=rid, step_id=sid2, weights=w2.detach(), rays_o=o2.detach(), rays_d=d2.detach())
     f2, _, nr2 = _stencil(c, P["sdf.grid"], p2)
     feat2 = torch.cat([_pe(c, p2), _view_pe(c, d2)[rid], s2[:, None], f2, nr2], -1)
     g2 = fp.to_norm(p2, c.xyz_min, c.xyz_max)
-    loff = fp.radiance(P, "off_rgbnet", torch.cat([fp.sample_grid(P["off_color.grid"], g2), feat2], -1))
-    lemo = fp.radiance(P, "emo_rgbnet", torch.cat([fp.sample_grid(P["emo_color.grid"], g2), feat2], -1))
+    kns = _knife(keep, p2)
+    loff = fp.radiance(P, "off_rgbnet", torch.cat([fp.sample_grid(P["off_color.grid"], g2), feat2], -1), kns)
+    lemo = fp.radiance(P, "emo_rgbnet", torch.cat([fp.sample_grid(P["emo_color.grid"], g2), feat2], -1), kns)
     off_m = torch.zeros(N2, 3).index_add(0, rid, w2[:, None] * loff)
     emo_m = torch.zeros(N2, 3).index_add(0, rid, w2[:, None] * lemo)
     env = sg_envmap(P, d2) * last2.unsqueeze(-1)

@@ -85,6 +85,7 @@ def load():
         pbr_module = importlib.import_module("app.utils.pbr.module")
         pbr_functions = importlib.import_module("app.utils.pbr.functions")
         image = importlib.import_module("utils2.image")
+        optimizer = importlib.import_module("app.utils.optimizer")
 
         def by_path(modname, rel):
             spec = importlib.util.spec_from_file_location(modname, os.path.join(REF_ROOT, rel))
@@ -104,7 +105,7 @@ def load():
     ns = types.SimpleNamespace(
         VoxurfF=voxurff.VoxurfF, ESRNeRF=esrnerf.ESRNeRF, VoxurfC=voxurfc.VoxurfC,
         functions=functions, module=module, pbr_module=pbr_module,
-        pbr_functions=pbr_functions, image=image,
+        pbr_functions=pbr_functions, image=image, optimizer=optimizer,
     )
     _state["ns"] = ns
     return ns

@@ -14,6 +14,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle is the checker of the GPU tests; a GPU box hands one GPU's share of its host cores (16) to this
+    # process while os.cpu_count() reports all of them -- torch's default thread count oversubscribes 8x there
+    if torch.cuda.device_count() > 0:
+        torch.set_num_threads(min(16, os.cpu_count() or 16))
 
 
 def load_npz(name):

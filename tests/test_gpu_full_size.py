@@ -1,0 +1,420 @@
+"""Every BASELINE.json GPU configuration at its FULL size under ``pytest -m gpu``:
+
+  C2  fine, 4096 rays x 128 samples, fp32   -- whole-batch oracle forward + backward, all 23 gradients
+  C3  fine, 4096 rays x 192 samples         -- fp32 with ``white_bg = False`` (the dtu half) against the whole-batch
+                                               oracle, the survivor SETS compared sample by sample, then bf16 MLPs:
+                                               PSNR against the fp32 render of the same 4096-ray image
+  C4  lts, 8192 rays + 100 x 256 secondary  -- supplied draws, exact survivor counts of the primary AND the secondary
+                                               march, 16 results, loss and all 43 gradients against the oracle
+  C5  pdra with bf16 MLPs at C4's size      -- tracks the fp32 step; the re-lighting fine-tune half at 4096 + 4096 rays
+                                               against the oracle
+
+The oracle (oracle/*.py, CPU) needs 15-60 s per configuration on the GPU box's host cores.  Tolerance 1e-4
+rel-to-max-norm for fp32 (north_star), PSNR within 0.1 dB for bf16 (BASELINE.json)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _fine_model(sc, dtype="f32"):
+    from esr_nerf_amd.config import fine_cfg
+    from esr_nerf_amd.synthetic import init_slab_model
+    from esr_nerf_amd.voxurff import VoxurfF
+    torch.manual_seed(0)
+    np.random.seed(0)
+    m = VoxurfF(fine_cfg("cuda:0"), sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max,
+                sc.mask_alpha_init, sc.mask_density, sc.s_val, sc.num_voxels)
+    init_slab_model(m, sc)
+    m.mlp_dtype = dtype
+    m.train()
+    return m
+
+
+def _fine_oracle(m, sc):
+    from esr_nerf_amd.config import fine_cfg
+    from oracle import fine_path as fp
+    c = fp.make_consts(fine_cfg("cpu").app.model, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max,
+                       sc.mask_alpha_init, sc.mask_density, sc.near, sc.num_voxels)
+    P = fp.params_from_state_dict({k: v.detach().cpu().contiguous() for k, v in m.state_dict().items()})
+    return fp, c, P
+
+
+def _records(counts, rec_ray, rec_step, rec_w):
+    """(ray, step, weight) of the samples a march kept, from its records (padding lanes have ray -1)."""
+    n = (-(-counts["n_on"] // 32) + -(-counts["n_off"] // 32)) * 32
+    ray = rec_ray[:n]
+    ok = ray >= 0
+    return ray[ok].cpu().long(), rec_step[:n][ok].cpu().long(), rec_w[:n][ok].cpu()
+
+
+def _survivors(m):
+    ws = m.engine.ws
+    return _records(m.last_counts, ws["rec_ray"], ws["rec_step"], ws["rec_w"])
+
+
+def _check_survivor_sets(gpu, ray_id, step_id, weights, rays_o, rays_d, c, near, thres=1e-4):
+    """A march's survivor set against the oracle's, sample by sample.  A sample may be in one set only if its weight
+    sits ON the ``> thres`` test.  How close is "on": alpha = (relu(pc - nc) + 1e-5) / (pc + 1e-5) with pc, nc two
+    sigmoids of O(1) -- at alpha ~ 1e-4 the difference pc - nc cancels four digits, so one ulp of expf (device vs
+    glibc) moves alpha, and w = T alpha, by up to ~1e-3 relative: |w - 1e-4| < 2e-7.  Such a sample carries 1e-4 of a
+    ray's colour (invisible at the 1e-4 tolerance of the outputs) but its presence switches its own gradient
+    contribution on or off.  Returns the positions of those samples (their cells are set aside by _compare_grads)."""
+    ray, step, w = gpu
+    key_g, key_o = ray * 100000 + step, ray_id * 100000 + step_id
+    kg, ko = set(key_g.tolist()), set(key_o.tolist())
+    w_gpu = dict(zip(key_g.tolist(), w.tolist()))
+    w_orc = dict(zip(key_o.tolist(), weights.detach().tolist()))
+    odd = sorted(kg ^ ko)
+    for k in odd:
+        wk = w_gpu.get(k, w_orc.get(k))
+        assert abs(wk - thres) < 2e-3 * thres, (k, wk)
+    r = torch.tensor([k // 100000 for k in odd], dtype=torch.long)
+    st = torch.tensor([k % 100000 for k in odd], dtype=torch.float32)
+    # position of (ray, step) with the sampler's formulas (render_utils_kernel.cu:12-35, 58-79, 167-194)
+    o, d = rays_o[r], rays_d[r]
+    v = torch.where(d == 0, torch.full_like(d, 1e-6), d)
+    ta, tb = (c.xyz_max - o) / v, (c.xyz_min - o) / v
+    t_min = torch.minimum(ta, tb).amax(-1).clamp(min=near)
+    pos = o + d * t_min[:, None] + d / d.norm(dim=-1, keepdim=True) * (float(c.stepsize * c.voxel_size) * st)[:, None]
+    return pos
+
+
+KNIFE = 2e-6      # |hidden pre-activation| below which the two summation orders can disagree on a ReLU's branch
+                  # (192 fmaf steps on partial sums of O(0.5): a random walk of ~4e-7; measured flips up to 6e-7)
+
+
+def _mark(mark, i0, dims, offsets):
+    for d in offsets:
+        q = torch.minimum(torch.maximum(i0 + torch.tensor(d), torch.zeros(3, dtype=torch.long)), dims - 1)
+        mark[q[:, 0], q[:, 1], q[:, 2]] = True
+
+
+CORNERS = [(x, y, z) for x in (0, 1) for y in (0, 1) for z in (0, 1)]
+# cells of the SDF grid a sample's 24-tap stencil reads: taps at +-0.5..2 voxels along ONE axis, 8 corners each
+CROSS = sorted({tuple(c[a] + (t if a == ax else 0) for a in range(3)) for ax in range(3) for t in range(-2, 3) for c in CORNERS})
+CUBE1 = [(x, y, z) for x in range(-1, 3) for y in range(-1, 3) for z in range(-1, 3)]      # + the NeuS neighbours' taps
+
+
+def _knife_cells(sets, c, sdf_grid):
+    """Grid cells that receive gradient from a sample with a ReLU unit on its kink (oracle/fine_path.py::mlp records
+    the smallest |hidden pre-activation| of every sample) or from a sample on a survivor threshold (record 0).
+    Colour grids: the 8 corners of the sample's cell; SDF grid: the cells of its 24-tap stencil (+ for threshold
+    samples, whose alpha also reads the neighbouring samples' SDF taps, the surrounding cube)."""
+    dims = torch.tensor([int(v) for v in c.world_size])
+    mark = torch.zeros(tuple(dims.tolist()), dtype=torch.bool)
+    n_knife = n_all = 0
+    for pts, knife in sets:
+        ks = knife < KNIFE
+        n_knife, n_all = n_knife + int(ks.sum()), n_all + knife.numel()
+        i0 = ((pts[ks] - c.xyz_min) / (c.xyz_max - c.xyz_min) * (dims - 1)).floor().long()
+        _mark(mark, i0, dims, CROSS if sdf_grid else CORNERS)
+        thr = knife[ks] == 0
+        if sdf_grid and bool(thr.any()):
+            _mark(mark, i0[thr], dims, CUBE1)
+    return mark, n_knife, n_all
+
+
+def _compare_grads(grads, P, sets, c, n_expected, max_marked=(0.10, 0.25), fp_log=None):
+    """Every gradient against the oracle at 1e-4 rel-to-max-norm.  Network weights are means over ~10^5-10^6 samples
+    and compare as they are.  A DENSE-GRID cell sums the contributions of the one or two samples that touch it, so a
+    sample whose ReLU unit sits on its kink (|pre-activation| < 2e-6, where the MFMA's k-ordered fmaf chain and the
+    oracle's BLAS can land on different sides of 0: ~100 actual flips per step at this size) moves that cell by up to
+    ~1e-2 of the max-norm although every forward value agrees to 1e-6.  Three checks per grid:
+      (a) ALL touched cells, nothing set aside: fewer than 2 in 1000 are beyond 1e-4;
+      (b) cell by cell outside the cells such samples touch (found from the ORACLE's pre-activations, and from the
+          threshold samples of _check_survivor_sets): 1e-4, and those cells must be a small share of the touched ones;
+      (c) the cells set aside stay within 5e-2."""
+    bad, n = {}, 0
+    for k, v in P.items():
+        if v.grad is None:
+            continue
+        n += 1
+        g, o = grads[k].detach().cpu(), v.grad
+        if not k.endswith(".grid"):
+            e = rel_err(g, o)
+            if not e < TOL:
+                # a hidden unit with a sample on its ReLU kink (fp.KNIFE_LOG, from the ORACLE's pre-activations): that
+                # sample's whole contribution to the unit's weight row / bias switches on or off.  At s_val = 220 a
+                # weight-gradient row is a sum of ~10^5 terms of both signs, one term can be 1e-4 of the max-norm.
+                # Rows beyond 1e-4 must all be such units, and stay within 2e-3.
+                rows = (g - o).abs().reshape(g.shape[0], -1).amax(1) / float(o.abs().max())
+                beyond = set((rows > TOL).nonzero()[:, 0].tolist())
+                kinks = set()
+                for kk, u in (fp_log or []):
+                    if k.startswith(kk + "."):
+                        kinks |= set(u.tolist())
+                if not (beyond and beyond <= kinks and float(rows.max()) < 2e-3):
+                    bad[k] = (e, sorted(beyond), sorted(kinks))
+            continue
+        mark, n_knife, n_all = _knife_cells(sets, c, k == "sdf.grid")
+        assert n_knife < 0.02 * n_all, (n_knife, n_all)
+        err = (g - o).abs().amax(1)[0] / float(o.abs().max())
+        touched = o.abs().amax(1)[0] > 0
+        n_touched = max(1, int(touched.sum()))
+        share = int((mark & touched).sum()) / n_touched
+        # (the BRDF grid only gets gradient at the ~100 surface points of the light-transport estimate: too few cells
+        # for a share to mean anything)
+        assert share < max_marked[k == "sdf.grid"] or n_touched < 5000, (k, share)
+        frac_bad = int((err > TOL).sum()) / n_touched
+        e_out, e_in = float(err[~mark].max()), float(err[mark].max()) if bool(mark.any()) else 0.0
+        if not (frac_bad < 2e-3 and e_out < TOL and e_in < 5e-2):
+            bad[k] = dict(beyond_tol=frac_bad, outside=e_out, set_aside=e_in, share=share)
+    assert n == n_expected and not bad, str(bad)
+
+
+def _run_fine(m, sc, s_val, white_bg=True):
+    from esr_nerf_amd.trainer import FineStep
+    b = {k: v.cuda() for k, v in sc.batch.items()}
+    loss, grads = FineStep(m, white_bg=white_bg).forward_loss_backward(b, s_val)
+    torch.cuda.synchronize()
+    return float(loss), {k: v.clone() for k, v in grads.items()}
+
+
+def _oracle_fine(fp, c, P, sc, s_val, white_bg=True):
+    keep = {}
+    res = fp.forward_training(P, c, sc.batch, s_val, keep=keep)
+    loss, _ = fp.fine_loss(res, sc.batch["rgbs"], white_bg=white_bg)
+    loss.backward()
+    return {k: v.detach() for k, v in res.items()}, float(loss), keep
+
+
+def test_c2_full_batch_forward_backward_vs_oracle():
+    """C2 = the headline configuration: 4096 rays x 128 samples, 524 288 surviving samples, fp32."""
+    from esr_nerf_amd.synthetic import slab_scene
+    sc = slab_scene("C2", s_val=20.0)
+    m = _fine_model(sc)
+    loss, grads = _run_fine(m, sc, 20.0)
+    lc = m.last_counts
+    assert lc["m0"] == lc["m1"] == lc["m2"] == lc["m3"] == 4096 * 128
+    fp, c, P = _fine_oracle(m, sc)
+    res, o_loss, keep = _oracle_fine(fp, c, P, sc, 20.0)
+    assert keep["counts"] == (lc["m0"], lc["m1"], lc["m2"], lc["m3"])
+    odd = _check_survivor_sets(_survivors(m), keep["ray_id"], keep["step_id"], keep["weights"], sc.batch["rays_o"],
+                               sc.batch["rays_d"], c, sc.near)
+    assert len(odd) == 0
+    assert abs(loss - o_loss) < 1e-5 * max(1.0, abs(o_loss))
+    b = {k: v.cuda() for k, v in sc.batch.items()}
+    out = m(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=b["em_modes"], s_val=20.0)
+    for k in res:
+        assert rel_err(out[k], res[k]) < TOL, (k, rel_err(out[k], res[k]))
+    _compare_grads(grads, P, [(keep["pts"], keep["knife"])], c, 23)
+
+
+def test_c3_full_size_fp32_no_white_bg_and_bf16_psnr():
+    """C3 = "dtu scan97 fine stage, 4096 rays x 192 samples, bf16": the dtu data sets ``white_bg = False``
+    (cfg/data/dtu.yaml), the slab is 96 voxels deep.  fp32 first -- it is what pins the arithmetic -- then bf16 MLPs."""
+    from esr_nerf_amd.synthetic import slab_scene
+    sc = slab_scene("C3", s_val=20.0)
+    m = _fine_model(sc)
+    loss, grads = _run_fine(m, sc, 20.0, white_bg=False)
+    lc = m.last_counts
+    assert lc["m0"] == lc["m1"] == 4096 * 192
+    fp, c, P = _fine_oracle(m, sc)
+    res, o_loss, keep = _oracle_fine(fp, c, P, sc, 20.0, white_bg=False)
+    n0, n1, n2, n3 = keep["counts"]
+    assert (lc["m0"], lc["m1"], lc["m2"]) == (n0, n1, n2)
+    # round 1 recorded 702 430 survivors here against the oracle's 702 431: the sets are compared sample by sample and
+    # every sample that is in one set only must have its weight on the threshold
+    odd = _check_survivor_sets(_survivors(m), keep["ray_id"], keep["step_id"], keep["weights"], sc.batch["rays_o"],
+                               sc.batch["rays_d"], c, sc.near)
+    assert abs(lc["m3"] - n3) <= len(odd) <= 3, (lc["m3"], n3, len(odd))
+    assert abs(loss - o_loss) < 1e-5 * max(1.0, abs(o_loss))
+    _compare_grads(grads, P, [(keep["pts"], keep["knife"]), (odd, torch.zeros(len(odd)))], c, 23)
+
+    # bf16 MLP operands at the same size: rendered image (forward_evaluate) against the fp32 render
+    m16 = _fine_model(sc, "bf16")
+    b = {k: v.cuda() for k, v in sc.batch.items()}
+    for mm in (m, m16):
+        mm.s_val = 20.0
+        mm.eval()
+    kw = dict(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=1, pos_rt=torch.eye(3).cuda())
+    r32, r16 = m(**kw), m16(**kw)
+    assert m16.engine.bf16 and not m.engine.bf16
+    img = lambda r: r["srgb/rgb"].clamp(0, 1)                       # white_bg = False: no background term
+    gt = b["rgbs"]
+    psnr = lambda x: -10.0 * math.log10(float(((x - gt) ** 2).mean()))
+    assert abs(psnr(img(r32)) - psnr(img(r16))) < 0.1              # BASELINE: PSNR within 0.1 dB of the reference
+    between = -10.0 * math.log10(max(float(((img(r32) - img(r16)) ** 2).mean()), 1e-12))
+    assert between > 45.0
+    # and the bf16 training step tracks the fp32 one
+    m16.train()
+    loss16, g16 = _run_fine(m16, sc, 20.0, white_bg=False)
+    assert m16.last_counts == lc and abs(loss16 - loss) < 2e-3 * max(1.0, abs(loss))
+    a_, b_ = g16["sdf.grid"].flatten().double(), grads["sdf.grid"].flatten().double()
+    assert float((a_ * b_).sum() / (a_.norm() * b_.norm())) > 0.995
+
+
+def _lts_model(sc, dtype="f32", **over):
+    from esr_nerf_amd.config import lts_cfg
+    from esr_nerf_amd.esrnerf import ESRNeRF
+    from esr_nerf_amd.synthetic import init_slab_model
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cfg = lts_cfg("cuda:0", **over)
+    m = ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max, sc.mask_alpha_init,
+                sc.mask_density, sc.s_val, sc.num_voxels)
+    init_slab_model(m, sc)
+    with torch.no_grad():
+        m.brdf.grid.copy_((torch.randn(m.brdf.grid.shape, generator=torch.Generator().manual_seed(9)) * 0.1).cuda())
+    m.mlp_dtype = dtype
+    m.train()
+    return m, cfg
+
+
+def _lts_draws(m3, pn, r, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    return dict(idx=torch.randperm(m3, generator=g)[:pn], dirs=torch.randn(pn, r + 1, 3, generator=g),
+                noise_normal=torch.randn(m3, 3, generator=g), noise_emit=torch.randn(m3, 3, generator=g))
+
+
+def test_c4_full_size_lts_step_vs_oracle():
+    """C4 = "giftbox_w lts stage, 8192 rays": 8192 primary rays x 128 samples + 100 surface points x 256 secondary
+    rays at s_val = 220 (lts.yaml:52), the reference's default sizes (lts.yaml:38-39)."""
+    from esr_nerf_amd.config import lts_cfg
+    from esr_nerf_amd.synthetic import slab_scene
+    from oracle import fine_path as fp
+    from oracle import lts_path as lp
+    s_val = 220.0
+    sc = slab_scene("C4", s_val=s_val)
+    m, cfg = _lts_model(sc)
+    assert (m.num_ltspts, m.num_2ndrays, sc.n_rays) == (100, 256, 8192)
+    ccfg = lts_cfg("cpu")
+    c = fp.make_consts(ccfg.app.model, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max, sc.mask_alpha_init,
+                       sc.mask_density, sc.near, sc.num_voxels)
+    sd = {k: v.detach().cpu().contiguous() for k, v in m.state_dict().items()}
+    P = fp.params_from_state_dict(sd)
+    k0 = {}
+    with torch.no_grad():
+        fp.forward_training(fp.params_from_state_dict(sd, requires_grad=False), c, sc.batch, s_val, keep=k0)
+    m3 = k0["counts"][3]
+    draws = _lts_draws(m3, 100, 256)
+    batch = dict(sc.batch, uncert_masks=torch.arange(sc.n_rays) % 3 == 0)
+    tr = cfg.app.trainer
+    keep = {}
+    fp.KNIFE_LOG = []
+    ro = lp.forward_training(P, c, batch, s_val, lp.Draws(**draws), tr.normal_eps, tr.emit_eps, 256,
+                             ccfg.app.model.lts_near, pdra_mode=False, keep=keep)
+    fp_log, fp.KNIFE_LOG = fp.KNIFE_LOG, None
+    lo, _ = lp.lts_loss(ro, batch["rgbs"], True, tr.weight_linear, tr.weight_lts, tr.weight_entropy_last,
+                        tr.weight_normal_smooth)
+    b = {k: v.cuda() for k, v in batch.items()}
+    rg = m(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=b["em_modes"],
+           uncert_masks=b["uncert_masks"], s_val=s_val, normal_eps=tr.normal_eps, emit_eps=tr.emit_eps,
+           draws={k: v.cuda() for k, v in draws.items()})
+    # exact survivor counts of BOTH marches
+    lc, sec = m.last_counts, m.engine.sec.counts
+    assert (lc["m0"], lc["m1"], lc["m2"], lc["m3"]) == keep["counts"] == k0["counts"]
+    assert (sec["m0"], sec["m1"]) == keep["sec_counts"][:2]
+    # 3.6 M secondary samples: the alpha > 1e-4 / weight > 1e-4 survivors are compared as SETS; a sample in one set
+    # only must sit on the threshold (first sample of a ray, T = 1, alpha = w = 1e-4 (1 +- 1e-5))
+    pb = m.engine.sec.bufs
+    ks = keep["sec"]
+    odd = _check_survivor_sets(_records(sec, pb["rec_ray"], pb["rec_step"], pb["rec_w"]), ks["ray_id"], ks["step_id"],
+                               ks["weights"], ks["rays_o"], ks["rays_d"], c, ccfg.app.model.lts_near)
+    assert abs(sec["m3"] - keep["sec_counts"][3]) <= len(odd) <= 3 and abs(sec["m2"] - keep["sec_counts"][2]) <= len(odd)
+    assert lc["m0"] == 8192 * 128 and lc["m2"] < lc["m1"] and lc["m3"] < lc["m2"] and sec["m0"] > 3_000_000
+    bad = {}
+    for k in sorted(ro):
+        assert rg[k].shape == ro[k].shape, k
+        e = rel_err(rg[k], ro[k])
+        if not e < TOL:
+            bad[k] = e
+    assert not bad, str(bad)
+    lg, _ = lp.lts_loss(rg, b["rgbs"], True, tr.weight_linear, tr.weight_lts, tr.weight_entropy_last, tr.weight_normal_smooth)
+    assert abs(float(lg.detach()) - float(lo.detach())) < 1e-5 * max(1.0, abs(float(lo.detach())))
+    # gradients: the L1 normal-smoothness term sits on its kink for a third of its arguments (slab SDF linear in z);
+    # both sides back-propagate it with the oracle's subgradient choice (see test_gpu_lts_path.py)
+    sgn = torch.sign(ro["etc/normal"].detach() - ro["etc/normal_eps"].detach())
+
+    def with_fixed_subgradient(res, loss, sg):
+        d = res["etc/normal"] - res["etc/normal_eps"]
+        return loss - tr.weight_normal_smooth * d.abs().mean() + tr.weight_normal_smooth * (d * sg).mean()
+
+    with_fixed_subgradient(ro, lo, sgn).backward()
+    with_fixed_subgradient(rg, lg, sgn.cuda()).backward()
+    _compare_grads({k: p.grad for k, p in m.named_parameters() if p.grad is not None}, P,
+                   keep["knife_sets"] + [(odd, torch.zeros(len(odd)))], c, 43, max_marked=(0.15, 0.5), fp_log=fp_log)
+
+
+def test_c5_full_size_pdra_bf16_tracks_fp32_and_finetune_vs_oracle():
+    """C5 = "book_w pdra stage + test_nvic re-lighting fine-tune, 8192 rays, bf16".  (a) the pdra training step with
+    bf16 MLP operands at 8192 rays + 100 x 256 secondary rays against the fp32 step on the same draws; (b) the
+    fine-tune half (forward_finetune, pdra.yaml:128-129: 4096 uncertain + 4096 certain rays) in fp32 against the
+    oracle and in bf16 against fp32."""
+    from esr_nerf_amd.config import lts_cfg
+    from esr_nerf_amd.synthetic import slab_scene
+    from esr_nerf_amd.trainer import LtsStep
+    from oracle import fine_path as fp
+    from oracle import lts_path as lp
+    s_val = 220.0
+    sc = slab_scene("C4", s_val=s_val)
+    b = {k: v.cuda() for k, v in sc.batch.items()}
+    b["uncert_masks"] = (torch.arange(sc.n_rays) % 3 == 0).cuda()
+    out, draws = {}, None
+    for dt in ("f32", "bf16"):
+        m, cfg = _lts_model(sc, dt)
+        step = LtsStep(m, cfg.app.trainer, stage="pdra")
+        if draws is None:
+            step.forward_loss_backward(b, s_val)
+            draws = {k: v.cuda() for k, v in _lts_draws(m.last_counts["m3"], 100, 256).items()}
+        loss, G, _ = step.forward_loss_backward(b, s_val, draws=draws)
+        out[dt] = (float(loss), dict(m.last_counts), dict(m.engine.sec.counts), {k: v.clone() for k, v in G.items()})
+        assert m.engine.bf16 == (dt == "bf16")
+    assert out["f32"][1] == out["bf16"][1] and out["f32"][2] == out["bf16"][2]       # the marches are fp32 in both
+    assert abs(out["f32"][0] - out["bf16"][0]) < 1e-2 * abs(out["f32"][0])
+    for k in ("sdf.grid", "emo_color.grid", "off_color.grid", "brdf.grid"):
+        a_, b_ = out["bf16"][3][k].flatten().double(), out["f32"][3][k].flatten().double()
+        assert bool(torch.isfinite(a_).all()) and float((a_ * b_).sum() / (a_.norm() * b_.norm())) > 0.98, k
+
+    # ---- fine-tune half: 4096 + 4096 rays, em_modes 0..4, edited intensities / colours
+    g = torch.Generator().manual_seed(21)
+    n = sc.n_rays
+    fb = dict(rays_o=sc.batch["rays_o"], rays_d=sc.batch["rays_d"], viewdirs=sc.batch["viewdirs"],
+              em_modes=(torch.arange(n) % 5).long(), em_intensities=0.25 + 2.0 * torch.rand(n, generator=g),
+              em_colors=torch.rand(n, 2, generator=g))
+    res = {}
+    for dt in ("f32", "bf16"):
+        m, cfg = _lts_model(sc, dt)
+        for p in m.parameters():
+            p.requires_grad_(False)
+        for p in list(m.emo_color.parameters()) + list(m.emo_rgbnet.parameters()):
+            p.requires_grad_(True)
+        m.s_val = s_val
+        m.train(True, finetune=True)
+        with torch.no_grad():
+            m.emo_color.grid.add_((torch.randn(m.emo_color.grid.shape, generator=torch.Generator().manual_seed(3)) * 0.05).cuda())
+        if dt == "f32":
+            ccfg = lts_cfg("cpu")
+            c = fp.make_consts(ccfg.app.model, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max,
+                               sc.mask_alpha_init, sc.mask_density, sc.near, sc.num_voxels)
+            sd = {k: v.detach().cpu().contiguous() for k, v in m.state_dict().items()}
+            P = fp.params_from_state_dict(sd)
+            k0 = {}
+            with torch.no_grad():
+                fp.forward_training(fp.params_from_state_dict(sd, requires_grad=False), c, sc.batch, s_val, keep=k0)
+            fdraws = dict(idx=torch.randperm(k0["counts"][3], generator=g)[:100], dirs=torch.randn(100, 257, 3, generator=g))
+            ro = lp.forward_finetune(P, c, fb, s_val, fdraws["idx"], fdraws["dirs"], 256, ccfg.app.model.lts_near)
+            lo = 0.5 * torch.nn.functional.mse_loss(ro["lin/pbr/emo"], ro["lin/pbr/emo_hat"])
+            lo.backward()
+        r = m(draws={k: v.cuda() for k, v in fdraws.items()}, **{k: v.cuda() for k, v in fb.items()})
+        l = 0.5 * torch.nn.functional.mse_loss(r["lin/pbr/emo"], r["lin/pbr/emo_hat"])
+        l.backward()
+        res[dt] = (r, float(l), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    r32, l32, g32 = res["f32"]
+    for k in ("lin/pbr/emo", "lin/pbr/emo_hat"):
+        assert r32[k].shape == ro[k].shape and rel_err(r32[k], ro[k]) < TOL, (k, rel_err(r32[k], ro[k]))
+    assert abs(l32 - float(lo)) < 1e-5 * max(1.0, abs(float(lo)))
+    want = {k for k, v in P.items() if v.grad is not None}
+    assert set(g32) == want and len(want) == 9
+    bad = {k: rel_err(g32[k], P[k].grad) for k in want if not rel_err(g32[k], P[k].grad) < TOL}
+    assert not bad, str(bad)
+    r16, l16, g16 = res["bf16"]
+    assert rel_err(r16["lin/pbr/emo"], r32["lin/pbr/emo"]) < 2e-2 and rel_err(r16["lin/pbr/emo_hat"], r32["lin/pbr/emo_hat"]) < 2e-2
+    assert abs(l16 - l32) < 2e-2 * max(abs(l32), 1e-6)
