@@ -60,14 +60,21 @@ class EsrMlpWeights(C.Structure):
     _fields_ = [("w", C.c_void_p * 4), ("b", C.c_void_p * 4)]
 
 
-# every exported symbol of include/esr_hip.h (checked by tests/test_abi.py)
+class EsrWgradJob(C.Structure):
+    """esr_wgrad_job_t"""
+    _fields_ = [("kind", C.c_int32), ("color_row0", C.c_int32), ("t0", C.c_int32), ("t1", C.c_int32),
+                ("X", C.c_void_p), ("H", C.c_void_p), ("dZ", C.c_void_p), ("dz", C.c_void_p),
+                ("gw", C.c_void_p), ("gb", C.c_void_p)]
+
+
+# every exported symbol of include/esr_hip.h (checked by tests/test_host.py::test_library_loads_and_exports_every_header_symbol)
 EXPORTS = [
     "esr_abi_version", "esr_build_info",
     "esr_sample_count", "esr_sample_fill", "esr_alpha2weight_fwd", "esr_alpha2weight_bwd",
     "esr_tv_add_grad", "esr_segment_sum",
     "esr_fine_march_count", "esr_fine_plan_begin", "esr_fine_plan", "esr_fine_march_fill",
     "esr_fine_march_bwd", "esr_fine_feat_fwd", "esr_fine_feat_bwd",
-    "esr_mlp_packed_floats", "esr_mlp_pack", "esr_mlp_fwd", "esr_mlp_dgrad", "esr_mlp_wgrad",
+    "esr_mlp_packed_floats", "esr_mlp_pack", "esr_mlp_fwd", "esr_mlp_fwd_mixed", "esr_mlp_dgrad", "esr_mlp_wgrad", "esr_mlp_wgrad_batch",
     "esr_mlp_wgrad_scratch_floats",
     "esr_fine_tone_in_fwd", "esr_fine_composite_fwd", "esr_fine_composite_bwd",
     "esr_fine_tone_in_bwd", "esr_fine_loss_fwd_bwd",

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/esr_hip.h"
 
 #define ESR_API extern "C" __attribute__((visibility("default")))
@@ -16,6 +18,23 @@
 #define ESR_WAVE 64
 
 static inline hipStream_t esr_stream(void *s) { return (hipStream_t)s; }
+
+// Opt-in for more than 64 KB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of
+// a kernel): set once per (kernel, device).  `done` = one static bit mask per kernel instantiation; the only state the
+// library keeps is this idempotent "attribute already set" memo.
+static inline int esr_lds_optin(const void *kernel, size_t bytes, std::atomic<uint64_t> &done)
+{
+    if (bytes <= 64 * 1024) return 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return 0;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    done.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
 
 static inline int esr_grid_for(int64_t n, int block, int cap = 256 * 8)
 {

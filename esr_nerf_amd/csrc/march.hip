@@ -341,6 +341,8 @@ int launch_march(MarchParams &P, hipStream_t s)
     int wpb = 4;
     while (wpb > 1 && per_wave * wpb > 64 * 1024) wpb >>= 1;
     if (per_wave * wpb > 160 * 1024) return ESR_ECAP;
+    static std::atomic<uint64_t> optin{0};             // one wave per block beyond 64 KB (cap > ~3.2k steps in BWD mode)
+    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&march_kernel<MODE, COARSE>), per_wave * wpb, optin)) return rc;
     const int grid = (P.n_rays + wpb - 1) / wpb;
     march_kernel<MODE, COARSE><<<grid, wpb * 64, per_wave * wpb, s>>>(P);
     ESR_CHECK_LAUNCH();

@@ -27,8 +27,6 @@
 //    wave streams the two operand tiles of every sample tile HBM -> LDS by LDS-DMA into a
 //    3-buffer ring (mlp_wgrad_dma_kernel); partial blocks go to per-workgroup slabs that a
 //    second kernel sums.  (bf16 operand modes: the register-staged mlp_wgrad_kernel.)
-#include <cstdlib>
-
 #include "esr_common.h"
 
 #include "mlp_common.h"
@@ -48,6 +46,8 @@ struct FwdArgs {
     unsigned *M[3];
     int save, crow;            // crow: X row of the 6-row colour group this net reads (0, 88 or 96)
     float *zout;
+    int t_det;                 // tiles t < t_det are evaluated detached: nothing saved, colour group crow_det
+    int crow_det;
 };
 
 template <int KIND>
@@ -67,7 +67,9 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
     for (int t = A.t0 + wave; t < A.t1; t += nwaves) {
         const rsrc_t RX = make_rsrc(A.X + (size_t)t * D.xrows * 32, D.xrows * 32 * 4);
         const int xvoff = (h * 32 + s) * 4;
-        const int coff = A.crow * 128;
+        const bool det = t < A.t_det;                        // wave-uniform
+        const int coff = (det ? A.crow_det : A.crow) * 128;
+        const bool save = A.save && !det;
         ESR_STAMP(0);
         float B1[KP1];
 #pragma unroll
@@ -96,7 +98,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
             __builtin_amdgcn_sched_barrier(0);            // keep the requests in front of the epilogue's stores
             __builtin_amdgcn_s_setprio(3);                // (see the note on wave priorities above the kernel)
             relu_tiles<HT>(cur);
-            if (A.save) {
+            if (save) {
                 store_tiles<HT>(make_rsrc(A.H[l] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
                 store_relu_mask<HT>(make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), cur, lane);
             }
@@ -189,8 +191,28 @@ struct WgradArgs {
     int b_tile_rows;             // rows per B tile in memory (>= RB; the X tile has extra colour rows)
     int crow;                    // first layer: B rows 0..cw-1 are read from X rows crow..crow+cw-1
     int cw8;                     // colour-group rows x 8 (float4 units per row)
-    int dbg;                     // timing experiments only (ESR_WGRAD_DBG): 1 = DMA through empty descriptors
+    int wg0, nwg;                // workgroups [wg0, wg0 + nwg) of the launch work on this job
 };
+
+// One launch can carry up to four JOBS of the same kernel shape (the same layer of the emissive and the non-emissive
+// net, both hidden layers of a net, the 3-row output layers of all three nets ...): each job gets a share of the 256
+// workgroups proportional to its tiles.  Why: a weight-gradient launch has a FIXED cost of ~25-35 us whatever its
+// tile count (tools/wgrad_scaling.py: 135 us per 4-layer net) -- the partial dW of every workgroup goes to a slab
+// (256 x 147 KB written, then read by the reduction) and the ring has to fill and drain.  With J jobs per launch each
+// job runs on 256/J workgroups: J times fewer, J times longer launches, and J times less slab traffic per layer.
+constexpr int MAX_JOBS = 4;
+struct WgradBatch {
+    int n;
+    WgradArgs job[MAX_JOBS];
+};
+__device__ __forceinline__ WgradArgs pick_job(const WgradBatch &B)
+{
+    WgradArgs W = B.job[0];            // static indices only: scalar loads + selects, no private-memory copy of the batch
+#pragma unroll
+    for (int k = 1; k < MAX_JOBS; ++k)
+        if (k < B.n && (int)blockIdx.x >= B.job[k].wg0) W = B.job[k];
+    return W;
+}
 
 // Cooperative weight-gradient kernel.  One workgroup covers the WHOLE dW of a layer:
 // wave (wm, wn, wk) owns the MI x NJ block of 32x32 output tiles at (wm, wn) and the
@@ -211,8 +233,9 @@ constexpr int LDS_STRIDE = 36;        // floats per staged row (32 samples + 4 p
 // network input X and the output gradient dz are fp32 (rounded on the way from LDS to the operand registers):
 //   1 = output layer (A = dz fp32, B = H bf16), 2 = hidden layer (both bf16), 3 = first layer (A = dZ bf16, B = X fp32).
 template <int MI, int NJ, int WM, int WN, int WK, int MODE>
-__global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradArgs W)
+__global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradBatch WB)
 {
+    const WgradArgs W = pick_job(WB);
     static_assert(MODE >= 1 && MODE <= 3, "f32 operands: mlp_wgrad_dma_kernel");
     constexpr bool A16 = MODE == 2 || MODE == 3, B16 = MODE == 1 || MODE == 2;
     constexpr int NW = WM * WN * WK, NT = 64 * NW;
@@ -224,7 +247,7 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradAr
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, rl = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = w % WK, wn = (w / WK) % WN, wm = w / (WK * WN);
-    const int nsplit = gridDim.x, split = blockIdx.x;
+    const int nsplit = W.nwg, split = blockIdx.x - W.wg0;
 
     f32x16 acc[MI][NJ];
 #pragma unroll
@@ -347,7 +370,7 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradAr
     // stores its block into its workgroup's private slab with plain 128-B-contiguous stores; a
     // second tiny kernel sums the slabs.  (1024 waves atomically adding into the same 147 KB at
     // kernel end ran at a fraction of the atomic rate: same-address contention.)
-    float *S = W.slab + (size_t)(blockIdx.x * WK + wk) * W.out_rows * W.ld;
+    float *S = W.slab + (size_t)(split * WK + wk) * W.out_rows * W.ld;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int rb = 32 * (NJ * wn + j) + rl;
@@ -407,8 +430,9 @@ __device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned lds_byte, int vof
 }
 
 template <int MI, int NJ, int WM, int WN, int WK>
-__global__ void __launch_bounds__(64 * (WM * WN * WK + 1), 1) mlp_wgrad_dma_kernel(WgradArgs W)
+__global__ void __launch_bounds__(64 * (WM * WN * WK + 1), 1) mlp_wgrad_dma_kernel(WgradBatch WB)
 {
+    const WgradArgs W = pick_job(WB);
     constexpr int NW = WM * WN * WK;                 // compute waves (one per SIMD); wave NW is the loader
     constexpr int RAP = WM * MI * 32, RBP = WN * NJ * 32, ROWS = RAP + RBP;
     constexpr int PIECES = ROWS / 8;                 // 1-KiB pieces (8 rows x 128 B) per tile
@@ -420,7 +444,7 @@ __global__ void __launch_bounds__(64 * (WM * WN * WK + 1), 1) mlp_wgrad_dma_kern
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, rl = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = w % WK, wn = (w / WK) % WN, wm = w / (WK * WN);
-    const int nsplit = gridDim.x, split = blockIdx.x;
+    const int nsplit = W.nwg, split = blockIdx.x - W.wg0;
 
     // rows that no DMA ever fills (operands shorter than the staged block) must not hold NaN patterns
     for (int i = tid; i < 3 * BUF; i += 64 * (NW + 1)) lds[i] = 0.f;
@@ -437,7 +461,7 @@ __global__ void __launch_bounds__(64 * (WM * WN * WK + 1), 1) mlp_wgrad_dma_kern
         const unsigned lds0 = (unsigned)(uintptr_t)(lds_void *)lds;
         const int cw = W.cw8 / 8;
         auto load_tile = [&](int t_next, int fb) {
-            const bool live = t_next < W.t1 && !(W.dbg & 1);     // past the range: zero records, no memory touched
+            const bool live = t_next < W.t1;                     // past the range: zero records, no memory touched
             const int tc = t_next < W.t1 ? t_next : W.t0;
             const u32x4 SA = raw_rsrc(reinterpret_cast<const char *>(W.A) + (size_t)tc * W.RA * 128u,
                                       live ? (unsigned)W.RA * 128u : 0u);
@@ -519,7 +543,7 @@ __global__ void __launch_bounds__(64 * (WM * WN * WK + 1), 1) mlp_wgrad_dma_kern
     }
     __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(0));
 
-    float *S = W.slab + (size_t)(blockIdx.x * WK + wk) * W.out_rows * W.ld;
+    float *S = W.slab + (size_t)(split * WK + wk) * W.out_rows * W.ld;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int rb = 32 * (NJ * wn + j) + rl;
@@ -542,20 +566,33 @@ __global__ void __launch_bounds__(64 * (WM * WN * WK + 1), 1) mlp_wgrad_dma_kern
     }
 }
 
-// gw[e] += sum over partial slabs; 32 slabs per thread, groups combined with one atomic each
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ slab, int n_partials,
-                                                           int n_elems, float *__restrict__ gw)
+// gw[e] += sum over the partial slabs of every job of a launch; 32 slabs per thread, groups combined with one atomic
+struct ReduceArgs {
+    int nseg;
+    const float *slab[MAX_JOBS];
+    int n_partials[MAX_JOBS], n_elems[MAX_JOBS];
+    float *gw[MAX_JOBS];
+    int64_t first[MAX_JOBS + 1];   // work-item prefix: segment l owns items [first[l], first[l+1])
+};
+constexpr int REDUCE_PG = 32;
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs R)
 {
-    constexpr int PG = 32;
-    const int groups = (n_partials + PG - 1) / PG;
-    const int64_t total = (int64_t)n_elems * groups;
+    const int64_t total = R.first[R.nseg];
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
-        const int e = (int)(i % n_elems), g = (int)(i / n_elems);
-        const int p1 = min((g + 1) * PG, n_partials);
+        int l = 0;
+#pragma unroll
+        for (int k = 1; k < MAX_JOBS; ++k)
+            if (k < R.nseg && i >= R.first[k]) l = k;
+        const int64_t j = i - R.first[l];
+        const int n_elems = R.n_elems[l], n_partials = R.n_partials[l];
+        const int e = (int)(j % n_elems), g = (int)(j / n_elems);
+        const int p1 = min((g + 1) * REDUCE_PG, n_partials);
+        const float *slab = R.slab[l];
         float acc = 0.f;
-        for (int p = g * PG; p < p1; ++p) acc += slab[(size_t)p * n_elems + e];
-        atomicAdd(&gw[e], acc);
+        for (int p = g * REDUCE_PG; p < p1; ++p) acc += slab[(size_t)p * n_elems + e];
+        atomicAdd(&R.gw[l][e], acc);
     }
 }
 
@@ -568,72 +605,119 @@ int mlp_grid(int n_tiles)
     return wg;
 }
 
-template <int MI, int NJ, int WM, int WN, int WK, int MODE = 0>
-int launch_wgrad(const WgradArgs &W, int64_t slab_floats, hipStream_t s)
+// Share of the launch's workgroups (one per CU) for every job, proportional to its tiles; slab regions back to back.
+template <int WK>
+int plan_batch(WgradBatch &B, float *scratch, int64_t slab_floats, ReduceArgs &R)
 {
-    const int n_tiles = W.t1 - W.t0;
-    if (n_tiles <= 0) return 0;
-    if (W.RA > WM * MI * 32 || W.RB > WN * NJ * 32) return ESR_ECAP;
-    constexpr int NT = 64 * WM * WN * WK;
-    constexpr size_t lds_bytes = 2 * (size_t)(WM * MI * 32 + WN * NJ * 32) * LDS_STRIDE * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {       // > 64 KB of dynamic LDS needs the opt-in
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_kernel<MI, NJ, WM, WN, WK, MODE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+    int64_t tiles = 0;
+    for (int j = 0; j < B.n; ++j) tiles += B.job[j].t1 - B.job[j].t0;
+    const int grid = tiles < 256 ? (int)tiles : 256;
+    int given = 0;
+    for (int j = 0; j < B.n; ++j) {
+        const int tj = B.job[j].t1 - B.job[j].t0;
+        int n = (int)((int64_t)grid * tj / tiles);
+        if (n < 1) n = 1;
+        B.job[j].nwg = n;
+        given += n;
     }
-    int grid = 256;        // one workgroup per CU (LDS-bound residency)
-    if (grid > n_tiles) grid = n_tiles;
-    const int n_elems = W.out_rows * W.ld;
-    if ((int64_t)grid * WK * n_elems > slab_floats) return ESR_ECAP;
-    mlp_wgrad_kernel<MI, NJ, WM, WN, WK, MODE><<<grid, NT, lds_bytes, s>>>(W);
-    ESR_CHECK_LAUNCH();
-    const int groups = (grid * WK + 31) / 32;
-    wgrad_reduce_kernel<<<esr_grid_for((int64_t)n_elems * groups, 256, 2048), 256, 0, s>>>(W.slab, grid * WK,
-                                                                                         n_elems, W.gw);
+    for (int j = 0; given != grid; j = (j + 1) % B.n) {            // hand out / take back the rounding remainder
+        WgradArgs &W = B.job[j];
+        if (given < grid && W.nwg < W.t1 - W.t0) { ++W.nwg; ++given; }
+        else if (given > grid && W.nwg > 1) { --W.nwg; --given; }
+    }
+    int64_t used = 0;
+    int wg0 = 0;
+    R = ReduceArgs{};
+    for (int j = 0; j < B.n; ++j) {
+        WgradArgs &W = B.job[j];
+        W.wg0 = wg0;
+        wg0 += W.nwg;
+        const int n_elems = W.out_rows * W.ld;
+        W.slab = scratch + used;
+        used += (int64_t)W.nwg * WK * n_elems;
+        R.slab[j] = W.slab; R.n_partials[j] = W.nwg * WK; R.n_elems[j] = n_elems; R.gw[j] = W.gw;
+        R.first[j + 1] = R.first[j] + (int64_t)n_elems * ((W.nwg * WK + REDUCE_PG - 1) / REDUCE_PG);
+    }
+    R.nseg = B.n;
+    if (used > slab_floats) return ESR_ECAP;
+    return wg0;                                                     // = grid
+}
+
+int launch_reduce(const ReduceArgs &R, hipStream_t s)
+{
+    wgrad_reduce_kernel<<<esr_grid_for(R.first[R.nseg], 256, 2048), 256, 0, s>>>(R);
     ESR_CHECK_LAUNCH();
     return 0;
 }
 
-template <int MI, int NJ, int WM, int WN, int WK>
-int launch_wgrad_dma(const WgradArgs &W, int64_t slab_floats, hipStream_t s)
+template <int MI, int NJ, int WM, int WN, int WK, int MODE = 0>
+int launch_wgrad(WgradBatch &B, float *scratch, int64_t slab_floats, hipStream_t s)
 {
-    const int n_tiles = W.t1 - W.t0;
-    if (n_tiles <= 0) return 0;
-    if (W.RA > WM * MI * 32 || W.RB > WN * NJ * 32) return ESR_ECAP;
+    for (int j = 0; j < B.n; ++j)
+        if (B.job[j].RA > WM * MI * 32 || B.job[j].RB > WN * NJ * 32) return ESR_ECAP;
+    constexpr int NT = 64 * WM * WN * WK;
+    constexpr size_t lds_bytes = 2 * (size_t)(WM * MI * 32 + WN * NJ * 32) * LDS_STRIDE * sizeof(float);
+    static std::atomic<uint64_t> optin{0};
+    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_wgrad_kernel<MI, NJ, WM, WN, WK, MODE>), lds_bytes, optin))
+        return rc;
+    ReduceArgs R;
+    const int grid = plan_batch<WK>(B, scratch, slab_floats, R);     // one workgroup per CU (LDS-bound residency)
+    if (grid < 0) return grid;
+    mlp_wgrad_kernel<MI, NJ, WM, WN, WK, MODE><<<grid, NT, lds_bytes, s>>>(B);
+    ESR_CHECK_LAUNCH();
+    return launch_reduce(R, s);
+}
+
+template <int MI, int NJ, int WM, int WN, int WK>
+int launch_wgrad_dma(WgradBatch &B, float *scratch, int64_t slab_floats, hipStream_t s)
+{
+    for (int j = 0; j < B.n; ++j)
+        if (B.job[j].RA > WM * MI * 32 || B.job[j].RB > WN * NJ * 32) return ESR_ECAP;
     constexpr int NT = 64 * (WM * WN * WK + 1);           // compute waves + the loader wave
     constexpr size_t lds_bytes = 3 * (size_t)(WM * MI * 32 + WN * NJ * 32) * 32 * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "three staged tiles must fit the CU's LDS");
-    static bool attr_set = false;
-    if (!attr_set) {       // > 64 KB of dynamic LDS needs the opt-in
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_dma_kernel<MI, NJ, WM, WN, WK>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    int grid = 256;        // one workgroup per CU (LDS-bound residency)
-    if (grid > n_tiles) grid = n_tiles;
-    const int n_elems = W.out_rows * W.ld;
-    if ((int64_t)grid * WK * n_elems > slab_floats) return ESR_ECAP;
-    static const int dbg = getenv("ESR_WGRAD_DBG") ? atoi(getenv("ESR_WGRAD_DBG")) : 0;
-    WgradArgs Wd = W;
-    Wd.dbg = dbg;
-    mlp_wgrad_dma_kernel<MI, NJ, WM, WN, WK><<<grid, NT, lds_bytes, s>>>(Wd);
+    static std::atomic<uint64_t> optin{0};
+    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_wgrad_dma_kernel<MI, NJ, WM, WN, WK>), lds_bytes, optin))
+        return rc;
+    ReduceArgs R;
+    const int grid = plan_batch<WK>(B, scratch, slab_floats, R);     // one workgroup per CU (LDS-bound residency)
+    if (grid < 0) return grid;
+    mlp_wgrad_dma_kernel<MI, NJ, WM, WN, WK><<<grid, NT, lds_bytes, s>>>(B);
     ESR_CHECK_LAUNCH();
-    const int groups = (grid * WK + 31) / 32;
-    wgrad_reduce_kernel<<<esr_grid_for((int64_t)n_elems * groups, 256, 2048), 256, 0, s>>>(W.slab, grid * WK,
-                                                                                         n_elems, W.gw);
-    ESR_CHECK_LAUNCH();
-    return 0;
+    return launch_reduce(R, s);
 }
 
 // f32: LDS-DMA staging; bf16 operand modes: the register-staged kernel
 template <int MI, int NJ, int WM, int WN, int WK, int MODE>
-int launch_wgrad_any(const WgradArgs &W, int64_t slab_floats, hipStream_t s)
+int launch_wgrad_any(WgradBatch &B, float *scratch, int64_t slab_floats, hipStream_t s)
 {
-    if constexpr (MODE == 0) return launch_wgrad_dma<MI, NJ, WM, WN, WK>(W, slab_floats, s);
-    else return launch_wgrad<MI, NJ, WM, WN, WK, MODE>(W, slab_floats, s);
+    if constexpr (MODE == 0) return launch_wgrad_dma<MI, NJ, WM, WN, WK>(B, scratch, slab_floats, s);
+    else return launch_wgrad<MI, NJ, WM, WN, WK, MODE>(B, scratch, slab_floats, s);
+}
+
+// kernel shapes (waves per workgroup wm x wn x wk, always 4 compute waves = 1 per SIMD):
+//   192-wide nets: 192x192 -> 2x2x1, 192x<=96 (first layer) -> 2x1x2, 192x<=64 (tone mapper's first) , zrows x 192 (output) -> 1x2x2
+//   128-wide nets: 128x128 -> 2x2x1, 128x96 -> 2x1x2, 8x128 -> 1x2x2
+enum { CFG_HID192, CFG_FIRST192, CFG_FIRST192_64, CFG_OUT192, CFG_HID128, CFG_FIRST128, CFG_OUT128, N_CFG };
+
+int layer_cfg(const NetDesc &D, bool first, bool last, int RB)
+{
+    if (D.hid_tiles == 6) return last ? CFG_OUT192 : first ? (RB <= 64 ? CFG_FIRST192_64 : CFG_FIRST192) : CFG_HID192;
+    return last ? CFG_OUT128 : first ? CFG_FIRST128 : CFG_HID128;
+}
+
+template <bool BF>
+int launch_cfg(int cfg, WgradBatch &B, float *scratch, int64_t slab_floats, hipStream_t s)
+{
+    switch (cfg) {
+    case CFG_HID192:      return launch_wgrad_any<3, 3, 2, 2, 1, BF ? 2 : 0>(B, scratch, slab_floats, s);
+    case CFG_FIRST192:    return launch_wgrad_any<3, 3, 2, 1, 2, BF ? 3 : 0>(B, scratch, slab_floats, s);
+    case CFG_FIRST192_64: return launch_wgrad_any<3, 2, 2, 1, 2, BF ? 3 : 0>(B, scratch, slab_floats, s);
+    case CFG_OUT192:      return launch_wgrad_any<1, 3, 1, 2, 2, BF ? 1 : 0>(B, scratch, slab_floats, s);
+    case CFG_HID128:      return launch_wgrad_any<2, 2, 2, 2, 1, BF ? 2 : 0>(B, scratch, slab_floats, s);
+    case CFG_FIRST128:    return launch_wgrad_any<2, 3, 2, 1, 2, BF ? 3 : 0>(B, scratch, slab_floats, s);
+    default:              return launch_wgrad_any<1, 2, 1, 2, 2, BF ? 1 : 0>(B, scratch, slab_floats, s);
+    }
 }
 
 }  // namespace
@@ -699,6 +783,29 @@ ESR_API int esr_mlp_fwd(int kind, const float *packed, const float *X, int32_t t
     return 0;
 }
 
+// One launch for a net that runs twice over disjoint tile ranges with the same weights: tiles [t0, t_mid) detached
+// (nothing saved, colour rows color_row_detached), tiles [t_mid, t1) saved with colour rows 0 -- the fine stage's
+// off-net (voxurff.py:244-254: `.detach()` on the on-rays, differentiable on the off-rays).
+ESR_API int esr_mlp_fwd_mixed(int kind, const float *packed, const float *X, int32_t t0, int32_t t_mid, int32_t t1,
+                              float *const *H, uint32_t *const *M, int color_row_detached, float *zout, void *stream)
+{
+    if (kind != ESR_MLP_RADIANCE || t0 < 0 || t_mid < t0 || t1 < t_mid) return ESR_EINVAL;
+    if (!color_row_ok(kind, color_row_detached)) return ESR_EINVAL;
+    if (t1 == t0) return 0;
+    if (!packed || !X || !zout || !H || !M) return ESR_EINVAL;
+    FwdArgs A = {};
+    A.packed = packed; A.X = X; A.t0 = t0; A.t1 = t1; A.save = 1; A.crow = 0; A.zout = zout;
+    A.t_det = t_mid; A.crow_det = color_row_detached;
+    for (int l = 0; l < 3; ++l) {
+        if (!H[l] || !M[l]) return ESR_EINVAL;
+        A.H[l] = H[l];
+        A.M[l] = M[l];
+    }
+    mlp_fwd_kernel<ESR_MLP_RADIANCE><<<mlp_grid(t1 - t0), 256, 0, esr_stream(stream)>>>(A);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
 ESR_API int esr_mlp_dgrad(int kind, const float *packed, const float *dz, int32_t t0, int32_t t1,
                           const uint32_t *const *M, float *const *dZ, float *dX, void *stream)
 {
@@ -727,48 +834,69 @@ ESR_API int esr_mlp_dgrad(int kind, const float *packed, const float *dz, int32_
 
 ESR_API int64_t esr_mlp_wgrad_scratch_floats(void) { return (int64_t)256 * 2 * 192 * 192; }
 
+// every layer of every net job, grouped by kernel shape: one launch per shape (up to MAX_JOBS layer jobs each)
+template <bool BF>
+static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, int64_t scratch_floats, void *stream)
+{
+    if (!jobs || n_jobs < 0 || !scratch) return ESR_EINVAL;
+    WgradBatch group[N_CFG][4];
+    int n_group[N_CFG] = {};
+    for (int c = 0; c < N_CFG; ++c)
+        for (int g = 0; g < 4; ++g) group[c][g].n = 0;
+    for (int q = 0; q < n_jobs; ++q) {
+        const esr_wgrad_job_t &J = jobs[q];
+        if (!kind_ok(J.kind) || J.t0 < 0 || J.t1 < J.t0) return ESR_EINVAL;
+        if (!color_row_ok(J.kind, J.color_row0)) return ESR_EINVAL;
+        if (J.t1 == J.t0) continue;
+        if (!J.X || !J.H || !J.dZ || !J.dz || !J.gw || !J.gb) return ESR_EINVAL;
+        const NetDesc D = net_desc(J.kind);
+        const int hid = 32 * D.hid_tiles;
+        for (int l = 0; l < D.n_layers; ++l) {
+            const bool first = l == 0, last = l == D.n_layers - 1;
+            WgradArgs W = {};
+            W.A = last ? J.dz : J.dZ[l];        W.RA = last ? D.zrows : hid;
+            W.B = first ? J.X : J.H[l - 1];     W.RB = first ? (D.xrows < 96 ? D.xrows : 96) : hid;
+            W.b_tile_rows = first ? D.xrows : hid;
+            W.crow = first ? J.color_row0 : 0;
+            W.cw8 = D.cw * 8;
+            W.t0 = J.t0; W.t1 = J.t1;
+            W.gw = J.gw[l]; W.ld = first ? D.in_dim : hid; W.out_rows = last ? D.out_dim : hid;
+            W.kind = J.kind; W.first = first ? 1 : 0; W.gb = J.gb[l];
+            if (!W.A || !W.B || !W.gw || !W.gb) return ESR_EINVAL;
+            const int c = layer_cfg(D, first, last, W.RB);
+            int g = n_group[c];
+            if (g == 0 || group[c][g - 1].n == MAX_JOBS) {
+                if (g == 4) return ESR_ECAP;
+                g = ++n_group[c];
+            }
+            WgradBatch &B = group[c][g - 1];
+            B.job[B.n++] = W;
+        }
+    }
+    hipStream_t s = esr_stream(stream);
+    for (int c = 0; c < N_CFG; ++c)
+        for (int g = 0; g < n_group[c]; ++g)
+            if (int rc = launch_cfg<BF>(c, group[c][g], scratch, scratch_floats, s)) return rc;
+    return 0;
+}
+
 template <bool BF>
 static int wgrad_all(int kind, const float *X, int color_row0, const float *const *H,
                      const float *const *dZ, const float *dz, int32_t t0, int32_t t1,
                      float *const *gw, float *const *gb, float *scratch, int64_t scratch_floats,
                      void *stream)
 {
-    if (!kind_ok(kind) || t0 < 0 || t1 < t0) return ESR_EINVAL;
-    if (!color_row_ok(kind, color_row0)) return ESR_EINVAL;
-    if (t1 == t0) return 0;
-    if (!X || !H || !dZ || !dz || !gw || !gb || !scratch) return ESR_EINVAL;
-    const NetDesc D = net_desc(kind);
-    const int hid = 32 * D.hid_tiles;
-    hipStream_t s = esr_stream(stream);
-    for (int l = 0; l < D.n_layers; ++l) {
-        const bool first = l == 0, last = l == D.n_layers - 1;
-        WgradArgs W = {};
-        W.A = last ? dz : dZ[l];          W.RA = last ? D.zrows : hid;
-        W.B = first ? X : H[l - 1];       W.RB = first ? (D.xrows < 96 ? D.xrows : 96) : hid;
-        W.b_tile_rows = first ? D.xrows : hid;
-        W.crow = first ? color_row0 : 0;
-        W.cw8 = D.cw * 8;
-        W.t0 = t0; W.t1 = t1;
-        W.gw = gw[l]; W.ld = first ? D.in_dim : hid; W.out_rows = last ? D.out_dim : hid;
-        W.kind = kind; W.first = first ? 1 : 0; W.gb = gb[l]; W.slab = scratch;
-        if (!W.A || !W.B || !W.gw || !W.gb) return ESR_EINVAL;
-        // waves per workgroup (wm x wn x wk), always 4 waves = 1 per SIMD:
-        //   192-wide nets: 192x192 -> 2x2x1, 192x<=96 (first layer) -> 2x1x2, zrows x 192 (output) -> 1x2x2
-        //   128-wide nets: 128x128 -> 2x2x1, 128x96 -> 2x1x2, 8x128 -> 1x2x2
-        int rc;
-        if (D.hid_tiles == 6) {
-            if (last) rc = launch_wgrad_any<1, 3, 1, 2, 2, BF ? 1 : 0>(W, scratch_floats, s);
-            else if (first && W.RB <= 64) rc = launch_wgrad_any<3, 2, 2, 1, 2, BF ? 3 : 0>(W, scratch_floats, s);   // tone mapper: 48 input rows
-            else if (first) rc = launch_wgrad_any<3, 3, 2, 1, 2, BF ? 3 : 0>(W, scratch_floats, s);
-            else rc = launch_wgrad_any<3, 3, 2, 2, 1, BF ? 2 : 0>(W, scratch_floats, s);
-        } else {
-            if (last) rc = launch_wgrad_any<1, 2, 1, 2, 2, BF ? 1 : 0>(W, scratch_floats, s);
-            else if (first) rc = launch_wgrad_any<2, 3, 2, 1, 2, BF ? 3 : 0>(W, scratch_floats, s);
-            else rc = launch_wgrad_any<2, 2, 2, 2, 1, BF ? 2 : 0>(W, scratch_floats, s);
-        }
-        if (rc) return rc;
-    }
-    return 0;
+    esr_wgrad_job_t J = {};
+    J.kind = kind; J.color_row0 = color_row0; J.t0 = t0; J.t1 = t1;
+    J.X = X; J.H = H; J.dZ = dZ; J.dz = dz; J.gw = gw; J.gb = gb;
+    return wgrad_jobs<BF>(&J, 1, scratch, scratch_floats, stream);
+}
+
+ESR_API int esr_mlp_wgrad_batch(const esr_wgrad_job_t *jobs, int32_t n_jobs, int bf16_operands, float *scratch,
+                                int64_t scratch_floats, void *stream)
+{
+    return bf16_operands ? wgrad_jobs<true>(jobs, n_jobs, scratch, scratch_floats, stream)
+                         : wgrad_jobs<false>(jobs, n_jobs, scratch, scratch_floats, stream);
 }
 
 ESR_API int esr_mlp_wgrad(int kind, const float *X, int color_row0, const float *const *H,

@@ -252,10 +252,14 @@ class FineEngine:
         ctx.feat_args = fa
         H, M = self._H(["H0", "H1", "H2"]), self._H(["M0", "M1", "M2"])
         # off net: detached pass on the on-tiles (alt colour rows, nothing saved), saved pass on the off-tiles
-        self._run("mlp_fwd(off|on-tiles)", self.mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), 0, tiles_on,
-                                 H, M, 0, 88, _lib.ptr(ws["z_off"]), s)
-        self._run("mlp_fwd(off)", self.mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), tiles_on,
-                                 tiles_all, H, M, 1, 0, _lib.ptr(ws["z_off"]), s)
+        if not self.bf16:       # one launch, same weights (no launch seam, one ramp-up / tail instead of two)
+            self._run("mlp_fwd(off)", L.esr_mlp_fwd_mixed, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]),
+                      0, tiles_on, tiles_all, H, M, 88, _lib.ptr(ws["z_off"]), s)
+        else:
+            self._run("mlp_fwd(off|on-tiles)", self.mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), 0, tiles_on,
+                                     H, M, 0, 88, _lib.ptr(ws["z_off"]), s)
+            self._run("mlp_fwd(off)", self.mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), tiles_on,
+                                     tiles_all, H, M, 1, 0, _lib.ptr(ws["z_off"]), s)
         self._run("mlp_fwd(emo)", self.mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["emo"]), _lib.ptr(ws["X"]), 0, tiles_on,
                                  H, M, 1, 0, _lib.ptr(ws["z_emo"]), s)
         self._run("tone_in_fwd", L.esr_fine_tone_in_fwd, _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), tiles_on, tiles_all,
@@ -386,6 +390,24 @@ class FineEngine:
                 after_grids()
 
         def wgrads(s):
+            # one call for the three nets: layers of the same kernel shape share a launch (esr_mlp_wgrad_batch)
+            Hh, dZh, Hth, dZth = self._H(["H0", "H1", "H2"]), self._H(["dZ0", "dZ1", "dZ2"]), self._H(["Ht"]), self._H(["dZt"])
+            keep = [Hh, dZh, Hth, dZth]
+            jobs = (_lib.EsrWgradJob * 3)()
+            for j, (kind, X, Hs, dZs, dzs, r0, r1, gwk, gbk) in enumerate((
+                    (KIND_RADIANCE, ws["X"], Hh, dZh, ws["dz"], 0, to, "emo_w", "emo_b"),
+                    (KIND_RADIANCE, ws["X"], Hh, dZh, ws["dz"], to, ta, "off_w", "off_b"),
+                    (KIND_TONEMAP, ws["Xt"], Hth, dZth, ws["dzt"], 0, ta, "tone_w", "tone_b"))):
+                gwa, gba = _lib.ptr_array(grads[gwk]), _lib.ptr_array(grads[gbk])
+                keep += [gwa, gba]
+                jb = jobs[j]
+                jb.kind, jb.color_row0, jb.t0, jb.t1 = kind, 0, r0, r1
+                jb.X, jb.dz = X.data_ptr(), dzs.data_ptr()
+                jb.H, jb.dZ = C.addressof(Hs), C.addressof(dZs)
+                jb.gw, jb.gb = C.addressof(gwa), C.addressof(gba)
+            self._run("mlp_wgrad(all)", L.esr_mlp_wgrad_batch, jobs, 3, 1 if self.bf16 else 0, _lib.ptr(self.wgrad_scratch),
+                      C.c_int64(self.wgrad_scratch.numel()), s)
+            return
             H, dZ = self._H(["H0", "H1", "H2"]), self._H(["dZ0", "dZ1", "dZ2"])
             sc = (_lib.ptr(self.wgrad_scratch), C.c_int64(self.wgrad_scratch.numel()))
             self._run("mlp_wgrad(tone)", self.mlp_wgrad, KIND_TONEMAP, _lib.ptr(ws["Xt"]), 0, self._H(["Ht"]), self._H(["dZt"]),

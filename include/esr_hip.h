@@ -13,7 +13,8 @@
  *     across the ABI.  The Python shim re-raises non-zero codes as RuntimeError,
  *     which is what the reference's TORCH_CHECK failures surface as
  *     (app/utils/base/cuda/render_utils.cpp:46-48).
- *   - re-entrant; no global state.
+ *   - re-entrant.  The only process-wide state is an idempotent per-(kernel, device) memo of the > 64 KB
+ *     dynamic-LDS opt-in (hipFuncSetAttribute); no environment variable is read on a launch path.
  *
  * Reference interfaces replaced (paths relative to the reference tree):
  *   app/utils/base/cuda/render_utils.cpp:170-184  pybind module render_utils_cuda
@@ -256,6 +257,14 @@ int esr_mlp_pack(int kind, const esr_mlp_weights_t *w, float *packed, void *stre
 int esr_mlp_fwd(int kind, const float *packed, const float *X, int32_t t0, int32_t t1,
                 float *const *H, uint32_t *const *M, int save, int color_row0, float *zout,
                 void *stream);
+/*
+ * The same net over two adjacent tile ranges in ONE launch: [t0,t_mid) detached (nothing saved, colour
+ * rows color_row_detached), [t_mid,t1) saved with colour rows 0.  This is the fine stage's off-net
+ * (app/fine/model/voxurff.py:244-254: `.detach()` on the emissive-on rays, differentiable on the off
+ * rays); RadianceNet only.
+ */
+int esr_mlp_fwd_mixed(int kind, const float *packed, const float *X, int32_t t0, int32_t t_mid, int32_t t1,
+                      float *const *H, uint32_t *const *M, int color_row_detached, float *zout, void *stream);
 
 /*
  * Input/hidden gradients over tiles [t0,t1).  dz [tiles,4,32] -> dZ[l] (each
@@ -274,6 +283,25 @@ int esr_mlp_wgrad(int kind, const float *X, int color_row0, const float *const *
                   const float *const *dZ, const float *dz, int32_t t0, int32_t t1,
                   float *const *gw, float *const *gb, float *scratch, int64_t scratch_floats,
                   void *stream);
+
+/*
+ * Weight gradients of SEVERAL nets / tile ranges in one call.  Layers of the same kernel shape share a launch (the
+ * same layer of the emissive and the non-emissive RadianceNet, both hidden layers, the 3-row output layers of all
+ * nets): a weight-gradient launch has a fixed cost of ~30 us whatever its tile count, and with J jobs per launch the
+ * per-workgroup partial sums that have to be exchanged shrink J-fold.  Results are those of one esr_mlp_wgrad (or
+ * esr_mlp_wgrad_bf16 with bf16_operands != 0) per job.  H, dZ, gw, gb are [host] arrays of device pointers.
+ */
+typedef struct esr_wgrad_job {
+    int32_t kind, color_row0, t0, t1;
+    const float *X;
+    const float *const *H;
+    const float *const *dZ;
+    const float *dz;
+    float *const *gw;
+    float *const *gb;
+} esr_wgrad_job_t;
+int esr_mlp_wgrad_batch(const esr_wgrad_job_t *jobs, int32_t n_jobs, int bf16_operands, float *scratch,
+                        int64_t scratch_floats, void *stream);
 
 /*
  * bf16 variants of the MLP engine for BASELINE.json's bf16 configurations (a build-side precision choice:
