@@ -46,6 +46,7 @@ struct FeatParams {
     const float *dsdf_extra;                          // [tiles*32] added to the SDF-value row, or null
     float *dsdf_out;                                  // explicit mode: gradient w.r.t. pt_sdf
     float *grad_sdf;
+    int t_begin, t_end;                               // backward: tiles that have a gradient source at all
 };
 
 // position, view direction and SDF value of sample j; false for padding lanes
@@ -392,7 +393,7 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     lds_cell *const lds = (lds_cell *)(win_all + (threadIdx.x >> 6) * WIN_CELLS);
     WinSet WS;
-    for (int t = wave; t < P.tiles_all; t += nwaves) {
+    for (int t = P.t_begin + wave; t < P.t_end; t += nwaves) {
         const int j = t * 32 + s;
         const float *Xt = P.X + (size_t)t * XROWS * 32 + s;
         const float *Gn = P.gnorm + (size_t)t * 4 * 32 + s;
@@ -615,8 +616,21 @@ ESR_API int esr_fine_feat_bwd(const esr_scene_t *scene, const esr_feat_args_t *a
         P.src_t0[k] = src[k].t0; P.src_t1[k] = src[k].t1;
     }
     P.dsdf_extra = dsdf_extra; P.dsdf_out = dsdf_out; P.grad_sdf = grad_sdf;
+    // tiles outside every source's range receive no gradient: the launch covers the sources' window only (the fine
+    // engine scatters the on-tiles while the off net's input gradients are still being computed)
+    P.t_begin = 0; P.t_end = P.tiles_all;
+    if (!dsdf_extra && !dsdf_out) {
+        int lo = P.tiles_all, hi = 0;
+        for (int k = 0; k < n_src; ++k) {
+            lo = src[k].t0 < lo ? src[k].t0 : lo;
+            hi = src[k].t1 > hi ? src[k].t1 : hi;
+        }
+        P.t_begin = lo < 0 ? 0 : lo;
+        P.t_end = hi > P.tiles_all ? P.tiles_all : hi;
+        if (P.t_end <= P.t_begin) return 0;
+    }
     // one wave per tile, 4 waves (4 x 20 KB LDS windows) per workgroup
-    feat_bwd_kernel<<<esr_grid_for((int64_t)P.tiles_all * 64, 256, 256 * 2), 256,
+    feat_bwd_kernel<<<esr_grid_for((int64_t)(P.t_end - P.t_begin) * 64, 256, 256 * 2), 256,
                       4 * WIN_CELLS * sizeof(double), esr_stream(stream)>>>(P);
     ESR_CHECK_LAUNCH();
     return 0;

@@ -809,7 +809,15 @@ ESR_API int esr_mlp_fwd_mixed(int kind, const float *packed, const float *X, int
 ESR_API int esr_mlp_dgrad(int kind, const float *packed, const float *dz, int32_t t0, int32_t t1,
                           const uint32_t *const *M, float *const *dZ, float *dX, void *stream)
 {
-    if (!kind_ok(kind) || t0 < 0 || t1 < t0) return ESR_EINVAL;
+    return esr_mlp_dgrad_wg(kind, packed, dz, t0, t1, M, dZ, dX, 0, stream);
+}
+
+// max_workgroups > 0 caps the grid (256 = one 4-wave workgroup per CU: half the register file and all of the LDS stay
+// free for a latency-bound kernel of another stream -- the grid scatters -- to run beside the matrix work).
+ESR_API int esr_mlp_dgrad_wg(int kind, const float *packed, const float *dz, int32_t t0, int32_t t1,
+                             const uint32_t *const *M, float *const *dZ, float *dX, int32_t max_workgroups, void *stream)
+{
+    if (!kind_ok(kind) || t0 < 0 || t1 < t0 || max_workgroups < 0) return ESR_EINVAL;
     if (t1 == t0) return 0;
     if (!packed || !dz || !M || !dZ || !dX) return ESR_EINVAL;
     const int nhid = net_desc(kind).n_layers - 1;
@@ -819,7 +827,8 @@ ESR_API int esr_mlp_dgrad(int kind, const float *packed, const float *dz, int32_
         if (!M[l] || !dZ[l]) return ESR_EINVAL;
         A.M[l] = M[l]; A.dZ[l] = dZ[l];
     }
-    const int grid = mlp_grid(t1 - t0);
+    int grid = mlp_grid(t1 - t0);
+    if (max_workgroups > 0 && grid > max_workgroups) grid = max_workgroups;
     hipStream_t s = esr_stream(stream);
     switch (kind) {
     case ESR_MLP_RADIANCE: mlp_dgrad_kernel<ESR_MLP_RADIANCE><<<grid, 256, 0, s>>>(A); break;

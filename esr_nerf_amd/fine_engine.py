@@ -118,6 +118,10 @@ class FineEngine:
         self._only = None
         self._events = []
         self.overlap_wgrad = os.environ.get("ESR_OVERLAP_WGRAD", "1") != "0"
+        # measured NEGATIVE on MI355X (C2: 4.08 ms without, 4.19 / 4.32 / 4.47 ms with the input-gradient kernels capped at
+        # 256 / 384 / uncapped workgroups): the atomics-heavy scatters slow the matrix kernels more than they hide
+        self.overlap_scatter = os.environ.get("ESR_OVERLAP_SCATTER", "0") != "0"
+        self.dgrad_cap = int(os.environ.get("ESR_DGRAD_CAP", "256"))
         self._side = None
 
     # -- helpers ---------------------------------------------------------------
@@ -209,9 +213,13 @@ class FineEngine:
         return fa
 
     # -- forward -----------------------------------------------------------------
-    def forward(self, scene, rays_o, rays_d, viewdirs, em_modes, mask_density, sdf, off_color, emo_color):
+    def forward(self, scene, rays_o, rays_d, viewdirs, em_modes, mask_density, sdf, off_color, emo_color, prelude=None):
         """-> (ctx, alphainv_last [N], srgb_marched [N,3], lin_marched [N,3]).
-        sdf [X,Y,Z], off_color/emo_color [X,Y,Z,6], mask_density [mx,my,mz]: contiguous fp32."""
+        sdf [X,Y,Z], off_color/emo_color [X,Y,Z,6], mask_density [mx,my,mz]: contiguous fp32.
+        ``prelude()``: enqueues work that does not depend on the march (weight packing, zeroing the gradient buffer).
+        It is called between the plan kernel and the host's wait for the plan header, so the device has ~80 us of work
+        while the host reads the survivor counts and enqueues the rest of the step (that wait left the GPU idle for
+        ~60 us per step: tools/trace_gaps.py)."""
         L, s, ws = self.L, self._s(), self.ws
         n = rays_o.shape[0]
         for t in (rays_o, rays_d, viewdirs):
@@ -231,7 +239,11 @@ class FineEngine:
         self._run("plan", L.esr_fine_plan, _lib.ptr(rb["cnt3"]), _lib.ptr(em_modes), _lib.ptr(rb["stats"]), n, _lib.ptr(rb["off3"]),
                                    _lib.ptr(self.plan_dev), s)
         self.plan_host.copy_(self.plan_dev, non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()        # the one sync of the step
+        landed = torch.cuda.Event()
+        landed.record()
+        if prelude is not None:
+            prelude()
+        landed.synchronize()                                        # the one host wait of the step
         n_on, n_off, tiles_on, tiles_all, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
         if overflow:
             raise RuntimeError("a ray exceeded scene.max_steps; the LDS bound of the march kernel is wrong")
@@ -253,7 +265,7 @@ class FineEngine:
         H, M = self._H(["H0", "H1", "H2"]), self._H(["M0", "M1", "M2"])
         # off net: detached pass on the on-tiles (alt colour rows, nothing saved), saved pass on the off-tiles
         if not self.bf16:       # one launch, same weights (no launch seam, one ramp-up / tail instead of two)
-            self._run("mlp_fwd(off)", L.esr_mlp_fwd_mixed, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]),
+                self._run("mlp_fwd(off)", L.esr_mlp_fwd_mixed, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]),
                       0, tiles_on, tiles_all, H, M, 88, _lib.ptr(ws["z_off"]), s)
         else:
             self._run("mlp_fwd(off|on-tiles)", self.mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), 0, tiles_on,
@@ -353,43 +365,48 @@ class FineEngine:
         g_last, g_srgb, g_lin = g_last.contiguous(), g_srgb.contiguous(), g_lin.contiguous()
         main = torch.cuda.current_stream(self.device)
         s = self._s()
-        if ta > 0:
-            self._run("composite_bwd", L.esr_fine_composite_bwd, _lib.ptr(g_srgb), _lib.ptr(g_lin), _lib.ptr(ws["rgb"]),
-                                                _lib.ptr(ws["lin"]), _lib.ptr(ws["rec_ray"]),
-                                                _lib.ptr(ws["rec_w"]), ta, _lib.ptr(ws["dweight"]),
-                                                _lib.ptr(ws["dzt"]), s)
-            self._run("mlp_dgrad(tone)", self.mlp_dgrad, KIND_TONEMAP, _lib.ptr(self.packed["tone"]), _lib.ptr(ws["dzt"]), 0, ta,
-                                       self._H(["Mt"]), self._H(["dZt"]), _lib.ptr(ws["dXt"]), s)
-            self._run("tone_in_bwd", L.esr_fine_tone_in_bwd, _lib.ptr(ws["dXt"]), _lib.ptr(g_lin), _lib.ptr(ws["lin"]),
-                                              _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]),
-                                              _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), to, ta,
-                                              _lib.ptr(ws["dz"]), s)
-            M, dZ = self._H(["M0", "M1", "M2"]), self._H(["dZ0", "dZ1", "dZ2"])
-            self._run("mlp_dgrad(emo)", self.mlp_dgrad, KIND_RADIANCE, _lib.ptr(self.packed["emo"]), _lib.ptr(ws["dz"]), 0, to,
-                                       M, dZ, _lib.ptr(ws["dX"]), s)
-            self._run("mlp_dgrad(off)", self.mlp_dgrad, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["dz"]), to, ta,
-                                       M, dZ, _lib.ptr(ws["dX"]), s)
-            dweight = ws["dweight"]
-        else:
-            dweight = torch.zeros(32, dtype=torch.float32, device=self.device)
+        dweight = ws["dweight"] if ta > 0 else torch.zeros(32, dtype=torch.float32, device=self.device)
+        # Queues (HIP streams of this device):
+        #   main     composite_bwd -> dgrad(tone) -> tone_in_bwd -> dgrad(emo) -> dgrad(off) -> feat_bwd -> march_bwd
+        #   wgrad    (overlap_wgrad) the weight gradients, after dgrad(off), beside the grid scatters
+        #   scatter  (overlap_scatter, OFF by default: measured slower) march_bwd as soon as composite_bwd has produced
+        #            d/d weight, feat_bwd(on-tiles) after dgrad(emo), feat_bwd(off-tiles) after dgrad(off), with the
+        #            input-gradient kernels capped at one workgroup per CU so that both fit a CU
+        overlap = self.overlap_wgrad and ta > 0
+        cap = self.dgrad_cap if overlap and self.overlap_scatter else 0
+        scat = self._side_stream(1) if overlap and self.overlap_scatter else None
 
-        def scatters(s):
-            if ta > 0:
+        def on(stream, after, fn):
+            """run fn on `stream` once `after` (an event) has happened; returns an event marking fn's end"""
+            stream.wait_event(after)
+            with torch.cuda.stream(stream):
+                fn(_lib.stream_ptr(self.device))
+                e = torch.cuda.Event()
+                e.record(stream)
+            return e
+
+        def mark():
+            e = torch.cuda.Event()
+            e.record(main)
+            return e
+
+        def march_bwd(s_):
+            self._run("march_bwd", L.esr_fine_march_bwd, sp, _lib.ptr(ctx.rays_o), _lib.ptr(ctx.rays_d),
+                      _lib.ptr(ctx.mask_density), _lib.ptr(ctx.sdf), ctx.n_rays, _lib.ptr(ctx.off3), _lib.ptr(dweight),
+                      _lib.ptr(g_last), _lib.ptr(grads["sdf"]), s_)
+
+        def feat_bwd(t0, t1):
+            def run(s_):
                 src = (_lib.EsrFeatBwdSrc * 1)()
                 src[0].dX = ws["dX"].data_ptr()
                 src[0].grad_color_on = grads["emo_color"].data_ptr()      # on-tiles carry the emo net's gradient
                 src[0].grad_color_off = grads["off_color"].data_ptr()
-                src[0].t0, src[0].t1 = 0, ta
+                src[0].t0, src[0].t1 = t0, t1
                 self._run("feat_bwd", L.esr_fine_feat_bwd, sp, C.byref(ctx.feat_args), _lib.ptr(ws["X"]),
-                          _lib.ptr(ws["gnorm"]), src, 1, None, _lib.ptr(grads["sdf"]), None, s)
-            self._run("march_bwd", L.esr_fine_march_bwd, sp, _lib.ptr(ctx.rays_o), _lib.ptr(ctx.rays_d),
-                                            _lib.ptr(ctx.mask_density), _lib.ptr(ctx.sdf), ctx.n_rays,
-                                            _lib.ptr(ctx.off3), _lib.ptr(dweight), _lib.ptr(g_last),
-                                            _lib.ptr(grads["sdf"]), s)
-            if after_grids is not None:
-                after_grids()
+                          _lib.ptr(ws["gnorm"]), src, 1, None, _lib.ptr(grads["sdf"]), None, s_)
+            return run
 
-        def wgrads(s):
+        def wgrads(s_):
             # one call for the three nets: layers of the same kernel shape share a launch (esr_mlp_wgrad_batch)
             Hh, dZh, Hth, dZth = self._H(["H0", "H1", "H2"]), self._H(["dZ0", "dZ1", "dZ2"]), self._H(["Ht"]), self._H(["dZt"])
             keep = [Hh, dZh, Hth, dZth]
@@ -406,39 +423,57 @@ class FineEngine:
                 jb.H, jb.dZ = C.addressof(Hs), C.addressof(dZs)
                 jb.gw, jb.gb = C.addressof(gwa), C.addressof(gba)
             self._run("mlp_wgrad(all)", L.esr_mlp_wgrad_batch, jobs, 3, 1 if self.bf16 else 0, _lib.ptr(self.wgrad_scratch),
-                      C.c_int64(self.wgrad_scratch.numel()), s)
-            return
-            H, dZ = self._H(["H0", "H1", "H2"]), self._H(["dZ0", "dZ1", "dZ2"])
-            sc = (_lib.ptr(self.wgrad_scratch), C.c_int64(self.wgrad_scratch.numel()))
-            self._run("mlp_wgrad(tone)", self.mlp_wgrad, KIND_TONEMAP, _lib.ptr(ws["Xt"]), 0, self._H(["Ht"]), self._H(["dZt"]),
-                                       _lib.ptr(ws["dzt"]), 0, ta, _lib.ptr_array(grads["tone_w"]),
-                                       _lib.ptr_array(grads["tone_b"]), *sc, s)
-            self._run("mlp_wgrad(emo)", self.mlp_wgrad, KIND_RADIANCE, _lib.ptr(ws["X"]), 0, H, dZ, _lib.ptr(ws["dz"]), 0, to,
-                                       _lib.ptr_array(grads["emo_w"]), _lib.ptr_array(grads["emo_b"]), *sc, s)
-            self._run("mlp_wgrad(off)", self.mlp_wgrad, KIND_RADIANCE, _lib.ptr(ws["X"]), 0, H, dZ, _lib.ptr(ws["dz"]), to, ta,
-                                       _lib.ptr_array(grads["off_w"]), _lib.ptr_array(grads["off_b"]), *sc, s)
+                      C.c_int64(self.wgrad_scratch.numel()), s_)
+
+        def dgrad(name, kind, packed, dz, t0, t1, Ms, dZs, dX):
+            if self.bf16:
+                self._run(name, self.mlp_dgrad, kind, _lib.ptr(packed), _lib.ptr(dz), t0, t1, Ms, dZs, _lib.ptr(dX), s)
+            else:
+                self._run(name, L.esr_mlp_dgrad_wg, kind, _lib.ptr(packed), _lib.ptr(dz), t0, t1, Ms, dZs, _lib.ptr(dX), cap, s)
 
         if ta == 0:
-            scatters(s)
-        elif not self.overlap_wgrad:
-            scatters(s)
+            march_bwd(s)
+            if after_grids is not None:
+                after_grids()
+            return
+        self._run("composite_bwd", L.esr_fine_composite_bwd, _lib.ptr(g_srgb), _lib.ptr(g_lin), _lib.ptr(ws["rgb"]),
+                  _lib.ptr(ws["lin"]), _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), ta, _lib.ptr(ws["dweight"]),
+                  _lib.ptr(ws["dzt"]), s)
+        e_scat = on(scat, mark(), march_bwd) if scat is not None else None
+        dgrad("mlp_dgrad(tone)", KIND_TONEMAP, self.packed["tone"], ws["dzt"], 0, ta, self._H(["Mt"]), self._H(["dZt"]), ws["dXt"])
+        self._run("tone_in_bwd", L.esr_fine_tone_in_bwd, _lib.ptr(ws["dXt"]), _lib.ptr(g_lin), _lib.ptr(ws["lin"]),
+                  _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), to, ta,
+                  _lib.ptr(ws["dz"]), s)
+        M, dZ = self._H(["M0", "M1", "M2"]), self._H(["dZ0", "dZ1", "dZ2"])
+        dgrad("mlp_dgrad(emo)", KIND_RADIANCE, self.packed["emo"], ws["dz"], 0, to, M, dZ, ws["dX"])
+        if scat is not None and to > 0:
+            e_scat = on(scat, mark(), feat_bwd(0, to))
+        dgrad("mlp_dgrad(off)", KIND_RADIANCE, self.packed["off"], ws["dz"], to, ta, M, dZ, ws["dX"])
+        if not overlap:
+            feat_bwd(0, ta)(s)
+            march_bwd(s)
+            if after_grids is not None:
+                after_grids()
             wgrads(s)
+            return
+        e_dgrad = mark()
+        e_w = on(self._side_stream(0), e_dgrad, wgrads)
+        if scat is not None:
+            e_scat = on(scat, e_dgrad, feat_bwd(to, ta))
+            main.wait_event(e_scat)
         else:
-            side = self._side_stream()
-            fork = torch.cuda.Event()
-            fork.record(main)
-            side.wait_event(fork)
-            with torch.cuda.stream(side):
-                wgrads(self._s())
-                join = torch.cuda.Event()
-                join.record(side)
-            scatters(s)
-            main.wait_event(join)
+            feat_bwd(0, ta)(s)
+            march_bwd(s)
+        if after_grids is not None:
+            after_grids()
+        main.wait_event(e_w)
 
-    def _side_stream(self):
+    def _side_stream(self, i=0):
         if self._side is None:
-            self._side = torch.cuda.Stream(self.device)
-        return self._side
+            self._side = {}
+        if i not in self._side:
+            self._side[i] = torch.cuda.Stream(self.device)
+        return self._side[i]
 
     # -- fused trainer-step loss (app/fine/fine.py:355-382) ------------------------
     def loss_fwd_bwd(self, last, srgb, lin, rgbs, white_bg=True, weight_linear=0.1, weight_entropy_last=0.001):

@@ -134,20 +134,25 @@ class FineStep:
         eng = m.engine
         m.s_val = s_val
         ps = m._mlp_params()
-        eng.pack("off", KIND_RADIANCE, list(ps[0:8:2]), list(ps[1:8:2]))
-        eng.pack("emo", KIND_RADIANCE, list(ps[8:16:2]), list(ps[9:16:2]))
-        eng.pack("tone", KIND_TONEMAP, list(ps[16:20:2]), list(ps[17:20:2]))
+        g = None
+
+        def prelude():        # independent of the march: runs on the device while the host waits for the plan header
+            nonlocal g
+            eng.pack("off", KIND_RADIANCE, list(ps[0:8:2]), list(ps[1:8:2]))
+            eng.pack("emo", KIND_RADIANCE, list(ps[8:16:2]), list(ps[9:16:2]))
+            eng.pack("tone", KIND_TONEMAP, list(ps[16:20:2]), list(ps[17:20:2]))
+            g = self._alloc_grads(batch["rays_o"].device)
+
         ctx, last, srgb, lin = eng.forward(
             m.scene_struct(), batch["rays_o"], batch["rays_d"], batch["viewdirs"], batch["em_modes"],
             m.mask_cache.density.view(*m.mask_cache.density.shape[2:]),
-            m.sdf.device_view(), m.off_color.device_view(), m.emo_color.device_view())
+            m.sdf.device_view(), m.off_color.device_view(), m.emo_color.device_view(), prelude=prelude)
         m.last_counts = ctx.counts
         scale, w_ent = dp_loss_weights(last.shape[0], global_rays, entropy_owner, self.weight_entropy_last)
         loss, g_last, g_srgb, g_lin = eng.loss_fwd_bwd(last, srgb, lin, batch["rgbs"], self.white_bg,
                                                        self.weight_linear, w_ent)
         if scale != 1.0:
             loss, g_last, g_srgb, g_lin = loss * scale, g_last * scale, g_srgb * scale, g_lin * scale
-        g = self._alloc_grads(last.device)
         names = self._param_names()
         grads = dict(sdf=g["sdf.grid"], off_color=g["off_color.grid"], emo_color=g["emo_color.grid"],
                      off_w=[g[n] for n in names[0:8:2]], off_b=[g[n] for n in names[1:8:2]],

@@ -30,14 +30,17 @@ class _FineRender(torch.autograd.Function):
     def forward(ctx, model, batch, sdf, off_color, emo_color, *mlp_params):
         eng: FineEngine = model.engine
         off_p, emo_p, tone_p = mlp_params[0:8], mlp_params[8:16], mlp_params[16:20]
-        eng.pack("off", KIND_RADIANCE, list(off_p[0::2]), list(off_p[1::2]))
-        eng.pack("emo", KIND_RADIANCE, list(emo_p[0::2]), list(emo_p[1::2]))
-        eng.pack("tone", KIND_TONEMAP, list(tone_p[0::2]), list(tone_p[1::2]))
+
+        def prelude():        # runs on the device while the host waits for the march's plan header
+            eng.pack("off", KIND_RADIANCE, list(off_p[0::2]), list(off_p[1::2]))
+            eng.pack("emo", KIND_RADIANCE, list(emo_p[0::2]), list(emo_p[1::2]))
+            eng.pack("tone", KIND_TONEMAP, list(tone_p[0::2]), list(tone_p[1::2]))
+
         scene = model.scene_struct()
         fctx, last, srgb, lin = eng.forward(
             scene, batch["rays_o"], batch["rays_d"], batch["viewdirs"], batch["em_modes"],
             model.mask_cache.density.view(*model.mask_cache.density.shape[2:]),
-            model.sdf.device_view(), model.off_color.device_view(), model.emo_color.device_view())
+            model.sdf.device_view(), model.off_color.device_view(), model.emo_color.device_view(), prelude=prelude)
         ctx.fctx = fctx
         ctx.model = model
         ctx.shapes = [tuple(p.shape) for p in mlp_params]

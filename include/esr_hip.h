@@ -272,6 +272,10 @@ int esr_mlp_fwd_mixed(int kind, const float *packed, const float *X, int32_t t0,
  */
 int esr_mlp_dgrad(int kind, const float *packed, const float *dz, int32_t t0, int32_t t1,
                   const uint32_t *const *M, float *const *dZ, float *dX, void *stream);
+/* The same with the grid capped at max_workgroups (0 = no cap; 256 = one workgroup per CU, which leaves half of the
+ * register file and the LDS to a latency-bound kernel enqueued on another stream). */
+int esr_mlp_dgrad_wg(int kind, const float *packed, const float *dz, int32_t t0, int32_t t1,
+                     const uint32_t *const *M, float *const *dZ, float *dX, int32_t max_workgroups, void *stream);
 
 /*
  * Weight/bias gradients accumulated into the reference-layout tensors gw[l] [out,in],
