@@ -83,7 +83,9 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
         StreamPre pre = stream_prefetch<HT * (KP1 / 4)>(W, (int)L.off_wf[0] * 4, lane);
         stream_layer_pre<KP1 / 4, HT>(W, (int)L.off_wf[0] * 4, pre, [&](int k) { return B1[k]; }, acc2[0], lane);
         ESR_STAMP(1);
-        f32x16 out[1];
+        constexpr int NP4 = D.zrows / 4;
+        f32x4 z4[NP4];
+        float bias4[D.zrows];
 #pragma unroll
         for (int l = 0; l < NHID; ++l) {
             f32x16 (&cur)[HT] = acc2[l & 1];
@@ -92,8 +94,9 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
                 load_bias<HT>(W, (int)L.off_bf[l + 1] * 4, nxt, lane);
                 pre = stream_prefetch<HT * HT * 4>(W, (int)L.off_wf[l + 1] * 4, lane);
             } else {
-                load_bias<1>(W, (int)L.off_bf[NHID] * 4, out, lane);
-                pre = stream_prefetch<HT * 4>(W, (int)L.off_wf[NHID] * 4, lane);
+#pragma unroll
+                for (int c = 0; c < D.zrows; ++c) bias4[c] = bload1(W, 0, ((int)L.off_b4 + c) * 4);
+                pre = stream_prefetch<NP4 * HT * 4>(W, (int)L.off_w4 * 4, lane);
             }
             __builtin_amdgcn_sched_barrier(0);            // keep the requests in front of the epilogue's stores
             __builtin_amdgcn_s_setprio(3);                // (see the note on wave priorities above the kernel)
@@ -108,18 +111,19 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
                 stream_layer_pre<HT * 4, HT>(W, (int)L.off_wf[l + 1] * 4, pre,
                                              [&](int k) { return cur[k >> 4][k & 15]; }, nxt, lane);
             else
-                stream_layer_pre<HT * 4, 1>(W, (int)L.off_wf[NHID] * 4, pre,
-                                            [&](int k) { return cur[k >> 4][k & 15]; }, out, lane);
+                out4_layer<HT, NP4>(W, (int)L.off_w4 * 4, pre, cur, z4, lane);
             ESR_STAMP(3 + 2 * l);
         }
-        // output rows 0-3 live in lanes 0-31 (regs 0-3), rows 4-7 in lanes 32-63 (regs 0-3)
+        // each half of the wave holds the sum over ITS 16*HT units: add the halves, then the bias (rows >= out_dim
+        // have zero weights and bias: the padding row of the output tile is written as 0)
         float *z = A.zout + (size_t)t * D.zrows * 32 + s;
-        if (D.zrows == 8) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) z[(4 * h + r) * 32] = out[0][r];
-        } else if (h == 0) {
-            z[0] = out[0][0]; z[32] = out[0][1]; z[64] = out[0][2]; z[96] = 0.f;
-        }
+        for (int p = 0; p < NP4; ++p)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float v = (z4[p][c] + __shfl_xor(z4[p][c], 32)) + bias4[4 * p + c];
+                if (h == 0) z[(4 * p + c) * 32] = v;
+            }
     }
 }
 

@@ -88,6 +88,10 @@ struct PackLayout {
     int kp[4], tiles_out[4], in_dim[4], out_dim[4];
     int kpo[4], tiles_in[4];
     int64_t off_wf[4], off_bf[4], off_wb[4];
+    // output layer for the f32 forward as v_mfma_f32_4x4x1 operands (see out4_layer): [pass][quad][64 lanes][4] and
+    // its bias [8]; the 32x32 forms above stay for the bf16 engine's bias loads
+    int n_pass4;
+    int64_t off_w4, off_b4;
     int64_t total;
 };
 __host__ __device__ constexpr PackLayout pack_layout(int kind)
@@ -109,6 +113,9 @@ __host__ __device__ constexpr PackLayout pack_layout(int kind)
         L.off_bf[l] = o; o += (int64_t)L.tiles_out[l] * 32;
         L.off_wb[l] = o; o += (int64_t)L.tiles_in[l] * L.kpo[l] * 64;
     }
+    L.n_pass4 = d.zrows / 4;
+    L.off_w4 = o; o += (int64_t)L.n_pass4 * d.hid_tiles * 16 * 64;
+    L.off_b4 = o; o += 8;
     L.total = o;
     return L;
 }
@@ -124,6 +131,24 @@ __global__ void __launch_bounds__(256) pack_kernel(PackArgs A)
     const PackLayout L = pack_layout(A.kind);
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < L.total;
          e += (int64_t)gridDim.x * blockDim.x) {
+        if (e >= L.off_w4) {                                 // output layer, 4x4x1 operand order
+            const int ll = L.n_layers - 1, hid = L.in_dim[ll], outd = L.out_dim[ll];
+            float v = 0.f;
+            if (e < L.off_b4) {
+                int64_t i = e - L.off_w4;
+                const int sub = i & 3; i >>= 2;
+                const int lane = i & 63; i >>= 6;
+                const int nq = hid / 8;                              // quads of k-registers per pass (hid/2 registers)
+                const int pass = (int)(i / nq), q = (int)(i % nq);
+                const int c = 4 * pass + (lane & 3), u = hid_feature(4 * q + sub, lane >> 5);
+                if (c < outd) v = A.w[ll][(int64_t)c * hid + u];
+            } else {
+                const int c = (int)(e - L.off_b4);
+                if (c < outd) v = A.b[ll][c];
+            }
+            A.out[e] = v;
+            continue;
+        }
         int l = 0;
         while (l + 1 < L.n_layers && e >= L.off_wf[l + 1]) ++l;
         const bool first = l == 0, last = l == L.n_layers - 1;
@@ -163,6 +188,15 @@ __global__ void __launch_bounds__(256) pack_kernel(PackArgs A)
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c)
 {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// 16 independent 4x4 outer products per instruction: D_b[i][j] += A_b[i] * B_b[j] for block b = lane / 4, with A row i
+// supplied by lane 4b+i, B column j by lane 4b+j, and D[i][j] in register i of lane 4b+j; 2 passes = 8 cycles, the same
+// 64 FLOP/clk/SIMD as the 32x32x2 form (MI355X_MICROARCH.md, Matrix cores)
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
 
 // Buffer addressing (SGPR descriptor + per-lane 32-bit offset + scalar constant offset):
@@ -293,6 +327,52 @@ __device__ __forceinline__ void stream_layer_pre(rsrc_t W, int woff, const Strea
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+// Output layer (out_dim <= 4 per pass) of the f32 forward on v_mfma_f32_4x4x1.  As a 32-row tile the 3-row output layer
+// costs HT*16 full MFMAs (6144 cycles for the 192-wide nets, as much as a fifth of a hidden layer) for 9 % useful
+// rows.  Here every hidden register r of a lane is one B operand as it stands -- lane l supplies H[unit(r, half)][its
+// sample] -- and the A operand carries W[c = l % 4][unit(r, half of l)]: block b = l / 4 accumulates
+// z[c][sample of lane 4b+j] over the units its half of the wave holds, 8 cycles per register instead of 64 per pair.
+// The two halves' partial sums are added with one cross-half exchange per output row.  Four independent accumulators
+// per pass (a 2-pass MFMA has a longer dependent-issue latency than its issue time).
+template <int HT, int NP>
+__device__ __forceinline__ void out4_layer(rsrc_t W, int woff, const StreamPre &pre, const f32x16 (&cur)[HT],
+                                           f32x4 (&z)[NP], int lane)
+{
+    constexpr int NQ = NP * HT * 4, G = STREAM_G, NG = (NQ + G - 1) / G;
+    const int voff = lane * 16;
+    f32x4 acc[NP][4];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[p][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 buf[2][G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) buf[0][i] = pre.q[i];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int n = (g + 1) * G + i;
+            if (n < NQ) buf[(g + 1) & 1][i] = bload4(W, voff, woff + n * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int n = g * G + i;
+            if (n < NQ) {
+                const int p = n / (HT * 4), q = n % (HT * 4);
+                const float4 a = buf[g & 1][i];
+                acc[p][0] = mfma4(a.x, cur[(4 * q + 0) >> 4][(4 * q + 0) & 15], acc[p][0]);
+                acc[p][1] = mfma4(a.y, cur[(4 * q + 1) >> 4][(4 * q + 1) & 15], acc[p][1]);
+                acc[p][2] = mfma4(a.z, cur[(4 * q + 2) >> 4][(4 * q + 2) & 15], acc[p][2]);
+                acc[p][3] = mfma4(a.w, cur[(4 * q + 3) >> 4][(4 * q + 3) & 15], acc[p][3]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) z[p] = (acc[p][0] + acc[p][1]) + (acc[p][2] + acc[p][3]);
 }
 
 // bias (packed in accumulator order at byte offset boff)
