@@ -129,8 +129,7 @@ class LtsEngine(FineEngine):
         self.pts = Pass(self.device, "points")
         self.sec = Pass(self.device, "secondary")
         self.epsp = Pass(self.device, "eps")
-        self._deferred = None
-        self._wgrad_side = None
+        self._wgrad_jobs = None
         for k, kind in (("brdf", KIND_BRDF), ("emit", KIND_EMIT)):
             self.packed[k] = torch.empty(self.L.esr_mlp_packed_floats(kind), dtype=torch.float32,
                                          device=self.device)
@@ -229,26 +228,15 @@ class LtsEngine(FineEngine):
             s = self._s()
             self._run(f"mlp_dgrad({net})[{P.name}]", self.mlp_dgrad, kind, _lib.ptr(self.packed[net]),
                       _lib.ptr(dz), t0, t1, _lib.ptr_array(M), _lib.ptr_array(dZ), _lib.ptr(dX), s)
-            def wgrad():
+            if self._wgrad_jobs is not None:
+                # inside lts_backward: the weight gradients of EVERY net and pass of the step go out as ONE batched call
+                # at the end (esr_mlp_wgrad_batch: layers of the same kernel shape share a launch -- eleven net calls
+                # with ~100-135 us of fixed cost each become four launch groups)
+                self._wgrad_jobs.append((f"{net}[{P.name}]", kind, x, crow, H, dZ, dz, t0, t1, gw, gb))
+            else:
                 self._run(f"mlp_wgrad({net})[{P.name}]", self.mlp_wgrad, kind, _lib.ptr(x), crow,
                           _lib.ptr_array(H), _lib.ptr_array(dZ), _lib.ptr(dz), t0, t1, _lib.ptr_array(gw),
                           _lib.ptr_array(gb), _lib.ptr(self.wgrad_scratch), C.c_int64(self.wgrad_scratch.numel()), self._s())
-            # Inside lts_backward the weight-gradient launches leave the main stream: with ``overlap_wgrad`` each one
-            # goes to a second HIP stream right behind its dgrad (matrix work beside the many small / atomic-bound
-            # kernels of the LTS backward); otherwise they are deferred to the end of the step.  Either way the
-            # dense-grid gradients are complete, and their exchange can start, without waiting for ~2.5 ms of wgrad.
-            if self._wgrad_side is not None:
-                main, side = torch.cuda.current_stream(self.device), self._wgrad_side
-                ev = torch.cuda.Event()
-                ev.record(main)
-                side.wait_event(ev)
-                dz.record_stream(side)          # may be a transient torch allocation of the main stream
-                with torch.cuda.stream(side):
-                    wgrad()
-            elif self._deferred is not None:
-                self._deferred.append(wgrad)
-            else:
-                wgrad()
         return dX
 
     def _act(self, P, zname, out, rows, n_ch, act, bwd_g=None, tiles=None):
@@ -722,19 +710,46 @@ class LtsEngine(FineEngine):
         data-parallel step exchanges the dense-grid gradients there); the weight-gradient launches run beside it on
         a second stream (or, without ``overlap_wgrad``, after it) and are joined at the end."""
         main = torch.cuda.current_stream(self.device)
-        self._deferred = []
-        self._wgrad_side = self._side_stream() if self.overlap_wgrad else None
+        self._wgrad_jobs = []
         try:
             self._lts_backward(ctx, g, grads)
+            jobs_done = None
+            if self._wgrad_jobs:
+                if self.overlap_wgrad:          # beside the dense-grid exchange / whatever follows on the main stream
+                    side = self._side_stream()
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        self._launch_wgrad_jobs()
+                        jobs_done = torch.cuda.Event()
+                        jobs_done.record(side)
+                else:
+                    if after_grids is not None:
+                        after_grids()
+                        after_grids = None
+                    self._launch_wgrad_jobs()
             if after_grids is not None:
                 after_grids()
-            for w in self._deferred:
-                w()
-            if self._wgrad_side is not None:
-                main.wait_stream(self._wgrad_side)
+            if jobs_done is not None:
+                main.wait_event(jobs_done)
         finally:
-            self._deferred = None
-            self._wgrad_side = None
+            self._wgrad_jobs = None
+
+    def _launch_wgrad_jobs(self):
+        jobs = self._wgrad_jobs
+        self.last_wgrad_jobs = [(name, t1 - t0) for name, _, _, _, _, _, _, t0, t1, _, _ in jobs]     # (net[pass], tiles)
+        arr = (_lib.EsrWgradJob * len(jobs))()
+        keep = []
+        for jb, (_, kind, x, crow, H, dZ, dz, t0, t1, gw, gb) in zip(arr, jobs):
+            ptrs = [_lib.ptr_array(H), _lib.ptr_array(dZ), _lib.ptr_array(gw), _lib.ptr_array(gb)]
+            keep.append(ptrs)
+            jb.kind, jb.color_row0, jb.t0, jb.t1 = kind, crow, t0, t1
+            jb.X, jb.dz = x.data_ptr(), dz.data_ptr()
+            jb.H, jb.dZ, jb.gw, jb.gb = (C.addressof(p) for p in ptrs)
+            dz.record_stream(torch.cuda.current_stream(self.device))      # may be a transient allocation of the main stream
+        self._run("mlp_wgrad(all)", self.L.esr_mlp_wgrad_batch, arr, len(jobs), 1 if self.bf16 else 0,
+                  _lib.ptr(self.wgrad_scratch), C.c_int64(self.wgrad_scratch.numel()), self._s())
 
     def _lts_backward(self, ctx: LtsCtx, g: Dict[str, Optional[torch.Tensor]], grads):
         L, s, dev = self.L, self._s(), self.device
