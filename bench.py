@@ -31,9 +31,35 @@ sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TF = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, Peak FP32 (matrix)
 MFMA_BF16_PEAK_TF = 2500.0        # same guide, dense BF16 MFMA
-RAD_MAC = 85 * 192 + 192 * 192 * 2 + 192 * 3          # RadianceNet MACs per sample (pbr/module.py:6-21)
-TONE_MAC = 33 * 192 + 192 * 3                          # TonemapNet MACs per sample
-DGRAD_RAD_MAC = 3 * 192 + 192 * 192 * 2 + 192 * 43     # dX needs only the 43 grid-fed columns
+HBM_PEAK_GBS = 8000.0             # same guide, HBM3E spec
+# net -> (inputs, hidden width, hidden layers, outputs, input rows that receive a gradient)    app/utils/pbr/module.py:6-83
+NETS = {"off": (85, 192, 3, 3, 43), "emo": (85, 192, 3, 3, 43), "tone": (33, 192, 1, 3, 33),
+        "brdf": (76, 128, 3, 5, 43), "emit": (76, 128, 3, 3, 43)}
+
+
+def net_macs(net, op):
+    """Algorithmic MACs per sample of one MLP pass (padding excluded).  fwd and wgrad: every weight once; dgrad: the
+    transposed weights, the first layer only towards the grid-fed input rows."""
+    i, h, nh, o, gi = NETS[net]
+    if op == "dgrad":
+        return o * h + (nh - 1) * h * h + h * gi
+    return i * h + (nh - 1) * h * h + h * o
+
+
+def net_bytes(net, op, bf16):
+    """Algorithmic HBM bytes per sample of one MLP launch: inputs read + activations / gradients saved for (or read
+    by) the other passes.  Hidden tiles are stored as bf16 (2 B) by the bf16 engine, fp32 (4 B) otherwise; the
+    network input X, the output z and their gradients are fp32 in both; ReLU masks 1 bit per unit."""
+    i, h, nh, o, gi = NETS[net]
+    hb = 2 if bf16 else 4
+    if op == "fwd":
+        return i * 4 + nh * h * hb + nh * h // 8 + 4 * 4
+    if op == "dgrad":
+        return 4 * 4 + nh * h // 8 + nh * h * hb + gi * 4
+    return i * 4 + 4 * 4 + 2 * nh * h * hb          # wgrad: X, dz, H and dZ of every hidden layer
+
+
+RAD_MAC, TONE_MAC = net_macs("off", "fwd"), net_macs("tone", "fwd")
 
 
 def parse():
@@ -44,8 +70,12 @@ def parse():
     ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5", "small", "tiny"],
                     help="BASELINE.json configs: C2 fine fp32 (headline), C3 fine 192 samples, C4 lts, C5 = C4 scene, pdra stage, "
                          "bf16 MLPs")
-    ap.add_argument("--stage", default=None, choices=["fine", "lts", "pdra"],
-                    help="trainer step to run (default: fine; C4 defaults to lts)")
+    ap.add_argument("--stage", default=None, choices=["fine", "lts", "pdra", "finetune"],
+                    help="trainer step to run (default: fine; C4 defaults to lts; finetune = the re-lighting fine-tune "
+                         "half of C5, pdra.py:1047-1109: forward_finetune + its loss + backward)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = the config's rays PER GPU (default, what the driver runs); strong = the config's "
+                         "rays in TOTAL, split over the ranks (SURVEY 8(d) asks for both)")
     ap.add_argument("--s-val", type=float, default=None, help="default 20 (fine.yaml:45) / 220 (lts.yaml:52)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=1024)
@@ -60,54 +90,66 @@ def parse():
     return ap.parse_args()
 
 
+def fine_calls(counts, merged_off):
+    """engine call name -> [(net, op, samples)] of the fine-stage step."""
+    n_on, n_off = counts["n_on"], counts["n_off"]
+    n_all = n_on + n_off
+    c = {"mlp_fwd(off|on-tiles)": [("off", "fwd", n_on)],
+         "mlp_fwd(off)": [("off", "fwd", n_all if merged_off else n_off)],
+         "mlp_fwd(emo)": [("emo", "fwd", n_on)], "mlp_fwd(tone)": [("tone", "fwd", n_all)],
+         "mlp_dgrad(emo)": [("emo", "dgrad", n_on)], "mlp_dgrad(off)": [("off", "dgrad", n_off)],
+         "mlp_dgrad(tone)": [("tone", "dgrad", n_all)],
+         "mlp_wgrad(all)": [("emo", "wgrad", n_on), ("off", "wgrad", n_off), ("tone", "wgrad", n_all)]}
+    return c
+
+
 def algorithmic_flops(name, counts):
-    """Algorithmic FLOPs of one launch of a named MLP kernel (padding and the
-    detached-pass bookkeeping excluded): 2 * MACs * samples it processes."""
-    n_on, n_off = counts["n_on"], counts["n_off"]
-    # f32 engine: the off net runs its detached on-tile pass and its saved off-tile pass in ONE launch (esr_mlp_fwd_mixed)
-    n_offnet = n_off + (n_on if counts.get("merged_off_pass") else 0)
-    table = {
-        "mlp_fwd(off|on-tiles)": 2 * RAD_MAC * n_on,
-        "mlp_fwd(off)": 2 * RAD_MAC * n_offnet,
-        "mlp_fwd(emo)": 2 * RAD_MAC * n_on,
-        "mlp_fwd(tone)": 2 * TONE_MAC * (n_on + n_off),
-        "mlp_dgrad(emo)": 2 * DGRAD_RAD_MAC * n_on,
-        "mlp_dgrad(off)": 2 * DGRAD_RAD_MAC * n_off,
-        "mlp_dgrad(tone)": 2 * (3 * 192 + 192 * 33) * (n_on + n_off),
-        "mlp_wgrad(emo)": 2 * RAD_MAC * n_on,
-        "mlp_wgrad(off)": 2 * RAD_MAC * n_off,
-        "mlp_wgrad(tone)": 2 * TONE_MAC * (n_on + n_off),
-        "mlp_wgrad(all)": 2 * RAD_MAC * (n_on + n_off) + 2 * TONE_MAC * (n_on + n_off),   # esr_mlp_wgrad_batch: the three nets
-    }
-    return table.get(name)
+    """Algorithmic FLOPs of one launch of a named MLP call (padding and the detached-pass bookkeeping excluded):
+    2 * MACs * samples it processes."""
+    calls = fine_calls(counts, counts.get("merged_off_pass", False)).get(name)
+    return sum(2 * net_macs(n, op) * k for n, op, k in calls) if calls else None
 
 
-def algorithmic_bytes(name, counts):
-    """Algorithmic HBM bytes of one launch of a named MLP kernel in bf16 mode, where the matrix work is 16x cheaper
-    and the activation traffic binds: inputs read + saved activations / gradients written (fp32 storage), per
-    surviving sample, padding excluded."""
-    n_on, n_off = counts["n_on"], counts["n_off"]
-    H3 = 3 * 192 * 4
-    table = {
-        "mlp_fwd(off|on-tiles)": (85 * 4 + 12) * n_on,
-        "mlp_fwd(off)": (85 * 4 + H3 + 12) * n_off,
-        "mlp_fwd(emo)": (85 * 4 + H3 + 12) * n_on,
-        "mlp_fwd(tone)": (33 * 4 + 192 * 4 + 12) * (n_on + n_off),
-        "mlp_dgrad(emo)": (12 + H3 + 43 * 4) * n_on,
-        "mlp_dgrad(off)": (12 + H3 + 43 * 4) * n_off,
-        "mlp_dgrad(tone)": (12 + 192 * 4 + 3 * 4) * (n_on + n_off),
-    }
-    return table.get(name)
+def algorithmic_bytes(name, counts, bf16=True):
+    """Algorithmic HBM bytes of one launch of a named MLP call (see net_bytes)."""
+    calls = fine_calls(counts, counts.get("merged_off_pass", False)).get(name)
+    if not calls:
+        return None
+    if name == "mlp_fwd(off)" and counts.get("merged_off_pass"):      # the detached on-tile half saves nothing
+        i = NETS["off"][0]
+        return (i * 4 + 16) * counts["n_on"] + net_bytes("off", "fwd", bf16) * counts["n_off"]
+    if name == "mlp_fwd(off|on-tiles)":
+        return (NETS["off"][0] * 4 + 16) * counts["n_on"]
+    return sum(net_bytes(n, op, bf16) * k for n, op, k in calls)
 
 
 # engine call name -> HIP kernel (as rocprofv3 names it).  Only single-dispatch calls are roofline
-# candidates; the wgrad call is 4 matrix kernels + 4 reduce kernels and is reported in all_mlp_kernels.
+# candidates; the batched wgrad call is several matrix + reduce kernels and is reported in all_mlp_kernels.
 KERNEL_OF = {
     "mlp_fwd(off|on-tiles)": "mlp_fwd_kernel<0>", "mlp_fwd(off)": "mlp_fwd_kernel<0>",
     "mlp_fwd(emo)": "mlp_fwd_kernel<0>", "mlp_fwd(tone)": "mlp_fwd_kernel<1>",
     "mlp_dgrad(emo)": "mlp_dgrad_kernel<0>", "mlp_dgrad(off)": "mlp_dgrad_kernel<0>",
     "mlp_dgrad(tone)": "mlp_dgrad_kernel<1>",
 }
+
+
+def best_threads(run, candidates):
+    """Time ``run()`` (one iteration, seconds) under each torch thread count and keep the fastest: the default (all
+    logical cores of the host) oversubscribes the small GEMMs of this path several-fold on a 128-256-thread box."""
+    best = None
+    for n in candidates:
+        torch.set_num_threads(n)
+        run()                                             # warm-up under this setting
+        t = run()
+        if best is None or t < best[1]:
+            best = (n, t)
+    torch.set_num_threads(best[0])
+    return best[0]
+
+
+def thread_candidates(with_all=True):
+    ncpu = os.cpu_count() or 8
+    return sorted({n for n in ((8, 16, 32, 64, ncpu) if with_all else (8, 16, 32, 64)) if n <= ncpu})
 
 
 def cpu_baseline(model, scene, s_val, n_rays, iters):
@@ -119,45 +161,54 @@ def cpu_baseline(model, scene, s_val, n_rays, iters):
                        scene.mask_alpha_init, scene.mask_density, scene.near, scene.num_voxels)
     P = fp.params_from_state_dict({k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()})
     batch = {k: v[:n_rays].contiguous() for k, v in scene.batch.items()}
-    times = []
-    for i in range(iters + 1):
+    probe = {k: v[:max(64, n_rays // 4)].contiguous() for k, v in scene.batch.items()}
+
+    def one(b=batch):
         for v in P.values():
             v.grad = None
         t0 = time.perf_counter()
-        res = fp.forward_training(P, c, batch, s_val)
-        loss, _ = fp.fine_loss(res, batch["rgbs"])
+        res = fp.forward_training(P, c, b, s_val)
+        loss, _ = fp.fine_loss(res, b["rgbs"])
         loss.backward()
-        times.append(time.perf_counter() - t0)
-    t = sum(times[1:]) / iters
-    return dict(value=n_rays / t, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+        return time.perf_counter() - t0
+
+    cand = thread_candidates()
+    threads = best_threads(lambda: one(probe), cand)     # the thread count is picked on a quarter of the sample
+    one()
+    t = sum(one() for _ in range(iters)) / iters
+    return dict(value=n_rays / t, unit="rays/s", cores=threads, kind="port",
                 sample=f"{n_rays} of the {scene.n_rays} rays of the same scene (full grid), fwd+loss+bwd, "
-                       f"{iters} iterations after 1 warm-up, {t:.2f} s/iter, torch {torch.__version__} CPU ops "
-                       f"+ oracle/esr_oracle.c")
+                       f"{iters} iterations after warm-up, {t:.2f} s/iter, best of torch thread counts {cand} "
+                       f"(host has {os.cpu_count()} logical cores), torch {torch.__version__} CPU ops + oracle/esr_oracle.c")
 
 
-def lts_mlp_flops(breakdown, eng, n_prof):
-    """Algorithmic FLOPs and milliseconds per step of every MLP launch of an LTS/PDRA step (names
-    ``mlp_<op>(<net>)[<pass>]``; samples per pass from the engine's survivor counts)."""
-    rad, tone = RAD_MAC, TONE_MAC
-    head = lambda o: 76 * 128 + 128 * 128 * 2 + 128 * o
-    mac = {"off": rad, "emo": rad, "tone": tone, "brdf": head(5), "emit": head(3)}
-    dg = {"off": DGRAD_RAD_MAC, "emo": DGRAD_RAD_MAC, "tone": 3 * 192 + 192 * 33,
-          "brdf": 5 * 128 + 128 * 128 * 2 + 128 * 43, "emit": 3 * 128 + 128 * 128 * 2 + 128 * 43}
+def lts_mlp_work(breakdown, eng, n_prof, bf16):
+    """Algorithmic FLOPs, algorithmic HBM bytes and milliseconds per step of every MLP launch of an LTS / PDRA /
+    fine-tune step.  Call names: ``mlp_<op>(<net>)[<pass>]`` (samples per pass from the engine's survivor counts) and
+    ``mlp_wgrad(all)`` = the batched weight gradients (jobs listed by the engine as (net[pass], tiles))."""
     pc = eng.prim.counts
     n_of = {"primary": {"off": pc["m3"], "emo": pc["n_on"], "tone": pc["m3"], "brdf": pc["m3"], "emit": pc["m3"]},
-            "points": dict.fromkeys(mac, eng.pts.tiles_all * 32), "secondary": dict.fromkeys(mac, eng.sec.counts.get("m3", 0)),
-            "eps": dict.fromkeys(mac, pc["m3"])}
-    fl = ms = 0.0
+            "points": dict.fromkeys(NETS, eng.pts.tiles_all * 32),
+            "secondary": dict.fromkeys(NETS, eng.sec.counts.get("m3", 0)),
+            "eps": dict.fromkeys(NETS, pc["m3"])}
+    fl = by = ms = 0.0
     for name, (n, t) in breakdown.items():
         if not name.startswith("mlp_") or "pack" in name:
+            continue
+        ms += t / max(n_prof, 1)
+        if name == "mlp_wgrad(all)":
+            for job, tiles in getattr(eng, "last_wgrad_jobs", []):
+                net, pas = job.rstrip("]").split("[")
+                k = min(tiles * 32, n_of[pas][net])
+                fl += 2.0 * net_macs(net, "wgrad") * k
+                by += net_bytes(net, "wgrad", bf16) * k
             continue
         op, rest = name[4:].split("(", 1)
         net, pas = rest.split(")[")
         pas = pas.rstrip("]")
-        k = dg[net] if op == "dgrad" else mac[net]
-        fl += 2.0 * k * n_of[pas][net]
-        ms += t / max(n_prof, 1)
-    return fl, ms
+        fl += 2.0 * net_macs(net, op) * n_of[pas][net]
+        by += net_bytes(net, op, bf16) * n_of[pas][net]
+    return fl, by, ms
 
 
 def cpu_baseline_lts(model, scene, s_val, n_rays, iters, stage, tr):
@@ -182,8 +233,8 @@ def cpu_baseline_lts(model, scene, s_val, n_rays, iters, stage, tr):
     g = torch.Generator().manual_seed(0)
     draws = lp.Draws(idx=torch.randperm(m3, generator=g)[:Pn], dirs=torch.randn(Pn, R + 1, 3, generator=g),
                      noise_normal=torch.randn(m3, 3, generator=g), noise_emit=torch.randn(m3, 3, generator=g))
-    times = []
-    for i in range(iters + 1):
+
+    def one():
         for v in P.values():
             v.grad = None
         t0 = time.perf_counter()
@@ -197,12 +248,34 @@ def cpu_baseline_lts(model, scene, s_val, n_rays, iters, stage, tr):
             loss, _ = lp.lts_loss(res, batch["rgbs"], True, tr.weight_linear, tr.weight_lts, tr.weight_entropy_last,
                                   tr.weight_normal_smooth)
         loss.backward()
-        times.append(time.perf_counter() - t0)
-    t = sum(times[1:]) / iters
-    return dict(value=n_rays / t, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+        return time.perf_counter() - t0
+
+    # (the all-logical-cores setting is left out here: on the fine stage it is 4-5x slower than 16 threads on a 256-thread
+    # host, and one LTS iteration under it takes minutes)
+    cand = thread_candidates(with_all=False)
+    threads = best_threads(one, cand)
+    t = sum(one() for _ in range(iters)) / iters
+    return dict(value=n_rays / t, unit="rays/s", cores=threads, kind="port",
                 sample=f"{n_rays} of the {scene.n_rays} primary rays + {Pn} surface points x {R} secondary rays "
-                       f"(same ratio as the full step), fwd+loss+bwd, {iters} iterations after 1 warm-up, "
-                       f"{t:.2f} s/iter, torch {torch.__version__} CPU ops + oracle/esr_oracle.c")
+                       f"(same ratio as the full step), fwd+loss+bwd, {iters} iterations after warm-up, "
+                       f"{t:.2f} s/iter, best of torch thread counts {cand} (host has {os.cpu_count()} logical cores), "
+                       f"torch {torch.__version__} CPU ops + oracle/esr_oracle.c")
+
+
+def pmc_traffic(a, stage, calls):
+    """HBM bytes per launch of the named calls from the committed counter passes (profiles/pmc_traffic.json, one entry
+    per workload: tools/pmc_summary.py), or None when no pass was taken on THIS workload.  ``__step__`` = all kernels
+    of one step."""
+    side = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(side):
+        return None
+    with open(side) as f:
+        tj = json.load(f)
+    wl = tj.get("workloads", {}).get(f"{a.config}/{stage}/{a.dtype}/{float(a.s_val):g}")
+    if not wl:
+        return None
+    vals = [wl[c] for c in calls if c in wl]
+    return sum(vals) / len(vals) if vals else None
 
 
 def main():
@@ -251,13 +324,21 @@ def main():
     from esr_nerf_amd.trainer import FineStep, LtsStep
     from esr_nerf_amd.voxurff import VoxurfF
 
-    # identical parameters on every rank (seed 0), different rays per rank (weak scaling)
-    scene = slab_scene(a.config, s_val=a.s_val, seed=rank)
+    # identical parameters on every rank (seed 0), different rays per rank; weak scaling: the config's ray count on
+    # every rank, strong scaling: the config's ray count split over the ranks
+    per_rank = None
+    if a.scaling == "strong" and world > 1:
+        per_rank = CONFIGS[a.config]["n_rays"] // world
+    scene = slab_scene(a.config, s_val=a.s_val, seed=rank, n_rays=per_rank)
     torch.manual_seed(0)
     np.random.seed(0)
     import contextlib
     import io
     cfg = fine_cfg(dev) if stage == "fine" else lts_cfg(dev)
+    if stage != "fine" and a.scaling == "strong" and world > 1:
+        # the reference draws num_ltspts surface points per process; with the global batch split over the ranks the
+        # points are split too, so the global secondary work equals the reference's single-process step
+        cfg.app.model.num_ltspts = max(1, cfg.app.model.num_ltspts // world)
     with contextlib.redirect_stdout(io.StringIO()):
         model = (VoxurfF if stage == "fine" else ESRNeRF)(
             cfg, scene.near, scene.far, scene.xyz_min, scene.xyz_max, scene.mask_xyz_min,
@@ -269,6 +350,25 @@ def main():
     n_rays = scene.n_rays
     if stage == "fine":
         step = FineStep(model, process_group=pg)
+    elif stage == "finetune":
+        # C5's second half (pdra.py:1047-1109, cfg/app/pdra.yaml:128-138): only emo_color / emo_rgbnet train, the target
+        # is the edited emission + its light transport; batch = uncertain + certain rays with edit codes 0..4
+        if pg is not None:
+            raise SystemExit("--stage finetune is a single-GPU line (the reference fine-tunes one image at a time)")
+        with torch.no_grad():
+            model.brdf.grid.normal_(0.0, 0.1)
+        for p_ in model.parameters():
+            p_.requires_grad_(False)
+        for p_ in list(model.emo_color.parameters()) + list(model.emo_rgbnet.parameters()):
+            p_.requires_grad_(True)
+        model.s_val = a.s_val
+        model.train(True, finetune=True)
+        g_ = torch.Generator().manual_seed(21)
+        batch = dict(rays_o=batch["rays_o"], rays_d=batch["rays_d"], viewdirs=batch["viewdirs"],
+                     em_modes=(torch.arange(n_rays, device=dev) % 5).long(),
+                     em_intensities=(0.25 + 2.0 * torch.rand(n_rays, generator=g_)).to(dev),
+                     em_colors=torch.rand(n_rays, 2, generator=g_).to(dev))
+        step = None
     else:
         model.pdra_mode = stage == "pdra"
         with torch.no_grad():
@@ -278,6 +378,12 @@ def main():
     eng = model.engine
 
     def one():
+        if stage == "finetune":
+            model.zero_grad(set_to_none=True)
+            res = model(**batch)
+            loss_ = 0.5 * torch.nn.functional.mse_loss(res["lin/pbr/emo"], res["lin/pbr/emo_hat"])   # pdra.py:1090-1093
+            loss_.backward()
+            return loss_.detach(), None
         # N > 1: this rank's rays are one shard of a global batch of n_rays * N rays
         return step.forward_loss_backward(batch, a.s_val, global_rays=n_rays * world if pg is not None else None,
                                           entropy_owner=(rank == world - 1))[:2]
@@ -316,7 +422,9 @@ def main():
             if call in breakdown:
                 by_kernel[kname] = by_kernel.get(kname, 0.0) + breakdown[call][1]
         dominant = max(by_kernel, key=by_kernel.get) if by_kernel else None
-    dom_calls = [c for c, k in KERNEL_OF.items() if k == dominant and c in breakdown]
+        if dominant and a.dtype == "bf16":                     # the bf16 engine's kernel symbols (csrc/mlp_bf16.hip)
+            dominant = dominant.replace("mlp_fwd_kernel", "mlp_fwd16_kernel").replace("mlp_dgrad_kernel", "mlp_dgrad16_kernel")
+    dom_calls = [c for c, k in KERNEL_OF.items() if dominant and k == dominant.replace("16_kernel", "_kernel") and c in breakdown]
     # one launch of that kernel per step is bracketed (each event pair costs ~40-80 us of wall time)
     dom_calls = sorted(dom_calls, key=lambda c: -breakdown[c][1])[:1]
     if not dom_calls and not a.no_kernel_timing and stage == "fine":
@@ -347,7 +455,7 @@ def main():
 
     # optimizer step, reported separately (outside the named path, never part of `value`)
     opt_ms = None
-    if not a.no_optimizer:         # every rank: one() is a collective step when N > 1 (rank 0 reports)
+    if not a.no_optimizer and stage != "finetune":   # every rank: one() is a collective step when N > 1 (rank 0 reports)
         from esr_nerf_amd.optimizer import create_optimizer_or_freeze_model
         lrs = dict(off_color=0.1, off_rgbnet=0.003, emo_color=0.1, emo_rgbnet=0.003, sdf=0.005, tonemapper=0.003,
                    brdf=0.1, brdfnet=0.003, emitnet=0.003, envmap=0.003)
@@ -385,7 +493,7 @@ def main():
             "metric": "training rays/sec at 4096 rays x 128 samples (fine stage)" if (a.config, stage, a.dtype) == ("C2", "fine", "f32")
                       else f"training rays/sec, config {a.config}, {stage} stage, {a.dtype} MLPs",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": a.dtype,
             "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)",
             "config": {
@@ -393,7 +501,9 @@ def main():
                             f"samples per GPU, grid {'x'.join(str(int(v)) for v in model.world_size.tolist())}, "
                             f"s_val={a.s_val:g}, forward + trainer loss + backward (no optimizer step)"
                             + ("" if stage == "fine" else f"; + {model.num_ltspts} surface points x {model.num_2ndrays} "
-                               f"secondary rays per GPU ({eng.sec.counts.get('m3')} surviving secondary samples)"),
+                               f"secondary rays per GPU ({eng.sec.counts.get('m3')} surviving secondary samples)")
+                            + ("; fine-tune target: edited emission + its light transport, only emo_color / emo_rgbnet "
+                               "train" if stage == "finetune" else ""),
                 "rays_per_gpu": n_rays, "samples_per_ray": samples, "surviving_samples": counts.get("m3"),
                 "parallelism": f"dp{world}",
             },
@@ -411,16 +521,8 @@ def main():
             ms = sum(kern[c][1] for c in dom_calls if c in kern)
             flops_total = sum(algorithmic_flops(c, counts) * kern[c][0] for c in dom_calls if c in kern)
             ach = flops_total / (ms * 1e-3) / 1e12
-            bytes_total = sum((algorithmic_bytes(c, counts) or 0) * kern[c][0] for c in dom_calls if c in kern)
-            traffic = None
-            side = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(side):
-                with open(side) as f:
-                    tj = json.load(f)
-                wl = tj.get("_workload", {})
-                same = (wl.get("config"), wl.get("stage"), wl.get("s_val")) == (a.config, stage, float(a.s_val))
-                vals = [tj[c] for c in dom_calls if c in tj] if same else []     # counters are per workload
-                traffic = sum(vals) / len(vals) if vals else None
+            bytes_total = sum((algorithmic_bytes(c, counts, a.dtype == "bf16") or 0) * kern[c][0] for c in dom_calls if c in kern)
+            traffic = pmc_traffic(a, stage, dom_calls)
             # matrix-pipe utilisation and effective clock of the same kernel from the committed counter pass
             # (tools/profile_mfma.sh -> profiles/*_mfma_util.csv; C2 fp32 only -- counters are per workload)
             pmc_mfma = None
@@ -437,7 +539,8 @@ def main():
             out["roofline"] = {
                 "bound": "mfma", "kernel": dominant, "calls": dom_calls, "achieved": ach,
                 "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF,
-                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, profiles/pmc_traffic.json)",
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC: FETCH_SIZE x 2 + WRITE_SIZE, "
+                                                    "profiles/pmc_traffic.json, same workload)",
                 "avg_launch_ms": ms / launches, "launches_timed": launches,
                 "algorithmic_gflop_per_launch": flops_total / launches / 1e9,
                 "share_of_kernel_time": sum(breakdown[c][1] for c in dom_calls if c in breakdown) / total_ms,
@@ -445,7 +548,7 @@ def main():
             }
             if a.dtype == "bf16":                  # bf16 operands: the activation traffic, not the MFMA pipe, binds
                 gbs = bytes_total / (ms * 1e-3) / 1e9
-                out["roofline"].update({"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                out["roofline"].update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                         "algorithmic_mb_per_launch": bytes_total / launches / 1e6,
                                         "mfma_tflops": ach, "mfma_frac_of_bf16_peak": ach / MFMA_BF16_PEAK_TF})
             # the whole MLP engine (all 10 calls per step), from the instrumented warm-up steps
@@ -453,22 +556,43 @@ def main():
             if mlp:
                 mf = sum(algorithmic_flops(k, counts) * v[0] for k, v in mlp.items())
                 mt = sum(v[1] for v in mlp.values()) * 1e-3
-                out["roofline"]["all_mlp_kernels"] = {"achieved": mf / mt / 1e12, "frac": mf / mt / 1e12 / MFMA_F32_PEAK_TF,
+                peak = MFMA_BF16_PEAK_TF if a.dtype == "bf16" else MFMA_F32_PEAK_TF
+                out["roofline"]["all_mlp_kernels"] = {"achieved": mf / mt / 1e12, "frac": mf / mt / 1e12 / peak, "peak": peak,
                                                       "share_of_kernel_time": mt * 1e3 / total_ms}
+                if a.dtype == "bf16":
+                    mb = sum((algorithmic_bytes(k, counts, True) or 0) * v[0] for k, v in mlp.items())
+                    out["roofline"]["all_mlp_kernels"].update(hbm_gbs=mb / mt / 1e9, hbm_frac=mb / mt / 1e9 / HBM_PEAK_GBS)
+                # the whole step against the path's roof: algorithmic FLOPs of the step / wall time
+                # every net pass counted at the forward's MACs x 3 (fwd, dgrad, wgrad); an on-ray sample runs
+                # the emo net x3, the off net x1 (detached) and the tone mapper x3, an off-ray sample the off net x3
+                # and the tone mapper x3: 766,464 / 585,216 FLOP per sample = 86.5 MFLOP per ray at C2
+                step_fl = (2 * (4 * RAD_MAC + 3 * TONE_MAC)) * counts["n_on"] + (2 * (3 * RAD_MAC + 3 * TONE_MAC)) * counts["n_off"]
+                out["roofline"]["whole_step"] = {"algorithmic_gflop": step_fl / 1e9,
+                                                 "achieved": step_fl / (dt / a.steps) / 1e12, "peak": peak,
+                                                 "frac": step_fl / (dt / a.steps) / 1e12 / peak}
                 out["kernel_ms_per_step_warmup"] = {k: round(v[1] / v[0], 4) for k, v in
                                                     sorted(breakdown.items(), key=lambda kv: -kv[1][1])}
         if breakdown and "kernel_ms_per_step_warmup" not in out:
             out["kernel_ms_per_step_warmup"] = {k: round(v[1] / max(n_prof, 1), 4) for k, v in
                                                 sorted(breakdown.items(), key=lambda kv: -kv[1][1])}
         if breakdown and stage != "fine":
-            fl, ms_mlp = lts_mlp_flops(breakdown, eng, n_prof)
+            bf = a.dtype == "bf16"
+            fl, by, ms_mlp = lts_mlp_work(breakdown, eng, n_prof, bf)
             total_ms = sum(ms_ for _, ms_ in breakdown.values()) / max(n_prof, 1)
-            out["roofline"] = {
-                "bound": "mfma", "kernel": "all mlp_fwd/dgrad/wgrad launches of the step (HIP events, instrumented "
-                                           "warm-up steps)", "achieved": fl / (ms_mlp * 1e-3) / 1e12,
-                "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": fl / (ms_mlp * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
-                "traffic": None, "mlp_ms_per_step": ms_mlp, "share_of_kernel_time": ms_mlp / total_ms,
-                "kernel_ms_per_step": total_ms}
+            tf, gbs = fl / (ms_mlp * 1e-3) / 1e12, by / (ms_mlp * 1e-3) / 1e9
+            peak = MFMA_BF16_PEAK_TF if bf else MFMA_F32_PEAK_TF
+            rl = {"kernel": "all mlp_fwd/dgrad/wgrad launches of the step (HIP events, instrumented warm-up steps)",
+                  "traffic": pmc_traffic(a, stage, ["__step__"]), "mlp_ms_per_step": ms_mlp,
+                  "share_of_kernel_time": ms_mlp / total_ms, "kernel_ms_per_step": total_ms,
+                  "mfma": {"achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak},
+                  "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                          "note": "algorithmic bytes of the MLP launches (inputs + saved activations / gradients)"}}
+            # f32 operands: the f32 matrix rate binds; bf16 operands: the matrix work is 16x cheaper and the saved
+            # activation traffic binds -- each line is priced against the roof of ITS operand type
+            pick = rl["hbm"] if bf else rl["mfma"]
+            rl.update(bound="hbm" if bf else "mfma", achieved=pick["achieved"], peak=pick["peak"], unit=pick["unit"],
+                      frac=pick["frac"])
+            out["roofline"] = rl
         sync = getattr(step, "_sync", None)
         if sync is not None:
             # data-parallel exchange of the dense-grid gradients (esr_nerf_amd/grad_sync.py), last step of rank 0
@@ -481,7 +605,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             if stage == "fine":
                 out["cpu_baseline"] = cpu_baseline(model, scene, a.s_val, min(a.cpu_rays, n_rays), a.cpu_iters)
-            else:
+            elif stage != "finetune":
                 out["cpu_baseline"] = cpu_baseline_lts(model, scene, a.s_val, min(a.cpu_rays, n_rays), a.cpu_iters,
                                                        stage, cfg.app.trainer)
         line = json.dumps(out)

@@ -7,8 +7,10 @@
 // z-column of the channels-last colour grid is a whole number of bricks at the usual sizes) and only
 // bricks that are non-zero on SOME rank travel:
 //   esr_brick_flags   one streaming read of the buffer -> one byte per brick (any non-zero value)
-//   esr_brick_pack    gather the listed bricks into a dense buffer (what the all-reduce sees)
-//   esr_brick_unpack  scatter the reduced bricks back
+//   esr_brick_pack    gather the listed bricks into a dense buffer (what the all-reduce sees); a NEGATIVE index is
+//                     an unused slot of a fixed-capacity list (grad_sync.py sizes the list on the host from the
+//                     previous step's count, without waiting for this step's): it packs as zeros
+//   esr_brick_unpack  scatter the reduced bricks back (negative indices are skipped)
 // All three are pure HBM streams (16-B accesses, one 32-lane group per brick); the union of the flags
 // over ranks and the brick list come from torch.distributed / torch (esr_nerf_amd/grad_sync.py).
 #include "esr_common.h"
@@ -47,8 +49,13 @@ __global__ void __launch_bounds__(256) brick_move_kernel(float *__restrict__ g, 
     const int64_t grp0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 5;
     const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 5;
     for (int64_t k = grp0; k < n_idx; k += ngrp) {
-        const int64_t e = idx[k] * BRICK + sub * 4;
+        const int64_t b = idx[k];
         float4 *pk = reinterpret_cast<float4 *>(packed + k * BRICK + sub * 4);
+        if (b < 0) {                                   // unused slot of a fixed-capacity list: packs as zeros, unpacks nowhere
+            if (!UNPACK) *pk = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
+        const int64_t e = b * BRICK + sub * 4;
         if (e + 4 <= n) {
             float4 *gp = reinterpret_cast<float4 *>(g + e);
             if (UNPACK) *gp = *pk;

@@ -139,6 +139,55 @@ class Adam(torch.optim.Optimizer):
         return loss
 
 
+def _hip_adam(p, g, m, v, lr, beta1, beta2, eps, step):
+    rc = _lib.lib().esr_adam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), None, C.c_int64(p.numel()),
+                                  C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(0.0),
+                                  int(step), _lib.stream_ptr(p.device))
+    _lib.check(rc, "esr_adam_step")
+
+
+class ShardedGridAdam:
+    """Adam over the dense grids with the state and the update sharded over the data-parallel ranks (SURVEY 8(e)
+    option 2; ZeRO-1 style).  ``grids``: grad_sync.ShardedGrids (the grid parameters as one flat buffer).  Every step:
+    ``grids.reduce_scatter(flat_grad)`` (started by the trainer step as soon as the grid gradients are complete) ->
+    the fused Adam on this rank's shard only -> ``all_gather`` of the updated parameters.  The moments exist for the
+    owned shard only (1/G of the dense optimizer's memory and update traffic).  Same arithmetic as ``Adam`` above
+    (``esr_adam_step``), per-attribute learning rates by position in the flat buffer; a per-voxel lr is not supported
+    (only the alphamask pre-stage of the reference uses one).  ``adam_fn``: test double for CPU rehearsals."""
+
+    def __init__(self, grids, lrs, betas=(0.9, 0.99), eps=1e-8, adam_fn=None):
+        self.grids = grids
+        self.lr = {n: float(lrs[n]) for n in grids.names}
+        self.betas, self.eps = betas, eps
+        self.step_count = 0
+        self.exp_avg = torch.zeros_like(grids.grad_shard)
+        self.exp_avg_sq = torch.zeros_like(grids.grad_shard)
+        self._adam = adam_fn or _hip_adam
+
+    def scale_lr(self, factor: float):
+        """what the trainers do to every param group after a step (fine.py:410-415)"""
+        for n in self.lr:
+            self.lr[n] *= factor
+
+    @torch.no_grad()
+    def step(self):
+        G = self.grids
+        G.wait()                                          # the reduce-scatter of this step's grid gradients
+        self.step_count += 1
+        lo, hi = G.my_range()
+        for name, b, e in G.bounds:                       # the shard may straddle two grids (different lr each)
+            a, z = max(lo, b), min(hi, e)
+            if a < z:
+                self._adam(G.flat[a:z], G.grad_shard[a - lo:z - lo], self.exp_avg[a - lo:z - lo],
+                           self.exp_avg_sq[a - lo:z - lo], self.lr[name], self.betas[0], self.betas[1], self.eps,
+                           self.step_count)
+        G.all_gather()
+
+    def state_dict(self):
+        return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lr=dict(self.lr),
+                    shard=self.grids.my_range())
+
+
 class CosineLR:
     """optimizer.py:231-275.  ``ratio(i)``: linear warm-up from ``warm_up_min_ratio`` to 1 over ``warm_up_iters``
     steps (held at the minimum with ``const_warm_up``), then a half cosine from 1 down to ``cos_min_ratio`` at

@@ -50,27 +50,39 @@ def _grid_sync(step, eng):
     """after_grids callback of a data-parallel step: how the dense-grid gradients are summed over ranks.
 
     * ``sparse`` -- grad_sync.GridGradSync: brick flags, union, ONE all-reduce of the packed union (C2: 35 MB per
-      rank instead of 218 MB).  Costs one host sync and two more collective launches on the critical path of the
-      exchange (measured with one rank: +0.35 ms per step, against +0.1 ms for the dense form), so it pays when
-      the wire time dominates: few ranks = few usable xGMI links (one at N = 2).
+      rank instead of 218 MB).  No host wait inside the exchange (fixed-capacity brick list sized from the previous
+      step, verified at the end of the step); two more collective launches than the dense form, so it pays when the
+      wire time dominates: few ranks = few usable xGMI links (one at N = 2).
     * ``dense`` -- one asynchronous all-reduce of the whole grid part, no host sync; underneath the weight-gradient
       kernels.  With all 7 links per GPU in play (N = 8) a ring moves 218 MB in about a millisecond, which the
       ~1.3 ms of wgrad work hides.
-    ``ESR_GRAD_SYNC=sparse|dense`` forces either; the default picks sparse for 2-4 ranks (link arithmetic, to be
+    * ``shard`` -- option 2 of SURVEY 8(e): reduce-scatter of the grid part into this rank's shard
+      (``step.sharded``: grad_sync.ShardedGrids, attached by the caller together with optimizer.ShardedGridAdam, which
+      updates the shard and all-gathers the parameters).  The grid part of the returned gradient buffer then holds
+      this rank's LOCAL gradients only.
+    ``ESR_GRAD_SYNC=sparse|dense|shard`` forces one; the default picks sparse for 2-4 ranks (link arithmetic, to be
     replaced by the driver's multi-GPU measurements)."""
     import os
     import torch.distributed as dist
     works = []
     mode = os.environ.get("ESR_GRAD_SYNC", "auto")
+    if getattr(step, "sharded", None) is not None:
+        mode = "shard"
+    elif mode == "shard":
+        raise RuntimeError("ESR_GRAD_SYNC=shard needs step.sharded = grad_sync.ShardedGrids(model, names, group) "
+                           "(and optimizer.ShardedGridAdam for the update)")
     if mode == "auto":
         mode = "sparse" if 2 <= dist.get_world_size(step.pg) <= 4 else "dense"
-    if mode == "sparse" and getattr(eng, "overlap_wgrad", False):   # the sync is free only with wgrad on its own stream
+    if mode == "shard":
+        def after_grids():
+            step.sharded.reduce_scatter(step._flat[: step._n_grid])
+    elif mode == "sparse":
         from .grad_sync import GridGradSync
         if step._sync is None:
             step._sync = GridGradSync(step.pg)
 
         def after_grids():
-            step._sync.reduce(step._flat[: step._n_grid])
+            step._sync.reduce(step._flat[: step._n_grid])      # no host wait inside; closed by _sync.verify() below
     else:
         def after_grids():
             works.append(dist.all_reduce(step._flat[: step._n_grid], group=step.pg, async_op=True))
@@ -172,6 +184,8 @@ class FineStep:
             works.append(dist.all_reduce(loss, group=self.pg, async_op=True))
             for w in works:
                 w.wait()                  # stream-level wait: the caller's stream sees reduced gradients
+            if self._sync is not None:
+                self._sync.verify()       # everything of the step is enqueued: close the brick exchange
         g["off_color.grid"] = g["off_color.grid"].permute(0, 4, 1, 2, 3)     # logical [1,6,X,Y,Z]
         g["emo_color.grid"] = g["emo_color.grid"].permute(0, 4, 1, 2, 3)
         return loss, g
@@ -340,6 +354,8 @@ class LtsStep:
             works.append(dist.all_reduce(loss, group=self.pg, async_op=True))
             for w in works:
                 w.wait()
+            if self._sync is not None:
+                self._sync.verify()       # everything of the step is enqueued: close the brick exchange
         for k in ("off_color.grid", "emo_color.grid", "brdf.grid"):
             G[k] = G[k].permute(0, 4, 1, 2, 3)
         return loss, G, out

@@ -21,10 +21,14 @@ class TorchBrickOps:
 
     def pack(self, flat, idx, packed):
         v, _ = self._view(flat)
-        packed.view(-1, self.brick).copy_(v[idx])
+        ok = idx >= 0                                    # negative = unused slot of a fixed-capacity list
+        out = packed.view(-1, self.brick)
+        out.zero_()
+        out[ok] = v[idx[ok]]
 
     def unpack(self, packed, idx, flat):
         v, n = self._view(flat)
-        v[idx] = packed.view(-1, self.brick)
+        ok = idx >= 0
+        v[idx[ok]] = packed.view(-1, self.brick)[ok]
         if n is not None:
             flat.copy_(v.view(-1)[:n])

@@ -158,10 +158,25 @@ from brick_ops_double import TorchBrickOps
 sparse = flat.float().clone()
 sparse[: sparse.numel() // 3] = 0        # untouched bricks on both ranks
 dense = sparse.clone()
-sync = GridGradSync(dist.group.WORLD, ops=TorchBrickOps())
+sync = GridGradSync(dist.group.WORLD, ops=TorchBrickOps(), min_capacity=1)
 sync.reduce(sparse)
+sync.verify()
 dist.all_reduce(dense)
 assert torch.equal(sparse, dense) and sync.last["mode"] == "sparse", sync.last
+# later steps size the brick list on the host from the previous step's count (no wait inside the exchange):
+# same pattern again (fits), then a pattern with MORE dirty bricks than the capacity (overflow pass in verify())
+for grow in (False, True):
+    cur = flat.float().clone()
+    if not grow:
+        cur[: cur.numel() // 3] = 0
+    else:
+        cur[: cur.numel() // 8] = 0
+        cur += (rank + 1) * 1e-3 * (cur != 0)
+    want = cur.clone(); dist.all_reduce(want)
+    sync.reduce(cur)
+    sync.verify()
+    assert torch.equal(cur, want), ("optimistic exchange", grow, sync.last)
+    assert sync.last["mode"] == "sparse" and (("overflow" in sync.last) == grow), sync.last
 sync2 = GridGradSync(dist.group.WORLD, dense_above=0.1, ops=TorchBrickOps())
 again = flat.float().clone(); sync2.reduce(again)
 ref2 = flat.float().clone(); dist.all_reduce(ref2)
@@ -190,6 +205,79 @@ def test_data_parallel_sharding_is_exact_gloo_world2():
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("DPRESULT")][0].split()
     assert float(line[1]) < 1e-5 and float(line[2]) < 1e-6, line
+
+
+SHARD_WORKER = r'''
+import math, os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from esr_nerf_amd.grad_sync import ShardedGrids
+from esr_nerf_amd.modules import DenseGrid
+from esr_nerf_amd.optimizer import ShardedGridAdam
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+ws = torch.tensor([6, 5, 4])
+lo, hi = torch.tensor([-1.0, -1.0, -1.0]), torch.tensor([1.0, 1.0, 1.0])
+class M(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(3)
+        self.sdf, self.off_color, self.emo_color = DenseGrid(1, ws, lo, hi), DenseGrid(6, ws, lo, hi), DenseGrid(6, ws, lo, hi)
+        with torch.no_grad():
+            for m_ in (self.sdf, self.off_color, self.emo_color):
+                m_.grid.copy_(torch.randn(m_.grid.shape, generator=g))
+model = M()
+names = ["sdf", "off_color", "emo_color"]
+lrs = {"sdf": 0.005, "off_color": 0.1, "emo_color": 0.05}
+ref = {n: getattr(model, n).grid.detach().clone() for n in names}          # single-process reference copy
+m_ref = {n: torch.zeros_like(v) for n, v in ref.items()}
+v_ref = {n: torch.zeros_like(v) for n, v in ref.items()}
+
+def torch_adam(p, g, m, v, lr, b1, b2, eps, step):                          # double of esr_adam_step (optimizer.py:183-228 arithmetic)
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    p.addcdiv_(m, (v.sqrt() / math.sqrt(1 - b2 ** step)).add_(eps), value=-(lr / (1 - b1 ** step)))
+
+grids = ShardedGrids(model, names, dist.group.WORLD)
+assert model.off_color.grid.is_contiguous(memory_format=torch.channels_last_3d) and model.off_color.grid.shape == (1, 6, 6, 5, 4)
+assert model.sdf.grid.data_ptr() == grids.flat.data_ptr()                  # parameters are views of the flat buffer
+assert grids.padded % (world * 128) == 0 and grids.shard * world == grids.padded
+opt = ShardedGridAdam(grids, lrs, adam_fn=torch_adam)
+for step in range(1, 4):
+    # every rank's LOCAL gradients (storage order of the step's flat buffer: sdf | off [X,Y,Z,6] | emo [X,Y,Z,6])
+    per_rank = [[torch.randn(ref[n].shape, generator=torch.Generator().manual_seed(1000 * step + 10 * r + i))
+                 for i, n in enumerate(names)] for r in range(world)]
+    mine = per_rank[rank]
+    flat_grad = torch.cat([mine[0].flatten()] + [g_.permute(0, 2, 3, 4, 1).reshape(-1) for g_ in mine[1:]])
+    grids.reduce_scatter(flat_grad)
+    opt.step()
+    opt.scale_lr(0.9)
+    for i, n in enumerate(names):                                            # the single-process run on the summed gradient
+        gsum = sum(per_rank[r][i] for r in range(world))
+        torch_adam(ref[n], gsum, m_ref[n], v_ref[n], lrs[n] * 0.9 ** (step - 1), 0.9, 0.99, 1e-8, step)
+    for n in names:
+        err = float((getattr(model, n).grid.detach() - ref[n]).abs().max())
+        assert err < 1e-6, (step, n, err)
+assert opt.exp_avg.numel() == grids.shard                                   # moments exist for the owned shard only
+print("SHARDOK", rank, grids.shard, grids.padded)
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_grid_adam_matches_single_process_gloo(world):
+    """SURVEY 8(e) option 2 (ESR_GRAD_SYNC=shard): reduce-scatter of the dense-grid gradients, Adam on the owned
+    shard, all-gather of the parameters -- three steps on 2 and 4 gloo ranks reproduce the single-process Adam on the
+    summed gradients (torch double of esr_adam_step; colour grids channels-last inside the flat buffer)."""
+    with tempfile.TemporaryDirectory() as d:
+        w = os.path.join(d, "w.py")
+        open(w, "w").write(SHARD_WORKER)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+        out = subprocess.run(
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+             "--master-addr", "127.0.0.1", "--master-port", str(29520 + world), w, ROOT],
+            env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.stdout.count("SHARDOK") == world, out.stdout[-2000:]
 
 
 def test_optimizer_groups_freeze_and_no_cpu_fallback():
