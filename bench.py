@@ -335,10 +335,8 @@ def main():
     import contextlib
     import io
     cfg = fine_cfg(dev) if stage == "fine" else lts_cfg(dev)
-    if stage != "fine" and a.scaling == "strong" and world > 1:
-        # the reference draws num_ltspts surface points per process; with the global batch split over the ranks the
-        # points are split too, so the global secondary work equals the reference's single-process step
-        cfg.app.model.num_ltspts = max(1, cfg.app.model.num_ltspts // world)
+    # (strong scaling of the LTS stages: the surface points are split over the ranks too -- LtsStep(split_points=True) --
+    # so that the global secondary work equals the reference's single-process step)
     with contextlib.redirect_stdout(io.StringIO()):
         model = (VoxurfF if stage == "fine" else ESRNeRF)(
             cfg, scene.near, scene.far, scene.xyz_min, scene.xyz_max, scene.mask_xyz_min,
@@ -374,7 +372,7 @@ def main():
         with torch.no_grad():
             model.brdf.grid.normal_(0.0, 0.1)
         batch["uncert_masks"] = (torch.arange(n_rays, device=dev) % 3 == 0)
-        step = LtsStep(model, cfg.app.trainer, stage=stage, process_group=pg)
+        step = LtsStep(model, cfg.app.trainer, stage=stage, process_group=pg, split_points=(a.scaling == "strong"))
     eng = model.engine
 
     def one():
@@ -500,7 +498,7 @@ def main():
                 "workload": f"{a.config}: giftbox_w {stage} stage on the slab scene, {n_rays} rays x {samples} "
                             f"samples per GPU, grid {'x'.join(str(int(v)) for v in model.world_size.tolist())}, "
                             f"s_val={a.s_val:g}, forward + trainer loss + backward (no optimizer step)"
-                            + ("" if stage == "fine" else f"; + {model.num_ltspts} surface points x {model.num_2ndrays} "
+                            + ("" if stage == "fine" else f"; + {getattr(step, 'ltspts', model.num_ltspts)} surface points x {model.num_2ndrays} "
                                f"secondary rays per GPU ({eng.sec.counts.get('m3')} surviving secondary samples)")
                             + ("; fine-tune target: edited emission + its light transport, only emo_color / emo_rgbnet "
                                "train" if stage == "finetune" else ""),

@@ -96,10 +96,10 @@ def lts_cfg(device: str = "cpu", **model_over) -> AttrDict:
     )
 
 
-def fine_cfg(device: str = "cpu") -> AttrDict:
+def fine_cfg(device: str = "cpu", **model_over) -> AttrDict:
     return AttrDict(
         system=dict(device=device, debug=True, seed=0, tqdm_iters=10),
-        app=dict(model=dict(FINE_MODEL), trainer=dict(FINE_TRAINER)),
+        app=dict(model=dict(FINE_MODEL, **model_over), trainer=dict(FINE_TRAINER)),
         data=dict(white_bg=True),
         global_step=0,
     )

@@ -214,6 +214,25 @@ __device__ __forceinline__ void esr_tri_scatter1(float *__restrict__ g, const in
             }
 }
 
+// Continuous index of one clamped stencil tap and the clamped coordinate along
+// its axis.  Replicates ind + offset -> clamp -> /(size-1)*2-1 -> grid_sample's
+// ((n+1)/2)*(size-1) so the tap lands on the same float as the reference's.
+__device__ __forceinline__ float tap_index(const float ind[3], const int dims[3], int axis, float disp,
+                                           float ix[3])
+{
+#pragma clang fp contract(off)
+    float along = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float t = ind[a] + ((a == axis) ? disp : 0.f);
+        t = fminf(fmaxf(t, 0.f), (float)(dims[a] - 1));
+        if (a == axis) along = t;
+        float n = __fdiv_rn(t, (float)(dims[a] - 1)) * 2.0f - 1.0f;
+        ix[a] = __fdiv_rn(n + 1.0f, 2.0f) * (float)(dims[a] - 1);
+    }
+    return along;
+}
+
 __device__ __forceinline__ float esr_softplus(float x)
 {
     // F.softplus(beta=1, threshold=20)

@@ -116,24 +116,6 @@ __device__ __forceinline__ void tri_scatter6(float *__restrict__ g, const int di
             }
 }
 
-// Continuous index of one clamped stencil tap and the clamped coordinate along
-// its axis.  Replicates ind + offset -> clamp -> /(size-1)*2-1 -> grid_sample's
-// ((n+1)/2)*(size-1) so the tap lands on the same float as the reference's.
-__device__ __forceinline__ float tap_index(const float ind[3], const int dims[3], int axis, float disp,
-                                           float ix[3])
-{
-#pragma clang fp contract(off)
-    float along = 0.f;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float t = ind[a] + ((a == axis) ? disp : 0.f);
-        t = fminf(fmaxf(t, 0.f), (float)(dims[a] - 1));
-        if (a == axis) along = t;
-        float n = __fdiv_rn(t, (float)(dims[a] - 1)) * 2.0f - 1.0f;
-        ix[a] = __fdiv_rn(n + 1.0f, 2.0f) * (float)(dims[a] - 1);
-    }
-    return along;
-}
 
 __global__ void __launch_bounds__(256) feat_fwd_kernel(FeatParams P)
 {

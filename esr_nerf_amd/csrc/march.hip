@@ -26,6 +26,7 @@ enum { MARCH_COUNT = 0, MARCH_FILL = 1, MARCH_BWD = 2 };
 struct MarchParams {
     esr_scene_t sc;
     const float *rays_o, *rays_d, *mask_density, *sdf;
+    const float *viewdirs;   // GA only: the batch's view directions (the reference indexes viewdirs[ray_id])
     int n_rays;
     int cap;                 // per-wave LDS capacity in samples (multiple of 64)
     // COUNT
@@ -49,9 +50,46 @@ __device__ __forceinline__ float neus_alpha(float pc, float nc)
     return fminf(fmaxf(r, 0.f), 1.f);
 }
 
+// 0.5 * dist * (viewdir . grad) with grad = (f(+1 voxel) - f(-1 voxel)) / clamped index distance / voxel_size per grid
+// axis (= world axis: grid axis 0 is world x); operation order of functions.py:53-55 and voxurff.py:706-711
+__device__ __forceinline__ float grad_alpha_ic(const float *__restrict__ sdf, const int dims[3], const float ind[3],
+                                               const float vd[3], float voxel_size, float dist)
+{
+#pragma clang fp contract(off)
+    float gv[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float ixp[3], ixm[3];
+        const float ap = tap_index(ind, dims, a, 1.0f, ixp), am = tap_index(ind, dims, a, -1.0f, ixm);
+        const float fd = esr_tri_fetch1(sdf, dims, ixp) - esr_tri_fetch1(sdf, dims, ixm);
+        gv[a] = __fdiv_rn(__fdiv_rn(fd, ap - am), voxel_size);
+    }
+    const float dotp = (vd[0] * gv[0] + vd[1] * gv[1]) + vd[2] * gv[2];
+    return (dotp * dist) * 0.5f;
+}
+
+__device__ __forceinline__ void grad_alpha_ic_bwd(float *__restrict__ grad_sdf, const int dims[3], const float ind[3],
+                                                  const float vd[3], float voxel_size, float dist, float dic)
+{
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float ixp[3], ixm[3];
+        const float ap = tap_index(ind, dims, a, 1.0f, ixp), am = tap_index(ind, dims, a, -1.0f, ixm);
+        const float coef = dic * 0.5f * dist * vd[a] / (ap - am) / voxel_size;
+        if (coef != 0.f) {
+            esr_tri_scatter1(grad_sdf, dims, ixp, coef);
+            esr_tri_scatter1(grad_sdf, dims, ixm, -coef);
+        }
+    }
+}
+
 // COARSE (VoxurfC.forward_training, voxurfc.py:207-219): no alpha threshold, and alpha2weight runs a SECOND
 // time over the weight > thres survivors of the first pass; weights and alphainv_last come from that pass.
-template <int MODE, bool COARSE>
+// GA = cfg neus_alpha: "grad" (app/utils/base/functions.py:45-69): the two section SDFs of a sample are extrapolated
+// from ITS OWN value and finite-difference gradient, sdf -+ 0.5 * dist * (viewdir . grad), instead of interpolated
+// towards its surviving neighbours; grad = the radius-1 clamped central differences of sample_sdf_grad
+// (voxurff.py:670-721), so a sample reads 7 trilinear taps and its backward scatters through all 7.
+template <int MODE, bool COARSE, bool GA = false>
 __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -61,8 +99,9 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
     const int r = blockIdx.x * waves_per_blk + wave_in_blk;
     if (r >= P.n_rays) return;                        // whole wave leaves together
 
-    constexpr int NARR = (MODE == MARCH_BWD) ? 5 : 2;
+    constexpr int NARR = ((MODE == MARCH_BWD) ? 5 : 2) + (GA ? 1 : 0);
     float *base = reinterpret_cast<float *>(smem_raw) + (size_t)wave_in_blk * NARR * P.cap;
+    float *ic1 = GA ? base + (NARR - 1) * P.cap : nullptr;   // 0.5 * dist * (viewdir . grad) of mask-cache survivors
     float *sdf1 = base;                                // SDF of mask-cache survivors
     int *step1 = reinterpret_cast<int *>(base + P.cap);
     float *alpha1 = (MODE == MARCH_BWD) ? base + 2 * P.cap : nullptr;   // later: d/d prev-midpoint
@@ -84,6 +123,8 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
         return;
     }
 
+    float vd[3] = {0.f, 0.f, 0.f};
+    if (GA) { vd[0] = P.viewdirs[3 * r]; vd[1] = P.viewdirs[3 * r + 1]; vd[2] = P.viewdirs[3 * r + 2]; }
     // ---- phase 1: walk the ray, keep in-box & mask-cache survivors in LDS ----
     int n0 = 0, n1 = 0;
     for (int c0 = 0; c0 < g.n_steps; c0 += 64) {
@@ -99,15 +140,18 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
             const float a = 1.f - expf(-esr_softplus(dens + sc.act_shift));
             ok = a >= sc.mask_thres;
         }
+        float ic = 0.f;
         if (ok) {
             esr_world_to_index(p, sc.xyz_min, sc.xyz_max, gdims, idx);
             s = esr_tri_fetch1(P.sdf, gdims, idx);
+            if (GA) ic = grad_alpha_ic(P.sdf, gdims, idx, vd, sc.voxel_size, sc.stepdist);
         }
         const unsigned long long b = __ballot(ok);
         if (ok) {
             const int pos = n1 + __popcll(b & ((1ull << lane) - 1ull));
             sdf1[pos] = s;
             step1[pos] = step;
+            if (GA) ic1[pos] = ic;
         }
         n1 += __popcll(b);
     }
@@ -124,8 +168,8 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
         float s = 0.f, alpha = 0.f;
         if (ok) {
             s = sdf1[j];
-            const float prv = (j > 0) ? (sdf1[j - 1] + s) * 0.5f : s;
-            const float nxt = (j < n1 - 1) ? (s + sdf1[j + 1]) * 0.5f : s;
+            const float prv = GA ? s - ic1[j] : (j > 0) ? (sdf1[j - 1] + s) * 0.5f : s;
+            const float nxt = GA ? s + ic1[j] : (j < n1 - 1) ? (s + sdf1[j + 1]) * 0.5f : s;
             alpha = neus_alpha(esr_sigmoid(prv * sc.s_val), esr_sigmoid(nxt * sc.s_val));
         }
         const bool v2 = ok && (COARSE || alpha > sc.fast_thres);
@@ -223,8 +267,8 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
             const float dalpha =
                 (float)((double)(gw * T) - (double)myback / ((double)(1.0f - alpha) + 1e-10));
             const float s = sdf1[j];
-            const float prv = (j > 0) ? (sdf1[j - 1] + s) * 0.5f : s;
-            const float nxt = (j < n1 - 1) ? (s + sdf1[j + 1]) * 0.5f : s;
+            const float prv = GA ? s - ic1[j] : (j > 0) ? (sdf1[j - 1] + s) * 0.5f : s;
+            const float nxt = GA ? s + ic1[j] : (j < n1 - 1) ? (s + sdf1[j + 1]) * 0.5f : s;
             const float pc = esr_sigmoid(prv * sc.s_val), nc = esr_sigmoid(nxt * sc.s_val);
             const float num = fmaxf(pc - nc, 0.f) + 1e-5f, den = pc + 1e-5f;
             const float ratio = num / den;
@@ -242,6 +286,17 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
     for (int c0 = 0; c0 < n1; c0 += 64) {
         const int j = c0 + lane;
         if (j >= n1) continue;
+        if (GA) {        // prev = sdf - ic, next = sdf + ic: d sdf = dprev + dnext, d ic = dnext - dprev
+            const float ds_ = alpha1[j] + T1[j], dic = T1[j] - alpha1[j];
+            if (ds_ != 0.f || dic != 0.f) {
+                float p[3], idx[3];
+                esr_ray_point(g.start, g.dir, sc.stepdist, step1[j], p);
+                esr_world_to_index(p, sc.xyz_min, sc.xyz_max, gdims, idx);
+                if (ds_ != 0.f) esr_tri_scatter1(P.grad_sdf, gdims, idx, ds_);
+                if (dic != 0.f) grad_alpha_ic_bwd(P.grad_sdf, gdims, idx, vd, sc.voxel_size, sc.stepdist, dic);
+            }
+            continue;
+        }
         float ds = alpha1[j] * ((j > 0) ? 0.5f : 1.f) + T1[j] * ((j < n1 - 1) ? 0.5f : 1.f);
         if (j + 1 < n1) ds += 0.5f * alpha1[j + 1];
         if (j > 0) ds += 0.5f * T1[j - 1];
@@ -332,19 +387,19 @@ __global__ void __launch_bounds__(1024) plan_kernel(const int32_t *__restrict__ 
 
 int march_cap(const esr_scene_t *sc) { return ((sc->max_steps + 63) / 64) * 64; }
 
-template <int MODE, bool COARSE = false>
+template <int MODE, bool COARSE = false, bool GA = false>
 int launch_march(MarchParams &P, hipStream_t s)
 {
     if (P.n_rays == 0) return 0;
-    constexpr int NARR = (MODE == MARCH_BWD) ? 5 : 2;
+    constexpr int NARR = ((MODE == MARCH_BWD) ? 5 : 2) + (GA ? 1 : 0);
     const size_t per_wave = (size_t)NARR * P.cap * sizeof(float);
     int wpb = 4;
     while (wpb > 1 && per_wave * wpb > 64 * 1024) wpb >>= 1;
     if (per_wave * wpb > 160 * 1024) return ESR_ECAP;
     static std::atomic<uint64_t> optin{0};             // one wave per block beyond 64 KB (cap > ~3.2k steps in BWD mode)
-    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&march_kernel<MODE, COARSE>), per_wave * wpb, optin)) return rc;
+    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&march_kernel<MODE, COARSE, GA>), per_wave * wpb, optin)) return rc;
     const int grid = (P.n_rays + wpb - 1) / wpb;
-    march_kernel<MODE, COARSE><<<grid, wpb * 64, per_wave * wpb, s>>>(P);
+    march_kernel<MODE, COARSE, GA><<<grid, wpb * 64, per_wave * wpb, s>>>(P);
     ESR_CHECK_LAUNCH();
     return 0;
 }
@@ -411,6 +466,50 @@ ESR_API int esr_fine_march_bwd(const esr_scene_t *scene, const float *rays_o, co
     P.n_rays = n_rays; P.cap = march_cap(scene); P.off3 = off3; P.dweight = dweight; P.dlast = dlast;
     P.grad_sdf = grad_sdf;
     return launch_march<MARCH_BWD>(P, esr_stream(stream));
+}
+
+// ---- cfg neus_alpha: "grad" (functions.py:45-69): the same three entry points with the batch's view directions ----
+ESR_API int esr_fine_march_count_ga(const esr_scene_t *scene, const float *rays_o, const float *rays_d, const float *viewdirs,
+                                    const float *mask_density, const float *sdf, int32_t n_rays, int32_t *cnt3,
+                                    float *alphainv_last, int32_t *ray_stats, esr_plan_t *plan, void *stream)
+{
+    if (!scene || n_rays < 0 || !plan) return ESR_EINVAL;
+    if (n_rays && (!rays_o || !rays_d || !viewdirs || !mask_density || !sdf || !cnt3 || !alphainv_last || !ray_stats))
+        return ESR_EINVAL;
+    MarchParams P = {};
+    P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d; P.viewdirs = viewdirs; P.mask_density = mask_density; P.sdf = sdf;
+    P.n_rays = n_rays; P.cap = march_cap(scene); P.cnt3 = cnt3; P.alphainv_last = alphainv_last;
+    P.stats = ray_stats; P.plan = plan;
+    return launch_march<MARCH_COUNT, false, true>(P, esr_stream(stream));
+}
+
+ESR_API int esr_fine_march_fill_ga(const esr_scene_t *scene, const float *rays_o, const float *rays_d, const float *viewdirs,
+                                   const float *mask_density, const float *sdf, int32_t n_rays, const int32_t *off3,
+                                   int32_t *rec_ray, int32_t *rec_step, float *rec_w, float *rec_sdf, void *stream)
+{
+    if (!scene || n_rays < 0) return ESR_EINVAL;
+    if (n_rays && (!rays_o || !rays_d || !viewdirs || !mask_density || !sdf || !off3 || !rec_ray || !rec_step ||
+                   !rec_w || !rec_sdf))
+        return ESR_EINVAL;
+    MarchParams P = {};
+    P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d; P.viewdirs = viewdirs; P.mask_density = mask_density; P.sdf = sdf;
+    P.n_rays = n_rays; P.cap = march_cap(scene); P.off3 = off3; P.rec_ray = rec_ray;
+    P.rec_step = rec_step; P.rec_w = rec_w; P.rec_sdf = rec_sdf;
+    return launch_march<MARCH_FILL, false, true>(P, esr_stream(stream));
+}
+
+ESR_API int esr_fine_march_bwd_ga(const esr_scene_t *scene, const float *rays_o, const float *rays_d, const float *viewdirs,
+                                  const float *mask_density, const float *sdf, int32_t n_rays, const int32_t *off3,
+                                  const float *dweight, const float *dlast, float *grad_sdf, void *stream)
+{
+    if (!scene || n_rays < 0) return ESR_EINVAL;
+    if (n_rays && (!rays_o || !rays_d || !viewdirs || !mask_density || !sdf || !off3 || !dweight || !dlast || !grad_sdf))
+        return ESR_EINVAL;
+    MarchParams P = {};
+    P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d; P.viewdirs = viewdirs; P.mask_density = mask_density; P.sdf = sdf;
+    P.n_rays = n_rays; P.cap = march_cap(scene); P.off3 = off3; P.dweight = dweight; P.dlast = dlast;
+    P.grad_sdf = grad_sdf;
+    return launch_march<MARCH_BWD, false, true>(P, esr_stream(stream));
 }
 
 // ---- coarse stage (VoxurfC): same march on the SMOOTHED sdf grid, two transmittance passes -------------

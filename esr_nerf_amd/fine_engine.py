@@ -60,6 +60,7 @@ class FineCtx:
     counts: Dict[str, int]
     rays_o: torch.Tensor
     rays_d: torch.Tensor
+    viewdirs: torch.Tensor
     off3: torch.Tensor
     mask_density: torch.Tensor
     sdf: torch.Tensor
@@ -123,6 +124,7 @@ class FineEngine:
         self.overlap_scatter = os.environ.get("ESR_OVERLAP_SCATTER", "0") != "0"
         self.dgrad_cap = int(os.environ.get("ESR_DGRAD_CAP", "256"))
         self._side = None
+        self.neus_grad = False          # cfg neus_alpha: "grad" (set by the renderer)
 
     # -- helpers ---------------------------------------------------------------
     def _s(self):
@@ -158,6 +160,15 @@ class FineEngine:
             n, ms = out.get(name, (0, 0.0))
             out[name] = (n + 1, ms + e0.elapsed_time(e1))
         return out
+
+    def _march(self, name, which, sp, rays_o, rays_d, viewdirs, *rest):
+        """One of the three march entry points; with ``neus_grad`` (cfg neus_alpha: "grad") the variants that take the
+        batch's view directions."""
+        if self.neus_grad:
+            fn = getattr(self.L, f"esr_fine_march_{which}_ga")
+            self._run(name, fn, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(viewdirs), *rest)
+        else:
+            self._run(name, getattr(self.L, f"esr_fine_march_{which}"), sp, _lib.ptr(rays_o), _lib.ptr(rays_d), *rest)
 
     def _ray_buf(self, n):
         if n not in self.ray_bufs:
@@ -233,9 +244,8 @@ class FineEngine:
         lin = torch.zeros(n, 3, dtype=torch.float32, device=self.device)
         sp = C.byref(scene)
         self._run("plan_begin", L.esr_fine_plan_begin, _lib.ptr(self.plan_dev), s)
-        self._run("march_count", L.esr_fine_march_count, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(mask_density),
-                                          _lib.ptr(sdf), n, _lib.ptr(rb["cnt3"]), _lib.ptr(last),
-                                          _lib.ptr(rb["stats"]), _lib.ptr(self.plan_dev), s)
+        self._march("march_count", "count", sp, rays_o, rays_d, viewdirs, _lib.ptr(mask_density),
+                    _lib.ptr(sdf), n, _lib.ptr(rb["cnt3"]), _lib.ptr(last), _lib.ptr(rb["stats"]), _lib.ptr(self.plan_dev), s)
         self._run("plan", L.esr_fine_plan, _lib.ptr(rb["cnt3"]), _lib.ptr(em_modes), _lib.ptr(rb["stats"]), n, _lib.ptr(rb["off3"]),
                                    _lib.ptr(self.plan_dev), s)
         self.plan_host.copy_(self.plan_dev, non_blocking=True)
@@ -249,15 +259,14 @@ class FineEngine:
             raise RuntimeError("a ray exceeded scene.max_steps; the LDS bound of the march kernel is wrong")
         ctx = FineCtx(scene=scene, n_rays=n, tiles_on=tiles_on, tiles_all=tiles_all,
                       counts=dict(m0=m0, m1=m1, m2=m2, m3=n_on + n_off, n_on=n_on, n_off=n_off),
-                      rays_o=rays_o, rays_d=rays_d, off3=rb["off3"], mask_density=mask_density, sdf=sdf)
+                      rays_o=rays_o, rays_d=rays_d, viewdirs=viewdirs, off3=rb["off3"], mask_density=mask_density, sdf=sdf)
         if tiles_all == 0:
             return ctx, last, srgb, lin
         ws.ensure(tiles_all)
         ws["rec_ray"][: tiles_all * 32].fill_(-1)
-        self._run("march_fill", L.esr_fine_march_fill, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(mask_density),
-                                         _lib.ptr(sdf), n, _lib.ptr(rb["off3"]), _lib.ptr(ws["rec_ray"]),
-                                         _lib.ptr(ws["rec_step"]), _lib.ptr(ws["rec_w"]),
-                                         _lib.ptr(ws["rec_sdf"]), s)
+        self._march("march_fill", "fill", sp, rays_o, rays_d, viewdirs, _lib.ptr(mask_density),
+                    _lib.ptr(sdf), n, _lib.ptr(rb["off3"]), _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_step"]),
+                    _lib.ptr(ws["rec_w"]), _lib.ptr(ws["rec_sdf"]), s)
         fa = self.feat_args(rays_o, rays_d, viewdirs, sdf, tiles_on, tiles_all,
                             color_on=(emo_color, off_color, None), color_off=(off_color, None, None))
         self._run("feat_fwd", L.esr_fine_feat_fwd, sp, C.byref(fa), _lib.ptr(ws["X"]), _lib.ptr(ws["gnorm"]), s)
@@ -296,8 +305,8 @@ class FineEngine:
         sp = C.byref(scene)
         em0 = torch.zeros(n, dtype=torch.int64, device=dev)            # tile partition only: every tile "off"
         self._run("plan_begin", L.esr_fine_plan_begin, _lib.ptr(self.plan_dev), s)
-        self._run("march_count", L.esr_fine_march_count, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(mask_density),
-                  _lib.ptr(sdf), n, _lib.ptr(rb["cnt3"]), _lib.ptr(last), _lib.ptr(rb["stats"]), _lib.ptr(self.plan_dev), s)
+        self._march("march_count", "count", sp, rays_o, rays_d, viewdirs, _lib.ptr(mask_density),
+                    _lib.ptr(sdf), n, _lib.ptr(rb["cnt3"]), _lib.ptr(last), _lib.ptr(rb["stats"]), _lib.ptr(self.plan_dev), s)
         self._run("plan", L.esr_fine_plan, _lib.ptr(rb["cnt3"]), _lib.ptr(em0), _lib.ptr(rb["stats"]), n, _lib.ptr(rb["off3"]),
                   _lib.ptr(self.plan_dev), s)
         self.plan_host.copy_(self.plan_dev, non_blocking=True)
@@ -313,9 +322,9 @@ class FineEngine:
         if T:
             ws.ensure(T)
             ws["rec_ray"][: T * 32].fill_(-1)
-            self._run("march_fill", L.esr_fine_march_fill, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(mask_density),
-                      _lib.ptr(sdf), n, _lib.ptr(rb["off3"]), _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_step"]),
-                      _lib.ptr(ws["rec_w"]), _lib.ptr(ws["rec_sdf"]), s)
+            self._march("march_fill", "fill", sp, rays_o, rays_d, viewdirs, _lib.ptr(mask_density),
+                        _lib.ptr(sdf), n, _lib.ptr(rb["off3"]), _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_step"]),
+                        _lib.ptr(ws["rec_w"]), _lib.ptr(ws["rec_sdf"]), s)
             fa = self.feat_args(rays_o, rays_d, viewdirs, sdf, 0, T, color_on=(None, None, None),
                                 color_off=(off_color, emo_color, None))
             self._run("feat_fwd", L.esr_fine_feat_fwd, sp, C.byref(fa), _lib.ptr(ws["X"]), _lib.ptr(ws["gnorm"]), s)
@@ -391,9 +400,9 @@ class FineEngine:
             return e
 
         def march_bwd(s_):
-            self._run("march_bwd", L.esr_fine_march_bwd, sp, _lib.ptr(ctx.rays_o), _lib.ptr(ctx.rays_d),
-                      _lib.ptr(ctx.mask_density), _lib.ptr(ctx.sdf), ctx.n_rays, _lib.ptr(ctx.off3), _lib.ptr(dweight),
-                      _lib.ptr(g_last), _lib.ptr(grads["sdf"]), s_)
+            self._march("march_bwd", "bwd", sp, ctx.rays_o, ctx.rays_d, ctx.viewdirs, _lib.ptr(ctx.mask_density),
+                        _lib.ptr(ctx.sdf), ctx.n_rays, _lib.ptr(ctx.off3), _lib.ptr(dweight), _lib.ptr(g_last),
+                        _lib.ptr(grads["sdf"]), s_)
 
         def feat_bwd(t0, t1):
             def run(s_):

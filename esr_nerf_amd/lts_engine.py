@@ -15,6 +15,7 @@ where the reference draws them) and for the autograd edge.
 from __future__ import annotations
 
 import ctypes as C
+import math
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -122,9 +123,23 @@ class _PointDraw:
         return torch.from_numpy(self._out)
 
 
+def fibonacci_hemisphere(count: int) -> torch.Tensor:
+    """``count`` unit vectors on the upper hemisphere (z >= 0) along a golden-angle spiral: the upper half of a
+    2*count-point Fibonacci sphere, k = count .. 2*count-1, azimuth = golden_angle * (k + 1), cos(polar) =
+    (k + 0.5) / count - 1 (pbr/functions.py:176-194 with random = False, up = True).  fp32 arithmetic on the host, as in the reference (an
+    int64 arange times python floats promotes to torch's default float32): the table is bit-identical to its."""
+    k = torch.arange(count, 2 * count)
+    ga = math.pi * (3.0 - math.sqrt(5.0))
+    phi = ga * ((k + 1.0) % (2 * count))
+    cos_t = ((k + 0.5) * (1.0 / count)) - 1.0
+    sin_t = torch.sqrt(1.0 - cos_t * cos_t)
+    return torch.stack([torch.cos(phi) * sin_t, torch.sin(phi) * sin_t, cos_t], dim=-1)
+
+
 class LtsEngine(FineEngine):
     def __init__(self, device, mlp_dtype: str = "f32"):
         super().__init__(device, mlp_dtype)
+        self.ray_sampling = "random"        # or "fib" (cfg.app.model.ray_sampling; esrnerf.py:188-192)
         self.prim = Pass(self.device, "primary")
         self.pts = Pass(self.device, "points")
         self.sec = Pass(self.device, "secondary")
@@ -133,6 +148,14 @@ class LtsEngine(FineEngine):
         for k, kind in (("brdf", KIND_BRDF), ("emit", KIND_EMIT)):
             self.packed[k] = torch.empty(self.L.esr_mlp_packed_floats(kind), dtype=torch.float32,
                                          device=self.device)
+
+    def _scatter_draws(self, n_pts: int, count: int) -> torch.Tensor:
+        """Un-normalised scattering directions [n_pts, count, 3] that ``esr_lts_dirs`` normalises and flips into each
+        point's hemisphere: standard-normal draws (``diffuse_scattering``, pbr/functions.py:10-18) or, with
+        ``ray_sampling: fib``, the same Fibonacci spiral for every point (``diffuse_scattering_fib``, :21-32)."""
+        if self.ray_sampling == "fib":
+            return fibonacci_hemisphere(count).to(self.device).float().expand(n_pts, count, 3).contiguous()
+        return torch.randn(n_pts, count, 3, device=self.device)
 
     # ------------------------------------------------------------------ building blocks
     def _march(self, P: Pass, scene, rays_o, rays_d, em_modes, mask_density, sdf):
@@ -365,7 +388,7 @@ class LtsEngine(FineEngine):
                 normal_c = torch.nn.functional.normalize(eg[jc, 1:4], dim=-1).contiguous()
                 base_c, rough_c, metal_c = brdf_rm[jc, 0:3].contiguous(), brdf_rm[jc, 3].contiguous(), brdf_rm[jc, 4].contiguous()
                 emit_c = emit_rm[jc, 0:3].contiguous()
-                raw = torch.randn(nc, R, 3, device=dev) if draws is None else draws[ci].to(dev).contiguous()
+                raw = self._scatter_draws(nc, R) if draws is None else draws[ci].to(dev).contiguous()
                 raw1 = torch.cat([raw, torch.ones(nc, 1, 3, device=dev)], 1).contiguous()       # slot R: unused second view
                 dirs_all = torch.empty(nc, R + 1, 3, device=dev)
                 self._run("lts_dirs", L.esr_lts_dirs, _lib.ptr(raw1), _lib.ptr(normal_c), nc, R + 1, _lib.ptr(dirs_all), s)
@@ -474,7 +497,7 @@ class LtsEngine(FineEngine):
         view_p = viewdirs[ray_p].contiguous()
         normal_p = torch.nn.functional.normalize(eg[jp, 1:4], dim=-1).contiguous()
         sdf_p = P0.bufs["rec_sdf"][: T * 32][jp].contiguous()
-        raw = torch.randn(Pn, R + 1, 3, device=dev) if draws is None else draws["dirs"].to(dev).contiguous()
+        raw = self._scatter_draws(Pn, R + 1) if draws is None or "dirs" not in draws else draws["dirs"].to(dev).contiguous()
         dirs_all = torch.empty(Pn, R + 1, 3, device=dev)
         self._run("lts_dirs", L.esr_lts_dirs, _lib.ptr(raw), _lib.ptr(normal_p), Pn, R + 1, _lib.ptr(dirs_all), s)
         v_rand = (-dirs_all[:, R]).contiguous()
@@ -610,7 +633,7 @@ class LtsEngine(FineEngine):
                                     brdf_rm[jp, 4].contiguous())
         emis_p = emit_rm[jp, 0:3].contiguous()
         umask_p = batch["uncert_masks"][ray_p].to(torch.uint8).contiguous()
-        raw = torch.randn(Pn, R + 1, 3, device=dev) if draws is None else draws["dirs"].to(dev).contiguous()
+        raw = self._scatter_draws(Pn, R + 1) if draws is None or "dirs" not in draws else draws["dirs"].to(dev).contiguous()
         dirs_all = torch.empty(Pn, R + 1, 3, device=dev)
         self._run("lts_dirs", L.esr_lts_dirs, _lib.ptr(raw), _lib.ptr(normal_p), Pn, R + 1, _lib.ptr(dirs_all), s)
         v_rand = (-dirs_all[:, R]).contiguous()

@@ -228,10 +228,18 @@ class LtsStep:
     NETS = (("off_rgbnet", "linear"), ("emo_rgbnet", "linear"), ("tonemapper", "srgb"), ("brdfnet", "brdfnet"),
             ("emitnet", "brdfnet"))
 
-    def __init__(self, model, trainer_cfg, stage: str = "lts", white_bg: bool = True, process_group=None):
+    def __init__(self, model, trainer_cfg, stage: str = "lts", white_bg: bool = True, process_group=None,
+                 split_points: bool = False):
+        """``split_points``: under data parallelism draw ``num_ltspts / G`` surface points per rank instead of
+        ``num_ltspts`` on each (the reference's setting is per process): the GLOBAL light-transport estimate then uses
+        the reference's number of points and secondary rays, and the per-rank secondary work shrinks with G."""
         if stage not in ("lts", "pdra"):
             raise ValueError("stage must be 'lts' or 'pdra'")
         self.model, self.t, self.stage, self.white_bg, self.pg = model, trainer_cfg, stage, white_bg, process_group
+        self.ltspts = int(model.num_ltspts)
+        if split_points and process_group is not None:
+            import torch.distributed as dist
+            self.ltspts = max(1, self.ltspts // dist.get_world_size(process_group))
         self._names = None
         self._flat = None
         self._sync = None
@@ -300,7 +308,7 @@ class LtsStep:
                      brdf=m.brdf.device_view(), mask=m.mask_cache.density.view(*m.mask_cache.density.shape[2:]))
         env = dict(mus=m.envmap.mus.detach(), lambdas=m.envmap.lambdas.detach(), lobes=m.envmap.lobes.detach())
         pdra = self.stage == "pdra"
-        cfg = dict(num_2ndrays=m.num_2ndrays, num_ltspts=m.num_ltspts, normal_eps=t.normal_eps, emit_eps=t.emit_eps,
+        cfg = dict(num_2ndrays=m.num_2ndrays, num_ltspts=self.ltspts, normal_eps=t.normal_eps, emit_eps=t.emit_eps,
                    pdra=m.pdra_mode, eps_grads=pdra)
         ctx, out = eng.lts_forward(m.scene_struct(), m.scene_struct(near=m.lts_near), batch, grids, env, cfg, draws)
         m.last_counts = dict(eng.prim.counts)

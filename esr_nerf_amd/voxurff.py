@@ -153,8 +153,12 @@ class VoxurfF(nn.Module):
                 raise NotImplementedError(f"libesr_hip kernels are built for {k}={v}, got {getattr(self, k)}")
         if len(self.grad_feat) != 4:
             raise NotImplementedError("libesr_hip kernels are built for 4 grad_feat radii")
-        if self.neus_alpha != "interp":
-            raise NotImplementedError("only neus_alpha='interp' (cfg/app/fine.yaml:30) is on the HIP path")
+        if self.neus_alpha not in ("interp", "grad"):
+            raise ValueError(f"neus_alpha must be 'interp' or 'grad' (functions.py:45-105), got {self.neus_alpha!r}")
+        if self.neus_alpha == "grad" and type(self).__name__ != "VoxurfF":
+            # the LTS renderer's grad mode extrapolates with the EXACT gradient (sample_sdf_expgrad); only the fine
+            # renderer's finite-difference form is on the HIP path
+            raise NotImplementedError("neus_alpha='grad' is on the HIP path for VoxurfF only")
 
     @property
     def engine(self) -> FineEngine:
@@ -163,6 +167,7 @@ class VoxurfF(nn.Module):
                 raise RuntimeError("VoxurfF renders through libesr_hip.so and needs a GPU device "
                                    "(there is no CPU fallback)")
             self._engine = FineEngine(self.device, getattr(self, "mlp_dtype", "f32"))
+            self._engine.neus_grad = self.neus_alpha == "grad"
         return self._engine
 
     def scene_struct(self):

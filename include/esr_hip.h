@@ -180,6 +180,22 @@ int esr_fine_march_bwd(const esr_scene_t *scene, const float *rays_o, const floa
                        float *grad_sdf, void *stream);
 
 /*
+ * The same three march entry points for cfg `neus_alpha: grad` (app/utils/base/functions.py:45-69): the section
+ * SDFs of a sample are sdf -+ 0.5 * dist * (viewdirs[ray] . grad) with grad = the radius-1 clamped central
+ * differences of sample_sdf_grad (app/fine/model/voxurff.py:670-721); `viewdirs` [n_rays,3] is the batch's
+ * view-direction tensor.  The backward scatters through the value tap and the six gradient taps.
+ */
+int esr_fine_march_count_ga(const esr_scene_t *scene, const float *rays_o, const float *rays_d, const float *viewdirs,
+                            const float *mask_density, const float *sdf, int32_t n_rays, int32_t *cnt3,
+                            float *alphainv_last, int32_t *ray_stats, esr_plan_t *plan, void *stream);
+int esr_fine_march_fill_ga(const esr_scene_t *scene, const float *rays_o, const float *rays_d, const float *viewdirs,
+                           const float *mask_density, const float *sdf, int32_t n_rays, const int32_t *off3,
+                           int32_t *rec_ray, int32_t *rec_step, float *rec_w, float *rec_sdf, void *stream);
+int esr_fine_march_bwd_ga(const esr_scene_t *scene, const float *rays_o, const float *rays_d, const float *viewdirs,
+                          const float *mask_density, const float *sdf, int32_t n_rays, const int32_t *off3,
+                          const float *dweight, const float *dlast, float *grad_sdf, void *stream);
+
+/*
  * Per-sample feature assembly (voxurff.py:219-254 + :678-721 + module.py:24-35; the LTS renderer's
  * esrnerf.py:728-765 uses the same features with three colour grids).
  * Colour grids are channel-last [gx,gy,gz,6] (torch.channels_last_3d storage of the reference's

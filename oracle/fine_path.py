@@ -60,6 +60,7 @@ class FineConsts:
     posbase_pe: int
     viewbase_pe: int
     colorbase_pe: int
+    neus_alpha: str = "interp"    # or "grad" (app/utils/base/functions.py:45-69)
 
 
 def grid_resolution(xyz_min: Tensor, xyz_max: Tensor, num_voxels: int):
@@ -84,6 +85,7 @@ def make_consts(cfg_model, xyz_min, xyz_max, mask_xyz_min, mask_xyz_max, mask_al
         grad_feat=torch.tensor(list(cfg_model.grad_feat), dtype=torch.float32),
         posbase_pe=int(cfg_model.posbase_pe), viewbase_pe=int(cfg_model.viewbase_pe),
         colorbase_pe=int(cfg_model.colorbase_pe),
+        neus_alpha=str(getattr(cfg_model, "neus_alpha", "interp")),
     )
 
 
@@ -171,6 +173,31 @@ def neus_alpha_interp(sdf: Tensor, ray_id: Tensor, s_val: float) -> Tensor:
     return ((F.relu(pc - nc) + 1e-5) / (pc + 1e-5)).clip(0.0, 1.0)
 
 
+def neus_alpha_grad(viewdirs: Tensor, ray_id: Tensor, dist: Tensor, sdf: Tensor, grad: Tensor, s_val: float) -> Tensor:
+    """cfg ``neus_alpha: grad`` (functions.py:45-69): section SDFs extrapolated along the ray from the sample's own
+    value and gradient, sdf -+ 0.5 * dist * (viewdir . grad)."""
+    half = (viewdirs[ray_id] * grad).sum(-1) * dist * 0.5
+    pc = torch.sigmoid((sdf - half) * s_val)
+    nc = torch.sigmoid((sdf + half) * s_val)
+    return ((F.relu(pc - nc) + 1e-5) / (pc + 1e-5)).clip(0.0, 1.0)
+
+
+def sdf_value_and_grad(c: FineConsts, P, pts: Tensor):
+    """``sample_sdf_grad`` (voxurff.py:670-676): value + radius-1 clamped central differences, in world xyz order."""
+    sdf = sample_grid(P["sdf.grid"], to_norm(pts, c.xyz_min, c.xyz_max))[:, 0]
+    _, g1, _ = sdf_stencil(c, P["sdf.grid"], pts, torch.tensor([1.0]))
+    return sdf, torch.cat([g1[:, [2]], g1[:, [1]], g1[:, [0]]], -1)
+
+
+def alpha_of(c: FineConsts, P, pts: Tensor, ray_id: Tensor, viewdirs: Tensor, s_val: float):
+    """(sdf, alpha) of the mask-cache survivors under the configured NeuS alpha mode (voxurff.py:193-199)."""
+    if c.neus_alpha == "grad":
+        sdf, grad = sdf_value_and_grad(c, P, pts)
+        return sdf, neus_alpha_grad(viewdirs, ray_id, c.stepsize * c.voxel_size, sdf, grad, s_val)
+    sdf = sample_grid(P["sdf.grid"], to_norm(pts, c.xyz_min, c.xyz_max))[:, 0]
+    return sdf, neus_alpha_interp(sdf, ray_id, s_val)
+
+
 class _Composite(torch.autograd.Function):
     """alpha -> (weights, alphainv_last) with the reference's early stop, through
     the C oracle (module.py:117-143 semantics)."""
@@ -243,8 +270,7 @@ def forward_training(P: Dict[str, Tensor], c: FineConsts, batch: Dict[str, Tenso
     pts, ray_id, step_id = pts[m], ray_id[m], step_id[m]
     n1 = pts.shape[0]
 
-    sdf = sample_grid(P["sdf.grid"], to_norm(pts, c.xyz_min, c.xyz_max))[:, 0]
-    alpha = neus_alpha_interp(sdf, ray_id, s_val)
+    sdf, alpha = alpha_of(c, P, pts, ray_id, viewdirs, s_val)
 
     m = alpha > c.fastcolor_thres
     alpha, pts, ray_id, step_id, sdf = alpha[m], pts[m], ray_id[m], step_id[m], sdf[m]
@@ -309,8 +335,7 @@ def forward_evaluate(P: Dict[str, Tensor], c: FineConsts, batch: Dict[str, Tenso
     pts, ray_id, step_id = pts[inb], ray_id[inb], step_id[inb]
     m = mask_cache(c, pts)
     pts, ray_id, step_id = pts[m], ray_id[m], step_id[m]
-    sdf = sample_grid(P["sdf.grid"], to_norm(pts, c.xyz_min, c.xyz_max))[:, 0]
-    alpha = neus_alpha_interp(sdf, ray_id, s_val)
+    sdf, alpha = alpha_of(c, P, pts, ray_id, viewdirs, s_val)
     m = alpha > c.fastcolor_thres
     alpha, pts, ray_id, step_id, sdf = alpha[m], pts[m], ray_id[m], step_id[m], sdf[m]
     zeros = torch.zeros(N, 3)

@@ -29,6 +29,8 @@ CASES = {
     "fine_g16_prune_oblique": (dict(name="g16", oblique=True, mask="prune"), 60.0),
     # data.white_bg = False (the dtu configs, cfg/data/dtu.yaml): the loss adds no background term
     "fine_g16_prune_oblique_nobg": (dict(name="g16", oblique=True, mask="prune"), 60.0),
+    # cfg neus_alpha: "grad" (functions.py:45-69): per-sample extrapolation with the finite-difference gradient
+    "fine_g16_prune_oblique_gradalpha": (dict(name="g16", oblique=True, mask="prune"), 60.0),
 }
 
 
@@ -58,19 +60,21 @@ def main():
     cfg = fine_cfg("cpu")
 
     models = {}
-    for mask in ("full", "prune"):
+    for mask in ("full", "prune", "prune/grad"):
         torch.manual_seed(0)
         np.random.seed(0)
-        base = slab_scene("g16", mask=mask)
-        model = ns.VoxurfF(cfg, base.near, base.far, base.xyz_min, base.xyz_max, base.mask_xyz_min,
+        base = slab_scene("g16", mask=mask.split("/")[0])
+        mcfg = cfg if "/" not in mask else fine_cfg("cpu", neus_alpha="grad")
+        model = ns.VoxurfF(mcfg, base.near, base.far, base.xyz_min, base.xyz_max, base.mask_xyz_min,
                            base.mask_xyz_max, base.mask_alpha_init, base.mask_density, base.s_val,
                            base.num_voxels)
         init_slab_model(model, base)
         model.train()
         models[mask] = model
     sd = {k: v.detach().clone() for k, v in models["full"].state_dict().items()}
-    for k, v in models["prune"].state_dict().items():
-        assert torch.equal(v, sd[k]), k            # the mask cache is not a parameter: one parameter file serves both
+    for mk in ("prune", "prune/grad"):
+        for k, v in models[mk].state_dict().items():
+            assert torch.equal(v, sd[k]), k        # mask cache and alpha mode are not parameters: one parameter file
     model = models["full"]
     np.savez_compressed(
         os.path.join(OUT, "fine_g16_params.npz"),
@@ -106,7 +110,7 @@ def main():
     for case, (skw, s_val) in CASES.items():
         sc = slab_scene(s_val=s_val, **skw)
         b = sc.batch
-        model = models[skw.get("mask", "full")]
+        model = models[skw.get("mask", "full") + ("/grad" if case.endswith("_gradalpha") else "")]
         model.zero_grad(set_to_none=True)
         rec.clear()
         hook = model.mask_cache.register_forward_hook(lambda mod, a, out: rec.__setitem__("mask_keep", out.clone()))
@@ -151,6 +155,7 @@ def main():
 
     ru.sample_pts_on_rays, ru.alpha2weight, ru.alpha2weight_backward = real_sample, real_a2w, real_a2w_b
     gen_host(ns)
+    gen_lts(ns, "prune", "fib")
     for mask in ("full", "prune"):
         gen_lts(ns, mask)
         gen_finetune(ns, mask)
@@ -290,11 +295,12 @@ def lts_reference_loss(ns, results, rgbs, cfg):
     return loss
 
 
-def gen_lts(ns, mask="full"):
+def gen_lts(ns, mask="full", sampling="random"):
     """ESRNeRF.forward_training (lts and pdra mode) on the small oblique slab, with every random draw
-    of the reference recorded so that restatements can be fed the same numbers."""
+    of the reference recorded so that restatements can be fed the same numbers.  ``sampling="fib"``: the
+    ``ray_sampling: fib`` variant (esrnerf.py:188-192; deterministic Fibonacci-spiral scattering directions)."""
     from esr_nerf_amd.config import lts_cfg
-    cfg = lts_cfg("cpu", num_2ndrays=8, num_ltspts=12)
+    cfg = lts_cfg("cpu", num_2ndrays=8, num_ltspts=12, ray_sampling=sampling)
     sc = slab_scene("g16", s_val=60.0, oblique=True, mask=mask)
     torch.manual_seed(0)
     np.random.seed(0)
@@ -313,7 +319,7 @@ def gen_lts(ns, mask="full"):
                 assert np.array_equal(z[k], v.detach().numpy()), k     # same parameters under every mask variant
     b = dict(sc.batch)
     b["uncert_masks"] = (torch.arange(sc.n_rays) % 3 == 0)
-    for mode in ("lts", "pdra"):
+    for mode in (("lts", "pdra") if sampling == "random" else ("lts",)):
         model.pdra_mode = mode == "pdra"
         model.zero_grad(set_to_none=True)
         rec = {"randn": [], "randn_like": []}
@@ -349,17 +355,18 @@ def gen_lts(ns, mask="full"):
         out = {"in/" + k: v.numpy() for k, v in b.items()}
         out["in/s_val"] = np.float32(60.0)
         out["draw/idx"] = rec["idx"].astype(np.int64)
-        out["draw/dirs"] = rec["randn"][0].numpy()
+        if sampling == "random":
+            out["draw/dirs"] = rec["randn"][0].numpy()
         out["draw/noise_normal"] = rec["randn_like"][0].numpy()
         out["draw/noise_emit"] = rec["randn_like"][1].numpy()
-        assert len(rec["randn"]) == 1 and len(rec["randn_like"]) == 2
+        assert len(rec["randn"]) == (1 if sampling == "random" else 0) and len(rec["randn_like"]) == 2
         for k, v in res_raw.items():
             out["out/" + k] = v.numpy()
         out["loss"] = loss.detach().numpy()
         for k, p in model.named_parameters():
             if p.grad is not None:
                 out["grad/" + k] = p.grad.detach().numpy()
-        np.savez_compressed(os.path.join(OUT, f"lts_g16_{mode}{_sfx(mask)}.npz"), **out)
+        np.savez_compressed(os.path.join(OUT, f"lts_g16_{mode}{_sfx(mask)}{'' if sampling == 'random' else '_' + sampling}.npz"), **out)
         print("lts", mode, "loss", float(loss), "M3", res_raw["etc/normal"].shape[0],
               "grads", sum(1 for k in out if k.startswith("grad/")))
 
@@ -619,6 +626,9 @@ def gen_eval(ns, mask="full"):
 
 if __name__ == "__main__":
     import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "fib":
+        gen_lts(ref_import.load(), "prune", "fib")
+        raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "host":
         gen_host(ref_import.load())
         raise SystemExit(0)

@@ -24,6 +24,8 @@ restatement and the HIP path can be fed identical numbers.
 """
 from __future__ import annotations
 
+import math
+
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -76,6 +78,18 @@ def sdf_expgrad(c: fp.FineConsts, grid: Tensor, pts: Tensor):
         sdf = trilinear_xyz(c, grid, p)
         (g,) = torch.autograd.grad(sdf.sum(), p, create_graph=True)
     return sdf, g
+
+
+def fib_dirs(count: int) -> Tensor:
+    """Fibonacci-spiral hemisphere table of ``ray_sampling: fib`` (pbr/functions.py:176-194, random = False, up = True):
+    point k of a 2*count-point spiral for k = count .. 2*count-1; azimuth golden_angle * ((k + 1) mod 2 count), height
+    (k + 0.5) / count - 1.  Used as the un-normalised ``dirs`` draw: every surface point gets the same table."""
+    k = torch.arange(count, 2 * count).to(torch.float32)
+    golden = math.pi * (3.0 - math.sqrt(5.0))
+    az = golden * torch.remainder(k + 1.0, 2 * count)
+    h = (k + 0.5) * (1.0 / count) - 1.0
+    r = torch.sqrt(1.0 - h * h)
+    return torch.stack([torch.cos(az) * r, torch.sin(az) * r, h], -1)
 
 
 def hemisphere_dirs(normal: Tensor, raw: Tensor) -> Tensor:

@@ -33,7 +33,7 @@ def golden_params():
 
 
 @pytest.fixture(scope="session", params=["fine_g16_axis", "fine_g16_oblique", "fine_g16_prune_axis", "fine_g16_prune_oblique",
-                                        "fine_g16_prune_oblique_nobg"])
+                                        "fine_g16_prune_oblique_nobg", "fine_g16_prune_oblique_gradalpha"])
 def golden_case(request):
     z = load_npz(request.param + ".npz")
     return request.param, {k: torch.from_numpy(np.asarray(v)) for k, v in z.items()}
@@ -44,6 +44,11 @@ def golden_scene(name, z):
     from esr_nerf_amd.synthetic import slab_scene
     return slab_scene("g16", oblique="oblique" in name, s_val=float(z["in/s_val"]),
                       mask="prune" if "_prune" in name else "full")
+
+
+def golden_alpha_mode(name):
+    """cfg neus_alpha of a fine_g16_* fixture."""
+    return "grad" if name.endswith("_gradalpha") else "interp"
 
 
 def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:

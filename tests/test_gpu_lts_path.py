@@ -29,15 +29,20 @@ def build_lts_model(scene, **over):
     return m, cfg
 
 
-@pytest.mark.parametrize("mask", MASKS)
-@pytest.mark.parametrize("mode", ["lts", "pdra"])
+@pytest.mark.parametrize("mode,mask", [("lts", "full"), ("pdra", "full"), ("lts", "prune"), ("pdra", "prune"),
+                                       ("lts", "prune_fib")])
 def test_lts_golden_reference_vectors(mode, mask):
+    """``prune_fib``: ``ray_sampling: fib`` -- the engine builds the Fibonacci scattering table itself (the fixture
+    holds no direction draw), the surface points and the two noise draws are replayed."""
     from esr_nerf_amd.synthetic import slab_scene
     from oracle import lts_path as lp
+    fib = mask.endswith("_fib")
     z = {k: torch.from_numpy(np.asarray(v)) for k, v in load_npz(f"lts_g16_{mode}{sfx(mask)}.npz").items()}
+    mask = mask.replace("_fib", "")
     sd = {k: torch.from_numpy(v) for k, v in load_npz("lts_g16_params.npz").items()}
     sc = slab_scene("g16", s_val=60.0, oblique=True, mask=mask)
-    m, cfg = build_lts_model(sc, num_2ndrays=8, num_ltspts=12)
+    m, cfg = build_lts_model(sc, num_2ndrays=8, num_ltspts=12, ray_sampling="fib" if fib else "random")
+    assert ("draw/dirs" in z) != fib and m.engine.ray_sampling == ("fib" if fib else "random")
     m.load_state_dict({k: v.cuda() for k, v in sd.items()})
     m.pdra_mode = (mode == "pdra")
     b = {k[3:]: v.cuda() for k, v in z.items() if k.startswith("in/") and k != "in/s_val"}

@@ -89,8 +89,9 @@ def test_no_cpu_fallback_and_loud_config_errors():
         m(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=b["em_modes"], s_val=20.0)
     with pytest.raises(NotImplementedError):
         _cpu_model(rgbnet_width=128)
-    with pytest.raises(NotImplementedError):
-        _cpu_model(neus_alpha="grad")
+    assert _cpu_model(neus_alpha="grad")[0].neus_alpha == "grad"        # both alpha modes of functions.py:45-105 exist
+    with pytest.raises(ValueError):
+        _cpu_model(neus_alpha="other")
     m.eval()                                   # image rendering is on the HIP path too: no CPU fallback either
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=0, pos_rt=torch.eye(3))
