@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
         const int xvoff = (h * 32 + s) * 4;
         const bool det = t < A.t_det;                        // wave-uniform
         const int coff = (det ? A.crow_det : A.crow) * 128;
-        const bool save = A.save && !det;
+        const bool save = A.save && !det;                    // 1: hidden tiles + ReLU masks, 2: masks only
         ESR_STAMP(0);
         float B1[KP1];
 #pragma unroll
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
             __builtin_amdgcn_s_setprio(3);                // (see the note on wave priorities above the kernel)
             relu_tiles<HT>(cur);
             if (save) {
-                store_tiles<HT>(make_rsrc(A.H[l] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
+                if (A.save == 1) store_tiles<HT>(make_rsrc(A.H[l] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
                 store_relu_mask<HT>(make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), cur, lane);
             }
             __builtin_amdgcn_s_setprio(0);
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256, 2) mlp_dgrad_kernel(DgradArgs A)
         layer_from_regs<4, HT>(W, (int)L.off_wb[NHID] * 4, B0, cur, lane);
         __builtin_amdgcn_s_setprio(3);
         apply_relu_mask<HT>(msk[NHID - 1], cur);
-        store_tiles<HT>(make_rsrc(A.dZ[NHID - 1] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
+        if (A.dZ[NHID - 1]) store_tiles<HT>(make_rsrc(A.dZ[NHID - 1] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
         __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int l = NHID - 1; l >= 1; --l) {
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256, 2) mlp_dgrad_kernel(DgradArgs A)
             layer_from_acc<HT, HT>(W, (int)L.off_wb[l] * 4, cur, nxt, lane);
             __builtin_amdgcn_s_setprio(3);
             apply_relu_mask<HT>(msk[l - 1], nxt);
-            store_tiles<HT>(make_rsrc(A.dZ[l - 1] + (size_t)t * (HBYTES / 4), HBYTES), nxt, lane);
+            if (A.dZ[l - 1]) store_tiles<HT>(make_rsrc(A.dZ[l - 1] + (size_t)t * (HBYTES / 4), HBYTES), nxt, lane);
             __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int it = 0; it < HT; ++it) cur[it] = nxt[it];
@@ -764,13 +764,13 @@ ESR_API int esr_mlp_fwd(int kind, const float *packed, const float *X, int32_t t
     if (!packed || !X || !zout) return ESR_EINVAL;
     const int nhid = net_desc(kind).n_layers - 1;
     FwdArgs A = {};
-    A.packed = packed; A.X = X; A.t0 = t0; A.t1 = t1; A.save = save ? 1 : 0; A.crow = color_row0;
+    A.packed = packed; A.X = X; A.t0 = t0; A.t1 = t1; A.save = save == 2 ? 2 : save ? 1 : 0; A.crow = color_row0;
     A.zout = zout;
     if (save) {
-        if (!H || !M) return ESR_EINVAL;
+        if (!M || (save != 2 && !H)) return ESR_EINVAL;
         for (int l = 0; l < nhid; ++l) {
-            if (!H[l] || !M[l]) return ESR_EINVAL;
-            A.H[l] = H[l];
+            if (!M[l] || (save != 2 && !H[l])) return ESR_EINVAL;
+            A.H[l] = save != 2 ? H[l] : nullptr;
             A.M[l] = M[l];
         }
     }
@@ -828,8 +828,8 @@ ESR_API int esr_mlp_dgrad_wg(int kind, const float *packed, const float *dz, int
     DgradArgs A = {};
     A.packed = packed; A.dz = dz; A.t0 = t0; A.t1 = t1; A.dX = dX;
     for (int l = 0; l < nhid; ++l) {
-        if (!M[l] || !dZ[l]) return ESR_EINVAL;
-        A.M[l] = M[l]; A.dZ[l] = dZ[l];
+        if (!M[l]) return ESR_EINVAL;
+        A.M[l] = M[l]; A.dZ[l] = dZ[l];      // a NULL dZ[l] is not stored (its weight gradient recomputes it)
     }
     int grid = mlp_grid(t1 - t0);
     if (max_workgroups > 0 && grid > max_workgroups) grid = max_workgroups;

@@ -1,0 +1,257 @@
+// Weight gradients of the tone mapper (TonemapNet 33 -> 192 -> 3, app/utils/pbr/module.py:24-39) WITHOUT its saved
+// hidden tiles: the hidden layer is recomputed, in a TRANSPOSED accumulator layout, inside the kernel that contracts
+// over the samples.
+//
+// Why a kernel of its own.  The tone mapper runs on every surviving sample (16 384 tiles at C2) but carries 13x less
+// matrix work per sample than a radiance net, so with the save-everything scheme of mlp.hip its three passes are pure
+// tile traffic: the forward writes Ht (24 KB per tile), the input-gradient pass writes dZt (24 KB), the weight-gradient
+// launches read both back (0.53 ms per step for 0.14 ms of matrix work at peak).  Recomputing the 33 -> 192 layer costs
+// 120 MFMAs per tile -- less than moving one of those tiles.
+//
+// The transposition problem and how it disappears.  dW = sum over SAMPLES needs the sample index as the MFMA's k, i.e.
+// in registers, while the forward chain (mlp.hip) keeps the sample on the LANE.  Here the hidden layer is evaluated as
+//     Ht^T[s][u] = sum_x Xt^T[s][x] W0^T[x][u]        (A = the X tile exactly as the forward loads it, B = W0^T)
+// whose 32x32 accumulator has the UNIT on the lane and the SAMPLE in the register: precisely the A-operand layout of
+//     dW0[u][x] += sum_s dZt^T[s][u] Xt[x][s]
+// and the natural layout for per-lane (= per-unit) FMA sums of dW1[c][u] = sum_s dzt[c][s] Ht^T[s][u], db0, and the
+// 33rd input column.  Nothing is transposed through memory; the only staged data is the wave's own 6-KB X tile
+// (written to LDS from the registers it was loaded into, read back row-per-lane as the B operand of dW0).
+//
+// A pair of waves = one tile at a time (each wave half of the hidden units), accumulators for dW0/dW1/db in registers
+// across the pair's tile range (1 wave per SIMD), partial sums to a per-pair slab, summed by a small reduce kernel.  fp32 throughout
+// (v_mfma_f32_32x32x2_f32): the recomputed Ht equals the forward's up to summation order.
+#include "esr_common.h"
+
+#include "mlp_common.h"
+
+namespace {
+
+constexpr int TIN = 33, THID = 192, TOUT = 3, TKP = 20;       // inputs, hidden units, outputs, k-pairs of the 40 padded input rows
+constexpr int XT_ROWS = 48;                                    // rows of the Xt tile in memory
+constexpr int XS = 36;                                         // LDS row stride (floats) of the staged tiles: 16-B reads of 16
+                                                               // consecutive rows then hit 16 distinct 4-bank groups
+constexpr int W0T_FLOATS = 2 * TKP * THID;                     // W0^T [40][192] in LDS
+constexpr int WAVE_LDS = (2 * TKP + 4) * XS;                   // per wave: Xt rows 0..39 + dzt rows 0..3
+constexpr int N_DW0 = THID * TIN, N_DW1 = TOUT * THID;
+constexpr int SLAB = N_DW0 + N_DW1 + THID + 4;                 // floats per wave slab: dW0 | dW1 | db0 | db1(+pad)
+
+struct ToneWgArgs {
+    const float *Xt, *dzt;                  // [tiles][48][32], [tiles][4][32]
+    const float *W0, *b0, *W1;              // reference layout: [192][33], [192], [3][192]
+    int t0, t1;
+    float *slab;                            // [n_wave_pairs][SLAB]
+};
+
+__global__ void __launch_bounds__(256, 1) tone_wgrad_t_kernel(ToneWgArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *w0t = lds;                                                   // [40][192]: w0t[x * 192 + u] = W0[u][x]
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, ul = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *lx = lds + W0T_FLOATS + wv * WAVE_LDS;                       // this wave's staged Xt tile [40][XS]
+    float *lz = lx + 2 * TKP * XS;                                      // and dzt tile [4][XS]
+    for (int i = tid; i < W0T_FLOATS; i += 256) {
+        const int x = i / THID, u = i % THID;
+        w0t[i] = x < TIN ? A.W0[u * TIN + x] : 0.f;
+    }
+    __syncthreads();
+
+    // Two waves share a sample tile: wave parity g owns hidden units [96 g, 96 g + 96) -- three 32-unit accumulator
+    // tiles of everything (Ht / dZt 48 registers, dW0 48): the whole working set stays inside the 256 architected VGPRs
+    // (with all 192 units in one wave the compiler spilled ~100 registers: VALU use of an accumulator tile needs it in
+    // the architected half of the file).  The X tile is loaded by both (6 KB, second read from L2).
+    const int g = wv & 1;
+    // stationary operands: B of dHt^T (W1[c][u], pairs (0,1) and (2,-)), the hidden bias
+    float w1b[3][2], b0r[3];
+#pragma unroll
+    for (int i3 = 0; i3 < 3; ++i3) {
+        const int u = 96 * g + 32 * i3 + ul;
+        w1b[i3][0] = A.W1[h * THID + u];                               // c = 0 + h
+        w1b[i3][1] = h == 0 ? A.W1[2 * THID + u] : 0.f;                // c = 2 + h (row 3 does not exist)
+        b0r[i3] = A.b0[u];
+    }
+    f32x16 dW0[3];
+    zero_tiles<3>(dW0);
+    float dW0c[3], dW1r[3][3], db0r[3], db1r[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i3 = 0; i3 < 3; ++i3) {
+        dW0c[i3] = 0.f; db0r[i3] = 0.f;
+        dW1r[i3][0] = dW1r[i3][1] = dW1r[i3][2] = 0.f;
+    }
+
+    const int pair = blockIdx.x * 2 + (wv >> 1), npairs = gridDim.x * 2;
+    // A operand of Ht^T (sample on the lane, input row in the register) = what the forward loads.  One wave per SIMD
+    // has nobody to hide its global-load latency behind: the NEXT tile's 22 loads are issued before this tile's math.
+    float xn[TKP], zn[2];
+    auto fetch = [&](int t) {
+        const bool live = t < A.t1;
+        const float *X = A.Xt + (size_t)(live ? t : A.t0) * XT_ROWS * 32 + ul;
+        const float *Zt = A.dzt + (size_t)(live ? t : A.t0) * 4 * 32 + ul;
+#pragma unroll
+        for (int j = 0; j < TKP; ++j) xn[j] = X[(2 * j + h) * 32];
+        zn[0] = Zt[h * 32];
+        zn[1] = h == 0 ? Zt[2 * 32] : 0.f;
+    };
+    if (A.t0 + pair < A.t1) fetch(A.t0 + pair);
+    for (int t = A.t0 + pair; t < A.t1; t += npairs) {
+        float xa[TKP], za[2];
+#pragma unroll
+        for (int j = 0; j < TKP; ++j) xa[j] = xn[j];
+        za[0] = zn[0]; za[1] = zn[1];
+        fetch(t + npairs);                              // (past the range: re-reads tile t0, never used)
+        db1r[0] += za[0]; db1r[1] += za[1];
+#pragma unroll
+        for (int j = 0; j < TKP; ++j) lx[(2 * j + h) * XS + ul] = xa[j];
+        lz[h * XS + ul] = za[0];
+        if (h == 0) lz[2 * XS + ul] = za[1];
+        // ---- Ht^T[s][u]: accumulator register r of lane (u, h) holds sample s = acc_row(r, h)
+        f32x16 ht[3];
+#pragma unroll
+        for (int i3 = 0; i3 < 3; ++i3)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ht[i3][r] = b0r[i3];
+#pragma unroll
+        for (int j = 0; j < TKP; ++j) {                 // k-pair outer: three B values live at a time
+            float wb[3];
+#pragma unroll
+            for (int i3 = 0; i3 < 3; ++i3) wb[i3] = w0t[(2 * j + h) * THID + 96 * g + 32 * i3 + ul];
+#pragma unroll
+            for (int i3 = 0; i3 < 3; ++i3) ht[i3] = mfma32(xa[j], wb[i3], ht[i3]);
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        relu_tiles<3>(ht);
+        // ---- dW1[c][u] += sum_s dzt[c][s] Ht[u][s]: per-lane sums over this lane's 16 samples; the per-sample scalars
+        // of this half-wave come from LDS four samples at a time (register r = 4q + i holds sample 8q + 4h + i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a = *reinterpret_cast<const float4 *>(lz + 0 * XS + 8 * q + 4 * h);
+            const float4 b = *reinterpret_cast<const float4 *>(lz + 1 * XS + 8 * q + 4 * h);
+            const float4 c = *reinterpret_cast<const float4 *>(lz + 2 * XS + 8 * q + 4 * h);
+            const float za4[4] = {a.x, a.y, a.z, a.w}, zb4[4] = {b.x, b.y, b.z, b.w}, zc4[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int i3 = 0; i3 < 3; ++i3)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    dW1r[i3][0] = fmaf(za4[i], ht[i3][4 * q + i], dW1r[i3][0]);
+                    dW1r[i3][1] = fmaf(zb4[i], ht[i3][4 * q + i], dW1r[i3][1]);
+                    dW1r[i3][2] = fmaf(zc4[i], ht[i3][4 * q + i], dW1r[i3][2]);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float x32[16];                                  // Xt row 32 (the 33rd input) at this half-wave's 16 samples
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 d = *reinterpret_cast<const float4 *>(lx + 32 * XS + 8 * q + 4 * h);
+            x32[4 * q] = d.x; x32[4 * q + 1] = d.y; x32[4 * q + 2] = d.z; x32[4 * q + 3] = d.w;
+        }
+        // ---- dHt^T = dzt^T W1, masked by the recomputed activation: dZt^T (same layout)
+#pragma unroll
+        for (int i3 = 0; i3 < 3; ++i3) {
+            f32x16 d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = 0.f;
+            d = mfma32(za[0], w1b[i3][0], d);
+            d = mfma32(za[1], w1b[i3][1], d);
+            float sb = 0.f, sc = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = ht[i3][r] > 0.f ? d[r] : 0.f;
+                ht[i3][r] = v;                                         // Ht is dead from here: the tile now holds dZt^T
+                sb += v;
+                sc = fmaf(v, x32[r], sc);
+            }
+            db0r[i3] += sb;
+            dW0c[i3] += sc;                                            // input column 32 (the 33rd row of Xt)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- dW0[u][x] += sum_s dZt^T[s][u] Xt[x][s], x = 0..31: A = the dZt^T registers, B = Xt row-per-lane from LDS
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 xb = *reinterpret_cast<const float4 *>(lx + ul * XS + 8 * q + 4 * h);
+#pragma unroll
+            for (int i3 = 0; i3 < 3; ++i3) {
+                dW0[i3] = mfma32(ht[i3][4 * q + 0], xb.x, dW0[i3]);
+                dW0[i3] = mfma32(ht[i3][4 * q + 1], xb.y, dW0[i3]);
+                dW0[i3] = mfma32(ht[i3][4 * q + 2], xb.z, dW0[i3]);
+                dW0[i3] = mfma32(ht[i3][4 * q + 3], xb.w, dW0[i3]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- flush this wave's partial sums into its pair's slab: dW0 [192][33] | dW1 [3][192] | db0 [192] | db1 [3]
+    float *S = A.slab + (size_t)pair * SLAB;
+#pragma unroll
+    for (int i3 = 0; i3 < 3; ++i3) {
+        const int ub = 96 * g + 32 * i3;
+        // accumulator of dW0: column = x (lane), row = u_local = acc_row(r, h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[(ub + acc_row(r, h)) * TIN + ul] = dW0[i3][r];
+        const int u = ub + ul;
+        const float c32 = dW0c[i3] + __shfl_xor(dW0c[i3], 32);
+        const float b = db0r[i3] + __shfl_xor(db0r[i3], 32);
+        float w1[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) w1[c] = dW1r[i3][c] + __shfl_xor(dW1r[i3][c], 32);
+        if (h == 0) {
+            S[u * TIN + 32] = c32;
+            S[N_DW0 + N_DW1 + u] = b;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) S[N_DW0 + c * THID + u] = w1[c];
+        }
+    }
+    float d0 = db1r[0], d1 = db1r[1];                                   // db1: rows h and 2 + h, summed over the 32 samples
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) { d0 += __shfl_xor(d0, off); d1 += __shfl_xor(d1, off); }
+    if (ul == 0 && g == 0) {                                            // (both waves of a pair saw the same dzt)
+        S[N_DW0 + N_DW1 + THID + h] = d0;
+        if (h == 0) { S[N_DW0 + N_DW1 + THID + 2] = d1; S[N_DW0 + N_DW1 + THID + 3] = 0.f; }
+    }
+}
+
+// gw[e] += sum over the wave slabs, all four outputs in one launch
+__global__ void __launch_bounds__(256) tone_wgrad_reduce_kernel(const float *__restrict__ slab, int n_slabs,
+                                                                float *gw0, float *gw1, float *gb0, float *gb1)
+{
+    constexpr int PG = 32;
+    const int groups = (n_slabs + PG - 1) / PG;
+    const int total = (SLAB - 1) * groups;                              // the pad word of db1 is skipped
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int e = i % (SLAB - 1), g = i / (SLAB - 1);
+        const int p1 = min((g + 1) * PG, n_slabs);
+        float acc = 0.f;
+        for (int p = g * PG; p < p1; ++p) acc += slab[(size_t)p * SLAB + e];
+        float *dst = e < N_DW0 ? gw0 + e : e < N_DW0 + N_DW1 ? gw1 + (e - N_DW0)
+                   : e < N_DW0 + N_DW1 + THID ? gb0 + (e - N_DW0 - N_DW1) : gb1 + (e - N_DW0 - N_DW1 - THID);
+        atomicAdd(dst, acc);
+    }
+}
+
+}  // namespace
+
+ESR_API int64_t esr_tone_wgrad_scratch_floats(void) { return (int64_t)512 * SLAB; }
+
+ESR_API int esr_tone_wgrad_recompute(const float *Xt, const float *dzt, const float *W0, const float *b0, const float *W1,
+                                     int32_t t0, int32_t t1, float *gw0, float *gb0, float *gw1, float *gb1,
+                                     float *scratch, int64_t scratch_floats, void *stream)
+{
+    if (t0 < 0 || t1 < t0) return ESR_EINVAL;
+    if (t1 == t0) return 0;
+    if (!Xt || !dzt || !W0 || !b0 || !W1 || !gw0 || !gb0 || !gw1 || !gb1 || !scratch) return ESR_EINVAL;
+    const int n_tiles = t1 - t0;
+    int grid = (n_tiles + 1) / 2;                                      // a workgroup = two wave pairs = two tiles at a time
+    if (grid > 256) grid = 256;                                        // one workgroup (4 waves, 1 per SIMD) per CU
+    if ((int64_t)grid * 2 * SLAB > scratch_floats) return ESR_ECAP;
+    constexpr size_t lds_bytes = (size_t)(W0T_FLOATS + 4 * WAVE_LDS) * sizeof(float);
+    static std::atomic<uint64_t> optin{0};
+    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&tone_wgrad_t_kernel), lds_bytes, optin)) return rc;
+    ToneWgArgs A = {Xt, dzt, W0, b0, W1, t0, t1, scratch};
+    hipStream_t s = esr_stream(stream);
+    tone_wgrad_t_kernel<<<grid, 256, lds_bytes, s>>>(A);
+    ESR_CHECK_LAUNCH();
+    const int n_slabs = grid * 2;
+    tone_wgrad_reduce_kernel<<<esr_grid_for((int64_t)(SLAB - 1) * ((n_slabs + 31) / 32), 256, 1024), 256, 0, s>>>(
+        scratch, n_slabs, gw0, gw1, gb0, gb1);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}

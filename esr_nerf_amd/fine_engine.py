@@ -124,6 +124,12 @@ class FineEngine:
         self.overlap_scatter = os.environ.get("ESR_OVERLAP_SCATTER", "0") != "0"
         self.dgrad_cap = int(os.environ.get("ESR_DGRAD_CAP", "256"))
         self._side = None
+        self._raw: Dict[str, tuple] = {}
+        # f32 engine: the tone mapper's weight gradients recompute its hidden layer (csrc/tone_wgrad.hip), so its forward
+        # keeps only the ReLU masks and its input-gradient pass stores no dZt
+        self.tone_recompute = not self.bf16
+        self.tone_scratch = torch.empty(self.L.esr_tone_wgrad_scratch_floats() if self.tone_recompute else 1,
+                                        dtype=torch.float32, device=self.device)
         self.neus_grad = False          # cfg neus_alpha: "grad" (set by the renderer)
 
     # -- helpers ---------------------------------------------------------------
@@ -179,6 +185,7 @@ class FineEngine:
         return self.ray_bufs[n]
 
     def pack(self, which: str, kind: int, weights: List[torch.Tensor], biases: List[torch.Tensor]):
+        self._raw[which] = (list(weights), list(biases))      # reference-layout tensors (esr_tone_wgrad_recompute reads them)
         w = _lib.EsrMlpWeights()
         for i, (a, b) in enumerate(zip(weights, biases)):
             if not (a.is_cuda and a.is_contiguous() and b.is_contiguous() and a.dtype == torch.float32):
@@ -286,7 +293,7 @@ class FineEngine:
         self._run("tone_in_fwd", L.esr_fine_tone_in_fwd, _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), tiles_on, tiles_all,
                                           _lib.ptr(ws["lin"]), _lib.ptr(ws["Xt"]), s)
         self._run("mlp_fwd(tone)", self.mlp_fwd, KIND_TONEMAP, _lib.ptr(self.packed["tone"]), _lib.ptr(ws["Xt"]), 0, tiles_all,
-                                 self._H(["Ht"]), self._H(["Mt"]), 1, 0, _lib.ptr(ws["zt"]), s)
+                                 self._H(["Ht"]), self._H(["Mt"]), 2 if self.tone_recompute else 1, 0, _lib.ptr(ws["zt"]), s)
         self._run("composite_fwd", L.esr_fine_composite_fwd, _lib.ptr(ws["zt"]), _lib.ptr(ws["lin"]), _lib.ptr(ws["rec_ray"]),
                                             _lib.ptr(ws["rec_w"]), tiles_all, _lib.ptr(ws["rgb"]),
                                             _lib.ptr(srgb), _lib.ptr(lin), s)
@@ -419,11 +426,18 @@ class FineEngine:
             # one call for the three nets: layers of the same kernel shape share a launch (esr_mlp_wgrad_batch)
             Hh, dZh, Hth, dZth = self._H(["H0", "H1", "H2"]), self._H(["dZ0", "dZ1", "dZ2"]), self._H(["Ht"]), self._H(["dZt"])
             keep = [Hh, dZh, Hth, dZth]
-            jobs = (_lib.EsrWgradJob * 3)()
-            for j, (kind, X, Hs, dZs, dzs, r0, r1, gwk, gbk) in enumerate((
-                    (KIND_RADIANCE, ws["X"], Hh, dZh, ws["dz"], 0, to, "emo_w", "emo_b"),
-                    (KIND_RADIANCE, ws["X"], Hh, dZh, ws["dz"], to, ta, "off_w", "off_b"),
-                    (KIND_TONEMAP, ws["Xt"], Hth, dZth, ws["dzt"], 0, ta, "tone_w", "tone_b"))):
+            todo = [(KIND_RADIANCE, ws["X"], Hh, dZh, ws["dz"], 0, to, "emo_w", "emo_b"),
+                    (KIND_RADIANCE, ws["X"], Hh, dZh, ws["dz"], to, ta, "off_w", "off_b")]
+            if self.tone_recompute:       # from Xt and dzt alone: the hidden layer is recomputed inside (tone_wgrad.hip)
+                (w0, w1), (b0, _) = self._raw["tone"]
+                self._run("tone_wgrad", L.esr_tone_wgrad_recompute, _lib.ptr(ws["Xt"]), _lib.ptr(ws["dzt"]), _lib.ptr(w0.detach()),
+                          _lib.ptr(b0.detach()), _lib.ptr(w1.detach()), 0, ta, _lib.ptr(grads["tone_w"][0]),
+                          _lib.ptr(grads["tone_b"][0]), _lib.ptr(grads["tone_w"][1]), _lib.ptr(grads["tone_b"][1]),
+                          _lib.ptr(self.tone_scratch), C.c_int64(self.tone_scratch.numel()), s_)
+            else:
+                todo.append((KIND_TONEMAP, ws["Xt"], Hth, dZth, ws["dzt"], 0, ta, "tone_w", "tone_b"))
+            jobs = (_lib.EsrWgradJob * len(todo))()
+            for j, (kind, X, Hs, dZs, dzs, r0, r1, gwk, gbk) in enumerate(todo):
                 gwa, gba = _lib.ptr_array(grads[gwk]), _lib.ptr_array(grads[gbk])
                 keep += [gwa, gba]
                 jb = jobs[j]
@@ -431,8 +445,8 @@ class FineEngine:
                 jb.X, jb.dz = X.data_ptr(), dzs.data_ptr()
                 jb.H, jb.dZ = C.addressof(Hs), C.addressof(dZs)
                 jb.gw, jb.gb = C.addressof(gwa), C.addressof(gba)
-            self._run("mlp_wgrad(all)", L.esr_mlp_wgrad_batch, jobs, 3, 1 if self.bf16 else 0, _lib.ptr(self.wgrad_scratch),
-                      C.c_int64(self.wgrad_scratch.numel()), s_)
+            self._run("mlp_wgrad(all)", L.esr_mlp_wgrad_batch, jobs, len(todo), 1 if self.bf16 else 0,
+                      _lib.ptr(self.wgrad_scratch), C.c_int64(self.wgrad_scratch.numel()), s_)
 
         def dgrad(name, kind, packed, dz, t0, t1, Ms, dZs, dX):
             if self.bf16:
@@ -449,7 +463,8 @@ class FineEngine:
                   _lib.ptr(ws["lin"]), _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), ta, _lib.ptr(ws["dweight"]),
                   _lib.ptr(ws["dzt"]), s)
         e_scat = on(scat, mark(), march_bwd) if scat is not None else None
-        dgrad("mlp_dgrad(tone)", KIND_TONEMAP, self.packed["tone"], ws["dzt"], 0, ta, self._H(["Mt"]), self._H(["dZt"]), ws["dXt"])
+        dgrad("mlp_dgrad(tone)", KIND_TONEMAP, self.packed["tone"], ws["dzt"], 0, ta, self._H(["Mt"]),
+              _lib.ptr_array([None]) if self.tone_recompute else self._H(["dZt"]), ws["dXt"])
         self._run("tone_in_bwd", L.esr_fine_tone_in_bwd, _lib.ptr(ws["dXt"]), _lib.ptr(g_lin), _lib.ptr(ws["lin"]),
                   _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), to, ta,
                   _lib.ptr(ws["dz"]), s)

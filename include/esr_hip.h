@@ -268,7 +268,8 @@ int esr_mlp_pack(int kind, const esr_mlp_weights_t *w, float *packed, void *stre
  * 768 B per tile instead of 24 KB).  zout [tiles,4,32]: pre-activation outputs
  * (row 3 = 0; [tiles,8,32] for the 5-output BRDF net).  Hidden tiles are [tiles,128,32]
  * and masks [tiles,2,64] for the 128-wide nets.  color_row0 (0, 88 or 96) selects which
- * 6-row colour group of the X tile feeds the first 6 inputs.
+ * 6-row colour group of the X tile feeds the first 6 inputs.  save == 2 keeps the masks M only (for a net
+ * whose weight gradient recomputes its hidden layer: esr_tone_wgrad_recompute); H may then be NULL.
  */
 int esr_mlp_fwd(int kind, const float *packed, const float *X, int32_t t0, int32_t t1,
                 float *const *H, uint32_t *const *M, int save, int color_row0, float *zout,
@@ -283,7 +284,7 @@ int esr_mlp_fwd_mixed(int kind, const float *packed, const float *X, int32_t t0,
                       float *const *H, uint32_t *const *M, int color_row_detached, float *zout, void *stream);
 
 /*
- * Input/hidden gradients over tiles [t0,t1).  dz [tiles,4,32] -> dZ[l] (each
+ * Input/hidden gradients over tiles [t0,t1) (a NULL dZ[l] is computed but not stored).  dz [tiles,4,32] -> dZ[l] (each
  * [tiles,192,32], pre-activation grads of hidden layer l) and dX [tiles,64,32].
  */
 int esr_mlp_dgrad(int kind, const float *packed, const float *dz, int32_t t0, int32_t t1,
@@ -322,6 +323,19 @@ typedef struct esr_wgrad_job {
 } esr_wgrad_job_t;
 int esr_mlp_wgrad_batch(const esr_wgrad_job_t *jobs, int32_t n_jobs, int bf16_operands, float *scratch,
                         int64_t scratch_floats, void *stream);
+
+/*
+ * Weight gradients of the tone mapper (TonemapNet 33-192-3, app/utils/pbr/module.py:24-39) from its INPUTS only:
+ * Xt [tiles,48,32] (the tile esr_fine_tone_in_fwd writes) and dzt [tiles,4,32] (d loss / d pre-sigmoid output).  The
+ * hidden layer is recomputed inside the kernel, so the forward need not save Ht (esr_mlp_fwd with save = 2) and the
+ * input-gradient pass need not store dZt (esr_mlp_dgrad with dZ[0] = NULL): 48 KB of tile traffic per 32 samples
+ * less than esr_mlp_wgrad(ESR_MLP_TONEMAP).  W0 [192,33], b0 [192], W1 [3,192]: the net's parameters in the
+ * reference layout; gw0 / gb0 / gw1 / gb1 receive += the gradients.  fp32.
+ */
+int64_t esr_tone_wgrad_scratch_floats(void);
+int esr_tone_wgrad_recompute(const float *Xt, const float *dzt, const float *W0, const float *b0, const float *W1,
+                             int32_t t0, int32_t t1, float *gw0, float *gb0, float *gw1, float *gb1,
+                             float *scratch, int64_t scratch_floats, void *stream);
 
 /*
  * bf16 variants of the MLP engine for BASELINE.json's bf16 configurations (a build-side precision choice:

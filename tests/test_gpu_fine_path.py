@@ -198,6 +198,40 @@ def test_mlp_engine_fwd_dgrad_wgrad_vs_torch(kind, tiles, crow):
         assert rel_err(gb[i], Bs[i].grad) < 2e-5, ("gb", i)
 
 
+@pytest.mark.parametrize("tiles,t0", [(1, 0), (7, 2), (300, 0), (1500, 17)])
+def test_tone_wgrad_recompute_vs_torch(tiles, t0):
+    """esr_tone_wgrad_recompute (csrc/tone_wgrad.hip): the tone mapper's weight gradients from Xt and dzt alone -- the
+    hidden layer recomputed in the transposed accumulator layout -- against a plain fp32 torch chain + autograd."""
+    from esr_nerf_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(tiles)
+    W0 = (torch.randn(192, 33, generator=g) / 33 ** 0.5).requires_grad_()
+    b0 = (torch.randn(192, generator=g) * 0.1).requires_grad_()
+    W1 = (torch.randn(3, 192, generator=g) / 192 ** 0.5).requires_grad_()
+    b1 = (torch.randn(3, generator=g) * 0.1).requires_grad_()
+    Xt = torch.randn(tiles, 48, 32, generator=g)
+    Xt[:, 33:] = 7.0                                              # rows the net does not read must not matter
+    x = Xt[t0:, :33].permute(0, 2, 1).reshape(-1, 33)
+    pre = torch.nn.functional.linear(x, W0, b0)
+    out = torch.nn.functional.linear(torch.relu(pre), W1, b1)
+    dz = torch.randn(out.shape, generator=g)
+    dz[(pre.detach().abs() < 1e-5).any(-1)] = 0                   # knife-edge samples: see the MLP engine test
+    out.backward(dz)
+    dzt = torch.zeros(tiles, 4, 32)
+    dzt[t0:, :3] = dz.reshape(tiles - t0, 32, 3).permute(0, 2, 1)
+    dzt[:t0] = 5.0                                                # tiles before t0 are outside the range
+    dev = lambda t: t.detach().cuda().contiguous()
+    gw0, gb0, gw1, gb1 = (torch.full(s_, 0.25, device="cuda") for s_ in ((192, 33), (192,), (3, 192), (3,)))
+    scratch = torch.empty(L.esr_tone_wgrad_scratch_floats(), device="cuda")
+    Xd, zd, W0d, b0d, W1d = dev(Xt), dev(dzt), dev(W0), dev(b0), dev(W1)        # (kept alive across the call)
+    _lib.check(L.esr_tone_wgrad_recompute(_lib.ptr(Xd), _lib.ptr(zd), _lib.ptr(W0d), _lib.ptr(b0d),
+                                          _lib.ptr(W1d), t0, tiles, _lib.ptr(gw0), _lib.ptr(gb0), _lib.ptr(gw1),
+                                          _lib.ptr(gb1), _lib.ptr(scratch), C.c_int64(scratch.numel()),
+                                          _lib.stream_ptr("cuda:0")), "tone_wgrad")
+    for got, want in ((gw0, W0.grad), (gb0, b0.grad), (gw1, W1.grad), (gb1, b1.grad)):      # += into the outputs
+        assert rel_err(got - 0.25, want) < 2e-5, rel_err(got - 0.25, want)
+
+
 def test_loss_kernel_matches_trainer_loss():
     from esr_nerf_amd.fine_engine import FineEngine
     from oracle import fine_path as fp
