@@ -99,7 +99,9 @@ def fine_calls(counts, merged_off):
          "mlp_fwd(emo)": [("emo", "fwd", n_on)], "mlp_fwd(tone)": [("tone", "fwd", n_all)],
          "mlp_dgrad(emo)": [("emo", "dgrad", n_on)], "mlp_dgrad(off)": [("off", "dgrad", n_off)],
          "mlp_dgrad(tone)": [("tone", "dgrad", n_all)],
-         "mlp_wgrad(all)": [("emo", "wgrad", n_on), ("off", "wgrad", n_off), ("tone", "wgrad", n_all)]}
+         # f32 engine: the tone mapper's weight gradients are a kernel of their own (csrc/tone_wgrad.hip)
+         "mlp_wgrad(all)": [("emo", "wgrad", n_on), ("off", "wgrad", n_off)] + ([] if merged_off else [("tone", "wgrad", n_all)]),
+         "tone_wgrad": [("tone", "wgrad", n_all)]}
     return c
 
 
@@ -193,6 +195,12 @@ def lts_mlp_work(breakdown, eng, n_prof, bf16):
             "eps": dict.fromkeys(NETS, pc["m3"])}
     fl = by = ms = 0.0
     for name, (n, t) in breakdown.items():
+        if name.startswith("tone_wgrad["):                       # f32 engine: tone weight gradients by recomputation
+            k = n_of[name[len("tone_wgrad["):-1]]["tone"]
+            ms += t / max(n_prof, 1)
+            fl += 2.0 * net_macs("tone", "wgrad") * k
+            by += (NETS["tone"][0] * 4 + 16) * k
+            continue
         if not name.startswith("mlp_") or "pack" in name:
             continue
         ms += t / max(n_prof, 1)

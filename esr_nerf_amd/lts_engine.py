@@ -234,8 +234,10 @@ class LtsEngine(FineEngine):
         z = P.buf(f"{net}.z", zrows)
         x = P.bufs["Xt"] if kind == KIND_TONEMAP else P.bufs["X"]
         if t1 > t0:
+            # tone mapper on the f32 engine: masks only, its weight gradient recomputes the hidden layer (tone_wgrad.hip)
+            mode = 0 if not save else 2 if (kind == KIND_TONEMAP and self.tone_recompute) else 1
             self._run(f"mlp_fwd({net})[{P.name}]", self.mlp_fwd, kind, _lib.ptr(self.packed[net]),
-                      _lib.ptr(x), t0, t1, _lib.ptr_array(H), _lib.ptr_array(M), 1 if save else 0, crow,
+                      _lib.ptr(x), t0, t1, _lib.ptr_array(H), _lib.ptr_array(M), mode, crow,
                       _lib.ptr(z), self._s())
         return z
 
@@ -249,9 +251,22 @@ class LtsEngine(FineEngine):
         x = P.bufs["Xt"] if kind == KIND_TONEMAP else P.bufs["X"]
         if t1 > t0:
             s = self._s()
+            recompute = kind == KIND_TONEMAP and self.tone_recompute
             self._run(f"mlp_dgrad({net})[{P.name}]", self.mlp_dgrad, kind, _lib.ptr(self.packed[net]),
-                      _lib.ptr(dz), t0, t1, _lib.ptr_array(M), _lib.ptr_array(dZ), _lib.ptr(dX), s)
-            if self._wgrad_jobs is not None:
+                      _lib.ptr(dz), t0, t1, _lib.ptr_array(M), _lib.ptr_array([None] * nh if recompute else dZ), _lib.ptr(dX), s)
+            if recompute:
+                (w0, w1), (b0, _) = self._raw[net]
+
+                def tone_wgrad():
+                    self._run(f"tone_wgrad[{P.name}]", self.L.esr_tone_wgrad_recompute, _lib.ptr(x), _lib.ptr(dz),
+                              _lib.ptr(w0.detach()), _lib.ptr(b0.detach()), _lib.ptr(w1.detach()), t0, t1, _lib.ptr(gw[0]),
+                              _lib.ptr(gb[0]), _lib.ptr(gw[1]), _lib.ptr(gb[1]), _lib.ptr(self.tone_scratch),
+                              C.c_int64(self.tone_scratch.numel()), self._s())
+                if self._wgrad_jobs is not None:
+                    self._wgrad_extra.append((tone_wgrad, dz))       # with the batched weight gradients, at the end
+                else:
+                    tone_wgrad()
+            elif self._wgrad_jobs is not None:
                 # inside lts_backward: the weight gradients of EVERY net and pass of the step go out as ONE batched call
                 # at the end (esr_mlp_wgrad_batch: layers of the same kernel shape share a launch -- eleven net calls
                 # with ~100-135 us of fixed cost each become four launch groups)
@@ -733,7 +748,7 @@ class LtsEngine(FineEngine):
         data-parallel step exchanges the dense-grid gradients there); the weight-gradient launches run beside it on
         a second stream (or, without ``overlap_wgrad``, after it) and are joined at the end."""
         main = torch.cuda.current_stream(self.device)
-        self._wgrad_jobs = []
+        self._wgrad_jobs, self._wgrad_extra = [], []
         try:
             self._lts_backward(ctx, g, grads)
             jobs_done = None
@@ -773,6 +788,9 @@ class LtsEngine(FineEngine):
             dz.record_stream(torch.cuda.current_stream(self.device))      # may be a transient allocation of the main stream
         self._run("mlp_wgrad(all)", self.L.esr_mlp_wgrad_batch, arr, len(jobs), 1 if self.bf16 else 0,
                   _lib.ptr(self.wgrad_scratch), C.c_int64(self.wgrad_scratch.numel()), self._s())
+        for fn, dz in self._wgrad_extra:
+            dz.record_stream(torch.cuda.current_stream(self.device))
+            fn()
 
     def _lts_backward(self, ctx: LtsCtx, g: Dict[str, Optional[torch.Tensor]], grads):
         L, s, dev = self.L, self._s(), self.device
