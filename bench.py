@@ -496,8 +496,8 @@ def main():
         c = CONFIGS[a.config]
         samples = int(round(c["res"] * c["z"] * 2))
         out = {
-            "metric": "training rays/sec at 4096 rays x 128 samples (fine stage)" if (a.config, stage, a.dtype) == ("C2", "fine", "f32")
-                      else f"training rays/sec, config {a.config}, {stage} stage, {a.dtype} MLPs",
+            "metric": "training rays/sec at 4096 rays x 128 samples (fine stage)" if (a.config, stage, a.dtype, float(a.s_val)) == ("C2", "fine", "f32", 20.0)
+                      else f"training rays/sec, config {a.config}, {stage} stage, {a.dtype} MLPs, s_val {a.s_val:g}",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": a.dtype,
