@@ -42,6 +42,9 @@ struct MarchParams {
     // BWD
     const float *dweight, *dlast;
     float *grad_sdf;
+    float *dsdf_rec;         // optional [n_tiles*32]: the value-tap gradient of a RECORDED sample is added here (the feature
+                             // backward scatters it with its own SDF taps) instead of 8 atomics into grad_sdf
+    int dsdf_acc;            // 0: every recorded slot is overwritten; 1: added to what the caller put there
 };
 
 __device__ __forceinline__ float neus_alpha(float pc, float nc)
@@ -300,6 +303,12 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
         float ds = alpha1[j] * ((j > 0) ? 0.5f : 1.f) + T1[j] * ((j < n1 - 1) ? 0.5f : 1.f);
         if (j + 1 < n1) ds += 0.5f * alpha1[j + 1];
         if (j > 0) ds += 0.5f * T1[j - 1];
+        const int rec = info1[j] >> 8;
+        if (P.dsdf_rec && rec) {                      // one record per slot: plain store / read-modify-write
+            float *q = P.dsdf_rec + out_base + rec - 1;
+            *q = P.dsdf_acc ? *q + ds : ds;
+            continue;
+        }
         if (ds != 0.f) {
             float p[3], idx[3];
             esr_ray_point(g.start, g.dir, sc.stepdist, step1[j], p);
@@ -465,6 +474,21 @@ ESR_API int esr_fine_march_bwd(const esr_scene_t *scene, const float *rays_o, co
     P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d; P.mask_density = mask_density; P.sdf = sdf;
     P.n_rays = n_rays; P.cap = march_cap(scene); P.off3 = off3; P.dweight = dweight; P.dlast = dlast;
     P.grad_sdf = grad_sdf;
+    return launch_march<MARCH_BWD>(P, esr_stream(stream));
+}
+
+ESR_API int esr_fine_march_bwd_rec(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                                   const float *mask_density, const float *sdf, int32_t n_rays,
+                                   const int32_t *off3, const float *dweight, const float *dlast,
+                                   float *grad_sdf, float *dsdf_rec, int32_t accumulate, void *stream)
+{
+    if (!scene || n_rays < 0) return ESR_EINVAL;
+    if (n_rays && (!rays_o || !rays_d || !mask_density || !sdf || !off3 || !dweight || !dlast || !grad_sdf || !dsdf_rec))
+        return ESR_EINVAL;
+    MarchParams P = {};
+    P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d; P.mask_density = mask_density; P.sdf = sdf;
+    P.n_rays = n_rays; P.cap = march_cap(scene); P.off3 = off3; P.dweight = dweight; P.dlast = dlast;
+    P.grad_sdf = grad_sdf; P.dsdf_rec = dsdf_rec; P.dsdf_acc = accumulate;
     return launch_march<MARCH_BWD>(P, esr_stream(stream));
 }
 

@@ -77,7 +77,7 @@ class _Workspace:
 
     ROWS = dict(X=X_ROWS, gnorm=4, H0=HID, H1=HID, H2=HID, z_off=4, z_emo=4, lin=4, Xt=XT_ROWS, Ht=HID,
                 zt=4, rgb=4, dzt=4, dZt=HID, dXt=DX_ROWS, dz=4, dZ0=HID, dZ1=HID, dZ2=HID, dX=DX_ROWS,
-                dweight=1, rec_w=1, rec_sdf=1)
+                dweight=1, rec_w=1, rec_sdf=1, dsdf=1)
 
     def ensure(self, tiles: int):
         if tiles <= self.cap_tiles:
@@ -406,7 +406,17 @@ class FineEngine:
             e.record(main)
             return e
 
+        # the march backward's value-tap gradients of the recorded samples ride on the feature backward's SDF window
+        # (ws["dsdf"]) instead of 8 L2 atomics each; not with neus_alpha "grad" (its gradient taps scatter anyway) and
+        # not on the scatter-stream variant (its feature backward runs in two windows)
+        fold = ta > 0 and not self.neus_grad and scat is None and grads.get("sdf") is not None
+
         def march_bwd(s_):
+            if fold:
+                self._run("march_bwd", L.esr_fine_march_bwd_rec, sp, _lib.ptr(ctx.rays_o), _lib.ptr(ctx.rays_d),
+                          _lib.ptr(ctx.mask_density), _lib.ptr(ctx.sdf), ctx.n_rays, _lib.ptr(ctx.off3), _lib.ptr(dweight),
+                          _lib.ptr(g_last), _lib.ptr(grads["sdf"]), _lib.ptr(ws["dsdf"]), 0, s_)
+                return
             self._march("march_bwd", "bwd", sp, ctx.rays_o, ctx.rays_d, ctx.viewdirs, _lib.ptr(ctx.mask_density),
                         _lib.ptr(ctx.sdf), ctx.n_rays, _lib.ptr(ctx.off3), _lib.ptr(dweight), _lib.ptr(g_last),
                         _lib.ptr(grads["sdf"]), s_)
@@ -419,7 +429,8 @@ class FineEngine:
                 src[0].grad_color_off = grads["off_color"].data_ptr()
                 src[0].t0, src[0].t1 = t0, t1
                 self._run("feat_bwd", L.esr_fine_feat_bwd, sp, C.byref(ctx.feat_args), _lib.ptr(ws["X"]),
-                          _lib.ptr(ws["gnorm"]), src, 1, None, _lib.ptr(grads["sdf"]), None, s_)
+                          _lib.ptr(ws["gnorm"]), src, 1, _lib.ptr(ws["dsdf"]) if fold else None, _lib.ptr(grads["sdf"]),
+                          None, s_)
             return run
 
         def wgrads(s_):
@@ -463,6 +474,8 @@ class FineEngine:
                   _lib.ptr(ws["lin"]), _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), ta, _lib.ptr(ws["dweight"]),
                   _lib.ptr(ws["dzt"]), s)
         e_scat = on(scat, mark(), march_bwd) if scat is not None else None
+        if fold:
+            march_bwd(s)
         dgrad("mlp_dgrad(tone)", KIND_TONEMAP, self.packed["tone"], ws["dzt"], 0, ta, self._H(["Mt"]),
               _lib.ptr_array([None]) if self.tone_recompute else self._H(["dZt"]), ws["dXt"])
         self._run("tone_in_bwd", L.esr_fine_tone_in_bwd, _lib.ptr(ws["dXt"]), _lib.ptr(g_lin), _lib.ptr(ws["lin"]),
@@ -475,7 +488,8 @@ class FineEngine:
         dgrad("mlp_dgrad(off)", KIND_RADIANCE, self.packed["off"], ws["dz"], to, ta, M, dZ, ws["dX"])
         if not overlap:
             feat_bwd(0, ta)(s)
-            march_bwd(s)
+            if not fold:
+                march_bwd(s)
             if after_grids is not None:
                 after_grids()
             wgrads(s)
@@ -487,7 +501,8 @@ class FineEngine:
             main.wait_event(e_scat)
         else:
             feat_bwd(0, ta)(s)
-            march_bwd(s)
+            if not fold:
+                march_bwd(s)
         if after_grids is not None:
             after_grids()
         main.wait_event(e_w)

@@ -829,13 +829,16 @@ class LtsEngine(FineEngine):
                 dz = self._act(P2, f"{nm}.z", f"{nm}.dz", 4, 3, ACT_SOFTPLUS, bwd_g=P2.bufs[f"{nm}.da"])
                 dX = self._net_bwd(P2, nm, KIND_RADIANCE, crow, 0, T2, dz, grads[f"{nm}_w"], grads[f"{nm}_b"])
                 src.append((dX, None, gon, 0, T2))
-            self._feat_bwd(P2, ctx.scene2, src, grads["sdf"])
-            dweight2 = dw2
+            # the secondary march's value-tap gradients of the recorded samples ride on the feature backward's window
+            ds2 = P2.buf("dsdf")
+            self._run("march_bwd[secondary]", L.esr_fine_march_bwd_rec, sp2, _lib.ptr(ctx.t["o2"]), _lib.ptr(ctx.t["d2"]),
+                      _lib.ptr(ctx.t["grids"]["mask"]), _lib.ptr(ctx.t["grids"]["sdf"]), Pn * R, _lib.ptr(ctx.t["off3_2"]),
+                      _lib.ptr(dw2), _lib.ptr(d["d_last2"]), _lib.ptr(grads["sdf"]), _lib.ptr(ds2), 0, s)
+            self._feat_bwd(P2, ctx.scene2, src, grads["sdf"], dsdf_extra=ds2)
         else:
-            dweight2 = z(32)
-        self._run("march_bwd[secondary]", L.esr_fine_march_bwd, sp2, _lib.ptr(ctx.t["o2"]), _lib.ptr(ctx.t["d2"]),
-                  _lib.ptr(ctx.t["grids"]["mask"]), _lib.ptr(ctx.t["grids"]["sdf"]), Pn * R, _lib.ptr(ctx.t["off3_2"]),
-                  _lib.ptr(dweight2), _lib.ptr(d["d_last2"]), _lib.ptr(grads["sdf"]), s)
+            self._run("march_bwd[secondary]", L.esr_fine_march_bwd, sp2, _lib.ptr(ctx.t["o2"]), _lib.ptr(ctx.t["d2"]),
+                      _lib.ptr(ctx.t["grids"]["mask"]), _lib.ptr(ctx.t["grids"]["sdf"]), Pn * R, _lib.ptr(ctx.t["off3_2"]),
+                      _lib.ptr(z(32)), _lib.ptr(d["d_last2"]), _lib.ptr(grads["sdf"]), s)
 
         # ---- radiance at the points
         T1 = P1.tiles_all
@@ -889,10 +892,10 @@ class LtsEngine(FineEngine):
                     grads["brdf"], grads["brdf"], 0, T))
         src.append((self._net_bwd(P0, "emit", KIND_EMIT, 88, 0, T, dze, grads["emit_w"], grads["emit_b"]),
                     grads["emo"], grads["emo"], 0, T))
-        self._feat_bwd(P0, ctx.scene, src, grads["sdf"], dsdf_extra=dsdf_extra)
-        self._run("march_bwd", L.esr_fine_march_bwd, sp, _lib.ptr(b["rays_o"]), _lib.ptr(b["rays_d"]),
+        self._run("march_bwd", L.esr_fine_march_bwd_rec, sp, _lib.ptr(b["rays_o"]), _lib.ptr(b["rays_d"]),
                   _lib.ptr(ctx.t["grids"]["mask"]), _lib.ptr(ctx.t["grids"]["sdf"]), P0.n_rays, _lib.ptr(ctx.t["off3"]),
-                  _lib.ptr(dweight), _lib.ptr(g_last), _lib.ptr(grads["sdf"]), s)
+                  _lib.ptr(dweight), _lib.ptr(g_last), _lib.ptr(grads["sdf"]), _lib.ptr(dsdf_extra), 1, s)
+        self._feat_bwd(P0, ctx.scene, src, grads["sdf"], dsdf_extra=dsdf_extra)
         # exact normals (linear in the grid): etc/normal and etc/normal_eps
         for key, noise, eps in (("etc/normal", None, 0.0), ("etc/normal_eps", ctx.t["noise_n"], ctx.eps["normal"])):
             if g.get(key) is None:

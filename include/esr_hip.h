@@ -180,6 +180,19 @@ int esr_fine_march_bwd(const esr_scene_t *scene, const float *rays_o, const floa
                        float *grad_sdf, void *stream);
 
 /*
+ * As esr_fine_march_bwd, but the value-tap gradient of every RECORDED sample (the ones esr_fine_march_fill wrote) is
+ * added to dsdf_rec [n_tiles*32] (indexed like the records) instead of being scattered: pass that array as
+ * `dsdf_extra` to esr_fine_feat_bwd, which folds it into the SDF window it builds anyway (no L2 atomics for it).
+ * Samples that were walked but not recorded (below a threshold, yet neighbours of a recorded one) are still scattered
+ * into grad_sdf.  accumulate = 0: every recorded slot of dsdf_rec is overwritten (padding slots are left alone; the
+ * feature backward never reads them); accumulate = 1: added to what the caller put there.
+ */
+int esr_fine_march_bwd_rec(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                           const float *mask_density, const float *sdf, int32_t n_rays,
+                           const int32_t *off3, const float *dweight, const float *dlast,
+                           float *grad_sdf, float *dsdf_rec, int32_t accumulate, void *stream);
+
+/*
  * The same three march entry points for cfg `neus_alpha: grad` (app/utils/base/functions.py:45-69): the section
  * SDFs of a sample are sdf -+ 0.5 * dist * (viewdirs[ray] . grad) with grad = the radius-1 clamped central
  * differences of sample_sdf_grad (app/fine/model/voxurff.py:670-721); `viewdirs` [n_rays,3] is the batch's
