@@ -20,6 +20,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-fno-fast-math"]
+FLAGS += os.environ.get("ESR_EXTRA_HIPCC_FLAGS", "").split()      # developer experiments (-DESR_EXP_...), build time only
 
 
 def _sources():

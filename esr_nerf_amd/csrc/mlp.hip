@@ -33,6 +33,9 @@
 
 // In-kernel time stamps: nothing in the product build; tools/ubench/fwd_stamps.hip defines ESR_STAMP before including
 // this file to record s_memtime at the layer seams of one traced wave per SIMD.
+#ifndef ESR_DSTAMP
+#define ESR_DSTAMP(i)
+#endif
 #ifndef ESR_STAMP
 #define ESR_STAMP(i)
 #endif
@@ -50,6 +53,10 @@ struct FwdArgs {
     int crow_det;
 };
 
+// Waves per SIMD of the input-gradient kernel: the tone mapper's chain is short (one hidden layer), a tile's loads are
+// not amortised, and its 142 VGPRs allow three.  (The forward kernel spills at three: 188 instead of 110 us.)
+constexpr int mlp_occ(int kind) { return kind == ESR_MLP_TONEMAP ? 3 : 2; }
+
 template <int KIND>
 __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
 {
@@ -64,6 +71,10 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const rsrc_t W = make_rsrc(A.packed, (unsigned)(L.total * 4));
+    constexpr int NP4 = D.zrows / 4;
+    __shared__ float4 w4s[NP4 * HT * 4 * 8];             // output layer as 4x4x1 operands (lds4_layer)
+    lds4_preload<NP4 * HT * 4 * 8>(W, (int)L.off_w4 * 4, w4s);
+    __syncthreads();
     for (int t = A.t0 + wave; t < A.t1; t += nwaves) {
         const rsrc_t RX = make_rsrc(A.X + (size_t)t * D.xrows * 32, D.xrows * 32 * 4);
         const int xvoff = (h * 32 + s) * 4;
@@ -83,7 +94,6 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
         StreamPre pre = stream_prefetch<HT * (KP1 / 4)>(W, (int)L.off_wf[0] * 4, lane);
         stream_layer_pre<KP1 / 4, HT>(W, (int)L.off_wf[0] * 4, pre, [&](int k) { return B1[k]; }, acc2[0], lane);
         ESR_STAMP(1);
-        constexpr int NP4 = D.zrows / 4;
         f32x4 z4[NP4];
         float bias4[D.zrows];
 #pragma unroll
@@ -96,7 +106,6 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
             } else {
 #pragma unroll
                 for (int c = 0; c < D.zrows; ++c) bias4[c] = bload1(W, 0, ((int)L.off_b4 + c) * 4);
-                pre = stream_prefetch<NP4 * HT * 4>(W, (int)L.off_w4 * 4, lane);
             }
             __builtin_amdgcn_sched_barrier(0);            // keep the requests in front of the epilogue's stores
             __builtin_amdgcn_s_setprio(3);                // (see the note on wave priorities above the kernel)
@@ -111,19 +120,12 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
                 stream_layer_pre<HT * 4, HT>(W, (int)L.off_wf[l + 1] * 4, pre,
                                              [&](int k) { return cur[k >> 4][k & 15]; }, nxt, lane);
             else
-                out4_layer<HT, NP4>(W, (int)L.off_w4 * 4, pre, cur, z4, lane);
+                lds4_layer<HT, NP4>(w4s, cur, z4, lane);
             ESR_STAMP(3 + 2 * l);
         }
         // each half of the wave holds the sum over ITS 16*HT units: add the halves, then the bias (rows >= out_dim
         // have zero weights and bias: the padding row of the output tile is written as 0)
-        float *z = A.zout + (size_t)t * D.zrows * 32 + s;
-#pragma unroll
-        for (int p = 0; p < NP4; ++p)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float v = (z4[p][c] + __shfl_xor(z4[p][c], 32)) + bias4[4 * p + c];
-                if (h == 0) z[(4 * p + c) * 32] = v;
-            }
+        store_rows4<NP4, true, false>(make_rsrc(A.zout + (size_t)t * D.zrows * 32, D.zrows * 32 * 4), 0, z4, bias4, lane);
     }
 }
 
@@ -136,7 +138,7 @@ struct DgradArgs {
 };
 
 template <int KIND>
-__global__ void __launch_bounds__(256, 2) mlp_dgrad_kernel(DgradArgs A)
+__global__ void __launch_bounds__(256, mlp_occ(KIND)) mlp_dgrad_kernel(DgradArgs A)
 {
     constexpr NetDesc D = net_desc(KIND);
     constexpr int NHID = D.n_layers - 1;
@@ -148,7 +150,14 @@ __global__ void __launch_bounds__(256, 2) mlp_dgrad_kernel(DgradArgs A)
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const rsrc_t W = make_rsrc(A.packed, (unsigned)(L.total * 4));
+    constexpr int NPX = L.n_passx;
+    __shared__ float4 wx4s[NPX > 0 ? NPX * HT * 4 * 8 : 1];     // first layer transposed, input rows >= 32 (lds4_layer)
+    if constexpr (NPX > 0) {
+        lds4_preload<NPX * HT * 4 * 8>(W, (int)L.off_wx4 * 4, wx4s);
+        __syncthreads();
+    }
     for (int t = A.t0 + wave; t < A.t1; t += nwaves) {
+        ESR_DSTAMP(0);
         const float *dzt = A.dz + (size_t)t * D.zrows * 32 + s;
         float B0[4];                                                         // pair p <-> rows 2p, 2p+1
 #pragma unroll
@@ -160,26 +169,47 @@ __global__ void __launch_bounds__(256, 2) mlp_dgrad_kernel(DgradArgs A)
         f32x16 cur[HT];
         zero_tiles<HT>(cur);
         layer_from_regs<4, HT>(W, (int)L.off_wb[NHID] * 4, B0, cur, lane);
+        ESR_DSTAMP(1);
         __builtin_amdgcn_s_setprio(3);
         apply_relu_mask<HT>(msk[NHID - 1], cur);
         if (A.dZ[NHID - 1]) store_tiles<HT>(make_rsrc(A.dZ[NHID - 1] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
         __builtin_amdgcn_s_setprio(0);
+        ESR_DSTAMP(2);
 #pragma unroll
         for (int l = NHID - 1; l >= 1; --l) {
             f32x16 nxt[HT];
             zero_tiles<HT>(nxt);
             layer_from_acc<HT, HT>(W, (int)L.off_wb[l] * 4, cur, nxt, lane);
+            ESR_DSTAMP(3 + 2 * (NHID - 1 - l));
             __builtin_amdgcn_s_setprio(3);
             apply_relu_mask<HT>(msk[l - 1], nxt);
             if (A.dZ[l - 1]) store_tiles<HT>(make_rsrc(A.dZ[l - 1] + (size_t)t * (HBYTES / 4), HBYTES), nxt, lane);
             __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int it = 0; it < HT; ++it) cur[it] = nxt[it];
+            ESR_DSTAMP(4 + 2 * (NHID - 1 - l));
         }
-        f32x16 dx[2];
-        zero_tiles<2>(dx);
-        layer_from_acc<HT, 2>(W, (int)L.off_wb[0] * 4, cur, dx, lane);
-        store_tiles<2>(make_rsrc(A.dX + (size_t)t * 64 * 32, 64 * 32 * 4), dx, lane);
+        // rows 0-31 as a 32x32 tile; the rows above that still lead to a grid (dx_rows) as 4-row 4x4x1 passes: a
+        // second 32x32 tile would spend 96 MFMAs on 1 (tone mapper) to 11 (sample nets) useful rows
+        f32x16 dx[1];
+        zero_tiles<1>(dx);
+        layer_from_acc<HT, 1>(W, (int)L.off_wb[0] * 4, cur, dx, lane);
+        ESR_DSTAMP(7);
+        store_tiles<1>(make_rsrc(A.dX + (size_t)t * 64 * 32, 64 * 32 * 4), dx, lane);
+        ESR_DSTAMP(8);
+        if constexpr (NPX > 0) {
+            f32x4 x4[NPX];
+            lds4_layer<HT, NPX>(wx4s, cur, x4, lane);
+            ESR_DSTAMP(9);
+#ifdef ESR_EXP_NO_X4STORE
+            float sink = 0.f;
+            for (int p = 0; p < NPX; ++p) for (int c = 0; c < 4; ++c) sink += x4[p][c];
+            if (sink == 123.456f) A.dX[t] = sink;
+#else
+            store_rows4<NPX, false, true>(make_rsrc(A.dX + (size_t)t * 64 * 32, 64 * 32 * 4), 32, x4, nullptr, lane);
+#endif
+            ESR_DSTAMP(10);
+        }
     }
 }
 
@@ -600,11 +630,12 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs R)
     }
 }
 
-int mlp_grid(int n_tiles)
+int mlp_grid(int n_tiles, int occ = 2)
 {
-    // 2 workgroups (8 waves) per CU resident; one tile per wave per trip
+    // `occ` workgroups (4 waves each) per CU resident; one tile per wave per trip
     int wg = (n_tiles + 3) / 4;
-    if (wg > 512) wg = 512;
+    const int cap = 256 * occ;
+    if (wg > cap) wg = cap;
     if (wg < 1) wg = 1;
     return wg;
 }
@@ -831,7 +862,7 @@ ESR_API int esr_mlp_dgrad_wg(int kind, const float *packed, const float *dz, int
         if (!M[l]) return ESR_EINVAL;
         A.M[l] = M[l]; A.dZ[l] = dZ[l];      // a NULL dZ[l] is not stored (its weight gradient recomputes it)
     }
-    int grid = mlp_grid(t1 - t0);
+    int grid = mlp_grid(t1 - t0, mlp_occ(kind));
     if (max_workgroups > 0 && grid > max_workgroups) grid = max_workgroups;
     hipStream_t s = esr_stream(stream);
     switch (kind) {

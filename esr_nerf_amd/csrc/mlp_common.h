@@ -41,6 +41,14 @@ __host__ __device__ constexpr NetDesc net_desc(int kind)
          : kind == ESR_MLP_EMIT     ? NetDesc{4, 76, 40, X_ROWS, 3, 4, 4, 6}   // EmissionNet, pbr/module.py:68-83
          :                            NetDesc{3, 57, 36, XC_ROWS, 3, 4, 4, 12}; // coarse rgbnet, voxurfc.py:134-149
 }
+// rows of the input tile that carry a gradient back to a grid (colour | sdf | feat24 | normal12 for the sample nets, the
+// 33 inputs of the tone mapper, colour12 | colour12 | normal3 for the coarse net): the input-gradient pass writes dX rows
+// 0 .. dx_rows-1 rounded up to 4 -- rows 0-31 as one 32x32 tile, the rest as 4-row v_mfma_f32_4x4x1 passes
+__host__ __device__ constexpr int dx_rows(int kind)
+{
+    return kind == ESR_MLP_TONEMAP ? 33 : kind == ESR_MLP_COARSE ? 27 : 43;
+}
+__host__ __device__ constexpr int dx_pass4(int kind) { return dx_rows(kind) > 32 ? (dx_rows(kind) - 32 + 3) / 4 : 0; }
 __host__ __device__ constexpr bool kind_ok(int kind) { return kind >= 0 && kind <= ESR_MLP_COARSE; }
 
 // X-tile row -> column of the reference's first-layer weight (-1: no column)
@@ -88,10 +96,14 @@ struct PackLayout {
     int kp[4], tiles_out[4], in_dim[4], out_dim[4];
     int kpo[4], tiles_in[4];
     int64_t off_wf[4], off_bf[4], off_wb[4];
-    // output layer for the f32 forward as v_mfma_f32_4x4x1 operands (see out4_layer): [pass][quad][64 lanes][4] and
-    // its bias [8]; the 32x32 forms above stay for the bf16 engine's bias loads
+    // output layer for the f32 forward as v_mfma_f32_4x4x1 operands (see lds4_layer): [pass][quad][2 halves][4 rows][4]
+    // and its bias [8]; the 32x32 forms above stay for the bf16 engine's bias loads
     int n_pass4;
     int64_t off_w4, off_b4;
+    // first layer, transposed, rows 32 .. 32 + 4 * n_passx - 1 of the input tile as 4x4x1 operands (see dx4_layer):
+    // [pass][quad][2 halves][4 rows][4]
+    int n_passx;
+    int64_t off_wx4;
     int64_t total;
 };
 __host__ __device__ constexpr PackLayout pack_layout(int kind)
@@ -114,8 +126,10 @@ __host__ __device__ constexpr PackLayout pack_layout(int kind)
         L.off_wb[l] = o; o += (int64_t)L.tiles_in[l] * L.kpo[l] * 64;
     }
     L.n_pass4 = d.zrows / 4;
-    L.off_w4 = o; o += (int64_t)L.n_pass4 * d.hid_tiles * 16 * 64;
+    L.off_w4 = o; o += (int64_t)L.n_pass4 * d.hid_tiles * 4 * 32;
     L.off_b4 = o; o += 8;
+    L.n_passx = dx_pass4(kind);
+    L.off_wx4 = o; o += (int64_t)L.n_passx * d.hid_tiles * 4 * 32;
     L.total = o;
     return L;
 }
@@ -131,16 +145,26 @@ __global__ void __launch_bounds__(256) pack_kernel(PackArgs A)
     const PackLayout L = pack_layout(A.kind);
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < L.total;
          e += (int64_t)gridDim.x * blockDim.x) {
+        if (e >= L.off_wx4) {                                // first layer transposed, input rows >= 32, 4x4x1 operand order
+            int64_t i = e - L.off_wx4;
+            const int sub = i & 3, r = (i >> 2) & 3, h = (i >> 4) & 1;
+            i >>= 5;
+            const int nq = L.in_dim[1] / 8;                          // quads of k-registers (hidden width / 2 registers)
+            const int pass = (int)(i / nq), q = (int)(i % nq);
+            const int col = in_colmap(A.kind, 32 + 4 * pass + r), u = hid_feature(4 * q + sub, h);
+            A.out[e] = (col >= 0 && col < L.in_dim[0]) ? A.w[0][(int64_t)u * L.in_dim[0] + col] : 0.f;
+            continue;
+        }
         if (e >= L.off_w4) {                                 // output layer, 4x4x1 operand order
             const int ll = L.n_layers - 1, hid = L.in_dim[ll], outd = L.out_dim[ll];
             float v = 0.f;
             if (e < L.off_b4) {
                 int64_t i = e - L.off_w4;
-                const int sub = i & 3; i >>= 2;
-                const int lane = i & 63; i >>= 6;
+                const int sub = i & 3, r = (i >> 2) & 3, h = (i >> 4) & 1;
+                i >>= 5;
                 const int nq = hid / 8;                              // quads of k-registers per pass (hid/2 registers)
                 const int pass = (int)(i / nq), q = (int)(i % nq);
-                const int c = 4 * pass + (lane & 3), u = hid_feature(4 * q + sub, lane >> 5);
+                const int c = 4 * pass + r, u = hid_feature(4 * q + sub, h);
                 if (c < outd) v = A.w[ll][(int64_t)c * hid + u];
             } else {
                 const int c = (int)(e - L.off_b4);
@@ -329,39 +353,76 @@ __device__ __forceinline__ void stream_layer_pre(rsrc_t W, int woff, const Strea
     }
 }
 
-// Output layer (out_dim <= 4 per pass) of the f32 forward on v_mfma_f32_4x4x1.  As a 32-row tile the 3-row output layer
-// costs HT*16 full MFMAs (6144 cycles for the 192-wide nets, as much as a fifth of a hidden layer) for 9 % useful
-// rows.  Here every hidden register r of a lane is one B operand as it stands -- lane l supplies H[unit(r, half)][its
-// sample] -- and the A operand carries W[c = l % 4][unit(r, half of l)]: block b = l / 4 accumulates
-// z[c][sample of lane 4b+j] over the units its half of the wave holds, 8 cycles per register instead of 64 per pair.
-// The two halves' partial sums are added with one cross-half exchange per output row.  Four independent accumulators
-// per pass (a 2-pass MFMA has a longer dependent-issue latency than its issue time).
-template <int HT, int NP>
-__device__ __forceinline__ void out4_layer(rsrc_t W, int woff, const StreamPre &pre, const f32x16 (&cur)[HT],
-                                           f32x4 (&z)[NP], int lane)
+// Small-M products on v_mfma_f32_4x4x1 (16 independent 4x4 outer products per instruction, 8.5 cycles measured with 4
+// accumulators in flight: tools/ubench/mfma4_loop.hip): rows [4 * pass, 4 * pass + 4) of   out[row][s] = sum_u Wt[row][u]
+// * cur[u][s]   for the 32 samples of the tile.  Used for the output layer of the forward (3-5 rows) and for the input
+// gradient's rows above 31 (1-11 rows): a 32x32 tile would spend 6144 cycles on them, a pass costs 96 x 8.5.
+//   A operand: the weight of row 4 * pass + lane % 4 for THIS half's unit of register k -- 8 distinct 16-B pieces per quad
+//   of registers, selected by (half, lane % 4); B operand: register k of `cur`.  Each half of the wave sums its own
+//   16 * HT units; the caller adds the halves (one __shfl_xor 32 per row).
+// The operands come from LDS (copied there once per workgroup by lds4_preload): a quad is only ~35 cycles of matrix
+// work, so streaming them from L2 one group ahead -- as the 32x32 layers do with their 1 k cycles per group -- left the
+// loop waiting on every group.
+// x(lane) + x(lane ^ 32) in every lane: one v_permlane32_swap + one add (ds_bpermute, which __shfl_xor compiles to, cost
+// ~500 cycles per row behind its lgkmcnt wait: 22 us of the radiance input-gradient kernel's 400 for 12 rows)
+__device__ __forceinline__ float half_sum(float x)
 {
-    constexpr int NQ = NP * HT * 4, G = STREAM_G, NG = (NQ + G - 1) / G;
-    const int voff = lane * 16;
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// rows [0, 4 * NP) of a [rows][32] tile from the per-half partial sums of lds4_layer (+ optional per-row bias): both
+// halves get the full sums, half 0 stores the even rows and half 1 the odd ones -- 2 * NP full-wave stores through the
+// tile's buffer descriptor (row0: first row)
+template <int NP, bool BIAS, bool NT>
+__device__ __forceinline__ void store_rows4(rsrc_t T, int row0, const f32x4 (&z)[NP], const float *bias, int lane)
+{
+    const int h = lane >> 5;
+    const int voff = ((row0 + h) * 32 + (lane & 31)) * 4;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int c = 0; c < 4; c += 2) {
+            float v0 = half_sum(z[p][c]), v1 = half_sum(z[p][c + 1]);
+            if (BIAS) { v0 += bias[4 * p + c]; v1 += bias[4 * p + c + 1]; }
+            if (NT) bstore1_nt(T, h ? v1 : v0, voff, (4 * p + c) * 128);
+            else bstore1(T, h ? v1 : v0, voff, (4 * p + c) * 128);
+        }
+}
+
+template <int NF4>
+__device__ __forceinline__ void lds4_preload(rsrc_t W, int woff, float4 *lds)
+{
+    for (int i = threadIdx.x; i < NF4; i += blockDim.x) lds[i] = bload4(W, i * 16, woff);
+}
+template <int HT, int NP>
+__device__ __forceinline__ void lds4_layer(const float4 *lds, const f32x16 (&cur)[HT], f32x4 (&z)[NP], int lane)
+{
+    // explicitly double-buffered in groups of G LDS reads (left to itself the compiler issues one read, waits for it and
+    // runs its 4 products: ~120 cycles of LDS latency per 34 cycles of matrix work)
+    constexpr int NQ = HT * 4, NTOT = NQ * NP, G = 6, NG = (NTOT + G - 1) / G;
+    const float4 *mine = lds + ((lane >> 5) * 4 + (lane & 3));
     f32x4 acc[NP][4];
 #pragma unroll
     for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[p][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 buf[2][G];
+    // flat index n = q * NP + p: consecutive products go to different passes' accumulators
 #pragma unroll
-    for (int i = 0; i < G; ++i) buf[0][i] = pre.q[i];
+    for (int i = 0; i < G; ++i)
+        if (i < NTOT) buf[0][i] = mine[((i % NP) * NQ + i / NP) * 8];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int n = (g + 1) * G + i;
-            if (n < NQ) buf[(g + 1) & 1][i] = bload4(W, voff, woff + n * 1024);
+            if (n < NTOT) buf[(g + 1) & 1][i] = mine[((n % NP) * NQ + n / NP) * 8];
         }
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int n = g * G + i;
-            if (n < NQ) {
-                const int p = n / (HT * 4), q = n % (HT * 4);
+            if (n < NTOT) {
+                const int p = n % NP, q = n / NP;
                 const float4 a = buf[g & 1][i];
                 acc[p][0] = mfma4(a.x, cur[(4 * q + 0) >> 4][(4 * q + 0) & 15], acc[p][0]);
                 acc[p][1] = mfma4(a.y, cur[(4 * q + 1) >> 4][(4 * q + 1) & 15], acc[p][1]);

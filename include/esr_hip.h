@@ -298,7 +298,10 @@ int esr_mlp_fwd_mixed(int kind, const float *packed, const float *X, int32_t t0,
 
 /*
  * Input/hidden gradients over tiles [t0,t1) (a NULL dZ[l] is computed but not stored).  dz [tiles,4,32] -> dZ[l] (each
- * [tiles,192,32], pre-activation grads of hidden layer l) and dX [tiles,64,32].
+ * [tiles,192,32], pre-activation grads of hidden layer l) and dX [tiles,64,32], of which the rows that lead back to a
+ * grid are written, rounded up to 4: rows 0-43 for the sample nets (colour | sdf | 24 stencil taps | 12 normal
+ * components = rows 0-42; the position / view-direction encodings are inputs without a gradient in the reference too),
+ * rows 0-35 for the tone mapper (33 inputs), rows 0-31 for the coarse net.  The other rows are left untouched.
  */
 int esr_mlp_dgrad(int kind, const float *packed, const float *dz, int32_t t0, int32_t t1,
                   const uint32_t *const *M, float *const *dZ, float *dX, void *stream);
