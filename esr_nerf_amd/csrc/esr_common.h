@@ -241,3 +241,42 @@ __device__ __forceinline__ float esr_softplus(float x)
 __device__ __forceinline__ float esr_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
 __device__ __forceinline__ int esr_lane() { return (int)(threadIdx.x & 63); }
+
+#ifndef ESR_NT_AUX
+#define ESR_NT_AUX 2          // gfx940+ buffer cache-policy bits: 1 = sc0, 2 = nt, 16 = sc1
+#endif
+// Buffer addressing for every hot kernel's tile traffic.  Besides the addressing economy described below, buffer STORES
+// retire much faster than plain global stores here: a wave's later loads wait for its earlier stores (vmcnt retires in
+// order and counts stores), and 6 `global_store_dword` per tile at the end of the MLP input-gradient kernel cost 31 us
+// per launch against ~0 for the same rows through a descriptor (profiles/r02_n_*).
+// Buffer addressing (SGPR descriptor + per-lane 32-bit offset + scalar constant offset):
+// with plain pointers hipcc materialises ~100 loop-invariant 64-bit addresses per kernel
+// (one per store/load slot) and spills kilobytes per lane.  Out-of-range accesses are
+// dropped by the hardware range check instead of faulting.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+static __device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+static __device__ __forceinline__ float4 bload4(rsrc_t r, int voff, int soff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+static __device__ __forceinline__ float bload1(rsrc_t r, int voff, int soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+static __device__ __forceinline__ void bstore1(rsrc_t r, float v, int voff, int soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+// streaming store (nt): saved activations / gradients are written once and read by a later kernel; keeping
+// them out of the L2's working set leaves it to the packed weights that every wave re-reads
+static __device__ __forceinline__ void bstore1_nt(rsrc_t r, float v, int voff, int soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, ESR_NT_AUX);
+}
+

@@ -124,12 +124,18 @@ __global__ void __launch_bounds__(256) feat_fwd_kernel(FeatParams P)
     const int total = P.tiles_all * 32;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
         const int t = j >> 5, s = j & 31;
-        float *Xt = P.X + (size_t)t * XROWS * 32 + s;
-        float *Gn = P.gnorm + (size_t)t * 4 * 32 + s;
+        // tile rows through buffer descriptors (see esr_common.h); X(row, v) writes X[t][row][s].
+        // A wave covers the two tiles t2, t2 + 1 (one per half): one wave-uniform descriptor over both.
+        const int t2 = __builtin_amdgcn_readfirstlane(t);
+        const rsrc_t RX = make_rsrc(P.X + (size_t)t2 * XROWS * 32, 2 * XROWS * 32 * 4);
+        const rsrc_t RG = make_rsrc(P.gnorm + (size_t)t2 * 4 * 32, 2 * 4 * 32 * 4);
+        const int xoff = ((t - t2) * XROWS * 32 + s) * 4, goff = ((t - t2) * 4 * 32 + s) * 4;
+        auto X = [&](int row, float v) { bstore1(RX, v, xoff, row * 128); };        // (not nt: the MLP kernels read X next)
+        auto G = [&](int row, float v) { bstore1(RG, v, goff, row * 128); };
         float p[3], ind[3], unit[3], vdir[3], sdfv;
         if (!sample_inputs(P, j, p, vdir, sdfv)) {       // padding lane: inert zeros
-            for (int r = 0; r < XROWS; ++r) Xt[r * 32] = 0.f;
-            for (int k = 0; k < 4; ++k) Gn[k * 32] = 0.f;
+            for (int r = 0; r < XROWS; ++r) X(r, 0.f);
+            for (int k = 0; k < 4; ++k) G(k, 0.f);
             continue;
         }
         const bool on_tile = t < P.tiles_on;
@@ -146,11 +152,11 @@ __global__ void __launch_bounds__(256) feat_fwd_kernel(FeatParams P)
             float col[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (grid) tri_fetch6(grid, gdims, ind, col);
 #pragma unroll
-            for (int c = 0; c < 6; ++c) Xt[(COLOR_ROW[gi] + c) * 32] = col[c];
+            for (int c = 0; c < 6; ++c) X(COLOR_ROW[gi] + c, col[c]);
         }
-        Xt[94 * 32] = 0.f; Xt[95 * 32] = 0.f; Xt[102 * 32] = 0.f; Xt[103 * 32] = 0.f;
-        Xt[85 * 32] = 0.f; Xt[86 * 32] = 0.f; Xt[87 * 32] = 0.f;
-        Xt[ROW_SDF * 32] = sdfv;
+        X(94, 0.f); X(95, 0.f); X(102, 0.f); X(103, 0.f);
+        X(85, 0.f); X(86, 0.f); X(87, 0.f);
+        X(ROW_SDF, sdfv);
         // 24-tap SDF stencil: reference axis order is (z, y, x) = grid axes (2, 1, 0)
         float grad[3][4];
 #pragma unroll
@@ -163,8 +169,8 @@ __global__ void __launch_bounds__(256) feat_fwd_kernel(FeatParams P)
                 const float cp = tap_index(ind, gdims, axis, sc.grad_feat[k], ixp);
                 const float fm = esr_tri_fetch1(P.sdf, gdims, ixm);
                 const float fp = esr_tri_fetch1(P.sdf, gdims, ixp);
-                Xt[(ROW_FEAT + (2 * ar) * 4 + k) * 32] = fm;
-                Xt[(ROW_FEAT + (2 * ar + 1) * 4 + k) * 32] = fp;
+                X(ROW_FEAT + (2 * ar) * 4 + k, fm);
+                X(ROW_FEAT + (2 * ar + 1) * 4 + k, fp);
                 // + 1e-12: the LTS renderer's guard (esrnerf.py:1560) for taps that clamp onto each other
                 // (points pushed outside the box); a no-op in fp32 for in-box samples, where cp - cm >= 0.5
                 grad[ar][k] = (fp - fm) / ((cp - cm) + 1e-12f) / sc.voxel_size;
@@ -174,24 +180,24 @@ __global__ void __launch_bounds__(256) feat_fwd_kernel(FeatParams P)
         for (int k = 0; k < 4; ++k) {
             const float nrm = sqrtf(grad[0][k] * grad[0][k] + grad[1][k] * grad[1][k] + grad[2][k] * grad[2][k]);
             const float den = fmaxf(nrm, 1e-12f);
-            Gn[k * 32] = nrm;
+            G(k, nrm);
 #pragma unroll
-            for (int ar = 0; ar < 3; ++ar) Xt[(ROW_NRM + ar * 4 + k) * 32] = grad[ar][k] / den;
+            for (int ar = 0; ar < 3; ++ar) X(ROW_NRM + ar * 4 + k, grad[ar][k] / den);
         }
         // positional encodings (coordinate-major, frequencies 1,2,4,8,16)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            Xt[(ROW_XYZ + c) * 32] = unit[c];
+            X(ROW_XYZ + c, unit[c]);
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 const float a = unit[c] * (float)(1 << i);
-                Xt[(ROW_SIN + c * 5 + i) * 32] = sinf(a);
-                Xt[(ROW_COS + c * 5 + i) * 32] = cosf(a);
+                X(ROW_SIN + c * 5 + i, sinf(a));
+                X(ROW_COS + c * 5 + i, cosf(a));
             }
             const float v = vdir[c];
-            Xt[(ROW_VD + c) * 32] = v;
-            Xt[(ROW_VSIN + c) * 32] = sinf(v);
-            Xt[(ROW_VCOS + c) * 32] = cosf(v);
+            X(ROW_VD + c, v);
+            X(ROW_VSIN + c, sinf(v));
+            X(ROW_VCOS + c, cosf(v));
         }
     }
 }

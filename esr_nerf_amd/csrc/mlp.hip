@@ -54,8 +54,9 @@ struct FwdArgs {
 };
 
 // Waves per SIMD of the input-gradient kernel: the tone mapper's chain is short (one hidden layer), a tile's loads are
-// not amortised, and its 142 VGPRs allow three.  (The forward kernel spills at three: 188 instead of 110 us.)
-constexpr int mlp_occ(int kind) { return kind == ESR_MLP_TONEMAP ? 3 : 2; }
+// not amortised, and its 142 VGPRs allow three; so do the 128-wide material nets' 160.  (The tone mapper's forward
+// kernel spills at three: 188 instead of 110 us.)
+constexpr int mlp_occ(int kind) { return (kind == ESR_MLP_TONEMAP || kind == ESR_MLP_BRDF || kind == ESR_MLP_EMIT) ? 3 : 2; }
 
 template <int KIND>
 __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
@@ -195,19 +196,13 @@ __global__ void __launch_bounds__(256, mlp_occ(KIND)) mlp_dgrad_kernel(DgradArgs
         zero_tiles<1>(dx);
         layer_from_acc<HT, 1>(W, (int)L.off_wb[0] * 4, cur, dx, lane);
         ESR_DSTAMP(7);
-        store_tiles<1>(make_rsrc(A.dX + (size_t)t * 64 * 32, 64 * 32 * 4), dx, lane);
+        store_tiles<1, false>(make_rsrc(A.dX + (size_t)t * 64 * 32, 64 * 32 * 4), dx, lane);    // (the scatter reads dX next)
         ESR_DSTAMP(8);
         if constexpr (NPX > 0) {
             f32x4 x4[NPX];
             lds4_layer<HT, NPX>(wx4s, cur, x4, lane);
             ESR_DSTAMP(9);
-#ifdef ESR_EXP_NO_X4STORE
-            float sink = 0.f;
-            for (int p = 0; p < NPX; ++p) for (int c = 0; c < 4; ++c) sink += x4[p][c];
-            if (sink == 123.456f) A.dX[t] = sink;
-#else
-            store_rows4<NPX, false, true>(make_rsrc(A.dX + (size_t)t * 64 * 32, 64 * 32 * 4), 32, x4, nullptr, lane);
-#endif
+            store_rows4<NPX, false, false>(make_rsrc(A.dX + (size_t)t * 64 * 32, 64 * 32 * 4), 32, x4, nullptr, lane);
             ESR_DSTAMP(10);
         }
     }

@@ -5,9 +5,6 @@
 #include "esr_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-#ifndef ESR_NT_AUX
-#define ESR_NT_AUX 2          // gfx940+ buffer cache-policy bits: 1 = sc0, 2 = nt, 16 = sc1
-#endif
 
 namespace {
 
@@ -223,37 +220,6 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
 
-// Buffer addressing (SGPR descriptor + per-lane 32-bit offset + scalar constant offset):
-// with plain pointers hipcc materialises ~100 loop-invariant 64-bit addresses per kernel
-// (one per store/load slot) and spills kilobytes per lane.  Out-of-range accesses are
-// dropped by the hardware range check instead of faulting.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-
-__device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 bload4(rsrc_t r, int voff, int soff)
-{
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-__device__ __forceinline__ float bload1(rsrc_t r, int voff, int soff)
-{
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
-__device__ __forceinline__ void bstore1(rsrc_t r, float v, int voff, int soff)
-{
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
-}
-// streaming store (nt): saved activations / gradients are written once and read by a later kernel; keeping
-// them out of the L2's working set leaves it to the packed weights that every wave re-reads
-__device__ __forceinline__ void bstore1_nt(rsrc_t r, float v, int voff, int soff)
-{
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, ESR_NT_AUX);
-}
-
 // acc[n / KP4] += (packed weight quad n) . B-quad (n % KP4), n = 0 .. NT*KP4-1.
 // The weight stream (byte offset `woff` in the packed buffer) is explicitly
 // double-buffered in groups of G 16-B loads (16 MFMAs = ~1k cycles of matrix work per
@@ -467,15 +433,19 @@ __device__ __forceinline__ int tile_voff(int lane) { return ((lane >> 5) * 4 * 3
 // scalar byte offset of accumulator register r of tile `it` (row = 32it + (r&3) + 8(r>>2))
 __host__ __device__ constexpr int tile_soff(int it, int r) { return (32 * it + (r & 3) + 8 * (r >> 2)) * 128; }
 
-// tile-major store of NT accumulator tiles through descriptor T (based at the tile)
-template <int NT>
+// tile-major store of NT accumulator tiles through descriptor T (based at the tile).  STREAM: non-temporal (tiles a
+// much later kernel reads); otherwise default policy (tiles the NEXT kernel reads: they stay in L2 / the memory-side cache)
+template <int NT, bool STREAM = true>
 __device__ __forceinline__ void store_tiles(rsrc_t T, const f32x16 (&acc)[NT], int lane)
 {
     const int voff = tile_voff(lane);
 #pragma unroll
     for (int it = 0; it < NT; ++it)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bstore1_nt(T, acc[it][r], voff, tile_soff(it, r));
+        for (int r = 0; r < 16; ++r) {
+            if (STREAM) bstore1_nt(T, acc[it][r], voff, tile_soff(it, r));
+            else bstore1(T, acc[it][r], voff, tile_soff(it, r));
+        }
 }
 
 // acc = (saved activation > 0) ? acc : 0

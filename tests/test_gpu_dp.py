@@ -69,6 +69,7 @@ step = FineStep(m, process_group=dist.group.WORLD)
 step.sharded = ShardedGrids(m, names, dist.group.WORLD)
 assert m.off_color.grid.is_contiguous(memory_format=torch.channels_last_3d)
 opt = ShardedGridAdam(step.sharded, lrs)
+seen = {}
 for it in range(2):
     loss, g = step.forward_loss_backward(local, sc.s_val, global_rays=n, entropy_owner=(rank == world - 1))
     opt.step()
@@ -84,11 +85,18 @@ for it in range(2):
     dense_opt.step()
     torch.cuda.synchronize()
     for k in names:
-        # Adam's first steps move every touched element by ~lr * g / (|g| + 1e-8): where |g| is of the order of eps
-        # the float-atomic summation order of the two runs shows (measured 0.4 % of lr); a wrong shard boundary or
-        # a missed element would be a full lr
-        e = float((cur[k] - dense_p[k].detach()).abs().max())
-        assert e < 0.02 * lrs[k], ("shard", it, k, e)
+        # Adam moves an element by ~lr * m / (sqrt(v) + 1e-8): where the gradient is a sum that cancels to rounding noise
+        # (|g| ~ 1e-8 of the grid's largest) the float-atomic summation order of the two runs decides its sign and the
+        # element moves by up to lr either way.  Elements with a real gradient in any step so far must agree closely
+        # (a wrong shard boundary or a missed element would be a full lr there); the noise-level ones are bounded by
+        # Adam's step bound.
+        gk = gf[k + ".grid"].abs()
+        seen[k] = torch.maximum(seen[k], gk / gk.max().clamp_min(1e-30)) if k in seen else gk / gk.max().clamp_min(1e-30)
+        d = (cur[k] - dense_p[k].detach()).abs()
+        real = seen[k].reshape(d.shape) > 1e-5
+        assert float(d[real].max()) < 0.02 * lrs[k], ("shard", it, k, float(d[real].max()))
+        assert float(d.max()) < 1.1 * (it + 1) * lrs[k], ("shard-noise", it, k, float(d.max()))
+        assert int(real.sum()) > 500                                           # ... the close comparison is not vacuous
         assert float((cur[k] - start[k]).abs().max()) > 0.5 * lrs[k]           # ... and the update did happen
         with torch.no_grad():
             getattr(m, k).grid.copy_(cur[k])
