@@ -203,13 +203,12 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd16_kernel(Fwd16Args A)
         f32x16 out[1];
         load_bias<1>(W32, (int)L32.off_bf[NHID] * 4, out, lane);
         layer16_from_acc<HT, 1>(W16, (int)L.off_wf[NHID] * 2, cur, out, lane);
-        float *z = A.zout + (size_t)t * D.zrows * 32 + s;
-        if (D.zrows == 8) {
+        // output rows through the tile's buffer descriptor (plain global stores retire slowly: esr_common.h); rows
+        // acc_row(r, h) = r + 4 h for r < 4: zrows = 8 takes both halves' rows, zrows = 4 half 0's (row 3 is padding = 0)
+        const rsrc_t RZ = make_rsrc(A.zout + (size_t)t * D.zrows * 32, D.zrows * 32 * 4);
+        const int zvoff = (D.zrows == 8) ? (4 * h * 32 + s) * 4 : ((h ? D.zrows : 0) * 32 + s) * 4;   // h = 1: out of range, dropped
 #pragma unroll
-            for (int r = 0; r < 4; ++r) z[(4 * h + r) * 32] = out[0][r];
-        } else if (h == 0) {
-            z[0] = out[0][0]; z[32] = out[0][1]; z[64] = out[0][2]; z[96] = 0.f;
-        }
+        for (int r = 0; r < 4; ++r) bstore1(RZ, (D.zrows == 8 || r < 3) ? out[0][r] : 0.f, zvoff, r * 128);
     }
 }
 
@@ -265,7 +264,7 @@ __global__ void __launch_bounds__(256, 2) mlp_dgrad16_kernel(Dgrad16Args A)
         f32x16 dx[2];
         zero_tiles<2>(dx);
         layer16_from_acc<HT, 2>(W16, (int)L.off_wb[0] * 2, cur, dx, lane);
-        store_tiles<2>(make_rsrc(A.dX + (size_t)t * 64 * 32, 64 * 32 * 4), dx, lane);
+        store_tiles<2, false>(make_rsrc(A.dX + (size_t)t * 64 * 32, 64 * 32 * 4), dx, lane);      // (the scatter reads dX next)
     }
 }
 

@@ -235,9 +235,9 @@ class FineEngine:
         """-> (ctx, alphainv_last [N], srgb_marched [N,3], lin_marched [N,3]).
         sdf [X,Y,Z], off_color/emo_color [X,Y,Z,6], mask_density [mx,my,mz]: contiguous fp32.
         ``prelude()``: enqueues work that does not depend on the march (weight packing, zeroing the gradient buffer).
-        It is called between the plan kernel and the host's wait for the plan header, so the device has ~80 us of work
-        while the host reads the survivor counts and enqueues the rest of the step (that wait left the GPU idle for
-        ~60 us per step: tools/trace_gaps.py)."""
+        It is called between the plan kernel and the host's wait for the plan header, on a SIDE stream: the device has
+        work while the host reads the survivor counts and enqueues the rest of the step, and these bandwidth-bound
+        kernels then run beside the march / feature kernels instead of in front of them (tools/trace_step.py)."""
         L, s, ws = self.L, self._s(), self.ws
         n = rays_o.shape[0]
         for t in (rays_o, rays_d, viewdirs):
@@ -247,10 +247,14 @@ class FineEngine:
             raise RuntimeError("em_modes must be int64")
         rb = self._ray_buf(n)
         last = torch.empty(n, dtype=torch.float32, device=self.device)
-        srgb = torch.zeros(n, 3, dtype=torch.float32, device=self.device)
-        lin = torch.zeros(n, 3, dtype=torch.float32, device=self.device)
+        # everything of the step that starts from zero in ONE fill (each small fill is a ~5 us launch on the step's
+        # critical path): plan header (8 x i32; what esr_fine_plan_begin does) | srgb | lin | the loss accumulator
+        zb = torch.zeros(8 + 6 * n + 1, dtype=torch.float32, device=self.device)
+        self.plan_dev = zb[:8].view(torch.int32)
+        srgb, lin = zb[8: 8 + 3 * n].view(n, 3), zb[8 + 3 * n: 8 + 6 * n].view(n, 3)
+        self._loss_acc = zb[8 + 6 * n:]
         sp = C.byref(scene)
-        self._run("plan_begin", L.esr_fine_plan_begin, _lib.ptr(self.plan_dev), s)
+        main = torch.cuda.current_stream(self.device)
         self._march("march_count", "count", sp, rays_o, rays_d, viewdirs, _lib.ptr(mask_density),
                     _lib.ptr(sdf), n, _lib.ptr(rb["cnt3"]), _lib.ptr(last), _lib.ptr(rb["stats"]), _lib.ptr(self.plan_dev), s)
         self._run("plan", L.esr_fine_plan, _lib.ptr(rb["cnt3"]), _lib.ptr(em_modes), _lib.ptr(rb["stats"]), n, _lib.ptr(rb["off3"]),
@@ -258,8 +262,16 @@ class FineEngine:
         self.plan_host.copy_(self.plan_dev, non_blocking=True)
         landed = torch.cuda.Event()
         landed.record()
+        e_pre = None
         if prelude is not None:
-            prelude()
+            # on a side stream: the packing / zeroing kernels are bandwidth-bound and run beside the march and feature
+            # kernels (gather latency) instead of in front of them; the main stream joins before the first MLP launch
+            side = self._side_stream(0)
+            side.wait_event(landed)                                 # (also orders it behind the previous step's readers)
+            with torch.cuda.stream(side):
+                prelude()
+                e_pre = torch.cuda.Event()
+                e_pre.record(side)
         landed.synchronize()                                        # the one host wait of the step
         n_on, n_off, tiles_on, tiles_all, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
         if overflow:
@@ -268,6 +280,8 @@ class FineEngine:
                       counts=dict(m0=m0, m1=m1, m2=m2, m3=n_on + n_off, n_on=n_on, n_off=n_off),
                       rays_o=rays_o, rays_d=rays_d, viewdirs=viewdirs, off3=rb["off3"], mask_density=mask_density, sdf=sdf)
         if tiles_all == 0:
+            if e_pre is not None:
+                main.wait_event(e_pre)
             return ctx, last, srgb, lin
         ws.ensure(tiles_all)
         ws["rec_ray"][: tiles_all * 32].fill_(-1)
@@ -279,6 +293,8 @@ class FineEngine:
         self._run("feat_fwd", L.esr_fine_feat_fwd, sp, C.byref(fa), _lib.ptr(ws["X"]), _lib.ptr(ws["gnorm"]), s)
         ctx.feat_args = fa
         H, M = self._H(["H0", "H1", "H2"]), self._H(["M0", "M1", "M2"])
+        if e_pre is not None:
+            main.wait_event(e_pre)
         # off net: detached pass on the on-tiles (alt colour rows, nothing saved), saved pass on the off-tiles
         if not self.bf16:       # one launch, same weights (no launch seam, one ramp-up / tail instead of two)
                 self._run("mlp_fwd(off)", L.esr_mlp_fwd_mixed, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]),
@@ -517,7 +533,9 @@ class FineEngine:
     # -- fused trainer-step loss (app/fine/fine.py:355-382) ------------------------
     def loss_fwd_bwd(self, last, srgb, lin, rgbs, white_bg=True, weight_linear=0.1, weight_entropy_last=0.001):
         n = last.shape[0]
-        loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        acc = getattr(self, "_loss_acc", None)           # zeroed with the step's other accumulators (forward)
+        self._loss_acc = None
+        loss = acc if acc is not None and acc.device == srgb.device else torch.zeros(1, dtype=torch.float32, device=self.device)
         g_srgb = torch.empty_like(srgb)
         g_lin = torch.empty_like(lin)
         g_last = torch.empty_like(last)

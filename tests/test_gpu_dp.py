@@ -56,9 +56,13 @@ for dense_above, mode in ((2.0, "sparse"), (0.0, "dense")):
     if mode == "sparse":
         assert step._sync.last["sent"] >= step._sync.last["union"] > 0 and "overflow" not in step._sync.last
 
-# ---- option 2 (ESR_GRAD_SYNC=shard): reduce-scatter + Adam on the owned shard + all-gather, against the dense fused
-# Adam on the full-batch gradients (both through esr_adam_step on the GPU)
-from esr_nerf_amd.grad_sync import ShardedGrids
+# ---- option 2 (ESR_GRAD_SYNC=shard): reduce-scatter + Adam on the owned shard + all-gather.  Two checks per step:
+# (a) the reduce-scattered gradient, gathered back, equals the full-batch gradient (1e-5 of each grid's largest);
+# (b) the sharded update equals the dense fused Adam fed with exactly those gradient values (elementwise the same
+#     kernel: agreement to rounding) -- shard boundaries, learning rate by position, moments, parameter all-gather.
+# (Comparing the updates of two separately summed gradients instead would test Adam's sensitivity to summation order:
+#  an element whose gradient cancels to rounding noise moves by up to lr either way.)
+from esr_nerf_amd.grad_sync import ShardedGrids, _all_gather
 from esr_nerf_amd.optimizer import Adam, ShardedGridAdam
 names = ["sdf", "off_color", "emo_color"]
 lrs = {"sdf": 0.005, "off_color": 0.1, "emo_color": 0.1}
@@ -67,39 +71,32 @@ dense_p = {k: torch.nn.Parameter(v.clone()) for k, v in start.items()}
 dense_opt = Adam([{"params": [dense_p[k]], "lr": lrs[k], "name": k} for k in names], betas=(0.9, 0.99))
 step = FineStep(m, process_group=dist.group.WORLD)
 step.sharded = ShardedGrids(m, names, dist.group.WORLD)
+SG = step.sharded
 assert m.off_color.grid.is_contiguous(memory_format=torch.channels_last_3d)
-opt = ShardedGridAdam(step.sharded, lrs)
-seen = {}
-for it in range(2):
+opt = ShardedGridAdam(SG, lrs)
+for it in range(3):
+    _, gf = FineStep(m).forward_loss_backward(full, sc.s_val)                 # full batch, same parameters
+    gf = {k: gf[k + ".grid"].clone() for k in names}
     loss, g = step.forward_loss_backward(local, sc.s_val, global_rays=n, entropy_owner=(rank == world - 1))
-    opt.step()
+    SG.wait()
+    gsum = torch.zeros(SG.padded, device="cuda")
+    _all_gather(gsum, SG.grad_shard.clone(), dist.group.WORLD)
     torch.cuda.synchronize()
-    # the same update with the dense optimizer on the full batch, from the same parameters
-    cur = {k: getattr(m, k).grid.detach().clone() for k in names}
-    with torch.no_grad():
-        for k in names:
-            getattr(m, k).grid.copy_(dense_p[k])
-    _, gf = FineStep(m).forward_loss_backward(full, sc.s_val)
-    for k in names:
-        dense_p[k].grad = gf[k + ".grid"].clone()
+    for k, (name, b0, b1) in zip(names, SG.bounds):
+        p = dense_p[k]
+        seg = gsum[b0:b1]
+        gk = seg.view(p.shape[0], *p.shape[2:], p.shape[1]).permute(0, 4, 1, 2, 3) if p.shape[1] > 1 else seg.view(p.shape)
+        e = float((gk - gf[k]).abs().max() / gf[k].abs().max().clamp_min(1e-30))
+        assert e < 1e-5, ("shard-grad", it, k, e)
+        p.grad = gk.clone()
+    opt.step()
     dense_opt.step()
     torch.cuda.synchronize()
     for k in names:
-        # Adam moves an element by ~lr * m / (sqrt(v) + 1e-8): where the gradient is a sum that cancels to rounding noise
-        # (|g| ~ 1e-8 of the grid's largest) the float-atomic summation order of the two runs decides its sign and the
-        # element moves by up to lr either way.  Elements with a real gradient in any step so far must agree closely
-        # (a wrong shard boundary or a missed element would be a full lr there); the noise-level ones are bounded by
-        # Adam's step bound.
-        gk = gf[k + ".grid"].abs()
-        seen[k] = torch.maximum(seen[k], gk / gk.max().clamp_min(1e-30)) if k in seen else gk / gk.max().clamp_min(1e-30)
-        d = (cur[k] - dense_p[k].detach()).abs()
-        real = seen[k].reshape(d.shape) > 1e-5
-        assert float(d[real].max()) < 0.02 * lrs[k], ("shard", it, k, float(d[real].max()))
-        assert float(d.max()) < 1.1 * (it + 1) * lrs[k], ("shard-noise", it, k, float(d.max()))
-        assert int(real.sum()) > 500                                           # ... the close comparison is not vacuous
-        assert float((cur[k] - start[k]).abs().max()) > 0.5 * lrs[k]           # ... and the update did happen
-        with torch.no_grad():
-            getattr(m, k).grid.copy_(cur[k])
+        cur = getattr(m, k).grid.detach()
+        e = float((cur - dense_p[k].detach()).abs().max())
+        assert e < 1e-3 * lrs[k], ("shard-adam", it, k, e)
+        assert float((cur - start[k]).abs().max()) > 0.5 * lrs[k]             # ... and the update did happen
 dist.barrier()
 if rank == 0:
     print("DPGPU", worst)
