@@ -107,7 +107,10 @@ class _PointDraw:
         self._st = st
         self._key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
         self._pos = C.c_int32(int(st[2]))
-        self._out = np.empty(k, dtype=np.int64)
+        # pinned: the upload in lts_forward must not block the host (a pageable copy waits for the stream to drain,
+        # after which every small launch of the light-transport glue shows its full launch latency: ~0.5 ms idle per step)
+        self._out_t = torch.empty(k, dtype=torch.int64, pin_memory=torch.cuda.is_available())
+        self._out = self._out_t.numpy()
         self._rc = None
         L = _lib.lib()
 
@@ -120,7 +123,7 @@ class _PointDraw:
         self._fut.result()
         _lib.check(self._rc, "esr_host_choice_noreplace")
         np.random.set_state((self._st[0], self._key, int(self._pos.value), self._st[3], self._st[4]))
-        return torch.from_numpy(self._out)
+        return self._out_t
 
 
 def fibonacci_hemisphere(count: int) -> torch.Tensor:
@@ -158,7 +161,10 @@ class LtsEngine(FineEngine):
         return torch.randn(n_pts, count, 3, device=self.device)
 
     # ------------------------------------------------------------------ building blocks
-    def _march(self, P: Pass, scene, rays_o, rays_d, em_modes, mask_density, sdf):
+    def _march(self, P: Pass, scene, rays_o, rays_d, em_modes, mask_density, sdf, prelude=None):
+        """count -> plan -> (host reads the plan header) -> fill.  ``prelude()``: work that does not depend on the march
+        (weight packing, zeroing the gradient buffer), enqueued on a side stream while the host waits; the returned
+        event (``P.e_pre``) must be waited for by the main stream before the first consumer."""
         L, s = self.L, self._s()
         n = rays_o.shape[0]
         P.n_rays = n
@@ -174,7 +180,19 @@ class LtsEngine(FineEngine):
         self._run("plan", L.esr_fine_plan, _lib.ptr(cnt3), _lib.ptr(em_modes), _lib.ptr(stats), n, _lib.ptr(off3),
                   _lib.ptr(self.plan_dev), s)
         self.plan_host.copy_(self.plan_dev, non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()
+        P.e_pre = None
+        if prelude is not None:
+            landed = torch.cuda.Event()
+            landed.record()
+            side = self._side_stream(0)
+            side.wait_event(landed)
+            with torch.cuda.stream(side):
+                prelude()
+                P.e_pre = torch.cuda.Event()
+                P.e_pre.record(side)
+            landed.synchronize()
+        else:
+            torch.cuda.current_stream(self.device).synchronize()
         n_on, n_off, tiles_on, tiles_all, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
         if overflow:
             raise RuntimeError("a ray exceeded scene.max_steps; the LDS bound of the march kernel is wrong")
@@ -576,7 +594,7 @@ class LtsEngine(FineEngine):
         self._feat_bwd(P1, ctx["scene"], [(dX, None, grads["emo"], 0, T1)], None)
 
     # ------------------------------------------------------------------ forward
-    def lts_forward(self, scene, scene2, batch, grids, envmap, cfg, draws=None):
+    def lts_forward(self, scene, scene2, batch, grids, envmap, cfg, draws=None, prelude=None):
         """grids: dict sdf [X,Y,Z], off/emo/brdf [X,Y,Z,6], mask [mx,my,mz].  cfg: num_2ndrays, num_ltspts,
         normal_eps, emit_eps, pdra.  draws (optional): dict idx, dirs, noise_normal, noise_emit -- when
         absent they are drawn exactly where the reference draws them."""
@@ -585,7 +603,7 @@ class LtsEngine(FineEngine):
         rays_o, rays_d, viewdirs = batch["rays_o"], batch["rays_d"], batch["viewdirs"]
         N = rays_o.shape[0]
         P0 = self.prim
-        cnt3, off3, last = self._march(P0, scene, rays_o, rays_d, batch["em_modes"], grids["mask"], sdf)
+        cnt3, off3, last = self._march(P0, scene, rays_o, rays_d, batch["em_modes"], grids["mask"], sdf, prelude=prelude)
         T, Ton = P0.tiles_all, P0.tiles_on
         srgb = torch.zeros(N, 3, device=dev)
         lin_m = torch.zeros(N, 3, device=dev)
@@ -608,6 +626,8 @@ class LtsEngine(FineEngine):
         pts_all = torch.empty(T * 32, 3, device=dev)
         self._run("sample_points", L.esr_sample_points, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
                   _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(P0.bufs["rec_step"]), T * 32, _lib.ptr(pts_all), s)
+        if P0.e_pre is not None:                  # packed weights (and the zeroed gradient buffer) from the side stream
+            torch.cuda.current_stream(dev).wait_event(P0.e_pre)
         # radiance heads: off on every tile, emo on the on-tiles (both carry gradients, esrnerf.py:751-757)
         self._net_fwd(P0, "off", KIND_RADIANCE, 0, 0, T)
         self._net_fwd(P0, "emo", KIND_RADIANCE, 88, 0, Ton)
@@ -634,7 +654,7 @@ class LtsEngine(FineEngine):
         # ---- light-transport segment
         idx_host = point_draw.result() if draws is None else draws["idx"]
         self.last_point_idx = idx_host
-        idx_ref = idx_host.to(dev)
+        idx_ref = idx_host.to(dev, non_blocking=True)
         Pn, R = idx_ref.numel(), ctx.n_2nd
         ctx.n_pts = Pn
         jp = perm[idx_ref]

@@ -300,17 +300,23 @@ class LtsStep:
         ps = m._mlp_params()
         from .fine_engine import KIND_RADIANCE as KR, KIND_TONEMAP as KT
         from .lts_engine import KIND_BRDF as KB, KIND_EMIT as KE
-        o = 0
-        for name, kind, n in (("off", KR, 8), ("emo", KR, 8), ("tone", KT, 4), ("brdf", KB, 8), ("emit", KE, 8)):
-            eng.pack(name, kind, list(ps[o:o + n:2]), list(ps[o + 1:o + n:2]))
-            o += n
+        G = None
+
+        def prelude():        # independent of the march: on a side stream while the host waits for the plan header
+            nonlocal G
+            o = 0
+            for name, kind, n in (("off", KR, 8), ("emo", KR, 8), ("tone", KT, 4), ("brdf", KB, 8), ("emit", KE, 8)):
+                eng.pack(name, kind, list(ps[o:o + n:2]), list(ps[o + 1:o + n:2]))
+                o += n
+            G = self._alloc_grads(batch["rays_o"].device)
         grids = dict(sdf=m.sdf.device_view(), off=m.off_color.device_view(), emo=m.emo_color.device_view(),
                      brdf=m.brdf.device_view(), mask=m.mask_cache.density.view(*m.mask_cache.density.shape[2:]))
         env = dict(mus=m.envmap.mus.detach(), lambdas=m.envmap.lambdas.detach(), lobes=m.envmap.lobes.detach())
         pdra = self.stage == "pdra"
         cfg = dict(num_2ndrays=m.num_2ndrays, num_ltspts=self.ltspts, normal_eps=t.normal_eps, emit_eps=t.emit_eps,
                    pdra=m.pdra_mode, eps_grads=pdra)
-        ctx, out = eng.lts_forward(m.scene_struct(), m.scene_struct(near=m.lts_near), batch, grids, env, cfg, draws)
+        ctx, out = eng.lts_forward(m.scene_struct(), m.scene_struct(near=m.lts_near), batch, grids, env, cfg, draws,
+                                   prelude=prelude)
         m.last_counts = dict(eng.prim.counts)
         last = out["etc/alphainv_cum"]
         scale, w_ent = dp_loss_weights(last.shape[0], global_rays, entropy_owner, t.weight_entropy_last)
@@ -341,7 +347,8 @@ class LtsStep:
         wn = t.weight_normal_smooth
         g["etc/normal"], g["etc/normal_eps"] = self._pair(eng, loss, out["etc/normal"], out["etc/normal_eps"], 1, wn, wn,
                                                           wn, scale)
-        G = self._alloc_grads(last.device)
+        if G is None:                     # (degenerate: the engine did not run the prelude)
+            G = self._alloc_grads(last.device)
         names = self._param_names()
         pick = lambda lo, hi: ([G[n] for n in names[lo:hi:2]], [G[n] for n in names[lo + 1:hi:2]])
         (ow, ob), (ew, eb), (tw, tb), (bw, bb), (mw, mb) = pick(0, 8), pick(8, 16), pick(16, 20), pick(20, 28), pick(28, 36)

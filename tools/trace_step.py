@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Every dispatch of the last profiled step of a rocprofv3 kernel trace, in start order, with the idle time in front of it:
-   python tools/trace_step.py <dir-with-kernel_trace.csv>"""
+   python tools/trace_step.py <dir-with-kernel_trace.csv> [marches-per-step, default 1; 2 for the lts / pdra stages]"""
 import csv, glob, os, sys
 d = sys.argv[1]
 f = glob.glob(os.path.join(d, "**/*kernel_trace.csv"), recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if "march_kernel<0" in r["Kernel_Name"]]
-a, b = starts[-2], starts[-1]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+a, b = starts[-1 - k], starts[-1]
 t0 = int(rows[a]["Start_Timestamp"])
 busy_end = t0
 idle = 0.0
