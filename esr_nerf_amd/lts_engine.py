@@ -651,6 +651,42 @@ class LtsEngine(FineEngine):
         brdf_rm = P0.rowmajor("brdf.a")            # [T*32, 8]
         emit_rm = P0.rowmajor("emit.a")            # [T*32, 4]
 
+        # ---- random draws in the reference's order (scattering directions, then the two perturbations), then the
+        # perturbed re-evaluations BEFORE the light-transport segment: that segment starts with ~45 small gathers whose
+        # enqueueing is host-bound (~15 us each against ~5 us on the device); with the large kernels of this block queued
+        # in front of them the device stays busy meanwhile (tools/trace_step.py: 0.5 ms idle per step otherwise)
+        Pn_, R_ = min(int(cfg["num_ltspts"]), m3) if draws is None else int(draws["idx"].numel()), ctx.n_2nd
+        raw = self._scatter_draws(Pn_, R_ + 1) if draws is None or "dirs" not in draws else draws["dirs"].to(dev).contiguous()
+        # perturbed re-evaluations (esrnerf.py:807-830)
+        nn_ = torch.randn(m3, 3, device=dev) if draws is None else draws["noise_normal"].to(dev)
+        ne_ = torch.randn(m3, 3, device=dev) if draws is None else draws["noise_emit"].to(dev)
+        noise_n = torch.zeros(T * 32, 3, device=dev)
+        noise_n[perm] = nn_
+        eg_eps = torch.empty(T * 32, 4, device=dev)
+        self._run("expgrad_fwd(eps)", L.esr_expgrad_fwd, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(P0.bufs["rec_ray"]),
+                  _lib.ptr(P0.bufs["rec_step"]), None, _lib.ptr(noise_n), C.c_float(ctx.eps["normal"]), _lib.ptr(sdf),
+                  T * 32, 0, _lib.ptr(eg_eps), s)
+        ctx.t.update(noise_n=noise_n)
+        # emit_eps / brdf_eps: forward only (explicit points in reference order)
+        P3 = self.epsp
+        pts_e = (pts_all[perm] + ne_ * ctx.eps["emit"]).contiguous()
+        sv = torch.empty(m3, 4, device=dev)
+        self._run("expgrad_fwd(pts)", L.esr_expgrad_fwd, sp, None, None, None, None, _lib.ptr(pts_e), None, C.c_float(0.0),
+                  _lib.ptr(sdf), m3, 1, _lib.ptr(sv), s)
+        sdf_e = sv[:, 0].contiguous()
+        vd_e = torch.zeros(m3, 3, device=dev)
+        self._feat_args_points(P3, pts_e, vd_e, sdf_e, sdf, (None, emog, brdfg))
+        self._features(P3, scene)
+        T3 = P3.tiles_all
+        eps_grads = bool(cfg.get("eps_grads", True))      # keep activations for d/d(emit_eps, brdf_eps)
+        self._net_fwd(P3, "emit", KIND_EMIT, 88, 0, T3, save=eps_grads)
+        self._net_fwd(P3, "brdf", KIND_BRDF, 96, 0, T3, save=eps_grads)
+        self._act(P3, "emit.z", "emit.a", 4, 3, ACT_SOFTPLUS)
+        self._act(P3, "brdf.z", "brdf.a", 8, 5, ACT_SIGMOID)
+        emit_eps = P3.rowmajor("emit.a")[:m3, :3].contiguous()
+        brdf_eps = P3.rowmajor("brdf.a")[:m3, :5].contiguous()
+
+
         # ---- light-transport segment
         idx_host = point_draw.result() if draws is None else draws["idx"]
         self.last_point_idx = idx_host
@@ -668,7 +704,6 @@ class LtsEngine(FineEngine):
                                     brdf_rm[jp, 4].contiguous())
         emis_p = emit_rm[jp, 0:3].contiguous()
         umask_p = batch["uncert_masks"][ray_p].to(torch.uint8).contiguous()
-        raw = self._scatter_draws(Pn, R + 1) if draws is None or "dirs" not in draws else draws["dirs"].to(dev).contiguous()
         dirs_all = torch.empty(Pn, R + 1, 3, device=dev)
         self._run("lts_dirs", L.esr_lts_dirs, _lib.ptr(raw), _lib.ptr(normal_p), Pn, R + 1, _lib.ptr(dirs_all), s)
         v_rand = (-dirs_all[:, R]).contiguous()
@@ -718,35 +753,6 @@ class LtsEngine(FineEngine):
         emo_hat = torch.empty(2 * Pn, 3, device=dev)
         self._run("lts_combine_fwd", L.esr_lts_combine_fwd, C.byref(a), _lib.ptr(off_hat), _lib.ptr(emo_hat), s)
         ctx.t.update(held=held, lts_args=a, off3_2=off3_2, o2=o2, d2=d2, eg=eg, pts_all=pts_all)
-
-        # ---- perturbed re-evaluations (esrnerf.py:807-830)
-        nn_ = torch.randn(m3, 3, device=dev) if draws is None else draws["noise_normal"].to(dev)
-        ne_ = torch.randn(m3, 3, device=dev) if draws is None else draws["noise_emit"].to(dev)
-        noise_n = torch.zeros(T * 32, 3, device=dev)
-        noise_n[perm] = nn_
-        eg_eps = torch.empty(T * 32, 4, device=dev)
-        self._run("expgrad_fwd(eps)", L.esr_expgrad_fwd, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(P0.bufs["rec_ray"]),
-                  _lib.ptr(P0.bufs["rec_step"]), None, _lib.ptr(noise_n), C.c_float(ctx.eps["normal"]), _lib.ptr(sdf),
-                  T * 32, 0, _lib.ptr(eg_eps), s)
-        ctx.t.update(noise_n=noise_n)
-        # emit_eps / brdf_eps: forward only (explicit points in reference order)
-        P3 = self.epsp
-        pts_e = (pts_all[perm] + ne_ * ctx.eps["emit"]).contiguous()
-        sv = torch.empty(m3, 4, device=dev)
-        self._run("expgrad_fwd(pts)", L.esr_expgrad_fwd, sp, None, None, None, None, _lib.ptr(pts_e), None, C.c_float(0.0),
-                  _lib.ptr(sdf), m3, 1, _lib.ptr(sv), s)
-        sdf_e = sv[:, 0].contiguous()
-        vd_e = torch.zeros(m3, 3, device=dev)
-        self._feat_args_points(P3, pts_e, vd_e, sdf_e, sdf, (None, emog, brdfg))
-        self._features(P3, scene)
-        T3 = P3.tiles_all
-        eps_grads = bool(cfg.get("eps_grads", True))      # keep activations for d/d(emit_eps, brdf_eps)
-        self._net_fwd(P3, "emit", KIND_EMIT, 88, 0, T3, save=eps_grads)
-        self._net_fwd(P3, "brdf", KIND_BRDF, 96, 0, T3, save=eps_grads)
-        self._act(P3, "emit.z", "emit.a", 4, 3, ACT_SOFTPLUS)
-        self._act(P3, "brdf.z", "brdf.a", 8, 5, ACT_SIGMOID)
-        emit_eps = P3.rowmajor("emit.a")[:m3, :3].contiguous()
-        brdf_eps = P3.rowmajor("brdf.a")[:m3, :5].contiguous()
 
         um = batch["uncert_masks"]
         out = {
