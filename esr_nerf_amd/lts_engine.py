@@ -14,6 +14,8 @@ where the reference draws them) and for the autograd edge.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 import math
 from dataclasses import dataclass, field
@@ -143,6 +145,7 @@ class LtsEngine(FineEngine):
     def __init__(self, device, mlp_dtype: str = "f32"):
         super().__init__(device, mlp_dtype)
         self.ray_sampling = "random"        # or "fib" (cfg.app.model.ray_sampling; esrnerf.py:188-192)
+        self.zero_arena = os.environ.get("ESR_ZERO_ARENA", "1") != "0"      # (read once, here; A/B switch of tools/ab.sh)
         self.prim = Pass(self.device, "primary")
         self.pts = Pass(self.device, "points")
         self.sec = Pass(self.device, "secondary")
@@ -159,6 +162,35 @@ class LtsEngine(FineEngine):
         if self.ray_sampling == "fib":
             return fibonacci_hemisphere(count).to(self.device).float().expand(n_pts, count, 3).contiguous()
         return torch.randn(n_pts, count, 3, device=self.device)
+
+    # ------------------------------------------------------------------ zero arena
+    # The light-transport step asks for ~35 zero-initialised buffers (composite targets, scattered gradient rows,
+    # masks ...): as torch.zeros each is a ~5 us fill launch, 0.16 ms per step in all.  They are carved out of ONE buffer
+    # that is allocated zeroed at the start of the step (a new one per step: results a caller still holds stay intact),
+    # sized by the previous step's total; requests beyond it fall back to torch.zeros.
+    def _zero_arena_begin(self):
+        if not self.zero_arena:
+            self._za = None
+            return
+        need = getattr(self, "_za_used", 0)
+        size = (int(need * 1.25) + 4096) // 256 * 256 if need else 0
+        self._za = torch.zeros(size, dtype=torch.uint8, device=self.device) if size else None
+        self._za_off, self._za_used = 0, 0
+
+    def _z(self, *shape, dtype=torch.float32, device=None):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+            shape = tuple(shape[0])
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = (n * torch.empty(0, dtype=dtype).element_size() + 255) // 256 * 256
+        self._za_used = getattr(self, "_za_used", 0) + nbytes
+        za = getattr(self, "_za", None)
+        if za is None or self._za_off + nbytes > za.numel() or n == 0:
+            return torch.zeros(*shape, dtype=dtype, device=self.device)
+        v = za[self._za_off: self._za_off + n * torch.empty(0, dtype=dtype).element_size()].view(dtype).view(*shape)
+        self._za_off += nbytes
+        return v
 
     # ------------------------------------------------------------------ building blocks
     def _march(self, P: Pass, scene, rays_o, rays_d, em_modes, mask_density, sdf, prelude=None):
@@ -600,14 +632,15 @@ class LtsEngine(FineEngine):
         absent they are drawn exactly where the reference draws them."""
         L, s, dev = self.L, self._s(), self.device
         sdf, offg, emog, brdfg = grids["sdf"], grids["off"], grids["emo"], grids["brdf"]
+        self._zero_arena_begin()
         rays_o, rays_d, viewdirs = batch["rays_o"], batch["rays_d"], batch["viewdirs"]
         N = rays_o.shape[0]
         P0 = self.prim
         cnt3, off3, last = self._march(P0, scene, rays_o, rays_d, batch["em_modes"], grids["mask"], sdf, prelude=prelude)
         T, Ton = P0.tiles_all, P0.tiles_on
-        srgb = torch.zeros(N, 3, device=dev)
-        lin_m = torch.zeros(N, 3, device=dev)
-        emit_m = torch.zeros(N, 3, device=dev)
+        srgb = self._z(N, 3, device=dev)
+        lin_m = self._z(N, 3, device=dev)
+        emit_m = self._z(N, 3, device=dev)
         ctx = LtsCtx(scene=scene, scene2=scene2, batch=batch, perm=None, jp=None, n_pts=0,
                      n_2nd=int(cfg["num_2ndrays"]), pdra=bool(cfg["pdra"]))
         ctx.t.update(cnt3=cnt3, off3=off3, last=last, grids=grids, envmap=envmap)
@@ -660,7 +693,7 @@ class LtsEngine(FineEngine):
         # perturbed re-evaluations (esrnerf.py:807-830)
         nn_ = torch.randn(m3, 3, device=dev) if draws is None else draws["noise_normal"].to(dev)
         ne_ = torch.randn(m3, 3, device=dev) if draws is None else draws["noise_emit"].to(dev)
-        noise_n = torch.zeros(T * 32, 3, device=dev)
+        noise_n = self._z(T * 32, 3, device=dev)
         noise_n[perm] = nn_
         eg_eps = torch.empty(T * 32, 4, device=dev)
         self._run("expgrad_fwd(eps)", L.esr_expgrad_fwd, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(P0.bufs["rec_ray"]),
@@ -674,7 +707,7 @@ class LtsEngine(FineEngine):
         self._run("expgrad_fwd(pts)", L.esr_expgrad_fwd, sp, None, None, None, None, _lib.ptr(pts_e), None, C.c_float(0.0),
                   _lib.ptr(sdf), m3, 1, _lib.ptr(sv), s)
         sdf_e = sv[:, 0].contiguous()
-        vd_e = torch.zeros(m3, 3, device=dev)
+        vd_e = self._z(m3, 3, device=dev)
         self._feat_args_points(P3, pts_e, vd_e, sdf_e, sdf, (None, emog, brdfg))
         self._features(P3, scene)
         T3 = P3.tiles_all
@@ -725,11 +758,11 @@ class LtsEngine(FineEngine):
         P2 = self.sec
         o2 = pts_p.repeat_interleave(R, 0).contiguous()
         d2 = dirs_all[:, :R].reshape(Pn * R, 3).contiguous()
-        em2 = torch.zeros(Pn * R, dtype=torch.int64, device=dev)
+        em2 = self._z(Pn * R, dtype=torch.int64, device=dev)
         _, off3_2, last2 = self._march(P2, scene2, o2, d2, em2, grids["mask"], sdf)
         T2 = P2.tiles_all
-        off_m = torch.zeros(Pn * R, 3, device=dev)
-        emo_m = torch.zeros(Pn * R, 3, device=dev)
+        off_m = self._z(Pn * R, 3, device=dev)
+        emo_m = self._z(Pn * R, 3, device=dev)
         if T2:
             self._feat_args_records(P2, o2, d2, d2, sdf, (offg, emog, None), (offg, emog, None))
             self._features(P2, scene2)
@@ -824,14 +857,14 @@ class LtsEngine(FineEngine):
         T, Ton = P0.tiles_all, P0.tiles_on
         Pn, R = ctx.n_pts, ctx.n_2nd
         perm, jp = ctx.perm, ctx.jp
-        zero = lambda k, shape: g[k].contiguous() if g.get(k) is not None else torch.zeros(shape, device=dev)
+        zero = lambda k, shape: g[k].contiguous() if g.get(k) is not None else self._z(shape, device=dev)
         sp, sp2 = C.byref(ctx.scene), C.byref(ctx.scene2)
         b = ctx.batch
         grid_g = grads
 
         # ---- rendering equation
         g_oh, g_eh = zero("lin/pbr/off_hat", (2 * Pn, 3)), zero("lin/pbr/emo_hat", (2 * Pn, 3))
-        z = lambda *sh: torch.zeros(*sh, device=dev)
+        z = lambda *sh: self._z(*sh, device=dev)
         d = dict(d_off_m=z(Pn * R, 3), d_emo_m=z(Pn * R, 3), d_last2=z(Pn * R), d_base=z(Pn, 3), d_rough=z(Pn),
                  d_metal=z(Pn), d_emission=z(Pn, 3), d_mus=grads["mus"], d_lambdas=grads["lambdas"].view(-1),
                  d_lobes=grads["lobes"])
@@ -870,18 +903,18 @@ class LtsEngine(FineEngine):
         T1 = P1.tiles_all
         src = []
         for nm, crow, key, gon in (("off", 0, "lin/pbr/off", grads["off"]), ("emo", 88, "lin/pbr/emo", grads["emo"])):
-            ga = torch.zeros(T1 * 32, 3, device=dev)
+            ga = self._z(T1 * 32, 3, device=dev)
             ga[: 2 * Pn] = zero(key, (2 * Pn, 3))
             gt = P1.from_rowmajor(f"{nm}.ga", 4, ga)
             dz = self._act(P1, f"{nm}.z", f"{nm}.dz", 4, 3, ACT_SOFTPLUS, bwd_g=gt)
             dX = self._net_bwd(P1, nm, KIND_RADIANCE, crow, 0, T1, dz, grads[f"{nm}_w"], grads[f"{nm}_b"])
             src.append((dX, None, gon, 0, T1))
-        dsdf_pts = torch.zeros(T1 * 32, device=dev)
+        dsdf_pts = self._z(T1 * 32, device=dev)
         self._feat_bwd(P1, ctx.scene, src, grads["sdf"], dsdf_out=dsdf_pts)
 
         # ---- primary pass: assemble per-sample head gradients in compact order
         def to_compact(key, c):
-            out = torch.zeros(T * 32, c, device=dev)
+            out = self._z(T * 32, c, device=dev)
             if g.get(key) is not None:
                 out[perm] = g[key]
             return out
@@ -889,7 +922,7 @@ class LtsEngine(FineEngine):
         d_brdf.index_add_(0, jp, torch.cat([d["d_base"], d["d_rough"][:, None], d["d_metal"][:, None]], 1))
         d_emit = to_compact("etc/emit", 3)
         d_emit.index_add_(0, jp, d["d_emission"])
-        dsdf_extra = torch.zeros(T * 32, device=dev)
+        dsdf_extra = self._z(T * 32, device=dev)
         dsdf_extra.index_add_(0, jp, dsdf_pts[:Pn] + dsdf_pts[Pn: 2 * Pn])
         # composites
         g_srgb, g_lin = zero("srgb/rgb", (P0.n_rays, 3)), zero("lin/rgb", (P0.n_rays, 3))
@@ -926,7 +959,7 @@ class LtsEngine(FineEngine):
         for key, noise, eps in (("etc/normal", None, 0.0), ("etc/normal_eps", ctx.t["noise_n"], ctx.eps["normal"])):
             if g.get(key) is None:
                 continue
-            g4 = torch.zeros(T * 32, 4, device=dev)
+            g4 = self._z(T * 32, 4, device=dev)
             g4[perm, 1:4] = g[key]
             self._run("expgrad_bwd", L.esr_expgrad_bwd, sp, _lib.ptr(b["rays_o"]), _lib.ptr(b["rays_d"]),
                       _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(P0.bufs["rec_step"]), None, _lib.ptr(noise), C.c_float(eps),
@@ -943,15 +976,15 @@ class LtsEngine(FineEngine):
                 continue
             if not ctx.t["eps_grads"]:
                 raise RuntimeError(f"gradient of {key} requested but the forward ran with eps_grads=False")
-            ga = torch.zeros(T3 * 32, nch, device=dev)
+            ga = self._z(T3 * 32, nch, device=dev)
             ga[:m3] = g[key]
             gt = P3.from_rowmajor(f"{nm}.ga", rows, ga)
             dz = self._act(P3, f"{nm}.z", f"{nm}.dz", rows, nch, act, bwd_g=gt)
             dX = self._net_bwd(P3, nm, kind, crow, 0, T3, dz, grads[f"{nm}_w"], grads[f"{nm}_b"])
             src.append((dX, None, ggrid, 0, T3))
         if src:
-            g4e = torch.zeros(T3 * 32, 4, device=dev)
-            dsdf_e = torch.zeros(T3 * 32, device=dev)
+            g4e = self._z(T3 * 32, 4, device=dev)
+            dsdf_e = self._z(T3 * 32, device=dev)
             self._feat_bwd(P3, ctx.scene, src, grads["sdf"], dsdf_out=dsdf_e)
             g4e[:, 0] = dsdf_e
             self._run("expgrad_bwd(pts)", L.esr_expgrad_bwd, sp, None, None, None, None, _lib.ptr(ctx.t["pts_e"]), None,
