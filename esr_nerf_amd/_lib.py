@@ -73,7 +73,8 @@ EXPORTS = [
     "esr_sample_count", "esr_sample_fill", "esr_alpha2weight_fwd", "esr_alpha2weight_bwd",
     "esr_tv_add_grad", "esr_segment_sum",
     "esr_fine_march_count", "esr_fine_plan_begin", "esr_fine_plan", "esr_fine_march_fill",
-    "esr_fine_march_bwd", "esr_fine_march_bwd_rec", "esr_fine_march_count_ga", "esr_fine_march_fill_ga", "esr_fine_march_bwd_ga",
+    "esr_fine_march_bwd", "esr_fine_march_bwd_rec", "esr_fine_march_cache_floats", "esr_fine_march_count_cached",
+    "esr_fine_march_fill_cached", "esr_fine_march_bwd_cached", "esr_fine_march_count_ga", "esr_fine_march_fill_ga", "esr_fine_march_bwd_ga",
     "esr_fine_feat_fwd", "esr_fine_feat_bwd",
     "esr_mlp_packed_floats", "esr_mlp_pack", "esr_mlp_fwd", "esr_mlp_fwd_mixed", "esr_mlp_dgrad", "esr_mlp_dgrad_wg", "esr_mlp_wgrad", "esr_mlp_wgrad_batch", "esr_tone_wgrad_scratch_floats", "esr_tone_wgrad_recompute",
     "esr_mlp_wgrad_scratch_floats",
@@ -107,6 +108,7 @@ def lib() -> C.CDLL:
             L.esr_mlp_packed_floats.restype = C.c_int64
             L.esr_mlp_wgrad_scratch_floats.restype = C.c_int64
             L.esr_tone_wgrad_scratch_floats.restype = C.c_int64
+            L.esr_fine_march_cache_floats.restype = C.c_int64
         if hasattr(L, "esr_mlp_packed_bf16_elems"):
             L.esr_mlp_packed_bf16_elems.restype = C.c_int64
         if L.esr_abi_version() != ABI_VERSION:

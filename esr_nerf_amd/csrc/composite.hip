@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) a2w_fwd_kernel(const float *__restrict__ 
             float myT = 1.f;
             bool done = false;
             for (int i = 0; i < cnt; ++i) {
-                const float ai = __shfl(a, i);
+                const float ai = esr_readlane(a, i);
                 if (lane == i) { myT = tc; done = true; }
                 tc = (float)((double)tc * (1.0 - (double)ai));
                 if ((double)tc < 1e-3) { stop = c0 + i + 1; stopped = true; break; }
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256) a2w_bwd_kernel(
             float myback = 0.f;
             for (int i = cnt - 1; i >= 0; --i) {
                 if (lane == i) myback = back;
-                back += __shfl(x, i);
+                back += esr_readlane(x, i);
             }
             if (ok) {
                 const float a = alpha[c0 + lane];

@@ -242,6 +242,12 @@ __device__ __forceinline__ float esr_sigmoid(float x) { return 1.f / (1.f + expf
 
 __device__ __forceinline__ int esr_lane() { return (int)(threadIdx.x & 63); }
 
+// value of `x` in lane `i` for a wave-uniform i (v_readlane_b32; __shfl would go through the LDS permute network)
+static __device__ __forceinline__ float esr_readlane(float x, int i)
+{
+    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), i));
+}
+
 #ifndef ESR_NT_AUX
 #define ESR_NT_AUX 2          // gfx940+ buffer cache-policy bits: 1 = sc0, 2 = nt, 16 = sc1
 #endif

@@ -45,7 +45,13 @@ struct MarchParams {
     float *dsdf_rec;         // optional [n_tiles*32]: the value-tap gradient of a RECORDED sample is added here (the feature
                              // backward scatters it with its own SDF taps) instead of 8 atomics into grad_sdf
     int dsdf_acc;            // 0: every recorded slot is overwritten; 1: added to what the caller put there
+    // march cache [n_rays][5][cap] (sdf | step | alpha | T | info of every mask-cache survivor, compacted per ray): written
+    // by the COUNT pass, it lets FILL be a plain copy and BWD start at its reverse scan -- the walk (two trilinear
+    // fetches per step) and the serial transmittance loop run once per step instead of three times
+    float *cache;
+    const float *last_in;    // BWD from the cache: alphainv_last of the COUNT pass
 };
+constexpr int CACHE_ARR = 5;
 
 __device__ __forceinline__ float neus_alpha(float pc, float nc)
 {
@@ -128,8 +134,36 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
 
     float vd[3] = {0.f, 0.f, 0.f};
     if (GA) { vd[0] = P.viewdirs[3 * r]; vd[1] = P.viewdirs[3 * r + 1]; vd[2] = P.viewdirs[3 * r + 2]; }
+    float *const csdf = P.cache ? P.cache + (size_t)r * CACHE_ARR * P.cap : nullptr;
+    int *const cstep = reinterpret_cast<int *>(csdf + P.cap);
+    float *const calpha = csdf + 2 * P.cap, *const cT = csdf + 3 * P.cap;
+    int *const cinfo = reinterpret_cast<int *>(csdf + 4 * P.cap);
+    if (MODE == MARCH_FILL && P.cache) {              // records straight from the COUNT pass's cache
+        const int n1c = P.stats[3 * r + 1], ob = P.off3[r];
+        for (int j = lane; j < n1c; j += 64) {
+            const int rec = cinfo[j] >> 8;
+            if (rec) {
+                const int o = ob + rec - 1;
+                P.rec_ray[o] = r;
+                P.rec_step[o] = cstep[j];
+                P.rec_w[o] = cT[j] * calpha[j];
+                P.rec_sdf[o] = csdf[j];
+            }
+        }
+        return;
+    }
     // ---- phase 1: walk the ray, keep in-box & mask-cache survivors in LDS ----
     int n0 = 0, n1 = 0;
+    float tc = 1.f, tc2 = 1.f, wsum = 0.f;
+    int n2 = 0, n3 = 0;
+    const int out_base = (MODE != MARCH_COUNT) ? P.off3[r] : 0;
+    if (MODE == MARCH_BWD && P.cache) {               // LDS arrays of the backward from the cache
+        n1 = P.stats[3 * r + 1];
+        for (int j = lane; j < n1; j += 64) {
+            sdf1[j] = csdf[j]; step1[j] = cstep[j]; alpha1[j] = calpha[j]; T1[j] = cT[j]; info1[j] = cinfo[j];
+        }
+        tc = tc2 = P.last_in[r];
+    } else {
     for (int c0 = 0; c0 < g.n_steps; c0 += 64) {
         const int step = c0 + lane;
         bool ok = step < g.n_steps;
@@ -155,16 +189,14 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
             sdf1[pos] = s;
             step1[pos] = step;
             if (GA) ic1[pos] = ic;
+            if (MODE == MARCH_COUNT && P.cache) { csdf[pos] = s; cstep[pos] = step; }
         }
         n1 += __popcll(b);
     }
     __threadfence_block();
 
     // ---- phase 2: alpha, thresholds, transmittance in serial order ----------
-    float tc = 1.f, tc2 = 1.f, wsum = 0.f;
     bool stopped = false, stopped2 = false;
-    int n2 = 0, n3 = 0;
-    const int out_base = (MODE != MARCH_COUNT) ? P.off3[r] : 0;
     for (int c0 = 0; c0 < n1; c0 += 64) {
         const int j = c0 + lane;
         const bool ok = j < n1;
@@ -185,7 +217,7 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
             while (rem) {
                 const int i = __ffsll((long long)rem) - 1;
                 rem &= rem - 1;
-                const float ai = __shfl(alpha, i);
+                const float ai = esr_readlane(alpha, i);        // i is wave-uniform: v_readlane, not an LDS permute
                 if (lane == i) { myT = tc; proc = true; }
                 tc = (float)((double)tc * (1.0 - (double)ai));
                 if ((double)tc < 1e-3) { stopped = true; break; }
@@ -203,7 +235,7 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
                 while (rem) {
                     const int i = __ffsll((long long)rem) - 1;
                     rem &= rem - 1;
-                    const float ai = __shfl(alpha, i);
+                    const float ai = esr_readlane(alpha, i);        // i is wave-uniform: v_readlane, not an LDS permute
                     if (lane == i) { myT = tc2; proc = true; }
                     tc2 = (float)((double)tc2 * (1.0 - (double)ai));
                     if ((double)tc2 < 1e-3) { stopped2 = true; break; }
@@ -224,8 +256,14 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
             T1[j] = myT;
             info1[j] = (v2 ? 1 : 0) | (proc ? 2 : 0) | (v3 ? ((rank + 1) << 8) : 0);
         }
+        if (MODE == MARCH_COUNT && P.cache && ok) {
+            calpha[j] = alpha;
+            cT[j] = myT;
+            cinfo[j] = (v2 ? 1 : 0) | (proc ? 2 : 0) | (v3 ? ((rank + 1) << 8) : 0);
+        }
         n3 += __popcll(b3);
     }
+    }   // (walk + serial pass; skipped by the backward when the COUNT pass's cache is given)
 
     if (MODE == MARCH_COUNT) {
         if (COARSE && P.cumw) {
@@ -264,7 +302,7 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
             if (lane + off < 64) v += u;
         }
         const float myback = back + (v - x);
-        back += __shfl(v, 0);
+        back += esr_readlane(v, 0);
         float dprev = 0.f, dnext = 0.f;
         if (proc) {
             const float dalpha =
@@ -488,6 +526,58 @@ ESR_API int esr_fine_march_bwd_rec(const esr_scene_t *scene, const float *rays_o
     MarchParams P = {};
     P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d; P.mask_density = mask_density; P.sdf = sdf;
     P.n_rays = n_rays; P.cap = march_cap(scene); P.off3 = off3; P.dweight = dweight; P.dlast = dlast;
+    P.grad_sdf = grad_sdf; P.dsdf_rec = dsdf_rec; P.dsdf_acc = accumulate;
+    return launch_march<MARCH_BWD>(P, esr_stream(stream));
+}
+
+// ---- the three passes sharing a cache (see MarchParams::cache) ----------------------------------------------------
+ESR_API int64_t esr_fine_march_cache_floats(const esr_scene_t *scene, int32_t n_rays)
+{
+    if (!scene || n_rays < 0) return ESR_EINVAL;
+    return (int64_t)n_rays * CACHE_ARR * march_cap(scene);
+}
+
+ESR_API int esr_fine_march_count_cached(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                                        const float *mask_density, const float *sdf, int32_t n_rays, int32_t *cnt3,
+                                        float *alphainv_last, int32_t *ray_stats, esr_plan_t *plan, float *cache,
+                                        void *stream)
+{
+    if (!scene || n_rays < 0 || !plan) return ESR_EINVAL;
+    if (n_rays && (!rays_o || !rays_d || !mask_density || !sdf || !cnt3 || !alphainv_last || !ray_stats || !cache))
+        return ESR_EINVAL;
+    MarchParams P = {};
+    P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d; P.mask_density = mask_density; P.sdf = sdf;
+    P.n_rays = n_rays; P.cap = march_cap(scene); P.cnt3 = cnt3; P.alphainv_last = alphainv_last;
+    P.stats = ray_stats; P.plan = plan; P.cache = cache;
+    return launch_march<MARCH_COUNT>(P, esr_stream(stream));
+}
+
+ESR_API int esr_fine_march_fill_cached(const esr_scene_t *scene, const float *rays_o, const float *rays_d, int32_t n_rays,
+                                       const int32_t *off3, const int32_t *ray_stats, const float *cache,
+                                       int32_t *rec_ray, int32_t *rec_step, float *rec_w, float *rec_sdf, void *stream)
+{
+    if (!scene || n_rays < 0) return ESR_EINVAL;
+    if (n_rays && (!rays_o || !rays_d || !off3 || !ray_stats || !cache || !rec_ray || !rec_step || !rec_w || !rec_sdf))
+        return ESR_EINVAL;
+    MarchParams P = {};
+    P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d;
+    P.n_rays = n_rays; P.cap = march_cap(scene); P.off3 = off3; P.stats = const_cast<int32_t *>(ray_stats);
+    P.cache = const_cast<float *>(cache); P.rec_ray = rec_ray; P.rec_step = rec_step; P.rec_w = rec_w; P.rec_sdf = rec_sdf;
+    return launch_march<MARCH_FILL>(P, esr_stream(stream));
+}
+
+ESR_API int esr_fine_march_bwd_cached(const esr_scene_t *scene, const float *rays_o, const float *rays_d, int32_t n_rays,
+                                      const int32_t *off3, const int32_t *ray_stats, const float *alphainv_last,
+                                      const float *cache, const float *dweight, const float *dlast, float *grad_sdf,
+                                      float *dsdf_rec, int32_t accumulate, void *stream)
+{
+    if (!scene || n_rays < 0) return ESR_EINVAL;
+    if (n_rays && (!rays_o || !rays_d || !off3 || !ray_stats || !alphainv_last || !cache || !dweight || !dlast || !grad_sdf))
+        return ESR_EINVAL;
+    MarchParams P = {};
+    P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d;
+    P.n_rays = n_rays; P.cap = march_cap(scene); P.off3 = off3; P.stats = const_cast<int32_t *>(ray_stats);
+    P.last_in = alphainv_last; P.cache = const_cast<float *>(cache); P.dweight = dweight; P.dlast = dlast;
     P.grad_sdf = grad_sdf; P.dsdf_rec = dsdf_rec; P.dsdf_acc = accumulate;
     return launch_march<MARCH_BWD>(P, esr_stream(stream));
 }

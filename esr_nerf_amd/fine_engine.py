@@ -65,6 +65,7 @@ class FineCtx:
     mask_density: torch.Tensor
     sdf: torch.Tensor
     feat_args: object = None
+    march_cache: object = None        # (ray_stats, alphainv_last, cache) of the count pass, for the backward
 
 
 class _Workspace:
@@ -176,13 +177,18 @@ class FineEngine:
         else:
             self._run(name, getattr(self.L, f"esr_fine_march_{which}"), sp, _lib.ptr(rays_o), _lib.ptr(rays_d), *rest)
 
-    def _ray_buf(self, n):
+    def _ray_buf(self, n, scene=None):
         if n not in self.ray_bufs:
             self.ray_bufs[n] = dict(
                 cnt3=torch.empty(n, dtype=torch.int32, device=self.device),
                 off3=torch.empty(n, dtype=torch.int32, device=self.device),
                 stats=torch.empty(n * 3, dtype=torch.int32, device=self.device))
-        return self.ray_bufs[n]
+        rb = self.ray_bufs[n]
+        if scene is not None:       # march cache (count -> fill -> backward share one walk): sized by the scene's step bound
+            need = int(self.L.esr_fine_march_cache_floats(C.byref(scene), n))
+            if rb.get("cache") is None or rb["cache"].numel() < need:
+                rb["cache"] = torch.empty(need, dtype=torch.float32, device=self.device)
+        return rb
 
     def pack(self, which: str, kind: int, weights: List[torch.Tensor], biases: List[torch.Tensor]):
         self._raw[which] = (list(weights), list(biases))      # reference-layout tensors (esr_tone_wgrad_recompute reads them)
@@ -245,7 +251,8 @@ class FineEngine:
                 raise RuntimeError("rays must be fp32")
         if em_modes.dtype != torch.int64:
             raise RuntimeError("em_modes must be int64")
-        rb = self._ray_buf(n)
+        cached = not self.neus_grad            # one walk per step (esr_fine_march_*_cached); not with neus_alpha "grad"
+        rb = self._ray_buf(n, scene if cached else None)
         last = torch.empty(n, dtype=torch.float32, device=self.device)
         # everything of the step that starts from zero in ONE fill (each small fill is a ~5 us launch on the step's
         # critical path): plan header (8 x i32; what esr_fine_plan_begin does) | srgb | lin | the loss accumulator
@@ -255,8 +262,13 @@ class FineEngine:
         self._loss_acc = zb[8 + 6 * n:]
         sp = C.byref(scene)
         main = torch.cuda.current_stream(self.device)
-        self._march("march_count", "count", sp, rays_o, rays_d, viewdirs, _lib.ptr(mask_density),
-                    _lib.ptr(sdf), n, _lib.ptr(rb["cnt3"]), _lib.ptr(last), _lib.ptr(rb["stats"]), _lib.ptr(self.plan_dev), s)
+        if cached:
+            self._run("march_count", L.esr_fine_march_count_cached, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(mask_density),
+                      _lib.ptr(sdf), n, _lib.ptr(rb["cnt3"]), _lib.ptr(last), _lib.ptr(rb["stats"]), _lib.ptr(self.plan_dev),
+                      _lib.ptr(rb["cache"]), s)
+        else:
+            self._march("march_count", "count", sp, rays_o, rays_d, viewdirs, _lib.ptr(mask_density),
+                        _lib.ptr(sdf), n, _lib.ptr(rb["cnt3"]), _lib.ptr(last), _lib.ptr(rb["stats"]), _lib.ptr(self.plan_dev), s)
         self._run("plan", L.esr_fine_plan, _lib.ptr(rb["cnt3"]), _lib.ptr(em_modes), _lib.ptr(rb["stats"]), n, _lib.ptr(rb["off3"]),
                                    _lib.ptr(self.plan_dev), s)
         self.plan_host.copy_(self.plan_dev, non_blocking=True)
@@ -285,9 +297,15 @@ class FineEngine:
             return ctx, last, srgb, lin
         ws.ensure(tiles_all)
         ws["rec_ray"][: tiles_all * 32].fill_(-1)
-        self._march("march_fill", "fill", sp, rays_o, rays_d, viewdirs, _lib.ptr(mask_density),
-                    _lib.ptr(sdf), n, _lib.ptr(rb["off3"]), _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_step"]),
-                    _lib.ptr(ws["rec_w"]), _lib.ptr(ws["rec_sdf"]), s)
+        if cached:
+            self._run("march_fill", L.esr_fine_march_fill_cached, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), n, _lib.ptr(rb["off3"]),
+                      _lib.ptr(rb["stats"]), _lib.ptr(rb["cache"]), _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_step"]),
+                      _lib.ptr(ws["rec_w"]), _lib.ptr(ws["rec_sdf"]), s)
+            ctx.march_cache = (rb["stats"], last, rb["cache"])
+        else:
+            self._march("march_fill", "fill", sp, rays_o, rays_d, viewdirs, _lib.ptr(mask_density),
+                        _lib.ptr(sdf), n, _lib.ptr(rb["off3"]), _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_step"]),
+                        _lib.ptr(ws["rec_w"]), _lib.ptr(ws["rec_sdf"]), s)
         fa = self.feat_args(rays_o, rays_d, viewdirs, sdf, tiles_on, tiles_all,
                             color_on=(emo_color, off_color, None), color_off=(off_color, None, None))
         self._run("feat_fwd", L.esr_fine_feat_fwd, sp, C.byref(fa), _lib.ptr(ws["X"]), _lib.ptr(ws["gnorm"]), s)
@@ -428,6 +446,12 @@ class FineEngine:
         fold = ta > 0 and not self.neus_grad and scat is None and grads.get("sdf") is not None
 
         def march_bwd(s_):
+            if fold and ctx.march_cache is not None:
+                st, la, ca = ctx.march_cache
+                self._run("march_bwd", L.esr_fine_march_bwd_cached, sp, _lib.ptr(ctx.rays_o), _lib.ptr(ctx.rays_d), ctx.n_rays,
+                          _lib.ptr(ctx.off3), _lib.ptr(st), _lib.ptr(la), _lib.ptr(ca), _lib.ptr(dweight), _lib.ptr(g_last),
+                          _lib.ptr(grads["sdf"]), _lib.ptr(ws["dsdf"]), 0, s_)
+                return
             if fold:
                 self._run("march_bwd", L.esr_fine_march_bwd_rec, sp, _lib.ptr(ctx.rays_o), _lib.ptr(ctx.rays_d),
                           _lib.ptr(ctx.mask_density), _lib.ptr(ctx.sdf), ctx.n_rays, _lib.ptr(ctx.off3), _lib.ptr(dweight),

@@ -193,6 +193,25 @@ int esr_fine_march_bwd_rec(const esr_scene_t *scene, const float *rays_o, const 
                            float *grad_sdf, float *dsdf_rec, int32_t accumulate, void *stream);
 
 /*
+ * The three passes with a shared CACHE: the count pass records, for every mask-cache survivor of every ray, its SDF,
+ * step id, alpha, transmittance and survivor flags (cache: esr_fine_march_cache_floats(scene, n_rays) floats); the fill
+ * pass is then a plain copy of the recorded samples and the backward starts at its reverse scan -- the walk (mask-cache
+ * and SDF fetch per step) and the serial transmittance loop run once per step instead of three times.  Results are
+ * bit-identical to the uncached entry points.  ray_stats / alphainv_last: the count pass's outputs, untouched since.
+ */
+int64_t esr_fine_march_cache_floats(const esr_scene_t *scene, int32_t n_rays);
+int esr_fine_march_count_cached(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
+                                const float *mask_density, const float *sdf, int32_t n_rays, int32_t *cnt3,
+                                float *alphainv_last, int32_t *ray_stats, esr_plan_t *plan, float *cache, void *stream);
+int esr_fine_march_fill_cached(const esr_scene_t *scene, const float *rays_o, const float *rays_d, int32_t n_rays,
+                               const int32_t *off3, const int32_t *ray_stats, const float *cache,
+                               int32_t *rec_ray, int32_t *rec_step, float *rec_w, float *rec_sdf, void *stream);
+int esr_fine_march_bwd_cached(const esr_scene_t *scene, const float *rays_o, const float *rays_d, int32_t n_rays,
+                              const int32_t *off3, const int32_t *ray_stats, const float *alphainv_last,
+                              const float *cache, const float *dweight, const float *dlast, float *grad_sdf,
+                              float *dsdf_rec, int32_t accumulate, void *stream);
+
+/*
  * The same three march entry points for cfg `neus_alpha: grad` (app/utils/base/functions.py:45-69): the section
  * SDFs of a sample are sdf -+ 0.5 * dist * (viewdirs[ray] . grad) with grad = the radius-1 clamped central
  * differences of sample_sdf_grad (app/fine/model/voxurff.py:670-721); `viewdirs` [n_rays,3] is the batch's
