@@ -206,9 +206,14 @@ class LtsEngine(FineEngine):
         stats = torch.empty(n * 3, dtype=torch.int32, device=self.device)
         sp = C.byref(scene)
         self._run("plan_begin", L.esr_fine_plan_begin, _lib.ptr(self.plan_dev), s)
-        self._run(f"march_count[{P.name}]", L.esr_fine_march_count, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
+        # march cache: the count pass records every mask-cache survivor; fill copies, the backward starts at its scan
+        need = int(L.esr_fine_march_cache_floats(sp, n))
+        if getattr(P, "cache", None) is None or P.cache.numel() < need:
+            P.cache = torch.empty(need, dtype=torch.float32, device=self.device)
+        self._run(f"march_count[{P.name}]", L.esr_fine_march_count_cached, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
                   _lib.ptr(mask_density), _lib.ptr(sdf), n, _lib.ptr(cnt3), _lib.ptr(last), _lib.ptr(stats),
-                  _lib.ptr(self.plan_dev), s)
+                  _lib.ptr(self.plan_dev), _lib.ptr(P.cache), s)
+        P.march = (stats, last, P.cache)
         self._run("plan", L.esr_fine_plan, _lib.ptr(cnt3), _lib.ptr(em_modes), _lib.ptr(stats), n, _lib.ptr(off3),
                   _lib.ptr(self.plan_dev), s)
         self.plan_host.copy_(self.plan_dev, non_blocking=True)
@@ -234,11 +239,11 @@ class LtsEngine(FineEngine):
         rec_ray = P.buf("rec_ray", 1, torch.int32)
         rec_ray[: max(tiles_all, 1) * 32].fill_(-1)
         if tiles_all:
-            self._run(f"march_fill[{P.name}]", L.esr_fine_march_fill, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
-                      _lib.ptr(mask_density), _lib.ptr(sdf), n, _lib.ptr(off3), _lib.ptr(rec_ray),
+            self._run(f"march_fill[{P.name}]", L.esr_fine_march_fill_cached, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), n,
+                      _lib.ptr(off3), _lib.ptr(stats), _lib.ptr(P.cache), _lib.ptr(rec_ray),
                       _lib.ptr(P.buf("rec_step", 1, torch.int32)), _lib.ptr(P.buf("rec_w")),
                       _lib.ptr(P.buf("rec_sdf")), s)
-        P.keep = [rays_o, rays_d, em_modes, cnt3, off3, last]
+        P.keep = [rays_o, rays_d, em_modes, cnt3, off3, last, stats]
         return cnt3, off3, last
 
     def _feat_args_records(self, P: Pass, rays_o, rays_d, viewdirs, sdf, color_on, color_off):
@@ -890,14 +895,16 @@ class LtsEngine(FineEngine):
                 src.append((dX, None, gon, 0, T2))
             # the secondary march's value-tap gradients of the recorded samples ride on the feature backward's window
             ds2 = P2.buf("dsdf")
-            self._run("march_bwd[secondary]", L.esr_fine_march_bwd_rec, sp2, _lib.ptr(ctx.t["o2"]), _lib.ptr(ctx.t["d2"]),
-                      _lib.ptr(ctx.t["grids"]["mask"]), _lib.ptr(ctx.t["grids"]["sdf"]), Pn * R, _lib.ptr(ctx.t["off3_2"]),
+            st2, la2, ca2 = P2.march
+            self._run("march_bwd[secondary]", L.esr_fine_march_bwd_cached, sp2, _lib.ptr(ctx.t["o2"]), _lib.ptr(ctx.t["d2"]),
+                      Pn * R, _lib.ptr(ctx.t["off3_2"]), _lib.ptr(st2), _lib.ptr(la2), _lib.ptr(ca2),
                       _lib.ptr(dw2), _lib.ptr(d["d_last2"]), _lib.ptr(grads["sdf"]), _lib.ptr(ds2), 0, s)
             self._feat_bwd(P2, ctx.scene2, src, grads["sdf"], dsdf_extra=ds2)
         else:
-            self._run("march_bwd[secondary]", L.esr_fine_march_bwd, sp2, _lib.ptr(ctx.t["o2"]), _lib.ptr(ctx.t["d2"]),
-                      _lib.ptr(ctx.t["grids"]["mask"]), _lib.ptr(ctx.t["grids"]["sdf"]), Pn * R, _lib.ptr(ctx.t["off3_2"]),
-                      _lib.ptr(z(32)), _lib.ptr(d["d_last2"]), _lib.ptr(grads["sdf"]), s)
+            st2, la2, ca2 = P2.march
+            self._run("march_bwd[secondary]", L.esr_fine_march_bwd_cached, sp2, _lib.ptr(ctx.t["o2"]), _lib.ptr(ctx.t["d2"]),
+                      Pn * R, _lib.ptr(ctx.t["off3_2"]), _lib.ptr(st2), _lib.ptr(la2), _lib.ptr(ca2),
+                      _lib.ptr(z(32)), _lib.ptr(d["d_last2"]), _lib.ptr(grads["sdf"]), None, 0, s)
 
         # ---- radiance at the points
         T1 = P1.tiles_all
@@ -951,8 +958,9 @@ class LtsEngine(FineEngine):
                     grads["brdf"], grads["brdf"], 0, T))
         src.append((self._net_bwd(P0, "emit", KIND_EMIT, 88, 0, T, dze, grads["emit_w"], grads["emit_b"]),
                     grads["emo"], grads["emo"], 0, T))
-        self._run("march_bwd", L.esr_fine_march_bwd_rec, sp, _lib.ptr(b["rays_o"]), _lib.ptr(b["rays_d"]),
-                  _lib.ptr(ctx.t["grids"]["mask"]), _lib.ptr(ctx.t["grids"]["sdf"]), P0.n_rays, _lib.ptr(ctx.t["off3"]),
+        st0, la0, ca0 = P0.march
+        self._run("march_bwd", L.esr_fine_march_bwd_cached, sp, _lib.ptr(b["rays_o"]), _lib.ptr(b["rays_d"]), P0.n_rays,
+                  _lib.ptr(ctx.t["off3"]), _lib.ptr(st0), _lib.ptr(la0), _lib.ptr(ca0),
                   _lib.ptr(dweight), _lib.ptr(g_last), _lib.ptr(grads["sdf"]), _lib.ptr(dsdf_extra), 1, s)
         self._feat_bwd(P0, ctx.scene, src, grads["sdf"], dsdf_extra=dsdf_extra)
         # exact normals (linear in the grid): etc/normal and etc/normal_eps
