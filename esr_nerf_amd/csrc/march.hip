@@ -92,6 +92,32 @@ __device__ __forceinline__ void grad_alpha_ic_bwd(float *__restrict__ grad_sdf, 
     }
 }
 
+// The reference's alpha2weight walks a ray's samples in order: T_i = T_cum;  T_cum = float(double(T_cum) * (1.0 - alpha_i));
+// stop once T_cum < 1e-3 (render_utils_kernel.cu; the early stop and every rounding step decide which samples survive,
+// so the order and the mixed precision are kept).  One wave per ray: the samples of `todo` (one bit per lane) are visited
+// in lane order; every wave instruction of the loop serves ONE sample, so the loop is kept to the dependent chain:
+// 1 - alpha is formed for all lanes beforehand (in double) and read with two v_readlane, and the comparison is done in
+// float -- (double)t < 1e-3 <=> t < 1e-3f for a float t, because the float nearest to 1e-3 lies above it.
+// Returns whether this lane's sample was visited; `mine` = its T_i.
+__device__ __forceinline__ bool serial_transmittance(float alpha, unsigned long long todo, int lane, float &t_cum,
+                                                     bool &stopped, float &mine)
+{
+    static_assert((double)1e-3f >= 1e-3, "float threshold must not lie below the double one");
+    const double om = 1.0 - (double)alpha;
+    const unsigned om_lo = (unsigned)__double_as_longlong(om), om_hi = (unsigned)(__double_as_longlong(om) >> 32);
+    unsigned long long rem = todo;
+    while (rem) {
+        const int i = __ffsll((long long)rem) - 1;
+        rem &= rem - 1;
+        const double omi = __longlong_as_double(((long long)__builtin_amdgcn_readlane(om_hi, i) << 32) |
+                                                (unsigned)__builtin_amdgcn_readlane(om_lo, i));
+        mine = (lane == i) ? t_cum : mine;
+        t_cum = (float)((double)t_cum * omi);
+        if (t_cum < 1e-3f) { stopped = true; break; }
+    }
+    return ((todo & ~rem) >> lane) & 1ull;
+}
+
 // COARSE (VoxurfC.forward_training, voxurfc.py:207-219): no alpha threshold, and alpha2weight runs a SECOND
 // time over the weight > thres survivors of the first pass; weights and alphainv_last come from that pass.
 // GA = cfg neus_alpha: "grad" (app/utils/base/functions.py:45-69): the two section SDFs of a sample are extrapolated
@@ -212,17 +238,7 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
         n2 += __popcll(b2);
         float myT = 1.f;
         bool proc = false;
-        if (!stopped) {
-            unsigned long long rem = b2;
-            while (rem) {
-                const int i = __ffsll((long long)rem) - 1;
-                rem &= rem - 1;
-                const float ai = esr_readlane(alpha, i);        // i is wave-uniform: v_readlane, not an LDS permute
-                if (lane == i) { myT = tc; proc = true; }
-                tc = (float)((double)tc * (1.0 - (double)ai));
-                if ((double)tc < 1e-3) { stopped = true; break; }
-            }
-        }
+        if (!stopped) proc = serial_transmittance(alpha, b2, lane, tc, stopped, myT);
         float w = proc ? myT * alpha : 0.f;
         const bool v3 = proc && w > sc.fast_thres;
         const unsigned long long b3 = __ballot(v3);
@@ -230,17 +246,7 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
         if (COARSE) {                     // second transmittance pass over the survivors, same serial order
             myT = 1.f;
             proc = false;
-            if (!stopped2) {
-                unsigned long long rem = b3;
-                while (rem) {
-                    const int i = __ffsll((long long)rem) - 1;
-                    rem &= rem - 1;
-                    const float ai = esr_readlane(alpha, i);        // i is wave-uniform: v_readlane, not an LDS permute
-                    if (lane == i) { myT = tc2; proc = true; }
-                    tc2 = (float)((double)tc2 * (1.0 - (double)ai));
-                    if ((double)tc2 < 1e-3) { stopped2 = true; break; }
-                }
-            }
+            if (!stopped2) proc = serial_transmittance(alpha, b3, lane, tc2, stopped2, myT);
             w = proc ? myT * alpha : 0.f;
             wsum += v3 ? w : 0.f;
         }
