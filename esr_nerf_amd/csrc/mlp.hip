@@ -159,10 +159,10 @@ __global__ void __launch_bounds__(256, mlp_occ(KIND)) mlp_dgrad_kernel(DgradArgs
     }
     for (int t = A.t0 + wave; t < A.t1; t += nwaves) {
         ESR_DSTAMP(0);
-        const float *dzt = A.dz + (size_t)t * D.zrows * 32 + s;
+        const rsrc_t RZ = make_rsrc(A.dz + (size_t)t * D.zrows * 32, D.zrows * 32 * 4);
         float B0[4];                                                         // pair p <-> rows 2p, 2p+1
 #pragma unroll
-        for (int p = 0; p < 4; ++p) B0[p] = (2 * p < D.zrows) ? dzt[(2 * p + h) * 32] : 0.f;
+        for (int p = 0; p < 4; ++p) B0[p] = (2 * p < D.zrows) ? bload1(RZ, (h * 32 + s) * 4, 2 * p * 128) : 0.f;
         unsigned msk[NHID][HT / 2];                                          // all layers' ReLU masks up front
 #pragma unroll
         for (int l = 0; l < NHID; ++l)
