@@ -286,3 +286,26 @@ static __device__ __forceinline__ void bstore1_nt(rsrc_t r, float v, int voff, i
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, ESR_NT_AUX);
 }
 
+// ---- LDS-DMA (buffer_load ... lds) and hand-counted waits: used by the weight-gradient kernels (mlp.hip) and the
+// shared-weights bf16 forward / input-gradient kernels (mlp_bf16.hip) ----
+static constexpr int wait_vm_lgkm0(int n) { return (n & 15) | 0x70 | ((n >> 4) << 14); }           // vmcnt(n) lgkmcnt(0)
+static constexpr int wait_vm(int n) { return (n & 15) | 0x70 | (15 << 8) | ((n >> 4) << 14); }     // vmcnt(n)
+
+// The DMA is issued from inline asm on purpose: hipcc orders every later ds_read behind a compiler-visible
+// LDS-DMA with `s_waitcnt vmcnt(0)` (it cannot tell the buffers apart), which drains the prefetch every step.
+// An asm load is absent from its bookkeeping; its completion is counted by hand below.  M0 (the LDS
+// destination base, wide enough for all 160 KB: tools/ubench/lds_dma_m0.hip) is compiler-reserved, so it is
+// saved and restored inside the statement that uses it.
+static __device__ __forceinline__ u32x4 raw_rsrc(const void *p, unsigned bytes)
+{
+    const uint64_t a = (uint64_t)(uintptr_t)p;
+    return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+static __device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned lds_byte, int voff)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_byte), "s"(rsrc) : "memory");
+}
+

@@ -437,27 +437,6 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradBa
 // 16-B chunk c of row r is stored at chunk position c ^ ((r >> 1) & 7), so 16 consecutive rows read at the
 // same logical chunk hit 16 distinct 4-bank groups.
 // Three buffers, one barrier per tile in the MIDDLE of the tile (schedule: comment above the main loop).
-constexpr int wait_vm_lgkm0(int n) { return (n & 15) | 0x70 | ((n >> 4) << 14); }           // vmcnt(n) lgkmcnt(0)
-constexpr int wait_vm(int n) { return (n & 15) | 0x70 | (15 << 8) | ((n >> 4) << 14); }     // vmcnt(n)
-
-// The DMA is issued from inline asm on purpose: hipcc orders every later ds_read behind a compiler-visible
-// LDS-DMA with `s_waitcnt vmcnt(0)` (it cannot tell the buffers apart), which drains the prefetch every step.
-// An asm load is absent from its bookkeeping; its completion is counted by hand below.  M0 (the LDS
-// destination base, wide enough for all 160 KB: tools/ubench/lds_dma_m0.hip) is compiler-reserved, so it is
-// saved and restored inside the statement that uses it.
-__device__ __forceinline__ u32x4 raw_rsrc(const void *p, unsigned bytes)
-{
-    const uint64_t a = (uint64_t)(uintptr_t)p;
-    return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
-}
-__device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned lds_byte, int voff)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(lds_byte), "s"(rsrc) : "memory");
-}
-
 template <int MI, int NJ, int WM, int WN, int WK>
 __global__ void __launch_bounds__(64 * (WM * WN * WK + 1), 1) mlp_wgrad_dma_kernel(WgradBatch WB)
 {

@@ -212,6 +212,209 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd16_kernel(Fwd16Args A)
     }
 }
 
+// ---- forward / input gradients with the weights SHARED through LDS ----------------------------------------------------
+// mlp_fwd16_kernel above lets every wave stream the whole weight set from L2 for every 32-sample tile, 16 loads ahead at
+// most: 8 MFMAs (256 cycles) of work per L2 round trip (~1.5 k cycles) -- matrix pipe 17-19 % busy, 14 TB/s of L2-to-CU
+// traffic (profiles/r02_p_c2bf16_*).  Here one workgroup per CU = SEVEN compute waves + ONE loader wave owns seven tiles
+// at a time; the loader stages every layer's weights in LDS once for all seven by LDS-DMA (buffer_load ... lds: no staging
+// registers, issued from a wave that has nothing else to do -- see the weight-gradient kernel in mlp.hip) into the buffer
+// the compute waves are NOT reading, one raw s_barrier per layer.  Per layer and tile group: 74 KB from L2 instead of
+// 7 x 74; operands by ds_read_b128 (conflict-free: the LDS image is the packed buffer's [chunk][64 lanes][16 B]); biases
+// from LDS too, so a compute wave has no global load inside a tile group but its X tile.  Same arithmetic, same packed
+// buffers, same saved tiles as the streaming kernels.
+constexpr int SHW = 7;                                      // compute waves (= tiles per group); wave SHW is the loader
+
+template <int KIND, bool BWD> struct Shared16 {
+    static constexpr NetDesc D = net_desc(KIND);
+    static constexpr Pack16Layout L = pack16_layout(KIND);
+    static constexpr int NL = D.n_layers;
+    // layer order of the pass: forward 0 .. NL-1; backward NL-1 .. 0 (transposed parts)
+    static constexpr int layer(int step) { return BWD ? NL - 1 - step : step; }
+    static constexpr int chunks(int l) { return BWD ? L.kso[l] * L.tiles_in[l] : L.ks[l] * L.tiles_out[l]; }   // 1-KB chunks
+    static constexpr int64_t off(int l) { return (BWD ? L.off_wb[l] : L.off_wf[l]) * 2; }                        // bytes
+    static constexpr int max_chunks()
+    {
+        int m = 0;
+        for (int l = 0; l < NL; ++l) m = chunks(l) > m ? chunks(l) : m;
+        return m;
+    }
+    static constexpr int BUF = max_chunks() * 1024;                                      // bytes per LDS weight buffer
+    static constexpr int BIAS_FLOATS = 32 * MAX_HID_TILES;                               // per layer, accumulator order
+    static constexpr int LDS_BYTES = 2 * BUF + NL * BIAS_FLOATS * 4;
+};
+
+// the loader's part of one layer step: stage `chunks` 1-KB pieces from packed byte offset `off` into LDS at `dst`
+__device__ __forceinline__ void loader_stage(u32x4 rs, unsigned dst, int off, int chunks, int lane)
+{
+    for (int c = 0; c < chunks; ++c) {
+        // vmcnt is a 6-bit counter: never more than 48 pieces in flight (72 per hidden layer would wrap it -- the
+        // first version did, and a layer's last pieces were read before they had landed)
+        if (c >= 48 && c % 8 == 0) __builtin_amdgcn_s_waitcnt(wait_vm(40));
+        lds_dma16(rs, dst + (unsigned)c * 1024u, off + c * 1024 + lane * 16);
+    }
+}
+
+// acc[it] += W[j][it] . B(j), weights read from the LDS image of the packed layer (explicitly double-buffered reads)
+template <int KS, int NT, typename BF>
+__device__ __forceinline__ void lds_layer16(const unsigned char *wsrc, BF bget, f32x16 (&acc)[NT], int lane)
+{
+    constexpr int NTOT = KS * NT, G = 4, NG = (NTOT + G - 1) / G;
+    const u32x4 *mine = reinterpret_cast<const u32x4 *>(wsrc) + lane;
+    u32x4 buf[2][G];
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+        if (i < NTOT) buf[0][i] = mine[i * 64];
+    bf16x8 b = {};
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int n = (g + 1) * G + i;
+            if (n < NTOT) buf[(g + 1) & 1][i] = mine[n * 64];
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int n = g * G + i;
+            if (n < NTOT) {
+                const int j = n / NT, it = n % NT;
+                if (it == 0) b = bget(j);
+                acc[it] = mfma16(__builtin_bit_cast(bf16x8, buf[g & 1][i]), b, acc[it]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// acc += bias (accumulator order, from LDS), AFTER the layer's products.  (Initialising the accumulators with ds_read_b128
+// straight into the MFMA's srcC registers gave wrong values in two registers of the last tile -- rows 11 / 15 / 16 / 20 of
+// units 160-191, deterministically, with bias and weights in LDS verified correct in-kernel; zero-initialised
+// accumulators + this add are exact.  Cause not established; the add costs ~100 VALU instructions per layer, beside a
+// matrix pipe that is not the f32 lanes.)
+template <int NT>
+__device__ __forceinline__ void lds_bias_add(const float *bl, f32x16 (&acc)[NT], int lane)
+{
+    const float4 *b4 = reinterpret_cast<const float4 *>(bl + (lane >> 5) * 16);
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = b4[it * 8 + q];
+            acc[it][4 * q + 0] += v.x; acc[it][4 * q + 1] += v.y; acc[it][4 * q + 2] += v.z; acc[it][4 * q + 3] += v.w;
+        }
+}
+// workgroup barrier between layer steps: LDS contents change hands here, nothing may be moved across it
+__device__ __forceinline__ void layer_barrier()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): this wave's LDS reads of the layer are done
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(64 * (SHW + 1), 1) mlp_fwd16s_kernel(Fwd16Args A)
+{
+    using S = Shared16<KIND, false>;
+    constexpr NetDesc D = S::D;
+    constexpr int NL = S::NL, NHID = NL - 1, HT = D.hid_tiles;
+    constexpr unsigned HBYTES = HT * 32 * 32 * 2, MBYTES = (HT / 2) * 256;
+    constexpr PackLayout L32 = pack_layout(KIND);
+    constexpr Pack16Layout L = S::L;
+    constexpr int KS1 = L.ks[0];
+    extern __shared__ __attribute__((aligned(16))) unsigned char wl[];          // buffer 0 | buffer 1 | biases
+    typedef __attribute__((address_space(3))) void lds_void;
+    float *bias_l = reinterpret_cast<float *>(wl + 2 * S::BUF);
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, s = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = A.t1 - A.t0, ngroups = (ntiles + SHW - 1) / SHW;
+    // biases of every layer into LDS (accumulator order, as packed for the fp32 engine)
+    for (int i = tid; i < NL * S::BIAS_FLOATS; i += 64 * (SHW + 1)) {
+        const int l = i / S::BIAS_FLOATS, k = i % S::BIAS_FLOATS;
+        bias_l[i] = k < L32.tiles_out[l] * 32 ? A.packed32[L32.off_bf[l] + k] : 0.f;
+    }
+    if (wv == SHW) {
+        // ---- loader wave: layer 0 (and, for a two-layer net, layer 1: then nothing moves in the loop) up front; in
+        // the loop, during layer step k of a group, the weights of step k + 1 (mod NL) into the other buffer
+        const u32x4 rs = raw_rsrc(A.packed16, (unsigned)(L.total * 2));
+        const unsigned lds0 = (unsigned)(uintptr_t)(lds_void *)wl;
+        loader_stage(rs, lds0, (int)S::off(0), S::chunks(0), lane);
+        if (NL == 2) loader_stage(rs, lds0 + S::BUF, (int)S::off(1), S::chunks(1), lane);
+        __builtin_amdgcn_s_waitcnt(wait_vm(0));
+        layer_barrier();
+        if (NL == 2) return;
+        int cur_buf = 0;
+        for (int tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                const int ln = (k + 1) % NL;
+                loader_stage(rs, lds0 + (unsigned)((cur_buf ^ 1) * S::BUF), (int)S::off(ln), S::chunks(ln), lane);
+                __builtin_amdgcn_s_waitcnt(wait_vm(0));
+                layer_barrier();
+                cur_buf ^= 1;
+            }
+        }
+        return;
+    }
+    const rsrc_t W32 = make_rsrc(A.packed32, (unsigned)(L32.total * 4));
+    (void)W32;
+    layer_barrier();
+    int cur_buf = 0;                                       // LDS buffer holding the layer about to run
+    for (int tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
+        const int tt = A.t0 + tg * SHW + wv;
+        const bool live = tt < A.t1;                       // a wave past the range runs on the last tile, stores nothing
+        const int t = live ? tt : A.t1 - 1;
+        const rsrc_t RX = make_rsrc(A.X + (size_t)t * D.xrows * 32, D.xrows * 32 * 4);
+        const int xvoff = (h * 8 * 32 + s) * 4;
+        const int coff = A.crow * 128;
+        bf16x8 B1[KS1];
+#pragma unroll
+        for (int j = 0; j < KS1; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = 16 * j + 8 * h + i;
+                B1[j][i] = (__bf16)bload1(RX, xvoff + (row < D.cw ? coff : 0), (16 * j + i) * 128);
+            }
+        const bool save = A.save && live;
+        f32x16 cur[HT];
+        zero_tiles<HT>(cur);
+        lds_layer16<KS1, HT>(wl + (NL == 2 ? 0 : cur_buf * S::BUF), [&](int j) { return B1[j]; }, cur, lane);
+        lds_bias_add<HT>(bias_l, cur, lane);
+        relu_tiles<HT>(cur);
+        if (save) {
+            store_tiles_bf16<HT>(make_rsrc(A.H[0] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
+            store_relu_mask<HT>(make_rsrc(A.M[0] + (size_t)t * (MBYTES / 4), MBYTES), cur, lane);
+        }
+        if (NL != 2) { layer_barrier(); cur_buf ^= 1; }
+#pragma unroll
+        for (int l = 1; l < NHID; ++l) {
+            f32x16 nxt[HT];
+            zero_tiles<HT>(nxt);
+            lds_layer16<2 * HT, HT>(wl + cur_buf * S::BUF, [&](int j) { return acc_to_b(cur[j >> 1], j & 1); }, nxt, lane);
+            lds_bias_add<HT>(bias_l + l * S::BIAS_FLOATS, nxt, lane);
+            relu_tiles<HT>(nxt);
+            if (save) {
+                store_tiles_bf16<HT>(make_rsrc(A.H[l] + (size_t)t * (HBYTES / 4), HBYTES), nxt, lane);
+                store_relu_mask<HT>(make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), nxt, lane);
+            }
+#pragma unroll
+            for (int it = 0; it < HT; ++it) cur[it] = nxt[it];
+            layer_barrier();
+            cur_buf ^= 1;
+        }
+        f32x16 out[1];
+        zero_tiles<1>(out);
+        lds_layer16<2 * HT, 1>(wl + (NL == 2 ? S::BUF : cur_buf * S::BUF), [&](int j) { return acc_to_b(cur[j >> 1], j & 1); },
+                               out, lane);
+        lds_bias_add<1>(bias_l + NHID * S::BIAS_FLOATS, out, lane);
+        const rsrc_t RZ = make_rsrc(A.zout + (size_t)t * D.zrows * 32, live ? D.zrows * 32 * 4 : 0);
+        const int zvoff = (D.zrows == 8) ? (4 * h * 32 + s) * 4 : ((h ? D.zrows : 0) * 32 + s) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bstore1(RZ, (D.zrows == 8 || r < 3) ? out[0][r] : 0.f, zvoff, r * 128);
+        if (NL != 2) { layer_barrier(); cur_buf ^= 1; }
+    }
+}
+
 struct Dgrad16Args {
     const __bf16 *packed16;
     const float *dz;
@@ -273,6 +476,19 @@ bool crow_ok(int kind, int crow)
     return kind == ESR_MLP_COARSE ? (crow == 0 || crow == 12) : (crow == 0 || crow == 88 || crow == 96);
 }
 
+// one workgroup (7 compute waves + loader) per CU, persistent over tile groups; > 64 KB of LDS needs the opt-in
+template <int KIND>
+int launch_fwd16s(const Fwd16Args &A, hipStream_t s)
+{
+    using S = Shared16<KIND, false>;
+    static std::atomic<uint64_t> optin{0};
+    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_fwd16s_kernel<KIND>), S::LDS_BYTES, optin)) return rc;
+    const int groups = (A.t1 - A.t0 + SHW - 1) / SHW;
+    mlp_fwd16s_kernel<KIND><<<groups < 256 ? groups : 256, 64 * (SHW + 1), S::LDS_BYTES, s>>>(A);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
 int grid16(int n_tiles)
 {
     int wg = (n_tiles + 3) / 4;
@@ -321,17 +537,14 @@ ESR_API int esr_mlp_fwd_bf16(int kind, const float *packed32, const void *packed
             A.H[l] = H[l]; A.M[l] = M[l];
         }
     }
-    const int grid = grid16(t1 - t0);
     hipStream_t s = esr_stream(stream);
     switch (kind) {
-    case ESR_MLP_RADIANCE: mlp_fwd16_kernel<ESR_MLP_RADIANCE><<<grid, 256, 0, s>>>(A); break;
-    case ESR_MLP_TONEMAP:  mlp_fwd16_kernel<ESR_MLP_TONEMAP><<<grid, 256, 0, s>>>(A); break;
-    case ESR_MLP_BRDF:     mlp_fwd16_kernel<ESR_MLP_BRDF><<<grid, 256, 0, s>>>(A); break;
-    case ESR_MLP_EMIT:     mlp_fwd16_kernel<ESR_MLP_EMIT><<<grid, 256, 0, s>>>(A); break;
-    default:               mlp_fwd16_kernel<ESR_MLP_COARSE><<<grid, 256, 0, s>>>(A); break;
+    case ESR_MLP_RADIANCE: return launch_fwd16s<ESR_MLP_RADIANCE>(A, s);
+    case ESR_MLP_TONEMAP:  return launch_fwd16s<ESR_MLP_TONEMAP>(A, s);
+    case ESR_MLP_BRDF:     return launch_fwd16s<ESR_MLP_BRDF>(A, s);
+    case ESR_MLP_EMIT:     return launch_fwd16s<ESR_MLP_EMIT>(A, s);
+    default:               return launch_fwd16s<ESR_MLP_COARSE>(A, s);
     }
-    ESR_CHECK_LAUNCH();
-    return 0;
 }
 
 ESR_API int esr_mlp_dgrad_bf16(int kind, const void *packed16, const float *dz, int32_t t0, int32_t t1,
