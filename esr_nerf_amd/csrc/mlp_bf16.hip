@@ -18,6 +18,13 @@
 // X, writing the saved H / dZ tiles) and by the L2 -> L1 weight stream, not by the MFMA pipe.
 #include "mlp_common.h"
 
+#include <type_traits>
+
+// in-kernel time stamps for tools/ubench/fwd16_stamps.hip (nothing in the product build)
+#ifndef ESR_STAMP16
+#define ESR_STAMP16(i)
+#endif
+
 namespace {
 
 __host__ __device__ constexpr int kfeat16(int j, int h, int i)
@@ -215,14 +222,13 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd16_kernel(Fwd16Args A)
 // ---- forward / input gradients with the weights SHARED through LDS ----------------------------------------------------
 // mlp_fwd16_kernel above lets every wave stream the whole weight set from L2 for every 32-sample tile, 16 loads ahead at
 // most: 8 MFMAs (256 cycles) of work per L2 round trip (~1.5 k cycles) -- matrix pipe 17-19 % busy, 14 TB/s of L2-to-CU
-// traffic (profiles/r02_p_c2bf16_*).  Here one workgroup per CU = SEVEN compute waves + ONE loader wave owns seven tiles
-// at a time; the loader stages every layer's weights in LDS once for all seven by LDS-DMA (buffer_load ... lds: no staging
-// registers, issued from a wave that has nothing else to do -- see the weight-gradient kernel in mlp.hip) into the buffer
-// the compute waves are NOT reading, one raw s_barrier per layer.  Per layer and tile group: 74 KB from L2 instead of
-// 7 x 74; operands by ds_read_b128 (conflict-free: the LDS image is the packed buffer's [chunk][64 lanes][16 B]); biases
-// from LDS too, so a compute wave has no global load inside a tile group but its X tile.  Same arithmetic, same packed
-// buffers, same saved tiles as the streaming kernels.
-constexpr int SHW = 7;                                      // compute waves (= tiles per group); wave SHW is the loader
+// traffic (profiles/r02_p_c2bf16_*).  Here one workgroup of EIGHT waves per CU (two per SIMD) owns eight tiles at a time and
+// stages every layer's weights in LDS once for all eight: while a layer runs from one LDS buffer, the eight waves copy the
+// NEXT layer's weights into the other (plain 16-B loads in three stages, 12 registers, see StagePlan), one raw s_barrier
+// per layer.  Per layer and tile group: 74 KB from L2 instead of 8 x 74; operands by ds_read_b128 (conflict-free: the LDS
+// image is the packed buffer's [chunk][64 lanes][16 B]); biases from LDS.  Same arithmetic, same packed buffers, same
+// saved tiles as the streaming kernels.
+constexpr int SHW = 8;                                      // waves per workgroup = tiles per group
 
 template <int KIND, bool BWD> struct Shared16 {
     static constexpr NetDesc D = net_desc(KIND);
@@ -243,27 +249,54 @@ template <int KIND, bool BWD> struct Shared16 {
     static constexpr int LDS_BYTES = 2 * BUF + NL * BIAS_FLOATS * 4;
 };
 
-// the loader's part of one layer step: stage `chunks` 1-KB pieces from packed byte offset `off` into LDS at `dst`
-__device__ __forceinline__ void loader_stage(u32x4 rs, unsigned dst, int off, int chunks, int lane)
+// Cooperative copy of the NEXT layer's CH 1-KB chunks into the other LDS buffer, in three stages spread over the current
+// layer's products: thread tid moves the 16-B pieces tid + 512 p.  Each stage's loads are issued a third of a layer
+// (~770 matrix cycles) before their ds_write, 3 x 4 registers.  (An LDS-DMA loader wave instead of this fills 25 GB/s per
+// CU -- 2.9 us per 72-KB layer, more than the layer's matrix time; plain loads spread over all waves do not have that limit.)
+template <int CH>
+struct StagePlan {
+    static constexpr int PIECES = CH * 64;                     // 16-B pieces
+    static constexpr int PASSES = (PIECES + 64 * SHW - 1) / (64 * SHW);
+    static constexpr int PER = (PASSES + 2) / 3;               // passes per stage
+    static_assert(PER <= 3, "stage registers");
+};
+template <int CH, int S>
+__device__ __forceinline__ void stage_load(rsrc_t W, int woff_bytes, int tid, u32x4 (&pre)[3])
 {
-    for (int c = 0; c < chunks; ++c) {
-        // vmcnt is a 6-bit counter: never more than 48 pieces in flight (72 per hidden layer would wrap it -- the
-        // first version did, and a layer's last pieces were read before they had landed)
-        if (c >= 48 && c % 8 == 0) __builtin_amdgcn_s_waitcnt(wait_vm(40));
-        lds_dma16(rs, dst + (unsigned)c * 1024u, off + c * 1024 + lane * 16);
+    using P = StagePlan<CH>;
+#pragma unroll
+    for (int k = 0; k < P::PER; ++k) {
+        const int p = S * P::PER + k;
+        if (p < P::PASSES) pre[k] = __builtin_amdgcn_raw_buffer_load_b128(W, (tid + 64 * SHW * p) * 16, woff_bytes, 0);
+    }
+}
+template <int CH, int S>
+__device__ __forceinline__ void stage_store(unsigned char *dst, int tid, const u32x4 (&pre)[3])
+{
+    using P = StagePlan<CH>;
+#pragma unroll
+    for (int k = 0; k < P::PER; ++k) {
+        const int p = S * P::PER + k;
+        if (p < P::PASSES && (tid + 64 * SHW * p) < P::PIECES)
+            *reinterpret_cast<u32x4 *>(dst + (size_t)(tid + 64 * SHW * p) * 16) = pre[k];
     }
 }
 
-// acc[it] += W[j][it] . B(j), weights read from the LDS image of the packed layer (explicitly double-buffered reads)
-template <int KS, int NT, typename BF>
-__device__ __forceinline__ void lds_layer16(const unsigned char *wsrc, BF bget, f32x16 (&acc)[NT], int lane)
+// acc[it] += W[j][it] . B(j), weights read from the LDS image of the packed layer (explicitly double-buffered reads);
+// interleaved at thirds of the layer: the staging of the NEXT layer's CHN chunks (packed byte offset noff) into `ndst`
+template <int KS, int NT, int CHN, typename BF>
+__device__ __forceinline__ void lds_layer16(const unsigned char *wsrc, BF bget, f32x16 (&acc)[NT], int lane, int tid,
+                                            rsrc_t W, int noff, unsigned char *ndst)
 {
-    constexpr int NTOT = KS * NT, G = 4, NG = (NTOT + G - 1) / G;
+    constexpr int NTOT = KS * NT, G = NTOT >= 12 ? 4 : 2, NG = (NTOT + G - 1) / G;
+    constexpr int G1 = NG / 3, G2 = (2 * NG) / 3;
+    static_assert(CHN == 0 || (G1 >= 1 && G2 > G1 && G2 < NG), "three distinct staging points inside the layer");
     const u32x4 *mine = reinterpret_cast<const u32x4 *>(wsrc) + lane;
-    u32x4 buf[2][G];
+    u32x4 buf[2][G], pre[3];
 #pragma unroll
     for (int i = 0; i < G; ++i)
         if (i < NTOT) buf[0][i] = mine[i * 64];
+    if (CHN > 0) stage_load<CHN, 0>(W, noff, tid, pre);
     bf16x8 b = {};
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -272,6 +305,8 @@ __device__ __forceinline__ void lds_layer16(const unsigned char *wsrc, BF bget, 
             const int n = (g + 1) * G + i;
             if (n < NTOT) buf[(g + 1) & 1][i] = mine[n * 64];
         }
+        if (CHN > 0 && g == G1) { stage_store<CHN, 0>(ndst, tid, pre); stage_load<CHN, 1>(W, noff, tid, pre); }
+        if (CHN > 0 && g == G2) { stage_store<CHN, 1>(ndst, tid, pre); stage_load<CHN, 2>(W, noff, tid, pre); }
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int n = g * G + i;
@@ -283,6 +318,7 @@ __device__ __forceinline__ void lds_layer16(const unsigned char *wsrc, BF bget, 
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (CHN > 0) stage_store<CHN, 2>(ndst, tid, pre);
 }
 // acc += bias (accumulator order, from LDS), AFTER the layer's products.  (Initialising the accumulators with ds_read_b128
 // straight into the MFMA's srcC registers gave wrong values in two registers of the last tile -- rows 11 / 15 / 16 / 20 of
@@ -313,7 +349,7 @@ __device__ __forceinline__ void layer_barrier()
 }
 
 template <int KIND>
-__global__ void __launch_bounds__(64 * (SHW + 1), 1) mlp_fwd16s_kernel(Fwd16Args A)
+__global__ void __launch_bounds__(64 * SHW, 1) mlp_fwd16s_kernel(Fwd16Args A)
 {
     using S = Shared16<KIND, false>;
     constexpr NetDesc D = S::D;
@@ -323,47 +359,34 @@ __global__ void __launch_bounds__(64 * (SHW + 1), 1) mlp_fwd16s_kernel(Fwd16Args
     constexpr Pack16Layout L = S::L;
     constexpr int KS1 = L.ks[0];
     extern __shared__ __attribute__((aligned(16))) unsigned char wl[];          // buffer 0 | buffer 1 | biases
-    typedef __attribute__((address_space(3))) void lds_void;
     float *bias_l = reinterpret_cast<float *>(wl + 2 * S::BUF);
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, s = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntiles = A.t1 - A.t0, ngroups = (ntiles + SHW - 1) / SHW;
     // biases of every layer into LDS (accumulator order, as packed for the fp32 engine)
-    for (int i = tid; i < NL * S::BIAS_FLOATS; i += 64 * (SHW + 1)) {
+    for (int i = tid; i < NL * S::BIAS_FLOATS; i += 64 * SHW) {
         const int l = i / S::BIAS_FLOATS, k = i % S::BIAS_FLOATS;
         bias_l[i] = k < L32.tiles_out[l] * 32 ? A.packed32[L32.off_bf[l] + k] : 0.f;
     }
-    if (wv == SHW) {
-        // ---- loader wave: layer 0 (and, for a two-layer net, layer 1: then nothing moves in the loop) up front; in
-        // the loop, during layer step k of a group, the weights of step k + 1 (mod NL) into the other buffer
-        const u32x4 rs = raw_rsrc(A.packed16, (unsigned)(L.total * 2));
-        const unsigned lds0 = (unsigned)(uintptr_t)(lds_void *)wl;
-        loader_stage(rs, lds0, (int)S::off(0), S::chunks(0), lane);
-        if (NL == 2) loader_stage(rs, lds0 + S::BUF, (int)S::off(1), S::chunks(1), lane);
-        __builtin_amdgcn_s_waitcnt(wait_vm(0));
-        layer_barrier();
-        if (NL == 2) return;
-        int cur_buf = 0;
-        for (int tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
-#pragma unroll
-            for (int k = 0; k < NL; ++k) {
-                const int ln = (k + 1) % NL;
-                loader_stage(rs, lds0 + (unsigned)((cur_buf ^ 1) * S::BUF), (int)S::off(ln), S::chunks(ln), lane);
-                __builtin_amdgcn_s_waitcnt(wait_vm(0));
-                layer_barrier();
-                cur_buf ^= 1;
-            }
+    const rsrc_t W16 = make_rsrc(A.packed16, (unsigned)(L.total * 2));
+    {   // layer 0 into buffer 0 (and, for a two-layer net, layer 1 into buffer 1: then nothing moves in the loop)
+        u32x4 pre[3];
+        stage_load<S::chunks(0), 0>(W16, (int)S::off(0), tid, pre); stage_store<S::chunks(0), 0>(wl, tid, pre);
+        stage_load<S::chunks(0), 1>(W16, (int)S::off(0), tid, pre); stage_store<S::chunks(0), 1>(wl, tid, pre);
+        stage_load<S::chunks(0), 2>(W16, (int)S::off(0), tid, pre); stage_store<S::chunks(0), 2>(wl, tid, pre);
+        if (NL == 2) {
+            stage_load<S::chunks(1), 0>(W16, (int)S::off(1), tid, pre); stage_store<S::chunks(1), 0>(wl + S::BUF, tid, pre);
+            stage_load<S::chunks(1), 1>(W16, (int)S::off(1), tid, pre); stage_store<S::chunks(1), 1>(wl + S::BUF, tid, pre);
+            stage_load<S::chunks(1), 2>(W16, (int)S::off(1), tid, pre); stage_store<S::chunks(1), 2>(wl + S::BUF, tid, pre);
         }
-        return;
     }
-    const rsrc_t W32 = make_rsrc(A.packed32, (unsigned)(L32.total * 4));
-    (void)W32;
     layer_barrier();
     int cur_buf = 0;                                       // LDS buffer holding the layer about to run
     for (int tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
         const int tt = A.t0 + tg * SHW + wv;
         const bool live = tt < A.t1;                       // a wave past the range runs on the last tile, stores nothing
         const int t = live ? tt : A.t1 - 1;
+        ESR_STAMP16(0);
         const rsrc_t RX = make_rsrc(A.X + (size_t)t * D.xrows * 32, D.xrows * 32 * 4);
         const int xvoff = (h * 8 * 32 + s) * 4;
         const int coff = A.crow * 128;
@@ -378,19 +401,25 @@ __global__ void __launch_bounds__(64 * (SHW + 1), 1) mlp_fwd16s_kernel(Fwd16Args
         const bool save = A.save && live;
         f32x16 cur[HT];
         zero_tiles<HT>(cur);
-        lds_layer16<KS1, HT>(wl + (NL == 2 ? 0 : cur_buf * S::BUF), [&](int j) { return B1[j]; }, cur, lane);
+        lds_layer16<KS1, HT, (NL == 2 ? 0 : S::chunks(1))>(wl + (NL == 2 ? 0 : cur_buf * S::BUF), [&](int j) { return B1[j]; }, cur,
+                                                         lane, tid, W16, (int)S::off(1), wl + (cur_buf ^ 1) * S::BUF);
+        ESR_STAMP16(1);
         lds_bias_add<HT>(bias_l, cur, lane);
         relu_tiles<HT>(cur);
         if (save) {
             store_tiles_bf16<HT>(make_rsrc(A.H[0] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
             store_relu_mask<HT>(make_rsrc(A.M[0] + (size_t)t * (MBYTES / 4), MBYTES), cur, lane);
         }
+        ESR_STAMP16(2);
         if (NL != 2) { layer_barrier(); cur_buf ^= 1; }
-#pragma unroll
-        for (int l = 1; l < NHID; ++l) {
+        ESR_STAMP16(3);
+        auto hidden = [&](auto LC) {
+            constexpr int l = decltype(LC)::value;
             f32x16 nxt[HT];
             zero_tiles<HT>(nxt);
-            lds_layer16<2 * HT, HT>(wl + cur_buf * S::BUF, [&](int j) { return acc_to_b(cur[j >> 1], j & 1); }, nxt, lane);
+            lds_layer16<2 * HT, HT, S::chunks(l + 1)>(wl + cur_buf * S::BUF, [&](int j) { return acc_to_b(cur[j >> 1], j & 1); },
+                                                     nxt, lane, tid, W16, (int)S::off(l + 1), wl + (cur_buf ^ 1) * S::BUF);
+            ESR_STAMP16(4 + 3 * (l - 1));
             lds_bias_add<HT>(bias_l + l * S::BIAS_FLOATS, nxt, lane);
             relu_tiles<HT>(nxt);
             if (save) {
@@ -399,19 +428,29 @@ __global__ void __launch_bounds__(64 * (SHW + 1), 1) mlp_fwd16s_kernel(Fwd16Args
             }
 #pragma unroll
             for (int it = 0; it < HT; ++it) cur[it] = nxt[it];
+            ESR_STAMP16(5 + 3 * (l - 1));
             layer_barrier();
             cur_buf ^= 1;
-        }
+            ESR_STAMP16(6 + 3 * (l - 1));
+        };
+        if constexpr (NHID > 1) hidden(std::integral_constant<int, 1>{});
+        if constexpr (NHID > 2) hidden(std::integral_constant<int, 2>{});
+        static_assert(NHID <= 3, "hidden steps are spelled out");
         f32x16 out[1];
         zero_tiles<1>(out);
-        lds_layer16<2 * HT, 1>(wl + (NL == 2 ? S::BUF : cur_buf * S::BUF), [&](int j) { return acc_to_b(cur[j >> 1], j & 1); },
-                               out, lane);
+        // (meanwhile layer 0 of the NEXT tile group is staged: the same weights, only the buffer differs)
+        lds_layer16<2 * HT, 1, (NL == 2 ? 0 : S::chunks(0))>(wl + (NL == 2 ? S::BUF : cur_buf * S::BUF),
+                                                           [&](int j) { return acc_to_b(cur[j >> 1], j & 1); }, out, lane, tid,
+                                                           W16, (int)S::off(0), wl + (cur_buf ^ 1) * S::BUF);
+        ESR_STAMP16(10);
         lds_bias_add<1>(bias_l + NHID * S::BIAS_FLOATS, out, lane);
         const rsrc_t RZ = make_rsrc(A.zout + (size_t)t * D.zrows * 32, live ? D.zrows * 32 * 4 : 0);
         const int zvoff = (D.zrows == 8) ? (4 * h * 32 + s) * 4 : ((h ? D.zrows : 0) * 32 + s) * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) bstore1(RZ, (D.zrows == 8 || r < 3) ? out[0][r] : 0.f, zvoff, r * 128);
+        ESR_STAMP16(11);
         if (NL != 2) { layer_barrier(); cur_buf ^= 1; }
+        ESR_STAMP16(12);
     }
 }
 
@@ -484,7 +523,7 @@ int launch_fwd16s(const Fwd16Args &A, hipStream_t s)
     static std::atomic<uint64_t> optin{0};
     if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_fwd16s_kernel<KIND>), S::LDS_BYTES, optin)) return rc;
     const int groups = (A.t1 - A.t0 + SHW - 1) / SHW;
-    mlp_fwd16s_kernel<KIND><<<groups < 256 ? groups : 256, 64 * (SHW + 1), S::LDS_BYTES, s>>>(A);
+    mlp_fwd16s_kernel<KIND><<<groups < 256 ? groups : 256, 64 * SHW, S::LDS_BYTES, s>>>(A);
     ESR_CHECK_LAUNCH();
     return 0;
 }

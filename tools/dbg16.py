@@ -7,11 +7,12 @@ def rel(a, b):
     a, b = a.float().cpu(), b.float().cpu()
     e = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
     per_tile = ((a - b).abs().flatten(1).max(1).values / b.abs().max()).tolist() if a.dim() == 3 else None
-    print("rel_err", round(e, 5), "per tile", [round(x, 4) for x in per_tile[:12]] if per_tile else None)
+    print("rel_err", round(e, 5), "worst tiles", sorted([(round(x, 4), i) for i, x in enumerate(per_tile)])[-4:] if per_tile else None)
     if a.dim() == 3 and e > 1e-2:
-        d = (a - b).abs()[0]
-        print("  tile0 rows with err:", (d.max(1).values > 1e-2).nonzero().flatten().tolist()[:40])
-        print("  tile0 cols with err:", (d.max(0).values > 1e-2).nonzero().flatten().tolist()[:40])
+        wt = int((a - b).abs().flatten(1).max(1).values.argmax())
+        d = (a - b).abs()[wt] / b.abs().max()
+        print("  worst tile", wt, "rows with err:", (d.max(1).values > 4e-3).nonzero().flatten().tolist()[:40])
+        print("  cols with err:", (d.max(0).values > 4e-3).nonzero().flatten().tolist()[:40])
     return 0.0
 T.rel_err = rel
 import torch as _t
@@ -22,14 +23,5 @@ def _z(*a, **k):
     if len(a) == 3 and a[2] == 32 and k.get('device') == 'cuda': keepH.append(t)
     return t
 _t.zeros = _z
-T.test_mlp_engine_bf16_vs_emulation(int(sys.argv[2]) if len(sys.argv) > 2 else 0, int(sys.argv[1]) if len(sys.argv) > 1 else 5, 0)
+T.test_mlp_engine_bf16_vs_emulation(int(sys.argv[2]) if len(sys.argv) > 2 else 0, int(sys.argv[1]) if len(sys.argv) > 1 else 5, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
 
-H2 = keepH[2].flatten().cpu()
-a = H2[30720 - 2048: 30720 - 2048 + 768]; b = H2[30720 - 1024: 30720 - 1024 + 768]
-print("dump equal:", bool((a == b).all()), "diff idx", (a != b).nonzero().flatten().tolist()[:20])
-print("a[350:380]", [round(float(x), 4) for x in a[350:380]])
-print("b[350:380]", [round(float(x), 4) for x in b[350:380]])
-
-d = H2[30720 - 8192: 30720 - 8192 + 72 * 64].view(72, 64)
-bad = (d != 0).nonzero()
-print("weight mismatches (chunk, lane):", bad.tolist()[:40], "max", float(d.abs().max()))
