@@ -137,6 +137,18 @@ class FineEngine:
     def _s(self):
         return _lib.stream_ptr(self.device)
 
+    # A ray that exceeds scene.max_steps (the march kernel's LDS bound) is skipped by the kernels and reported in the
+    # plan header.  Single process: raise at once.  Data parallel (``defer_overflow``, set by the trainer steps): raising
+    # on one rank would leave the others waiting in the gradient exchange, so the flag is remembered, summed over the
+    # ranks with the loss, and every rank raises together (trainer._check_overflow).
+    defer_overflow = False
+    overflow_seen = False
+
+    def _overflow(self):
+        if not self.defer_overflow:
+            raise RuntimeError("a ray exceeded scene.max_steps; the LDS bound of the march kernel is wrong")
+        self.overflow_seen = True
+
     def _run(self, name, fn, *args):
         """Enqueue one C-ABI call; with timing on, bracket it with HIP events recorded on the
         stream the kernel is launched on (torch's current stream == the `stream` argument)."""
@@ -287,7 +299,7 @@ class FineEngine:
         landed.synchronize()                                        # the one host wait of the step
         n_on, n_off, tiles_on, tiles_all, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
         if overflow:
-            raise RuntimeError("a ray exceeded scene.max_steps; the LDS bound of the march kernel is wrong")
+            self._overflow()
         ctx = FineCtx(scene=scene, n_rays=n, tiles_on=tiles_on, tiles_all=tiles_all,
                       counts=dict(m0=m0, m1=m1, m2=m2, m3=n_on + n_off, n_on=n_on, n_off=n_off),
                       rays_o=rays_o, rays_d=rays_d, viewdirs=viewdirs, off3=rb["off3"], mask_density=mask_density, sdf=sdf)

@@ -232,7 +232,7 @@ class LtsEngine(FineEngine):
             torch.cuda.current_stream(self.device).synchronize()
         n_on, n_off, tiles_on, tiles_all, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
         if overflow:
-            raise RuntimeError("a ray exceeded scene.max_steps; the LDS bound of the march kernel is wrong")
+            self._overflow()
         P.tiles_on, P.tiles_all = tiles_on, tiles_all
         P.counts = dict(m0=m0, m1=m1, m2=m2, m3=n_on + n_off, n_on=n_on, n_off=n_off)
         P.ensure(max(tiles_all, 1))

@@ -89,6 +89,40 @@ def _grid_sync(step, eng):
     return after_grids, works
 
 
+def _reduce_loss_and_overflow(step, eng, loss, works):
+    """Data-parallel end of step: the loss and the march-overflow flag of this rank summed over the ranks in ONE small
+    all-reduce; the flag goes to pinned host memory and is examined at the start of the NEXT step (by then it has landed:
+    no host wait), where every rank raises together."""
+    import torch.distributed as dist
+    lf = torch.cat([loss.reshape(1), torch.full((1,), 1.0 if eng.overflow_seen else 0.0, device=loss.device)])
+    eng.overflow_seen = False
+    w = dist.all_reduce(lf, group=step.pg, async_op=True)
+    works.append(w)
+    return lf
+
+
+def _publish_overflow(step, lf):
+    if getattr(step, "_ovf_host", None) is None:
+        step._ovf_host = torch.zeros(1, pin_memory=lf.is_cuda)
+    step._ovf_host.copy_(lf[1:2], non_blocking=True)
+    step._ovf_event = None
+    if lf.is_cuda:
+        step._ovf_event = torch.cuda.Event()
+        step._ovf_event.record()
+
+
+def _check_overflow(step):
+    ev = getattr(step, "_ovf_event", None)
+    if getattr(step, "_ovf_host", None) is None:
+        return
+    if ev is not None:
+        ev.synchronize()
+    if float(step._ovf_host[0]) > 0:
+        step._ovf_host.zero_()
+        raise RuntimeError("a ray exceeded scene.max_steps on at least one rank in the previous step; the LDS bound of "
+                           "the march kernel is wrong (its rays were skipped)")
+
+
 class FineStep:
     def __init__(self, model, white_bg: bool = True, weight_linear: float = 0.1,
                  weight_entropy_last: float = 0.001, process_group=None):
@@ -147,6 +181,9 @@ class FineStep:
         m.s_val = s_val
         ps = m._mlp_params()
         g = None
+        if self.pg is not None:
+            eng.defer_overflow = True
+            _check_overflow(self)
 
         def prelude():        # independent of the march: runs on the device while the host waits for the plan header
             nonlocal g
@@ -181,9 +218,11 @@ class FineStep:
         eng.backward(ctx, g_last, g_srgb, g_lin, grads, after_grids=after_grids)
         if self.pg is not None:
             works.append(dist.all_reduce(self._flat[self._n_grid:], group=self.pg, async_op=True))
-            works.append(dist.all_reduce(loss, group=self.pg, async_op=True))
+            lf = _reduce_loss_and_overflow(self, eng, loss, works)
             for w in works:
                 w.wait()                  # stream-level wait: the caller's stream sees reduced gradients
+            loss = lf[0:1].reshape(loss.shape)
+            _publish_overflow(self, lf)
             if self._sync is not None:
                 self._sync.verify()       # everything of the step is enqueued: close the brick exchange
         g["off_color.grid"] = g["off_color.grid"].permute(0, 4, 1, 2, 3)     # logical [1,6,X,Y,Z]
@@ -298,6 +337,9 @@ class LtsStep:
         eng = m.engine
         m.s_val = s_val
         ps = m._mlp_params()
+        if self.pg is not None:
+            eng.defer_overflow = True
+            _check_overflow(self)
         from .fine_engine import KIND_RADIANCE as KR, KIND_TONEMAP as KT
         from .lts_engine import KIND_BRDF as KB, KIND_EMIT as KE
         G = None
@@ -366,9 +408,11 @@ class LtsStep:
         eng.lts_backward(ctx, g, grads, after_grids=after_grids)
         if self.pg is not None:
             works.append(dist.all_reduce(self._flat[self._n_grid:], group=self.pg, async_op=True))
-            works.append(dist.all_reduce(loss, group=self.pg, async_op=True))
+            lf = _reduce_loss_and_overflow(self, eng, loss, works)
             for w in works:
                 w.wait()
+            loss = lf[0:1].reshape(loss.shape)
+            _publish_overflow(self, lf)
             if self._sync is not None:
                 self._sync.verify()       # everything of the step is enqueued: close the brick exchange
         for k in ("off_color.grid", "emo_color.grid", "brdf.grid"):

@@ -357,3 +357,19 @@ def test_host_point_draw_equals_numpy_choice():
             b = ours(n, k); rb = np.random.random()
             assert np.array_equal(a, b) and ra == rb, (seed, n, k)
     assert L.esr_host_choice_noreplace(None, None, C.c_int64(3), C.c_int64(5), None) < 0
+
+
+def test_deferred_march_overflow_raises_on_the_next_step():
+    """Data-parallel steps do not raise inside the step when a ray exceeded the march bound (the other ranks would hang in
+    the exchange): the flag is reduced with the loss and every rank raises at the start of its next step."""
+    import types
+    from esr_nerf_amd import trainer
+    step = types.SimpleNamespace()
+    trainer._check_overflow(step)                                   # nothing published yet: no-op
+    lf = torch.tensor([0.25, 0.0])
+    trainer._publish_overflow(step, lf)
+    trainer._check_overflow(step)                                   # flag 0: fine
+    trainer._publish_overflow(step, torch.tensor([0.25, 2.0]))      # two ranks saw an overflow
+    with pytest.raises(RuntimeError, match="max_steps"):
+        trainer._check_overflow(step)
+    trainer._check_overflow(step)                                   # raised once, then cleared
