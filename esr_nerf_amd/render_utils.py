@@ -120,3 +120,17 @@ def segment_coo(src, index, out=None, dim_size=None, reduce="sum"):
         _lib.ptr(src), _lib.ptr(index), C.c_int64(src.shape[0]), C.c_int64(c), _lib.ptr(out),
         C.c_int64(out.shape[0]), _lib.stream_ptr(src.device)), "esr_segment_sum")
     return out
+
+
+# Exported by the reference's extensions but never called from its Python: asking for one of them
+# gets a message instead of a bare AttributeError.
+_REFERENCE_DEAD_OPS = ("infer_t_minmax", "infer_n_samples", "infer_ray_start_dir", "sample_ndc_pts_on_rays",
+                       "sample_bg_pts_on_rays", "maskcache_lookup", "raw2alpha", "raw2alpha_backward",
+                       "raw2alpha_nonuni", "raw2alpha_nonuni_backward", "total_variation_add_grad_new")
+
+
+def __getattr__(name):
+    if name in _REFERENCE_DEAD_OPS:
+        raise NotImplementedError(f"{name}: exported by the reference's CUDA extension but never called from its Python "
+                                  "(app/utils/base/functions.py, module.py); not part of the accelerated path")
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

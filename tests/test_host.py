@@ -373,3 +373,11 @@ def test_deferred_march_overflow_raises_on_the_next_step():
     with pytest.raises(RuntimeError, match="max_steps"):
         trainer._check_overflow(step)
     trainer._check_overflow(step)                                   # raised once, then cleared
+
+
+def test_render_utils_shim_names_dead_reference_ops():
+    from esr_nerf_amd import render_utils
+    with pytest.raises(NotImplementedError, match="never called"):
+        render_utils.maskcache_lookup
+    with pytest.raises(AttributeError):
+        render_utils.no_such_op
