@@ -258,7 +258,8 @@ constexpr int LDS_STRIDE = 36;        // floats per staged row (32 samples + 4 p
 
 // (f32 operands: mlp_wgrad_dma_kernel below.)  MODE 1-3: bf16 operands (v_mfma_f32_32x32x16_bf16, 16 samples per k-step), fp32
 // accumulation -- the weight-gradient kernel of the bf16 configurations, where the saved hidden tiles (H, dZ) are
-// bf16 [row][32] (64-B rows, staged as they are and read from LDS as ready-made 8-element operands) while the
+// bf16 in the row-quad layout of store_tiles_bf16 (the stager turns 64-B pieces back into rows; LDS then holds
+// [row][32] bf16 and a 16-B read IS an 8-sample operand) while the
 // network input X and the output gradient dz are fp32 (rounded on the way from LDS to the operand registers):
 //   1 = output layer (A = dz fp32, B = H bf16), 2 = hidden layer (both bf16), 3 = first layer (A = dZ bf16, B = X fp32).
 template <int MI, int NJ, int WM, int WN, int WK, int MODE>
@@ -271,7 +272,7 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradBa
     constexpr int RAP = WM * MI * 32, RBP = WN * NJ * 32;          // staged rows (padded to tiles)
     constexpr int BUF = (RAP + RBP) * LDS_STRIDE;                  // floats per LDS buffer
     constexpr int STRIDE16 = 20;                                   // floats per staged bf16 row (64 B + 16 B pad)
-    constexpr int LA = RAP * (A16 ? 4 : 8) / NT, LB = RBP * (B16 ? 4 : 8) / NT;   // 16-B loads per thread
+    constexpr int LA = A16 ? 4 : RAP * 8 / NT, LB = B16 ? 4 : RBP * 8 / NT;       // 16-B loads per thread (bf16: one 64-B unit)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, rl = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -294,7 +295,7 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradBa
     // zero): no per-load branches, so the whole step is one basic block and hipcc keeps a COUNTED
     // vmcnt at the commit (with predicated plain loads it fell back to vmcnt(0) and drained the
     // prefetch every iteration).
-    static_assert(LA * NT == RAP * (A16 ? 4 : 8) && LB * NT == RBP * (B16 ? 4 : 8),
+    static_assert((A16 ? RAP <= NT : LA * NT == RAP * 8) && (B16 ? RBP <= NT : LB * NT == RBP * 8),
                   "staging covers the padded tiles exactly");
     // Past the end of the tile range the descriptor gets ZERO records: the loads still issue (so the
     // vmcnt arithmetic is the same on every trip) but touch no memory and return zeros.
@@ -306,29 +307,60 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradBa
                                     live ? (unsigned)W.RA * RBA : 0u);
         const rsrc_t SB = make_rsrc(reinterpret_cast<const char *>(W.B) + (size_t)tc * W.b_tile_rows * RBB,
                                     live ? (unsigned)W.b_tile_rows * RBB : 0u);
+        // bf16 operand (row-quad layout, mlp_common.h: store_tiles_bf16): thread u < rows takes the 64 contiguous bytes
+        // of quad u / 4, samples 8 (u % 4) .. + 7 -- four 16-B pieces of 2 samples x 4 rows each
 #pragma unroll
-        for (int k = 0; k < LA; ++k) ra[k] = bload4(SA, (tid + k * NT) * 16, 0);
+        for (int k = 0; k < LA; ++k) ra[k] = A16 ? bload4(SA, tid * 64 + k * 16, 0) : bload4(SA, (tid + k * NT) * 16, 0);
 #pragma unroll
         for (int k = 0; k < LB; ++k) {
-            const int q = tid + k * NT;                                  // float4 index: row q/8
-            // rows 0-5 of a first layer come from the net's colour group of the X tile
-            const int src = (!B16 && q < W.cw8) ? q + W.crow * 8 : q;
-            rb_[k] = bload4(SB, src * 16, 0);       // (tiles shorter than the staged block read as zero)
+            if (B16) {
+                rb_[k] = bload4(SB, tid * 64 + k * 16, 0);
+            } else {
+                const int q = tid + k * NT;                              // float4 index: row q/8
+                // rows 0-5 of a first layer come from the net's colour group of the X tile
+                const int src = (q < W.cw8) ? q + W.crow * 8 : q;
+                rb_[k] = bload4(SB, src * 16, 0);   // (tiles shorter than the staged block read as zero)
+            }
         }
+    };
+    // 2 samples x 4 rows per piece -> row r of the thread's quad: dword k = {row r of sample 2k, row r of sample 2k + 1}
+    auto quad_rows = [&](float *Lrows, int rows, const float4 *p) {
+        if (tid >= rows) return;                                         // one 64-byte unit per thread, `rows` units per tile
+        const int quad = tid >> 2, blk = tid & 3;                        // LDS rows 4 quad .. + 3, 16-B piece blk of each
+        unsigned w[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned d0 = __float_as_uint(p[k].x), d1 = __float_as_uint(p[k].y);      // sample 2k:     rows 01 | 23
+            const unsigned d2 = __float_as_uint(p[k].z), d3 = __float_as_uint(p[k].w);      // sample 2k + 1: rows 01 | 23
+            w[0][k] = __builtin_amdgcn_perm(d2, d0, 0x05040100u);        // low halves:  row 0
+            w[1][k] = __builtin_amdgcn_perm(d2, d0, 0x07060302u);        // high halves: row 1
+            w[2][k] = __builtin_amdgcn_perm(d3, d1, 0x05040100u);        // row 2
+            w[3][k] = __builtin_amdgcn_perm(d3, d1, 0x07060302u);        // row 3
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float4 *>(Lrows + (4 * quad + r) * STRIDE16 + blk * 4) =
+                make_float4(__uint_as_float(w[r][0]), __uint_as_float(w[r][1]), __uint_as_float(w[r][2]), __uint_as_float(w[r][3]));
     };
     auto commit = [&](int buf, const float4 (&ra)[LA], const float4 (&rb_)[LB]) {
         float *La = lds + buf * BUF, *Lb = La + RAP * (A16 ? STRIDE16 : LDS_STRIDE);
+        if (A16) {
+            quad_rows(La, RAP, ra);
+        } else {
 #pragma unroll
-        for (int k = 0; k < LA; ++k) {
-            const int q = tid + k * NT;
-            if (A16) *reinterpret_cast<float4 *>(La + (q >> 2) * STRIDE16 + (q & 3) * 4) = ra[k];
-            else *reinterpret_cast<float4 *>(La + (q >> 3) * LDS_STRIDE + (q & 7) * 4) = ra[k];
+            for (int k = 0; k < LA; ++k) {
+                const int q = tid + k * NT;
+                *reinterpret_cast<float4 *>(La + (q >> 3) * LDS_STRIDE + (q & 7) * 4) = ra[k];
+            }
         }
+        if (B16) {
+            quad_rows(Lb, RBP, rb_);
+        } else {
 #pragma unroll
-        for (int k = 0; k < LB; ++k) {
-            const int q = tid + k * NT;
-            if (B16) *reinterpret_cast<float4 *>(Lb + (q >> 2) * STRIDE16 + (q & 3) * 4) = rb_[k];
-            else *reinterpret_cast<float4 *>(Lb + (q >> 3) * LDS_STRIDE + (q & 7) * 4) = rb_[k];
+            for (int k = 0; k < LB; ++k) {
+                const int q = tid + k * NT;
+                *reinterpret_cast<float4 *>(Lb + (q >> 3) * LDS_STRIDE + (q & 7) * 4) = rb_[k];
+            }
         }
     };
     auto compute = [&](int cur) {

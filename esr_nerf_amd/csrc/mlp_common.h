@@ -513,18 +513,27 @@ __device__ __forceinline__ void zero_tiles(f32x16 (&acc)[NT])
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// bf16 tile-major store [row][32 samples] (64 B per row, streaming): what the bf16 engine saves for its backward
+// bf16 saved tiles (H, dZ of the bf16 engine), ROW-QUAD layout: [row / 4][32 samples][4 rows] -- 8 bytes per (quad, sample).
+// Registers 4q .. 4q+3 of an accumulator tile are four CONSECUTIVE rows (acc_row), so a lane stores a tile with 4 eight-byte
+// stores (512 contiguous bytes per wave instruction) instead of 16 two-byte ones: the two-byte form made the bf16 forward /
+// input-gradient kernels store-issue bound (tools/ubench/fwd16_stamps.hip: 6.3 k of a layer step's ~9 k cycles in the
+// epilogue).  The weight-gradient kernel's stager transposes 64-byte pieces back to rows on its way to LDS (mlp.hip).
 template <int NT>
 __device__ __forceinline__ void store_tiles_bf16(rsrc_t T, const f32x16 (&acc)[NT], int lane)
 {
-    const int voff = ((lane >> 5) * 4 * 32 + (lane & 31)) * 2;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const int voff = lane * 8;                             // lane = 32 h + s: quad 2q + h of tile it, sample s
 #pragma unroll
     for (int it = 0; it < NT; ++it)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const __bf16 v = (__bf16)acc[it][r];
-            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), T, voff,
-                                                  (32 * it + (r & 3) + 8 * (r >> 2)) * 64, ESR_NT_AUX);
+        for (int q = 0; q < 4; ++q) {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            bf16x2 lo, hi;
+            lo[0] = (__bf16)acc[it][4 * q + 0]; lo[1] = (__bf16)acc[it][4 * q + 1];
+            hi[0] = (__bf16)acc[it][4 * q + 2]; hi[1] = (__bf16)acc[it][4 * q + 3];
+            u32x2 v;
+            v[0] = __builtin_bit_cast(unsigned, lo); v[1] = __builtin_bit_cast(unsigned, hi);
+            __builtin_amdgcn_raw_buffer_store_b64(v, T, voff, (8 * it + 2 * q) * 256, ESR_NT_AUX);
         }
 }
 
