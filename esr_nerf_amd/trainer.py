@@ -20,6 +20,8 @@ reduced gradient equals the single-process gradient of the full batch.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -62,10 +64,9 @@ def _grid_sync(step, eng):
       this rank's LOCAL gradients only.
     ``ESR_GRAD_SYNC=sparse|dense|shard`` forces one; the default picks sparse for 2-4 ranks (link arithmetic, to be
     replaced by the driver's multi-GPU measurements)."""
-    import os
     import torch.distributed as dist
     works = []
-    mode = os.environ.get("ESR_GRAD_SYNC", "auto")
+    mode = step._sync_mode                    # ESR_GRAD_SYNC, read once when the step object was built
     if getattr(step, "sharded", None) is not None:
         mode = "shard"
     elif mode == "shard":
@@ -134,6 +135,7 @@ class FineStep:
         self._names = None
         self._flat = None
         self._sync = None
+        self._sync_mode = os.environ.get("ESR_GRAD_SYNC", "auto")
 
     # names follow state_dict / named_parameters of the renderer
     def _param_names(self):
@@ -282,6 +284,7 @@ class LtsStep:
         self._names = None
         self._flat = None
         self._sync = None
+        self._sync_mode = os.environ.get("ESR_GRAD_SYNC", "auto")
 
     def _param_names(self):
         if self._names is None:
