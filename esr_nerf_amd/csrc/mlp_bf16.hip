@@ -288,7 +288,7 @@ template <int KS, int NT, int CHN, typename BF>
 __device__ __forceinline__ void lds_layer16(const unsigned char *wsrc, BF bget, f32x16 (&acc)[NT], int lane, int tid,
                                             rsrc_t W, int noff, unsigned char *ndst)
 {
-    constexpr int NTOT = KS * NT, G = NTOT >= 12 ? 4 : 2, NG = (NTOT + G - 1) / G;
+    constexpr int NTOT = KS * NT, G = NTOT >= 12 ? 4 : NTOT >= 6 ? 2 : 1, NG = (NTOT + G - 1) / G;
     constexpr int G1 = NG / 3, G2 = (2 * NG) / 3;
     static_assert(CHN == 0 || (G1 >= 1 && G2 > G1 && G2 < NG), "three distinct staging points inside the layer");
     const u32x4 *mine = reinterpret_cast<const u32x4 *>(wsrc) + lane;
@@ -510,6 +510,95 @@ __global__ void __launch_bounds__(256, 2) mlp_dgrad16_kernel(Dgrad16Args A)
     }
 }
 
+// ---- input gradients with the weights shared through LDS (the forward's scheme, layers in reverse) -------------------
+template <int KIND>
+__global__ void __launch_bounds__(64 * SHW, 1) mlp_dgrad16s_kernel(Dgrad16Args A)
+{
+    using S = Shared16<KIND, true>;
+    constexpr NetDesc D = S::D;
+    constexpr int NL = S::NL, NHID = NL - 1, HT = D.hid_tiles;
+    constexpr unsigned HBYTES = HT * 32 * 32 * 2, MBYTES = (HT / 2) * 256;
+    constexpr Pack16Layout L = S::L;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wl[];          // buffer 0 | buffer 1
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, s = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = A.t1 - A.t0, ngroups = (ntiles + SHW - 1) / SHW;
+    const rsrc_t W16 = make_rsrc(A.packed16, (unsigned)(L.total * 2));
+    {   // step 0 (the output layer's transpose) into buffer 0; a two-layer net: its other layer into buffer 1, for good
+        u32x4 pre[3];
+        stage_load<S::chunks(NL - 1), 0>(W16, (int)S::off(NL - 1), tid, pre); stage_store<S::chunks(NL - 1), 0>(wl, tid, pre);
+        stage_load<S::chunks(NL - 1), 1>(W16, (int)S::off(NL - 1), tid, pre); stage_store<S::chunks(NL - 1), 1>(wl, tid, pre);
+        stage_load<S::chunks(NL - 1), 2>(W16, (int)S::off(NL - 1), tid, pre); stage_store<S::chunks(NL - 1), 2>(wl, tid, pre);
+        if (NL == 2) {
+            stage_load<S::chunks(0), 0>(W16, (int)S::off(0), tid, pre); stage_store<S::chunks(0), 0>(wl + S::BUF, tid, pre);
+            stage_load<S::chunks(0), 1>(W16, (int)S::off(0), tid, pre); stage_store<S::chunks(0), 1>(wl + S::BUF, tid, pre);
+            stage_load<S::chunks(0), 2>(W16, (int)S::off(0), tid, pre); stage_store<S::chunks(0), 2>(wl + S::BUF, tid, pre);
+        }
+    }
+    layer_barrier();
+    int cur_buf = 0;
+    for (int tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
+        const int tt = A.t0 + tg * SHW + wv;
+        const bool live = tt < A.t1;                       // a wave past the range runs on the last tile, stores nothing
+        const int t = live ? tt : A.t1 - 1;
+        const rsrc_t RZ = make_rsrc(A.dz + (size_t)t * D.zrows * 32, D.zrows * 32 * 4);
+        bf16x8 B0;                                                           // slot i of half h <-> dz row 8 h + i
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 8 * h + i;
+            B0[i] = (__bf16)((row < D.zrows) ? bload1(RZ, (row * 32 + s) * 4, 0) : 0.f);
+        }
+        unsigned msk[NHID][HT / 2];
+#pragma unroll
+        for (int l = 0; l < NHID; ++l)
+            load_relu_mask<HT>(make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), msk[l], lane);
+        const unsigned hb = live ? HBYTES : 0u;            // zero-record descriptors drop the stores of a wave past the range
+        f32x16 cur[HT];
+        zero_tiles<HT>(cur);
+        lds_layer16<1, HT, (NL == 2 ? 0 : S::chunks(NL - 2))>(wl + (NL == 2 ? 0 : cur_buf * S::BUF), [&](int) { return B0; }, cur, lane,
+                                                            tid, W16, (int)S::off(NL - 2), wl + (cur_buf ^ 1) * S::BUF);
+        apply_relu_mask<HT>(msk[NHID - 1], cur);
+        store_tiles_bf16<HT>(make_rsrc(A.dZ[NHID - 1] + (size_t)t * (HBYTES / 4), hb), cur, lane);
+        if (NL != 2) { layer_barrier(); cur_buf ^= 1; }
+        auto hidden = [&](auto LC) {
+            constexpr int l = decltype(LC)::value;                               // layer l's transpose: dZ[l] -> dZ[l - 1]
+            f32x16 nxt[HT];
+            zero_tiles<HT>(nxt);
+            lds_layer16<2 * HT, HT, S::chunks(l - 1)>(wl + cur_buf * S::BUF, [&](int j) { return acc_to_b(cur[j >> 1], j & 1); },
+                                                     nxt, lane, tid, W16, (int)S::off(l - 1), wl + (cur_buf ^ 1) * S::BUF);
+            apply_relu_mask<HT>(msk[l - 1], nxt);
+            store_tiles_bf16<HT>(make_rsrc(A.dZ[l - 1] + (size_t)t * (HBYTES / 4), hb), nxt, lane);
+#pragma unroll
+            for (int it = 0; it < HT; ++it) cur[it] = nxt[it];
+            layer_barrier();
+            cur_buf ^= 1;
+        };
+        if constexpr (NHID > 2) hidden(std::integral_constant<int, NHID - 1>{});
+        if constexpr (NHID > 1) hidden(std::integral_constant<int, 1>{});
+        static_assert(NHID <= 3, "hidden steps are spelled out");
+        f32x16 dx[2];
+        zero_tiles<2>(dx);
+        // first layer's transpose; meanwhile step 0 of the NEXT tile group is staged
+        lds_layer16<2 * HT, 2, (NL == 2 ? 0 : S::chunks(NL - 1))>(wl + (NL == 2 ? S::BUF : cur_buf * S::BUF),
+                                                                [&](int j) { return acc_to_b(cur[j >> 1], j & 1); }, dx, lane, tid,
+                                                                W16, (int)S::off(NL - 1), wl + (cur_buf ^ 1) * S::BUF);
+        store_tiles<2, false>(make_rsrc(A.dX + (size_t)t * 64 * 32, live ? 64 * 32 * 4 : 0), dx, lane);     // (the scatter reads dX next)
+        if (NL != 2) { layer_barrier(); cur_buf ^= 1; }
+    }
+}
+
+template <int KIND>
+int launch_dgrad16s(const Dgrad16Args &A, hipStream_t s)
+{
+    using S = Shared16<KIND, true>;
+    static std::atomic<uint64_t> optin{0};
+    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_dgrad16s_kernel<KIND>), 2 * S::BUF, optin)) return rc;
+    const int groups = (A.t1 - A.t0 + SHW - 1) / SHW;
+    mlp_dgrad16s_kernel<KIND><<<groups < 256 ? groups : 256, 64 * SHW, 2 * S::BUF, s>>>(A);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
 bool crow_ok(int kind, int crow)
 {
     return kind == ESR_MLP_COARSE ? (crow == 0 || crow == 12) : (crow == 0 || crow == 88 || crow == 96);
@@ -599,15 +688,12 @@ ESR_API int esr_mlp_dgrad_bf16(int kind, const void *packed16, const float *dz, 
         if (!M[l] || !dZ[l]) return ESR_EINVAL;
         A.M[l] = M[l]; A.dZ[l] = dZ[l];
     }
-    const int grid = grid16(t1 - t0);
     hipStream_t s = esr_stream(stream);
     switch (kind) {
-    case ESR_MLP_RADIANCE: mlp_dgrad16_kernel<ESR_MLP_RADIANCE><<<grid, 256, 0, s>>>(A); break;
-    case ESR_MLP_TONEMAP:  mlp_dgrad16_kernel<ESR_MLP_TONEMAP><<<grid, 256, 0, s>>>(A); break;
-    case ESR_MLP_BRDF:     mlp_dgrad16_kernel<ESR_MLP_BRDF><<<grid, 256, 0, s>>>(A); break;
-    case ESR_MLP_EMIT:     mlp_dgrad16_kernel<ESR_MLP_EMIT><<<grid, 256, 0, s>>>(A); break;
-    default:               mlp_dgrad16_kernel<ESR_MLP_COARSE><<<grid, 256, 0, s>>>(A); break;
+    case ESR_MLP_RADIANCE: return launch_dgrad16s<ESR_MLP_RADIANCE>(A, s);
+    case ESR_MLP_TONEMAP:  return launch_dgrad16s<ESR_MLP_TONEMAP>(A, s);
+    case ESR_MLP_BRDF:     return launch_dgrad16s<ESR_MLP_BRDF>(A, s);
+    case ESR_MLP_EMIT:     return launch_dgrad16s<ESR_MLP_EMIT>(A, s);
+    default:               return launch_dgrad16s<ESR_MLP_COARSE>(A, s);
     }
-    ESR_CHECK_LAUNCH();
-    return 0;
 }
