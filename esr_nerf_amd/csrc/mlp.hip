@@ -307,14 +307,16 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradBa
                                     live ? (unsigned)W.RA * RBA : 0u);
         const rsrc_t SB = make_rsrc(reinterpret_cast<const char *>(W.B) + (size_t)tc * W.b_tile_rows * RBB,
                                     live ? (unsigned)W.b_tile_rows * RBB : 0u);
-        // bf16 operand (row-quad layout, mlp_common.h: store_tiles_bf16): thread u < rows takes the 64 contiguous bytes
-        // of quad u / 4, samples 8 (u % 4) .. + 7 -- four 16-B pieces of 2 samples x 4 rows each
+        // bf16 operand (row-quad layout, mlp_common.h: store_tiles_bf16): thread u < rows takes quad u / 4, samples
+        // 8 (u % 4) .. + 7 -- four 16-B pieces of 2 samples x 4 rows each, piece k at + 64 k (so that four neighbouring
+        // threads read a full 64-byte run per load)
 #pragma unroll
-        for (int k = 0; k < LA; ++k) ra[k] = A16 ? bload4(SA, tid * 64 + k * 16, 0) : bload4(SA, (tid + k * NT) * 16, 0);
+        for (int k = 0; k < LA; ++k)
+            ra[k] = A16 ? bload4(SA, (tid >> 2) * 256 + k * 64 + (tid & 3) * 16, 0) : bload4(SA, (tid + k * NT) * 16, 0);
 #pragma unroll
         for (int k = 0; k < LB; ++k) {
             if (B16) {
-                rb_[k] = bload4(SB, tid * 64 + k * 16, 0);
+                rb_[k] = bload4(SB, (tid >> 2) * 256 + k * 64 + (tid & 3) * 16, 0);
             } else {
                 const int q = tid + k * NT;                              // float4 index: row q/8
                 // rows 0-5 of a first layer come from the net's colour group of the X tile

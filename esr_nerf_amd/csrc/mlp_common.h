@@ -513,7 +513,7 @@ __device__ __forceinline__ void zero_tiles(f32x16 (&acc)[NT])
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// bf16 saved tiles (H, dZ of the bf16 engine), ROW-QUAD layout: [row / 4][32 samples][4 rows] -- 8 bytes per (quad, sample).
+// bf16 saved tiles (H, dZ of the bf16 engine), ROW-QUAD layout: [row / 4][32 sample slots][4 rows] -- 8 bytes per (quad, sample).
 // Registers 4q .. 4q+3 of an accumulator tile are four CONSECUTIVE rows (acc_row), so a lane stores a tile with 4 eight-byte
 // stores (512 contiguous bytes per wave instruction) instead of 16 two-byte ones: the two-byte form made the bf16 forward /
 // input-gradient kernels store-issue bound (tools/ubench/fwd16_stamps.hip: 6.3 k of a layer step's ~9 k cycles in the
@@ -522,7 +522,11 @@ template <int NT>
 __device__ __forceinline__ void store_tiles_bf16(rsrc_t T, const f32x16 (&acc)[NT], int lane)
 {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const int voff = lane * 8;                             // lane = 32 h + s: quad 2q + h of tile it, sample s
+    // lane = 32 h + s: quad 2q + h of tile it.  Inside a quad's 256 bytes the 32 sample slots are ordered so that the
+    // weight-gradient stager's four 16-B loads (samples 8m+2k, 8m+2k+1 for k = 0..3 of its 8-sample block m) are each a
+    // full 64-byte run over four neighbouring threads: slot(s) = 8 ((s >> 1) & 3) + 2 (s >> 3) + (s & 1)
+    const int s_ = lane & 31;
+    const int voff = ((lane >> 5) * 32 + 8 * ((s_ >> 1) & 3) + 2 * (s_ >> 3) + (s_ & 1)) * 8;
 #pragma unroll
     for (int it = 0; it < NT; ++it)
 #pragma unroll

@@ -470,8 +470,10 @@ def test_mlp_engine_bf16_vs_emulation(kind, tiles, crow):
     _lib.check(L.esr_mlp_fwd_bf16(kind, _lib.ptr(packed), _lib.ptr(packed16), _lib.ptr(Xd), 0, tiles, _lib.ptr_array(Hd),
                                   _lib.ptr_array(Md), 1, crow, _lib.ptr(zout), s), "fwd16")
     T16 = 2e-3
-    # saved tiles are bf16 in the row-quad layout [row / 4][32 samples][4 rows] (mlp_common.h: store_tiles_bf16)
-    as_bf16 = lambda t: (t.view(-1).view(torch.bfloat16)[: tiles * hid * 32].view(tiles, hid // 4, 32, 4)
+    # saved tiles are bf16 in the row-quad layout [row / 4][32 sample slots][4 rows] (mlp_common.h: store_tiles_bf16)
+    # with the 32 sample slots of a quad ordered slot(s) = 8 ((s >> 1) & 3) + 2 (s >> 3) + (s & 1)
+    slot = torch.tensor([8 * ((s_ >> 1) & 3) + 2 * (s_ >> 3) + (s_ & 1) for s_ in range(32)], device="cuda")
+    as_bf16 = lambda t: (t.view(-1).view(torch.bfloat16)[: tiles * hid * 32].view(tiles, hid // 4, 32, 4)[:, :, slot, :]
                          .permute(0, 1, 3, 2).reshape(tiles, hid, 32).float())
     assert rel_err(zout[:, :nout], tm(z_ref, nout)) < T16
     for a_, b_ in zip(Hd, hs):                 # one bf16 ulp (2^-8) where the two fp32 values straddle a rounding boundary
