@@ -51,6 +51,12 @@ class EsrLtsArgs(C.Structure):
                                           "last2", "mus", "lambdas", "lobes", "emission", "umask")]
 
 
+class EsrLtsGather(C.Structure):          # esr_lts_gather_t
+    _fields_ = [(n, C.c_void_p) for n in ("jp", "ray64", "pts_all", "eg", "rec_sdf", "viewdirs", "brdf_a", "emit_a",
+                                          "umask_rays")] + [("n_pts", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("pts2", "vd2", "sdf2", "normal", "base", "rough", "metal", "emis", "umask")]
+
+
 class EsrLtsGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("d_off_m", "d_emo_m", "d_last2", "d_base", "d_rough", "d_metal",
                                           "d_emission", "d_mus", "d_lambdas", "d_lobes")]
@@ -80,7 +86,8 @@ EXPORTS = [
     "esr_mlp_wgrad_scratch_floats",
     "esr_fine_tone_in_fwd", "esr_fine_composite_fwd", "esr_fine_composite_bwd",
     "esr_fine_tone_in_bwd", "esr_fine_loss_fwd_bwd",
-    "esr_expgrad_fwd", "esr_expgrad_bwd", "esr_lts_dirs", "esr_lts_combine_fwd", "esr_lts_combine_bwd",
+    "esr_expgrad_fwd", "esr_expgrad_bwd", "esr_lts_dirs", "esr_lts_ref_order", "esr_lts_perturb", "esr_lts_gather_rows",
+    "esr_lts_gather_points", "esr_lts_combine_fwd", "esr_lts_combine_bwd",
     "esr_act_fwd", "esr_act_bwd", "esr_composite3_fwd", "esr_composite3_bwd", "esr_lts_tone_in_bwd",
     "esr_sample_points", "esr_pair_loss_fwd_bwd", "esr_emit_edit",
     "esr_gauss3d_fwd", "esr_gauss3d_bwd", "esr_central_grad_fwd", "esr_central_grad_bwd",

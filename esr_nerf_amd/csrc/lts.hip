@@ -137,6 +137,99 @@ __global__ void __launch_bounds__(256) lts_dirs_kernel(const float *__restrict__
     }
 }
 
+// ---- glue of the light-transport step, fused ---------------------------------------------------------------------------
+// The reference runs these lines as ~60 small torch ops (gathers, cats, index_put); as that many launches they were
+// host-bound here: ~15 us of enqueue each against ~5 us on the device (tools/trace_step.py: 0.46 ms per C4 step in two
+// runs of 27 and 32 sub-15-us kernels).  Four kernels instead.
+
+// compact (tile-order) slot j of a surviving sample -> its position in the reference's ray-sorted order:
+// perm[pos] = j with pos = (samples of earlier rays) + (j - first slot of its ray); also the int64 ray id of every slot
+__global__ void __launch_bounds__(256) lts_ref_order_kernel(const int32_t *__restrict__ rec_ray, const int32_t *__restrict__ cnt3,
+                                                            const int32_t *__restrict__ off3, const int64_t *__restrict__ csum,
+                                                            int n_slots, int64_t *__restrict__ perm, int64_t *__restrict__ ray64)
+{
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_slots; j += gridDim.x * blockDim.x) {
+        const int r = rec_ray[j];
+        ray64[j] = r;
+        if (r >= 0) perm[csum[r] - cnt3[r] + (j - off3[r])] = j;
+    }
+}
+
+// perturbed positions and the scattered normal noise of esrnerf.py:807-830: for the k-th sample in reference order
+//   pts_e[k] = pts_all[perm[k]] + noise_emit[k] * eps      noise_n[perm[k]] = noise_normal[k]     (noise_n pre-zeroed)
+__global__ void __launch_bounds__(256) lts_perturb_kernel(const float *__restrict__ pts_all, const int64_t *__restrict__ perm,
+                                                          const float *__restrict__ nn, const float *__restrict__ ne, float eps,
+                                                          int m3, float *__restrict__ noise_n, float *__restrict__ pts_e)
+{
+#pragma clang fp contract(off)
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < m3; k += gridDim.x * blockDim.x) {
+        const int64_t j = perm[k];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            noise_n[3 * j + a] = nn[3 * k + a];
+            const float t = ne[3 * k + a] * eps;              // (mul, then add: as the two torch ops round)
+            pts_e[3 * k + a] = pts_all[3 * j + a] + t;
+        }
+    }
+}
+
+// out[k][c] = src(row perm[k] (or k), column c0 + c), c < n_ch.  src is tile-major [tiles][rows][32] (rows > 0) or
+// row-major with `stride` floats per row (rows == 0)
+__global__ void __launch_bounds__(256) lts_gather_rows_kernel(const float *__restrict__ src, int rows, int stride, int c0, int n_ch,
+                                                              const int64_t *__restrict__ perm, int n, float *__restrict__ out)
+{
+    const int64_t total = (int64_t)n * n_ch;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i / n_ch), c = (int)(i - (int64_t)k * n_ch);
+        const int64_t j = perm ? perm[k] : k;
+        out[i] = rows > 0 ? src[((j >> 5) * rows + (c0 + c)) * 32 + (j & 31)] : src[j * stride + c0 + c];
+    }
+}
+
+// everything the light-transport segment needs at its P surface points (esrnerf.py:792-806), one thread per point:
+// pts2 [2P,3] (the point twice), vd2 [2P,3] (rows < P: the camera direction of the point's ray), sdf2 [2P], unit normal
+// (F.normalize of the exact SDF gradient), base colour / roughness / metallic / emission heads, uncertainty mask
+struct LtsGather {
+    const int64_t *jp;                       // compact slot of every point
+    const int64_t *ray64;                    // ray id of every compact slot
+    const float *pts_all, *eg, *rec_sdf;     // [T32,3], [T32,4] (sdf | gradient), [T32]
+    const float *viewdirs;                   // [N,3]
+    const float *brdf_a, *emit_a;            // tile-major heads [T][8][32], [T][4][32]
+    const uint8_t *umask_rays;               // [N] (bool)
+    int n_pts;
+    float *pts2, *vd2, *sdf2, *normal, *base, *rough, *metal, *emis;
+    uint8_t *umask;
+};
+__global__ void __launch_bounds__(256) lts_gather_points_kernel(LtsGather G)
+{
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < G.n_pts; p += gridDim.x * blockDim.x) {
+        const int64_t j = G.jp[p];
+        const int64_t r = G.ray64[j];
+        const int64_t t = j >> 5;
+        const int s = (int)(j & 31);
+        float g[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float x = G.pts_all[3 * j + a];
+            G.pts2[3 * p + a] = x;
+            G.pts2[3 * (G.n_pts + p) + a] = x;
+            G.vd2[3 * p + a] = G.viewdirs[3 * r + a];
+            g[a] = G.eg[4 * j + 1 + a];
+            G.base[3 * p + a] = G.brdf_a[(t * 8 + a) * 32 + s];
+            G.emis[3 * p + a] = G.emit_a[(t * 4 + a) * 32 + s];
+        }
+        const float nrm = fmaxf(sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]), 1e-12f);     // F.normalize eps
+#pragma unroll
+        for (int a = 0; a < 3; ++a) G.normal[3 * p + a] = g[a] / nrm;
+        const float sd = G.rec_sdf[j];
+        G.sdf2[p] = sd;
+        G.sdf2[G.n_pts + p] = sd;
+        G.rough[p] = G.brdf_a[(t * 8 + 3) * 32 + s];
+        G.metal[p] = G.brdf_a[(t * 8 + 4) * 32 + s];
+        G.umask[p] = G.umask_rays[r];
+    }
+}
+
 // ---- emission edit of the re-lighting fine-tune (esrnerf.py:427-441, pbr/functions.py:214-255) --------
 // mode 0: off; 2, 4: intensity scale; 3, 4: hue and saturation replaced (value kept) through the
 // reference's rgb<->hsv pair.  `%` below is torch's remainder (result in [0, divisor)).
@@ -467,6 +560,62 @@ ESR_API int esr_lts_dirs(const float *raw, const float *normal, int32_t n_pts, i
     if (!raw || !normal || !dirs) return ESR_EINVAL;
     lts_dirs_kernel<<<esr_grid_for((int64_t)n_pts * rays_plus_one, 256), 256, 0, esr_stream(stream)>>>(
         raw, normal, n_pts, rays_plus_one, dirs);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_lts_ref_order(const int32_t *rec_ray, const int32_t *cnt3, const int32_t *off3, const int64_t *cnt3_cumsum,
+                              int32_t n_slots, int64_t *perm, int64_t *ray64, void *stream)
+{
+    if (n_slots < 0) return ESR_EINVAL;
+    if (n_slots == 0) return 0;
+    if (!rec_ray || !cnt3 || !off3 || !cnt3_cumsum || !perm || !ray64) return ESR_EINVAL;
+    lts_ref_order_kernel<<<esr_grid_for(n_slots, 256), 256, 0, esr_stream(stream)>>>(rec_ray, cnt3, off3, cnt3_cumsum, n_slots,
+                                                                                    perm, ray64);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_lts_perturb(const float *pts_all, const int64_t *perm, const float *noise_normal, const float *noise_emit,
+                            float emit_eps, int32_t m3, float *noise_n, float *pts_e, void *stream)
+{
+    if (m3 < 0) return ESR_EINVAL;
+    if (m3 == 0) return 0;
+    if (!pts_all || !perm || !noise_normal || !noise_emit || !noise_n || !pts_e) return ESR_EINVAL;
+    lts_perturb_kernel<<<esr_grid_for(m3, 256), 256, 0, esr_stream(stream)>>>(pts_all, perm, noise_normal, noise_emit, emit_eps,
+                                                                              m3, noise_n, pts_e);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_lts_gather_rows(const float *src, int32_t tile_rows, int32_t row_stride, int32_t col0, int32_t n_ch,
+                                const int64_t *perm, int32_t n, float *out, void *stream)
+{
+    if (n < 0 || n_ch < 1 || col0 < 0 || tile_rows < 0 || (tile_rows == 0 && row_stride < col0 + n_ch) ||
+        (tile_rows > 0 && tile_rows < col0 + n_ch))
+        return ESR_EINVAL;
+    if (n == 0) return 0;
+    if (!src || !out) return ESR_EINVAL;
+    lts_gather_rows_kernel<<<esr_grid_for((int64_t)n * n_ch, 256), 256, 0, esr_stream(stream)>>>(src, tile_rows, row_stride, col0,
+                                                                                                n_ch, perm, n, out);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_lts_gather_points(const esr_lts_gather_t *g, void *stream)
+{
+    if (!g || g->n_pts < 0) return ESR_EINVAL;
+    if (g->n_pts == 0) return 0;
+    if (!g->jp || !g->ray64 || !g->pts_all || !g->eg || !g->rec_sdf || !g->viewdirs || !g->brdf_a || !g->emit_a ||
+        !g->umask_rays || !g->pts2 || !g->vd2 || !g->sdf2 || !g->normal || !g->base || !g->rough || !g->metal || !g->emis ||
+        !g->umask)
+        return ESR_EINVAL;
+    LtsGather G;
+    G.jp = g->jp; G.ray64 = g->ray64; G.pts_all = g->pts_all; G.eg = g->eg; G.rec_sdf = g->rec_sdf; G.viewdirs = g->viewdirs;
+    G.brdf_a = g->brdf_a; G.emit_a = g->emit_a; G.umask_rays = g->umask_rays; G.n_pts = g->n_pts;
+    G.pts2 = g->pts2; G.vd2 = g->vd2; G.sdf2 = g->sdf2; G.normal = g->normal; G.base = g->base; G.rough = g->rough;
+    G.metal = g->metal; G.emis = g->emis; G.umask = g->umask;
+    lts_gather_points_kernel<<<esr_grid_for(g->n_pts, 256), 256, 0, esr_stream(stream)>>>(G);
     ESR_CHECK_LAUNCH();
     return 0;
 }

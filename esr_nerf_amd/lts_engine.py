@@ -358,18 +358,25 @@ class LtsEngine(FineEngine):
 
     def _ref_order(self, P0: Pass, cnt3, off3):
         """perm[k] = compact (tile-order) index of the k-th surviving sample in the reference's ray-sorted
-        order; also the int64 ray id of every compact slot."""
+        order; also the int64 ray id of every compact slot (one fused launch after the cumsum)."""
         dev = self.device
-        T, Ton = P0.tiles_all, P0.tiles_on
-        n_on, n_off = P0.counts["n_on"], P0.counts["n_off"]
-        jidx = torch.cat([torch.arange(n_on, device=dev), Ton * 32 + torch.arange(n_off, device=dev)])
-        rec_ray = P0.bufs["rec_ray"][: T * 32].long()
-        ray_j = rec_ray[jidx]
-        ref_off = torch.cumsum(cnt3.long(), 0) - cnt3.long()
-        ref_pos = ref_off[ray_j] + (jidx - off3.long()[ray_j])
-        perm = torch.empty(n_on + n_off, dtype=torch.long, device=dev)
-        perm[ref_pos] = jidx
+        T = P0.tiles_all
+        m3 = P0.counts["n_on"] + P0.counts["n_off"]
+        csum = torch.cumsum(cnt3, 0, dtype=torch.int64)
+        perm = torch.empty(m3, dtype=torch.long, device=dev)
+        rec_ray = torch.empty(T * 32, dtype=torch.long, device=dev)
+        self._run("lts_ref_order", self.L.esr_lts_ref_order, _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(cnt3), _lib.ptr(off3),
+                  _lib.ptr(csum), T * 32, _lib.ptr(perm), _lib.ptr(rec_ray), self._s())
+        P0.keep += [csum]
         return perm, rec_ray
+
+    def _gather_rows(self, src, tile_rows, stride, col0, n_ch, perm, n):
+        """out[k, c] = src(row perm[k] (or k), column col0 + c): from a tile-major buffer (tile_rows > 0) or a row-major
+        one -- one launch instead of permute-copy + gather + slice-copy."""
+        out = torch.empty(n, n_ch, device=self.device)
+        self._run("lts_gather_rows", self.L.esr_lts_gather_rows, _lib.ptr(src), tile_rows, stride, col0, n_ch,
+                  _lib.ptr(perm), n, _lib.ptr(out), self._s())
+        return out
 
     # ------------------------------------------------------------------ image rendering
     @torch.no_grad()
@@ -686,8 +693,6 @@ class LtsEngine(FineEngine):
         # ---- compact order <-> the reference's ray-sorted order
         perm, rec_ray = self._ref_order(P0, cnt3, off3)
         ctx.perm = perm
-        brdf_rm = P0.rowmajor("brdf.a")            # [T*32, 8]
-        emit_rm = P0.rowmajor("emit.a")            # [T*32, 4]
 
         # ---- random draws in the reference's order (scattering directions, then the two perturbations), then the
         # perturbed re-evaluations BEFORE the light-transport segment: that segment starts with ~45 small gathers whose
@@ -699,7 +704,11 @@ class LtsEngine(FineEngine):
         nn_ = torch.randn(m3, 3, device=dev) if draws is None else draws["noise_normal"].to(dev)
         ne_ = torch.randn(m3, 3, device=dev) if draws is None else draws["noise_emit"].to(dev)
         noise_n = self._z(T * 32, 3, device=dev)
-        noise_n[perm] = nn_
+        pts_e = torch.empty(m3, 3, device=dev)
+        nn_, ne_ = nn_.contiguous(), ne_.contiguous()
+        self._run("lts_perturb", L.esr_lts_perturb, _lib.ptr(pts_all), _lib.ptr(perm), _lib.ptr(nn_), _lib.ptr(ne_),
+                  C.c_float(ctx.eps["emit"]), m3, _lib.ptr(noise_n), _lib.ptr(pts_e), s)
+        P0.keep += [nn_, ne_]
         eg_eps = torch.empty(T * 32, 4, device=dev)
         self._run("expgrad_fwd(eps)", L.esr_expgrad_fwd, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(P0.bufs["rec_ray"]),
                   _lib.ptr(P0.bufs["rec_step"]), None, _lib.ptr(noise_n), C.c_float(ctx.eps["normal"]), _lib.ptr(sdf),
@@ -707,7 +716,6 @@ class LtsEngine(FineEngine):
         ctx.t.update(noise_n=noise_n)
         # emit_eps / brdf_eps: forward only (explicit points in reference order)
         P3 = self.epsp
-        pts_e = (pts_all[perm] + ne_ * ctx.eps["emit"]).contiguous()
         sv = torch.empty(m3, 4, device=dev)
         self._run("expgrad_fwd(pts)", L.esr_expgrad_fwd, sp, None, None, None, None, _lib.ptr(pts_e), None, C.c_float(0.0),
                   _lib.ptr(sdf), m3, 1, _lib.ptr(sv), s)
@@ -721,8 +729,8 @@ class LtsEngine(FineEngine):
         self._net_fwd(P3, "brdf", KIND_BRDF, 96, 0, T3, save=eps_grads)
         self._act(P3, "emit.z", "emit.a", 4, 3, ACT_SOFTPLUS)
         self._act(P3, "brdf.z", "brdf.a", 8, 5, ACT_SIGMOID)
-        emit_eps = P3.rowmajor("emit.a")[:m3, :3].contiguous()
-        brdf_eps = P3.rowmajor("brdf.a")[:m3, :5].contiguous()
+        emit_eps = self._gather_rows(P3.bufs["emit.a"], 4, 0, 0, 3, None, m3)
+        brdf_eps = self._gather_rows(P3.bufs["brdf.a"], 8, 0, 0, 5, None, m3)
 
 
         # ---- light-transport segment
@@ -733,23 +741,29 @@ class LtsEngine(FineEngine):
         ctx.n_pts = Pn
         jp = perm[idx_ref]
         ctx.jp = jp
-        pts_p = pts_all[jp].contiguous()
-        ray_p = rec_ray[jp]
-        view_p = viewdirs[ray_p].contiguous()
-        normal_p = torch.nn.functional.normalize(eg[jp, 1:4], dim=-1).contiguous()      # detached normals
-        sdf_p = P0.bufs["rec_sdf"][: T * 32][jp].contiguous()
-        base_p, rough_p, metal_p = (brdf_rm[jp, 0:3].contiguous(), brdf_rm[jp, 3].contiguous(),
-                                    brdf_rm[jp, 4].contiguous())
-        emis_p = emit_rm[jp, 0:3].contiguous()
-        umask_p = batch["uncert_masks"][ray_p].to(torch.uint8).contiguous()
+        # everything the segment needs at the points, one launch (pts2 / sdf2: the point twice; vd2: camera direction |
+        # random direction, the second half filled below)
+        pts2, vd2, sdf2 = torch.empty(2 * Pn, 3, device=dev), torch.empty(2 * Pn, 3, device=dev), torch.empty(2 * Pn, device=dev)
+        normal_p, base_p, emis_p = (torch.empty(Pn, 3, device=dev) for _ in range(3))           # (detached normals)
+        rough_p, metal_p = torch.empty(Pn, device=dev), torch.empty(Pn, device=dev)
+        umask_p = torch.empty(Pn, dtype=torch.uint8, device=dev)
+        um_rays = batch["uncert_masks"]
+        if um_rays.dtype not in (torch.bool, torch.uint8):
+            um_rays = um_rays.to(torch.uint8)
+        um_rays = um_rays.contiguous()
+        gp = _lib.EsrLtsGather()
+        gp.n_pts = Pn
+        for k, v in dict(jp=jp, ray64=rec_ray, pts_all=pts_all, eg=eg, rec_sdf=P0.bufs["rec_sdf"], viewdirs=viewdirs,
+                         brdf_a=P0.bufs["brdf.a"], emit_a=P0.bufs["emit.a"], umask_rays=um_rays, pts2=pts2, vd2=vd2, sdf2=sdf2,
+                         normal=normal_p, base=base_p, rough=rough_p, metal=metal_p, emis=emis_p, umask=umask_p).items():
+            setattr(gp, k, v.data_ptr())
+        self._run("lts_gather_points", L.esr_lts_gather_points, C.byref(gp), s)
+        pts_p, view_p, sdf_p = pts2[:Pn], vd2[:Pn], sdf2[:Pn]
         dirs_all = torch.empty(Pn, R + 1, 3, device=dev)
         self._run("lts_dirs", L.esr_lts_dirs, _lib.ptr(raw), _lib.ptr(normal_p), Pn, R + 1, _lib.ptr(dirs_all), s)
-        v_rand = (-dirs_all[:, R]).contiguous()
+        torch.neg(dirs_all[:, R], out=vd2[Pn:])                  # v_rand
         # (a) radiance predicted by the nets at the points, camera direction and random direction
         P1 = self.pts
-        pts2 = torch.cat([pts_p, pts_p]).contiguous()
-        vd2 = torch.cat([view_p, v_rand]).contiguous()
-        sdf2 = torch.cat([sdf_p, sdf_p]).contiguous()
         self._feat_args_points(P1, pts2, vd2, sdf2, sdf, (offg, emog, None))
         self._features(P1, scene)
         T1 = P1.tiles_all
@@ -757,8 +771,8 @@ class LtsEngine(FineEngine):
         self._net_fwd(P1, "emo", KIND_RADIANCE, 88, 0, T1)
         self._act(P1, "off.z", "off.a", 4, 3, ACT_SOFTPLUS)
         self._act(P1, "emo.z", "emo.a", 4, 3, ACT_SOFTPLUS)
-        off_pt = P1.rowmajor("off.a")[: 2 * Pn, :3].contiguous()
-        emo_pt = P1.rowmajor("emo.a")[: 2 * Pn, :3].contiguous()
+        off_pt = self._gather_rows(P1.bufs["off.a"], 4, 0, 0, 3, None, 2 * Pn)
+        emo_pt = self._gather_rows(P1.bufs["emo.a"], 4, 0, 0, 3, None, 2 * Pn)
         # (b) incoming radiance along the secondary rays
         P2 = self.sec
         o2 = pts_p.repeat_interleave(R, 0).contiguous()
@@ -797,9 +811,9 @@ class LtsEngine(FineEngine):
             "etc/alphainv_cum": last, "srgb/rgb": srgb, "lin/rgb": lin_m,
             "lin/pbr/off": off_pt, "lin/pbr/off_hat": off_hat, "lin/pbr/emo": emo_pt, "lin/pbr/emo_hat": emo_hat,
             "emit_marched": emit_m,
-            "etc/normal": eg[perm, 1:4].contiguous(), "etc/normal_eps": eg_eps[perm, 1:4].contiguous(),
-            "etc/emit": emit_rm[perm, :3].contiguous(), "etc/emit_eps": emit_eps,
-            "etc/brdf": brdf_rm[perm, :5].contiguous(), "etc/brdf_eps": brdf_eps,
+            "etc/normal": self._gather_rows(eg, 0, 4, 1, 3, perm, m3), "etc/normal_eps": self._gather_rows(eg_eps, 0, 4, 1, 3, perm, m3),
+            "etc/emit": self._gather_rows(P0.bufs["emit.a"], 4, 0, 0, 3, perm, m3), "etc/emit_eps": emit_eps,
+            "etc/brdf": self._gather_rows(P0.bufs["brdf.a"], 8, 0, 0, 5, perm, m3), "etc/brdf_eps": brdf_eps,
         }
         ctx.t.update(um=um, pts_e=pts_e, eps_grads=eps_grads, m3=m3)
         return ctx, out

@@ -477,6 +477,34 @@ int esr_expgrad_bwd(const esr_scene_t *scene, const float *rays_o, const float *
                     float *grad_sdf, void *stream);
 
 /*
+ * The light-transport step's glue (esrnerf.py:781-830: reference-order bookkeeping, surface-point gathers, perturbed
+ * positions), fused: four launches for what are ~60 small torch ops in the reference.
+ *   esr_lts_ref_order: perm[pos] = j for every compact slot j with rec_ray[j] >= 0, pos = its rank in the reference's
+ *       ray-sorted sample order (cnt3_cumsum = inclusive int64 cumsum of cnt3); ray64[j] = (int64) rec_ray[j].
+ *   esr_lts_perturb:   pts_e[k] = pts_all[perm[k]] + noise_emit[k] * emit_eps,  noise_n[perm[k]] = noise_normal[k]
+ *       (noise_n [n_slots,3] zeroed by the caller).
+ *   esr_lts_gather_rows: out[k][c] = src(row perm[k] -- or k when perm is NULL --, column col0 + c); src tile-major
+ *       [tiles][tile_rows][32] when tile_rows > 0, else row-major with row_stride floats per row.
+ *   esr_lts_gather_points: per surface point (compact slot jp[p]) position / view direction / SDF (each written twice:
+ *       pts2, sdf2 [2P], vd2 rows < P), unit normal, material heads, uncertainty mask.
+ */
+int esr_lts_ref_order(const int32_t *rec_ray, const int32_t *cnt3, const int32_t *off3, const int64_t *cnt3_cumsum,
+                      int32_t n_slots, int64_t *perm, int64_t *ray64, void *stream);
+int esr_lts_perturb(const float *pts_all, const int64_t *perm, const float *noise_normal, const float *noise_emit,
+                    float emit_eps, int32_t m3, float *noise_n, float *pts_e, void *stream);
+int esr_lts_gather_rows(const float *src, int32_t tile_rows, int32_t row_stride, int32_t col0, int32_t n_ch,
+                        const int64_t *perm, int32_t n, float *out, void *stream);
+typedef struct esr_lts_gather {
+    const int64_t *jp, *ray64;
+    const float *pts_all, *eg, *rec_sdf, *viewdirs, *brdf_a, *emit_a;
+    const uint8_t *umask_rays;
+    int32_t n_pts;
+    float *pts2, *vd2, *sdf2, *normal, *base, *rough, *metal, *emis;
+    uint8_t *umask;
+} esr_lts_gather_t;
+int esr_lts_gather_points(const esr_lts_gather_t *g, void *stream);
+
+/*
  * Hemisphere directions -- replaces diffuse_scattering (app/utils/pbr/functions.py:10-18)
  * given the standard-normal draws: normalise, flip into the hemisphere of `normal`.
  * raw, dirs [n_pts, rays_plus_one, 3]; normal [n_pts,3].
