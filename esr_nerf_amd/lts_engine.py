@@ -555,6 +555,8 @@ class LtsEngine(FineEngine):
         T, m3 = P0.tiles_all, P0.counts["m3"]
         if T == 0:
             raise RuntimeError("fine-tune step with no surviving sample (degenerate batch)")
+        # the surface-point draw (a full host-side shuffle of range(m3): 1.5 ms at C5) on the worker thread, collected below
+        point_draw = _PointDraw(m3, min(int(cfg["num_ltspts"]), m3)) if draws is None else None
         sp = C.byref(scene)
         eg = torch.empty(T * 32, 4, device=dev)
         self._run("expgrad_fwd", L.esr_expgrad_fwd, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(P0.bufs["rec_ray"]),
@@ -563,10 +565,7 @@ class LtsEngine(FineEngine):
         self._run("sample_points", L.esr_sample_points, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
                   _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(P0.bufs["rec_step"]), T * 32, _lib.ptr(pts_all), s)
         perm, rec_ray = self._ref_order(P0, cnt3, off3)
-        if draws is None:
-            idx_ref = torch.from_numpy(np.random.choice(m3, min(int(cfg["num_ltspts"]), m3), replace=False)).to(dev)
-        else:
-            idx_ref = draws["idx"].to(dev)
+        idx_ref = (point_draw.result() if draws is None else draws["idx"]).to(dev, non_blocking=True)
         Pn, R = idx_ref.numel(), int(cfg["num_2ndrays"])
         jp = perm[idx_ref]
         ray_p = rec_ray[jp]
