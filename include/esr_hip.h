@@ -376,8 +376,9 @@ int esr_tone_wgrad_recompute(const float *Xt, const float *dzt, const float *W0,
  * bf16 variants of the MLP engine for BASELINE.json's bf16 configurations (a build-side precision choice:
  * the reference is fp32 everywhere): bf16 MFMA OPERANDS (v_mfma_f32_32x32x16_bf16), fp32 accumulation;
  * weights are rounded by esr_mlp_pack_bf16, activations when they become an operand; biases are read from
- * the esr_mlp_pack buffer.  The tiles saved for the backward -- H[l] and dZ[l] -- are bf16 [tiles,hid,32]
- * (half the bytes of the fp32 engine's; they are only read back as bf16 operands by esr_mlp_wgrad_bf16);
+ * the esr_mlp_pack buffer.  The tiles saved for the backward -- H[l] and dZ[l] -- are bf16, hid * 32 values per tile
+ * (half the bytes of the fp32 engine's) in an engine-private order: [row / 4][32 sample slots][4 rows], sample s in
+ * slot 8 ((s >> 1) & 3) + 2 (s >> 3) + (s & 1) -- written 8 bytes per lane, read back only by esr_mlp_wgrad_bf16;
  * X, zout, dz, dX, the masks M and the weight / bias gradients are fp32 with the layouts above, so the
  * feature / shading kernels are shared.  packed16: esr_mlp_packed_bf16_elems(kind) bf16 values.
  */
