@@ -2,11 +2,12 @@
 // BASELINE.json's bf16 configurations (C3, C5; the reference itself is fp32 everywhere).
 //
 // Same networks, same "transposed" chain as mlp.hip (one wave owns 32 samples end to end, the accumulator of
-// layer l is the B operand of layer l+1), with bf16 OPERANDS and fp32 ACCUMULATION: weights are rounded to bf16
+// layer l is the B operand of layer l+1; here eight waves of a workgroup share each layer's weights through LDS, see
+// Shared16 below), with bf16 OPERANDS and fp32 ACCUMULATION: weights are rounded to bf16
 // by esr_mlp_pack_bf16, activations are rounded when they become an MFMA operand (v_cvt_pk_bf16_f32); biases and
 // accumulators are fp32; the tiles saved for the backward (hidden activations H, hidden gradients dZ) are stored as
-// bf16 -- they are only ever read back as bf16 operands of the weight-gradient kernel, and they are most of this
-// engine's HBM traffic; the network inputs X, outputs z / dz and the input gradient dX stay fp32, so the feature and
+// bf16 in a row-quad order (mlp_common.h: store_tiles_bf16) -- they are only ever read back as bf16 operands of the
+// weight-gradient kernel, and they are most of this engine's HBM traffic; the network inputs X, outputs z / dz and the input gradient dX stay fp32, so the feature and
 // shading kernels of the fp32 path are shared unchanged.
 //
 // A 32x32x16 bf16 MFMA takes 8 consecutive k values per lane (k block = lane >> 5).  Accumulator register r
@@ -14,8 +15,9 @@
 // exactly registers 8 jj .. 8 jj + 7 of both halves: k-step j = 2 * tile + jj, slot i of half h <-> feature
 // 32 (j >> 1) + 16 (j & 1) + 4 h + (i & 3) + 8 (i >> 2).  That permutation is folded into the weight packing.
 //
-// Matrix time drops 16x against the f32 cores, so these kernels are bound by the activation traffic (reading
-// X, writing the saved H / dZ tiles) and by the L2 -> L1 weight stream, not by the MFMA pipe.
+// Matrix time drops 16x against the f32 cores, so these kernels are bound by everything else: the epilogues (ReLU, masks,
+// stores of the saved tiles), the X loads and the barriers between layer steps (tools/ubench/fwd16_stamps.hip), not by
+// the MFMA pipe.
 #include "mlp_common.h"
 
 #include <type_traits>
@@ -110,43 +112,6 @@ __device__ __forceinline__ bf16x8 acc_to_b(const f32x16 &t, int jj)
     return b;
 }
 
-// acc[it] += W16[j][it] . B(j) for j < KS, it < NT.  One 16-B-per-lane load per MFMA, streamed G loads ahead.
-template <int KS, int NT, typename BF>
-__device__ __forceinline__ void stream_layer16(rsrc_t W, int woff, BF bget, f32x16 (&acc)[NT], int lane)
-{
-    constexpr int NTOT = KS * NT, G = 8, NG = (NTOT + G - 1) / G;
-    const int voff = lane * 16;
-    u32x4 buf[2][G];
-#pragma unroll
-    for (int i = 0; i < G; ++i)
-        if (i < NTOT) buf[0][i] = __builtin_amdgcn_raw_buffer_load_b128(W, voff, woff + i * 1024, 0);
-    bf16x8 b = {};
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int n = (g + 1) * G + i;
-            if (n < NTOT) buf[(g + 1) & 1][i] = __builtin_amdgcn_raw_buffer_load_b128(W, voff, woff + n * 1024, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int n = g * G + i;
-            if (n < NTOT) {
-                const int j = n / NT, it = n % NT;
-                if (it == 0) b = bget(j);
-                acc[it] = mfma16(__builtin_bit_cast(bf16x8, buf[g & 1][i]), b, acc[it]);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-template <int NP, int NT>
-__device__ __forceinline__ void layer16_from_acc(rsrc_t W, int woff, const f32x16 (&prev)[NP], f32x16 (&acc)[NT], int lane)
-{
-    stream_layer16<2 * NP, NT>(W, woff, [&](int j) { return acc_to_b(prev[j >> 1], j & 1); }, acc, lane);
-}
-
 struct Fwd16Args {
     const float *packed32;     // esr_mlp_pack buffer (biases)
     const __bf16 *packed16;
@@ -158,70 +123,9 @@ struct Fwd16Args {
     float *zout;
 };
 
-template <int KIND>
-__global__ void __launch_bounds__(256, 2) mlp_fwd16_kernel(Fwd16Args A)
-{
-    constexpr NetDesc D = net_desc(KIND);
-    constexpr int NHID = D.n_layers - 1;
-    constexpr int HT = D.hid_tiles;
-    constexpr unsigned HBYTES = HT * 32 * 32 * 2, MBYTES = (HT / 2) * 256;      // saved tiles are bf16
-    constexpr PackLayout L32 = pack_layout(KIND);
-    constexpr Pack16Layout L = pack16_layout(KIND);
-    constexpr int KS1 = L.ks[0];
-    const int lane = esr_lane();
-    const int h = lane >> 5, s = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const rsrc_t W32 = make_rsrc(A.packed32, (unsigned)(L32.total * 4));
-    const rsrc_t W16 = make_rsrc(A.packed16, (unsigned)(L.total * 2));
-    for (int t = A.t0 + wave; t < A.t1; t += nwaves) {
-        const rsrc_t RX = make_rsrc(A.X + (size_t)t * D.xrows * 32, D.xrows * 32 * 4);
-        const int xvoff = (h * 8 * 32 + s) * 4;
-        const int coff = A.crow * 128;
-        bf16x8 B1[KS1];
-#pragma unroll
-        for (int j = 0; j < KS1; ++j)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = 16 * j + 8 * h + i;                 // the net's colour group feeds rows < cw
-                B1[j][i] = (__bf16)bload1(RX, xvoff + (row < D.cw ? coff : 0), (16 * j + i) * 128);
-            }
-        f32x16 cur[HT];
-        load_bias<HT>(W32, (int)L32.off_bf[0] * 4, cur, lane);
-        stream_layer16<KS1, HT>(W16, (int)L.off_wf[0] * 2, [&](int j) { return B1[j]; }, cur, lane);
-        relu_tiles<HT>(cur);
-        if (A.save) {
-            store_tiles_bf16<HT>(make_rsrc(A.H[0] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
-            store_relu_mask<HT>(make_rsrc(A.M[0] + (size_t)t * (MBYTES / 4), MBYTES), cur, lane);
-        }
-#pragma unroll
-        for (int l = 1; l < NHID; ++l) {
-            f32x16 nxt[HT];
-            load_bias<HT>(W32, (int)L32.off_bf[l] * 4, nxt, lane);
-            layer16_from_acc<HT, HT>(W16, (int)L.off_wf[l] * 2, cur, nxt, lane);
-            relu_tiles<HT>(nxt);
-            if (A.save) {
-                store_tiles_bf16<HT>(make_rsrc(A.H[l] + (size_t)t * (HBYTES / 4), HBYTES), nxt, lane);
-                store_relu_mask<HT>(make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), nxt, lane);
-            }
-#pragma unroll
-            for (int it = 0; it < HT; ++it) cur[it] = nxt[it];
-        }
-        f32x16 out[1];
-        load_bias<1>(W32, (int)L32.off_bf[NHID] * 4, out, lane);
-        layer16_from_acc<HT, 1>(W16, (int)L.off_wf[NHID] * 2, cur, out, lane);
-        // output rows through the tile's buffer descriptor (plain global stores retire slowly: esr_common.h); rows
-        // acc_row(r, h) = r + 4 h for r < 4: zrows = 8 takes both halves' rows, zrows = 4 half 0's (row 3 is padding = 0)
-        const rsrc_t RZ = make_rsrc(A.zout + (size_t)t * D.zrows * 32, D.zrows * 32 * 4);
-        const int zvoff = (D.zrows == 8) ? (4 * h * 32 + s) * 4 : ((h ? D.zrows : 0) * 32 + s) * 4;   // h = 1: out of range, dropped
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bstore1(RZ, (D.zrows == 8 || r < 3) ? out[0][r] : 0.f, zvoff, r * 128);
-    }
-}
-
 // ---- forward / input gradients with the weights SHARED through LDS ----------------------------------------------------
-// mlp_fwd16_kernel above lets every wave stream the whole weight set from L2 for every 32-sample tile, 16 loads ahead at
-// most: 8 MFMAs (256 cycles) of work per L2 round trip (~1.5 k cycles) -- matrix pipe 17-19 % busy, 14 TB/s of L2-to-CU
+// The first version of these kernels (one wave = one tile end to end, as in mlp.hip) let every wave stream the whole
+// weight set from L2 for every 32-sample tile, 16 loads ahead at most: 8 MFMAs (256 cycles) of work per L2 round trip (~1.5 k cycles) -- matrix pipe 17-19 % busy, 14 TB/s of L2-to-CU
 // traffic (profiles/r02_p_c2bf16_*).  Here one workgroup of EIGHT waves per CU (two per SIMD) owns eight tiles at a time and
 // stages every layer's weights in LDS once for all eight: while a layer runs from one LDS buffer, the eight waves copy the
 // NEXT layer's weights into the other (plain 16-B loads in three stages, 12 registers, see StagePlan), one raw s_barrier
@@ -463,53 +367,6 @@ struct Dgrad16Args {
     float *dX;
 };
 
-template <int KIND>
-__global__ void __launch_bounds__(256, 2) mlp_dgrad16_kernel(Dgrad16Args A)
-{
-    constexpr NetDesc D = net_desc(KIND);
-    constexpr int NHID = D.n_layers - 1;
-    constexpr int HT = D.hid_tiles;
-    constexpr unsigned HBYTES = HT * 32 * 32 * 2, MBYTES = (HT / 2) * 256;      // dZ tiles are bf16
-    constexpr Pack16Layout L = pack16_layout(KIND);
-    const int lane = esr_lane();
-    const int h = lane >> 5, s = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const rsrc_t W16 = make_rsrc(A.packed16, (unsigned)(L.total * 2));
-    for (int t = A.t0 + wave; t < A.t1; t += nwaves) {
-        const float *dzt = A.dz + (size_t)t * D.zrows * 32 + s;
-        bf16x8 B0;                                                           // slot i of half h <-> dz row 8 h + i
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = 8 * h + i;
-            B0[i] = (__bf16)((row < D.zrows) ? dzt[row * 32] : 0.f);
-        }
-        unsigned msk[NHID][HT / 2];
-#pragma unroll
-        for (int l = 0; l < NHID; ++l)
-            load_relu_mask<HT>(make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), msk[l], lane);
-        f32x16 cur[HT];
-        zero_tiles<HT>(cur);
-        stream_layer16<1, HT>(W16, (int)L.off_wb[NHID] * 2, [&](int) { return B0; }, cur, lane);
-        apply_relu_mask<HT>(msk[NHID - 1], cur);
-        store_tiles_bf16<HT>(make_rsrc(A.dZ[NHID - 1] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
-#pragma unroll
-        for (int l = NHID - 1; l >= 1; --l) {
-            f32x16 nxt[HT];
-            zero_tiles<HT>(nxt);
-            layer16_from_acc<HT, HT>(W16, (int)L.off_wb[l] * 2, cur, nxt, lane);
-            apply_relu_mask<HT>(msk[l - 1], nxt);
-            store_tiles_bf16<HT>(make_rsrc(A.dZ[l - 1] + (size_t)t * (HBYTES / 4), HBYTES), nxt, lane);
-#pragma unroll
-            for (int it = 0; it < HT; ++it) cur[it] = nxt[it];
-        }
-        f32x16 dx[2];
-        zero_tiles<2>(dx);
-        layer16_from_acc<HT, 2>(W16, (int)L.off_wb[0] * 2, cur, dx, lane);
-        store_tiles<2, false>(make_rsrc(A.dX + (size_t)t * 64 * 32, 64 * 32 * 4), dx, lane);      // (the scatter reads dX next)
-    }
-}
-
 // ---- input gradients with the weights shared through LDS (the forward's scheme, layers in reverse) -------------------
 template <int KIND>
 __global__ void __launch_bounds__(64 * SHW, 1) mlp_dgrad16s_kernel(Dgrad16Args A)
@@ -617,12 +474,6 @@ int launch_fwd16s(const Fwd16Args &A, hipStream_t s)
     return 0;
 }
 
-int grid16(int n_tiles)
-{
-    int wg = (n_tiles + 3) / 4;
-    if (wg > 512) wg = 512;
-    return wg < 1 ? 1 : wg;
-}
 
 }  // namespace
 
