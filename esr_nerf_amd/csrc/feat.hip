@@ -117,11 +117,66 @@ __device__ __forceinline__ void tri_scatter6(float *__restrict__ g, const int di
 }
 
 
+// The 8 stencil taps of one axis (+-0.5 .. +-2 voxels, clamped) differ only in their coordinate ALONG the axis: their
+// 8 x 8 corner fetches fall on a few cells along the axis x the same 2 x 2 perpendicular corners.  Those cells are read
+// once into a lane-private LDS strip ("bar", [along 7][perp 4]) and each tap takes its 2 x 4 corners from there with two
+// ds_read_b128 -- 84 gathers (and cell addresses) per sample instead of 192; the taps were 83 of the kernel's 155 us.
+// 7 cells from the base cell of the lowest tap always suffice when no displacement exceeds 2 voxels: clamping is
+// 1-Lipschitz, so the taps span <= 4 voxels (+ a few ulps of the reference's normalise / de-normalise round trip, which
+// is why it is 7 and not 6) and the base cells differ by <= 5.  Other configurations take the direct kernel (BAR = false).
+// The tap's arithmetic is esr_tri_fetch1's, operand for operand (an out-of-grid corner is a stored 0 with weight 0
+// instead of a skipped term), so the features are bit-identical to the direct form.
+constexpr int BAR_ALONG = 7, BAR_STRIDE = 4 * BAR_ALONG;    // 28 floats per lane: 16 lanes' b128 reads on distinct banks
+constexpr float BAR_MAX_DISP = 2.0f;
+
+__device__ __forceinline__ void bar_fill(const float *__restrict__ sdf, const int dims[3], const int i0[3], int axis,
+                                         int b0, float *bar)
+{
+    const int pb = axis == 0 ? 1 : 0, pc = axis == 2 ? 1 : 2;        // the two perpendicular axes, in x,y,z order
+#pragma unroll
+    for (int o = 0; o < BAR_ALONG; ++o)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                int c[3];
+                c[axis] = b0 + o; c[pb] = i0[pb] + cb; c[pc] = i0[pc] + cc;
+                const bool inb = (c[0] >= 0) & (c[0] < dims[0]) & (c[1] >= 0) & (c[1] < dims[1]) & (c[2] >= 0) &
+                                 (c[2] < dims[2]);
+                bar[o * 4 + cb * 2 + cc] = inb ? sdf[((int64_t)c[0] * dims[1] + c[1]) * dims[2] + c[2]] : 0.f;
+            }
+}
+
+__device__ __forceinline__ float bar_fetch1(int axis, int b0, const float *bar, const float idx[3])
+{
+    const Tri t = esr_tri_setup(idx);
+    const int o = t.i0[axis] - b0;                                    // 0 .. 5 (see above)
+    const float4 lo = *reinterpret_cast<const float4 *>(bar + o * 4), hi = *reinterpret_cast<const float4 *>(bar + o * 4 + 4);
+    const float v[2][4] = {{lo.x, lo.y, lo.z, lo.w}, {hi.x, hi.y, hi.z, hi.w}};
+    float acc = 0.f;
+#pragma unroll
+    for (int cx = 0; cx < 2; ++cx)
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+            for (int cz = 0; cz < 2; ++cz) {
+                const int ca = axis == 0 ? cx : axis == 1 ? cy : cz;
+                const int cb = axis == 0 ? cy : cx, cc = axis == 2 ? cy : cz;
+                // explicit fma: the direct form compiles to one per corner; left to the compiler this loop became
+                // packed multiplies + separate adds (1-ulp differences in half the taps)
+                acc = __builtin_fmaf(v[ca][cb * 2 + cc], esr_corner_w(t, idx, cx, cy, cz), acc);
+            }
+    return acc;
+}
+
+template <bool BAR>
 __global__ void __launch_bounds__(256) feat_fwd_kernel(FeatParams P)
 {
     const esr_scene_t &sc = P.sc;
     const int gdims[3] = {sc.gx, sc.gy, sc.gz};
     const int total = P.tiles_all * 32;
+    __shared__ __attribute__((aligned(16))) float bar_lds[256 * BAR_STRIDE];
+    float *bar = bar_lds + threadIdx.x * BAR_STRIDE;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
         const int t = j >> 5, s = j & 31;
         // tile rows through buffer descriptors (see esr_common.h); X(row, v) writes X[t][row][s].
@@ -162,18 +217,30 @@ __global__ void __launch_bounds__(256) feat_fwd_kernel(FeatParams P)
 #pragma unroll
         for (int ar = 0; ar < 3; ++ar) {
             const int axis = 2 - ar;
+            float ixm[4][3], ixp[4][3], cm[4], cp[4];
+            int b0 = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float ixm[3], ixp[3];
-                const float cm = tap_index(ind, gdims, axis, -sc.grad_feat[k], ixm);
-                const float cp = tap_index(ind, gdims, axis, sc.grad_feat[k], ixp);
-                const float fm = esr_tri_fetch1(P.sdf, gdims, ixm);
-                const float fp = esr_tri_fetch1(P.sdf, gdims, ixp);
+                cm[k] = tap_index(ind, gdims, axis, -sc.grad_feat[k], ixm[k]);
+                cp[k] = tap_index(ind, gdims, axis, sc.grad_feat[k], ixp[k]);
+            }
+            if constexpr (BAR) {
+                float low = ixm[0][axis];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) low = fminf(low, ixm[k][axis]);
+                b0 = (int)floorf(low);
+                const Tri t0 = esr_tri_setup(ixm[0]);            // perpendicular base cells: the same for every tap
+                bar_fill(P.sdf, gdims, t0.i0, axis, b0, bar);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float fm = BAR ? bar_fetch1(axis, b0, bar, ixm[k]) : esr_tri_fetch1(P.sdf, gdims, ixm[k]);
+                const float fp = BAR ? bar_fetch1(axis, b0, bar, ixp[k]) : esr_tri_fetch1(P.sdf, gdims, ixp[k]);
                 X(ROW_FEAT + (2 * ar) * 4 + k, fm);
                 X(ROW_FEAT + (2 * ar + 1) * 4 + k, fp);
                 // + 1e-12: the LTS renderer's guard (esrnerf.py:1560) for taps that clamp onto each other
                 // (points pushed outside the box); a no-op in fp32 for in-box samples, where cp - cm >= 0.5
-                grad[ar][k] = (fp - fm) / ((cp - cm) + 1e-12f) / sc.voxel_size;
+                grad[ar][k] = (fp - fm) / ((cp[k] - cm[k]) + 1e-12f) / sc.voxel_size;
             }
         }
 #pragma unroll
@@ -583,7 +650,14 @@ ESR_API int esr_fine_feat_fwd(const esr_scene_t *scene, const esr_feat_args_t *a
     if (c <= 0) return c;
     if (!X || !gnorm) return ESR_EINVAL;
     P.X = X; P.gnorm = gnorm;
-    feat_fwd_kernel<<<esr_grid_for((int64_t)P.tiles_all * 32, 256, 256 * 16), 256, 0, esr_stream(stream)>>>(P);
+    bool bar = true;                                    // every stencil radius within the bar's reach?
+    for (int k = 0; k < 4; ++k) bar = bar && scene->grad_feat[k] >= 0.f && scene->grad_feat[k] <= BAR_MAX_DISP;
+#ifdef ESR_FEAT_DIRECT
+    bar = false;                                        // developer build: the direct form, for bit comparisons
+#endif
+    const int grid = esr_grid_for((int64_t)P.tiles_all * 32, 256, 256 * 16);
+    if (bar) feat_fwd_kernel<true><<<grid, 256, 0, esr_stream(stream)>>>(P);
+    else feat_fwd_kernel<false><<<grid, 256, 0, esr_stream(stream)>>>(P);
     ESR_CHECK_LAUNCH();
     return 0;
 }

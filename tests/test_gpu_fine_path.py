@@ -15,6 +15,7 @@ from conftest import rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+KNIFE = 1e-6      # |hidden pre-activation| below which a ReLU decision is summation-order noise (see the oracle test)
 
 
 # --------------------------------------------------------------------------- helpers
@@ -312,6 +313,22 @@ def test_fused_path_vs_oracle(name, oblique, s_val, n_rays, mask, alpha):
     fp, c, P = oracle_for(m, sc)
     out, loss, grads = run_gpu(m, sc, s_val)
     o_out, o_loss, o_grads, keep = run_oracle(fp, c, P, sc, s_val)
+    # A hidden unit whose pre-activation lies within fp32 summation noise of 0 (~1e-7 here) may take the other ReLU
+    # branch on the GPU: both are correct roundings, but the sample's gradient jumps (one such unit in ~10 k samples
+    # moved emo_color.grid's gradient by 3e-3 when feat_fwd's taps changed by nothing but an fma).  Rays are
+    # independent, so rays holding a sample within KNIFE of a kink are dropped and both sides run again.
+    kr = torch.unique(keep["ray_id"][keep["knife"] < KNIFE])
+    if len(kr):
+        n_all = sc.batch["rays_o"].shape[0]
+        assert len(kr) < 0.2 * n_all, (len(kr), n_all)
+        sel = torch.ones(n_all, dtype=torch.bool)
+        sel[kr] = False
+        sc.batch = {k: v[sel].contiguous() for k, v in sc.batch.items()}
+        out, loss, grads = run_gpu(m, sc, s_val)
+        for v in P.values():
+            v.grad = None
+        o_out, o_loss, o_grads, keep = run_oracle(fp, c, P, sc, s_val)
+        assert not (keep["knife"] < KNIFE).any()
     n0, n1, n2, n3 = keep["counts"]
     lc = m.last_counts
     assert (lc["m0"], lc["m1"], lc["m2"], lc["m3"]) == (n0, n1, n2, n3)
