@@ -429,8 +429,8 @@ def main():
                 by_kernel[kname] = by_kernel.get(kname, 0.0) + breakdown[call][1]
         dominant = max(by_kernel, key=by_kernel.get) if by_kernel else None
         if dominant and a.dtype == "bf16":                     # the bf16 engine's kernel symbols (csrc/mlp_bf16.hip)
-            dominant = dominant.replace("mlp_fwd_kernel", "mlp_fwd16_kernel").replace("mlp_dgrad_kernel", "mlp_dgrad16_kernel")
-    dom_calls = [c for c, k in KERNEL_OF.items() if dominant and k == dominant.replace("16_kernel", "_kernel") and c in breakdown]
+            dominant = dominant.replace("mlp_fwd_kernel", "mlp_fwd16s_kernel").replace("mlp_dgrad_kernel", "mlp_dgrad16s_kernel")
+    dom_calls = [c for c, k in KERNEL_OF.items() if dominant and k == dominant.replace("16s_kernel", "_kernel") and c in breakdown]
     # one launch of that kernel per step is bracketed (each event pair costs ~40-80 us of wall time)
     dom_calls = sorted(dom_calls, key=lambda c: -breakdown[c][1])[:1]
     if not dom_calls and not a.no_kernel_timing and stage == "fine":
