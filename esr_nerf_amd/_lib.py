@@ -127,7 +127,9 @@ def lib() -> C.CDLL:
 def check(code: int, what: str):
     if code != 0:
         raise RuntimeError(f"{what} failed with code {code}" +
-                           (" (hipError)" if code > 0 else " (bad argument)"))
+                           (" (hipError)" if code > 0 else
+                            " (a capacity limit of the kernels is exceeded, include/esr_hip.h: ESR_ECAP)" if code == -2 else
+                            " (bad argument)"))
 
 
 def ptr(t):

@@ -678,6 +678,11 @@ ESR_API int esr_fine_feat_bwd(const esr_scene_t *scene, const esr_feat_args_t *a
         P.src_t0[k] = src[k].t0; P.src_t1[k] = src[k].t1;
     }
     P.dsdf_extra = dsdf_extra; P.dsdf_out = dsdf_out; P.grad_sdf = grad_sdf;
+    // the scatter reduces a sample's stencil onto three 6-cell bars (and sizes its LDS windows for them): radii beyond
+    // 2 voxels would fall off the bars -- refused rather than dropped (the forward has a direct form for any radius)
+    if (grad_sdf)
+        for (int k = 0; k < 4; ++k)
+            if (!(scene->grad_feat[k] >= 0.f && scene->grad_feat[k] <= BAR_MAX_DISP)) return ESR_ECAP;
     // tiles outside every source's range receive no gradient: the launch covers the sources' window only (the fine
     // engine scatters the on-tiles while the off net's input gradients are still being computed)
     P.t_begin = 0; P.t_end = P.tiles_all;

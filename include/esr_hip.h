@@ -261,6 +261,8 @@ int esr_fine_feat_fwd(const esr_scene_t *scene, const esr_feat_args_t *args, flo
  * SDF-value row.  With explicit points the SDF-value gradient is returned in dsdf_out [tiles*32]
  * instead of being scattered.  grad_sdf NULL: the SDF grid is frozen, only the colour grids receive
  * gradients (re-lighting fine-tune).  Scatter = LDS accumulation window + z-contiguous float atomics.
+ * The SDF scatter is built for stencil radii (scene->grad_feat) in [0, 2] voxels, the reference's configuration
+ * (fine.yaml: [0.5, 1.0, 1.5, 2.0]); other radii return ESR_ECAP (esr_fine_feat_fwd takes any radius).
  */
 typedef struct esr_feat_bwd_src {
     const float *dX;

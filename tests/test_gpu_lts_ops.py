@@ -233,6 +233,65 @@ def test_feat_kernels_explicit_points_straddling_the_box():
     assert rel_err(dsdf_out[:n], dXr[:, 6]) < 1e-6
 
 
+def test_feat_fwd_direct_form_for_wide_stencils():
+    """cfg grad_feat radii beyond 2 voxels (voxurff.py:164-167 takes any list): the forward's stencil bars do not reach,
+    the direct form runs (feat.hip: feat_fwd_kernel<false>) -- rows against the oracle's stencil; the scatter, whose bars
+    and LDS windows are sized for radii <= 2, refuses (ESR_ECAP) instead of dropping the outer taps."""
+    import ctypes as C
+    from esr_nerf_amd import _lib
+    from esr_nerf_amd.config import lts_cfg
+    from esr_nerf_amd.fine_engine import make_scene
+    from esr_nerf_amd.synthetic import slab_scene
+    from oracle import fine_path as fp
+    L = _lib.lib()
+    sc = slab_scene("tiny", s_val=40.0)
+    c = fp.make_consts(lts_cfg("cpu").app.model, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max,
+                       sc.mask_alpha_init, sc.mask_density, sc.near, sc.num_voxels)
+    ws = [int(v) for v in c.world_size]
+    g = torch.Generator().manual_seed(9)
+    sdf = torch.randn(1, 1, *ws, generator=g)
+    n = 160
+    lo, hi = sc.xyz_min, sc.xyz_max
+    pts = lo + (hi - lo) * torch.rand(n, 3, generator=g)
+    pts[:40, 2] = lo[2] + (hi[2] - lo[2]) * 0.02 * torch.rand(40, generator=g)       # near a face: the wide taps clamp
+    radii = torch.tensor([0.5, 1.0, 2.5, 3.0])
+    feat, _, nrm = fp.sdf_stencil(c, sdf, pts, radii, diff_eps=1e-12)
+    vox = float(c.voxel_size)
+    tiles = (n + 31) // 32
+    pd, vd, sv = pts.cuda().contiguous(), torch.zeros(n, 3, device="cuda"), torch.zeros(n, device="cuda")
+    sdf_d = sdf[0, 0].contiguous().cuda()
+    fa = _lib.EsrFeatArgs()
+    fa.pts, fa.pt_viewdirs, fa.pt_sdf, fa.n_pts = pd.data_ptr(), vd.data_ptr(), sv.data_ptr(), n
+    fa.sdf = sdf_d.data_ptr()
+    fa.tiles_on, fa.tiles_all = 0, tiles
+    X = torch.empty(tiles * 104 * 32, device="cuda")
+    gn = torch.empty(tiles * 4 * 32, device="cuda")
+    s = _lib.stream_ptr("cuda:0")
+    out = {}
+    for name, rr in (("wide", radii), ("default", torch.tensor([0.5, 1.0, 1.5, 2.0]))):
+        scene = make_scene(lo.tolist(), hi.tolist(), lo.tolist(), hi.tolist(), ws, [32, 32, 32], sc.near,
+                           float(c.stepsize * c.voxel_size), vox, 0.0, 1e-3, 1e-4, 40.0, [float(v) for v in rr])
+        _lib.check(L.esr_fine_feat_fwd(C.byref(scene), C.byref(fa), _lib.ptr(X), _lib.ptr(gn), s), "feat_fwd")
+        out[name] = X.view(tiles, 104, 32).permute(0, 2, 1).reshape(tiles * 32, 104)[:n].cpu().clone()
+        if name == "wide":
+            wide_scene = scene
+    assert rel_err(out["wide"][:, 7:31], feat) < 1e-5
+    assert rel_err(out["wide"][:, 31:43], nrm) < 1e-4
+    # radii 0.5 and 1.0 are in both lists: the bar form (default radii) and the direct form agree bit for bit on them
+    for ar in range(6):
+        for k in (0, 1):
+            assert torch.equal(out["wide"][:, 7 + ar * 4 + k], out["default"][:, 7 + ar * 4 + k])
+    dX = torch.zeros(tiles * 64 * 32, device="cuda")
+    gs = torch.zeros_like(sdf_d)
+    src = (_lib.EsrFeatBwdSrc * 1)()
+    src[0].dX, src[0].t0, src[0].t1 = dX.data_ptr(), 0, tiles
+    rc = L.esr_fine_feat_bwd(C.byref(wide_scene), C.byref(fa), _lib.ptr(X), _lib.ptr(gn), src, 1, None, _lib.ptr(gs),
+                             None, s)
+    assert rc == -2
+    with pytest.raises(RuntimeError, match="capacity"):
+        _lib.check(rc, "feat_bwd")
+
+
 def test_emit_edit_kernel_all_modes():
     """esr_emit_edit against the oracle's restatement of esrnerf.py:427-441 + the reference's hsv pair."""
     from esr_nerf_amd import _lib
