@@ -77,6 +77,9 @@ def parse():
                     help="N > 1: weak = the config's rays PER GPU (default, what the driver runs); strong = the config's "
                          "rays in TOTAL, split over the ranks (SURVEY 8(d) asks for both)")
     ap.add_argument("--s-val", type=float, default=None, help="default 20 (fine.yaml:45) / 220 (lts.yaml:52)")
+    ap.add_argument("--oblique", action="store_true",
+                    help="tilted, un-normalised ray directions (synthetic.slab_scene(oblique=True)): NOT BASELINE's workload "
+                         "(its rays are axis-parallel) -- a robustness line for the kernels that exploit ray coherence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--cpu-iters", type=int, default=3)
@@ -337,7 +340,7 @@ def main():
     per_rank = None
     if a.scaling == "strong" and world > 1:
         per_rank = CONFIGS[a.config]["n_rays"] // world
-    scene = slab_scene(a.config, s_val=a.s_val, seed=rank, n_rays=per_rank)
+    scene = slab_scene(a.config, s_val=a.s_val, seed=rank, n_rays=per_rank, oblique=a.oblique)
     torch.manual_seed(0)
     np.random.seed(0)
     import contextlib
@@ -496,8 +499,8 @@ def main():
         c = CONFIGS[a.config]
         samples = int(round(c["res"] * c["z"] * 2))
         out = {
-            "metric": "training rays/sec at 4096 rays x 128 samples (fine stage)" if (a.config, stage, a.dtype, float(a.s_val)) == ("C2", "fine", "f32", 20.0)
-                      else f"training rays/sec, config {a.config}, {stage} stage, {a.dtype} MLPs, s_val {a.s_val:g}",
+            "metric": "training rays/sec at 4096 rays x 128 samples (fine stage)" if (a.config, stage, a.dtype, float(a.s_val), a.oblique) == ("C2", "fine", "f32", 20.0, False)
+                      else f"training rays/sec, config {a.config}, {stage} stage, {a.dtype} MLPs, s_val {a.s_val:g}" + (", OBLIQUE rays (not BASELINE's workload)" if a.oblique else ""),
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": a.dtype,

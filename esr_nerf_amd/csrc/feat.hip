@@ -380,6 +380,20 @@ __device__ __forceinline__ void winset_phase(WinSet &W, const int dims[3], int b
     }
 }
 
+// does a window's box exceed its LDS share in the SDF phase (margins 2 + 3, 1 channel) or a colour phase (0 + 1, 6)?
+__device__ __forceinline__ bool winset_overflows(const WinSet &W)
+{
+    const int share = WIN_CELLS / (W.nw > 0 ? W.nw : 1);
+    bool over = false;
+#pragma unroll
+    for (int k = 0; k < MAX_WIN; ++k) {
+        if (k >= W.nw) continue;
+        const long long e0 = W.mx[k][0] - W.mn[k][0] + 1, e1 = W.mx[k][1] - W.mn[k][1] + 1, e2 = W.mx[k][2] - W.mn[k][2] + 1;
+        over = over || (e0 + 5) * (e1 + 5) * (e2 + 5) > share || (e0 + 1) * (e1 + 1) * (e2 + 1) * 6 > share;
+    }
+    return over;
+}
+
 __device__ __forceinline__ LaneWin lane_view(const WinSet &W, int wid, lds_cell *lds)
 {
     LaneWin w;
@@ -426,11 +440,16 @@ __device__ __forceinline__ void winset_flush(const WinSet &W, lds_cell *lds, flo
     for (int k = 0; k < MAX_WIN; ++k) {
         const int row = W.wd[k][2] * W.ch;                // floats per (x,y) column, contiguous in memory too
         const int n = W.wd[k][0] * W.wd[k][1] * row;
+        // i / row and xy / wd[1] through the (wave-uniform) reciprocals: gfx950 has no integer divide, the two signed
+        // divisions were ~50 of this loop's ~70 vector instructions.  floor((i + 0.5) * (1 / d)) == i / d for
+        // 0 <= i < 2^21: the product is within 1.2e-7 relative of (i + 0.5) / d, which lies >= 0.5 / d from an integer.
+        static_assert(WIN_CELLS * 6 < (1 << 21), "reciprocal division below is exact for i < 2^21");
+        const float r_row = 1.0f / (float)max(row, 1), r_wy = 1.0f / (float)max(W.wd[k][1], 1);
         for (int i = lane; i < n; i += 64) {
             const float v = (float)lds[W.base[k] + i];
             if (v != 0.f) {
-                const int xy = i / row, r = i - xy * row;
-                const int wx = xy / W.wd[k][1], wy = xy - wx * W.wd[k][1];
+                const int xy = (int)(((float)i + 0.5f) * r_row), r = i - xy * row;
+                const int wx = (int)(((float)xy + 0.5f) * r_wy), wy = xy - wx * W.wd[k][1];
                 atomicAdd(&g[(((int64_t)(W.lo[k][0] + wx) * dims[1] + (W.lo[k][1] + wy)) * dims[2] + W.lo[k][2]) * W.ch + r], v);
             }
         }
@@ -482,7 +501,36 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
             }
         }
         // one accumulation window per ray of the tile (explicit points: a single window)
-        const int wid = winset_init(WS, P.pts ? 0 : (valid ? P.rec_ray[j] : 0), valid, i0c);
+        const int key = P.pts ? 0 : (valid ? P.rec_ray[j] : 0);
+        int wid = winset_init(WS, key, valid, i0c);
+        // A ray piece that runs diagonally through the grid has a bounding box far larger than the cells it touches
+        // (32 samples = 16 voxels of path along (1,1,1): 15^3 SDF cells, 11^3 x 6 colour floats) -- the box was shaved to
+        // its LDS share and the samples outside went to global atomics one tap at a time (secondary rays of the LTS
+        // stage: 65 atomic instructions per tile against 18 for axis-parallel rays).  When a window of the tile does not
+        // fit, its ray piece is cut into consecutive runs of samples with a window each (4 windows per tile as before:
+        // 1 ray -> 4 runs, 2 rays -> 2 + 2, 3 rays -> the longest piece 2): 8 samples span <= 4 voxels, whose box fits.
+        if (!P.pts && WS.nw < MAX_WIN && winset_overflows(WS)) {
+            int newkey = 0;
+            int longest = 0, longest_len = -1;
+            unsigned pieces[MAX_WIN];
+#pragma unroll
+            for (int k = 0; k < MAX_WIN; ++k) {
+                pieces[k] = (unsigned)__ballot(valid && wid == k);           // low half: one bit per sample
+                const int len = __popc(pieces[k]);
+                if (k < WS.nw && len > longest_len) { longest_len = len; longest = k; }
+            }
+#pragma unroll
+            for (int k = 0; k < MAX_WIN; ++k) {
+                if (k >= WS.nw) continue;
+                const int parts = WS.nw == 1 ? 4 : WS.nw == 2 ? 2 : (k == longest ? 2 : 1);
+                const int len = __popc(pieces[k]), first = __ffs(pieces[k]) - 1;
+                const int q = (len + parts - 1) / parts;                        // samples per run (wave-uniform)
+                const int d = s - first;
+                const int part = min(parts - 1, (d >= q) + (d >= 2 * q) + (d >= 3 * q));
+                if (wid == k) newkey = 4 * k + part;
+            }
+            wid = winset_init(WS, newkey, valid, i0c);
+        }
         // ---- phase 1: SDF grid.  The value tap and the 24 stencil taps of a sample touch only three
         // 6x2x2 "bars" of cells (one per axis, sharing the central 2x2x2): the taps of an axis are first
         // reduced in registers onto the 6 cells along that axis, then spread over the 2x2 perpendicular
