@@ -24,6 +24,12 @@ import os
 import sys
 import time
 
+# HIP multiplexes its streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  With an RCCL communicator alive its
+# streams take queues too, and the engine's side stream (weight gradients beside the grid scatters, packing beside the
+# march) landed on the SAME in-order hardware queue as the main stream: everything serialised, +0.12 ms per step
+# (tools/trace_step.py on `bench.py --force-dist`: one queue id for all kernels).  Must be set before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -113,6 +113,11 @@ def _publish_overflow(step, lf):
 
 
 def _check_overflow(step):
+    """Raise (on every rank together) if a rank flagged an overflow in the PREVIOUS step.  Called right after this
+    step's forward has waited for its plan header: the flag's copy was enqueued before that on the same stream, so the
+    event below is already complete.  (Checked at the very start of the step it was a full host wait for the previous
+    step's backward: the host could not run ahead, and every launch up to the plan wait -- march, plan, the prelude's
+    packs and fill -- was exposed: 0.25 ms of GPU idle per step, tools/trace_step.py on `bench.py --force-dist`.)"""
     ev = getattr(step, "_ovf_event", None)
     if getattr(step, "_ovf_host", None) is None:
         return
@@ -185,7 +190,6 @@ class FineStep:
         g = None
         if self.pg is not None:
             eng.defer_overflow = True
-            _check_overflow(self)
 
         def prelude():        # independent of the march: runs on the device while the host waits for the plan header
             nonlocal g
@@ -199,6 +203,8 @@ class FineStep:
             m.mask_cache.density.view(*m.mask_cache.density.shape[2:]),
             m.sdf.device_view(), m.off_color.device_view(), m.emo_color.device_view(), prelude=prelude)
         m.last_counts = ctx.counts
+        if self.pg is not None:
+            _check_overflow(self)         # (after the forward's host wait: see _check_overflow)
         scale, w_ent = dp_loss_weights(last.shape[0], global_rays, entropy_owner, self.weight_entropy_last)
         loss, g_last, g_srgb, g_lin = eng.loss_fwd_bwd(last, srgb, lin, batch["rgbs"], self.white_bg,
                                                        self.weight_linear, w_ent)
@@ -342,7 +348,6 @@ class LtsStep:
         ps = m._mlp_params()
         if self.pg is not None:
             eng.defer_overflow = True
-            _check_overflow(self)
         from .fine_engine import KIND_RADIANCE as KR, KIND_TONEMAP as KT
         from .lts_engine import KIND_BRDF as KB, KIND_EMIT as KE
         G = None
@@ -363,6 +368,8 @@ class LtsStep:
         ctx, out = eng.lts_forward(m.scene_struct(), m.scene_struct(near=m.lts_near), batch, grids, env, cfg, draws,
                                    prelude=prelude)
         m.last_counts = dict(eng.prim.counts)
+        if self.pg is not None:
+            _check_overflow(self)         # (after the forward's host waits: see _check_overflow)
         last = out["etc/alphainv_cum"]
         scale, w_ent = dp_loss_weights(last.shape[0], global_rays, entropy_owner, t.weight_entropy_last)
         loss, g_last, g_srgb, g_lin = eng.loss_fwd_bwd(last, out["srgb/rgb"], out["lin/rgb"], batch["rgbs"],
