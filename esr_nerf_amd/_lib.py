@@ -85,7 +85,7 @@ EXPORTS = [
     "esr_mlp_packed_floats", "esr_mlp_pack", "esr_mlp_fwd", "esr_mlp_fwd_mixed", "esr_mlp_dgrad", "esr_mlp_dgrad_wg", "esr_mlp_wgrad", "esr_mlp_wgrad_batch", "esr_tone_wgrad_scratch_floats", "esr_tone_wgrad_recompute",
     "esr_mlp_wgrad_scratch_floats",
     "esr_fine_tone_in_fwd", "esr_fine_composite_fwd", "esr_fine_composite_bwd",
-    "esr_fine_tone_in_bwd", "esr_fine_loss_fwd_bwd",
+    "esr_fine_tone_in_bwd", "esr_fine_loss_fwd_bwd", "esr_fine_loss_fwd_bwd_dp",
     "esr_expgrad_fwd", "esr_expgrad_bwd", "esr_lts_dirs", "esr_lts_ref_order", "esr_lts_perturb", "esr_lts_gather_rows",
     "esr_lts_gather_points", "esr_lts_combine_fwd", "esr_lts_combine_bwd",
     "esr_act_fwd", "esr_act_bwd", "esr_composite3_fwd", "esr_composite3_bwd", "esr_lts_tone_in_bwd",

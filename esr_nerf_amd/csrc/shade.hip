@@ -170,11 +170,13 @@ __global__ void __launch_bounds__(256) loss_kernel(const float *__restrict__ srg
                                                    const float *__restrict__ lin_m,
                                                    const float *__restrict__ last,
                                                    const float *__restrict__ rgbs, int n_rays, float white_bg,
-                                                   float w_lin, float w_ent, float *__restrict__ loss,
+                                                   float w_lin, float w_ent, float scale, float *__restrict__ loss,
                                                    float *__restrict__ g_srgb, float *__restrict__ g_lin,
                                                    float *__restrict__ g_last)
 {
-    const float inv = 1.f / (3.f * (float)n_rays);
+    // scale: a rank's share n_local / n_global of a data-parallel batch (1: the whole batch) -- applied to every term
+    const float inv = scale == 1.f ? 1.f / (3.f * (float)n_rays) : scale / (3.f * (float)n_rays);
+    w_ent *= scale;
     float acc = 0.f;
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += gridDim.x * blockDim.x) {
         const float al = last[r];
@@ -479,10 +481,10 @@ ESR_API int esr_fine_tone_in_bwd(const float *dXt, const float *g_lin, const flo
     return 0;
 }
 
-ESR_API int esr_fine_loss_fwd_bwd(const float *srgb_marched, const float *lin_marched,
-                                  const float *alphainv_last, const float *rgbs, int32_t n_rays,
-                                  float white_bg, float weight_linear, float weight_entropy_last,
-                                  float *loss, float *g_srgb, float *g_lin, float *g_last, void *stream)
+ESR_API int esr_fine_loss_fwd_bwd_dp(const float *srgb_marched, const float *lin_marched,
+                                     const float *alphainv_last, const float *rgbs, int32_t n_rays,
+                                     float white_bg, float weight_linear, float weight_entropy_last, float scale,
+                                     float *loss, float *g_srgb, float *g_lin, float *g_last, void *stream)
 {
     if (n_rays < 0) return ESR_EINVAL;
     if (n_rays == 0) return 0;
@@ -490,9 +492,18 @@ ESR_API int esr_fine_loss_fwd_bwd(const float *srgb_marched, const float *lin_ma
         return ESR_EINVAL;
     loss_kernel<<<esr_grid_for(n_rays, 256), 256, 0, esr_stream(stream)>>>(
         srgb_marched, lin_marched, alphainv_last, rgbs, n_rays, white_bg, weight_linear,
-        weight_entropy_last, loss, g_srgb, g_lin, g_last);
+        weight_entropy_last, scale, loss, g_srgb, g_lin, g_last);
     ESR_CHECK_LAUNCH();
     return 0;
+}
+
+ESR_API int esr_fine_loss_fwd_bwd(const float *srgb_marched, const float *lin_marched,
+                                  const float *alphainv_last, const float *rgbs, int32_t n_rays,
+                                  float white_bg, float weight_linear, float weight_entropy_last,
+                                  float *loss, float *g_srgb, float *g_lin, float *g_last, void *stream)
+{
+    return esr_fine_loss_fwd_bwd_dp(srgb_marched, lin_marched, alphainv_last, rgbs, n_rays, white_bg, weight_linear,
+                                    weight_entropy_last, 1.f, loss, g_srgb, g_lin, g_last, stream);
 }
 
 ESR_API int esr_eval_aux(const float *X, int32_t xrows, int32_t row_nx, int32_t row_ny, int32_t row_nz,

@@ -268,7 +268,7 @@ class FineEngine:
         last = torch.empty(n, dtype=torch.float32, device=self.device)
         # everything of the step that starts from zero in ONE fill (each small fill is a ~5 us launch on the step's
         # critical path): plan header (8 x i32; what esr_fine_plan_begin does) | srgb | lin | the loss accumulator
-        zb = torch.zeros(8 + 6 * n + 1, dtype=torch.float32, device=self.device)
+        zb = torch.zeros(8 + 6 * n + 2, dtype=torch.float32, device=self.device)     # (+ the overflow flag's slot: loss_pair)
         self.plan_dev = zb[:8].view(torch.int32)
         srgb, lin = zb[8: 8 + 3 * n].view(n, 3), zb[8 + 3 * n: 8 + 6 * n].view(n, 3)
         self._loss_acc = zb[8 + 6 * n:]
@@ -567,16 +567,22 @@ class FineEngine:
         return self._side[i]
 
     # -- fused trainer-step loss (app/fine/fine.py:355-382) ------------------------
-    def loss_fwd_bwd(self, last, srgb, lin, rgbs, white_bg=True, weight_linear=0.1, weight_entropy_last=0.001):
+    def loss_fwd_bwd(self, last, srgb, lin, rgbs, white_bg=True, weight_linear=0.1, weight_entropy_last=0.001,
+                     scale=1.0):
+        """``scale``: multiplies the loss and its gradients inside the kernel (a data-parallel rank's share of the batch)."""
         n = last.shape[0]
         acc = getattr(self, "_loss_acc", None)           # zeroed with the step's other accumulators (forward)
         self._loss_acc = None
-        loss = acc if acc is not None and acc.device == srgb.device else torch.zeros(1, dtype=torch.float32, device=self.device)
+        pair = acc if acc is not None and acc.device == srgb.device else torch.zeros(2, dtype=torch.float32, device=self.device)
+        # [loss, 0]: the data-parallel step all-reduces this pair as it is (second slot: its overflow flag) instead of
+        # building one with a fill and a cat at the end of the step
+        self.loss_pair = pair
+        loss = pair[:1]
         g_srgb = torch.empty_like(srgb)
         g_lin = torch.empty_like(lin)
         g_last = torch.empty_like(last)
-        self._run("loss", self.L.esr_fine_loss_fwd_bwd,
+        self._run("loss", self.L.esr_fine_loss_fwd_bwd_dp,
                   _lib.ptr(srgb), _lib.ptr(lin), _lib.ptr(last), _lib.ptr(rgbs.contiguous()), n,
                   C.c_float(1.0 if white_bg else 0.0), C.c_float(weight_linear), C.c_float(weight_entropy_last),
-                  _lib.ptr(loss), _lib.ptr(g_srgb), _lib.ptr(g_lin), _lib.ptr(g_last), self._s())
+                  C.c_float(scale), _lib.ptr(loss), _lib.ptr(g_srgb), _lib.ptr(g_lin), _lib.ptr(g_last), self._s())
         return loss, g_last, g_srgb, g_lin

@@ -95,7 +95,11 @@ def _reduce_loss_and_overflow(step, eng, loss, works):
     all-reduce; the flag goes to pinned host memory and is examined at the start of the NEXT step (by then it has landed:
     no host wait), where every rank raises together."""
     import torch.distributed as dist
-    lf = torch.cat([loss.reshape(1), torch.full((1,), 1.0 if eng.overflow_seen else 0.0, device=loss.device)])
+    lf = getattr(eng, "loss_pair", None)      # [loss, 0] of this step (fine_engine.loss_fwd_bwd): nothing to build
+    if lf is None or lf.data_ptr() != loss.data_ptr():
+        lf = torch.cat([loss.reshape(1), torch.zeros(1, device=loss.device)])
+    if eng.overflow_seen:
+        lf[1:2].fill_(1.0)
     eng.overflow_seen = False
     w = dist.all_reduce(lf, group=step.pg, async_op=True)
     works.append(w)
@@ -207,9 +211,7 @@ class FineStep:
             _check_overflow(self)         # (after the forward's host wait: see _check_overflow)
         scale, w_ent = dp_loss_weights(last.shape[0], global_rays, entropy_owner, self.weight_entropy_last)
         loss, g_last, g_srgb, g_lin = eng.loss_fwd_bwd(last, srgb, lin, batch["rgbs"], self.white_bg,
-                                                       self.weight_linear, w_ent)
-        if scale != 1.0:
-            loss, g_last, g_srgb, g_lin = loss * scale, g_last * scale, g_srgb * scale, g_lin * scale
+                                                       self.weight_linear, w_ent, scale=scale)      # scaled in the kernel
         names = self._param_names()
         grads = dict(sdf=g["sdf.grid"], off_color=g["off_color.grid"], emo_color=g["emo_color.grid"],
                      off_w=[g[n] for n in names[0:8:2]], off_b=[g[n] for n in names[1:8:2]],
@@ -373,9 +375,7 @@ class LtsStep:
         last = out["etc/alphainv_cum"]
         scale, w_ent = dp_loss_weights(last.shape[0], global_rays, entropy_owner, t.weight_entropy_last)
         loss, g_last, g_srgb, g_lin = eng.loss_fwd_bwd(last, out["srgb/rgb"], out["lin/rgb"], batch["rgbs"],
-                                                       self.white_bg, t.weight_linear, w_ent)
-        if scale != 1.0:
-            loss, g_last, g_srgb, g_lin = loss * scale, g_last * scale, g_srgb * scale, g_lin * scale
+                                                       self.white_bg, t.weight_linear, w_ent, scale=scale)
         g = {"etc/alphainv_cum": g_last, "srgb/rgb": g_srgb, "lin/rgb": g_lin}
         wl = t.weight_lts
         if not pdra:

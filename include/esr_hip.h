@@ -437,6 +437,13 @@ int esr_fine_loss_fwd_bwd(const float *srgb_marched, const float *lin_marched,
                           float white_bg, float weight_linear, float weight_entropy_last,
                           float *loss, float *g_srgb, float *g_lin, float *g_last,
                           void *stream);
+/* The same with every term (loss and gradients) multiplied by `scale`: a rank's share n_local / n_global of a
+ * data-parallel batch, whose mean-reduced terms are means over the GLOBAL batch (no reference counterpart). */
+int esr_fine_loss_fwd_bwd_dp(const float *srgb_marched, const float *lin_marched,
+                             const float *alphainv_last, const float *rgbs, int32_t n_rays,
+                             float white_bg, float weight_linear, float weight_entropy_last, float scale,
+                             float *loss, float *g_srgb, float *g_lin, float *g_last,
+                             void *stream);
 
 /*
  * One mean-reduced two-operand term of the LTS / PDRA trainer losses and its gradients
