@@ -223,13 +223,13 @@ struct WgradArgs {
     int wg0, nwg;                // workgroups [wg0, wg0 + nwg) of the launch work on this job
 };
 
-// One launch can carry up to four JOBS of the same kernel shape (the same layer of the emissive and the non-emissive
+// One launch can carry up to MAX_JOBS jobs of the same kernel shape (the same layer of the emissive and the non-emissive
 // net, both hidden layers of a net, the 3-row output layers of all three nets ...): each job gets a share of the 256
 // workgroups proportional to its tiles.  Why: a weight-gradient launch has a FIXED cost of ~25-35 us whatever its
 // tile count (tools/wgrad_scaling.py: 135 us per 4-layer net) -- the partial dW of every workgroup goes to a slab
 // (256 x 147 KB written, then read by the reduction) and the ring has to fill and drain.  With J jobs per launch each
 // job runs on 256/J workgroups: J times fewer, J times longer launches, and J times less slab traffic per layer.
-constexpr int MAX_JOBS = 4;
+constexpr int MAX_JOBS = 8;
 struct WgradBatch {
     int n;
     WgradArgs job[MAX_JOBS];
