@@ -18,7 +18,9 @@ from esr_nerf_amd.config import fine_cfg
 from esr_nerf_amd.synthetic import init_slab_model, slab_scene
 from oracle import native, ref_import
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+# ESR_GOLDEN_OUT: write somewhere else (tests/test_golden_regen.py regenerates into a scratch directory and diffs)
+OUT = os.environ.get("ESR_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                       "tests", "golden")
 
 CASES = {
     # name: (scene kwargs, s_val)
@@ -155,15 +157,15 @@ def main():
 
     ru.sample_pts_on_rays, ru.alpha2weight, ru.alpha2weight_backward = real_sample, real_a2w, real_a2w_b
     gen_host(ns)
-    gen_lts(ns, "prune", "fib")
     for mask in ("full", "prune"):
-        gen_lts(ns, mask)
+        gen_lts(ns, mask)            # the "full" variant writes lts_g16_params.npz, which every later variant checks
         gen_finetune(ns, mask)
         gen_coarse(ns, mask)
         gen_eval(ns, mask)
         gen_lts_evals(ns, mask)
         gen_coarse_eval(ns, mask)
         gen_lts_eval(ns, mask)
+    gen_lts(ns, "prune", "fib")
 
 
 def gen_host(ns):
