@@ -87,13 +87,18 @@ def parse():
                     help="tilted, un-normalised ray directions (synthetic.slab_scene(oblique=True)): NOT BASELINE's workload "
                          "(its rays are axis-parallel) -- a robustness line for the kernels that exploit ray coherence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=1024)
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-rays", type=int, default=None,
+                    help="rays of the CPU baseline sample (default: the whole batch in the fine stage -- SURVEY 8(d): same N, "
+                         ">= 5 iterations -- and 1024 in the LTS stages, whose CPU step is ~10x longer)")
+    ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
                     help="MLP operand type: f32 (f32 matrix cores, the headline) or bf16 (bf16 operands, fp32 accumulation)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the gradient all-reduces even with one rank (self-test)")
     ap.add_argument("--no-optimizer", action="store_true", help="skip the separately reported fused-Adam timing")
+    ap.add_argument("--no-tv", action="store_true",
+                    help="fine stage: leave the trainer's every-third-iteration TV lines (SURVEY A12, fine.py:383-400) out of "
+                         "the timed steps (they are inside by default: the metric is forward A1-A12 + loss + backward)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not bracket kernels with HIP events (drops the roofline object)")
     return ap.parse_args()
@@ -392,7 +397,17 @@ def main():
         step = LtsStep(model, cfg.app.trainer, stage=stage, process_group=pg, split_points=(a.scaling == "strong"))
     eng = model.engine
 
-    def one():
+    tv_in_step = stage == "fine" and not a.no_tv
+    TVS, W_TV, TV_EVERY = dict(sdf=0.1, smooth_grad=0.05), 0.01, 3        # cfg/app/fine.yaml:73-83
+
+    def one(it=None):
+        """One step; ``it``: iteration number of a timed / warm-up step -- on every TV_EVERY-th the trainer's do_tv
+        lines (fine.py:383-400: smoothed-gradient TV value + gradient, in-place 6-neighbour TV gradient) run too."""
+        if stage == "fine" and tv_in_step and it is not None and it % TV_EVERY == 0:
+            l_, g_ = step.forward_loss_backward(batch, a.s_val, global_rays=n_rays * world if pg is not None else None,
+                                                entropy_owner=(rank == world - 1))[:2]
+            step.add_regularisers(l_, g_, n_rays * world, W_TV, TVS, True)
+            return l_, g_
         if stage == "finetune":
             model.zero_grad(set_to_none=True)
             res = model(**batch)
@@ -428,8 +443,8 @@ def main():
         breakdown = {k: (n, ms) for k, (n, ms) in eng.timing_summary().items()}
         eng.overlap_wgrad = overlap
         eng.enable_timing(False)
-    for _ in range(a.warmup - n_prof - n_lead):
-        one()
+    for i_ in range(a.warmup - n_prof - n_lead):
+        one(i_)
     if n_prof:
         counts = dict(model.last_counts, merged_off_pass=(a.dtype == "f32" and stage == "fine"))
         by_kernel = {}
@@ -452,8 +467,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss, _ = one()
+    for i_ in range(a.steps):
+        loss, _ = one(i_)
     torch.cuda.synchronize()
     if pg is not None:
         dist.barrier()
@@ -490,13 +505,12 @@ def main():
     tv_ms = None
     if not a.no_optimizer and stage == "fine":
         l_tv, g_tv = one()
-        tvs = dict(sdf=0.1, smooth_grad=0.05)
         for _ in range(2):
-            step.add_regularisers(l_tv, g_tv, n_rays * world, 0.01, tvs, True)
+            step.add_regularisers(l_tv, g_tv, n_rays * world, W_TV, TVS, True)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(5):
-            step.add_regularisers(l_tv, g_tv, n_rays * world, 0.01, tvs, True)
+            step.add_regularisers(l_tv, g_tv, n_rays * world, W_TV, TVS, True)
         torch.cuda.synchronize()
         tv_ms = (time.perf_counter() - t1) / 5 * 1e3
 
@@ -514,7 +528,8 @@ def main():
             "config": {
                 "workload": f"{a.config}: giftbox_w {stage} stage on the slab scene, {n_rays} rays x {samples} "
                             f"samples per GPU, grid {'x'.join(str(int(v)) for v in model.world_size.tolist())}, "
-                            f"s_val={a.s_val:g}, forward + trainer loss + backward (no optimizer step)"
+                            f"s_val={a.s_val:g}, forward + trainer loss + backward"
+                            + (" + the TV lines on every third step" if tv_in_step else "") + " (no optimizer step)"
                             + ("" if stage == "fine" else f"; + {getattr(step, 'ltspts', model.num_ltspts)} surface points x {model.num_2ndrays} "
                                f"secondary rays per GPU ({eng.sec.counts.get('m3')} surviving secondary samples)")
                             + ("; fine-tune target: edited emission + its light transport, only emo_color / emo_rgbnet "
@@ -529,8 +544,11 @@ def main():
                                      "hbm_gbs": n_params * 28 / (opt_ms * 1e-3) / 1e9,
                                      "note": "reported separately, not part of value / ms_per_step"}
         if tv_ms is not None:
-            out["tv_terms"] = {"ms": tv_ms, "every": 3, "kernels": "esr_smooth_grad_tv_fwd/bwd + esr_tv_add_grad",
-                               "note": "do_tv lines of the trainer (fine.py:383-400), reported separately"}
+            out["tv_terms"] = {"ms": tv_ms, "every": TV_EVERY, "kernels": "esr_smooth_grad_tv_fwd/bwd + esr_tv_add_grad",
+                               "in_timed_steps": tv_in_step,
+                               "note": "do_tv lines of the trainer (fine.py:383-400): run on every third TIMED step (part of "
+                                       "value / ms_per_step) and timed alone here" if tv_in_step else
+                                       "do_tv lines of the trainer (fine.py:383-400), timed alone; NOT in the timed steps (--no-tv)"}
         if dominant:
             launches = sum(kern[c][0] for c in dom_calls if c in kern)
             ms = sum(kern[c][1] for c in dom_calls if c in kern)
@@ -582,9 +600,17 @@ def main():
                 # the emo net x3, the off net x1 (detached) and the tone mapper x3, an off-ray sample the off net x3
                 # and the tone mapper x3: 766,464 / 585,216 FLOP per sample = 86.5 MFLOP per ray at C2
                 step_fl = (2 * (4 * RAD_MAC + 3 * TONE_MAC)) * counts["n_on"] + (2 * (3 * RAD_MAC + 3 * TONE_MAC)) * counts["n_off"]
+                # exact MACs: the input-gradient pass multiplies the first layer only towards the grid-fed input rows
+                # (43 of 85; 33 of 33 for the tone mapper) -- SURVEY's x3 convention over-counts it
+                exact = sum(2 * net_macs(n_, op_) * k_ for call_ in ("mlp_fwd(off)", "mlp_fwd(emo)", "mlp_fwd(tone)",
+                                                                       "mlp_dgrad(emo)", "mlp_dgrad(off)", "mlp_dgrad(tone)",
+                                                                       "mlp_wgrad(all)", "tone_wgrad")
+                            for n_, op_, k_ in fine_calls(counts, True)[call_])
                 out["roofline"]["whole_step"] = {"algorithmic_gflop": step_fl / 1e9,
                                                  "achieved": step_fl / (dt / a.steps) / 1e12, "peak": peak,
-                                                 "frac": step_fl / (dt / a.steps) / 1e12 / peak}
+                                                 "frac": step_fl / (dt / a.steps) / 1e12 / peak,
+                                                 "exact_mac_gflop": exact / 1e9,
+                                                 "frac_exact_mac": exact / (dt / a.steps) / 1e12 / peak}
                 out["kernel_ms_per_step_warmup"] = {k: round(v[1] / v[0], 4) for k, v in
                                                     sorted(breakdown.items(), key=lambda kv: -kv[1][1])}
         if breakdown and "kernel_ms_per_step_warmup" not in out:
@@ -608,6 +634,11 @@ def main():
             rl.update(bound="hbm" if bf else "mfma", achieved=pick["achieved"], peak=pick["peak"], unit=pick["unit"],
                       frac=pick["frac"])
             out["roofline"] = rl
+        if pg is not None:
+            # how many ranks the collective library actually saw, and which exchange ran (trainer._grid_sync)
+            out["dist"] = {"backend": dist.get_backend(pg), "rccl_ranks": dist.get_world_size(pg),
+                           "grad_sync": getattr(step, "sync_mode_used", None),
+                           "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}
         sync = getattr(step, "_sync", None)
         if sync is not None:
             # data-parallel exchange of the dense-grid gradients (esr_nerf_amd/grad_sync.py), last step of rank 0
@@ -619,9 +650,9 @@ def main():
                                         sent_mb=round(step._n_grid * 4 / 1e6, 1))
         if world == 1 and not a.no_cpu_baseline:
             if stage == "fine":
-                out["cpu_baseline"] = cpu_baseline(model, scene, a.s_val, min(a.cpu_rays, n_rays), a.cpu_iters)
+                out["cpu_baseline"] = cpu_baseline(model, scene, a.s_val, min(a.cpu_rays or n_rays, n_rays), a.cpu_iters)
             elif stage != "finetune":
-                out["cpu_baseline"] = cpu_baseline_lts(model, scene, a.s_val, min(a.cpu_rays, n_rays), a.cpu_iters,
+                out["cpu_baseline"] = cpu_baseline_lts(model, scene, a.s_val, min(a.cpu_rays or 1024, n_rays), a.cpu_iters,
                                                        stage, cfg.app.trainer)
         line = json.dumps(out)
     if pg is not None:

@@ -180,8 +180,11 @@ class ESRNeRF(VoxurfF):
         self.num_2ndrays, self.num_ltspts, self.lts_near = m.num_2ndrays, m.num_ltspts, m.lts_near
         if self.brdfnet_width != 128 or self.brdfnet_depth != 4:
             raise NotImplementedError("libesr_hip kernels are built for brdfnet 128 x 4 (cfg/app/lts.yaml:25-26)")
-        if str(self.ray_sampling).lower() not in ("random", "fib"):        # esrnerf.py:188-192
-            raise ValueError(f"ray_sampling must be 'random' or 'fib', got {self.ray_sampling!r}")
+        # the reference's spellings (esrnerf.py:188-192): 'random' | 'rand' and 'fib' | 'fibo' | 'fibonacci'
+        alias = {"random": "random", "rand": "random", "fib": "fib", "fibo": "fib", "fibonacci": "fib"}
+        if str(self.ray_sampling).lower() not in alias:
+            raise ValueError(f"ray_sampling must be one of {sorted(alias)}, got {self.ray_sampling!r}")
+        self._ray_sampling_mode = alias[str(self.ray_sampling).lower()]
         grid_args = dict(world_size=self.world_size, xyz_min=self.xyz_min, xyz_max=self.xyz_max)
         self.brdf = DenseGrid(channels=self.color_dim, **grid_args)
         dim0 = (3 + 3 * self.posbase_pe * 2) + self.color_dim + len(self.grad_feat) * 9 + 1
@@ -198,7 +201,7 @@ class ESRNeRF(VoxurfF):
                 raise RuntimeError("ESRNeRF.forward_training runs on libesr_hip.so and needs a GPU device "
                                    "(there is no CPU fallback)")
             self._engine = LtsEngine(self.device, getattr(self, "mlp_dtype", "f32"))
-            self._engine.ray_sampling = str(self.ray_sampling).lower()
+            self._engine.ray_sampling = self._ray_sampling_mode
         return self._engine
 
     def scene_struct(self, near=None):

@@ -268,22 +268,24 @@ class FineEngine:
         last = torch.empty(n, dtype=torch.float32, device=self.device)
         # everything of the step that starts from zero in ONE fill (each small fill is a ~5 us launch on the step's
         # critical path): plan header (8 x i32; what esr_fine_plan_begin does) | srgb | lin | the loss accumulator
-        zb = torch.zeros(8 + 6 * n + 2, dtype=torch.float32, device=self.device)     # (+ the overflow flag's slot: loss_pair)
-        self.plan_dev = zb[:8].view(torch.int32)
-        srgb, lin = zb[8: 8 + 3 * n].view(n, 3), zb[8 + 3 * n: 8 + 6 * n].view(n, 3)
-        self._loss_acc = zb[8 + 6 * n:]
+        # every carve starts on a 16-byte boundary (ragged n: a future float4 access must not straddle)
+        n3 = (3 * n + 3) // 4 * 4
+        zb = torch.zeros(8 + 2 * n3 + 4, dtype=torch.float32, device=self.device)     # (+ the overflow flag's slot: loss_pair)
+        plan_dev = zb[:8].view(torch.int32)       # this step's header; self.plan_dev stays the persistent one (plan_begin paths)
+        srgb, lin = zb[8: 8 + 3 * n].view(n, 3), zb[8 + n3: 8 + n3 + 3 * n].view(n, 3)
+        self._loss_acc = zb[8 + 2 * n3: 8 + 2 * n3 + 2]
         sp = C.byref(scene)
         main = torch.cuda.current_stream(self.device)
         if cached:
             self._run("march_count", L.esr_fine_march_count_cached, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(mask_density),
-                      _lib.ptr(sdf), n, _lib.ptr(rb["cnt3"]), _lib.ptr(last), _lib.ptr(rb["stats"]), _lib.ptr(self.plan_dev),
+                      _lib.ptr(sdf), n, _lib.ptr(rb["cnt3"]), _lib.ptr(last), _lib.ptr(rb["stats"]), _lib.ptr(plan_dev),
                       _lib.ptr(rb["cache"]), s)
         else:
             self._march("march_count", "count", sp, rays_o, rays_d, viewdirs, _lib.ptr(mask_density),
-                        _lib.ptr(sdf), n, _lib.ptr(rb["cnt3"]), _lib.ptr(last), _lib.ptr(rb["stats"]), _lib.ptr(self.plan_dev), s)
+                        _lib.ptr(sdf), n, _lib.ptr(rb["cnt3"]), _lib.ptr(last), _lib.ptr(rb["stats"]), _lib.ptr(plan_dev), s)
         self._run("plan", L.esr_fine_plan, _lib.ptr(rb["cnt3"]), _lib.ptr(em_modes), _lib.ptr(rb["stats"]), n, _lib.ptr(rb["off3"]),
-                                   _lib.ptr(self.plan_dev), s)
-        self.plan_host.copy_(self.plan_dev, non_blocking=True)
+                                   _lib.ptr(plan_dev), s)
+        self.plan_host.copy_(plan_dev, non_blocking=True)
         landed = torch.cuda.Event()
         landed.record()
         e_pre = None

@@ -74,6 +74,7 @@ def _grid_sync(step, eng):
                            "(and optimizer.ShardedGridAdam for the update)")
     if mode == "auto":
         mode = "sparse" if 2 <= dist.get_world_size(step.pg) <= 4 else "dense"
+    step.sync_mode_used = mode            # what bench.py reports (grad_exchange.mode)
     if mode == "shard":
         def after_grids():
             step.sharded.reduce_scatter(step._flat[: step._n_grid])
@@ -133,6 +134,47 @@ def _check_overflow(step):
                            "the march kernel is wrong (its rays were skipped)")
 
 
+def _warn_hw_queues(process_group):
+    """Data-parallel steps need >= 8 HIP hardware queues (see esr_nerf_amd/__init__.py); warn once when the process
+    was started with fewer -- the step still runs, with its side stream serialised behind the main one."""
+    if process_group is None:
+        return
+    try:
+        q = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        q = 4
+    if q < 8:
+        import warnings
+        warnings.warn(f"GPU_MAX_HW_QUEUES={q}: with an RCCL communicator alive the engine's side stream shares a hardware "
+                      "queue with the main stream (weight gradients and packing serialise); export GPU_MAX_HW_QUEUES=8 "
+                      "before the process initialises HIP", RuntimeWarning, stacklevel=3)
+
+
+class _OverflowScope:
+    """``eng.defer_overflow`` for the duration of ONE data-parallel step (an overflow must not raise on one rank while
+    the others wait in the exchange); restored afterwards so that later non-DP uses of the same engine -- the autograd
+    route, single-process stepping -- raise at once again."""
+
+    def __init__(self, eng, on):
+        self.eng, self.on = eng, on
+
+    def __enter__(self):
+        self.prev = self.eng.defer_overflow
+        if self.on:
+            self.eng.defer_overflow = True
+
+    def __exit__(self, *exc):
+        self.eng.defer_overflow = self.prev
+        return False
+
+
+def _finish(step):
+    """After the LAST step of a data-parallel run: the overflow flag of a step is examined by the next step's
+    ``_check_overflow``; this examines the final one (every rank raises together)."""
+    if step.pg is not None:
+        _check_overflow(step)
+
+
 class FineStep:
     def __init__(self, model, white_bg: bool = True, weight_linear: float = 0.1,
                  weight_entropy_last: float = 0.001, process_group=None):
@@ -145,6 +187,7 @@ class FineStep:
         self._flat = None
         self._sync = None
         self._sync_mode = os.environ.get("ESR_GRAD_SYNC", "auto")
+        _warn_hw_queues(process_group)
 
     # names follow state_dict / named_parameters of the renderer
     def _param_names(self):
@@ -192,8 +235,17 @@ class FineStep:
         m.s_val = s_val
         ps = m._mlp_params()
         g = None
-        if self.pg is not None:
-            eng.defer_overflow = True
+        with _OverflowScope(eng, self.pg is not None):
+            return self._step(batch, s_val, global_rays, entropy_owner, m, eng, ps)
+
+    def close(self):
+        """Call once after the final step (data parallel): reports a march overflow flagged by that step."""
+        _finish(self)
+
+    finish = close
+
+    def _step(self, batch, s_val, global_rays, entropy_owner, m, eng, ps):
+        g = None
 
         def prelude():        # independent of the march: runs on the device while the host waits for the plan header
             nonlocal g
@@ -293,6 +345,13 @@ class LtsStep:
         self._flat = None
         self._sync = None
         self._sync_mode = os.environ.get("ESR_GRAD_SYNC", "auto")
+        _warn_hw_queues(process_group)
+
+    def close(self):
+        """Call once after the final step (data parallel): reports a march overflow flagged by that step."""
+        _finish(self)
+
+    finish = close
 
     def _param_names(self):
         if self._names is None:
@@ -348,8 +407,10 @@ class LtsStep:
         eng = m.engine
         m.s_val = s_val
         ps = m._mlp_params()
-        if self.pg is not None:
-            eng.defer_overflow = True
+        with _OverflowScope(eng, self.pg is not None):
+            return self._step(batch, s_val, global_rays, entropy_owner, draws, m, t, eng, ps)
+
+    def _step(self, batch, s_val, global_rays, entropy_owner, draws, m, t, eng, ps):
         from .fine_engine import KIND_RADIANCE as KR, KIND_TONEMAP as KT
         from .lts_engine import KIND_BRDF as KB, KIND_EMIT as KE
         G = None

@@ -79,8 +79,21 @@ def test_training_loop_learns_and_resumes_from_a_checkpoint(tmp_path):
     _loop(m2, sampler2, opt2, z["trainer"]["global_step"] + 1, 6, losses2)
     for a, b in zip(losses[12:], losses2):
         assert abs(a - b) < 1e-4 * max(abs(a), 1e-3), (losses[12:], losses2)
+    # Float-atomic ordering noise is amplified by Adam where a cell's gradient is ~ 0: its update is lr * sign(noise), so
+    # the two runs may walk such a cell in opposite directions for all 6 steps (seen: one SDF cell 1.5 lr apart).  What
+    # the resume must guarantee: all but a vanishing share of every tensor within 1e-2 of its max-norm, and NO element
+    # further apart than Adam can carry it in 6 steps (2 * 6 * lr): a stale moment buffer or a misplaced sampler
+    # position moves whole tensors, not isolated noise cells.
     for k, v in m2.state_dict().items():
-        assert rel_err(v, want[k]) < 1e-2, k          # float-atomic ordering noise, amplified by Adam where v ~ 0 (step = lr * sign)
+        lr = next((r for n_, r in LRS.items() if k.startswith(n_)), None)
+        d = (v.float() - want[k].float()).abs()
+        scale = float(want[k].float().abs().max().clamp_min(1e-12))
+        far = float((d > 1e-2 * scale).float().mean())
+        assert far < 1e-3, (k, far)
+        if lr is not None:
+            assert float(d.max()) <= 2 * 6 * lr * 1.05, (k, float(d.max()), lr)
+        else:
+            assert rel_err(v, want[k]) < 1e-2, k
 
 
 def test_pdra_loop_with_ray_groups():

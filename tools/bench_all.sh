@@ -5,6 +5,7 @@ TAG=${1:-prof}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
+export GPU_MAX_HW_QUEUES=8
 cd "$ROOT"
 python3 bench.py > "$OUT/${TAG}_bench_c2_f32.json" 2>/dev/null
 python3 bench.py --s-val 220 --steps 50 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_c2_s220.json" 2>/dev/null

@@ -4,6 +4,7 @@
 TAG=${1:-k}; shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 export ESR_OVERLAP_WGRAD=0
+export GPU_MAX_HW_QUEUES=8       # as bench.py sets it; under rocprofv3 HIP is initialised before python runs, so it must come from the shell
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/${TAG}_stats" -o run -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-optimizer --no-kernel-timing "$@" > "$ROOT/gpurun_out/${TAG}_stats.log" 2>&1
 cd "$ROOT"

@@ -11,6 +11,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 export ESR_OVERLAP_WGRAD=0
+export GPU_MAX_HW_QUEUES=8       # as bench.py sets it; under rocprofv3 HIP is initialised before python runs, so it must come from the shell
 cd /tmp && export TMPDIR=/tmp
 ARGS="--no-cpu-baseline --no-optimizer --no-kernel-timing $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats" -o run -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 $ARGS > "$OUT/${TAG}_stats.log" 2>&1 &&
