@@ -111,6 +111,9 @@ def fine_calls(counts, merged_off):
     c = {"mlp_fwd(off|on-tiles)": [("off", "fwd", n_on)],
          "mlp_fwd(off)": [("off", "fwd", n_all if merged_off else n_off)],
          "mlp_fwd(emo)": [("emo", "fwd", n_on)], "mlp_fwd(tone)": [("tone", "fwd", n_all)],
+         # f32 engine, merged launches (esr_mlp_fwd_fine / esr_mlp_dgrad_fine)
+         "mlp_fwd(rad)": [("off", "fwd", n_all), ("emo", "fwd", n_on)],
+         "mlp_dgrad(rad)": [("emo", "dgrad", n_on), ("off", "dgrad", n_off)],
          "mlp_dgrad(emo)": [("emo", "dgrad", n_on)], "mlp_dgrad(off)": [("off", "dgrad", n_off)],
          "mlp_dgrad(tone)": [("tone", "dgrad", n_all)],
          # f32 engine: the tone mapper's weight gradients are a kernel of their own (csrc/tone_wgrad.hip)
@@ -134,6 +137,10 @@ def algorithmic_bytes(name, counts, bf16=True):
     if name == "mlp_fwd(off)" and counts.get("merged_off_pass"):      # the detached on-tile half saves nothing
         i = NETS["off"][0]
         return (i * 4 + 16) * counts["n_on"] + net_bytes("off", "fwd", bf16) * counts["n_off"]
+    if name == "mlp_fwd(rad)":          # off net: detached on-tile half saves nothing; emo net saves on the on-tiles
+        i = NETS["off"][0]
+        return ((i * 4 + 16) * counts["n_on"] + net_bytes("off", "fwd", bf16) * counts["n_off"]
+                + net_bytes("emo", "fwd", bf16) * counts["n_on"])
     if name == "mlp_fwd(off|on-tiles)":
         return (NETS["off"][0] * 4 + 16) * counts["n_on"]
     return sum(net_bytes(n, op, bf16) * k for n, op, k in calls)
@@ -146,6 +153,7 @@ KERNEL_OF = {
     "mlp_fwd(emo)": "mlp_fwd_kernel<0>", "mlp_fwd(tone)": "mlp_fwd_kernel<1>",
     "mlp_dgrad(emo)": "mlp_dgrad_kernel<0>", "mlp_dgrad(off)": "mlp_dgrad_kernel<0>",
     "mlp_dgrad(tone)": "mlp_dgrad_kernel<1>",
+    "mlp_fwd(rad)": "mlp_fwd_kernel<0>", "mlp_dgrad(rad)": "mlp_dgrad_kernel<0>",
 }
 
 
@@ -459,7 +467,7 @@ def main():
     dom_calls = sorted(dom_calls, key=lambda c: -breakdown[c][1])[:1]
     if not dom_calls and not a.no_kernel_timing and stage == "fine":
         # too few warm-up steps for the breakdown: bracket the kernel that dominates every profile taken so far
-        dominant, dom_calls = "mlp_fwd_kernel<0>", ["mlp_fwd(emo)"]
+        dominant, dom_calls = "mlp_fwd_kernel<0>", ["mlp_fwd(rad)" if (getattr(eng, "merge_rad", False) and a.dtype == "f32") else "mlp_fwd(emo)"]
     # timed region: exactly K steps, events only around the dominant kernel's launches (on their stream)
     eng.enable_timing(dominant is not None, only=dom_calls if dominant else None)
     if pg is not None:
@@ -602,9 +610,8 @@ def main():
                 step_fl = (2 * (4 * RAD_MAC + 3 * TONE_MAC)) * counts["n_on"] + (2 * (3 * RAD_MAC + 3 * TONE_MAC)) * counts["n_off"]
                 # exact MACs: the input-gradient pass multiplies the first layer only towards the grid-fed input rows
                 # (43 of 85; 33 of 33 for the tone mapper) -- SURVEY's x3 convention over-counts it
-                exact = sum(2 * net_macs(n_, op_) * k_ for call_ in ("mlp_fwd(off)", "mlp_fwd(emo)", "mlp_fwd(tone)",
-                                                                       "mlp_dgrad(emo)", "mlp_dgrad(off)", "mlp_dgrad(tone)",
-                                                                       "mlp_wgrad(all)", "tone_wgrad")
+                exact = sum(2 * net_macs(n_, op_) * k_ for call_ in ("mlp_fwd(rad)", "mlp_fwd(tone)", "mlp_dgrad(rad)",
+                                                                       "mlp_dgrad(tone)", "mlp_wgrad(all)", "tone_wgrad")
                             for n_, op_, k_ in fine_calls(counts, True)[call_])
                 out["roofline"]["whole_step"] = {"algorithmic_gflop": step_fl / 1e9,
                                                  "achieved": step_fl / (dt / a.steps) / 1e12, "peak": peak,

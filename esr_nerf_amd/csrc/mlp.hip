@@ -51,6 +51,13 @@ struct FwdArgs {
     float *zout;
     int t_det;                 // tiles t < t_det are evaluated detached: nothing saved, colour group crow_det
     int crow_det;
+    // A SECOND net of the same kind in the same launch (esr_mlp_fwd_fine: the fine stage's emissive net beside the
+    // non-emissive one): after the first net's tiles [t0, t1) the waves go on with tiles [t0_2, t0_2 + n2) under
+    // `packed2` (colour group crow2, save mode save2, output zout2).  One ramp-up and one tail instead of two, and a
+    // wave's 12 tiles mix detached (light epilogue) and saved ones.
+    const float *packed2;
+    float *zout2;
+    int t0_2, n2, crow2, save2;
 };
 
 // Waves per SIMD of the input-gradient kernel: the tone mapper's chain is short (one hidden layer), a tile's loads are
@@ -71,17 +78,27 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
     const int h = lane >> 5, s = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const rsrc_t W = make_rsrc(A.packed, (unsigned)(L.total * 4));
+    const rsrc_t W1 = make_rsrc(A.packed, (unsigned)(L.total * 4));
+    const rsrc_t W2 = make_rsrc(A.packed2 ? A.packed2 : A.packed, (unsigned)(L.total * 4));
     constexpr int NP4 = D.zrows / 4;
-    __shared__ float4 w4s[NP4 * HT * 4 * 8];             // output layer as 4x4x1 operands (lds4_layer)
-    lds4_preload<NP4 * HT * 4 * 8>(W, (int)L.off_w4 * 4, w4s);
+    constexpr int NW4 = NP4 * HT * 4 * 8;
+    __shared__ float4 w4s[2 * NW4];                      // output layers as 4x4x1 operands (lds4_layer), both nets
+    lds4_preload<NW4>(W1, (int)L.off_w4 * 4, w4s);
+    if (A.n2 > 0) lds4_preload<NW4>(W2, (int)L.off_w4 * 4, w4s + NW4);
     __syncthreads();
-    for (int t = A.t0 + wave; t < A.t1; t += nwaves) {
+    const int n1 = A.t1 - A.t0, nv = n1 + A.n2;
+    for (int v = wave; v < nv; v += nwaves) {
+        const bool second = v >= n1;                         // wave-uniform
+        const int t = second ? A.t0_2 + (v - n1) : A.t0 + v;
+        const rsrc_t W = second ? W2 : W1;
+        const float4 *w4 = w4s + (second ? NW4 : 0);
         const rsrc_t RX = make_rsrc(A.X + (size_t)t * D.xrows * 32, D.xrows * 32 * 4);
         const int xvoff = (h * 32 + s) * 4;
-        const bool det = t < A.t_det;                        // wave-uniform
-        const int coff = (det ? A.crow_det : A.crow) * 128;
-        const bool save = A.save && !det;                    // 1: hidden tiles + ReLU masks, 2: masks only
+        const bool det = !second && t < A.t_det;             // wave-uniform
+        const int coff = (second ? A.crow2 : det ? A.crow_det : A.crow) * 128;
+        const int sv = second ? A.save2 : det ? 0 : A.save;  // 1: hidden tiles + ReLU masks, 2: masks only
+        const bool save = sv != 0;
+        float *const zdst = second ? A.zout2 : A.zout;
         ESR_STAMP(0);
         float B1[KP1];
 #pragma unroll
@@ -112,7 +129,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
             __builtin_amdgcn_s_setprio(3);                // (see the note on wave priorities above the kernel)
             relu_tiles<HT>(cur);
             if (save) {
-                if (A.save == 1) store_tiles<HT>(make_rsrc(A.H[l] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
+                if (sv == 1) store_tiles<HT>(make_rsrc(A.H[l] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
                 store_relu_mask<HT>(make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), cur, lane);
             }
             __builtin_amdgcn_s_setprio(0);
@@ -121,12 +138,12 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(FwdArgs A)
                 stream_layer_pre<HT * 4, HT>(W, (int)L.off_wf[l + 1] * 4, pre,
                                              [&](int k) { return cur[k >> 4][k & 15]; }, nxt, lane);
             else
-                lds4_layer<HT, NP4>(w4s, cur, z4, lane);
+                lds4_layer<HT, NP4>(w4, cur, z4, lane);
             ESR_STAMP(3 + 2 * l);
         }
         // each half of the wave holds the sum over ITS 16*HT units: add the halves, then the bias (rows >= out_dim
         // have zero weights and bias: the padding row of the output tile is written as 0)
-        store_rows4<NP4, true, false>(make_rsrc(A.zout + (size_t)t * D.zrows * 32, D.zrows * 32 * 4), 0, z4, bias4, lane);
+        store_rows4<NP4, true, false>(make_rsrc(zdst + (size_t)t * D.zrows * 32, D.zrows * 32 * 4), 0, z4, bias4, lane);
     }
 }
 
@@ -136,6 +153,10 @@ struct DgradArgs {
     const unsigned *M[3];
     float *dZ[3];
     float *dX;
+    // tiles t >= t_split run under `packed2` (esr_mlp_dgrad_fine: emissive net on the on-tiles, non-emissive net on the
+    // off-tiles, one launch); packed2 == NULL: one net
+    const float *packed2;
+    int t_split;
 };
 
 template <int KIND>
@@ -150,14 +171,20 @@ __global__ void __launch_bounds__(256, mlp_occ(KIND)) mlp_dgrad_kernel(DgradArgs
     const int h = lane >> 5, s = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const rsrc_t W = make_rsrc(A.packed, (unsigned)(L.total * 4));
+    const rsrc_t W1 = make_rsrc(A.packed, (unsigned)(L.total * 4));
+    const rsrc_t W2 = make_rsrc(A.packed2 ? A.packed2 : A.packed, (unsigned)(L.total * 4));
     constexpr int NPX = L.n_passx;
-    __shared__ float4 wx4s[NPX > 0 ? NPX * HT * 4 * 8 : 1];     // first layer transposed, input rows >= 32 (lds4_layer)
+    constexpr int NWX = NPX > 0 ? NPX * HT * 4 * 8 : 1;
+    __shared__ float4 wx4s[2 * NWX];                            // first layer transposed, input rows >= 32 (lds4_layer), both nets
     if constexpr (NPX > 0) {
-        lds4_preload<NPX * HT * 4 * 8>(W, (int)L.off_wx4 * 4, wx4s);
+        lds4_preload<NWX>(W1, (int)L.off_wx4 * 4, wx4s);
+        if (A.packed2) lds4_preload<NWX>(W2, (int)L.off_wx4 * 4, wx4s + NWX);
         __syncthreads();
     }
     for (int t = A.t0 + wave; t < A.t1; t += nwaves) {
+        const bool second = A.packed2 && t >= A.t_split;         // wave-uniform
+        const rsrc_t W = second ? W2 : W1;
+        const float4 *wx4 = wx4s + (second ? NWX : 0);
         ESR_DSTAMP(0);
         const rsrc_t RZ = make_rsrc(A.dz + (size_t)t * D.zrows * 32, D.zrows * 32 * 4);
         float B0[4];                                                         // pair p <-> rows 2p, 2p+1
@@ -200,7 +227,7 @@ __global__ void __launch_bounds__(256, mlp_occ(KIND)) mlp_dgrad_kernel(DgradArgs
         ESR_DSTAMP(8);
         if constexpr (NPX > 0) {
             f32x4 x4[NPX];
-            lds4_layer<HT, NPX>(wx4s, cur, x4, lane);
+            lds4_layer<HT, NPX>(wx4, cur, x4, lane);
             ESR_DSTAMP(9);
             store_rows4<NPX, false, false>(make_rsrc(A.dX + (size_t)t * 64 * 32, 64 * 32 * 4), 32, x4, nullptr, lane);
             ESR_DSTAMP(10);
@@ -221,6 +248,7 @@ struct WgradArgs {
     int crow;                    // first layer: B rows 0..cw-1 are read from X rows crow..crow+cw-1
     int cw8;                     // colour-group rows x 8 (float4 units per row)
     int wg0, nwg;                // workgroups [wg0, wg0 + nwg) of the launch work on this job
+    int cfg;                     // kernel shape of this job (layer_cfg) -- read by the unified launch (mlp_wgrad_uni192_kernel)
 };
 
 // One launch can carry up to MAX_JOBS jobs of the same kernel shape (the same layer of the emissive and the non-emissive
@@ -472,9 +500,8 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradBa
 // same logical chunk hit 16 distinct 4-bank groups.
 // Three buffers, one barrier per tile in the MIDDLE of the tile (schedule: comment above the main loop).
 template <int MI, int NJ, int WM, int WN, int WK>
-__global__ void __launch_bounds__(64 * (WM * WN * WK + 1), 1) mlp_wgrad_dma_kernel(WgradBatch WB)
+__device__ __forceinline__ void wgrad_dma_body(const WgradArgs &W)
 {
-    const WgradArgs W = pick_job(WB);
     constexpr int NW = WM * WN * WK;                 // compute waves (one per SIMD); wave NW is the loader
     constexpr int RAP = WM * MI * 32, RBP = WN * NJ * 32, ROWS = RAP + RBP;
     constexpr int PIECES = ROWS / 8;                 // 1-KiB pieces (8 rows x 128 B) per tile
@@ -608,6 +635,26 @@ __global__ void __launch_bounds__(64 * (WM * WN * WK + 1), 1) mlp_wgrad_dma_kern
     }
 }
 
+template <int MI, int NJ, int WM, int WN, int WK>
+__global__ void __launch_bounds__(64 * (WM * WN * WK + 1), 1) mlp_wgrad_dma_kernel(WgradBatch WB)
+{
+    wgrad_dma_body<MI, NJ, WM, WN, WK>(pick_job(WB));
+}
+
+// Every f32 weight-gradient job of the 192-wide nets of a step in ONE launch: hidden layers (192 x 192), first layers
+// (192 x <= 96) and the 3-row output layers each keep their own shape (all three are 4 compute waves + the loader
+// wave; a workgroup works on exactly one job, so the switch is workgroup-uniform) and get a share of the 256 workgroups
+// proportional to tiles x cost per tile.  Why: every launch pays a fixed 25-35 us (slab round trip, ring fill and
+// drain, tail) whatever its tile count -- three launches + three reductions per step became one + one.
+enum { UNI_HID192 = 0, UNI_FIRST192 = 1, UNI_OUT192 = 2 };
+__global__ void __launch_bounds__(320, 1) mlp_wgrad_uni192_kernel(WgradBatch WB)
+{
+    const WgradArgs W = pick_job(WB);
+    if (W.cfg == UNI_HID192) wgrad_dma_body<3, 3, 2, 2, 1>(W);
+    else if (W.cfg == UNI_FIRST192) wgrad_dma_body<3, 3, 2, 1, 2>(W);
+    else wgrad_dma_body<1, 3, 1, 2, 2>(W);
+}
+
 // gw[e] += sum over the partial slabs of every job of a launch; 32 slabs per thread, groups combined with one atomic
 struct ReduceArgs {
     int nseg;
@@ -738,6 +785,104 @@ int launch_wgrad_any(WgradBatch &B, float *scratch, int64_t slab_floats, hipStre
     else return launch_wgrad<MI, NJ, WM, WN, WK, MODE>(B, scratch, slab_floats, s);
 }
 
+// ---- unified launch of the 192-wide f32 jobs --------------------------------------------------------------
+// relative cost of one sample tile per job shape (hidden : first : output), from the per-shape launches' times at C2
+// (4.4 : 2.2 : 0.8 us per tile per workgroup; the output shape is bound by its loader wave, not by matrix work);
+// ESR_WGRAD_COST="h,f,o" overrides (developer knob, read once)
+const double *uni_cost()
+{
+    static double c[3] = {1.0, 0.5, 0.2};
+    static std::atomic<int> done{0};
+    if (!done.load()) {
+        if (const char *e = std::getenv("ESR_WGRAD_COST")) {
+            double a, b, d;
+            if (std::sscanf(e, "%lf,%lf,%lf", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0) { c[0] = a; c[1] = b; c[2] = d; }
+        }
+        done.store(1);
+    }
+    return c;
+}
+constexpr int uni_wk(int cfg) { return cfg == UNI_HID192 ? 1 : 2; }
+
+// workgroups per job proportional to tiles x cost (every job >= 1, none more than its tiles); slab regions back to back
+int plan_uni(WgradBatch &B, float *scratch, int64_t slab_floats, ReduceArgs &R)
+{
+    const double *cost = uni_cost();
+    double w[MAX_JOBS], wt = 0.0;
+    int64_t tiles = 0;
+    for (int j = 0; j < B.n; ++j) {
+        const int tj = B.job[j].t1 - B.job[j].t0;
+        w[j] = tj * cost[B.job[j].cfg];
+        wt += w[j];
+        tiles += tj;
+    }
+    const int grid = tiles < 256 ? (int)tiles : 256;
+    if (grid < B.n) return ESR_ECAP;
+    int given = 0;
+    for (int j = 0; j < B.n; ++j) {
+        const int tj = B.job[j].t1 - B.job[j].t0;
+        int n = (int)(grid * w[j] / wt);
+        if (n < 1) n = 1;
+        if (n > tj) n = tj;
+        B.job[j].nwg = n;
+        given += n;
+    }
+    // remainder: one workgroup at a time to the most loaded job / from the least loaded one
+    for (int guard = 0; given != grid && guard < 4096; ++guard) {
+        int pick = -1;
+        double best = 0.0;
+        for (int j = 0; j < B.n; ++j) {
+            const WgradArgs &W = B.job[j];
+            if (given < grid) {
+                if (W.nwg >= W.t1 - W.t0) continue;
+                const double load = w[j] / W.nwg;
+                if (pick < 0 || load > best) { pick = j; best = load; }
+            } else {
+                if (W.nwg <= 1) continue;
+                const double load = w[j] / (W.nwg - 1);
+                if (pick < 0 || load < best) { pick = j; best = load; }
+            }
+        }
+        if (pick < 0) break;
+        B.job[pick].nwg += given < grid ? 1 : -1;
+        given += given < grid ? 1 : -1;
+    }
+    int64_t used = 0;
+    int wg0 = 0;
+    R = ReduceArgs{};
+    for (int j = 0; j < B.n; ++j) {
+        WgradArgs &W = B.job[j];
+        W.wg0 = wg0;
+        wg0 += W.nwg;
+        const int n_elems = W.out_rows * W.ld, wk = uni_wk(W.cfg);
+        W.slab = scratch + used;
+        used += (int64_t)W.nwg * wk * n_elems;
+        R.slab[j] = W.slab; R.n_partials[j] = W.nwg * wk; R.n_elems[j] = n_elems; R.gw[j] = W.gw;
+        R.first[j + 1] = R.first[j] + (int64_t)n_elems * ((W.nwg * wk + REDUCE_PG - 1) / REDUCE_PG);
+    }
+    R.nseg = B.n;
+    if (used > slab_floats) return ESR_ECAP;
+    return wg0;
+}
+
+int launch_wgrad_uni(WgradBatch &B, float *scratch, int64_t slab_floats, hipStream_t s)
+{
+    for (int j = 0; j < B.n; ++j) {
+        const WgradArgs &W = B.job[j];
+        const int rap = W.cfg == UNI_OUT192 ? 32 : 192, rbp = W.cfg == UNI_FIRST192 ? 96 : 192;
+        if (W.RA > rap || W.RB > rbp) return ESR_ECAP;
+    }
+    constexpr size_t lds_bytes = 3 * (size_t)(192 + 192) * 32 * sizeof(float);       // the largest shape's ring
+    static std::atomic<uint64_t> optin{0};
+    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_wgrad_uni192_kernel), lds_bytes, optin)) return rc;
+    ReduceArgs R;
+    const int grid = plan_uni(B, scratch, slab_floats, R);
+    if (grid < 0) return grid;
+    mlp_wgrad_uni192_kernel<<<grid, 320, lds_bytes, s>>>(B);
+    ESR_CHECK_LAUNCH();
+    return launch_reduce(R, s);
+}
+
 // kernel shapes (waves per workgroup wm x wn x wk, always 4 compute waves = 1 per SIMD):
 //   192-wide nets: 192x192 -> 2x2x1, 192x<=96 (first layer) -> 2x1x2, 192x<=64 (tone mapper's first) , zrows x 192 (output) -> 1x2x2
 //   128-wide nets: 128x128 -> 2x2x1, 128x96 -> 2x1x2, 8x128 -> 1x2x2
@@ -747,6 +892,13 @@ int layer_cfg(const NetDesc &D, bool first, bool last, int RB)
 {
     if (D.hid_tiles == 6) return last ? CFG_OUT192 : first ? (RB <= 64 ? CFG_FIRST192_64 : CFG_FIRST192) : CFG_HID192;
     return last ? CFG_OUT128 : first ? CFG_FIRST128 : CFG_HID128;
+}
+
+// ESR_WGRAD_UNI=0: one launch per kernel shape as in round 2 (A/B timing)
+bool uni_on()
+{
+    static const bool on = [] { const char *e = std::getenv("ESR_WGRAD_UNI"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 template <bool BF>
@@ -849,6 +1001,50 @@ ESR_API int esr_mlp_fwd_mixed(int kind, const float *packed, const float *X, int
     return 0;
 }
 
+// The fine stage's three radiance passes in ONE launch (voxurff.py:243-256): non-emissive net on tiles [0, t_on)
+// detached (colour rows color_row_detached, nothing saved) and on [t_on, t_all) saved, emissive net on [0, t_on) saved.
+// Both nets save into the same H / M arrays (disjoint tiles).
+ESR_API int esr_mlp_fwd_fine(const float *packed_off, const float *packed_emo, const float *X, int32_t t_on, int32_t t_all,
+                             float *const *H, uint32_t *const *M, int color_row_detached, float *z_off, float *z_emo,
+                             void *stream)
+{
+    if (t_on < 0 || t_all < t_on) return ESR_EINVAL;
+    if (!color_row_ok(ESR_MLP_RADIANCE, color_row_detached)) return ESR_EINVAL;
+    if (t_all == 0) return 0;
+    if (!packed_off || !packed_emo || !X || !z_off || !z_emo || !H || !M) return ESR_EINVAL;
+    FwdArgs A = {};
+    A.packed = packed_off; A.X = X; A.t0 = 0; A.t1 = t_all; A.save = 1; A.crow = 0; A.zout = z_off;
+    A.t_det = t_on; A.crow_det = color_row_detached;
+    A.packed2 = packed_emo; A.zout2 = z_emo; A.t0_2 = 0; A.n2 = t_on; A.crow2 = 0; A.save2 = 1;
+    for (int l = 0; l < 3; ++l) {
+        if (!H[l] || !M[l]) return ESR_EINVAL;
+        A.H[l] = H[l];
+        A.M[l] = M[l];
+    }
+    mlp_fwd_kernel<ESR_MLP_RADIANCE><<<mlp_grid(t_all + t_on), 256, 0, esr_stream(stream)>>>(A);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+// Input gradients of the fine stage's two radiance nets in ONE launch: emissive net on tiles [0, t_on), non-emissive
+// net on [t_on, t_all) (its on-tile pass is detached in the reference: no gradient).
+ESR_API int esr_mlp_dgrad_fine(const float *packed_emo, const float *packed_off, const float *dz, int32_t t_on, int32_t t_all,
+                               const uint32_t *const *M, float *const *dZ, float *dX, void *stream)
+{
+    if (t_on < 0 || t_all < t_on) return ESR_EINVAL;
+    if (t_all == 0) return 0;
+    if (!packed_emo || !packed_off || !dz || !M || !dZ || !dX) return ESR_EINVAL;
+    DgradArgs A = {};
+    A.packed = packed_emo; A.packed2 = packed_off; A.t_split = t_on; A.dz = dz; A.t0 = 0; A.t1 = t_all; A.dX = dX;
+    for (int l = 0; l < 3; ++l) {
+        if (!M[l]) return ESR_EINVAL;
+        A.M[l] = M[l]; A.dZ[l] = dZ[l];
+    }
+    mlp_dgrad_kernel<ESR_MLP_RADIANCE><<<mlp_grid(t_all, mlp_occ(ESR_MLP_RADIANCE)), 256, 0, esr_stream(stream)>>>(A);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
 ESR_API int esr_mlp_dgrad(int kind, const float *packed, const float *dz, int32_t t0, int32_t t1,
                           const uint32_t *const *M, float *const *dZ, float *dX, void *stream)
 {
@@ -893,6 +1089,9 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
     if (!jobs || n_jobs < 0 || !scratch) return ESR_EINVAL;
     WgradBatch group[N_CFG][4];
     int n_group[N_CFG] = {};
+    constexpr int MAX_UNI = 8;
+    WgradBatch uni[MAX_UNI];
+    int n_uni = 0;
     for (int c = 0; c < N_CFG; ++c)
         for (int g = 0; g < 4; ++g) group[c][g].n = 0;
     for (int q = 0; q < n_jobs; ++q) {
@@ -916,6 +1115,16 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
             W.kind = J.kind; W.first = first ? 1 : 0; W.gb = J.gb[l];
             if (!W.A || !W.B || !W.gw || !W.gb) return ESR_EINVAL;
             const int c = layer_cfg(D, first, last, W.RB);
+            if (!BF && uni_on() && (c == CFG_HID192 || c == CFG_FIRST192 || c == CFG_OUT192)) {
+                W.cfg = c == CFG_HID192 ? UNI_HID192 : c == CFG_FIRST192 ? UNI_FIRST192 : UNI_OUT192;
+                if (n_uni == 0 || uni[n_uni - 1].n == MAX_JOBS) {
+                    if (n_uni == MAX_UNI) return ESR_ECAP;
+                    uni[n_uni++].n = 0;
+                }
+                WgradBatch &U = uni[n_uni - 1];
+                U.job[U.n++] = W;
+                continue;
+            }
             int g = n_group[c];
             if (g == 0 || group[c][g - 1].n == MAX_JOBS) {
                 if (g == 4) return ESR_ECAP;
@@ -926,6 +1135,8 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
         }
     }
     hipStream_t s = esr_stream(stream);
+    for (int u = 0; u < n_uni; ++u)
+        if (int rc = launch_wgrad_uni(uni[u], scratch, scratch_floats, s)) return rc;
     for (int c = 0; c < N_CFG; ++c)
         for (int g = 0; g < n_group[c]; ++g)
             if (int rc = launch_cfg<BF>(c, group[c][g], scratch, scratch_floats, s)) return rc;

@@ -26,7 +26,7 @@
 
 namespace {
 
-constexpr int TIN = 33, THID = 192, TOUT = 3, TKP = 20;       // inputs, hidden units, outputs, k-pairs of the 40 padded input rows
+constexpr int TIN = 33, THID = 192, TOUT = 3, TKP = 17;       // inputs, hidden units, outputs, k-pairs of the input rows 0..33 (row 33: zero weight; the forward pads to 40 only because its weight stream comes in quads)
 constexpr int XT_ROWS = 48;                                    // rows of the Xt tile in memory
 constexpr int XS = 36;                                         // LDS row stride (floats) of the staged tiles: 16-B reads of 16
                                                                // consecutive rows then hit 16 distinct 4-bank groups

@@ -120,6 +120,9 @@ class FineEngine:
         self._only = None
         self._events = []
         self.overlap_wgrad = os.environ.get("ESR_OVERLAP_WGRAD", "1") != "0"
+        # f32 engine: the three radiance forward passes of a step as ONE launch (esr_mlp_fwd_fine) and the two radiance
+        # input-gradient passes as one (esr_mlp_dgrad_fine); ESR_MERGE_RAD=0 keeps the separate launches (A/B timing)
+        self.merge_rad = os.environ.get("ESR_MERGE_RAD", "1") != "0"
         # measured NEGATIVE on MI355X (C2: 4.08 ms without, 4.19 / 4.32 / 4.47 ms with the input-gradient kernels capped at
         # 256 / 384 / uncapped workgroups): the atomics-heavy scatters slow the matrix kernels more than they hide
         self.overlap_scatter = os.environ.get("ESR_OVERLAP_SCATTER", "0") != "0"
@@ -328,7 +331,10 @@ class FineEngine:
         if e_pre is not None:
             main.wait_event(e_pre)
         # off net: detached pass on the on-tiles (alt colour rows, nothing saved), saved pass on the off-tiles
-        if not self.bf16:       # one launch, same weights (no launch seam, one ramp-up / tail instead of two)
+        if not self.bf16 and self.merge_rad:     # off net (detached on-tiles + saved off-tiles) and emo net: one launch
+            self._run("mlp_fwd(rad)", L.esr_mlp_fwd_fine, _lib.ptr(self.packed["off"]), _lib.ptr(self.packed["emo"]),
+                      _lib.ptr(ws["X"]), tiles_on, tiles_all, H, M, 88, _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), s)
+        elif not self.bf16:       # one launch, same weights (no launch seam, one ramp-up / tail instead of two)
                 self._run("mlp_fwd(off)", L.esr_mlp_fwd_mixed, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]),
                       0, tiles_on, tiles_all, H, M, 88, _lib.ptr(ws["z_off"]), s)
         else:
@@ -336,8 +342,9 @@ class FineEngine:
                                      H, M, 0, 88, _lib.ptr(ws["z_off"]), s)
             self._run("mlp_fwd(off)", self.mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), tiles_on,
                                      tiles_all, H, M, 1, 0, _lib.ptr(ws["z_off"]), s)
-        self._run("mlp_fwd(emo)", self.mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["emo"]), _lib.ptr(ws["X"]), 0, tiles_on,
-                                 H, M, 1, 0, _lib.ptr(ws["z_emo"]), s)
+        if self.bf16 or not self.merge_rad:
+            self._run("mlp_fwd(emo)", self.mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["emo"]), _lib.ptr(ws["X"]), 0, tiles_on,
+                                     H, M, 1, 0, _lib.ptr(ws["z_emo"]), s)
         self._run("tone_in_fwd", L.esr_fine_tone_in_fwd, _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), tiles_on, tiles_all,
                                           _lib.ptr(ws["lin"]), _lib.ptr(ws["Xt"]), s)
         self._run("mlp_fwd(tone)", self.mlp_fwd, KIND_TONEMAP, _lib.ptr(self.packed["tone"]), _lib.ptr(ws["Xt"]), 0, tiles_all,
@@ -536,10 +543,14 @@ class FineEngine:
                   _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), to, ta,
                   _lib.ptr(ws["dz"]), s)
         M, dZ = self._H(["M0", "M1", "M2"]), self._H(["dZ0", "dZ1", "dZ2"])
-        dgrad("mlp_dgrad(emo)", KIND_RADIANCE, self.packed["emo"], ws["dz"], 0, to, M, dZ, ws["dX"])
-        if scat is not None and to > 0:
-            e_scat = on(scat, mark(), feat_bwd(0, to))
-        dgrad("mlp_dgrad(off)", KIND_RADIANCE, self.packed["off"], ws["dz"], to, ta, M, dZ, ws["dX"])
+        if not self.bf16 and self.merge_rad and scat is None:      # both radiance nets' input gradients: one launch
+            self._run("mlp_dgrad(rad)", L.esr_mlp_dgrad_fine, _lib.ptr(self.packed["emo"]), _lib.ptr(self.packed["off"]),
+                      _lib.ptr(ws["dz"]), to, ta, M, dZ, _lib.ptr(ws["dX"]), s)
+        else:
+            dgrad("mlp_dgrad(emo)", KIND_RADIANCE, self.packed["emo"], ws["dz"], 0, to, M, dZ, ws["dX"])
+            if scat is not None and to > 0:
+                e_scat = on(scat, mark(), feat_bwd(0, to))
+            dgrad("mlp_dgrad(off)", KIND_RADIANCE, self.packed["off"], ws["dz"], to, ta, M, dZ, ws["dX"])
         if not overlap:
             feat_bwd(0, ta)(s)
             if not fold:

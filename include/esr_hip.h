@@ -318,6 +318,20 @@ int esr_mlp_fwd_mixed(int kind, const float *packed, const float *X, int32_t t0,
                       float *const *H, uint32_t *const *M, int color_row_detached, float *zout, void *stream);
 
 /*
+ * The fine stage's three radiance passes of one step in ONE launch (app/fine/model/voxurff.py:243-256): the non-emissive
+ * net on tiles [0,t_on) detached (colour rows color_row_detached, nothing saved) and on [t_on,t_all) saved with colour
+ * rows 0, the emissive net on [0,t_on) saved with colour rows 0.  Both nets save into the same H / M arrays (disjoint
+ * tiles); z_off [t_all,4,32], z_emo [t_on,4,32].  One ramp-up and one tail instead of two launches' worth.
+ */
+int esr_mlp_fwd_fine(const float *packed_off, const float *packed_emo, const float *X, int32_t t_on, int32_t t_all,
+                     float *const *H, uint32_t *const *M, int color_row_detached, float *z_off, float *z_emo,
+                     void *stream);
+/* Its backward twin: input gradients of the emissive net on tiles [0,t_on) and of the non-emissive net on
+ * [t_on,t_all) in one launch (the non-emissive net's on-tile pass is detached in the reference: no gradient). */
+int esr_mlp_dgrad_fine(const float *packed_emo, const float *packed_off, const float *dz, int32_t t_on, int32_t t_all,
+                       const uint32_t *const *M, float *const *dZ, float *dX, void *stream);
+
+/*
  * Input/hidden gradients over tiles [t0,t1) (a NULL dZ[l] is computed but not stored).  dz [tiles,4,32] -> dZ[l] (each
  * [tiles,192,32], pre-activation grads of hidden layer l) and dX [tiles,64,32], of which the rows that lead back to a
  * grid are written, rounded up to 4: rows 0-43 for the sample nets (colour | sdf | 24 stencil taps | 12 normal

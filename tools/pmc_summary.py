@@ -37,7 +37,8 @@ G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 # order of the single-dispatch MLP calls of one fine-stage step, per kernel symbol (f32 engine: the off net's detached
 # and saved forward passes are ONE launch; bf16 engine: two)
-ORDER_F32 = {"mlp_fwd_kernel<0>": ["mlp_fwd(off)", "mlp_fwd(emo)"], "mlp_dgrad_kernel<0>": ["mlp_dgrad(emo)", "mlp_dgrad(off)"],
+# (round 3: the three radiance forward passes are one launch, esr_mlp_fwd_fine, and so are the two input-gradient passes)
+ORDER_F32 = {"mlp_fwd_kernel<0>": ["mlp_fwd(rad)"], "mlp_dgrad_kernel<0>": ["mlp_dgrad(rad)"],
              "mlp_fwd_kernel<1>": ["mlp_fwd(tone)"], "mlp_dgrad_kernel<1>": ["mlp_dgrad(tone)"]}
 ORDER_BF16 = {"mlp_fwd16s_kernel<0>": ["mlp_fwd(off|on-tiles)", "mlp_fwd(off)", "mlp_fwd(emo)"], "mlp_fwd16s_kernel<1>": ["mlp_fwd(tone)"], "mlp_fwd16_kernel<0>": ["mlp_fwd(off|on-tiles)", "mlp_fwd(off)", "mlp_fwd(emo)"],
               "mlp_dgrad16_kernel<0>": ["mlp_dgrad(emo)", "mlp_dgrad(off)"], "mlp_dgrad16s_kernel<0>": ["mlp_dgrad(emo)", "mlp_dgrad(off)"], "mlp_dgrad16s_kernel<1>": ["mlp_dgrad(tone)"],
