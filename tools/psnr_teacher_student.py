@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Held-out PSNR of a student trained with f32 and with bf16 MLP operands against a fixed teacher's image
+(tests/teacher_student.py).  Run on the GPU box:
+    python tools/psnr_teacher_student.py [--steps 300] [--seeds 0 1 2] [--stage fine|pdra]
+Prints one line per (seed, dtype): PSNR at the evaluation steps; the difference f32 - bf16 at the end; and a second
+f32 run per seed (same seeds, float-atomic ordering differs) as the noise floor of the comparison."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import teacher_student as ts  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=300)
+ap.add_argument("--seeds", type=int, nargs="+", default=[0])
+ap.add_argument("--stage", default="fine", choices=["fine", "pdra", "finetune"])
+ap.add_argument("--noise-floor", action="store_true", help="also a second f32 run per seed")
+a = ap.parse_args()
+run = dict(fine=ts.fine_experiment, pdra=ts.pdra_experiment, finetune=ts.finetune_experiment)[a.stage]
+ev = sorted({0, a.steps // 4, a.steps // 2, 3 * a.steps // 4, a.steps})
+for seed in a.seeds:
+    res = {}
+    for tag, dt in (("f32", "f32"), ("bf16", "bf16")) + ((("f32b", "f32"),) if a.noise_floor else ()):
+        scores, losses, spread = run(dt, steps=a.steps, seed=seed, eval_at=ev)
+        res[tag] = scores
+        if a.stage == "finetune":
+            res[tag + "_img"], spread = spread, float(spread.std())
+        print(json.dumps(dict(stage=a.stage, seed=seed, dtype=tag, psnr={k: round(v, 3) for k, v in scores.items()},
+                              loss0=round(losses[0], 5), lossN=round(sum(losses[-10:]) / 10, 6), img_std=round(spread, 3))),
+              flush=True)
+    d = res["f32"][a.steps] - res["bf16"][a.steps]
+    line = f"seed {seed}: final PSNR f32 {res['f32'][a.steps]:.3f}  bf16 {res['bf16'][a.steps]:.3f}  diff {d:+.3f} dB"
+    if a.noise_floor:
+        line += f"  | f32 rerun diff {res['f32'][a.steps] - res['f32b'][a.steps]:+.3f} dB"
+    if a.stage == "finetune":
+        line += f"  | images f32 vs bf16: {ts.psnr(res['f32_img'], res['bf16_img']):.1f} dB"
+    print(line, flush=True)
