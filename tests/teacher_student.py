@@ -35,7 +35,7 @@ def smooth_field(shape, coarse, amp, gen):
     return torch.nn.functional.interpolate(lat, size=tuple(shape[2:]), mode="trilinear", align_corners=True).contiguous()
 
 
-def build_fine(scene, mlp_seed: int, grid_seed: int, dtype: str, smooth_amp: float = 0.0):
+def build_fine(scene, mlp_seed: int, grid_seed: int, dtype: str, smooth_amp: float = 0.0, lattice=(6, 6, 4)):
     from esr_nerf_amd.config import fine_cfg
     from esr_nerf_amd.synthetic import init_slab_model
     from esr_nerf_amd.voxurff import VoxurfF
@@ -49,7 +49,7 @@ def build_fine(scene, mlp_seed: int, grid_seed: int, dtype: str, smooth_amp: flo
         with torch.no_grad():
             for name in ("off_color", "emo_color"):
                 grid = getattr(m, name).grid
-                grid.copy_(smooth_field(grid.shape, (6, 6, 4), smooth_amp, g).to(grid.device))
+                grid.copy_(smooth_field(grid.shape, tuple(lattice), smooth_amp, g).to(grid.device))
     m.mlp_dtype = dtype
     return m
 
@@ -85,14 +85,15 @@ def cosine_schedule(steps: int):
 
 
 def train_fine(student, train_rays: Dict[str, torch.Tensor], s_val: float, steps: int, batch: int, seed: int,
-               eval_at: List[int], test_rays: Dict[str, torch.Tensor], test_img: torch.Tensor):
+               eval_at: List[int], test_rays: Dict[str, torch.Tensor], test_img: torch.Tensor, lrs=None,
+               weight_linear: float = 0.1):
     """The fine-stage trainer's loop shape (fine.py:346-415): batch -> FineStep -> every third step the TV lines ->
     fused Adam -> cosine learning-rate decay.  Returns {step: held-out PSNR} at the requested steps and the loss curve."""
     from esr_nerf_amd.optimizer import create_optimizer_or_freeze_model
     from esr_nerf_amd.trainer import FineStep
     student.train()
-    step = FineStep(student)
-    opt = create_optimizer_or_freeze_model(student, **LRS_FINE)
+    step = FineStep(student, weight_linear=weight_linear)
+    opt = create_optimizer_or_freeze_model(student, **(lrs or LRS_FINE))
     sched = cosine_schedule(steps)
     g = torch.Generator().manual_seed(seed)
     n = train_rays["rays_o"].shape[0]
@@ -117,20 +118,33 @@ def train_fine(student, train_rays: Dict[str, torch.Tensor], s_val: float, steps
 
 
 def fine_experiment(dtype: str, steps: int = 300, n_train: int = 12288, n_test: int = 4096, batch: int = 2048,
-                    s_val: float = 40.0, seed: int = 0, eval_at=None):
+                    s_val: float = 40.0, seed: int = 0, eval_at=None, lrs=None, perturb=None,
+                    weight_linear: float = 0.1, lattice=(6, 6, 4)):
     """Teacher (f32, smooth colour grids, MLP seed 100) -> image on n_train + n_test oblique rays of the `small` slab;
     student (MLP seed 200 + seed, N(0, 0.1) colour grids) trained with ``dtype`` MLP operands.  Returns held-out PSNR."""
     from esr_nerf_amd.synthetic import slab_scene
     sc = slab_scene("small", s_val=s_val, oblique=True, n_rays=n_train + n_test, seed=31)
     rays = {k: v.cuda() for k, v in sc.batch.items() if k != "rgbs"}
-    teacher = build_fine(sc, 100, 100, "f32", smooth_amp=0.6)
+    teacher = build_fine(sc, 100, 100, "f32", smooth_amp=0.6, lattice=lattice)
     img = render_image(teacher, rays, s_val)
     train = {k: v[:n_train].contiguous() for k, v in rays.items()}
     train["rgbs"] = img[:n_train].contiguous()
     test = {k: v[n_train:].contiguous() for k, v in rays.items()}
-    student = build_fine(sc, 200 + seed, 200 + seed, dtype)
+    if perturb is None:
+        student = build_fine(sc, 200 + seed, 200 + seed, dtype)
+    else:
+        # the teacher's own parameters, perturbed: colour grids + N(0, perturb[0]), MLP weights x (1 + N(0, perturb[1]))
+        student = build_fine(sc, 100, 100, dtype, smooth_amp=0.6)
+        gp = torch.Generator().manual_seed(600 + seed)
+        with torch.no_grad():
+            for name, p_ in student.named_parameters():
+                if name.startswith(("off_color", "emo_color")):
+                    p_.add_((torch.randn(p_.shape, generator=gp) * perturb[0]).to(p_.device))
+                elif name.startswith(("off_rgbnet", "emo_rgbnet", "tonemapper")):
+                    p_.mul_((1.0 + perturb[1] * torch.randn(p_.shape, generator=gp)).to(p_.device))
     eval_at = eval_at if eval_at is not None else [0, steps]
-    scores, losses = train_fine(student, train, s_val, steps, batch, 7 + seed, eval_at, test, img[n_train:])
+    scores, losses = train_fine(student, train, s_val, steps, batch, 7 + seed, eval_at, test, img[n_train:], lrs=lrs,
+                                weight_linear=weight_linear)
     return scores, losses, float(img.std())
 
 

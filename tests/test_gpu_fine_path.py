@@ -320,7 +320,8 @@ def test_fused_path_vs_oracle(name, oblique, s_val, n_rays, mask, alpha):
     kr = torch.unique(keep["ray_id"][keep["knife"] < KNIFE])
     if len(kr):
         n_all = sc.batch["rays_o"].shape[0]
-        assert len(kr) < 0.2 * n_all, (len(kr), n_all)
+        print(f"[fused-vs-oracle] {len(kr)} of {n_all} rays hold a sample within {KNIFE:g} of a ReLU kink: dropped, both sides re-run")
+        assert len(kr) < 0.2 * n_all, (len(kr), n_all)             # (measured: up to 9 of 64 rays on the `tiny` cases)
         sel = torch.ones(n_all, dtype=torch.bool)
         sel[kr] = False
         sc.batch = {k: v[sel].contiguous() for k, v in sc.batch.items()}

@@ -121,7 +121,7 @@ def _knife_cells(sets, c, sdf_grid):
     return mark, n_knife, n_all
 
 
-def _compare_grads(grads, P, sets, c, n_expected, max_marked=(0.10, 0.25), fp_log=None):
+def _compare_grads(grads, P, sets, c, n_expected, max_marked=(0.06, 0.12), fp_log=None):
     """Every gradient against the oracle at 1e-4 rel-to-max-norm.  Network weights are means over ~10^5-10^6 samples
     and compare as they are.  A DENSE-GRID cell sums the contributions of the one or two samples that touch it, so a
     sample whose ReLU unit sits on its kink (|pre-activation| < 2e-6, where the MFMA's k-ordered fmaf chain and the
@@ -130,7 +130,9 @@ def _compare_grads(grads, P, sets, c, n_expected, max_marked=(0.10, 0.25), fp_lo
       (a) ALL touched cells, nothing set aside: fewer than 2 in 1000 are beyond 1e-4;
       (b) cell by cell outside the cells such samples touch (found from the ORACLE's pre-activations, and from the
           threshold samples of _check_survivor_sets): 1e-4, and those cells must be a small share of the touched ones;
-      (c) the cells set aside stay within 5e-2."""
+      (c) the cells set aside stay within 5e-2.
+    ``max_marked`` = (colour grids, SDF grid): measured share of marked cells + 50 % -- C2 / C3: 0.037-0.040 colour,
+    0.080-0.081 SDF; the measured values of every run are printed (pytest -s)."""
     bad, n = {}, 0
     for k, v in P.items():
         if v.grad is None:
@@ -164,6 +166,10 @@ def _compare_grads(grads, P, sets, c, n_expected, max_marked=(0.10, 0.25), fp_lo
         assert share < max_marked[k == "sdf.grid"] or n_touched < 5000, (k, share)
         frac_bad = int((err > TOL).sum()) / n_touched
         e_out, e_in = float(err[~mark].max()), float(err[mark].max()) if bool(mark.any()) else 0.0
+        # measured values, one line per grid (pytest -s / the captured log): the caps above are these + 50 %
+        print(f"[full-size grads] {k}: touched {n_touched}, marked share {share:.4f} (cap {max_marked[k == 'sdf.grid']}), "
+              f"beyond 1e-4 {frac_bad:.2e} (cap 2e-3), max err outside marks {e_out:.2e}, inside {e_in:.2e}, "
+              f"knife samples {n_knife}/{n_all}")
         if not (frac_bad < 2e-3 and e_out < TOL and e_in < 5e-2):
             bad[k] = dict(beyond_tol=frac_bad, outside=e_out, set_aside=e_in, share=share)
     assert n == n_expected and not bad, str(bad)
@@ -340,7 +346,8 @@ def test_c4_full_size_lts_step_vs_oracle():
     with_fixed_subgradient(ro, lo, sgn).backward()
     with_fixed_subgradient(rg, lg, sgn.cuda()).backward()
     _compare_grads({k: p.grad for k, p in m.named_parameters() if p.grad is not None}, P,
-                   keep["knife_sets"] + [(odd, torch.zeros(len(odd)))], c, 43, max_marked=(0.15, 0.5), fp_log=fp_log)
+                   keep["knife_sets"] + [(odd, torch.zeros(len(odd)))], c, 43, max_marked=(0.20, 0.45), fp_log=fp_log)    # C4 at s_val = 220, measured: colour 0.136 / 0.142, SDF 0.362 (few survivors per ray:
+                   # the 24-tap crosses of the kink samples cover a third of the touched cells)
 
 
 def test_c5_full_size_pdra_bf16_tracks_fp32_and_finetune_vs_oracle():

@@ -19,6 +19,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=300)
 ap.add_argument("--seeds", type=int, nargs="+", default=[0])
 ap.add_argument("--stage", default="fine", choices=["fine", "pdra", "finetune"])
+ap.add_argument("--sdf-lr", type=float, default=None, help="fine stage: override the SDF grid learning rate")
+ap.add_argument("--perturb", type=float, nargs=2, default=None, help="fine stage: student = teacher + (grid sigma, weight sigma)")
+ap.add_argument("--weight-linear", type=float, default=None)
+ap.add_argument("--lattice", type=int, nargs=3, default=None)
 ap.add_argument("--noise-floor", action="store_true", help="also a second f32 run per seed")
 a = ap.parse_args()
 run = dict(fine=ts.fine_experiment, pdra=ts.pdra_experiment, finetune=ts.finetune_experiment)[a.stage]
@@ -26,7 +30,14 @@ ev = sorted({0, a.steps // 4, a.steps // 2, 3 * a.steps // 4, a.steps})
 for seed in a.seeds:
     res = {}
     for tag, dt in (("f32", "f32"), ("bf16", "bf16")) + ((("f32b", "f32"),) if a.noise_floor else ()):
-        scores, losses, spread = run(dt, steps=a.steps, seed=seed, eval_at=ev)
+        kw = dict(lrs=dict(ts.LRS_FINE, sdf=a.sdf_lr)) if (a.sdf_lr is not None and a.stage == 'fine') else {}
+        if a.weight_linear is not None and a.stage == 'fine':
+            kw['weight_linear'] = a.weight_linear
+        if a.lattice is not None and a.stage == 'fine':
+            kw['lattice'] = tuple(a.lattice)
+        if a.perturb is not None and a.stage == 'fine':
+            kw['perturb'] = tuple(a.perturb)
+        scores, losses, spread = run(dt, steps=a.steps, seed=seed, eval_at=ev, **kw)
         res[tag] = scores
         if a.stage == "finetune":
             res[tag + "_img"], spread = spread, float(spread.std())
