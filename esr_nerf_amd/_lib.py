@@ -91,7 +91,7 @@ EXPORTS = [
     "esr_act_fwd", "esr_act_bwd", "esr_composite3_fwd", "esr_composite3_bwd", "esr_lts_tone_in_bwd",
     "esr_sample_points", "esr_pair_loss_fwd_bwd", "esr_emit_edit",
     "esr_gauss3d_fwd", "esr_gauss3d_bwd", "esr_central_grad_fwd", "esr_central_grad_bwd",
-    "esr_coarse_march_count", "esr_coarse_march_fill", "esr_coarse_march_bwd",
+    "esr_coarse_march_count", "esr_coarse_march_fill", "esr_coarse_march_bwd", "esr_coarse_march_count_ga", "esr_coarse_march_fill_ga", "esr_coarse_march_bwd_ga",
     "esr_coarse_feat_fwd", "esr_coarse_feat_bwd", "esr_coarse_shade_fwd", "esr_coarse_shade_bwd",
     "esr_adam_step", "esr_eval_aux", "esr_eval_disp",
     "esr_mlp_packed_bf16_elems", "esr_mlp_pack_bf16", "esr_mlp_fwd_bf16", "esr_mlp_dgrad_bf16", "esr_mlp_wgrad_bf16",

@@ -50,6 +50,10 @@ struct MarchParams {
     // fetches per step) and the serial transmittance loop run once per step instead of three times
     float *cache;
     const float *last_in;    // BWD from the cache: alphainv_last of the COUNT pass
+    // COARSE + GA: the dense central-difference gradient grid [X,Y,Z,3] the coarse renderer samples (voxurfc.py:204-206)
+    // and, in the backward, its gradient buffer (summed into the SDF grid by esr_central_grad_bwd)
+    const float *gg;
+    float *grad_gg;
 };
 constexpr int CACHE_ARR = 5;
 
@@ -90,6 +94,55 @@ __device__ __forceinline__ void grad_alpha_ic_bwd(float *__restrict__ grad_sdf, 
             esr_tri_scatter1(grad_sdf, dims, ixm, -coef);
         }
     }
+}
+
+// Coarse renderer (voxurfc.py:204-210): the gradient is a trilinear sample of the dense central-difference grid
+// (3 channels, stored channel-last), iter_cos = (viewdir . gradient) * dist * 0.5 (functions.py:53-55).
+__device__ __forceinline__ float coarse_alpha_ic(const float *__restrict__ gg, const int dims[3], const float ind[3],
+                                                 const float vd[3], float dist)
+{
+#pragma clang fp contract(off)
+    const Tri t = esr_tri_setup(ind);
+    float gv[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cx = 0; cx < 2; ++cx)
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+            for (int cz = 0; cz < 2; ++cz) {
+                const int x = t.i0[0] + cx, y = t.i0[1] + cy, z = t.i0[2] + cz;
+                const bool inb = (x >= 0) & (x < dims[0]) & (y >= 0) & (y < dims[1]) & (z >= 0) & (z < dims[2]);
+                const float w = esr_corner_w(t, ind, cx, cy, cz);
+                if (inb) {
+                    const float *q = gg + (((int64_t)x * dims[1] + y) * dims[2] + z) * 3;
+                    gv[0] += q[0] * w; gv[1] += q[1] * w; gv[2] += q[2] * w;
+                }
+            }
+    const float dotp = (vd[0] * gv[0] + vd[1] * gv[1]) + vd[2] * gv[2];
+    return (dotp * dist) * 0.5f;
+}
+
+__device__ __forceinline__ void coarse_alpha_ic_bwd(float *__restrict__ grad_gg, const int dims[3], const float ind[3],
+                                                    const float vd[3], float dist, float dic)
+{
+    const Tri t = esr_tri_setup(ind);
+    const float k = dic * 0.5f * dist;
+#pragma unroll
+    for (int cx = 0; cx < 2; ++cx)
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+            for (int cz = 0; cz < 2; ++cz) {
+                const int x = t.i0[0] + cx, y = t.i0[1] + cy, z = t.i0[2] + cz;
+                const bool inb = (x >= 0) & (x < dims[0]) & (y >= 0) & (y < dims[1]) & (z >= 0) & (z < dims[2]);
+                const float w = esr_corner_w(t, ind, cx, cy, cz);
+                if (inb && w != 0.f) {
+                    float *q = grad_gg + (((int64_t)x * dims[1] + y) * dims[2] + z) * 3;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+                        if (vd[a] != 0.f) atomicAdd(q + a, k * vd[a] * w);
+                }
+            }
 }
 
 // The reference's alpha2weight walks a ray's samples in order: T_i = T_cum;  T_cum = float(double(T_cum) * (1.0 - alpha_i));
@@ -207,7 +260,8 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
         if (ok) {
             esr_world_to_index(p, sc.xyz_min, sc.xyz_max, gdims, idx);
             s = esr_tri_fetch1(P.sdf, gdims, idx);
-            if (GA) ic = grad_alpha_ic(P.sdf, gdims, idx, vd, sc.voxel_size, sc.stepdist);
+            if (GA) ic = COARSE ? coarse_alpha_ic(P.gg, gdims, idx, vd, sc.stepdist)
+                                : grad_alpha_ic(P.sdf, gdims, idx, vd, sc.voxel_size, sc.stepdist);
         }
         const unsigned long long b = __ballot(ok);
         if (ok) {
@@ -340,7 +394,10 @@ __global__ void __launch_bounds__(256) march_kernel(MarchParams P)
                 esr_ray_point(g.start, g.dir, sc.stepdist, step1[j], p);
                 esr_world_to_index(p, sc.xyz_min, sc.xyz_max, gdims, idx);
                 if (ds_ != 0.f) esr_tri_scatter1(P.grad_sdf, gdims, idx, ds_);
-                if (dic != 0.f) grad_alpha_ic_bwd(P.grad_sdf, gdims, idx, vd, sc.voxel_size, sc.stepdist, dic);
+                if (dic != 0.f) {
+                    if (COARSE) coarse_alpha_ic_bwd(P.grad_gg, gdims, idx, vd, sc.stepdist, dic);
+                    else grad_alpha_ic_bwd(P.grad_sdf, gdims, idx, vd, sc.voxel_size, sc.stepdist, dic);
+                }
             }
             continue;
         }
@@ -694,4 +751,58 @@ ESR_API int esr_coarse_march_bwd(const esr_scene_t *scene, const float *rays_o, 
     P.n_rays = n_rays; P.cap = march_cap(scene); P.off3 = off3; P.dweight = dweight; P.dlast = dlast;
     P.grad_sdf = grad_sdf_smooth;
     return launch_march<MARCH_BWD, true>(P, esr_stream(stream));
+}
+
+// ---- coarse stage with cfg neus_alpha: "grad" (voxurfc.py:171-174, 204-210): the section SDFs are extrapolated with the
+// trilinear sample of the dense gradient grid `gg` [X,Y,Z,3] (esr_central_grad_fwd of the UNSMOOTHED grid); the backward
+// adds d/d gg into grad_gg, which esr_central_grad_bwd folds into the SDF gradient ----
+ESR_API int esr_coarse_march_count_ga(const esr_scene_t *scene, const float *rays_o, const float *rays_d, const float *viewdirs,
+                                      const float *mask_density, const float *sdf_smooth, const float *gg, int32_t n_rays,
+                                      int32_t *cnt3, float *alphainv_last, float *cum_weights, int32_t *ray_stats,
+                                      esr_plan_t *plan, void *stream)
+{
+    if (!scene || n_rays < 0 || !plan) return ESR_EINVAL;
+    if (n_rays && (!rays_o || !rays_d || !viewdirs || !mask_density || !sdf_smooth || !gg || !cnt3 || !alphainv_last ||
+                   !cum_weights || !ray_stats))
+        return ESR_EINVAL;
+    MarchParams P = {};
+    P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d; P.viewdirs = viewdirs; P.mask_density = mask_density;
+    P.sdf = sdf_smooth; P.gg = gg;
+    P.n_rays = n_rays; P.cap = march_cap(scene); P.cnt3 = cnt3; P.alphainv_last = alphainv_last;
+    P.cumw = cum_weights; P.stats = ray_stats; P.plan = plan;
+    return launch_march<MARCH_COUNT, true, true>(P, esr_stream(stream));
+}
+
+ESR_API int esr_coarse_march_fill_ga(const esr_scene_t *scene, const float *rays_o, const float *rays_d, const float *viewdirs,
+                                     const float *mask_density, const float *sdf_smooth, const float *gg, int32_t n_rays,
+                                     const int32_t *off3, int32_t *rec_ray, int32_t *rec_step, float *rec_w,
+                                     float *rec_sdf, void *stream)
+{
+    if (!scene || n_rays < 0) return ESR_EINVAL;
+    if (n_rays && (!rays_o || !rays_d || !viewdirs || !mask_density || !sdf_smooth || !gg || !off3 || !rec_ray ||
+                   !rec_step || !rec_w || !rec_sdf))
+        return ESR_EINVAL;
+    MarchParams P = {};
+    P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d; P.viewdirs = viewdirs; P.mask_density = mask_density;
+    P.sdf = sdf_smooth; P.gg = gg;
+    P.n_rays = n_rays; P.cap = march_cap(scene); P.off3 = off3; P.rec_ray = rec_ray;
+    P.rec_step = rec_step; P.rec_w = rec_w; P.rec_sdf = rec_sdf;
+    return launch_march<MARCH_FILL, true, true>(P, esr_stream(stream));
+}
+
+ESR_API int esr_coarse_march_bwd_ga(const esr_scene_t *scene, const float *rays_o, const float *rays_d, const float *viewdirs,
+                                    const float *mask_density, const float *sdf_smooth, const float *gg, int32_t n_rays,
+                                    const int32_t *off3, const float *dweight, const float *dlast,
+                                    float *grad_sdf_smooth, float *grad_gg, void *stream)
+{
+    if (!scene || n_rays < 0) return ESR_EINVAL;
+    if (n_rays && (!rays_o || !rays_d || !viewdirs || !mask_density || !sdf_smooth || !gg || !off3 || !dweight || !dlast ||
+                   !grad_sdf_smooth || !grad_gg))
+        return ESR_EINVAL;
+    MarchParams P = {};
+    P.sc = *scene; P.rays_o = rays_o; P.rays_d = rays_d; P.viewdirs = viewdirs; P.mask_density = mask_density;
+    P.sdf = sdf_smooth; P.gg = gg;
+    P.n_rays = n_rays; P.cap = march_cap(scene); P.off3 = off3; P.dweight = dweight; P.dlast = dlast;
+    P.grad_sdf = grad_sdf_smooth; P.grad_gg = grad_gg;
+    return launch_march<MARCH_BWD, true, true>(P, esr_stream(stream));
 }

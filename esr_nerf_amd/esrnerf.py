@@ -202,6 +202,7 @@ class ESRNeRF(VoxurfF):
                                    "(there is no CPU fallback)")
             self._engine = LtsEngine(self.device, getattr(self, "mlp_dtype", "f32"))
             self._engine.ray_sampling = self._ray_sampling_mode
+            self._engine.neus_grad = self.neus_alpha == "grad"
         return self._engine
 
     def scene_struct(self, near=None):

@@ -193,8 +193,10 @@ class LtsEngine(FineEngine):
         return v
 
     # ------------------------------------------------------------------ building blocks
-    def _march(self, P: Pass, scene, rays_o, rays_d, em_modes, mask_density, sdf, prelude=None):
-        """count -> plan -> (host reads the plan header) -> fill.  ``prelude()``: work that does not depend on the march
+    def _march(self, P: Pass, scene, rays_o, rays_d, em_modes, mask_density, sdf, prelude=None, viewdirs=None):
+        """count -> plan -> (host reads the plan header) -> fill.  ``viewdirs``: the rays' view directions -- read under cfg
+        neus_alpha "grad" (esrnerf.py:197-200: every march of the renderer extrapolates its section SDFs along them;
+        the secondary rays' view directions are their own directions, esrnerf.py:575-591).  ``prelude()``: work that does not depend on the march
         (weight packing, zeroing the gradient buffer), enqueued on a side stream while the host waits; the returned
         event (``P.e_pre``) must be waited for by the main stream before the first consumer."""
         L, s = self.L, self._s()
@@ -206,14 +208,26 @@ class LtsEngine(FineEngine):
         stats = torch.empty(n * 3, dtype=torch.int32, device=self.device)
         sp = C.byref(scene)
         self._run("plan_begin", L.esr_fine_plan_begin, _lib.ptr(self.plan_dev), s)
-        # march cache: the count pass records every mask-cache survivor; fill copies, the backward starts at its scan
-        need = int(L.esr_fine_march_cache_floats(sp, n))
-        if getattr(P, "cache", None) is None or P.cache.numel() < need:
-            P.cache = torch.empty(need, dtype=torch.float32, device=self.device)
-        self._run(f"march_count[{P.name}]", L.esr_fine_march_count_cached, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
-                  _lib.ptr(mask_density), _lib.ptr(sdf), n, _lib.ptr(cnt3), _lib.ptr(last), _lib.ptr(stats),
-                  _lib.ptr(self.plan_dev), _lib.ptr(P.cache), s)
-        P.march = (stats, last, P.cache)
+        ga = self.neus_grad
+        if ga:
+            if viewdirs is None:
+                raise RuntimeError("neus_alpha='grad' marches need the rays' view directions")
+            viewdirs = viewdirs.contiguous()
+            # (no march cache in this mode: the gradient taps are not recorded; fill and backward walk again)
+            self._run(f"march_count[{P.name}]", L.esr_fine_march_count_ga, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
+                      _lib.ptr(viewdirs), _lib.ptr(mask_density), _lib.ptr(sdf), n, _lib.ptr(cnt3), _lib.ptr(last),
+                      _lib.ptr(stats), _lib.ptr(self.plan_dev), s)
+            P.march = None
+            P.ga = (viewdirs, mask_density, sdf)
+        else:
+            # march cache: the count pass records every mask-cache survivor; fill copies, the backward starts at its scan
+            need = int(L.esr_fine_march_cache_floats(sp, n))
+            if getattr(P, "cache", None) is None or P.cache.numel() < need:
+                P.cache = torch.empty(need, dtype=torch.float32, device=self.device)
+            self._run(f"march_count[{P.name}]", L.esr_fine_march_count_cached, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
+                      _lib.ptr(mask_density), _lib.ptr(sdf), n, _lib.ptr(cnt3), _lib.ptr(last), _lib.ptr(stats),
+                      _lib.ptr(self.plan_dev), _lib.ptr(P.cache), s)
+            P.march = (stats, last, P.cache)
         self._run("plan", L.esr_fine_plan, _lib.ptr(cnt3), _lib.ptr(em_modes), _lib.ptr(stats), n, _lib.ptr(off3),
                   _lib.ptr(self.plan_dev), s)
         self.plan_host.copy_(self.plan_dev, non_blocking=True)
@@ -238,13 +252,35 @@ class LtsEngine(FineEngine):
         P.ensure(max(tiles_all, 1))
         rec_ray = P.buf("rec_ray", 1, torch.int32)
         rec_ray[: max(tiles_all, 1) * 32].fill_(-1)
-        if tiles_all:
+        if tiles_all and ga:
+            self._run(f"march_fill[{P.name}]", L.esr_fine_march_fill_ga, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
+                      _lib.ptr(viewdirs), _lib.ptr(mask_density), _lib.ptr(sdf), n, _lib.ptr(off3), _lib.ptr(rec_ray),
+                      _lib.ptr(P.buf("rec_step", 1, torch.int32)), _lib.ptr(P.buf("rec_w")),
+                      _lib.ptr(P.buf("rec_sdf")), s)
+        elif tiles_all:
             self._run(f"march_fill[{P.name}]", L.esr_fine_march_fill_cached, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), n,
                       _lib.ptr(off3), _lib.ptr(stats), _lib.ptr(P.cache), _lib.ptr(rec_ray),
                       _lib.ptr(P.buf("rec_step", 1, torch.int32)), _lib.ptr(P.buf("rec_w")),
                       _lib.ptr(P.buf("rec_sdf")), s)
         P.keep = [rays_o, rays_d, em_modes, cnt3, off3, last, stats]
         return cnt3, off3, last
+
+    def _march_bwd(self, name, P: Pass, sp, rays_o, rays_d, n, off3, dweight, dlast, grad_sdf, dsdf, acc):
+        """Backward of one march.  Cached form: the value-tap gradients of the recorded samples go to ``dsdf`` (the
+        feature backward folds them into its SDF window).  neus_alpha "grad": a fresh walk that scatters every tap
+        straight into ``grad_sdf`` (``dsdf`` is left untouched).  Returns whether ``dsdf`` was written."""
+        L, s = self.L, self._s()
+        if P.march is None:
+            vd, mask_density, sdf = P.ga
+            self._run(name, L.esr_fine_march_bwd_ga, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(vd),
+                      _lib.ptr(mask_density), _lib.ptr(sdf), n, _lib.ptr(off3), _lib.ptr(dweight), _lib.ptr(dlast),
+                      _lib.ptr(grad_sdf), s)
+            return False
+        st, la, ca = P.march
+        self._run(name, L.esr_fine_march_bwd_cached, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), n, _lib.ptr(off3),
+                  _lib.ptr(st), _lib.ptr(la), _lib.ptr(ca), _lib.ptr(dweight), _lib.ptr(dlast), _lib.ptr(grad_sdf),
+                  _lib.ptr(dsdf) if dsdf is not None else None, acc, s)
+        return dsdf is not None
 
     def _feat_args_records(self, P: Pass, rays_o, rays_d, viewdirs, sdf, color_on, color_off):
         fa = _lib.EsrFeatArgs()
@@ -392,7 +428,7 @@ class LtsEngine(FineEngine):
         n = rays_o.shape[0]
         P0 = self.prim
         cnt3, off3, last = self._march(P0, scene, rays_o, rays_d, torch.zeros(n, dtype=torch.int64, device=dev),
-                                       grids["mask"], sdf)
+                                       grids["mask"], sdf, viewdirs=viewdirs)
         T, m3 = P0.tiles_all, P0.counts["m3"]
         z3 = lambda: torch.zeros(n, 3, dtype=torch.float32, device=dev)
         out = {f"{sp_}/{v}_rgb": z3() for v in ("off", "on", "emo") for sp_ in ("srgb", "lin")}
@@ -472,7 +508,7 @@ class LtsEngine(FineEngine):
                 o2 = pts_c.repeat_interleave(R, 0).contiguous()
                 d2 = dirs_all[:, :R].reshape(nc * R, 3).contiguous()
                 _, _, last2 = self._march(P2, scene2, o2, d2, torch.zeros(nc * R, dtype=torch.int64, device=dev),
-                                          grids["mask"], sdf)
+                                          grids["mask"], sdf, viewdirs=d2)
                 T2 = P2.tiles_all
                 off_m, emo_m = torch.zeros(nc * R, 3, device=dev), torch.zeros(nc * R, 3, device=dev)
                 if T2:
@@ -519,7 +555,8 @@ class LtsEngine(FineEngine):
         L, s, dev = self.L, self._s(), self.device
         n = rays_o.shape[0]
         P0 = self.prim
-        self._march(P0, scene, rays_o, rays_d, torch.zeros(n, dtype=torch.int64, device=dev), mask_density, sdf)
+        self._march(P0, scene, rays_o, rays_d, torch.zeros(n, dtype=torch.int64, device=dev), mask_density, sdf,
+                    viewdirs=viewdirs)
         T = P0.tiles_all
         out = torch.zeros(n, 3, dtype=torch.float32, device=dev)
         if T == 0:
@@ -551,7 +588,7 @@ class LtsEngine(FineEngine):
         N = rays_o.shape[0]
         P0, P1, P2 = self.prim, self.pts, self.sec
         cnt3, off3, _ = self._march(P0, scene, rays_o, rays_d, torch.zeros(N, dtype=torch.int64, device=dev),
-                                    grids["mask"], sdf)
+                                    grids["mask"], sdf, viewdirs=viewdirs)
         T, m3 = P0.tiles_all, P0.counts["m3"]
         if T == 0:
             raise RuntimeError("fine-tune step with no surviving sample (degenerate batch)")
@@ -600,7 +637,8 @@ class LtsEngine(FineEngine):
         # incoming emo radiance along the secondary rays (no gradient: esrnerf.py:241 no_grad)
         o2 = pts_p.repeat_interleave(R, 0).contiguous()
         d2 = dirs_all[:, :R].reshape(Pn * R, 3).contiguous()
-        _, _, last2 = self._march(P2, scene2, o2, d2, torch.zeros(Pn * R, dtype=torch.int64, device=dev), grids["mask"], sdf)
+        _, _, last2 = self._march(P2, scene2, o2, d2, torch.zeros(Pn * R, dtype=torch.int64, device=dev), grids["mask"], sdf,
+                                  viewdirs=d2)
         T2 = P2.tiles_all
         emo_m = torch.zeros(Pn * R, 3, device=dev)
         if T2:
@@ -647,7 +685,8 @@ class LtsEngine(FineEngine):
         rays_o, rays_d, viewdirs = batch["rays_o"], batch["rays_d"], batch["viewdirs"]
         N = rays_o.shape[0]
         P0 = self.prim
-        cnt3, off3, last = self._march(P0, scene, rays_o, rays_d, batch["em_modes"], grids["mask"], sdf, prelude=prelude)
+        cnt3, off3, last = self._march(P0, scene, rays_o, rays_d, batch["em_modes"], grids["mask"], sdf, prelude=prelude,
+                                       viewdirs=viewdirs)
         T, Ton = P0.tiles_all, P0.tiles_on
         srgb = self._z(N, 3, device=dev)
         lin_m = self._z(N, 3, device=dev)
@@ -777,7 +816,7 @@ class LtsEngine(FineEngine):
         o2 = pts_p.repeat_interleave(R, 0).contiguous()
         d2 = dirs_all[:, :R].reshape(Pn * R, 3).contiguous()
         em2 = self._z(Pn * R, dtype=torch.int64, device=dev)
-        _, off3_2, last2 = self._march(P2, scene2, o2, d2, em2, grids["mask"], sdf)
+        _, off3_2, last2 = self._march(P2, scene2, o2, d2, em2, grids["mask"], sdf, viewdirs=d2)
         T2 = P2.tiles_all
         off_m = self._z(Pn * R, 3, device=dev)
         emo_m = self._z(Pn * R, 3, device=dev)
@@ -908,16 +947,12 @@ class LtsEngine(FineEngine):
                 src.append((dX, None, gon, 0, T2))
             # the secondary march's value-tap gradients of the recorded samples ride on the feature backward's window
             ds2 = P2.buf("dsdf")
-            st2, la2, ca2 = P2.march
-            self._run("march_bwd[secondary]", L.esr_fine_march_bwd_cached, sp2, _lib.ptr(ctx.t["o2"]), _lib.ptr(ctx.t["d2"]),
-                      Pn * R, _lib.ptr(ctx.t["off3_2"]), _lib.ptr(st2), _lib.ptr(la2), _lib.ptr(ca2),
-                      _lib.ptr(dw2), _lib.ptr(d["d_last2"]), _lib.ptr(grads["sdf"]), _lib.ptr(ds2), 0, s)
-            self._feat_bwd(P2, ctx.scene2, src, grads["sdf"], dsdf_extra=ds2)
+            wrote = self._march_bwd("march_bwd[secondary]", P2, sp2, ctx.t["o2"], ctx.t["d2"], Pn * R, ctx.t["off3_2"], dw2,
+                                    d["d_last2"], grads["sdf"], ds2, 0)
+            self._feat_bwd(P2, ctx.scene2, src, grads["sdf"], dsdf_extra=ds2 if wrote else None)
         else:
-            st2, la2, ca2 = P2.march
-            self._run("march_bwd[secondary]", L.esr_fine_march_bwd_cached, sp2, _lib.ptr(ctx.t["o2"]), _lib.ptr(ctx.t["d2"]),
-                      Pn * R, _lib.ptr(ctx.t["off3_2"]), _lib.ptr(st2), _lib.ptr(la2), _lib.ptr(ca2),
-                      _lib.ptr(z(32)), _lib.ptr(d["d_last2"]), _lib.ptr(grads["sdf"]), None, 0, s)
+            self._march_bwd("march_bwd[secondary]", P2, sp2, ctx.t["o2"], ctx.t["d2"], Pn * R, ctx.t["off3_2"], z(32),
+                            d["d_last2"], grads["sdf"], None, 0)
 
         # ---- radiance at the points
         T1 = P1.tiles_all
@@ -971,10 +1006,8 @@ class LtsEngine(FineEngine):
                     grads["brdf"], grads["brdf"], 0, T))
         src.append((self._net_bwd(P0, "emit", KIND_EMIT, 88, 0, T, dze, grads["emit_w"], grads["emit_b"]),
                     grads["emo"], grads["emo"], 0, T))
-        st0, la0, ca0 = P0.march
-        self._run("march_bwd", L.esr_fine_march_bwd_cached, sp, _lib.ptr(b["rays_o"]), _lib.ptr(b["rays_d"]), P0.n_rays,
-                  _lib.ptr(ctx.t["off3"]), _lib.ptr(st0), _lib.ptr(la0), _lib.ptr(ca0),
-                  _lib.ptr(dweight), _lib.ptr(g_last), _lib.ptr(grads["sdf"]), _lib.ptr(dsdf_extra), 1, s)
+        self._march_bwd("march_bwd", P0, sp, b["rays_o"], b["rays_d"], P0.n_rays, ctx.t["off3"], dweight, g_last,
+                        grads["sdf"], dsdf_extra, 1)
         self._feat_bwd(P0, ctx.scene, src, grads["sdf"], dsdf_extra=dsdf_extra)
         # exact normals (linear in the grid): etc/normal and etc/normal_eps
         for key, noise, eps in (("etc/normal", None, 0.0), ("etc/normal_eps", ctx.t["noise_n"], ctx.eps["normal"])):

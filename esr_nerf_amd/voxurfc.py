@@ -74,9 +74,14 @@ class CoarseEngine(FineEngine):
         srgb = torch.zeros(n, 3, dtype=torch.float32, device=dev)
         sp = C.byref(scene)
         self._run("plan_begin", L.esr_fine_plan_begin, _lib.ptr(self.plan_dev), s)
-        self._run("march_count", L.esr_coarse_march_count, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
-                  _lib.ptr(mask_density), _lib.ptr(sm), n, _lib.ptr(cnt3), _lib.ptr(last), _lib.ptr(cumw),
-                  _lib.ptr(stats), _lib.ptr(self.plan_dev), s)
+        if self.neus_grad:      # cfg neus_alpha: "grad": section SDFs extrapolated with the sampled gradient grid
+            self._run("march_count", L.esr_coarse_march_count_ga, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(viewdirs),
+                      _lib.ptr(mask_density), _lib.ptr(sm), _lib.ptr(gg), n, _lib.ptr(cnt3), _lib.ptr(last), _lib.ptr(cumw),
+                      _lib.ptr(stats), _lib.ptr(self.plan_dev), s)
+        else:
+            self._run("march_count", L.esr_coarse_march_count, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
+                      _lib.ptr(mask_density), _lib.ptr(sm), n, _lib.ptr(cnt3), _lib.ptr(last), _lib.ptr(cumw),
+                      _lib.ptr(stats), _lib.ptr(self.plan_dev), s)
         self._run("plan", L.esr_fine_plan, _lib.ptr(cnt3), _lib.ptr(em_modes), _lib.ptr(stats), n, _lib.ptr(off3),
                   _lib.ptr(self.plan_dev), s)
         self.plan_host.copy_(self.plan_dev, non_blocking=True)
@@ -94,9 +99,14 @@ class CoarseEngine(FineEngine):
         b = self.b
         T, Ton = tiles_all, tiles_on
         b["rec_ray"][: T * 32].fill_(-1)
-        self._run("march_fill", L.esr_coarse_march_fill, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
-                  _lib.ptr(mask_density), _lib.ptr(sm), n, _lib.ptr(off3), _lib.ptr(b["rec_ray"]),
-                  _lib.ptr(b["rec_step"]), _lib.ptr(b["rec_w"]), _lib.ptr(b["rec_sdf"]), s)
+        if self.neus_grad:
+            self._run("march_fill", L.esr_coarse_march_fill_ga, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(viewdirs),
+                      _lib.ptr(mask_density), _lib.ptr(sm), _lib.ptr(gg), n, _lib.ptr(off3), _lib.ptr(b["rec_ray"]),
+                      _lib.ptr(b["rec_step"]), _lib.ptr(b["rec_w"]), _lib.ptr(b["rec_sdf"]), s)
+        else:
+            self._run("march_fill", L.esr_coarse_march_fill, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
+                      _lib.ptr(mask_density), _lib.ptr(sm), n, _lib.ptr(off3), _lib.ptr(b["rec_ray"]),
+                      _lib.ptr(b["rec_step"]), _lib.ptr(b["rec_w"]), _lib.ptr(b["rec_sdf"]), s)
         self._run("feat_fwd", L.esr_coarse_feat_fwd, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(viewdirs),
                   _lib.ptr(b["rec_ray"]), _lib.ptr(b["rec_step"]), Ton, T, _lib.ptr(gg), _lib.ptr(off_color),
                   _lib.ptr(emo_color), _lib.ptr(b["X"]), _lib.ptr(b["gnorm"]), s)
@@ -181,9 +191,14 @@ class CoarseEngine(FineEngine):
         else:
             dweight = z(32)
         # alphainv_last and the weights depend on the SMOOTHED grid; white_bg's dependence rides in dweight
-        self._run("march_bwd", L.esr_coarse_march_bwd, sp, _lib.ptr(bt["rays_o"]), _lib.ptr(bt["rays_d"]),
-                  _lib.ptr(ctx["mask_density"]), _lib.ptr(ctx["sm"]), n, _lib.ptr(ctx["off3"]), _lib.ptr(dweight),
-                  _lib.ptr(g_last), _lib.ptr(g_sm), s)
+        if self.neus_grad:      # also adds d/d gradient-grid into g_gg (folded into the SDF gradient below)
+            self._run("march_bwd", L.esr_coarse_march_bwd_ga, sp, _lib.ptr(bt["rays_o"]), _lib.ptr(bt["rays_d"]),
+                      _lib.ptr(bt["viewdirs"]), _lib.ptr(ctx["mask_density"]), _lib.ptr(ctx["sm"]), _lib.ptr(ctx["gg"]), n,
+                      _lib.ptr(ctx["off3"]), _lib.ptr(dweight), _lib.ptr(g_last), _lib.ptr(g_sm), _lib.ptr(g_gg), s)
+        else:
+            self._run("march_bwd", L.esr_coarse_march_bwd, sp, _lib.ptr(bt["rays_o"]), _lib.ptr(bt["rays_d"]),
+                      _lib.ptr(ctx["mask_density"]), _lib.ptr(ctx["sm"]), n, _lib.ptr(ctx["off3"]), _lib.ptr(dweight),
+                      _lib.ptr(g_last), _lib.ptr(g_sm), s)
         self._run("gauss3d_bwd", L.esr_gauss3d_bwd, _lib.ptr(g_sm), ctx["kernel_w"], ctx["ksize"], *dims,
                   _lib.ptr(grads["sdf"]), s)
         self._run("central_grad_bwd", L.esr_central_grad_bwd, _lib.ptr(g_gg), *dims, C.c_float(ctx["voxel"]),
@@ -245,8 +260,8 @@ class VoxurfC(nn.Module):
         for k, v in want.items():
             if getattr(self, k) != v:
                 raise NotImplementedError(f"libesr_hip kernels are built for {k}={v}, got {getattr(self, k)}")
-        if self.neus_alpha != "interp":
-            raise NotImplementedError("only neus_alpha='interp' (cfg/app/coarse.yaml:30) is on the HIP path")
+        if self.neus_alpha not in ("interp", "grad"):
+            raise ValueError(f"neus_alpha must be 'interp' or 'grad' (functions.py:45-105), got {self.neus_alpha!r}")
         if self.smooth_ksize > 7 or self.smooth_ksize % 2 == 0:
             raise NotImplementedError("esr_gauss3d_* support odd kernel sizes up to 7")
 
@@ -282,6 +297,7 @@ class VoxurfC(nn.Module):
                 raise RuntimeError("VoxurfC.forward_training runs on libesr_hip.so and needs a GPU device "
                                    "(there is no CPU fallback)")
             self._engine = CoarseEngine(self.device, getattr(self, "mlp_dtype", "f32"))
+            self._engine.neus_grad = self.neus_alpha == "grad"
         return self._engine
 
     def scene_struct(self):

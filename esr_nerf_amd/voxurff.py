@@ -155,10 +155,8 @@ class VoxurfF(nn.Module):
             raise NotImplementedError("libesr_hip kernels are built for 4 grad_feat radii")
         if self.neus_alpha not in ("interp", "grad"):
             raise ValueError(f"neus_alpha must be 'interp' or 'grad' (functions.py:45-105), got {self.neus_alpha!r}")
-        if self.neus_alpha == "grad" and type(self).__name__ != "VoxurfF":
-            # the LTS renderer's grad mode extrapolates with the EXACT gradient (sample_sdf_expgrad); only the fine
-            # renderer's finite-difference form is on the HIP path
-            raise NotImplementedError("neus_alpha='grad' is on the HIP path for VoxurfF only")
+        # (ESRNeRF's grad mode passes the same radius-1 finite-difference gradient to the alpha -- esrnerf.py:587-591,
+        # 700-706, sample_sdf_grad / sample_sdf_expgrad_grad_normal -- so its marches use the same kernels)
 
     @property
     def engine(self) -> FineEngine:

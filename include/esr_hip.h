@@ -645,6 +645,26 @@ int esr_coarse_march_bwd(const esr_scene_t *scene, const float *rays_o, const fl
                          float *grad_sdf_smooth, void *stream);
 
 /*
+ * The coarse march under cfg neus_alpha: "grad" (app/coarse/model/voxurfc.py:171-174, 204-210;
+ * app/utils/base/functions.py:45-69): section SDFs extrapolated with the trilinear sample of the dense gradient grid
+ * gg [X,Y,Z,3] (esr_central_grad_fwd of the unsmoothed SDF grid) along the batch's view directions.  The backward adds
+ * d/d gg into grad_gg [X,Y,Z,3] (zero-initialised or already holding the normal features' share), which
+ * esr_central_grad_bwd folds into the SDF gradient.
+ */
+int esr_coarse_march_count_ga(const esr_scene_t *scene, const float *rays_o, const float *rays_d, const float *viewdirs,
+                              const float *mask_density, const float *sdf_smooth, const float *gg, int32_t n_rays,
+                              int32_t *cnt3, float *alphainv_last, float *cum_weights, int32_t *ray_stats,
+                              esr_plan_t *plan, void *stream);
+int esr_coarse_march_fill_ga(const esr_scene_t *scene, const float *rays_o, const float *rays_d, const float *viewdirs,
+                             const float *mask_density, const float *sdf_smooth, const float *gg, int32_t n_rays,
+                             const int32_t *off3, int32_t *rec_ray, int32_t *rec_step, float *rec_w, float *rec_sdf,
+                             void *stream);
+int esr_coarse_march_bwd_ga(const esr_scene_t *scene, const float *rays_o, const float *rays_d, const float *viewdirs,
+                            const float *mask_density, const float *sdf_smooth, const float *gg, int32_t n_rays,
+                            const int32_t *off3, const float *dweight, const float *dlast, float *grad_sdf_smooth,
+                            float *grad_gg, void *stream);
+
+/*
  * Per-sample features of the coarse renderer (app/coarse/model/voxurfc.py:221-250) on the march
  * records.  grad_grid [gx,gy,gz,3] (esr_central_grad_fwd), off_color / emo_color [gx,gy,gz,12]
  * channels-last.  X [tiles,72,32] rows: 0-11 off colour | 12-23 emo colour (on-tiles) | 24-26 normal

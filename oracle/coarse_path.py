@@ -61,7 +61,14 @@ def make_consts(cfg_model, xyz_min, xyz_max, mask_xyz_min, mask_xyz_max, mask_al
         mask_density=pooled, act_shift=math.log(1 / (1 - mask_alpha_init) - 1),
         maskcache_thres=float(cfg_model.maskcache_thres), fastcolor_thres=float(cfg_model.fastcolor_thres),
         grad_feat=torch.zeros(0), posbase_pe=int(cfg_model.posbase_pe), viewbase_pe=int(cfg_model.viewbase_pe),
-        colorbase_pe=0)
+        colorbase_pe=0, neus_alpha=str(getattr(cfg_model, "neus_alpha", "interp")))
+
+
+def _alpha(c, viewdirs, ray_id, dist, sdf, grad, s_val):
+    """voxurfc.py:171-174, 207-210: the configured NeuS alpha; "grad" extrapolates with the SAMPLED dense gradient."""
+    if c.neus_alpha == "grad":
+        return fp.neus_alpha_grad(viewdirs, ray_id, dist, sdf, grad, s_val)
+    return fp.neus_alpha_interp(sdf, ray_id, s_val)
 
 
 def forward_training(P: Dict[str, Tensor], c: fp.FineConsts, batch: Dict[str, Tensor], s_val: float,
@@ -81,7 +88,7 @@ def forward_training(P: Dict[str, Tensor], c: fp.FineConsts, batch: Dict[str, Te
     norm = fp.to_norm(pts, c.xyz_min, c.xyz_max)
     sdf = fp.sample_grid(sm, norm)[:, 0]
     grad = fp.sample_grid(dense_gradient(P["sdf.grid"], c.voxel_size), norm)
-    alpha = fp.neus_alpha_interp(sdf, ray_id, s_val)
+    alpha = _alpha(c, viewdirs, ray_id, torch.as_tensor(float(stepdist)), sdf, grad, s_val)
     weights, _ = fp._Composite.apply(alpha, ray_id, N)
     m = weights > c.fastcolor_thres
     pts, ray_id, alpha, grad, norm = pts[m], ray_id[m], alpha[m], grad[m], norm[m]
@@ -133,7 +140,7 @@ def forward_evaluate(P: Dict[str, Tensor], c: fp.FineConsts, batch: Dict[str, Te
     norm = fp.to_norm(pts, c.xyz_min, c.xyz_max)
     sdf = fp.sample_grid(smooth_grid(P["sdf.grid"], gaussian_kernel(ksize, sigma)), norm)[:, 0]
     grad = fp.sample_grid(dense_gradient(P["sdf.grid"], c.voxel_size), norm)
-    alpha = fp.neus_alpha_interp(sdf, ray_id, s_val)
+    alpha = _alpha(c, viewdirs, ray_id, torch.as_tensor(float(stepdist)), sdf, grad, s_val)
     weights, _ = fp._Composite.apply(alpha, ray_id, N)
     m = weights > c.fastcolor_thres
     pts, ray_id, step_id, alpha, grad, norm = pts[m], ray_id[m], step_id[m], alpha[m], grad[m], norm[m]

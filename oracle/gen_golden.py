@@ -166,6 +166,8 @@ def main():
         gen_coarse_eval(ns, mask)
         gen_lts_eval(ns, mask)
     gen_lts(ns, "prune", "fib")
+    gen_coarse(ns, "prune", neus_alpha="grad")
+    gen_lts(ns, "prune", neus_alpha="grad")
 
 
 def gen_host(ns):
@@ -297,12 +299,12 @@ def lts_reference_loss(ns, results, rgbs, cfg):
     return loss
 
 
-def gen_lts(ns, mask="full", sampling="random"):
+def gen_lts(ns, mask="full", sampling="random", neus_alpha="interp"):
     """ESRNeRF.forward_training (lts and pdra mode) on the small oblique slab, with every random draw
     of the reference recorded so that restatements can be fed the same numbers.  ``sampling="fib"``: the
     ``ray_sampling: fib`` variant (esrnerf.py:188-192; deterministic Fibonacci-spiral scattering directions)."""
     from esr_nerf_amd.config import lts_cfg
-    cfg = lts_cfg("cpu", num_2ndrays=8, num_ltspts=12, ray_sampling=sampling)
+    cfg = lts_cfg("cpu", num_2ndrays=8, num_ltspts=12, ray_sampling=sampling, neus_alpha=neus_alpha)
     sc = slab_scene("g16", s_val=60.0, oblique=True, mask=mask)
     torch.manual_seed(0)
     np.random.seed(0)
@@ -321,7 +323,7 @@ def gen_lts(ns, mask="full", sampling="random"):
                 assert np.array_equal(z[k], v.detach().numpy()), k     # same parameters under every mask variant
     b = dict(sc.batch)
     b["uncert_masks"] = (torch.arange(sc.n_rays) % 3 == 0)
-    for mode in (("lts", "pdra") if sampling == "random" else ("lts",)):
+    for mode in (("lts", "pdra") if (sampling == "random" and neus_alpha == "interp") else ("lts",)):
         model.pdra_mode = mode == "pdra"
         model.zero_grad(set_to_none=True)
         rec = {"randn": [], "randn_like": []}
@@ -368,7 +370,8 @@ def gen_lts(ns, mask="full", sampling="random"):
         for k, p in model.named_parameters():
             if p.grad is not None:
                 out["grad/" + k] = p.grad.detach().numpy()
-        np.savez_compressed(os.path.join(OUT, f"lts_g16_{mode}{_sfx(mask)}{'' if sampling == 'random' else '_' + sampling}.npz"), **out)
+        tail = ("" if sampling == "random" else "_" + sampling) + ("" if neus_alpha == "interp" else "_gradalpha")
+        np.savez_compressed(os.path.join(OUT, f"lts_g16_{mode}{_sfx(mask)}{tail}.npz"), **out)
         print("lts", mode, "loss", float(loss), "M3", res_raw["etc/normal"].shape[0],
               "grads", sum(1 for k in out if k.startswith("grad/")))
 
@@ -520,12 +523,13 @@ def gen_lts_eval(ns, mask="full"):
     print("lts eval: chunks", len(rec), "keys", len(res1), len(res0))
 
 
-def gen_coarse(ns, mask="full"):
-    """VoxurfC.forward_training + the loss lines of coarse.py:341-352 on the small oblique slab (A17)."""
+def gen_coarse(ns, mask="full", neus_alpha="interp"):
+    """VoxurfC.forward_training + the loss lines of coarse.py:341-352 on the small oblique slab (A17).
+    ``neus_alpha="grad"``: the cfg variant of voxurfc.py:171-174 (section SDFs extrapolated with the sampled gradient)."""
     from esr_nerf_amd.config import coarse_cfg
     from esr_nerf_amd.synthetic import analytic_sdf
     sc = slab_scene("g16", s_val=8.0, oblique=True, mask=mask)
-    cfg = coarse_cfg("cpu", num_voxels=sc.num_voxels)
+    cfg = coarse_cfg("cpu", num_voxels=sc.num_voxels, neus_alpha=neus_alpha)
     torch.manual_seed(0)
     np.random.seed(0)
     model = ns.VoxurfC(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max,
@@ -561,7 +565,8 @@ def gen_coarse(ns, mask="full"):
         for k, p_ in model.named_parameters():
             if p_.grad is not None:
                 out["grad/" + k] = p_.grad.detach().numpy()
-        np.savez_compressed(os.path.join(OUT, f"coarse_g16_s{int(s_val)}{_sfx(mask)}.npz"), **out)
+        tail = "" if neus_alpha == "interp" else "_gradalpha"
+        np.savez_compressed(os.path.join(OUT, f"coarse_g16_s{int(s_val)}{_sfx(mask)}{tail}.npz"), **out)
         print("coarse s_val", s_val, "loss", float(loss), "grads", sum(1 for k in out if k.startswith("grad/")))
 
 

@@ -172,6 +172,17 @@ def _march(P, c: fp.FineConsts, rays_o, rays_d, near, s_val, counts: Optional[li
     return N, pts[m], ray_id[m]
 
 
+def _alpha(c, P, pts, ray_id, viewdirs, sdf, s_val):
+    """The configured NeuS alpha of one march (esrnerf.py:197-200).  "grad": section SDFs extrapolated with the radius-1
+    finite-difference gradient of ``sample_sdf_grad`` (esrnerf.py:1519-1525; its + 1e-12 guard included) along the
+    rays' view directions -- for the secondary rays those are their own directions (esrnerf.py:575-591)."""
+    if c.neus_alpha == "grad":
+        _, g1, _ = fp.sdf_stencil(c, P["sdf.grid"], pts, torch.tensor([1.0]), diff_eps=1e-12)
+        grad = torch.cat([g1[:, [2]], g1[:, [1]], g1[:, [0]]], -1)
+        return fp.neus_alpha_grad(viewdirs, ray_id, c.stepsize * c.voxel_size, sdf, grad, s_val)
+    return fp.neus_alpha_interp(sdf, ray_id, s_val)
+
+
 def _stencil(c, grid, pts):
     return fp.sdf_stencil(c, grid, pts, c.grad_feat, diff_eps=1e-12)
 
@@ -185,7 +196,7 @@ def forward_training(P: Dict[str, Tensor], c: fp.FineConsts, batch: Dict[str, Te
     N, pts, ray_id = _march(P, c, rays_o, rays_d, c.near, s_val, prim_counts)
     prim_counts.pop()
     sdf, expg = sdf_expgrad(c, P["sdf.grid"], pts)
-    alpha = fp.neus_alpha_interp(sdf, ray_id, s_val)
+    alpha = _alpha(c, P, pts, ray_id, viewdirs, sdf, s_val)
     m = alpha > c.fastcolor_thres
     alpha, pts, ray_id, sdf, expg = alpha[m], pts[m], ray_id[m], sdf[m], expg[m]
     prim_counts.append(int(pts.shape[0]))
@@ -272,7 +283,7 @@ def light_transport_segment(P, c, pts, viewdirs, normal, sdf, base, rough, metal
     N2, p2, rid = _march(P, c, o2, d2, lts_near, s_val, sec_counts)
     sid2 = sec_counts.pop()                                   # step ids of the mask-cache survivors (bookkeeping)
     s2 = fp.sample_grid(P["sdf.grid"], fp.to_norm(p2, c.xyz_min, c.xyz_max))[:, 0]
-    a2 = fp.neus_alpha_interp(s2, rid, s_val) if s2.numel() > 1 else s2.new_zeros(s2.shape)
+    a2 = _alpha(c, P, p2, rid, d2, s2, s_val) if s2.numel() > 1 else s2.new_zeros(s2.shape)
     m = a2 > c.fastcolor_thres
     a2, p2, rid, s2, sid2 = a2[m], p2[m], rid[m], s2[m], sid2[m]
     sec_counts.append(int(p2.shape[0]))
@@ -379,7 +390,7 @@ def forward_finetune(P: Dict[str, Tensor], c: fp.FineConsts, batch: Dict[str, Te
     with torch.no_grad():
         N, pts, ray_id = _march(P, c, rays_o, rays_d, c.near, s_val)
         sdf = fp.sample_grid(P["sdf.grid"], fp.to_norm(pts, c.xyz_min, c.xyz_max))[:, 0]
-        alpha = fp.neus_alpha_interp(sdf, ray_id, s_val)
+        alpha = _alpha(c, P, pts, ray_id, viewdirs, sdf, s_val)
         m = alpha > c.fastcolor_thres
         alpha, pts, ray_id = alpha[m], pts[m], ray_id[m]
         weights, _ = fp._Composite.apply(alpha, ray_id, N)
@@ -408,7 +419,7 @@ def forward_finetune(P: Dict[str, Tensor], c: fp.FineConsts, batch: Dict[str, Te
                                torch.cat([-ex(vd), -ex(v_rand)], 0))
         N2, p2, rid = _march(P, c, o2, d2, lts_near, s_val)
         s2 = fp.sample_grid(P["sdf.grid"], fp.to_norm(p2, c.xyz_min, c.xyz_max))[:, 0]
-        a2 = fp.neus_alpha_interp(s2, rid, s_val) if s2.numel() > 1 else s2.new_zeros(s2.shape)
+        a2 = _alpha(c, P, p2, rid, d2, s2, s_val) if s2.numel() > 1 else s2.new_zeros(s2.shape)
         m = a2 > c.fastcolor_thres
         a2, p2, rid, s2 = a2[m], p2[m], rid[m], s2[m]
         w2, _ = fp._Composite.apply(a2, rid, N2)
@@ -430,7 +441,7 @@ def _primary_survivors(P, c, batch, s_val):
     rays_o, rays_d = batch["rays_o"], batch["rays_d"]
     N, pts, ray_id = _march(P, c, rays_o, rays_d, c.near, s_val)
     sdf = fp.sample_grid(P["sdf.grid"], fp.to_norm(pts, c.xyz_min, c.xyz_max))[:, 0]
-    alpha = fp.neus_alpha_interp(sdf, ray_id, s_val)
+    alpha = _alpha(c, P, pts, ray_id, batch["viewdirs"], sdf, s_val)
     m = alpha > c.fastcolor_thres
     alpha, pts, ray_id, sdf = alpha[m], pts[m], ray_id[m], sdf[m]
     weights, _ = fp._Composite.apply(alpha, ray_id, N)
@@ -467,7 +478,7 @@ def _evaluate_lts(P, c, pts, viewdirs, normal, base, rough, metal, emit, raw_dir
     Rf = disney_reflection(ex(base), ex(rough), ex(metal), ex(normal), d2, -ex(viewdirs))
     N2, p2, rid = _march(P, c, ex(pts), d2, lts_near, s_val)
     s2 = fp.sample_grid(P["sdf.grid"], fp.to_norm(p2, c.xyz_min, c.xyz_max))[:, 0]
-    a2 = fp.neus_alpha_interp(s2, rid, s_val) if s2.numel() > 1 else s2.new_zeros(s2.shape)
+    a2 = _alpha(c, P, p2, rid, d2, s2, s_val) if s2.numel() > 1 else s2.new_zeros(s2.shape)
     m = a2 > c.fastcolor_thres
     a2, p2, rid, s2 = a2[m], p2[m], rid[m], s2[m]
     w2, last2 = fp._Composite.apply(a2, rid, N2)
@@ -504,7 +515,7 @@ def forward_evaluate(P, c, batch, s_val, far, em_mode, pos_rt, render_pbr, chunk
     pts, ray_id, step_id = pts[m], ray_id[m], step_id[m]
     sdf, expg = sdf_expgrad(c, P["sdf.grid"], pts)
     sdf, expg = sdf.detach(), expg.detach()
-    alpha = fp.neus_alpha_interp(sdf, ray_id, s_val)
+    alpha = _alpha(c, P, pts, ray_id, viewdirs, sdf, s_val)
     m = alpha > c.fastcolor_thres
     alpha, pts, ray_id, step_id, sdf, expg = alpha[m], pts[m], ray_id[m], step_id[m], sdf[m], expg[m]
     weights, alphainv_last = fp._Composite.apply(alpha, ray_id, N)

@@ -30,18 +30,21 @@ def build_lts_model(scene, **over):
 
 
 @pytest.mark.parametrize("mode,mask", [("lts", "full"), ("pdra", "full"), ("lts", "prune"), ("pdra", "prune"),
-                                       ("lts", "prune_fib")])
+                                       ("lts", "prune_fib"), ("lts", "prune_gradalpha")])
 def test_lts_golden_reference_vectors(mode, mask):
     """``prune_fib``: ``ray_sampling: fib`` -- the engine builds the Fibonacci scattering table itself (the fixture
-    holds no direction draw), the surface points and the two noise draws are replayed."""
+    holds no direction draw), the surface points and the two noise draws are replayed.  ``prune_gradalpha``: cfg
+    ``neus_alpha: grad`` (esrnerf.py:197-200) -- primary and secondary march through the GA kernels."""
     from esr_nerf_amd.synthetic import slab_scene
     from oracle import lts_path as lp
-    fib = mask.endswith("_fib")
+    fib, ga = mask.endswith("_fib"), mask.endswith("_gradalpha")
     z = {k: torch.from_numpy(np.asarray(v)) for k, v in load_npz(f"lts_g16_{mode}{sfx(mask)}.npz").items()}
-    mask = mask.replace("_fib", "")
+    mask = mask.replace("_fib", "").replace("_gradalpha", "")
     sd = {k: torch.from_numpy(v) for k, v in load_npz("lts_g16_params.npz").items()}
     sc = slab_scene("g16", s_val=60.0, oblique=True, mask=mask)
-    m, cfg = build_lts_model(sc, num_2ndrays=8, num_ltspts=12, ray_sampling="fib" if fib else "random")
+    m, cfg = build_lts_model(sc, num_2ndrays=8, num_ltspts=12, ray_sampling="fib" if fib else "random",
+                             neus_alpha="grad" if ga else "interp")
+    assert m.engine.neus_grad == ga
     assert ("draw/dirs" in z) != fib and m.engine.ray_sampling == ("fib" if fib else "random")
     m.load_state_dict({k: v.cuda() for k, v in sd.items()})
     m.pdra_mode = (mode == "pdra")
@@ -138,7 +141,8 @@ def test_lts_internal_draws_run_and_are_finite():
 
 
 @pytest.mark.parametrize("mode,scene_name,n_rays,s_val,mask", [("lts", "tiny", 96, 45.0, "full"), ("pdra", "tiny", 64, 90.0, "full"),
-                                                                ("lts", "tiny", 160, 45.0, "prune"), ("pdra", "tiny", 128, 90.0, "prune")])
+                                                                ("lts", "tiny", 160, 45.0, "prune"), ("pdra", "tiny", 128, 90.0, "prune"),
+                                                                ("pdra", "tiny", 128, 60.0, "prune+ga"), ("lts", "tiny", 96, 45.0, "full+ga")])
 def test_lts_path_vs_oracle_linear_functional(mode, scene_name, n_rays, s_val, mask):
     """Every result tensor and every gradient against oracle/lts_path.py on scenes other than the fixture's.
     The scalar is a fixed random LINEAR functional of all 16 results, so each backward edge of the path
@@ -154,13 +158,15 @@ def test_lts_path_vs_oracle_linear_functional(mode, scene_name, n_rays, s_val, m
     from oracle import fine_path as fp
     from oracle import lts_path as lp
     R, Pn = 16, 20
+    ga, mask = mask.endswith("+ga"), mask.replace("+ga", "")          # +ga: cfg neus_alpha "grad" in both marches
+    alpha_mode = "grad" if ga else "interp"
     sc = slab_scene(scene_name, s_val=s_val, oblique=True, n_rays=n_rays, seed=11, mask=mask)
-    m, cfg = build_lts_model(sc, num_2ndrays=R, num_ltspts=Pn)
+    m, cfg = build_lts_model(sc, num_2ndrays=R, num_ltspts=Pn, neus_alpha=alpha_mode)
     init_slab_model(m, sc, seed=4)
     with torch.no_grad():
         m.brdf.grid.normal_(0.0, 0.3, generator=None)
     m.pdra_mode = (mode == "pdra")
-    ccfg = lts_cfg("cpu", num_2ndrays=R, num_ltspts=Pn)
+    ccfg = lts_cfg("cpu", num_2ndrays=R, num_ltspts=Pn, neus_alpha=alpha_mode)
     c = fp.make_consts(ccfg.app.model, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max, sc.mask_alpha_init,
                        sc.mask_density, sc.near, sc.num_voxels)
     sd = {k: v.detach().cpu().contiguous() for k, v in m.state_dict().items()}
