@@ -86,6 +86,10 @@ def parse():
     ap.add_argument("--oblique", action="store_true",
                     help="tilted, un-normalised ray directions (synthetic.slab_scene(oblique=True)): NOT BASELINE's workload "
                          "(its rays are axis-parallel) -- a robustness line for the kernels that exploit ray coherence")
+    ap.add_argument("--grid", type=int, default=None, choices=[256],
+                    help="C2 only: the production-size grid of the fine stage's end (cfg/app/fine.yaml:41-43), world "
+                         "256 x 256 x 256, same 4096 rays x 128 surviving samples (synthetic.CONFIGS['C2g256']) -- a labelled "
+                         "robustness line, NOT BASELINE's workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=None,
                     help="rays of the CPU baseline sample (default: the whole batch in the fine stage -- SURVEY 8(d): same N, "
@@ -313,6 +317,10 @@ def main():
     if a.config == "C5":
         a.config, a.stage, a.dtype = "C4", a.stage or "pdra", a.dtype or "bf16"
     a.dtype = a.dtype or "f32"
+    if a.grid:
+        if a.config != "C2":
+            raise SystemExit("--grid applies to --config C2")
+        a.config = f"C2g{a.grid}"
     stage = a.stage or ("lts" if a.config == "C4" else "fine")
     if a.s_val is None:
         a.s_val = 20.0 if stage == "fine" else 220.0
@@ -509,6 +517,16 @@ def main():
         torch.cuda.synchronize()
         opt_ms = (time.perf_counter() - t1) / 5 * 1e3
         n_params = sum(p.numel() for g_ in opt.param_groups for p in g_["params"])
+    # the per-step zero-fill of the flat gradient buffer (the reference's dense zeros_like(grid) allocations), timed alone:
+    # it is inside every step (on the side stream, beside the march) and grows with the grid
+    zero_ms = None
+    if not a.no_optimizer and getattr(step, "_flat", None) is not None:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            step._flat.zero_()
+        torch.cuda.synchronize()
+        zero_ms = (time.perf_counter() - t1) / 5 * 1e3
     # the trainer's every-third-iteration TV lines (fine.py:383-400), reported separately like the optimizer
     tv_ms = None
     if not a.no_optimizer and stage == "fine":
@@ -528,7 +546,8 @@ def main():
         samples = int(round(c["res"] * c["z"] * 2))
         out = {
             "metric": "training rays/sec at 4096 rays x 128 samples (fine stage)" if (a.config, stage, a.dtype, float(a.s_val), a.oblique) == ("C2", "fine", "f32", 20.0, False)
-                      else f"training rays/sec, config {a.config}, {stage} stage, {a.dtype} MLPs, s_val {a.s_val:g}" + (", OBLIQUE rays (not BASELINE's workload)" if a.oblique else ""),
+                      else f"training rays/sec, config {a.config}, {stage} stage, {a.dtype} MLPs, s_val {a.s_val:g}" + (", OBLIQUE rays (not BASELINE's workload)" if a.oblique else "")
+                           + (", PRODUCTION-SIZE GRID 256^3 (not BASELINE's workload)" if a.grid else ""),
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": a.dtype,
@@ -542,7 +561,7 @@ def main():
                                f"secondary rays per GPU ({eng.sec.counts.get('m3')} surviving secondary samples)")
                             + ("; fine-tune target: edited emission + its light transport, only emo_color / emo_rgbnet "
                                "train" if stage == "finetune" else ""),
-                "rays_per_gpu": n_rays, "samples_per_ray": samples, "surviving_samples": counts.get("m3"),
+                "rays_per_gpu": n_rays, "samples_per_ray": samples if not a.grid else 128, "surviving_samples": counts.get("m3"),
                 "parallelism": f"dp{world}",
             },
             "loss": float(loss),
@@ -551,6 +570,9 @@ def main():
             out["optimizer_step"] = {"ms": opt_ms, "parameters": n_params, "kernel": "esr_adam_step (fused Adam, 28 B/param)",
                                      "hbm_gbs": n_params * 28 / (opt_ms * 1e-3) / 1e9,
                                      "note": "reported separately, not part of value / ms_per_step"}
+        if zero_ms is not None:
+            out["grad_zero_fill"] = {"ms": zero_ms, "mb": step._flat.numel() * 4 / 1e6,
+                                     "note": "one memset of the flat gradient buffer per step; inside value / ms_per_step"}
         if tv_ms is not None:
             out["tv_terms"] = {"ms": tv_ms, "every": TV_EVERY, "kernels": "esr_smooth_grad_tv_fwd/bwd + esr_tv_add_grad",
                                "in_timed_steps": tv_in_step,

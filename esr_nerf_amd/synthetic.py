@@ -25,6 +25,10 @@ CONFIGS = {
     "tiny": dict(n_rays=64, z=0.25, res=64),          # 32 samples, golden-vector size
     "small": dict(n_rays=512, z=0.25, res=128),       # 64 samples
     "g16": dict(n_rays=48, z=0.25, res=32),           # 16 samples, committed golden fixtures
+    # production-size grid (cfg/app/fine.yaml:41-43: the fine stage ends at 256^3): the cube (-1,-1,-1)..(1,1,1) at 256
+    # voxels per axis; the mask cache's box is the slab |z| < 0.25 (the occupied part of a real scene is a fraction of
+    # its box), so an axis-parallel ray walks 512 steps through the box and keeps C2's 128 samples
+    "C2g256": dict(n_rays=4096, z=1.0, res=256, mask_z=0.25),
 }
 
 
@@ -103,6 +107,8 @@ def slab_scene(name: str = "C2", s_val: float = 20.0, seed: int = 0, n_rays: int
     else:
         assert mask == "full", mask
         mask_density, mlo, mhi = torch.full((1, 1, 32, 32, 32), 30.0), xyz_min.clone(), xyz_max.clone()
+        if "mask_z" in c:                                               # mask box = a slab inside the scene box
+            mlo[2], mhi[2] = -float(c["mask_z"]), float(c["mask_z"])
     return SlabScene(
         name=name, n_rays=n, xyz_min=xyz_min, xyz_max=xyz_max, num_voxels=num_voxels,
         near=0.05, far=6.0, mask_density=mask_density, mask_xyz_min=mlo, mask_xyz_max=mhi,

@@ -425,3 +425,53 @@ def test_c5_full_size_pdra_bf16_tracks_fp32_and_finetune_vs_oracle():
     r16, l16, g16 = res["bf16"]
     assert rel_err(r16["lin/pbr/emo"], r32["lin/pbr/emo"]) < 2e-2 and rel_err(r16["lin/pbr/emo_hat"], r32["lin/pbr/emo_hat"]) < 2e-2
     assert abs(l16 - l32) < 2e-2 * max(abs(l32), 1e-6)
+
+
+def test_production_size_grid_256_ray_subset_vs_oracle():
+    """The fine stage ends at 256^3 (cfg/app/fine.yaml:41-43; colour grids 403 MB each -- beyond the 256 MB memory-side
+    cache -- 218 M parameters): `synthetic.CONFIGS["C2g256"]`, the cube at 256 voxels per axis with the mask cache's box
+    on the slab |z| < 0.25, so a ray walks ~512 steps through the box and keeps ~128 samples.  512 oblique rays (the
+    oracle's autograd holds the dense 256^3 gradients on the host) against oracle/fine_path.py: survivor counts exact,
+    outputs, loss, all 23 gradients; then ONE fused-Adam step over all 218 M parameters against the reference's update
+    rule on the host."""
+    from esr_nerf_amd.optimizer import create_optimizer_or_freeze_model
+    from esr_nerf_amd.synthetic import slab_scene
+    from esr_nerf_amd.trainer import FineStep
+    sc = slab_scene("C2g256", s_val=40.0, n_rays=512, oblique=True, seed=3)
+    m = _fine_model(sc)
+    assert [int(v) for v in m.world_size] == [256, 256, 256]
+    b = {k: v.cuda() for k, v in sc.batch.items()}
+    step = FineStep(m)
+    loss, grads = step.forward_loss_backward(b, 40.0)
+    torch.cuda.synchronize()
+    loss, grads = float(loss), {k: v.clone() for k, v in grads.items()}
+    lc = m.last_counts
+    assert lc["m0"] > 2.5 * lc["m1"] > 0 and lc["m1"] >= lc["m2"] >= lc["m3"] > 0           # the slab mask prunes ~3/4
+    fp, c, P = _fine_oracle(m, sc)
+    fp.KNIFE_LOG = []                     # hidden units with a sample on their ReLU kink (65 k samples: a single sample is
+    res, o_loss, keep = _oracle_fine(fp, c, P, sc, 40.0)     # 1.5e-4 of a weight-gradient row, see _compare_grads)
+    fp_log, fp.KNIFE_LOG = fp.KNIFE_LOG, None
+    n0, n1, n2, n3 = keep["counts"]
+    assert (lc["m0"], lc["m1"], lc["m2"]) == (n0, n1, n2)
+    odd = _check_survivor_sets(_survivors(m), keep["ray_id"], keep["step_id"], keep["weights"], sc.batch["rays_o"],
+                               sc.batch["rays_d"], c, sc.near)
+    assert abs(lc["m3"] - n3) <= len(odd) <= 3, (lc["m3"], n3, len(odd))
+    assert abs(loss - o_loss) < 1e-5 * max(1.0, abs(o_loss))
+    out = m(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=b["em_modes"], s_val=40.0)
+    for k in res:
+        assert rel_err(out[k], res[k]) < TOL, (k, rel_err(out[k], res[k]))
+    # (measured marked shares: SDF 0.043, colour 0.033 / 0.023 -- inside the default caps)
+    _compare_grads(grads, P, [(keep["pts"], keep["knife"]), (odd, torch.zeros(len(odd)))], c, 23, fp_log=fp_log)
+    # one fused Adam step at this size (first step from zero moments: update = -lr * g / (|g| + eps) where g != 0)
+    lrs = dict(off_color=0.1, off_rgbnet=0.003, emo_color=0.1, emo_rgbnet=0.003, sdf=0.005, tonemapper=0.003)
+    opt = create_optimizer_or_freeze_model(m, **lrs)
+    before = {k: v.detach().clone() for k, v in m.state_dict().items() if k in grads}
+    step.assign_grads(grads)
+    opt.step()
+    torch.cuda.synchronize()
+    for k in ("sdf.grid", "off_color.grid", "emo_color.grid"):
+        g, p0, p1 = grads[k], before[k], m.state_dict()[k]
+        lr = lrs[k.split(".")[0]]
+        want = p0 - lr * g / (g.abs() + 1e-8)                      # bias-corrected first step of Adam (optimizer.py:213-228)
+        assert rel_err(p1, want) < 1e-5, k
+        assert bool((p1[g == 0] == p0[g == 0]).all())              # untouched cells do not move (skip-zero-grad rule)
