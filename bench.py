@@ -540,6 +540,14 @@ def main():
         torch.cuda.synchronize()
         tv_ms = (time.perf_counter() - t1) / 5 * 1e3
 
+    # fixed costs of the brick exchange (HIP events; EVERY rank: the phases contain collectives; with one rank they are
+    # local): flags / union / list / pack / all-reduce / unpack -- what the driver's multi-GPU runs can be read against
+    phases = None
+    if pg is not None and step is not None and getattr(step, "_flat", None) is not None and not rehearsal:
+        from esr_nerf_amd.grad_sync import GridGradSync
+        prof = getattr(step, "_sync", None) or GridGradSync(pg)
+        phases = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in prof.profile(step._flat[: step._n_grid]).items()}
+
     if rank == 0:
         value = n_rays * world * a.steps / dt
         c = CONFIGS[a.config]
@@ -669,6 +677,8 @@ def main():
                            "grad_sync": getattr(step, "sync_mode_used", None),
                            "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}
         sync = getattr(step, "_sync", None)
+        if phases is not None:
+            out["grad_exchange_phases_ms"] = phases
         if sync is not None:
             # data-parallel exchange of the dense-grid gradients (esr_nerf_amd/grad_sync.py), last step of rank 0
             out["grad_exchange"] = dict(sync.last, brick_bytes=sync.brick * 4,

@@ -76,9 +76,105 @@ __global__ void __launch_bounds__(256) brick_move_kernel(float *__restrict__ g, 
     }
 }
 
+// ---- the union's brick list, built on the device (one call instead of six torch launches: to(int64), cumsum, where,
+// full, arange, scatter_ over ~4e5 - 2e6 bricks inside the step) ------------------------------------------------------
+// LIST_BLOCKS workgroups own contiguous chunks of the flags.  Pass 1: flagged bricks per chunk.  Pass 2: every
+// workgroup sums the chunk counts in front of it (<= 256 ints), ranks its own flags with a block scan and writes
+// idx[rank] = brick for rank < cap; slots [total, cap) get -1; workgroup 0 publishes the total.
+constexpr int LIST_BLOCKS = 256, LIST_THREADS = 256;
+
+__device__ __forceinline__ int block_scan_excl(int v, int *tmp, int &total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int u = __shfl_up(inc, off);
+        if (lane >= off) inc += u;
+    }
+    if (lane == 63) tmp[w] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < LIST_THREADS / 64; ++k) {
+        const int t = tmp[k];
+        if (k < w) base += t;
+        tot += t;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+__global__ void __launch_bounds__(LIST_THREADS) brick_count_kernel(const uint8_t *__restrict__ flags, int64_t nb,
+                                                                   int *__restrict__ counts)
+{
+    __shared__ int tmp[LIST_THREADS / 64];
+    const int64_t chunk = (nb + LIST_BLOCKS - 1) / LIST_BLOCKS, per = (chunk + LIST_THREADS - 1) / LIST_THREADS;
+    const int64_t b0 = blockIdx.x * chunk, e0 = min(b0 + chunk, nb);
+    const int64_t lo = min(b0 + threadIdx.x * per, e0), hi = min(lo + per, e0);
+    int c = 0;
+    for (int64_t i = lo; i < hi; ++i) c += flags[i] != 0;
+    int total;
+    block_scan_excl(c, tmp, total);
+    if (threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(LIST_THREADS) brick_list_kernel(const uint8_t *__restrict__ flags, int64_t nb, int64_t cap,
+                                                                  const int *__restrict__ counts, int64_t *__restrict__ idx,
+                                                                  int64_t *__restrict__ count_out)
+{
+    __shared__ int tmp[LIST_THREADS / 64];
+    // chunk counts in front of this workgroup, and all of them
+    int mine = 0, all = 0;
+    {
+        const int c = counts[threadIdx.x];                  // LIST_BLOCKS == LIST_THREADS
+        int tot;
+        const int ex = block_scan_excl(c, tmp, tot);
+        __shared__ int base_s;
+        if (threadIdx.x == blockIdx.x) base_s = ex;
+        __syncthreads();
+        mine = base_s;
+        all = tot;
+    }
+    const int64_t chunk = (nb + LIST_BLOCKS - 1) / LIST_BLOCKS, per = (chunk + LIST_THREADS - 1) / LIST_THREADS;
+    const int64_t b0 = blockIdx.x * chunk, e0 = min(b0 + chunk, nb);
+    const int64_t lo = min(b0 + threadIdx.x * per, e0), hi = min(lo + per, e0);
+    int c = 0;
+    for (int64_t i = lo; i < hi; ++i) c += flags[i] != 0;
+    int total;
+    int64_t r = mine + block_scan_excl(c, tmp, total);
+    for (int64_t i = lo; i < hi; ++i)
+        if (flags[i]) {
+            if (r < cap) idx[r] = i;
+            ++r;
+        }
+    // unused slots of the fixed-capacity list
+    for (int64_t k = all + blockIdx.x * (int64_t)LIST_THREADS + threadIdx.x; k < cap; k += (int64_t)LIST_BLOCKS * LIST_THREADS)
+        idx[k] = -1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = all;
+}
+
 }  // namespace
 
 ESR_API int esr_brick_floats(void) { return BRICK; }
+
+ESR_API int64_t esr_brick_list_scratch_ints(void) { return LIST_BLOCKS; }
+
+// idx[0 .. cap): the first `cap` flagged bricks in ascending order, then -1; *count = number of flagged bricks (may exceed
+// cap: the caller sends the overflow in a second pass).  scratch: esr_brick_list_scratch_ints() ints.
+ESR_API int esr_brick_list(const uint8_t *flags, int64_t n_bricks, int64_t cap, int64_t *idx, int64_t *count,
+                           int32_t *scratch, void *stream)
+{
+    if (n_bricks < 0 || cap < 0) return ESR_EINVAL;
+    if (!count || (n_bricks && !flags) || (cap && !idx) || !scratch) return ESR_EINVAL;
+    hipStream_t s = esr_stream(stream);
+    brick_count_kernel<<<LIST_BLOCKS, LIST_THREADS, 0, s>>>(flags, n_bricks, scratch);
+    ESR_CHECK_LAUNCH();
+    brick_list_kernel<<<LIST_BLOCKS, LIST_THREADS, 0, s>>>(flags, n_bricks, cap, scratch, idx, count);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
 
 ESR_API int esr_brick_flags(const float *buf, int64_t n, uint8_t *flags, void *stream)
 {

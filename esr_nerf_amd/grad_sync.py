@@ -56,6 +56,18 @@ class HipBrickOps:
                                          C.c_int64(idx.numel()), _lib.ptr(packed),
                                          _lib.stream_ptr(flat.device)), "esr_brick_pack")
 
+    def list(self, flags: torch.Tensor, cap: int):
+        """(idx [cap] int64: the first ``cap`` flagged bricks ascending, unused slots -1; count [1] int64 on the device)
+        in ONE call (esr_brick_list) -- the torch form is six launches over all bricks inside the step."""
+        dev = flags.device
+        if getattr(self, "_scratch", None) is None or self._scratch.device != dev:
+            self._scratch = torch.empty(int(self.L.esr_brick_list_scratch_ints()), dtype=torch.int32, device=dev)
+        idx = torch.empty(cap, dtype=torch.int64, device=dev)
+        count = torch.empty(1, dtype=torch.int64, device=dev)
+        _lib.check(self.L.esr_brick_list(_lib.ptr(flags), C.c_int64(flags.numel()), C.c_int64(cap), _lib.ptr(idx),
+                                         _lib.ptr(count), _lib.ptr(self._scratch), _lib.stream_ptr(dev)), "esr_brick_list")
+        return idx, count
+
     def unpack(self, packed: torch.Tensor, idx: torch.Tensor, flat: torch.Tensor):
         _lib.check(self.L.esr_brick_unpack(_lib.ptr(packed), _lib.ptr(idx), C.c_int64(idx.numel()),
                                            _lib.ptr(flat), C.c_int64(flat.numel()),
@@ -74,7 +86,7 @@ class GridGradSync:
         self._flags: Optional[torch.Tensor] = None
         self._packed: Optional[torch.Tensor] = None
         self._cap: Optional[int] = None           # capacity (bricks) of this step's list; None: learn it first
-        self._pending = None                      # (flat, rank_of_brick, count_host, event, cap) of the open step
+        self._pending = None                      # (flat, count_host, event, cap) of the open step
         self.last = dict(bricks=0, sent=0, mode="none")
 
     # ------------------------------------------------------------------ helpers
@@ -121,41 +133,95 @@ class GridGradSync:
                 self.last = dict(bricks=nb, sent=k, union=k, mode="sparse")
             return
         cap = min(self._cap, nb)
-        on = self._flags.to(torch.int64)
-        rank_of = torch.cumsum(on, 0) - 1                       # position of a flagged brick in the union's list
+        dense = cap >= self.dense_above * nb
         count_host = torch.empty(1, dtype=torch.int64, pin_memory=flat.is_cuda)
-        count_host.copy_(rank_of[-1:] + 1, non_blocking=True)
+        if hasattr(self.ops, "list"):
+            # list of capacity `cap` and the union's count built by ONE device call (csrc/brick.hip: esr_brick_list)
+            idx, count_dev = self.ops.list(self._flags, 0 if dense else cap)
+            count_host.copy_(count_dev, non_blocking=True)
+        else:
+            # torch form (the CPU test double): slot r <- the r-th flagged brick; bricks of rank >= cap (the union
+            # outgrew the capacity) and unflagged bricks all fall into a dump slot; unused slots stay -1
+            on = self._flags.to(torch.int64)
+            rank_of = torch.cumsum(on, 0) - 1                   # position of a flagged brick in the union's list
+            count_host.copy_(rank_of[-1:] + 1, non_blocking=True)
+            if not dense:
+                slot = torch.where((on > 0) & (rank_of < cap), rank_of, torch.full_like(rank_of, cap))
+                idx = torch.full((cap + 1,), -1, dtype=torch.int64, device=flat.device)
+                idx.scatter_(0, slot, torch.arange(nb, dtype=torch.int64, device=flat.device))
+                idx = idx[:cap]
         ev = None
         if flat.is_cuda:
             ev = torch.cuda.Event()
             ev.record()
-        if cap >= self.dense_above * nb:
+        if dense:
             dist.all_reduce(flat, group=self.pg)
-            self._pending = (None, None, count_host, ev, nb)
+            self._pending = (None, count_host, ev, nb)
             self.last = dict(bricks=nb, sent=nb, mode="dense")
             return
-        # list of capacity `cap` built on the device: slot r <- the r-th flagged brick; bricks of rank >= cap (the
-        # union outgrew the capacity) and unflagged bricks all fall into a dump slot; unused slots stay -1
-        slot = torch.where((on > 0) & (rank_of < cap), rank_of, torch.full_like(rank_of, cap))
-        idx = torch.full((cap + 1,), -1, dtype=torch.int64, device=flat.device)
-        idx.scatter_(0, slot, torch.arange(nb, dtype=torch.int64, device=flat.device))
-        self._exchange(flat, idx[:cap])
-        self._pending = (flat, rank_of, count_host, ev, cap)
+        self._exchange(flat, idx)
+        self._pending = (flat, count_host, ev, cap)
         self.last = dict(bricks=nb, sent=cap, mode="sparse")
+
+    @torch.no_grad()
+    def profile(self, flat: torch.Tensor, reps: int = 5):
+        """Milliseconds of every phase of one sparse exchange of ``flat`` (HIP events on the current stream, mean of
+        ``reps``): what the data-parallel step pays before / beside the wire time.  With a one-rank group the two
+        collectives are local copies, so these are the fixed costs the driver's first multi-GPU run can be read against.
+        Works on a copy: ``flat`` is left as it is."""
+        flat = flat.clone()
+        n = flat.numel()
+        nb = (n + self.brick - 1) // self.brick
+        self._ensure(nb, 0, flat.device)
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        phases = ["flags", "allreduce_flags", "list", "pack", "allreduce_packed", "unpack"]
+        acc = {k: 0.0 for k in phases}
+        world = dist.get_world_size(self.pg)
+        k_used = 0
+        cap_known = self._cap
+        if cap_known is None:           # (a sync object that has not run a step yet: size the list as its second step would)
+            self.ops.flags(flat, self._flags)
+            dist.all_reduce(self._flags, op=dist.ReduceOp.MAX, group=self.pg)
+            cap_known = max(self.min_capacity, int(int(self._flags.sum(dtype=torch.int64)) * self.headroom))
+        for _ in range(reps):
+            marks = [ev() for _ in range(len(phases) + 1)]
+            marks[0].record()
+            self.ops.flags(flat, self._flags); marks[1].record()
+            dist.all_reduce(self._flags, op=dist.ReduceOp.MAX, group=self.pg); marks[2].record()
+            cap = int(cap_known)
+            if hasattr(self.ops, "list"):
+                idx, _ = self.ops.list(self._flags, min(cap, nb))
+            else:
+                idx = self._flags.nonzero().view(-1)
+            marks[3].record()
+            k_used = idx.numel()
+            self._ensure(nb, k_used, flat.device)
+            packed = self._packed[: k_used * self.brick]
+            self.ops.pack(flat, idx, packed); marks[4].record()
+            dist.all_reduce(packed, group=self.pg); marks[5].record()
+            self.ops.unpack(packed, idx, flat); marks[6].record()
+            torch.cuda.synchronize(flat.device)
+            for i, k in enumerate(phases):
+                acc[k] += marks[i].elapsed_time(marks[i + 1])
+        out = {k: v / reps for k, v in acc.items()}
+        out.update(bricks=nb, list_slots=k_used, packed_mb=round(k_used * self.brick * 4 / 1e6, 1), ranks=world)
+        return out
 
     def verify(self):
         """Close the step's exchange: read the union's true brick count (a host wait on a copy that was enqueued
         before the packed all-reduce, i.e. long done), adapt the capacity, and send any overflow exactly."""
         if self._pending is None:
             return
-        flat, rank_of, count_host, ev, cap = self._pending
+        flat, count_host, ev, cap = self._pending
         self._pending = None
         if ev is not None:
             ev.synchronize()
         k = int(count_host[0])
         self.last["union"] = k
         if flat is not None and k > cap:
-            over = ((self._flags > 0) & (rank_of >= cap)).nonzero().view(-1)     # rare: the union grew by > 25 %
+            # rare (the union grew by > 25 %): the flagged bricks beyond the list's capacity, from the flags, which stay
+            # intact until the next reduce()
+            over = (self._flags > 0).nonzero().view(-1)[cap:]
             self._exchange(flat, over)
             self.last["sent"] += over.numel()
             self.last["overflow"] = over.numel()
@@ -197,6 +263,7 @@ class ShardedGrids:
         params = [getattr(model, n).grid for n in names]
         self.names = names
         self.sizes = [p.numel() for p in params]
+        self.shapes = [tuple(p.shape) for p in params]       # logical [1,C,X,Y,Z]; colour grids are STORED [1,X,Y,Z,C]
         n = sum(self.sizes)
         quantum = self.world * 128                           # whole 512-byte bricks per shard
         self.n = n
@@ -224,10 +291,37 @@ class ShardedGrids:
     def my_range(self) -> Tuple[int, int]:
         return self.rank * self.shard, (self.rank + 1) * self.shard
 
+    # flat-buffer order <-> the reference's per-parameter layout (contiguous [1,C,X,Y,Z]): checkpoints interchange
+    def to_reference_layout(self, flat: torch.Tensor):
+        """[padded] buffer in this object's order -> {name: contiguous tensor of the parameter's logical shape}."""
+        out = {}
+        for (name, b, e), shp in zip(self.bounds, self.shapes):
+            seg = flat[b:e]
+            if len(shp) == 5 and shp[1] > 1:
+                out[name] = seg.view(shp[0], *shp[2:], shp[1]).permute(0, 4, 1, 2, 3).contiguous()
+            else:
+                out[name] = seg.view(shp).clone()
+        return out
+
+    def from_reference_layout(self, tensors, device=None) -> torch.Tensor:
+        """{name: tensor of the parameter's logical shape, any strides} -> [padded] buffer in this object's order."""
+        flat = torch.zeros(self.padded, dtype=torch.float32, device=device or self.flat.device)
+        for (name, b, e), shp in zip(self.bounds, self.shapes):
+            t = tensors[name].to(flat.device, torch.float32)
+            if tuple(t.shape) != tuple(shp):
+                raise ValueError(f"{name}: shape {tuple(t.shape)} does not match the parameter's {tuple(shp)}")
+            if len(shp) == 5 and shp[1] > 1:
+                flat[b:e].view(shp[0], *shp[2:], shp[1]).copy_(t.permute(0, 2, 3, 4, 1))
+            else:
+                flat[b:e].view(shp).copy_(t)
+        return flat
+
     def reduce_scatter(self, flat_grad: torch.Tensor):
         """Start summing the grid part of the step's gradient buffer (``flat_grad``: [n] or [padded]) into
         ``grad_shard``; asynchronous on RCCL."""
         if flat_grad.numel() != self.padded:
+            # (the trainer steps lay their flat buffer out with the grid part padded to ``self.padded`` once
+            # ``step.sharded`` is attached -- trainer._grid_pad -- so this 218 MB-per-step copy is the fallback for other callers)
             if not hasattr(self, "_gpad") or self._gpad.device != flat_grad.device:
                 self._gpad = torch.zeros(self.padded, dtype=torch.float32, device=flat_grad.device)
             self._gpad[: self.n].copy_(flat_grad[: self.n])

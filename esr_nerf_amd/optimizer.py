@@ -184,8 +184,56 @@ class ShardedGridAdam:
         G.all_gather()
 
     def state_dict(self):
+        """This rank's shard of the state (resume with the SAME world size: ``load_state_dict``).  For a checkpoint in
+        the reference's per-parameter format -- readable by the dense ``Adam``, by the reference, or by a run with
+        another world size -- use ``full_state`` / ``load_full_state``."""
         return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lr=dict(self.lr),
-                    shard=self.grids.my_range())
+                    shard=self.grids.my_range(), world=self.grids.world, names=list(self.grids.names))
+
+    def load_state_dict(self, sd):
+        G = self.grids
+        if tuple(sd["shard"]) != tuple(G.my_range()) or int(sd.get("world", G.world)) != G.world:
+            raise ValueError(f"shard state {sd['shard']} (world {sd.get('world')}) does not fit this rank's shard "
+                             f"{G.my_range()} (world {G.world}); convert through full_state / load_full_state")
+        if set(sd["lr"]) != set(self.lr):
+            raise ValueError(f"learning-rate keys {sorted(sd['lr'])} do not match the grids {sorted(self.lr)}")
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"].to(self.exp_avg.device))
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"].to(self.exp_avg_sq.device))
+        self.lr = {k: float(v) for k, v in sd["lr"].items()}
+
+    @torch.no_grad()
+    def full_state(self):
+        """COLLECTIVE.  The whole state in the reference's format on every rank: {name: {"step", "exp_avg",
+        "exp_avg_sq"}} with contiguous [1,C,X,Y,Z] moments (app/utils/optimizer.py:104-121), plus the lrs."""
+        from .grad_sync import _all_gather
+        G = self.grids
+        lo, hi = G.my_range()
+        out = {n: {"step": self.step_count} for n in G.names}
+        for key, shard in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+            flat = torch.zeros(G.padded, dtype=torch.float32, device=shard.device)
+            flat[lo:hi].copy_(shard)
+            _all_gather(flat, flat[lo:hi], G.pg)
+            for n, t in G.to_reference_layout(flat).items():
+                out[n][key] = t
+        return dict(state=out, lr=dict(self.lr))
+
+    @torch.no_grad()
+    def load_full_state(self, full):
+        """Inverse of ``full_state`` (no communication: every rank cuts its own shard out of the full moments); accepts a
+        state written under any world size, by the dense ``Adam`` or by the reference."""
+        G = self.grids
+        lo, hi = G.my_range()
+        st = full["state"]
+        steps = {int(st[n]["step"]) for n in G.names}
+        if len(steps) != 1:
+            raise ValueError(f"the grids' step counts differ: {steps}")
+        self.step_count = steps.pop()
+        for key, shard in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+            flat = G.from_reference_layout({n: st[n][key] for n in G.names}, device=shard.device)
+            shard.copy_(flat[lo:hi])
+        if "lr" in full:
+            self.lr = {n: float(full["lr"][n]) for n in G.names}
 
 
 class CosineLR:

@@ -77,7 +77,7 @@ def _grid_sync(step, eng):
     step.sync_mode_used = mode            # what bench.py reports (grad_exchange.mode)
     if mode == "shard":
         def after_grids():
-            step.sharded.reduce_scatter(step._flat[: step._n_grid])
+            step.sharded.reduce_scatter(step._flat[: step._n_grid_pad])      # padded in place: no copy
     elif mode == "sparse":
         from .grad_sync import GridGradSync
         if step._sync is None:
@@ -132,6 +132,15 @@ def _check_overflow(step):
         step._ovf_host.zero_()
         raise RuntimeError("a ray exceeded scene.max_steps on at least one rank in the previous step; the LDS bound of "
                            "the march kernel is wrong (its rays were skipped)")
+
+
+def _grid_pad(step, n_grid: int) -> int:
+    """Size of the grid part of a step's flat gradient buffer: with ``step.sharded`` (grad_sync.ShardedGrids) attached it
+    is padded to the shard quantum, so that reduce_scatter reads the buffer in place (no per-step padded copy)."""
+    sh = getattr(step, "sharded", None)
+    if sh is not None and sh.n == n_grid:
+        return int(sh.padded)
+    return n_grid
 
 
 def _warn_hw_queues(process_group):
@@ -209,7 +218,9 @@ class FineStep:
         shapes = [("sdf.grid", (1, 1, X, Y, Z)), ("off_color.grid", (1, X, Y, Z, 6)),
                   ("emo_color.grid", (1, X, Y, Z, 6))]
         shapes += [(n, tuple(p.shape)) for n, p in zip(self._param_names(), m._mlp_params())]
-        total = sum(int(torch.Size(s).numel()) for _, s in shapes)
+        n_grid = sum(int(torch.Size(s).numel()) for _, s in shapes[:3])
+        pad = _grid_pad(self, n_grid) - n_grid
+        total = sum(int(torch.Size(s).numel()) for _, s in shapes) + pad
         if self._flat is None or self._flat.numel() != total:
             self._flat = torch.empty(total, dtype=torch.float32, device=dev)
         self._flat.zero_()
@@ -219,7 +230,9 @@ class FineStep:
             out[n] = self._flat[o:o + k].view(s)
             o += k
             if i == 2:
-                self._n_grid = o          # [0, _n_grid): the three dense grids; the rest: MLP tensors
+                self._n_grid = o          # [0, _n_grid): the three dense grids; [_n_grid, _n_grid_pad): zero padding
+                o += pad                  # (shard mode); the rest: MLP tensors
+                self._n_grid_pad = o
         return out
 
     @torch.no_grad()
@@ -279,7 +292,7 @@ class FineStep:
             after_grids = None
         eng.backward(ctx, g_last, g_srgb, g_lin, grads, after_grids=after_grids)
         if self.pg is not None:
-            works.append(dist.all_reduce(self._flat[self._n_grid:], group=self.pg, async_op=True))
+            works.append(dist.all_reduce(self._flat[self._n_grid_pad:], group=self.pg, async_op=True))
             lf = _reduce_loss_and_overflow(self, eng, loss, works)
             for w in works:
                 w.wait()                  # stream-level wait: the caller's stream sees reduced gradients
@@ -371,7 +384,9 @@ class LtsStep:
                   ("brdf.grid", (1, X, Y, Z, 6))]
         shapes += [(n, tuple(p.shape)) for n, p in zip(self._param_names(), m._mlp_params())]
         shapes += [("envmap.mus", (J, 3)), ("envmap.lambdas", (J, 1)), ("envmap.lobes", (J, 3))]
-        total = sum(int(torch.Size(s).numel()) for _, s in shapes)
+        n_grid = sum(int(torch.Size(s).numel()) for _, s in shapes[:4])
+        pad = _grid_pad(self, n_grid) - n_grid
+        total = sum(int(torch.Size(s).numel()) for _, s in shapes) + pad
         if self._flat is None or self._flat.numel() != total:
             self._flat = torch.empty(total, dtype=torch.float32, device=dev)
         self._flat.zero_()
@@ -381,7 +396,9 @@ class LtsStep:
             out[n] = self._flat[o:o + k].view(s)
             o += k
             if i == 3:
-                self._n_grid = o          # [0, _n_grid): the four dense grids; the rest: MLP + env-map tensors
+                self._n_grid = o          # [0, _n_grid): the four dense grids; [_n_grid, _n_grid_pad): zero padding
+                o += pad                  # (shard mode); the rest: MLP + env-map tensors
+                self._n_grid_pad = o
         return out
 
     def _pair(self, eng, loss, a, b, kind, w_value, w_a, w_b, scale, want_gb=True, row_mask=None, mask_value=0,
@@ -478,7 +495,7 @@ class LtsStep:
             after_grids = None
         eng.lts_backward(ctx, g, grads, after_grids=after_grids)
         if self.pg is not None:
-            works.append(dist.all_reduce(self._flat[self._n_grid:], group=self.pg, async_op=True))
+            works.append(dist.all_reduce(self._flat[self._n_grid_pad:], group=self.pg, async_op=True))
             lf = _reduce_loss_and_overflow(self, eng, loss, works)
             for w in works:
                 w.wait()

@@ -772,6 +772,15 @@ int esr_brick_pack(const float *buf, int64_t n, const int64_t *brick_idx, int64_
                    void *stream);
 int esr_brick_unpack(const float *packed, const int64_t *brick_idx, int64_t n_idx, float *buf, int64_t n,
                      void *stream);
+/*
+ * The union's brick list on the device: idx[0..cap) = the first `cap` flagged bricks in ascending order, unused slots -1
+ * (what esr_brick_pack / _unpack skip); *count = the number of flagged bricks, which may exceed cap (the caller reads it
+ * later and sends the overflow in a second pass).  scratch: esr_brick_list_scratch_ints() int32.  Replaces six torch
+ * launches inside the data-parallel step (esr_nerf_amd/grad_sync.py).
+ */
+int64_t esr_brick_list_scratch_ints(void);
+int esr_brick_list(const uint8_t *flags, int64_t n_bricks, int64_t cap, int64_t *idx, int64_t *count, int32_t *scratch,
+                   void *stream);
 
 #ifdef __cplusplus
 }

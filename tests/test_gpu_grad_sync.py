@@ -76,3 +76,45 @@ def test_grid_grad_sync_one_rank_group(density, mode):
     assert sync.last["mode"] == mode and sync.last["bricks"] == nb
     if mode == "sparse":
         assert sync.last["sent"] == int(keep.sum())
+
+
+@pytest.mark.parametrize("nb,density,cap", [(5000, 0.2, 1300), (5000, 0.2, 700), (37, 0.5, 64), (426_000, 0.16, 90_000),
+                                            (1_705_000, 0.05, 100_000), (300, 0.0, 16), (1, 1.0, 4)])
+def test_brick_list_matches_torch(nb, density, cap):
+    """esr_brick_list (the union's fixed-capacity brick list + count, one device call) against the torch form it
+    replaces: the first `cap` flagged bricks in ascending order, -1 in the unused slots, the true count even when it
+    exceeds the capacity."""
+    from esr_nerf_amd.grad_sync import HipBrickOps
+    g = torch.Generator().manual_seed(nb + cap)
+    flags = (torch.rand(nb, generator=g) < density).to(torch.uint8)
+    want = flags.nonzero().view(-1)
+    idx, count = HipBrickOps().list(flags.cuda(), cap)
+    torch.cuda.synchronize()
+    assert int(count) == want.numel()
+    k = min(cap, want.numel())
+    assert torch.equal(idx[:k].cpu(), want[:k]) and bool((idx[k:] == -1).all()) and idx.numel() == cap
+
+
+def test_grid_grad_sync_optimistic_steps_and_overflow_on_device_list():
+    """Steps 2+ of GridGradSync run on the device-built list (no host wait inside); a union that outgrows the capacity
+    is completed by verify()'s second pass.  One-rank RCCL group: the buffer must come back unchanged every time."""
+    import torch.distributed as dist
+    from esr_nerf_amd.grad_sync import GridGradSync
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    nb = 20000
+    g = torch.Generator().manual_seed(5)
+    sync = GridGradSync(dist.group.WORLD)
+    for dens in (0.10, 0.11, 0.30, 0.30, 0.05):                # step 3 overflows the capacity learnt from step 2
+        keep = (torch.rand(nb, generator=g) < dens).float()
+        flat = (torch.randn(nb, 128, generator=g) * keep[:, None]).view(-1).cuda()
+        want = flat.clone()
+        sync.reduce(flat)
+        sync.verify()
+        torch.cuda.synchronize()
+        assert torch.equal(flat, want)
+        assert sync.last["union"] == int(keep.sum())
+    ph = sync.profile(flat)
+    assert set(ph) >= {"flags", "list", "pack", "unpack", "allreduce_packed"} and torch.equal(flat, want)

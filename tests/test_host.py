@@ -259,6 +259,26 @@ for step in range(1, 4):
         err = float((getattr(model, n).grid.detach() - ref[n]).abs().max())
         assert err < 1e-6, (step, n, err)
 assert opt.exp_avg.numel() == grids.shard                                   # moments exist for the owned shard only
+# checkpoints: (a) the full state in the reference's per-parameter layout equals the single-process moments; (b) it loads
+# back into a fresh sharded optimizer (any world size: every rank cuts its shard); (c) the shard-local state dict round-trips
+full = opt.full_state()
+for n in names:
+    assert full["state"][n]["step"] == 3 and full["state"][n]["exp_avg"].is_contiguous()
+    assert float((full["state"][n]["exp_avg"] - m_ref[n]).abs().max()) < 1e-6, n
+    assert float((full["state"][n]["exp_avg_sq"] - v_ref[n]).abs().max()) < 1e-6, n
+opt2 = ShardedGridAdam(grids, lrs, adam_fn=torch_adam)
+opt2.load_full_state(full)
+assert opt2.step_count == 3 and torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+assert all(abs(opt2.lr[n] - opt.lr[n]) < 1e-12 for n in names)
+opt3 = ShardedGridAdam(grids, lrs, adam_fn=torch_adam)
+opt3.load_state_dict(opt.state_dict())
+assert opt3.step_count == 3 and torch.equal(opt3.exp_avg_sq, opt.exp_avg_sq)
+bad = dict(opt.state_dict(), shard=(1, 2))
+try:
+    opt3.load_state_dict(bad)
+    raise SystemExit("a foreign shard range must be refused")
+except ValueError:
+    pass
 print("SHARDOK", rank, grids.shard, grids.padded)
 dist.destroy_process_group()
 '''
