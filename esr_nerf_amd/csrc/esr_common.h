@@ -135,6 +135,18 @@ __device__ __forceinline__ RayGeom esr_ray_geom(const float *rays_o, const float
 // align_corners=True, padding_mode="zeros") on a [X,Y,Z] volume, as the
 // reference calls it (app/utils/base/module.py:24-35): world x -> slowest axis.
 // ---------------------------------------------------------------------------
+// sin and cos of one argument with ONE range reduction (ocml's sincosf: the same reduction and polynomials as its sinf /
+// cosf, so the values are theirs bit for bit); the positional encodings evaluate 18-30 such pairs per sample and the
+// two separate calls were most of the feature kernel's vector instructions
+__device__ __forceinline__ void esr_sincos(float a, float &s, float &c)
+{
+#ifdef ESR_EXP_SEPARATE_SINCOS
+    s = sinf(a); c = cosf(a);
+#else
+    sincosf(a, &s, &c);
+#endif
+}
+
 struct Tri {
     int i0[3];      // floor index per GRID axis (0 = X slowest, 2 = Z fastest)
     float f[3];     // fractional part per grid axis

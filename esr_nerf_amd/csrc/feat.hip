@@ -258,13 +258,17 @@ __global__ void __launch_bounds__(256) feat_fwd_kernel(FeatParams P)
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 const float a = unit[c] * (float)(1 << i);
-                X(ROW_SIN + c * 5 + i, sinf(a));
-                X(ROW_COS + c * 5 + i, cosf(a));
+                float sn, cs;
+                esr_sincos(a, sn, cs);
+                X(ROW_SIN + c * 5 + i, sn);
+                X(ROW_COS + c * 5 + i, cs);
             }
             const float v = vdir[c];
+            float sn, cs;
+            esr_sincos(v, sn, cs);
             X(ROW_VD + c, v);
-            X(ROW_VSIN + c, sinf(v));
-            X(ROW_VCOS + c, cosf(v));
+            X(ROW_VSIN + c, sn);
+            X(ROW_VCOS + c, cs);
         }
     }
 }
@@ -596,8 +600,19 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
                         const float top = (float)(dimA - 1);
                         cm = fminf(fmaxf(indA - sc.grad_feat[k], 0.f), top);
                         cp = fminf(fmaxf(indA + sc.grad_feat[k], 0.f), top);
+#ifdef FEAT_EXP_BWD_ROUNDTRIP
                         ixm = __fdiv_rn((__fdiv_rn(cm, top) * 2.0f - 1.0f) + 1.0f, 2.0f) * top;
                         ixp = __fdiv_rn((__fdiv_rn(cp, top) * 2.0f - 1.0f) + 1.0f, 2.0f) * top;
+#else
+                        // The forward reproduces the reference's normalise / de-normalise round trip of the tap index
+                        // bit for bit (tap_index: it decides which float the tap lands on).  Here the index only
+                        // splits a gradient between two neighbouring cells: the round trip moves it by <= 2 ulp, i.e.
+                        // the two shares by ~1e-7 of the value, continuously (a tap within an ulp of a cell boundary
+                        // has weight ~0 on the far side) -- the two correctly rounded divisions per tap (16 per lane,
+                        // ~160 vector instructions) are not worth that.
+                        ixm = cm;
+                        ixp = cp;
+#endif
                     }
                     const float thr = (ar == 0 ? through[0][k] : (ar == 1 ? through[1][k] : through[2][k])) /
                                       ((cp - cm) + 1e-12f) / sc.voxel_size;

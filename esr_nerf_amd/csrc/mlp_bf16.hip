@@ -310,8 +310,8 @@ __global__ void __launch_bounds__(64 * SHW, 1) mlp_fwd16s_kernel(Fwd16Args A)
         ESR_STAMP16(1);
         lds_bias_add<HT>(bias_l, cur, lane);
         relu_tiles<HT>(cur);
-        if (save) {
-            store_tiles_bf16<HT>(make_rsrc(A.H[0] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
+        if (save) {                                        // save == 2: ReLU masks only (the weight gradients recompute the layer)
+            if (A.save == 1) store_tiles_bf16<HT>(make_rsrc(A.H[0] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
             store_relu_mask<HT>(make_rsrc(A.M[0] + (size_t)t * (MBYTES / 4), MBYTES), cur, lane);
         }
         ESR_STAMP16(2);
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(64 * SHW, 1) mlp_fwd16s_kernel(Fwd16Args A)
             lds_bias_add<HT>(bias_l + l * S::BIAS_FLOATS, nxt, lane);
             relu_tiles<HT>(nxt);
             if (save) {
-                store_tiles_bf16<HT>(make_rsrc(A.H[l] + (size_t)t * (HBYTES / 4), HBYTES), nxt, lane);
+                if (A.save == 1) store_tiles_bf16<HT>(make_rsrc(A.H[l] + (size_t)t * (HBYTES / 4), HBYTES), nxt, lane);
                 store_relu_mask<HT>(make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), nxt, lane);
             }
 #pragma unroll
@@ -415,7 +415,8 @@ __global__ void __launch_bounds__(64 * SHW, 1) mlp_dgrad16s_kernel(Dgrad16Args A
         lds_layer16<1, HT, (NL == 2 ? 0 : S::chunks(NL - 2))>(wl + (NL == 2 ? 0 : cur_buf * S::BUF), [&](int) { return B0; }, cur, lane,
                                                             tid, W16, (int)S::off(NL - 2), wl + (cur_buf ^ 1) * S::BUF);
         apply_relu_mask<HT>(msk[NHID - 1], cur);
-        store_tiles_bf16<HT>(make_rsrc(A.dZ[NHID - 1] + (size_t)t * (HBYTES / 4), hb), cur, lane);
+        if (A.dZ[NHID - 1])                                // (a NULL dZ[l] is not stored: its weight gradient recomputes it)
+            store_tiles_bf16<HT>(make_rsrc(A.dZ[NHID - 1] + (size_t)t * (HBYTES / 4), hb), cur, lane);
         if (NL != 2) { layer_barrier(); cur_buf ^= 1; }
         auto hidden = [&](auto LC) {
             constexpr int l = decltype(LC)::value;                               // layer l's transpose: dZ[l] -> dZ[l - 1]
@@ -424,7 +425,7 @@ __global__ void __launch_bounds__(64 * SHW, 1) mlp_dgrad16s_kernel(Dgrad16Args A
             lds_layer16<2 * HT, HT, S::chunks(l - 1)>(wl + cur_buf * S::BUF, [&](int j) { return acc_to_b(cur[j >> 1], j & 1); },
                                                      nxt, lane, tid, W16, (int)S::off(l - 1), wl + (cur_buf ^ 1) * S::BUF);
             apply_relu_mask<HT>(msk[l - 1], nxt);
-            store_tiles_bf16<HT>(make_rsrc(A.dZ[l - 1] + (size_t)t * (HBYTES / 4), hb), nxt, lane);
+            if (A.dZ[l - 1]) store_tiles_bf16<HT>(make_rsrc(A.dZ[l - 1] + (size_t)t * (HBYTES / 4), hb), nxt, lane);
 #pragma unroll
             for (int it = 0; it < HT; ++it) cur[it] = nxt[it];
             layer_barrier();
@@ -508,12 +509,12 @@ ESR_API int esr_mlp_fwd_bf16(int kind, const float *packed32, const void *packed
     const int nhid = net_desc(kind).n_layers - 1;
     Fwd16Args A = {};
     A.packed32 = packed32; A.packed16 = static_cast<const __bf16 *>(packed16); A.X = X; A.t0 = t0; A.t1 = t1;
-    A.save = save ? 1 : 0; A.crow = color_row0; A.zout = zout;
+    A.save = save == 2 ? 2 : save ? 1 : 0; A.crow = color_row0; A.zout = zout;
     if (save) {
-        if (!H || !M) return ESR_EINVAL;
+        if (!M || (save != 2 && !H)) return ESR_EINVAL;
         for (int l = 0; l < nhid; ++l) {
-            if (!H[l] || !M[l]) return ESR_EINVAL;
-            A.H[l] = H[l]; A.M[l] = M[l];
+            if (!M[l] || (save != 2 && !H[l])) return ESR_EINVAL;
+            A.H[l] = save != 2 ? H[l] : nullptr; A.M[l] = M[l];
         }
     }
     hipStream_t s = esr_stream(stream);
@@ -536,8 +537,8 @@ ESR_API int esr_mlp_dgrad_bf16(int kind, const void *packed16, const float *dz, 
     Dgrad16Args A = {};
     A.packed16 = static_cast<const __bf16 *>(packed16); A.dz = dz; A.t0 = t0; A.t1 = t1; A.dX = dX;
     for (int l = 0; l < nhid; ++l) {
-        if (!M[l] || !dZ[l]) return ESR_EINVAL;
-        A.M[l] = M[l]; A.dZ[l] = dZ[l];
+        if (!M[l]) return ESR_EINVAL;
+        A.M[l] = M[l]; A.dZ[l] = dZ[l];                 // a NULL dZ[l] is computed but not stored
     }
     hipStream_t s = esr_stream(stream);
     switch (kind) {

@@ -418,6 +418,11 @@ __device__ __forceinline__ void load_bias(rsrc_t W, int boff, f32x16 (&acc)[NT],
     }
 }
 
+// CAUTION (inline asm reading MFMA results): hipcc's hazard recogniser does not see inside an asm statement, so nothing
+// inserts the wait states a vector instruction needs behind the MFMA that wrote its operand.  Call this only where the
+// tile read first was written long before (the layer loops write tile 0 first and tile NT-1 last, and the 16 v_max per
+// tile put >= 80 instructions between a tile's last MFMA and its v_max); csrc/tone_wgrad.hip's bf16 kernel, whose
+// tiles are finished by a single 8-pass MFMA each, uses fmaxf instead.
 template <int NT>
 __device__ __forceinline__ void relu_tiles(f32x16 (&acc)[NT])
 {

@@ -209,6 +209,209 @@ __global__ void __launch_bounds__(256, 1) tone_wgrad_t_kernel(ToneWgArgs A)
     }
 }
 
+
+// ---- bf16 twin (the bf16 configurations C3 / C5) --------------------------------------------------------------------
+// Same scheme with v_mfma_f32_32x32x16_bf16: operands rounded to bf16 where the bf16 engine rounds them (Xt, W0, dzt, W1
+// when they become an operand; the recomputed Ht and dZt when THEY become an operand of dW1 / dW0 / db0 -- the values
+// the saved-tile path stored as bf16), fp32 accumulation.  With it the bf16 step saves neither Ht nor dZt: 48 KB of HBM
+// traffic per sample tile (1.05 GB per C3 step) and the tone mapper's share of the staged weight-gradient launches.
+// Matrix work drops from 114 f32 MFMAs (7.3 k cycles) to 18 bf16 ones (0.6 k) per wave and tile, so the kernel is bound by
+// its vector work (ReLU, masks, dW1 / db0 sums, bf16 packing) and runs two waves per SIMD.
+//
+// k-slot conventions of the 32x32x16 operands (lane = 32 h + i, 8 slots e per lane and k-step q):
+//   Ht^T = Xt^T W0^T     k = input row 16 q + 8 h + e          A: lane i = sample, B: lane i = unit (16-B LDS read of w0b)
+//   dHt^T = dzt^T W1     k = output channel e (half 0 only)     one k-step
+//   dW0 = dZt Xt^T       k = sample acc_row(8 q + e, h): the accumulator registers 8q .. 8q+7 of dZt^T ARE the A operand;
+//                        B: row x = lane i of the Xt tile staged in LDS as bf16 with its 32 samples PERMUTED so that
+//                        those 8 samples are one 16-B read (xperm below)
+constexpr int W0B_U = 56;                                      // bf16 per unit row of W0 in LDS: 48 input rows + pad (112-B stride)
+constexpr int XS16 = 40;                                       // bf16 per staged Xt row: 32 samples + pad (80-B stride: 16 lanes' 16-B reads on distinct banks)
+constexpr int WAVE_LDS16 = 32 * XS16 * 2 + (4 + 1) * XS * 4;   // bytes per wave: Xt rows 0..31 (bf16) | dzt rows 0..3 + Xt row 32 (f32)
+constexpr int W0B_BYTES = THID * W0B_U * 2;
+
+__device__ __forceinline__ float bf16r(float x) { return (float)(__bf16)x; }
+__device__ __forceinline__ int xperm(int s)                    // position of sample s inside a staged Xt row
+{
+    const int r = (s & 3) + 4 * (s >> 3), hh = (s >> 2) & 1;   // s = acc_row(r, hh)
+    return (2 * (r >> 3) + hh) * 8 + (r & 7);
+}
+
+__global__ void __launch_bounds__(256, 2) tone_wgrad16_t_kernel(ToneWgArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
+    __bf16 *w0b = reinterpret_cast<__bf16 *>(lds16);                       // [192][W0B_U]: w0b[u * W0B_U + x] = bf16(W0[u][x])
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, ul = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char *mine = lds16 + W0B_BYTES + wv * WAVE_LDS16;
+    __bf16 *xb = reinterpret_cast<__bf16 *>(mine);                         // [32][XS16]
+    float *lz = reinterpret_cast<float *>(mine + 32 * XS16 * 2);           // dzt rows 0..3, [4][XS]
+    float *lx32 = lz + 4 * XS;                                             // Xt row 32, [XS]
+    for (int i = tid; i < THID * W0B_U; i += 256) {
+        const int u = i / W0B_U, x = i % W0B_U;
+        w0b[i] = (__bf16)(x < TIN ? A.W0[u * TIN + x] : 0.f);
+    }
+    __syncthreads();
+
+    const int g = wv & 1;                                                   // this wave's hidden units [96 g, 96 g + 96)
+    bf16x8 w1b[3];
+    float b0r[3];
+#pragma unroll
+    for (int i3 = 0; i3 < 3; ++i3) {
+        const int u = 96 * g + 32 * i3 + ul;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w1b[i3][e] = (__bf16)((h == 0 && e < TOUT) ? A.W1[e * THID + u] : 0.f);
+        b0r[i3] = A.b0[u];
+    }
+    f32x16 dW0[3];
+    zero_tiles<3>(dW0);
+    float dW0c[3], dW1r[3][3], db0r[3], db1r[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i3 = 0; i3 < 3; ++i3) {
+        dW0c[i3] = 0.f; db0r[i3] = 0.f;
+        dW1r[i3][0] = dW1r[i3][1] = dW1r[i3][2] = 0.f;
+    }
+    const int pair = blockIdx.x * 2 + (wv >> 1), npairs = gridDim.x * 2;
+    // rows this lane feeds into the A operand of Ht^T: 16 q + 8 h + e (q = 0, 1) and 32 + 8 h (the 33rd input; rows
+    // 33..47 of the tile are zero)
+    float xn[17], zn[2];
+    auto fetch = [&](int t) {
+        const bool live = t < A.t1;
+        const float *X = A.Xt + (size_t)(live ? t : A.t0) * XT_ROWS * 32 + ul;
+        const float *Zt = A.dzt + (size_t)(live ? t : A.t0) * 4 * 32 + ul;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xn[j] = X[(16 * (j >> 3) + 8 * h + (j & 7)) * 32];
+        xn[16] = X[(32 + 8 * h) * 32];
+        zn[0] = Zt[h * 32];
+        zn[1] = h == 0 ? Zt[2 * 32] : 0.f;
+    };
+    const int xp = xperm(ul);
+    if (A.t0 + pair < A.t1) fetch(A.t0 + pair);
+    for (int t = A.t0 + pair; t < A.t1; t += npairs) {
+        float xa[17], za[2];
+#pragma unroll
+        for (int j = 0; j < 17; ++j) xa[j] = xn[j];
+        za[0] = zn[0]; za[1] = zn[1];
+        fetch(t + npairs);
+        db1r[0] += za[0]; db1r[1] += za[1];
+        // stage: Xt rows 0..31 as bf16 (permuted samples), dzt rows and Xt row 32 as f32
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xb[(16 * (j >> 3) + 8 * h + (j & 7)) * XS16 + xp] = (__bf16)xa[j];
+        lz[h * XS + ul] = za[0];
+        if (h == 0) { lz[2 * XS + ul] = za[1]; lx32[ul] = xa[16]; }
+        // ---- Ht^T[s][u]
+        bf16x8 a8[3];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            a8[q] = pack8(make_float4(xa[8 * q], xa[8 * q + 1], xa[8 * q + 2], xa[8 * q + 3]),
+                          make_float4(xa[8 * q + 4], xa[8 * q + 5], xa[8 * q + 6], xa[8 * q + 7]));
+        a8[2] = pack8(make_float4(xa[16], 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f));
+        f32x16 ht[3];
+#pragma unroll
+        for (int i3 = 0; i3 < 3; ++i3) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ht[i3][r] = b0r[i3];
+            const __bf16 *wrow = w0b + (96 * g + 32 * i3 + ul) * W0B_U + 8 * h;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const bf16x8 wb = *reinterpret_cast<const bf16x8 *>(wrow + 16 * q);
+                ht[i3] = mfma16(a8[q], wb, ht[i3]);
+            }
+        }
+        // ReLU in C, NOT relu_tiles' inline asm: the compiler's hazard recogniser does not look inside an asm statement,
+        // and here it schedules a tile's v_max right behind the tile's last (8-pass) MFMA -- the v_max then read the
+        // accumulator before that MFMA had written it (seen as the 33rd input's contribution missing from some
+        // units).  The f32 kernels' relu_tiles calls sit >= 80 vector instructions behind the MFMA that wrote their tile.
+#pragma unroll
+        for (int i3 = 0; i3 < 3; ++i3)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ht[i3][r] = fmaxf(ht[i3][r], 0.f);
+        // ---- dW1[c][u] += sum_s bf16(dzt[c][s]) bf16(Ht[u][s])   (the saved-tile path's operands: dz rounded on its way
+        // to the operand registers, Ht stored as bf16)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a = *reinterpret_cast<const float4 *>(lz + 0 * XS + 8 * q + 4 * h);
+            const float4 b = *reinterpret_cast<const float4 *>(lz + 1 * XS + 8 * q + 4 * h);
+            const float4 c = *reinterpret_cast<const float4 *>(lz + 2 * XS + 8 * q + 4 * h);
+            const float za4[4] = {bf16r(a.x), bf16r(a.y), bf16r(a.z), bf16r(a.w)};
+            const float zb4[4] = {bf16r(b.x), bf16r(b.y), bf16r(b.z), bf16r(b.w)};
+            const float zc4[4] = {bf16r(c.x), bf16r(c.y), bf16r(c.z), bf16r(c.w)};
+#pragma unroll
+            for (int i3 = 0; i3 < 3; ++i3)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float hv = bf16r(ht[i3][4 * q + i]);
+                    dW1r[i3][0] = fmaf(za4[i], hv, dW1r[i3][0]);
+                    dW1r[i3][1] = fmaf(zb4[i], hv, dW1r[i3][1]);
+                    dW1r[i3][2] = fmaf(zc4[i], hv, dW1r[i3][2]);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float x32[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 d = *reinterpret_cast<const float4 *>(lx32 + 8 * q + 4 * h);
+            x32[4 * q] = bf16r(d.x); x32[4 * q + 1] = bf16r(d.y); x32[4 * q + 2] = bf16r(d.z); x32[4 * q + 3] = bf16r(d.w);
+        }
+        // ---- dHt^T = dzt^T W1 masked by the recomputed activation; then dW0 += dZt Xt^T
+        // slots 0..2 of half 0 = dzt rows 0..2 of this lane's sample (row 1 lives in the OTHER half's za[0])
+        const float z1 = __shfl_xor(za[0], 32);
+        const bf16x8 za8 = pack8(make_float4(h == 0 ? za[0] : 0.f, h == 0 ? z1 : 0.f, h == 0 ? za[1] : 0.f, 0.f),
+                                 make_float4(0.f, 0.f, 0.f, 0.f));
+#pragma unroll
+        for (int i3 = 0; i3 < 3; ++i3) {
+            f32x16 d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = 0.f;
+            d = mfma16(za8, w1b[i3], d);
+            float sb = 0.f, sc = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = ht[i3][r] > 0.f ? bf16r(d[r]) : 0.f;         // dZt as the saved-tile path stored it
+                d[r] = v;
+                sb += v;
+                sc = fmaf(v, x32[r], sc);
+            }
+            db0r[i3] += sb;
+            dW0c[i3] += sc;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const bf16x8 aq = pack8(make_float4(d[8 * q], d[8 * q + 1], d[8 * q + 2], d[8 * q + 3]),
+                                        make_float4(d[8 * q + 4], d[8 * q + 5], d[8 * q + 6], d[8 * q + 7]));
+                const bf16x8 xq = *reinterpret_cast<const bf16x8 *>(xb + ul * XS16 + (2 * q + h) * 8);
+                dW0[i3] = mfma16(aq, xq, dW0[i3]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- flush (same slab layout as the f32 kernel)
+    float *S = A.slab + (size_t)pair * SLAB;
+#pragma unroll
+    for (int i3 = 0; i3 < 3; ++i3) {
+        const int ub = 96 * g + 32 * i3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[(ub + acc_row(r, h)) * TIN + ul] = dW0[i3][r];
+        const int u = ub + ul;
+        const float c32 = dW0c[i3] + __shfl_xor(dW0c[i3], 32);
+        const float b = db0r[i3] + __shfl_xor(db0r[i3], 32);
+        float w1[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) w1[c] = dW1r[i3][c] + __shfl_xor(dW1r[i3][c], 32);
+        if (h == 0) {
+            S[u * TIN + 32] = c32;
+            S[N_DW0 + N_DW1 + u] = b;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) S[N_DW0 + c * THID + u] = w1[c];
+        }
+    }
+    float d0 = db1r[0], d1 = db1r[1];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) { d0 += __shfl_xor(d0, off); d1 += __shfl_xor(d1, off); }
+    if (ul == 0 && g == 0) {
+        S[N_DW0 + N_DW1 + THID + h] = d0;
+        if (h == 0) { S[N_DW0 + N_DW1 + THID + 2] = d1; S[N_DW0 + N_DW1 + THID + 3] = 0.f; }
+    }
+}
+
 // gw[e] += sum over the wave slabs, all four outputs in one launch
 __global__ void __launch_bounds__(256) tone_wgrad_reduce_kernel(const float *__restrict__ slab, int n_slabs,
                                                                 float *gw0, float *gw1, float *gb0, float *gb1)
@@ -229,7 +432,7 @@ __global__ void __launch_bounds__(256) tone_wgrad_reduce_kernel(const float *__r
 
 }  // namespace
 
-ESR_API int64_t esr_tone_wgrad_scratch_floats(void) { return (int64_t)512 * SLAB; }
+ESR_API int64_t esr_tone_wgrad_scratch_floats(void) { return (int64_t)1024 * SLAB; }
 
 ESR_API int esr_tone_wgrad_recompute(const float *Xt, const float *dzt, const float *W0, const float *b0, const float *W1,
                                      int32_t t0, int32_t t1, float *gw0, float *gb0, float *gw1, float *gb1,
@@ -248,6 +451,31 @@ ESR_API int esr_tone_wgrad_recompute(const float *Xt, const float *dzt, const fl
     ToneWgArgs A = {Xt, dzt, W0, b0, W1, t0, t1, scratch};
     hipStream_t s = esr_stream(stream);
     tone_wgrad_t_kernel<<<grid, 256, lds_bytes, s>>>(A);
+    ESR_CHECK_LAUNCH();
+    const int n_slabs = grid * 2;
+    tone_wgrad_reduce_kernel<<<esr_grid_for((int64_t)(SLAB - 1) * ((n_slabs + 31) / 32), 256, 1024), 256, 0, s>>>(
+        scratch, n_slabs, gw0, gw1, gb0, gb1);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+// bf16-operand twin (the bf16 engine): same arguments; Xt / dzt / the weights stay fp32 in memory and are rounded to bf16
+// where the bf16 engine's kernels round them.
+ESR_API int esr_tone_wgrad_recompute_bf16(const float *Xt, const float *dzt, const float *W0, const float *b0, const float *W1,
+                                          int32_t t0, int32_t t1, float *gw0, float *gb0, float *gw1, float *gb1,
+                                          float *scratch, int64_t scratch_floats, void *stream)
+{
+    if (t0 < 0 || t1 < t0) return ESR_EINVAL;
+    if (t1 == t0) return 0;
+    if (!Xt || !dzt || !W0 || !b0 || !W1 || !gw0 || !gb0 || !gw1 || !gb1 || !scratch) return ESR_EINVAL;
+    const int n_tiles = t1 - t0;
+    int grid = (n_tiles + 1) / 2;
+    if (grid > 512) grid = 512;                                        // two workgroups (8 waves) per CU
+    if ((int64_t)grid * 2 * SLAB > scratch_floats) return ESR_ECAP;
+    constexpr size_t lds_bytes = (size_t)W0B_BYTES + 4 * WAVE_LDS16;
+    ToneWgArgs A = {Xt, dzt, W0, b0, W1, t0, t1, scratch};
+    hipStream_t s = esr_stream(stream);
+    tone_wgrad16_t_kernel<<<grid, 256, lds_bytes, s>>>(A);
     ESR_CHECK_LAUNCH();
     const int n_slabs = grid * 2;
     tone_wgrad_reduce_kernel<<<esr_grid_for((int64_t)(SLAB - 1) * ((n_slabs + 31) / 32), 256, 1024), 256, 0, s>>>(

@@ -129,9 +129,10 @@ class FineEngine:
         self.dgrad_cap = int(os.environ.get("ESR_DGRAD_CAP", "256"))
         self._side = None
         self._raw: Dict[str, tuple] = {}
-        # f32 engine: the tone mapper's weight gradients recompute its hidden layer (csrc/tone_wgrad.hip), so its forward
-        # keeps only the ReLU masks and its input-gradient pass stores no dZt
-        self.tone_recompute = not self.bf16
+        # the tone mapper's weight gradients recompute its hidden layer (csrc/tone_wgrad.hip; round 3: also with bf16
+        # operands), so its forward keeps only the ReLU masks and its input-gradient pass stores no dZt;
+        # ESR_TONE_RECOMPUTE16=0: the bf16 engine's saved-tile path of round 2 (A/B timing)
+        self.tone_recompute = (not self.bf16) or os.environ.get("ESR_TONE_RECOMPUTE16", "1") != "0"
         self.tone_scratch = torch.empty(self.L.esr_tone_wgrad_scratch_floats() if self.tone_recompute else 1,
                                         dtype=torch.float32, device=self.device)
         self.neus_grad = False          # cfg neus_alpha: "grad" (set by the renderer)
@@ -502,7 +503,8 @@ class FineEngine:
                     (KIND_RADIANCE, ws["X"], Hh, dZh, ws["dz"], to, ta, "off_w", "off_b")]
             if self.tone_recompute:       # from Xt and dzt alone: the hidden layer is recomputed inside (tone_wgrad.hip)
                 (w0, w1), (b0, _) = self._raw["tone"]
-                self._run("tone_wgrad", L.esr_tone_wgrad_recompute, _lib.ptr(ws["Xt"]), _lib.ptr(ws["dzt"]), _lib.ptr(w0.detach()),
+                self._run("tone_wgrad", L.esr_tone_wgrad_recompute_bf16 if self.bf16 else L.esr_tone_wgrad_recompute,
+                          _lib.ptr(ws["Xt"]), _lib.ptr(ws["dzt"]), _lib.ptr(w0.detach()),
                           _lib.ptr(b0.detach()), _lib.ptr(w1.detach()), 0, ta, _lib.ptr(grads["tone_w"][0]),
                           _lib.ptr(grads["tone_b"][0]), _lib.ptr(grads["tone_w"][1]), _lib.ptr(grads["tone_b"][1]),
                           _lib.ptr(self.tone_scratch), C.c_int64(self.tone_scratch.numel()), s_)

@@ -325,7 +325,7 @@ class LtsEngine(FineEngine):
         z = P.buf(f"{net}.z", zrows)
         x = P.bufs["Xt"] if kind == KIND_TONEMAP else P.bufs["X"]
         if t1 > t0:
-            # tone mapper on the f32 engine: masks only, its weight gradient recomputes the hidden layer (tone_wgrad.hip)
+            # tone mapper: masks only, its weight gradient recomputes the hidden layer (tone_wgrad.hip, f32 and bf16 operands)
             mode = 0 if not save else 2 if (kind == KIND_TONEMAP and self.tone_recompute) else 1
             self._run(f"mlp_fwd({net})[{P.name}]", self.mlp_fwd, kind, _lib.ptr(self.packed[net]),
                       _lib.ptr(x), t0, t1, _lib.ptr_array(H), _lib.ptr_array(M), mode, crow,
@@ -349,7 +349,8 @@ class LtsEngine(FineEngine):
                 (w0, w1), (b0, _) = self._raw[net]
 
                 def tone_wgrad():
-                    self._run(f"tone_wgrad[{P.name}]", self.L.esr_tone_wgrad_recompute, _lib.ptr(x), _lib.ptr(dz),
+                    self._run(f"tone_wgrad[{P.name}]",
+                              self.L.esr_tone_wgrad_recompute_bf16 if self.bf16 else self.L.esr_tone_wgrad_recompute, _lib.ptr(x), _lib.ptr(dz),
                               _lib.ptr(w0.detach()), _lib.ptr(b0.detach()), _lib.ptr(w1.detach()), t0, t1, _lib.ptr(gw[0]),
                               _lib.ptr(gb[0]), _lib.ptr(gw[1]), _lib.ptr(gb[1]), _lib.ptr(self.tone_scratch),
                               C.c_int64(self.tone_scratch.numel()), self._s())

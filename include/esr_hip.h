@@ -387,6 +387,11 @@ int64_t esr_tone_wgrad_scratch_floats(void);
 int esr_tone_wgrad_recompute(const float *Xt, const float *dzt, const float *W0, const float *b0, const float *W1,
                              int32_t t0, int32_t t1, float *gw0, float *gb0, float *gw1, float *gb1,
                              float *scratch, int64_t scratch_floats, void *stream);
+/* The same with bf16 matrix operands (fp32 accumulation): Xt, dzt and the weights stay fp32 in memory and are rounded
+ * where the bf16 engine rounds them, so neither Ht nor dZt of the tone mapper is saved by the bf16 step either. */
+int esr_tone_wgrad_recompute_bf16(const float *Xt, const float *dzt, const float *W0, const float *b0, const float *W1,
+                                  int32_t t0, int32_t t1, float *gw0, float *gb0, float *gw1, float *gb1,
+                                  float *scratch, int64_t scratch_floats, void *stream);
 
 /*
  * bf16 variants of the MLP engine for BASELINE.json's bf16 configurations (a build-side precision choice:

@@ -236,6 +236,43 @@ def test_tone_wgrad_recompute_vs_torch(tiles, t0):
         assert rel_err(got - 0.25, want) < 2e-5, rel_err(got - 0.25, want)
 
 
+@pytest.mark.parametrize("tiles,t0", [(1, 0), (7, 2), (300, 0), (1500, 17)])
+def test_tone_wgrad_recompute_bf16_vs_emulation(tiles, t0):
+    """esr_tone_wgrad_recompute_bf16: the same kernel scheme with bf16 matrix operands, against a torch emulation of
+    exactly that arithmetic -- Xt, W0, dzt, W1 rounded to bf16 where they become an operand, the recomputed Ht and dZt
+    rounded where the saved-tile path stored them as bf16, sums in fp32.  2e-3 of the max-norm, as for the bf16 MLP
+    kernels (a value on a bf16 rounding boundary may round the other way under a different summation order)."""
+    from esr_nerf_amd import _lib
+    L = _lib.lib()
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    g = torch.Generator().manual_seed(tiles + 99)
+    W0 = torch.randn(192, 33, generator=g) / 33 ** 0.5
+    b0 = torch.randn(192, generator=g) * 0.1
+    W1 = torch.randn(3, 192, generator=g) / 192 ** 0.5
+    Xt = torch.randn(tiles, 48, 32, generator=g)
+    Xt[:, 33:] = 0.0                                              # (tone_in_fwd writes zeros there)
+    x = Xt[t0:, :33].permute(0, 2, 1).reshape(-1, 33)
+    pre = bf(x) @ bf(W0).t() + b0
+    ht = torch.relu(pre)
+    dz = torch.randn(x.shape[0], 3, generator=g)
+    dz[(pre.abs() < 1e-3).any(-1)] = 0                            # knife-edge samples (bf16 operands: a wider edge)
+    dZt = bf((bf(dz) @ bf(W1)) * (ht > 0))
+    want = (dZt.t() @ bf(x), dZt.sum(0), bf(dz).t() @ bf(ht), dz.sum(0))
+    dzt = torch.zeros(tiles, 4, 32)
+    dzt[t0:, :3] = dz.reshape(tiles - t0, 32, 3).permute(0, 2, 1)
+    dzt[:t0] = 5.0
+    dev = lambda t: t.detach().cuda().contiguous()
+    gw0, gb0, gw1, gb1 = (torch.full(s_, 0.25, device="cuda") for s_ in ((192, 33), (192,), (3, 192), (3,)))
+    scratch = torch.empty(L.esr_tone_wgrad_scratch_floats(), device="cuda")
+    Xd, zd, W0d, b0d, W1d = dev(Xt), dev(dzt), dev(W0), dev(b0), dev(W1)
+    _lib.check(L.esr_tone_wgrad_recompute_bf16(_lib.ptr(Xd), _lib.ptr(zd), _lib.ptr(W0d), _lib.ptr(b0d),
+                                               _lib.ptr(W1d), t0, tiles, _lib.ptr(gw0), _lib.ptr(gb0), _lib.ptr(gw1),
+                                               _lib.ptr(gb1), _lib.ptr(scratch), C.c_int64(scratch.numel()),
+                                               _lib.stream_ptr("cuda:0")), "tone_wgrad16")
+    for name, got, w in zip(("gw0", "gb0", "gw1", "gb1"), (gw0, gb0, gw1, gb1), want):
+        assert rel_err(got - 0.25, w) < 2e-3, (name, rel_err(got - 0.25, w))
+
+
 def test_loss_kernel_matches_trainer_loss():
     from esr_nerf_amd.fine_engine import FineEngine
     from oracle import fine_path as fp
