@@ -67,6 +67,11 @@ with open(os.path.join(P, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
         if float(r[4]) >= 0.05:
             w.writerow(r)
 
+import shutil
+byg = glob.glob(os.path.join(G, f"{tag}_stats", "**", "kernel_by_grid.csv"), recursive=True)
+if byg:
+    shutil.copy(byg[0], os.path.join(P, f"{tag}_kernel_by_grid.csv"))
+
 per_call, per_kernel, step = {}, {}, {}
 for what in ("fetch", "write"):
     src = one(f"{tag}_{what}/**/*counter_collection.csv")

@@ -18,6 +18,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats" -o r
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${TAG}_fetch" -o run -- python3 "$ROOT/bench.py" --steps 3 --warmup 2 $ARGS > "$OUT/${TAG}_fetch.log" 2>&1 &&
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${TAG}_write" -o run -- python3 "$ROOT/bench.py" --steps 3 --warmup 2 $ARGS > "$OUT/${TAG}_write.log" 2>&1
 for w in stats fetch write; do echo "== $w"; tail -n 1 "$OUT/${TAG}_$w.log" | cut -c1-200; done
+# per-(kernel, grid size) table from the per-dispatch trace (before the trace is dropped): what bench.py's single-launch
+# roofline figure can be checked against
+python3 "$ROOT/tools/kstats_by_grid.py" "$(find "$OUT/${TAG}_stats" -name "*kernel_trace.csv" | head -1)" "$OUT/${TAG}_stats/kernel_by_grid.csv" 13
 # keep the csv summaries only (gpurun copies back at most 64 MiB)
 find "$OUT" -path "*${TAG}_*" -type f ! -name "*.csv" ! -name "*.log" -delete
 find "$OUT" -path "*${TAG}_*" -name "*kernel_trace.csv" -delete
