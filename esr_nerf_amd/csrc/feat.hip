@@ -504,8 +504,23 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
                 i0c[a] = (int)floorf(indc[a]);
             }
         }
-        // one accumulation window per ray of the tile (explicit points: a single window)
-        const int key = P.pts ? 0 : (valid ? P.rec_ray[j] : 0);
+        // one accumulation window per ray of the tile.  Explicit points carry no ray id, but the large explicit passes
+        // of the LTS stages (the perturbed re-evaluation of every surviving sample, esrnerf.py:807-830) list their points
+        // in ray order: the tile is cut into runs wherever consecutive points jump by more than 3 cells -- each run gets
+        // a tight window like a ray piece does.  (One box over a tile that holds pieces of 2-3 rays was shaved to its LDS
+        // share and most of the tile went to global atomics tap by tap: 0.52 ms for the perturbed pass against 0.23 ms
+        // for the primary pass over the same samples.)
+        int key = 0;
+        if (P.pts) {
+            const int px = __shfl_up(i0c[0], 1), py = __shfl_up(i0c[1], 1), pz = __shfl_up(i0c[2], 1);
+            const bool pv = __shfl_up(valid ? 1 : 0, 1) != 0;
+            const bool jump = valid && s > 0 && pv &&
+                              (abs(i0c[0] - px) > 3 || abs(i0c[1] - py) > 3 || abs(i0c[2] - pz) > 3);
+            const unsigned runs = (unsigned)__ballot(jump);                  // low half: one bit per sample
+            key = __popc(runs & ((2u << s) - 1u));
+        } else {
+            key = valid ? P.rec_ray[j] : 0;
+        }
         int wid = winset_init(WS, key, valid, i0c);
         // A ray piece that runs diagonally through the grid has a bounding box far larger than the cells it touches
         // (32 samples = 16 voxels of path along (1,1,1): 15^3 SDF cells, 11^3 x 6 colour floats) -- the box was shaved to
@@ -513,7 +528,7 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
         // stage: 65 atomic instructions per tile against 18 for axis-parallel rays).  When a window of the tile does not
         // fit, its ray piece is cut into consecutive runs of samples with a window each (4 windows per tile as before:
         // 1 ray -> 4 runs, 2 rays -> 2 + 2, 3 rays -> the longest piece 2): 8 samples span <= 4 voxels, whose box fits.
-        if (!P.pts && WS.nw < MAX_WIN && winset_overflows(WS)) {
+        if (WS.nw < MAX_WIN && winset_overflows(WS)) {
             int newkey = 0;
             int longest = 0, longest_len = -1;
             unsigned pieces[MAX_WIN];
