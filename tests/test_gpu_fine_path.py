@@ -202,6 +202,52 @@ def test_mlp_engine_fwd_dgrad_wgrad_vs_torch(kind, tiles, crow):
         assert rel_err(gb[i], Bs[i].grad) < 2e-5, ("gb", i)
 
 
+@pytest.mark.parametrize("t_on,t_all", [(0, 5), (7, 7), (3, 11), (130, 257), (600, 1100)])
+def test_merged_radiance_launches_equal_the_separate_ones(t_on, t_all):
+    """esr_mlp_fwd_fine / esr_mlp_dgrad_fine (round 3: the step's three radiance forward passes as one launch, the two
+    input-gradient passes as one) against the separate launches they replace -- same kernels, same per-tile arithmetic:
+    every output tile, saved activation, mask, dZ and dX bit for bit."""
+    from esr_nerf_amd import _lib
+    from esr_nerf_amd.fine_engine import FineEngine
+    eng = FineEngine("cuda:0")
+    L, s = eng.L, _lib.stream_ptr("cuda:0")
+    g = torch.Generator().manual_seed(t_all * 7 + t_on)
+    dims = [85, 192, 192, 192, 3]
+    nets = {}
+    for name in ("off", "emo"):
+        Ws = [(torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5).cuda() for i in range(4)]
+        Bs = [(torch.randn(dims[i + 1], generator=g) * 0.1).cuda() for i in range(4)]
+        eng.pack(name, 0, Ws, Bs)
+        nets[name] = (Ws, Bs)
+    X = torch.randn(t_all * 104 * 32, generator=g).cuda()
+    dz = torch.randn(t_all * 4 * 32, generator=g).cuda()
+
+    def bufs():
+        f = lambda rows, dt=torch.float32: torch.full((max(t_all, 1) * rows * 32,), -3, dtype=dt, device="cuda")
+        return dict(H=[f(192) for _ in range(3)], M=[torch.full((max(t_all, 1) * 3 * 64,), -3, dtype=torch.int32, device="cuda") for _ in range(3)],
+                    z_off=f(4), z_emo=f(4), dZ=[f(192) for _ in range(3)], dX=f(64))
+    A, B = bufs(), bufs()
+    pa = _lib.ptr_array
+    # separate launches (round 2's sequence)
+    _lib.check(L.esr_mlp_fwd_mixed(0, _lib.ptr(eng.packed["off"]), _lib.ptr(X), 0, t_on, t_all, pa(A["H"]), pa(A["M"]), 88,
+                                   _lib.ptr(A["z_off"]), s), "mixed")
+    _lib.check(L.esr_mlp_fwd(0, _lib.ptr(eng.packed["emo"]), _lib.ptr(X), 0, t_on, pa(A["H"]), pa(A["M"]), 1, 0,
+                             _lib.ptr(A["z_emo"]), s), "emo")
+    _lib.check(L.esr_mlp_dgrad(0, _lib.ptr(eng.packed["emo"]), _lib.ptr(dz), 0, t_on, pa(A["M"]), pa(A["dZ"]), _lib.ptr(A["dX"]), s), "dg emo")
+    _lib.check(L.esr_mlp_dgrad(0, _lib.ptr(eng.packed["off"]), _lib.ptr(dz), t_on, t_all, pa(A["M"]), pa(A["dZ"]), _lib.ptr(A["dX"]), s), "dg off")
+    # merged launches
+    _lib.check(L.esr_mlp_fwd_fine(_lib.ptr(eng.packed["off"]), _lib.ptr(eng.packed["emo"]), _lib.ptr(X), t_on, t_all, pa(B["H"]),
+                                  pa(B["M"]), 88, _lib.ptr(B["z_off"]), _lib.ptr(B["z_emo"]), s), "fwd_fine")
+    _lib.check(L.esr_mlp_dgrad_fine(_lib.ptr(eng.packed["emo"]), _lib.ptr(eng.packed["off"]), _lib.ptr(dz), t_on, t_all, pa(B["M"]),
+                                    pa(B["dZ"]), _lib.ptr(B["dX"]), s), "dgrad_fine")
+    torch.cuda.synchronize()
+    for k in ("z_off", "z_emo", "dX"):
+        assert torch.equal(A[k], B[k]), k
+    for k in ("H", "M", "dZ"):
+        for l in range(3):
+            assert torch.equal(A[k][l], B[k][l]), (k, l)
+
+
 @pytest.mark.parametrize("tiles,t0", [(1, 0), (7, 2), (300, 0), (1500, 17)])
 def test_tone_wgrad_recompute_vs_torch(tiles, t0):
     """esr_tone_wgrad_recompute (csrc/tone_wgrad.hip): the tone mapper's weight gradients from Xt and dzt alone -- the
