@@ -236,7 +236,9 @@ __device__ __forceinline__ int xperm(int s)                    // position of sa
     return (2 * (r >> 3) + hh) * 8 + (r & 7);
 }
 
-__global__ void __launch_bounds__(256, 2) tone_wgrad16_t_kernel(ToneWgArgs A)
+// (launch bound 1, not 2: asked for two waves per SIMD the compiler squeezes into 256 registers with 46 spills -- 0.19 ms at
+// C3; left alone it takes 230 without spills, which still lets two workgroups share a CU -- 0.14 ms)
+__global__ void __launch_bounds__(256, 1) tone_wgrad16_t_kernel(ToneWgArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
     __bf16 *w0b = reinterpret_cast<__bf16 *>(lds16);                       // [192][W0B_U]: w0b[u * W0B_U + x] = bf16(W0[u][x])
@@ -325,21 +327,20 @@ __global__ void __launch_bounds__(256, 2) tone_wgrad16_t_kernel(ToneWgArgs A)
         for (int i3 = 0; i3 < 3; ++i3)
 #pragma unroll
             for (int r = 0; r < 16; ++r) ht[i3][r] = fmaxf(ht[i3][r], 0.f);
-        // ---- dW1[c][u] += sum_s bf16(dzt[c][s]) bf16(Ht[u][s])   (the saved-tile path's operands: dz rounded on its way
-        // to the operand registers, Ht stored as bf16)
+        // ---- dW1[c][u] += sum_s dzt[c][s] Ht[u][s]: fp32 sums of UNROUNDED values (the saved-tile path rounded both to
+        // bf16 on their way to its MFMA; here they are vector operands, and rounding them would only add ~100 vector
+        // instructions per tile to a kernel that is bound by its vector work)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 a = *reinterpret_cast<const float4 *>(lz + 0 * XS + 8 * q + 4 * h);
             const float4 b = *reinterpret_cast<const float4 *>(lz + 1 * XS + 8 * q + 4 * h);
             const float4 c = *reinterpret_cast<const float4 *>(lz + 2 * XS + 8 * q + 4 * h);
-            const float za4[4] = {bf16r(a.x), bf16r(a.y), bf16r(a.z), bf16r(a.w)};
-            const float zb4[4] = {bf16r(b.x), bf16r(b.y), bf16r(b.z), bf16r(b.w)};
-            const float zc4[4] = {bf16r(c.x), bf16r(c.y), bf16r(c.z), bf16r(c.w)};
+            const float za4[4] = {a.x, a.y, a.z, a.w}, zb4[4] = {b.x, b.y, b.z, b.w}, zc4[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
             for (int i3 = 0; i3 < 3; ++i3)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float hv = bf16r(ht[i3][4 * q + i]);
+                    const float hv = ht[i3][4 * q + i];
                     dW1r[i3][0] = fmaf(za4[i], hv, dW1r[i3][0]);
                     dW1r[i3][1] = fmaf(zb4[i], hv, dW1r[i3][1]);
                     dW1r[i3][2] = fmaf(zc4[i], hv, dW1r[i3][2]);
@@ -350,7 +351,7 @@ __global__ void __launch_bounds__(256, 2) tone_wgrad16_t_kernel(ToneWgArgs A)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 d = *reinterpret_cast<const float4 *>(lx32 + 8 * q + 4 * h);
-            x32[4 * q] = bf16r(d.x); x32[4 * q + 1] = bf16r(d.y); x32[4 * q + 2] = bf16r(d.z); x32[4 * q + 3] = bf16r(d.w);
+            x32[4 * q] = d.x; x32[4 * q + 1] = d.y; x32[4 * q + 2] = d.z; x32[4 * q + 3] = d.w;
         }
         // ---- dHt^T = dzt^T W1 masked by the recomputed activation; then dW0 += dZt Xt^T
         // slots 0..2 of half 0 = dzt rows 0..2 of this lane's sample (row 1 lives in the OTHER half's za[0])
@@ -366,7 +367,7 @@ __global__ void __launch_bounds__(256, 2) tone_wgrad16_t_kernel(ToneWgArgs A)
             float sb = 0.f, sc = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = ht[i3][r] > 0.f ? bf16r(d[r]) : 0.f;         // dZt as the saved-tile path stored it
+                const float v = ht[i3][r] > 0.f ? d[r] : 0.f;                // (rounded to bf16 only as the operand of dW0 below)
                 d[r] = v;
                 sb += v;
                 sc = fmaf(v, x32[r], sc);

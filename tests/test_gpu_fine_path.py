@@ -285,8 +285,8 @@ def test_tone_wgrad_recompute_vs_torch(tiles, t0):
 @pytest.mark.parametrize("tiles,t0", [(1, 0), (7, 2), (300, 0), (1500, 17)])
 def test_tone_wgrad_recompute_bf16_vs_emulation(tiles, t0):
     """esr_tone_wgrad_recompute_bf16: the same kernel scheme with bf16 matrix operands, against a torch emulation of
-    exactly that arithmetic -- Xt, W0, dzt, W1 rounded to bf16 where they become an operand, the recomputed Ht and dZt
-    rounded where the saved-tile path stored them as bf16, sums in fp32.  2e-3 of the max-norm, as for the bf16 MLP
+    exactly that arithmetic -- Xt, W0, dzt, W1 and the recomputed dZt rounded to bf16 where they become a matrix operand,
+    everything the kernel sums on the vector lanes (dW1, db0, the 33rd input column) unrounded, sums in fp32.  2e-3 of the max-norm, as for the bf16 MLP
     kernels (a value on a bf16 rounding boundary may round the other way under a different summation order)."""
     from esr_nerf_amd import _lib
     L = _lib.lib()
@@ -302,8 +302,10 @@ def test_tone_wgrad_recompute_bf16_vs_emulation(tiles, t0):
     ht = torch.relu(pre)
     dz = torch.randn(x.shape[0], 3, generator=g)
     dz[(pre.abs() < 1e-3).any(-1)] = 0                            # knife-edge samples (bf16 operands: a wider edge)
-    dZt = bf((bf(dz) @ bf(W1)) * (ht > 0))
-    want = (dZt.t() @ bf(x), dZt.sum(0), bf(dz).t() @ bf(ht), dz.sum(0))
+    dZt = (bf(dz) @ bf(W1)) * (ht > 0)                            # fp32 accumulators of the kernel's dHt MFMA, masked
+    gw0 = torch.cat([bf(dZt).t() @ bf(x[:, :32]),                 # columns 0..31: bf16 MFMA operands
+                     (dZt.t() @ x[:, 32:33])], 1)                 # column 32, db0, dW1: fp32 vector sums of unrounded values
+    want = (gw0, dZt.sum(0), dz.t() @ ht, dz.sum(0))
     dzt = torch.zeros(tiles, 4, 32)
     dzt[t0:, :3] = dz.reshape(tiles - t0, 32, 3).permute(0, 2, 1)
     dzt[:t0] = 5.0
