@@ -462,7 +462,7 @@ def main():
     for i_ in range(a.warmup - n_prof - n_lead):
         one(i_)
     if n_prof:
-        counts = dict(model.last_counts, merged_off_pass=(a.dtype == "f32" and stage == "fine"))
+        counts = dict(model.last_counts, merged_off_pass=(stage == "fine"))
         by_kernel = {}
         for call, kname in KERNEL_OF.items():
             if call in breakdown:
@@ -475,7 +475,7 @@ def main():
     dom_calls = sorted(dom_calls, key=lambda c: -breakdown[c][1])[:1]
     if not dom_calls and not a.no_kernel_timing and stage == "fine":
         # too few warm-up steps for the breakdown: bracket the kernel that dominates every profile taken so far
-        dominant, dom_calls = "mlp_fwd_kernel<0>", ["mlp_fwd(rad)" if (getattr(eng, "merge_rad", False) and a.dtype == "f32") else "mlp_fwd(emo)"]
+        dominant, dom_calls = "mlp_fwd_kernel<0>", ["mlp_fwd(rad)" if getattr(eng, "merge_rad", False) else "mlp_fwd(emo)"]
     # timed region: exactly K steps, events only around the dominant kernel's launches (on their stream)
     eng.enable_timing(dominant is not None, only=dom_calls if dominant else None)
     if pg is not None:
@@ -497,7 +497,7 @@ def main():
     kern = eng.timing_summary() if dominant else {}      # dominant kernel only: name -> (launches, total ms)
     eng.enable_timing(False)
     gc.enable()
-    counts = dict(model.last_counts, merged_off_pass=(a.dtype == "f32" and stage == "fine"))
+    counts = dict(model.last_counts, merged_off_pass=(stage == "fine"))
 
     # optimizer step, reported separately (outside the named path, never part of `value`)
     opt_ms = None

@@ -122,6 +122,35 @@ struct Fwd16Args {
     int save, crow;
     float *zout;
 };
+// Several passes of the same net KIND in ONE launch (esr_mlp_fwd_fine_bf16: the fine stage's three radiance forward passes,
+// esr_mlp_dgrad_fine_bf16: its two input-gradient passes): a workgroup works on exactly one segment (its weights stay in
+// LDS), segments get a share of the launch's workgroups proportional to their tiles.  X, H, M, dZ, dX are shared arrays.
+constexpr int MAX_SEG16 = 3;
+struct Seg16 {
+    const float *packed32;
+    const __bf16 *packed16;
+    int t0, t1, save, crow;
+    float *zout;
+    int b0, nb;                // workgroups [b0, b0 + nb) of the launch
+};
+struct Fwd16Batch {
+    Fwd16Args base;            // X, H, M (and, for nseg == 0, the single pass)
+    int nseg;
+    Seg16 seg[MAX_SEG16];
+};
+__device__ __forceinline__ Fwd16Args pick_seg16(const Fwd16Batch &B, int &b0, int &nb)
+{
+    Fwd16Args A = B.base;
+    b0 = 0; nb = (int)gridDim.x;
+#pragma unroll
+    for (int k = 0; k < MAX_SEG16; ++k)
+        if (k < B.nseg && (int)blockIdx.x >= B.seg[k].b0) {
+            const Seg16 &S = B.seg[k];
+            A.packed32 = S.packed32; A.packed16 = S.packed16; A.t0 = S.t0; A.t1 = S.t1; A.save = S.save; A.crow = S.crow;
+            A.zout = S.zout; b0 = S.b0; nb = S.nb;
+        }
+    return A;
+}
 
 // ---- forward / input gradients with the weights SHARED through LDS ----------------------------------------------------
 // The first version of these kernels (one wave = one tile end to end, as in mlp.hip) let every wave stream the whole
@@ -253,8 +282,10 @@ __device__ __forceinline__ void layer_barrier()
 }
 
 template <int KIND>
-__global__ void __launch_bounds__(64 * SHW, 1) mlp_fwd16s_kernel(Fwd16Args A)
+__global__ void __launch_bounds__(64 * SHW, 1) mlp_fwd16s_kernel(Fwd16Batch AB)
 {
+    int blk0, nblk;
+    const Fwd16Args A = pick_seg16(AB, blk0, nblk);
     using S = Shared16<KIND, false>;
     constexpr NetDesc D = S::D;
     constexpr int NL = S::NL, NHID = NL - 1, HT = D.hid_tiles;
@@ -286,7 +317,7 @@ __global__ void __launch_bounds__(64 * SHW, 1) mlp_fwd16s_kernel(Fwd16Args A)
     }
     layer_barrier();
     int cur_buf = 0;                                       // LDS buffer holding the layer about to run
-    for (int tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
+    for (int tg = (int)blockIdx.x - blk0; tg < ngroups; tg += nblk) {
         const int tt = A.t0 + tg * SHW + wv;
         const bool live = tt < A.t1;                       // a wave past the range runs on the last tile, stores nothing
         const int t = live ? tt : A.t1 - 1;
@@ -366,11 +397,29 @@ struct Dgrad16Args {
     float *dZ[3];
     float *dX;
 };
+struct Dgrad16Batch {
+    Dgrad16Args base;
+    int nseg;
+    Seg16 seg[MAX_SEG16];      // packed16, t0, t1, b0, nb used
+};
+__device__ __forceinline__ Dgrad16Args pick_dseg16(const Dgrad16Batch &B, int &b0, int &nb)
+{
+    Dgrad16Args A = B.base;
+    b0 = 0; nb = (int)gridDim.x;
+#pragma unroll
+    for (int k = 0; k < MAX_SEG16; ++k)
+        if (k < B.nseg && (int)blockIdx.x >= B.seg[k].b0) {
+            A.packed16 = B.seg[k].packed16; A.t0 = B.seg[k].t0; A.t1 = B.seg[k].t1; b0 = B.seg[k].b0; nb = B.seg[k].nb;
+        }
+    return A;
+}
 
 // ---- input gradients with the weights shared through LDS (the forward's scheme, layers in reverse) -------------------
 template <int KIND>
-__global__ void __launch_bounds__(64 * SHW, 1) mlp_dgrad16s_kernel(Dgrad16Args A)
+__global__ void __launch_bounds__(64 * SHW, 1) mlp_dgrad16s_kernel(Dgrad16Batch AB)
 {
+    int blk0, nblk;
+    const Dgrad16Args A = pick_dseg16(AB, blk0, nblk);
     using S = Shared16<KIND, true>;
     constexpr NetDesc D = S::D;
     constexpr int NL = S::NL, NHID = NL - 1, HT = D.hid_tiles;
@@ -394,7 +443,7 @@ __global__ void __launch_bounds__(64 * SHW, 1) mlp_dgrad16s_kernel(Dgrad16Args A
     }
     layer_barrier();
     int cur_buf = 0;
-    for (int tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
+    for (int tg = (int)blockIdx.x - blk0; tg < ngroups; tg += nblk) {
         const int tt = A.t0 + tg * SHW + wv;
         const bool live = tt < A.t1;                       // a wave past the range runs on the last tile, stores nothing
         const int t = live ? tt : A.t1 - 1;
@@ -452,9 +501,48 @@ int launch_dgrad16s(const Dgrad16Args &A, hipStream_t s)
     static std::atomic<uint64_t> optin{0};
     if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_dgrad16s_kernel<KIND>), 2 * S::BUF, optin)) return rc;
     const int groups = (A.t1 - A.t0 + SHW - 1) / SHW;
-    mlp_dgrad16s_kernel<KIND><<<groups < 256 ? groups : 256, 64 * SHW, 2 * S::BUF, s>>>(A);
+    Dgrad16Batch B = {};
+    B.base = A;
+    mlp_dgrad16s_kernel<KIND><<<groups < 256 ? groups : 256, 64 * SHW, 2 * S::BUF, s>>>(B);
     ESR_CHECK_LAUNCH();
     return 0;
+}
+
+// workgroups per segment proportional to its tile groups (every non-empty segment >= 1); returns the grid
+int share_blocks16(Seg16 *seg, int nseg)
+{
+    int groups[MAX_SEG16], total = 0;
+    for (int k = 0; k < nseg; ++k) { groups[k] = (seg[k].t1 - seg[k].t0 + SHW - 1) / SHW; total += groups[k]; }
+    const int grid = total < 256 ? total : 256;
+    int given = 0;
+    for (int k = 0; k < nseg; ++k) {
+        int n = (int)((int64_t)grid * groups[k] / (total > 0 ? total : 1));
+        if (n < 1) n = 1;
+        if (n > groups[k]) n = groups[k];
+        seg[k].nb = n;
+        given += n;
+    }
+    for (int guard = 0; given != grid && guard < 1024; ++guard) {
+        int pick = -1;
+        double best = 0.0;
+        for (int k = 0; k < nseg; ++k) {
+            if (given < grid) {
+                if (seg[k].nb >= groups[k]) continue;
+                const double load = (double)groups[k] / seg[k].nb;
+                if (pick < 0 || load > best) { pick = k; best = load; }
+            } else {
+                if (seg[k].nb <= 1) continue;
+                const double load = (double)groups[k] / (seg[k].nb - 1);
+                if (pick < 0 || load < best) { pick = k; best = load; }
+            }
+        }
+        if (pick < 0) break;
+        seg[pick].nb += given < grid ? 1 : -1;
+        given += given < grid ? 1 : -1;
+    }
+    int b0 = 0;
+    for (int k = 0; k < nseg; ++k) { seg[k].b0 = b0; b0 += seg[k].nb; }
+    return b0;
 }
 
 bool crow_ok(int kind, int crow)
@@ -470,7 +558,9 @@ int launch_fwd16s(const Fwd16Args &A, hipStream_t s)
     static std::atomic<uint64_t> optin{0};
     if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_fwd16s_kernel<KIND>), S::LDS_BYTES, optin)) return rc;
     const int groups = (A.t1 - A.t0 + SHW - 1) / SHW;
-    mlp_fwd16s_kernel<KIND><<<groups < 256 ? groups : 256, 64 * SHW, S::LDS_BYTES, s>>>(A);
+    Fwd16Batch B = {};
+    B.base = A;
+    mlp_fwd16s_kernel<KIND><<<groups < 256 ? groups : 256, 64 * SHW, S::LDS_BYTES, s>>>(B);
     ESR_CHECK_LAUNCH();
     return 0;
 }
@@ -525,6 +615,61 @@ ESR_API int esr_mlp_fwd_bf16(int kind, const float *packed32, const void *packed
     case ESR_MLP_EMIT:     return launch_fwd16s<ESR_MLP_EMIT>(A, s);
     default:               return launch_fwd16s<ESR_MLP_COARSE>(A, s);
     }
+}
+
+// The fine stage's three radiance forward passes of a step (bf16 engine) as ONE launch: see esr_mlp_fwd_fine.
+ESR_API int esr_mlp_fwd_fine_bf16(const float *packed32_off, const void *packed16_off, const float *packed32_emo,
+                                  const void *packed16_emo, const float *X, int32_t t_on, int32_t t_all, float *const *H,
+                                  uint32_t *const *M, int color_row_detached, float *z_off, float *z_emo, void *stream)
+{
+    if (t_on < 0 || t_all < t_on || !crow_ok(ESR_MLP_RADIANCE, color_row_detached)) return ESR_EINVAL;
+    if (t_all == 0) return 0;
+    if (!packed32_off || !packed16_off || !packed32_emo || !packed16_emo || !X || !H || !M || !z_off || !z_emo) return ESR_EINVAL;
+    using S = Shared16<ESR_MLP_RADIANCE, false>;
+    Fwd16Batch B = {};
+    B.base.X = X;
+    for (int l = 0; l < 3; ++l) {
+        if (!H[l] || !M[l]) return ESR_EINVAL;
+        B.base.H[l] = H[l]; B.base.M[l] = M[l];
+    }
+    const __bf16 *p16o = static_cast<const __bf16 *>(packed16_off), *p16e = static_cast<const __bf16 *>(packed16_emo);
+    int n = 0;
+    if (t_on > 0) B.seg[n++] = Seg16{packed32_off, p16o, 0, t_on, 0, color_row_detached, z_off, 0, 0};
+    if (t_all > t_on) B.seg[n++] = Seg16{packed32_off, p16o, t_on, t_all, 1, 0, z_off, 0, 0};
+    if (t_on > 0) B.seg[n++] = Seg16{packed32_emo, p16e, 0, t_on, 1, 0, z_emo, 0, 0};
+    B.nseg = n;
+    const int grid = share_blocks16(B.seg, n);
+    static std::atomic<uint64_t> optin{0};
+    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_fwd16s_kernel<ESR_MLP_RADIANCE>), S::LDS_BYTES, optin)) return rc;
+    mlp_fwd16s_kernel<ESR_MLP_RADIANCE><<<grid, 64 * SHW, S::LDS_BYTES, esr_stream(stream)>>>(B);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+// Both radiance nets' input gradients (bf16 engine) as ONE launch: emissive net on [0, t_on), non-emissive on [t_on, t_all).
+ESR_API int esr_mlp_dgrad_fine_bf16(const void *packed16_emo, const void *packed16_off, const float *dz, int32_t t_on,
+                                    int32_t t_all, const uint32_t *const *M, float *const *dZ, float *dX, void *stream)
+{
+    if (t_on < 0 || t_all < t_on) return ESR_EINVAL;
+    if (t_all == 0) return 0;
+    if (!packed16_emo || !packed16_off || !dz || !M || !dZ || !dX) return ESR_EINVAL;
+    using S = Shared16<ESR_MLP_RADIANCE, true>;
+    Dgrad16Batch B = {};
+    B.base.dz = dz; B.base.dX = dX;
+    for (int l = 0; l < 3; ++l) {
+        if (!M[l]) return ESR_EINVAL;
+        B.base.M[l] = M[l]; B.base.dZ[l] = dZ[l];
+    }
+    int n = 0;
+    if (t_on > 0) B.seg[n++] = Seg16{nullptr, static_cast<const __bf16 *>(packed16_emo), 0, t_on, 0, 0, nullptr, 0, 0};
+    if (t_all > t_on) B.seg[n++] = Seg16{nullptr, static_cast<const __bf16 *>(packed16_off), t_on, t_all, 0, 0, nullptr, 0, 0};
+    B.nseg = n;
+    const int grid = share_blocks16(B.seg, n);
+    static std::atomic<uint64_t> optin{0};
+    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_dgrad16s_kernel<ESR_MLP_RADIANCE>), 2 * S::BUF, optin)) return rc;
+    mlp_dgrad16s_kernel<ESR_MLP_RADIANCE><<<grid, 64 * SHW, 2 * S::BUF, esr_stream(stream)>>>(B);
+    ESR_CHECK_LAUNCH();
+    return 0;
 }
 
 ESR_API int esr_mlp_dgrad_bf16(int kind, const void *packed16, const float *dz, int32_t t0, int32_t t1,

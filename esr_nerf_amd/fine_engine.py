@@ -338,12 +338,16 @@ class FineEngine:
         elif not self.bf16:       # one launch, same weights (no launch seam, one ramp-up / tail instead of two)
                 self._run("mlp_fwd(off)", L.esr_mlp_fwd_mixed, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]),
                       0, tiles_on, tiles_all, H, M, 88, _lib.ptr(ws["z_off"]), s)
+        elif self.merge_rad:        # bf16 engine: the same three passes as one launch (a workgroup = one pass's weights in LDS)
+            po, pe = _lib.ptr(self.packed["off"]), _lib.ptr(self.packed["emo"])
+            self._run("mlp_fwd(rad)", L.esr_mlp_fwd_fine_bf16, po, self._p16[po.value], pe, self._p16[pe.value], _lib.ptr(ws["X"]),
+                      tiles_on, tiles_all, H, M, 88, _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), s)
         else:
             self._run("mlp_fwd(off|on-tiles)", self.mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), 0, tiles_on,
                                      H, M, 0, 88, _lib.ptr(ws["z_off"]), s)
             self._run("mlp_fwd(off)", self.mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), tiles_on,
                                      tiles_all, H, M, 1, 0, _lib.ptr(ws["z_off"]), s)
-        if self.bf16 or not self.merge_rad:
+        if not self.merge_rad:
             self._run("mlp_fwd(emo)", self.mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["emo"]), _lib.ptr(ws["X"]), 0, tiles_on,
                                      H, M, 1, 0, _lib.ptr(ws["z_emo"]), s)
         self._run("tone_in_fwd", L.esr_fine_tone_in_fwd, _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), tiles_on, tiles_all,
@@ -545,9 +549,14 @@ class FineEngine:
                   _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), to, ta,
                   _lib.ptr(ws["dz"]), s)
         M, dZ = self._H(["M0", "M1", "M2"]), self._H(["dZ0", "dZ1", "dZ2"])
-        if not self.bf16 and self.merge_rad and scat is None:      # both radiance nets' input gradients: one launch
-            self._run("mlp_dgrad(rad)", L.esr_mlp_dgrad_fine, _lib.ptr(self.packed["emo"]), _lib.ptr(self.packed["off"]),
-                      _lib.ptr(ws["dz"]), to, ta, M, dZ, _lib.ptr(ws["dX"]), s)
+        if self.merge_rad and scat is None:                        # both radiance nets' input gradients: one launch
+            if self.bf16:
+                pe, po = _lib.ptr(self.packed["emo"]), _lib.ptr(self.packed["off"])
+                self._run("mlp_dgrad(rad)", L.esr_mlp_dgrad_fine_bf16, self._p16[pe.value], self._p16[po.value],
+                          _lib.ptr(ws["dz"]), to, ta, M, dZ, _lib.ptr(ws["dX"]), s)
+            else:
+                self._run("mlp_dgrad(rad)", L.esr_mlp_dgrad_fine, _lib.ptr(self.packed["emo"]), _lib.ptr(self.packed["off"]),
+                          _lib.ptr(ws["dz"]), to, ta, M, dZ, _lib.ptr(ws["dX"]), s)
         else:
             dgrad("mlp_dgrad(emo)", KIND_RADIANCE, self.packed["emo"], ws["dz"], 0, to, M, dZ, ws["dX"])
             if scat is not None and to > 0:

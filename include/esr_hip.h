@@ -330,6 +330,12 @@ int esr_mlp_fwd_fine(const float *packed_off, const float *packed_emo, const flo
  * [t_on,t_all) in one launch (the non-emissive net's on-tile pass is detached in the reference: no gradient). */
 int esr_mlp_dgrad_fine(const float *packed_emo, const float *packed_off, const float *dz, int32_t t_on, int32_t t_all,
                        const uint32_t *const *M, float *const *dZ, float *dX, void *stream);
+/* The bf16 engine's twins of the two entries above (weights of both nets as packed by esr_mlp_pack / esr_mlp_pack_bf16). */
+int esr_mlp_fwd_fine_bf16(const float *packed32_off, const void *packed16_off, const float *packed32_emo,
+                          const void *packed16_emo, const float *X, int32_t t_on, int32_t t_all, float *const *H,
+                          uint32_t *const *M, int color_row_detached, float *z_off, float *z_emo, void *stream);
+int esr_mlp_dgrad_fine_bf16(const void *packed16_emo, const void *packed16_off, const float *dz, int32_t t_on, int32_t t_all,
+                            const uint32_t *const *M, float *const *dZ, float *dX, void *stream);
 
 /*
  * Input/hidden gradients over tiles [t0,t1) (a NULL dZ[l] is computed but not stored).  dz [tiles,4,32] -> dZ[l] (each

@@ -248,6 +248,47 @@ def test_merged_radiance_launches_equal_the_separate_ones(t_on, t_all):
             assert torch.equal(A[k][l], B[k][l]), (k, l)
 
 
+@pytest.mark.parametrize("t_on,t_all", [(0, 5), (7, 7), (3, 11), (130, 257), (1000, 2100)])
+def test_merged_radiance_launches_bf16_equal_the_separate_ones(t_on, t_all):
+    """The bf16 engine's twins (esr_mlp_fwd_fine_bf16 / esr_mlp_dgrad_fine_bf16: one workgroup = one pass's weights in
+    LDS, passes share the launch's workgroups by tile count) against the separate launches: bit for bit."""
+    from esr_nerf_amd import _lib
+    from esr_nerf_amd.fine_engine import FineEngine
+    eng = FineEngine("cuda:0", "bf16")
+    L, s = eng.L, _lib.stream_ptr("cuda:0")
+    g = torch.Generator().manual_seed(t_all * 5 + t_on)
+    dims = [85, 192, 192, 192, 3]
+    for name in ("off", "emo"):
+        Ws = [(torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5).cuda() for i in range(4)]
+        Bs = [(torch.randn(dims[i + 1], generator=g) * 0.1).cuda() for i in range(4)]
+        eng.pack(name, 0, Ws, Bs)
+    X = torch.randn(t_all * 104 * 32, generator=g).cuda()
+    dz = torch.randn(t_all * 4 * 32, generator=g).cuda()
+    po, pe = _lib.ptr(eng.packed["off"]), _lib.ptr(eng.packed["emo"])
+    p16o, p16e = eng._p16[po.value], eng._p16[pe.value]
+
+    def bufs():
+        f = lambda rows: torch.full((max(t_all, 1) * rows * 32,), -3.0, device="cuda")
+        return dict(H=[f(192) for _ in range(3)], M=[torch.full((max(t_all, 1) * 3 * 64,), -3, dtype=torch.int32, device="cuda") for _ in range(3)],
+                    z_off=f(4), z_emo=f(4), dZ=[f(192) for _ in range(3)], dX=f(64))
+    A, B = bufs(), bufs()
+    pa = _lib.ptr_array
+    _lib.check(L.esr_mlp_fwd_bf16(0, po, p16o, _lib.ptr(X), 0, t_on, pa(A["H"]), pa(A["M"]), 0, 88, _lib.ptr(A["z_off"]), s), "off det")
+    _lib.check(L.esr_mlp_fwd_bf16(0, po, p16o, _lib.ptr(X), t_on, t_all, pa(A["H"]), pa(A["M"]), 1, 0, _lib.ptr(A["z_off"]), s), "off")
+    _lib.check(L.esr_mlp_fwd_bf16(0, pe, p16e, _lib.ptr(X), 0, t_on, pa(A["H"]), pa(A["M"]), 1, 0, _lib.ptr(A["z_emo"]), s), "emo")
+    _lib.check(L.esr_mlp_dgrad_bf16(0, p16e, _lib.ptr(dz), 0, t_on, pa(A["M"]), pa(A["dZ"]), _lib.ptr(A["dX"]), s), "dg emo")
+    _lib.check(L.esr_mlp_dgrad_bf16(0, p16o, _lib.ptr(dz), t_on, t_all, pa(A["M"]), pa(A["dZ"]), _lib.ptr(A["dX"]), s), "dg off")
+    _lib.check(L.esr_mlp_fwd_fine_bf16(po, p16o, pe, p16e, _lib.ptr(X), t_on, t_all, pa(B["H"]), pa(B["M"]), 88,
+                                       _lib.ptr(B["z_off"]), _lib.ptr(B["z_emo"]), s), "fwd_fine16")
+    _lib.check(L.esr_mlp_dgrad_fine_bf16(p16e, p16o, _lib.ptr(dz), t_on, t_all, pa(B["M"]), pa(B["dZ"]), _lib.ptr(B["dX"]), s), "dgrad_fine16")
+    torch.cuda.synchronize()
+    for k in ("z_off", "z_emo", "dX"):
+        assert torch.equal(A[k], B[k]), k
+    for k in ("H", "M", "dZ"):
+        for l in range(3):
+            assert torch.equal(A[k][l], B[k][l]), (k, l)
+
+
 @pytest.mark.parametrize("tiles,t0", [(1, 0), (7, 2), (300, 0), (1500, 17)])
 def test_tone_wgrad_recompute_vs_torch(tiles, t0):
     """esr_tone_wgrad_recompute (csrc/tone_wgrad.hip): the tone mapper's weight gradients from Xt and dzt alone -- the

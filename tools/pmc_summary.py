@@ -40,8 +40,8 @@ P = os.path.join(ROOT, "profiles")
 # (round 3: the three radiance forward passes are one launch, esr_mlp_fwd_fine, and so are the two input-gradient passes)
 ORDER_F32 = {"mlp_fwd_kernel<0>": ["mlp_fwd(rad)"], "mlp_dgrad_kernel<0>": ["mlp_dgrad(rad)"],
              "mlp_fwd_kernel<1>": ["mlp_fwd(tone)"], "mlp_dgrad_kernel<1>": ["mlp_dgrad(tone)"]}
-ORDER_BF16 = {"mlp_fwd16s_kernel<0>": ["mlp_fwd(off|on-tiles)", "mlp_fwd(off)", "mlp_fwd(emo)"], "mlp_fwd16s_kernel<1>": ["mlp_fwd(tone)"], "mlp_fwd16_kernel<0>": ["mlp_fwd(off|on-tiles)", "mlp_fwd(off)", "mlp_fwd(emo)"],
-              "mlp_dgrad16_kernel<0>": ["mlp_dgrad(emo)", "mlp_dgrad(off)"], "mlp_dgrad16s_kernel<0>": ["mlp_dgrad(emo)", "mlp_dgrad(off)"], "mlp_dgrad16s_kernel<1>": ["mlp_dgrad(tone)"],
+ORDER_BF16 = {"mlp_fwd16s_kernel<0>": ["mlp_fwd(rad)"], "mlp_fwd16s_kernel<1>": ["mlp_fwd(tone)"],
+              "mlp_dgrad16s_kernel<0>": ["mlp_dgrad(rad)"], "mlp_dgrad16s_kernel<1>": ["mlp_dgrad(tone)"],
               "mlp_fwd16_kernel<1>": ["mlp_fwd(tone)"], "mlp_dgrad16_kernel<1>": ["mlp_dgrad(tone)"]}
 ORDER = (ORDER_BF16 if a.dtype == "bf16" else ORDER_F32) if a.stage == "fine" else {}
 
