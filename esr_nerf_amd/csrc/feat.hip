@@ -479,14 +479,54 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
         float p[3] = {0.f, 0.f, 0.f}, ind[3] = {0.f, 0.f, 0.f}, vdir_[3], sdfv_;
         int i0[3] = {0, 0, 0};
         const bool valid = sample_inputs(P, j, p, vdir_, sdfv_);
-        // gradient rows of this sample: sum over the nets that consumed the tile (rows 6-42 are shared)
-        auto dxrow = [&](int row) {
-            float v = 0.f;
+        // Gradient rows of this sample, summed over the nets that consumed the tile (rows 6-42 are shared), and the saved
+        // normals: ALL of a tile's loads are issued here, before anything waits.  (They used to be fetched where they are
+        // used, behind wave-uniform branches: ~60 load -> wait round trips per tile were 0.08 of this kernel's 0.29 ms at
+        // C2 -- tools/variant.sh with the loads replaced by constants.)  Lane half h needs the rows of its two bars only.
+        int nact = 0, k_one = 0;
 #pragma unroll
-            for (int k = 0; k < MAX_SRC; ++k)
-                if (k < P.n_src && t >= P.src_t0[k] && t < P.src_t1[k]) v += P.dX[k][((size_t)t * DXROWS + row) * 32 + s];
-            return v;
+        for (int k = 0; k < MAX_SRC; ++k)
+            if (k < P.n_src && t >= P.src_t0[k] && t < P.src_t1[k]) { if (!nact) k_one = k; ++nact; }
+        float r_n[3][4], r_dn[3][4], r_nrm[4], r_df[2][2][4], r_dsdf = 0.f, r_d3[3] = {0.f, 0.f, 0.f};
+        auto dx_rows = [&](const float *dXt, bool first) {
+            auto put = [&](float &dst, int row) { const float v = dXt[row * 32]; dst = first ? v : dst + v; };
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int ar = 0; ar < 3; ++ar) put(r_dn[ar][k], ROW_NRM + ar * 4 + k);
+#pragma unroll
+                for (int bar = 0; bar < 2; ++bar) {
+                    const int ar = bar == 0 ? h : 2;
+                    put(r_df[bar][0][k], ROW_FEAT + (2 * ar) * 4 + k);
+                    put(r_df[bar][1][k], ROW_FEAT + (2 * ar + 1) * 4 + k);
+                }
+            }
+            put(r_dsdf, ROW_SDF);
         };
+        if (P.grad_sdf) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                r_nrm[k] = Gn[k * 32];
+#pragma unroll
+                for (int ar = 0; ar < 3; ++ar) r_n[ar][k] = Xt[(ROW_NRM + ar * 4 + k) * 32];
+            }
+            if (nact == 1) {
+                dx_rows(P.dX[k_one] + (size_t)t * DXROWS * 32 + s, true);
+            } else {
+                bool first = true;
+#pragma unroll
+                for (int k = 0; k < MAX_SRC; ++k)
+                    if (k < P.n_src && t >= P.src_t0[k] && t < P.src_t1[k]) {
+                        dx_rows(P.dX[k] + (size_t)t * DXROWS * 32 + s, first);
+                        first = false;
+                    }
+            }
+            if (P.dsdf_extra) r_dsdf += P.dsdf_extra[j];
+        }
+        if (nact == 1) {             // the colour rows of the tile's only net (several nets: fetched in their passes)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) r_d3[c] = P.dX[k_one][((size_t)t * DXROWS + ROW_COL + 3 * h + c) * 32 + s];
+        }
         if (valid) {
             esr_world_to_index(p, sc.xyz_min, sc.xyz_max, gdims, ind);
 #pragma unroll
@@ -566,17 +606,13 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
             float through[3][4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float nrm = Gn[k * 32];
-                float n[3], dn[3], dot = 0.f;
+                const float nrm = r_nrm[k];
+                float dot = 0.f;
 #pragma unroll
-                for (int ar = 0; ar < 3; ++ar) {
-                    n[ar] = Xt[(ROW_NRM + ar * 4 + k) * 32];
-                    dn[ar] = dxrow(ROW_NRM + ar * 4 + k);
-                    dot += n[ar] * dn[ar];
-                }
+                for (int ar = 0; ar < 3; ++ar) dot += r_n[ar][k] * r_dn[ar][k];
 #pragma unroll
                 for (int ar = 0; ar < 3; ++ar)   // projection for |g| > eps, plain 1/eps scaling below it
-                    through[ar][k] = (nrm > 1e-12f) ? (dn[ar] - n[ar] * dot) / nrm : dn[ar] / 1e-12f;
+                    through[ar][k] = (nrm > 1e-12f) ? (r_dn[ar][k] - r_n[ar][k] * dot) / nrm : r_dn[ar][k] / 1e-12f;
             }
             // perpendicular (centre) weights per grid axis: [axis][low/high corner]
             float wc[3][2];
@@ -585,7 +621,7 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
                 wc[a][0] = (float)(i0c[a] + 1) - indc[a];
                 wc[a][1] = indc[a] - (float)i0c[a];
             }
-            float d_sdf = dxrow(ROW_SDF) + (P.dsdf_extra ? P.dsdf_extra[j] : 0.f);
+            float d_sdf = r_dsdf;
             if (P.dsdf_out) {                 // explicit points: the SDF value is an input, not a grid tap
                 if (h == 0) P.dsdf_out[j] = d_sdf;
                 d_sdf = 0.f;
@@ -631,8 +667,8 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
                     }
                     const float thr = (ar == 0 ? through[0][k] : (ar == 1 ? through[1][k] : through[2][k])) /
                                       ((cp - cm) + 1e-12f) / sc.voxel_size;
-                    const float dfm = dxrow(ROW_FEAT + (2 * ar) * 4 + k) - thr;
-                    const float dfp = dxrow(ROW_FEAT + (2 * ar + 1) * 4 + k) + thr;
+                    const float dfm = r_df[bar][0][k] - thr;
+                    const float dfp = r_df[bar][1][k] + thr;
                     deposit(ixm, dfm);
                     deposit(ixp, dfp);
                 }
@@ -676,7 +712,7 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
             if (valid) {
                 float d3[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) d3[c] = dXt[(ROW_COL + 3 * h + c) * 32];
+                for (int c = 0; c < 3; ++c) d3[c] = nact == 1 ? r_d3[c] : dXt[(ROW_COL + 3 * h + c) * 32];
                 Tri tr = esr_tri_setup(ind);
 #pragma unroll
                 for (int cx = 0; cx < 2; ++cx)
