@@ -46,11 +46,10 @@ __device__ __forceinline__ void tri_fetch_c(const float *__restrict__ g, const i
                 const int x = t.i0[0] + cx, y = t.i0[1] + cy, z = t.i0[2] + cz;
                 const bool inb = (x >= 0) & (x < dims[0]) & (y >= 0) & (y < dims[1]) & (z >= 0) & (z < dims[2]);
                 const float w = esr_corner_w(t, idx, cx, cy, cz);
-                if (inb) {
-                    const float *v = g + (((int64_t)x * dims[1] + y) * dims[2] + z) * C;
+                const float *v = g + (inb ? (((int64_t)x * dims[1] + y) * dims[2] + z) * C : 0);   // esr_ld_or0's reasoning
+                const float wz = inb ? w : 0.f;
 #pragma unroll
-                    for (int c = 0; c < C; ++c) out[c] += v[c] * w;
-                }
+                for (int c = 0; c < C; ++c) out[c] += v[c] * wz;
             }
 }
 

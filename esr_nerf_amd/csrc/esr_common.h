@@ -188,6 +188,17 @@ __device__ __forceinline__ float esr_corner_w(const Tri &t, const float idx[3], 
     return (wz * wy) * wx;
 }
 
+// Conditional gathers.  A load the compiler may not speculate -- `if (inb) acc += g[i] * w` or `inb ? g[i] : 0` -- becomes an
+// exec-masked region that ends in its own s_waitcnt vmcnt(0): the 8 corners of a trilinear fetch were 8 SERIAL memory
+// round trips (feat_fwd: ~140 of them per sample, 72 % of its wave time waiting).  Here the address of an out-of-grid
+// corner is replaced by element 0 and the value by 0: the loads of a fetch issue back to back, the sum is unchanged
+// (x + 0 * w == x).
+__device__ __forceinline__ float esr_ld_or0(const float *__restrict__ g, int64_t i, bool inb)
+{
+    const float v = g[inb ? i : 0];
+    return inb ? v : 0.f;
+}
+
 // 1-channel fetch with zero padding
 __device__ __forceinline__ float esr_tri_fetch1(const float *__restrict__ g, const int dims[3],
                                                 const float idx[3])
@@ -203,7 +214,8 @@ __device__ __forceinline__ float esr_tri_fetch1(const float *__restrict__ g, con
                 int x = t.i0[0] + cx, y = t.i0[1] + cy, z = t.i0[2] + cz;
                 bool inb = (x >= 0) & (x < dims[0]) & (y >= 0) & (y < dims[1]) & (z >= 0) & (z < dims[2]);
                 float w = esr_corner_w(t, idx, cx, cy, cz);
-                if (inb) acc += g[((int64_t)x * dims[1] + y) * dims[2] + z] * w;
+                // (explicit fma: what `if (inb) acc += g[i] * w` contracted to)
+                acc = __builtin_fmaf(esr_ld_or0(g, ((int64_t)x * dims[1] + y) * dims[2] + z, inb), w, acc);
             }
     return acc;
 }

@@ -85,13 +85,13 @@ __device__ __forceinline__ void tri_fetch6(const float *__restrict__ g, const in
                 int x = t.i0[0] + cx, y = t.i0[1] + cy, z = t.i0[2] + cz;
                 bool inb = (x >= 0) & (x < dims[0]) & (y >= 0) & (y < dims[1]) & (z >= 0) & (z < dims[2]);
                 float w = esr_corner_w(t, idx, cx, cy, cz);
-                if (inb) {
-                    const float2 *v = reinterpret_cast<const float2 *>(
-                        g + (((int64_t)x * dims[1] + y) * dims[2] + z) * 6);
-                    float2 a = v[0], b = v[1], c = v[2];
-                    out[0] += a.x * w; out[1] += a.y * w; out[2] += b.x * w;
-                    out[3] += b.y * w; out[4] += c.x * w; out[5] += c.y * w;
-                }
+                // unconditional loads (esr_ld_or0's reasoning): an out-of-grid corner reads voxel 0 with weight 0
+                const float2 *v = reinterpret_cast<const float2 *>(
+                    g + (inb ? (((int64_t)x * dims[1] + y) * dims[2] + z) * 6 : 0));
+                const float2 a = v[0], b = v[1], c = v[2];
+                w = inb ? w : 0.f;
+                out[0] += a.x * w; out[1] += a.y * w; out[2] += b.x * w;
+                out[3] += b.y * w; out[4] += c.x * w; out[5] += c.y * w;
             }
 }
 
@@ -143,7 +143,7 @@ __device__ __forceinline__ void bar_fill(const float *__restrict__ sdf, const in
                 c[axis] = b0 + o; c[pb] = i0[pb] + cb; c[pc] = i0[pc] + cc;
                 const bool inb = (c[0] >= 0) & (c[0] < dims[0]) & (c[1] >= 0) & (c[1] < dims[1]) & (c[2] >= 0) &
                                  (c[2] < dims[2]);
-                bar[o * 4 + cb * 2 + cc] = inb ? sdf[((int64_t)c[0] * dims[1] + c[1]) * dims[2] + c[2]] : 0.f;
+                bar[o * 4 + cb * 2 + cc] = esr_ld_or0(sdf, ((int64_t)c[0] * dims[1] + c[1]) * dims[2] + c[2], inb);
             }
 }
 

@@ -103,7 +103,8 @@ __global__ void __launch_bounds__(256) expgrad_kernel(ExpGradParams P)
                                      (i0[1] + cy < dims[1]) & (i0[2] + cz >= 0) & (i0[2] + cz < dims[2]);
                     const bool dropped = P.zero_pad && !inb;        // F.grid_sample zero padding
                     if (!BWD) {
-                        const float gcell = dropped ? 0.f : P.sdf[cell];
+                        const float raw = P.sdf[cell];                 // (cell is clamped: always loadable)
+                        const float gcell = dropped ? 0.f : raw;
                         val += gcell * c0; d[0] += gcell * c1; d[1] += gcell * c2; d[2] += gcell * c3;
                     } else {
                         const float t = gv * c0 + gd[0] * c1 + gd[1] * c2 + gd[2] * c3;

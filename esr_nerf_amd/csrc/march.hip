@@ -113,10 +113,9 @@ __device__ __forceinline__ float coarse_alpha_ic(const float *__restrict__ gg, c
                 const int x = t.i0[0] + cx, y = t.i0[1] + cy, z = t.i0[2] + cz;
                 const bool inb = (x >= 0) & (x < dims[0]) & (y >= 0) & (y < dims[1]) & (z >= 0) & (z < dims[2]);
                 const float w = esr_corner_w(t, ind, cx, cy, cz);
-                if (inb) {
-                    const float *q = gg + (((int64_t)x * dims[1] + y) * dims[2] + z) * 3;
-                    gv[0] += q[0] * w; gv[1] += q[1] * w; gv[2] += q[2] * w;
-                }
+                const float *q = gg + (inb ? (((int64_t)x * dims[1] + y) * dims[2] + z) * 3 : 0);   // esr_ld_or0's reasoning
+                const float q0 = inb ? q[0] : 0.f, q1 = inb ? q[1] : 0.f, q2 = inb ? q[2] : 0.f;
+                gv[0] += q0 * w; gv[1] += q1 * w; gv[2] += q2 * w;
             }
     const float dotp = (vd[0] * gv[0] + vd[1] * gv[1]) + vd[2] * gv[2];
     return (dotp * dist) * 0.5f;
