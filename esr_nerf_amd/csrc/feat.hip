@@ -305,6 +305,7 @@ struct WinSet {                        // wave-uniform
     int lo[MAX_WIN][3], wd[MAX_WIN][3];    // current phase: origin and extent in cells (x, y, z); z fastest
     int base[MAX_WIN];                 // first LDS word of the window
     int ch;
+    bool fit;                          // no window of this phase was shaved: every in-grid tap of every lane lies inside
 };
 struct LaneWin {                       // the window of THIS lane's sample
     lds_cell *lds;
@@ -364,6 +365,7 @@ __device__ __forceinline__ int winset_init(WinSet &W, int key, bool valid, const
 __device__ __forceinline__ void winset_phase(WinSet &W, const int dims[3], int below, int above, int ch)
 {
     W.ch = ch;
+    W.fit = true;
     const int share = WIN_CELLS / (W.nw > 0 ? W.nw : 1);
     const int cap = share / ch;
 #pragma unroll
@@ -377,6 +379,7 @@ __device__ __forceinline__ void winset_phase(WinSet &W, const int dims[3], int b
         }
         // too large: shave the longest extent until it fits (the rest goes straight to global memory)
         while ((long long)W.wd[k][0] * W.wd[k][1] * W.wd[k][2] > cap) {
+            W.fit = false;
             if (W.wd[k][0] >= W.wd[k][1] && W.wd[k][0] >= W.wd[k][2]) W.wd[k][0] = (W.wd[k][0] + 1) >> 1;
             else if (W.wd[k][1] >= W.wd[k][2]) W.wd[k][1] = (W.wd[k][1] + 1) >> 1;
             else W.wd[k][2] = (W.wd[k][2] + 1) >> 1;
@@ -437,6 +440,15 @@ __device__ __forceinline__ void window_add(const LaneWin &w, float *__restrict__
         atomicAdd(&g[(((int64_t)x * dims[1] + y) * dims[2] + z) * w.ch + c], v);
 }
 
+// The common case: no window of the phase was shaved (WinSet::fit).  A window spans the lanes' base cells with the phase's
+// margins, so every in-grid tap lies inside by construction: no bounds tests, the cell index is the lane's base index plus
+// offsets that are compile-time multiples of the window's strides (window_add's index arithmetic and tests were ~15 vector
+// instructions per LDS atomic, 72-96 atomics per lane).
+__device__ __forceinline__ void lds_add(lds_cell *p, float v)
+{
+    __hip_atomic_fetch_add(p, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __device__ __forceinline__ void winset_flush(const WinSet &W, lds_cell *lds, float *__restrict__ g, const int dims[3],
                                              int lane)
 {
@@ -460,7 +472,7 @@ __device__ __forceinline__ void winset_flush(const WinSet &W, lds_cell *lds, flo
     }
 }
 
-__global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
+__global__ void __launch_bounds__(256, 2) feat_bwd_kernel(FeatParams P)
 {
     extern __shared__ __attribute__((aligned(16))) double win_all[];
     const esr_scene_t &sc = P.sc;
@@ -599,6 +611,7 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
         if (P.grad_sdf) {       // null: the SDF grid is frozen (re-lighting fine-tune), colour phase only
         winset_phase(WS, gdims, 2, 3, 1);
         LaneWin w = lane_view(WS, wid, lds);
+        const bool fast = WS.fit && w.has;       // (a fifth ray of a tile has no window: global atomics)
         winset_zero(WS, lds, lane);
         lds_fence();
         if (valid) {
@@ -675,6 +688,11 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
                 // spread over the 2x2 perpendicular corners (axes pb < pc are the two axes != axis)
                 const int pb = axis == 0 ? 1 : 0, pc = axis == 2 ? 1 : 2;
                 const int o_lo = (bar == 1 && h == 1) ? 3 : 0, o_hi = (bar == 1 && h == 0) ? 3 : 6;
+                // window strides of the three grid axes (1 channel) and this lane's base cell in its window
+                const int st[3] = {w.wd[1] * w.wd[2], w.wd[2], 1};
+                const int sA = axis == 0 ? st[0] : (axis == 1 ? st[1] : st[2]);
+                const int sB = pb == 0 ? st[0] : st[1], sC = pc == 1 ? st[1] : st[2];
+                lds_cell *const cell0 = w.lds + (((i0c[0] - w.lo[0]) * w.wd[1] + (i0c[1] - w.lo[1])) * w.wd[2] + (i0c[2] - w.lo[2]));
 #pragma unroll
                 for (int o = 0; o < 6; ++o) {
                     if (o < o_lo || o >= o_hi || acc6[o] == 0.f) continue;
@@ -691,7 +709,10 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
                             xyz[pc] = (pc == 1 ? i0c[1] : i0c[2]) + c;
                             const bool inb = (xyz[pb] < (pb == 0 ? gdims[0] : gdims[1])) &
                                              (xyz[pc] < (pc == 1 ? gdims[1] : gdims[2]));
-                            if (inb && wgt != 0.f) window_add(w, P.grad_sdf, gdims, xyz[0], xyz[1], xyz[2], 0, acc6[o] * wgt);
+                            if (inb && wgt != 0.f) {
+                                if (fast) lds_add(cell0 + ((o - 2) * sA + b * sB + c * sC), acc6[o] * wgt);
+                                else window_add(w, P.grad_sdf, gdims, xyz[0], xyz[1], xyz[2], 0, acc6[o] * wgt);
+                            }
                         }
                 }
             }
@@ -707,6 +728,7 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
             const float *dXt = P.dX[k] + (size_t)t * DXROWS * 32 + s;
             winset_phase(WS, gdims, 0, 1, 6);
             const LaneWin w = lane_view(WS, wid, lds);
+            const bool fast = WS.fit && w.has;
             winset_zero(WS, lds, lane);
             lds_fence();
             if (valid) {
@@ -714,6 +736,9 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) d3[c] = nact == 1 ? r_d3[c] : dXt[(ROW_COL + 3 * h + c) * 32];
                 Tri tr = esr_tri_setup(ind);
+                // (an in-grid corner of a sample is its clamped base cell or that cell + 1, also for points outside the box)
+                lds_cell *const cell0 = w.lds + ((((tr.i0[0] - w.lo[0]) * w.wd[1] + (tr.i0[1] - w.lo[1])) * w.wd[2] + (tr.i0[2] - w.lo[2])) * 6 + 3 * h);
+                const int sx = w.wd[1] * w.wd[2] * 6, sy = w.wd[2] * 6;
 #pragma unroll
                 for (int cx = 0; cx < 2; ++cx)
 #pragma unroll
@@ -725,7 +750,10 @@ __global__ void __launch_bounds__(256) feat_bwd_kernel(FeatParams P)
                             float wgt = esr_corner_w(tr, ind, cx, cy, cz);
                             if (inb && wgt != 0.f) {
 #pragma unroll
-                                for (int c = 0; c < 3; ++c) window_add(w, gcol, gdims, x, y, z, 3 * h + c, d3[c] * wgt);
+                                for (int c = 0; c < 3; ++c) {
+                                    if (fast) lds_add(cell0 + (cx * sx + cy * sy + cz * 6 + c), d3[c] * wgt);
+                                    else window_add(w, gcol, gdims, x, y, z, 3 * h + c, d3[c] * wgt);
+                                }
                             }
                         }
             }
