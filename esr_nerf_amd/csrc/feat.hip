@@ -293,25 +293,28 @@ constexpr int WIN_CELLS = 2560;           // 20 KB of doubles per wave (2 workgr
 // branch of window_add into one flat_atomic_add_f32 on a selected address
 typedef __attribute__((address_space(3))) double lds_cell;
 
-// Up to four ray-local windows per tile.  At the start of training a tile is 32 consecutive samples of ONE ray;
-// later (large s_val) a ray keeps ~20 samples and a tile holds pieces of 2-3 rays that can sit anywhere in the
-// grid: one bounding box over all of them is mostly empty (the zero / flush loops walked 4096 words per
-// phase) and its clipped remainder sent the other rays' samples to global atomics.  Each of the first four rays
-// of a tile now gets its own tight window (WIN_CELLS / n_windows cells each); a fifth ray goes to global atomics.
-constexpr int MAX_WIN = 4;
-struct WinSet {                        // wave-uniform
-    int nw;                            // windows in use
-    int mn[MAX_WIN][3], mx[MAX_WIN][3];    // bounds of the (clamped) base cells of the window's lanes
-    int lo[MAX_WIN][3], wd[MAX_WIN][3];    // current phase: origin and extent in cells (x, y, z); z fastest
-    int base[MAX_WIN];                 // first LDS word of the window
-    int ch;
-    bool fit;                          // no window of this phase was shaved: every in-grid tap of every lane lies inside
+// One accumulation window per SEGMENT of the tile: a run of consecutive samples of one ray (or, for explicit points, of
+// one spatially coherent run).  At the start of training a tile is 32 consecutive samples of ONE ray; later (large s_val) a
+// ray keeps ~20 samples, and the secondary rays of the LTS stages 7 (median): a tile then holds pieces of 2-10 rays that
+// can sit anywhere in the grid.  Everything about the segments lives in per-lane registers (both lane halves hold the
+// same values) and is built with SEGMENTED scans over the 32 samples -- 5 shuffle steps whatever the number of
+// segments -- and every window gets exactly the LDS cells its box needs (exclusive prefix sum of the box sizes).
+// Round 2's form kept <= 4 windows in wave-uniform registers (one 6-step wave reduction per window and bound: 48-174
+// shuffles per tile, 35 spilled scalar registers), gave each an EQUAL share of the LDS and shaved boxes to fit: the fifth ray
+// of a tile and everything outside a shaved box went to global atomics tap by tap (12 % resp. ~40 % of the C4 secondary
+// pass's tiles, which ran 5x slower per tile than the primary pass).  A window that does not fit now gets no cells at all
+// (its lanes use global atomics): no bounds tests anywhere.
+struct Segs {
+    unsigned heads;                    // wave-uniform: bit s set = sample s starts a segment
+    int start, last;                   // per lane: first / last sample (0..31) of this lane's segment
+    int mn[3], mx[3];                  // per lane: bounds of the (clamped) base cells of the segment's samples
 };
-struct LaneWin {                       // the window of THIS lane's sample
-    lds_cell *lds;
-    int lo[3], wd[3];
-    int ch;
-    bool has;
+struct LaneWin {                       // the window of THIS lane's segment in one phase
+    lds_cell *lds;                     // its first cell
+    int lo[3], wd[3];                  // origin and extent in grid cells (x, y, z); z fastest
+    int base, cells;                   // first LDS word, number of words (cells x channels)
+    int total;                         // wave-uniform: words asked for by all segments of the tile
+    bool has;                          // the window fits (else: this lane scatters straight to global memory)
 };
 
 // Ordering of one wave's own LDS accesses: the hardware executes a wave's DS instructions in
@@ -319,154 +322,121 @@ struct LaneWin {                       // the window of THIS lane's sample
 // would also wait vmcnt(0), i.e. drain the global atomics of the previous flush (~us each).
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-__device__ __forceinline__ int wave_min_i(int v)
+// segments of the tile: a new one starts where the key changes (ray id / run id), after a padding lane, and -- cut8 --
+// at every 8th sample of a segment (see the kernel: ray pieces whose box does not fit)
+__device__ __forceinline__ Segs segs_build(int key, bool valid, bool cut8, const int i0c[3], int s, int h)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ int wave_max_i(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return v;
-}
-
-// window id of every lane (key = ray id of the lane's sample, ascending inside a tile; invalid lanes: none)
-// and the raw cell bounds of each window
-__device__ __forceinline__ int winset_init(WinSet &W, int key, bool valid, const int i0[3])
-{
-    constexpr int NONE = 0x7fffffff;
-    const int k0 = valid ? key : NONE;
-    int wid = -1, lower = -1;
-    W.nw = 0;
-#pragma unroll
-    for (int k = 0; k < MAX_WIN; ++k) {
-        const int c = (k == W.nw) ? wave_min_i(k0 > lower ? k0 : NONE) : NONE;   // k-th smallest distinct key
-        const bool live = c != NONE;                             // wave-uniform
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { W.mn[k][a] = 0x3fffffff; W.mx[k][a] = -0x3fffffff; }
-        if (live) {                                              // (single-ray tiles pay for one window only)
-            W.nw = k + 1;
-            lower = c;
-            const bool mine = k0 == c;
-            if (mine) wid = k;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                W.mn[k][a] = wave_min_i(mine ? i0[a] : 0x3fffffff);
-                W.mx[k][a] = wave_max_i(mine ? i0[a] : -0x3fffffff);
-            }
-        }
+    Segs S;
+    const int pk = __shfl_up(key, 1);
+    const bool pv = __shfl_up(valid ? 1 : 0, 1) != 0;
+    bool head = valid && (s == 0 || !pv || key != pk);
+    S.heads = (unsigned)__ballot(head);                              // low word: one bit per sample
+    const unsigned upto = (2u << s) - 1u;                            // bits 0..s  (s = 31: 2u << 31 == 0, - 1 -> all ones)
+    unsigned below = S.heads & upto;
+    S.start = below ? 31 - __clz(below) : s;
+    if (cut8) {
+        head = head || (valid && ((s - S.start) & 7) == 0);
+        S.heads = (unsigned)__ballot(head);
+        below = S.heads & upto;
+        S.start = below ? 31 - __clz(below) : s;
     }
-    return wid;
-}
-
-// windows of one phase: [mn - below, mx + above] clipped to the grid and to its share of the LDS budget
-__device__ __forceinline__ void winset_phase(WinSet &W, const int dims[3], int below, int above, int ch)
-{
-    W.ch = ch;
-    W.fit = true;
-    const int share = WIN_CELLS / (W.nw > 0 ? W.nw : 1);
-    const int cap = share / ch;
+    const unsigned above = S.heads & ~upto;
+    const int endx = above ? __ffs(above) - 1 : 32;                  // first sample of the next segment
+    const unsigned vmask = (unsigned)__ballot(valid);
+    const unsigned inseg = vmask & (endx == 32 ? 0xffffffffu : ((1u << endx) - 1u)) & ~((1u << S.start) - 1u);
+    S.last = inseg ? 31 - __clz(inseg) : s;
+    // segmented min-scan; half 0 scans the cells, half 1 their negatives (= max): 3 values x 5 steps for both bounds
+    int v[3];
 #pragma unroll
-    for (int k = 0; k < MAX_WIN; ++k) {
-        W.base[k] = k * share;
+    for (int a = 0; a < 3; ++a) v[a] = valid ? (h ? -i0c[a] : i0c[a]) : 0x3fffffff;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            W.lo[k][a] = max(W.mn[k][a] - below, 0);
-            const int hi = min(W.mx[k][a] + above, dims[a] - 1);
-            W.wd[k][a] = (k < W.nw) ? max(hi - W.lo[k][a] + 1, 0) : 0;
-        }
-        // too large: shave the longest extent until it fits (the rest goes straight to global memory)
-        while ((long long)W.wd[k][0] * W.wd[k][1] * W.wd[k][2] > cap) {
-            W.fit = false;
-            if (W.wd[k][0] >= W.wd[k][1] && W.wd[k][0] >= W.wd[k][2]) W.wd[k][0] = (W.wd[k][0] + 1) >> 1;
-            else if (W.wd[k][1] >= W.wd[k][2]) W.wd[k][1] = (W.wd[k][1] + 1) >> 1;
-            else W.wd[k][2] = (W.wd[k][2] + 1) >> 1;
+            const int o = __shfl_up(v[a], off);
+            if (s - off >= S.start) v[a] = min(v[a], o);             // (same segment => same lane half)
         }
     }
-}
-
-// does a window's box exceed its LDS share in the SDF phase (margins 2 + 3, 1 channel) or a colour phase (0 + 1, 6)?
-__device__ __forceinline__ bool winset_overflows(const WinSet &W)
-{
-    const int share = WIN_CELLS / (W.nw > 0 ? W.nw : 1);
-    bool over = false;
 #pragma unroll
-    for (int k = 0; k < MAX_WIN; ++k) {
-        if (k >= W.nw) continue;
-        const long long e0 = W.mx[k][0] - W.mn[k][0] + 1, e1 = W.mx[k][1] - W.mn[k][1] + 1, e2 = W.mx[k][2] - W.mn[k][2] + 1;
-        over = over || (e0 + 5) * (e1 + 5) * (e2 + 5) > share || (e0 + 1) * (e1 + 1) * (e2 + 1) * 6 > share;
+    for (int a = 0; a < 3; ++a) {
+        const int r = __shfl(v[a], 32 * h + S.last);                 // the segment's last sample holds the whole scan
+        const int other = __shfl_xor(r, 32);
+        S.mn[a] = h == 0 ? r : other;
+        S.mx[a] = h == 0 ? -other : -r;
     }
-    return over;
+    return S;
 }
 
-__device__ __forceinline__ LaneWin lane_view(const WinSet &W, int wid, lds_cell *lds)
+// this lane's window for one phase: the segment's box [mn - below, mx + above] clipped to the grid, `ch` words per cell
+__device__ __forceinline__ LaneWin seg_window(const Segs &S, bool valid, const int dims[3], int below, int above, int ch,
+                                              lds_cell *lds, int s, int h)
 {
     LaneWin w;
-    w.ch = W.ch;
-    w.has = wid >= 0;
-    int base = 0;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { w.lo[a] = 0; w.wd[a] = 0; }
+    for (int a = 0; a < 3; ++a) {
+        w.lo[a] = max(S.mn[a] - below, 0);
+        w.wd[a] = max(min(S.mx[a] + above, dims[a] - 1) - w.lo[a] + 1, 0);
+    }
+    // (a box too large to count in 32 bits is simply "does not fit")
+    const long long want = valid ? (long long)w.wd[0] * w.wd[1] * w.wd[2] * ch : 0;
+    w.cells = (int)(want < (long long)WIN_CELLS + 1 ? want : (long long)WIN_CELLS + 1);
+    int inc = (valid && s == S.start) ? w.cells : 0;                 // one contribution per segment, at its head
 #pragma unroll
-    for (int k = 0; k < MAX_WIN; ++k)
-        if (wid == k) {
-            base = W.base[k];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) { w.lo[a] = W.lo[k][a]; w.wd[a] = W.wd[k][a]; }
-        }
-    w.lds = lds + base;
+    for (int off = 1; off < 32; off <<= 1) {
+        const int o = __shfl_up(inc, off);
+        if (s >= off) inc += o;
+    }
+    w.base = __shfl(inc, 32 * h + S.start) - w.cells;
+    w.total = __builtin_amdgcn_readlane(inc, 31);
+    w.has = valid && w.base + w.cells <= WIN_CELLS;
+    w.lds = lds + w.base;
     return w;
 }
 
-__device__ __forceinline__ void winset_zero(const WinSet &W, lds_cell *lds, int lane)
-{
-#pragma unroll
-    for (int k = 0; k < MAX_WIN; ++k) {
-        const int n = W.wd[k][0] * W.wd[k][1] * W.wd[k][2] * W.ch;
-        for (int i = lane; i < n; i += 64) lds[W.base[k] + i] = 0.0;
-    }
-}
-
-__device__ __forceinline__ void window_add(const LaneWin &w, float *__restrict__ g, const int dims[3],
-                                           int x, int y, int z, int c, float v)
-{
-    const int wx = x - w.lo[0], wy = y - w.lo[1], wz = z - w.lo[2];
-    if ((unsigned)wx < (unsigned)w.wd[0] && (unsigned)wy < (unsigned)w.wd[1] && (unsigned)wz < (unsigned)w.wd[2])
-        __hip_atomic_fetch_add(&w.lds[((wx * w.wd[1] + wy) * w.wd[2] + wz) * w.ch + c], (double)v, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
-    else
-        atomicAdd(&g[(((int64_t)x * dims[1] + y) * dims[2] + z) * w.ch + c], v);
-}
-
-// The common case: no window of the phase was shaved (WinSet::fit).  A window spans the lanes' base cells with the phase's
-// margins, so every in-grid tap lies inside by construction: no bounds tests, the cell index is the lane's base index plus
-// offsets that are compile-time multiples of the window's strides (window_add's index arithmetic and tests were ~15 vector
-// instructions per LDS atomic, 72-96 atomics per lane).
 __device__ __forceinline__ void lds_add(lds_cell *p, float v)
 {
     __hip_atomic_fetch_add(p, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-__device__ __forceinline__ void winset_flush(const WinSet &W, lds_cell *lds, float *__restrict__ g, const int dims[3],
-                                             int lane)
+// every in-grid tap of a lane lies inside its window by construction (the box spans the segment's base cells plus the
+// phase's margins): no bounds tests; a lane without a window goes to global memory
+__device__ __forceinline__ void cell_add(const LaneWin &w, int off, float *__restrict__ g, int64_t gi, float v)
 {
-#pragma unroll
-    for (int k = 0; k < MAX_WIN; ++k) {
-        const int row = W.wd[k][2] * W.ch;                // floats per (x,y) column, contiguous in memory too
-        const int n = W.wd[k][0] * W.wd[k][1] * row;
+    if (w.has) lds_add(w.lds + off, v);
+    else atomicAdd(g + gi, v);
+}
+
+__device__ __forceinline__ void windows_zero(const LaneWin &w, lds_cell *lds, int lane)
+{
+    const int n = min(w.total, WIN_CELLS);
+    for (int i = lane; i < n; i += 64) lds[i] = 0.0;
+}
+
+// non-zero cells of every window that fitted -> z-contiguous global atomics
+__device__ __forceinline__ void windows_flush(const Segs &S, const LaneWin &w, int ch, lds_cell *lds,
+                                              float *__restrict__ g, const int dims[3], int lane)
+{
+    unsigned hm = S.heads;
+    while (hm) {                                                     // wave-uniform loop over the segments
+        const int hs = __builtin_amdgcn_readfirstlane(__ffs(hm) - 1);
+        hm &= hm - 1;
+        const int base = __builtin_amdgcn_readlane(w.base, hs), n = __builtin_amdgcn_readlane(w.cells, hs);
+        if (base + n > WIN_CELLS) continue;
+        const int lo0 = __builtin_amdgcn_readlane(w.lo[0], hs), lo1 = __builtin_amdgcn_readlane(w.lo[1], hs),
+                  lo2 = __builtin_amdgcn_readlane(w.lo[2], hs);
+        const int wd1 = __builtin_amdgcn_readlane(w.wd[1], hs), wd2 = __builtin_amdgcn_readlane(w.wd[2], hs);
+        const int row = wd2 * ch;                         // floats per (x,y) column, contiguous in memory too
         // i / row and xy / wd[1] through the (wave-uniform) reciprocals: gfx950 has no integer divide, the two signed
         // divisions were ~50 of this loop's ~70 vector instructions.  floor((i + 0.5) * (1 / d)) == i / d for
         // 0 <= i < 2^21: the product is within 1.2e-7 relative of (i + 0.5) / d, which lies >= 0.5 / d from an integer.
         static_assert(WIN_CELLS * 6 < (1 << 21), "reciprocal division below is exact for i < 2^21");
-        const float r_row = 1.0f / (float)max(row, 1), r_wy = 1.0f / (float)max(W.wd[k][1], 1);
+        const float r_row = 1.0f / (float)max(row, 1), r_wy = 1.0f / (float)max(wd1, 1);
         for (int i = lane; i < n; i += 64) {
-            const float v = (float)lds[W.base[k] + i];
+            const float v = (float)lds[base + i];
             if (v != 0.f) {
                 const int xy = (int)(((float)i + 0.5f) * r_row), r = i - xy * row;
-                const int wx = (int)(((float)xy + 0.5f) * r_wy), wy = xy - wx * W.wd[k][1];
-                atomicAdd(&g[(((int64_t)(W.lo[k][0] + wx) * dims[1] + (W.lo[k][1] + wy)) * dims[2] + W.lo[k][2]) * W.ch + r], v);
+                const int wx = (int)(((float)xy + 0.5f) * r_wy), wy = xy - wx * wd1;
+                atomicAdd(&g[(((int64_t)(lo0 + wx) * dims[1] + (lo1 + wy)) * dims[2] + lo2) * ch + r], v);
             }
         }
     }
@@ -482,7 +452,6 @@ __global__ void __launch_bounds__(256, 2) feat_bwd_kernel(FeatParams P)
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     lds_cell *const lds = (lds_cell *)(win_all + (threadIdx.x >> 6) * WIN_CELLS);
-    WinSet WS;
     for (int t = P.t_begin + wave; t < P.t_end; t += nwaves) {
         const int j = t * 32 + s;
         const float *Xt = P.X + (size_t)t * XROWS * 32 + s;
@@ -556,12 +525,10 @@ __global__ void __launch_bounds__(256, 2) feat_bwd_kernel(FeatParams P)
                 i0c[a] = (int)floorf(indc[a]);
             }
         }
-        // one accumulation window per ray of the tile.  Explicit points carry no ray id, but the large explicit passes
+        // One accumulation window per ray piece of the tile.  Explicit points carry no ray id, but the large explicit passes
         // of the LTS stages (the perturbed re-evaluation of every surviving sample, esrnerf.py:807-830) list their points
         // in ray order: the tile is cut into runs wherever consecutive points jump by more than 3 cells -- each run gets
-        // a tight window like a ray piece does.  (One box over a tile that holds pieces of 2-3 rays was shaved to its LDS
-        // share and most of the tile went to global atomics tap by tap: 0.52 ms for the perturbed pass against 0.23 ms
-        // for the primary pass over the same samples.)
+        // a tight window like a ray piece does.
         int key = 0;
         if (P.pts) {
             const int px = __shfl_up(i0c[0], 1), py = __shfl_up(i0c[1], 1), pz = __shfl_up(i0c[2], 1);
@@ -573,34 +540,14 @@ __global__ void __launch_bounds__(256, 2) feat_bwd_kernel(FeatParams P)
         } else {
             key = valid ? P.rec_ray[j] : 0;
         }
-        int wid = winset_init(WS, key, valid, i0c);
+        Segs SG = segs_build(key, valid, false, i0c, s, h);
         // A ray piece that runs diagonally through the grid has a bounding box far larger than the cells it touches
-        // (32 samples = 16 voxels of path along (1,1,1): 15^3 SDF cells, 11^3 x 6 colour floats) -- the box was shaved to
-        // its LDS share and the samples outside went to global atomics one tap at a time (secondary rays of the LTS
-        // stage: 65 atomic instructions per tile against 18 for axis-parallel rays).  When a window of the tile does not
-        // fit, its ray piece is cut into consecutive runs of samples with a window each (4 windows per tile as before:
-        // 1 ray -> 4 runs, 2 rays -> 2 + 2, 3 rays -> the longest piece 2): 8 samples span <= 4 voxels, whose box fits.
-        if (WS.nw < MAX_WIN && winset_overflows(WS)) {
-            int newkey = 0;
-            int longest = 0, longest_len = -1;
-            unsigned pieces[MAX_WIN];
-#pragma unroll
-            for (int k = 0; k < MAX_WIN; ++k) {
-                pieces[k] = (unsigned)__ballot(valid && wid == k);           // low half: one bit per sample
-                const int len = __popc(pieces[k]);
-                if (k < WS.nw && len > longest_len) { longest_len = len; longest = k; }
-            }
-#pragma unroll
-            for (int k = 0; k < MAX_WIN; ++k) {
-                if (k >= WS.nw) continue;
-                const int parts = WS.nw == 1 ? 4 : WS.nw == 2 ? 2 : (k == longest ? 2 : 1);
-                const int len = __popc(pieces[k]), first = __ffs(pieces[k]) - 1;
-                const int q = (len + parts - 1) / parts;                        // samples per run (wave-uniform)
-                const int d = s - first;
-                const int part = min(parts - 1, (d >= q) + (d >= 2 * q) + (d >= 3 * q));
-                if (wid == k) newkey = 4 * k + part;
-            }
-            wid = winset_init(WS, newkey, valid, i0c);
+        // (32 samples = 16 voxels of path along (1,1,1): 15^3 SDF cells, 11^3 x 6 colour floats).  When the tile's boxes
+        // do not fit, every piece is cut into runs of 8 samples with a window each: 8 samples span <= 4 voxels.
+        {
+            const LaneWin probe = P.grad_sdf ? seg_window(SG, valid, gdims, 2, 3, 1, lds, s, h)
+                                             : seg_window(SG, valid, gdims, 0, 1, 6, lds, s, h);
+            if (probe.total > WIN_CELLS) SG = segs_build(key, valid, true, i0c, s, h);
         }
         // ---- phase 1: SDF grid.  The value tap and the 24 stencil taps of a sample touch only three
         // 6x2x2 "bars" of cells (one per axis, sharing the central 2x2x2): the taps of an axis are first
@@ -609,10 +556,8 @@ __global__ void __launch_bounds__(256, 2) feat_bwd_kernel(FeatParams P)
         // clocks and were 59 % of this kernel's wave time).  Lane half 0 owns the z bar and the lower half
         // of the x bar, lane half 1 the y bar and the upper half of the x bar.
         if (P.grad_sdf) {       // null: the SDF grid is frozen (re-lighting fine-tune), colour phase only
-        winset_phase(WS, gdims, 2, 3, 1);
-        LaneWin w = lane_view(WS, wid, lds);
-        const bool fast = WS.fit && w.has;       // (a fifth ray of a tile has no window: global atomics)
-        winset_zero(WS, lds, lane);
+        const LaneWin w = seg_window(SG, valid, gdims, 2, 3, 1, lds, s, h);
+        windows_zero(w, lds, lane);
         lds_fence();
         if (valid) {
             // gradient w.r.t. the finite-difference vectors (through F.normalize), all 3 axes x 4 radii
@@ -692,7 +637,10 @@ __global__ void __launch_bounds__(256, 2) feat_bwd_kernel(FeatParams P)
                 const int st[3] = {w.wd[1] * w.wd[2], w.wd[2], 1};
                 const int sA = axis == 0 ? st[0] : (axis == 1 ? st[1] : st[2]);
                 const int sB = pb == 0 ? st[0] : st[1], sC = pc == 1 ? st[1] : st[2];
-                lds_cell *const cell0 = w.lds + (((i0c[0] - w.lo[0]) * w.wd[1] + (i0c[1] - w.lo[1])) * w.wd[2] + (i0c[2] - w.lo[2]));
+                const int gst[3] = {gdims[1] * gdims[2], gdims[2], 1};                 // the same for the grid itself
+                const int gA = axis == 0 ? gst[0] : (axis == 1 ? gst[1] : gst[2]);
+                const int gB = pb == 0 ? gst[0] : gst[1], gC = pc == 1 ? gst[1] : gst[2];
+                const int cell0 = ((i0c[0] - w.lo[0]) * w.wd[1] + (i0c[1] - w.lo[1])) * w.wd[2] + (i0c[2] - w.lo[2]);
 #pragma unroll
                 for (int o = 0; o < 6; ++o) {
                     if (o < o_lo || o >= o_hi || acc6[o] == 0.f) continue;
@@ -703,22 +651,17 @@ __global__ void __launch_bounds__(256, 2) feat_bwd_kernel(FeatParams P)
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
                             const float wgt = (pb == 0 ? wc[0][b] : wc[1][b]) * (pc == 1 ? wc[1][c] : wc[2][c]);
-                            int xyz[3];
-                            xyz[axis] = cA;
-                            xyz[pb] = (pb == 0 ? i0c[0] : i0c[1]) + b;
-                            xyz[pc] = (pc == 1 ? i0c[1] : i0c[2]) + c;
-                            const bool inb = (xyz[pb] < (pb == 0 ? gdims[0] : gdims[1])) &
-                                             (xyz[pc] < (pc == 1 ? gdims[1] : gdims[2]));
-                            if (inb && wgt != 0.f) {
-                                if (fast) lds_add(cell0 + ((o - 2) * sA + b * sB + c * sC), acc6[o] * wgt);
-                                else window_add(w, P.grad_sdf, gdims, xyz[0], xyz[1], xyz[2], 0, acc6[o] * wgt);
-                            }
+                            const int qb = (pb == 0 ? i0c[0] : i0c[1]) + b, qc = (pc == 1 ? i0c[1] : i0c[2]) + c;
+                            const bool inb = (qb < (pb == 0 ? gdims[0] : gdims[1])) & (qc < (pc == 1 ? gdims[1] : gdims[2]));
+                            if (inb && wgt != 0.f)
+                                cell_add(w, cell0 + ((o - 2) * sA + b * sB + c * sC), P.grad_sdf,
+                                         (int64_t)cA * gA + (int64_t)qb * gB + (int64_t)qc * gC, acc6[o] * wgt);
                         }
                 }
             }
         }
         lds_fence();
-        winset_flush(WS, lds, P.grad_sdf, gdims, lane);
+        windows_flush(SG, w, 1, lds, P.grad_sdf, gdims, lane);
         lds_fence();
         }
         // ---- phase 2: colour grids, one pass per net that read a colour group (3 channels per lane half)
@@ -726,10 +669,8 @@ __global__ void __launch_bounds__(256, 2) feat_bwd_kernel(FeatParams P)
             float *gcol = on_tile ? P.gcol_on[k] : P.gcol_off[k];
             if (!gcol || t < P.src_t0[k] || t >= P.src_t1[k]) continue;       // wave-uniform
             const float *dXt = P.dX[k] + (size_t)t * DXROWS * 32 + s;
-            winset_phase(WS, gdims, 0, 1, 6);
-            const LaneWin w = lane_view(WS, wid, lds);
-            const bool fast = WS.fit && w.has;
-            winset_zero(WS, lds, lane);
+            const LaneWin w = seg_window(SG, valid, gdims, 0, 1, 6, lds, s, h);
+            windows_zero(w, lds, lane);
             lds_fence();
             if (valid) {
                 float d3[3];
@@ -737,7 +678,7 @@ __global__ void __launch_bounds__(256, 2) feat_bwd_kernel(FeatParams P)
                 for (int c = 0; c < 3; ++c) d3[c] = nact == 1 ? r_d3[c] : dXt[(ROW_COL + 3 * h + c) * 32];
                 Tri tr = esr_tri_setup(ind);
                 // (an in-grid corner of a sample is its clamped base cell or that cell + 1, also for points outside the box)
-                lds_cell *const cell0 = w.lds + ((((tr.i0[0] - w.lo[0]) * w.wd[1] + (tr.i0[1] - w.lo[1])) * w.wd[2] + (tr.i0[2] - w.lo[2])) * 6 + 3 * h);
+                const int cell0 = (((tr.i0[0] - w.lo[0]) * w.wd[1] + (tr.i0[1] - w.lo[1])) * w.wd[2] + (tr.i0[2] - w.lo[2])) * 6 + 3 * h;
                 const int sx = w.wd[1] * w.wd[2] * 6, sy = w.wd[2] * 6;
 #pragma unroll
                 for (int cx = 0; cx < 2; ++cx)
@@ -750,15 +691,14 @@ __global__ void __launch_bounds__(256, 2) feat_bwd_kernel(FeatParams P)
                             float wgt = esr_corner_w(tr, ind, cx, cy, cz);
                             if (inb && wgt != 0.f) {
 #pragma unroll
-                                for (int c = 0; c < 3; ++c) {
-                                    if (fast) lds_add(cell0 + (cx * sx + cy * sy + cz * 6 + c), d3[c] * wgt);
-                                    else window_add(w, gcol, gdims, x, y, z, 3 * h + c, d3[c] * wgt);
-                                }
+                                for (int c = 0; c < 3; ++c)
+                                    cell_add(w, cell0 + (cx * sx + cy * sy + cz * 6 + c), gcol,
+                                             (((int64_t)x * gdims[1] + y) * gdims[2] + z) * 6 + 3 * h + c, d3[c] * wgt);
                             }
                         }
             }
             lds_fence();
-            winset_flush(WS, lds, gcol, gdims, lane);
+            windows_flush(SG, w, 6, lds, gcol, gdims, lane);
             lds_fence();
         }
     }
