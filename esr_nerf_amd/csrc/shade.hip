@@ -37,8 +37,10 @@ __global__ void __launch_bounds__(256) tone_in_fwd_kernel(const float *__restric
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 const float a = v * (float)(1 << i);
-                X[(3 + c * 5 + i) * 32] = sinf(a);
-                X[(18 + c * 5 + i) * 32] = cosf(a);
+                float sn, cs;
+                esr_sincos(a, sn, cs);
+                X[(3 + c * 5 + i) * 32] = sn;
+                X[(18 + c * 5 + i) * 32] = cs;
             }
         }
         lin[z4 + 96] = 0.f;
@@ -128,8 +130,10 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float *__restr
     }
 }
 
+// (the derivative's cos(a) / sin(a) factors are the forward's own rows of Xt: the 30 accurate sin / cos evaluations per
+// sample of a recomputation were most of this kernel)
 __global__ void __launch_bounds__(256) tone_in_bwd_kernel(
-    const float *__restrict__ dXt, const float *__restrict__ g_lin, const float *__restrict__ lin,
+    const float *__restrict__ dXt, const float *__restrict__ Xt, const float *__restrict__ g_lin, const float *__restrict__ lin,
     const float *__restrict__ z_off, const float *__restrict__ z_emo, const int32_t *__restrict__ rec_ray,
     const float *__restrict__ rec_w, int tiles_on, int tiles_all, float *__restrict__ dz)
 {
@@ -138,6 +142,7 @@ __global__ void __launch_bounds__(256) tone_in_bwd_kernel(
         const int t = j >> 5, s = j & 31;
         const size_t z4 = (size_t)t * 4 * 32 + s;
         const float *dX = dXt + (size_t)t * 64 * 32 + s;
+        const float *X = Xt + (size_t)t * XT_ROWS * 32 + s;
         const int ray = rec_ray[j];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -147,8 +152,8 @@ __global__ void __launch_bounds__(256) tone_in_bwd_kernel(
                 d = rec_w[j] * g_lin[3 * ray + c] + dX[c * 32];
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
-                    const float f = (float)(1 << i), a = v * f;
-                    d += f * (dX[(3 + c * 5 + i) * 32] * cosf(a) - dX[(18 + c * 5 + i) * 32] * sinf(a));
+                    const float f = (float)(1 << i);
+                    d += f * (dX[(3 + c * 5 + i) * 32] * X[(18 + c * 5 + i) * 32] - dX[(18 + c * 5 + i) * 32] * X[(3 + c * 5 + i) * 32]);
                 }
                 const float z = (t < tiles_on) ? z_emo[z4 + c * 32] : z_off[z4 + c * 32];
                 d *= softplus_grad(z);
@@ -378,7 +383,7 @@ __global__ void __launch_bounds__(256) composite3_bwd_kernel(const float *__rest
 // LTS renderer: lin = softplus(z_off) + [on] softplus(z_emo) with NO detach (esrnerf.py:751-757):
 // dz_off on every tile, dz_emo on the on-tiles.  dlin_extra [tiles,4,32] (optional) is added.
 __global__ void __launch_bounds__(256) lts_tone_in_bwd_kernel(
-    const float *__restrict__ dXt, const float *__restrict__ g_lin, const float *__restrict__ lin,
+    const float *__restrict__ dXt, const float *__restrict__ Xt, const float *__restrict__ g_lin, const float *__restrict__ lin,
     const float *__restrict__ z_off, const float *__restrict__ z_emo, const int32_t *__restrict__ rec_ray,
     const float *__restrict__ rec_w, int tiles_on, int tiles_all, float *__restrict__ dz_off,
     float *__restrict__ dz_emo)
@@ -388,6 +393,7 @@ __global__ void __launch_bounds__(256) lts_tone_in_bwd_kernel(
         const int t = j >> 5, s = j & 31;
         const size_t z4 = (size_t)t * 4 * 32 + s;
         const float *dX = dXt + (size_t)t * 64 * 32 + s;
+        const float *X = Xt + (size_t)t * XT_ROWS * 32 + s;
         const int ray = rec_ray[j];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -397,8 +403,8 @@ __global__ void __launch_bounds__(256) lts_tone_in_bwd_kernel(
                 d = rec_w[j] * g_lin[3 * ray + c] + dX[c * 32];
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
-                    const float f = (float)(1 << i), a = v * f;
-                    d += f * (dX[(3 + c * 5 + i) * 32] * cosf(a) - dX[(18 + c * 5 + i) * 32] * sinf(a));
+                    const float f = (float)(1 << i);
+                    d += f * (dX[(3 + c * 5 + i) * 32] * X[(18 + c * 5 + i) * 32] - dX[(18 + c * 5 + i) * 32] * X[(3 + c * 5 + i) * 32]);
                 }
             }
             dz_off[z4 + c * 32] = d * softplus_grad(z_off[z4 + c * 32]);
@@ -467,16 +473,16 @@ ESR_API int esr_fine_composite_bwd(const float *g_srgb, const float *g_lin, cons
     return 0;
 }
 
-ESR_API int esr_fine_tone_in_bwd(const float *dXt, const float *g_lin, const float *lin,
+ESR_API int esr_fine_tone_in_bwd(const float *dXt, const float *Xt, const float *g_lin, const float *lin,
                                  const float *z_off, const float *z_emo, const int32_t *rec_ray,
                                  const float *rec_w, int32_t tiles_on, int32_t tiles_all, float *dz,
                                  void *stream)
 {
     if (tiles_all < 0 || tiles_on < 0 || tiles_on > tiles_all) return ESR_EINVAL;
     if (tiles_all == 0) return 0;
-    if (!dXt || !g_lin || !lin || !z_off || (tiles_on && !z_emo) || !rec_ray || !rec_w || !dz) return ESR_EINVAL;
+    if (!dXt || !Xt || !g_lin || !lin || !z_off || (tiles_on && !z_emo) || !rec_ray || !rec_w || !dz) return ESR_EINVAL;
     tone_in_bwd_kernel<<<esr_grid_for((int64_t)tiles_all * 32, 256), 256, 0, esr_stream(stream)>>>(
-        dXt, g_lin, lin, z_off, z_emo, rec_ray, rec_w, tiles_on, tiles_all, dz);
+        dXt, Xt, g_lin, lin, z_off, z_emo, rec_ray, rec_w, tiles_on, tiles_all, dz);
     ESR_CHECK_LAUNCH();
     return 0;
 }
@@ -599,16 +605,16 @@ ESR_API int esr_composite3_bwd(const float *g, const float *v, int32_t rows, con
     return 0;
 }
 
-ESR_API int esr_lts_tone_in_bwd(const float *dXt, const float *g_lin, const float *lin, const float *z_off,
+ESR_API int esr_lts_tone_in_bwd(const float *dXt, const float *Xt, const float *g_lin, const float *lin, const float *z_off,
                                 const float *z_emo, const int32_t *rec_ray, const float *rec_w,
                                 int32_t tiles_on, int32_t tiles_all, float *dz_off, float *dz_emo, void *stream)
 {
     if (tiles_all < 0 || tiles_on < 0 || tiles_on > tiles_all) return ESR_EINVAL;
     if (tiles_all == 0) return 0;
-    if (!dXt || !g_lin || !lin || !z_off || (tiles_on && (!z_emo || !dz_emo)) || !rec_ray || !rec_w || !dz_off)
+    if (!dXt || !Xt || !g_lin || !lin || !z_off || (tiles_on && (!z_emo || !dz_emo)) || !rec_ray || !rec_w || !dz_off)
         return ESR_EINVAL;
     lts_tone_in_bwd_kernel<<<esr_grid_for((int64_t)tiles_all * 32, 256), 256, 0, esr_stream(stream)>>>(
-        dXt, g_lin, lin, z_off, z_emo, rec_ray, rec_w, tiles_on, tiles_all, dz_off, dz_emo);
+        dXt, Xt, g_lin, lin, z_off, z_emo, rec_ray, rec_w, tiles_on, tiles_all, dz_off, dz_emo);
     ESR_CHECK_LAUNCH();
     return 0;
 }

@@ -11,6 +11,18 @@ namespace {
 
 __device__ __forceinline__ float clamp1(float v) { return fminf(fmaxf(v, -1.f), 1.f); }
 
+// (x, y, z) of linear cell i in a [.., gy, gz] grid.  gfx950 has no integer divide: a 64-bit division by a run-time value is
+// ~150 instructions, a 32-bit one ~25 -- every grid of the reference's configurations has < 2^31 cells.
+__device__ __forceinline__ void cell_xyz(int64_t i, int gy, int gz, int &x, int &y, int &z)
+{
+    if (i < 0x7fffffffLL) {
+        const unsigned u = (unsigned)i, q = u / (unsigned)gz, q2 = q / (unsigned)gy;
+        z = (int)(u - q * (unsigned)gz); y = (int)(q - q2 * (unsigned)gy); x = (int)q2;
+    } else {
+        z = (int)(i % gz); y = (int)(i / gz % gy); x = (int)(i / ((int64_t)gz * gy));
+    }
+}
+
 template <bool DENSE>
 __global__ void __launch_bounds__(256) tv_add_grad_kernel(const float *__restrict__ param,
                                                           float *__restrict__ grad, float wy, float wz,
@@ -22,16 +34,23 @@ __global__ void __launch_bounds__(256) tv_add_grad_kernel(const float *__restric
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < n; idx += stride) {
         const float g0 = grad[idx];
         if (!DENSE && g0 == 0.f) continue;
-        const int64_t k = idx % sz_k, j = idx / sz_k % sz_j, i = idx / plane % sz_i;
+        int i, j, k;
+        cell_xyz(idx, (int)sz_j, (int)sz_k, i, j, k);
+        i = (int)((unsigned)i % (unsigned)sz_i);           // (several channels stacked along the slowest axis)
+        // The six neighbours are loaded UNCONDITIONALLY (a face cell re-reads itself): a load behind a condition is an
+        // exec-masked region with its own wait -- six serial round trips per cell (esr_common.h: esr_ld_or0).
         const float p = param[idx];
+        const float n0 = param[idx - (k == 0 ? 0 : 1)], n1 = param[idx + (k == sz_k - 1 ? 0 : 1)];
+        const float n2 = param[idx - (j == 0 ? 0 : sz_k)], n3 = param[idx + (j == sz_j - 1 ? 0 : sz_k)];
+        const float n4 = param[idx - (i == 0 ? 0 : plane)], n5 = param[idx + (i == sz_i - 1 ? 0 : plane)];
         float g = 0.f;
         // same accumulation order as the reference; note wz on BOTH the k and i axes
-        g += (k == 0)        ? 0.f : wz * clamp1(p - param[idx - 1]);
-        g += (k == sz_k - 1) ? 0.f : wz * clamp1(p - param[idx + 1]);
-        g += (j == 0)        ? 0.f : wy * clamp1(p - param[idx - sz_k]);
-        g += (j == sz_j - 1) ? 0.f : wy * clamp1(p - param[idx + sz_k]);
-        g += (i == 0)        ? 0.f : wz * clamp1(p - param[idx - plane]);
-        g += (i == sz_i - 1) ? 0.f : wz * clamp1(p - param[idx + plane]);
+        g += (k == 0)        ? 0.f : wz * clamp1(p - n0);
+        g += (k == sz_k - 1) ? 0.f : wz * clamp1(p - n1);
+        g += (j == 0)        ? 0.f : wy * clamp1(p - n2);
+        g += (j == sz_j - 1) ? 0.f : wy * clamp1(p - n3);
+        g += (i == 0)        ? 0.f : wz * clamp1(p - n4);
+        g += (i == sz_i - 1) ? 0.f : wz * clamp1(p - n5);
         grad[idx] = g0 + g;
     }
 }
@@ -77,15 +96,18 @@ __device__ __forceinline__ float central(const float *__restrict__ s, const TvGr
     const int64_t i = ((int64_t)x * G.gy + y) * G.gz + z;
     const int64_t st = c == 0 ? (int64_t)G.gy * G.gz : (c == 1 ? G.gz : 1);
     const int p = c == 0 ? x : (c == 1 ? y : z), n = c == 0 ? G.gx : (c == 1 ? G.gy : G.gz);
-    if (p < 1 || p > n - 2) return 0.f;
-    return __fdiv_rn(__fdiv_rn(s[i + st] - s[i - st], 2.0f), G.voxel_size);
+    const bool interior = p >= 1 && p <= n - 2;
+    const int64_t so = interior ? st : 0;                       // (unconditional loads: see tv_add_grad_kernel)
+    const float v = __fdiv_rn(__fdiv_rn(s[i + so] - s[i - so], 2.0f), G.voxel_size);
+    return interior ? v : 0.f;
 }
 
 __global__ void __launch_bounds__(256) tv_gradient_kernel(const float *__restrict__ sdf, TvGrid G, float *__restrict__ g)
 {
     const int64_t n = (int64_t)G.gx * G.gy * G.gz;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int z = (int)(i % G.gz), y = (int)(i / G.gz % G.gy), x = (int)(i / ((int64_t)G.gz * G.gy));
+        int x, y, z;
+        cell_xyz(i, G.gy, G.gz, x, y, z);
 #pragma unroll
         for (int c = 0; c < 3; ++c) g[c * n + i] = central(sdf, G, x, y, z, c);
     }
@@ -100,7 +122,8 @@ __global__ void __launch_bounds__(256) tv_error_kernel(const float *__restrict__
     const int64_t n = (int64_t)G.gx * G.gy * G.gz;
     float part = 0.f;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int z = (int)(i % G.gz), y = (int)(i / G.gz % G.gy), x = (int)(i / ((int64_t)G.gz * G.gy));
+        int x, y, z;
+        cell_xyz(i, G.gy, G.gz, x, y, z);
         const bool m = mask[i] != 0;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -141,14 +164,17 @@ __global__ void __launch_bounds__(256) tv_error_bwd_kernel(const float *__restri
     const int64_t n = (int64_t)G.gx * G.gy * G.gz;
     if (grad_out) coeff *= grad_out[0];
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int z = (int)(i % G.gz), y = (int)(i / G.gz % G.gy), x = (int)(i / ((int64_t)G.gz * G.gy));
+        int x, y, z;
+        cell_xyz(i, G.gy, G.gz, x, y, z);
         float acc = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int64_t st = c == 0 ? (int64_t)G.gy * G.gz : (c == 1 ? G.gz : 1);
             const int p = c == 0 ? x : (c == 1 ? y : z), m = c == 0 ? G.gx : (c == 1 ? G.gy : G.gz);
-            if (p - 1 >= 1 && p - 1 <= m - 2) acc += err[c * n + i - st];
-            if (p + 1 >= 1 && p + 1 <= m - 2) acc -= err[c * n + i + st];
+            const bool lo = p - 1 >= 1 && p - 1 <= m - 2, hi = p + 1 >= 1 && p + 1 <= m - 2;
+            const float el = err[c * n + i - (lo ? st : 0)], eh = err[c * n + i + (hi ? st : 0)];   // (unconditional loads)
+            if (lo) acc += el;
+            if (hi) acc -= eh;
         }
         grad_sdf[i] += coeff * acc;
     }

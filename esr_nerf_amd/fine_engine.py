@@ -545,7 +545,7 @@ class FineEngine:
             march_bwd(s)
         dgrad("mlp_dgrad(tone)", KIND_TONEMAP, self.packed["tone"], ws["dzt"], 0, ta, self._H(["Mt"]),
               _lib.ptr_array([None]) if self.tone_recompute else self._H(["dZt"]), ws["dXt"])
-        self._run("tone_in_bwd", L.esr_fine_tone_in_bwd, _lib.ptr(ws["dXt"]), _lib.ptr(g_lin), _lib.ptr(ws["lin"]),
+        self._run("tone_in_bwd", L.esr_fine_tone_in_bwd, _lib.ptr(ws["dXt"]), _lib.ptr(ws["Xt"]), _lib.ptr(g_lin), _lib.ptr(ws["lin"]),
                   _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), to, ta,
                   _lib.ptr(ws["dz"]), s)
         M, dZ = self._H(["M0", "M1", "M2"]), self._H(["dZ0", "dZ1", "dZ2"])

@@ -994,7 +994,7 @@ class LtsEngine(FineEngine):
         d_brdf_t = P0.from_rowmajor("brdf.da", 8, d_brdf)
         # tonemapper -> radiance heads
         dXt = self._net_bwd(P0, "tone", KIND_TONEMAP, 0, 0, T, P0.bufs["tone.dz"], grads["tone_w"], grads["tone_b"])
-        self._run("lts_tone_in_bwd", L.esr_lts_tone_in_bwd, _lib.ptr(dXt), _lib.ptr(g_lin), _lib.ptr(P0.bufs["lin"]),
+        self._run("lts_tone_in_bwd", L.esr_lts_tone_in_bwd, _lib.ptr(dXt), _lib.ptr(P0.bufs["Xt"]), _lib.ptr(g_lin), _lib.ptr(P0.bufs["lin"]),
                   _lib.ptr(P0.bufs["off.z"]), _lib.ptr(P0.bufs["emo.z"]), _lib.ptr(P0.bufs["rec_ray"]),
                   _lib.ptr(P0.bufs["rec_w"]), Ton, T, _lib.ptr(P0.buf("off.dz", 4)), _lib.ptr(P0.buf("emo.dz", 4)), s)
         src = [(self._net_bwd(P0, "off", KIND_RADIANCE, 0, 0, T, P0.bufs["off.dz"], grads["off_w"], grads["off_b"]),

@@ -445,9 +445,10 @@ int esr_fine_composite_bwd(const float *g_srgb, const float *g_lin, const float 
 
 /*
  * dXt [tiles,64,32] (tonemap input grads) + g_lin -> dz [tiles,4,32] (grad of the
- * radiance pre-activations: emo net on on-tiles, off net on off-tiles).
+ * radiance pre-activations: emo net on on-tiles, off net on off-tiles).  Xt [tiles,48,32]: the tile
+ * esr_fine_tone_in_fwd wrote (its sin / cos rows are the factors of the encoding's derivative).
  */
-int esr_fine_tone_in_bwd(const float *dXt, const float *g_lin, const float *lin,
+int esr_fine_tone_in_bwd(const float *dXt, const float *Xt, const float *g_lin, const float *lin,
                          const float *z_off, const float *z_emo, const int32_t *rec_ray,
                          const float *rec_w, int32_t tiles_on, int32_t tiles_all, float *dz,
                          void *stream);
@@ -603,7 +604,7 @@ int esr_composite3_fwd(const float *v, int32_t rows, const int32_t *rec_ray, con
 int esr_composite3_bwd(const float *g, const float *v, int32_t rows, const int32_t *rec_ray,
                        const float *rec_w, int32_t tiles, int accumulate, float *dv, float *dweight,
                        void *stream);
-int esr_lts_tone_in_bwd(const float *dXt, const float *g_lin, const float *lin, const float *z_off,
+int esr_lts_tone_in_bwd(const float *dXt, const float *Xt, const float *g_lin, const float *lin, const float *z_off,
                         const float *z_emo, const int32_t *rec_ray, const float *rec_w, int32_t tiles_on,
                         int32_t tiles_all, float *dz_off, float *dz_emo, void *stream);
 int esr_sample_points(const esr_scene_t *scene, const float *rays_o, const float *rays_d,
