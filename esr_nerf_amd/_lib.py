@@ -147,8 +147,21 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+_dev_index = {}
+
+
 def stream_ptr(device=None):
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """The current HIP stream of ``device`` as a void pointer.  (``torch.cuda.current_stream(device).cuda_stream`` builds a
+    Stream object per call, ~5 us; a light-transport step asks ~100 times -- the raw getter is what torch's own
+    compiled code uses.)"""
+    idx = _dev_index.get(device)
+    if idx is None:
+        idx = torch.cuda.current_device() if device is None else torch.device(device).index
+        if idx is None:
+            idx = torch.cuda.current_device()            # ("cuda" without an index: not cached)
+        elif device is not None:
+            _dev_index[device] = idx
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(idx))
 
 
 def ptr_array(tensors, n=None):

@@ -64,19 +64,65 @@ struct Mt19937 {
 
 // key: the 624 state words (updated in place), *pos: position in the block (0..624, updated).
 // out[0..k) = np.random.RandomState(state).choice(n, k, replace=False).
+//
+// Two stages (round 3: as the device side of the primary pass got faster the draw -- 1.2 ms for C5's 157 k survivors -- became
+// the step's critical path: the GPU sat idle for 0.46 of 4.4 ms waiting for the indices).  Stage 1 turns generator output
+// into the ACCEPTED draws j_i, i = n-1 .. 1: a block of 624 outputs is tempered in one vectorisable loop, the
+// rejection test is branch-free (store the candidate, advance only if it was accepted; the mask is constant while i
+// stays between two powers of two) -- the one-at-a-time form mispredicted its rejection branch on ~40 % of the draws.
+// Stage 2 applies the swaps on a 32-bit array (half the cache footprint), the addresses known in advance.  The generator
+// is consumed exactly as numpy does: one 32-bit output per candidate.
 ESR_API int esr_host_choice_noreplace(uint32_t *key, int32_t *pos, int64_t n, int64_t k, int64_t *out)
 {
     if (!key || !pos || !out || n < 0 || k < 0 || k > n || *pos < 0 || *pos > 624) return ESR_EINVAL;
     Mt19937 g{key, *pos};
-    std::vector<int64_t> a((size_t)n);
-    for (int64_t i = 0; i < n; ++i) a[(size_t)i] = i;
-    for (int64_t i = n - 1; i >= 1; --i) {               // mtrand.pyx::_shuffle_raw
-        const int64_t j = (int64_t)g.interval((uint64_t)i);
-        const int64_t t = a[(size_t)j];
-        a[(size_t)j] = a[(size_t)i];
-        a[(size_t)i] = t;
+    if (n - 1 > 0x7fffffffLL) {                          // (64-bit draws: the plain form)
+        std::vector<int64_t> a((size_t)n);
+        for (int64_t i = 0; i < n; ++i) a[(size_t)i] = i;
+        for (int64_t i = n - 1; i >= 1; --i) {           // mtrand.pyx::_shuffle_raw
+            const int64_t j = (int64_t)g.interval((uint64_t)i);
+            const int64_t t = a[(size_t)j];
+            a[(size_t)j] = a[(size_t)i];
+            a[(size_t)i] = t;
+        }
+        for (int64_t i = 0; i < k; ++i) out[i] = a[(size_t)i];
+        *pos = g.pos;
+        return 0;
     }
-    for (int64_t i = 0; i < k; ++i) out[i] = a[(size_t)i];
+    std::vector<uint32_t> js((size_t)n + 1), a((size_t)n);
+    uint32_t buf[624];
+    int64_t i = n - 1;
+    while (i >= 1) {
+        if (g.pos == 624) g.refill();
+        const int cnt = 624 - g.pos;
+        for (int q = 0; q < cnt; ++q) {
+            uint32_t y = key[g.pos + q];
+            y ^= (y >> 11);
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= (y >> 18);
+            buf[q] = y;
+        }
+        int q = 0;
+        while (q < cnt && i >= 1) {
+            uint32_t mask = (uint32_t)i;                 // smallest 2^b - 1 >= i: constant while i > mask >> 1
+            mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+            const int64_t lo = (int64_t)(mask >> 1);
+            for (; q < cnt && i > lo; ++q) {
+                const uint32_t v = buf[q] & mask;
+                js[(size_t)i] = v;                       // (a rejected candidate is overwritten by the next one)
+                i -= (v <= (uint32_t)i) ? 1 : 0;
+            }
+        }
+        g.pos += q;
+    }
+    for (int64_t t = 0; t < n; ++t) a[(size_t)t] = (uint32_t)t;
+    for (int64_t t = n - 1; t >= 1; --t) {               // mtrand.pyx::_shuffle_raw
+        const uint32_t j = js[(size_t)t], x = a[j];
+        a[j] = a[(size_t)t];
+        a[(size_t)t] = x;
+    }
+    for (int64_t t = 0; t < k; ++t) out[t] = (int64_t)a[(size_t)t];
     *pos = g.pos;
     return 0;
 }
