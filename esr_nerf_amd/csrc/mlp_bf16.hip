@@ -317,22 +317,49 @@ __global__ void __launch_bounds__(64 * SHW, 1) mlp_fwd16s_kernel(Fwd16Batch AB)
     }
     layer_barrier();
     int cur_buf = 0;                                       // LDS buffer holding the layer about to run
-    for (int tg = (int)blockIdx.x - blk0; tg < ngroups; tg += nblk) {
+    // The smaller nets (everything but the 256-register radiance instance) request the NEXT tile group's input rows while
+    // this one runs: the workgroup's eight waves march in step behind the layer barriers, so at the top of a group all of
+    // them waited for these loads at once (mlp_dgrad16s_kernel does the same with its gradients and masks).
+    constexpr bool PREFETCH = KIND != ESR_MLP_RADIANCE;
+    float xn[PREFETCH ? KS1 * 8 : 1];
+    const int xvoff = (h * 8 * 32 + s) * 4;
+    auto fetch = [&](int tg) {
         const int tt = A.t0 + tg * SHW + wv;
-        const bool live = tt < A.t1;                       // a wave past the range runs on the last tile, stores nothing
-        const int t = live ? tt : A.t1 - 1;
-        ESR_STAMP16(0);
+        const int t = tt < A.t1 ? tt : A.t1 - 1;
         const rsrc_t RX = make_rsrc(A.X + (size_t)t * D.xrows * 32, D.xrows * 32 * 4);
-        const int xvoff = (h * 8 * 32 + s) * 4;
         const int coff = A.crow * 128;
-        bf16x8 B1[KS1];
 #pragma unroll
         for (int j = 0; j < KS1; ++j)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int row = 16 * j + 8 * h + i;
-                B1[j][i] = (__bf16)bload1(RX, xvoff + (row < D.cw ? coff : 0), (16 * j + i) * 128);
+                xn[PREFETCH ? j * 8 + i : 0] = bload1(RX, xvoff + (row < D.cw ? coff : 0), (16 * j + i) * 128);
             }
+    };
+    if (PREFETCH && (int)blockIdx.x - blk0 < ngroups) fetch((int)blockIdx.x - blk0);
+    for (int tg = (int)blockIdx.x - blk0; tg < ngroups; tg += nblk) {
+        const int tt = A.t0 + tg * SHW + wv;
+        const bool live = tt < A.t1;                       // a wave past the range runs on the last tile, stores nothing
+        const int t = live ? tt : A.t1 - 1;
+        ESR_STAMP16(0);
+        bf16x8 B1[KS1];
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int j = 0; j < KS1; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) B1[j][i] = (__bf16)xn[j * 8 + i];
+            fetch(tg + nblk < ngroups ? tg + nblk : tg);   // (past the end: this group again, never used)
+        } else {
+            const rsrc_t RX = make_rsrc(A.X + (size_t)t * D.xrows * 32, D.xrows * 32 * 4);
+            const int coff = A.crow * 128;
+#pragma unroll
+            for (int j = 0; j < KS1; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = 16 * j + 8 * h + i;
+                    B1[j][i] = (__bf16)bload1(RX, xvoff + (row < D.cw ? coff : 0), (16 * j + i) * 128);
+                }
+        }
         const bool save = A.save && live;
         f32x16 cur[HT];
         zero_tiles<HT>(cur);
@@ -443,21 +470,37 @@ __global__ void __launch_bounds__(64 * SHW, 1) mlp_dgrad16s_kernel(Dgrad16Batch 
     }
     layer_barrier();
     int cur_buf = 0;
+    // The output gradients and ReLU masks of the NEXT tile group are requested while this one runs (13 registers): the
+    // eight waves of the workgroup march in step behind the layer barriers, so at the top of a group all of them waited
+    // for these loads at once -- nobody to hide them behind.
+    constexpr int ZN = D.zrows < 8 ? D.zrows : 8;                              // dz rows 0 .. ZN-1 live in half 0's slots
+    float zn[ZN];
+    unsigned mn[NHID][HT / 2];
+    auto fetch = [&](int tg) {
+        const int tt = A.t0 + tg * SHW + wv;
+        const int t = tt < A.t1 ? tt : A.t1 - 1;
+        const rsrc_t RZ = make_rsrc(A.dz + (size_t)t * D.zrows * 32, D.zrows * 32 * 4);
+        const int zoff = h == 0 ? s * 4 : 0x7ffffff0;                          // (half 1: k = 8 .. 15, zeros -- out of range)
+#pragma unroll
+        for (int i = 0; i < ZN; ++i) zn[i] = bload1(RZ, zoff, i * 128);
+#pragma unroll
+        for (int l = 0; l < NHID; ++l)
+            load_relu_mask<HT>(make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), mn[l], lane);
+    };
+    if ((int)blockIdx.x - blk0 < ngroups) fetch((int)blockIdx.x - blk0);
     for (int tg = (int)blockIdx.x - blk0; tg < ngroups; tg += nblk) {
         const int tt = A.t0 + tg * SHW + wv;
         const bool live = tt < A.t1;                       // a wave past the range runs on the last tile, stores nothing
         const int t = live ? tt : A.t1 - 1;
-        const rsrc_t RZ = make_rsrc(A.dz + (size_t)t * D.zrows * 32, D.zrows * 32 * 4);
         bf16x8 B0;                                                           // slot i of half h <-> dz row 8 h + i
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = 8 * h + i;
-            B0[i] = (__bf16)((row < D.zrows) ? bload1(RZ, (row * 32 + s) * 4, 0) : 0.f);
-        }
+        for (int i = 0; i < 8; ++i) B0[i] = (__bf16)(i < ZN ? zn[i] : 0.f);
         unsigned msk[NHID][HT / 2];
 #pragma unroll
         for (int l = 0; l < NHID; ++l)
-            load_relu_mask<HT>(make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), msk[l], lane);
+#pragma unroll
+            for (int q = 0; q < HT / 2; ++q) msk[l][q] = mn[l][q];
+        fetch(tg + nblk < ngroups ? tg + nblk : tg);       // (past the end: this group again, never used)
         const unsigned hb = live ? HBYTES : 0u;            // zero-record descriptors drop the stores of a wave past the range
         f32x16 cur[HT];
         zero_tiles<HT>(cur);
