@@ -697,7 +697,7 @@ int mlp_grid(int n_tiles, int occ = 2)
 
 // Share of the launch's workgroups (one per CU) for every job, proportional to its tiles; slab regions back to back.
 template <int WK>
-int plan_batch(WgradBatch &B, float *scratch, int64_t slab_floats, ReduceArgs &R)
+int plan_batch(WgradBatch &B, float *scratch, int64_t slab_floats, ReduceArgs &R, int64_t &used_out)
 {
     int64_t tiles = 0;
     for (int j = 0; j < B.n; ++j) tiles += B.job[j].t1 - B.job[j].t0;
@@ -729,6 +729,7 @@ int plan_batch(WgradBatch &B, float *scratch, int64_t slab_floats, ReduceArgs &R
         R.first[j + 1] = R.first[j] + (int64_t)n_elems * ((W.nwg * WK + REDUCE_PG - 1) / REDUCE_PG);
     }
     R.nseg = B.n;
+    used_out = used;
     if (used > slab_floats) return ESR_ECAP;
     return wg0;                                                     // = grid
 }
@@ -740,9 +741,59 @@ int launch_reduce(const ReduceArgs &R, hipStream_t s)
     return 0;
 }
 
+// The slab workspace of one esr_mlp_wgrad_batch call.  Every weight-gradient launch used to be followed by its own
+// reduction (12-15 us each, and the next launch could not start before it had finished): the launches of a call now take
+// consecutive regions of the workspace and ONE reduction (segments of all launches, <= MAX_JOBS per reduce launch) runs
+// at the end -- or earlier, when the next launch's slabs no longer fit behind the pending ones.
+struct SlabPool {
+    float *base;
+    int64_t total, used;
+    hipStream_t s;
+    ReduceArgs pending[4 * MAX_JOBS];
+    int n_pending;
+    SlabPool(float *b, int64_t t, hipStream_t st) : base(b), total(t), used(0), s(st), n_pending(0) {}
+    int flush()
+    {
+        ReduceArgs M = {};
+        for (int q = 0; q < n_pending; ++q) {
+            const ReduceArgs &R = pending[q];
+            for (int j = 0; j < R.nseg; ++j) {
+                if (M.nseg == MAX_JOBS) {
+                    if (int rc = launch_reduce(M, s)) return rc;
+                    M = ReduceArgs{};
+                }
+                const int k = M.nseg++;
+                M.slab[k] = R.slab[j]; M.n_partials[k] = R.n_partials[j]; M.n_elems[k] = R.n_elems[j]; M.gw[k] = R.gw[j];
+                M.first[k + 1] = M.first[k] + (R.first[j + 1] - R.first[j]);
+            }
+        }
+        n_pending = 0;
+        used = 0;
+        return M.nseg ? launch_reduce(M, s) : 0;
+    }
+    // plan(scratch, floats, R, used) -> grid or error: behind the pending slabs if it fits, else after a flush
+    template <class Plan>
+    int place(Plan plan, ReduceArgs &R, int64_t &n)
+    {
+        int grid = plan(base + used, total - used, R, n);
+        if (grid == ESR_ECAP && used > 0) {
+            if (int rc = flush()) return rc;
+            grid = plan(base, total, R, n);
+        }
+        return grid;
+    }
+    int launched(const ReduceArgs &R, int64_t n)
+    {
+        pending[n_pending++] = R;
+        used += n;
+        return n_pending == 4 * MAX_JOBS ? flush() : 0;
+    }
+};
+
 template <int MI, int NJ, int WM, int WN, int WK, int MODE = 0>
-int launch_wgrad(WgradBatch &B, float *scratch, int64_t slab_floats, hipStream_t s)
+int launch_wgrad(WgradBatch &B, SlabPool &P)
 {
+    hipStream_t s = P.s;
     for (int j = 0; j < B.n; ++j)
         if (B.job[j].RA > WM * MI * 32 || B.job[j].RB > WN * NJ * 32) return ESR_ECAP;
     constexpr int NT = 64 * WM * WN * WK;
@@ -751,16 +802,18 @@ int launch_wgrad(WgradBatch &B, float *scratch, int64_t slab_floats, hipStream_t
     if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_wgrad_kernel<MI, NJ, WM, WN, WK, MODE>), lds_bytes, optin))
         return rc;
     ReduceArgs R;
-    const int grid = plan_batch<WK>(B, scratch, slab_floats, R);     // one workgroup per CU (LDS-bound residency)
+    int64_t n = 0;
+    const int grid = P.place([&](float *sc, int64_t fl, ReduceArgs &R_, int64_t &n_) { return plan_batch<WK>(B, sc, fl, R_, n_); }, R, n);     // one workgroup per CU (LDS-bound residency)
     if (grid < 0) return grid;
     mlp_wgrad_kernel<MI, NJ, WM, WN, WK, MODE><<<grid, NT, lds_bytes, s>>>(B);
     ESR_CHECK_LAUNCH();
-    return launch_reduce(R, s);
+    return P.launched(R, n);
 }
 
 template <int MI, int NJ, int WM, int WN, int WK>
-int launch_wgrad_dma(WgradBatch &B, float *scratch, int64_t slab_floats, hipStream_t s)
+int launch_wgrad_dma(WgradBatch &B, SlabPool &P)
 {
+    hipStream_t s = P.s;
     for (int j = 0; j < B.n; ++j)
         if (B.job[j].RA > WM * MI * 32 || B.job[j].RB > WN * NJ * 32) return ESR_ECAP;
     constexpr int NT = 64 * (WM * WN * WK + 1);           // compute waves + the loader wave
@@ -770,19 +823,20 @@ int launch_wgrad_dma(WgradBatch &B, float *scratch, int64_t slab_floats, hipStre
     if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_wgrad_dma_kernel<MI, NJ, WM, WN, WK>), lds_bytes, optin))
         return rc;
     ReduceArgs R;
-    const int grid = plan_batch<WK>(B, scratch, slab_floats, R);     // one workgroup per CU (LDS-bound residency)
+    int64_t n = 0;
+    const int grid = P.place([&](float *sc, int64_t fl, ReduceArgs &R_, int64_t &n_) { return plan_batch<WK>(B, sc, fl, R_, n_); }, R, n);     // one workgroup per CU (LDS-bound residency)
     if (grid < 0) return grid;
     mlp_wgrad_dma_kernel<MI, NJ, WM, WN, WK><<<grid, NT, lds_bytes, s>>>(B);
     ESR_CHECK_LAUNCH();
-    return launch_reduce(R, s);
+    return P.launched(R, n);
 }
 
 // f32: LDS-DMA staging; bf16 operand modes: the register-staged kernel
 template <int MI, int NJ, int WM, int WN, int WK, int MODE>
-int launch_wgrad_any(WgradBatch &B, float *scratch, int64_t slab_floats, hipStream_t s)
+int launch_wgrad_any(WgradBatch &B, SlabPool &P)
 {
-    if constexpr (MODE == 0) return launch_wgrad_dma<MI, NJ, WM, WN, WK>(B, scratch, slab_floats, s);
-    else return launch_wgrad<MI, NJ, WM, WN, WK, MODE>(B, scratch, slab_floats, s);
+    if constexpr (MODE == 0) return launch_wgrad_dma<MI, NJ, WM, WN, WK>(B, P);
+    else return launch_wgrad<MI, NJ, WM, WN, WK, MODE>(B, P);
 }
 
 // ---- unified launch of the 192-wide f32 jobs --------------------------------------------------------------
@@ -805,7 +859,7 @@ const double *uni_cost()
 constexpr int uni_wk(int cfg) { return cfg == UNI_HID192 ? 1 : 2; }
 
 // workgroups per job proportional to tiles x cost (every job >= 1, none more than its tiles); slab regions back to back
-int plan_uni(WgradBatch &B, float *scratch, int64_t slab_floats, ReduceArgs &R)
+int plan_uni(WgradBatch &B, float *scratch, int64_t slab_floats, ReduceArgs &R, int64_t &used_out)
 {
     const double *cost = uni_cost();
     double w[MAX_JOBS], wt = 0.0;
@@ -861,12 +915,14 @@ int plan_uni(WgradBatch &B, float *scratch, int64_t slab_floats, ReduceArgs &R)
         R.first[j + 1] = R.first[j] + (int64_t)n_elems * ((W.nwg * wk + REDUCE_PG - 1) / REDUCE_PG);
     }
     R.nseg = B.n;
+    used_out = used;
     if (used > slab_floats) return ESR_ECAP;
     return wg0;
 }
 
-int launch_wgrad_uni(WgradBatch &B, float *scratch, int64_t slab_floats, hipStream_t s)
+int launch_wgrad_uni(WgradBatch &B, SlabPool &P)
 {
+    hipStream_t s = P.s;
     for (int j = 0; j < B.n; ++j) {
         const WgradArgs &W = B.job[j];
         const int rap = W.cfg == UNI_OUT192 ? 32 : 192, rbp = W.cfg == UNI_FIRST192 ? 96 : 192;
@@ -876,11 +932,12 @@ int launch_wgrad_uni(WgradBatch &B, float *scratch, int64_t slab_floats, hipStre
     static std::atomic<uint64_t> optin{0};
     if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_wgrad_uni192_kernel), lds_bytes, optin)) return rc;
     ReduceArgs R;
-    const int grid = plan_uni(B, scratch, slab_floats, R);
+    int64_t n = 0;
+    const int grid = P.place([&](float *sc, int64_t fl, ReduceArgs &R_, int64_t &n_) { return plan_uni(B, sc, fl, R_, n_); }, R, n);
     if (grid < 0) return grid;
     mlp_wgrad_uni192_kernel<<<grid, 320, lds_bytes, s>>>(B);
     ESR_CHECK_LAUNCH();
-    return launch_reduce(R, s);
+    return P.launched(R, n);
 }
 
 // kernel shapes (waves per workgroup wm x wn x wk, always 4 compute waves = 1 per SIMD):
@@ -902,16 +959,16 @@ bool uni_on()
 }
 
 template <bool BF>
-int launch_cfg(int cfg, WgradBatch &B, float *scratch, int64_t slab_floats, hipStream_t s)
+int launch_cfg(int cfg, WgradBatch &B, SlabPool &P)
 {
     switch (cfg) {
-    case CFG_HID192:      return launch_wgrad_any<3, 3, 2, 2, 1, BF ? 2 : 0>(B, scratch, slab_floats, s);
-    case CFG_FIRST192:    return launch_wgrad_any<3, 3, 2, 1, 2, BF ? 3 : 0>(B, scratch, slab_floats, s);
-    case CFG_FIRST192_64: return launch_wgrad_any<3, 2, 2, 1, 2, BF ? 3 : 0>(B, scratch, slab_floats, s);
-    case CFG_OUT192:      return launch_wgrad_any<1, 3, 1, 2, 2, BF ? 1 : 0>(B, scratch, slab_floats, s);
-    case CFG_HID128:      return launch_wgrad_any<2, 2, 2, 2, 1, BF ? 2 : 0>(B, scratch, slab_floats, s);
-    case CFG_FIRST128:    return launch_wgrad_any<2, 3, 2, 1, 2, BF ? 3 : 0>(B, scratch, slab_floats, s);
-    default:              return launch_wgrad_any<1, 2, 1, 2, 2, BF ? 1 : 0>(B, scratch, slab_floats, s);
+    case CFG_HID192:      return launch_wgrad_any<3, 3, 2, 2, 1, BF ? 2 : 0>(B, P);
+    case CFG_FIRST192:    return launch_wgrad_any<3, 3, 2, 1, 2, BF ? 3 : 0>(B, P);
+    case CFG_FIRST192_64: return launch_wgrad_any<3, 2, 2, 1, 2, BF ? 3 : 0>(B, P);
+    case CFG_OUT192:      return launch_wgrad_any<1, 3, 1, 2, 2, BF ? 1 : 0>(B, P);
+    case CFG_HID128:      return launch_wgrad_any<2, 2, 2, 2, 1, BF ? 2 : 0>(B, P);
+    case CFG_FIRST128:    return launch_wgrad_any<2, 3, 2, 1, 2, BF ? 3 : 0>(B, P);
+    default:              return launch_wgrad_any<1, 2, 1, 2, 2, BF ? 1 : 0>(B, P);
     }
 }
 
@@ -1134,13 +1191,13 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
             B.job[B.n++] = W;
         }
     }
-    hipStream_t s = esr_stream(stream);
+    SlabPool P(scratch, scratch_floats, esr_stream(stream));
     for (int u = 0; u < n_uni; ++u)
-        if (int rc = launch_wgrad_uni(uni[u], scratch, scratch_floats, s)) return rc;
+        if (int rc = launch_wgrad_uni(uni[u], P)) return rc;
     for (int c = 0; c < N_CFG; ++c)
         for (int g = 0; g < n_group[c]; ++g)
-            if (int rc = launch_cfg<BF>(c, group[c][g], scratch, scratch_floats, s)) return rc;
-    return 0;
+            if (int rc = launch_cfg<BF>(c, group[c][g], P)) return rc;
+    return P.flush();
 }
 
 template <bool BF>
