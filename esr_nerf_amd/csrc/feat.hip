@@ -45,6 +45,11 @@ struct FeatParams {
     int src_t0[MAX_SRC], src_t1[MAX_SRC];
     const float *dsdf_extra;                          // [tiles*32] added to the SDF-value row, or null
     float *dsdf_out;                                  // explicit mode: gradient w.r.t. pt_sdf
+    // gradient of the EXACT trilinear interpolant at the sample (value, d/dx, d/dy, d/dz in world units; esr_expgrad_fwd's
+    // outputs), scattered here with esr_expgrad_bwd's weights: g4 [tiles*32][4] and / or (g4_self) the sample's own
+    // SDF-value gradient as the value component; g4_zero_pad: out-of-grid corners dropped instead of border-replicated
+    const float *g4;
+    int g4_self, g4_zero_pad;
     float *grad_sdf;
     int t_begin, t_end;                               // backward: tiles that have a gradient source at all
 };
@@ -504,6 +509,8 @@ __global__ void __launch_bounds__(256, 2) feat_bwd_kernel(FeatParams P)
             }
             if (P.dsdf_extra) r_dsdf += P.dsdf_extra[j];
         }
+        float4 r_g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (P.grad_sdf && P.g4) r_g4 = *reinterpret_cast<const float4 *>(P.g4 + 4 * (size_t)j);
         if (nact == 1) {             // the colour rows of the tile's only net (several nets: fetched in their passes)
 #pragma unroll
             for (int c = 0; c < 3; ++c) r_d3[c] = P.dX[k_one][((size_t)t * DXROWS + ROW_COL + 3 * h + c) * 32 + s];
@@ -580,9 +587,9 @@ __global__ void __launch_bounds__(256, 2) feat_bwd_kernel(FeatParams P)
                 wc[a][1] = indc[a] - (float)i0c[a];
             }
             float d_sdf = r_dsdf;
-            if (P.dsdf_out) {                 // explicit points: the SDF value is an input, not a grid tap
-                if (h == 0) P.dsdf_out[j] = d_sdf;
-                d_sdf = 0.f;
+            if (P.dsdf_out || P.g4_self) {    // explicit points: the SDF value is an input, not a tap of the stencil
+                if (P.dsdf_out && h == 0) P.dsdf_out[j] = d_sdf;         // (g4_self: it goes to the grid through the exact
+                d_sdf = 0.f;                                             //  interpolant below)
             }
 #pragma unroll
             for (int bar = 0; bar < 2; ++bar) {
@@ -659,6 +666,40 @@ __global__ void __launch_bounds__(256, 2) feat_bwd_kernel(FeatParams P)
                         }
                 }
             }
+        }
+        // ---- the exact interpolant's gradient (esr_expgrad_bwd's scatter, lts.hip, folded in: the LTS stages ran it as
+        // launches of their own over the same samples, 8 scattered float atomics per sample): value weights
+        // w_x w_y w_z and derivative weights +-w_y w_z ... on the 8 corners of the UNCLAMPED base cell, corners
+        // border-replicated (or dropped: g4_zero_pad).  A clamped corner is the sample's clamped base cell or that + 1:
+        // inside the window.  Lane half h takes the corners with cx = h.
+        if (valid && (P.g4 || P.g4_self)) {
+            float gd[3] = {r_g4.y, r_g4.z, r_g4.w}, wq[3][2];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float fl = floorf(ind[a]);
+                wq[a][0] = (fl + 1.f) - ind[a];
+                wq[a][1] = ind[a] - fl;
+                gd[a] *= (float)(gdims[a] - 1) / (sc.xyz_max[a] - sc.xyz_min[a]);
+            }
+            const float gv = P.g4_self ? r_g4.x + (r_dsdf) : r_g4.x;
+            const int cell0 = ((i0c[0] - w.lo[0]) * w.wd[1] + (i0c[1] - w.lo[1])) * w.wd[2] + (i0c[2] - w.lo[2]);
+            const int cx = h;
+#pragma unroll
+            for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+                for (int cz = 0; cz < 2; ++cz) {
+                    const int ux = i0[0] + cx, uy = i0[1] + cy, uz = i0[2] + cz;
+                    const int x = min(max(ux, 0), gdims[0] - 1), y = min(max(uy, 0), gdims[1] - 1), z = min(max(uz, 0), gdims[2] - 1);
+                    const bool inb = (ux == x) & (uy == y) & (uz == z);
+                    const float sx = cx ? 1.f : -1.f, sy = cy ? 1.f : -1.f, sz = cz ? 1.f : -1.f;
+                    const float wx = cx ? wq[0][1] : wq[0][0];
+                    const float c0 = wx * wq[1][cy] * wq[2][cz];
+                    const float c1 = sx * wq[1][cy] * wq[2][cz], c2 = wx * sy * wq[2][cz], c3 = wx * wq[1][cy] * sz;
+                    const float t = gv * c0 + gd[0] * c1 + gd[1] * c2 + gd[2] * c3;
+                    if (t != 0.f && !(P.g4_zero_pad && !inb))
+                        cell_add(w, cell0 + ((x - i0c[0]) * w.wd[1] + (y - i0c[1])) * w.wd[2] + (z - i0c[2]), P.grad_sdf,
+                                 ((int64_t)x * gdims[1] + y) * gdims[2] + z, t);
+                }
         }
         lds_fence();
         windows_flush(SG, w, 1, lds, P.grad_sdf, gdims, lane);
@@ -746,7 +787,8 @@ ESR_API int esr_fine_feat_fwd(const esr_scene_t *scene, const esr_feat_args_t *a
 
 ESR_API int esr_fine_feat_bwd(const esr_scene_t *scene, const esr_feat_args_t *args, const float *X,
                               const float *gnorm, const esr_feat_bwd_src_t *src, int32_t n_src,
-                              const float *dsdf_extra, float *grad_sdf, float *dsdf_out, void *stream)
+                              const float *dsdf_extra, float *grad_sdf, float *dsdf_out, const float *grad4,
+                              int32_t grad4_mode, void *stream)
 {
     FeatParams P = {};
     const int c = feat_common(scene, args, P);
@@ -760,6 +802,8 @@ ESR_API int esr_fine_feat_bwd(const esr_scene_t *scene, const esr_feat_args_t *a
         P.src_t0[k] = src[k].t0; P.src_t1[k] = src[k].t1;
     }
     P.dsdf_extra = dsdf_extra; P.dsdf_out = dsdf_out; P.grad_sdf = grad_sdf;
+    if ((grad4 || (grad4_mode & 2)) && !grad_sdf) return ESR_EINVAL;
+    P.g4 = grad4; P.g4_zero_pad = grad4_mode & 1; P.g4_self = (grad4_mode & 2) ? 1 : 0;
     // the scatter reduces a sample's stencil onto three 6-cell bars (and sizes its LDS windows for them): radii beyond
     // 2 voxels would fall off the bars -- refused rather than dropped (the forward has a direct form for any radius)
     if (grad_sdf)
@@ -768,7 +812,7 @@ ESR_API int esr_fine_feat_bwd(const esr_scene_t *scene, const esr_feat_args_t *a
     // tiles outside every source's range receive no gradient: the launch covers the sources' window only (the fine
     // engine scatters the on-tiles while the off net's input gradients are still being computed)
     P.t_begin = 0; P.t_end = P.tiles_all;
-    if (!dsdf_extra && !dsdf_out) {
+    if (!dsdf_extra && !dsdf_out && !grad4) {
         int lo = P.tiles_all, hi = 0;
         for (int k = 0; k < n_src; ++k) {
             lo = src[k].t0 < lo ? src[k].t0 : lo;

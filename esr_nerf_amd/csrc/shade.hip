@@ -148,7 +148,6 @@ __global__ void __launch_bounds__(256) tone_in_bwd_kernel(
         for (int c = 0; c < 3; ++c) {
             float d = 0.f;
             if (ray >= 0) {
-                const float v = lin[z4 + c * 32];
                 d = rec_w[j] * g_lin[3 * ray + c] + dX[c * 32];
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
@@ -399,7 +398,6 @@ __global__ void __launch_bounds__(256) lts_tone_in_bwd_kernel(
         for (int c = 0; c < 3; ++c) {
             float d = 0.f;
             if (ray >= 0) {
-                const float v = lin[z4 + c * 32];
                 d = rec_w[j] * g_lin[3 * ray + c] + dX[c * 32];
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {

@@ -496,7 +496,7 @@ class FineEngine:
                 src[0].t0, src[0].t1 = t0, t1
                 self._run("feat_bwd", L.esr_fine_feat_bwd, sp, C.byref(ctx.feat_args), _lib.ptr(ws["X"]),
                           _lib.ptr(ws["gnorm"]), src, 1, _lib.ptr(ws["dsdf"]) if fold else None, _lib.ptr(grads["sdf"]),
-                          None, s_)
+                          None, None, 0, s_)
             return run
 
         def wgrads(s_):

@@ -380,7 +380,7 @@ class LtsEngine(FineEngine):
                           _lib.ptr(o), self._s())
         return o
 
-    def _feat_bwd(self, P: Pass, scene, sources, grad_sdf, dsdf_extra=None, dsdf_out=None):
+    def _feat_bwd(self, P: Pass, scene, sources, grad_sdf, dsdf_extra=None, dsdf_out=None, grad4=None, grad4_mode=0):
         if not P.tiles_all:
             return
         src = (_lib.EsrFeatBwdSrc * len(sources))()
@@ -391,7 +391,7 @@ class LtsEngine(FineEngine):
             src[i].t0, src[i].t1 = t0, t1
         self._run(f"feat_bwd[{P.name}]", self.L.esr_fine_feat_bwd, C.byref(scene), C.byref(P.fa),
                   _lib.ptr(P.bufs["X"]), _lib.ptr(P.bufs["gnorm"]), src, len(sources), _lib.ptr(dsdf_extra),
-                  _lib.ptr(grad_sdf), _lib.ptr(dsdf_out), self._s())
+                  _lib.ptr(grad_sdf), _lib.ptr(dsdf_out), _lib.ptr(grad4), grad4_mode, self._s())
 
     def _ref_order(self, P0: Pass, cnt3, off3):
         """perm[k] = compact (tile-order) index of the k-th surviving sample in the reference's ray-sorted
@@ -1009,9 +1009,14 @@ class LtsEngine(FineEngine):
                     grads["emo"], grads["emo"], 0, T))
         self._march_bwd("march_bwd", P0, sp, b["rays_o"], b["rays_d"], P0.n_rays, ctx.t["off3"], dweight, g_last,
                         grads["sdf"], dsdf_extra, 1)
-        self._feat_bwd(P0, ctx.scene, src, grads["sdf"], dsdf_extra=dsdf_extra)
-        # exact normals (linear in the grid): etc/normal and etc/normal_eps
-        for key, noise, eps in (("etc/normal", None, 0.0), ("etc/normal_eps", ctx.t["noise_n"], ctx.eps["normal"])):
+        # exact normals (linear in the grid): the gradient of etc/normal is scattered inside the feature backward (same
+        # samples, esr_fine_feat_bwd's grad4); etc/normal_eps sits up to several voxels away and keeps its own launch
+        g4n = None
+        if g.get("etc/normal") is not None:
+            g4n = self._z(T * 32, 4, device=dev)
+            g4n[perm, 1:4] = g["etc/normal"]
+        self._feat_bwd(P0, ctx.scene, src, grads["sdf"], dsdf_extra=dsdf_extra, grad4=g4n)
+        for key, noise, eps in (("etc/normal_eps", ctx.t["noise_n"], ctx.eps["normal"]),):
             if g.get(key) is None:
                 continue
             g4 = self._z(T * 32, 4, device=dev)
@@ -1038,9 +1043,6 @@ class LtsEngine(FineEngine):
             dX = self._net_bwd(P3, nm, kind, crow, 0, T3, dz, grads[f"{nm}_w"], grads[f"{nm}_b"])
             src.append((dX, None, ggrid, 0, T3))
         if src:
-            g4e = self._z(T3 * 32, 4, device=dev)
-            dsdf_e = self._z(T3 * 32, device=dev)
-            self._feat_bwd(P3, ctx.scene, src, grads["sdf"], dsdf_out=dsdf_e)
-            g4e[:, 0] = dsdf_e
-            self._run("expgrad_bwd(pts)", L.esr_expgrad_bwd, sp, None, None, None, None, _lib.ptr(ctx.t["pts_e"]), None,
-                      C.c_float(0.0), _lib.ptr(g4e), m3, 1, _lib.ptr(grads["sdf"]), s)
+            # the points' SDF values came from esr_expgrad_fwd(pts_e, zero padding): their gradient goes back through the
+            # same interpolant, inside the feature backward (grad4_mode 3 = zero_pad | own SDF-value gradient)
+            self._feat_bwd(P3, ctx.scene, src, grads["sdf"], grad4_mode=3)

@@ -261,6 +261,10 @@ int esr_fine_feat_fwd(const esr_scene_t *scene, const esr_feat_args_t *args, flo
  * SDF-value row.  With explicit points the SDF-value gradient is returned in dsdf_out [tiles*32]
  * instead of being scattered.  grad_sdf NULL: the SDF grid is frozen, only the colour grids receive
  * gradients (re-lighting fine-tune).  Scatter = LDS accumulation window + z-contiguous float atomics.
+ * grad4 [tiles*32][4] (optional; needs grad_sdf): per sample the gradient w.r.t. esr_expgrad_fwd's four outputs at the
+ * SAME position (value, d sdf / d x, y, z) -- scattered with esr_expgrad_bwd's weights inside this launch.  grad4_mode:
+ * bit 0 = out-of-grid corners dropped (esr_expgrad_bwd's zero_pad) instead of border-replicated; bit 1 = explicit points:
+ * the SDF-value gradient (what dsdf_out receives) is scattered the same way, as the value component.
  * The SDF scatter is built for stencil radii (scene->grad_feat) in [0, 2] voxels, the reference's configuration
  * (fine.yaml: [0.5, 1.0, 1.5, 2.0]); other radii return ESR_ECAP (esr_fine_feat_fwd takes any radius).
  */
@@ -272,7 +276,8 @@ typedef struct esr_feat_bwd_src {
 
 int esr_fine_feat_bwd(const esr_scene_t *scene, const esr_feat_args_t *args, const float *X,
                       const float *gnorm, const esr_feat_bwd_src_t *src, int32_t n_src,
-                      const float *dsdf_extra, float *grad_sdf, float *dsdf_out, void *stream);
+                      const float *dsdf_extra, float *grad_sdf, float *dsdf_out, const float *grad4,
+                      int32_t grad4_mode, void *stream);
 
 /*
  * Tiny-MLP engine (RadianceNet 85-192-192-192-3, TonemapNet 33-192-3;

@@ -227,7 +227,7 @@ def test_feat_kernels_explicit_points_straddling_the_box():
     src[0].dX, src[0].grad_color_on, src[0].grad_color_off = dX.data_ptr(), None, g_col.data_ptr()
     src[0].t0, src[0].t1 = 0, tiles
     _lib.check(L.esr_fine_feat_bwd(C.byref(scene), C.byref(fa), _lib.ptr(X), _lib.ptr(gn), src, 1, None,
-                                   _lib.ptr(g_sdf), _lib.ptr(dsdf_out), s), "feat_bwd")
+                                   _lib.ptr(g_sdf), _lib.ptr(dsdf_out), None, 0, s), "feat_bwd")
     assert rel_err(g_sdf, sdf.grad[0, 0]) < 1e-4, rel_err(g_sdf, sdf.grad[0, 0])
     assert rel_err(g_col.permute(3, 0, 1, 2), col.grad[0]) < 2e-5
     assert rel_err(dsdf_out[:n], dXr[:, 6]) < 1e-6
@@ -286,7 +286,7 @@ def test_feat_fwd_direct_form_for_wide_stencils():
     src = (_lib.EsrFeatBwdSrc * 1)()
     src[0].dX, src[0].t0, src[0].t1 = dX.data_ptr(), 0, tiles
     rc = L.esr_fine_feat_bwd(C.byref(wide_scene), C.byref(fa), _lib.ptr(X), _lib.ptr(gn), src, 1, None, _lib.ptr(gs),
-                             None, s)
+                             None, None, 0, s)
     assert rc == -2
     with pytest.raises(RuntimeError, match="capacity"):
         _lib.check(rc, "feat_bwd")
