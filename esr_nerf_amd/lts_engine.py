@@ -98,6 +98,7 @@ class _PointDraw:
     from ``np.random`` in between (nothing on this path does)."""
 
     _pool = None           # one persistent worker: creating a thread per step costs ~0.1 ms of host time
+    _pinned = {}           # k -> [buffer, buffer, last slot]
 
     def __init__(self, n: int, k: int):
         from concurrent.futures import ThreadPoolExecutor
@@ -111,7 +112,13 @@ class _PointDraw:
         self._pos = C.c_int32(int(st[2]))
         # pinned: the upload in lts_forward must not block the host (a pageable copy waits for the stream to drain,
         # after which every small launch of the light-transport glue shows its full launch latency: ~0.5 ms idle per step)
-        self._out_t = torch.empty(k, dtype=torch.int64, pin_memory=torch.cuda.is_available())
+        # (two alternating buffers per size, allocated once: a pinned allocation per step cost the host ~60 us right after
+        # the plan read, with the device idle -- tools/trace_lts.sh)
+        ring = _PointDraw._pinned.setdefault(k, [None, None, 0])
+        slot = ring[2] = ring[2] ^ 1
+        if ring[slot] is None:
+            ring[slot] = torch.empty(k, dtype=torch.int64, pin_memory=torch.cuda.is_available())
+        self._out_t = ring[slot]
         self._out = self._out_t.numpy()
         self._rc = None
         L = _lib.lib()
@@ -193,12 +200,14 @@ class LtsEngine(FineEngine):
         return v
 
     # ------------------------------------------------------------------ building blocks
-    def _march(self, P: Pass, scene, rays_o, rays_d, em_modes, mask_density, sdf, prelude=None, viewdirs=None):
+    def _march(self, P: Pass, scene, rays_o, rays_d, em_modes, mask_density, sdf, prelude=None, viewdirs=None, between=None):
         """count -> plan -> (host reads the plan header) -> fill.  ``viewdirs``: the rays' view directions -- read under cfg
         neus_alpha "grad" (esrnerf.py:197-200: every march of the renderer extrapolates its section SDFs along them;
         the secondary rays' view directions are their own directions, esrnerf.py:575-591).  ``prelude()``: work that does not depend on the march
         (weight packing, zeroing the gradient buffer), enqueued on a side stream while the host waits; the returned
-        event (``P.e_pre``) must be waited for by the main stream before the first consumer."""
+        event (``P.e_pre``) must be waited for by the main stream before the first consumer.  ``between()``: work for the
+        MAIN stream that does not need the march's result, enqueued behind the plan's copy: the device runs it while the host
+        reads the plan and enqueues the fill (otherwise it idles for the host's wake-up + first launches, ~0.1 ms)."""
         L, s = self.L, self._s()
         n = rays_o.shape[0]
         P.n_rays = n
@@ -232,18 +241,18 @@ class LtsEngine(FineEngine):
                   _lib.ptr(self.plan_dev), s)
         self.plan_host.copy_(self.plan_dev, non_blocking=True)
         P.e_pre = None
+        landed = torch.cuda.Event()
+        landed.record()
+        if between is not None:
+            between()
         if prelude is not None:
-            landed = torch.cuda.Event()
-            landed.record()
             side = self._side_stream(0)
             side.wait_event(landed)
             with torch.cuda.stream(side):
                 prelude()
                 P.e_pre = torch.cuda.Event()
                 P.e_pre.record(side)
-            landed.synchronize()
-        else:
-            torch.cuda.current_stream(self.device).synchronize()
+        landed.synchronize()
         n_on, n_off, tiles_on, tiles_all, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
         if overflow:
             self._overflow()
@@ -699,10 +708,13 @@ class LtsEngine(FineEngine):
         m3 = P0.counts["m3"]
         if T == 0:
             raise RuntimeError("LTS step with no surviving sample (degenerate batch)")
-        point_draw = _PointDraw(m3, min(int(cfg["num_ltspts"]), m3)) if draws is None else None
         sp = C.byref(scene)
         self._feat_args_records(P0, rays_o, rays_d, viewdirs, sdf, (offg, emog, brdfg), (offg, emog, brdfg))
         self._features(P0, scene)
+        # (started behind the first large launch: checking out numpy's state and waking the worker is ~50 us of host time
+        # the device would otherwise spend idle right after the plan read; the draw itself is 0.4 ms against ~0.8 ms of
+        # primary-pass work queued in front of its consumer)
+        point_draw = _PointDraw(m3, min(int(cfg["num_ltspts"]), m3)) if draws is None else None
         # exact normals (+ positions) of every surviving sample
         eg = torch.empty(T * 32, 4, device=dev)
         self._run("expgrad_fwd", L.esr_expgrad_fwd, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(P0.bufs["rec_ray"]),
@@ -803,21 +815,26 @@ class LtsEngine(FineEngine):
         torch.neg(dirs_all[:, R], out=vd2[Pn:])                  # v_rand
         # (a) radiance predicted by the nets at the points, camera direction and random direction
         P1 = self.pts
-        self._feat_args_points(P1, pts2, vd2, sdf2, sdf, (offg, emog, None))
-        self._features(P1, scene)
-        T1 = P1.tiles_all
-        self._net_fwd(P1, "off", KIND_RADIANCE, 0, 0, T1)
-        self._net_fwd(P1, "emo", KIND_RADIANCE, 88, 0, T1)
-        self._act(P1, "off.z", "off.a", 4, 3, ACT_SOFTPLUS)
-        self._act(P1, "emo.z", "emo.a", 4, 3, ACT_SOFTPLUS)
-        off_pt = self._gather_rows(P1.bufs["off.a"], 4, 0, 0, 3, None, 2 * Pn)
-        emo_pt = self._gather_rows(P1.bufs["emo.a"], 4, 0, 0, 3, None, 2 * Pn)
-        # (b) incoming radiance along the secondary rays
+        at_pts = {}
+
+        def points_pass():
+            self._feat_args_points(P1, pts2, vd2, sdf2, sdf, (offg, emog, None))
+            self._features(P1, scene)
+            T1 = P1.tiles_all
+            self._net_fwd(P1, "off", KIND_RADIANCE, 0, 0, T1)
+            self._net_fwd(P1, "emo", KIND_RADIANCE, 88, 0, T1)
+            self._act(P1, "off.z", "off.a", 4, 3, ACT_SOFTPLUS)
+            self._act(P1, "emo.z", "emo.a", 4, 3, ACT_SOFTPLUS)
+            at_pts["off"] = self._gather_rows(P1.bufs["off.a"], 4, 0, 0, 3, None, 2 * Pn)
+            at_pts["emo"] = self._gather_rows(P1.bufs["emo.a"], 4, 0, 0, 3, None, 2 * Pn)
+        # (b) incoming radiance along the secondary rays; (a) is enqueued behind the march's count + plan, so the device
+        # works on it while the host waits for the plan header and enqueues the fill
         P2 = self.sec
         o2 = pts_p.repeat_interleave(R, 0).contiguous()
         d2 = dirs_all[:, :R].reshape(Pn * R, 3).contiguous()
         em2 = self._z(Pn * R, dtype=torch.int64, device=dev)
-        _, off3_2, last2 = self._march(P2, scene2, o2, d2, em2, grids["mask"], sdf, viewdirs=d2)
+        _, off3_2, last2 = self._march(P2, scene2, o2, d2, em2, grids["mask"], sdf, viewdirs=d2, between=points_pass)
+        off_pt, emo_pt = at_pts["off"], at_pts["emo"]
         T2 = P2.tiles_all
         off_m = self._z(Pn * R, 3, device=dev)
         emo_m = self._z(Pn * R, 3, device=dev)
