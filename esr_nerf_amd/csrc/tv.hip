@@ -125,27 +125,21 @@ __global__ void __launch_bounds__(256) tv_error_kernel(const float *__restrict__
         int x, y, z;
         cell_xyz(i, G.gy, G.gz, x, y, z);
         const bool m = mask[i] != 0;
-        // the 27 replicate-padded taps as sums of three per-axis offsets (32-bit: cell_xyz's reasoning; the clamps and a
-        // 64-bit index product per tap were most of this kernel)
-        int ox[3], oy[3], oz[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            ox[d] = min(max(x + d - 1, 0), G.gx - 1) * (G.gy * G.gz);
-            oy[d] = min(max(y + d - 1, 0), G.gy - 1) * G.gz;
-            oz[d] = min(max(z + d - 1, 0), G.gz - 1);
-        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float e = 0.f;
             if (m) {
-                const float *gc = g + c * n;
                 float s = K.bias;
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
+                for (int dx = -1; dx <= 1; ++dx)
 #pragma unroll
-                    for (int dy = 0; dy < 3; ++dy)
+                    for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-                        for (int dz = 0; dz < 3; ++dz) s += K.w[dx * 9 + dy * 3 + dz] * gc[ox[dx] + oy[dy] + oz[dz]];
+                        for (int dz = -1; dz <= 1; ++dz) {
+                            const int xx = min(max(x + dx, 0), G.gx - 1), yy = min(max(y + dy, 0), G.gy - 1),
+                                      zz = min(max(z + dz, 0), G.gz - 1);
+                            s += K.w[(dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)] * g[c * n + ((int64_t)xx * G.gy + yy) * G.gz + zz];
+                        }
                 e = s - g[c * n + i];
                 part += e * e;
             }
@@ -195,7 +189,6 @@ ESR_API int esr_smooth_grad_tv_fwd(const float *sdf, const uint8_t *mask, const 
     if (gx < 1 || gy < 1 || gz < 1 || masked_cells < 0) return ESR_EINVAL;
     if (!sdf || !mask || !conv_w27 || !work6 || !loss) return ESR_EINVAL;
     const int64_t n = (int64_t)gx * gy * gz;
-    if (n >= (1LL << 31)) return ESR_ECAP;                     // (tv_error_kernel's tap offsets are 32-bit)
     TvGrid G = {gx, gy, gz, voxel_size};
     Conv27 K;
     for (int i = 0; i < 27; ++i) K.w[i] = conv_w27[i];          // host array
