@@ -233,6 +233,72 @@ def test_feat_kernels_explicit_points_straddling_the_box():
     assert rel_err(dsdf_out[:n], dXr[:, 6]) < 1e-6
 
 
+@pytest.mark.parametrize("zero_pad", [0, 1])
+def test_feat_bwd_grad4_equals_expgrad_bwd(zero_pad):
+    """esr_fine_feat_bwd's folded exact-gradient scatter (grad4 / grad4_mode) against esr_expgrad_bwd at the same points,
+    incl. points up to ~1 voxel outside the box (border-replicated or dropped corners) and tiles whose windows do not all
+    fit (random points: one segment each); bit 1 of grad4_mode: the points' own SDF-value gradient as the value component."""
+    from esr_nerf_amd import _lib
+    from esr_nerf_amd.config import lts_cfg
+    from esr_nerf_amd.fine_engine import make_scene
+    from esr_nerf_amd.synthetic import slab_scene
+    from oracle import fine_path as fp
+    L = _lib.lib()
+    sc = slab_scene("tiny", s_val=40.0)
+    c = fp.make_consts(lts_cfg("cpu").app.model, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max,
+                       sc.mask_alpha_init, sc.mask_density, sc.near, sc.num_voxels)
+    ws = [int(v) for v in c.world_size]
+    g = torch.Generator().manual_seed(11 + zero_pad)
+    n = 300
+    lo, hi = sc.xyz_min, sc.xyz_max
+    vox = float(c.voxel_size)
+    pts = lo + (hi - lo) * torch.rand(n, 3, generator=g)
+    pts[:100] = pts[:1] + torch.cumsum(torch.full((100, 3), 0.4 * vox), 0)           # a diagonal run (windows that fit)
+    pts[100:140, 0] = hi[0] + (torch.rand(40, generator=g) * 2 - 1) * 0.9 * vox        # around / beyond a face
+    pts[140:150] = lo - 0.7 * vox
+    scene = make_scene(lo.tolist(), hi.tolist(), lo.tolist(), hi.tolist(), ws, [32, 32, 32], sc.near,
+                       float(c.stepsize * c.voxel_size), vox, 0.0, 1e-3, 1e-4, 40.0, [float(v) for v in c.grad_feat])
+    tiles = (n + 31) // 32
+    dev = "cuda"
+    pd, vd, sv = pts.cuda().contiguous(), torch.zeros(n, 3, device=dev), torch.zeros(n, device=dev)
+    sdf_d = torch.randn(*ws, generator=g).cuda()
+    fa = _lib.EsrFeatArgs()
+    fa.pts, fa.pt_viewdirs, fa.pt_sdf, fa.n_pts = pd.data_ptr(), vd.data_ptr(), sv.data_ptr(), n
+    fa.sdf = sdf_d.data_ptr()
+    fa.tiles_on, fa.tiles_all = 0, tiles
+    X = torch.empty(tiles * 104 * 32, device=dev)
+    gn = torch.empty(tiles * 4 * 32, device=dev)
+    s = _lib.stream_ptr("cuda:0")
+    _lib.check(L.esr_fine_feat_fwd(C.byref(scene), C.byref(fa), _lib.ptr(X), _lib.ptr(gn), s), "feat_fwd")
+    g4 = torch.zeros(tiles * 32, 4, device=dev)
+    g4[:n] = torch.randn(n, 4, generator=g).cuda()
+    dX = torch.zeros(tiles * 64 * 32, device=dev)
+    src = (_lib.EsrFeatBwdSrc * 1)()
+    src[0].dX, src[0].t0, src[0].t1 = dX.data_ptr(), 0, tiles
+    # (a) grad4 alone (all dX rows zero: the stencil contributes nothing)
+    ours, ref = torch.zeros_like(sdf_d), torch.zeros_like(sdf_d)
+    dsdf_out = torch.zeros(tiles * 32, device=dev)
+    _lib.check(L.esr_fine_feat_bwd(C.byref(scene), C.byref(fa), _lib.ptr(X), _lib.ptr(gn), src, 1, None, _lib.ptr(ours),
+                                   _lib.ptr(dsdf_out), _lib.ptr(g4), zero_pad, s), "feat_bwd")
+    _lib.check(L.esr_expgrad_bwd(C.byref(scene), None, None, None, None, _lib.ptr(pd), None, C.c_float(0.0), _lib.ptr(g4), n,
+                                 zero_pad, _lib.ptr(ref), s), "expgrad_bwd")
+    assert float(ref.abs().max()) > 0.1
+    assert rel_err(ours, ref) < 1e-5, rel_err(ours, ref)
+    # (b) the points' own SDF-value gradient (dX row 6) scattered as the value component
+    dXt = torch.zeros(tiles * 32, 64)
+    dXt[:n, 6] = torch.randn(n, generator=g)
+    dX2 = dXt.view(tiles, 32, 64).permute(0, 2, 1).contiguous().cuda()
+    src[0].dX = dX2.data_ptr()
+    ours2, ref2 = torch.zeros_like(sdf_d), torch.zeros_like(sdf_d)
+    _lib.check(L.esr_fine_feat_bwd(C.byref(scene), C.byref(fa), _lib.ptr(X), _lib.ptr(gn), src, 1, None, _lib.ptr(ours2),
+                                   None, None, 2 | zero_pad, s), "feat_bwd")
+    g4v = torch.zeros(tiles * 32, 4, device=dev)
+    g4v[:, 0] = dXt[:, 6].cuda()
+    _lib.check(L.esr_expgrad_bwd(C.byref(scene), None, None, None, None, _lib.ptr(pd), None, C.c_float(0.0), _lib.ptr(g4v), n,
+                                 zero_pad, _lib.ptr(ref2), s), "expgrad_bwd")
+    assert rel_err(ours2, ref2) < 1e-5, rel_err(ours2, ref2)
+
+
 def test_feat_fwd_direct_form_for_wide_stencils():
     """cfg grad_feat radii beyond 2 voxels (voxurff.py:164-167 takes any list): the forward's stencil bars do not reach,
     the direct form runs (feat.hip: feat_fwd_kernel<false>) -- rows against the oracle's stencil; the scatter, whose bars
