@@ -457,14 +457,49 @@ __global__ void __launch_bounds__(256, 2) feat_bwd_kernel(FeatParams P)
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     lds_cell *const lds = (lds_cell *)(win_all + (threadIdx.x >> 6) * WIN_CELLS);
+    // The march record and the ray of the NEXT tile travel one tile ahead (8 registers): record -> ray -> position is a chain
+    // of two dependent loads that every tile used to start with, with nothing to hide it behind.
+    int nx_ray = -1, nx_step = 0;
+    float nx_o[3] = {0.f, 0.f, 0.f}, nx_d[3] = {0.f, 0.f, 1.f};
+    auto fetch_rec = [&](int tt) {
+        if (P.pts) return;                                                 // (explicit points: independent loads, below)
+        const int jj = (tt < P.t_end ? tt : P.t_end - 1) * 32 + s;         // past the end: the last tile again, unused
+        nx_ray = P.rec_ray[jj];
+        nx_step = P.rec_step[jj];
+    };
+    auto fetch_ray = [&]() {
+        if (P.pts) return;
+        const int rc = max(nx_ray, 0);                                     // padding lanes read ray 0 (unconditional loads)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { nx_o[a] = P.rays_o[3 * rc + a]; nx_d[a] = P.rays_d[3 * rc + a]; }
+    };
+    if (P.t_begin + wave < P.t_end) { fetch_rec(P.t_begin + wave); fetch_ray(); }
     for (int t = P.t_begin + wave; t < P.t_end; t += nwaves) {
         const int j = t * 32 + s;
+        const int ray_ = nx_ray, step_ = nx_step;
+        float ro_[3], rd_[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { ro_[a] = nx_o[a]; rd_[a] = nx_d[a]; }
+        fetch_rec(t + nwaves);
         const float *Xt = P.X + (size_t)t * XROWS * 32 + s;
         const float *Gn = P.gnorm + (size_t)t * 4 * 32 + s;
         const bool on_tile = t < P.tiles_on;
-        float p[3] = {0.f, 0.f, 0.f}, ind[3] = {0.f, 0.f, 0.f}, vdir_[3], sdfv_;
+        float p[3] = {0.f, 0.f, 0.f}, ind[3] = {0.f, 0.f, 0.f};
         int i0[3] = {0, 0, 0};
-        const bool valid = sample_inputs(P, j, p, vdir_, sdfv_);
+        bool valid;
+        if (P.pts) {
+            valid = j < P.n_pts;
+            if (valid) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) p[a] = P.pts[3 * j + a];
+            }
+        } else {                                         // sample_inputs' arithmetic on the prefetched record and ray
+            valid = ray_ >= 0;
+            float t_min, t_max, start[3], dir[3];
+            esr_ray_trange(ro_, rd_, sc.xyz_min, sc.xyz_max, sc.near_, 1e9f, t_min, t_max);
+            esr_ray_start_dir(ro_, rd_, t_min, esr_ray_norm(rd_), start, dir);
+            esr_ray_point(start, dir, sc.stepdist, step_, p);
+        }
         // Gradient rows of this sample, summed over the nets that consumed the tile (rows 6-42 are shared), and the saved
         // normals: ALL of a tile's loads are issued here, before anything waits.  (They used to be fetched where they are
         // used, behind wave-uniform branches: ~60 load -> wait round trips per tile were 0.08 of this kernel's 0.29 ms at
@@ -545,7 +580,7 @@ __global__ void __launch_bounds__(256, 2) feat_bwd_kernel(FeatParams P)
             const unsigned runs = (unsigned)__ballot(jump);                  // low half: one bit per sample
             key = __popc(runs & ((2u << s) - 1u));
         } else {
-            key = valid ? P.rec_ray[j] : 0;
+            key = valid ? ray_ : 0;
         }
         Segs SG = segs_build(key, valid, false, i0c, s, h);
         // A ray piece that runs diagonally through the grid has a bounding box far larger than the cells it touches
@@ -747,6 +782,7 @@ __global__ void __launch_bounds__(256, 2) feat_bwd_kernel(FeatParams P)
             windows_flush(SG, w, 6, lds, gcol, gdims, lane);
             lds_fence();
         }
+        fetch_ray();                                     // the next tile's ray (its record arrived long ago)
     }
 }
 
