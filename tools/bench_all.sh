@@ -18,4 +18,5 @@ python3 bench.py --config C5 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/${T
 python3 bench.py --config C5 --stage finetune --steps 30 --warmup 5 --no-cpu-baseline > "$OUT/${TAG}_bench_c5_finetune_bf16.json" 2>/dev/null
 python3 bench.py --grid 256 --steps 30 --warmup 8 --no-cpu-baseline > "$OUT/${TAG}_bench_c2_g256_f32.json" 2>/dev/null
 python3 bench.py --oblique --steps 50 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_c2_oblique_f32.json" 2>/dev/null
+python3 bench.py --grid 256 --oblique --steps 30 --warmup 8 --no-cpu-baseline > "$OUT/${TAG}_bench_c2_g256_oblique_f32.json" 2>/dev/null
 for f in "$OUT/${TAG}"_bench_*.json; do echo "$(basename $f): $(tail -1 $f | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']), d['ms_per_step'], d['dtype'], d['roofline'].get('frac'), (d['roofline'].get('whole_step') or {}).get('frac'))")"; done
