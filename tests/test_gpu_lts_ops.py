@@ -299,6 +299,87 @@ def test_feat_bwd_grad4_equals_expgrad_bwd(zero_pad):
     assert rel_err(ours2, ref2) < 1e-5, rel_err(ours2, ref2)
 
 
+def test_feat_bwd_many_short_ray_pieces_per_tile():
+    """The feature backward's per-segment LDS windows on tiles that hold pieces of up to ~20 rays, with padding lanes in
+    the middle of tiles (the LTS stages' secondary pass looks like this; round 2's form handled four rays per tile in
+    windows and sent the rest to global atomics): march-record mode, positions from esr_sample_points, gradients against
+    autograd through the oracle's stencil at those positions."""
+    from esr_nerf_amd import _lib
+    from esr_nerf_amd.config import lts_cfg
+    from esr_nerf_amd.fine_engine import make_scene
+    from esr_nerf_amd.synthetic import slab_scene
+    from oracle import fine_path as fp
+    L = _lib.lib()
+    sc = slab_scene("tiny", s_val=40.0)
+    c = fp.make_consts(lts_cfg("cpu").app.model, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max,
+                       sc.mask_alpha_init, sc.mask_density, sc.near, sc.num_voxels)
+    ws = [int(v) for v in c.world_size]
+    g = torch.Generator().manual_seed(23)
+    lo, hi = sc.xyz_min, sc.xyz_max
+    vox = float(c.voxel_size)
+    stepdist = float(c.stepsize * c.voxel_size)
+    n_rays = 150
+    # rays from inside the box in random directions (every step stays a few voxels from the start)
+    rays_o = lo + (hi - lo) * (0.2 + 0.6 * torch.rand(n_rays, 3, generator=g))
+    rays_d = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=-1)
+    rec_ray, rec_step = [], []
+    for r in range(n_rays):
+        k = int(torch.randint(1, 7, (1,), generator=g))
+        first = int(torch.randint(0, 4, (1,), generator=g))
+        for q in range(k):
+            rec_ray.append(r); rec_step.append(first + q)
+        if r % 11 == 0:                                   # a padding lane in the middle of the records
+            rec_ray.append(-1); rec_step.append(0)
+    tiles = (len(rec_ray) + 31) // 32
+    rec_ray += [-1] * (tiles * 32 - len(rec_ray)); rec_step += [0] * (tiles * 32 - len(rec_step))
+    rr = torch.tensor(rec_ray, dtype=torch.int32); rs = torch.tensor(rec_step, dtype=torch.int32)
+    scene = make_scene(lo.tolist(), hi.tolist(), lo.tolist(), hi.tolist(), ws, [32, 32, 32], 0.0, stepdist, vox, 0.0, 1e-3,
+                       1e-4, 40.0, [float(v) for v in c.grad_feat])
+    dev = "cuda"
+    ro, rd = rays_o.cuda().contiguous(), rays_d.cuda().contiguous()
+    rrd, rsd = rr.cuda(), rs.cuda()
+    s = _lib.stream_ptr("cuda:0")
+    pts = torch.zeros(tiles * 32, 3, device=dev)
+    _lib.check(L.esr_sample_points(C.byref(scene), _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(rrd), _lib.ptr(rsd), tiles * 32,
+                                   _lib.ptr(pts), s), "sample_points")
+    live = rr >= 0
+    p_live = pts.cpu()[live]
+    assert bool(((p_live >= lo) & (p_live <= hi)).all())
+    assert max(int((rr[t * 32:(t + 1) * 32][live[t * 32:(t + 1) * 32]]).unique().numel()) for t in range(tiles)) >= 8
+    sdf = torch.randn(1, 1, *ws, generator=g).requires_grad_(True)
+    col = (torch.randn(1, 6, *ws, generator=g) * 0.3).requires_grad_(True)
+    feat, _, nrm = fp.sdf_stencil(c, sdf, p_live, c.grad_feat, diff_eps=1e-12)
+    colv = fp.sample_grid(col, fp.to_norm(p_live, lo, hi))
+    sdf_d = sdf.detach()[0, 0].contiguous().cuda()
+    col_d = col.detach()[0].permute(1, 2, 3, 0).contiguous().cuda()
+    rsdf = torch.zeros(tiles * 32, device=dev)
+    fa = _lib.EsrFeatArgs()
+    fa.rays_o, fa.rays_d, fa.viewdirs = ro.data_ptr(), rd.data_ptr(), rd.data_ptr()
+    fa.rec_ray, fa.rec_step, fa.rec_sdf = rrd.data_ptr(), rsd.data_ptr(), rsdf.data_ptr()
+    fa.sdf = sdf_d.data_ptr()
+    fa.color_off[0] = col_d.data_ptr()
+    fa.tiles_on, fa.tiles_all = 0, tiles
+    X = torch.empty(tiles * 104 * 32, device=dev)
+    gn = torch.empty(tiles * 4 * 32, device=dev)
+    _lib.check(L.esr_fine_feat_fwd(C.byref(scene), C.byref(fa), _lib.ptr(X), _lib.ptr(gn), s), "feat_fwd")
+    Xr = X.view(tiles, 104, 32).permute(0, 2, 1).reshape(tiles * 32, 104).cpu()[live]
+    assert rel_err(Xr[:, 7:31], feat) < 1e-5 and rel_err(Xr[:, 31:43], nrm) < 1e-4
+    dXr = torch.randn(int(live.sum()), 43, generator=g)
+    dXr[:, 6] = 0.0                                       # (record mode: the SDF value row is a grid tap of the march)
+    (colv * dXr[:, 0:6]).sum().add((feat * dXr[:, 7:31]).sum()).add((nrm * dXr[:, 31:43]).sum()).backward()
+    dXt = torch.zeros(tiles * 32, 64)
+    dXt[live, :43] = dXr
+    dX = dXt.view(tiles, 32, 64).permute(0, 2, 1).contiguous().cuda()
+    g_sdf, g_col = torch.zeros_like(sdf_d), torch.zeros_like(col_d)
+    src = (_lib.EsrFeatBwdSrc * 1)()
+    src[0].dX, src[0].grad_color_on, src[0].grad_color_off = dX.data_ptr(), None, g_col.data_ptr()
+    src[0].t0, src[0].t1 = 0, tiles
+    _lib.check(L.esr_fine_feat_bwd(C.byref(scene), C.byref(fa), _lib.ptr(X), _lib.ptr(gn), src, 1, None,
+                                   _lib.ptr(g_sdf), None, None, 0, s), "feat_bwd")
+    assert rel_err(g_sdf, sdf.grad[0, 0]) < 1e-4, rel_err(g_sdf, sdf.grad[0, 0])
+    assert rel_err(g_col.permute(3, 0, 1, 2), col.grad[0]) < 2e-5
+
+
 def test_feat_fwd_direct_form_for_wide_stencils():
     """cfg grad_feat radii beyond 2 voxels (voxurff.py:164-167 takes any list): the forward's stencil bars do not reach,
     the direct form runs (feat.hip: feat_fwd_kernel<false>) -- rows against the oracle's stencil; the scatter, whose bars
