@@ -24,6 +24,12 @@
 
 #include "mlp_common.h"
 
+// In-kernel time stamps: nothing in the product build; tools/ubench/tone_stamps.hip defines ESR_TSTAMP before including
+// this file.
+#ifndef ESR_TSTAMP
+#define ESR_TSTAMP(i)
+#endif
+
 namespace {
 
 constexpr int TIN = 33, THID = 192, TOUT = 3, TKP = 17;       // inputs, hidden units, outputs, k-pairs of the input rows 0..33 (row 33: zero weight; the forward pads to 40 only because its weight stream comes in quads)
@@ -94,6 +100,7 @@ __global__ void __launch_bounds__(256, 1) tone_wgrad_t_kernel(ToneWgArgs A)
     };
     if (A.t0 + pair < A.t1) fetch(A.t0 + pair);
     for (int t = A.t0 + pair; t < A.t1; t += npairs) {
+        ESR_TSTAMP(0);
         float xa[TKP], za[2];
 #pragma unroll
         for (int j = 0; j < TKP; ++j) xa[j] = xn[j];
@@ -104,6 +111,7 @@ __global__ void __launch_bounds__(256, 1) tone_wgrad_t_kernel(ToneWgArgs A)
         for (int j = 0; j < TKP; ++j) lx[(2 * j + h) * XS + ul] = xa[j];
         lz[h * XS + ul] = za[0];
         if (h == 0) lz[2 * XS + ul] = za[1];
+        ESR_TSTAMP(1);
         // ---- Ht^T[s][u]: accumulator register r of lane (u, h) holds sample s = acc_row(r, h)
         f32x16 ht[3];
 #pragma unroll
@@ -119,6 +127,7 @@ __global__ void __launch_bounds__(256, 1) tone_wgrad_t_kernel(ToneWgArgs A)
             for (int i3 = 0; i3 < 3; ++i3) ht[i3] = mfma32(xa[j], wb[i3], ht[i3]);
             if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
+        ESR_TSTAMP(2);
         relu_tiles<3>(ht);
         // ---- dW1[c][u] += sum_s dzt[c][s] Ht[u][s]: per-lane sums over this lane's 16 samples; the per-sample scalars
         // of this half-wave come from LDS four samples at a time (register r = 4q + i holds sample 8q + 4h + i)
@@ -138,6 +147,7 @@ __global__ void __launch_bounds__(256, 1) tone_wgrad_t_kernel(ToneWgArgs A)
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
+        ESR_TSTAMP(3);
         float x32[16];                                  // Xt row 32 (the 33rd input) at this half-wave's 16 samples
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -164,6 +174,7 @@ __global__ void __launch_bounds__(256, 1) tone_wgrad_t_kernel(ToneWgArgs A)
             dW0c[i3] += sc;                                            // input column 32 (the 33rd row of Xt)
         }
         __builtin_amdgcn_sched_barrier(0);
+        ESR_TSTAMP(4);
         // ---- dW0[u][x] += sum_s dZt^T[s][u] Xt[x][s], x = 0..31: A = the dZt^T registers, B = Xt row-per-lane from LDS
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -177,6 +188,7 @@ __global__ void __launch_bounds__(256, 1) tone_wgrad_t_kernel(ToneWgArgs A)
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        ESR_TSTAMP(5);
     }
 
     // ---- flush this wave's partial sums into its pair's slab: dW0 [192][33] | dW1 [3][192] | db0 [192] | db1 [3]
