@@ -458,10 +458,23 @@ __global__ void __launch_bounds__(1024) plan_kernel(const int32_t *__restrict__ 
     const int tid = threadIdx.x;
     {   // survivor statistics m0, m1, m2 = sums of the per-ray counts (element j of stats is of class j % 3)
         int s[3] = {0, 0, 0};
-        // (unrolled: one workgroup has nobody to hide a load behind -- 75 dependent round trips for the 25.6 k secondary
-        // rays were most of this kernel's 58 us, which sit right in front of the host's read of the plan)
-#pragma unroll 8
-        for (int j = tid; j < 3 * n_rays; j += 1024) {
+        // 16-byte loads, unrolled: one workgroup has nobody to hide a load behind -- 75 dependent dword round trips for the
+        // 25.6 k secondary rays were most of this kernel's 58 us, which sit right in front of the host's read of the plan
+        const int n3 = 3 * n_rays;
+        const int n4 = (reinterpret_cast<uintptr_t>(stats) & 15) ? 0 : n3 >> 2;   // (an unaligned array: the dword loop below)
+        const int4 *st4 = reinterpret_cast<const int4 *>(stats);
+#pragma unroll 4
+        for (int q = tid; q < n4; q += 1024) {
+            const int4 v = st4[q];
+            const int c0 = (4 * q) % 3;                                        // class of v.x; the others follow cyclically
+            const int vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = (c0 + e) % 3;
+                s[0] += c == 0 ? vv[e] : 0; s[1] += c == 1 ? vv[e] : 0; s[2] += c == 2 ? vv[e] : 0;
+            }
+        }
+        for (int j = 4 * n4 + tid; j < n3; j += 1024) {                       // tail (< 4 elements)
             const int v = stats[j], c = j % 3;
             s[0] += c == 0 ? v : 0; s[1] += c == 1 ? v : 0; s[2] += c == 2 ? v : 0;
         }
