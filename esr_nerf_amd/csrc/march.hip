@@ -498,8 +498,11 @@ __global__ void __launch_bounds__(1024) plan_kernel(const int32_t *__restrict__ 
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
             const bool live = i0 + k < n_rays;
-            cnt[k] = live ? cnt3[i0 + k] : 0;
-            on[k] = live && em_modes[i0 + k] == 1;
+            const int ic = live ? i0 + k : n_rays - 1;   // unconditional loads of a clamped index (esr_ld_or0's reasoning:
+            const int cv = cnt3[ic];                      // `live ? a[i] : 0` is one exec-masked load + wait per element)
+            const int64_t mv = em_modes[ic];
+            cnt[k] = live ? cv : 0;
+            on[k] = live && mv == 1;
             v.x += on[k] ? cnt[k] : 0;
             v.y += on[k] ? 0 : cnt[k];
         }
