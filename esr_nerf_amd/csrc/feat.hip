@@ -38,6 +38,7 @@ struct FeatParams {
     const float *color_on[3], *color_off[3];         // grid per colour group on on-tiles / off-tiles
     int tiles_on, tiles_all;
     float *X, *gnorm;
+    void *X16;                                        // bf16 row-quad tile of the bf16 engine (feat_fwd_kernel<., true>)
     // backward
     int n_src;
     const float *dX[MAX_SRC];
@@ -274,6 +275,167 @@ __global__ void __launch_bounds__(256) feat_fwd_kernel(FeatParams P)
             X(ROW_VD + c, v);
             X(ROW_VSIN + c, sn);
             X(ROW_VCOS + c, cs);
+        }
+    }
+}
+
+// feat_fwd16_kernel: the bf16 engine's input tile.  Instead of the fp32 tile the kernel writes the rows as bf16 in the ROW-QUAD layout of
+// the saved hidden tiles (mlp_common.h: store_tiles_bf16 -- [row / 4][32 sample slots][4 rows], 8 bytes per (quad, sample)):
+// the forward's first-layer operand is then two 8-byte loads per 16 input rows instead of 16 dword loads + conversions, and
+// the first-layer weight gradient stages the tile exactly like a hidden layer's.  24 quads = rows 0..95 (85..87, 94, 95
+// zero) + quads 24, 25 = the first eight rows with the SECOND colour group in rows 0..5 (the non-emissive net's detached
+// pass over emissive-on tiles reads its colours from rows 88..93).  The values are the fp32 rows rounded to bf16 -- what
+// the bf16 kernels made of them on load -- so nothing downstream changes.  Of the fp32 tile only the normal rows 31..42
+// are still written (the feature backward reads them).  Rows are produced in ascending order so that a quad can leave as
+// soon as its four rows exist (the fp32 kernel keeps its own order: this one holds ~10 more registers, which costs that
+// kernel its fourth wave per SIMD: 0.095 -> 0.122 ms at C2).
+constexpr int X16_QUADS = 26;
+__global__ void __launch_bounds__(256) feat_fwd16_kernel(FeatParams P)
+{
+    constexpr bool BAR = true, X16M = true;          // (the stencil bars' reach is checked by the host entry)
+    const esr_scene_t &sc = P.sc;
+    const int gdims[3] = {sc.gx, sc.gy, sc.gz};
+    const int total = P.tiles_all * 32;
+    __shared__ __attribute__((aligned(16))) float bar_lds[256 * BAR_STRIDE];
+    float *bar = bar_lds + threadIdx.x * BAR_STRIDE;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+        const int t = j >> 5, s = j & 31;
+        // tile rows through buffer descriptors (see esr_common.h); X(row, v) writes X[t][row][s].
+        // A wave covers the two tiles t2, t2 + 1 (one per half): one wave-uniform descriptor over both.
+        const int t2 = __builtin_amdgcn_readfirstlane(t);
+        const rsrc_t RX = make_rsrc(P.X + (size_t)t2 * XROWS * 32, 2 * XROWS * 32 * 4);
+        const rsrc_t RG = make_rsrc(P.gnorm + (size_t)t2 * 4 * 32, 2 * 4 * 32 * 4);
+        const int xoff = ((t - t2) * XROWS * 32 + s) * 4, goff = ((t - t2) * 4 * 32 + s) * 4;
+        auto X = [&](int row, float v) { bstore1(RX, v, xoff, row * 128); };        // (not nt: the MLP kernels read X next)
+        auto G = [&](int row, float v) { bstore1(RG, v, goff, row * 128); };
+        // bf16 tile: this sample's 8 bytes of quad q
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        uint2 *const x16 = X16M ? reinterpret_cast<uint2 *>(P.X16) + ((size_t)t * X16_QUADS * 32 +
+                                                                     (8 * ((s >> 1) & 3) + 2 * (s >> 3) + (s & 1)))
+                                : nullptr;
+        auto quad = [&](int q, float a, float b, float c, float d) {
+            bf16x2_t lo, hi;
+            lo[0] = (__bf16)a; lo[1] = (__bf16)b; hi[0] = (__bf16)c; hi[1] = (__bf16)d;
+            x16[q * 32] = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+        };
+        float pend[4] = {0.f, 0.f, 0.f, 0.f};
+        auto put = [&](int row, float v) {               // rows arrive in ascending order (row: compile-time constant)
+            if constexpr (X16M) {
+                pend[row & 3] = v;
+                if ((row & 3) == 3) quad(row >> 2, pend[0], pend[1], pend[2], pend[3]);
+                if (row >= ROW_NRM && row < ROW_NRM + 12) X(row, v);
+            } else {
+                X(row, v);
+            }
+        };
+        float p[3], ind[3], unit[3], vdir[3], sdfv;
+        if (!sample_inputs(P, j, p, vdir, sdfv)) {       // padding lane: inert zeros
+            if constexpr (X16M) {
+                for (int q = 0; q < X16_QUADS; ++q) quad(q, 0.f, 0.f, 0.f, 0.f);
+                for (int r = ROW_NRM; r < ROW_NRM + 12; ++r) X(r, 0.f);
+            } else {
+                for (int r = 0; r < XROWS; ++r) X(r, 0.f);
+            }
+            for (int k = 0; k < 4; ++k) G(k, 0.f);
+            continue;
+        }
+        const bool on_tile = t < P.tiles_on;
+        esr_world_to_index(p, sc.xyz_min, sc.xyz_max, gdims, ind);
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) unit[a] = __fdiv_rn(p[a] - sc.xyz_min[a], sc.xyz_max[a] - sc.xyz_min[a]);
+        }
+        // colour groups (rows 0-5, 88-93, 96-101): each fed by the grid configured for this tile type
+        float col[3][6];
+#pragma unroll
+        for (int gi = 0; gi < 3; ++gi) {
+            const float *grid = on_tile ? P.color_on[gi] : P.color_off[gi];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) col[gi][c] = 0.f;
+            if (grid && !(X16M && gi == 2)) tri_fetch6(grid, gdims, ind, col[gi]);
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) put(COLOR_ROW[0] + c, col[0][c]);
+        put(ROW_SDF, sdfv);
+        // 24-tap SDF stencil: reference axis order is (z, y, x) = grid axes (2, 1, 0)
+        float grad[3][4], feat7 = 0.f;
+#pragma unroll
+        for (int ar = 0; ar < 3; ++ar) {
+            const int axis = 2 - ar;
+            float ixm[4][3], ixp[4][3], cm[4], cp[4], fm[4], fp[4];
+            int b0 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                cm[k] = tap_index(ind, gdims, axis, -sc.grad_feat[k], ixm[k]);
+                cp[k] = tap_index(ind, gdims, axis, sc.grad_feat[k], ixp[k]);
+            }
+            if constexpr (BAR) {
+                float low = ixm[0][axis];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) low = fminf(low, ixm[k][axis]);
+                b0 = (int)floorf(low);
+                const Tri t0 = esr_tri_setup(ixm[0]);            // perpendicular base cells: the same for every tap
+                bar_fill(P.sdf, gdims, t0.i0, axis, b0, bar);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                fm[k] = BAR ? bar_fetch1(axis, b0, bar, ixm[k]) : esr_tri_fetch1(P.sdf, gdims, ixm[k]);
+                fp[k] = BAR ? bar_fetch1(axis, b0, bar, ixp[k]) : esr_tri_fetch1(P.sdf, gdims, ixp[k]);
+                // + 1e-12: the LTS renderer's guard (esrnerf.py:1560) for taps that clamp onto each other
+                // (points pushed outside the box); a no-op in fp32 for in-box samples, where cp - cm >= 0.5
+                grad[ar][k] = (fp[k] - fm[k]) / ((cp[k] - cm[k]) + 1e-12f) / sc.voxel_size;
+            }
+            if (ar == 0) feat7 = fm[0];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) put(ROW_FEAT + (2 * ar) * 4 + k, fm[k]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) put(ROW_FEAT + (2 * ar + 1) * 4 + k, fp[k]);
+        }
+        float den[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float nrm = sqrtf(grad[0][k] * grad[0][k] + grad[1][k] * grad[1][k] + grad[2][k] * grad[2][k]);
+            den[k] = fmaxf(nrm, 1e-12f);
+            G(k, nrm);
+        }
+#pragma unroll
+        for (int ar = 0; ar < 3; ++ar)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) put(ROW_NRM + ar * 4 + k, grad[ar][k] / den[k]);
+        // positional encodings (coordinate-major, frequencies 1,2,4,8,16)
+        float cs[15], vs[3], vc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) put(ROW_XYZ + c, unit[c]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {                    // the sine rows leave as they are formed, the cosines wait their turn
+                float sn;
+                esr_sincos(unit[c] * (float)(1 << i), sn, cs[c * 5 + i]);
+                put(ROW_SIN + c * 5 + i, sn);
+            }
+#pragma unroll
+        for (int q = 0; q < 15; ++q) put(ROW_COS + q, cs[q]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) esr_sincos(vdir[c], vs[c], vc[c]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) put(ROW_VD + c, vdir[c]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) put(ROW_VSIN + c, vs[c]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) put(ROW_VCOS + c, vc[c]);
+        put(85, 0.f); put(86, 0.f); put(87, 0.f);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) put(COLOR_ROW[1] + c, col[1][c]);
+        put(94, 0.f); put(95, 0.f);
+        if constexpr (X16M) {
+            quad(24, col[1][0], col[1][1], col[1][2], col[1][3]);
+            quad(25, col[1][4], col[1][5], sdfv, feat7);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) X(COLOR_ROW[2] + c, col[2][c]);
+            X(102, 0.f); X(103, 0.f);
         }
     }
 }
@@ -822,6 +984,26 @@ ESR_API int esr_fine_feat_fwd(const esr_scene_t *scene, const esr_feat_args_t *a
     const int grid = esr_grid_for((int64_t)P.tiles_all * 32, 256, 256 * 16);
     if (bar) feat_fwd_kernel<true><<<grid, 256, 0, esr_stream(stream)>>>(P);
     else feat_fwd_kernel<false><<<grid, 256, 0, esr_stream(stream)>>>(P);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int64_t esr_fine_feat_x16_bytes(int32_t n_tiles) { return n_tiles < 0 ? (int64_t)ESR_EINVAL : (int64_t)n_tiles * X16_QUADS * 256; }
+
+// The bf16 engine's form: the input tile as bf16 in the row-quad layout (comment above feat_fwd_kernel); X receives the
+// normal rows 31..42 only.  Stencil radii beyond the bars' reach: ESR_ECAP (use esr_fine_feat_fwd).
+ESR_API int esr_fine_feat_fwd_x16(const esr_scene_t *scene, const esr_feat_args_t *args, float *X, float *gnorm, void *X16,
+                                  void *stream)
+{
+    FeatParams P = {};
+    const int c = feat_common(scene, args, P);
+    if (c <= 0) return c;
+    if (!X || !gnorm || !X16) return ESR_EINVAL;
+    for (int k = 0; k < 4; ++k)
+        if (!(scene->grad_feat[k] >= 0.f && scene->grad_feat[k] <= BAR_MAX_DISP)) return ESR_ECAP;
+    P.X = X; P.gnorm = gnorm; P.X16 = X16;
+    const int grid = esr_grid_for((int64_t)P.tiles_all * 32, 256, 256 * 16);
+    feat_fwd16_kernel<<<grid, 256, 0, esr_stream(stream)>>>(P);
     ESR_CHECK_LAUNCH();
     return 0;
 }

@@ -943,7 +943,7 @@ int launch_wgrad_uni(WgradBatch &B, SlabPool &P)
 // kernel shapes (waves per workgroup wm x wn x wk, always 4 compute waves = 1 per SIMD):
 //   192-wide nets: 192x192 -> 2x2x1, 192x<=96 (first layer) -> 2x1x2, 192x<=64 (tone mapper's first) , zrows x 192 (output) -> 1x2x2
 //   128-wide nets: 128x128 -> 2x2x1, 128x96 -> 2x1x2, 8x128 -> 1x2x2
-enum { CFG_HID192, CFG_FIRST192, CFG_FIRST192_64, CFG_OUT192, CFG_HID128, CFG_FIRST128, CFG_OUT128, N_CFG };
+enum { CFG_HID192, CFG_FIRST192, CFG_FIRST192_64, CFG_OUT192, CFG_HID128, CFG_FIRST128, CFG_OUT128, CFG_FIRST192_X16, N_CFG };
 
 int layer_cfg(const NetDesc &D, bool first, bool last, int RB)
 {
@@ -968,6 +968,9 @@ int launch_cfg(int cfg, WgradBatch &B, SlabPool &P)
     case CFG_OUT192:      return launch_wgrad_any<1, 3, 1, 2, 2, BF ? 1 : 0>(B, P);
     case CFG_HID128:      return launch_wgrad_any<2, 2, 2, 2, 1, BF ? 2 : 0>(B, P);
     case CFG_FIRST128:    return launch_wgrad_any<2, 3, 2, 1, 2, BF ? 3 : 0>(B, P);
+    case CFG_FIRST192_X16:  // first layer of a radiance net whose input tile is bf16 in the row-quad layout: staged like a hidden layer's
+        if constexpr (BF) return launch_wgrad_any<3, 3, 2, 1, 2, 2>(B, P);
+        else return ESR_EINVAL;
     default:              return launch_wgrad_any<1, 2, 1, 2, 2, BF ? 1 : 0>(B, P);
     }
 }
@@ -1156,7 +1159,7 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
         if (!kind_ok(J.kind) || J.t0 < 0 || J.t1 < J.t0) return ESR_EINVAL;
         if (!color_row_ok(J.kind, J.color_row0)) return ESR_EINVAL;
         if (J.t1 == J.t0) continue;
-        if (!J.X || !J.H || !J.dZ || !J.dz || !J.gw || !J.gb) return ESR_EINVAL;
+        if ((!J.X && !J.X16) || !J.H || !J.dZ || !J.dz || !J.gw || !J.gb) return ESR_EINVAL;
         const NetDesc D = net_desc(J.kind);
         const int hid = 32 * D.hid_tiles;
         for (int l = 0; l < D.n_layers; ++l) {
@@ -1171,7 +1174,13 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
             W.gw = J.gw[l]; W.ld = first ? D.in_dim : hid; W.out_rows = last ? D.out_dim : hid;
             W.kind = J.kind; W.first = first ? 1 : 0; W.gb = J.gb[l];
             if (!W.A || !W.B || !W.gw || !W.gb) return ESR_EINVAL;
-            const int c = layer_cfg(D, first, last, W.RB);
+            int c = layer_cfg(D, first, last, W.RB);
+            if (BF && first && J.X16 && J.kind == ESR_MLP_RADIANCE) {
+                if (J.color_row0 != 0) return ESR_EINVAL;          // (the bf16 tile's alternate colour rows are the forward's only)
+                W.B = static_cast<const float *>(J.X16);
+                W.RB = 96; W.b_tile_rows = 104;                    // 24 row quads of operand rows, 26 quads (6656 B) per tile
+                c = CFG_FIRST192_X16;
+            }
             if (!BF && uni_on() && (c == CFG_HID192 || c == CFG_FIRST192 || c == CFG_OUT192)) {
                 W.cfg = c == CFG_HID192 ? UNI_HID192 : c == CFG_FIRST192 ? UNI_FIRST192 : UNI_OUT192;
                 if (n_uni == 0 || uni[n_uni - 1].n == MAX_JOBS) {

@@ -121,6 +121,9 @@ struct Fwd16Args {
     unsigned *M[3];
     int save, crow;
     float *zout;
+    // radiance nets: the input tile as bf16 in the row-quad layout (feat.hip: feat_fwd16_kernel; 26 quads x 256 B per tile,
+    // quads 24 / 25 = the first eight rows with the colour group of rows 88..93) -- then X is not read
+    const void *X16;
 };
 // Several passes of the same net KIND in ONE launch (esr_mlp_fwd_fine_bf16: the fine stage's three radiance forward passes,
 // esr_mlp_dgrad_fine_bf16: its two input-gradient passes): a workgroup works on exactly one segment (its weights stay in
@@ -337,13 +340,33 @@ __global__ void __launch_bounds__(64 * SHW, 1) mlp_fwd16s_kernel(Fwd16Batch AB)
             }
     };
     if (PREFETCH && (int)blockIdx.x - blk0 < ngroups) fetch((int)blockIdx.x - blk0);
+    // radiance instance with the bf16 input tile: the first layer's operand IS the tile's bytes -- two 8-byte loads per 16
+    // input rows (quads 4 j + 2 h and + 1 of this lane's sample slot) instead of 16 dword loads and 16 conversions, and
+    // the next tile group's go out as soon as the first layer has consumed the registers (nothing extra is held)
+    const bool x16 = KIND == ESR_MLP_RADIANCE && A.X16 != nullptr;
+    bf16x8 B1[KS1];
+    auto fetch16 = [&](int tg) {
+        const int tt = A.t0 + tg * SHW + wv;
+        const int t = tt < A.t1 ? tt : A.t1 - 1;
+        const uint2 *q0 = reinterpret_cast<const uint2 *>(A.X16) + ((size_t)t * 26 * 32 + (8 * ((s >> 1) & 3) + 2 * (s >> 3) + (s & 1)));
+#pragma unroll
+        for (int j = 0; j < KS1; ++j) {
+            int q = 4 * j + 2 * h;
+            if (j == 0 && h == 0 && A.crow == 88) q = 24;          // colour rows 0..5 <- the group of rows 88..93
+            const uint2 a = q0[q * 32], b = q0[(q + 1) * 32];
+            u32x4 v = {a.x, a.y, b.x, b.y};
+            B1[j] = __builtin_bit_cast(bf16x8, v);
+        }
+    };
+    if (x16 && (int)blockIdx.x - blk0 < ngroups) fetch16((int)blockIdx.x - blk0);
     for (int tg = (int)blockIdx.x - blk0; tg < ngroups; tg += nblk) {
         const int tt = A.t0 + tg * SHW + wv;
         const bool live = tt < A.t1;                       // a wave past the range runs on the last tile, stores nothing
         const int t = live ? tt : A.t1 - 1;
         ESR_STAMP16(0);
-        bf16x8 B1[KS1];
-        if constexpr (PREFETCH) {
+        if (x16) {
+            // (B1 was requested behind the previous group's first layer, or before the loop)
+        } else if constexpr (PREFETCH) {
 #pragma unroll
             for (int j = 0; j < KS1; ++j)
 #pragma unroll
@@ -365,6 +388,7 @@ __global__ void __launch_bounds__(64 * SHW, 1) mlp_fwd16s_kernel(Fwd16Batch AB)
         zero_tiles<HT>(cur);
         lds_layer16<KS1, HT, (NL == 2 ? 0 : S::chunks(1))>(wl + (NL == 2 ? 0 : cur_buf * S::BUF), [&](int j) { return B1[j]; }, cur,
                                                          lane, tid, W16, (int)S::off(1), wl + (cur_buf ^ 1) * S::BUF);
+        if (x16) fetch16(tg + nblk < ngroups ? tg + nblk : tg);    // (past the end: this group again, never used)
         ESR_STAMP16(1);
         lds_bias_add<HT>(bias_l, cur, lane);
         relu_tiles<HT>(cur);
@@ -662,15 +686,18 @@ ESR_API int esr_mlp_fwd_bf16(int kind, const float *packed32, const void *packed
 
 // The fine stage's three radiance forward passes of a step (bf16 engine) as ONE launch: see esr_mlp_fwd_fine.
 ESR_API int esr_mlp_fwd_fine_bf16(const float *packed32_off, const void *packed16_off, const float *packed32_emo,
-                                  const void *packed16_emo, const float *X, int32_t t_on, int32_t t_all, float *const *H,
-                                  uint32_t *const *M, int color_row_detached, float *z_off, float *z_emo, void *stream)
+                                  const void *packed16_emo, const float *X, const void *X16, int32_t t_on, int32_t t_all,
+                                  float *const *H, uint32_t *const *M, int color_row_detached, float *z_off, float *z_emo,
+                                  void *stream)
 {
     if (t_on < 0 || t_all < t_on || !crow_ok(ESR_MLP_RADIANCE, color_row_detached)) return ESR_EINVAL;
     if (t_all == 0) return 0;
-    if (!packed32_off || !packed16_off || !packed32_emo || !packed16_emo || !X || !H || !M || !z_off || !z_emo) return ESR_EINVAL;
+    if (!packed32_off || !packed16_off || !packed32_emo || !packed16_emo || (!X && !X16) || !H || !M || !z_off || !z_emo)
+        return ESR_EINVAL;
+    if (X16 && color_row_detached != 0 && color_row_detached != 88) return ESR_EINVAL;     // (the bf16 tile carries rows 88..93 only)
     using S = Shared16<ESR_MLP_RADIANCE, false>;
     Fwd16Batch B = {};
-    B.base.X = X;
+    B.base.X = X; B.base.X16 = X16;
     for (int l = 0; l < 3; ++l) {
         if (!H[l] || !M[l]) return ESR_EINVAL;
         B.base.H[l] = H[l]; B.base.M[l] = M[l];

@@ -66,6 +66,7 @@ class FineCtx:
     sdf: torch.Tensor
     feat_args: object = None
     march_cache: object = None        # (ray_stats, alphainv_last, cache) of the count pass, for the backward
+    x16: bool = False                 # the features of this step are the bf16 tile (ws["X16"]), not the fp32 one
 
 
 class _Workspace:
@@ -90,6 +91,7 @@ class _Workspace:
             self.buf[k] = torch.empty(cap * 3 * 64, dtype=torch.int32, device=self.device)
         self.buf["rec_ray"] = torch.empty(cap * 32, dtype=torch.int32, device=self.device)
         self.buf["rec_step"] = torch.empty(cap * 32, dtype=torch.int32, device=self.device)
+        self.buf["X16"] = torch.empty(cap * 26 * 256, dtype=torch.uint8, device=self.device)      # bf16 input tile (esr_fine_feat_fwd_x16)
         self.cap_tiles = cap
 
     def __getitem__(self, k):
@@ -134,6 +136,9 @@ class FineEngine:
         # operands), so its forward keeps only the ReLU masks and its input-gradient pass stores no dZt;
         # ESR_TONE_RECOMPUTE16=0: the bf16 engine's saved-tile path of round 2 (A/B timing)
         self.tone_recompute = (not self.bf16) or os.environ.get("ESR_TONE_RECOMPUTE16", "1") != "0"
+        # bf16 engine, merged radiance launches: the features are written as a bf16 tile in the operand layout of the
+        # first layer (esr_fine_feat_fwd_x16); ESR_X16=0: the fp32 tile, converted on load (A/B timing)
+        self.x16 = self.bf16 and os.environ.get("ESR_X16", "1") != "0"
         self.tone_scratch = torch.empty(self.L.esr_tone_wgrad_scratch_floats() if self.tone_recompute else 1,
                                         dtype=torch.float32, device=self.device)
         self.neus_grad = False          # cfg neus_alpha: "grad" (set by the renderer)
@@ -341,7 +346,13 @@ class FineEngine:
                         _lib.ptr(ws["rec_w"]), _lib.ptr(ws["rec_sdf"]), s)
         fa = self.feat_args(rays_o, rays_d, viewdirs, sdf, tiles_on, tiles_all,
                             color_on=(emo_color, off_color, None), color_off=(off_color, None, None))
-        self._run("feat_fwd", L.esr_fine_feat_fwd, sp, C.byref(fa), _lib.ptr(ws["X"]), _lib.ptr(ws["gnorm"]), s)
+        x16 = self.x16 and self.merge_rad and all(0.0 <= float(r) <= 2.0 for r in scene.grad_feat)
+        ctx.x16 = x16
+        if x16:
+            self._run("feat_fwd", L.esr_fine_feat_fwd_x16, sp, C.byref(fa), _lib.ptr(ws["X"]), _lib.ptr(ws["gnorm"]),
+                      _lib.ptr(ws["X16"]), s)
+        else:
+            self._run("feat_fwd", L.esr_fine_feat_fwd, sp, C.byref(fa), _lib.ptr(ws["X"]), _lib.ptr(ws["gnorm"]), s)
         ctx.feat_args = fa
         H, M = self._H(["H0", "H1", "H2"]), self._H(["M0", "M1", "M2"])
         if e_pre is not None:
@@ -356,7 +367,8 @@ class FineEngine:
         elif self.merge_rad:        # bf16 engine: the same three passes as one launch (a workgroup = one pass's weights in LDS)
             po, pe = _lib.ptr(self.packed["off"]), _lib.ptr(self.packed["emo"])
             self._run("mlp_fwd(rad)", L.esr_mlp_fwd_fine_bf16, po, self._p16[po.value], pe, self._p16[pe.value], _lib.ptr(ws["X"]),
-                      tiles_on, tiles_all, H, M, 88, _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), s)
+                      _lib.ptr(ws["X16"]) if x16 else None, tiles_on, tiles_all, H, M, 88, _lib.ptr(ws["z_off"]),
+                      _lib.ptr(ws["z_emo"]), s)
         else:
             self._run("mlp_fwd(off|on-tiles)", self.mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), 0, tiles_on,
                                      H, M, 0, 88, _lib.ptr(ws["z_off"]), s)
@@ -538,6 +550,8 @@ class FineEngine:
                 jb.X, jb.dz = X.data_ptr(), dzs.data_ptr()
                 jb.H, jb.dZ = C.addressof(Hs), C.addressof(dZs)
                 jb.gw, jb.gb = C.addressof(gwa), C.addressof(gba)
+                if getattr(ctx, "x16", False) and kind == KIND_RADIANCE:
+                    jb.X16 = ws["X16"].data_ptr()
             self._run("mlp_wgrad(all)", L.esr_mlp_wgrad_batch, jobs, len(todo), 1 if self.bf16 else 0,
                       _lib.ptr(self.wgrad_scratch), C.c_int64(self.wgrad_scratch.numel()), s_)
 

@@ -253,6 +253,17 @@ typedef struct esr_feat_args {
 
 int esr_fine_feat_fwd(const esr_scene_t *scene, const esr_feat_args_t *args, float *X, float *gnorm,
                       void *stream);
+/*
+ * The bf16 engine's form: the input tile goes to X16 as bf16 in the row-quad layout of that engine's saved tiles
+ * (esr_fine_feat_x16_bytes(n_tiles) bytes: 26 quads of 256 B per tile = rows 0..95 + the first eight rows once more with
+ * the colour group of rows 88..93 in rows 0..5) -- the fp32 rows rounded to bf16, i.e. what the bf16 kernels made of
+ * them on load.  X still receives the normal rows 31..42 (the backward reads them), nothing else.  Consumers:
+ * esr_mlp_fwd_fine_bf16 (X16 argument; then X may be NULL) and esr_wgrad_job_t::X16.  Stencil radii outside [0, 2] voxels:
+ * ESR_ECAP (use esr_fine_feat_fwd).
+ */
+int64_t esr_fine_feat_x16_bytes(int32_t n_tiles);
+int esr_fine_feat_fwd_x16(const esr_scene_t *scene, const esr_feat_args_t *args, float *X, float *gnorm, void *X16,
+                          void *stream);
 
 /*
  * Backward.  Every net that consumed the tiles contributes a dX [n_tiles,64,32] (rows 0-42 used)
@@ -337,8 +348,9 @@ int esr_mlp_dgrad_fine(const float *packed_emo, const float *packed_off, const f
                        const uint32_t *const *M, float *const *dZ, float *dX, void *stream);
 /* The bf16 engine's twins of the two entries above (weights of both nets as packed by esr_mlp_pack / esr_mlp_pack_bf16). */
 int esr_mlp_fwd_fine_bf16(const float *packed32_off, const void *packed16_off, const float *packed32_emo,
-                          const void *packed16_emo, const float *X, int32_t t_on, int32_t t_all, float *const *H,
-                          uint32_t *const *M, int color_row_detached, float *z_off, float *z_emo, void *stream);
+                          const void *packed16_emo, const float *X, const void *X16, int32_t t_on, int32_t t_all,
+                          float *const *H, uint32_t *const *M, int color_row_detached, float *z_off, float *z_emo,
+                          void *stream);
 int esr_mlp_dgrad_fine_bf16(const void *packed16_emo, const void *packed16_off, const float *dz, int32_t t_on, int32_t t_all,
                             const uint32_t *const *M, float *const *dZ, float *dX, void *stream);
 
@@ -382,6 +394,9 @@ typedef struct esr_wgrad_job {
     const float *dz;
     float *const *gw;
     float *const *gb;
+    /* optional (bf16 operands, ESR_MLP_RADIANCE, color_row0 == 0): the net's input tile as written by
+     * esr_fine_feat_fwd_x16 -- the first-layer job then stages it like a hidden layer's tile and X is not read. */
+    const void *X16;
 } esr_wgrad_job_t;
 int esr_mlp_wgrad_batch(const esr_wgrad_job_t *jobs, int32_t n_jobs, int bf16_operands, float *scratch,
                         int64_t scratch_floats, void *stream);

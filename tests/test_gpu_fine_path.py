@@ -278,7 +278,7 @@ def test_merged_radiance_launches_bf16_equal_the_separate_ones(t_on, t_all):
     _lib.check(L.esr_mlp_fwd_bf16(0, pe, p16e, _lib.ptr(X), 0, t_on, pa(A["H"]), pa(A["M"]), 1, 0, _lib.ptr(A["z_emo"]), s), "emo")
     _lib.check(L.esr_mlp_dgrad_bf16(0, p16e, _lib.ptr(dz), 0, t_on, pa(A["M"]), pa(A["dZ"]), _lib.ptr(A["dX"]), s), "dg emo")
     _lib.check(L.esr_mlp_dgrad_bf16(0, p16o, _lib.ptr(dz), t_on, t_all, pa(A["M"]), pa(A["dZ"]), _lib.ptr(A["dX"]), s), "dg off")
-    _lib.check(L.esr_mlp_fwd_fine_bf16(po, p16o, pe, p16e, _lib.ptr(X), t_on, t_all, pa(B["H"]), pa(B["M"]), 88,
+    _lib.check(L.esr_mlp_fwd_fine_bf16(po, p16o, pe, p16e, _lib.ptr(X), None, t_on, t_all, pa(B["H"]), pa(B["M"]), 88,
                                        _lib.ptr(B["z_off"]), _lib.ptr(B["z_emo"]), s), "fwd_fine16")
     _lib.check(L.esr_mlp_dgrad_fine_bf16(p16e, p16o, _lib.ptr(dz), t_on, t_all, pa(B["M"]), pa(B["dZ"]), _lib.ptr(B["dX"]), s), "dgrad_fine16")
     torch.cuda.synchronize()
