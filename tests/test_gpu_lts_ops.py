@@ -380,6 +380,67 @@ def test_feat_bwd_many_short_ray_pieces_per_tile():
     assert rel_err(g_col.permute(3, 0, 1, 2), col.grad[0]) < 2e-5
 
 
+def test_feat_fwd_x16_tile_is_the_fp32_tile_rounded_to_bf16():
+    """esr_fine_feat_fwd_x16: every row of the bf16 row-quad tile equals the fp32 tile's row rounded to bf16 (what the bf16
+    kernels made of it on load), the two alternate quads carry the colour group of rows 88..93 in front of rows 6, 7, padding
+    lanes are zero, and the fp32 tile still receives the normal rows."""
+    from esr_nerf_amd import _lib
+    from esr_nerf_amd.config import lts_cfg
+    from esr_nerf_amd.fine_engine import make_scene
+    from esr_nerf_amd.synthetic import slab_scene
+    from oracle import fine_path as fp
+    L = _lib.lib()
+    sc = slab_scene("tiny", s_val=40.0)
+    c = fp.make_consts(lts_cfg("cpu").app.model, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max,
+                       sc.mask_alpha_init, sc.mask_density, sc.near, sc.num_voxels)
+    ws = [int(v) for v in c.world_size]
+    g = torch.Generator().manual_seed(31)
+    n = 150                                                     # 5 tiles, the last one with 22 padding lanes
+    lo, hi = sc.xyz_min, sc.xyz_max
+    pts = lo + (hi - lo) * torch.rand(n, 3, generator=g)
+    vox = float(c.voxel_size)
+    scene = make_scene(lo.tolist(), hi.tolist(), lo.tolist(), hi.tolist(), ws, [32, 32, 32], sc.near,
+                       float(c.stepsize * c.voxel_size), vox, 0.0, 1e-3, 1e-4, 40.0, [float(v) for v in c.grad_feat])
+    tiles = (n + 31) // 32
+    dev = "cuda"
+    pd = pts.cuda().contiguous()
+    vd = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).cuda().contiguous()
+    sv = torch.randn(n, generator=g).cuda()
+    sdf_d = torch.randn(*ws, generator=g).cuda()
+    col_a = (torch.randn(*ws, 6, generator=g) * 0.3).cuda().contiguous()
+    col_b = (torch.randn(*ws, 6, generator=g) * 0.3).cuda().contiguous()
+    fa = _lib.EsrFeatArgs()
+    fa.pts, fa.pt_viewdirs, fa.pt_sdf, fa.n_pts = pd.data_ptr(), vd.data_ptr(), sv.data_ptr(), n
+    fa.sdf = sdf_d.data_ptr()
+    fa.color_on[0], fa.color_on[1] = col_a.data_ptr(), col_b.data_ptr()
+    fa.color_off[0] = col_b.data_ptr()
+    fa.tiles_on, fa.tiles_all = 2, tiles                         # two emissive-on tiles (both colour groups), three others
+    s = _lib.stream_ptr("cuda:0")
+    X = torch.empty(tiles * 104 * 32, device=dev)
+    gn = torch.empty(tiles * 4 * 32, device=dev)
+    _lib.check(L.esr_fine_feat_fwd(C.byref(scene), C.byref(fa), _lib.ptr(X), _lib.ptr(gn), s), "feat_fwd")
+    assert int(L.esr_fine_feat_x16_bytes(tiles)) == tiles * 26 * 256
+    X16 = torch.full((tiles * 26 * 256,), 0x7f, dtype=torch.uint8, device=dev)
+    Xn = torch.full_like(X, float("nan"))
+    gn2 = torch.empty_like(gn)
+    _lib.check(L.esr_fine_feat_fwd_x16(C.byref(scene), C.byref(fa), _lib.ptr(Xn), _lib.ptr(gn2), _lib.ptr(X16), s), "feat_fwd_x16")
+    Xr = X.view(tiles, 104, 32).cpu()
+    want = Xr.to(torch.bfloat16)                                 # [tile][row][sample]
+    q = X16.cpu().view(torch.bfloat16).view(tiles, 26, 32, 4)    # [tile][quad][slot][row in quad]
+    sidx = torch.arange(32)
+    slot = 8 * ((sidx >> 1) & 3) + 2 * (sidx >> 3) + (sidx & 1)
+    got = q[:, :24][:, :, slot, :].permute(0, 1, 3, 2).reshape(tiles, 96, 32)     # -> [tile][row][sample]
+    assert torch.equal(got.view(torch.int16), want[:, :96].contiguous().view(torch.int16))
+    alt = q[:, 24:26][:, :, slot, :].permute(0, 1, 3, 2).reshape(tiles, 8, 32)
+    want_alt = torch.cat([want[:, 88:94], want[:, 6:8]], 1)
+    assert torch.equal(alt.view(torch.int16), want_alt.contiguous().view(torch.int16))
+    assert bool((want[:2, 88:94].float().abs() > 0).any())       # (the second colour group is fed on the emissive-on tiles)
+    assert torch.equal(gn2, gn)
+    Xn = Xn.view(tiles, 104, 32).cpu()
+    assert torch.equal(Xn[:, 31:43], Xr[:, 31:43])               # the normal rows, fp32 (the backward reads them)
+    assert bool(torch.isnan(Xn[:, :31]).all()) and bool(torch.isnan(Xn[:, 43:]).all())
+
+
 def test_feat_fwd_direct_form_for_wide_stencils():
     """cfg grad_feat radii beyond 2 voxels (voxurff.py:164-167 takes any list): the forward's stencil bars do not reach,
     the direct form runs (feat.hip: feat_fwd_kernel<false>) -- rows against the oracle's stencil; the scatter, whose bars
