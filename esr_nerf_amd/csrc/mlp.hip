@@ -986,7 +986,9 @@ ESR_API int64_t esr_mlp_packed_floats(int kind)
 ESR_API int esr_mlp_pack(int kind, const esr_mlp_weights_t *w, float *packed, void *stream)
 {
     if (!kind_ok(kind) || !w || !packed) return ESR_EINVAL;
-    PackArgs A = {};
+    PackBatch B = {};
+    B.n = 1;
+    PackArgs &A = B.job[0];
     A.kind = kind;
     const int nl = net_desc(kind).n_layers;
     for (int l = 0; l < nl; ++l) {
@@ -995,7 +997,37 @@ ESR_API int esr_mlp_pack(int kind, const esr_mlp_weights_t *w, float *packed, vo
         A.b[l] = w->b[l];
     }
     A.out = packed;
-    pack_kernel<<<esr_grid_for(pack_layout(kind).total, 256, 1024), 256, 0, esr_stream(stream)>>>(A);
+    pack_kernel<<<dim3(esr_grid_for(pack_layout(kind).total, 256, 1024), 1), 256, 0, esr_stream(stream)>>>(B);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+// Every net of a step in ONE launch: packed32[i] (and, where packed16 != NULL and packed16[i] != NULL, its bf16 twin) from
+// the reference-layout tensors of w[i].  n <= 8.
+ESR_API int esr_mlp_pack_batch(int n, const int32_t *kinds, const esr_mlp_weights_t *const *w, float *const *packed32,
+                               void *const *packed16, void *stream)
+{
+    if (n < 0 || n > MAX_PACK_JOBS || (n > 0 && (!kinds || !w || !packed32))) return ESR_EINVAL;
+    if (n == 0) return 0;
+    PackBatch B = {};
+    B.n = n;
+    int64_t most = 0;
+    for (int i = 0; i < n; ++i) {
+        const int kind = kinds[i];
+        if (!kind_ok(kind) || !w[i] || !packed32[i]) return ESR_EINVAL;
+        PackArgs &A = B.job[i];
+        A.kind = kind;
+        for (int l = 0; l < net_desc(kind).n_layers; ++l) {
+            if (!w[i]->w[l] || !w[i]->b[l]) return ESR_EINVAL;
+            A.w[l] = w[i]->w[l];
+            A.b[l] = w[i]->b[l];
+        }
+        A.out = packed32[i];
+        A.out16 = packed16 ? static_cast<__bf16 *>(packed16[i]) : nullptr;
+        const int64_t tot = pack_layout(kind).total + (A.out16 ? pack16_layout(kind).total : 0);
+        most = tot > most ? tot : most;
+    }
+    pack_kernel<<<dim3(esr_grid_for(most, 256, 256), n), 256, 0, esr_stream(stream)>>>(B);
     ESR_CHECK_LAUNCH();
     return 0;
 }

@@ -29,80 +29,6 @@
 
 namespace {
 
-__host__ __device__ constexpr int kfeat16(int j, int h, int i)
-{
-    return 32 * (j >> 1) + 16 * (j & 1) + 4 * h + (i & 3) + 8 * (i >> 2);
-}
-
-// Packed bf16 buffer (elements).  Forward part of layer l: [ks][tiles_out][64 lanes][8]; transposed part
-// (dgrad): [kso][tiles_in][64][8].  Biases are read from the fp32 packed buffer of esr_mlp_pack.
-struct Pack16Layout {
-    int n_layers;
-    int ks[4], tiles_out[4], kso[4], tiles_in[4], in_dim[4], out_dim[4];
-    int64_t off_wf[4], off_wb[4];
-    int64_t total;
-};
-__host__ __device__ constexpr Pack16Layout pack16_layout(int kind)
-{
-    const NetDesc d = net_desc(kind);
-    Pack16Layout L = {};
-    L.n_layers = d.n_layers;
-    int64_t o = 0;
-    for (int l = 0; l < d.n_layers; ++l) {
-        const bool first = l == 0, last = l == d.n_layers - 1;
-        const int hid = 32 * d.hid_tiles;
-        L.ks[l] = first ? (2 * d.in_kp + 15) / 16 : hid / 16;
-        L.in_dim[l] = first ? d.in_dim : hid;
-        L.out_dim[l] = last ? d.out_dim : hid;
-        L.tiles_out[l] = last ? 1 : d.hid_tiles;
-        L.kso[l] = last ? 1 : hid / 16;
-        L.tiles_in[l] = first ? 2 : d.hid_tiles;
-        L.off_wf[l] = o; o += (int64_t)L.ks[l] * L.tiles_out[l] * 512;
-        L.off_wb[l] = o; o += (int64_t)L.kso[l] * L.tiles_in[l] * 512;
-    }
-    L.total = o;
-    return L;
-}
-
-struct Pack16Args {
-    int kind;
-    const float *w[4];
-    __bf16 *out;
-};
-
-__global__ void __launch_bounds__(256) pack16_kernel(Pack16Args A)
-{
-    const Pack16Layout L = pack16_layout(A.kind);
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < L.total; e += (int64_t)gridDim.x * blockDim.x) {
-        int l = 0;
-        while (l + 1 < L.n_layers && e >= L.off_wf[l + 1]) ++l;
-        const bool first = l == 0, last = l == L.n_layers - 1;
-        const float *W = A.w[l];
-        const int ind = L.in_dim[l], outd = L.out_dim[l];
-        float v = 0.f;
-        if (e < L.off_wb[l]) {                               // forward weights, order [k-step][out tile]
-            int64_t i = e - L.off_wf[l];
-            const int slot = i & 7; i >>= 3;
-            const int lane = i & 63; i >>= 6;
-            const int it = (int)(i % L.tiles_out[l]), j = (int)(i / L.tiles_out[l]);
-            const int h = lane >> 5, row = 32 * it + (lane & 31);
-            const int col = first ? in_colmap(A.kind, 16 * j + 8 * h + slot) : kfeat16(j, h, slot);
-            if (row < outd && col >= 0 && col < ind) v = W[(int64_t)row * ind + col];
-        } else {                                             // transposed weights, order [k-step][in tile]
-            int64_t i = e - L.off_wb[l];
-            const int slot = i & 7; i >>= 3;
-            const int lane = i & 63; i >>= 6;
-            const int it = (int)(i % L.tiles_in[l]), j = (int)(i / L.tiles_in[l]);
-            const int h = lane >> 5;
-            const int orow = last ? (8 * h + slot) : kfeat16(j, h, slot);      // output feature of layer l
-            const int irow = 32 * it + (lane & 31);                            // input feature / X row
-            const int col = first ? in_colmap(A.kind, irow) : irow;
-            if (orow < outd && col >= 0 && col < ind) v = W[(int64_t)orow * ind + col];
-        }
-        A.out[e] = (__bf16)v;
-    }
-}
-
 // registers 8 jj .. 8 jj + 7 of an accumulator tile, rounded to bf16: the B operand of k-step 2 * tile + jj
 __device__ __forceinline__ bf16x8 acc_to_b(const f32x16 &t, int jj)
 {
@@ -138,6 +64,7 @@ struct Seg16 {
 };
 struct Fwd16Batch {
     Fwd16Args base;            // X, H, M (and, for nseg == 0, the single pass)
+    int stag;                  // staggered teams (see mlp_fwd16s_kernel); 0: lock step (ESR_STAG16=0, A/B timing)
     int nseg;
     Seg16 seg[MAX_SEG16];
 };
@@ -319,6 +246,20 @@ __global__ void __launch_bounds__(64 * SHW, 1) mlp_fwd16s_kernel(Fwd16Batch AB)
         }
     }
     layer_barrier();
+    // STAGGERED TEAMS (round 4).  The eight waves used to march in lock step: all of them in a layer's products, then all of
+    // them in its epilogue (bias, ReLU, masks, rounding, ~27 stores: ~480 vector instructions per wave) -- per SIMD the
+    // matrix pipe idled through both waves' epilogues and the vector lanes through both waves' products, 12.8 k cycles per
+    // layer step for 4.6 k of matrix work (profiles/r03_w_c3bf16_*: 22 % busy, 3.2 TB/s).  Now the workgroup is two teams
+    // (waves 0-3 / 4-7: one of each per SIMD) that run the SAME program one phase apart: a barrier separates a layer's
+    // products from its epilogue, team B passes one extra barrier up front (team A one at the end), so while one team
+    // streams MFMAs the other team's epilogue has the vector lanes, the LDS port carries one team's weight reads at a
+    // time, and the stores spread over the whole step.  The LDS hand-over still holds: a layer's buffer is read in two
+    // consecutive phases (A, then B), each wave stages its share of the next layer during its own product phase, and the
+    // buffer being overwritten was last read two phases earlier.  Two-layer nets keep both layers resident and have no
+    // barriers at all; they stay as they were.
+    const bool STAG = NL != 2 && AB.stag;
+    const int team = wv >> 2;
+    if (STAG && team == 1) layer_barrier();
     int cur_buf = 0;                                       // LDS buffer holding the layer about to run
     // The smaller nets (everything but the 256-register radiance instance) request the NEXT tile group's input rows while
     // this one runs: the workgroup's eight waves march in step behind the layer barriers, so at the top of a group all of
@@ -384,36 +325,40 @@ __global__ void __launch_bounds__(64 * SHW, 1) mlp_fwd16s_kernel(Fwd16Batch AB)
                 }
         }
         const bool save = A.save && live;
-        f32x16 cur[HT];
-        zero_tiles<HT>(cur);
-        lds_layer16<KS1, HT, (NL == 2 ? 0 : S::chunks(1))>(wl + (NL == 2 ? 0 : cur_buf * S::BUF), [&](int j) { return B1[j]; }, cur,
+        // The layer input lives as PACKED bf16 (hb: 8 registers per 32 rows, 48 for a 192-wide layer): it is what the next
+        // layer's MFMAs consume and what the saved H tile holds, so each accumulator is rounded ONCE, in the epilogue, and
+        // the fp32 tile dies there.  (Rounds 2-3 kept the fp32 tile through the next layer and converted per k-step:
+        // 96 + 96 accumulator registers + 32 LDS-read + 12 staging + 24 input-prefetch registers = 260 -> 12 spilled.)
+        bf16x8 hb[2 * HT];
+        f32x16 acc[HT];
+        auto epilogue = [&](auto LC) __attribute__((always_inline)) {
+            constexpr int l = decltype(LC)::value;
+            lds_bias_add<HT>(bias_l + l * S::BIAS_FLOATS, acc, lane);
+            relu_tiles<HT>(acc);
+            if (save) store_relu_mask<HT>(make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), acc, lane);   // (x > 0) of the fp32 value
+#pragma unroll
+            for (int j = 0; j < 2 * HT; ++j) hb[j] = acc_to_b(acc[j >> 1], j & 1);
+            // save == 2: ReLU masks only (the weight gradients recompute the layer)
+            if (save && A.save == 1) store_tiles_bf16_packed<HT>(make_rsrc(A.H[l] + (size_t)t * (HBYTES / 4), HBYTES), hb, lane);
+        };
+        zero_tiles<HT>(acc);
+        lds_layer16<KS1, HT, (NL == 2 ? 0 : S::chunks(1))>(wl + (NL == 2 ? 0 : cur_buf * S::BUF), [&](int j) { return B1[j]; }, acc,
                                                          lane, tid, W16, (int)S::off(1), wl + (cur_buf ^ 1) * S::BUF);
         if (x16) fetch16(tg + nblk < ngroups ? tg + nblk : tg);    // (past the end: this group again, never used)
         ESR_STAMP16(1);
-        lds_bias_add<HT>(bias_l, cur, lane);
-        relu_tiles<HT>(cur);
-        if (save) {                                        // save == 2: ReLU masks only (the weight gradients recompute the layer)
-            if (A.save == 1) store_tiles_bf16<HT>(make_rsrc(A.H[0] + (size_t)t * (HBYTES / 4), HBYTES), cur, lane);
-            store_relu_mask<HT>(make_rsrc(A.M[0] + (size_t)t * (MBYTES / 4), MBYTES), cur, lane);
-        }
+        if (STAG) layer_barrier();
+        epilogue(std::integral_constant<int, 0>{});
         ESR_STAMP16(2);
         if (NL != 2) { layer_barrier(); cur_buf ^= 1; }
         ESR_STAMP16(3);
         auto hidden = [&](auto LC) {
             constexpr int l = decltype(LC)::value;
-            f32x16 nxt[HT];
-            zero_tiles<HT>(nxt);
-            lds_layer16<2 * HT, HT, S::chunks(l + 1)>(wl + cur_buf * S::BUF, [&](int j) { return acc_to_b(cur[j >> 1], j & 1); },
-                                                     nxt, lane, tid, W16, (int)S::off(l + 1), wl + (cur_buf ^ 1) * S::BUF);
+            zero_tiles<HT>(acc);
+            lds_layer16<2 * HT, HT, S::chunks(l + 1)>(wl + cur_buf * S::BUF, [&](int j) { return hb[j]; },
+                                                     acc, lane, tid, W16, (int)S::off(l + 1), wl + (cur_buf ^ 1) * S::BUF);
             ESR_STAMP16(4 + 3 * (l - 1));
-            lds_bias_add<HT>(bias_l + l * S::BIAS_FLOATS, nxt, lane);
-            relu_tiles<HT>(nxt);
-            if (save) {
-                if (A.save == 1) store_tiles_bf16<HT>(make_rsrc(A.H[l] + (size_t)t * (HBYTES / 4), HBYTES), nxt, lane);
-                store_relu_mask<HT>(make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), nxt, lane);
-            }
-#pragma unroll
-            for (int it = 0; it < HT; ++it) cur[it] = nxt[it];
+            if (STAG) layer_barrier();
+            epilogue(std::integral_constant<int, l>{});
             ESR_STAMP16(5 + 3 * (l - 1));
             layer_barrier();
             cur_buf ^= 1;
@@ -426,9 +371,10 @@ __global__ void __launch_bounds__(64 * SHW, 1) mlp_fwd16s_kernel(Fwd16Batch AB)
         zero_tiles<1>(out);
         // (meanwhile layer 0 of the NEXT tile group is staged: the same weights, only the buffer differs)
         lds_layer16<2 * HT, 1, (NL == 2 ? 0 : S::chunks(0))>(wl + (NL == 2 ? S::BUF : cur_buf * S::BUF),
-                                                           [&](int j) { return acc_to_b(cur[j >> 1], j & 1); }, out, lane, tid,
+                                                           [&](int j) { return hb[j]; }, out, lane, tid,
                                                            W16, (int)S::off(0), wl + (cur_buf ^ 1) * S::BUF);
         ESR_STAMP16(10);
+        if (STAG) layer_barrier();
         lds_bias_add<1>(bias_l + NHID * S::BIAS_FLOATS, out, lane);
         const rsrc_t RZ = make_rsrc(A.zout + (size_t)t * D.zrows * 32, live ? D.zrows * 32 * 4 : 0);
         const int zvoff = (D.zrows == 8) ? (4 * h * 32 + s) * 4 : ((h ? D.zrows : 0) * 32 + s) * 4;
@@ -438,6 +384,7 @@ __global__ void __launch_bounds__(64 * SHW, 1) mlp_fwd16s_kernel(Fwd16Batch AB)
         if (NL != 2) { layer_barrier(); cur_buf ^= 1; }
         ESR_STAMP16(12);
     }
+    if (STAG && team == 0) layer_barrier();                // (every wave passes the same number of barriers)
 }
 
 struct Dgrad16Args {
@@ -575,6 +522,13 @@ int launch_dgrad16s(const Dgrad16Args &A, hipStream_t s)
     return 0;
 }
 
+// ESR_STAG16=0: the lock-step schedule of rounds 2-3 (read once)
+int stag16()
+{
+    static const int v = [] { const char *e = getenv("ESR_STAG16"); return (e && e[0] == '0') ? 0 : 1; }();
+    return v;
+}
+
 // workgroups per segment proportional to its tile groups (every non-empty segment >= 1); returns the grid
 int share_blocks16(Seg16 *seg, int nseg)
 {
@@ -627,6 +581,7 @@ int launch_fwd16s(const Fwd16Args &A, hipStream_t s)
     const int groups = (A.t1 - A.t0 + SHW - 1) / SHW;
     Fwd16Batch B = {};
     B.base = A;
+    B.stag = stag16();
     mlp_fwd16s_kernel<KIND><<<groups < 256 ? groups : 256, 64 * SHW, S::LDS_BYTES, s>>>(B);
     ESR_CHECK_LAUNCH();
     return 0;
@@ -644,14 +599,17 @@ ESR_API int64_t esr_mlp_packed_bf16_elems(int kind)
 ESR_API int esr_mlp_pack_bf16(int kind, const esr_mlp_weights_t *w, void *packed16, void *stream)
 {
     if (!kind_ok(kind) || !w || !packed16) return ESR_EINVAL;
-    Pack16Args A = {};
+    PackBatch B = {};
+    B.n = 1;
+    PackArgs &A = B.job[0];
     A.kind = kind;
-    A.out = static_cast<__bf16 *>(packed16);
+    A.out16 = static_cast<__bf16 *>(packed16);
     for (int l = 0; l < net_desc(kind).n_layers; ++l) {
         if (!w->w[l]) return ESR_EINVAL;
         A.w[l] = w->w[l];
     }
-    pack16_kernel<<<esr_grid_for(pack16_layout(kind).total, 256, 1024), 256, 0, esr_stream(stream)>>>(A);
+    // (fp32 part skipped: out == NULL; the element range still starts with it)
+    pack_kernel<<<dim3(esr_grid_for(pack_layout(kind).total + pack16_layout(kind).total, 256, 1024), 1), 256, 0, esr_stream(stream)>>>(B);
     ESR_CHECK_LAUNCH();
     return 0;
 }
@@ -697,6 +655,7 @@ ESR_API int esr_mlp_fwd_fine_bf16(const float *packed32_off, const void *packed1
     if (X16 && color_row_detached != 0 && color_row_detached != 88) return ESR_EINVAL;     // (the bf16 tile carries rows 88..93 only)
     using S = Shared16<ESR_MLP_RADIANCE, false>;
     Fwd16Batch B = {};
+    B.stag = stag16();
     B.base.X = X; B.base.X16 = X16;
     for (int l = 0; l < 3; ++l) {
         if (!H[l] || !M[l]) return ESR_EINVAL;

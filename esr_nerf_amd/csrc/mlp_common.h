@@ -135,47 +135,53 @@ struct PackArgs {
     int kind;
     const float *w[4], *b[4];
     float *out;
+    __bf16 *out16;          // bf16 twin (pack16_body), or NULL
 };
 
-__global__ void __launch_bounds__(256) pack_kernel(PackArgs A)
+// One element of the packed fp32 buffer.  KIND is a template argument so that the layout table is a set of immediates:
+// with a run-time kind the table was built per thread and indexed dynamically -> 256 B of scratch per lane, 48 MB of
+// scratch writes to pack 0.75 MB of weights (round 3's profiles: Scratch_Size 256 for pack_kernel).
+template <int KIND>
+__device__ __forceinline__ void pack_body(const PackArgs &A, int64_t e)
 {
-    const PackLayout L = pack_layout(A.kind);
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < L.total;
-         e += (int64_t)gridDim.x * blockDim.x) {
-        if (e >= L.off_wx4) {                                // first layer transposed, input rows >= 32, 4x4x1 operand order
-            int64_t i = e - L.off_wx4;
+    constexpr PackLayout L = pack_layout(KIND);
+    if (e >= L.off_wx4) {                                // first layer transposed, input rows >= 32, 4x4x1 operand order
+        int64_t i = e - L.off_wx4;
+        const int sub = i & 3, r = (i >> 2) & 3, h = (i >> 4) & 1;
+        i >>= 5;
+        constexpr int nq = L.in_dim[1] / 8;                      // quads of k-registers (hidden width / 2 registers)
+        const int pass = (int)(i / nq), q = (int)(i % nq);
+        const int col = in_colmap(KIND, 32 + 4 * pass + r), u = hid_feature(4 * q + sub, h);
+        A.out[e] = (col >= 0 && col < L.in_dim[0]) ? A.w[0][(int64_t)u * L.in_dim[0] + col] : 0.f;
+        return;
+    }
+    if (e >= L.off_w4) {                                 // output layer, 4x4x1 operand order
+        constexpr int ll = L.n_layers - 1, hid = L.in_dim[ll], outd = L.out_dim[ll];
+        float v = 0.f;
+        if (e < L.off_b4) {
+            int64_t i = e - L.off_w4;
             const int sub = i & 3, r = (i >> 2) & 3, h = (i >> 4) & 1;
             i >>= 5;
-            const int nq = L.in_dim[1] / 8;                          // quads of k-registers (hidden width / 2 registers)
+            constexpr int nq = hid / 8;                          // quads of k-registers per pass (hid/2 registers)
             const int pass = (int)(i / nq), q = (int)(i % nq);
-            const int col = in_colmap(A.kind, 32 + 4 * pass + r), u = hid_feature(4 * q + sub, h);
-            A.out[e] = (col >= 0 && col < L.in_dim[0]) ? A.w[0][(int64_t)u * L.in_dim[0] + col] : 0.f;
-            continue;
+            const int c = 4 * pass + r, u = hid_feature(4 * q + sub, h);
+            if (c < outd) v = A.w[ll][(int64_t)c * hid + u];
+        } else {
+            const int c = (int)(e - L.off_b4);
+            if (c < outd) v = A.b[ll][c];
         }
-        if (e >= L.off_w4) {                                 // output layer, 4x4x1 operand order
-            const int ll = L.n_layers - 1, hid = L.in_dim[ll], outd = L.out_dim[ll];
-            float v = 0.f;
-            if (e < L.off_b4) {
-                int64_t i = e - L.off_w4;
-                const int sub = i & 3, r = (i >> 2) & 3, h = (i >> 4) & 1;
-                i >>= 5;
-                const int nq = hid / 8;                              // quads of k-registers per pass (hid/2 registers)
-                const int pass = (int)(i / nq), q = (int)(i % nq);
-                const int c = 4 * pass + r, u = hid_feature(4 * q + sub, h);
-                if (c < outd) v = A.w[ll][(int64_t)c * hid + u];
-            } else {
-                const int c = (int)(e - L.off_b4);
-                if (c < outd) v = A.b[ll][c];
-            }
-            A.out[e] = v;
-            continue;
-        }
-        int l = 0;
-        while (l + 1 < L.n_layers && e >= L.off_wf[l + 1]) ++l;
+        A.out[e] = v;
+        return;
+    }
+    float v = 0.f;
+    bool done = false;
+#pragma unroll
+    for (int l = 0; l < L.n_layers; ++l) {               // (unrolled: every layer's constants are immediates)
+        if (done || (l + 1 < L.n_layers && e >= L.off_wf[l + 1])) continue;
+        done = true;
         const bool first = l == 0, last = l == L.n_layers - 1;
         const float *W = A.w[l];
         const int ind = L.in_dim[l], outd = L.out_dim[l];
-        float v = 0.f;
         if (e < L.off_bf[l]) {                               // forward weights
             int64_t i = e - L.off_wf[l];
             const int sub = i & 3; i >>= 2;
@@ -183,7 +189,7 @@ __global__ void __launch_bounds__(256) pack_kernel(PackArgs A)
             const int q = (int)(i % (L.kp[l] / 4)), it = (int)(i / (L.kp[l] / 4));
             const int p = 4 * q + sub, h = lane >> 5;
             const int row = 32 * it + (lane & 31);
-            const int col = first ? in_colmap(A.kind, 2 * p + h) : hid_feature(p, h);
+            const int col = first ? in_colmap(KIND, 2 * p + h) : hid_feature(p, h);
             if (row < outd && col >= 0 && col < ind) v = W[(int64_t)row * ind + col];
         } else if (e < L.off_wb[l]) {                        // bias in accumulator order
             int64_t i = e - L.off_bf[l];
@@ -198,10 +204,110 @@ __global__ void __launch_bounds__(256) pack_kernel(PackArgs A)
             const int p = 4 * q + sub, h = lane >> 5;
             const int orow = last ? (2 * p + h) : hid_feature(p, h);          // output feature of layer l
             const int irow = 32 * it + (lane & 31);                           // input feature / X row
-            const int col = first ? in_colmap(A.kind, irow) : irow;
+            const int col = first ? in_colmap(KIND, irow) : irow;
             if (orow < outd && col >= 0 && col < ind) v = W[(int64_t)orow * ind + col];
         }
-        A.out[e] = v;
+    }
+    A.out[e] = v;
+}
+
+// ---- packed bf16 buffer (the bf16 engine, mlp_bf16.hip) ------------------------------------------------------------
+// A 32x32x16 bf16 MFMA takes 8 consecutive k values per lane (k block = lane >> 5); k-step j = 2 * tile + jj, slot i of
+// half h <-> feature kfeat16(j, h, i) (see mlp_bf16.hip).
+__host__ __device__ constexpr int kfeat16(int j, int h, int i)
+{
+    return 32 * (j >> 1) + 16 * (j & 1) + 4 * h + (i & 3) + 8 * (i >> 2);
+}
+// Packed bf16 buffer (elements).  Forward part of layer l: [ks][tiles_out][64 lanes][8]; transposed part
+// (dgrad): [kso][tiles_in][64][8].  Biases are read from the fp32 packed buffer of esr_mlp_pack.
+struct Pack16Layout {
+    int n_layers;
+    int ks[4], tiles_out[4], kso[4], tiles_in[4], in_dim[4], out_dim[4];
+    int64_t off_wf[4], off_wb[4];
+    int64_t total;
+};
+__host__ __device__ constexpr Pack16Layout pack16_layout(int kind)
+{
+    const NetDesc d = net_desc(kind);
+    Pack16Layout L = {};
+    L.n_layers = d.n_layers;
+    int64_t o = 0;
+    for (int l = 0; l < d.n_layers; ++l) {
+        const bool first = l == 0, last = l == d.n_layers - 1;
+        const int hid = 32 * d.hid_tiles;
+        L.ks[l] = first ? (2 * d.in_kp + 15) / 16 : hid / 16;
+        L.in_dim[l] = first ? d.in_dim : hid;
+        L.out_dim[l] = last ? d.out_dim : hid;
+        L.tiles_out[l] = last ? 1 : d.hid_tiles;
+        L.kso[l] = last ? 1 : hid / 16;
+        L.tiles_in[l] = first ? 2 : d.hid_tiles;
+        L.off_wf[l] = o; o += (int64_t)L.ks[l] * L.tiles_out[l] * 512;
+        L.off_wb[l] = o; o += (int64_t)L.kso[l] * L.tiles_in[l] * 512;
+    }
+    L.total = o;
+    return L;
+}
+template <int KIND>
+__device__ __forceinline__ void pack16_body(const PackArgs &A, int64_t e)
+{
+    constexpr Pack16Layout L = pack16_layout(KIND);
+    float v = 0.f;
+    bool done = false;
+#pragma unroll
+    for (int l = 0; l < L.n_layers; ++l) {
+        if (done || (l + 1 < L.n_layers && e >= L.off_wf[l + 1])) continue;
+        done = true;
+        const bool first = l == 0, last = l == L.n_layers - 1;
+        const float *W = A.w[l];
+        const int ind = L.in_dim[l], outd = L.out_dim[l];
+        if (e < L.off_wb[l]) {                               // forward weights, order [k-step][out tile]
+            int64_t i = e - L.off_wf[l];
+            const int slot = i & 7; i >>= 3;
+            const int lane = i & 63; i >>= 6;
+            const int it = (int)(i % L.tiles_out[l]), j = (int)(i / L.tiles_out[l]);
+            const int h = lane >> 5, row = 32 * it + (lane & 31);
+            const int col = first ? in_colmap(KIND, 16 * j + 8 * h + slot) : kfeat16(j, h, slot);
+            if (row < outd && col >= 0 && col < ind) v = W[(int64_t)row * ind + col];
+        } else {                                             // transposed weights, order [k-step][in tile]
+            int64_t i = e - L.off_wb[l];
+            const int slot = i & 7; i >>= 3;
+            const int lane = i & 63; i >>= 6;
+            const int it = (int)(i % L.tiles_in[l]), j = (int)(i / L.tiles_in[l]);
+            const int h = lane >> 5;
+            const int orow = last ? (8 * h + slot) : kfeat16(j, h, slot);      // output feature of layer l
+            const int irow = 32 * it + (lane & 31);                            // input feature / X row
+            const int col = first ? in_colmap(KIND, irow) : irow;
+            if (orow < outd && col >= 0 && col < ind) v = W[(int64_t)orow * ind + col];
+        }
+    }
+    A.out16[e] = (__bf16)v;
+}
+
+// Every net of a step in ONE launch (esr_mlp_pack_batch): blockIdx.y = job; fp32 elements first, then the bf16 twin's.
+constexpr int MAX_PACK_JOBS = 8;
+struct PackBatch {
+    int n;
+    PackArgs job[MAX_PACK_JOBS];
+};
+template <int KIND>
+__device__ __forceinline__ void pack_job(const PackArgs &A)
+{
+    constexpr int64_t N32 = pack_layout(KIND).total, N16 = pack16_layout(KIND).total;
+    const int64_t n = N32 + (A.out16 ? N16 : 0);
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < N32) { if (A.out) pack_body<KIND>(A, e); }
+        else pack16_body<KIND>(A, e - N32);
+    }
+}
+__global__ void __launch_bounds__(256) pack_kernel(PackBatch B)
+{
+    const PackArgs &A = B.job[blockIdx.y];
+    switch (A.kind) {                                    // (block-uniform)
+    case ESR_MLP_RADIANCE: pack_job<ESR_MLP_RADIANCE>(A); break;
+    case ESR_MLP_TONEMAP:  pack_job<ESR_MLP_TONEMAP>(A); break;
+    case ESR_MLP_BRDF:     pack_job<ESR_MLP_BRDF>(A); break;
+    case ESR_MLP_EMIT:     pack_job<ESR_MLP_EMIT>(A); break;
+    default:               pack_job<ESR_MLP_COARSE>(A); break;
     }
 }
 
@@ -418,19 +524,24 @@ __device__ __forceinline__ void load_bias(rsrc_t W, int boff, f32x16 (&acc)[NT],
     }
 }
 
-// CAUTION (inline asm reading MFMA results): hipcc's hazard recogniser does not see inside an asm statement, so nothing
-// inserts the wait states a vector instruction needs behind the MFMA that wrote its operand.  Call this only where the
-// tile read first was written long before (the layer loops write tile 0 first and tile NT-1 last, and the 16 v_max per
-// tile put >= 80 instructions between a tile's last MFMA and its v_max); csrc/tone_wgrad.hip's bf16 kernel, whose
-// tiles are finished by a single 8-pass MFMA each, uses fmaxf instead.
+// ReLU of accumulator tiles as ONE integer instruction per element: max((int)bits, 0) -- non-negative floats are
+// non-negative integers in the same order, every negative float (and -0) has the sign bit and becomes +0.  fmaxf on an
+// MFMA result compiles to a canonicalising max + the max (two instructions); rounds 1-3 used an inline-asm v_max_f32
+// instead, which hipcc's hazard recogniser cannot see into: nothing inserted the wait states a vector instruction needs
+// behind the MFMA that wrote its operand, and round 3's bf16 tone-mapper kernel read an accumulator before its (single,
+// 8-pass) MFMA had written it.  The integer form is compiler-visible: the dependency on the MFMA is tracked, the hazard
+// nops are inserted where a schedule needs them (tests/test_isa.py checks the generated code: no hand-written vector
+// instruction reads an MFMA result, and the ReLU is one v_max_i32 per element), and nothing is canonicalised.
 template <int NT>
 __device__ __forceinline__ void relu_tiles(f32x16 (&acc)[NT])
 {
 #pragma unroll
     for (int it = 0; it < NT; ++it)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)      // one v_max_f32 (fmaxf on an MFMA result compiles to a canonicalising max + the max)
-            asm("v_max_f32 %0, %1, 0" : "=v"(acc[it][r]) : "v"(acc[it][r]));
+        for (int r = 0; r < 16; ++r) {
+            const int b = __float_as_int(acc[it][r]);
+            acc[it][r] = __int_as_float(b > 0 ? b : 0);
+        }
 }
 
 // per-lane byte offset inside a tile-major tile: row 4h, sample s
@@ -542,6 +653,26 @@ __device__ __forceinline__ void store_tiles_bf16(rsrc_t T, const f32x16 (&acc)[N
             hi[0] = (__bf16)acc[it][4 * q + 2]; hi[1] = (__bf16)acc[it][4 * q + 3];
             u32x2 v;
             v[0] = __builtin_bit_cast(unsigned, lo); v[1] = __builtin_bit_cast(unsigned, hi);
+            __builtin_amdgcn_raw_buffer_store_b64(v, T, voff, (8 * it + 2 * q) * 256, ESR_NT_AUX);
+        }
+}
+
+// the same tile store from ALREADY packed values: hb[2 * it + jj] = registers 8 jj .. 8 jj + 7 of tile `it` rounded to bf16
+// (the next layer's B operands); quad q of the tile = elements 4 (q & 1) .. + 3 of hb[2 * it + (q >> 1)]
+template <int NT>
+__device__ __forceinline__ void store_tiles_bf16_packed(rsrc_t T, const bf16x8 (&hb)[2 * NT], int lane)
+{
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    const int s_ = lane & 31;
+    const int voff = ((lane >> 5) * 32 + 8 * ((s_ >> 1) & 3) + 2 * (s_ >> 3) + (s_ & 1)) * 8;
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32x4_ w = __builtin_bit_cast(u32x4_, hb[2 * it + (q >> 1)]);
+            u32x2 v;
+            v[0] = w[2 * (q & 1)]; v[1] = w[2 * (q & 1) + 1];
             __builtin_amdgcn_raw_buffer_store_b64(v, T, voff, (8 * it + 2 * q) * 256, ESR_NT_AUX);
         }
 }

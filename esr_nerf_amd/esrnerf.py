@@ -91,10 +91,11 @@ class _LtsRender(torch.autograd.Function):
         nets = (("off", KIND_RADIANCE, 8), ("emo", KIND_RADIANCE, 8), ("tone", KIND_TONEMAP, 4),
                 ("brdf", KIND_BRDF, 8), ("emit", KIND_EMIT, 8))
         o = 0
-        for name, kind, n in nets:
-            ps = mlp_params[o:o + n]
-            eng.pack(name, kind, list(ps[0::2]), list(ps[1::2]))
-            o += n
+        with eng.packing():
+            for name, kind, n in nets:
+                ps = mlp_params[o:o + n]
+                eng.pack(name, kind, list(ps[0::2]), list(ps[1::2]))
+                o += n
         scene = model.scene_struct()
         scene2 = model.scene_struct(near=model.lts_near)
         grids = dict(sdf=model.sdf.device_view(), off=model.off_color.device_view(),
@@ -136,10 +137,11 @@ class _FinetuneRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, batch, draws, emo_color, *emo_params):
         eng: LtsEngine = model.engine
-        eng.pack("emo", KIND_RADIANCE, list(emo_params[0::2]), list(emo_params[1::2]))
-        for name, kind, net in (("brdf", KIND_BRDF, model.brdfnet), ("emit", KIND_EMIT, model.emitnet)):
-            lins = net.layers()
-            eng.pack(name, kind, [l.weight.detach() for l in lins], [l.bias.detach() for l in lins])
+        with eng.packing():
+            eng.pack("emo", KIND_RADIANCE, list(emo_params[0::2]), list(emo_params[1::2]))
+            for name, kind, net in (("brdf", KIND_BRDF, model.brdfnet), ("emit", KIND_EMIT, model.emitnet)):
+                lins = net.layers()
+                eng.pack(name, kind, [l.weight.detach() for l in lins], [l.bias.detach() for l in lins])
         grids = dict(sdf=model.sdf.device_view(), emo=model.emo_color.device_view(), brdf=model.brdf.device_view(),
                      emit=model.emit_color.device_view(),
                      mask=model.mask_cache.density.view(*model.mask_cache.density.shape[2:]))

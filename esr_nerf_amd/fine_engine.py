@@ -132,6 +132,8 @@ class FineEngine:
         self._side = None
         self._raw: Dict[str, tuple] = {}
         self._pack_cache: Dict[str, tuple] = {}
+        self._pack_pending = None         # inside `with self.packing():` the jobs of one esr_mlp_pack_batch launch
+        self._pack_batch_cache = None
         # the tone mapper's weight gradients recompute its hidden layer (csrc/tone_wgrad.hip; round 3: also with bf16
         # operands), so its forward keeps only the ReLU masks and its input-gradient pass stores no dZt;
         # ESR_TONE_RECOMPUTE16=0: the bf16 engine's saved-tile path of round 2 (A/B timing)
@@ -213,15 +215,22 @@ class FineEngine:
         return rb
 
     def pack(self, which: str, kind: int, weights: List[torch.Tensor], biases: List[torch.Tensor]):
+        """Rewrite one net's reference-layout tensors into MFMA operand order.  Inside ``with eng.packing():`` the nets of
+        a step are collected and go out as ONE launch (esr_mlp_pack_batch: fp32 buffers and, for the bf16 engine, their
+        bf16 twins); outside, one launch per call."""
         self._raw[which] = (list(weights), list(biases))      # reference-layout tensors (esr_tone_wgrad_recompute reads them)
-        # the argument struct is rebuilt (and the tensors re-validated) only when a parameter tensor moved: five nets x
-        # eight tensors of checks and marshalling per step sat on the host's critical path right before the plan read
-        key = tuple(t.data_ptr() for t in weights) + tuple(t.data_ptr() for t in biases)
+        # the argument struct is rebuilt (and the tensors re-validated) only when a parameter tensor moved or changed its
+        # type / layout: five nets x eight tensors of marshalling per step sat on the host's critical path right before
+        # the plan read.  The key holds everything the kernel assumes about a tensor (address, dtype, size, contiguity):
+        # the caching allocator re-uses addresses, so an address alone does not identify a tensor.
+        key = tuple((t.data_ptr(), t.dtype, t.numel(), t.is_contiguous()) for t in weights) + \
+            tuple((t.data_ptr(), t.dtype, t.numel(), t.is_contiguous()) for t in biases)
         hit = self._pack_cache.get(which)
-        if hit is None or hit[0] != key or hit[1] != kind:
+        if hit is None or hit[0] != key or hit[1] != kind or hit[6] != self.packed[which].data_ptr():
             w = _lib.EsrMlpWeights()
             for i, (a, b) in enumerate(zip(weights, biases)):
-                if not (a.is_cuda and a.is_contiguous() and b.is_contiguous() and a.dtype == torch.float32):
+                if not (a.is_cuda and b.is_cuda and a.is_contiguous() and b.is_contiguous()
+                        and a.dtype == torch.float32 and b.dtype == torch.float32):
                     raise RuntimeError("MLP parameters must be contiguous fp32 device tensors")
                 w.w[i], w.b[i] = a.data_ptr(), b.data_ptr()
             p32 = _lib.ptr(self.packed[which])
@@ -233,14 +242,42 @@ class FineEngine:
                 p16 = _lib.ptr(self.packed16[which])
                 self._p16[self.packed[which].data_ptr()] = p16
             hit = self._pack_cache[which] = (key, kind, w, C.byref(w), p32, p16, self.packed[which].data_ptr())
-        elif hit[6] != self.packed[which].data_ptr():
-            self._pack_cache.pop(which)
-            return self.pack(which, kind, weights, biases)
         _, _, w, wref, p32, p16, _ = hit
+        if self._pack_pending is not None:
+            self._pack_pending.append((which, kind, w, p32, p16))
+            return
         s = self._s()
         self._run(f"mlp_pack({which})", self.L.esr_mlp_pack, kind, wref, p32, s)
         if self.bf16:
             self._run(f"mlp_pack16({which})", self.L.esr_mlp_pack_bf16, kind, wref, p16, s)
+
+    def packing(self):
+        """Context manager: the ``pack`` calls inside go out as one launch at exit."""
+        eng = self
+
+        class _Group:
+            def __enter__(self_):
+                eng._pack_pending = []
+
+            def __exit__(self_, et, ev, tb):
+                jobs, eng._pack_pending = eng._pack_pending, None
+                if et is None and jobs:
+                    eng._pack_flush(jobs)
+                return False
+        return _Group()
+
+    def _pack_flush(self, jobs):
+        sig = tuple((which, kind, C.addressof(w), p32.value, p16.value if p16 is not None else 0) for which, kind, w, p32, p16 in jobs)
+        hit = self._pack_batch_cache
+        if hit is None or hit[0] != sig:
+            n = len(jobs)
+            kinds = (C.c_int32 * n)(*[k for _, k, _, _, _ in jobs])
+            ws = (C.c_void_p * n)(*[C.addressof(w) for _, _, w, _, _ in jobs])
+            p32s = (C.c_void_p * n)(*[p.value for _, _, _, p, _ in jobs])
+            p16s = (C.c_void_p * n)(*[(p.value if p is not None else 0) for _, _, _, _, p in jobs]) if self.bf16 else None
+            hit = self._pack_batch_cache = (sig, n, kinds, ws, p32s, p16s)
+        _, n, kinds, ws, p32s, p16s = hit
+        self._run("mlp_pack(all)", self.L.esr_mlp_pack_batch, n, kinds, ws, p32s, p16s, self._s())
 
     # the three MLP entry points with the fp32 signatures; in bf16 mode the packed fp32 pointer selects its bf16 twin
     def mlp_fwd(self, kind, packed, *rest):

@@ -98,9 +98,11 @@ class _PointDraw:
     from ``np.random`` in between (nothing on this path does)."""
 
     _pool = None           # one persistent worker: creating a thread per step costs ~0.1 ms of host time
-    _pinned = {}           # k -> [buffer, buffer, last slot]
 
-    def __init__(self, n: int, k: int):
+    def __init__(self, n: int, k: int, ring: list):
+        """``ring``: the calling engine's [buffer, buffer, last slot, capacity] -- two alternating pinned buffers sized
+        for the engine's LARGEST draw and sliced to k (one ring per engine: a class-level dict keyed by k grew by two
+        pinned buffers for every distinct survivor-limited k and was shared by every engine of the process)."""
         from concurrent.futures import ThreadPoolExecutor
         if _PointDraw._pool is None:
             _PointDraw._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="esr-point-draw")
@@ -112,13 +114,15 @@ class _PointDraw:
         self._pos = C.c_int32(int(st[2]))
         # pinned: the upload in lts_forward must not block the host (a pageable copy waits for the stream to drain,
         # after which every small launch of the light-transport glue shows its full launch latency: ~0.5 ms idle per step)
-        # (two alternating buffers per size, allocated once: a pinned allocation per step cost the host ~60 us right after
+        # (two alternating buffers, allocated once: a pinned allocation per step cost the host ~60 us right after
         # the plan read, with the device idle -- tools/trace_lts.sh)
-        ring = _PointDraw._pinned.setdefault(k, [None, None, 0])
+        if k > ring[3]:
+            ring[0] = ring[1] = None
+            ring[3] = k
         slot = ring[2] = ring[2] ^ 1
         if ring[slot] is None:
-            ring[slot] = torch.empty(k, dtype=torch.int64, pin_memory=torch.cuda.is_available())
-        self._out_t = ring[slot]
+            ring[slot] = torch.empty(ring[3], dtype=torch.int64, pin_memory=torch.cuda.is_available())
+        self._out_t = ring[slot][:k]
         self._out = self._out_t.numpy()
         self._rc = None
         L = _lib.lib()
@@ -152,6 +156,7 @@ class LtsEngine(FineEngine):
     def __init__(self, device, mlp_dtype: str = "f32"):
         super().__init__(device, mlp_dtype)
         self.ray_sampling = "random"        # or "fib" (cfg.app.model.ray_sampling; esrnerf.py:188-192)
+        self._draw_ring = [None, None, 0, 0]   # pinned buffers of the surface-point draw (_PointDraw)
         self.zero_arena = os.environ.get("ESR_ZERO_ARENA", "1") != "0"      # (read once, here; A/B switch of tools/ab.sh)
         self.prim = Pass(self.device, "primary")
         self.pts = Pass(self.device, "points")
@@ -603,7 +608,7 @@ class LtsEngine(FineEngine):
         if T == 0:
             raise RuntimeError("fine-tune step with no surviving sample (degenerate batch)")
         # the surface-point draw (a full host-side shuffle of range(m3): 1.5 ms at C5) on the worker thread, collected below
-        point_draw = _PointDraw(m3, min(int(cfg["num_ltspts"]), m3)) if draws is None else None
+        point_draw = _PointDraw(m3, min(int(cfg["num_ltspts"]), m3), self._draw_ring) if draws is None else None
         sp = C.byref(scene)
         eg = torch.empty(T * 32, 4, device=dev)
         self._run("expgrad_fwd", L.esr_expgrad_fwd, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(P0.bufs["rec_ray"]),
@@ -714,7 +719,7 @@ class LtsEngine(FineEngine):
         # (started behind the first large launch: checking out numpy's state and waking the worker is ~50 us of host time
         # the device would otherwise spend idle right after the plan read; the draw itself is 0.4 ms against ~0.8 ms of
         # primary-pass work queued in front of its consumer)
-        point_draw = _PointDraw(m3, min(int(cfg["num_ltspts"]), m3)) if draws is None else None
+        point_draw = _PointDraw(m3, min(int(cfg["num_ltspts"]), m3), self._draw_ring) if draws is None else None
         # exact normals (+ positions) of every surviving sample
         eg = torch.empty(T * 32, 4, device=dev)
         self._run("expgrad_fwd", L.esr_expgrad_fwd, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(P0.bufs["rec_ray"]),

@@ -257,14 +257,24 @@ class FineStep:
 
     finish = close
 
+    # `with FineStep(...) as step:` -- close() runs at exit, so the last step's deferred overflow flag cannot be dropped
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is None:
+            self.close()
+        return False
+
     def _step(self, batch, s_val, global_rays, entropy_owner, m, eng, ps):
         g = None
 
         def prelude():        # independent of the march: runs on the device while the host waits for the plan header
             nonlocal g
-            eng.pack("off", KIND_RADIANCE, list(ps[0:8:2]), list(ps[1:8:2]))
-            eng.pack("emo", KIND_RADIANCE, list(ps[8:16:2]), list(ps[9:16:2]))
-            eng.pack("tone", KIND_TONEMAP, list(ps[16:20:2]), list(ps[17:20:2]))
+            with eng.packing():       # the three nets' packs: one launch
+                eng.pack("off", KIND_RADIANCE, list(ps[0:8:2]), list(ps[1:8:2]))
+                eng.pack("emo", KIND_RADIANCE, list(ps[8:16:2]), list(ps[9:16:2]))
+                eng.pack("tone", KIND_TONEMAP, list(ps[16:20:2]), list(ps[17:20:2]))
             g = self._alloc_grads(batch["rays_o"].device)
 
         ctx, last, srgb, lin = eng.forward(
@@ -366,6 +376,15 @@ class LtsStep:
 
     finish = close
 
+    # `with FineStep(...) as step:` -- close() runs at exit, so the last step's deferred overflow flag cannot be dropped
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is None:
+            self.close()
+        return False
+
     def _param_names(self):
         if self._names is None:
             names = []
@@ -435,9 +454,10 @@ class LtsStep:
         def prelude():        # independent of the march: on a side stream while the host waits for the plan header
             nonlocal G
             o = 0
-            for name, kind, n in (("off", KR, 8), ("emo", KR, 8), ("tone", KT, 4), ("brdf", KB, 8), ("emit", KE, 8)):
-                eng.pack(name, kind, list(ps[o:o + n:2]), list(ps[o + 1:o + n:2]))
-                o += n
+            with eng.packing():       # the five nets' packs: one launch
+                for name, kind, n in (("off", KR, 8), ("emo", KR, 8), ("tone", KT, 4), ("brdf", KB, 8), ("emit", KE, 8)):
+                    eng.pack(name, kind, list(ps[o:o + n:2]), list(ps[o + 1:o + n:2]))
+                    o += n
             G = self._alloc_grads(batch["rays_o"].device)
         grids = dict(sdf=m.sdf.device_view(), off=m.off_color.device_view(), emo=m.emo_color.device_view(),
                      brdf=m.brdf.device_view(), mask=m.mask_cache.density.view(*m.mask_cache.density.shape[2:]))

@@ -32,9 +32,10 @@ class _FineRender(torch.autograd.Function):
         off_p, emo_p, tone_p = mlp_params[0:8], mlp_params[8:16], mlp_params[16:20]
 
         def prelude():        # runs on the device while the host waits for the march's plan header
-            eng.pack("off", KIND_RADIANCE, list(off_p[0::2]), list(off_p[1::2]))
-            eng.pack("emo", KIND_RADIANCE, list(emo_p[0::2]), list(emo_p[1::2]))
-            eng.pack("tone", KIND_TONEMAP, list(tone_p[0::2]), list(tone_p[1::2]))
+            with eng.packing():
+                eng.pack("off", KIND_RADIANCE, list(off_p[0::2]), list(off_p[1::2]))
+                eng.pack("emo", KIND_RADIANCE, list(emo_p[0::2]), list(emo_p[1::2]))
+                eng.pack("tone", KIND_TONEMAP, list(tone_p[0::2]), list(tone_p[1::2]))
 
         scene = model.scene_struct()
         fctx, last, srgb, lin = eng.forward(

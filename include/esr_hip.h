@@ -310,6 +310,11 @@ typedef struct esr_mlp_weights {       /* [host] struct of device pointers */
 
 int64_t esr_mlp_packed_floats(int kind);     /* size of the packed buffer */
 int esr_mlp_pack(int kind, const esr_mlp_weights_t *w, float *packed, void *stream);
+/* Every net of a step in ONE launch (n <= 8): packed32[i] <- w[i] for net kinds[i]; where packed16 != NULL and
+ * packed16[i] != NULL also its bf16 twin (esr_mlp_pack_bf16).  The reference has no counterpart: its nn.Linear
+ * weights are used as they are (app/utils/pbr/module.py:6-83). */
+int esr_mlp_pack_batch(int n, const int32_t *kinds, const esr_mlp_weights_t *const *w, float *const *packed32,
+                       void *const *packed16, void *stream);
 
 /*
  * Forward over tiles [t0,t1).  X: layer-1 input, tile-major [tiles,xrows,32].

@@ -55,6 +55,39 @@ for dense_above, mode in ((2.0, "sparse"), (0.0, "dense")):
             assert e < 1e-5, (mode, it, k, e)
     if mode == "sparse":
         assert step._sync.last["sent"] >= step._sync.last["union"] > 0 and "overflow" not in step._sync.last
+    step.close()                                     # the last step's deferred march-overflow flag: nothing flagged
+
+# a march overflow in the LAST step of a data-parallel run must not be dropped: only rank 1's rays overflow (its scene
+# gets a step bound of 4 -> an LDS capacity of 64 steps, the tilted rays of this scene take up to ~68), the flag travels
+# with the loss all-reduce, and close() raises on EVERY rank
+sc2 = slab_scene("small", s_val=40.0, oblique=True)
+m2 = VoxurfF(fine_cfg("cuda:0"), sc2.near, sc2.far, sc2.xyz_min, sc2.xyz_max, sc2.mask_xyz_min, sc2.mask_xyz_max,
+             sc2.mask_alpha_init, sc2.mask_density, sc2.s_val, sc2.num_voxels)
+init_slab_model(m2, sc2)
+m2.train()
+full2 = {k: v.cuda() for k, v in sc2.batch.items()}
+local2 = shard_batch(full2, rank, world)
+n2 = full2["rays_o"].shape[0]
+real_scene = m2.scene_struct
+def tight():
+    sc_ = real_scene()
+    if rank == 1:
+        sc_.max_steps = 4
+    return sc_
+with FineStep(m2, process_group=dist.group.WORLD) as step:         # (context manager: close() at exit, nothing flagged)
+    step.forward_loss_backward(local2, sc2.s_val, global_rays=n2, entropy_owner=(rank == world - 1))
+step = FineStep(m2, process_group=dist.group.WORLD)
+step.forward_loss_backward(local2, sc2.s_val, global_rays=n2, entropy_owner=(rank == world - 1))
+m2.scene_struct = tight
+step.forward_loss_backward(local2, sc2.s_val, global_rays=n2, entropy_owner=(rank == world - 1))     # raises nothing yet
+m2.scene_struct = real_scene
+raised = False
+try:
+    step.close()
+except RuntimeError as e:
+    raised = "max_steps" in str(e)
+assert raised, "close() did not report the last step's overflow on rank %d" % rank
+del m2, step
 
 # ---- option 2 (ESR_GRAD_SYNC=shard): reduce-scatter + Adam on the owned shard + all-gather.  Two checks per step:
 # (a) the reduce-scattered gradient, gathered back, equals the full-batch gradient (1e-5 of each grid's largest);

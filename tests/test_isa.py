@@ -1,0 +1,110 @@
+"""Checks on the GENERATED gfx950 code (`hipcc -S` of the MLP sources; CPU only, no GPU needed).
+
+1. No hand-written (inline-asm) vector instruction reads a register that an MFMA wrote fewer than HAZARD wait states
+   earlier.  hipcc's hazard recogniser inserts the wait states a VALU instruction needs behind the MFMA that produced its
+   operand, but it does not look inside asm statements: round 3's bf16 tone-mapper kernel read an accumulator with an
+   asm `v_max_f32` before its single 8-pass MFMA had written it ("compiler hazard").  The ReLU is a
+   compiler-visible integer max since round 4; this test keeps every remaining / future asm statement honest.
+2. The ReLU of the MLP kernels is ONE instruction per accumulator element (`v_max_i32`), not fmaxf's canonicalise + max.
+3. Register budgets that performance depends on: no scratch in the pack kernel (round 3: 256 B per lane), no spilled
+   vector registers in the bf16 radiance forward (round 3: 12).
+"""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import kernel_meta as km      # noqa: E402
+
+# wait states between an XDL (MFMA) write of a VGPR and a VALU read of it: up to 18 for a 16-pass instruction on
+# gfx940-class hardware (LLVM's GCNHazardRecognizer: 2-pass 5, 4-pass 7 / 8-pass 11 / 16-pass 19 for some pairs); the
+# test asks for the largest figure whatever the MFMA, which is what "safe by construction" should mean
+HAZARD = 19
+
+
+def _asm(name):
+    return km.asm_of(os.path.join(ROOT, "esr_nerf_amd", "csrc", name))
+
+
+def _regs(tok):
+    """VGPR / AGPR numbers named by an operand token: v12, a3, v[4:7], a[0:15]."""
+    out = set()
+    for kind, lo, hi in re.findall(r"\b([va])\[(\d+):(\d+)\]", tok):
+        out |= {(kind, i) for i in range(int(lo), int(hi) + 1)}
+    for kind, n in re.findall(r"\b([va])(\d+)\b", tok):
+        out.add((kind, int(n)))
+    return out
+
+
+def asm_reads_behind_mfma(path):
+    """[(kernel, line number, instruction, distance)] of inline-asm instructions whose sources an MFMA wrote < HAZARD
+    wait states before (linear scan per function: conservative across branches)."""
+    bad, recent, in_asm, func, slot = [], [], False, None, 0
+    for ln, line in enumerate(open(path), 1):
+        m = re.match(r"^(_Z\w+|\w+):\s*(;.*)?$", line)
+        if m and not line.startswith(".L"):
+            func, recent, slot = m.group(1), [], 0
+            continue
+        t = line.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not t or t.startswith((";", ".", "//")) or t.endswith(":"):
+            continue
+        op, _, rest = t.partition(" ")
+        rest = rest.split(";")[0]
+        if op == "s_nop":
+            slot += int(rest.strip() or 0) + 1
+            continue
+        slot += 1
+        ops = [o.strip() for o in rest.split(",")]
+        if op.startswith(("v_mfma", "v_smfmac")):
+            recent.append((slot, _regs(ops[0])))
+            recent = [(s, r) for s, r in recent if slot - s < 4 * HAZARD]
+            continue
+        if in_asm and op.startswith("v_"):
+            srcs = set().union(*[_regs(o) for o in ops[1:]]) if len(ops) > 1 else set()
+            for s, dst in recent:
+                if slot - s < HAZARD and srcs & dst:
+                    bad.append((func, ln, t, slot - s))
+    return bad
+
+
+@pytest.mark.parametrize("src", ["mlp.hip", "mlp_bf16.hip", "tone_wgrad.hip"])
+def test_no_inline_asm_reads_a_fresh_mfma_result(src):
+    bad = asm_reads_behind_mfma(_asm(src))
+    assert not bad, bad[:5]
+
+
+def test_scanner_catches_a_planted_hazard(tmp_path):
+    p = tmp_path / "k.s"
+    p.write_text("_Zfoo:\n\tv_mfma_f32_32x32x2_f32 v[0:15], v16, v17, v[0:15]\n\t;;#ASMSTART\n\tv_max_f32 v3, v3, 0\n"
+                 "\t;;#ASMEND\n\ts_nop 15\n\ts_nop 3\n\t;;#ASMSTART\n\tv_max_f32 v4, v4, 0\n\t;;#ASMEND\n"
+                 "\tv_max_i32_e32 v5, 0, v5\n.Lfunc_end0:\n")
+    bad = asm_reads_behind_mfma(str(p))
+    assert len(bad) == 1 and bad[0][2].startswith("v_max_f32 v3") and bad[0][3] == 1
+
+
+def test_relu_is_one_compiler_visible_instruction():
+    txt = open(_asm("mlp.hip")).read()
+    body = txt[txt.index("mlp_fwd_kernelILi0E"):]
+    body = body[: body.index(".Lfunc_end")]
+    n_imax = len(re.findall(r"\bv_max_i32", body))
+    n_fmax = len(re.findall(r"\bv_max(_num)?_f32", body))
+    # 3 hidden layers x 6 tiles x 16 registers = 288 ReLUs per tile pass, in two net variants of the merged launch
+    assert n_imax >= 288 and n_fmax == 0, (n_imax, n_fmax)
+
+
+def test_register_budgets():
+    meta = km.kernel_meta(_asm("mlp.hip"))
+    pack = [v for k, v in meta.items() if "pack_kernel" in k]
+    assert pack and all(v.get("scratch", 0) == 0 for v in pack), pack
+    meta16 = km.kernel_meta(_asm("mlp_bf16.hip"))
+    fwd0 = [v for k, v in meta16.items() if "mlp_fwd16s_kernelILi0E" in k]
+    assert fwd0 and fwd0[0].get("spill_v", 0) == 0 and fwd0[0].get("scratch", 0) == 0, fwd0
