@@ -29,6 +29,22 @@
 
 namespace {
 
+// ReLU masks of the bf16 engine: one u32 per lane and tile PAIR, written by the forward from packed bf16 pairs -- register r
+// of tile `it` is bit 8 (it & 1) + (r >> 1) + 16 (r & 1) of word it / 2 (the f32 engine's order is 16 (it & 1) + r)
+__host__ __device__ constexpr int mask_bit16(int it, int r) { return 8 * (it & 1) + (r >> 1) + 16 * (r & 1); }
+template <int NT>
+__device__ __forceinline__ void apply_relu_mask16(const unsigned (&m)[NT / 2], f32x16 (&acc)[NT])
+{
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // sign-extended one-bit field (v_bfe_i32: 0 or -1) ANDed onto the value: two instructions, no VCC
+            const int keep = ((int)(m[it >> 1] << (31 - mask_bit16(it, r)))) >> 31;
+            acc[it][r] = __int_as_float(__float_as_int(acc[it][r]) & keep);
+        }
+}
+
 // registers 8 jj .. 8 jj + 7 of an accumulator tile, rounded to bf16: the B operand of k-step 2 * tile + jj
 __device__ __forceinline__ bf16x8 acc_to_b(const f32x16 &t, int jj)
 {
@@ -64,7 +80,7 @@ struct Seg16 {
 };
 struct Fwd16Batch {
     Fwd16Args base;            // X, H, M (and, for nseg == 0, the single pass)
-    int stag;                  // staggered teams (see mlp_fwd16s_kernel); 0: lock step (ESR_STAG16=0, A/B timing)
+    int skew;                  // see layer_skew()
     int nseg;
     Seg16 seg[MAX_SEG16];
 };
@@ -183,6 +199,64 @@ __device__ __forceinline__ void lds_layer16(const unsigned char *wsrc, BF bget, 
     }
     if (CHN > 0) stage_store<CHN, 2>(ndst, tid, pre);
 }
+// The same layer TILE BY TILE (round 4): output tile `it` receives all its KS k-steps before the next tile starts, so it is
+// finished early and its epilogue -- done(it, acc): bias, ReLU, mask bits, rounding, stores, ~80 vector instructions -- is
+// issued while the NEXT tile's MFMAs execute and while the SIMD's other wave streams its own.  In the k-step-major order
+// of lds_layer16 all NT tiles finish together at the end of the layer: the eight waves of the workgroup then sat in
+// their epilogues at the same time with the matrix pipe idle, and in their products with the vector lanes idle
+// (tools/ubench/fwd16_stamps.hip, round 4: products 3.0-3.8 k, epilogue 5.1-5.8 k, barrier wait 2.6 k cycles per layer).
+// Two accumulators alternate (tile it -> a[it & 1]); the weights' LDS chunk of (j, it) is j * NT + it as before.
+// (compile-time loop: the tile index reaches done() as an integral_constant, so every register-array index in the
+// epilogue is a constant whatever the optimiser decides about unrolling)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int KS, int NT, int CHN, typename BF, typename DONE>
+__device__ __forceinline__ void lds_layer16_tiled(const unsigned char *wsrc, BF bget, DONE done, int lane, int tid,
+                                                  rsrc_t W, int noff, unsigned char *ndst)
+{
+    constexpr int NTOT = KS * NT, G = NTOT >= 12 ? 4 : NTOT >= 6 ? 2 : 1, NG = (NTOT + G - 1) / G;
+    constexpr int G1 = NG / 3, G2 = (2 * NG) / 3;
+    static_assert(CHN == 0 || (G1 >= 1 && G2 > G1 && G2 < NG), "three distinct staging points inside the layer");
+    const u32x4 *mine = reinterpret_cast<const u32x4 *>(wsrc) + lane;
+    u32x4 buf[2][G], pre[3];
+    static_for<0, G>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (i < NTOT) buf[0][i] = mine[((i % KS) * NT + i / KS) * 64];      // flat n = it * KS + j -> chunk j * NT + it
+    });
+    if (CHN > 0) stage_load<CHN, 0>(W, noff, tid, pre);
+    f32x16 a[2];
+    static_for<0, NG>([&](auto GI) {
+        constexpr int g = decltype(GI)::value;
+        static_for<0, G>([&](auto I) {
+            constexpr int n = (g + 1) * G + decltype(I)::value;
+            if constexpr (n < NTOT) buf[(g + 1) & 1][decltype(I)::value] = mine[((n % KS) * NT + n / KS) * 64];
+        });
+        if constexpr (CHN > 0 && g == G1) { stage_store<CHN, 0>(ndst, tid, pre); stage_load<CHN, 1>(W, noff, tid, pre); }
+        if constexpr (CHN > 0 && g == G2) { stage_store<CHN, 1>(ndst, tid, pre); stage_load<CHN, 2>(W, noff, tid, pre); }
+        static_for<0, G>([&](auto I) {
+            constexpr int i = decltype(I)::value, n = g * G + i;
+            if constexpr (n < NTOT) {
+                constexpr int it = n / KS, j = n % KS;
+                if constexpr (j == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a[it & 1][r] = 0.f;
+                }
+                a[it & 1] = mfma16(__builtin_bit_cast(bf16x8, buf[g & 1][i]), bget(j), a[it & 1]);
+                if constexpr (j == KS - 1 && it > 0)               // (behind this tile's MFMAs in issue order)
+                    done(std::integral_constant<int, it - 1>{}, a[(it - 1) & 1]);
+            }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    done(std::integral_constant<int, NT - 1>{}, a[(NT - 1) & 1]);
+    if (CHN > 0) stage_store<CHN, 2>(ndst, tid, pre);
+}
 // acc += bias (accumulator order, from LDS), AFTER the layer's products.  (Initialising the accumulators with ds_read_b128
 // straight into the MFMA's srcC registers gave wrong values in two registers of the last tile -- rows 11 / 15 / 16 / 20 of
 // units 160-191, deterministically, with bias and weights in LDS verified correct in-kernel; zero-initialised
@@ -209,6 +283,22 @@ __device__ __forceinline__ void layer_barrier()
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+}
+
+// The two waves of a SIMD run the same instruction stream from the same barrier: left alone they stay in phase -- both in a
+// tile's MFMAs (taking turns on the matrix pipe), then both in a tile's epilogue (taking turns on the vector lanes) -- and
+// the per-SIMD time is the SUM of matrix and vector time.  Holding back the second wave of every SIMD (waves 4-7) by
+// about one tile's products after each barrier puts its MFMAs under the first wave's epilogues and vice versa.
+// skew: units of 64 clocks (s_sleep 1); ESR_SKEW16 overrides (0 = off; A/B timing).
+__device__ __forceinline__ void layer_skew(int wv, int skew)
+{
+    if (wv >= SHW / 2)
+        for (int i = 0; i < skew; ++i) __builtin_amdgcn_s_sleep(1);
+}
+int skew16()
+{
+    static const int v = [] { const char *e = getenv("ESR_SKEW16"); return e ? atoi(e) : 6; }();
+    return v;
 }
 
 template <int KIND>
@@ -246,20 +336,7 @@ __global__ void __launch_bounds__(64 * SHW, 1) mlp_fwd16s_kernel(Fwd16Batch AB)
         }
     }
     layer_barrier();
-    // STAGGERED TEAMS (round 4).  The eight waves used to march in lock step: all of them in a layer's products, then all of
-    // them in its epilogue (bias, ReLU, masks, rounding, ~27 stores: ~480 vector instructions per wave) -- per SIMD the
-    // matrix pipe idled through both waves' epilogues and the vector lanes through both waves' products, 12.8 k cycles per
-    // layer step for 4.6 k of matrix work (profiles/r03_w_c3bf16_*: 22 % busy, 3.2 TB/s).  Now the workgroup is two teams
-    // (waves 0-3 / 4-7: one of each per SIMD) that run the SAME program one phase apart: a barrier separates a layer's
-    // products from its epilogue, team B passes one extra barrier up front (team A one at the end), so while one team
-    // streams MFMAs the other team's epilogue has the vector lanes, the LDS port carries one team's weight reads at a
-    // time, and the stores spread over the whole step.  The LDS hand-over still holds: a layer's buffer is read in two
-    // consecutive phases (A, then B), each wave stages its share of the next layer during its own product phase, and the
-    // buffer being overwritten was last read two phases earlier.  Two-layer nets keep both layers resident and have no
-    // barriers at all; they stay as they were.
-    const bool STAG = NL != 2 && AB.stag;
-    const int team = wv >> 2;
-    if (STAG && team == 1) layer_barrier();
+    layer_skew(wv, AB.skew);
     int cur_buf = 0;                                       // LDS buffer holding the layer about to run
     // The smaller nets (everything but the 256-register radiance instance) request the NEXT tile group's input rows while
     // this one runs: the workgroup's eight waves march in step behind the layer barriers, so at the top of a group all of
@@ -325,66 +402,104 @@ __global__ void __launch_bounds__(64 * SHW, 1) mlp_fwd16s_kernel(Fwd16Batch AB)
                 }
         }
         const bool save = A.save && live;
-        // The layer input lives as PACKED bf16 (hb: 8 registers per 32 rows, 48 for a 192-wide layer): it is what the next
-        // layer's MFMAs consume and what the saved H tile holds, so each accumulator is rounded ONCE, in the epilogue, and
-        // the fp32 tile dies there.  (Rounds 2-3 kept the fp32 tile through the next layer and converted per k-step:
-        // 96 + 96 accumulator registers + 32 LDS-read + 12 staging + 24 input-prefetch registers = 260 -> 12 spilled.)
-        bf16x8 hb[2 * HT];
-        f32x16 acc[HT];
-        auto epilogue = [&](auto LC) __attribute__((always_inline)) {
-            constexpr int l = decltype(LC)::value;
-            lds_bias_add<HT>(bias_l + l * S::BIAS_FLOATS, acc, lane);
-            relu_tiles<HT>(acc);
-            if (save) store_relu_mask<HT>(make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), acc, lane);   // (x > 0) of the fp32 value
+        // A layer's input and output live as PACKED bf16 (8 registers per 32 rows, 48 for a 192-wide layer): that is what
+        // the next layer's MFMAs consume and what the saved H tile holds, so each accumulator is rounded ONCE, in its
+        // tile's epilogue, and the fp32 tile dies there (rounds 2-3 kept the whole fp32 layer through the next layer:
+        // 96 + 96 accumulator registers + 32 + 12 + 24 = 260 -> 12 spilled).  Two sets alternate: a layer reads one
+        // while its tiles' epilogues fill the other.
+        bf16x8 hbA[2 * HT], hbB[2 * HT];
+        const int s_ = lane & 31;
+        const int hvoff = ((lane >> 5) * 32 + 8 * ((s_ >> 1) & 3) + 2 * (s_ >> 3) + (s_ & 1)) * 8;      // store_tiles_bf16's slot order
+        unsigned mword = 0;
+        // epilogue of ONE finished tile of layer l: bias (LDS, accumulator order), ReLU, the tile's 16 mask bits,
+        // rounding into `hout`, the tile's four 8-byte row-quad stores; masks leave as one word per tile pair
+        auto tile_epilogue = [&](auto LC, auto IT, f32x16 &acc, bf16x8 (&hout)[2 * HT]) __attribute__((always_inline)) {
+            constexpr int l = decltype(LC)::value, it = decltype(IT)::value;
+            const float4 *b4 = reinterpret_cast<const float4 *>(bias_l + l * S::BIAS_FLOATS + (lane >> 5) * 16) + it * 8;
 #pragma unroll
-            for (int j = 0; j < 2 * HT; ++j) hb[j] = acc_to_b(acc[j >> 1], j & 1);
-            // save == 2: ReLU masks only (the weight gradients recompute the layer)
-            if (save && A.save == 1) store_tiles_bf16_packed<HT>(make_rsrc(A.H[l] + (size_t)t * (HBYTES / 4), HBYTES), hb, lane);
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = b4[q];
+                acc[4 * q + 0] += v.x; acc[4 * q + 1] += v.y; acc[4 * q + 2] += v.z; acc[4 * q + 3] += v.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int bts = __float_as_int(acc[r]);
+                acc[r] = __int_as_float(bts > 0 ? bts : 0);
+            }
+            hout[2 * it] = acc_to_b(acc, 0);
+            hout[2 * it + 1] = acc_to_b(acc, 1);
+            if (save) {
+                // ReLU mask from the PACKED values, two elements per instruction pair: min(u16, 1) per half (a rounded
+                // ReLU output is +0 or a positive bf16; a normal fp32 never rounds to zero, bf16 has fp32's exponent
+                // range) shifted into place -- dword k of the tile (registers 2k, 2k + 1) lands on bits mask_bit16(it, 2k)
+                // and + 16.  One vector instruction per element instead of two (v_med3 + v_lshl_or on the fp32 value).
+                const u32x4 w0 = __builtin_bit_cast(u32x4, hout[2 * it]), w1 = __builtin_bit_cast(u32x4, hout[2 * it + 1]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    unsigned one;     // (asm: hipcc turns the C form into compare + select per half; the operand is a conversion's result -- a VALU value, no MFMA hazard)
+                    asm("v_pk_min_u16 %0, %1, %2" : "=v"(one) : "v"(k < 4 ? w0[k & 3] : w1[k & 3]), "s"(0x00010001u));
+                    mword |= one << mask_bit16(it, 2 * k);
+                }
+                if ((it & 1) || it == HT - 1) {
+                    __builtin_amdgcn_raw_buffer_store_b32(mword, make_rsrc(A.M[l] + (size_t)t * (MBYTES / 4), MBYTES), lane * 4,
+                                                          (it >> 1) * 256, 0);
+                    mword = 0;
+                }
+            }
+            if (save && A.save == 1) {                             // save == 2: ReLU masks only (the weight gradients recompute the layer)
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const rsrc_t RH = make_rsrc(A.H[l] + (size_t)t * (HBYTES / 4), HBYTES);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u32x4 w = __builtin_bit_cast(u32x4, hout[2 * it + (q >> 1)]);
+                    u32x2 v;
+                    v[0] = w[2 * (q & 1)]; v[1] = w[2 * (q & 1) + 1];
+                    __builtin_amdgcn_raw_buffer_store_b64(v, RH, hvoff, (8 * it + 2 * q) * 256, ESR_NT_AUX);
+                }
+            }
         };
-        zero_tiles<HT>(acc);
-        lds_layer16<KS1, HT, (NL == 2 ? 0 : S::chunks(1))>(wl + (NL == 2 ? 0 : cur_buf * S::BUF), [&](int j) { return B1[j]; }, acc,
-                                                         lane, tid, W16, (int)S::off(1), wl + (cur_buf ^ 1) * S::BUF);
+        lds_layer16_tiled<KS1, HT, (NL == 2 ? 0 : S::chunks(1))>(
+            wl + (NL == 2 ? 0 : cur_buf * S::BUF), [&](int j) { return B1[j]; },
+            [&](auto IT, f32x16 &acc) __attribute__((always_inline)) { tile_epilogue(std::integral_constant<int, 0>{}, IT, acc, hbA); },
+            lane, tid, W16, (int)S::off(1), wl + (cur_buf ^ 1) * S::BUF);
         if (x16) fetch16(tg + nblk < ngroups ? tg + nblk : tg);    // (past the end: this group again, never used)
         ESR_STAMP16(1);
-        if (STAG) layer_barrier();
-        epilogue(std::integral_constant<int, 0>{});
         ESR_STAMP16(2);
-        if (NL != 2) { layer_barrier(); cur_buf ^= 1; }
+        if (NL != 2) { layer_barrier(); layer_skew(wv, AB.skew); cur_buf ^= 1; }
         ESR_STAMP16(3);
-        auto hidden = [&](auto LC) {
+        auto hidden = [&](auto LC, bf16x8 (&hin)[2 * HT], bf16x8 (&hout)[2 * HT]) __attribute__((always_inline)) {
             constexpr int l = decltype(LC)::value;
-            zero_tiles<HT>(acc);
-            lds_layer16<2 * HT, HT, S::chunks(l + 1)>(wl + cur_buf * S::BUF, [&](int j) { return hb[j]; },
-                                                     acc, lane, tid, W16, (int)S::off(l + 1), wl + (cur_buf ^ 1) * S::BUF);
+            lds_layer16_tiled<2 * HT, HT, S::chunks(l + 1)>(
+                wl + cur_buf * S::BUF, [&](int j) { return hin[j]; },
+                [&](auto IT, f32x16 &acc) __attribute__((always_inline)) { tile_epilogue(LC, IT, acc, hout); },
+                lane, tid, W16, (int)S::off(l + 1), wl + (cur_buf ^ 1) * S::BUF);
             ESR_STAMP16(4 + 3 * (l - 1));
-            if (STAG) layer_barrier();
-            epilogue(std::integral_constant<int, l>{});
             ESR_STAMP16(5 + 3 * (l - 1));
             layer_barrier();
+            layer_skew(wv, AB.skew);
             cur_buf ^= 1;
             ESR_STAMP16(6 + 3 * (l - 1));
         };
-        if constexpr (NHID > 1) hidden(std::integral_constant<int, 1>{});
-        if constexpr (NHID > 2) hidden(std::integral_constant<int, 2>{});
+        if constexpr (NHID > 1) hidden(std::integral_constant<int, 1>{}, hbA, hbB);
+        if constexpr (NHID > 2) hidden(std::integral_constant<int, 2>{}, hbB, hbA);
         static_assert(NHID <= 3, "hidden steps are spelled out");
+        bf16x8 (&hlast)[2 * HT] = (NHID == 2) ? hbB : hbA;         // output of the last hidden layer
         f32x16 out[1];
         zero_tiles<1>(out);
         // (meanwhile layer 0 of the NEXT tile group is staged: the same weights, only the buffer differs)
         lds_layer16<2 * HT, 1, (NL == 2 ? 0 : S::chunks(0))>(wl + (NL == 2 ? S::BUF : cur_buf * S::BUF),
-                                                           [&](int j) { return hb[j]; }, out, lane, tid,
+                                                           [&](int j) { return hlast[j]; }, out, lane, tid,
                                                            W16, (int)S::off(0), wl + (cur_buf ^ 1) * S::BUF);
         ESR_STAMP16(10);
-        if (STAG) layer_barrier();
         lds_bias_add<1>(bias_l + NHID * S::BIAS_FLOATS, out, lane);
         const rsrc_t RZ = make_rsrc(A.zout + (size_t)t * D.zrows * 32, live ? D.zrows * 32 * 4 : 0);
         const int zvoff = (D.zrows == 8) ? (4 * h * 32 + s) * 4 : ((h ? D.zrows : 0) * 32 + s) * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) bstore1(RZ, (D.zrows == 8 || r < 3) ? out[0][r] : 0.f, zvoff, r * 128);
         ESR_STAMP16(11);
-        if (NL != 2) { layer_barrier(); cur_buf ^= 1; }
+        if (NL != 2) { layer_barrier(); layer_skew(wv, AB.skew); cur_buf ^= 1; }
         ESR_STAMP16(12);
     }
-    if (STAG && team == 0) layer_barrier();                // (every wave passes the same number of barriers)
 }
 
 struct Dgrad16Args {
@@ -477,7 +592,7 @@ __global__ void __launch_bounds__(64 * SHW, 1) mlp_dgrad16s_kernel(Dgrad16Batch 
         zero_tiles<HT>(cur);
         lds_layer16<1, HT, (NL == 2 ? 0 : S::chunks(NL - 2))>(wl + (NL == 2 ? 0 : cur_buf * S::BUF), [&](int) { return B0; }, cur, lane,
                                                             tid, W16, (int)S::off(NL - 2), wl + (cur_buf ^ 1) * S::BUF);
-        apply_relu_mask<HT>(msk[NHID - 1], cur);
+        apply_relu_mask16<HT>(msk[NHID - 1], cur);
         if (A.dZ[NHID - 1])                                // (a NULL dZ[l] is not stored: its weight gradient recomputes it)
             store_tiles_bf16<HT>(make_rsrc(A.dZ[NHID - 1] + (size_t)t * (HBYTES / 4), hb), cur, lane);
         if (NL != 2) { layer_barrier(); cur_buf ^= 1; }
@@ -487,7 +602,7 @@ __global__ void __launch_bounds__(64 * SHW, 1) mlp_dgrad16s_kernel(Dgrad16Batch 
             zero_tiles<HT>(nxt);
             lds_layer16<2 * HT, HT, S::chunks(l - 1)>(wl + cur_buf * S::BUF, [&](int j) { return acc_to_b(cur[j >> 1], j & 1); },
                                                      nxt, lane, tid, W16, (int)S::off(l - 1), wl + (cur_buf ^ 1) * S::BUF);
-            apply_relu_mask<HT>(msk[l - 1], nxt);
+            apply_relu_mask16<HT>(msk[l - 1], nxt);
             if (A.dZ[l - 1]) store_tiles_bf16<HT>(make_rsrc(A.dZ[l - 1] + (size_t)t * (HBYTES / 4), hb), nxt, lane);
 #pragma unroll
             for (int it = 0; it < HT; ++it) cur[it] = nxt[it];
@@ -520,13 +635,6 @@ int launch_dgrad16s(const Dgrad16Args &A, hipStream_t s)
     mlp_dgrad16s_kernel<KIND><<<groups < 256 ? groups : 256, 64 * SHW, 2 * S::BUF, s>>>(B);
     ESR_CHECK_LAUNCH();
     return 0;
-}
-
-// ESR_STAG16=0: the lock-step schedule of rounds 2-3 (read once)
-int stag16()
-{
-    static const int v = [] { const char *e = getenv("ESR_STAG16"); return (e && e[0] == '0') ? 0 : 1; }();
-    return v;
 }
 
 // workgroups per segment proportional to its tile groups (every non-empty segment >= 1); returns the grid
@@ -581,7 +689,7 @@ int launch_fwd16s(const Fwd16Args &A, hipStream_t s)
     const int groups = (A.t1 - A.t0 + SHW - 1) / SHW;
     Fwd16Batch B = {};
     B.base = A;
-    B.stag = stag16();
+    B.skew = skew16();
     mlp_fwd16s_kernel<KIND><<<groups < 256 ? groups : 256, 64 * SHW, S::LDS_BYTES, s>>>(B);
     ESR_CHECK_LAUNCH();
     return 0;
@@ -655,7 +763,7 @@ ESR_API int esr_mlp_fwd_fine_bf16(const float *packed32_off, const void *packed1
     if (X16 && color_row_detached != 0 && color_row_detached != 88) return ESR_EINVAL;     // (the bf16 tile carries rows 88..93 only)
     using S = Shared16<ESR_MLP_RADIANCE, false>;
     Fwd16Batch B = {};
-    B.stag = stag16();
+    B.skew = skew16();
     B.base.X = X; B.base.X16 = X16;
     for (int l = 0; l < 3; ++l) {
         if (!H[l] || !M[l]) return ESR_EINVAL;
