@@ -56,7 +56,25 @@ class EsrLtsArgs(C.Structure):
 class EsrLtsGather(C.Structure):          # esr_lts_gather_t
     _fields_ = [(n, C.c_void_p) for n in ("jp", "ray64", "pts_all", "eg", "rec_sdf", "viewdirs", "brdf_a", "emit_a",
                                           "umask_rays")] + [("n_pts", C.c_int32)] + \
-               [(n, C.c_void_p) for n in ("pts2", "vd2", "sdf2", "normal", "base", "rough", "metal", "emis", "umask")]
+               [(n, C.c_void_p) for n in ("pts2", "vd2", "sdf2", "normal", "base", "rough", "metal", "emis", "umask", "pt1")]
+
+
+class EsrActJob(C.Structure):             # esr_act_job_t
+    _fields_ = [("z", C.c_void_p), ("g_tile", C.c_void_p), ("out", C.c_void_p), ("tiles", C.c_int32), ("rows", C.c_int32),
+                ("n_ch", C.c_int32), ("act", C.c_int32), ("bwd", C.c_int32), ("src", C.c_void_p), ("src_c", C.c_int32),
+                ("n_src", C.c_int32), ("inv", C.c_void_p), ("pt1", C.c_void_p), ("ex", C.c_void_p * 3),
+                ("ex_c", C.c_int32 * 3), ("ex_col0", C.c_int32 * 3)]
+
+
+class EsrGatherJob(C.Structure):          # esr_gather_job_t
+    _fields_ = [("src", C.c_void_p), ("tile_rows", C.c_int32), ("row_stride", C.c_int32), ("col0", C.c_int32),
+                ("n_ch", C.c_int32), ("perm", C.c_void_p), ("n", C.c_int32), ("out", C.c_void_p)]
+
+
+class EsrPairJob(C.Structure):            # esr_pair_job_t
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int32), ("row_mask", C.c_void_p),
+                ("mask_value", C.c_int32), ("count_dev", C.c_void_p), ("kind", C.c_int32), ("w_value", C.c_float),
+                ("w_a", C.c_float), ("w_b", C.c_float), ("ga", C.c_void_p), ("gb", C.c_void_p)]
 
 
 class EsrLtsGrads(C.Structure):
@@ -90,7 +108,7 @@ EXPORTS = [
     "esr_fine_tone_in_bwd", "esr_fine_loss_fwd_bwd", "esr_fine_loss_fwd_bwd_dp",
     "esr_expgrad_fwd", "esr_expgrad_bwd", "esr_lts_dirs", "esr_lts_ref_order", "esr_lts_perturb", "esr_lts_gather_rows",
     "esr_lts_gather_points", "esr_lts_combine_fwd", "esr_lts_combine_bwd",
-    "esr_act_fwd", "esr_act_bwd", "esr_composite3_fwd", "esr_composite3_bwd", "esr_lts_tone_in_bwd",
+    "esr_act_fwd", "esr_act_bwd", "esr_act_batch", "esr_lts_gather_rows_batch", "esr_pair_loss_batch", "esr_lts_ref_order_inv", "esr_lts_dirs_rays", "esr_composite3_fwd", "esr_composite3_bwd", "esr_lts_tone_in_bwd",
     "esr_sample_points", "esr_pair_loss_fwd_bwd", "esr_emit_edit",
     "esr_gauss3d_fwd", "esr_gauss3d_bwd", "esr_central_grad_fwd", "esr_central_grad_bwd",
     "esr_coarse_march_count", "esr_coarse_march_fill", "esr_coarse_march_bwd", "esr_coarse_march_count_ga", "esr_coarse_march_fill_ga", "esr_coarse_march_bwd_ga",

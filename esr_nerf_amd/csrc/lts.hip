@@ -120,13 +120,16 @@ __global__ void __launch_bounds__(256) expgrad_kernel(ExpGradParams P)
 }
 
 // ---- hemisphere directions ---------------------------------------------------------------
+// (o2 / d2 / v_rand: optional -- the secondary rays' origins and directions and the random view direction, which the
+//  caller used to build with repeat_interleave / reshape().contiguous() / neg: four more launches)
 __global__ void __launch_bounds__(256) lts_dirs_kernel(const float *__restrict__ raw,
                                                        const float *__restrict__ normal, int n_pts, int r1,
-                                                       float *__restrict__ dirs)
+                                                       float *__restrict__ dirs, const float *__restrict__ pts,
+                                                       float *__restrict__ o2, float *__restrict__ d2, float *__restrict__ v_rand)
 {
     const int total = n_pts * r1;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int p = i / r1;
+        const int p = i / r1, k = i - p * r1;
         float v[3] = {raw[3 * i], raw[3 * i + 1], raw[3 * i + 2]};
         const float nrm = fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);   // F.normalize eps
 #pragma unroll
@@ -134,7 +137,19 @@ __global__ void __launch_bounds__(256) lts_dirs_kernel(const float *__restrict__
         const float dt = v[0] * normal[3 * p] + v[1] * normal[3 * p + 1] + v[2] * normal[3 * p + 2];
         const float sgn = dt < 0.f ? -1.f : 1.f;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) dirs[3 * i + a] = v[a] * sgn;
+        for (int a = 0; a < 3; ++a) {
+            const float d = v[a] * sgn;
+            dirs[3 * i + a] = d;
+            if (o2) {
+                if (k < r1 - 1) {
+                    const int64_t q = (int64_t)p * (r1 - 1) + k;
+                    d2[3 * q + a] = d;
+                    o2[3 * q + a] = pts[3 * p + a];
+                } else {
+                    v_rand[3 * p + a] = -d;
+                }
+            }
+        }
     }
 }
 
@@ -147,12 +162,15 @@ __global__ void __launch_bounds__(256) lts_dirs_kernel(const float *__restrict__
 // perm[pos] = j with pos = (samples of earlier rays) + (j - first slot of its ray); also the int64 ray id of every slot
 __global__ void __launch_bounds__(256) lts_ref_order_kernel(const int32_t *__restrict__ rec_ray, const int32_t *__restrict__ cnt3,
                                                             const int32_t *__restrict__ off3, const int64_t *__restrict__ csum,
-                                                            int n_slots, int64_t *__restrict__ perm, int64_t *__restrict__ ray64)
+                                                            int n_slots, int64_t *__restrict__ perm, int64_t *__restrict__ ray64,
+                                                            int32_t *__restrict__ inv)
 {
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_slots; j += gridDim.x * blockDim.x) {
         const int r = rec_ray[j];
         ray64[j] = r;
-        if (r >= 0) perm[csum[r] - cnt3[r] + (j - off3[r])] = j;
+        int64_t pos = -1;
+        if (r >= 0) { pos = csum[r] - cnt3[r] + (j - off3[r]); perm[pos] = j; }
+        if (inv) inv[j] = (int32_t)pos;
     }
 }
 
@@ -187,6 +205,22 @@ __global__ void __launch_bounds__(256) lts_gather_rows_kernel(const float *__res
     }
 }
 
+struct GatherBatch {
+    int n;
+    esr_gather_job_t job[ESR_GATHER_MAX_JOBS];
+};
+__global__ void __launch_bounds__(256) lts_gather_rows_batch_kernel(GatherBatch B)
+{
+    const esr_gather_job_t &J = B.job[blockIdx.y];
+    const int64_t total = (int64_t)J.n * J.n_ch;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i / J.n_ch), c = (int)(i - (int64_t)k * J.n_ch);
+        const int64_t j = J.perm ? J.perm[k] : k;
+        J.out[i] = J.tile_rows > 0 ? J.src[((j >> 5) * J.tile_rows + (J.col0 + c)) * 32 + (j & 31)]
+                                   : J.src[j * J.row_stride + J.col0 + c];
+    }
+}
+
 // everything the light-transport segment needs at its P surface points (esrnerf.py:792-806), one thread per point:
 // pts2 [2P,3] (the point twice), vd2 [2P,3] (rows < P: the camera direction of the point's ray), sdf2 [2P], unit normal
 // (F.normalize of the exact SDF gradient), base colour / roughness / metallic / emission heads, uncertainty mask
@@ -200,6 +234,7 @@ struct LtsGather {
     int n_pts;
     float *pts2, *vd2, *sdf2, *normal, *base, *rough, *metal, *emis;
     uint8_t *umask;
+    int32_t *pt1;                            // optional: slot -> point + 1
 };
 __global__ void __launch_bounds__(256) lts_gather_points_kernel(LtsGather G)
 {
@@ -228,6 +263,7 @@ __global__ void __launch_bounds__(256) lts_gather_points_kernel(LtsGather G)
         G.rough[p] = G.brdf_a[(t * 8 + 3) * 32 + s];
         G.metal[p] = G.brdf_a[(t * 8 + 4) * 32 + s];
         G.umask[p] = G.umask_rays[r];
+        if (G.pt1) G.pt1[j] = p + 1;
     }
 }
 
@@ -560,7 +596,19 @@ ESR_API int esr_lts_dirs(const float *raw, const float *normal, int32_t n_pts, i
     if (n_pts == 0) return 0;
     if (!raw || !normal || !dirs) return ESR_EINVAL;
     lts_dirs_kernel<<<esr_grid_for((int64_t)n_pts * rays_plus_one, 256), 256, 0, esr_stream(stream)>>>(
-        raw, normal, n_pts, rays_plus_one, dirs);
+        raw, normal, n_pts, rays_plus_one, dirs, nullptr, nullptr, nullptr, nullptr);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_lts_dirs_rays(const float *raw, const float *normal, const float *pts, int32_t n_pts, int32_t rays_plus_one,
+                              float *dirs, float *o2, float *d2, float *v_rand, void *stream)
+{
+    if (n_pts < 0 || rays_plus_one < 2) return ESR_EINVAL;
+    if (n_pts == 0) return 0;
+    if (!raw || !normal || !pts || !dirs || !o2 || !d2 || !v_rand) return ESR_EINVAL;
+    lts_dirs_kernel<<<esr_grid_for((int64_t)n_pts * rays_plus_one, 256), 256, 0, esr_stream(stream)>>>(
+        raw, normal, n_pts, rays_plus_one, dirs, pts, o2, d2, v_rand);
     ESR_CHECK_LAUNCH();
     return 0;
 }
@@ -572,7 +620,19 @@ ESR_API int esr_lts_ref_order(const int32_t *rec_ray, const int32_t *cnt3, const
     if (n_slots == 0) return 0;
     if (!rec_ray || !cnt3 || !off3 || !cnt3_cumsum || !perm || !ray64) return ESR_EINVAL;
     lts_ref_order_kernel<<<esr_grid_for(n_slots, 256), 256, 0, esr_stream(stream)>>>(rec_ray, cnt3, off3, cnt3_cumsum, n_slots,
-                                                                                    perm, ray64);
+                                                                                    perm, ray64, nullptr);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_lts_ref_order_inv(const int32_t *rec_ray, const int32_t *cnt3, const int32_t *off3, const int64_t *cnt3_cumsum,
+                                  int32_t n_slots, int64_t *perm, int64_t *ray64, int32_t *inv, void *stream)
+{
+    if (n_slots < 0) return ESR_EINVAL;
+    if (n_slots == 0) return 0;
+    if (!rec_ray || !cnt3 || !off3 || !cnt3_cumsum || !perm || !ray64 || !inv) return ESR_EINVAL;
+    lts_ref_order_kernel<<<esr_grid_for(n_slots, 256), 256, 0, esr_stream(stream)>>>(rec_ray, cnt3, off3, cnt3_cumsum, n_slots,
+                                                                                    perm, ray64, inv);
     ESR_CHECK_LAUNCH();
     return 0;
 }
@@ -603,6 +663,28 @@ ESR_API int esr_lts_gather_rows(const float *src, int32_t tile_rows, int32_t row
     return 0;
 }
 
+ESR_API int esr_lts_gather_rows_batch(const esr_gather_job_t *jobs, int32_t n_jobs, void *stream)
+{
+    if (n_jobs < 0 || n_jobs > ESR_GATHER_MAX_JOBS || (n_jobs > 0 && !jobs)) return ESR_EINVAL;
+    GatherBatch B = {};
+    int64_t most = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const esr_gather_job_t &J = jobs[i];
+        if (J.n < 0 || J.n_ch < 1 || J.col0 < 0 || J.tile_rows < 0 || (J.tile_rows == 0 && J.row_stride < J.col0 + J.n_ch) ||
+            (J.tile_rows > 0 && J.tile_rows < J.col0 + J.n_ch))
+            return ESR_EINVAL;
+        if (J.n == 0) continue;
+        if (!J.src || !J.out) return ESR_EINVAL;
+        B.job[B.n++] = J;
+        const int64_t tot = (int64_t)J.n * J.n_ch;
+        most = tot > most ? tot : most;
+    }
+    if (B.n == 0) return 0;
+    lts_gather_rows_batch_kernel<<<dim3(esr_grid_for(most, 256, 512), B.n), 256, 0, esr_stream(stream)>>>(B);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
 ESR_API int esr_lts_gather_points(const esr_lts_gather_t *g, void *stream)
 {
     if (!g || g->n_pts < 0) return ESR_EINVAL;
@@ -615,7 +697,7 @@ ESR_API int esr_lts_gather_points(const esr_lts_gather_t *g, void *stream)
     G.jp = g->jp; G.ray64 = g->ray64; G.pts_all = g->pts_all; G.eg = g->eg; G.rec_sdf = g->rec_sdf; G.viewdirs = g->viewdirs;
     G.brdf_a = g->brdf_a; G.emit_a = g->emit_a; G.umask_rays = g->umask_rays; G.n_pts = g->n_pts;
     G.pts2 = g->pts2; G.vd2 = g->vd2; G.sdf2 = g->sdf2; G.normal = g->normal; G.base = g->base; G.rough = g->rough;
-    G.metal = g->metal; G.emis = g->emis; G.umask = g->umask;
+    G.metal = g->metal; G.emis = g->emis; G.umask = g->umask; G.pt1 = g->pt1;
     lts_gather_points_kernel<<<esr_grid_for(g->n_pts, 256), 256, 0, esr_stream(stream)>>>(G);
     ESR_CHECK_LAUNCH();
     return 0;

@@ -326,6 +326,81 @@ __global__ void __launch_bounds__(256) act_kernel(const float *__restrict__ z, c
     }
 }
 
+// Up to ESR_ACT_MAX_JOBS activation jobs in one launch (blockIdx.y = job); a backward job also gathers the row-major
+// gradient sources of its head (include/esr_hip.h: esr_act_job_t) -- the index_put / index_add_ / cat / permute-copy glue
+// that stood in front of every act_bwd launch.
+struct ActBatch {
+    int n;
+    esr_act_job_t job[ESR_ACT_MAX_JOBS];
+};
+__global__ void __launch_bounds__(256) act_batch_kernel(ActBatch B)
+{
+    const esr_act_job_t &J = B.job[blockIdx.y];
+    const int64_t total = (int64_t)J.tiles * J.rows * 32;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)((i >> 5) % J.rows);
+        float v = 0.f;
+        if (row < J.n_ch) {
+            const float x = J.z[i];
+            if (!J.bwd) v = J.act ? esr_sigmoid(x) : esr_softplus(x);
+            else {
+                const int64_t slot = (i / (32 * (int64_t)J.rows)) * 32 + (i & 31);
+                float g = J.g_tile ? J.g_tile[i] : 0.f;
+                if (J.src && row < J.src_c) {
+                    const int64_t k = J.inv ? (int64_t)J.inv[slot] : slot;
+                    if (k >= 0 && k < J.n_src) g += J.src[k * J.src_c + row];
+                }
+                if (J.pt1) {
+                    const int p = J.pt1[slot] - 1;
+                    if (p >= 0) {
+#pragma unroll
+                        for (int e = 0; e < 3; ++e)
+                            if (J.ex[e] && row >= J.ex_col0[e] && row < J.ex_col0[e] + J.ex_c[e])
+                                g += J.ex[e][(int64_t)p * J.ex_c[e] + (row - J.ex_col0[e])];
+                    }
+                }
+                const float sg = esr_sigmoid(x);
+                v = g * (J.act ? sg * (1.f - sg) : (x > 20.f ? 1.f : sg));
+            }
+        }
+        J.out[i] = v;
+    }
+}
+
+struct PairBatch {
+    int n;
+    esr_pair_job_t job[ESR_PAIR_MAX_JOBS];
+    float *loss;
+};
+__global__ void __launch_bounds__(256) pair_loss_batch_kernel(PairBatch B)
+{
+    const esr_pair_job_t &J = B.job[blockIdx.y];
+    const int64_t total = J.rows * J.cols;
+    const int64_t n_sel = J.count_dev ? (int64_t)J.count_dev[0] * J.cols : total;
+    const float inv = n_sel > 0 ? 1.f / (float)n_sel : 0.f;
+    float acc = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool sel = !J.row_mask || (int)J.row_mask[i / J.cols] == J.mask_value;
+        float g = 0.f;
+        if (sel) {
+            const float d = J.a[i] - (J.b ? J.b[i] : 0.f);
+            if (J.kind == 0) { acc += d * d * inv; g = 2.f * d * inv; }
+            else { acc += fabsf(d) * inv; g = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv; }
+        }
+        if (J.ga) J.ga[i] = J.w_a * g;
+        if (J.gb) J.gb[i] = -J.w_b * g;
+    }
+    __shared__ float part[4];
+    acc = wave_sum(acc);
+    if (esr_lane() == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = ((part[0] + part[1]) + (part[2] + part[3])) * J.w_value;
+        if (tot != 0.f) atomicAdd(B.loss, tot);
+    }
+}
+
 // out[ray, c] += w * v[c] for a 3-channel tile-major quantity (segmented wave reduction)
 __global__ void __launch_bounds__(256) composite3_fwd_kernel(const float *__restrict__ v, int rows,
                                                              const int32_t *__restrict__ rec_ray,
@@ -550,6 +625,52 @@ ESR_API int esr_pair_loss_fwd_bwd(const float *a, const float *b, int64_t rows, 
     if (!a || !loss) return ESR_EINVAL;
     pair_loss_kernel<<<esr_grid_for(rows * cols, 256, 256), 256, 0, esr_stream(stream)>>>(
         a, b, rows, cols, row_mask, mask_value, count_dev, kind, w_value, w_a, w_b, loss, ga, gb);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_act_batch(const esr_act_job_t *jobs, int32_t n_jobs, void *stream)
+{
+    if (n_jobs < 0 || n_jobs > ESR_ACT_MAX_JOBS || (n_jobs > 0 && !jobs)) return ESR_EINVAL;
+    ActBatch B = {};
+    int64_t most = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const esr_act_job_t &J = jobs[i];
+        if (J.tiles < 0 || J.rows < 1 || J.n_ch < 0 || J.n_ch > J.rows || (J.act != 0 && J.act != 1)) return ESR_EINVAL;
+        if (J.tiles == 0) continue;
+        if (!J.z || !J.out) return ESR_EINVAL;
+        if (J.bwd) {
+            if (!J.g_tile && !J.src && !J.pt1) return ESR_EINVAL;
+            if (J.src && (J.src_c < 1 || J.n_src < 0)) return ESR_EINVAL;
+            for (int e = 0; e < 3; ++e)
+                if (J.pt1 && J.ex[e] && (J.ex_c[e] < 1 || J.ex_col0[e] < 0)) return ESR_EINVAL;
+        }
+        B.job[B.n++] = J;
+        const int64_t tot = (int64_t)J.tiles * J.rows * 32;
+        most = tot > most ? tot : most;
+    }
+    if (B.n == 0) return 0;
+    act_batch_kernel<<<dim3(esr_grid_for(most, 256, 1024), B.n), 256, 0, esr_stream(stream)>>>(B);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_pair_loss_batch(const esr_pair_job_t *jobs, int32_t n_jobs, float *loss, void *stream)
+{
+    if (n_jobs < 0 || n_jobs > ESR_PAIR_MAX_JOBS || (n_jobs > 0 && (!jobs || !loss))) return ESR_EINVAL;
+    PairBatch B = {};
+    B.loss = loss;
+    int64_t most = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const esr_pair_job_t &J = jobs[i];
+        if (J.rows < 0 || J.cols < 1 || (J.kind != 0 && J.kind != 1)) return ESR_EINVAL;
+        if (J.rows == 0) continue;
+        if (!J.a) return ESR_EINVAL;
+        B.job[B.n++] = J;
+        most = J.rows * J.cols > most ? J.rows * J.cols : most;
+    }
+    if (B.n == 0) return 0;
+    pair_loss_batch_kernel<<<dim3(esr_grid_for(most, 256, 128), B.n), 256, 0, esr_stream(stream)>>>(B);
     ESR_CHECK_LAUNCH();
     return 0;
 }

@@ -394,6 +394,57 @@ class LtsEngine(FineEngine):
                           _lib.ptr(o), self._s())
         return o
 
+    def _act_batch(self, name, jobs):
+        """One launch for up to four activation jobs (esr_act_batch).  job: dict(P, z, out, rows, n_ch, act[, tiles][, bwd_g]
+        [, src, inv][, pt1, ex]) -- ``bwd_g``: tile-major upstream gradient; ``src`` [n, c] row-major gradient rows
+        (through ``inv``: slot -> row, or identity); ``ex``: list of ([P, c] tensor, first row) added at the slots
+        ``pt1`` marks.  Returns the output buffers."""
+        arr = (_lib.EsrActJob * len(jobs))()
+        outs, keep, n = [], [], 0
+        for jd in jobs:
+            P = jd["P"]
+            tiles = P.tiles_all if jd.get("tiles") is None else jd["tiles"]
+            o = P.buf(jd["out"], jd["rows"])
+            outs.append(o)
+            if not tiles:
+                continue
+            jb = arr[n]
+            n += 1
+            jb.z, jb.out = P.bufs[jd["z"]].data_ptr(), o.data_ptr()
+            jb.tiles, jb.rows, jb.n_ch, jb.act = tiles, jd["rows"], jd["n_ch"], jd["act"]
+            bwd = any(k in jd for k in ("bwd_g", "src", "ex"))
+            jb.bwd = 1 if bwd else 0
+            if jd.get("bwd_g") is not None:
+                jb.g_tile = jd["bwd_g"].data_ptr()
+            if jd.get("src") is not None:
+                src = jd["src"].contiguous()
+                keep.append(src)
+                jb.src, jb.src_c, jb.n_src = src.data_ptr(), src.shape[1], src.shape[0]
+                if jd.get("inv") is not None:
+                    jb.inv = jd["inv"].data_ptr()
+            if jd.get("ex"):
+                jb.pt1 = jd["pt1"].data_ptr()
+                for e, (t, col0) in enumerate(jd["ex"]):
+                    t = t.contiguous()
+                    keep.append(t)
+                    jb.ex[e], jb.ex_c[e], jb.ex_col0[e] = t.data_ptr(), (t.shape[1] if t.dim() > 1 else 1), col0
+        if n:
+            self._run(name, self.L.esr_act_batch, arr, n, self._s())
+        return outs
+
+    def _gather_batch(self, jobs):
+        """One launch for up to four esr_lts_gather_rows jobs: (src, tile_rows, stride, col0, n_ch, perm, n) -> outputs."""
+        arr = (_lib.EsrGatherJob * len(jobs))()
+        outs = []
+        for jb, (src, tile_rows, stride, col0, n_ch, perm, n) in zip(arr, jobs):
+            out = torch.empty(n, n_ch, device=self.device)
+            outs.append(out)
+            jb.src, jb.tile_rows, jb.row_stride, jb.col0, jb.n_ch = src.data_ptr(), tile_rows, stride, col0, n_ch
+            jb.perm = perm.data_ptr() if perm is not None else None
+            jb.n, jb.out = n, out.data_ptr()
+        self._run("lts_gather_rows", self.L.esr_lts_gather_rows_batch, arr, len(jobs), self._s())
+        return outs
+
     def _feat_bwd(self, P: Pass, scene, sources, grad_sdf, dsdf_extra=None, dsdf_out=None, grad4=None, grad4_mode=0):
         if not P.tiles_all:
             return
@@ -416,8 +467,9 @@ class LtsEngine(FineEngine):
         csum = torch.cumsum(cnt3, 0, dtype=torch.int64)
         perm = torch.empty(m3, dtype=torch.long, device=dev)
         rec_ray = torch.empty(T * 32, dtype=torch.long, device=dev)
-        self._run("lts_ref_order", self.L.esr_lts_ref_order, _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(cnt3), _lib.ptr(off3),
-                  _lib.ptr(csum), T * 32, _lib.ptr(perm), _lib.ptr(rec_ray), self._s())
+        self.inv_order = torch.empty(T * 32, dtype=torch.int32, device=dev)      # slot -> rank in reference order (-1: padding)
+        self._run("lts_ref_order", self.L.esr_lts_ref_order_inv, _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(cnt3), _lib.ptr(off3),
+                  _lib.ptr(csum), T * 32, _lib.ptr(perm), _lib.ptr(rec_ray), _lib.ptr(self.inv_order), self._s())
         P0.keep += [csum]
         return perm, rec_ray
 
@@ -741,8 +793,8 @@ class LtsEngine(FineEngine):
         # material heads on every sample
         self._net_fwd(P0, "brdf", KIND_BRDF, 96, 0, T)
         self._net_fwd(P0, "emit", KIND_EMIT, 88, 0, T)
-        self._act(P0, "brdf.z", "brdf.a", 8, 5, ACT_SIGMOID)
-        self._act(P0, "emit.z", "emit.a", 4, 3, ACT_SOFTPLUS)
+        self._act_batch("act_fwd", [dict(P=P0, z="brdf.z", out="brdf.a", rows=8, n_ch=5, act=ACT_SIGMOID),
+                                    dict(P=P0, z="emit.z", out="emit.a", rows=4, n_ch=3, act=ACT_SOFTPLUS)])
         self._run("composite3_fwd(emit)", L.esr_composite3_fwd, _lib.ptr(P0.bufs["emit.a"]), 4,
                   _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(P0.bufs["rec_w"]), T, _lib.ptr(emit_m), s)
 
@@ -783,10 +835,10 @@ class LtsEngine(FineEngine):
         eps_grads = bool(cfg.get("eps_grads", True))      # keep activations for d/d(emit_eps, brdf_eps)
         self._net_fwd(P3, "emit", KIND_EMIT, 88, 0, T3, save=eps_grads)
         self._net_fwd(P3, "brdf", KIND_BRDF, 96, 0, T3, save=eps_grads)
-        self._act(P3, "emit.z", "emit.a", 4, 3, ACT_SOFTPLUS)
-        self._act(P3, "brdf.z", "brdf.a", 8, 5, ACT_SIGMOID)
-        emit_eps = self._gather_rows(P3.bufs["emit.a"], 4, 0, 0, 3, None, m3)
-        brdf_eps = self._gather_rows(P3.bufs["brdf.a"], 8, 0, 0, 5, None, m3)
+        self._act_batch("act_fwd", [dict(P=P3, z="emit.z", out="emit.a", rows=4, n_ch=3, act=ACT_SOFTPLUS),
+                                    dict(P=P3, z="brdf.z", out="brdf.a", rows=8, n_ch=5, act=ACT_SIGMOID)])
+        emit_eps, brdf_eps = self._gather_batch([(P3.bufs["emit.a"], 4, 0, 0, 3, None, m3),
+                                                 (P3.bufs["brdf.a"], 8, 0, 0, 5, None, m3)])
 
 
         # ---- light-transport segment
@@ -807,17 +859,21 @@ class LtsEngine(FineEngine):
         if um_rays.dtype not in (torch.bool, torch.uint8):
             um_rays = um_rays.to(torch.uint8)
         um_rays = um_rays.contiguous()
+        pt1 = self._z(T * 32, dtype=torch.int32, device=dev)     # slot -> surface point + 1 (the backward's gathers)
         gp = _lib.EsrLtsGather()
         gp.n_pts = Pn
         for k, v in dict(jp=jp, ray64=rec_ray, pts_all=pts_all, eg=eg, rec_sdf=P0.bufs["rec_sdf"], viewdirs=viewdirs,
                          brdf_a=P0.bufs["brdf.a"], emit_a=P0.bufs["emit.a"], umask_rays=um_rays, pts2=pts2, vd2=vd2, sdf2=sdf2,
-                         normal=normal_p, base=base_p, rough=rough_p, metal=metal_p, emis=emis_p, umask=umask_p).items():
+                         normal=normal_p, base=base_p, rough=rough_p, metal=metal_p, emis=emis_p, umask=umask_p, pt1=pt1).items():
             setattr(gp, k, v.data_ptr())
         self._run("lts_gather_points", L.esr_lts_gather_points, C.byref(gp), s)
+        ctx.t.update(pt1=pt1)
         pts_p, view_p, sdf_p = pts2[:Pn], vd2[:Pn], sdf2[:Pn]
+        # hemisphere directions + the secondary rays' origins / directions + the random view direction (vd2's second half)
         dirs_all = torch.empty(Pn, R + 1, 3, device=dev)
-        self._run("lts_dirs", L.esr_lts_dirs, _lib.ptr(raw), _lib.ptr(normal_p), Pn, R + 1, _lib.ptr(dirs_all), s)
-        torch.neg(dirs_all[:, R], out=vd2[Pn:])                  # v_rand
+        o2, d2 = torch.empty(Pn * R, 3, device=dev), torch.empty(Pn * R, 3, device=dev)
+        self._run("lts_dirs", L.esr_lts_dirs_rays, _lib.ptr(raw), _lib.ptr(normal_p), _lib.ptr(pts_p), Pn, R + 1,
+                  _lib.ptr(dirs_all), _lib.ptr(o2), _lib.ptr(d2), C.c_void_p(vd2.data_ptr() + Pn * 3 * 4), s)
         # (a) radiance predicted by the nets at the points, camera direction and random direction
         P1 = self.pts
         at_pts = {}
@@ -828,15 +884,13 @@ class LtsEngine(FineEngine):
             T1 = P1.tiles_all
             self._net_fwd(P1, "off", KIND_RADIANCE, 0, 0, T1)
             self._net_fwd(P1, "emo", KIND_RADIANCE, 88, 0, T1)
-            self._act(P1, "off.z", "off.a", 4, 3, ACT_SOFTPLUS)
-            self._act(P1, "emo.z", "emo.a", 4, 3, ACT_SOFTPLUS)
-            at_pts["off"] = self._gather_rows(P1.bufs["off.a"], 4, 0, 0, 3, None, 2 * Pn)
-            at_pts["emo"] = self._gather_rows(P1.bufs["emo.a"], 4, 0, 0, 3, None, 2 * Pn)
+            self._act_batch("act_fwd", [dict(P=P1, z="off.z", out="off.a", rows=4, n_ch=3, act=ACT_SOFTPLUS),
+                                        dict(P=P1, z="emo.z", out="emo.a", rows=4, n_ch=3, act=ACT_SOFTPLUS)])
+            at_pts["off"], at_pts["emo"] = self._gather_batch([(P1.bufs["off.a"], 4, 0, 0, 3, None, 2 * Pn),
+                                                               (P1.bufs["emo.a"], 4, 0, 0, 3, None, 2 * Pn)])
         # (b) incoming radiance along the secondary rays; (a) is enqueued behind the march's count + plan, so the device
         # works on it while the host waits for the plan header and enqueues the fill
         P2 = self.sec
-        o2 = pts_p.repeat_interleave(R, 0).contiguous()
-        d2 = dirs_all[:, :R].reshape(Pn * R, 3).contiguous()
         em2 = self._z(Pn * R, dtype=torch.int64, device=dev)
         _, off3_2, last2 = self._march(P2, scene2, o2, d2, em2, grids["mask"], sdf, viewdirs=d2, between=points_pass)
         off_pt, emo_pt = at_pts["off"], at_pts["emo"]
@@ -848,8 +902,8 @@ class LtsEngine(FineEngine):
             self._features(P2, scene2)
             self._net_fwd(P2, "off", KIND_RADIANCE, 0, 0, T2)
             self._net_fwd(P2, "emo", KIND_RADIANCE, 88, 0, T2)
-            self._act(P2, "off.z", "off.a", 4, 3, ACT_SOFTPLUS)
-            self._act(P2, "emo.z", "emo.a", 4, 3, ACT_SOFTPLUS)
+            self._act_batch("act_fwd", [dict(P=P2, z="off.z", out="off.a", rows=4, n_ch=3, act=ACT_SOFTPLUS),
+                                        dict(P=P2, z="emo.z", out="emo.a", rows=4, n_ch=3, act=ACT_SOFTPLUS)])
             for nm, dst in (("off.a", off_m), ("emo.a", emo_m)):
                 self._run("composite3_fwd", L.esr_composite3_fwd, _lib.ptr(P2.bufs[nm]), 4, _lib.ptr(P2.bufs["rec_ray"]),
                           _lib.ptr(P2.bufs["rec_w"]), T2, _lib.ptr(dst), s)
@@ -868,15 +922,18 @@ class LtsEngine(FineEngine):
         ctx.t.update(held=held, lts_args=a, off3_2=off3_2, o2=o2, d2=d2, eg=eg, pts_all=pts_all)
 
         um = batch["uncert_masks"]
+        r_normal, r_normal_eps, r_emit, r_brdf = self._gather_batch([
+            (eg, 0, 4, 1, 3, perm, m3), (eg_eps, 0, 4, 1, 3, perm, m3),
+            (P0.bufs["emit.a"], 4, 0, 0, 3, perm, m3), (P0.bufs["brdf.a"], 8, 0, 0, 5, perm, m3)])
         out = {
             "etc/alphainv_cum": last, "srgb/rgb": srgb, "lin/rgb": lin_m,
             "lin/pbr/off": off_pt, "lin/pbr/off_hat": off_hat, "lin/pbr/emo": emo_pt, "lin/pbr/emo_hat": emo_hat,
             "emit_marched": emit_m,
-            "etc/normal": self._gather_rows(eg, 0, 4, 1, 3, perm, m3), "etc/normal_eps": self._gather_rows(eg_eps, 0, 4, 1, 3, perm, m3),
-            "etc/emit": self._gather_rows(P0.bufs["emit.a"], 4, 0, 0, 3, perm, m3), "etc/emit_eps": emit_eps,
-            "etc/brdf": self._gather_rows(P0.bufs["brdf.a"], 8, 0, 0, 5, perm, m3), "etc/brdf_eps": brdf_eps,
+            "etc/normal": r_normal, "etc/normal_eps": r_normal_eps,
+            "etc/emit": r_emit, "etc/emit_eps": emit_eps,
+            "etc/brdf": r_brdf, "etc/brdf_eps": brdf_eps,
         }
-        ctx.t.update(um=um, pts_e=pts_e, eps_grads=eps_grads, m3=m3)
+        ctx.t.update(um=um, pts_e=pts_e, eps_grads=eps_grads, m3=m3, inv=self.inv_order)
         return ctx, out
 
     # ------------------------------------------------------------------ backward
@@ -964,8 +1021,9 @@ class LtsEngine(FineEngine):
                           _lib.ptr(P2.bufs["rec_ray"]), _lib.ptr(P2.bufs["rec_w"]), T2, 2 if i else 0, _lib.ptr(da),
                           _lib.ptr(dw2), s)      # (second call: fresh dv, accumulated dweight)
             src = []
-            for nm, crow, gon in (("off", 0, grads["off"]), ("emo", 88, grads["emo"])):
-                dz = self._act(P2, f"{nm}.z", f"{nm}.dz", 4, 3, ACT_SOFTPLUS, bwd_g=P2.bufs[f"{nm}.da"])
+            dzs = self._act_batch("act_bwd", [dict(P=P2, z=f"{nm}.z", out=f"{nm}.dz", rows=4, n_ch=3, act=ACT_SOFTPLUS,
+                                                   bwd_g=P2.bufs[f"{nm}.da"]) for nm in ("off", "emo")])
+            for (nm, crow, gon), dz in zip((("off", 0, grads["off"]), ("emo", 88, grads["emo"])), dzs):
                 dX = self._net_bwd(P2, nm, KIND_RADIANCE, crow, 0, T2, dz, grads[f"{nm}_w"], grads[f"{nm}_b"])
                 src.append((dX, None, gon, 0, T2))
             # the secondary march's value-tap gradients of the recorded samples ride on the feature backward's window
@@ -980,26 +1038,16 @@ class LtsEngine(FineEngine):
         # ---- radiance at the points
         T1 = P1.tiles_all
         src = []
-        for nm, crow, key, gon in (("off", 0, "lin/pbr/off", grads["off"]), ("emo", 88, "lin/pbr/emo", grads["emo"])):
-            ga = self._z(T1 * 32, 3, device=dev)
-            ga[: 2 * Pn] = zero(key, (2 * Pn, 3))
-            gt = P1.from_rowmajor(f"{nm}.ga", 4, ga)
-            dz = self._act(P1, f"{nm}.z", f"{nm}.dz", 4, 3, ACT_SOFTPLUS, bwd_g=gt)
+        # the gradient rows [2P, 3] of the two heads at the points go straight into the activation's backward (slot k <- row k)
+        dzs = self._act_batch("act_bwd", [dict(P=P1, z=f"{nm}.z", out=f"{nm}.dz", rows=4, n_ch=3, act=ACT_SOFTPLUS,
+                                               src=zero(key, (2 * Pn, 3))) for nm, key in (("off", "lin/pbr/off"), ("emo", "lin/pbr/emo"))])
+        for (nm, crow, gon), dz in zip((("off", 0, grads["off"]), ("emo", 88, grads["emo"])), dzs):
             dX = self._net_bwd(P1, nm, KIND_RADIANCE, crow, 0, T1, dz, grads[f"{nm}_w"], grads[f"{nm}_b"])
             src.append((dX, None, gon, 0, T1))
         dsdf_pts = self._z(T1 * 32, device=dev)
         self._feat_bwd(P1, ctx.scene, src, grads["sdf"], dsdf_out=dsdf_pts)
 
         # ---- primary pass: assemble per-sample head gradients in compact order
-        def to_compact(key, c):
-            out = self._z(T * 32, c, device=dev)
-            if g.get(key) is not None:
-                out[perm] = g[key]
-            return out
-        d_brdf = to_compact("etc/brdf", 5)
-        d_brdf.index_add_(0, jp, torch.cat([d["d_base"], d["d_rough"][:, None], d["d_metal"][:, None]], 1))
-        d_emit = to_compact("etc/emit", 3)
-        d_emit.index_add_(0, jp, d["d_emission"])
         dsdf_extra = self._z(T * 32, device=dev)
         dsdf_extra.index_add_(0, jp, dsdf_pts[:Pn] + dsdf_pts[Pn: 2 * Pn])
         # composites
@@ -1010,10 +1058,12 @@ class LtsEngine(FineEngine):
         self._run("composite_bwd", L.esr_fine_composite_bwd, _lib.ptr(g_srgb), _lib.ptr(g_lin), _lib.ptr(P0.bufs["rgb"]),
                   _lib.ptr(P0.bufs["lin"]), _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(P0.bufs["rec_w"]), T, _lib.ptr(dweight),
                   _lib.ptr(P0.buf("tone.dz", 4)), s)
-        d_emit_t = P0.from_rowmajor("emit.da", 4, d_emit)
+        # d(emission head): the composite's share lands in a FRESH tile-major buffer (mode 2: dv written, dweight
+        # accumulated); the reference-order rows of etc/emit and the rendering equation's d_emission at the surface points
+        # are gathered inside the activation's backward below (esr_act_batch) -- no index_put / index_add_ / permute-copy
+        d_emit_t = P0.buf("emit.da", 4)
         self._run("composite3_bwd(emit)", L.esr_composite3_bwd, _lib.ptr(g_em), _lib.ptr(P0.bufs["emit.a"]), 4,
-                  _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(P0.bufs["rec_w"]), T, 3, _lib.ptr(d_emit_t), _lib.ptr(dweight), s)
-        d_brdf_t = P0.from_rowmajor("brdf.da", 8, d_brdf)
+                  _lib.ptr(P0.bufs["rec_ray"]), _lib.ptr(P0.bufs["rec_w"]), T, 2, _lib.ptr(d_emit_t), _lib.ptr(dweight), s)
         # tonemapper -> radiance heads
         dXt = self._net_bwd(P0, "tone", KIND_TONEMAP, 0, 0, T, P0.bufs["tone.dz"], grads["tone_w"], grads["tone_b"])
         self._run("lts_tone_in_bwd", L.esr_lts_tone_in_bwd, _lib.ptr(dXt), _lib.ptr(P0.bufs["Xt"]), _lib.ptr(g_lin), _lib.ptr(P0.bufs["lin"]),
@@ -1023,8 +1073,12 @@ class LtsEngine(FineEngine):
                 grads["off"], grads["off"], 0, T),
                (self._net_bwd(P0, "emo", KIND_RADIANCE, 88, 0, Ton, P0.bufs["emo.dz"], grads["emo_w"], grads["emo_b"]),
                 grads["emo"], grads["emo"], 0, Ton)]
-        dzb = self._act(P0, "brdf.z", "brdf.dz", 8, 5, ACT_SIGMOID, bwd_g=d_brdf_t)
-        dze = self._act(P0, "emit.z", "emit.dz", 4, 3, ACT_SOFTPLUS, bwd_g=d_emit_t)
+        inv, pt1 = ctx.t["inv"], ctx.t["pt1"]
+        dzb, dze = self._act_batch("act_bwd", [
+            dict(P=P0, z="brdf.z", out="brdf.dz", rows=8, n_ch=5, act=ACT_SIGMOID, src=g.get("etc/brdf"), inv=inv, pt1=pt1,
+                 ex=[(d["d_base"], 0), (d["d_rough"], 3), (d["d_metal"], 4)]),
+            dict(P=P0, z="emit.z", out="emit.dz", rows=4, n_ch=3, act=ACT_SOFTPLUS, bwd_g=d_emit_t, src=g.get("etc/emit"),
+                 inv=inv, pt1=pt1, ex=[(d["d_emission"], 0)])])
         src.append((self._net_bwd(P0, "brdf", KIND_BRDF, 96, 0, T, dzb, grads["brdf_w"], grads["brdf_b"]),
                     grads["brdf"], grads["brdf"], 0, T))
         src.append((self._net_bwd(P0, "emit", KIND_EMIT, 88, 0, T, dze, grads["emit_w"], grads["emit_b"]),
@@ -1051,17 +1105,13 @@ class LtsEngine(FineEngine):
         P3, m3 = self.epsp, ctx.t["m3"]
         T3 = P3.tiles_all
         src = []
-        for key, nm, kind, crow, rows, nch, act, ggrid in (
-                ("etc/emit_eps", "emit", KIND_EMIT, 88, 4, 3, ACT_SOFTPLUS, grads["emo"]),
-                ("etc/brdf_eps", "brdf", KIND_BRDF, 96, 8, 5, ACT_SIGMOID, grads["brdf"])):
-            if g.get(key) is None:
-                continue
-            if not ctx.t["eps_grads"]:
-                raise RuntimeError(f"gradient of {key} requested but the forward ran with eps_grads=False")
-            ga = self._z(T3 * 32, nch, device=dev)
-            ga[:m3] = g[key]
-            gt = P3.from_rowmajor(f"{nm}.ga", rows, ga)
-            dz = self._act(P3, f"{nm}.z", f"{nm}.dz", rows, nch, act, bwd_g=gt)
+        heads = [h for h in (("etc/emit_eps", "emit", KIND_EMIT, 88, 4, 3, ACT_SOFTPLUS, grads["emo"]),
+                             ("etc/brdf_eps", "brdf", KIND_BRDF, 96, 8, 5, ACT_SIGMOID, grads["brdf"])) if g.get(h[0]) is not None]
+        if heads and not ctx.t["eps_grads"]:
+            raise RuntimeError(f"gradient of {heads[0][0]} requested but the forward ran with eps_grads=False")
+        dzs = self._act_batch("act_bwd", [dict(P=P3, z=f"{nm}.z", out=f"{nm}.dz", rows=rows, n_ch=nch, act=act, tiles=T3,
+                                               src=g[key]) for key, nm, _, _, rows, nch, act, _ in heads]) if heads else []
+        for (key, nm, kind, crow, rows, nch, act, ggrid), dz in zip(heads, dzs):
             dX = self._net_bwd(P3, nm, kind, crow, 0, T3, dz, grads[f"{nm}_w"], grads[f"{nm}_b"])
             src.append((dX, None, ggrid, 0, T3))
         if src:

@@ -25,6 +25,9 @@ CONFIGS = {
     "tiny": dict(n_rays=64, z=0.25, res=64),          # 32 samples, golden-vector size
     "small": dict(n_rays=512, z=0.25, res=128),       # 64 samples
     "g16": dict(n_rays=48, z=0.25, res=32),           # 16 samples, committed golden fixtures
+    # the fine stage's STARTING resolution class (cfg/app/fine.yaml:41-43: 160^3 until step 15000, then 256^3): the slab
+    # at 160 voxels along x -- world [160,160,40]; tests/test_gpu_scale_event.py scales it to [256,256,64] mid-run
+    "g160": dict(n_rays=1024, z=0.25, res=160),
     # production-size grid (cfg/app/fine.yaml:41-43: the fine stage ends at 256^3): the cube (-1,-1,-1)..(1,1,1) at 256
     # voxels per axis; the mask cache's box is the slab |z| < 0.25 (the occupied part of a real scene is a fraction of
     # its box), so an axis-parallel ray walks 512 steps through the box and keeps C2's 128 samples

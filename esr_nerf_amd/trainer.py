@@ -368,6 +368,7 @@ class LtsStep:
         self._flat = None
         self._sync = None
         self._sync_mode = os.environ.get("ESR_GRAD_SYNC", "auto")
+        self._pair_jobs = []
         _warn_hw_queues(process_group)
 
     def close(self):
@@ -430,11 +431,28 @@ class LtsStep:
         rows = a.shape[0]
         cols = a.numel() // max(rows, 1)
         if rows:
-            eng._run("pair_loss", eng.L.esr_pair_loss_fwd_bwd, _lib.ptr(a), _lib.ptr(b.contiguous() if b is not None else None),
-                     C.c_int64(rows), cols, _lib.ptr(row_mask), mask_value, _lib.ptr(count), kind,
-                     C.c_float(w_value * scale), C.c_float(w_a * scale), C.c_float(w_b * scale), _lib.ptr(loss),
-                     _lib.ptr(ga), _lib.ptr(gb), eng._s())
+            # collected; ONE launch for all terms of the step (_pair_flush -> esr_pair_loss_batch)
+            b = b.contiguous() if b is not None else None
+            self._pair_jobs.append((a, b, rows, cols, row_mask, mask_value, count, kind, w_value * scale, w_a * scale,
+                                    w_b * scale, ga, gb))
         return ga, gb
+
+    def _pair_flush(self, eng, loss):
+        import ctypes as C
+        from . import _lib
+        jobs, self._pair_jobs = self._pair_jobs, []
+        if not jobs:
+            return
+        arr = (_lib.EsrPairJob * len(jobs))()
+        for jb, (a, b, rows, cols, row_mask, mask_value, count, kind, wv, wa, wb, ga, gb) in zip(arr, jobs):
+            jb.a, jb.b = a.data_ptr(), (b.data_ptr() if b is not None else None)
+            jb.rows, jb.cols = rows, cols
+            jb.row_mask = row_mask.data_ptr() if row_mask is not None else None
+            jb.mask_value = mask_value
+            jb.count_dev = count.data_ptr() if count is not None else None
+            jb.kind, jb.w_value, jb.w_a, jb.w_b = kind, wv, wa, wb
+            jb.ga, jb.gb = ga.data_ptr(), (gb.data_ptr() if gb is not None else None)
+        eng._run("pair_loss", eng.L.esr_pair_loss_batch, arr, len(jobs), _lib.ptr(loss), eng._s())
 
     @torch.no_grad()
     def forward_loss_backward(self, batch: Dict[str, torch.Tensor], s_val: float, global_rays: Optional[int] = None,
@@ -497,6 +515,7 @@ class LtsStep:
         wn = t.weight_normal_smooth
         g["etc/normal"], g["etc/normal_eps"] = self._pair(eng, loss, out["etc/normal"], out["etc/normal_eps"], 1, wn, wn,
                                                           wn, scale)
+        self._pair_flush(eng, loss)       # the step's two-operand loss terms: one launch
         if G is None:                     # (degenerate: the engine did not run the prelude)
             G = self._alloc_grads(last.device)
         names = self._param_names()

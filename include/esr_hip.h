@@ -562,6 +562,7 @@ typedef struct esr_lts_gather {
     int32_t n_pts;
     float *pts2, *vd2, *sdf2, *normal, *base, *rough, *metal, *emis;
     uint8_t *umask;
+    int32_t *pt1;      /* optional: pt1[jp[p]] = p + 1 (int32 [n_slots], zeroed by the caller): slot -> surface point */
 } esr_lts_gather_t;
 int esr_lts_gather_points(const esr_lts_gather_t *g, void *stream);
 
@@ -621,6 +622,72 @@ int esr_emit_edit(float *emit, const int64_t *em_modes, const float *em_intensit
  *     (esrnerf.py:751-757): dz_off on all tiles, dz_emo on the on-tiles.
  *  esr_sample_points: world positions of the march records (padding -> 0).
  */
+/*
+ * Round 4: the same glue with FEWER launches (a light-transport step issued ~100 kernels shorter than 10 us; what they
+ * cost is the host's enqueue time, tools/host_profile.py).  Batched forms: one launch, blockIdx.y = job.
+ *
+ * esr_act_batch: up to ESR_ACT_MAX_JOBS activation jobs.  A forward job is esr_act_fwd.  A backward job computes
+ *   dz[slot][c] = act'(z) * ( g_tile[slot][c]                                  (tile-major, optional)
+ *                           + src[k][c]       k = inv ? inv[slot] : slot, if 0 <= k < n_src and c < src_c   (optional)
+ *                           + ex_i[p][c - ex_col0[i]]   p = pt1[slot] - 1 >= 0, for up to three extras       (optional) )
+ *   i.e. the reference-order gradient rows of a head (`src`, scattered back through the inverse of esr_lts_ref_order's
+ *   permutation), the rendering equation's gradients at the chosen surface points (`ex`, through pt1 of
+ *   esr_lts_gather_points) and a tile-major upstream gradient, summed and multiplied by the activation's derivative in
+ *   one pass -- the reference's lines are index_put / index_add_ / cat on [M3, C] tensors followed by the activation's
+ *   autograd (app/fine/model/esrnerf.py:770-806, backward of :792-851).
+ */
+#define ESR_ACT_MAX_JOBS 4
+typedef struct esr_act_job {
+    const float *z;            /* [tiles, rows, 32] pre-activations                                        */
+    const float *g_tile;       /* backward: tile-major upstream gradient or NULL                           */
+    float *out;                /* [tiles, rows, 32]                                                        */
+    int32_t tiles, rows, n_ch, act, bwd;
+    const float *src;          /* backward: [n_src, src_c] row-major or NULL                               */
+    int32_t src_c, n_src;
+    const int32_t *inv;        /* slot -> row of src (-1: none); NULL: identity                            */
+    const int32_t *pt1;        /* slot -> surface point + 1 (0: none) or NULL                              */
+    const float *ex[3];        /* [P, ex_c[i]] row-major or NULL                                           */
+    int32_t ex_c[3], ex_col0[3];
+} esr_act_job_t;
+int esr_act_batch(const esr_act_job_t *jobs, int32_t n_jobs, void *stream);
+
+/* esr_lts_gather_rows for up to ESR_GATHER_MAX_JOBS (src, out) pairs in one launch. */
+#define ESR_GATHER_MAX_JOBS 4
+typedef struct esr_gather_job {
+    const float *src;
+    int32_t tile_rows, row_stride, col0, n_ch;
+    const int64_t *perm;
+    int32_t n;
+    float *out;
+} esr_gather_job_t;
+int esr_lts_gather_rows_batch(const esr_gather_job_t *jobs, int32_t n_jobs, void *stream);
+
+/* esr_pair_loss_fwd_bwd for up to ESR_PAIR_MAX_JOBS terms in one launch (all add into the same `loss`). */
+#define ESR_PAIR_MAX_JOBS 6
+typedef struct esr_pair_job {
+    const float *a, *b;
+    int64_t rows;
+    int32_t cols;
+    const uint8_t *row_mask;
+    int32_t mask_value;
+    const int32_t *count_dev;
+    int32_t kind;
+    float w_value, w_a, w_b;
+    float *ga, *gb;
+} esr_pair_job_t;
+int esr_pair_loss_batch(const esr_pair_job_t *jobs, int32_t n_jobs, float *loss, void *stream);
+
+/* esr_lts_ref_order that also writes the INVERSE: inv[j] = rank of compact slot j in the reference's order, -1 for a
+ * padding slot (inv: int32 [n_slots]). */
+int esr_lts_ref_order_inv(const int32_t *rec_ray, const int32_t *cnt3, const int32_t *off3, const int64_t *cnt3_cumsum,
+                          int32_t n_slots, int64_t *perm, int64_t *ray64, int32_t *inv, void *stream);
+
+/* esr_lts_dirs that also writes what the secondary march and the points pass read (esrnerf.py:565-591): the secondary
+ * rays' origins o2 [P * n_rays, 3] (pts[p] repeated), their directions d2 [P * n_rays, 3] (dirs[:, :n_rays]) and the
+ * random view direction v_rand [P, 3] = -dirs[:, n_rays]; pts [P, 3].  rays_plus_one = n_rays + 1. */
+int esr_lts_dirs_rays(const float *raw, const float *normal, const float *pts, int32_t n_pts, int32_t rays_plus_one,
+                      float *dirs, float *o2, float *d2, float *v_rand, void *stream);
+
 int esr_act_fwd(const float *z, int32_t tiles, int32_t rows, int32_t n_ch, int act, float *out, void *stream);
 int esr_act_bwd(const float *z, const float *g, int32_t tiles, int32_t rows, int32_t n_ch, int act,
                 float *dz, void *stream);

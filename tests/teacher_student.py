@@ -23,6 +23,20 @@ LRS_LTS = dict(LRS_FINE, brdf=0.1, brdfnet=0.003, emitnet=0.003, envmap=0.003)
 TVS = dict(sdf=0.1, smooth_grad=0.05)
 
 
+_TEACHER_CACHE: Dict[tuple, tuple] = {}
+
+
+def paired_stats(d) -> Dict[str, float]:
+    """mean, standard deviation and the 95 % confidence interval of the mean (Student t) of paired differences."""
+    d = np.asarray(list(d), dtype=np.float64)
+    n = len(d)
+    mean, sd = float(d.mean()), float(d.std(ddof=1)) if n > 1 else float("nan")
+    # two-sided 97.5 % quantile of Student's t with n-1 degrees of freedom (scipy is importable in this image)
+    from scipy import stats
+    half = float(stats.t.ppf(0.975, n - 1) * sd / math.sqrt(n)) if n > 1 else float("nan")
+    return dict(n=n, mean=mean, sd=sd, ci95_half_width=half, ci95=(mean - half, mean + half))
+
+
 def psnr(a: torch.Tensor, b: torch.Tensor) -> float:
     return -10.0 * math.log10(max(float(((a.double() - b.double()) ** 2).mean()), 1e-20))
 
@@ -188,10 +202,14 @@ def pdra_experiment(dtype: str, steps: int = 200, n_train: int = 6144, n_test: i
     from esr_nerf_amd.optimizer import create_optimizer_or_freeze_model
     from esr_nerf_amd.synthetic import slab_scene
     from esr_nerf_amd.trainer import LtsStep
-    sc = slab_scene("small", s_val=s_val, oblique=True, n_rays=n_train + n_test, seed=37)
-    rays = {k: v.cuda() for k, v in sc.batch.items() if k != "rgbs"}
-    teacher, _ = build_lts(sc, 100, 100, "f32", smooth_amp=0.6)
-    img = render_image(teacher, rays, s_val)
+    key = ("pdra", n_train, n_test, s_val)
+    if key not in _TEACHER_CACHE:          # the teacher's image is the same for every seed and dtype: rendered once per process
+        sc_ = slab_scene("small", s_val=s_val, oblique=True, n_rays=n_train + n_test, seed=37)
+        rays_ = {k: v.cuda() for k, v in sc_.batch.items() if k != "rgbs"}
+        teacher, _ = build_lts(sc_, 100, 100, "f32", smooth_amp=0.6)
+        _TEACHER_CACHE[key] = (sc_, rays_, render_image(teacher, rays_, s_val))
+        del teacher
+    sc, rays, img = _TEACHER_CACHE[key]
     train = {k: v[:n_train].contiguous() for k, v in rays.items()}
     train["rgbs"] = img[:n_train].contiguous()
     test = {k: v[n_train:].contiguous() for k, v in rays.items()}

@@ -24,7 +24,14 @@ ap.add_argument("--perturb", type=float, nargs=2, default=None, help="fine stage
 ap.add_argument("--weight-linear", type=float, default=None)
 ap.add_argument("--lattice", type=int, nargs=3, default=None)
 ap.add_argument("--noise-floor", action="store_true", help="also a second f32 run per seed")
+ap.add_argument("--seeds-range", type=int, default=None, help="seeds 0 .. N-1 (overrides --seeds)")
+ap.add_argument("--summary", default=None,
+                help="write paired statistics (bf16 - f32 and, with --noise-floor, f32 rerun - f32: mean, sd, 95 %% CI of the "
+                     "mean) and the per-seed scores to this JSON file")
 a = ap.parse_args()
+if a.seeds_range:
+    a.seeds = list(range(a.seeds_range))
+per_seed = []
 run = dict(fine=ts.fine_experiment, pdra=ts.pdra_experiment, finetune=ts.finetune_experiment)[a.stage]
 ev = sorted({0, a.steps // 4, a.steps // 2, 3 * a.steps // 4, a.steps})
 for seed in a.seeds:
@@ -51,3 +58,17 @@ for seed in a.seeds:
     if a.stage == "finetune":
         line += f"  | images f32 vs bf16: {ts.psnr(res['f32_img'], res['bf16_img']):.1f} dB"
     print(line, flush=True)
+    per_seed.append(dict(seed=seed, f32=res["f32"][a.steps], bf16=res["bf16"][a.steps],
+                         f32_rerun=res["f32b"][a.steps] if a.noise_floor else None, start=res["f32"][0]))
+if len(per_seed) > 1:
+    out = dict(stage=a.stage, steps=a.steps, seeds=len(per_seed),
+               bf16_minus_f32=ts.paired_stats(r["bf16"] - r["f32"] for r in per_seed),
+               mean_f32=sum(r["f32"] for r in per_seed) / len(per_seed), mean_bf16=sum(r["bf16"] for r in per_seed) / len(per_seed),
+               mean_gain_f32=sum(r["f32"] - r["start"] for r in per_seed) / len(per_seed))
+    if a.noise_floor:
+        out["f32rerun_minus_f32"] = ts.paired_stats(r["f32_rerun"] - r["f32"] for r in per_seed)
+    print(json.dumps({k: v for k, v in out.items()}), flush=True)
+    if a.summary:
+        out["per_seed"] = per_seed
+        with open(a.summary, "w") as f:
+            json.dump(out, f, indent=1)
