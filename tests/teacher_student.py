@@ -26,15 +26,16 @@ TVS = dict(sdf=0.1, smooth_grad=0.05)
 _TEACHER_CACHE: Dict[tuple, tuple] = {}
 
 
-def paired_stats(d) -> Dict[str, float]:
-    """mean, standard deviation and the 95 % confidence interval of the mean (Student t) of paired differences."""
+def paired_stats(d, conf: float = 0.95) -> Dict[str, float]:
+    """mean, standard deviation and the ``conf`` confidence interval of the mean (Student t) of paired differences
+    (keys keep the name ci95 whatever the level; ``conf`` is returned)."""
     d = np.asarray(list(d), dtype=np.float64)
     n = len(d)
     mean, sd = float(d.mean()), float(d.std(ddof=1)) if n > 1 else float("nan")
     # two-sided 97.5 % quantile of Student's t with n-1 degrees of freedom (scipy is importable in this image)
     from scipy import stats
-    half = float(stats.t.ppf(0.975, n - 1) * sd / math.sqrt(n)) if n > 1 else float("nan")
-    return dict(n=n, mean=mean, sd=sd, ci95_half_width=half, ci95=(mean - half, mean + half))
+    half = float(stats.t.ppf(0.5 + conf / 2.0, n - 1) * sd / math.sqrt(n)) if n > 1 else float("nan")
+    return dict(n=n, mean=mean, sd=sd, conf=conf, ci95_half_width=half, ci95=(mean - half, mean + half))
 
 
 def psnr(a: torch.Tensor, b: torch.Tensor) -> float:
@@ -133,19 +134,32 @@ def train_fine(student, train_rays: Dict[str, torch.Tensor], s_val: float, steps
 
 def fine_experiment(dtype: str, steps: int = 300, n_train: int = 12288, n_test: int = 4096, batch: int = 2048,
                     s_val: float = 40.0, seed: int = 0, eval_at=None, lrs=None, perturb=None,
-                    weight_linear: float = 0.1, lattice=(6, 6, 4)):
+                    weight_linear: float = 0.1, lattice=(6, 6, 4), jitter: float = 0.0):
     """Teacher (f32, smooth colour grids, MLP seed 100) -> image on n_train + n_test oblique rays of the `small` slab;
-    student (MLP seed 200 + seed, N(0, 0.1) colour grids) trained with ``dtype`` MLP operands.  Returns held-out PSNR."""
+    student (MLP seed 200 + seed, N(0, 0.1) colour grids) trained with ``dtype`` MLP operands.  Returns held-out PSNR.
+    ``jitter``: the student's initial MLP weights are multiplied by 1 + jitter * N(0, 1) -- with jitter = 1e-6, a
+    perturbation 4000 times smaller than one bf16 rounding step: a seed whose f32 outcome moves under it is bistable at
+    fp32-noise level, whatever the operand type (tests/test_gpu_psnr.py uses it to MEASURE which seeds bifurcate)."""
     from esr_nerf_amd.synthetic import slab_scene
-    sc = slab_scene("small", s_val=s_val, oblique=True, n_rays=n_train + n_test, seed=31)
-    rays = {k: v.cuda() for k, v in sc.batch.items() if k != "rgbs"}
-    teacher = build_fine(sc, 100, 100, "f32", smooth_amp=0.6, lattice=lattice)
-    img = render_image(teacher, rays, s_val)
+    key = ("fine", n_train, n_test, s_val, tuple(lattice))
+    if key not in _TEACHER_CACHE:          # the teacher's image is the same for every seed and dtype: rendered once per process
+        sc_ = slab_scene("small", s_val=s_val, oblique=True, n_rays=n_train + n_test, seed=31)
+        rays_ = {k: v.cuda() for k, v in sc_.batch.items() if k != "rgbs"}
+        teacher = build_fine(sc_, 100, 100, "f32", smooth_amp=0.6, lattice=lattice)
+        _TEACHER_CACHE[key] = (sc_, rays_, render_image(teacher, rays_, s_val))
+        del teacher
+    sc, rays, img = _TEACHER_CACHE[key]
     train = {k: v[:n_train].contiguous() for k, v in rays.items()}
     train["rgbs"] = img[:n_train].contiguous()
     test = {k: v[n_train:].contiguous() for k, v in rays.items()}
     if perturb is None:
         student = build_fine(sc, 200 + seed, 200 + seed, dtype)
+        if jitter:
+            gj = torch.Generator().manual_seed(900 + seed)
+            with torch.no_grad():
+                for name, p_ in student.named_parameters():
+                    if name.startswith(("off_rgbnet", "emo_rgbnet", "tonemapper")):
+                        p_.mul_((1.0 + jitter * torch.randn(p_.shape, generator=gj)).to(p_.device))
     else:
         # the teacher's own parameters, perturbed: colour grids + N(0, perturb[0]), MLP weights x (1 + N(0, perturb[1]))
         student = build_fine(sc, 100, 100, dtype, smooth_amp=0.6)
