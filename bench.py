@@ -106,7 +106,7 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not bracket kernels with HIP events (drops the roofline object)")
     ap.add_argument("--no-other", action="store_true",
-                    help="headline run only: skip the `other_workloads` key (C3 bf16, C4 lts f32, C5 pdra bf16; 10 steps each, "
+                    help="headline run only: skip the `other_workloads` key (C3 bf16, C4 lts f32, C5 pdra bf16; 30 steps each, "
                          "one child process per workload after the headline has been measured)")
     return ap.parse_args()
 
@@ -321,8 +321,9 @@ OTHER_WORKLOADS = (("C3_fine_bf16", ["--config", "C3", "--dtype", "bf16"]),
 
 
 def other_workloads(budget_s=150.0):
-    """The other single-GPU BASELINE configs, each timed by a CHILD process of this script (10 steps after 6 warm-up
-    steps, no CPU baseline, no optimizer section) AFTER the headline has been measured: {name: {rays_per_s, ms_per_step,
+    """The other single-GPU BASELINE configs, each timed by a CHILD process of this script (30 steps after 10 warm-up
+    steps -- with 10 + 6 the first timed steps still carried the warm-up's workspace growth and clock ramp: C3 bf16 read
+    1.78 ms against 1.64 ms of the 50-step run -- no CPU baseline, no optimizer section) AFTER the headline has been measured: {name: {rays_per_s, ms_per_step,
     dtype, roofline fractions}}.  A child that fails or runs out of the time budget is reported as such, never guessed."""
     import subprocess
     out, t_start = {}, time.perf_counter()
@@ -331,7 +332,7 @@ def other_workloads(budget_s=150.0):
         if left < 20.0:
             out[name] = {"skipped": "time budget of the default run spent"}
             continue
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *args, "--steps", "10", "--warmup", "6", "--no-cpu-baseline",
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *args, "--steps", "30", "--warmup", "10", "--no-cpu-baseline",
                "--no-optimizer", "--no-other"]
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=left, cwd=ROOT)

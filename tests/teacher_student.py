@@ -137,9 +137,9 @@ def fine_experiment(dtype: str, steps: int = 300, n_train: int = 12288, n_test: 
                     weight_linear: float = 0.1, lattice=(6, 6, 4), jitter: float = 0.0):
     """Teacher (f32, smooth colour grids, MLP seed 100) -> image on n_train + n_test oblique rays of the `small` slab;
     student (MLP seed 200 + seed, N(0, 0.1) colour grids) trained with ``dtype`` MLP operands.  Returns held-out PSNR.
-    ``jitter``: the student's initial MLP weights are multiplied by 1 + jitter * N(0, 1) -- with jitter = 1e-6, a
-    perturbation 4000 times smaller than one bf16 rounding step: a seed whose f32 outcome moves under it is bistable at
-    fp32-noise level, whatever the operand type (tests/test_gpu_psnr.py uses it to MEASURE which seeds bifurcate)."""
+    ``jitter``: the student's initial MLP weights are multiplied by 1 + jitter * N(0, 1), once.  With jitter = 1e-3 (the
+    rms size of one bf16 rounding) a seed whose f32 outcome moves by more than the bar cannot resolve a bf16-vs-f32
+    question at that bar, whatever the operand type (tests/test_gpu_psnr.py uses it to MEASURE which seeds bifurcate)."""
     from esr_nerf_amd.synthetic import slab_scene
     key = ("fine", n_train, n_test, s_val, tuple(lattice))
     if key not in _TEACHER_CACHE:          # the teacher's image is the same for every seed and dtype: rendered once per process
