@@ -346,7 +346,7 @@ def other_workloads(budget_s=150.0):
                          "warmup": d["warmup"], "workload": d["config"]["workload"],
                          "roofline": {k: rl.get(k) for k in ("bound", "frac", "mfma_frac", "hbm_frac") if k in rl},
                          "whole_step_frac": (rl.get("whole_step") or {}).get("frac"),
-                         "dispatches_per_step": d.get("dispatches_per_step")}
+                         "c_abi_launches_per_step": d.get("c_abi_launches_per_step")}
         except subprocess.TimeoutExpired:
             out[name] = {"failed": f"timeout after {left:.0f} s"}
     return out
@@ -524,6 +524,7 @@ def main():
         import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize()
+    calls0 = getattr(eng, "n_calls", 0)
     t0 = time.perf_counter()
     for i_ in range(a.steps):
         loss, _ = one(i_)
@@ -532,6 +533,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    calls_per_step = (getattr(eng, "n_calls", 0) - calls0) / max(a.steps, 1)
     if pg is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -617,6 +619,9 @@ def main():
                 "parallelism": f"dp{world}",
             },
             "loss": float(loss),
+            # launches of this library's kernels per step (C-ABI calls; torch's own fills / copies / gathers come on top:
+            # tools/dispatches.sh counts every device dispatch from a rocprofv3 trace)
+            "c_abi_launches_per_step": calls_per_step,
         }
         if opt_ms is not None:
             out["optimizer_step"] = {"ms": opt_ms, "parameters": n_params, "kernel": "esr_adam_step (fused Adam, 28 B/param)",

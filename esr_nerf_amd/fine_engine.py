@@ -121,6 +121,7 @@ class FineEngine:
         self._timing = False
         self._only = None
         self._events = []
+        self.n_calls = 0
         self.overlap_wgrad = os.environ.get("ESR_OVERLAP_WGRAD", "1") != "0"
         # f32 engine: the three radiance forward passes of a step as ONE launch (esr_mlp_fwd_fine) and the two radiance
         # input-gradient passes as one (esr_mlp_dgrad_fine); ESR_MERGE_RAD=0 keeps the separate launches (A/B timing)
@@ -164,6 +165,7 @@ class FineEngine:
     def _run(self, name, fn, *args):
         """Enqueue one C-ABI call; with timing on, bracket it with HIP events recorded on the
         stream the kernel is launched on (torch's current stream == the `stream` argument)."""
+        self.n_calls += 1                     # C-ABI launches enqueued by this engine (bench.py: per step)
         if self._timing and (self._only is None or name in self._only):
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)

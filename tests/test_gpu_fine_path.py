@@ -699,3 +699,45 @@ def test_bf16_mode_end_to_end_close_to_fp32_and_psnr():
     assert abs(psnr(img(r32)) - psnr(img(r16))) < 0.1
     mse = float(((img(r32) - img(r16)) ** 2).mean())
     assert -10.0 * math.log10(max(mse, 1e-12)) > 45.0               # bf16 vs fp32 rendering: > 45 dB
+
+
+def test_pack_batch_equals_single_packs():
+    """esr_mlp_pack_batch (every net of a step in one launch, fp32 buffers + their bf16 twins) against esr_mlp_pack /
+    esr_mlp_pack_bf16 net by net: bit-identical packed buffers for all five net kinds."""
+    import ctypes as C
+    from esr_nerf_amd import _lib
+    L, s = _lib.lib(), _lib.stream_ptr("cuda:0")
+    g = torch.Generator().manual_seed(12)
+    dims = {0: (85, 192, 3, 3), 1: (33, 192, 1, 3), 2: (76, 128, 3, 5), 3: (76, 128, 3, 3), 4: (57, 128, 2, 3)}
+    kinds = [0, 0, 1, 2, 3, 4]
+    ws, keep, p32a, p32b, p16a, p16b = [], [], [], [], [], []
+    for kind in kinds:
+        i, h, nh, o = dims[kind]
+        sizes = [(h, i)] + [(h, h)] * (nh - 1) + [(o, h)]
+        w = _lib.EsrMlpWeights()
+        for l, (r, c) in enumerate(sizes):
+            wt, bt = torch.randn(r, c, generator=g).cuda(), torch.randn(r, generator=g).cuda()
+            keep += [wt, bt]
+            w.w[l], w.b[l] = wt.data_ptr(), bt.data_ptr()
+        ws.append(w)
+        n32, n16 = L.esr_mlp_packed_floats(kind), L.esr_mlp_packed_bf16_elems(kind)
+        p32a.append(torch.full((n32,), 7.0, device="cuda")); p32b.append(torch.full((n32,), 9.0, device="cuda"))
+        p16a.append(torch.full((n16,), 7.0, dtype=torch.bfloat16, device="cuda"))
+        p16b.append(torch.full((n16,), 9.0, dtype=torch.bfloat16, device="cuda"))
+        _lib.check(L.esr_mlp_pack(kind, C.byref(w), _lib.ptr(p32a[-1]), s), "pack")
+        _lib.check(L.esr_mlp_pack_bf16(kind, C.byref(w), _lib.ptr(p16a[-1]), s), "pack16")
+    n = len(kinds)
+    ka = (C.c_int32 * n)(*kinds)
+    wa = (C.c_void_p * n)(*[C.addressof(w) for w in ws])
+    a32 = (C.c_void_p * n)(*[t.data_ptr() for t in p32b])
+    a16 = (C.c_void_p * n)(*[t.data_ptr() for t in p16b])
+    _lib.check(L.esr_mlp_pack_batch(n, ka, wa, a32, a16, s), "pack_batch")
+    for k in range(n):
+        assert torch.equal(p32a[k], p32b[k]), kinds[k]
+        assert torch.equal(p16a[k].view(torch.int16), p16b[k].view(torch.int16)), kinds[k]
+    # fp32 only (packed16 NULL) leaves the bf16 buffers alone
+    for t in p32b:
+        t.fill_(3.0)
+    _lib.check(L.esr_mlp_pack_batch(n, ka, wa, a32, None, s), "pack_batch")
+    assert all(torch.equal(x, y) for x, y in zip(p32a, p32b))
+    assert L.esr_mlp_pack_batch(9, ka, wa, a32, a16, s) != 0

@@ -33,9 +33,10 @@ def test_library_loads_and_exports_every_header_symbol():
 
 def test_ctypes_structs_match_the_c_layout():
     from esr_nerf_amd import _lib
-    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "esr_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu",'
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "esr_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu",'
            'sizeof(esr_scene_t),sizeof(esr_plan_t),sizeof(esr_mlp_weights_t),offsetof(esr_scene_t,grad_feat),'
-           'offsetof(esr_scene_t,near_));return 0;}')
+           'offsetof(esr_scene_t,near_),sizeof(esr_act_job_t),offsetof(esr_act_job_t,ex_col0),sizeof(esr_gather_job_t),'
+           'offsetof(esr_gather_job_t,out),sizeof(esr_pair_job_t),offsetof(esr_pair_job_t,gb),sizeof(esr_lts_gather_t));return 0;}')
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
         open(c, "w").write(src)
@@ -47,6 +48,11 @@ def test_ctypes_structs_match_the_c_layout():
     assert sizes[2] == ctypes.sizeof(_lib.EsrMlpWeights)
     assert sizes[3] == _lib.EsrScene.grad_feat.offset
     assert sizes[4] == _lib.EsrScene.near_.offset
+    # round 4: the job structs of the batched glue launches
+    assert sizes[5] == ctypes.sizeof(_lib.EsrActJob) and sizes[6] == _lib.EsrActJob.ex_col0.offset
+    assert sizes[7] == ctypes.sizeof(_lib.EsrGatherJob) and sizes[8] == _lib.EsrGatherJob.out.offset
+    assert sizes[9] == ctypes.sizeof(_lib.EsrPairJob) and sizes[10] == _lib.EsrPairJob.gb.offset
+    assert sizes[11] == ctypes.sizeof(_lib.EsrLtsGather)
 
 
 def _cpu_model(**model_over):
