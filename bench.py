@@ -751,7 +751,9 @@ def main():
             elif stage != "finetune":
                 out["cpu_baseline"] = cpu_baseline_lts(model, scene, a.s_val, min(a.cpu_rays or 1024, n_rays), a.cpu_iters,
                                                        stage, cfg.app.trainer)
-        if headline and world == 1 and not a.no_other and not a.force_dist:
+        # (only the plain default run: profiling / A-B invocations of the headline workload pass one of the --no-* switches)
+        if headline and world == 1 and not (a.no_other or a.force_dist or a.no_cpu_baseline or a.no_optimizer
+                                            or a.no_kernel_timing or a.no_tv):
             # the other BASELINE configs, driver-observed: measured AFTER the headline (its fields above are final)
             out["other_workloads"] = other_workloads()
         line = json.dumps(out)
