@@ -1004,8 +1004,14 @@ ESR_API int esr_mlp_pack(int kind, const esr_mlp_weights_t *w, float *packed, vo
 
 // Every net of a step in ONE launch: packed32[i] (and, where packed16 != NULL and packed16[i] != NULL, its bf16 twin) from
 // the reference-layout tensors of w[i].  n <= 8.
+ESR_API int64_t esr_mlp_packed_split_elems(int kind)
+{
+    if (!kind_ok(kind)) return ESR_EINVAL;
+    return (int64_t)split_layout(kind).total_chunks * 512;
+}
+
 ESR_API int esr_mlp_pack_batch(int n, const int32_t *kinds, const esr_mlp_weights_t *const *w, float *const *packed32,
-                               void *const *packed16, void *stream)
+                               void *const *packed16, void *const *packed_split, void *stream)
 {
     if (n < 0 || n > MAX_PACK_JOBS || (n > 0 && (!kinds || !w || !packed32))) return ESR_EINVAL;
     if (n == 0) return 0;
@@ -1024,7 +1030,9 @@ ESR_API int esr_mlp_pack_batch(int n, const int32_t *kinds, const esr_mlp_weight
         }
         A.out = packed32[i];
         A.out16 = packed16 ? static_cast<__bf16 *>(packed16[i]) : nullptr;
-        const int64_t tot = pack_layout(kind).total + (A.out16 ? pack16_layout(kind).total : 0);
+        A.outs = packed_split ? static_cast<_Float16 *>(packed_split[i]) : nullptr;
+        const int64_t tot = pack_layout(kind).total + pack16_layout(kind).total +
+                            (A.outs ? (int64_t)split_layout(kind).total_chunks * 512 : 0);
         most = tot > most ? tot : most;
     }
     pack_kernel<<<dim3(esr_grid_for(most, 256, 256), n), 256, 0, esr_stream(stream)>>>(B);

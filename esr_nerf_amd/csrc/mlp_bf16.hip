@@ -717,7 +717,7 @@ ESR_API int esr_mlp_pack_bf16(int kind, const esr_mlp_weights_t *w, void *packed
         A.w[l] = w->w[l];
     }
     // (fp32 part skipped: out == NULL; the element range still starts with it)
-    pack_kernel<<<dim3(esr_grid_for(pack_layout(kind).total + pack16_layout(kind).total, 256, 1024), 1), 256, 0, esr_stream(stream)>>>(B);
+    pack_kernel<<<dim3(esr_grid_for(pack_layout(kind).total + pack16_layout(kind).total, 256, 1024), 1), 256, 0, esr_stream(stream)>>>(B);   // (fp32 part skipped: out == NULL)
     ESR_CHECK_LAUNCH();
     return 0;
 }

@@ -136,6 +136,7 @@ struct PackArgs {
     const float *w[4], *b[4];
     float *out;
     __bf16 *out16;          // bf16 twin (pack16_body), or NULL
+    _Float16 *outs;         // split-fp16 planes of the forward weights (packs_body; mlp_split.hip), or NULL
 };
 
 // One element of the packed fp32 buffer.  KIND is a template argument so that the layout table is a set of immediates:
@@ -283,6 +284,59 @@ __device__ __forceinline__ void pack16_body(const PackArgs &A, int64_t e)
     A.out16[e] = (__bf16)v;
 }
 
+// ---- split-fp16 planes (the f32 engine's forward on the 16-bit matrix cores, mlp_split.hip) ---------------------------------
+// w = w1 + w2 / 2048 with w1 = fp16(w), w2 = fp16((w - w1) * 2048): two fp16 planes carry 22 bits of the fp32 mantissa
+// (the residual is scaled into fp16's NORMAL range: unscaled it would be a subnormal for every |w| < 0.125).  Forward
+// weights only.  Chunk order: the kernel stages ONE step = (layer, pair of output tiles) at a time, so a step's chunks are
+// contiguous: [layer][pair][tile of the pair][plane][k-step], each chunk [64 lanes][8] as in the bf16 buffer (lane: output
+// row 32 it + lane % 32, k block lane / 32; slot i: input feature kfeat16(j, h, i), first layer: in_colmap).
+struct SplitLayout {
+    int n_layers;
+    int ks[4], tiles_out[4], pairs[4], in_dim[4], out_dim[4];
+    int off_chunk[4];          // first 1-KB chunk of the layer
+    int total_chunks;
+};
+__host__ __device__ constexpr SplitLayout split_layout(int kind)
+{
+    const Pack16Layout P = pack16_layout(kind);
+    SplitLayout L = {};
+    L.n_layers = P.n_layers;
+    int o = 0;
+    for (int l = 0; l < P.n_layers; ++l) {
+        L.ks[l] = P.ks[l]; L.tiles_out[l] = P.tiles_out[l]; L.pairs[l] = (P.tiles_out[l] + 1) / 2;
+        L.in_dim[l] = P.in_dim[l]; L.out_dim[l] = P.out_dim[l];
+        L.off_chunk[l] = o;
+        o += P.tiles_out[l] * 2 * P.ks[l];
+    }
+    L.total_chunks = o;
+    return L;
+}
+template <int KIND>
+__device__ __forceinline__ void packs_body(const PackArgs &A, int64_t e)
+{
+    constexpr SplitLayout L = split_layout(KIND);
+    float v = 0.f;
+    int plane = 0;
+    bool done = false;
+#pragma unroll
+    for (int l = 0; l < L.n_layers; ++l) {
+        if (done || (l + 1 < L.n_layers && e >= (int64_t)L.off_chunk[l + 1] * 512)) continue;
+        done = true;
+        const bool first = l == 0;
+        int64_t i = e - (int64_t)L.off_chunk[l] * 512;
+        const int slot = i & 7; i >>= 3;
+        const int lane = i & 63; i >>= 6;
+        const int j = (int)(i % L.ks[l]); i /= L.ks[l];
+        plane = (int)(i & 1);
+        const int it = (int)(i >> 1);                                           // (pair, tile of the pair) = tile index
+        const int h = lane >> 5, row = 32 * it + (lane & 31);
+        const int col = first ? in_colmap(KIND, 16 * j + 8 * h + slot) : kfeat16(j, h, slot);
+        if (row < L.out_dim[l] && col >= 0 && col < L.in_dim[l]) v = A.w[l][(int64_t)row * L.in_dim[l] + col];
+    }
+    const _Float16 w1 = (_Float16)v;
+    A.outs[e] = plane == 0 ? w1 : (_Float16)((v - (float)w1) * 2048.f);
+}
+
 // Every net of a step in ONE launch (esr_mlp_pack_batch): blockIdx.y = job; fp32 elements first, then the bf16 twin's.
 constexpr int MAX_PACK_JOBS = 8;
 struct PackBatch {
@@ -293,10 +347,12 @@ template <int KIND>
 __device__ __forceinline__ void pack_job(const PackArgs &A)
 {
     constexpr int64_t N32 = pack_layout(KIND).total, N16 = pack16_layout(KIND).total;
-    const int64_t n = N32 + (A.out16 ? N16 : 0);
+    constexpr int64_t NS = (int64_t)split_layout(KIND).total_chunks * 512;
+    const int64_t n = N32 + N16 + (A.outs ? NS : 0);
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         if (e < N32) { if (A.out) pack_body<KIND>(A, e); }
-        else pack16_body<KIND>(A, e - N32);
+        else if (e < N32 + N16) { if (A.out16) pack16_body<KIND>(A, e - N32); }
+        else packs_body<KIND>(A, e - N32 - N16);
     }
 }
 __global__ void __launch_bounds__(256) pack_kernel(PackBatch B)

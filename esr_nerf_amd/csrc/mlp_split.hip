@@ -1,0 +1,438 @@
+// The f32 engine's RADIANCE FORWARD on the 16-bit matrix cores, with fp32 results (round 4).
+//
+// On gfx950 v_mfma_f32_32x32x2_f32 runs at 1/16 of the 16-bit MFMA rate (157 vs 2500 TFLOP/s) and ON the vector lanes; the
+// radiance forward -- 142.5 GFLOP per C2 step -- was the step's dominant launch at 1.06 ms (0.85 of the f32 matrix peak).
+// Here every operand is split into TWO fp16 planes, x = x1 + x2 / 2048 with x1 = fp16(x), x2 = fp16((x - x1) * 2048) (the
+// subtraction is exact in fp32; the residual is scaled back into fp16's normal range), and a product is formed as
+//     w . x  =  w1 . x1  +  (w1 . x2 + w2 . x1) / 2048            (+ w2 . x2 / 2^22, dropped: below fp32's own rounding)
+// on v_mfma_f32_32x32x16_f16 with fp32 accumulation: three 16-bit MFMAs per k-step instead of eight f32 ones of a quarter of
+// the depth -- 16/3 of the f32 matrix rate.  Two fp16 planes carry 22 mantissa bits; through the four layers of the net the
+// result differs from a double-precision evaluation by 4e-7 .. 8e-7 of the layer's largest value, the same as torch's own
+// fp32 chain (5e-7; tools/ubench/mfma_f32_shapes.hip for the rates, tests/test_gpu_split.py for the accuracy).  With bf16
+// planes the same three products give 6e-6 .. 9e-6: fp16's three extra mantissa bits per plane are what makes two planes
+// enough, and the forward's operands (weights ~ 0.1, activations ~ 1, inputs below a few hundred) sit inside fp16's
+// range; a |value| above 65504 would overflow the first plane (the fp32 MFMA path stays available: ESR_SPLIT_FWD=0).
+//
+// Everything OUTSIDE the products is the f32 engine's: fp32 input tile X, fp32 bias add, ReLU, the saved hidden tiles H
+// (fp32, tile-major) and ReLU masks in mlp.hip's formats -- the f32 input-gradient and weight-gradient kernels consume them
+// unchanged -- and the fp32 output rows.
+//
+// Structure: mlp_bf16.hip's shared-weights scheme, re-cut for the register budget.  A layer's input AND output live in
+// registers as two fp16 planes each (2 x 48 + 2 x 48), beside two accumulator pairs (main / residual sums of the tile in
+// flight and of the tile in its epilogue), the staged weights and the next group's inputs: ~400 registers, i.e. ONE wave
+// per SIMD, four waves (= four 32-sample tiles) per workgroup and CU.  The weights (two planes: 148 KB per hidden layer)
+// are staged through LDS in STEPS of one pair of output tiles (48 KB, double-buffered): a step's chunks are contiguous in
+// the packed buffer, all 256 threads request the next step's 48 KB at the top of a step and write it to the other buffer at
+// its end, one barrier per step.  Inside a step the tile order of mlp_bf16.hip's lds_layer16_tiled: a tile's epilogue
+// (scale + bias, ReLU, fp32 stores, mask bits, the split into the next layer's planes) is issued behind the NEXT tile's
+// MFMAs.
+#include "mlp_common.h"
+
+#include <type_traits>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int SPW = 4;                                      // waves per workgroup = tiles per group
+constexpr float SPLIT_SCALE = 2048.f, SPLIT_INV = 1.f / 2048.f;
+
+__device__ __forceinline__ f32x16 mfma_h(f16x8 a, f16x8 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void sfor(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sfor<I + 1, N>(f);
+    }
+}
+
+// x -> (fp16(x), fp16((x - fp16(x)) * 2048)) for eight values
+__device__ __forceinline__ void split8(const float (&v)[8], f16x8 &p1, f16x8 &p2)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const _Float16 h = (_Float16)v[i];
+        p1[i] = h;
+        p2[i] = (_Float16)((v[i] - (float)h) * SPLIT_SCALE);
+    }
+}
+
+template <int KIND> struct SplitSteps {
+    static constexpr SplitLayout L = split_layout(KIND);
+    static constexpr int NL = L.n_layers;
+    static constexpr int n_steps()
+    {
+        int n = 0;
+        for (int l = 0; l < NL; ++l) n += L.pairs[l];
+        return n;
+    }
+    static constexpr int NS = n_steps();
+    static constexpr int layer_of(int s)
+    {
+        int l = 0;
+        while (s >= L.pairs[l]) { s -= L.pairs[l]; ++l; }
+        return l;
+    }
+    static constexpr int pair_of(int s)
+    {
+        int l = 0;
+        while (s >= L.pairs[l]) { s -= L.pairs[l]; ++l; }
+        return s;
+    }
+    static constexpr int tiles_in(int s)                   // output tiles of the step (2, or 1 for an odd tail / the output layer)
+    {
+        const int l = layer_of(s), p = pair_of(s);
+        return L.tiles_out[l] - 2 * p >= 2 ? 2 : 1;
+    }
+    static constexpr int chunks(int s) { return tiles_in(s) * 2 * L.ks[layer_of(s)]; }
+    static constexpr int chunk0(int s) { return L.off_chunk[layer_of(s)] + pair_of(s) * 2 * 2 * L.ks[layer_of(s)]; }
+    static constexpr int max_chunks()
+    {
+        int m = 0;
+        for (int s = 0; s < NS; ++s) m = chunks(s) > m ? chunks(s) : m;
+        return m;
+    }
+    static constexpr int BUF = max_chunks() * 1024;
+    static constexpr int BIAS_FLOATS = 32 * MAX_HID_TILES;
+    static constexpr int LDS_BYTES = 2 * BUF + NL * BIAS_FLOATS * 4;
+    static constexpr int PRE = (max_chunks() * 64 + 64 * SPW - 1) / (64 * SPW);     // 16-byte pieces per thread and step
+};
+
+struct SplitSeg {
+    const float *packed32;     // esr_mlp_pack buffer (biases)
+    const _Float16 *planes;    // esr_mlp_pack_batch's split planes
+    int t0, t1, save, crow;
+    float *zout;
+    int b0, nb;                // workgroups [b0, b0 + nb) of the launch
+};
+constexpr int MAX_SPLIT_SEG = 3;
+struct SplitBatch {
+    const float *X;
+    float *H[3];
+    unsigned *M[3];
+    int nseg;
+    SplitSeg seg[MAX_SPLIT_SEG];
+};
+
+__device__ __forceinline__ void step_barrier()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): this wave's LDS reads / writes of the step are done
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch AB)
+{
+    using S = SplitSteps<KIND>;
+    constexpr NetDesc D = net_desc(KIND);
+    constexpr SplitLayout L = S::L;
+    constexpr PackLayout L32 = pack_layout(KIND);
+    constexpr int NL = S::NL, NHID = NL - 1, HT = D.hid_tiles, KS1 = L.ks[0], NS = S::NS;
+    constexpr unsigned HBYTES = HT * 32 * 32 * 4, MBYTES = (HT / 2) * 256;
+    static_assert(NHID == 3 && HT % 2 == 0, "written for the four-layer 192-wide radiance net");
+    // segment of this workgroup
+    SplitSeg A = AB.seg[0];
+#pragma unroll
+    for (int k = 1; k < MAX_SPLIT_SEG; ++k)
+        if (k < AB.nseg && (int)blockIdx.x >= AB.seg[k].b0) A = AB.seg[k];
+    const int blk0 = A.b0, nblk = A.nb;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wl[];          // buffer 0 | buffer 1 | biases
+    float *bias_l = reinterpret_cast<float *>(wl + 2 * S::BUF);
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, s_ = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = A.t1 - A.t0, ngroups = (ntiles + SPW - 1) / SPW;
+    for (int i = tid; i < NL * S::BIAS_FLOATS; i += 64 * SPW) {
+        const int l = i / S::BIAS_FLOATS, k = i % S::BIAS_FLOATS;
+        bias_l[i] = k < L32.tiles_out[l] * 32 ? A.packed32[L32.off_bf[l] + k] : 0.f;
+    }
+    const rsrc_t WP = make_rsrc(A.planes, (unsigned)(L.total_chunks * 1024));
+    u32x4 pre[S::PRE];
+    // request / write the chunks of step `st` (compile-time) into LDS buffer `dst`
+    auto stage_load = [&](auto ST) __attribute__((always_inline)) {
+        constexpr int st = decltype(ST)::value, pieces = S::chunks(st) * 64;
+#pragma unroll
+        for (int k = 0; k < S::PRE; ++k)
+            if (k * 64 * SPW < pieces) pre[k] = __builtin_amdgcn_raw_buffer_load_b128(WP, (tid + 64 * SPW * k) * 16, S::chunk0(st) * 1024, 0);
+    };
+    auto stage_store = [&](auto ST, unsigned char *dst) __attribute__((always_inline)) {
+        constexpr int st = decltype(ST)::value, pieces = S::chunks(st) * 64;
+#pragma unroll
+        for (int k = 0; k < S::PRE; ++k)
+            if (k * 64 * SPW < pieces && tid + 64 * SPW * k < pieces)
+                *reinterpret_cast<u32x4 *>(dst + (size_t)(tid + 64 * SPW * k) * 16) = pre[k];
+    };
+    stage_load(std::integral_constant<int, 0>{});
+    stage_store(std::integral_constant<int, 0>{}, wl);
+    step_barrier();
+
+    // the group's input rows: lane (h, s) needs rows 16 j + 8 h + i of its sample s (first layer's k order)
+    float xn[KS1 * 8];
+    auto fetch = [&](int tg) {
+        const int tt = A.t0 + tg * SPW + wv;
+        const int t = tt < A.t1 ? tt : A.t1 - 1;
+        const rsrc_t RX = make_rsrc(AB.X + (size_t)t * D.xrows * 32, D.xrows * 32 * 4);
+        const int xvoff = (h * 8 * 32 + s_) * 4, coff = A.crow * 128;
+#pragma unroll
+        for (int j = 0; j < KS1; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = 16 * j + 8 * h + i;
+                xn[j * 8 + i] = bload1(RX, xvoff + (row < D.cw ? coff : 0), (16 * j + i) * 128);
+            }
+    };
+    if ((int)blockIdx.x - blk0 < ngroups) fetch((int)blockIdx.x - blk0);
+    const int hvoff = tile_voff(lane);
+
+    for (int tg = (int)blockIdx.x - blk0; tg < ngroups; tg += nblk) {
+        const int tt = A.t0 + tg * SPW + wv;
+        const bool live = tt < A.t1;                       // a wave past the range runs on the last tile, stores nothing
+        const int t = live ? tt : A.t1 - 1;
+        const bool save = A.save && live;
+        // planes: first layer's input (from X) | set A | set B; layer 0 writes A, 1 reads A writes B, 2 reads B writes A, 3 reads A
+        f16x8 xi1[KS1], xi2[KS1], pa1[2 * HT], pa2[2 * HT], pb1[2 * HT], pb2[2 * HT];
+#pragma unroll
+        for (int j = 0; j < KS1; ++j) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = xn[j * 8 + i];
+            split8(v, xi1[j], xi2[j]);
+        }
+        fetch(tg + nblk < ngroups ? tg + nblk : tg);       // the next group's rows (past the end: this group again, never used)
+        f32x16 am[2], ar[2];                               // main / residual sums, two tiles alternate
+        unsigned mword = 0;
+
+        // epilogue of hidden tile `it` of layer l: value, bias, ReLU, saves, split into the next layer's planes
+        auto tile_epilogue = [&](auto LC, auto IT, f32x16 &accm, f32x16 &accr, f16x8 (&o1)[2 * HT], f16x8 (&o2)[2 * HT])
+                                 __attribute__((always_inline)) {
+            constexpr int l = decltype(LC)::value, it = decltype(IT)::value;
+            const float4 *b4 = reinterpret_cast<const float4 *>(bias_l + l * S::BIAS_FLOATS + (lane >> 5) * 16) + it * 8;
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b = b4[q];
+                v[4 * q + 0] = fmaf(accr[4 * q + 0], SPLIT_INV, accm[4 * q + 0]) + b.x;
+                v[4 * q + 1] = fmaf(accr[4 * q + 1], SPLIT_INV, accm[4 * q + 1]) + b.y;
+                v[4 * q + 2] = fmaf(accr[4 * q + 2], SPLIT_INV, accm[4 * q + 2]) + b.z;
+                v[4 * q + 3] = fmaf(accr[4 * q + 3], SPLIT_INV, accm[4 * q + 3]) + b.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int bts = __float_as_int(v[r]);
+                v[r] = __int_as_float(bts > 0 ? bts : 0);
+            }
+            if (save) {
+                if (A.save == 1) {                                 // fp32 tile, mlp.hip's store_tiles order
+                    const rsrc_t RH = make_rsrc(AB.H[l] + (size_t)t * (HBYTES / 4), HBYTES);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) bstore1_nt(RH, v[r], hvoff, tile_soff(it, r));
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {                     // mlp_common.h: store_relu_mask's bit order
+                    int one;                                       // (operand: the integer max above -- a VALU result)
+                    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(one) : "v"(__float_as_int(v[r])));
+                    mword |= (unsigned)one << ((it & 1) * 16 + r);
+                }
+                if (it & 1) {
+                    __builtin_amdgcn_raw_buffer_store_b32(mword, make_rsrc(AB.M[l] + (size_t)t * (MBYTES / 4), MBYTES), lane * 4,
+                                                          (it >> 1) * 256, 0);
+                    mword = 0;
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                float u[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) u[i] = v[8 * jj + i];
+                split8(u, o1[2 * it + jj], o2[2 * it + jj]);
+            }
+        };
+
+        // one step: the MFMAs of its tiles from LDS buffer (st & 1); a finished tile's epilogue behind the next tile's MFMAs
+        auto run_layer = [&](auto LC, auto in1, auto in2, f16x8 (&o1)[2 * HT], f16x8 (&o2)[2 * HT]) __attribute__((always_inline)) {
+            constexpr int l = decltype(LC)::value, KS = L.ks[l], NT = L.tiles_out[l], NP = L.pairs[l];
+            constexpr int s0 = [] { int s = 0; for (int k = 0; k < l; ++k) s += L.pairs[k]; return s; }();
+            sfor<0, NP>([&](auto PC) {
+                constexpr int p = decltype(PC)::value, st = s0 + p, tin = S::tiles_in(st), nxt_st = (st + 1) % NS;
+                const unsigned char *wsrc = wl + (st & 1) * S::BUF;
+                const u32x4 *mine = reinterpret_cast<const u32x4 *>(wsrc) + lane;
+                stage_load(std::integral_constant<int, nxt_st>{});
+                // flat MFMA-triple index n = tt_ * KS + j; chunk of (tile tt_, plane q, k-step j) = (tt_ * 2 + q) * KS + j
+                constexpr int NTOT = tin * KS;
+                u32x4 wb[2][2];
+                wb[0][0] = mine[0 * 64];
+                wb[0][1] = mine[KS * 64];
+                sfor<0, NTOT>([&](auto NC) {
+                    constexpr int n = decltype(NC)::value, tt_ = n / KS, j = n % KS, it = 2 * p + tt_;
+                    if constexpr (n + 1 < NTOT) {
+                        constexpr int t2 = (n + 1) / KS, j2 = (n + 1) % KS;
+                        wb[(n + 1) & 1][0] = mine[((t2 * 2 + 0) * KS + j2) * 64];
+                        wb[(n + 1) & 1][1] = mine[((t2 * 2 + 1) * KS + j2) * 64];
+                    }
+                    f32x16 &m = am[it & 1], &r = ar[it & 1];
+                    if constexpr (j == 0) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) { m[q] = 0.f; r[q] = 0.f; }
+                    }
+                    const f16x8 w1 = __builtin_bit_cast(f16x8, wb[n & 1][0]), w2 = __builtin_bit_cast(f16x8, wb[n & 1][1]);
+                    m = mfma_h(w1, in1(j), m);
+                    r = mfma_h(w1, in2(j), r);
+                    r = mfma_h(w2, in1(j), r);
+                    if constexpr (j == KS - 1) {
+                        // the previous tile's epilogue, behind this tile's MFMAs in issue order
+                        if constexpr (it > 0) tile_epilogue(LC, std::integral_constant<int, it - 1>{}, am[(it - 1) & 1], ar[(it - 1) & 1], o1, o2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+                if constexpr (p == NP - 1)                         // last tile of the layer: the next layer needs it
+                    tile_epilogue(LC, std::integral_constant<int, NT - 1>{}, am[(NT - 1) & 1], ar[(NT - 1) & 1], o1, o2);
+                stage_store(std::integral_constant<int, nxt_st>{}, wl + ((st + 1) & 1) * S::BUF);
+                step_barrier();
+            });
+        };
+        run_layer(std::integral_constant<int, 0>{}, [&](int j) { return xi1[j]; }, [&](int j) { return xi2[j]; }, pa1, pa2);
+        run_layer(std::integral_constant<int, 1>{}, [&](int j) { return pa1[j]; }, [&](int j) { return pa2[j]; }, pb1, pb2);
+        run_layer(std::integral_constant<int, 2>{}, [&](int j) { return pb1[j]; }, [&](int j) { return pb2[j]; }, pa1, pa2);
+        {   // output layer: one tile, one step
+            constexpr int l = NL - 1, KS = L.ks[l], st = NS - 1, nxt_st = 0;
+            static_assert(S::layer_of(st) == l && S::tiles_in(st) == 1, "the output layer is the last step");
+            const unsigned char *wsrc = wl + (st & 1) * S::BUF;
+            const u32x4 *mine = reinterpret_cast<const u32x4 *>(wsrc) + lane;
+            stage_load(std::integral_constant<int, nxt_st>{});
+            f32x16 zm, zr;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { zm[q] = 0.f; zr[q] = 0.f; }
+            u32x4 wb[2][2];
+            wb[0][0] = mine[0];
+            wb[0][1] = mine[KS * 64];
+            sfor<0, KS>([&](auto JC) {
+                constexpr int j = decltype(JC)::value;
+                if constexpr (j + 1 < KS) {
+                    wb[(j + 1) & 1][0] = mine[(j + 1) * 64];
+                    wb[(j + 1) & 1][1] = mine[(KS + j + 1) * 64];
+                }
+                const f16x8 w1 = __builtin_bit_cast(f16x8, wb[j & 1][0]), w2 = __builtin_bit_cast(f16x8, wb[j & 1][1]);
+                zm = mfma_h(w1, pa1[j], zm);
+                zr = mfma_h(w1, pa2[j], zr);
+                zr = mfma_h(w2, pa1[j], zr);
+            });
+            const float4 bz = *reinterpret_cast<const float4 *>(bias_l + l * S::BIAS_FLOATS + (lane >> 5) * 16);
+            const float bzv[4] = {bz.x, bz.y, bz.z, bz.w};
+            const rsrc_t RZ = make_rsrc(A.zout + (size_t)t * D.zrows * 32, live ? D.zrows * 32 * 4 : 0);
+            // rows 0..3 of the output tile live in registers 0..3 of lane half 0 (acc_row(r, 0) = r); half 1's lanes are
+            // pointed past the 4-row tile's range, which the descriptor drops
+            const int zvoff = ((h ? D.zrows : 0) * 32 + s_) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bstore1(RZ, r < 3 ? fmaf(zr[r], SPLIT_INV, zm[r]) + bzv[r] : 0.f, zvoff, r * 128);
+            stage_store(std::integral_constant<int, nxt_st>{}, wl + ((st + 1) & 1) * S::BUF);
+            step_barrier();
+        }
+        static_assert(NS % 2 == 0, "an even number of steps per group: step 0 of every group sits in LDS buffer 0");
+    }
+}
+
+// workgroups per segment proportional to its tile groups (every non-empty segment >= 1); returns the grid
+int share_blocks_split(SplitSeg *seg, int nseg)
+{
+    int groups[MAX_SPLIT_SEG], total = 0;
+    for (int k = 0; k < nseg; ++k) { groups[k] = (seg[k].t1 - seg[k].t0 + SPW - 1) / SPW; total += groups[k]; }
+    const int grid = total < 256 ? total : 256;
+    int given = 0;
+    for (int k = 0; k < nseg; ++k) {
+        int n = (int)((int64_t)grid * groups[k] / (total > 0 ? total : 1));
+        if (n < 1) n = 1;
+        if (n > groups[k]) n = groups[k];
+        seg[k].nb = n;
+        given += n;
+    }
+    for (int guard = 0; given != grid && guard < 1024; ++guard) {
+        int pick = -1;
+        double best = 0.0;
+        for (int k = 0; k < nseg; ++k) {
+            if (given < grid) {
+                if (seg[k].nb >= groups[k]) continue;
+                const double load = (double)groups[k] / seg[k].nb;
+                if (pick < 0 || load > best) { pick = k; best = load; }
+            } else {
+                if (seg[k].nb <= 1) continue;
+                const double load = (double)groups[k] / (seg[k].nb - 1);
+                if (pick < 0 || load < best) { pick = k; best = load; }
+            }
+        }
+        if (pick < 0) break;
+        seg[pick].nb += given < grid ? 1 : -1;
+        given += given < grid ? 1 : -1;
+    }
+    int b0 = 0;
+    for (int k = 0; k < nseg; ++k) { seg[k].b0 = b0; b0 += seg[k].nb; }
+    return b0;
+}
+
+int launch_split(SplitBatch &B, hipStream_t s)
+{
+    using S = SplitSteps<ESR_MLP_RADIANCE>;
+    const int grid = share_blocks_split(B.seg, B.nseg);
+    static std::atomic<uint64_t> optin{0};
+    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_fwd_split_kernel<ESR_MLP_RADIANCE>), S::LDS_BYTES, optin)) return rc;
+    mlp_fwd_split_kernel<ESR_MLP_RADIANCE><<<grid, 64 * SPW, S::LDS_BYTES, s>>>(B);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+bool crow_ok_split(int crow) { return crow == 0 || crow == 88 || crow == 96; }
+
+}  // namespace
+
+// One radiance forward pass over tiles [t0, t1) (esr_mlp_fwd's contract: save 0 / 1 / 2, colour group color_row0), products
+// on the 16-bit matrix cores from split fp16 planes.  packed32: esr_mlp_pack's buffer (biases); planes: the net's split
+// planes (esr_mlp_pack_batch, esr_mlp_packed_split_elems values).  ESR_MLP_RADIANCE only.
+ESR_API int esr_mlp_fwd_split(int kind, const float *packed32, const void *planes, const float *X, int32_t t0, int32_t t1,
+                              float *const *H, uint32_t *const *M, int save, int color_row0, float *zout, void *stream)
+{
+    if (kind != ESR_MLP_RADIANCE || t0 < 0 || t1 < t0 || !crow_ok_split(color_row0)) return ESR_EINVAL;
+    if (t1 == t0) return 0;
+    if (!packed32 || !planes || !X || !zout) return ESR_EINVAL;
+    SplitBatch B = {};
+    B.X = X;
+    if (save) {
+        if (!M || (save != 2 && !H)) return ESR_EINVAL;
+        for (int l = 0; l < 3; ++l) {
+            if (!M[l] || (save != 2 && !H[l])) return ESR_EINVAL;
+            B.H[l] = save != 2 ? H[l] : nullptr; B.M[l] = M[l];
+        }
+    }
+    B.nseg = 1;
+    B.seg[0] = SplitSeg{packed32, static_cast<const _Float16 *>(planes), t0, t1, save == 2 ? 2 : save ? 1 : 0, color_row0, zout, 0, 0};
+    return launch_split(B, esr_stream(stream));
+}
+
+// The fine stage's three radiance forward passes of a step as ONE launch (esr_mlp_fwd_fine's contract and argument meaning).
+ESR_API int esr_mlp_fwd_fine_split(const float *packed32_off, const void *planes_off, const float *packed32_emo,
+                                   const void *planes_emo, const float *X, int32_t t_on, int32_t t_all, float *const *H,
+                                   uint32_t *const *M, int color_row_detached, float *z_off, float *z_emo, void *stream)
+{
+    if (t_on < 0 || t_all < t_on || !crow_ok_split(color_row_detached)) return ESR_EINVAL;
+    if (t_all == 0) return 0;
+    if (!packed32_off || !planes_off || !packed32_emo || !planes_emo || !X || !H || !M || !z_off || !z_emo) return ESR_EINVAL;
+    SplitBatch B = {};
+    B.X = X;
+    for (int l = 0; l < 3; ++l) {
+        if (!H[l] || !M[l]) return ESR_EINVAL;
+        B.H[l] = H[l]; B.M[l] = M[l];
+    }
+    const _Float16 *po = static_cast<const _Float16 *>(planes_off), *pe = static_cast<const _Float16 *>(planes_emo);
+    int n = 0;
+    if (t_on > 0) B.seg[n++] = SplitSeg{packed32_off, po, 0, t_on, 0, color_row_detached, z_off, 0, 0};
+    if (t_all > t_on) B.seg[n++] = SplitSeg{packed32_off, po, t_on, t_all, 1, 0, z_off, 0, 0};
+    if (t_on > 0) B.seg[n++] = SplitSeg{packed32_emo, pe, 0, t_on, 1, 0, z_emo, 0, 0};
+    B.nseg = n;
+    return launch_split(B, esr_stream(stream));
+}

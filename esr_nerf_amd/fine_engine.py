@@ -142,6 +142,10 @@ class FineEngine:
         # bf16 engine, merged radiance launches: the features are written as a bf16 tile in the operand layout of the
         # first layer (esr_fine_feat_fwd_x16); ESR_X16=0: the fp32 tile, converted on load (A/B timing)
         self.x16 = self.bf16 and os.environ.get("ESR_X16", "1") != "0"
+        # f32 engine: the radiance forward's products on the 16-bit matrix cores from split fp16 planes, fp32 results
+        # (csrc/mlp_split.hip); ESR_SPLIT_FWD=0: the f32 MFMA forward (A/B timing, and for inputs beyond fp16's range)
+        self.split_fwd = (not self.bf16) and os.environ.get("ESR_SPLIT_FWD", "1") != "0"
+        self.packed_split: Dict[str, torch.Tensor] = {}
         self.tone_scratch = torch.empty(self.L.esr_tone_wgrad_scratch_floats() if self.tone_recompute else 1,
                                         dtype=torch.float32, device=self.device)
         self.neus_grad = False          # cfg neus_alpha: "grad" (set by the renderer)
@@ -243,11 +247,17 @@ class FineEngine:
                     self.packed16[which] = torch.empty(n16, dtype=torch.bfloat16, device=self.device)
                 p16 = _lib.ptr(self.packed16[which])
                 self._p16[self.packed[which].data_ptr()] = p16
+            if self.split_fwd and kind == KIND_RADIANCE:        # split fp16 planes of the forward weights (mlp_split.hip)
+                ns = self.L.esr_mlp_packed_split_elems(kind)
+                if which not in self.packed_split or self.packed_split[which].numel() != ns:
+                    self.packed_split[which] = torch.empty(ns, dtype=torch.float16, device=self.device)
             hit = self._pack_cache[which] = (key, kind, w, C.byref(w), p32, p16, self.packed[which].data_ptr())
         _, _, w, wref, p32, p16, _ = hit
         if self._pack_pending is not None:
             self._pack_pending.append((which, kind, w, p32, p16))
             return
+        if self.split_fwd and kind == KIND_RADIANCE:            # (outside a packing() group: the batch entry with one job)
+            return self._pack_flush([(which, kind, w, p32, p16)])
         s = self._s()
         self._run(f"mlp_pack({which})", self.L.esr_mlp_pack, kind, wref, p32, s)
         if self.bf16:
@@ -269,7 +279,10 @@ class FineEngine:
         return _Group()
 
     def _pack_flush(self, jobs):
-        sig = tuple((which, kind, C.addressof(w), p32.value, p16.value if p16 is not None else 0) for which, kind, w, p32, p16 in jobs)
+        split = [(self.packed_split[which].data_ptr() if (self.split_fwd and kind == KIND_RADIANCE) else 0)
+                 for which, kind, _, _, _ in jobs]
+        sig = tuple((which, kind, C.addressof(w), p32.value, p16.value if p16 is not None else 0, sp)
+                    for (which, kind, w, p32, p16), sp in zip(jobs, split))
         hit = self._pack_batch_cache
         if hit is None or hit[0] != sig:
             n = len(jobs)
@@ -277,9 +290,10 @@ class FineEngine:
             ws = (C.c_void_p * n)(*[C.addressof(w) for _, _, w, _, _ in jobs])
             p32s = (C.c_void_p * n)(*[p.value for _, _, _, p, _ in jobs])
             p16s = (C.c_void_p * n)(*[(p.value if p is not None else 0) for _, _, _, _, p in jobs]) if self.bf16 else None
-            hit = self._pack_batch_cache = (sig, n, kinds, ws, p32s, p16s)
-        _, n, kinds, ws, p32s, p16s = hit
-        self._run("mlp_pack(all)", self.L.esr_mlp_pack_batch, n, kinds, ws, p32s, p16s, self._s())
+            psp = (C.c_void_p * n)(*split) if any(split) else None
+            hit = self._pack_batch_cache = (sig, n, kinds, ws, p32s, p16s, psp)
+        _, n, kinds, ws, p32s, p16s, psp = hit
+        self._run("mlp_pack(all)", self.L.esr_mlp_pack_batch, n, kinds, ws, p32s, p16s, psp, self._s())
 
     # the three MLP entry points with the fp32 signatures; in bf16 mode the packed fp32 pointer selects its bf16 twin
     def mlp_fwd(self, kind, packed, *rest):
@@ -397,7 +411,12 @@ class FineEngine:
         if e_pre is not None:
             main.wait_event(e_pre)
         # off net: detached pass on the on-tiles (alt colour rows, nothing saved), saved pass on the off-tiles
-        if not self.bf16 and self.merge_rad:     # off net (detached on-tiles + saved off-tiles) and emo net: one launch
+        if not self.bf16 and self.merge_rad and self.split_fwd and "off" in self.packed_split and "emo" in self.packed_split:
+            # the same three passes, products from split fp16 planes on the 16-bit matrix cores (fp32 results)
+            self._run("mlp_fwd(rad)", L.esr_mlp_fwd_fine_split, _lib.ptr(self.packed["off"]), _lib.ptr(self.packed_split["off"]),
+                      _lib.ptr(self.packed["emo"]), _lib.ptr(self.packed_split["emo"]), _lib.ptr(ws["X"]), tiles_on, tiles_all,
+                      H, M, 88, _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), s)
+        elif not self.bf16 and self.merge_rad:     # off net (detached on-tiles + saved off-tiles) and emo net: one launch
             self._run("mlp_fwd(rad)", L.esr_mlp_fwd_fine, _lib.ptr(self.packed["off"]), _lib.ptr(self.packed["emo"]),
                       _lib.ptr(ws["X"]), tiles_on, tiles_all, H, M, 88, _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), s)
         elif not self.bf16:       # one launch, same weights (no launch seam, one ramp-up / tail instead of two)

@@ -156,6 +156,7 @@ class LtsEngine(FineEngine):
     def __init__(self, device, mlp_dtype: str = "f32"):
         super().__init__(device, mlp_dtype)
         self.ray_sampling = "random"        # or "fib" (cfg.app.model.ray_sampling; esrnerf.py:188-192)
+        self.split_fwd = False              # (the split-fp16 forward is wired into the fine stage's merged launch only)
         self._draw_ring = [None, None, 0, 0]   # pinned buffers of the surface-point draw (_PointDraw)
         self.zero_arena = os.environ.get("ESR_ZERO_ARENA", "1") != "0"      # (read once, here; A/B switch of tools/ab.sh)
         self.prim = Pass(self.device, "primary")

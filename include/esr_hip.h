@@ -314,7 +314,23 @@ int esr_mlp_pack(int kind, const esr_mlp_weights_t *w, float *packed, void *stre
  * packed16[i] != NULL also its bf16 twin (esr_mlp_pack_bf16).  The reference has no counterpart: its nn.Linear
  * weights are used as they are (app/utils/pbr/module.py:6-83). */
 int esr_mlp_pack_batch(int n, const int32_t *kinds, const esr_mlp_weights_t *const *w, float *const *packed32,
-                       void *const *packed16, void *stream);
+                       void *const *packed16, void *const *packed_split, void *stream);
+/*
+ * Round 4: the f32 engine's radiance FORWARD on the 16-bit matrix cores with fp32 results (csrc/mlp_split.hip): every operand
+ * as two fp16 planes x = x1 + x2 / 2048, a product as w1.x1 + (w1.x2 + w2.x1) / 2048 on v_mfma_f32_32x32x16_f16 with fp32
+ * accumulation -- fp32-level accuracy (4e-7 .. 8e-7 of a layer's largest value against double precision, torch's own fp32
+ * chain: 5e-7) at 16/3 of the f32 matrix rate.  packed_split[i] of esr_mlp_pack_batch (or NULL) receives the net's forward
+ * weights as split planes, esr_mlp_packed_split_elems(kind) fp16 values.  esr_mlp_fwd_split / esr_mlp_fwd_fine_split keep the
+ * contracts of esr_mlp_fwd / esr_mlp_fwd_fine (inputs X, saved tiles H and masks M, outputs z are the f32 engine's, so the
+ * f32 input-gradient and weight-gradient entries follow unchanged); ESR_MLP_RADIANCE only.  The reference evaluates these
+ * layers with fp32 nn.Linear (app/utils/pbr/module.py:6-21).
+ */
+int64_t esr_mlp_packed_split_elems(int kind);
+int esr_mlp_fwd_split(int kind, const float *packed32, const void *planes, const float *X, int32_t t0, int32_t t1,
+                      float *const *H, uint32_t *const *M, int save, int color_row0, float *zout, void *stream);
+int esr_mlp_fwd_fine_split(const float *packed32_off, const void *planes_off, const float *packed32_emo,
+                           const void *planes_emo, const float *X, int32_t t_on, int32_t t_all, float *const *H,
+                           uint32_t *const *M, int color_row_detached, float *z_off, float *z_emo, void *stream);
 
 /*
  * Forward over tiles [t0,t1).  X: layer-1 input, tile-major [tiles,xrows,32].

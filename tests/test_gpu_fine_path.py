@@ -731,13 +731,13 @@ def test_pack_batch_equals_single_packs():
     wa = (C.c_void_p * n)(*[C.addressof(w) for w in ws])
     a32 = (C.c_void_p * n)(*[t.data_ptr() for t in p32b])
     a16 = (C.c_void_p * n)(*[t.data_ptr() for t in p16b])
-    _lib.check(L.esr_mlp_pack_batch(n, ka, wa, a32, a16, s), "pack_batch")
+    _lib.check(L.esr_mlp_pack_batch(n, ka, wa, a32, a16, None, s), "pack_batch")
     for k in range(n):
         assert torch.equal(p32a[k], p32b[k]), kinds[k]
         assert torch.equal(p16a[k].view(torch.int16), p16b[k].view(torch.int16)), kinds[k]
     # fp32 only (packed16 NULL) leaves the bf16 buffers alone
     for t in p32b:
         t.fill_(3.0)
-    _lib.check(L.esr_mlp_pack_batch(n, ka, wa, a32, None, s), "pack_batch")
+    _lib.check(L.esr_mlp_pack_batch(n, ka, wa, a32, None, None, s), "pack_batch")
     assert all(torch.equal(x, y) for x, y in zip(p32a, p32b))
-    assert L.esr_mlp_pack_batch(9, ka, wa, a32, a16, s) != 0
+    assert L.esr_mlp_pack_batch(9, ka, wa, a32, a16, None, s) != 0
