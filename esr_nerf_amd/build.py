@@ -33,7 +33,14 @@ def _stamp(paths):
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA.items())).encode())
     return h.hexdigest()
+
+
+# per-source flags (none at present).  Tried for mlp_split.hip, which runs ONE wave per SIMD on ~460 registers:
+# `-mllvm -amdgpu-mfma-vgpr-form=1` keeps the MFMA accumulators in the VGPR half (1163 -> 477 v_accvgpr_read per tile group,
+# 6.6 k -> 6.1 k instructions in the loop body) but moves the planes' traffic to v_accvgpr_write: 0.705 -> 0.72 ms at C2.
+EXTRA = {}
 
 
 def _compile(src):
@@ -44,7 +51,7 @@ def _compile(src):
     sfile = obj + ".stamp"
     if os.path.exists(obj) and os.path.exists(sfile) and open(sfile).read() == stamp:
         return obj, False
-    cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [HIPCC, *FLAGS, *EXTRA.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

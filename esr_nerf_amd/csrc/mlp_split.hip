@@ -32,6 +32,11 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// in-kernel time stamps for tools/ubench/split_stamps.hip (nothing in the product build)
+#ifndef ESR_SPLIT_STAMP
+#define ESR_SPLIT_STAMP(i)
+#endif
+
 namespace {
 
 constexpr int SPW = 4;                                      // waves per workgroup = tiles per group
@@ -158,10 +163,12 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
     u32x4 pre[S::PRE];
     // request / write the chunks of step `st` (compile-time) into LDS buffer `dst`
     auto stage_load = [&](auto ST) __attribute__((always_inline)) {
-        constexpr int st = decltype(ST)::value, pieces = S::chunks(st) * 64;
+        // (constexpr locals: as plain call arguments the step table's lookups -- loops over the layer list -- were evaluated at
+        //  RUN time for the later steps, a chain of scalar loads per use: steps 5-8 took 10 k clocks instead of 2.5 k)
+        constexpr int st = decltype(ST)::value, pieces = S::chunks(st) * 64, base = S::chunk0(st) * 1024;
 #pragma unroll
         for (int k = 0; k < S::PRE; ++k)
-            if (k * 64 * SPW < pieces) pre[k] = __builtin_amdgcn_raw_buffer_load_b128(WP, (tid + 64 * SPW * k) * 16, S::chunk0(st) * 1024, 0);
+            if (k * 64 * SPW < pieces) pre[k] = __builtin_amdgcn_raw_buffer_load_b128(WP, (tid + 64 * SPW * k) * 16, base, 0);
     };
     auto stage_store = [&](auto ST, unsigned char *dst) __attribute__((always_inline)) {
         constexpr int st = decltype(ST)::value, pieces = S::chunks(st) * 64;
@@ -206,135 +213,149 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
             for (int i = 0; i < 8; ++i) v[i] = xn[j * 8 + i];
             split8(v, xi1[j], xi2[j]);
         }
+        ESR_SPLIT_STAMP(0);
         fetch(tg + nblk < ngroups ? tg + nblk : tg);       // the next group's rows (past the end: this group again, never used)
-        f32x16 am[2], ar[2];                               // main / residual sums, two tiles alternate
+        // main sums and the two residual sums (w1.x2, w2.x1: one accumulator each, so that every accumulator is touched once
+        // per k-step -- a dependent MFMA waits for its predecessor's last pass), two tiles alternate; bz: a tile's biases,
+        // requested when its MFMAs start and used a tile later (a ds_read inside a micro-slice is a full LDS round trip
+        // in front of one MFMA's worth of work: the first version of the slices waited ~100 clocks in each)
+        f32x16 am[2], ar[2], aq[2];
+        float4 bz4[2][4];
         unsigned mword = 0;
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // zero-record descriptors drop the stores of a pass that saves nothing (no branch inside the MFMA stream)
+        const unsigned hrec = (save && A.save == 1) ? HBYTES : 0u, mrec = save ? MBYTES : 0u;
 
-        // epilogue of hidden tile `it` of layer l: value, bias, ReLU, saves, split into the next layer's planes
-        auto tile_epilogue = [&](auto LC, auto IT, f32x16 &accm, f32x16 &accr, f16x8 (&o1)[2 * HT], f16x8 (&o2)[2 * HT])
-                                 __attribute__((always_inline)) {
+        // ---- the epilogue of a finished hidden tile, cut into 24 MICRO-SLICES (8 register pairs x 3 phases) ------------------
+        // One wave per SIMD has nobody to overlap with: the matrix pipe takes one 8-pass MFMA per 32 clocks and the wave
+        // issues in order, so a tile's ~170 epilogue instructions behind its MFMAs idle the pipe for their whole length (the
+        // first version of this kernel: 0.98 ms at C2, 9 k clocks per step for 2.3 k of matrix work).  Each micro-slice
+        // (5-7 vector instructions) is therefore issued right behind ONE MFMA of the FOLLOWING tile -- also across a layer
+        // boundary: the last tile of layer l is finished inside the first tile of layer l + 1, whose k-steps 10 / 11 (the only
+        // ones that read that tile's planes) come after micro-slice 23.
+        //   phase 0 (pair p): value = main + residual / 2048 + bias, ReLU, the fp32 tile stores -> kept in the main accumulator
+        //   phase 1: mask bits, first plane (fp16 of the value), scaled residual -> kept in the residual accumulator
+        //   phase 2: second plane (fp16 of the scaled residual)
+        auto micro = [&](auto LC, auto IT, auto MS, f32x16 &accm, f32x16 &accr, f32x16 &accq, auto &o1, auto &o2) __attribute__((always_inline)) {
+            constexpr int l = decltype(LC)::value, it = decltype(IT)::value, ms = decltype(MS)::value, p = ms / 3, q = ms % 3;
+            constexpr int r0 = 2 * p, jj = r0 >> 3, i0 = r0 & 7;
+            if constexpr (q == 0) {
+                const float4 b4 = bz4[it & 1][p >> 1];
+                const float bx = (p & 1) ? b4.z : b4.x, by = (p & 1) ? b4.w : b4.y;
+                float v0 = fmaf(accr[r0] + accq[r0], SPLIT_INV, accm[r0]) + bx, v1 = fmaf(accr[r0 + 1] + accq[r0 + 1], SPLIT_INV, accm[r0 + 1]) + by;
+                const int b0 = __float_as_int(v0), b1 = __float_as_int(v1);
+                v0 = __int_as_float(b0 > 0 ? b0 : 0);
+                v1 = __int_as_float(b1 > 0 ? b1 : 0);
+                const rsrc_t RH = make_rsrc(AB.H[l] + (size_t)t * (HBYTES / 4), hrec);      // fp32 tile, mlp.hip's store_tiles order
+                bstore1_nt(RH, v0, hvoff, tile_soff(it, r0));
+                bstore1_nt(RH, v1, hvoff, tile_soff(it, r0 + 1));
+                accm[r0] = v0; accm[r0 + 1] = v1;
+            } else if constexpr (q == 1) {
+                const float v0 = accm[r0], v1 = accm[r0 + 1];
+                int one0, one1;                                    // (operands: phase 0's integer max -- VALU results, no MFMA hazard)
+                asm("v_med3_i32 %0, %1, 0, 1" : "=v"(one0) : "v"(__float_as_int(v0)));
+                asm("v_med3_i32 %0, %1, 0, 1" : "=v"(one1) : "v"(__float_as_int(v1)));
+                mword |= ((unsigned)one0 << ((it & 1) * 16 + r0)) | ((unsigned)one1 << ((it & 1) * 16 + r0 + 1));
+                const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+                o1[2 * it + jj][i0] = h0; o1[2 * it + jj][i0 + 1] = h1;
+            } else {                                               // (back-conversion, residual, scale, second plane: ~8 instructions)
+                const float v0 = accm[r0], v1 = accm[r0 + 1];
+                const _Float16 h0 = o1[2 * it + jj][i0], h1 = o1[2 * it + jj][i0 + 1];
+                o2[2 * it + jj][i0] = (_Float16)((v0 - (float)h0) * SPLIT_SCALE);
+                o2[2 * it + jj][i0 + 1] = (_Float16)((v1 - (float)h1) * SPLIT_SCALE);
+            }
+        };
+        // micro-slices of the pending tile that ride on MFMA slot u (of NSLOT) of the tile in flight
+        auto pending = [&](auto LC, auto IT, auto U, auto NSLOTC, f32x16 &accm, f32x16 &accr, f32x16 &accq, auto &o1, auto &o2) __attribute__((always_inline)) {
+            constexpr int u = decltype(U)::value, nslot = decltype(NSLOTC)::value;
+            if constexpr (u < 24) micro(LC, IT, std::integral_constant<int, u>{}, accm, accr, accq, o1, o2);
+            if constexpr (u + nslot < 24) micro(LC, IT, std::integral_constant<int, u + nslot>{}, accm, accr, accq, o1, o2);
+            static_assert(2 * nslot >= 24, "every micro-slice finds a slot");
+            // behind the LAST micro-slice of an odd tile: the mask word of the tile pair (mlp_common.h: store_relu_mask's order)
             constexpr int l = decltype(LC)::value, it = decltype(IT)::value;
-            const float4 *b4 = reinterpret_cast<const float4 *>(bias_l + l * S::BIAS_FLOATS + (lane >> 5) * 16) + it * 8;
-            float v[16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 b = b4[q];
-                v[4 * q + 0] = fmaf(accr[4 * q + 0], SPLIT_INV, accm[4 * q + 0]) + b.x;
-                v[4 * q + 1] = fmaf(accr[4 * q + 1], SPLIT_INV, accm[4 * q + 1]) + b.y;
-                v[4 * q + 2] = fmaf(accr[4 * q + 2], SPLIT_INV, accm[4 * q + 2]) + b.z;
-                v[4 * q + 3] = fmaf(accr[4 * q + 3], SPLIT_INV, accm[4 * q + 3]) + b.w;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int bts = __float_as_int(v[r]);
-                v[r] = __int_as_float(bts > 0 ? bts : 0);
-            }
-            if (save) {
-                if (A.save == 1) {                                 // fp32 tile, mlp.hip's store_tiles order
-                    const rsrc_t RH = make_rsrc(AB.H[l] + (size_t)t * (HBYTES / 4), HBYTES);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) bstore1_nt(RH, v[r], hvoff, tile_soff(it, r));
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {                     // mlp_common.h: store_relu_mask's bit order
-                    int one;                                       // (operand: the integer max above -- a VALU result)
-                    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(one) : "v"(__float_as_int(v[r])));
-                    mword |= (unsigned)one << ((it & 1) * 16 + r);
-                }
-                if (it & 1) {
-                    __builtin_amdgcn_raw_buffer_store_b32(mword, make_rsrc(AB.M[l] + (size_t)t * (MBYTES / 4), MBYTES), lane * 4,
-                                                          (it >> 1) * 256, 0);
-                    mword = 0;
-                }
-            }
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                float u[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) u[i] = v[8 * jj + i];
-                split8(u, o1[2 * it + jj], o2[2 * it + jj]);
+            if constexpr (u == (nslot < 24 ? nslot : 24) - 1 && (it & 1)) {
+                __builtin_amdgcn_raw_buffer_store_b32(mword, make_rsrc(AB.M[l] + (size_t)t * (MBYTES / 4), mrec), lane * 4,
+                                                      (it >> 1) * 256, 0);
+                mword = 0;
             }
         };
 
-        // one step: the MFMAs of its tiles from LDS buffer (st & 1); a finished tile's epilogue behind the next tile's MFMAs
-        auto run_layer = [&](auto LC, auto in1, auto in2, f16x8 (&o1)[2 * HT], f16x8 (&o2)[2 * HT]) __attribute__((always_inline)) {
+        // one layer: its steps (pairs of output tiles); `in`: the layer's input planes (= the previous layer's output planes,
+        // which the pending tile of that layer is still filling during tile 0), `o`: its output planes
+        auto run_layer = [&](auto LC, auto &in1, auto &in2, auto &o1, auto &o2) __attribute__((always_inline)) {
             constexpr int l = decltype(LC)::value, KS = L.ks[l], NT = L.tiles_out[l], NP = L.pairs[l];
             constexpr int s0 = [] { int s = 0; for (int k = 0; k < l; ++k) s += L.pairs[k]; return s; }();
+            constexpr bool LAST = l == NL - 1;
+            f32x16 zm, zr, zq;                                     // (output layer: its single tile's sums)
             sfor<0, NP>([&](auto PC) {
                 constexpr int p = decltype(PC)::value, st = s0 + p, tin = S::tiles_in(st), nxt_st = (st + 1) % NS;
                 const unsigned char *wsrc = wl + (st & 1) * S::BUF;
                 const u32x4 *mine = reinterpret_cast<const u32x4 *>(wsrc) + lane;
                 stage_load(std::integral_constant<int, nxt_st>{});
-                // flat MFMA-triple index n = tt_ * KS + j; chunk of (tile tt_, plane q, k-step j) = (tt_ * 2 + q) * KS + j
+                // flat k-step index n = tt_ * KS + j; chunk of (tile tt_, plane q, k-step j) = (tt_ * 2 + q) * KS + j
                 constexpr int NTOT = tin * KS;
-                u32x4 wb[2][2];
+                // weight operands: a ring of three k-steps (requested two k-steps = ~190 clocks ahead)
+                u32x4 wb[3][2];
                 wb[0][0] = mine[0 * 64];
                 wb[0][1] = mine[KS * 64];
+                if constexpr (NTOT > 1) {
+                    wb[1][0] = mine[((0 * 2 + 0) * KS + 1) * 64];
+                    wb[1][1] = mine[((0 * 2 + 1) * KS + 1) * 64];
+                }
                 sfor<0, NTOT>([&](auto NC) {
                     constexpr int n = decltype(NC)::value, tt_ = n / KS, j = n % KS, it = 2 * p + tt_;
-                    if constexpr (n + 1 < NTOT) {
-                        constexpr int t2 = (n + 1) / KS, j2 = (n + 1) % KS;
-                        wb[(n + 1) & 1][0] = mine[((t2 * 2 + 0) * KS + j2) * 64];
-                        wb[(n + 1) & 1][1] = mine[((t2 * 2 + 1) * KS + j2) * 64];
+                    if constexpr (n + 2 < NTOT) {
+                        constexpr int t2 = (n + 2) / KS, j2 = (n + 2) % KS;
+                        wb[(n + 2) % 3][0] = mine[((t2 * 2 + 0) * KS + j2) * 64];
+                        wb[(n + 2) % 3][1] = mine[((t2 * 2 + 1) * KS + j2) * 64];
                     }
-                    f32x16 &m = am[it & 1], &r = ar[it & 1];
-                    if constexpr (j == 0) {
+                    if constexpr (j == 0 && !LAST) {               // this tile's biases, for its epilogue a tile from now
+                        const float4 *bp = reinterpret_cast<const float4 *>(bias_l + l * S::BIAS_FLOATS + it * 32 + (lane >> 5) * 16);
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) { m[q] = 0.f; r[q] = 0.f; }
+                        for (int q = 0; q < 4; ++q) bz4[it & 1][q] = bp[q];
                     }
-                    const f16x8 w1 = __builtin_bit_cast(f16x8, wb[n & 1][0]), w2 = __builtin_bit_cast(f16x8, wb[n & 1][1]);
-                    m = mfma_h(w1, in1(j), m);
-                    r = mfma_h(w1, in2(j), r);
-                    r = mfma_h(w2, in1(j), r);
-                    if constexpr (j == KS - 1) {
-                        // the previous tile's epilogue, behind this tile's MFMAs in issue order
-                        if constexpr (it > 0) tile_epilogue(LC, std::integral_constant<int, it - 1>{}, am[(it - 1) & 1], ar[(it - 1) & 1], o1, o2);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    f32x16 &m = LAST ? zm : am[it & 1], &r = LAST ? zr : ar[it & 1], &qq = LAST ? zq : aq[it & 1];
+                    const f16x8 w1 = __builtin_bit_cast(f16x8, wb[n % 3][0]), w2 = __builtin_bit_cast(f16x8, wb[n % 3][1]);
+                    // the pending tile: the previous tile of this layer, or the last tile of the previous layer
+                    constexpr bool HAVE = it > 0 || l > 0;
+                    constexpr int pl = it > 0 ? l : l - 1, pit = it > 0 ? it - 1 : (l > 0 ? L.tiles_out[l > 0 ? l - 1 : 0] - 1 : 0);
+                    auto ride = [&](auto U) __attribute__((always_inline)) {
+                        if constexpr (HAVE) {
+                            if constexpr (it > 0) pending(std::integral_constant<int, pl>{}, std::integral_constant<int, pit>{}, U,
+                                                          std::integral_constant<int, 3 * KS>{}, am[pit & 1], ar[pit & 1], aq[pit & 1], o1, o2);
+                            else pending(std::integral_constant<int, pl>{}, std::integral_constant<int, pit>{}, U,
+                                         std::integral_constant<int, 3 * KS>{}, am[pit & 1], ar[pit & 1], aq[pit & 1], in1, in2);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);         // one MFMA + its micro-slice per scheduling region
+                    };
+                    r = mfma_h(w1, in2[j], j == 0 ? zero16 : r);
+                    ride(std::integral_constant<int, 3 * j + 0>{});
+                    m = mfma_h(w1, in1[j], j == 0 ? zero16 : m);
+                    ride(std::integral_constant<int, 3 * j + 1>{});
+                    qq = mfma_h(w2, in1[j], j == 0 ? zero16 : qq);
+                    ride(std::integral_constant<int, 3 * j + 2>{});
                 });
-                if constexpr (p == NP - 1)                         // last tile of the layer: the next layer needs it
-                    tile_epilogue(LC, std::integral_constant<int, NT - 1>{}, am[(NT - 1) & 1], ar[(NT - 1) & 1], o1, o2);
+                if constexpr (LAST) {
+                    const float4 bz = *reinterpret_cast<const float4 *>(bias_l + l * S::BIAS_FLOATS + (lane >> 5) * 16);
+                    const float bzv[4] = {bz.x, bz.y, bz.z, bz.w};
+                    const rsrc_t RZ = make_rsrc(A.zout + (size_t)t * D.zrows * 32, live ? D.zrows * 32 * 4 : 0);
+                    // rows 0..3 of the output tile live in registers 0..3 of lane half 0 (acc_row(r, 0) = r); half 1's lanes
+                    // are pointed past the 4-row tile's range, which the descriptor drops
+                    const int zvoff = ((h ? D.zrows : 0) * 32 + s_) * 4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bstore1(RZ, q < 3 ? fmaf(zr[q] + zq[q], SPLIT_INV, zm[q]) + bzv[q] : 0.f, zvoff, q * 128);
+                }
+                ESR_SPLIT_STAMP(1 + 3 * st);
                 stage_store(std::integral_constant<int, nxt_st>{}, wl + ((st + 1) & 1) * S::BUF);
+                ESR_SPLIT_STAMP(2 + 3 * st);
                 step_barrier();
+                ESR_SPLIT_STAMP(3 + 3 * st);
             });
         };
-        run_layer(std::integral_constant<int, 0>{}, [&](int j) { return xi1[j]; }, [&](int j) { return xi2[j]; }, pa1, pa2);
-        run_layer(std::integral_constant<int, 1>{}, [&](int j) { return pa1[j]; }, [&](int j) { return pa2[j]; }, pb1, pb2);
-        run_layer(std::integral_constant<int, 2>{}, [&](int j) { return pb1[j]; }, [&](int j) { return pb2[j]; }, pa1, pa2);
-        {   // output layer: one tile, one step
-            constexpr int l = NL - 1, KS = L.ks[l], st = NS - 1, nxt_st = 0;
-            static_assert(S::layer_of(st) == l && S::tiles_in(st) == 1, "the output layer is the last step");
-            const unsigned char *wsrc = wl + (st & 1) * S::BUF;
-            const u32x4 *mine = reinterpret_cast<const u32x4 *>(wsrc) + lane;
-            stage_load(std::integral_constant<int, nxt_st>{});
-            f32x16 zm, zr;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) { zm[q] = 0.f; zr[q] = 0.f; }
-            u32x4 wb[2][2];
-            wb[0][0] = mine[0];
-            wb[0][1] = mine[KS * 64];
-            sfor<0, KS>([&](auto JC) {
-                constexpr int j = decltype(JC)::value;
-                if constexpr (j + 1 < KS) {
-                    wb[(j + 1) & 1][0] = mine[(j + 1) * 64];
-                    wb[(j + 1) & 1][1] = mine[(KS + j + 1) * 64];
-                }
-                const f16x8 w1 = __builtin_bit_cast(f16x8, wb[j & 1][0]), w2 = __builtin_bit_cast(f16x8, wb[j & 1][1]);
-                zm = mfma_h(w1, pa1[j], zm);
-                zr = mfma_h(w1, pa2[j], zr);
-                zr = mfma_h(w2, pa1[j], zr);
-            });
-            const float4 bz = *reinterpret_cast<const float4 *>(bias_l + l * S::BIAS_FLOATS + (lane >> 5) * 16);
-            const float bzv[4] = {bz.x, bz.y, bz.z, bz.w};
-            const rsrc_t RZ = make_rsrc(A.zout + (size_t)t * D.zrows * 32, live ? D.zrows * 32 * 4 : 0);
-            // rows 0..3 of the output tile live in registers 0..3 of lane half 0 (acc_row(r, 0) = r); half 1's lanes are
-            // pointed past the 4-row tile's range, which the descriptor drops
-            const int zvoff = ((h ? D.zrows : 0) * 32 + s_) * 4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bstore1(RZ, r < 3 ? fmaf(zr[r], SPLIT_INV, zm[r]) + bzv[r] : 0.f, zvoff, r * 128);
-            stage_store(std::integral_constant<int, nxt_st>{}, wl + ((st + 1) & 1) * S::BUF);
-            step_barrier();
-        }
+        run_layer(std::integral_constant<int, 0>{}, xi1, xi2, pa1, pa2);
+        run_layer(std::integral_constant<int, 1>{}, pa1, pa2, pb1, pb2);
+        run_layer(std::integral_constant<int, 2>{}, pb1, pb2, pa1, pa2);
+        run_layer(std::integral_constant<int, 3>{}, pa1, pa2, pb1, pb2);      // output layer (pb: unused)
         static_assert(NS % 2 == 0, "an even number of steps per group: step 0 of every group sits in LDS buffer 0");
     }
 }

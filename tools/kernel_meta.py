@@ -6,7 +6,11 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fvisibility=hi
          "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only"]
 
 
+EXTRA = {}     # per-source flags, as esr_nerf_amd/build.py
+
+
 def asm_of(src, out=None, extra=()):
+    extra = tuple(extra) + EXTRA.get(os.path.basename(src), ())
     out = out or os.path.join("/tmp", "esr_asm_" + os.path.basename(src) + ".s")
     stamp = out + ".stamp"
     deps = [src] + glob.glob(os.path.join(os.path.dirname(src), "*.h")) + [os.path.join(ROOT, "include", "esr_hip.h")]
