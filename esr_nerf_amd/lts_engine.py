@@ -156,7 +156,6 @@ class LtsEngine(FineEngine):
     def __init__(self, device, mlp_dtype: str = "f32"):
         super().__init__(device, mlp_dtype)
         self.ray_sampling = "random"        # or "fib" (cfg.app.model.ray_sampling; esrnerf.py:188-192)
-        self.split_fwd = False              # (the split-fp16 forward is wired into the fine stage's merged launch only)
         self._draw_ring = [None, None, 0, 0]   # pinned buffers of the surface-point draw (_PointDraw)
         self.zero_arena = os.environ.get("ESR_ZERO_ARENA", "1") != "0"      # (read once, here; A/B switch of tools/ab.sh)
         self.prim = Pass(self.device, "primary")
@@ -342,9 +341,15 @@ class LtsEngine(FineEngine):
         if t1 > t0:
             # tone mapper: masks only, its weight gradient recomputes the hidden layer (tone_wgrad.hip, f32 and bf16 operands)
             mode = 0 if not save else 2 if (kind == KIND_TONEMAP and self.tone_recompute) else 1
-            self._run(f"mlp_fwd({net})[{P.name}]", self.mlp_fwd, kind, _lib.ptr(self.packed[net]),
-                      _lib.ptr(x), t0, t1, _lib.ptr_array(H), _lib.ptr_array(M), mode, crow,
-                      _lib.ptr(z), self._s())
+            if kind == KIND_RADIANCE and self.split_fwd and net in self.packed_split:
+                # f32 engine: the radiance forward's products on the 16-bit matrix cores, fp32 results (csrc/mlp_split.hip)
+                self._run(f"mlp_fwd({net})[{P.name}]", self.L.esr_mlp_fwd_split, kind, _lib.ptr(self.packed[net]),
+                          _lib.ptr(self.packed_split[net]), _lib.ptr(x), t0, t1, _lib.ptr_array(H), _lib.ptr_array(M), mode,
+                          crow, _lib.ptr(z), self._s())
+            else:
+                self._run(f"mlp_fwd({net})[{P.name}]", self.mlp_fwd, kind, _lib.ptr(self.packed[net]),
+                          _lib.ptr(x), t0, t1, _lib.ptr_array(H), _lib.ptr_array(M), mode, crow,
+                          _lib.ptr(z), self._s())
         return z
 
     def _net_bwd(self, P: Pass, net, kind, crow, t0, t1, dz, gw, gb):
