@@ -1007,7 +1007,7 @@ ESR_API int esr_mlp_pack(int kind, const esr_mlp_weights_t *w, float *packed, vo
 ESR_API int64_t esr_mlp_packed_split_elems(int kind)
 {
     if (!kind_ok(kind)) return ESR_EINVAL;
-    return (int64_t)split_layout(kind).total_chunks * 512;
+    return ((int64_t)split_layout(kind).total_chunks + split_layout_t(kind).total_chunks) * 512;      // forward | transposed planes
 }
 
 ESR_API int esr_mlp_pack_batch(int n, const int32_t *kinds, const esr_mlp_weights_t *const *w, float *const *packed32,
@@ -1032,7 +1032,7 @@ ESR_API int esr_mlp_pack_batch(int n, const int32_t *kinds, const esr_mlp_weight
         A.out16 = packed16 ? static_cast<__bf16 *>(packed16[i]) : nullptr;
         A.outs = packed_split ? static_cast<_Float16 *>(packed_split[i]) : nullptr;
         const int64_t tot = pack_layout(kind).total + pack16_layout(kind).total +
-                            (A.outs ? (int64_t)split_layout(kind).total_chunks * 512 : 0);
+                            (A.outs ? ((int64_t)split_layout(kind).total_chunks + split_layout_t(kind).total_chunks) * 512 : 0);
         most = tot > most ? tot : most;
     }
     pack_kernel<<<dim3(esr_grid_for(most, 256, 256), n), 256, 0, esr_stream(stream)>>>(B);

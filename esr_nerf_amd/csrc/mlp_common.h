@@ -311,6 +311,56 @@ __host__ __device__ constexpr SplitLayout split_layout(int kind)
     L.total_chunks = o;
     return L;
 }
+// The TRANSPOSED weights as split planes, for the input-gradient chain (mlp_split.hip: mlp_dgrad_split_kernel): "layer" q of
+// this layout is the transpose of network layer NL-1-q (the chain runs output -> input); its k dimension is that layer's
+// OUTPUT features (kfeat16 order; the output layer's 3 rows in slots 8 h + i of a single k-step), its rows the layer's
+// INPUT features (X rows through in_colmap for the first layer: 2 tiles).  Appended to the forward planes.
+__host__ __device__ constexpr SplitLayout split_layout_t(int kind)
+{
+    const Pack16Layout P = pack16_layout(kind);
+    SplitLayout L = {};
+    L.n_layers = P.n_layers;
+    int o = 0;
+    for (int q = 0; q < P.n_layers; ++q) {
+        const int l = P.n_layers - 1 - q;
+        L.ks[q] = P.kso[l]; L.tiles_out[q] = P.tiles_in[l]; L.pairs[q] = (P.tiles_in[l] + 1) / 2;
+        L.in_dim[q] = P.in_dim[l]; L.out_dim[q] = P.out_dim[l];
+        L.off_chunk[q] = o;
+        o += P.tiles_in[l] * 2 * P.kso[l];
+    }
+    L.total_chunks = o;
+    return L;
+}
+template <int KIND>
+__device__ __forceinline__ void packst_body(const PackArgs &A, int64_t e)
+{
+    constexpr SplitLayout L = split_layout_t(KIND);
+    constexpr int64_t BASE = (int64_t)split_layout(KIND).total_chunks * 512;
+    float v = 0.f;
+    int plane = 0;
+    bool done = false;
+#pragma unroll
+    for (int q = 0; q < L.n_layers; ++q) {
+        if (done || (q + 1 < L.n_layers && e >= (int64_t)L.off_chunk[q + 1] * 512)) continue;
+        done = true;
+        const int l = L.n_layers - 1 - q;
+        const bool first = l == 0, last = l == L.n_layers - 1;
+        int64_t i = e - (int64_t)L.off_chunk[q] * 512;
+        const int slot = i & 7; i >>= 3;
+        const int lane = i & 63; i >>= 6;
+        const int j = (int)(i % L.ks[q]); i /= L.ks[q];
+        plane = (int)(i & 1);
+        const int it = (int)(i >> 1);
+        const int h = lane >> 5;
+        const int orow = last ? (8 * h + slot) : kfeat16(j, h, slot);          // output feature of network layer l
+        const int irow = 32 * it + (lane & 31);                                // its input feature / X row
+        const int col = first ? in_colmap(KIND, irow) : irow;
+        if (orow < L.out_dim[q] && col >= 0 && col < L.in_dim[q]) v = A.w[l][(int64_t)orow * L.in_dim[q] + col];
+    }
+    const _Float16 w1 = (_Float16)v;
+    A.outs[BASE + e] = plane == 0 ? w1 : (_Float16)((v - (float)w1) * 2048.f);
+}
+
 template <int KIND>
 __device__ __forceinline__ void packs_body(const PackArgs &A, int64_t e)
 {
@@ -347,12 +397,13 @@ template <int KIND>
 __device__ __forceinline__ void pack_job(const PackArgs &A)
 {
     constexpr int64_t N32 = pack_layout(KIND).total, N16 = pack16_layout(KIND).total;
-    constexpr int64_t NS = (int64_t)split_layout(KIND).total_chunks * 512;
-    const int64_t n = N32 + N16 + (A.outs ? NS : 0);
+    constexpr int64_t NS = (int64_t)split_layout(KIND).total_chunks * 512, NST = (int64_t)split_layout_t(KIND).total_chunks * 512;
+    const int64_t n = N32 + N16 + (A.outs ? NS + NST : 0);
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         if (e < N32) { if (A.out) pack_body<KIND>(A, e); }
         else if (e < N32 + N16) { if (A.out16) pack16_body<KIND>(A, e - N32); }
-        else packs_body<KIND>(A, e - N32 - N16);
+        else if (e < N32 + N16 + NS) packs_body<KIND>(A, e - N32 - N16);
+        else packst_body<KIND>(A, e - N32 - N16 - NS);
     }
 }
 __global__ void __launch_bounds__(256) pack_kernel(PackBatch B)

@@ -67,8 +67,9 @@ __device__ __forceinline__ void split8(const float (&v)[8], f16x8 &p1, f16x8 &p2
     }
 }
 
-template <int KIND> struct SplitSteps {
-    static constexpr SplitLayout L = split_layout(KIND);
+template <int KIND, bool BWD = false> struct SplitSteps {
+    static constexpr SplitLayout L = BWD ? split_layout_t(KIND) : split_layout(KIND);
+    static constexpr int BASE_CHUNK = BWD ? split_layout(KIND).total_chunks : 0;      // the transposed planes follow the forward ones
     static constexpr int NL = L.n_layers;
     static constexpr int n_steps()
     {
@@ -95,7 +96,7 @@ template <int KIND> struct SplitSteps {
         return L.tiles_out[l] - 2 * p >= 2 ? 2 : 1;
     }
     static constexpr int chunks(int s) { return tiles_in(s) * 2 * L.ks[layer_of(s)]; }
-    static constexpr int chunk0(int s) { return L.off_chunk[layer_of(s)] + pair_of(s) * 2 * 2 * L.ks[layer_of(s)]; }
+    static constexpr int chunk0(int s) { return BASE_CHUNK + L.off_chunk[layer_of(s)] + pair_of(s) * 2 * 2 * L.ks[layer_of(s)]; }
     static constexpr int max_chunks()
     {
         int m = 0;
@@ -360,6 +361,215 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
     }
 }
 
+// ---- the input-gradient chain on the same scheme ---------------------------------------------------------------------
+// dZ[2] = mask ⊙ (W3ᵀ dz), dZ[1] = mask ⊙ (W2ᵀ dZ[2]), dZ[0] = mask ⊙ (W1ᵀ dZ[1]), dX = W0ᵀ dZ[0] (rows 0 .. 43: the rows that
+// lead back to a grid) -- mlp.hip's mlp_dgrad_kernel<0> with the products on the 16-bit matrix cores.  Gradients are small
+// (1e-3 .. 1e-9) where fp16's normal range ends at 6e-5, so a tile's chain runs SCALED: s = 2^k with max |dz| of the tile
+// brought to ~16 (the multiplications by s and 1 / s are exact, the ReLU masks do not care, and the chain is linear); a
+// layer can grow a value by at most its row-sum of |W| -- a few units -- against fp16's ceiling of 65504.  What counts for
+// the consumers (weight gradients and grid scatters sum over samples) is the error relative to the tile's LARGEST
+// gradients: 2^-22 of them, as in the forward; a sample whose gradient is 2^-20 of its tile's largest loses relative
+// precision, as it does in any sum with the large ones.
+struct DSplitSeg {
+    const _Float16 *planes;    // the net's split planes (forward | transposed)
+    int t0, t1;
+    int b0, nb;
+};
+struct DSplitBatch {
+    const float *dz;
+    const unsigned *M[3];
+    float *dZ[3];
+    float *dX;
+    int nseg;
+    DSplitSeg seg[2];
+};
+
+template <int KIND>
+__global__ void __launch_bounds__(64 * SPW, 1) mlp_dgrad_split_kernel(DSplitBatch AB)
+{
+    using S = SplitSteps<KIND, true>;
+    constexpr NetDesc D = net_desc(KIND);
+    constexpr SplitLayout L = S::L;
+    constexpr int NL = S::NL, NHID = NL - 1, HT = D.hid_tiles, NS = S::NS;
+    constexpr unsigned HBYTES = HT * 32 * 32 * 4, MBYTES = (HT / 2) * 256;
+    static_assert(NHID == 3 && HT % 2 == 0 && L.ks[0] == 1 && L.tiles_out[NL - 1] == 2, "written for the radiance net");
+    DSplitSeg A = AB.seg[0];
+    if (AB.nseg > 1 && (int)blockIdx.x >= AB.seg[1].b0) A = AB.seg[1];
+    const int blk0 = A.b0, nblk = A.nb;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wl[];          // buffer 0 | buffer 1
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, s_ = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = A.t1 - A.t0, ngroups = (ntiles + SPW - 1) / SPW;
+    const rsrc_t WP = make_rsrc(A.planes, (unsigned)((S::BASE_CHUNK + L.total_chunks) * 1024));
+    u32x4 pre[S::PRE];
+    auto stage_load = [&](auto ST) __attribute__((always_inline)) {
+        constexpr int st = decltype(ST)::value, pieces = S::chunks(st) * 64, base = S::chunk0(st) * 1024;
+#pragma unroll
+        for (int k = 0; k < S::PRE; ++k)
+            if (k * 64 * SPW < pieces) pre[k] = __builtin_amdgcn_raw_buffer_load_b128(WP, (tid + 64 * SPW * k) * 16, base, 0);
+    };
+    auto stage_store = [&](auto ST, unsigned char *dst) __attribute__((always_inline)) {
+        constexpr int st = decltype(ST)::value, pieces = S::chunks(st) * 64;
+#pragma unroll
+        for (int k = 0; k < S::PRE; ++k)
+            if (k * 64 * SPW < pieces && tid + 64 * SPW * k < pieces)
+                *reinterpret_cast<u32x4 *>(dst + (size_t)(tid + 64 * SPW * k) * 16) = pre[k];
+    };
+    stage_load(std::integral_constant<int, 0>{});
+    stage_store(std::integral_constant<int, 0>{}, wl);
+    step_barrier();
+
+    // the group's output gradients (rows 0..3 of the 4-row tile: half 0's slots 0..3, everything else of the k-step is zero)
+    // and ReLU masks
+    float zn[4];
+    unsigned mn[NHID][HT / 2];
+    auto fetch = [&](int tg) {
+        const int tt = A.t0 + tg * SPW + wv;
+        const int t = tt < A.t1 ? tt : A.t1 - 1;
+        const rsrc_t RZ = make_rsrc(AB.dz + (size_t)t * D.zrows * 32, D.zrows * 32 * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) zn[i] = bload1(RZ, s_ * 4, i * 128);
+#pragma unroll
+        for (int l = 0; l < NHID; ++l)
+            load_relu_mask<HT>(make_rsrc(AB.M[l] + (size_t)t * (MBYTES / 4), MBYTES), mn[l], lane);
+    };
+    if ((int)blockIdx.x - blk0 < ngroups) fetch((int)blockIdx.x - blk0);
+    const int hvoff = tile_voff(lane);
+
+    for (int tg = (int)blockIdx.x - blk0; tg < ngroups; tg += nblk) {
+        const int tt = A.t0 + tg * SPW + wv;
+        const bool live = tt < A.t1;
+        const int t = live ? tt : A.t1 - 1;
+        // the tile's scale: 2^k with the largest |dz| of its 32 samples at ~16 (exponent arithmetic; an all-zero tile: 1)
+        float zmax = fmaxf(fmaxf(fabsf(zn[0]), fabsf(zn[1])), fabsf(zn[2]));
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, o));
+        const int ez = (__float_as_int(zmax) >> 23) & 0xff;                   // biased exponent of the maximum
+        const int ks = ez == 0 ? 0 : 131 - ez;                                // scale exponent: max lands in [16, 32)
+        const int kc = ks < -100 ? -100 : (ks > 100 ? 100 : ks);
+        const float sc = __int_as_float((127 + kc) << 23), isc = __int_as_float((127 - kc) << 23);
+        f16x8 xi1[1], xi2[1];
+        {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (h == 0 && i < 3) ? zn[i] * sc : 0.f;
+            split8(v, xi1[0], xi2[0]);
+        }
+        unsigned msk[NHID][HT / 2];
+#pragma unroll
+        for (int l = 0; l < NHID; ++l)
+#pragma unroll
+            for (int w = 0; w < HT / 2; ++w) msk[l][w] = mn[l][w];
+        fetch(tg + nblk < ngroups ? tg + nblk : tg);
+        f16x8 pa1[2 * HT], pa2[2 * HT], pb1[2 * HT], pb2[2 * HT];
+        f32x16 am[2], ar[2], aq[2];
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+        // micro-slices of a finished tile of transposed layer q (8 register pairs x 3 phases, as in the forward):
+        //   q < 3: phase 0 value (scaled), ReLU mask of the layer below, the unscaled fp32 dZ store; phases 1 / 2 the planes
+        //   q = 3: phase 0 unscaled value -> dX rows (the descriptor ends at row 44: the rows above are not written)
+        auto micro = [&](auto QC, auto IT, auto MS, f32x16 &accm, f32x16 &accr, f32x16 &accq, auto &o1, auto &o2) __attribute__((always_inline)) {
+            constexpr int q = decltype(QC)::value, it = decltype(IT)::value, ms = decltype(MS)::value, p = ms / 3, ph = ms % 3;
+            constexpr int r0 = 2 * p, jj = r0 >> 3, i0 = r0 & 7;
+            if constexpr (q == NL - 1) {
+                if constexpr (ph == 0) {
+                    const float v0 = fmaf(accr[r0] + accq[r0], SPLIT_INV, accm[r0]) * isc;
+                    const float v1 = fmaf(accr[r0 + 1] + accq[r0 + 1], SPLIT_INV, accm[r0 + 1]) * isc;
+                    const rsrc_t RX = make_rsrc(AB.dX + (size_t)t * 64 * 32, live ? dx_rows(KIND) / 4 * 4 * 128 + (dx_rows(KIND) % 4 ? 512 : 0) : 0);
+                    bstore1(RX, v0, hvoff, tile_soff(it, r0));           // (default policy: the scatter reads dX next)
+                    bstore1(RX, v1, hvoff, tile_soff(it, r0 + 1));
+                }
+            } else {
+                constexpr int d = NHID - 1 - q;                              // this tile is a tile of dZ[d]
+                if constexpr (ph == 0) {
+                    float v0 = fmaf(accr[r0] + accq[r0], SPLIT_INV, accm[r0]), v1 = fmaf(accr[r0 + 1] + accq[r0 + 1], SPLIT_INV, accm[r0 + 1]);
+                    const int k0 = ((int)(msk[d][it >> 1] << (31 - ((it & 1) * 16 + r0)))) >> 31;
+                    const int k1 = ((int)(msk[d][it >> 1] << (31 - ((it & 1) * 16 + r0 + 1)))) >> 31;
+                    v0 = __int_as_float(__float_as_int(v0) & k0);
+                    v1 = __int_as_float(__float_as_int(v1) & k1);
+                    const rsrc_t RD = make_rsrc(AB.dZ[d] + (size_t)t * (HBYTES / 4), (live && AB.dZ[d]) ? HBYTES : 0u);
+                    bstore1_nt(RD, v0 * isc, hvoff, tile_soff(it, r0));
+                    bstore1_nt(RD, v1 * isc, hvoff, tile_soff(it, r0 + 1));
+                    accm[r0] = v0; accm[r0 + 1] = v1;
+                } else if constexpr (ph == 1) {
+                    o1[2 * it + jj][i0] = (_Float16)accm[r0]; o1[2 * it + jj][i0 + 1] = (_Float16)accm[r0 + 1];
+                } else {
+                    const float v0 = accm[r0], v1 = accm[r0 + 1];
+                    const _Float16 h0 = o1[2 * it + jj][i0], h1 = o1[2 * it + jj][i0 + 1];
+                    o2[2 * it + jj][i0] = (_Float16)((v0 - (float)h0) * SPLIT_SCALE);
+                    o2[2 * it + jj][i0 + 1] = (_Float16)((v1 - (float)h1) * SPLIT_SCALE);
+                }
+            }
+        };
+        // the pending tile's micro-slices u, u + nslot, u + 2 nslot, ... ride on MFMA slot u of the tile in flight
+        auto pending = [&](auto QC, auto IT, auto U, auto NSLOTC, f32x16 &accm, f32x16 &accr, f32x16 &accq, auto &o1, auto &o2) __attribute__((always_inline)) {
+            constexpr int u = decltype(U)::value, nslot = decltype(NSLOTC)::value;
+            sfor<0, (24 + nslot - 1) / nslot>([&](auto KC) {
+                constexpr int msi = u + decltype(KC)::value * nslot;
+                if constexpr (msi < 24) micro(QC, IT, std::integral_constant<int, msi>{}, accm, accr, accq, o1, o2);
+            });
+        };
+        auto run_layer = [&](auto QC, auto &in1, auto &in2, auto &o1, auto &o2) __attribute__((always_inline)) {
+            constexpr int q = decltype(QC)::value, KS = L.ks[q], NT = L.tiles_out[q], NP = L.pairs[q];
+            constexpr int s0 = [] { int s = 0; for (int k = 0; k < q; ++k) s += L.pairs[k]; return s; }();
+            sfor<0, NP>([&](auto PC) {
+                constexpr int p = decltype(PC)::value, st = s0 + p, tin = S::tiles_in(st), nxt_st = (st + 1) % NS;
+                const unsigned char *wsrc = wl + (st & 1) * S::BUF;
+                const u32x4 *mine = reinterpret_cast<const u32x4 *>(wsrc) + lane;
+                stage_load(std::integral_constant<int, nxt_st>{});
+                constexpr int NTOT = tin * KS;
+                u32x4 wb[3][2];
+                wb[0][0] = mine[0 * 64];
+                wb[0][1] = mine[KS * 64];
+                if constexpr (NTOT > 1) {
+                    constexpr int t1_ = 1 / KS, j1_ = 1 % KS;
+                    wb[1][0] = mine[((t1_ * 2 + 0) * KS + j1_) * 64];
+                    wb[1][1] = mine[((t1_ * 2 + 1) * KS + j1_) * 64];
+                }
+                sfor<0, NTOT>([&](auto NC) {
+                    constexpr int n = decltype(NC)::value, tt_ = n / KS, j = n % KS, it = 2 * p + tt_;
+                    if constexpr (n + 2 < NTOT) {
+                        constexpr int t2 = (n + 2) / KS, j2 = (n + 2) % KS;
+                        wb[(n + 2) % 3][0] = mine[((t2 * 2 + 0) * KS + j2) * 64];
+                        wb[(n + 2) % 3][1] = mine[((t2 * 2 + 1) * KS + j2) * 64];
+                    }
+                    f32x16 &m = am[it & 1], &r = ar[it & 1], &qq = aq[it & 1];
+                    const f16x8 w1 = __builtin_bit_cast(f16x8, wb[n % 3][0]), w2 = __builtin_bit_cast(f16x8, wb[n % 3][1]);
+                    constexpr bool HAVE = it > 0 || q > 0;
+                    constexpr int pq = it > 0 ? q : q - 1, pit = it > 0 ? it - 1 : (q > 0 ? L.tiles_out[q > 0 ? q - 1 : 0] - 1 : 0);
+                    auto ride = [&](auto U) __attribute__((always_inline)) {
+                        if constexpr (HAVE) {
+                            if constexpr (it > 0) pending(std::integral_constant<int, pq>{}, std::integral_constant<int, pit>{}, U,
+                                                          std::integral_constant<int, 3 * KS>{}, am[pit & 1], ar[pit & 1], aq[pit & 1], o1, o2);
+                            else pending(std::integral_constant<int, pq>{}, std::integral_constant<int, pit>{}, U,
+                                         std::integral_constant<int, 3 * KS>{}, am[pit & 1], ar[pit & 1], aq[pit & 1], in1, in2);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    r = mfma_h(w1, in2[j], j == 0 ? zero16 : r);
+                    ride(std::integral_constant<int, 3 * j + 0>{});
+                    m = mfma_h(w1, in1[j], j == 0 ? zero16 : m);
+                    ride(std::integral_constant<int, 3 * j + 1>{});
+                    qq = mfma_h(w2, in1[j], j == 0 ? zero16 : qq);
+                    ride(std::integral_constant<int, 3 * j + 2>{});
+                });
+                if constexpr (q == NL - 1 && p == NP - 1) {         // the very last tile (dX rows 32..63): nobody to ride on
+                    sfor<0, 24>([&](auto MC) {
+                        micro(QC, std::integral_constant<int, NT - 1>{}, MC, am[(NT - 1) & 1], ar[(NT - 1) & 1], aq[(NT - 1) & 1], o1, o2);
+                    });
+                }
+                stage_store(std::integral_constant<int, nxt_st>{}, wl + ((st + 1) & 1) * S::BUF);
+                step_barrier();
+            });
+        };
+        run_layer(std::integral_constant<int, 0>{}, xi1, xi2, pa1, pa2);      // W3ᵀ dz -> dZ[2]
+        run_layer(std::integral_constant<int, 1>{}, pa1, pa2, pb1, pb2);      // -> dZ[1]
+        run_layer(std::integral_constant<int, 2>{}, pb1, pb2, pa1, pa2);      // -> dZ[0]
+        run_layer(std::integral_constant<int, 3>{}, pa1, pa2, pb1, pb2);      // -> dX (pb unused)
+        static_assert(NS % 2 == 0, "an even number of steps per group: step 0 of every group sits in LDS buffer 0");
+    }
+}
+
 // workgroups per segment proportional to its tile groups (every non-empty segment >= 1); returns the grid
 int share_blocks_split(SplitSeg *seg, int nseg)
 {
@@ -456,4 +666,66 @@ ESR_API int esr_mlp_fwd_fine_split(const float *packed32_off, const void *planes
     if (t_on > 0) B.seg[n++] = SplitSeg{packed32_emo, pe, 0, t_on, 1, 0, z_emo, 0, 0};
     B.nseg = n;
     return launch_split(B, esr_stream(stream));
+}
+
+namespace {
+int launch_dsplit(DSplitBatch &B, hipStream_t s)
+{
+    using S = SplitSteps<ESR_MLP_RADIANCE, true>;
+    int groups[2], total = 0;
+    for (int k = 0; k < B.nseg; ++k) { groups[k] = (B.seg[k].t1 - B.seg[k].t0 + SPW - 1) / SPW; total += groups[k]; }
+    const int grid = total < 256 ? total : 256;
+    if (B.nseg == 1) { B.seg[0].b0 = 0; B.seg[0].nb = grid; }
+    else {
+        int n0 = (int)((int64_t)grid * groups[0] / total);
+        if (n0 < 1) n0 = 1;
+        if (n0 > groups[0]) n0 = groups[0];
+        if (grid - n0 > groups[1]) n0 = grid - groups[1];
+        if (grid - n0 < 1) n0 = grid - 1;
+        B.seg[0].b0 = 0; B.seg[0].nb = n0; B.seg[1].b0 = n0; B.seg[1].nb = grid - n0;
+    }
+    static std::atomic<uint64_t> optin{0};
+    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_dgrad_split_kernel<ESR_MLP_RADIANCE>), 2 * S::BUF, optin)) return rc;
+    mlp_dgrad_split_kernel<ESR_MLP_RADIANCE><<<grid, 64 * SPW, 2 * S::BUF, s>>>(B);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace
+
+// esr_mlp_dgrad's contract (ESR_MLP_RADIANCE only): input / hidden gradients over tiles [t0, t1) from the net's split planes.
+ESR_API int esr_mlp_dgrad_split(int kind, const void *planes, const float *dz, int32_t t0, int32_t t1, const uint32_t *const *M,
+                                float *const *dZ, float *dX, void *stream)
+{
+    if (kind != ESR_MLP_RADIANCE || t0 < 0 || t1 < t0) return ESR_EINVAL;
+    if (t1 == t0) return 0;
+    if (!planes || !dz || !M || !dZ || !dX) return ESR_EINVAL;
+    DSplitBatch B = {};
+    B.dz = dz; B.dX = dX;
+    for (int l = 0; l < 3; ++l) {
+        if (!M[l]) return ESR_EINVAL;
+        B.M[l] = M[l]; B.dZ[l] = dZ[l];                     // a NULL dZ[l] is computed but not stored
+    }
+    B.nseg = 1;
+    B.seg[0] = DSplitSeg{static_cast<const _Float16 *>(planes), t0, t1, 0, 0};
+    return launch_dsplit(B, esr_stream(stream));
+}
+
+// esr_mlp_dgrad_fine's contract: the emissive net on tiles [0, t_on), the non-emissive net on [t_on, t_all), one launch.
+ESR_API int esr_mlp_dgrad_fine_split(const void *planes_emo, const void *planes_off, const float *dz, int32_t t_on, int32_t t_all,
+                                     const uint32_t *const *M, float *const *dZ, float *dX, void *stream)
+{
+    if (t_on < 0 || t_all < t_on) return ESR_EINVAL;
+    if (t_all == 0) return 0;
+    if (!planes_emo || !planes_off || !dz || !M || !dZ || !dX) return ESR_EINVAL;
+    DSplitBatch B = {};
+    B.dz = dz; B.dX = dX;
+    for (int l = 0; l < 3; ++l) {
+        if (!M[l]) return ESR_EINVAL;
+        B.M[l] = M[l]; B.dZ[l] = dZ[l];
+    }
+    int n = 0;
+    if (t_on > 0) B.seg[n++] = DSplitSeg{static_cast<const _Float16 *>(planes_emo), 0, t_on, 0, 0};
+    if (t_all > t_on) B.seg[n++] = DSplitSeg{static_cast<const _Float16 *>(planes_off), t_on, t_all, 0, 0};
+    B.nseg = n;
+    return launch_dsplit(B, esr_stream(stream));
 }

@@ -146,6 +146,8 @@ class FineEngine:
         # (csrc/mlp_split.hip); ESR_SPLIT_FWD=0: the f32 MFMA forward (A/B timing, and for inputs beyond fp16's range)
         self.split_fwd = (not self.bf16) and os.environ.get("ESR_SPLIT_FWD", "1") != "0"
         self.packed_split: Dict[str, torch.Tensor] = {}
+        # ... and the radiance input-gradient chain the same way (per-tile power-of-two scaling); ESR_SPLIT_BWD=0: f32 MFMA
+        self.split_bwd = self.split_fwd and os.environ.get("ESR_SPLIT_BWD", "1") != "0"
         self.tone_scratch = torch.empty(self.L.esr_tone_wgrad_scratch_floats() if self.tone_recompute else 1,
                                         dtype=torch.float32, device=self.device)
         self.neus_grad = False          # cfg neus_alpha: "grad" (set by the renderer)
@@ -641,6 +643,9 @@ class FineEngine:
                 pe, po = _lib.ptr(self.packed["emo"]), _lib.ptr(self.packed["off"])
                 self._run("mlp_dgrad(rad)", L.esr_mlp_dgrad_fine_bf16, self._p16[pe.value], self._p16[po.value],
                           _lib.ptr(ws["dz"]), to, ta, M, dZ, _lib.ptr(ws["dX"]), s)
+            elif self.split_fwd and self.split_bwd and "off" in self.packed_split and "emo" in self.packed_split:
+                self._run("mlp_dgrad(rad)", L.esr_mlp_dgrad_fine_split, _lib.ptr(self.packed_split["emo"]),
+                          _lib.ptr(self.packed_split["off"]), _lib.ptr(ws["dz"]), to, ta, M, dZ, _lib.ptr(ws["dX"]), s)
             else:
                 self._run("mlp_dgrad(rad)", L.esr_mlp_dgrad_fine, _lib.ptr(self.packed["emo"]), _lib.ptr(self.packed["off"]),
                           _lib.ptr(ws["dz"]), to, ta, M, dZ, _lib.ptr(ws["dX"]), s)

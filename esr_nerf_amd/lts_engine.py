@@ -363,8 +363,12 @@ class LtsEngine(FineEngine):
         if t1 > t0:
             s = self._s()
             recompute = kind == KIND_TONEMAP and self.tone_recompute
-            self._run(f"mlp_dgrad({net})[{P.name}]", self.mlp_dgrad, kind, _lib.ptr(self.packed[net]),
-                      _lib.ptr(dz), t0, t1, _lib.ptr_array(M), _lib.ptr_array([None] * nh if recompute else dZ), _lib.ptr(dX), s)
+            if kind == KIND_RADIANCE and self.split_fwd and self.split_bwd and net in self.packed_split:
+                self._run(f"mlp_dgrad({net})[{P.name}]", self.L.esr_mlp_dgrad_split, kind, _lib.ptr(self.packed_split[net]),
+                          _lib.ptr(dz), t0, t1, _lib.ptr_array(M), _lib.ptr_array(dZ), _lib.ptr(dX), s)
+            else:
+                self._run(f"mlp_dgrad({net})[{P.name}]", self.mlp_dgrad, kind, _lib.ptr(self.packed[net]),
+                          _lib.ptr(dz), t0, t1, _lib.ptr_array(M), _lib.ptr_array([None] * nh if recompute else dZ), _lib.ptr(dX), s)
             if recompute:
                 (w0, w1), (b0, _) = self._raw[net]
 

@@ -331,6 +331,13 @@ int esr_mlp_fwd_split(int kind, const float *packed32, const void *planes, const
 int esr_mlp_fwd_fine_split(const float *packed32_off, const void *planes_off, const float *packed32_emo,
                            const void *planes_emo, const float *X, int32_t t_on, int32_t t_all, float *const *H,
                            uint32_t *const *M, int color_row_detached, float *z_off, float *z_emo, void *stream);
+/* The input-gradient chain the same way (contracts of esr_mlp_dgrad / esr_mlp_dgrad_fine; ESR_MLP_RADIANCE only): the split
+ * buffer also holds the TRANSPOSED weights' planes.  Gradients are far below fp16's normal range, so each 32-sample tile's
+ * chain runs scaled by a power of two chosen from its largest |dz| (exact), and dZ / dX are written unscaled in fp32. */
+int esr_mlp_dgrad_split(int kind, const void *planes, const float *dz, int32_t t0, int32_t t1, const uint32_t *const *M,
+                        float *const *dZ, float *dX, void *stream);
+int esr_mlp_dgrad_fine_split(const void *planes_emo, const void *planes_off, const float *dz, int32_t t_on, int32_t t_all,
+                             const uint32_t *const *M, float *const *dZ, float *dX, void *stream);
 
 /*
  * Forward over tiles [t0,t1).  X: layer-1 input, tile-major [tiles,xrows,32].

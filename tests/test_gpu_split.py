@@ -157,3 +157,103 @@ def test_trainer_step_with_split_forward_equals_the_f32_forward_step():
     for k in g_f:
         assert rel_err(g_s[k], g_f[k]) < 5e-4, (k, rel_err(g_s[k], g_f[k]))
     assert np.median([rel_err(g_s[k], g_f[k]) for k in g_f]) < 2e-5
+
+
+@pytest.mark.parametrize("tiles,gscale", [(1, 1.0), (37, 1e-4), (300, 1e-7), (64, 30.0)])
+def test_split_dgrad_vs_double_precision_and_vs_the_f32_kernel(tiles, gscale):
+    """The input-gradient chain from split planes (per-tile power-of-two scaling) against a double-precision evaluation with
+    the SAME ReLU masks, and against mlp.hip's f32 kernel: dZ[0..2] and the grid-fed dX rows; output gradients of very different
+    magnitudes per sample and per tile (weights of the compositor span orders of magnitude), rows above 43 left untouched."""
+    from esr_nerf_amd import _lib
+    from esr_nerf_amd.fine_engine import FineEngine
+    eng = FineEngine("cuda:0")
+    L, s = eng.L, _lib.stream_ptr("cuda:0")
+    g = torch.Generator().manual_seed(tiles + 11)
+    Ws, Bs = _net(g)
+    _pack(L, eng, "off", Ws, Bs)
+    X = torch.randn(tiles, 104, 32, generator=g)
+    Xd = X.cuda().contiguous()
+    H = [torch.zeros(tiles, 192, 32, device="cuda") for _ in range(3)]
+    M = [torch.zeros(tiles, 3, 64, dtype=torch.int32, device="cuda") for _ in range(3)]
+    z = torch.zeros(tiles, 4, 32, device="cuda")
+    _lib.check(L.esr_mlp_fwd(0, _lib.ptr(eng.packed["off"]), _lib.ptr(Xd), 0, tiles, _lib.ptr_array(H), _lib.ptr_array(M), 1, 0,
+                             _lib.ptr(z), s), "fwd")
+    # per-sample magnitudes over six decades, per-tile magnitudes over three
+    dz = torch.randn(tiles, 4, 32, generator=g) * gscale
+    dz *= 10.0 ** (-6.0 * torch.rand(tiles, 1, 32, generator=g)) * 10.0 ** (-3.0 * torch.rand(tiles, 1, 1, generator=g))
+    dz[:, 3] = 0.0
+    if tiles > 2:
+        dz[1] = 0.0                                                   # an all-zero tile
+    dzd = dz.cuda().contiguous()
+
+    def run(split):
+        dZ = [torch.full((tiles, 192, 32), -3.0, device="cuda") for _ in range(3)]
+        dX = torch.full((tiles, 64, 32), 3.0, device="cuda")
+        if split:
+            rc = L.esr_mlp_dgrad_split(0, _lib.ptr(eng.packed_split["off"]), _lib.ptr(dzd), 0, tiles, _lib.ptr_array(M),
+                                       _lib.ptr_array(dZ), _lib.ptr(dX), s)
+        else:
+            rc = L.esr_mlp_dgrad(0, _lib.ptr(eng.packed["off"]), _lib.ptr(dzd), 0, tiles, _lib.ptr_array(M), _lib.ptr_array(dZ),
+                                 _lib.ptr(dX), s)
+        _lib.check(rc, "dgrad")
+        torch.cuda.synchronize()
+        return dZ, dX
+    dZs, dXs = run(True)
+    dZf, dXf = run(False)
+    # double-precision chain with the kernel's masks (h > 0 of the f32 forward's saved tiles)
+    tm = lambda t, r: t.reshape(tiles, 32, r).permute(0, 2, 1).contiguous()
+    rm = lambda t: t.permute(0, 2, 1).reshape(tiles * 32, t.shape[1])
+    gcur = rm(dz[:, :3].double())
+    masks = [(rm(H[l].cpu()) > 0).double() for l in range(3)]
+    refs = []
+    for l in (3, 2, 1):
+        gcur = (gcur @ Ws[l].double()) * masks[l - 1]
+        refs.append(gcur)
+    dx_ref = gcur @ Ws[0].double()                                    # [n, 85] in the reference's input order
+    rows = [r for r in range(44) if _in_colmap(0, r) >= 0]
+    cols = [_in_colmap(0, r) for r in rows]
+    for name, got_s, got_f, ref in (("dZ2", dZs[2], dZf[2], refs[0]), ("dZ1", dZs[1], dZf[1], refs[1]), ("dZ0", dZs[0], dZf[0], refs[2])):
+        # per TILE: the error relative to the tile's largest gradient (what the per-tile scaling promises)
+        r_t, s_t, f_t = tm(ref, 192), got_s.cpu().double(), got_f.cpu().double()
+        scale = r_t.abs().amax(dim=(1, 2)).clamp_min(1e-300)
+        es = float(((s_t - r_t).abs().amax(dim=(1, 2)) / scale).max())
+        ef = float(((f_t - r_t).abs().amax(dim=(1, 2)) / scale).max())
+        print(f"{name}: split {es:.2e}, f32 MFMA {ef:.2e} (per-tile max-norm)")
+        assert es < 3e-6 and es < 4 * ef + 1e-6, (name, es, ef)
+    dxr = tm(dx_ref[:, cols], len(rows))
+    scale = dxr.abs().amax(dim=(1, 2)).clamp_min(1e-300)
+    es = float(((dXs[:, rows].cpu().double() - dxr).abs().amax(dim=(1, 2)) / scale).max())
+    ef = float(((dXf[:, rows].cpu().double() - dxr).abs().amax(dim=(1, 2)) / scale).max())
+    print(f"dX: split {es:.2e}, f32 MFMA {ef:.2e}")
+    assert es < 3e-6 and es < 4 * ef + 1e-6
+    assert float((dXs[:, 44:] - 3.0).abs().max()) == 0.0                 # rows that lead to no grid: untouched
+    if tiles > 2:
+        assert float(dXs[1, :44].abs().max()) == 0.0 and float(dZs[0][1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("t_on,t_all", [(0, 5), (7, 7), (3, 11), (130, 257)])
+def test_merged_split_dgrad_equals_the_single_passes(t_on, t_all):
+    from esr_nerf_amd import _lib
+    from esr_nerf_amd.fine_engine import FineEngine
+    eng = FineEngine("cuda:0")
+    L, s = eng.L, _lib.stream_ptr("cuda:0")
+    g = torch.Generator().manual_seed(t_all * 3 + t_on)
+    for name in ("off", "emo"):
+        Ws, Bs = _net(g)
+        _pack(L, eng, name, Ws, Bs)
+    M = [torch.randint(-2 ** 31, 2 ** 31 - 1, (t_all * 3 * 64,), generator=g, dtype=torch.int64).to(torch.int32).cuda() for _ in range(3)]
+    dz = (torch.randn(t_all * 4 * 32, generator=g) * 1e-4).cuda()
+    pa = _lib.ptr_array
+
+    def bufs():
+        f = lambda rows: torch.full((max(t_all, 1) * rows * 32,), -3.0, device="cuda")
+        return dict(dZ=[f(192) for _ in range(3)], dX=f(64))
+    A, B = bufs(), bufs()
+    se, so = _lib.ptr(eng.packed_split["emo"]), _lib.ptr(eng.packed_split["off"])
+    _lib.check(L.esr_mlp_dgrad_split(0, se, _lib.ptr(dz), 0, t_on, pa(M), pa(A["dZ"]), _lib.ptr(A["dX"]), s), "emo")
+    _lib.check(L.esr_mlp_dgrad_split(0, so, _lib.ptr(dz), t_on, t_all, pa(M), pa(A["dZ"]), _lib.ptr(A["dX"]), s), "off")
+    _lib.check(L.esr_mlp_dgrad_fine_split(se, so, _lib.ptr(dz), t_on, t_all, pa(M), pa(B["dZ"]), _lib.ptr(B["dX"]), s), "merged")
+    torch.cuda.synchronize()
+    assert torch.equal(A["dX"], B["dX"])
+    for l in range(3):
+        assert torch.equal(A["dZ"][l], B["dZ"][l]), l
