@@ -162,6 +162,8 @@ KERNEL_OF = {
     "mlp_dgrad(emo)": "mlp_dgrad_kernel<0>", "mlp_dgrad(off)": "mlp_dgrad_kernel<0>",
     "mlp_dgrad(tone)": "mlp_dgrad_kernel<1>",
     "mlp_fwd(rad)": "mlp_fwd_kernel<0>", "mlp_dgrad(rad)": "mlp_dgrad_kernel<0>",
+    # fine stage, f32 engine: the step's eight weight-gradient jobs are ONE launch (+ a ~14 us slab reduction in the same call)
+    "mlp_wgrad(all)": "mlp_wgrad_uni192_kernel",
 }
 
 
@@ -511,21 +513,31 @@ def main():
             if call in breakdown:
                 by_kernel[kname] = by_kernel.get(kname, 0.0) + breakdown[call][1]
         split_fwd = bool(getattr(eng, "split_fwd", False)) and a.dtype == "f32" and stage == "fine"
+        split_bwd = split_fwd and bool(getattr(eng, "split_bwd", False))
+        if not (stage == "fine" and a.dtype == "f32"):
+            by_kernel.pop("mlp_wgrad_uni192_kernel", None)             # (one launch only in the fine stage's f32 engine)
         if split_fwd:
-            # the radiance forward runs on the 16-bit matrix cores (csrc/mlp_split.hip): it is priced against THAT pipe and
-            # HBM in `roofline.split_forward`; the f32-MFMA roofline below is taken on the largest remaining f32 launch
+            # the radiance forward (and, with split_bwd, the input-gradient chain) runs on the 16-bit matrix cores
+            # (csrc/mlp_split.hip): priced against THAT pipe and HBM in `roofline.split_forward` / `split_dgrad`; the
+            # f32-MFMA roofline below is taken on the largest remaining f32 launch
             by_kernel.pop("mlp_fwd_kernel<0>", None)
+            if split_bwd:
+                by_kernel.pop("mlp_dgrad_kernel<0>", None)
+        else:
+            by_kernel.pop("mlp_wgrad_uni192_kernel", None)             # (rounds 1-3's choice of launch stays comparable)
         dominant = max(by_kernel, key=by_kernel.get) if by_kernel else None
         if dominant and a.dtype == "bf16":                     # the bf16 engine's kernel symbols (csrc/mlp_bf16.hip)
             dominant = dominant.replace("mlp_fwd_kernel", "mlp_fwd16s_kernel").replace("mlp_dgrad_kernel", "mlp_dgrad16s_kernel")
     dom_calls = [c for c, k in KERNEL_OF.items() if dominant and k == dominant.replace("16s_kernel", "_kernel") and c in breakdown
-                 and not (c == "mlp_fwd(rad)" and n_prof and split_fwd)]
+                 and not (c == "mlp_fwd(rad)" and n_prof and split_fwd) and not (c == "mlp_dgrad(rad)" and n_prof and split_fwd and split_bwd)]
     # one launch of that kernel per step is bracketed (each event pair costs ~40-80 us of wall time)
     dom_calls = sorted(dom_calls, key=lambda c: -breakdown[c][1])[:1]
     if not dom_calls and not a.no_kernel_timing and stage == "fine":
         # too few warm-up steps for the breakdown: bracket the kernel that dominates every profile taken so far
         split_fwd = bool(getattr(eng, "split_fwd", False)) and a.dtype == "f32"
-        dominant, dom_calls = (("mlp_dgrad_kernel<0>", ["mlp_dgrad(rad)"]) if split_fwd else
+        split_bwd = split_fwd and bool(getattr(eng, "split_bwd", False))
+        dominant, dom_calls = (("mlp_wgrad_uni192_kernel", ["mlp_wgrad(all)"]) if split_bwd else
+                               ("mlp_dgrad_kernel<0>", ["mlp_dgrad(rad)"]) if split_fwd else
                                ("mlp_fwd_kernel<0>", ["mlp_fwd(rad)" if getattr(eng, "merge_rad", False) else "mlp_fwd(emo)"]))
     # timed region: exactly K steps, events only around the dominant kernel's launches (on their stream)
     eng.enable_timing(dominant is not None, only=dom_calls if dominant else None)
@@ -687,7 +699,8 @@ def main():
                                         "mfma_tflops": ach, "mfma_frac_of_bf16_peak": mf_})
             # the whole MLP engine (all 10 calls per step), from the instrumented warm-up steps
             mlp = {k: v for k, v in breakdown.items() if algorithmic_flops(k, counts)
-                   and not (split_fwd and k == "mlp_fwd(rad)")}      # (f32-pipe launches only: the split forward is priced apart)
+                   and not (split_fwd and k == "mlp_fwd(rad)") and not (split_fwd and split_bwd and k == "mlp_dgrad(rad)")}
+            # (f32-pipe launches only: the split forward / input gradients are priced apart)
             if mlp:
                 mf = sum(algorithmic_flops(k, counts) * v[0] for k, v in mlp.items())
                 mt = sum(v[1] for v in mlp.values()) * 1e-3
@@ -722,6 +735,19 @@ def main():
                         "hbm_gbs_algorithmic": by_ / (ms_ * 1e-3) / 1e9, "hbm_frac": by_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "fp32_equivalent_tflops": fl_ / (ms_ * 1e-3) / 1e12,
                         "note": "not priced against the f32 matrix peak: it does not run on that pipe"}
+                if split_fwd and split_bwd and "mlp_dgrad(rad)" in breakdown:
+                    n_, t_ = breakdown["mlp_dgrad(rad)"]
+                    fl_, by_ = algorithmic_flops("mlp_dgrad(rad)", counts), algorithmic_bytes("mlp_dgrad(rad)", counts, False)
+                    ms_ = t_ / n_
+                    out["roofline"]["split_dgrad"] = {
+                        "kernel": "mlp_dgrad_split_kernel<0>", "avg_launch_ms": ms_,
+                        "what": "both radiance nets' input-gradient chains; products as 3 fp16 MFMAs on split planes, each tile "
+                                "scaled by a power of two from its largest |dz|, fp32 dZ / dX (csrc/mlp_split.hip)",
+                        "algorithmic_gflop": fl_ / 1e9, "issued_16bit_gflop": 3 * fl_ / 1e9,
+                        "mfma16_frac": 3 * fl_ / (ms_ * 1e-3) / 1e12 / MFMA_F16_PEAK_TF,
+                        "hbm_gbs_algorithmic": by_ / (ms_ * 1e-3) / 1e9, "hbm_frac": by_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "fp32_equivalent_tflops": fl_ / (ms_ * 1e-3) / 1e12,
+                        "note": "not priced against the f32 matrix peak: it does not run on that pipe"}
                 out["roofline"]["whole_step"] = {"algorithmic_gflop": step_fl / 1e9,
                                                  "achieved": step_fl / (dt / a.steps) / 1e12, "peak": peak,
                                                  "frac": step_fl / (dt / a.steps) / 1e12 / peak,
@@ -729,7 +755,7 @@ def main():
                                                  "frac_exact_mac": exact / (dt / a.steps) / 1e12 / peak}
                 if split_fwd:
                     out["roofline"]["whole_step"]["note"] = (
-                        "the radiance forward's FLOPs (algorithmic, counted once) run on the 16-bit matrix cores since round 4: "
+                        "the radiance forward's (and input gradients') FLOPs (algorithmic, counted once) run on the 16-bit matrix cores since round 4: "
                         "`frac` is the step's algorithmic FLOP rate over the f32 matrix peak, kept for comparison with earlier "
                         "rounds -- it is no longer bounded by 1 in principle; the f32-pipe launches are priced one by one in "
                         "roofline / all_mlp_kernels")

@@ -76,7 +76,7 @@ def asm_reads_behind_mfma(path):
     return bad
 
 
-@pytest.mark.parametrize("src", ["mlp.hip", "mlp_bf16.hip", "tone_wgrad.hip"])
+@pytest.mark.parametrize("src", ["mlp.hip", "mlp_bf16.hip", "tone_wgrad.hip", "mlp_split.hip"])
 def test_no_inline_asm_reads_a_fresh_mfma_result(src):
     bad = asm_reads_behind_mfma(_asm(src))
     assert not bad, bad[:5]
@@ -108,3 +108,19 @@ def test_register_budgets():
     meta16 = km.kernel_meta(_asm("mlp_bf16.hip"))
     fwd0 = [v for k, v in meta16.items() if "mlp_fwd16s_kernelILi0E" in k]
     assert fwd0 and fwd0[0].get("spill_v", 0) == 0 and fwd0[0].get("scratch", 0) == 0, fwd0
+    # the split-fp16 kernels run one wave per SIMD on the whole register file: spills into the AGPR half are fine, scratch is not
+    metas = km.kernel_meta(_asm("mlp_split.hip"))
+    for name in ("mlp_fwd_split_kernel", "mlp_dgrad_split_kernel"):
+        ks = [v for k, v in metas.items() if name in k]
+        assert ks and all(v.get("scratch", 0) == 0 for v in ks), (name, ks)
+
+
+def test_split_kernels_evaluate_their_step_tables_at_compile_time():
+    """The first build of mlp_split.hip looked its step table up at RUN time in the later steps (chains of scalar loads per use:
+    steps 5-8 took 10 k clocks instead of 2.5 k): the loop bodies hold a handful of scalar loads and branches, not hundreds."""
+    txt = open(_asm("mlp_split.hip")).read()
+    for name in ("mlp_fwd_split_kernelILi0E", "mlp_dgrad_split_kernelILi0E"):
+        body = txt[txt.index(name + "EEv"):]
+        body = body[: body.index(".Lfunc_end")]
+        n_sload, n_branch = len(re.findall(r"\bs_load_dword", body)), len(re.findall(r"\bs_cbranch", body))
+        assert n_sload < 40 and n_branch < 80, (name, n_sload, n_branch)
