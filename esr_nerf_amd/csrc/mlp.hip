@@ -249,6 +249,7 @@ struct WgradArgs {
     int cw8;                     // colour-group rows x 8 (float4 units per row)
     int wg0, nwg;                // workgroups [wg0, wg0 + nwg) of the launch work on this job
     int cfg;                     // kernel shape of this job (layer_cfg) -- read by the unified launch (mlp_wgrad_uni192_kernel)
+    const float *amax;           // split-fp16 kernel: max |dz| of the step (device), the source of the gradient operand's scale
 };
 
 // One launch can carry up to MAX_JOBS jobs of the same kernel shape (the same layer of the emissive and the non-emissive
@@ -499,7 +500,46 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradBa
 // 16-B chunk c of row r is stored at chunk position c ^ ((r >> 1) & 7), so 16 consecutive rows read at the
 // same logical chunk hit 16 distinct 4-bank groups.
 // Three buffers, one barrier per tile in the MIDDLE of the tile (schedule: comment above the main loop).
-template <int MI, int NJ, int WM, int WN, int WK>
+//
+// SPLIT: the same staging, fp32 operands in HBM and LDS, but the products run on the 16-bit matrix cores
+// (v_mfma_f32_32x32x16_f16, 16x the f32 MFMA rate): every operand value is cut into two fp16 planes on its way from LDS to
+// the operand registers, x = x1 + x2 with x1 = fp16(x) and x2 = fp16(x - x1) (the subtraction is exact), and
+//   A.B = A1.B1 + A1.B2 + A2.B1   (+ A2.B2, < 2^-22 relative: dropped)
+// goes into ONE fp32 accumulator.  The gradient operand A (dZ / dz, ~1e-3 .. 1e-7) is first multiplied by a power of two
+// s chosen from the step's max |dz| (W.amax) so that max |dz| s is in [2^7, 2^8): fp16's range then holds 128x that
+// maximum (hidden-layer gradients exceed the output gradient by the weights' row sums), and a residual x2 below fp16's
+// normal range (|x| s < 2^-3) is rounded to 2^-25 ABSOLUTE, 2^-32 of the maximum -- far below the fp32 accumulation's own
+// error.  The activation operand B (H / X, O(1)) is not scaled: a residual below the normal range means |x| < 0.125 and
+// an absolute error of 3e-8.  The accumulator is divided by s at the flush; the bias gradient sums the raw fp32 values.
+// Accuracy: tests/test_gpu_split.py (vs float64: as the f32 MFMA kernel).  Cost: 8 samples per lane and operand row are
+// converted by ~4 VALU instructions each -- the kernel is HBM-bound with them.
+typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void wg_split8(const float4 &lo, const float4 &hi, float s, wg_f16x8 &p1, wg_f16x8 &p2)
+{
+    const float v[8] = {lo.x * s, lo.y * s, lo.z * s, lo.w * s, hi.x * s, hi.y * s, hi.z * s, hi.w * s};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 h1 = (_Float16)v[e];
+        p1[e] = h1;
+        p2[e] = (_Float16)(v[e] - (float)h1);
+    }
+}
+__device__ __forceinline__ f32x16 wg_mfma_f16(wg_f16x8 a, wg_f16x8 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// power of two s with amax * s in [2^7, 2^8) (amax == 0 or not finite: 1)
+__device__ __forceinline__ float wg_scale(float amax)
+{
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
+    int e;
+    frexpf(amax, &e);                     // amax = m 2^e, m in [0.5, 1)
+    e = 8 - e;
+    e = e > 120 ? 120 : e < -120 ? -120 : e;
+    return ldexpf(1.f, e);
+}
+
+template <int MI, int NJ, int WM, int WN, int WK, bool SPLIT = false>
 __device__ __forceinline__ void wgrad_dma_body(const WgradArgs &W)
 {
     constexpr int NW = WM * WN * WK;                 // compute waves (one per SIMD); wave NW is the loader
@@ -580,6 +620,57 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs &W)
     // Operands are register double-buffered by group; the last group of a tile reads the first group of the next
     // tile (readable since the mid-tile barrier), so no LDS latency is exposed at the tile seam.
     static_assert(NU == 2 || NU == 4, "two halves of whole groups");
+    float osc = 1.f;                                      // SPLIT: 1 / (scale of the gradient operand)
+    if constexpr (SPLIT) {
+        // one k-step of the 16-bit MFMA = two 8-sample groups (lane half h: chunks 2u + h of both, the same samples for A
+        // and B).  Per k-step: the A rows of the wave become planes once (MI x 2 x 4 registers), the B rows per output
+        // column block j; raw fp32 operands are prefetched one block ahead (A: one k-step ahead).
+        constexpr int KS = NU / 2;
+        const float sc = wg_scale(W.amax ? *W.amax : 0.f);
+        osc = 1.f / sc;
+        auto read2 = [&](int buf, int ks, int row0, float4 &lo, float4 &hi) {
+            const int c0 = ((2 * (wk * NU + 2 * ks) + h) ^ swz) * 4, c1 = ((2 * (wk * NU + 2 * ks + 1) + h) ^ swz) * 4;
+            lo = *reinterpret_cast<const float4 *>(lds + buf * BUF + row0 + c0);
+            hi = *reinterpret_cast<const float4 *>(lds + buf * BUF + row0 + c1);
+        };
+        float4 ral[MI], rah[MI], rbl[2], rbh[2];
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < MI; ++i) read2(0, 0, a_row + i * 32 * 32, ral[i], rah[i]);
+        read2(0, 0, b_row, rbl[0], rbh[0]);
+        int t = W.t0 + split;
+        for (int buf = 0; t < W.t1; t += nsplit) {
+            const int nb = buf == 2 ? 0 : buf + 1;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks == KS - 1) __builtin_amdgcn_s_barrier();          // the next tile has landed (see the schedule above)
+                const int nbuf = ks + 1 < KS ? buf : nb, nks = ks + 1 < KS ? ks + 1 : 0;
+                wg_f16x8 a1[MI], a2[MI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    bsum[i] += ((ral[i].x + ral[i].y) + (ral[i].z + ral[i].w)) + ((rah[i].x + rah[i].y) + (rah[i].z + rah[i].w));
+                    wg_split8(ral[i], rah[i], sc, a1[i], a2[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i) read2(nbuf, nks, a_row + i * 32 * 32, ral[i], rah[i]);     // (stale but unused after the last tile)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    wg_f16x8 b1, b2;
+                    wg_split8(rbl[j & 1], rbh[j & 1], 1.f, b1, b2);
+                    // raw rows of the next block (next k-step: slot 0 again) -- in flight under this block's MFMAs
+                    if (j + 1 < NJ) read2(buf, ks, b_row + (j + 1) * 32 * 32, rbl[(j + 1) & 1], rbh[(j + 1) & 1]);
+                    else read2(nbuf, nks, b_row, rbl[0], rbh[0]);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        acc[i][j] = wg_mfma_f16(a1[i], b1, acc[i][j]);
+                        acc[i][j] = wg_mfma_f16(a1[i], b2, acc[i][j]);
+                        acc[i][j] = wg_mfma_f16(a2[i], b1, acc[i][j]);
+                    }
+                }
+            }
+            buf = nb;
+        }
+    } else {
     float4 a0[MI], b0[NJ], a1[MI], b1[NJ];
     __builtin_amdgcn_s_barrier();
     lds_read(0, 0, a0, b0);
@@ -610,6 +701,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs &W)
         }
         buf = nb;
     }
+    }
     __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(0));
 
     float *S = W.slab + (size_t)(split * WK + wk) * W.out_rows * W.ld;
@@ -622,7 +714,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs &W)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ra = 32 * (MI * wm + i) + acc_row(r, h);
-                if (col >= 0 && col < W.ld && ra < W.out_rows) S[(size_t)ra * W.ld + col] = acc[i][j][r];
+                if (col >= 0 && col < W.ld && ra < W.out_rows) S[(size_t)ra * W.ld + col] = SPLIT ? acc[i][j][r] * osc : acc[i][j][r];
             }
     }
     if (W.gb && wn == 0) {
@@ -653,6 +745,14 @@ __global__ void __launch_bounds__(320, 1) mlp_wgrad_uni192_kernel(WgradBatch WB)
     if (W.cfg == UNI_HID192) wgrad_dma_body<3, 3, 2, 2, 1>(W);
     else if (W.cfg == UNI_FIRST192) wgrad_dma_body<3, 3, 2, 1, 2>(W);
     else wgrad_dma_body<1, 3, 1, 2, 2>(W);
+}
+// the same launch with the products on the 16-bit matrix cores (wgrad_dma_body<..., SPLIT>)
+__global__ void __launch_bounds__(320, 1) mlp_wgrad_uni192s_kernel(WgradBatch WB)
+{
+    const WgradArgs W = pick_job(WB);
+    if (W.cfg == UNI_HID192) wgrad_dma_body<3, 3, 2, 2, 1, true>(W);
+    else if (W.cfg == UNI_FIRST192) wgrad_dma_body<3, 3, 2, 1, 2, true>(W);
+    else wgrad_dma_body<1, 3, 1, 2, 2, true>(W);
 }
 
 // gw[e] += sum over the partial slabs of every job of a launch; 32 slabs per thread, groups combined with one atomic
@@ -843,25 +943,30 @@ int launch_wgrad_any(WgradBatch &B, SlabPool &P)
 // relative cost of one sample tile per job shape (hidden : first : output), from the per-shape launches' times at C2
 // (4.4 : 2.2 : 0.8 us per tile per workgroup; the output shape is bound by its loader wave, not by matrix work);
 // ESR_WGRAD_COST="h,f,o" overrides (developer knob, read once)
-const double *uni_cost()
+// The split-fp16 launch is bound by the bytes it streams, not by matrix work: the shares follow the tile sizes
+// (48 : 36 : 25 KB per sample tile; measured at C2: "1,0.85,0.6" 0.466 ms, "1,1,0.6" 0.480-0.489, the f32 table 0.850; C4: 0.954 / 0.986 / -).
+// ESR_WGRAD_COST_SPLIT overrides.
+const double *uni_cost(bool split)
 {
-    static double c[3] = {1.0, 0.5, 0.2};
+    static double c[2][3] = {{1.0, 0.5, 0.2}, {1.0, 0.8, 0.6}};
     static std::atomic<int> done{0};
     if (!done.load()) {
-        if (const char *e = std::getenv("ESR_WGRAD_COST")) {
-            double a, b, d;
-            if (std::sscanf(e, "%lf,%lf,%lf", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0) { c[0] = a; c[1] = b; c[2] = d; }
-        }
+        const char *names[2] = {"ESR_WGRAD_COST", "ESR_WGRAD_COST_SPLIT"};
+        for (int k = 0; k < 2; ++k)
+            if (const char *e = std::getenv(names[k])) {
+                double a, b, d;
+                if (std::sscanf(e, "%lf,%lf,%lf", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0) { c[k][0] = a; c[k][1] = b; c[k][2] = d; }
+            }
         done.store(1);
     }
-    return c;
+    return c[split ? 1 : 0];
 }
 constexpr int uni_wk(int cfg) { return cfg == UNI_HID192 ? 1 : 2; }
 
 // workgroups per job proportional to tiles x cost (every job >= 1, none more than its tiles); slab regions back to back
-int plan_uni(WgradBatch &B, float *scratch, int64_t slab_floats, ReduceArgs &R, int64_t &used_out)
+int plan_uni(WgradBatch &B, float *scratch, int64_t slab_floats, ReduceArgs &R, int64_t &used_out, bool split)
 {
-    const double *cost = uni_cost();
+    const double *cost = uni_cost(split);
     double w[MAX_JOBS], wt = 0.0;
     int64_t tiles = 0;
     for (int j = 0; j < B.n; ++j) {
@@ -920,9 +1025,12 @@ int plan_uni(WgradBatch &B, float *scratch, int64_t slab_floats, ReduceArgs &R, 
     return wg0;
 }
 
+template <bool SPLIT>
 int launch_wgrad_uni(WgradBatch &B, SlabPool &P)
 {
     hipStream_t s = P.s;
+    const void *kern = SPLIT ? reinterpret_cast<const void *>(&mlp_wgrad_uni192s_kernel)
+                             : reinterpret_cast<const void *>(&mlp_wgrad_uni192_kernel);
     for (int j = 0; j < B.n; ++j) {
         const WgradArgs &W = B.job[j];
         const int rap = W.cfg == UNI_OUT192 ? 32 : 192, rbp = W.cfg == UNI_FIRST192 ? 96 : 192;
@@ -930,12 +1038,13 @@ int launch_wgrad_uni(WgradBatch &B, SlabPool &P)
     }
     constexpr size_t lds_bytes = 3 * (size_t)(192 + 192) * 32 * sizeof(float);       // the largest shape's ring
     static std::atomic<uint64_t> optin{0};
-    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_wgrad_uni192_kernel), lds_bytes, optin)) return rc;
+    if (int rc = esr_lds_optin(kern, lds_bytes, optin)) return rc;
     ReduceArgs R;
     int64_t n = 0;
-    const int grid = P.place([&](float *sc, int64_t fl, ReduceArgs &R_, int64_t &n_) { return plan_uni(B, sc, fl, R_, n_); }, R, n);
+    const int grid = P.place([&](float *sc, int64_t fl, ReduceArgs &R_, int64_t &n_) { return plan_uni(B, sc, fl, R_, n_, SPLIT); }, R, n);
     if (grid < 0) return grid;
-    mlp_wgrad_uni192_kernel<<<grid, 320, lds_bytes, s>>>(B);
+    if (SPLIT) mlp_wgrad_uni192s_kernel<<<grid, 320, lds_bytes, s>>>(B);
+    else mlp_wgrad_uni192_kernel<<<grid, 320, lds_bytes, s>>>(B);
     ESR_CHECK_LAUNCH();
     return P.launched(R, n);
 }
@@ -1180,6 +1289,30 @@ ESR_API int esr_mlp_dgrad_wg(int kind, const float *packed, const float *dz, int
     return 0;
 }
 
+// max |x| into out[0] (atomic maximum of non-negative floats = of their bit patterns); NaN inputs are ignored by fmaxf
+__global__ void __launch_bounds__(256) absmax_kernel(const float *__restrict__ x, int64_t n, float *out)
+{
+    float m = 0.f;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned *>(out), __float_as_uint(m));
+}
+
+ESR_API int esr_absmax(const float *x, int64_t n, float *out, void *stream)
+{
+    if (n < 0 || !out || (n > 0 && !x) || (reinterpret_cast<uintptr_t>(x) & 15)) return ESR_EINVAL;
+    if (n == 0) return 0;
+    absmax_kernel<<<esr_grid_for((n + 3) / 4, 256, 1024), 256, 0, esr_stream(stream)>>>(x, n, out);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
 ESR_API int64_t esr_mlp_wgrad_scratch_floats(void) { return (int64_t)256 * 2 * 192 * 192; }
 
 // every layer of every net job, grouped by kernel shape: one launch per shape (up to MAX_JOBS layer jobs each)
@@ -1191,6 +1324,7 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
     int n_group[N_CFG] = {};
     constexpr int MAX_UNI = 8;
     WgradBatch uni[MAX_UNI];
+    bool uni_split[MAX_UNI];
     int n_uni = 0;
     for (int c = 0; c < N_CFG; ++c)
         for (int g = 0; g < 4; ++g) group[c][g].n = 0;
@@ -1223,8 +1357,11 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
             }
             if (!BF && uni_on() && (c == CFG_HID192 || c == CFG_FIRST192 || c == CFG_OUT192)) {
                 W.cfg = c == CFG_HID192 ? UNI_HID192 : c == CFG_FIRST192 ? UNI_FIRST192 : UNI_OUT192;
-                if (n_uni == 0 || uni[n_uni - 1].n == MAX_JOBS) {
+                W.amax = J.amax;                                   // non-NULL: the split-fp16 kernel (esr_hip.h)
+                const bool sp = J.amax != nullptr;
+                if (n_uni == 0 || uni[n_uni - 1].n == MAX_JOBS || uni_split[n_uni - 1] != sp) {
                     if (n_uni == MAX_UNI) return ESR_ECAP;
+                    uni_split[n_uni] = sp;
                     uni[n_uni++].n = 0;
                 }
                 WgradBatch &U = uni[n_uni - 1];
@@ -1242,7 +1379,7 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
     }
     SlabPool P(scratch, scratch_floats, esr_stream(stream));
     for (int u = 0; u < n_uni; ++u)
-        if (int rc = launch_wgrad_uni(uni[u], P)) return rc;
+        if (int rc = uni_split[u] ? launch_wgrad_uni<true>(uni[u], P) : launch_wgrad_uni<false>(uni[u], P)) return rc;
     for (int c = 0; c < N_CFG; ++c)
         for (int g = 0; g < n_group[c]; ++g)
             if (int rc = launch_cfg<BF>(c, group[c][g], P)) return rc;

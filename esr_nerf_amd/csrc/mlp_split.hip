@@ -380,6 +380,7 @@ struct DSplitBatch {
     const unsigned *M[3];
     float *dZ[3];
     float *dX;
+    float *amax;               // optional: max |dz| over the launch's tiles (atomic max of the tiles' own maxima)
     int nseg;
     DSplitSeg seg[2];
 };
@@ -444,6 +445,8 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_dgrad_split_kernel(DSplitBatc
         float zmax = fmaxf(fmaxf(fabsf(zn[0]), fabsf(zn[1])), fabsf(zn[2]));
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, o));
+        if (AB.amax && live && lane == 0)                                     // (non-negative floats order like their bit patterns)
+            atomicMax(reinterpret_cast<unsigned *>(AB.amax), __float_as_uint(zmax));
         const int ez = (__float_as_int(zmax) >> 23) & 0xff;                   // biased exponent of the maximum
         const int ks = ez == 0 ? 0 : 131 - ez;                                // scale exponent: max lands in [16, 32)
         const int kc = ks < -100 ? -100 : (ks > 100 ? 100 : ks);
@@ -694,13 +697,13 @@ int launch_dsplit(DSplitBatch &B, hipStream_t s)
 
 // esr_mlp_dgrad's contract (ESR_MLP_RADIANCE only): input / hidden gradients over tiles [t0, t1) from the net's split planes.
 ESR_API int esr_mlp_dgrad_split(int kind, const void *planes, const float *dz, int32_t t0, int32_t t1, const uint32_t *const *M,
-                                float *const *dZ, float *dX, void *stream)
+                                float *const *dZ, float *dX, float *amax, void *stream)
 {
     if (kind != ESR_MLP_RADIANCE || t0 < 0 || t1 < t0) return ESR_EINVAL;
     if (t1 == t0) return 0;
     if (!planes || !dz || !M || !dZ || !dX) return ESR_EINVAL;
     DSplitBatch B = {};
-    B.dz = dz; B.dX = dX;
+    B.dz = dz; B.dX = dX; B.amax = amax;
     for (int l = 0; l < 3; ++l) {
         if (!M[l]) return ESR_EINVAL;
         B.M[l] = M[l]; B.dZ[l] = dZ[l];                     // a NULL dZ[l] is computed but not stored
@@ -712,13 +715,13 @@ ESR_API int esr_mlp_dgrad_split(int kind, const void *planes, const float *dz, i
 
 // esr_mlp_dgrad_fine's contract: the emissive net on tiles [0, t_on), the non-emissive net on [t_on, t_all), one launch.
 ESR_API int esr_mlp_dgrad_fine_split(const void *planes_emo, const void *planes_off, const float *dz, int32_t t_on, int32_t t_all,
-                                     const uint32_t *const *M, float *const *dZ, float *dX, void *stream)
+                                     const uint32_t *const *M, float *const *dZ, float *dX, float *amax, void *stream)
 {
     if (t_on < 0 || t_all < t_on) return ESR_EINVAL;
     if (t_all == 0) return 0;
     if (!planes_emo || !planes_off || !dz || !M || !dZ || !dX) return ESR_EINVAL;
     DSplitBatch B = {};
-    B.dz = dz; B.dX = dX;
+    B.dz = dz; B.dX = dX; B.amax = amax;
     for (int l = 0; l < 3; ++l) {
         if (!M[l]) return ESR_EINVAL;
         B.M[l] = M[l]; B.dZ[l] = dZ[l];

@@ -148,6 +148,9 @@ class FineEngine:
         self.packed_split: Dict[str, torch.Tensor] = {}
         # ... and the radiance input-gradient chain the same way (per-tile power-of-two scaling); ESR_SPLIT_BWD=0: f32 MFMA
         self.split_bwd = self.split_fwd and os.environ.get("ESR_SPLIT_BWD", "1") != "0"
+        # ... and the weight gradients of the 192-wide nets (csrc/mlp.hip: wgrad_dma_body<..., SPLIT>); their gradient
+        # operand's scale comes from max |dz|, which the split input-gradient kernel leaves behind (else esr_absmax)
+        self.split_wgrad = self.split_bwd and os.environ.get("ESR_SPLIT_WGRAD", "1") != "0"
         self.tone_scratch = torch.empty(self.L.esr_tone_wgrad_scratch_floats() if self.tone_recompute else 1,
                                         dtype=torch.float32, device=self.device)
         self.neus_grad = False          # cfg neus_alpha: "grad" (set by the renderer)
@@ -353,6 +356,7 @@ class FineEngine:
         plan_dev = zb[:8].view(torch.int32)       # this step's header; self.plan_dev stays the persistent one (plan_begin paths)
         srgb, lin = zb[8: 8 + 3 * n].view(n, 3), zb[8 + n3: 8 + n3 + 3 * n].view(n, 3)
         self._loss_acc = zb[8 + 2 * n3: 8 + 2 * n3 + 2]
+        self._amax = zb[8 + 2 * n3 + 3: 8 + 2 * n3 + 4]        # max |dz| of the step (split-fp16 weight gradients)
         sp = C.byref(scene)
         main = torch.cuda.current_stream(self.device)
         if cached:
@@ -403,6 +407,7 @@ class FineEngine:
                             color_on=(emo_color, off_color, None), color_off=(off_color, None, None))
         x16 = self.x16 and self.merge_rad and all(0.0 <= float(r) <= 2.0 for r in scene.grad_feat)
         ctx.x16 = x16
+        ctx.amax, ctx.amax_set = self._amax, False
         if x16:
             self._run("feat_fwd", L.esr_fine_feat_fwd_x16, sp, C.byref(fa), _lib.ptr(ws["X"]), _lib.ptr(ws["gnorm"]),
                       _lib.ptr(ws["X16"]), s)
@@ -612,6 +617,11 @@ class FineEngine:
                 jb.gw, jb.gb = C.addressof(gwa), C.addressof(gba)
                 if getattr(ctx, "x16", False) and kind == KIND_RADIANCE:
                     jb.X16 = ws["X16"].data_ptr()
+                if self.split_wgrad and kind == KIND_RADIANCE and getattr(ctx, "amax", None) is not None:
+                    if not ctx.amax_set:        # (the f32 input-gradient kernels ran: one small reduction over dz)
+                        self._run("absmax(dz)", L.esr_absmax, _lib.ptr(ws["dz"]), C.c_int64(ta * 4 * 32), _lib.ptr(ctx.amax), s_)
+                        ctx.amax_set = True
+                    jb.amax = ctx.amax.data_ptr()
             self._run("mlp_wgrad(all)", L.esr_mlp_wgrad_batch, jobs, len(todo), 1 if self.bf16 else 0,
                       _lib.ptr(self.wgrad_scratch), C.c_int64(self.wgrad_scratch.numel()), s_)
 
@@ -645,7 +655,9 @@ class FineEngine:
                           _lib.ptr(ws["dz"]), to, ta, M, dZ, _lib.ptr(ws["dX"]), s)
             elif self.split_fwd and self.split_bwd and "off" in self.packed_split and "emo" in self.packed_split:
                 self._run("mlp_dgrad(rad)", L.esr_mlp_dgrad_fine_split, _lib.ptr(self.packed_split["emo"]),
-                          _lib.ptr(self.packed_split["off"]), _lib.ptr(ws["dz"]), to, ta, M, dZ, _lib.ptr(ws["dX"]), s)
+                          _lib.ptr(self.packed_split["off"]), _lib.ptr(ws["dz"]), to, ta, M, dZ, _lib.ptr(ws["dX"]),
+                          _lib.ptr(ctx.amax) if getattr(ctx, "amax", None) is not None else None, s)
+                ctx.amax_set = getattr(ctx, "amax", None) is not None
             else:
                 self._run("mlp_dgrad(rad)", L.esr_mlp_dgrad_fine, _lib.ptr(self.packed["emo"]), _lib.ptr(self.packed["off"]),
                           _lib.ptr(ws["dz"]), to, ta, M, dZ, _lib.ptr(ws["dX"]), s)

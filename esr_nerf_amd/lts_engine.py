@@ -363,9 +363,14 @@ class LtsEngine(FineEngine):
         if t1 > t0:
             s = self._s()
             recompute = kind == KIND_TONEMAP and self.tone_recompute
+            amax = None
             if kind == KIND_RADIANCE and self.split_fwd and self.split_bwd and net in self.packed_split:
+                # max |dz| of this net and pass, left behind by the input-gradient kernel: the scale of the split-fp16
+                # weight-gradient job (esr_wgrad_job_t::amax)
+                amax = self._z(1) if (self.split_wgrad and self._wgrad_jobs is not None) else None
                 self._run(f"mlp_dgrad({net})[{P.name}]", self.L.esr_mlp_dgrad_split, kind, _lib.ptr(self.packed_split[net]),
-                          _lib.ptr(dz), t0, t1, _lib.ptr_array(M), _lib.ptr_array(dZ), _lib.ptr(dX), s)
+                          _lib.ptr(dz), t0, t1, _lib.ptr_array(M), _lib.ptr_array(dZ), _lib.ptr(dX),
+                          _lib.ptr(amax) if amax is not None else None, s)
             else:
                 self._run(f"mlp_dgrad({net})[{P.name}]", self.mlp_dgrad, kind, _lib.ptr(self.packed[net]),
                           _lib.ptr(dz), t0, t1, _lib.ptr_array(M), _lib.ptr_array([None] * nh if recompute else dZ), _lib.ptr(dX), s)
@@ -386,7 +391,7 @@ class LtsEngine(FineEngine):
                 # inside lts_backward: the weight gradients of EVERY net and pass of the step go out as ONE batched call
                 # at the end (esr_mlp_wgrad_batch: layers of the same kernel shape share a launch -- eleven net calls
                 # with ~100-135 us of fixed cost each become four launch groups)
-                self._wgrad_jobs.append((f"{net}[{P.name}]", kind, x, crow, H, dZ, dz, t0, t1, gw, gb))
+                self._wgrad_jobs.append((f"{net}[{P.name}]", kind, x, crow, H, dZ, dz, t0, t1, gw, gb, amax))
             else:
                 self._run(f"mlp_wgrad({net})[{P.name}]", self.mlp_wgrad, kind, _lib.ptr(x), crow,
                           _lib.ptr_array(H), _lib.ptr_array(dZ), _lib.ptr(dz), t0, t1, _lib.ptr_array(gw),
@@ -982,12 +987,15 @@ class LtsEngine(FineEngine):
 
     def _launch_wgrad_jobs(self):
         jobs = self._wgrad_jobs
-        self.last_wgrad_jobs = [(name, t1 - t0) for name, _, _, _, _, _, _, t0, t1, _, _ in jobs]     # (net[pass], tiles)
+        self.last_wgrad_jobs = [(name, t1 - t0) for name, _, _, _, _, _, _, t0, t1, _, _, _ in jobs]     # (net[pass], tiles)
         arr = (_lib.EsrWgradJob * len(jobs))()
         keep = []
-        for jb, (_, kind, x, crow, H, dZ, dz, t0, t1, gw, gb) in zip(arr, jobs):
+        for jb, (_, kind, x, crow, H, dZ, dz, t0, t1, gw, gb, amax) in zip(arr, jobs):
             ptrs = [_lib.ptr_array(H), _lib.ptr_array(dZ), _lib.ptr_array(gw), _lib.ptr_array(gb)]
             keep.append(ptrs)
+            if amax is not None:
+                jb.amax = amax.data_ptr()
+                amax.record_stream(torch.cuda.current_stream(self.device))
             jb.kind, jb.color_row0, jb.t0, jb.t1 = kind, crow, t0, t1
             jb.X, jb.dz = x.data_ptr(), dz.data_ptr()
             jb.H, jb.dZ, jb.gw, jb.gb = (C.addressof(p) for p in ptrs)

@@ -334,10 +334,15 @@ int esr_mlp_fwd_fine_split(const float *packed32_off, const void *planes_off, co
 /* The input-gradient chain the same way (contracts of esr_mlp_dgrad / esr_mlp_dgrad_fine; ESR_MLP_RADIANCE only): the split
  * buffer also holds the TRANSPOSED weights' planes.  Gradients are far below fp16's normal range, so each 32-sample tile's
  * chain runs scaled by a power of two chosen from its largest |dz| (exact), and dZ / dX are written unscaled in fp32. */
+/* amax (optional, device, one float, >= 0 on entry -- normally zero): raised to the largest |dz| of the launch's tiles with an
+ * atomic maximum; esr_wgrad_job_t::amax reads it (the scale of the split-fp16 weight-gradient kernel). */
 int esr_mlp_dgrad_split(int kind, const void *planes, const float *dz, int32_t t0, int32_t t1, const uint32_t *const *M,
-                        float *const *dZ, float *dX, void *stream);
+                        float *const *dZ, float *dX, float *amax, void *stream);
 int esr_mlp_dgrad_fine_split(const void *planes_emo, const void *planes_off, const float *dz, int32_t t_on, int32_t t_all,
-                             const uint32_t *const *M, float *const *dZ, float *dX, void *stream);
+                             const uint32_t *const *M, float *const *dZ, float *dX, float *amax, void *stream);
+/* out[0] = max(out[0], max |x[i]|, i < n) (device; out >= 0 on entry): the same quantity for callers that do not run the
+ * split input-gradient kernel. */
+int esr_absmax(const float *x, int64_t n, float *out, void *stream);
 
 /*
  * Forward over tiles [t0,t1).  X: layer-1 input, tile-major [tiles,xrows,32].
@@ -425,6 +430,11 @@ typedef struct esr_wgrad_job {
     /* optional (bf16 operands, ESR_MLP_RADIANCE, color_row0 == 0): the net's input tile as written by
      * esr_fine_feat_fwd_x16 -- the first-layer job then stages it like a hidden layer's tile and X is not read. */
     const void *X16;
+    /* optional (f32 operands, the 192-wide nets): device pointer to max |dz| over the step's output gradients
+     * (esr_absmax, or esr_mlp_dgrad_fine_split's amax output).  Non-NULL selects the split-fp16 weight-gradient kernel:
+     * the same fp32 operands, every value cut into two fp16 planes on its way into the 16-bit matrix cores, fp32
+     * accumulation; the gradient operand is scaled by a power of two derived from *amax (csrc/mlp.hip, SPLIT). */
+    const float *amax;
 } esr_wgrad_job_t;
 int esr_mlp_wgrad_batch(const esr_wgrad_job_t *jobs, int32_t n_jobs, int bf16_operands, float *scratch,
                         int64_t scratch_floats, void *stream);

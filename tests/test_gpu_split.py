@@ -190,8 +190,10 @@ def test_split_dgrad_vs_double_precision_and_vs_the_f32_kernel(tiles, gscale):
         dZ = [torch.full((tiles, 192, 32), -3.0, device="cuda") for _ in range(3)]
         dX = torch.full((tiles, 64, 32), 3.0, device="cuda")
         if split:
+            amax = torch.zeros(1, device="cuda")
             rc = L.esr_mlp_dgrad_split(0, _lib.ptr(eng.packed_split["off"]), _lib.ptr(dzd), 0, tiles, _lib.ptr_array(M),
-                                       _lib.ptr_array(dZ), _lib.ptr(dX), s)
+                                       _lib.ptr_array(dZ), _lib.ptr(dX), _lib.ptr(amax), s)
+            assert float(amax) == float(dz.abs().max())                # the launch's largest |dz| (scale of the weight gradients)
         else:
             rc = L.esr_mlp_dgrad(0, _lib.ptr(eng.packed["off"]), _lib.ptr(dzd), 0, tiles, _lib.ptr_array(M), _lib.ptr_array(dZ),
                                  _lib.ptr(dX), s)
@@ -250,10 +252,82 @@ def test_merged_split_dgrad_equals_the_single_passes(t_on, t_all):
         return dict(dZ=[f(192) for _ in range(3)], dX=f(64))
     A, B = bufs(), bufs()
     se, so = _lib.ptr(eng.packed_split["emo"]), _lib.ptr(eng.packed_split["off"])
-    _lib.check(L.esr_mlp_dgrad_split(0, se, _lib.ptr(dz), 0, t_on, pa(M), pa(A["dZ"]), _lib.ptr(A["dX"]), s), "emo")
-    _lib.check(L.esr_mlp_dgrad_split(0, so, _lib.ptr(dz), t_on, t_all, pa(M), pa(A["dZ"]), _lib.ptr(A["dX"]), s), "off")
-    _lib.check(L.esr_mlp_dgrad_fine_split(se, so, _lib.ptr(dz), t_on, t_all, pa(M), pa(B["dZ"]), _lib.ptr(B["dX"]), s), "merged")
+    am = torch.zeros(2, device="cuda")
+    _lib.check(L.esr_mlp_dgrad_split(0, se, _lib.ptr(dz), 0, t_on, pa(M), pa(A["dZ"]), _lib.ptr(A["dX"]), None, s), "emo")
+    _lib.check(L.esr_mlp_dgrad_split(0, so, _lib.ptr(dz), t_on, t_all, pa(M), pa(A["dZ"]), _lib.ptr(A["dX"]), _lib.ptr(am[1:]), s), "off")
+    _lib.check(L.esr_mlp_dgrad_fine_split(se, so, _lib.ptr(dz), t_on, t_all, pa(M), pa(B["dZ"]), _lib.ptr(B["dX"]), _lib.ptr(am), s), "merged")
     torch.cuda.synchronize()
+    z3 = dz.view(t_all, 4, 32)[:, :3]                                   # (row 3 of the 4-row tile is padding: not part of the maximum)
+    assert float(am[0]) == float(z3.abs().max())
+    assert float(am[1]) == (float(z3[t_on:].abs().max()) if t_all > t_on else 0.0)
     assert torch.equal(A["dX"], B["dX"])
     for l in range(3):
         assert torch.equal(A["dZ"][l], B["dZ"][l]), l
+
+
+def _wgrad_operands(tiles, g, gscale, spread):
+    """Random saved tiles of a 85-192-192-192-3 net's backward: H (>= 0, a third of them exactly zero like a ReLU's), dZ with
+    per-sample magnitudes over `spread` decades times gscale, dz likewise; X with the stencil rows x5."""
+    H = [torch.relu(torch.randn(tiles, 192, 32, generator=g) + 0.4) for _ in range(3)]
+    mag = lambda: gscale * 10.0 ** (-spread * torch.rand(tiles, 1, 32, generator=g))
+    dZ = [torch.randn(tiles, 192, 32, generator=g) * mag() * (1.0 + 3.0 * l) for l in range(3)]
+    dz = torch.randn(tiles, 4, 32, generator=g) * mag()
+    dz[:, 3] = 0.0
+    X = torch.randn(tiles, 104, 32, generator=g)
+    X[:, 7:31] *= 5.0
+    return X, H, dZ, dz
+
+
+@pytest.mark.parametrize("tiles,t0,crow,gscale,spread", [(1, 0, 0, 1.0, 0.0), (37, 5, 88, 1e-4, 4.0), (700, 0, 96, 1e-7, 6.0),
+                                                         (1300, 11, 0, 3e-3, 3.0), (300, 0, 0, 50.0, 2.0)])
+def test_split_wgrad_vs_double_precision_and_vs_the_f32_kernel(tiles, t0, crow, gscale, spread):
+    """Weight gradients of the 192-wide net with the products on the 16-bit matrix cores (esr_wgrad_job_t::amax set;
+    csrc/mlp.hip: wgrad_dma_body<..., SPLIT>) against float64 sums of the same fp32 operands, beside the f32 MFMA kernel on
+    the same inputs: all four layers' dW and db, a tile range that does not start at 0, the three colour-row groups,
+    gradient magnitudes from 1e-13 to 50.  Bar: max-norm error relative to the largest |dW| entry of the layer < 2e-6 and
+    no more than 4x the f32 kernel's (+1e-7): the accuracy class of the kernel it replaces."""
+    from esr_nerf_amd import _lib
+    L = _lib.lib()
+    s = _lib.stream_ptr("cuda:0")
+    g = torch.Generator().manual_seed(tiles * 7 + crow)
+    X, H, dZ, dz = _wgrad_operands(tiles, g, gscale, spread)
+    rows = [r for r in range(96) if _in_colmap(0, r) >= 0]
+    cols = [_in_colmap(0, r) for r in rows]
+    src_rows = [r + crow if r < 6 else r for r in rows]
+    rm = lambda t: t[t0:].permute(0, 2, 1).reshape((tiles - t0) * 32, t.shape[1]).double()
+    x_ref = torch.zeros((tiles - t0) * 32, 85, dtype=torch.float64)
+    x_ref[:, cols] = rm(X[:, src_rows])
+    A = [rm(dZ[0]), rm(dZ[1]), rm(dZ[2]), rm(dz[:, :3])]
+    Bm = [x_ref, rm(H[0]), rm(H[1]), rm(H[2])]
+    want_w = [a.t() @ b for a, b in zip(A, Bm)]
+    want_b = [a.sum(0) for a in A]
+    dev = lambda t: t.cuda().contiguous()
+    Xd, Hd, dZd, dzd = dev(X), [dev(h) for h in H], [dev(z) for z in dZ], dev(dz)
+    scratch = torch.empty(L.esr_mlp_wgrad_scratch_floats(), device="cuda")
+    amax = torch.zeros(1, device="cuda")
+    _lib.check(L.esr_absmax(_lib.ptr(dzd[t0:]), C.c_int64((tiles - t0) * 128), _lib.ptr(amax), s), "absmax")
+    assert float(amax) == float(dz[t0:].abs().max())
+
+    def run(split):
+        gw = [torch.zeros(sh, device="cuda") for sh in ((192, 85), (192, 192), (192, 192), (3, 192))]
+        gb = [torch.zeros(n, device="cuda") for n in (192, 192, 192, 3)]
+        jobs = (_lib.EsrWgradJob * 1)()
+        ptrs = [_lib.ptr_array(Hd), _lib.ptr_array(dZd), _lib.ptr_array(gw), _lib.ptr_array(gb)]
+        jb = jobs[0]
+        jb.kind, jb.color_row0, jb.t0, jb.t1 = 0, crow, t0, tiles
+        jb.X, jb.dz = Xd.data_ptr(), dzd.data_ptr()
+        jb.H, jb.dZ, jb.gw, jb.gb = (C.addressof(p) for p in ptrs)
+        if split:
+            jb.amax = amax.data_ptr()
+        _lib.check(L.esr_mlp_wgrad_batch(jobs, 1, 0, _lib.ptr(scratch), C.c_int64(scratch.numel()), s), "wgrad")
+        torch.cuda.synchronize()
+        return [w.cpu().double() for w in gw], [b.cpu().double() for b in gb]
+    ws, bs = run(True)
+    wf, bf_ = run(False)
+    for l in range(4):
+        scale = float(want_w[l].abs().max())
+        es, ef = float((ws[l] - want_w[l]).abs().max()) / scale, float((wf[l] - want_w[l]).abs().max()) / scale
+        print(f"layer {l}: dW split {es:.2e}, f32 MFMA {ef:.2e} of the largest entry ({scale:.2e})")
+        assert es < 2e-6 and es < 4 * ef + 1e-7, (l, es, ef)
+        sb = float(want_b[l].abs().max()) + 1e-300
+        assert float((bs[l] - want_b[l]).abs().max()) / sb < 1e-5
