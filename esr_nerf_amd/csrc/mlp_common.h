@@ -285,11 +285,13 @@ __device__ __forceinline__ void pack16_body(const PackArgs &A, int64_t e)
 }
 
 // ---- split-fp16 planes (the f32 engine's forward on the 16-bit matrix cores, mlp_split.hip) ---------------------------------
-// w = w1 + w2 / 2048 with w1 = fp16(w), w2 = fp16((w - w1) * 2048): two fp16 planes carry 22 bits of the fp32 mantissa
-// (the residual is scaled into fp16's NORMAL range: unscaled it would be a subnormal for every |w| < 0.125).  Forward
-// weights only.  Chunk order: the kernel stages ONE step = (layer, pair of output tiles) at a time, so a step's chunks are
+// 64 w = w1 + w2 with w1 = fp16(64 w), w2 = fp16(64 w - w1): two fp16 planes carry 22 bits of the fp32 mantissa.  The
+// power of two (SPLIT_W_SCALE) lifts the residual into fp16's NORMAL range for every |w| >= 2^-9 (unscaled it would be a
+// subnormal below |w| = 0.125, i.e. for every weight of a 192-wide layer); both planes carry the SAME scale, so all three
+// products of a k-step go into one accumulator and the kernels fold 1/64 into their bias / scale multiply.  Chunk order: the kernel stages ONE step = (layer, pair of output tiles) at a time, so a step's chunks are
 // contiguous: [layer][pair][tile of the pair][plane][k-step], each chunk [64 lanes][8] as in the bf16 buffer (lane: output
 // row 32 it + lane % 32, k block lane / 32; slot i: input feature kfeat16(j, h, i), first layer: in_colmap).
+constexpr float SPLIT_W_SCALE = 64.f, SPLIT_W_INV = 1.f / 64.f;
 struct SplitLayout {
     int n_layers;
     int ks[4], tiles_out[4], pairs[4], in_dim[4], out_dim[4];
@@ -357,8 +359,9 @@ __device__ __forceinline__ void packst_body(const PackArgs &A, int64_t e)
         const int col = first ? in_colmap(KIND, irow) : irow;
         if (orow < L.out_dim[q] && col >= 0 && col < L.in_dim[q]) v = A.w[l][(int64_t)orow * L.in_dim[q] + col];
     }
+    v *= SPLIT_W_SCALE;
     const _Float16 w1 = (_Float16)v;
-    A.outs[BASE + e] = plane == 0 ? w1 : (_Float16)((v - (float)w1) * 2048.f);
+    A.outs[BASE + e] = plane == 0 ? w1 : (_Float16)(v - (float)w1);
 }
 
 template <int KIND>
@@ -383,8 +386,9 @@ __device__ __forceinline__ void packs_body(const PackArgs &A, int64_t e)
         const int col = first ? in_colmap(KIND, 16 * j + 8 * h + slot) : kfeat16(j, h, slot);
         if (row < L.out_dim[l] && col >= 0 && col < L.in_dim[l]) v = A.w[l][(int64_t)row * L.in_dim[l] + col];
     }
+    v *= SPLIT_W_SCALE;
     const _Float16 w1 = (_Float16)v;
-    A.outs[e] = plane == 0 ? w1 : (_Float16)((v - (float)w1) * 2048.f);
+    A.outs[e] = plane == 0 ? w1 : (_Float16)(v - (float)w1);
 }
 
 // Every net of a step in ONE launch (esr_mlp_pack_batch): blockIdx.y = job; fp32 elements first, then the bf16 twin's.

@@ -2,16 +2,22 @@
 //
 // On gfx950 v_mfma_f32_32x32x2_f32 runs at 1/16 of the 16-bit MFMA rate (157 vs 2500 TFLOP/s) and ON the vector lanes; the
 // radiance forward -- 142.5 GFLOP per C2 step -- was the step's dominant launch at 1.06 ms (0.85 of the f32 matrix peak).
-// Here every operand is split into TWO fp16 planes, x = x1 + x2 / 2048 with x1 = fp16(x), x2 = fp16((x - x1) * 2048) (the
-// subtraction is exact in fp32; the residual is scaled back into fp16's normal range), and a product is formed as
-//     w . x  =  w1 . x1  +  (w1 . x2 + w2 . x1) / 2048            (+ w2 . x2 / 2^22, dropped: below fp32's own rounding)
-// on v_mfma_f32_32x32x16_f16 with fp32 accumulation: three 16-bit MFMAs per k-step instead of eight f32 ones of a quarter of
-// the depth -- 16/3 of the f32 matrix rate.  Two fp16 planes carry 22 mantissa bits; through the four layers of the net the
-// result differs from a double-precision evaluation by 4e-7 .. 8e-7 of the layer's largest value, the same as torch's own
-// fp32 chain (5e-7; tools/ubench/mfma_f32_shapes.hip for the rates, tests/test_gpu_split.py for the accuracy).  With bf16
-// planes the same three products give 6e-6 .. 9e-6: fp16's three extra mantissa bits per plane are what makes two planes
-// enough, and the forward's operands (weights ~ 0.1, activations ~ 1, inputs below a few hundred) sit inside fp16's
-// range; a |value| above 65504 would overflow the first plane (the fp32 MFMA path stays available: ESR_SPLIT_FWD=0).
+// Here every operand is split into TWO fp16 planes, x = x1 + x2 with x1 = fp16(x), x2 = fp16(x - x1) (the subtraction is
+// exact in fp32), and a product is formed as
+//     w . x  =  w1 . x1  +  w1 . x2  +  w2 . x1                   (+ w2 . x2, dropped: 2^-22 relative, below fp32's own rounding)
+// on v_mfma_f32_32x32x16_f16 with fp32 accumulation, all three into ONE accumulator: three 16-bit MFMAs per k-step instead
+// of eight f32 ones of a quarter of the depth -- 16/3 of the f32 matrix rate.  Two fp16 planes carry 22 mantissa bits as
+// long as the residual x2 is a NORMAL fp16 number (|x| >= 0.125); below that it is rounded to 2^-25 ABSOLUTE (3e-8).  The
+// weights (~0.07 in a 192-wide layer) are therefore stored times 64 (mlp_common.h: SPLIT_W_SCALE; the epilogue's bias
+// multiply-add takes the 1/64), activations and inputs are O(1) and stay unscaled: their worst case is the 3e-8 absolute,
+// i.e. the two-plane error of a value of 0.125.  Through the four layers of the net the result differs from a
+// double-precision evaluation by 4e-7 .. 8e-7 of the layer's largest value, the same as torch's own fp32 chain (5e-7;
+// tools/ubench/mfma_f32_shapes.hip for the rates, tests/test_gpu_split.py for the accuracy).  With bf16 planes the same
+// three products give 6e-6 .. 9e-6: fp16's three extra mantissa bits per plane are what makes two planes enough; a |value|
+// above 65504 (a weight above 1023) would overflow the first plane (the fp32 MFMA path stays available: ESR_SPLIT_FWD=0).
+// (Until the middle of round 4 the residual planes were scaled by 2048 and summed in accumulators of their own: three
+// accumulator sets whose every value had to be fetched from the accumulation registers and recombined in the epilogue --
+// the epilogue, not the matrix pipe, bounded the kernel: tools/ubench/split_stamps.hip.)
 //
 // Everything OUTSIDE the products is the f32 engine's: fp32 input tile X, fp32 bias add, ReLU, the saved hidden tiles H
 // (fp32, tile-major) and ReLU masks in mlp.hip's formats -- the f32 input-gradient and weight-gradient kernels consume them
@@ -40,7 +46,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 constexpr int SPW = 4;                                      // waves per workgroup = tiles per group
-constexpr float SPLIT_SCALE = 2048.f, SPLIT_INV = 1.f / 2048.f;
 
 __device__ __forceinline__ f32x16 mfma_h(f16x8 a, f16x8 b, f32x16 c)
 {
@@ -56,15 +61,31 @@ __device__ __forceinline__ void sfor(F &&f)
     }
 }
 
-// x -> (fp16(x), fp16((x - fp16(x)) * 2048)) for eight values
+// x -> (fp16(x), fp16(x - fp16(x))) for eight values
 __device__ __forceinline__ void split8(const float (&v)[8], f16x8 &p1, f16x8 &p2)
 {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const _Float16 h = (_Float16)v[i];
         p1[i] = h;
-        p2[i] = (_Float16)((v[i] - (float)h) * SPLIT_SCALE);
+        p2[i] = (_Float16)(v[i] - (float)h);
     }
+}
+
+// Two fp16 values into slots i0, i0 + 1 of a plane register, PINNED where they are computed: the planes of a layer are first
+// read by the next layer's MFMAs, and LLVM sinks a computation towards its first use -- without the pin the conversions of
+// all six tiles of a layer left their micro-slices and ran as one block of ~300 instructions behind the layer's last MFMA
+// (tools/ubench/split_stamps.hip; the empty asm's operand is a VALU result: no MFMA hazard involved).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <int I0>
+__device__ __forceinline__ void put_pair(f16x8 &dst, float a, float b)
+{
+    const f16x2 hh = {(_Float16)a, (_Float16)b};
+    unsigned u = __builtin_bit_cast(unsigned, hh);
+    asm volatile("" : "+v"(u));
+    const f16x2 pinned = __builtin_bit_cast(f16x2, u);
+    dst[I0] = pinned[0];
+    dst[I0 + 1] = pinned[1];
 }
 
 template <int KIND, bool BWD = false> struct SplitSteps {
@@ -178,6 +199,13 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
             if (k * 64 * SPW < pieces && tid + 64 * SPW * k < pieces)
                 *reinterpret_cast<u32x4 *>(dst + (size_t)(tid + 64 * SPW * k) * 16) = pre[k];
     };
+    // one 16-byte piece per thread: the step's last tile issues these behind its MFMAs (the other LDS buffer is idle since
+    // the previous step's barrier), instead of 12 writes + their wait between the last MFMA and the barrier
+    auto stage_piece = [&](auto ST, auto KC, unsigned char *dst) __attribute__((always_inline)) {
+        constexpr int st = decltype(ST)::value, k = decltype(KC)::value, pieces = S::chunks(st) * 64;
+        if constexpr (k * 64 * SPW < pieces)
+            if (tid + 64 * SPW * k < pieces) *reinterpret_cast<u32x4 *>(dst + (size_t)(tid + 64 * SPW * k) * 16) = pre[k];
+    };
     stage_load(std::integral_constant<int, 0>{});
     stage_store(std::integral_constant<int, 0>{}, wl);
     step_barrier();
@@ -216,61 +244,65 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
         }
         ESR_SPLIT_STAMP(0);
         fetch(tg + nblk < ngroups ? tg + nblk : tg);       // the next group's rows (past the end: this group again, never used)
-        // main sums and the two residual sums (w1.x2, w2.x1: one accumulator each, so that every accumulator is touched once
-        // per k-step -- a dependent MFMA waits for its predecessor's last pass), two tiles alternate; bz: a tile's biases,
-        // requested when its MFMAs start and used a tile later (a ds_read inside a micro-slice is a full LDS round trip
-        // in front of one MFMA's worth of work: the first version of the slices waited ~100 clocks in each)
-        f32x16 am[2], ar[2], aq[2];
+        // one accumulator per tile (two tiles alternate: the one in flight and the one in its epilogue); bz: a tile's biases,
+        // requested when its MFMAs start and used a tile later (a ds_read inside a micro-slice is a full LDS round trip in
+        // front of one MFMA's worth of work: the first version of the slices waited ~100 clocks in each); ev: the pending
+        // tile's finished values between the phases of its epilogue (vector registers: every touch of an accumulation
+        // register costs a v_accvgpr_read / _write of its own)
+        f32x16 am[2];
         float4 bz4[2][4];
+        float ev[16];
         unsigned mword = 0;
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         // zero-record descriptors drop the stores of a pass that saves nothing (no branch inside the MFMA stream)
         const unsigned hrec = (save && A.save == 1) ? HBYTES : 0u, mrec = save ? MBYTES : 0u;
 
         // ---- the epilogue of a finished hidden tile, cut into 24 MICRO-SLICES (8 register pairs x 3 phases) ------------------
-        // One wave per SIMD has nobody to overlap with: the matrix pipe takes one 8-pass MFMA per 32 clocks and the wave
-        // issues in order, so a tile's ~170 epilogue instructions behind its MFMAs idle the pipe for their whole length (the
-        // first version of this kernel: 0.98 ms at C2, 9 k clocks per step for 2.3 k of matrix work).  Each micro-slice
-        // (5-7 vector instructions) is therefore issued right behind ONE MFMA of the FOLLOWING tile -- also across a layer
-        // boundary: the last tile of layer l is finished inside the first tile of layer l + 1, whose k-steps 10 / 11 (the only
-        // ones that read that tile's planes) come after micro-slice 23.
-        //   phase 0 (pair p): value = main + residual / 2048 + bias, ReLU, the fp32 tile stores -> kept in the main accumulator
-        //   phase 1: mask bits, first plane (fp16 of the value), scaled residual -> kept in the residual accumulator
-        //   phase 2: second plane (fp16 of the scaled residual)
-        auto micro = [&](auto LC, auto IT, auto MS, f32x16 &accm, f32x16 &accr, f32x16 &accq, auto &o1, auto &o2) __attribute__((always_inline)) {
+        // One wave per SIMD has nobody to overlap with, and the wave issues in order: independent vector instructions DO run
+        // in the shadow of an MFMA's 32 clocks (tools/ubench/mfma_valu_overlap.hip: a group of one MFMA + V vector
+        // instructions costs max(32, 4.75 V) + 4.5 clocks), but a tile's whole epilogue behind its MFMAs idles the pipe for its
+        // length (the first version of this kernel: 0.98 ms at C2, 9 k clocks per step for 2.3 k of matrix work).  Each
+        // micro-slice (5-8 vector instructions) is therefore issued right behind ONE MFMA of the FOLLOWING tile -- also across
+        // a layer boundary: the last tile of layer l is finished inside the first tile of layer l + 1, whose k-steps 10 / 11
+        // (the only ones that read that tile's planes) come after micro-slice 23.
+        //   phase 0 (pair p): value = accumulator / 64 + bias (one fma), ReLU, the fp32 tile stores -> ev
+        //   phase 1: mask bits, first plane (fp16 of the value)
+        //   phase 2: second plane (fp16 of value - first plane)
+        auto micro = [&](auto LC, auto IT, auto MS, f32x16 &accm, auto &o1, auto &o2) __attribute__((always_inline)) {
             constexpr int l = decltype(LC)::value, it = decltype(IT)::value, ms = decltype(MS)::value, p = ms / 3, q = ms % 3;
             constexpr int r0 = 2 * p, jj = r0 >> 3, i0 = r0 & 7;
             if constexpr (q == 0) {
                 const float4 b4 = bz4[it & 1][p >> 1];
                 const float bx = (p & 1) ? b4.z : b4.x, by = (p & 1) ? b4.w : b4.y;
-                float v0 = fmaf(accr[r0] + accq[r0], SPLIT_INV, accm[r0]) + bx, v1 = fmaf(accr[r0 + 1] + accq[r0 + 1], SPLIT_INV, accm[r0 + 1]) + by;
+                float v0 = fmaf(accm[r0], SPLIT_W_INV, bx), v1 = fmaf(accm[r0 + 1], SPLIT_W_INV, by);
                 const int b0 = __float_as_int(v0), b1 = __float_as_int(v1);
                 v0 = __int_as_float(b0 > 0 ? b0 : 0);
                 v1 = __int_as_float(b1 > 0 ? b1 : 0);
                 const rsrc_t RH = make_rsrc(AB.H[l] + (size_t)t * (HBYTES / 4), hrec);      // fp32 tile, mlp.hip's store_tiles order
-                bstore1_nt(RH, v0, hvoff, tile_soff(it, r0));
-                bstore1_nt(RH, v1, hvoff, tile_soff(it, r0 + 1));
-                accm[r0] = v0; accm[r0 + 1] = v1;
+#ifndef ESR_SPLIT_NO_HSTORE
+                bstore1_nt(RH, v0, hvoff + tile_soff(0, r0), it * 4096);      // (row offset < 4096: the instruction's immediate)
+                bstore1_nt(RH, v1, hvoff + tile_soff(0, r0 + 1), it * 4096);
+#endif
+                ev[r0] = v0; ev[r0 + 1] = v1;
             } else if constexpr (q == 1) {
-                const float v0 = accm[r0], v1 = accm[r0 + 1];
+                const float v0 = ev[r0], v1 = ev[r0 + 1];
                 int one0, one1;                                    // (operands: phase 0's integer max -- VALU results, no MFMA hazard)
                 asm("v_med3_i32 %0, %1, 0, 1" : "=v"(one0) : "v"(__float_as_int(v0)));
                 asm("v_med3_i32 %0, %1, 0, 1" : "=v"(one1) : "v"(__float_as_int(v1)));
                 mword |= ((unsigned)one0 << ((it & 1) * 16 + r0)) | ((unsigned)one1 << ((it & 1) * 16 + r0 + 1));
-                const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
-                o1[2 * it + jj][i0] = h0; o1[2 * it + jj][i0 + 1] = h1;
-            } else {                                               // (back-conversion, residual, scale, second plane: ~8 instructions)
-                const float v0 = accm[r0], v1 = accm[r0 + 1];
+                asm volatile("" : "+v"(mword));
+                put_pair<i0>(o1[2 * it + jj], v0, v1);
+            } else {
+                const float v0 = ev[r0], v1 = ev[r0 + 1];
                 const _Float16 h0 = o1[2 * it + jj][i0], h1 = o1[2 * it + jj][i0 + 1];
-                o2[2 * it + jj][i0] = (_Float16)((v0 - (float)h0) * SPLIT_SCALE);
-                o2[2 * it + jj][i0 + 1] = (_Float16)((v1 - (float)h1) * SPLIT_SCALE);
+                put_pair<i0>(o2[2 * it + jj], v0 - (float)h0, v1 - (float)h1);
             }
         };
         // micro-slices of the pending tile that ride on MFMA slot u (of NSLOT) of the tile in flight
-        auto pending = [&](auto LC, auto IT, auto U, auto NSLOTC, f32x16 &accm, f32x16 &accr, f32x16 &accq, auto &o1, auto &o2) __attribute__((always_inline)) {
+        auto pending = [&](auto LC, auto IT, auto U, auto NSLOTC, f32x16 &accm, auto &o1, auto &o2) __attribute__((always_inline)) {
             constexpr int u = decltype(U)::value, nslot = decltype(NSLOTC)::value;
-            if constexpr (u < 24) micro(LC, IT, std::integral_constant<int, u>{}, accm, accr, accq, o1, o2);
-            if constexpr (u + nslot < 24) micro(LC, IT, std::integral_constant<int, u + nslot>{}, accm, accr, accq, o1, o2);
+            if constexpr (u < 24) micro(LC, IT, std::integral_constant<int, u>{}, accm, o1, o2);
+            if constexpr (u + nslot < 24) micro(LC, IT, std::integral_constant<int, u + nslot>{}, accm, o1, o2);
             static_assert(2 * nslot >= 24, "every micro-slice finds a slot");
             // behind the LAST micro-slice of an odd tile: the mask word of the tile pair (mlp_common.h: store_relu_mask's order)
             constexpr int l = decltype(LC)::value, it = decltype(IT)::value;
@@ -287,7 +319,7 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
             constexpr int l = decltype(LC)::value, KS = L.ks[l], NT = L.tiles_out[l], NP = L.pairs[l];
             constexpr int s0 = [] { int s = 0; for (int k = 0; k < l; ++k) s += L.pairs[k]; return s; }();
             constexpr bool LAST = l == NL - 1;
-            f32x16 zm, zr, zq;                                     // (output layer: its single tile's sums)
+            f32x16 zm;                                             // (output layer: its single tile's sums)
             sfor<0, NP>([&](auto PC) {
                 constexpr int p = decltype(PC)::value, st = s0 + p, tin = S::tiles_in(st), nxt_st = (st + 1) % NS;
                 const unsigned char *wsrc = wl + (st & 1) * S::BUF;
@@ -305,17 +337,21 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
                 }
                 sfor<0, NTOT>([&](auto NC) {
                     constexpr int n = decltype(NC)::value, tt_ = n / KS, j = n % KS, it = 2 * p + tt_;
+#ifndef ESR_SPLIT_NO_WREAD
                     if constexpr (n + 2 < NTOT) {
                         constexpr int t2 = (n + 2) / KS, j2 = (n + 2) % KS;
                         wb[(n + 2) % 3][0] = mine[((t2 * 2 + 0) * KS + j2) * 64];
                         wb[(n + 2) % 3][1] = mine[((t2 * 2 + 1) * KS + j2) * 64];
                     }
+#else
+                    if constexpr (n == 0 && NTOT > 2) { wb[2][0] = mine[2 * 64]; wb[2][1] = mine[(KS + 2) * 64]; }
+#endif
                     if constexpr (j == 0 && !LAST) {               // this tile's biases, for its epilogue a tile from now
                         const float4 *bp = reinterpret_cast<const float4 *>(bias_l + l * S::BIAS_FLOATS + it * 32 + (lane >> 5) * 16);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) bz4[it & 1][q] = bp[q];
                     }
-                    f32x16 &m = LAST ? zm : am[it & 1], &r = LAST ? zr : ar[it & 1], &qq = LAST ? zq : aq[it & 1];
+                    f32x16 &m = LAST ? zm : am[it & 1];
                     const f16x8 w1 = __builtin_bit_cast(f16x8, wb[n % 3][0]), w2 = __builtin_bit_cast(f16x8, wb[n % 3][1]);
                     // the pending tile: the previous tile of this layer, or the last tile of the previous layer
                     constexpr bool HAVE = it > 0 || l > 0;
@@ -323,18 +359,34 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
                     auto ride = [&](auto U) __attribute__((always_inline)) {
                         if constexpr (HAVE) {
                             if constexpr (it > 0) pending(std::integral_constant<int, pl>{}, std::integral_constant<int, pit>{}, U,
-                                                          std::integral_constant<int, 3 * KS>{}, am[pit & 1], ar[pit & 1], aq[pit & 1], o1, o2);
+                                                          std::integral_constant<int, 3 * KS>{}, am[pit & 1], o1, o2);
                             else pending(std::integral_constant<int, pl>{}, std::integral_constant<int, pit>{}, U,
-                                         std::integral_constant<int, 3 * KS>{}, am[pit & 1], ar[pit & 1], aq[pit & 1], in1, in2);
+                                         std::integral_constant<int, 3 * KS>{}, am[pit & 1], in1, in2);
+                        }
+                        if constexpr (tt_ == tin - 1) {            // the next step's weights: one piece per slot, last slots of the step
+                            constexpr int u_ = decltype(U)::value, first = 3 * KS - S::PRE;
+                            static_assert(first >= 0, "a tile has a slot for every staged piece");
+                            if constexpr (u_ >= first) stage_piece(std::integral_constant<int, nxt_st>{}, std::integral_constant<int, u_ - first>{},
+                                                                   wl + ((st + 1) & 1) * S::BUF);
                         }
                         __builtin_amdgcn_sched_barrier(0);         // one MFMA + its micro-slice per scheduling region
                     };
-                    r = mfma_h(w1, in2[j], j == 0 ? zero16 : r);
+#ifdef ESR_SPLIT_NO_MFMA                                           // (timing variants of tools/ubench/split_stamps.hip: wrong results)
+                    if (j == 0) m = zero16;
+                    m[j & 15] += (float)(w1[0] + in2[j][0]) + (float)(w2[0] + in1[j][0]);
                     ride(std::integral_constant<int, 3 * j + 0>{});
-                    m = mfma_h(w1, in1[j], j == 0 ? zero16 : m);
                     ride(std::integral_constant<int, 3 * j + 1>{});
-                    qq = mfma_h(w2, in1[j], j == 0 ? zero16 : qq);
                     ride(std::integral_constant<int, 3 * j + 2>{});
+#else
+                    // (three dependent MFMAs in a row: behind a micro-slice the predecessor has long finished; in the
+                    //  slots without one the dependent issue costs a few clocks -- tools/ubench/mfma_valu_overlap.hip)
+                    m = mfma_h(w1, in2[j], j == 0 ? zero16 : m);
+                    ride(std::integral_constant<int, 3 * j + 0>{});
+                    m = mfma_h(w1, in1[j], m);
+                    ride(std::integral_constant<int, 3 * j + 1>{});
+                    m = mfma_h(w2, in1[j], m);
+                    ride(std::integral_constant<int, 3 * j + 2>{});
+#endif
                 });
                 if constexpr (LAST) {
                     const float4 bz = *reinterpret_cast<const float4 *>(bias_l + l * S::BIAS_FLOATS + (lane >> 5) * 16);
@@ -344,10 +396,9 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
                     // are pointed past the 4-row tile's range, which the descriptor drops
                     const int zvoff = ((h ? D.zrows : 0) * 32 + s_) * 4;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) bstore1(RZ, q < 3 ? fmaf(zr[q] + zq[q], SPLIT_INV, zm[q]) + bzv[q] : 0.f, zvoff, q * 128);
+                    for (int q = 0; q < 4; ++q) bstore1(RZ, q < 3 ? fmaf(zm[q], SPLIT_W_INV, bzv[q]) : 0.f, zvoff, q * 128);
                 }
                 ESR_SPLIT_STAMP(1 + 3 * st);
-                stage_store(std::integral_constant<int, nxt_st>{}, wl + ((st + 1) & 1) * S::BUF);
                 ESR_SPLIT_STAMP(2 + 3 * st);
                 step_barrier();
                 ESR_SPLIT_STAMP(3 + 3 * st);
@@ -416,6 +467,13 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_dgrad_split_kernel(DSplitBatc
             if (k * 64 * SPW < pieces && tid + 64 * SPW * k < pieces)
                 *reinterpret_cast<u32x4 *>(dst + (size_t)(tid + 64 * SPW * k) * 16) = pre[k];
     };
+    // one 16-byte piece per thread: the step's last tile issues these behind its MFMAs (the other LDS buffer is idle since
+    // the previous step's barrier), instead of 12 writes + their wait between the last MFMA and the barrier
+    auto stage_piece = [&](auto ST, auto KC, unsigned char *dst) __attribute__((always_inline)) {
+        constexpr int st = decltype(ST)::value, k = decltype(KC)::value, pieces = S::chunks(st) * 64;
+        if constexpr (k * 64 * SPW < pieces)
+            if (tid + 64 * SPW * k < pieces) *reinterpret_cast<u32x4 *>(dst + (size_t)(tid + 64 * SPW * k) * 16) = pre[k];
+    };
     stage_load(std::integral_constant<int, 0>{});
     stage_store(std::integral_constant<int, 0>{}, wl);
     step_barrier();
@@ -465,51 +523,49 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_dgrad_split_kernel(DSplitBatc
             for (int w = 0; w < HT / 2; ++w) msk[l][w] = mn[l][w];
         fetch(tg + nblk < ngroups ? tg + nblk : tg);
         f16x8 pa1[2 * HT], pa2[2 * HT], pb1[2 * HT], pb2[2 * HT];
-        f32x16 am[2], ar[2], aq[2];
+        f32x16 am[2];
+        float ev[16];
+        const float wisc = SPLIT_W_INV * isc;                                 // accumulator (64 x the scaled gradient) -> the fp32 store
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
         // micro-slices of a finished tile of transposed layer q (8 register pairs x 3 phases, as in the forward):
         //   q < 3: phase 0 value (scaled), ReLU mask of the layer below, the unscaled fp32 dZ store; phases 1 / 2 the planes
         //   q = 3: phase 0 unscaled value -> dX rows (the descriptor ends at row 44: the rows above are not written)
-        auto micro = [&](auto QC, auto IT, auto MS, f32x16 &accm, f32x16 &accr, f32x16 &accq, auto &o1, auto &o2) __attribute__((always_inline)) {
+        auto micro = [&](auto QC, auto IT, auto MS, f32x16 &accm, auto &o1, auto &o2) __attribute__((always_inline)) {
             constexpr int q = decltype(QC)::value, it = decltype(IT)::value, ms = decltype(MS)::value, p = ms / 3, ph = ms % 3;
             constexpr int r0 = 2 * p, jj = r0 >> 3, i0 = r0 & 7;
             if constexpr (q == NL - 1) {
                 if constexpr (ph == 0) {
-                    const float v0 = fmaf(accr[r0] + accq[r0], SPLIT_INV, accm[r0]) * isc;
-                    const float v1 = fmaf(accr[r0 + 1] + accq[r0 + 1], SPLIT_INV, accm[r0 + 1]) * isc;
+                    const float v0 = accm[r0] * wisc, v1 = accm[r0 + 1] * wisc;
                     const rsrc_t RX = make_rsrc(AB.dX + (size_t)t * 64 * 32, live ? dx_rows(KIND) / 4 * 4 * 128 + (dx_rows(KIND) % 4 ? 512 : 0) : 0);
-                    bstore1(RX, v0, hvoff, tile_soff(it, r0));           // (default policy: the scatter reads dX next)
-                    bstore1(RX, v1, hvoff, tile_soff(it, r0 + 1));
+                    bstore1(RX, v0, hvoff + tile_soff(0, r0), it * 4096);           // (default policy: the scatter reads dX next)
+                    bstore1(RX, v1, hvoff + tile_soff(0, r0 + 1), it * 4096);
                 }
             } else {
                 constexpr int d = NHID - 1 - q;                              // this tile is a tile of dZ[d]
                 if constexpr (ph == 0) {
-                    float v0 = fmaf(accr[r0] + accq[r0], SPLIT_INV, accm[r0]), v1 = fmaf(accr[r0 + 1] + accq[r0 + 1], SPLIT_INV, accm[r0 + 1]);
                     const int k0 = ((int)(msk[d][it >> 1] << (31 - ((it & 1) * 16 + r0)))) >> 31;
                     const int k1 = ((int)(msk[d][it >> 1] << (31 - ((it & 1) * 16 + r0 + 1)))) >> 31;
-                    v0 = __int_as_float(__float_as_int(v0) & k0);
-                    v1 = __int_as_float(__float_as_int(v1) & k1);
+                    const int a0 = __float_as_int(accm[r0]) & k0, a1 = __float_as_int(accm[r0 + 1]) & k1;      // 64 x the masked value
                     const rsrc_t RD = make_rsrc(AB.dZ[d] + (size_t)t * (HBYTES / 4), (live && AB.dZ[d]) ? HBYTES : 0u);
-                    bstore1_nt(RD, v0 * isc, hvoff, tile_soff(it, r0));
-                    bstore1_nt(RD, v1 * isc, hvoff, tile_soff(it, r0 + 1));
-                    accm[r0] = v0; accm[r0 + 1] = v1;
+                    bstore1_nt(RD, __int_as_float(a0) * wisc, hvoff + tile_soff(0, r0), it * 4096);
+                    bstore1_nt(RD, __int_as_float(a1) * wisc, hvoff + tile_soff(0, r0 + 1), it * 4096);
+                    ev[r0] = __int_as_float(a0) * SPLIT_W_INV; ev[r0 + 1] = __int_as_float(a1) * SPLIT_W_INV;
                 } else if constexpr (ph == 1) {
-                    o1[2 * it + jj][i0] = (_Float16)accm[r0]; o1[2 * it + jj][i0 + 1] = (_Float16)accm[r0 + 1];
+                    put_pair<i0>(o1[2 * it + jj], ev[r0], ev[r0 + 1]);
                 } else {
-                    const float v0 = accm[r0], v1 = accm[r0 + 1];
+                    const float v0 = ev[r0], v1 = ev[r0 + 1];
                     const _Float16 h0 = o1[2 * it + jj][i0], h1 = o1[2 * it + jj][i0 + 1];
-                    o2[2 * it + jj][i0] = (_Float16)((v0 - (float)h0) * SPLIT_SCALE);
-                    o2[2 * it + jj][i0 + 1] = (_Float16)((v1 - (float)h1) * SPLIT_SCALE);
+                    put_pair<i0>(o2[2 * it + jj], v0 - (float)h0, v1 - (float)h1);
                 }
             }
         };
         // the pending tile's micro-slices u, u + nslot, u + 2 nslot, ... ride on MFMA slot u of the tile in flight
-        auto pending = [&](auto QC, auto IT, auto U, auto NSLOTC, f32x16 &accm, f32x16 &accr, f32x16 &accq, auto &o1, auto &o2) __attribute__((always_inline)) {
+        auto pending = [&](auto QC, auto IT, auto U, auto NSLOTC, f32x16 &accm, auto &o1, auto &o2) __attribute__((always_inline)) {
             constexpr int u = decltype(U)::value, nslot = decltype(NSLOTC)::value;
             sfor<0, (24 + nslot - 1) / nslot>([&](auto KC) {
                 constexpr int msi = u + decltype(KC)::value * nslot;
-                if constexpr (msi < 24) micro(QC, IT, std::integral_constant<int, msi>{}, accm, accr, accq, o1, o2);
+                if constexpr (msi < 24) micro(QC, IT, std::integral_constant<int, msi>{}, accm, o1, o2);
             });
         };
         auto run_layer = [&](auto QC, auto &in1, auto &in2, auto &o1, auto &o2) __attribute__((always_inline)) {
@@ -536,32 +592,38 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_dgrad_split_kernel(DSplitBatc
                         wb[(n + 2) % 3][0] = mine[((t2 * 2 + 0) * KS + j2) * 64];
                         wb[(n + 2) % 3][1] = mine[((t2 * 2 + 1) * KS + j2) * 64];
                     }
-                    f32x16 &m = am[it & 1], &r = ar[it & 1], &qq = aq[it & 1];
+                    f32x16 &m = am[it & 1];
                     const f16x8 w1 = __builtin_bit_cast(f16x8, wb[n % 3][0]), w2 = __builtin_bit_cast(f16x8, wb[n % 3][1]);
                     constexpr bool HAVE = it > 0 || q > 0;
                     constexpr int pq = it > 0 ? q : q - 1, pit = it > 0 ? it - 1 : (q > 0 ? L.tiles_out[q > 0 ? q - 1 : 0] - 1 : 0);
                     auto ride = [&](auto U) __attribute__((always_inline)) {
                         if constexpr (HAVE) {
                             if constexpr (it > 0) pending(std::integral_constant<int, pq>{}, std::integral_constant<int, pit>{}, U,
-                                                          std::integral_constant<int, 3 * KS>{}, am[pit & 1], ar[pit & 1], aq[pit & 1], o1, o2);
+                                                          std::integral_constant<int, 3 * KS>{}, am[pit & 1], o1, o2);
                             else pending(std::integral_constant<int, pq>{}, std::integral_constant<int, pit>{}, U,
-                                         std::integral_constant<int, 3 * KS>{}, am[pit & 1], ar[pit & 1], aq[pit & 1], in1, in2);
+                                         std::integral_constant<int, 3 * KS>{}, am[pit & 1], in1, in2);
+                        }
+                        if constexpr (tt_ == tin - 1 && 3 * KS >= S::PRE) {
+                            constexpr int u_ = decltype(U)::value, first = 3 * KS - S::PRE;
+                            if constexpr (u_ >= first) stage_piece(std::integral_constant<int, nxt_st>{}, std::integral_constant<int, u_ - first>{},
+                                                                   wl + ((st + 1) & 1) * S::BUF);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     };
-                    r = mfma_h(w1, in2[j], j == 0 ? zero16 : r);
+                    m = mfma_h(w1, in2[j], j == 0 ? zero16 : m);
                     ride(std::integral_constant<int, 3 * j + 0>{});
-                    m = mfma_h(w1, in1[j], j == 0 ? zero16 : m);
+                    m = mfma_h(w1, in1[j], m);
                     ride(std::integral_constant<int, 3 * j + 1>{});
-                    qq = mfma_h(w2, in1[j], j == 0 ? zero16 : qq);
+                    m = mfma_h(w2, in1[j], m);
                     ride(std::integral_constant<int, 3 * j + 2>{});
                 });
                 if constexpr (q == NL - 1 && p == NP - 1) {         // the very last tile (dX rows 32..63): nobody to ride on
                     sfor<0, 24>([&](auto MC) {
-                        micro(QC, std::integral_constant<int, NT - 1>{}, MC, am[(NT - 1) & 1], ar[(NT - 1) & 1], aq[(NT - 1) & 1], o1, o2);
+                        micro(QC, std::integral_constant<int, NT - 1>{}, MC, am[(NT - 1) & 1], o1, o2);
                     });
                 }
-                stage_store(std::integral_constant<int, nxt_st>{}, wl + ((st + 1) & 1) * S::BUF);
+                if constexpr (3 * KS < S::PRE)                     // (the one-k-step first layer: too few slots, all pieces here)
+                    stage_store(std::integral_constant<int, nxt_st>{}, wl + ((st + 1) & 1) * S::BUF);
                 step_barrier();
             });
         };

@@ -1,6 +1,11 @@
 // Where does a wave of the split-fp16 forward (csrc/mlp_split.hip) spend its time?  The PRODUCT kernel with s_memtime stamps of
 // wave 0 of every workgroup: stamp 0 = inputs split, then per step s (10 per tile group): 1+3s MFMA block done, 2+3s next
-// step's weights written to LDS, 3+3s barrier passed.   gpurun -- './tools/ubench/split_stamps'
+// step's weights written to LDS (since the pieces ride in the last tile's slots: nothing), 3+3s barrier passed.
+//   gpurun -- './tools/ubench/split_stamps'
+// Timing variants (wrong results, same instruction stream minus one ingredient): build with -DESR_SPLIT_NO_MFMA (everything
+// but the MFMAs: 3.4 k of a hidden step's 4.0 k clocks -- the step is bound by the in-order issue of its ~450 vector /
+// scalar instructions, 48 LDS reads and 32 stores, not by the matrix pipe's 2.3 k), -DESR_SPLIT_NO_HSTORE (-0.35 k per
+// step), -DESR_SPLIT_NO_WREAD (no weight reads from LDS: -0.8 k per step).
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
