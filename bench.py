@@ -165,6 +165,9 @@ KERNEL_OF = {
     # fine stage, f32 engine: the step's eight weight-gradient jobs are ONE launch (+ a ~14 us slab reduction in the same call)
     "mlp_wgrad(all)": "mlp_wgrad_uni192_kernel",
 }
+# the same calls when the f32 engine runs them on the 16-bit matrix cores from split fp16 planes (round 4)
+SPLIT_KERNELS = {"mlp_fwd(rad)": "mlp_fwd_split_kernel<0>", "mlp_dgrad(rad)": "mlp_dgrad_split_kernel<0>",
+                 "mlp_wgrad(all)": "mlp_wgrad_uni192s_kernel"}
 
 
 def best_threads(run, candidates):
@@ -318,19 +321,23 @@ def pmc_traffic(a, stage, calls):
     return sum(vals) / len(vals) if vals else None
 
 
-OTHER_WORKLOADS = (("C3_fine_bf16", ["--config", "C3", "--dtype", "bf16"]),
-                   ("C4_lts_f32", ["--config", "C4"]),
-                   ("C5_pdra_bf16", ["--config", "C5"]))
+# (name, bench.py arguments, environment of the child)
+OTHER_WORKLOADS = (("C3_fine_bf16", ["--config", "C3", "--dtype", "bf16"], {}),
+                   ("C4_lts_f32", ["--config", "C4"], {}),
+                   ("C5_pdra_bf16", ["--config", "C5"], {}),
+                   # the headline workload with every MLP product on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32), i.e. the
+                   # engine of rounds 1-3: what the split-fp16 radiance kernels are measured against
+                   ("C2_fine_f32_mfma_f32_only", [], {"ESR_SPLIT_FWD": "0"}))
 
 
-def other_workloads(budget_s=150.0):
+def other_workloads(budget_s=170.0):
     """The other single-GPU BASELINE configs, each timed by a CHILD process of this script (30 steps after 10 warm-up
     steps -- with 10 + 6 the first timed steps still carried the warm-up's workspace growth and clock ramp: C3 bf16 read
     1.78 ms against 1.64 ms of the 50-step run -- no CPU baseline, no optimizer section) AFTER the headline has been measured: {name: {rays_per_s, ms_per_step,
     dtype, roofline fractions}}.  A child that fails or runs out of the time budget is reported as such, never guessed."""
     import subprocess
     out, t_start = {}, time.perf_counter()
-    for name, args in OTHER_WORKLOADS:
+    for name, args, env in OTHER_WORKLOADS:
         left = budget_s - (time.perf_counter() - t_start)
         if left < 20.0:
             out[name] = {"skipped": "time budget of the default run spent"}
@@ -338,7 +345,7 @@ def other_workloads(budget_s=150.0):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *args, "--steps", "30", "--warmup", "10", "--no-cpu-baseline",
                "--no-optimizer", "--no-other"]
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=left, cwd=ROOT)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=left, cwd=ROOT, env=dict(os.environ, **env))
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not line:
                 out[name] = {"failed": (r.stderr or r.stdout)[-300:]}
@@ -347,7 +354,7 @@ def other_workloads(budget_s=150.0):
             rl = d.get("roofline") or {}
             out[name] = {"rays_per_s": d["value"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "steps": d["steps"],
                          "warmup": d["warmup"], "workload": d["config"]["workload"],
-                         "roofline": {k: rl.get(k) for k in ("bound", "frac", "mfma_frac", "hbm_frac") if k in rl},
+                         "roofline": {k: rl.get(k) for k in ("bound", "kernel", "frac", "mfma_frac", "hbm_frac") if k in rl},
                          "whole_step_frac": (rl.get("whole_step") or {}).get("frac"),
                          "c_abi_launches_per_step": d.get("c_abi_launches_per_step")}
         except subprocess.TimeoutExpired:
@@ -514,30 +521,39 @@ def main():
                 by_kernel[kname] = by_kernel.get(kname, 0.0) + breakdown[call][1]
         split_fwd = bool(getattr(eng, "split_fwd", False)) and a.dtype == "f32" and stage == "fine"
         split_bwd = split_fwd and bool(getattr(eng, "split_bwd", False))
+        split_wg = split_bwd and bool(getattr(eng, "split_wgrad", False))
+        # the f32 engine's radiance launches run on the 16-bit matrix cores from split fp16 planes (csrc/mlp_split.hip,
+        # wgrad_dma_body<SPLIT>): their kernel symbols
+        for on, call, kname in ((split_fwd, "mlp_fwd(rad)", SPLIT_KERNELS["mlp_fwd(rad)"]),
+                                (split_bwd, "mlp_dgrad(rad)", SPLIT_KERNELS["mlp_dgrad(rad)"]),
+                                (split_wg, "mlp_wgrad(all)", SPLIT_KERNELS["mlp_wgrad(all)"])):
+            if on and call in breakdown:
+                by_kernel[KERNEL_OF[call]] = by_kernel.get(KERNEL_OF[call], 0.0) - breakdown[call][1]
+                if by_kernel[KERNEL_OF[call]] <= 1e-9:
+                    by_kernel.pop(KERNEL_OF[call])
+                by_kernel[kname] = breakdown[call][1]
         if not (stage == "fine" and a.dtype == "f32"):
             by_kernel.pop("mlp_wgrad_uni192_kernel", None)             # (one launch only in the fine stage's f32 engine)
-        if split_fwd:
-            # the radiance forward (and, with split_bwd, the input-gradient chain) runs on the 16-bit matrix cores
-            # (csrc/mlp_split.hip): priced against THAT pipe and HBM in `roofline.split_forward` / `split_dgrad`; the
-            # f32-MFMA roofline below is taken on the largest remaining f32 launch
-            by_kernel.pop("mlp_fwd_kernel<0>", None)
-            if split_bwd:
-                by_kernel.pop("mlp_dgrad_kernel<0>", None)
-        else:
+        elif not split_fwd:
             by_kernel.pop("mlp_wgrad_uni192_kernel", None)             # (rounds 1-3's choice of launch stays comparable)
         dominant = max(by_kernel, key=by_kernel.get) if by_kernel else None
         if dominant and a.dtype == "bf16":                     # the bf16 engine's kernel symbols (csrc/mlp_bf16.hip)
             dominant = dominant.replace("mlp_fwd_kernel", "mlp_fwd16s_kernel").replace("mlp_dgrad_kernel", "mlp_dgrad16s_kernel")
-    dom_calls = [c for c, k in KERNEL_OF.items() if dominant and k == dominant.replace("16s_kernel", "_kernel") and c in breakdown
-                 and not (c == "mlp_fwd(rad)" and n_prof and split_fwd) and not (c == "mlp_dgrad(rad)" and n_prof and split_fwd and split_bwd)]
+    split_of = {v: k for k, v in SPLIT_KERNELS.items()}
+    if dominant in split_of:
+        dom_calls = [split_of[dominant]]
+    else:
+        dom_calls = [c for c, k in KERNEL_OF.items() if dominant and k == dominant.replace("16s_kernel", "_kernel") and c in breakdown
+                     and not (c == "mlp_fwd(rad)" and n_prof and split_fwd) and not (c == "mlp_dgrad(rad)" and n_prof and split_fwd and split_bwd)
+                     and not (c == "mlp_wgrad(all)" and n_prof and split_wg)]
     # one launch of that kernel per step is bracketed (each event pair costs ~40-80 us of wall time)
     dom_calls = sorted(dom_calls, key=lambda c: -breakdown[c][1])[:1]
     if not dom_calls and not a.no_kernel_timing and stage == "fine":
         # too few warm-up steps for the breakdown: bracket the kernel that dominates every profile taken so far
         split_fwd = bool(getattr(eng, "split_fwd", False)) and a.dtype == "f32"
         split_bwd = split_fwd and bool(getattr(eng, "split_bwd", False))
-        dominant, dom_calls = (("mlp_wgrad_uni192_kernel", ["mlp_wgrad(all)"]) if split_bwd else
-                               ("mlp_dgrad_kernel<0>", ["mlp_dgrad(rad)"]) if split_fwd else
+        split_wg = split_bwd and bool(getattr(eng, "split_wgrad", False))
+        dominant, dom_calls = ((SPLIT_KERNELS["mlp_fwd(rad)"], ["mlp_fwd(rad)"]) if split_fwd else
                                ("mlp_fwd_kernel<0>", ["mlp_fwd(rad)" if getattr(eng, "merge_rad", False) else "mlp_fwd(emo)"]))
     # timed region: exactly K steps, events only around the dominant kernel's launches (on their stream)
     eng.enable_timing(dominant is not None, only=dom_calls if dominant else None)
@@ -687,7 +703,28 @@ def main():
                 "share_of_kernel_time": sum(breakdown[c][1] for c in dom_calls if c in breakdown) / total_ms,
                 "pmc": pmc_mfma,
             }
-            if a.dtype == "bf16":                  # bf16 operands: the activation traffic, not the MFMA pipe, binds
+            if dominant in SPLIT_KERNELS.values():
+                # products as split-fp16 triples on the 16-bit matrix cores: three ISSUED 16-bit MFMA FLOPs per algorithmic
+                # FLOP, priced against THAT pipe's dense peak, and the algorithmic bytes against HBM.  Neither roof
+                # reached to 0.6 = bound by the wave's in-order instruction issue (tools/ubench/split_stamps.hip,
+                # issue_cost.hip): labelled "latency", `achieved` / `peak` / `frac` then quote the NEARER roof.
+                gbs = bytes_total / (ms * 1e-3) / 1e9
+                issued = 3.0 * ach
+                hf, mf_ = gbs / HBM_PEAK_GBS, issued / MFMA_F16_PEAK_TF
+                near_hbm = hf >= mf_
+                out["roofline"].update({
+                    "bound": "hbm" if hf >= 0.6 else "mfma" if mf_ >= 0.6 else "latency",
+                    "achieved": gbs if near_hbm else issued, "peak": HBM_PEAK_GBS if near_hbm else MFMA_F16_PEAK_TF,
+                    "unit": "GB/s" if near_hbm else "TFLOP/s", "frac": hf if near_hbm else mf_,
+                    "hbm_frac": hf, "mfma_frac": mf_, "hbm_gbs_algorithmic": gbs,
+                    "algorithmic_mb_per_launch": bytes_total / launches / 1e6,
+                    "mfma16_tflops_issued": issued, "issued_16bit_gflop_per_launch": 3.0 * flops_total / launches / 1e9,
+                    "fp32_equivalent_tflops": ach, "fp32_equivalent_over_f32_matrix_peak": ach / MFMA_F32_PEAK_TF,
+                    "pipe": "v_mfma_f32_32x32x16_f16 on two fp16 planes per fp32 operand (x = x1 + x2), three products per "
+                            "algorithmic product, fp32 accumulation and fp32 results; error vs float64 as the f32 MFMA "
+                            "kernels' (tests/test_gpu_split.py)",
+                    "pmc": None})
+            elif a.dtype == "bf16":                # bf16 operands: the activation traffic, not the MFMA pipe, binds
                 gbs = bytes_total / (ms * 1e-3) / 1e9
                 hf, mf_ = gbs / HBM_PEAK_GBS, ach / MFMA_BF16_PEAK_TF
                 # neither roof reached to 0.6: the kernel is bound by latency (barriers, epilogues), not by a roof -- say so;
@@ -699,7 +736,8 @@ def main():
                                         "mfma_tflops": ach, "mfma_frac_of_bf16_peak": mf_})
             # the whole MLP engine (all 10 calls per step), from the instrumented warm-up steps
             mlp = {k: v for k, v in breakdown.items() if algorithmic_flops(k, counts)
-                   and not (split_fwd and k == "mlp_fwd(rad)") and not (split_fwd and split_bwd and k == "mlp_dgrad(rad)")}
+                   and not (split_fwd and k == "mlp_fwd(rad)") and not (split_fwd and split_bwd and k == "mlp_dgrad(rad)")
+                   and not (split_wg and k == "mlp_wgrad(all)")}
             # (f32-pipe launches only: the split forward / input gradients are priced apart)
             if mlp:
                 mf = sum(algorithmic_flops(k, counts) * v[0] for k, v in mlp.items())
@@ -748,6 +786,19 @@ def main():
                         "hbm_gbs_algorithmic": by_ / (ms_ * 1e-3) / 1e9, "hbm_frac": by_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "fp32_equivalent_tflops": fl_ / (ms_ * 1e-3) / 1e12,
                         "note": "not priced against the f32 matrix peak: it does not run on that pipe"}
+                if split_wg and "mlp_wgrad(all)" in breakdown:
+                    n_, t_ = breakdown["mlp_wgrad(all)"]
+                    fl_, by_ = algorithmic_flops("mlp_wgrad(all)", counts), algorithmic_bytes("mlp_wgrad(all)", counts, False)
+                    ms_ = t_ / n_
+                    out["roofline"]["split_wgrad"] = {
+                        "kernel": "mlp_wgrad_uni192s_kernel (+ wgrad_reduce_kernel in the same call)", "avg_launch_ms": ms_,
+                        "what": "every weight-gradient job of the two radiance nets in one launch; fp32 H / dZ / X tiles staged by "
+                                "LDS-DMA, cut into two fp16 planes between LDS and the operand registers, three 16-bit MFMAs per "
+                                "product block, fp32 accumulation (csrc/mlp.hip: wgrad_dma_body<SPLIT>)",
+                        "bound": "hbm", "algorithmic_gflop": fl_ / 1e9, "algorithmic_mb": by_ / 1e6,
+                        "hbm_gbs_algorithmic": by_ / (ms_ * 1e-3) / 1e9, "hbm_frac": by_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "mfma16_frac": 3 * fl_ / (ms_ * 1e-3) / 1e12 / MFMA_F16_PEAK_TF,
+                        "fp32_equivalent_tflops": fl_ / (ms_ * 1e-3) / 1e12}
                 out["roofline"]["whole_step"] = {"algorithmic_gflop": step_fl / 1e9,
                                                  "achieved": step_fl / (dt / a.steps) / 1e12, "peak": peak,
                                                  "frac": step_fl / (dt / a.steps) / 1e12 / peak,
@@ -755,7 +806,7 @@ def main():
                                                  "frac_exact_mac": exact / (dt / a.steps) / 1e12 / peak}
                 if split_fwd:
                     out["roofline"]["whole_step"]["note"] = (
-                        "the radiance forward's (and input gradients') FLOPs (algorithmic, counted once) run on the 16-bit matrix cores since round 4: "
+                        "the radiance nets' FLOPs (forward, input and weight gradients; algorithmic, counted once) run on the 16-bit matrix cores since round 4: "
                         "`frac` is the step's algorithmic FLOP rate over the f32 matrix peak, kept for comparison with earlier "
                         "rounds -- it is no longer bounded by 1 in principle; the f32-pipe launches are priced one by one in "
                         "roofline / all_mlp_kernels")
@@ -783,6 +834,11 @@ def main():
                       ("mfma" if rl["mfma"]["frac"] >= 0.6 else "latency"),
                       achieved=pick["achieved"], peak=pick["peak"], unit=pick["unit"], frac=pick["frac"],
                       hbm_frac=rl["hbm"]["frac"], mfma_frac=rl["mfma"]["frac"])
+            if not bf and getattr(eng, "split_fwd", False):
+                rl["note"] = ("f32 engine, round 4: the radiance nets' forward / input-gradient / weight-gradient launches run on the "
+                              "16-bit matrix cores from split fp16 planes (fp32 results); `mfma` is still the step's ALGORITHMIC "
+                              "FLOP rate over the f32 matrix peak, kept for comparison with earlier rounds -- the brdf / emission "
+                              "/ tone-mapper launches are the ones left on that pipe")
             out["roofline"] = rl
         if pg is not None:
             # how many ranks the collective library actually saw, and which exchange ran (trainer._grid_sync)

@@ -38,7 +38,10 @@ P = os.path.join(ROOT, "profiles")
 # order of the single-dispatch MLP calls of one fine-stage step, per kernel symbol (f32 engine: the off net's detached
 # and saved forward passes are ONE launch; bf16 engine: two)
 # (round 3: the three radiance forward passes are one launch, esr_mlp_fwd_fine, and so are the two input-gradient passes)
+# (round 4: the radiance launches of the f32 engine are the split-fp16 kernels)
 ORDER_F32 = {"mlp_fwd_kernel<0>": ["mlp_fwd(rad)"], "mlp_dgrad_kernel<0>": ["mlp_dgrad(rad)"],
+             "mlp_fwd_split_kernel<0>": ["mlp_fwd(rad)"], "mlp_dgrad_split_kernel<0>": ["mlp_dgrad(rad)"],
+             "mlp_wgrad_uni192s_kernel": ["mlp_wgrad(all)"], "mlp_wgrad_uni192_kernel": ["mlp_wgrad(all)"],
              "mlp_fwd_kernel<1>": ["mlp_fwd(tone)"], "mlp_dgrad_kernel<1>": ["mlp_dgrad(tone)"]}
 ORDER_BF16 = {"mlp_fwd16s_kernel<0>": ["mlp_fwd(rad)"], "mlp_fwd16s_kernel<1>": ["mlp_fwd(tone)"],
               "mlp_dgrad16s_kernel<0>": ["mlp_dgrad(rad)"], "mlp_dgrad16s_kernel<1>": ["mlp_dgrad(tone)"],
