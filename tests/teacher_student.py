@@ -132,6 +132,30 @@ def train_fine(student, train_rays: Dict[str, torch.Tensor], s_val: float, steps
     return scores, losses
 
 
+def _mfma_f32_variant(fn):
+    """dtype "f32mfma": the f32 engine with every MLP product on the f32 MFMA pipe (ESR_SPLIT_FWD=0 for the engines built
+    inside the experiment) -- the arithmetic of rounds 1-3, against which the split-fp16 radiance kernels ("f32") are
+    compared the same way bf16 is."""
+    import functools
+    import os
+
+    @functools.wraps(fn)
+    def run(dtype, *args, **kw):
+        if dtype != "f32mfma":
+            return fn(dtype, *args, **kw)
+        keep = os.environ.get("ESR_SPLIT_FWD")
+        os.environ["ESR_SPLIT_FWD"] = "0"
+        try:
+            return fn("f32", *args, **kw)
+        finally:
+            if keep is None:
+                os.environ.pop("ESR_SPLIT_FWD", None)
+            else:
+                os.environ["ESR_SPLIT_FWD"] = keep
+    return run
+
+
+@_mfma_f32_variant
 def fine_experiment(dtype: str, steps: int = 300, n_train: int = 12288, n_test: int = 4096, batch: int = 2048,
                     s_val: float = 40.0, seed: int = 0, eval_at=None, lrs=None, perturb=None,
                     weight_linear: float = 0.1, lattice=(6, 6, 4), jitter: float = 0.0):
@@ -200,6 +224,7 @@ def build_lts(scene, mlp_seed: int, grid_seed: int, dtype: str, smooth_amp: floa
     return m, cfg
 
 
+@_mfma_f32_variant
 def pdra_experiment(dtype: str, steps: int = 200, n_train: int = 6144, n_test: int = 2048, batch: int = 1024,
                     s_val: float = 60.0, seed: int = 0, eval_at=None, num_2ndrays: int = 256, num_ltspts: int = 100):
     """C5's first half: a student ``ESRNeRF`` trained with ``LtsStep(stage="pdra")`` (image loss + light-transport,
@@ -260,6 +285,7 @@ def pdra_experiment(dtype: str, steps: int = 200, n_train: int = 6144, n_test: i
     return scores, losses, float(img.std())
 
 
+@_mfma_f32_variant
 def finetune_experiment(dtype: str, steps: int = 80, n_rays: int = 2048, n_test: int = 2048, s_val: float = 60.0,
                         seed: int = 0, eval_at=None):
     """C5's second half (pdra.py:1047-1109): from a fixed parameter set only ``emo_color`` / ``emo_rgbnet`` train, towards

@@ -24,6 +24,9 @@ ap.add_argument("--perturb", type=float, nargs=2, default=None, help="fine stage
 ap.add_argument("--weight-linear", type=float, default=None)
 ap.add_argument("--lattice", type=int, nargs=3, default=None)
 ap.add_argument("--noise-floor", action="store_true", help="also a second f32 run per seed")
+ap.add_argument("--other", default="bf16", choices=["bf16", "f32mfma"],
+                help="the arithmetic compared with the f32 engine: bf16 MLP operands (default), or f32mfma = the f32 engine with "
+                     "every product on the f32 MFMA pipe (ESR_SPLIT_FWD=0) -- then 'f32' is the split-fp16 engine under test")
 ap.add_argument("--seeds-range", type=int, default=None, help="seeds 0 .. N-1 (overrides --seeds)")
 ap.add_argument("--summary", default=None,
                 help="write paired statistics (bf16 - f32 and, with --noise-floor, f32 rerun - f32: mean, sd, 95 %% CI of the "
@@ -36,7 +39,7 @@ run = dict(fine=ts.fine_experiment, pdra=ts.pdra_experiment, finetune=ts.finetun
 ev = sorted({0, a.steps // 4, a.steps // 2, 3 * a.steps // 4, a.steps})
 for seed in a.seeds:
     res = {}
-    for tag, dt in (("f32", "f32"), ("bf16", "bf16")) + ((("f32b", "f32"),) if a.noise_floor else ()):
+    for tag, dt in (("f32", "f32"), ("bf16", a.other)) + ((("f32b", "f32"),) if a.noise_floor else ()):
         kw = dict(lrs=dict(ts.LRS_FINE, sdf=a.sdf_lr)) if (a.sdf_lr is not None and a.stage == 'fine') else {}
         if a.weight_linear is not None and a.stage == 'fine':
             kw['weight_linear'] = a.weight_linear
@@ -61,7 +64,7 @@ for seed in a.seeds:
     per_seed.append(dict(seed=seed, f32=res["f32"][a.steps], bf16=res["bf16"][a.steps],
                          f32_rerun=res["f32b"][a.steps] if a.noise_floor else None, start=res["f32"][0]))
 if len(per_seed) > 1:
-    out = dict(stage=a.stage, steps=a.steps, seeds=len(per_seed),
+    out = dict(stage=a.stage, steps=a.steps, seeds=len(per_seed), other=a.other,
                bf16_minus_f32=ts.paired_stats(r["bf16"] - r["f32"] for r in per_seed),
                mean_f32=sum(r["f32"] for r in per_seed) / len(per_seed), mean_bf16=sum(r["bf16"] for r in per_seed) / len(per_seed),
                mean_gain_f32=sum(r["f32"] - r["start"] for r in per_seed) / len(per_seed))
