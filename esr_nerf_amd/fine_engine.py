@@ -123,6 +123,7 @@ class FineEngine:
         self._events = []
         self.n_calls = 0
         self.overlap_wgrad = os.environ.get("ESR_OVERLAP_WGRAD", "1") != "0"
+        self.tone_wgrad_early = os.environ.get("ESR_TONE_WGRAD_EARLY", "0") != "0"       # (A/B switch, OFF: backward())
         # f32 engine: the three radiance forward passes of a step as ONE launch (esr_mlp_fwd_fine) and the two radiance
         # input-gradient passes as one (esr_mlp_dgrad_fine); ESR_MERGE_RAD=0 keeps the separate launches (A/B timing)
         self.merge_rad = os.environ.get("ESR_MERGE_RAD", "1") != "0"
@@ -591,19 +592,29 @@ class FineEngine:
                           None, None, 0, s_)
             return run
 
+        def tone_wgrad(s_):
+            # from Xt and dzt alone: the hidden layer is recomputed inside (tone_wgrad.hip)
+            (w0, w1), (b0, _) = self._raw["tone"]
+            self._run("tone_wgrad", L.esr_tone_wgrad_recompute_bf16 if self.bf16 else L.esr_tone_wgrad_recompute,
+                      _lib.ptr(ws["Xt"]), _lib.ptr(ws["dzt"]), _lib.ptr(w0.detach()),
+                      _lib.ptr(b0.detach()), _lib.ptr(w1.detach()), 0, ta, _lib.ptr(grads["tone_w"][0]),
+                      _lib.ptr(grads["tone_b"][0]), _lib.ptr(grads["tone_w"][1]), _lib.ptr(grads["tone_b"][1]),
+                      _lib.ptr(self.tone_scratch), C.c_int64(self.tone_scratch.numel()), s_)
+        # ESR_TONE_WGRAD_EARLY=1 (OFF by default, measured): the tone mapper's weight gradients need composite_bwd's dzt only
+        # and could run on the weight-gradient stream BESIDE the input-gradient chain instead of in front of the radiance
+        # weight gradients at the end of the step.  C2 f32: 2.13 -> 2.18 ms (the issue-bound split kernels lose more than the
+        # overlap gains), C3 bf16: 1.689 -> 1.671 ms (inside the run-to-run spread).
+        tone_early = overlap and self.tone_recompute and self.tone_wgrad_early and scat is None
+
         def wgrads(s_):
             # one call for the three nets: layers of the same kernel shape share a launch (esr_mlp_wgrad_batch)
             Hh, dZh, Hth, dZth = self._H(["H0", "H1", "H2"]), self._H(["dZ0", "dZ1", "dZ2"]), self._H(["Ht"]), self._H(["dZt"])
             keep = [Hh, dZh, Hth, dZth]
             todo = [(KIND_RADIANCE, ws["X"], Hh, dZh, ws["dz"], 0, to, "emo_w", "emo_b"),
                     (KIND_RADIANCE, ws["X"], Hh, dZh, ws["dz"], to, ta, "off_w", "off_b")]
-            if self.tone_recompute:       # from Xt and dzt alone: the hidden layer is recomputed inside (tone_wgrad.hip)
-                (w0, w1), (b0, _) = self._raw["tone"]
-                self._run("tone_wgrad", L.esr_tone_wgrad_recompute_bf16 if self.bf16 else L.esr_tone_wgrad_recompute,
-                          _lib.ptr(ws["Xt"]), _lib.ptr(ws["dzt"]), _lib.ptr(w0.detach()),
-                          _lib.ptr(b0.detach()), _lib.ptr(w1.detach()), 0, ta, _lib.ptr(grads["tone_w"][0]),
-                          _lib.ptr(grads["tone_b"][0]), _lib.ptr(grads["tone_w"][1]), _lib.ptr(grads["tone_b"][1]),
-                          _lib.ptr(self.tone_scratch), C.c_int64(self.tone_scratch.numel()), s_)
+            if self.tone_recompute:
+                if not tone_early:
+                    tone_wgrad(s_)
             else:
                 todo.append((KIND_TONEMAP, ws["Xt"], Hth, dZth, ws["dzt"], 0, ta, "tone_w", "tone_b"))
             jobs = (_lib.EsrWgradJob * len(todo))()
@@ -639,6 +650,8 @@ class FineEngine:
         self._run("composite_bwd", L.esr_fine_composite_bwd, _lib.ptr(g_srgb), _lib.ptr(g_lin), _lib.ptr(ws["rgb"]),
                   _lib.ptr(ws["lin"]), _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), ta, _lib.ptr(ws["dweight"]),
                   _lib.ptr(ws["dzt"]), s)
+        if tone_early:
+            on(self._side_stream(0), mark(), tone_wgrad)          # (the stream's later work -- wgrads -- is ordered behind it)
         e_scat = on(scat, mark(), march_bwd) if scat is not None else None
         if fold:
             march_bwd(s)
