@@ -88,6 +88,26 @@ __device__ __forceinline__ void put_pair(f16x8 &dst, float a, float b)
     dst[I0 + 1] = pinned[1];
 }
 
+// second plane of a value pair: fp16(v - x1) with x1 read from the packed first-plane dword -- v_fma_mix_f32 takes the fp16
+// half directly (one instruction per value instead of a conversion and a subtraction; the difference is exact either way).
+// Operands are VALU results (phase 1's conversion, phase 0's values): nothing here reads an MFMA result.
+template <int I0>
+__device__ __forceinline__ void put_residual_pair(f16x8 &dst, const f16x8 &first, float v0, float v1)
+{
+    const unsigned u = __builtin_bit_cast(u32x4, first)[I0 >> 1];
+    unsigned r;
+    float d0, d1;
+    // ONE asm statement: between two statements the compiler puts an `s_nop 0` when the second reads the first's result
+    // (VALU -> VALU needs none on this hardware); volatile = the pin of put_pair
+    asm volatile("v_fma_mix_f32 %1, %3, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+                 "v_fma_mix_f32 %2, %3, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                 "v_cvt_pk_f16_f32 %0, %1, %2"
+                 : "=v"(r), "=&v"(d0), "=&v"(d1) : "v"(u), "v"(v0), "v"(v1));
+    const f16x2 pinned = __builtin_bit_cast(f16x2, r);
+    dst[I0] = pinned[0];
+    dst[I0 + 1] = pinned[1];
+}
+
 template <int KIND, bool BWD = false> struct SplitSteps {
     static constexpr SplitLayout L = BWD ? split_layout_t(KIND) : split_layout(KIND);
     static constexpr int BASE_CHUNK = BWD ? split_layout(KIND).total_chunks : 0;      // the transposed planes follow the forward ones
@@ -233,6 +253,11 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
         const bool live = tt < A.t1;                       // a wave past the range runs on the last tile, stores nothing
         const int t = live ? tt : A.t1 - 1;
         const bool save = A.save && live;
+        // the lane's tile offset, opaque per group: as a loop invariant `hvoff + row offset` was hoisted out of the group loop
+        // for all 16 rows (16 registers, spilled to accumulation registers, one v_accvgpr_read per store); inside the loop
+        // the constant folds into the store's immediate offset
+        int hv = hvoff;
+        asm volatile("" : "+v"(hv));
         // planes: first layer's input (from X) | set A | set B; layer 0 writes A, 1 reads A writes B, 2 reads B writes A, 3 reads A
         f16x8 xi1[KS1], xi2[KS1], pa1[2 * HT], pa2[2 * HT], pb1[2 * HT], pb2[2 * HT];
 #pragma unroll
@@ -280,22 +305,23 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
                 v1 = __int_as_float(b1 > 0 ? b1 : 0);
                 const rsrc_t RH = make_rsrc(AB.H[l] + (size_t)t * (HBYTES / 4), hrec);      // fp32 tile, mlp.hip's store_tiles order
 #ifndef ESR_SPLIT_NO_HSTORE
-                bstore1_nt(RH, v0, hvoff + tile_soff(0, r0), it * 4096);      // (row offset < 4096: the instruction's immediate)
-                bstore1_nt(RH, v1, hvoff + tile_soff(0, r0 + 1), it * 4096);
+                asm volatile("" : "+v"(hv));                       // (opaque per slice: a shared `hv + row offset` is kept in a
+                bstore1_nt(RH, v0, hv + tile_soff(0, r0), it * 4096);       //  register of its own instead of the store's immediate)
+                bstore1_nt(RH, v1, hv + tile_soff(0, r0 + 1), it * 4096);
 #endif
                 ev[r0] = v0; ev[r0 + 1] = v1;
             } else if constexpr (q == 1) {
                 const float v0 = ev[r0], v1 = ev[r0 + 1];
-                int one0, one1;                                    // (operands: phase 0's integer max -- VALU results, no MFMA hazard)
-                asm("v_med3_i32 %0, %1, 0, 1" : "=v"(one0) : "v"(__float_as_int(v0)));
-                asm("v_med3_i32 %0, %1, 0, 1" : "=v"(one1) : "v"(__float_as_int(v1)));
-                mword |= ((unsigned)one0 << ((it & 1) * 16 + r0)) | ((unsigned)one1 << ((it & 1) * 16 + r0 + 1));
-                asm volatile("" : "+v"(mword));
+                int one0, one1;                                    // (operands: phase 0's integer max -- VALU results, no MFMA hazard;
+                asm volatile("v_med3_i32 %1, %3, 0, 1\n\t"         //  one statement: see put_residual_pair)
+                             "v_med3_i32 %2, %4, 0, 1\n\t"
+                             "v_lshl_or_b32 %0, %1, %5, %0\n\t"
+                             "v_lshl_or_b32 %0, %2, %6, %0"
+                             : "+v"(mword), "=&v"(one0), "=&v"(one1)
+                             : "v"(__float_as_int(v0)), "v"(__float_as_int(v1)), "n"((it & 1) * 16 + r0), "n"((it & 1) * 16 + r0 + 1));
                 put_pair<i0>(o1[2 * it + jj], v0, v1);
             } else {
-                const float v0 = ev[r0], v1 = ev[r0 + 1];
-                const _Float16 h0 = o1[2 * it + jj][i0], h1 = o1[2 * it + jj][i0 + 1];
-                put_pair<i0>(o2[2 * it + jj], v0 - (float)h0, v1 - (float)h1);
+                put_residual_pair<i0>(o2[2 * it + jj], o1[2 * it + jj], ev[r0], ev[r0 + 1]);
             }
         };
         // micro-slices of the pending tile that ride on MFMA slot u (of NSLOT) of the tile in flight
@@ -499,6 +525,8 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_dgrad_split_kernel(DSplitBatc
         const int tt = A.t0 + tg * SPW + wv;
         const bool live = tt < A.t1;
         const int t = live ? tt : A.t1 - 1;
+        int hv = hvoff;                                                       // (opaque per group: see the forward)
+        asm volatile("" : "+v"(hv));
         // the tile's scale: 2^k with the largest |dz| of its 32 samples at ~16 (exponent arithmetic; an all-zero tile: 1)
         float zmax = fmaxf(fmaxf(fabsf(zn[0]), fabsf(zn[1])), fabsf(zn[2]));
 #pragma unroll
@@ -538,25 +566,29 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_dgrad_split_kernel(DSplitBatc
                 if constexpr (ph == 0) {
                     const float v0 = accm[r0] * wisc, v1 = accm[r0 + 1] * wisc;
                     const rsrc_t RX = make_rsrc(AB.dX + (size_t)t * 64 * 32, live ? dx_rows(KIND) / 4 * 4 * 128 + (dx_rows(KIND) % 4 ? 512 : 0) : 0);
-                    bstore1(RX, v0, hvoff + tile_soff(0, r0), it * 4096);           // (default policy: the scatter reads dX next)
-                    bstore1(RX, v1, hvoff + tile_soff(0, r0 + 1), it * 4096);
+                    asm volatile("" : "+v"(hv));
+                    bstore1(RX, v0, hv + tile_soff(0, r0), it * 4096);           // (default policy: the scatter reads dX next)
+                    bstore1(RX, v1, hv + tile_soff(0, r0 + 1), it * 4096);
                 }
             } else {
                 constexpr int d = NHID - 1 - q;                              // this tile is a tile of dZ[d]
                 if constexpr (ph == 0) {
-                    const int k0 = ((int)(msk[d][it >> 1] << (31 - ((it & 1) * 16 + r0)))) >> 31;
-                    const int k1 = ((int)(msk[d][it >> 1] << (31 - ((it & 1) * 16 + r0 + 1)))) >> 31;
+                    // mask bit -> 0 / ~0 with one v_bfe_i32 (in C, a shift pair or the bfe builtin became and + compare + select
+                    // through vcc, with the wait states that go with vcc)
+                    // (the operand is the mask word, loaded from memory a tile group ago: no MFMA result near this asm)
+                    int k0, k1;
+                    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(k0) : "v"(msk[d][it >> 1]), "n"((it & 1) * 16 + r0));
+                    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(k1) : "v"(msk[d][it >> 1]), "n"((it & 1) * 16 + r0 + 1));
                     const int a0 = __float_as_int(accm[r0]) & k0, a1 = __float_as_int(accm[r0 + 1]) & k1;      // 64 x the masked value
                     const rsrc_t RD = make_rsrc(AB.dZ[d] + (size_t)t * (HBYTES / 4), (live && AB.dZ[d]) ? HBYTES : 0u);
-                    bstore1_nt(RD, __int_as_float(a0) * wisc, hvoff + tile_soff(0, r0), it * 4096);
-                    bstore1_nt(RD, __int_as_float(a1) * wisc, hvoff + tile_soff(0, r0 + 1), it * 4096);
+                    asm volatile("" : "+v"(hv));
+                    bstore1_nt(RD, __int_as_float(a0) * wisc, hv + tile_soff(0, r0), it * 4096);
+                    bstore1_nt(RD, __int_as_float(a1) * wisc, hv + tile_soff(0, r0 + 1), it * 4096);
                     ev[r0] = __int_as_float(a0) * SPLIT_W_INV; ev[r0 + 1] = __int_as_float(a1) * SPLIT_W_INV;
                 } else if constexpr (ph == 1) {
                     put_pair<i0>(o1[2 * it + jj], ev[r0], ev[r0 + 1]);
                 } else {
-                    const float v0 = ev[r0], v1 = ev[r0 + 1];
-                    const _Float16 h0 = o1[2 * it + jj][i0], h1 = o1[2 * it + jj][i0 + 1];
-                    put_pair<i0>(o2[2 * it + jj], v0 - (float)h0, v1 - (float)h1);
+                    put_residual_pair<i0>(o2[2 * it + jj], o1[2 * it + jj], ev[r0], ev[r0 + 1]);
                 }
             }
         };
