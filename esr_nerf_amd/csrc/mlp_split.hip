@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
     constexpr PackLayout L32 = pack_layout(KIND);
     constexpr int NL = S::NL, NHID = NL - 1, HT = D.hid_tiles, KS1 = L.ks[0], NS = S::NS;
     constexpr unsigned HBYTES = HT * 32 * 32 * 4, MBYTES = (HT / 2) * 256;
-    static_assert(NHID == 3 && HT % 2 == 0, "written for the four-layer 192-wide radiance net");
+    static_assert((NL == 4 || NL == 2) && HT % 2 == 0, "the four-layer nets (radiance, BRDF, emission) and the tone mapper");
     // segment of this workgroup
     SplitSeg A = AB.seg[0];
 #pragma unroll
@@ -248,7 +248,10 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
     if ((int)blockIdx.x - blk0 < ngroups) fetch((int)blockIdx.x - blk0);
     const int hvoff = tile_voff(lane);
 
-    for (int tg = (int)blockIdx.x - blk0; tg < ngroups; tg += nblk) {
+    // LDS buffer of step st = (st + par) & 1: a net with an odd number of steps per group (the 128-wide nets: 7) starts every
+    // other group in buffer 1
+    for (int tg = (int)blockIdx.x - blk0, trip = 0; tg < ngroups; tg += nblk, ++trip) {
+        const int par = (NS & 1) ? (trip & 1) : 0;
         const int tt = A.t0 + tg * SPW + wv;
         const bool live = tt < A.t1;                       // a wave past the range runs on the last tile, stores nothing
         const int t = live ? tt : A.t1 - 1;
@@ -324,15 +327,20 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
                 put_residual_pair<i0>(o2[2 * it + jj], o1[2 * it + jj], ev[r0], ev[r0 + 1]);
             }
         };
-        // micro-slices of the pending tile that ride on MFMA slot u (of NSLOT) of the tile in flight
-        auto pending = [&](auto LC, auto IT, auto U, auto NSLOTC, f32x16 &accm, auto &o1, auto &o2) __attribute__((always_inline)) {
-            constexpr int u = decltype(U)::value, nslot = decltype(NSLOTC)::value;
-            if constexpr (u < 24) micro(LC, IT, std::integral_constant<int, u>{}, accm, o1, o2);
-            if constexpr (u + nslot < 24) micro(LC, IT, std::integral_constant<int, u + nslot>{}, accm, o1, o2);
-            static_assert(2 * nslot >= 24, "every micro-slice finds a slot");
+        // micro-slices of the pending tile that ride on MFMA slot u of the tile in flight: slice i on slot i % NAVAIL, where
+        // NAVAIL = the slots before the tile in flight first READS the pending tile's planes (all of them for a tile of
+        // the same layer; all but the last two k-steps when the pending tile is the previous layer's last tile)
+        auto pending = [&](auto LC, auto IT, auto U, auto NAVAILC, f32x16 &accm, auto &o1, auto &o2) __attribute__((always_inline)) {
+            constexpr int u = decltype(U)::value, navail = decltype(NAVAILC)::value;
+            static_assert(navail >= 3 && navail % 3 == 0, "whole register pairs per pass");
+            if constexpr (u < navail)
+                sfor<0, (24 + navail - 1) / navail>([&](auto KC) {
+                    constexpr int msi = u + decltype(KC)::value * navail;
+                    if constexpr (msi < 24) micro(LC, IT, std::integral_constant<int, msi>{}, accm, o1, o2);
+                });
             // behind the LAST micro-slice of an odd tile: the mask word of the tile pair (mlp_common.h: store_relu_mask's order)
             constexpr int l = decltype(LC)::value, it = decltype(IT)::value;
-            if constexpr (u == (nslot < 24 ? nslot : 24) - 1 && (it & 1)) {
+            if constexpr (u == (navail < 24 ? navail : 24) - 1 && (it & 1)) {
                 __builtin_amdgcn_raw_buffer_store_b32(mword, make_rsrc(AB.M[l] + (size_t)t * (MBYTES / 4), mrec), lane * 4,
                                                       (it >> 1) * 256, 0);
                 mword = 0;
@@ -348,7 +356,7 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
             f32x16 zm;                                             // (output layer: its single tile's sums)
             sfor<0, NP>([&](auto PC) {
                 constexpr int p = decltype(PC)::value, st = s0 + p, tin = S::tiles_in(st), nxt_st = (st + 1) % NS;
-                const unsigned char *wsrc = wl + (st & 1) * S::BUF;
+                const unsigned char *wsrc = wl + ((st + par) & 1) * S::BUF;
                 const u32x4 *mine = reinterpret_cast<const u32x4 *>(wsrc) + lane;
                 stage_load(std::integral_constant<int, nxt_st>{});
                 // flat k-step index n = tt_ * KS + j; chunk of (tile tt_, plane q, k-step j) = (tt_ * 2 + q) * KS + j
@@ -387,13 +395,13 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
                             if constexpr (it > 0) pending(std::integral_constant<int, pl>{}, std::integral_constant<int, pit>{}, U,
                                                           std::integral_constant<int, 3 * KS>{}, am[pit & 1], o1, o2);
                             else pending(std::integral_constant<int, pl>{}, std::integral_constant<int, pit>{}, U,
-                                         std::integral_constant<int, 3 * KS>{}, am[pit & 1], in1, in2);
+                                         std::integral_constant<int, 3 * (KS - 2)>{}, am[pit & 1], in1, in2);
                         }
                         if constexpr (tt_ == tin - 1) {            // the next step's weights: one piece per slot, last slots of the step
                             constexpr int u_ = decltype(U)::value, first = 3 * KS - S::PRE;
                             static_assert(first >= 0, "a tile has a slot for every staged piece");
                             if constexpr (u_ >= first) stage_piece(std::integral_constant<int, nxt_st>{}, std::integral_constant<int, u_ - first>{},
-                                                                   wl + ((st + 1) & 1) * S::BUF);
+                                                                   wl + ((st + 1 + par) & 1) * S::BUF);
                         }
                         __builtin_amdgcn_sched_barrier(0);         // one MFMA + its micro-slice per scheduling region
                     };
@@ -418,11 +426,12 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
                     const float4 bz = *reinterpret_cast<const float4 *>(bias_l + l * S::BIAS_FLOATS + (lane >> 5) * 16);
                     const float bzv[4] = {bz.x, bz.y, bz.z, bz.w};
                     const rsrc_t RZ = make_rsrc(A.zout + (size_t)t * D.zrows * 32, live ? D.zrows * 32 * 4 : 0);
-                    // rows 0..3 of the output tile live in registers 0..3 of lane half 0 (acc_row(r, 0) = r); half 1's lanes
-                    // are pointed past the 4-row tile's range, which the descriptor drops
-                    const int zvoff = ((h ? D.zrows : 0) * 32 + s_) * 4;
+                    // rows 4 h + q of the output tile live in registers q = 0..3 of lane half h (acc_row(q, h)); the rows past
+                    // out_dim are written as zeros, the rows past the tile (half 1 of a 4-row tile) are dropped by the descriptor
+                    const int zvoff = (4 * h * 32 + s_) * 4;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) bstore1(RZ, q < 3 ? fmaf(zm[q], SPLIT_W_INV, bzv[q]) : 0.f, zvoff, q * 128);
+                    for (int q = 0; q < 4; ++q)
+                        bstore1(RZ, 4 * h + q < D.out_dim ? fmaf(zm[q], SPLIT_W_INV, bzv[q]) : 0.f, zvoff, q * 128);
                 }
                 ESR_SPLIT_STAMP(1 + 3 * st);
                 ESR_SPLIT_STAMP(2 + 3 * st);
@@ -431,10 +440,11 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
             });
         };
         run_layer(std::integral_constant<int, 0>{}, xi1, xi2, pa1, pa2);
-        run_layer(std::integral_constant<int, 1>{}, pa1, pa2, pb1, pb2);
-        run_layer(std::integral_constant<int, 2>{}, pb1, pb2, pa1, pa2);
-        run_layer(std::integral_constant<int, 3>{}, pa1, pa2, pb1, pb2);      // output layer (pb: unused)
-        static_assert(NS % 2 == 0, "an even number of steps per group: step 0 of every group sits in LDS buffer 0");
+        if constexpr (NL == 4) {
+            run_layer(std::integral_constant<int, 1>{}, pa1, pa2, pb1, pb2);
+            run_layer(std::integral_constant<int, 2>{}, pb1, pb2, pa1, pa2);
+        }
+        run_layer(std::integral_constant<int, NL - 1>{}, pa1, pa2, pb1, pb2);      // output layer (pb: unused)
     }
 }
 
@@ -470,7 +480,8 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_dgrad_split_kernel(DSplitBatc
     constexpr SplitLayout L = S::L;
     constexpr int NL = S::NL, NHID = NL - 1, HT = D.hid_tiles, NS = S::NS;
     constexpr unsigned HBYTES = HT * 32 * 32 * 4, MBYTES = (HT / 2) * 256;
-    static_assert(NHID == 3 && HT % 2 == 0 && L.ks[0] == 1 && L.tiles_out[NL - 1] == 2, "written for the radiance net");
+    static_assert((NL == 4 || NL == 2) && HT % 2 == 0 && L.ks[0] == 1 && L.tiles_out[NL - 1] == 2 && D.out_dim <= 8 && D.zrows <= 8,
+                  "the four-layer nets and the tone mapper: outputs in one k-step, grid-fed input rows in two tiles");
     DSplitSeg A = AB.seg[0];
     if (AB.nseg > 1 && (int)blockIdx.x >= AB.seg[1].b0) A = AB.seg[1];
     const int blk0 = A.b0, nblk = A.nb;
@@ -506,14 +517,14 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_dgrad_split_kernel(DSplitBatc
 
     // the group's output gradients (rows 0..3 of the 4-row tile: half 0's slots 0..3, everything else of the k-step is zero)
     // and ReLU masks
-    float zn[4];
+    float zn[D.zrows];
     unsigned mn[NHID][HT / 2];
     auto fetch = [&](int tg) {
         const int tt = A.t0 + tg * SPW + wv;
         const int t = tt < A.t1 ? tt : A.t1 - 1;
         const rsrc_t RZ = make_rsrc(AB.dz + (size_t)t * D.zrows * 32, D.zrows * 32 * 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) zn[i] = bload1(RZ, s_ * 4, i * 128);
+        for (int i = 0; i < D.zrows; ++i) zn[i] = bload1(RZ, s_ * 4, i * 128);
 #pragma unroll
         for (int l = 0; l < NHID; ++l)
             load_relu_mask<HT>(make_rsrc(AB.M[l] + (size_t)t * (MBYTES / 4), MBYTES), mn[l], lane);
@@ -521,14 +532,19 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_dgrad_split_kernel(DSplitBatc
     if ((int)blockIdx.x - blk0 < ngroups) fetch((int)blockIdx.x - blk0);
     const int hvoff = tile_voff(lane);
 
-    for (int tg = (int)blockIdx.x - blk0; tg < ngroups; tg += nblk) {
+    // LDS buffer of step st = (st + par) & 1: a net with an odd number of steps per group (the 128-wide nets: 7) starts every
+    // other group in buffer 1
+    for (int tg = (int)blockIdx.x - blk0, trip = 0; tg < ngroups; tg += nblk, ++trip) {
+        const int par = (NS & 1) ? (trip & 1) : 0;
         const int tt = A.t0 + tg * SPW + wv;
         const bool live = tt < A.t1;
         const int t = live ? tt : A.t1 - 1;
         int hv = hvoff;                                                       // (opaque per group: see the forward)
         asm volatile("" : "+v"(hv));
         // the tile's scale: 2^k with the largest |dz| of its 32 samples at ~16 (exponent arithmetic; an all-zero tile: 1)
-        float zmax = fmaxf(fmaxf(fabsf(zn[0]), fabsf(zn[1])), fabsf(zn[2]));
+        float zmax = 0.f;
+#pragma unroll
+        for (int i = 0; i < D.out_dim; ++i) zmax = fmaxf(zmax, fabsf(zn[i]));
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, o));
         if (AB.amax && live && lane == 0)                                     // (non-negative floats order like their bit patterns)
@@ -541,7 +557,7 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_dgrad_split_kernel(DSplitBatc
         {
             float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = (h == 0 && i < 3) ? zn[i] * sc : 0.f;
+            for (int i = 0; i < 8; ++i) v[i] = (h == 0 && i < D.out_dim) ? zn[i < D.out_dim ? i : 0] * sc : 0.f;
             split8(v, xi1[0], xi2[0]);
         }
         unsigned msk[NHID][HT / 2];
@@ -592,20 +608,23 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_dgrad_split_kernel(DSplitBatc
                 }
             }
         };
-        // the pending tile's micro-slices u, u + nslot, u + 2 nslot, ... ride on MFMA slot u of the tile in flight
-        auto pending = [&](auto QC, auto IT, auto U, auto NSLOTC, f32x16 &accm, auto &o1, auto &o2) __attribute__((always_inline)) {
-            constexpr int u = decltype(U)::value, nslot = decltype(NSLOTC)::value;
-            sfor<0, (24 + nslot - 1) / nslot>([&](auto KC) {
-                constexpr int msi = u + decltype(KC)::value * nslot;
-                if constexpr (msi < 24) micro(QC, IT, std::integral_constant<int, msi>{}, accm, o1, o2);
-            });
+        // the pending tile's micro-slices u, u + navail, u + 2 navail, ... ride on MFMA slot u of the tile in flight (navail: as
+        // in the forward)
+        auto pending = [&](auto QC, auto IT, auto U, auto NAVAILC, f32x16 &accm, auto &o1, auto &o2) __attribute__((always_inline)) {
+            constexpr int u = decltype(U)::value, navail = decltype(NAVAILC)::value;
+            static_assert(navail >= 3 && navail % 3 == 0, "whole register pairs per pass");
+            if constexpr (u < navail)
+                sfor<0, (24 + navail - 1) / navail>([&](auto KC) {
+                    constexpr int msi = u + decltype(KC)::value * navail;
+                    if constexpr (msi < 24) micro(QC, IT, std::integral_constant<int, msi>{}, accm, o1, o2);
+                });
         };
         auto run_layer = [&](auto QC, auto &in1, auto &in2, auto &o1, auto &o2) __attribute__((always_inline)) {
             constexpr int q = decltype(QC)::value, KS = L.ks[q], NT = L.tiles_out[q], NP = L.pairs[q];
             constexpr int s0 = [] { int s = 0; for (int k = 0; k < q; ++k) s += L.pairs[k]; return s; }();
             sfor<0, NP>([&](auto PC) {
                 constexpr int p = decltype(PC)::value, st = s0 + p, tin = S::tiles_in(st), nxt_st = (st + 1) % NS;
-                const unsigned char *wsrc = wl + (st & 1) * S::BUF;
+                const unsigned char *wsrc = wl + ((st + par) & 1) * S::BUF;
                 const u32x4 *mine = reinterpret_cast<const u32x4 *>(wsrc) + lane;
                 stage_load(std::integral_constant<int, nxt_st>{});
                 constexpr int NTOT = tin * KS;
@@ -633,12 +652,12 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_dgrad_split_kernel(DSplitBatc
                             if constexpr (it > 0) pending(std::integral_constant<int, pq>{}, std::integral_constant<int, pit>{}, U,
                                                           std::integral_constant<int, 3 * KS>{}, am[pit & 1], o1, o2);
                             else pending(std::integral_constant<int, pq>{}, std::integral_constant<int, pit>{}, U,
-                                         std::integral_constant<int, 3 * KS>{}, am[pit & 1], in1, in2);
+                                         std::integral_constant<int, 3 * (KS - 2)>{}, am[pit & 1], in1, in2);
                         }
                         if constexpr (tt_ == tin - 1 && 3 * KS >= S::PRE) {
                             constexpr int u_ = decltype(U)::value, first = 3 * KS - S::PRE;
                             if constexpr (u_ >= first) stage_piece(std::integral_constant<int, nxt_st>{}, std::integral_constant<int, u_ - first>{},
-                                                                   wl + ((st + 1) & 1) * S::BUF);
+                                                                   wl + ((st + 1 + par) & 1) * S::BUF);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     };
@@ -655,15 +674,16 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_dgrad_split_kernel(DSplitBatc
                     });
                 }
                 if constexpr (3 * KS < S::PRE)                     // (the one-k-step first layer: too few slots, all pieces here)
-                    stage_store(std::integral_constant<int, nxt_st>{}, wl + ((st + 1) & 1) * S::BUF);
+                    stage_store(std::integral_constant<int, nxt_st>{}, wl + ((st + 1 + par) & 1) * S::BUF);
                 step_barrier();
             });
         };
-        run_layer(std::integral_constant<int, 0>{}, xi1, xi2, pa1, pa2);      // W3ᵀ dz -> dZ[2]
-        run_layer(std::integral_constant<int, 1>{}, pa1, pa2, pb1, pb2);      // -> dZ[1]
-        run_layer(std::integral_constant<int, 2>{}, pb1, pb2, pa1, pa2);      // -> dZ[0]
-        run_layer(std::integral_constant<int, 3>{}, pa1, pa2, pb1, pb2);      // -> dX (pb unused)
-        static_assert(NS % 2 == 0, "an even number of steps per group: step 0 of every group sits in LDS buffer 0");
+        run_layer(std::integral_constant<int, 0>{}, xi1, xi2, pa1, pa2);      // W3ᵀ dz -> dZ[2]   (tone mapper: W1ᵀ dz -> dZ[0])
+        if constexpr (NL == 4) {
+            run_layer(std::integral_constant<int, 1>{}, pa1, pa2, pb1, pb2);  // -> dZ[1]
+            run_layer(std::integral_constant<int, 2>{}, pb1, pb2, pa1, pa2);  // -> dZ[0]
+        }
+        run_layer(std::integral_constant<int, NL - 1>{}, pa1, pa2, pb1, pb2);      // -> dX (pb unused)
     }
 }
 
@@ -704,42 +724,57 @@ int share_blocks_split(SplitSeg *seg, int nseg)
     return b0;
 }
 
-int launch_split(SplitBatch &B, hipStream_t s)
+template <int KIND>
+int launch_split_k(SplitBatch &B, hipStream_t s)
 {
-    using S = SplitSteps<ESR_MLP_RADIANCE>;
+    using S = SplitSteps<KIND>;
     const int grid = share_blocks_split(B.seg, B.nseg);
     static std::atomic<uint64_t> optin{0};
-    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_fwd_split_kernel<ESR_MLP_RADIANCE>), S::LDS_BYTES, optin)) return rc;
-    mlp_fwd_split_kernel<ESR_MLP_RADIANCE><<<grid, 64 * SPW, S::LDS_BYTES, s>>>(B);
+    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_fwd_split_kernel<KIND>), S::LDS_BYTES, optin)) return rc;
+    mlp_fwd_split_kernel<KIND><<<grid, 64 * SPW, S::LDS_BYTES, s>>>(B);
     ESR_CHECK_LAUNCH();
     return 0;
 }
+int launch_split(int kind, SplitBatch &B, hipStream_t s)
+{
+    switch (kind) {
+    case ESR_MLP_RADIANCE: return launch_split_k<ESR_MLP_RADIANCE>(B, s);
+    case ESR_MLP_TONEMAP:  return launch_split_k<ESR_MLP_TONEMAP>(B, s);
+    case ESR_MLP_BRDF:     return launch_split_k<ESR_MLP_BRDF>(B, s);
+    case ESR_MLP_EMIT:     return launch_split_k<ESR_MLP_EMIT>(B, s);
+    default:               return ESR_EINVAL;
+    }
+}
+bool split_kind_ok(int kind)
+{
+    return kind == ESR_MLP_RADIANCE || kind == ESR_MLP_TONEMAP || kind == ESR_MLP_BRDF || kind == ESR_MLP_EMIT;
+}
 
-bool crow_ok_split(int crow) { return crow == 0 || crow == 88 || crow == 96; }
+bool crow_ok_split(int kind, int crow) { return crow == 0 || (kind != ESR_MLP_TONEMAP && (crow == 88 || crow == 96)); }
 
 }  // namespace
 
 // One radiance forward pass over tiles [t0, t1) (esr_mlp_fwd's contract: save 0 / 1 / 2, colour group color_row0), products
 // on the 16-bit matrix cores from split fp16 planes.  packed32: esr_mlp_pack's buffer (biases); planes: the net's split
-// planes (esr_mlp_pack_batch, esr_mlp_packed_split_elems values).  ESR_MLP_RADIANCE only.
+// planes (esr_mlp_pack_batch, esr_mlp_packed_split_elems values).  Radiance, tone mapper, BRDF and emission nets.
 ESR_API int esr_mlp_fwd_split(int kind, const float *packed32, const void *planes, const float *X, int32_t t0, int32_t t1,
                               float *const *H, uint32_t *const *M, int save, int color_row0, float *zout, void *stream)
 {
-    if (kind != ESR_MLP_RADIANCE || t0 < 0 || t1 < t0 || !crow_ok_split(color_row0)) return ESR_EINVAL;
+    if (!split_kind_ok(kind) || t0 < 0 || t1 < t0 || !crow_ok_split(kind, color_row0)) return ESR_EINVAL;
     if (t1 == t0) return 0;
     if (!packed32 || !planes || !X || !zout) return ESR_EINVAL;
     SplitBatch B = {};
     B.X = X;
     if (save) {
         if (!M || (save != 2 && !H)) return ESR_EINVAL;
-        for (int l = 0; l < 3; ++l) {
+        for (int l = 0; l < net_desc(kind).n_layers - 1; ++l) {
             if (!M[l] || (save != 2 && !H[l])) return ESR_EINVAL;
             B.H[l] = save != 2 ? H[l] : nullptr; B.M[l] = M[l];
         }
     }
     B.nseg = 1;
     B.seg[0] = SplitSeg{packed32, static_cast<const _Float16 *>(planes), t0, t1, save == 2 ? 2 : save ? 1 : 0, color_row0, zout, 0, 0};
-    return launch_split(B, esr_stream(stream));
+    return launch_split(kind, B, esr_stream(stream));
 }
 
 // The fine stage's three radiance forward passes of a step as ONE launch (esr_mlp_fwd_fine's contract and argument meaning).
@@ -747,7 +782,7 @@ ESR_API int esr_mlp_fwd_fine_split(const float *packed32_off, const void *planes
                                    const void *planes_emo, const float *X, int32_t t_on, int32_t t_all, float *const *H,
                                    uint32_t *const *M, int color_row_detached, float *z_off, float *z_emo, void *stream)
 {
-    if (t_on < 0 || t_all < t_on || !crow_ok_split(color_row_detached)) return ESR_EINVAL;
+    if (t_on < 0 || t_all < t_on || !crow_ok_split(ESR_MLP_RADIANCE, color_row_detached)) return ESR_EINVAL;
     if (t_all == 0) return 0;
     if (!packed32_off || !planes_off || !packed32_emo || !planes_emo || !X || !H || !M || !z_off || !z_emo) return ESR_EINVAL;
     SplitBatch B = {};
@@ -762,13 +797,14 @@ ESR_API int esr_mlp_fwd_fine_split(const float *packed32_off, const void *planes
     if (t_all > t_on) B.seg[n++] = SplitSeg{packed32_off, po, t_on, t_all, 1, 0, z_off, 0, 0};
     if (t_on > 0) B.seg[n++] = SplitSeg{packed32_emo, pe, 0, t_on, 1, 0, z_emo, 0, 0};
     B.nseg = n;
-    return launch_split(B, esr_stream(stream));
+    return launch_split(ESR_MLP_RADIANCE, B, esr_stream(stream));
 }
 
 namespace {
-int launch_dsplit(DSplitBatch &B, hipStream_t s)
+template <int KIND>
+int launch_dsplit_k(DSplitBatch &B, hipStream_t s)
 {
-    using S = SplitSteps<ESR_MLP_RADIANCE, true>;
+    using S = SplitSteps<KIND, true>;
     int groups[2], total = 0;
     for (int k = 0; k < B.nseg; ++k) { groups[k] = (B.seg[k].t1 - B.seg[k].t0 + SPW - 1) / SPW; total += groups[k]; }
     const int grid = total < 256 ? total : 256;
@@ -782,29 +818,39 @@ int launch_dsplit(DSplitBatch &B, hipStream_t s)
         B.seg[0].b0 = 0; B.seg[0].nb = n0; B.seg[1].b0 = n0; B.seg[1].nb = grid - n0;
     }
     static std::atomic<uint64_t> optin{0};
-    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_dgrad_split_kernel<ESR_MLP_RADIANCE>), 2 * S::BUF, optin)) return rc;
-    mlp_dgrad_split_kernel<ESR_MLP_RADIANCE><<<grid, 64 * SPW, 2 * S::BUF, s>>>(B);
+    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_dgrad_split_kernel<KIND>), 2 * S::BUF, optin)) return rc;
+    mlp_dgrad_split_kernel<KIND><<<grid, 64 * SPW, 2 * S::BUF, s>>>(B);
     ESR_CHECK_LAUNCH();
     return 0;
 }
+int launch_dsplit(int kind, DSplitBatch &B, hipStream_t s)
+{
+    switch (kind) {
+    case ESR_MLP_RADIANCE: return launch_dsplit_k<ESR_MLP_RADIANCE>(B, s);
+    case ESR_MLP_TONEMAP:  return launch_dsplit_k<ESR_MLP_TONEMAP>(B, s);
+    case ESR_MLP_BRDF:     return launch_dsplit_k<ESR_MLP_BRDF>(B, s);
+    case ESR_MLP_EMIT:     return launch_dsplit_k<ESR_MLP_EMIT>(B, s);
+    default:               return ESR_EINVAL;
+    }
+}
 }  // namespace
 
-// esr_mlp_dgrad's contract (ESR_MLP_RADIANCE only): input / hidden gradients over tiles [t0, t1) from the net's split planes.
+// esr_mlp_dgrad's contract (radiance, tone mapper, BRDF and emission nets): input / hidden gradients over tiles [t0, t1) from the net's split planes.
 ESR_API int esr_mlp_dgrad_split(int kind, const void *planes, const float *dz, int32_t t0, int32_t t1, const uint32_t *const *M,
                                 float *const *dZ, float *dX, float *amax, void *stream)
 {
-    if (kind != ESR_MLP_RADIANCE || t0 < 0 || t1 < t0) return ESR_EINVAL;
+    if (!split_kind_ok(kind) || t0 < 0 || t1 < t0) return ESR_EINVAL;
     if (t1 == t0) return 0;
     if (!planes || !dz || !M || !dZ || !dX) return ESR_EINVAL;
     DSplitBatch B = {};
     B.dz = dz; B.dX = dX; B.amax = amax;
-    for (int l = 0; l < 3; ++l) {
+    for (int l = 0; l < net_desc(kind).n_layers - 1; ++l) {
         if (!M[l]) return ESR_EINVAL;
         B.M[l] = M[l]; B.dZ[l] = dZ[l];                     // a NULL dZ[l] is computed but not stored
     }
     B.nseg = 1;
     B.seg[0] = DSplitSeg{static_cast<const _Float16 *>(planes), t0, t1, 0, 0};
-    return launch_dsplit(B, esr_stream(stream));
+    return launch_dsplit(kind, B, esr_stream(stream));
 }
 
 // esr_mlp_dgrad_fine's contract: the emissive net on tiles [0, t_on), the non-emissive net on [t_on, t_all), one launch.
@@ -824,5 +870,5 @@ ESR_API int esr_mlp_dgrad_fine_split(const void *planes_emo, const void *planes_
     if (t_on > 0) B.seg[n++] = DSplitSeg{static_cast<const _Float16 *>(planes_emo), 0, t_on, 0, 0};
     if (t_all > t_on) B.seg[n++] = DSplitSeg{static_cast<const _Float16 *>(planes_off), t_on, t_all, 0, 0};
     B.nseg = n;
-    return launch_dsplit(B, esr_stream(stream));
+    return launch_dsplit(ESR_MLP_RADIANCE, B, esr_stream(stream));
 }

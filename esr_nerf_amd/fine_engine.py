@@ -149,6 +149,12 @@ class FineEngine:
         self.packed_split: Dict[str, torch.Tensor] = {}
         # ... and the radiance input-gradient chain the same way (per-tile power-of-two scaling); ESR_SPLIT_BWD=0: f32 MFMA
         self.split_bwd = self.split_fwd and os.environ.get("ESR_SPLIT_BWD", "1") != "0"
+        # net kinds that run on the split kernels: radiance (0), BRDF (2), emission (3).  The tone mapper (1) is supported
+        # and tested but measured no faster (C2: forward 0.097 -> 0.093 ms, input gradients 0.087 -> 0.096 ms: two-layer
+        # kernels of < 0.1 ms are launch- and fill-bound), so it stays on the f32 MFMA kernels; BRDF + emission: C4 lts
+        # 4.54 -> 4.25 ms.  ESR_SPLIT_KINDS overrides ("0" = the radiance nets only).
+        self.split_kinds = {int(k) for k in os.environ.get("ESR_SPLIT_KINDS", "0,2,3").split(",") if k.strip() != ""}
+        self._psplit = {}
         # ... and the weight gradients of the 192-wide nets (csrc/mlp.hip: wgrad_dma_body<..., SPLIT>); their gradient
         # operand's scale comes from max |dz|, which the split input-gradient kernel leaves behind (else esr_absmax)
         self.split_wgrad = self.split_bwd and os.environ.get("ESR_SPLIT_WGRAD", "1") != "0"
@@ -253,16 +259,17 @@ class FineEngine:
                     self.packed16[which] = torch.empty(n16, dtype=torch.bfloat16, device=self.device)
                 p16 = _lib.ptr(self.packed16[which])
                 self._p16[self.packed[which].data_ptr()] = p16
-            if self.split_fwd and kind == KIND_RADIANCE:        # split fp16 planes of the forward weights (mlp_split.hip)
+            if self.split_fwd and kind in self.split_kinds:     # split fp16 planes of the weights (mlp_split.hip)
                 ns = self.L.esr_mlp_packed_split_elems(kind)
                 if which not in self.packed_split or self.packed_split[which].numel() != ns:
                     self.packed_split[which] = torch.empty(ns, dtype=torch.float16, device=self.device)
+                self._psplit[self.packed[which].data_ptr()] = _lib.ptr(self.packed_split[which])
             hit = self._pack_cache[which] = (key, kind, w, C.byref(w), p32, p16, self.packed[which].data_ptr())
         _, _, w, wref, p32, p16, _ = hit
         if self._pack_pending is not None:
             self._pack_pending.append((which, kind, w, p32, p16))
             return
-        if self.split_fwd and kind == KIND_RADIANCE:            # (outside a packing() group: the batch entry with one job)
+        if self.split_fwd and kind in self.split_kinds:         # (outside a packing() group: the batch entry with one job)
             return self._pack_flush([(which, kind, w, p32, p16)])
         s = self._s()
         self._run(f"mlp_pack({which})", self.L.esr_mlp_pack, kind, wref, p32, s)
@@ -285,7 +292,7 @@ class FineEngine:
         return _Group()
 
     def _pack_flush(self, jobs):
-        split = [(self.packed_split[which].data_ptr() if (self.split_fwd and kind == KIND_RADIANCE) else 0)
+        split = [(self.packed_split[which].data_ptr() if (self.split_fwd and kind in self.split_kinds) else 0)
                  for which, kind, _, _, _ in jobs]
         sig = tuple((which, kind, C.addressof(w), p32.value, p16.value if p16 is not None else 0, sp)
                     for (which, kind, w, p32, p16), sp in zip(jobs, split))
@@ -302,13 +309,21 @@ class FineEngine:
         self._run("mlp_pack(all)", self.L.esr_mlp_pack_batch, n, kinds, ws, p32s, p16s, psp, self._s())
 
     # the three MLP entry points with the fp32 signatures; in bf16 mode the packed fp32 pointer selects its bf16 twin
+    # f32 engine: a net whose split planes were packed (self._psplit: packed fp32 pointer -> planes) runs on the 16-bit matrix
+    # cores with fp32 results (csrc/mlp_split.hip), any other on the f32 MFMA kernels
     def mlp_fwd(self, kind, packed, *rest):
         if not self.bf16:
+            planes = self._psplit.get(packed.value) if self.split_fwd else None
+            if planes is not None:
+                return self.L.esr_mlp_fwd_split(kind, packed, planes, *rest)
             return self.L.esr_mlp_fwd(kind, packed, *rest)
         return self.L.esr_mlp_fwd_bf16(kind, packed, self._p16[packed.value], *rest)
 
     def mlp_dgrad(self, kind, packed, *rest):
         if not self.bf16:
+            planes = self._psplit.get(packed.value) if (self.split_fwd and self.split_bwd) else None
+            if planes is not None:                      # (..., dX, stream) -> (..., dX, amax = NULL, stream)
+                return self.L.esr_mlp_dgrad_split(kind, planes, *rest[:-1], None, rest[-1])
             return self.L.esr_mlp_dgrad(kind, packed, *rest)
         return self.L.esr_mlp_dgrad_bf16(kind, self._p16[packed.value], *rest)
 
@@ -640,7 +655,10 @@ class FineEngine:
             if self.bf16:
                 self._run(name, self.mlp_dgrad, kind, _lib.ptr(packed), _lib.ptr(dz), t0, t1, Ms, dZs, _lib.ptr(dX), s)
             else:
-                self._run(name, L.esr_mlp_dgrad_wg, kind, _lib.ptr(packed), _lib.ptr(dz), t0, t1, Ms, dZs, _lib.ptr(dX), cap, s)
+                if cap == 0:                    # (no workgroup cap: the dispatcher, i.e. the split kernel where planes exist)
+                    self._run(name, self.mlp_dgrad, kind, _lib.ptr(packed), _lib.ptr(dz), t0, t1, Ms, dZs, _lib.ptr(dX), s)
+                else:
+                    self._run(name, L.esr_mlp_dgrad_wg, kind, _lib.ptr(packed), _lib.ptr(dz), t0, t1, Ms, dZs, _lib.ptr(dX), cap, s)
 
         if ta == 0:
             march_bwd(s)

@@ -316,14 +316,15 @@ int esr_mlp_pack(int kind, const esr_mlp_weights_t *w, float *packed, void *stre
 int esr_mlp_pack_batch(int n, const int32_t *kinds, const esr_mlp_weights_t *const *w, float *const *packed32,
                        void *const *packed16, void *const *packed_split, void *stream);
 /*
- * Round 4: the f32 engine's radiance FORWARD on the 16-bit matrix cores with fp32 results (csrc/mlp_split.hip): every operand
- * as two fp16 planes x = x1 + x2 / 2048, a product as w1.x1 + (w1.x2 + w2.x1) / 2048 on v_mfma_f32_32x32x16_f16 with fp32
- * accumulation -- fp32-level accuracy (4e-7 .. 8e-7 of a layer's largest value against double precision, torch's own fp32
- * chain: 5e-7) at 16/3 of the f32 matrix rate.  packed_split[i] of esr_mlp_pack_batch (or NULL) receives the net's forward
- * weights as split planes, esr_mlp_packed_split_elems(kind) fp16 values.  esr_mlp_fwd_split / esr_mlp_fwd_fine_split keep the
- * contracts of esr_mlp_fwd / esr_mlp_fwd_fine (inputs X, saved tiles H and masks M, outputs z are the f32 engine's, so the
- * f32 input-gradient and weight-gradient entries follow unchanged); ESR_MLP_RADIANCE only.  The reference evaluates these
- * layers with fp32 nn.Linear (app/utils/pbr/module.py:6-21).
+ * Round 4: the f32 engine's MLP FORWARD on the 16-bit matrix cores with fp32 results (csrc/mlp_split.hip): every operand as
+ * two fp16 planes x = x1 + x2 (x1 = fp16(x), x2 = fp16(x - x1); the weights' planes hold 64 w), a product as
+ * w1.x1 + w1.x2 + w2.x1 on v_mfma_f32_32x32x16_f16 into one fp32 accumulator -- fp32-level accuracy (2e-7 .. 6e-7 of a layer's
+ * largest value against double precision, as the f32 MFMA kernels) at 16/3 of the f32 matrix rate.  packed_split[i] of
+ * esr_mlp_pack_batch (or NULL) receives the net's forward and transposed weights as split planes,
+ * esr_mlp_packed_split_elems(kind) fp16 values.  esr_mlp_fwd_split / esr_mlp_fwd_fine_split keep the contracts of
+ * esr_mlp_fwd / esr_mlp_fwd_fine (inputs X, saved tiles H and masks M, outputs z are the f32 engine's, so the f32
+ * input-gradient and weight-gradient entries follow unchanged).  Kinds: ESR_MLP_RADIANCE, _TONEMAP, _BRDF, _EMIT (the coarse
+ * net: ESR_EINVAL).  The reference evaluates these layers with fp32 nn.Linear (app/utils/pbr/module.py:6-83).
  */
 int64_t esr_mlp_packed_split_elems(int kind);
 int esr_mlp_fwd_split(int kind, const float *packed32, const void *planes, const float *X, int32_t t0, int32_t t1,
@@ -331,7 +332,7 @@ int esr_mlp_fwd_split(int kind, const float *packed32, const void *planes, const
 int esr_mlp_fwd_fine_split(const float *packed32_off, const void *planes_off, const float *packed32_emo,
                            const void *planes_emo, const float *X, int32_t t_on, int32_t t_all, float *const *H,
                            uint32_t *const *M, int color_row_detached, float *z_off, float *z_emo, void *stream);
-/* The input-gradient chain the same way (contracts of esr_mlp_dgrad / esr_mlp_dgrad_fine; ESR_MLP_RADIANCE only): the split
+/* The input-gradient chain the same way (contracts of esr_mlp_dgrad / esr_mlp_dgrad_fine; the same four kinds): the split
  * buffer also holds the TRANSPOSED weights' planes.  Gradients are far below fp16's normal range, so each 32-sample tile's
  * chain runs scaled by a power of two chosen from its largest |dz| (exact), and dZ / dX are written unscaled in fp32. */
 /* amax (optional, device, one float, >= 0 on entry -- normally zero): raised to the largest |dz| of the launch's tiles with an

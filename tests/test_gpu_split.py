@@ -331,3 +331,115 @@ def test_split_wgrad_vs_double_precision_and_vs_the_f32_kernel(tiles, t0, crow, 
         assert es < 2e-6 and es < 4 * ef + 1e-7, (l, es, ef)
         sb = float(want_b[l].abs().max()) + 1e-300
         assert float((bs[l] - want_b[l]).abs().max()) / sb < 1e-5
+
+
+@pytest.mark.parametrize("kind,tiles,crow,save", [(1, 1, 0, 2), (1, 37, 0, 1), (1, 700, 0, 2), (2, 1, 0, 1), (2, 41, 88, 1), (2, 600, 96, 1),
+                                                  (3, 5, 0, 1), (3, 333, 88, 0), (0, 9, 0, 1)])
+def test_split_kernels_for_every_net_vs_double_precision_and_vs_the_f32_kernels(kind, tiles, crow, save):
+    """esr_mlp_fwd_split / esr_mlp_dgrad_split for the tone mapper (33-192-3, two layers), the BRDF net (76-128-128-128-5, an
+    8-row output tile) and the emission net (76-128-128-128-3) -- the 128-wide nets run 7 steps per tile group, i.e. every
+    other group starts in the second LDS buffer, and finish a layer's last tile inside the 18 slots before the next layer
+    reads it -- against a float64 chain and beside the f32 MFMA kernels on the same buffers: outputs, saved tiles, masks
+    (equal except where a pre-activation is within rounding of zero), hidden and input gradients."""
+    from esr_nerf_amd import _lib
+    L = _lib.lib()
+    s = _lib.stream_ptr("cuda:0")
+    n = NET[kind]
+    in_dim, xrows, nl, hid, nout, zrows = n["in_dim"], n["xrows"], n["nl"], n["hid"], n["out"], n["zrows"]
+    g = torch.Generator().manual_seed(kind * 1000 + tiles)
+    dims = [in_dim] + [hid] * (nl - 1) + [nout]
+    Ws = [torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5 for i in range(nl)]
+    Bs = [torch.randn(dims[i + 1], generator=g) * 0.1 for i in range(nl)]
+    X = torch.randn(tiles, xrows, 32, generator=g)
+    rows = [r for r in range(min(xrows, 96)) if _in_colmap(kind, r) >= 0]
+    cols = [_in_colmap(kind, r) for r in rows]
+    cw = n.get("cw", 6)
+    src_rows = [r + crow if r < cw else r for r in rows]
+    x_ref = torch.zeros(tiles * 32, in_dim, dtype=torch.float64)
+    x_ref[:, cols] = X[:, src_rows, :].permute(0, 2, 1).reshape(tiles * 32, len(rows)).double()
+    h, hs, pres = x_ref, [], []
+    for i in range(nl):
+        h = torch.nn.functional.linear(h, Ws[i].double(), Bs[i].double())
+        if i + 1 < nl:
+            pres.append(h)
+            h = torch.relu(h)
+            hs.append(h)
+    tm = lambda t, r: t.reshape(tiles, 32, r).permute(0, 2, 1).contiguous()
+    # pack: fp32 buffer + split planes in one batch launch
+    keep = [(a.cuda().contiguous(), b.cuda().contiguous()) for a, b in zip(Ws, Bs)]
+    w = _lib.EsrMlpWeights()
+    for i, (a, b) in enumerate(keep):
+        w.w[i], w.b[i] = a.data_ptr(), b.data_ptr()
+    packed = torch.empty(L.esr_mlp_packed_floats(kind), device="cuda")
+    planes = torch.empty(L.esr_mlp_packed_split_elems(kind), dtype=torch.float16, device="cuda")
+    kinds = (C.c_int32 * 1)(kind)
+    wsp = (C.c_void_p * 1)(C.addressof(w))
+    p32 = (C.c_void_p * 1)(packed.data_ptr())
+    psp = (C.c_void_p * 1)(planes.data_ptr())
+    _lib.check(L.esr_mlp_pack_batch(1, kinds, wsp, p32, None, psp, s), "pack")
+    Xd = X.cuda().contiguous()
+
+    def fwd(split):
+        H = [torch.full((tiles, hid, 32), -3.0, device="cuda") for _ in range(nl - 1)]
+        M = [torch.full((tiles, hid // 64, 64), -3, dtype=torch.int32, device="cuda") for _ in range(nl - 1)]
+        z = torch.full((tiles, zrows, 32), 7.0, device="cuda")
+        if split:
+            rc = L.esr_mlp_fwd_split(kind, _lib.ptr(packed), _lib.ptr(planes), _lib.ptr(Xd), 0, tiles, _lib.ptr_array(H),
+                                     _lib.ptr_array(M), save, crow, _lib.ptr(z), s)
+        else:
+            rc = L.esr_mlp_fwd(kind, _lib.ptr(packed), _lib.ptr(Xd), 0, tiles, _lib.ptr_array(H), _lib.ptr_array(M), save, crow,
+                               _lib.ptr(z), s)
+        _lib.check(rc, "fwd")
+        torch.cuda.synchronize()
+        return H, M, z
+    Hs, Ms, zs = fwd(True)
+    Hf, Mf, zf = fwd(False)
+    zr = tm(h, nout)
+    scale = float(zr.abs().max())
+    es, ef = float((zs[:, :nout].cpu().double() - zr).abs().max()) / scale, float((zf[:, :nout].cpu().double() - zr).abs().max()) / scale
+    print(f"kind {kind}: z split {es:.2e}, f32 MFMA {ef:.2e}")
+    assert es < 3e-6 and es < 4 * ef + 1e-6
+    assert float(zs[:, nout:].abs().max()) == 0.0                       # padding rows of the output tile: zeros
+    if save == 1:
+        for l in range(nl - 1):
+            hr = tm(hs[l], hid)
+            sc = float(hr.abs().max())
+            assert float((Hs[l].cpu().double() - hr).abs().max()) / sc < 3e-6, l
+    else:
+        for l in range(nl - 1):
+            assert float((Hs[l] + 3.0).abs().max()) == 0.0              # not saved: untouched
+    if save:
+        for l in range(nl - 1):
+            # bit (it & 1) * 16 + r of word [tile][it >> 1][lane]: compare the two kernels bit for bit away from the knife edge
+            edge = tm((pres[l].abs() < 1e-5).double(), hid).sum(dim=(1, 2)) > 0
+            same = (Ms[l] == Mf[l]).all(dim=(1, 2)).cpu()
+            assert bool((same | edge).all()), l
+    # input gradients from the split forward's masks, both kernels
+    dz = torch.randn(tiles, zrows, 32, generator=g) * 1e-3 * 10.0 ** (-3.0 * torch.rand(tiles, 1, 32, generator=g))
+    dz[:, nout:] = 0.0
+    dzd = dz.cuda().contiguous()
+    if not save:
+        return
+
+    def bwd(split):
+        dZ = [torch.full((tiles, hid, 32), -3.0, device="cuda") for _ in range(nl - 1)]
+        dX = torch.full((tiles, 64, 32), 3.0, device="cuda")
+        if split:
+            rc = L.esr_mlp_dgrad_split(kind, _lib.ptr(planes), _lib.ptr(dzd), 0, tiles, _lib.ptr_array(Ms), _lib.ptr_array(dZ),
+                                       _lib.ptr(dX), None, s)
+        else:
+            rc = L.esr_mlp_dgrad(kind, _lib.ptr(packed), _lib.ptr(dzd), 0, tiles, _lib.ptr_array(Ms), _lib.ptr_array(dZ),
+                                 _lib.ptr(dX), s)
+        _lib.check(rc, "dgrad")
+        torch.cuda.synchronize()
+        return dZ, dX
+    dZs, dXs = bwd(True)
+    dZf, dXf = bwd(False)
+    n_dx = {0: 44, 1: 36, 2: 44, 3: 44}[kind]
+    for name, a, b in [(f"dZ{l}", dZs[l], dZf[l]) for l in range(nl - 1)] + [("dX", dXs[:, :n_dx], dXf[:, :n_dx])]:
+        a_, b_ = a.cpu().double(), b.cpu().double()
+        scale_t = b_.abs().amax(dim=(1, 2)).clamp_min(1e-300)            # per tile: what the per-tile scaling promises
+        e = float(((a_ - b_).abs().amax(dim=(1, 2)) / scale_t).max())
+        print(f"kind {kind}: {name} split vs f32 MFMA {e:.2e} (per-tile max-norm)")
+        assert e < 4e-6, (name, e)
+    assert float((dXs[:, n_dx:] - 3.0).abs().max()) == 0.0
