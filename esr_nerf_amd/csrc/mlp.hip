@@ -727,10 +727,10 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs &W)
     }
 }
 
-template <int MI, int NJ, int WM, int WN, int WK>
+template <int MI, int NJ, int WM, int WN, int WK, bool SPLIT = false>
 __global__ void __launch_bounds__(64 * (WM * WN * WK + 1), 1) mlp_wgrad_dma_kernel(WgradBatch WB)
 {
-    wgrad_dma_body<MI, NJ, WM, WN, WK>(pick_job(WB));
+    wgrad_dma_body<MI, NJ, WM, WN, WK, SPLIT>(pick_job(WB));
 }
 
 // Every f32 weight-gradient job of the 192-wide nets of a step in ONE launch: hidden layers (192 x 192), first layers
@@ -910,7 +910,7 @@ int launch_wgrad(WgradBatch &B, SlabPool &P)
     return P.launched(R, n);
 }
 
-template <int MI, int NJ, int WM, int WN, int WK>
+template <int MI, int NJ, int WM, int WN, int WK, bool SPLIT = false>
 int launch_wgrad_dma(WgradBatch &B, SlabPool &P)
 {
     hipStream_t s = P.s;
@@ -920,22 +920,23 @@ int launch_wgrad_dma(WgradBatch &B, SlabPool &P)
     constexpr size_t lds_bytes = 3 * (size_t)(WM * MI * 32 + WN * NJ * 32) * 32 * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "three staged tiles must fit the CU's LDS");
     static std::atomic<uint64_t> optin{0};
-    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_wgrad_dma_kernel<MI, NJ, WM, WN, WK>), lds_bytes, optin))
+    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_wgrad_dma_kernel<MI, NJ, WM, WN, WK, SPLIT>), lds_bytes, optin))
         return rc;
     ReduceArgs R;
     int64_t n = 0;
     const int grid = P.place([&](float *sc, int64_t fl, ReduceArgs &R_, int64_t &n_) { return plan_batch<WK>(B, sc, fl, R_, n_); }, R, n);     // one workgroup per CU (LDS-bound residency)
     if (grid < 0) return grid;
-    mlp_wgrad_dma_kernel<MI, NJ, WM, WN, WK><<<grid, NT, lds_bytes, s>>>(B);
+    mlp_wgrad_dma_kernel<MI, NJ, WM, WN, WK, SPLIT><<<grid, NT, lds_bytes, s>>>(B);
     ESR_CHECK_LAUNCH();
     return P.launched(R, n);
 }
 
-// f32: LDS-DMA staging; bf16 operand modes: the register-staged kernel
+// f32: LDS-DMA staging (MODE 4: products on the 16-bit matrix cores from split planes); bf16 operand modes: the register-staged kernel
 template <int MI, int NJ, int WM, int WN, int WK, int MODE>
 int launch_wgrad_any(WgradBatch &B, SlabPool &P)
 {
     if constexpr (MODE == 0) return launch_wgrad_dma<MI, NJ, WM, WN, WK>(B, P);
+    else if constexpr (MODE == 4) return launch_wgrad_dma<MI, NJ, WM, WN, WK, true>(B, P);
     else return launch_wgrad<MI, NJ, WM, WN, WK, MODE>(B, P);
 }
 
@@ -1067,20 +1068,23 @@ bool uni_on()
     return on;
 }
 
-template <bool BF>
+// F: 0 = f32 MFMA, 1 = bf16 operands, 2 = f32 operands as split fp16 planes (jobs with esr_wgrad_job_t::amax)
+template <int F>
 int launch_cfg(int cfg, WgradBatch &B, SlabPool &P)
 {
+    constexpr bool BF = F == 1;
+    constexpr int M0 = F == 2 ? 4 : 0;
     switch (cfg) {
-    case CFG_HID192:      return launch_wgrad_any<3, 3, 2, 2, 1, BF ? 2 : 0>(B, P);
-    case CFG_FIRST192:    return launch_wgrad_any<3, 3, 2, 1, 2, BF ? 3 : 0>(B, P);
-    case CFG_FIRST192_64: return launch_wgrad_any<3, 2, 2, 1, 2, BF ? 3 : 0>(B, P);
-    case CFG_OUT192:      return launch_wgrad_any<1, 3, 1, 2, 2, BF ? 1 : 0>(B, P);
-    case CFG_HID128:      return launch_wgrad_any<2, 2, 2, 2, 1, BF ? 2 : 0>(B, P);
-    case CFG_FIRST128:    return launch_wgrad_any<2, 3, 2, 1, 2, BF ? 3 : 0>(B, P);
+    case CFG_HID192:      return launch_wgrad_any<3, 3, 2, 2, 1, BF ? 2 : M0>(B, P);
+    case CFG_FIRST192:    return launch_wgrad_any<3, 3, 2, 1, 2, BF ? 3 : M0>(B, P);
+    case CFG_FIRST192_64: return launch_wgrad_any<3, 2, 2, 1, 2, BF ? 3 : M0>(B, P);
+    case CFG_OUT192:      return launch_wgrad_any<1, 3, 1, 2, 2, BF ? 1 : M0>(B, P);
+    case CFG_HID128:      return launch_wgrad_any<2, 2, 2, 2, 1, BF ? 2 : M0>(B, P);
+    case CFG_FIRST128:    return launch_wgrad_any<2, 3, 2, 1, 2, BF ? 3 : M0>(B, P);
     case CFG_FIRST192_X16:  // first layer of a radiance net whose input tile is bf16 in the row-quad layout: staged like a hidden layer's
         if constexpr (BF) return launch_wgrad_any<3, 3, 2, 1, 2, 2>(B, P);
         else return ESR_EINVAL;
-    default:              return launch_wgrad_any<1, 2, 1, 2, 2, BF ? 1 : 0>(B, P);
+    default:              return launch_wgrad_any<1, 2, 1, 2, 2, BF ? 1 : M0>(B, P);
     }
 }
 
@@ -1320,14 +1324,15 @@ template <bool BF>
 static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, int64_t scratch_floats, void *stream)
 {
     if (!jobs || n_jobs < 0 || !scratch) return ESR_EINVAL;
-    WgradBatch group[N_CFG][4];
-    int n_group[N_CFG] = {};
+    WgradBatch group[2][N_CFG][4];          // [0]: this call's operand type, [1]: f32 operands as split planes (jobs with amax)
+    int n_group[2][N_CFG] = {};
     constexpr int MAX_UNI = 8;
     WgradBatch uni[MAX_UNI];
     bool uni_split[MAX_UNI];
     int n_uni = 0;
-    for (int c = 0; c < N_CFG; ++c)
-        for (int g = 0; g < 4; ++g) group[c][g].n = 0;
+    for (int v = 0; v < 2; ++v)
+        for (int c = 0; c < N_CFG; ++c)
+            for (int g = 0; g < 4; ++g) group[v][c][g].n = 0;
     for (int q = 0; q < n_jobs; ++q) {
         const esr_wgrad_job_t &J = jobs[q];
         if (!kind_ok(J.kind) || J.t0 < 0 || J.t1 < J.t0) return ESR_EINVAL;
@@ -1368,21 +1373,26 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
                 U.job[U.n++] = W;
                 continue;
             }
-            int g = n_group[c];
-            if (g == 0 || group[c][g - 1].n == MAX_JOBS) {
+            const int v = (!BF && J.amax) ? 1 : 0;
+            W.amax = J.amax;
+            int g = n_group[v][c];
+            if (g == 0 || group[v][c][g - 1].n == MAX_JOBS) {
                 if (g == 4) return ESR_ECAP;
-                g = ++n_group[c];
+                g = ++n_group[v][c];
             }
-            WgradBatch &B = group[c][g - 1];
+            WgradBatch &B = group[v][c][g - 1];
             B.job[B.n++] = W;
         }
     }
     SlabPool P(scratch, scratch_floats, esr_stream(stream));
     for (int u = 0; u < n_uni; ++u)
         if (int rc = uni_split[u] ? launch_wgrad_uni<true>(uni[u], P) : launch_wgrad_uni<false>(uni[u], P)) return rc;
-    for (int c = 0; c < N_CFG; ++c)
-        for (int g = 0; g < n_group[c]; ++g)
-            if (int rc = launch_cfg<BF>(c, group[c][g], P)) return rc;
+    for (int c = 0; c < N_CFG; ++c) {
+        for (int g = 0; g < n_group[0][c]; ++g)
+            if (int rc = launch_cfg<BF ? 1 : 0>(c, group[0][c][g], P)) return rc;
+        for (int g = 0; g < n_group[1][c]; ++g)
+            if (int rc = launch_cfg<2>(c, group[1][c][g], P)) return rc;
+    }
     return P.flush();
 }
 

@@ -364,9 +364,9 @@ class LtsEngine(FineEngine):
             s = self._s()
             recompute = kind == KIND_TONEMAP and self.tone_recompute
             amax = None
-            if kind == KIND_RADIANCE and self.split_fwd and self.split_bwd and net in self.packed_split:
-                # max |dz| of this net and pass, left behind by the input-gradient kernel: the scale of the split-fp16
-                # weight-gradient job (esr_wgrad_job_t::amax)
+            if kind in self.split_kinds and self.split_fwd and self.split_bwd and net in self.packed_split:
+                # (radiance, BRDF, emission nets.)  max |dz| of this net and pass, left behind by the input-gradient kernel:
+                # the scale of the split-fp16 weight-gradient job (esr_wgrad_job_t::amax)
                 amax = self._z(1) if (self.split_wgrad and self._wgrad_jobs is not None) else None
                 self._run(f"mlp_dgrad({net})[{P.name}]", self.L.esr_mlp_dgrad_split, kind, _lib.ptr(self.packed_split[net]),
                           _lib.ptr(dz), t0, t1, _lib.ptr_array(M), _lib.ptr_array(dZ), _lib.ptr(dX),

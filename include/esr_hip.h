@@ -431,7 +431,7 @@ typedef struct esr_wgrad_job {
     /* optional (bf16 operands, ESR_MLP_RADIANCE, color_row0 == 0): the net's input tile as written by
      * esr_fine_feat_fwd_x16 -- the first-layer job then stages it like a hidden layer's tile and X is not read. */
     const void *X16;
-    /* optional (f32 operands, the 192-wide nets): device pointer to max |dz| over the step's output gradients
+    /* optional (f32 operands; every net kind and layer shape): device pointer to max |dz| over the step's output gradients
      * (esr_absmax, or esr_mlp_dgrad_fine_split's amax output).  Non-NULL selects the split-fp16 weight-gradient kernel:
      * the same fp32 operands, every value cut into two fp16 planes on its way into the 16-bit matrix cores, fp32
      * accumulation; the gradient operand is scaled by a power of two derived from *amax (csrc/mlp.hip, SPLIT). */

@@ -443,3 +443,60 @@ def test_split_kernels_for_every_net_vs_double_precision_and_vs_the_f32_kernels(
         print(f"kind {kind}: {name} split vs f32 MFMA {e:.2e} (per-tile max-norm)")
         assert e < 4e-6, (name, e)
     assert float((dXs[:, n_dx:] - 3.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("kind,tiles,t0,crow,gscale", [(2, 1, 0, 0, 1.0), (2, 500, 3, 88, 1e-5), (3, 900, 0, 96, 1e-3), (1, 300, 0, 0, 1e-4)])
+def test_split_wgrad_of_the_other_nets_vs_double_precision(kind, tiles, t0, crow, gscale):
+    """esr_wgrad_job_t::amax on the 128-wide nets (BRDF: 5 outputs in an 8-row tile; emission) and the tone mapper: their
+    layer shapes run the per-shape LDS-DMA kernels with the SPLIT products (csrc/mlp.hip: launch_cfg<2>) -- against float64
+    sums, beside the f32 MFMA kernels."""
+    from esr_nerf_amd import _lib
+    L = _lib.lib()
+    s = _lib.stream_ptr("cuda:0")
+    n = NET[kind]
+    in_dim, xrows, nl, hid, nout, zrows = n["in_dim"], n["xrows"], n["nl"], n["hid"], n["out"], n["zrows"]
+    g = torch.Generator().manual_seed(kind * 77 + tiles)
+    H = [torch.relu(torch.randn(tiles, hid, 32, generator=g) + 0.4) for _ in range(nl - 1)]
+    mag = lambda: gscale * 10.0 ** (-3.0 * torch.rand(tiles, 1, 32, generator=g))
+    dZ = [torch.randn(tiles, hid, 32, generator=g) * mag() * (1.0 + 3.0 * l) for l in range(nl - 1)]
+    dz = torch.randn(tiles, zrows, 32, generator=g) * mag()
+    dz[:, nout:] = 0.0
+    X = torch.randn(tiles, xrows, 32, generator=g)
+    rows = [r for r in range(min(xrows, 96)) if _in_colmap(kind, r) >= 0]
+    cols = [_in_colmap(kind, r) for r in rows]
+    src_rows = [r + crow if r < 6 else r for r in rows]
+    rm = lambda t: t[t0:].permute(0, 2, 1).reshape((tiles - t0) * 32, t.shape[1]).double()
+    x_ref = torch.zeros((tiles - t0) * 32, in_dim, dtype=torch.float64)
+    x_ref[:, cols] = rm(X[:, src_rows])
+    A = [rm(z) for z in dZ] + [rm(dz[:, :nout])]
+    Bm = [x_ref] + [rm(h) for h in H]
+    want_w = [a.t() @ b for a, b in zip(A, Bm)]
+    dev = lambda t: t.cuda().contiguous()
+    Xd, Hd, dZd, dzd = dev(X), [dev(h) for h in H], [dev(z) for z in dZ], dev(dz)
+    scratch = torch.empty(L.esr_mlp_wgrad_scratch_floats(), device="cuda")
+    amax = torch.zeros(1, device="cuda")
+    _lib.check(L.esr_absmax(_lib.ptr(dzd), C.c_int64(dzd.numel()), _lib.ptr(amax), s), "absmax")
+    dims = [in_dim] + [hid] * (nl - 1) + [nout]
+
+    def run(split):
+        gw = [torch.zeros(dims[i + 1], dims[i], device="cuda") for i in range(nl)]
+        gb = [torch.zeros(dims[i + 1], device="cuda") for i in range(nl)]
+        jobs = (_lib.EsrWgradJob * 1)()
+        ptrs = [_lib.ptr_array(Hd), _lib.ptr_array(dZd), _lib.ptr_array(gw), _lib.ptr_array(gb)]
+        jb = jobs[0]
+        jb.kind, jb.color_row0, jb.t0, jb.t1 = kind, crow, t0, tiles
+        jb.X, jb.dz = Xd.data_ptr(), dzd.data_ptr()
+        jb.H, jb.dZ, jb.gw, jb.gb = (C.addressof(p) for p in ptrs)
+        if split:
+            jb.amax = amax.data_ptr()
+        _lib.check(L.esr_mlp_wgrad_batch(jobs, 1, 0, _lib.ptr(scratch), C.c_int64(scratch.numel()), s), "wgrad")
+        torch.cuda.synchronize()
+        return [w.cpu().double() for w in gw], [b.cpu().double() for b in gb]
+    ws, bs = run(True)
+    wf, _ = run(False)
+    for l in range(nl):
+        scale = float(want_w[l].abs().max())
+        es, ef = float((ws[l] - want_w[l]).abs().max()) / scale, float((wf[l] - want_w[l]).abs().max()) / scale
+        print(f"kind {kind} layer {l}: dW split {es:.2e}, f32 MFMA {ef:.2e}")
+        assert es < 2e-6 and es < 4 * ef + 1e-7, (l, es, ef)
+        assert float((bs[l] - A[l].sum(0)).abs().max()) / (float(A[l].sum(0).abs().max()) + 1e-300) < 1e-5
