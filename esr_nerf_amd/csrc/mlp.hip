@@ -292,9 +292,8 @@ constexpr int LDS_STRIDE = 36;        // floats per staged row (32 samples + 4 p
 // network input X and the output gradient dz are fp32 (rounded on the way from LDS to the operand registers):
 //   1 = output layer (A = dz fp32, B = H bf16), 2 = hidden layer (both bf16), 3 = first layer (A = dZ bf16, B = X fp32).
 template <int MI, int NJ, int WM, int WN, int WK, int MODE>
-__global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradBatch WB)
+__device__ __forceinline__ void wgrad_reg_body(const WgradArgs &W)
 {
-    const WgradArgs W = pick_job(WB);
     static_assert(MODE >= 1 && MODE <= 3, "f32 operands: mlp_wgrad_dma_kernel");
     constexpr bool A16 = MODE == 2 || MODE == 3, B16 = MODE == 1 || MODE == 2;
     constexpr int NW = WM * WN * WK, NT = 64 * NW;
@@ -483,6 +482,12 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradBa
             if (h == 0 && ra < W.out_rows) atomicAdd(&W.gb[ra], tot);
         }
     }
+}
+
+template <int MI, int NJ, int WM, int WN, int WK, int MODE>
+__global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradBatch WB)
+{
+    wgrad_reg_body<MI, NJ, WM, WN, WK, MODE>(pick_job(WB));
 }
 
 // ---- f32 weight gradients, operands staged by LDS-DMA -------------------------------------------------
@@ -746,6 +751,17 @@ __global__ void __launch_bounds__(320, 1) mlp_wgrad_uni192_kernel(WgradBatch WB)
     else if (W.cfg == UNI_FIRST192) wgrad_dma_body<3, 3, 2, 1, 2>(W);
     else wgrad_dma_body<1, 3, 1, 2, 2>(W);
 }
+// the bf16 engine's 192-wide jobs the same way (register-staged bodies, four waves each; UNI_FIRST192_X16: the first layer
+// reading the bf16 input tile).  Three launches + their fill / drain became one.
+enum { UNI_FIRST192_X16 = 3 };
+__global__ void __launch_bounds__(256, 1) mlp_wgrad_uni192b_kernel(WgradBatch WB)
+{
+    const WgradArgs W = pick_job(WB);
+    if (W.cfg == UNI_HID192) wgrad_reg_body<3, 3, 2, 2, 1, 2>(W);
+    else if (W.cfg == UNI_FIRST192) wgrad_reg_body<3, 3, 2, 1, 2, 3>(W);
+    else if (W.cfg == UNI_FIRST192_X16) wgrad_reg_body<3, 3, 2, 1, 2, 2>(W);
+    else wgrad_reg_body<1, 3, 1, 2, 2, 1>(W);
+}
 // the same launch with the products on the 16-bit matrix cores (wgrad_dma_body<..., SPLIT>)
 __global__ void __launch_bounds__(320, 1) mlp_wgrad_uni192s_kernel(WgradBatch WB)
 {
@@ -947,27 +963,29 @@ int launch_wgrad_any(WgradBatch &B, SlabPool &P)
 // The split-fp16 launch is bound by the bytes it streams, not by matrix work: the shares follow the tile sizes
 // (48 : 36 : 25 KB per sample tile; measured at C2: "1,0.85,0.6" 0.466 ms, "1,1,0.6" 0.480-0.489, the f32 table 0.850; C4: 0.954 / 0.986 / -).
 // ESR_WGRAD_COST_SPLIT overrides.
-const double *uni_cost(bool split)
+// variant: 0 = f32 MFMA, 1 = split fp16 planes, 2 = bf16 operands (bytes per tile: hidden 24.6 KB, first layer 18-24 KB,
+// output layer 12.8 KB); the fourth entry is the bf16 first layer on the bf16 input tile
+const double *uni_cost(int variant)
 {
-    static double c[2][3] = {{1.0, 0.5, 0.2}, {1.0, 0.8, 0.6}};
+    static double c[3][4] = {{1.0, 0.5, 0.2, 0.5}, {1.0, 0.8, 0.6, 0.8}, {1.0, 1.0, 0.7, 0.9}};
     static std::atomic<int> done{0};
     if (!done.load()) {
-        const char *names[2] = {"ESR_WGRAD_COST", "ESR_WGRAD_COST_SPLIT"};
-        for (int k = 0; k < 2; ++k)
+        const char *names[3] = {"ESR_WGRAD_COST", "ESR_WGRAD_COST_SPLIT", "ESR_WGRAD_COST_BF16"};
+        for (int k = 0; k < 3; ++k)
             if (const char *e = std::getenv(names[k])) {
                 double a, b, d;
-                if (std::sscanf(e, "%lf,%lf,%lf", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0) { c[k][0] = a; c[k][1] = b; c[k][2] = d; }
+                if (std::sscanf(e, "%lf,%lf,%lf", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0) { c[k][0] = a; c[k][1] = b; c[k][2] = d; c[k][3] = b; }
             }
         done.store(1);
     }
-    return c[split ? 1 : 0];
+    return c[variant];
 }
-constexpr int uni_wk(int cfg) { return cfg == UNI_HID192 ? 1 : 2; }
+constexpr int uni_wk(int cfg) { return cfg == UNI_HID192 ? 1 : 2; }      // (both first-layer forms and the output layer: k split in two)
 
 // workgroups per job proportional to tiles x cost (every job >= 1, none more than its tiles); slab regions back to back
-int plan_uni(WgradBatch &B, float *scratch, int64_t slab_floats, ReduceArgs &R, int64_t &used_out, bool split)
+int plan_uni(WgradBatch &B, float *scratch, int64_t slab_floats, ReduceArgs &R, int64_t &used_out, int variant)
 {
-    const double *cost = uni_cost(split);
+    const double *cost = uni_cost(variant);
     double w[MAX_JOBS], wt = 0.0;
     int64_t tiles = 0;
     for (int j = 0; j < B.n; ++j) {
@@ -1026,25 +1044,29 @@ int plan_uni(WgradBatch &B, float *scratch, int64_t slab_floats, ReduceArgs &R, 
     return wg0;
 }
 
-template <bool SPLIT>
+// V: 0 = f32 MFMA (LDS-DMA), 1 = the same with split fp16 products, 2 = bf16 operands (register-staged)
+template <int V>
 int launch_wgrad_uni(WgradBatch &B, SlabPool &P)
 {
     hipStream_t s = P.s;
-    const void *kern = SPLIT ? reinterpret_cast<const void *>(&mlp_wgrad_uni192s_kernel)
-                             : reinterpret_cast<const void *>(&mlp_wgrad_uni192_kernel);
+    const void *kern = V == 1 ? reinterpret_cast<const void *>(&mlp_wgrad_uni192s_kernel)
+                     : V == 2 ? reinterpret_cast<const void *>(&mlp_wgrad_uni192b_kernel)
+                              : reinterpret_cast<const void *>(&mlp_wgrad_uni192_kernel);
     for (int j = 0; j < B.n; ++j) {
         const WgradArgs &W = B.job[j];
-        const int rap = W.cfg == UNI_OUT192 ? 32 : 192, rbp = W.cfg == UNI_FIRST192 ? 96 : 192;
+        const int rap = W.cfg == UNI_OUT192 ? 32 : 192, rbp = (W.cfg == UNI_FIRST192 || W.cfg == UNI_FIRST192_X16) ? 96 : 192;
         if (W.RA > rap || W.RB > rbp) return ESR_ECAP;
     }
-    constexpr size_t lds_bytes = 3 * (size_t)(192 + 192) * 32 * sizeof(float);       // the largest shape's ring
+    constexpr size_t lds_bytes = V == 2 ? 2 * (size_t)(192 + 192) * LDS_STRIDE * sizeof(float)       // two register-staged buffers
+                                        : 3 * (size_t)(192 + 192) * 32 * sizeof(float);              // the largest shape's ring
     static std::atomic<uint64_t> optin{0};
     if (int rc = esr_lds_optin(kern, lds_bytes, optin)) return rc;
     ReduceArgs R;
     int64_t n = 0;
-    const int grid = P.place([&](float *sc, int64_t fl, ReduceArgs &R_, int64_t &n_) { return plan_uni(B, sc, fl, R_, n_, SPLIT); }, R, n);
+    const int grid = P.place([&](float *sc, int64_t fl, ReduceArgs &R_, int64_t &n_) { return plan_uni(B, sc, fl, R_, n_, V); }, R, n);
     if (grid < 0) return grid;
-    if (SPLIT) mlp_wgrad_uni192s_kernel<<<grid, 320, lds_bytes, s>>>(B);
+    if (V == 1) mlp_wgrad_uni192s_kernel<<<grid, 320, lds_bytes, s>>>(B);
+    else if (V == 2) mlp_wgrad_uni192b_kernel<<<grid, 256, lds_bytes, s>>>(B);
     else mlp_wgrad_uni192_kernel<<<grid, 320, lds_bytes, s>>>(B);
     ESR_CHECK_LAUNCH();
     return P.launched(R, n);
@@ -1360,10 +1382,10 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
                 W.RB = 96; W.b_tile_rows = 104;                    // 24 row quads of operand rows, 26 quads (6656 B) per tile
                 c = CFG_FIRST192_X16;
             }
-            if (!BF && uni_on() && (c == CFG_HID192 || c == CFG_FIRST192 || c == CFG_OUT192)) {
-                W.cfg = c == CFG_HID192 ? UNI_HID192 : c == CFG_FIRST192 ? UNI_FIRST192 : UNI_OUT192;
-                W.amax = J.amax;                                   // non-NULL: the split-fp16 kernel (esr_hip.h)
-                const bool sp = J.amax != nullptr;
+            if (uni_on() && (c == CFG_HID192 || c == CFG_FIRST192 || c == CFG_OUT192 || (BF && c == CFG_FIRST192_X16))) {
+                W.cfg = c == CFG_HID192 ? UNI_HID192 : c == CFG_FIRST192 ? UNI_FIRST192 : c == CFG_OUT192 ? UNI_OUT192 : UNI_FIRST192_X16;
+                W.amax = BF ? nullptr : J.amax;                    // non-NULL: the split-fp16 kernel (esr_hip.h)
+                const bool sp = !BF && J.amax != nullptr;
                 if (n_uni == 0 || uni[n_uni - 1].n == MAX_JOBS || uni_split[n_uni - 1] != sp) {
                     if (n_uni == MAX_UNI) return ESR_ECAP;
                     uni_split[n_uni] = sp;
@@ -1386,7 +1408,7 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
     }
     SlabPool P(scratch, scratch_floats, esr_stream(stream));
     for (int u = 0; u < n_uni; ++u)
-        if (int rc = uni_split[u] ? launch_wgrad_uni<true>(uni[u], P) : launch_wgrad_uni<false>(uni[u], P)) return rc;
+        if (int rc = BF ? launch_wgrad_uni<2>(uni[u], P) : uni_split[u] ? launch_wgrad_uni<1>(uni[u], P) : launch_wgrad_uni<0>(uni[u], P)) return rc;
     for (int c = 0; c < N_CFG; ++c) {
         for (int g = 0; g < n_group[0][c]; ++g)
             if (int rc = launch_cfg<BF ? 1 : 0>(c, group[0][c][g], P)) return rc;
