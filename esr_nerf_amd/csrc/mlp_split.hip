@@ -46,6 +46,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 constexpr int SPW = 4;                                      // waves per workgroup = tiles per group
+#ifndef ESR_SPLIT_WRING
+#define ESR_SPLIT_WRING 3
+#endif
+constexpr int WRING = ESR_SPLIT_WRING;                      // k-steps of weight operands in flight per wave (tools/ubench/split_stamps.hip: 3 / 4 / 5 / 6)
 
 __device__ __forceinline__ f32x16 mfma_h(f16x8 a, f16x8 b, f32x16 c)
 {
@@ -176,8 +180,13 @@ __device__ __forceinline__ void step_barrier()
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// workgroups per CU the register budget is cut for: the 192-wide radiance net needs a whole SIMD's registers per wave; the
+// 128-wide nets and the two-layer tone mapper fit two waves per SIMD (and 2 x 66 KB of LDS), which lets one wave's MFMAs run
+// under the other's epilogue
+constexpr int split_occ(int kind) { return kind == ESR_MLP_RADIANCE ? 1 : 2; }
+
 template <int KIND>
-__global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch AB)
+__global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_fwd_split_kernel(SplitBatch AB)
 {
     using S = SplitSteps<KIND>;
     constexpr NetDesc D = net_desc(KIND);
@@ -245,7 +254,11 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
                 xn[j * 8 + i] = bload1(RX, xvoff + (row < D.cw ? coff : 0), (16 * j + i) * 128);
             }
     };
-    if ((int)blockIdx.x - blk0 < ngroups) fetch((int)blockIdx.x - blk0);
+    // one wave per SIMD: the next group's input rows are requested a group ahead (nobody else hides the load); two waves
+    // per SIMD: the rows are loaded where they are needed -- 40 registers less, which is what makes the second wave fit
+    constexpr bool PREFETCH_X = split_occ(KIND) == 1;
+    constexpr int WR = PREFETCH_X ? WRING : 2;                  // (weight ring: one k-step ahead is enough beside a second wave)
+    if (PREFETCH_X && (int)blockIdx.x - blk0 < ngroups) fetch((int)blockIdx.x - blk0);
     const int hvoff = tile_voff(lane);
 
     // LDS buffer of step st = (st + par) & 1: a net with an odd number of steps per group (the 128-wide nets: 7) starts every
@@ -263,6 +276,7 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
         asm volatile("" : "+v"(hv));
         // planes: first layer's input (from X) | set A | set B; layer 0 writes A, 1 reads A writes B, 2 reads B writes A, 3 reads A
         f16x8 xi1[KS1], xi2[KS1], pa1[2 * HT], pa2[2 * HT], pb1[2 * HT], pb2[2 * HT];
+        if constexpr (!PREFETCH_X) fetch(tg);
 #pragma unroll
         for (int j = 0; j < KS1; ++j) {
             float v[8];
@@ -271,7 +285,7 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
             split8(v, xi1[j], xi2[j]);
         }
         ESR_SPLIT_STAMP(0);
-        fetch(tg + nblk < ngroups ? tg + nblk : tg);       // the next group's rows (past the end: this group again, never used)
+        if constexpr (PREFETCH_X) fetch(tg + nblk < ngroups ? tg + nblk : tg);       // the next group's rows (past the end: this group again, never used)
         // one accumulator per tile (two tiles alternate: the one in flight and the one in its epilogue); bz: a tile's biases,
         // requested when its MFMAs start and used a tile later (a ds_read inside a micro-slice is a full LDS round trip in
         // front of one MFMA's worth of work: the first version of the slices waited ~100 clocks in each); ev: the pending
@@ -362,34 +376,40 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_fwd_split_kernel(SplitBatch A
                 // flat k-step index n = tt_ * KS + j; chunk of (tile tt_, plane q, k-step j) = (tt_ * 2 + q) * KS + j
                 constexpr int NTOT = tin * KS;
                 // weight operands: a ring of three k-steps (requested two k-steps = ~190 clocks ahead)
-                u32x4 wb[3][2];
-                wb[0][0] = mine[0 * 64];
-                wb[0][1] = mine[KS * 64];
-                if constexpr (NTOT > 1) {
-                    wb[1][0] = mine[((0 * 2 + 0) * KS + 1) * 64];
-                    wb[1][1] = mine[((0 * 2 + 1) * KS + 1) * 64];
-                }
+                // weight operands: a ring of WR k-steps, requested WR - 1 k-steps ahead (the LDS serves four streaming
+                // waves at ~91 B/clk: a read waits behind ~24 KB of its neighbours' requests)
+                u32x4 wb[WR][2];
+                sfor<0, (WR - 1 < NTOT ? WR - 1 : NTOT)>([&](auto NC) {
+                    constexpr int n0 = decltype(NC)::value, t0_ = n0 / KS, j0_ = n0 % KS;
+                    wb[n0][0] = mine[((t0_ * 2 + 0) * KS + j0_) * 64];
+                    wb[n0][1] = mine[((t0_ * 2 + 1) * KS + j0_) * 64];
+                });
                 sfor<0, NTOT>([&](auto NC) {
                     constexpr int n = decltype(NC)::value, tt_ = n / KS, j = n % KS, it = 2 * p + tt_;
 #ifndef ESR_SPLIT_NO_WREAD
-                    if constexpr (n + 2 < NTOT) {
-                        constexpr int t2 = (n + 2) / KS, j2 = (n + 2) % KS;
-                        wb[(n + 2) % 3][0] = mine[((t2 * 2 + 0) * KS + j2) * 64];
-                        wb[(n + 2) % 3][1] = mine[((t2 * 2 + 1) * KS + j2) * 64];
+                    if constexpr (n + WR - 1 < NTOT) {
+                        constexpr int t2 = (n + WR - 1) / KS, j2 = (n + WR - 1) % KS;
+                        wb[(n + WR - 1) % WR][0] = mine[((t2 * 2 + 0) * KS + j2) * 64];
+                        wb[(n + WR - 1) % WR][1] = mine[((t2 * 2 + 1) * KS + j2) * 64];
                     }
 #else
-                    if constexpr (n == 0 && NTOT > 2) { wb[2][0] = mine[2 * 64]; wb[2][1] = mine[(KS + 2) * 64]; }
+                    if constexpr (n == 0 && NTOT >= WR) { wb[WR - 1][0] = mine[(WR - 1) * 64]; wb[WR - 1][1] = mine[(KS + WR - 1) * 64]; }
 #endif
-                    if constexpr (j == 0 && !LAST) {               // this tile's biases, for its epilogue a tile from now
+                    if constexpr (j == 0 && !LAST && PREFETCH_X) { // this tile's biases, for its epilogue a tile from now
                         const float4 *bp = reinterpret_cast<const float4 *>(bias_l + l * S::BIAS_FLOATS + it * 32 + (lane >> 5) * 16);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) bz4[it & 1][q] = bp[q];
                     }
                     f32x16 &m = LAST ? zm : am[it & 1];
-                    const f16x8 w1 = __builtin_bit_cast(f16x8, wb[n % 3][0]), w2 = __builtin_bit_cast(f16x8, wb[n % 3][1]);
+                    const f16x8 w1 = __builtin_bit_cast(f16x8, wb[n % WR][0]), w2 = __builtin_bit_cast(f16x8, wb[n % WR][1]);
                     // the pending tile: the previous tile of this layer, or the last tile of the previous layer
                     constexpr bool HAVE = it > 0 || l > 0;
                     constexpr int pl = it > 0 ? l : l - 1, pit = it > 0 ? it - 1 : (l > 0 ? L.tiles_out[l > 0 ? l - 1 : 0] - 1 : 0);
+                    if constexpr (j == 0 && HAVE && !PREFETCH_X) { // two waves per SIMD: the PENDING tile's biases, right where its
+                        const float4 *bp = reinterpret_cast<const float4 *>(bias_l + pl * S::BIAS_FLOATS + pit * 32 + (lane >> 5) * 16);
+#pragma unroll                                                     // epilogue starts (one live set instead of two: 16 registers)
+                        for (int q = 0; q < 4; ++q) bz4[pit & 1][q] = bp[q];
+                    }
                     auto ride = [&](auto U) __attribute__((always_inline)) {
                         if constexpr (HAVE) {
                             if constexpr (it > 0) pending(std::integral_constant<int, pl>{}, std::integral_constant<int, pit>{}, U,
@@ -473,7 +493,7 @@ struct DSplitBatch {
 };
 
 template <int KIND>
-__global__ void __launch_bounds__(64 * SPW, 1) mlp_dgrad_split_kernel(DSplitBatch AB)
+__global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_dgrad_split_kernel(DSplitBatch AB)
 {
     using S = SplitSteps<KIND, true>;
     constexpr NetDesc D = net_desc(KIND);
@@ -628,23 +648,21 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_dgrad_split_kernel(DSplitBatc
                 const u32x4 *mine = reinterpret_cast<const u32x4 *>(wsrc) + lane;
                 stage_load(std::integral_constant<int, nxt_st>{});
                 constexpr int NTOT = tin * KS;
-                u32x4 wb[3][2];
-                wb[0][0] = mine[0 * 64];
-                wb[0][1] = mine[KS * 64];
-                if constexpr (NTOT > 1) {
-                    constexpr int t1_ = 1 / KS, j1_ = 1 % KS;
-                    wb[1][0] = mine[((t1_ * 2 + 0) * KS + j1_) * 64];
-                    wb[1][1] = mine[((t1_ * 2 + 1) * KS + j1_) * 64];
-                }
+                u32x4 wb[WRING][2];
+                sfor<0, (WRING - 1 < NTOT ? WRING - 1 : NTOT)>([&](auto NC) {
+                    constexpr int n0 = decltype(NC)::value, t0_ = n0 / KS, j0_ = n0 % KS;
+                    wb[n0][0] = mine[((t0_ * 2 + 0) * KS + j0_) * 64];
+                    wb[n0][1] = mine[((t0_ * 2 + 1) * KS + j0_) * 64];
+                });
                 sfor<0, NTOT>([&](auto NC) {
                     constexpr int n = decltype(NC)::value, tt_ = n / KS, j = n % KS, it = 2 * p + tt_;
-                    if constexpr (n + 2 < NTOT) {
-                        constexpr int t2 = (n + 2) / KS, j2 = (n + 2) % KS;
-                        wb[(n + 2) % 3][0] = mine[((t2 * 2 + 0) * KS + j2) * 64];
-                        wb[(n + 2) % 3][1] = mine[((t2 * 2 + 1) * KS + j2) * 64];
+                    if constexpr (n + WRING - 1 < NTOT) {
+                        constexpr int t2 = (n + WRING - 1) / KS, j2 = (n + WRING - 1) % KS;
+                        wb[(n + WRING - 1) % WRING][0] = mine[((t2 * 2 + 0) * KS + j2) * 64];
+                        wb[(n + WRING - 1) % WRING][1] = mine[((t2 * 2 + 1) * KS + j2) * 64];
                     }
                     f32x16 &m = am[it & 1];
-                    const f16x8 w1 = __builtin_bit_cast(f16x8, wb[n % 3][0]), w2 = __builtin_bit_cast(f16x8, wb[n % 3][1]);
+                    const f16x8 w1 = __builtin_bit_cast(f16x8, wb[n % WRING][0]), w2 = __builtin_bit_cast(f16x8, wb[n % WRING][1]);
                     constexpr bool HAVE = it > 0 || q > 0;
                     constexpr int pq = it > 0 ? q : q - 1, pit = it > 0 ? it - 1 : (q > 0 ? L.tiles_out[q > 0 ? q - 1 : 0] - 1 : 0);
                     auto ride = [&](auto U) __attribute__((always_inline)) {
@@ -688,11 +706,11 @@ __global__ void __launch_bounds__(64 * SPW, 1) mlp_dgrad_split_kernel(DSplitBatc
 }
 
 // workgroups per segment proportional to its tile groups (every non-empty segment >= 1); returns the grid
-int share_blocks_split(SplitSeg *seg, int nseg)
+int share_blocks_split(SplitSeg *seg, int nseg, int cap = 256)
 {
     int groups[MAX_SPLIT_SEG], total = 0;
     for (int k = 0; k < nseg; ++k) { groups[k] = (seg[k].t1 - seg[k].t0 + SPW - 1) / SPW; total += groups[k]; }
-    const int grid = total < 256 ? total : 256;
+    const int grid = total < cap ? total : cap;
     int given = 0;
     for (int k = 0; k < nseg; ++k) {
         int n = (int)((int64_t)grid * groups[k] / (total > 0 ? total : 1));
@@ -728,7 +746,7 @@ template <int KIND>
 int launch_split_k(SplitBatch &B, hipStream_t s)
 {
     using S = SplitSteps<KIND>;
-    const int grid = share_blocks_split(B.seg, B.nseg);
+    const int grid = share_blocks_split(B.seg, B.nseg, 256 * split_occ(KIND));       // resident workgroups: one or two per CU
     static std::atomic<uint64_t> optin{0};
     if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_fwd_split_kernel<KIND>), S::LDS_BYTES, optin)) return rc;
     mlp_fwd_split_kernel<KIND><<<grid, 64 * SPW, S::LDS_BYTES, s>>>(B);
@@ -807,7 +825,8 @@ int launch_dsplit_k(DSplitBatch &B, hipStream_t s)
     using S = SplitSteps<KIND, true>;
     int groups[2], total = 0;
     for (int k = 0; k < B.nseg; ++k) { groups[k] = (B.seg[k].t1 - B.seg[k].t0 + SPW - 1) / SPW; total += groups[k]; }
-    const int grid = total < 256 ? total : 256;
+    constexpr int cap = 256 * split_occ(KIND);
+    const int grid = total < cap ? total : cap;
     if (B.nseg == 1) { B.seg[0].b0 = 0; B.seg[0].nb = grid; }
     else {
         int n0 = (int)((int64_t)grid * groups[0] / total);

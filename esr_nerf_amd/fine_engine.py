@@ -149,11 +149,12 @@ class FineEngine:
         self.packed_split: Dict[str, torch.Tensor] = {}
         # ... and the radiance input-gradient chain the same way (per-tile power-of-two scaling); ESR_SPLIT_BWD=0: f32 MFMA
         self.split_bwd = self.split_fwd and os.environ.get("ESR_SPLIT_BWD", "1") != "0"
-        # net kinds that run on the split kernels: radiance (0), BRDF (2), emission (3).  The tone mapper (1) is supported
-        # and tested but measured no faster (C2: forward 0.097 -> 0.093 ms, input gradients 0.087 -> 0.096 ms: two-layer
-        # kernels of < 0.1 ms are launch- and fill-bound), so it stays on the f32 MFMA kernels; BRDF + emission: C4 lts
-        # 4.54 -> 4.25 ms.  ESR_SPLIT_KINDS overrides ("0" = the radiance nets only).
-        self.split_kinds = {int(k) for k in os.environ.get("ESR_SPLIT_KINDS", "0,2,3").split(",") if k.strip() != ""}
+        # net kinds that run on the split kernels: radiance (0), tone mapper (1, forward only), BRDF (2), emission (3).
+        # Measured (one box each): BRDF + emission, two waves per SIMD: C4 lts 4.58 -> 4.22 ms; tone mapper at C2: forward
+        # 0.099 -> 0.074 ms, input gradients 0.088 -> 0.097 ms (its one-k-step first layer has three slots per tile for 24
+        # epilogue slices), so those stay on the f32 MFMA kernel.  ESR_SPLIT_KINDS / ESR_SPLIT_KINDS_BWD override.
+        self.split_kinds = {int(k) for k in os.environ.get("ESR_SPLIT_KINDS", "0,1,2,3").split(",") if k.strip() != ""}
+        self.split_kinds_bwd = {int(k) for k in os.environ.get("ESR_SPLIT_KINDS_BWD", "0,2,3").split(",") if k.strip() != ""} & self.split_kinds
         self._psplit = {}
         # ... and the weight gradients of the 192-wide nets (csrc/mlp.hip: wgrad_dma_body<..., SPLIT>); their gradient
         # operand's scale comes from max |dz|, which the split input-gradient kernel leaves behind (else esr_absmax)
@@ -321,7 +322,7 @@ class FineEngine:
 
     def mlp_dgrad(self, kind, packed, *rest):
         if not self.bf16:
-            planes = self._psplit.get(packed.value) if (self.split_fwd and self.split_bwd) else None
+            planes = self._psplit.get(packed.value) if (self.split_fwd and self.split_bwd and kind in self.split_kinds_bwd) else None
             if planes is not None:                      # (..., dX, stream) -> (..., dX, amax = NULL, stream)
                 return self.L.esr_mlp_dgrad_split(kind, planes, *rest[:-1], None, rest[-1])
             return self.L.esr_mlp_dgrad(kind, packed, *rest)

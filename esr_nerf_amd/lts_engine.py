@@ -364,7 +364,7 @@ class LtsEngine(FineEngine):
             s = self._s()
             recompute = kind == KIND_TONEMAP and self.tone_recompute
             amax = None
-            if kind in self.split_kinds and self.split_fwd and self.split_bwd and net in self.packed_split:
+            if kind in self.split_kinds_bwd and self.split_fwd and self.split_bwd and net in self.packed_split:
                 # (radiance, BRDF, emission nets.)  max |dz| of this net and pass, left behind by the input-gradient kernel:
                 # the scale of the split-fp16 weight-gradient job (esr_wgrad_job_t::amax)
                 amax = self._z(1) if (self.split_wgrad and self._wgrad_jobs is not None) else None
