@@ -41,6 +41,7 @@ P = os.path.join(ROOT, "profiles")
 # (round 4: the radiance launches of the f32 engine are the split-fp16 kernels)
 ORDER_F32 = {"mlp_fwd_kernel<0>": ["mlp_fwd(rad)"], "mlp_dgrad_kernel<0>": ["mlp_dgrad(rad)"],
              "mlp_fwd_split_kernel<0>": ["mlp_fwd(rad)"], "mlp_dgrad_split_kernel<0>": ["mlp_dgrad(rad)"],
+             "mlp_fwd_split_kernel<1>": ["mlp_fwd(tone)"], "mlp_dgrad_split_kernel<1>": ["mlp_dgrad(tone)"],
              "mlp_wgrad_uni192s_kernel": ["mlp_wgrad(all)"], "mlp_wgrad_uni192_kernel": ["mlp_wgrad(all)"],
              "mlp_fwd_kernel<1>": ["mlp_fwd(tone)"], "mlp_dgrad_kernel<1>": ["mlp_dgrad(tone)"]}
 ORDER_BF16 = {"mlp_fwd16s_kernel<0>": ["mlp_fwd(rad)"], "mlp_fwd16s_kernel<1>": ["mlp_fwd(tone)"],
