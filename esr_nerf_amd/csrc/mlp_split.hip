@@ -46,6 +46,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 constexpr int SPW = 4;                                      // waves per workgroup = tiles per group
+constexpr float SPLIT_RANGE = 60000.f;                      // hidden activations at or above this raise the range flag (fp16 ends at 65504)
 #ifndef ESR_SPLIT_WRING
 #define ESR_SPLIT_WRING 3
 #endif
@@ -166,6 +167,7 @@ struct SplitBatch {
     const float *X;
     float *H[3];
     unsigned *M[3];
+    unsigned *range;           // optional: set to 1 when a hidden activation leaves fp16's range (esr_mlp_split_range_flag)
     int nseg;
     SplitSeg seg[MAX_SPLIT_SEG];
 };
@@ -261,6 +263,7 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_fwd_split_kerne
     if (PREFETCH_X && (int)blockIdx.x - blk0 < ngroups) fetch((int)blockIdx.x - blk0);
     const int hvoff = tile_voff(lane);
 
+    int rmax = 0;                                           // largest hidden activation of this wave, as bits (all >= 0 after the ReLU)
     // LDS buffer of step st = (st + par) & 1: a net with an odd number of steps per group (the 128-wide nets: 7) starts every
     // other group in buffer 1
     for (int tg = (int)blockIdx.x - blk0, trip = 0; tg < ngroups; tg += nblk, ++trip) {
@@ -320,6 +323,9 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_fwd_split_kerne
                 const int b0 = __float_as_int(v0), b1 = __float_as_int(v1);
                 v0 = __int_as_float(b0 > 0 ? b0 : 0);
                 v1 = __int_as_float(b1 > 0 ? b1 : 0);
+                // range check: inf and +NaN order above every number as integers (volatile: left to itself the chain of maxima
+                // sank to the kernel's end and kept every value alive; operands are the integer max's VALU results)
+                asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(rmax) : "v"(__float_as_int(v0)), "v"(__float_as_int(v1)));
                 const rsrc_t RH = make_rsrc(AB.H[l] + (size_t)t * (HBYTES / 4), hrec);      // fp32 tile, mlp.hip's store_tiles order
 #ifndef ESR_SPLIT_NO_HSTORE
                 asm volatile("" : "+v"(hv));                       // (opaque per slice: a shared `hv + row offset` is kept in a
@@ -466,6 +472,9 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_fwd_split_kerne
         }
         run_layer(std::integral_constant<int, NL - 1>{}, pa1, pa2, pb1, pb2);      // output layer (pb: unused)
     }
+    // a first plane holds |x| < 65504: a hidden activation at or above SPLIT_RANGE (or inf / NaN, which an overflowing input or
+    // weight turns into) raises the caller's sticky flag -- the host reports it instead of training on inf (fine_engine.py)
+    if (AB.range && rmax >= __float_as_int(SPLIT_RANGE)) atomicOr(AB.range, 1u);
 }
 
 // ---- the input-gradient chain on the same scheme ---------------------------------------------------------------------
@@ -742,10 +751,15 @@ int share_blocks_split(SplitSeg *seg, int nseg, int cap = 256)
     return b0;
 }
 
+// per-device sticky flag registered by the caller (esr_mlp_split_range_flag); NULL: no check
+std::atomic<unsigned *> g_range_flag[16];
+
 template <int KIND>
 int launch_split_k(SplitBatch &B, hipStream_t s)
 {
     using S = SplitSteps<KIND>;
+    int dev = 0;
+    B.range = (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) ? g_range_flag[dev].load() : nullptr;
     const int grid = share_blocks_split(B.seg, B.nseg, 256 * split_occ(KIND));       // resident workgroups: one or two per CU
     static std::atomic<uint64_t> optin{0};
     if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_fwd_split_kernel<KIND>), S::LDS_BYTES, optin)) return rc;
@@ -793,6 +807,16 @@ ESR_API int esr_mlp_fwd_split(int kind, const float *packed32, const void *plane
     B.nseg = 1;
     B.seg[0] = SplitSeg{packed32, static_cast<const _Float16 *>(planes), t0, t1, save == 2 ? 2 : save ? 1 : 0, color_row0, zout, 0, 0};
     return launch_split(kind, B, esr_stream(stream));
+}
+
+// Registers (NULL: removes) the CURRENT device's range flag: a device uint32 that every later split forward launch on this
+// device ORs with 1 when a hidden activation reaches 60000 (or is inf / NaN): the products' first plane is fp16.
+ESR_API int esr_mlp_split_range_flag(uint32_t *flag)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return ESR_EINVAL;
+    g_range_flag[dev].store(flag);
+    return 0;
 }
 
 // The fine stage's three radiance forward passes of a step as ONE launch (esr_mlp_fwd_fine's contract and argument meaning).

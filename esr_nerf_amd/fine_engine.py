@@ -50,6 +50,9 @@ def make_scene(xyz_min, xyz_max, mask_min, mask_max, world_size, mask_size, near
     return sc
 
 
+_RANGE_FLAGS = {}          # device -> the split kernels' sticky range flag (FineEngine.__init__)
+
+
 @dataclass
 class FineCtx:
     """What the backward needs from the forward of one step."""
@@ -156,6 +159,17 @@ class FineEngine:
         self.split_kinds = {int(k) for k in os.environ.get("ESR_SPLIT_KINDS", "0,1,2,3").split(",") if k.strip() != ""}
         self.split_kinds_bwd = {int(k) for k in os.environ.get("ESR_SPLIT_KINDS_BWD", "0,2,3").split(",") if k.strip() != ""} & self.split_kinds
         self._psplit = {}
+        # the split kernels' first planes are fp16: a hidden activation beyond fp16's range would become inf.  One sticky
+        # device flag per device (never freed: the library keeps its address), read back with every step's plan header
+        self.range_flag = None
+        if self.split_fwd:
+            key = str(self.device)
+            if key not in _RANGE_FLAGS:
+                _RANGE_FLAGS[key] = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.range_flag = _RANGE_FLAGS[key]
+            self.range_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            with torch.cuda.device(self.device):
+                _lib.check(self.L.esr_mlp_split_range_flag(_lib.ptr(self.range_flag)), "esr_mlp_split_range_flag")
         # ... and the weight gradients of the 192-wide nets (csrc/mlp.hip: wgrad_dma_body<..., SPLIT>); their gradient
         # operand's scale comes from max |dz|, which the split input-gradient kernel leaves behind (else esr_absmax)
         self.split_wgrad = self.split_bwd and os.environ.get("ESR_SPLIT_WGRAD", "1") != "0"
@@ -178,6 +192,18 @@ class FineEngine:
         if not self.defer_overflow:
             raise RuntimeError("a ray exceeded scene.max_steps; the LDS bound of the march kernel is wrong")
         self.overflow_seen = True
+
+    def _range_readback(self):
+        """Enqueue the copy of the split kernels' range flag beside the plan header's (same host wait)."""
+        if self.range_flag is not None:
+            self.range_host.copy_(self.range_flag, non_blocking=True)
+
+    def _range_check(self):
+        if self.range_flag is not None and int(self.range_host[0]) != 0:
+            self.range_flag.zero_()
+            raise RuntimeError("a hidden activation of an MLP left fp16's range (|x| >= 60000, or inf / NaN) in a split-fp16 forward "
+                               "kernel (csrc/mlp_split.hip): its results since the previous step are not valid.  Set "
+                               "ESR_SPLIT_FWD=0 to run every product on the f32 MFMA pipe, which has no such limit.")
 
     def _run(self, name, fn, *args):
         """Enqueue one C-ABI call; with timing on, bracket it with HIP events recorded on the
@@ -386,6 +412,7 @@ class FineEngine:
         self._run("plan", L.esr_fine_plan, _lib.ptr(rb["cnt3"]), _lib.ptr(em_modes), _lib.ptr(rb["stats"]), n, _lib.ptr(rb["off3"]),
                                    _lib.ptr(plan_dev), s)
         self.plan_host.copy_(plan_dev, non_blocking=True)
+        self._range_readback()
         landed = torch.cuda.Event()
         landed.record()
         e_pre = None
@@ -399,6 +426,7 @@ class FineEngine:
                 e_pre = torch.cuda.Event()
                 e_pre.record(side)
         landed.synchronize()                                        # the one host wait of the step
+        self._range_check()                                         # (the PREVIOUS steps' forward launches)
         n_on, n_off, tiles_on, tiles_all, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
         if overflow:
             self._overflow()

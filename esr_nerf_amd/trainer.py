@@ -178,10 +178,15 @@ class _OverflowScope:
 
 
 def _finish(step):
-    """After the LAST step of a data-parallel run: the overflow flag of a step is examined by the next step's
-    ``_check_overflow``; this examines the final one (every rank raises together)."""
+    """After the LAST step: the march-overflow flag of a data-parallel step is examined by the next step's
+    ``_check_overflow``, the split-fp16 kernels' range flag by the next step's plan read-back; this examines the final ones
+    (data parallel: every rank raises together)."""
     if step.pg is not None:
         _check_overflow(step)
+    eng = getattr(step.model, "_engine", None)          # the split-fp16 kernels' range flag of the last step(s): a device read
+    if eng is not None and getattr(eng, "range_flag", None) is not None:
+        eng.range_host.copy_(eng.range_flag)
+        eng._range_check()
 
 
 class FineStep:

@@ -327,6 +327,11 @@ int esr_mlp_pack_batch(int n, const int32_t *kinds, const esr_mlp_weights_t *con
  * net: ESR_EINVAL).  The reference evaluates these layers with fp32 nn.Linear (app/utils/pbr/module.py:6-83).
  */
 int64_t esr_mlp_packed_split_elems(int kind);
+/* The split kernels' range: a first plane is fp16, so a hidden activation (or input, or 64 x weight) beyond 65504 would become
+ * inf.  flag (device uint32, owned by the caller, sticky; NULL unregisters) is registered for the CURRENT device; every later
+ * esr_mlp_fwd_split / esr_mlp_fwd_fine_split launch on it ORs the flag with 1 when a hidden activation reaches 60000 or is
+ * inf / NaN.  The engines read it back with the step's plan header and raise (fine_engine.py). */
+int esr_mlp_split_range_flag(uint32_t *flag);
 int esr_mlp_fwd_split(int kind, const float *packed32, const void *planes, const float *X, int32_t t0, int32_t t1,
                       float *const *H, uint32_t *const *M, int save, int color_row0, float *zout, void *stream);
 int esr_mlp_fwd_fine_split(const float *packed32_off, const void *planes_off, const float *packed32_emo,

@@ -500,3 +500,39 @@ def test_split_wgrad_of_the_other_nets_vs_double_precision(kind, tiles, t0, crow
         print(f"kind {kind} layer {l}: dW split {es:.2e}, f32 MFMA {ef:.2e}")
         assert es < 2e-6 and es < 4 * ef + 1e-7, (l, es, ef)
         assert float((bs[l] - A[l].sum(0)).abs().max()) / (float(A[l].sum(0).abs().max()) + 1e-300) < 1e-5
+
+
+def test_split_forward_raises_its_range_flag_and_the_engine_reports_it():
+    """A hidden activation beyond fp16's range (here: inputs of 3e4 against weights of ~0.1: pre-activations of ~1e5) cannot be
+    represented by the first plane.  The kernel ORs the device's sticky range flag (esr_mlp_split_range_flag); the engine
+    reads it back with the next plan header -- or in step.close() -- and raises instead of training on inf.  In-range
+    inputs leave the flag alone."""
+    from esr_nerf_amd import _lib
+    from esr_nerf_amd.fine_engine import FineEngine
+    eng = FineEngine("cuda:0")
+    assert eng.split_fwd and eng.range_flag is not None
+    L, s = eng.L, _lib.stream_ptr("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    Ws, Bs = _net(g)
+    _pack(L, eng, "off", Ws, Bs)
+    tiles = 9
+
+    def fwd(scale):
+        X = (torch.randn(tiles, 104, 32, generator=g) * scale).cuda().contiguous()
+        H = [torch.zeros(tiles, 192, 32, device="cuda") for _ in range(3)]
+        M = [torch.zeros(tiles, 3, 64, dtype=torch.int32, device="cuda") for _ in range(3)]
+        z = torch.zeros(tiles, 4, 32, device="cuda")
+        _lib.check(L.esr_mlp_fwd_split(0, _lib.ptr(eng.packed["off"]), _lib.ptr(eng.packed_split["off"]), _lib.ptr(X), 0, tiles,
+                                       _lib.ptr_array(H), _lib.ptr_array(M), 1, 0, _lib.ptr(z), s), "fwd")
+        torch.cuda.synchronize()
+        return H
+    eng.range_flag.zero_()
+    fwd(1.0)
+    assert int(eng.range_flag) == 0
+    H = fwd(3.0e4)
+    assert float(H[0].max()) > 6.0e4                                   # (the fp32 epilogue still shows the magnitude)
+    assert int(eng.range_flag) == 1
+    eng.range_host.copy_(eng.range_flag)
+    with pytest.raises(RuntimeError, match="fp16's range"):
+        eng._range_check()
+    assert int(eng.range_flag) == 0                                    # reported once, then cleared
