@@ -737,7 +737,9 @@ def main():
             # the whole MLP engine (all 10 calls per step), from the instrumented warm-up steps
             mlp = {k: v for k, v in breakdown.items() if algorithmic_flops(k, counts)
                    and not (split_fwd and k == "mlp_fwd(rad)") and not (split_fwd and split_bwd and k == "mlp_dgrad(rad)")
-                   and not (split_wg and k == "mlp_wgrad(all)")}
+                   and not (split_wg and k == "mlp_wgrad(all)")
+                   and not (split_fwd and k == "mlp_fwd(tone)" and 1 in getattr(eng, "split_kinds", ()))
+                   and not (split_wg and k == "tone_wgrad" and getattr(eng, "split_tone_wgrad", False))}
             # (f32-pipe launches only: the split forward / input gradients are priced apart)
             if mlp:
                 mf = sum(algorithmic_flops(k, counts) * v[0] for k, v in mlp.items())

@@ -1315,9 +1315,11 @@ ESR_API int esr_mlp_dgrad_wg(int kind, const float *packed, const float *dz, int
     return 0;
 }
 
-// max |x| into out[0] (atomic maximum of non-negative floats = of their bit patterns); NaN inputs are ignored by fmaxf
+// max |x| into out[0] (atomic maximum of non-negative floats = of their bit patterns); NaN inputs are ignored by fmaxf.
+// One atomic per WORKGROUP (256 of them): with one per wave, 4096 same-address atomics made an 8 MB reduction take 52 us.
 __global__ void __launch_bounds__(256) absmax_kernel(const float *__restrict__ x, int64_t n, float *out)
 {
+    __shared__ float part[4];
     float m = 0.f;
     const int64_t n4 = n >> 2;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1327,14 +1329,19 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float *__restrict__ x
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned *>(out), __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+        if (m > 0.f) atomicMax(reinterpret_cast<unsigned *>(out), __float_as_uint(m));
+    }
 }
 
 ESR_API int esr_absmax(const float *x, int64_t n, float *out, void *stream)
 {
     if (n < 0 || !out || (n > 0 && !x) || (reinterpret_cast<uintptr_t>(x) & 15)) return ESR_EINVAL;
     if (n == 0) return 0;
-    absmax_kernel<<<esr_grid_for((n + 3) / 4, 256, 1024), 256, 0, esr_stream(stream)>>>(x, n, out);
+    absmax_kernel<<<esr_grid_for((n + 3) / 4, 256, 256), 256, 0, esr_stream(stream)>>>(x, n, out);
     ESR_CHECK_LAUNCH();
     return 0;
 }

@@ -425,6 +425,242 @@ __global__ void __launch_bounds__(256, 1) tone_wgrad16_t_kernel(ToneWgArgs A)
     }
 }
 
+// ---- split-fp16 twin (the f32 engine, round 4) ------------------------------------------------------------------------
+// The bf16 twin's scheme with fp32-accurate products: every MFMA operand as two fp16 planes (x = hi + lo, hi = fp16(x),
+// lo = fp16(x - hi)), a product as hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16 into the same fp32 accumulator
+// (csrc/mlp_split.hip).  Scales (powers of two, exact): W0 and W1 planes hold 64 w (residuals of ~0.1-sized weights stay
+// normal fp16 numbers), so the recomputed Ht is carried as 64 Ht -- the ReLU and the masks do not care, the dW1 sums are
+// divided by 64 at the flush; the output gradient dzt (1e-3 .. 1e-9) is multiplied by S = 2^k with max |dzt| S in [16, 32)
+// (the step's max |dzt|: `amax`, esr_absmax), so dZt is carried as 64 S dZt and dW0 / db0 are divided by 64 S at the flush.
+// A tile whose gradients are far below the step's largest loses RELATIVE precision in its residual plane (2^-25 absolute of
+// a scale where the largest value is ~1e3) -- in a sum over all tiles that is 2^-35 of the dominant terms.
+typedef _Float16 tf16x8 __attribute__((ext_vector_type(8)));
+constexpr float TW_SCALE = 64.f;
+constexpr int WAVE_LDSS = 2 * 32 * XS16 * 2 + (4 + 1) * XS * 4;  // bytes per wave: Xt rows 0..31 as two fp16 planes | dzt rows 0..3 + Xt row 32 (f32)
+constexpr int W0S_BYTES = 2 * THID * W0B_U * 2;                 // W0 as two fp16 planes [192][W0B_U]
+
+__device__ __forceinline__ void tsplit8(const float (&v)[8], tf16x8 &hi, tf16x8 &lo)
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 hh = (_Float16)v[e];
+        hi[e] = hh;
+        lo[e] = (_Float16)(v[e] - (float)hh);
+    }
+}
+__device__ __forceinline__ f32x16 tmfma(tf16x8 a, tf16x8 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// a.b with both operands as plane pairs: three MFMAs into one accumulator
+__device__ __forceinline__ f32x16 tmfma3(tf16x8 ah, tf16x8 al, tf16x8 bh, tf16x8 bl, f32x16 c)
+{
+    c = tmfma(ah, bl, c);
+    c = tmfma(ah, bh, c);
+    return tmfma(al, bh, c);
+}
+
+struct ToneWgSplitArgs {
+    ToneWgArgs a;
+    const float *amax;                      // max |dzt| of the step (device)
+};
+
+__global__ void __launch_bounds__(256, 1) tone_wgrad_split_t_kernel(ToneWgSplitArgs AS)
+{
+    const ToneWgArgs &A = AS.a;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldss[];
+    _Float16 *w0h = reinterpret_cast<_Float16 *>(ldss), *w0l = w0h + THID * W0B_U;      // [192][W0B_U] each: 64 W0[u][x]
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, ul = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char *mine = ldss + W0S_BYTES + wv * WAVE_LDSS;
+    _Float16 *xh = reinterpret_cast<_Float16 *>(mine), *xl = xh + 32 * XS16;            // [32][XS16] each
+    float *lz = reinterpret_cast<float *>(mine + 2 * 32 * XS16 * 2);                   // dzt rows 0..3, [4][XS]
+    float *lx32 = lz + 4 * XS;                                                          // Xt row 32, [XS]
+    for (int i = tid; i < THID * W0B_U; i += 256) {
+        const int u = i / W0B_U, x = i % W0B_U;
+        const float w = x < TIN ? TW_SCALE * A.W0[u * TIN + x] : 0.f;
+        const _Float16 hh = (_Float16)w;
+        w0h[i] = hh;
+        w0l[i] = (_Float16)(w - (float)hh);
+    }
+    __syncthreads();
+    // the step's gradient scale: 2^k with max |dzt| 2^k in [16, 32) (1 for an all-zero or non-finite maximum)
+    float S = 1.f;
+    {
+        const float am = AS.amax ? *AS.amax : 0.f;
+        const int ez = (__float_as_int(am) >> 23) & 0xff;
+        if (am > 0.f && ez != 0 && ez != 0xff) {
+            int k = 131 - ez;
+            k = k < -100 ? -100 : (k > 100 ? 100 : k);
+            S = __int_as_float((127 + k) << 23);
+        }
+    }
+
+    const int g = wv & 1;                                                   // this wave's hidden units [96 g, 96 g + 96)
+    tf16x8 w1h[3], w1l[3];
+    float b0r[3];
+#pragma unroll
+    for (int i3 = 0; i3 < 3; ++i3) {
+        const int u = 96 * g + 32 * i3 + ul;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (h == 0 && e < TOUT) ? TW_SCALE * A.W1[e * THID + u] : 0.f;
+        tsplit8(v, w1h[i3], w1l[i3]);
+        b0r[i3] = TW_SCALE * A.b0[u];
+    }
+    f32x16 dW0[3];
+    zero_tiles<3>(dW0);
+    float dW0c[3], dW1r[3][3], db0r[3], db1r[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i3 = 0; i3 < 3; ++i3) {
+        dW0c[i3] = 0.f; db0r[i3] = 0.f;
+        dW1r[i3][0] = dW1r[i3][1] = dW1r[i3][2] = 0.f;
+    }
+    const int pair = blockIdx.x * 2 + (wv >> 1), npairs = gridDim.x * 2;
+    float xn[17], zn[2];
+    auto fetch = [&](int t) {
+        const bool live = t < A.t1;
+        const float *X = A.Xt + (size_t)(live ? t : A.t0) * XT_ROWS * 32 + ul;
+        const float *Zt = A.dzt + (size_t)(live ? t : A.t0) * 4 * 32 + ul;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xn[j] = X[(16 * (j >> 3) + 8 * h + (j & 7)) * 32];
+        xn[16] = X[(32 + 8 * h) * 32];
+        zn[0] = Zt[h * 32];
+        zn[1] = h == 0 ? Zt[2 * 32] : 0.f;
+    };
+    const int xp = xperm(ul);
+    if (A.t0 + pair < A.t1) fetch(A.t0 + pair);
+    for (int t = A.t0 + pair; t < A.t1; t += npairs) {
+        float xa[17], za[2];
+#pragma unroll
+        for (int j = 0; j < 17; ++j) xa[j] = xn[j];
+        za[0] = zn[0]; za[1] = zn[1];
+        fetch(t + npairs);                              // one wave per SIMD: the next tile's rows a tile ahead
+        db1r[0] += za[0]; db1r[1] += za[1];
+        // the A operands of Ht^T (this lane's 8 input rows per k-step) as planes; the same values, permuted, staged for dW0's B
+        tf16x8 a8h[3], a8l[3];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = xa[8 * q + e];
+            tsplit8(v, a8h[q], a8l[q]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xh[(16 * q + 8 * h + e) * XS16 + xp] = a8h[q][e];
+                xl[(16 * q + 8 * h + e) * XS16 + xp] = a8l[q][e];
+            }
+        }
+        {
+            const float v[8] = {xa[16], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            tsplit8(v, a8h[2], a8l[2]);
+        }
+        lz[h * XS + ul] = za[0];
+        if (h == 0) { lz[2 * XS + ul] = za[1]; lx32[ul] = xa[16]; }
+        float x32[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 d4 = *reinterpret_cast<const float4 *>(lx32 + 8 * q + 4 * h);
+            x32[4 * q] = d4.x; x32[4 * q + 1] = d4.y; x32[4 * q + 2] = d4.z; x32[4 * q + 3] = d4.w;
+        }
+        // (S dzt)^T as the A operand of dHt^T: slots 0..2 of half 0 = dzt rows 0..2 of this lane's sample
+        const float z1 = __shfl_xor(za[0], 32);
+        tf16x8 zah, zal;
+        {
+            const float v[8] = {h == 0 ? S * za[0] : 0.f, h == 0 ? S * z1 : 0.f, h == 0 ? S * za[1] : 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            tsplit8(v, zah, zal);
+        }
+        // one 32-unit block at a time (one Ht tile live instead of three)
+#pragma unroll
+        for (int i3 = 0; i3 < 3; ++i3) {
+            // ---- 64 Ht^T[s][u]
+            f32x16 ht;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ht[r] = b0r[i3];
+            const int wrow = (96 * g + 32 * i3 + ul) * W0B_U + 8 * h;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const tf16x8 bh = *reinterpret_cast<const tf16x8 *>(w0h + wrow + 16 * q);
+                const tf16x8 bl = *reinterpret_cast<const tf16x8 *>(w0l + wrow + 16 * q);
+                ht = tmfma3(a8h[q], a8l[q], bh, bl, ht);
+            }
+            // (ReLU in C: the compiler's hazard recogniser must see the read of the MFMA result -- see the bf16 twin)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ht[r] = fmaxf(ht[r], 0.f);
+            // ---- 64 dW1[c][u] += sum_s dzt[c][s] (64 Ht[u][s]): fp32 vector sums
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 a = *reinterpret_cast<const float4 *>(lz + 0 * XS + 8 * q + 4 * h);
+                const float4 b = *reinterpret_cast<const float4 *>(lz + 1 * XS + 8 * q + 4 * h);
+                const float4 c = *reinterpret_cast<const float4 *>(lz + 2 * XS + 8 * q + 4 * h);
+                const float za4[4] = {a.x, a.y, a.z, a.w}, zb4[4] = {b.x, b.y, b.z, b.w}, zc4[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float hv = ht[4 * q + i];
+                    dW1r[i3][0] = fmaf(za4[i], hv, dW1r[i3][0]);
+                    dW1r[i3][1] = fmaf(zb4[i], hv, dW1r[i3][1]);
+                    dW1r[i3][2] = fmaf(zc4[i], hv, dW1r[i3][2]);
+                }
+            }
+            // ---- 64 S dHt^T = (S dzt)^T (64 W1), masked by the recomputed activation; then 64 S dW0 += (64 S dZt) Xt^T
+            f32x16 d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = 0.f;
+            d = tmfma3(zah, zal, w1h[i3], w1l[i3], d);
+            float sb = 0.f, sc = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = ht[r] > 0.f ? d[r] : 0.f;
+                d[r] = v;
+                sb += v;
+                sc = fmaf(v, x32[r], sc);
+            }
+            db0r[i3] += sb;
+            dW0c[i3] += sc;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = d[8 * q + e];
+                tf16x8 aqh, aql;
+                tsplit8(v, aqh, aql);
+                const tf16x8 xqh = *reinterpret_cast<const tf16x8 *>(xh + ul * XS16 + (2 * q + h) * 8);
+                const tf16x8 xql = *reinterpret_cast<const tf16x8 *>(xl + ul * XS16 + (2 * q + h) * 8);
+                dW0[i3] = tmfma3(aqh, aql, xqh, xql, dW0[i3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- flush (same slab layout as the f32 kernel), scales removed
+    const float iw = 1.f / TW_SCALE, ig = 1.f / (TW_SCALE * S);
+    float *Sl = A.slab + (size_t)pair * SLAB;
+#pragma unroll
+    for (int i3 = 0; i3 < 3; ++i3) {
+        const int ub = 96 * g + 32 * i3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Sl[(ub + acc_row(r, h)) * TIN + ul] = dW0[i3][r] * ig;
+        const int u = ub + ul;
+        const float c32 = dW0c[i3] + __shfl_xor(dW0c[i3], 32);
+        const float b = db0r[i3] + __shfl_xor(db0r[i3], 32);
+        float w1[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) w1[c] = dW1r[i3][c] + __shfl_xor(dW1r[i3][c], 32);
+        if (h == 0) {
+            Sl[u * TIN + 32] = c32 * ig;
+            Sl[N_DW0 + N_DW1 + u] = b * ig;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Sl[N_DW0 + c * THID + u] = w1[c] * iw;
+        }
+    }
+    float d0 = db1r[0], d1 = db1r[1];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) { d0 += __shfl_xor(d0, off); d1 += __shfl_xor(d1, off); }
+    if (ul == 0 && g == 0) {
+        Sl[N_DW0 + N_DW1 + THID + h] = d0;
+        if (h == 0) { Sl[N_DW0 + N_DW1 + THID + 2] = d1; Sl[N_DW0 + N_DW1 + THID + 3] = 0.f; }
+    }
+}
+
 // gw[e] += sum over the wave slabs, all four outputs in one launch
 __global__ void __launch_bounds__(256) tone_wgrad_reduce_kernel(const float *__restrict__ slab, int n_slabs,
                                                                 float *gw0, float *gw1, float *gb0, float *gb1)
@@ -489,6 +725,33 @@ ESR_API int esr_tone_wgrad_recompute_bf16(const float *Xt, const float *dzt, con
     ToneWgArgs A = {Xt, dzt, W0, b0, W1, t0, t1, scratch};
     hipStream_t s = esr_stream(stream);
     tone_wgrad16_t_kernel<<<grid, 256, lds_bytes, s>>>(A);
+    ESR_CHECK_LAUNCH();
+    const int n_slabs = grid * 2;
+    tone_wgrad_reduce_kernel<<<esr_grid_for((int64_t)(SLAB - 1) * ((n_slabs + 31) / 32), 256, 1024), 256, 0, s>>>(
+        scratch, n_slabs, gw0, gw1, gb0, gb1);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+// Split-fp16 twin (the f32 engine): same arguments + amax, a device pointer to max |dzt| over the step's tiles (esr_absmax);
+// fp32 results of the f32 kernel's accuracy class with the products on the 16-bit matrix cores.
+ESR_API int esr_tone_wgrad_recompute_split(const float *Xt, const float *dzt, const float *W0, const float *b0, const float *W1,
+                                           const float *amax, int32_t t0, int32_t t1, float *gw0, float *gb0, float *gw1,
+                                           float *gb1, float *scratch, int64_t scratch_floats, void *stream)
+{
+    if (t0 < 0 || t1 < t0) return ESR_EINVAL;
+    if (t1 == t0) return 0;
+    if (!Xt || !dzt || !W0 || !b0 || !W1 || !amax || !gw0 || !gb0 || !gw1 || !gb1 || !scratch) return ESR_EINVAL;
+    const int n_tiles = t1 - t0;
+    int grid = (n_tiles + 1) / 2;
+    if (grid > 512) grid = 512;                                        // two workgroups (8 waves) per CU
+    if ((int64_t)grid * 2 * SLAB > scratch_floats) return ESR_ECAP;
+    constexpr size_t lds_bytes = (size_t)W0S_BYTES + 4 * WAVE_LDSS;
+    static std::atomic<uint64_t> optin{0};
+    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&tone_wgrad_split_t_kernel), lds_bytes, optin)) return rc;
+    ToneWgSplitArgs A = {{Xt, dzt, W0, b0, W1, t0, t1, scratch}, amax};
+    hipStream_t s = esr_stream(stream);
+    tone_wgrad_split_t_kernel<<<grid, 256, lds_bytes, s>>>(A);
     ESR_CHECK_LAUNCH();
     const int n_slabs = grid * 2;
     tone_wgrad_reduce_kernel<<<esr_grid_for((int64_t)(SLAB - 1) * ((n_slabs + 31) / 32), 256, 1024), 256, 0, s>>>(

@@ -173,6 +173,8 @@ class FineEngine:
         # ... and the weight gradients of the 192-wide nets (csrc/mlp.hip: wgrad_dma_body<..., SPLIT>); their gradient
         # operand's scale comes from max |dz|, which the split input-gradient kernel leaves behind (else esr_absmax)
         self.split_wgrad = self.split_bwd and os.environ.get("ESR_SPLIT_WGRAD", "1") != "0"
+        # ... and the tone mapper's weight gradients by recomputation (csrc/tone_wgrad.hip: tone_wgrad_split_t_kernel)
+        self.split_tone_wgrad = self.split_wgrad and os.environ.get("ESR_SPLIT_TONE_WGRAD", "1") != "0"
         self.tone_scratch = torch.empty(self.L.esr_tone_wgrad_scratch_floats() if self.tone_recompute else 1,
                                         dtype=torch.float32, device=self.device)
         self.neus_grad = False          # cfg neus_alpha: "grad" (set by the renderer)
@@ -400,6 +402,7 @@ class FineEngine:
         srgb, lin = zb[8: 8 + 3 * n].view(n, 3), zb[8 + n3: 8 + n3 + 3 * n].view(n, 3)
         self._loss_acc = zb[8 + 2 * n3: 8 + 2 * n3 + 2]
         self._amax = zb[8 + 2 * n3 + 3: 8 + 2 * n3 + 4]        # max |dz| of the step (split-fp16 weight gradients)
+        self._amax_t = zb[8 + 2 * n3 + 2: 8 + 2 * n3 + 3]      # max |dzt| (the tone mapper's)
         sp = C.byref(scene)
         main = torch.cuda.current_stream(self.device)
         if cached:
@@ -453,6 +456,7 @@ class FineEngine:
         x16 = self.x16 and self.merge_rad and all(0.0 <= float(r) <= 2.0 for r in scene.grad_feat)
         ctx.x16 = x16
         ctx.amax, ctx.amax_set = self._amax, False
+        ctx.amax_t = self._amax_t
         if x16:
             self._run("feat_fwd", L.esr_fine_feat_fwd_x16, sp, C.byref(fa), _lib.ptr(ws["X"]), _lib.ptr(ws["gnorm"]),
                       _lib.ptr(ws["X16"]), s)
@@ -639,6 +643,14 @@ class FineEngine:
         def tone_wgrad(s_):
             # from Xt and dzt alone: the hidden layer is recomputed inside (tone_wgrad.hip)
             (w0, w1), (b0, _) = self._raw["tone"]
+            if self.split_tone_wgrad and getattr(ctx, "amax_t", None) is not None:
+                # f32 engine: the products on the 16-bit matrix cores; the gradient operand's scale from max |dzt|
+                self._run("absmax(dzt)", L.esr_absmax, _lib.ptr(ws["dzt"]), C.c_int64(ta * 4 * 32), _lib.ptr(ctx.amax_t), s_)
+                self._run("tone_wgrad", L.esr_tone_wgrad_recompute_split, _lib.ptr(ws["Xt"]), _lib.ptr(ws["dzt"]), _lib.ptr(w0.detach()),
+                          _lib.ptr(b0.detach()), _lib.ptr(w1.detach()), _lib.ptr(ctx.amax_t), 0, ta, _lib.ptr(grads["tone_w"][0]),
+                          _lib.ptr(grads["tone_b"][0]), _lib.ptr(grads["tone_w"][1]), _lib.ptr(grads["tone_b"][1]),
+                          _lib.ptr(self.tone_scratch), C.c_int64(self.tone_scratch.numel()), s_)
+                return
             self._run("tone_wgrad", L.esr_tone_wgrad_recompute_bf16 if self.bf16 else L.esr_tone_wgrad_recompute,
                       _lib.ptr(ws["Xt"]), _lib.ptr(ws["dzt"]), _lib.ptr(w0.detach()),
                       _lib.ptr(b0.detach()), _lib.ptr(w1.detach()), 0, ta, _lib.ptr(grads["tone_w"][0]),

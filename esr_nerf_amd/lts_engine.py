@@ -380,6 +380,16 @@ class LtsEngine(FineEngine):
                 (w0, w1), (b0, _) = self._raw[net]
 
                 def tone_wgrad():
+                    if self.split_tone_wgrad:
+                        amax_t = self._z(1)
+                        self._run(f"absmax(dzt)[{P.name}]", self.L.esr_absmax, C.c_void_p(dz.data_ptr() + t0 * 4 * 32 * 4),
+                                  C.c_int64((t1 - t0) * 4 * 32), _lib.ptr(amax_t), self._s())
+                        self._run(f"tone_wgrad[{P.name}]", self.L.esr_tone_wgrad_recompute_split, _lib.ptr(x), _lib.ptr(dz),
+                                  _lib.ptr(w0.detach()), _lib.ptr(b0.detach()), _lib.ptr(w1.detach()), _lib.ptr(amax_t), t0, t1,
+                                  _lib.ptr(gw[0]), _lib.ptr(gb[0]), _lib.ptr(gw[1]), _lib.ptr(gb[1]), _lib.ptr(self.tone_scratch),
+                                  C.c_int64(self.tone_scratch.numel()), self._s())
+                        amax_t.record_stream(torch.cuda.current_stream(self.device))
+                        return
                     self._run(f"tone_wgrad[{P.name}]",
                               self.L.esr_tone_wgrad_recompute_bf16 if self.bf16 else self.L.esr_tone_wgrad_recompute, _lib.ptr(x), _lib.ptr(dz),
                               _lib.ptr(w0.detach()), _lib.ptr(b0.detach()), _lib.ptr(w1.detach()), t0, t1, _lib.ptr(gw[0]),

@@ -462,6 +462,11 @@ int esr_tone_wgrad_recompute(const float *Xt, const float *dzt, const float *W0,
 int esr_tone_wgrad_recompute_bf16(const float *Xt, const float *dzt, const float *W0, const float *b0, const float *W1,
                                   int32_t t0, int32_t t1, float *gw0, float *gb0, float *gw1, float *gb1,
                                   float *scratch, int64_t scratch_floats, void *stream);
+/* The same with the products on the 16-bit matrix cores from split fp16 planes, fp32 results (round 4; csrc/tone_wgrad.hip):
+ * amax = device pointer to max |dzt| over the tiles (esr_absmax), the source of the gradient operand's power-of-two scale. */
+int esr_tone_wgrad_recompute_split(const float *Xt, const float *dzt, const float *W0, const float *b0, const float *W1,
+                                   const float *amax, int32_t t0, int32_t t1, float *gw0, float *gb0, float *gw1,
+                                   float *gb1, float *scratch, int64_t scratch_floats, void *stream);
 
 /*
  * bf16 variants of the MLP engine for BASELINE.json's bf16 configurations (a build-side precision choice:

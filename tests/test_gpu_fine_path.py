@@ -321,6 +321,28 @@ def test_tone_wgrad_recompute_vs_torch(tiles, t0):
                                           _lib.stream_ptr("cuda:0")), "tone_wgrad")
     for got, want in ((gw0, W0.grad), (gb0, b0.grad), (gw1, W1.grad), (gb1, b1.grad)):      # += into the outputs
         assert rel_err(got - 0.25, want) < 2e-5, rel_err(got - 0.25, want)
+    # round 4: the same with the products on the 16-bit matrix cores from split fp16 planes (esr_tone_wgrad_recompute_split),
+    # for output gradients of the magnitudes training sees (1e-4 .. 1e-8 per sample) as well as O(1)
+    for gscale in (1.0, 1e-4):
+        zs = dev(dzt * gscale * 10.0 ** (-3.0 * torch.rand(tiles, 1, 32, generator=g)) if gscale != 1.0 else dzt)
+        want_s = None
+        if gscale != 1.0:
+            for p_ in (W0, b0, W1, b1):
+                p_.grad = None
+            pre2 = torch.nn.functional.linear(x, W0, b0)
+            out2 = torch.nn.functional.linear(torch.relu(pre2), W1, b1)
+            dz2 = zs[t0:, :3].cpu().permute(0, 2, 1).reshape(-1, 3)
+            out2.backward(dz2)
+        want_s = (W0.grad, b0.grad, W1.grad, b1.grad)
+        amax = torch.zeros(1, device="cuda")
+        _lib.check(L.esr_absmax(_lib.ptr(zs[t0:]), C.c_int64((tiles - t0) * 128), _lib.ptr(amax), _lib.stream_ptr("cuda:0")), "absmax")
+        hw0, hb0, hw1, hb1 = (torch.zeros(s_, device="cuda") for s_ in ((192, 33), (192,), (3, 192), (3,)))
+        _lib.check(L.esr_tone_wgrad_recompute_split(_lib.ptr(Xd), _lib.ptr(zs), _lib.ptr(W0d), _lib.ptr(b0d), _lib.ptr(W1d),
+                                                    _lib.ptr(amax), t0, tiles, _lib.ptr(hw0), _lib.ptr(hb0), _lib.ptr(hw1),
+                                                    _lib.ptr(hb1), _lib.ptr(scratch), C.c_int64(scratch.numel()),
+                                                    _lib.stream_ptr("cuda:0")), "tone_wgrad_split")
+        for got, want in zip((hw0, hb0, hw1, hb1), want_s):
+            assert rel_err(got, want) < 2e-5, (gscale, rel_err(got, want))
 
 
 @pytest.mark.parametrize("tiles,t0", [(1, 0), (7, 2), (300, 0), (1500, 17)])
