@@ -113,6 +113,11 @@ def test_register_budgets():
     for name in ("mlp_fwd_split_kernel", "mlp_dgrad_split_kernel"):
         ks = [v for k, v in metas.items() if name in k]
         assert ks and all(v.get("scratch", 0) == 0 for v in ks), (name, ks)
+        # ... and the 128-wide nets' / the tone mapper's instantiations fit TWO waves per SIMD (256 registers in all)
+        small = [v for k, v in metas.items() if name in k and "ILi0E" not in k]
+        assert len(small) == 3 and all(v.get("vgpr", 0) + v.get("agpr", 0) <= 256 for v in small), (name, small)
+    tw = [v for k, v in km.kernel_meta(_asm("tone_wgrad.hip")).items() if "tone_wgrad" in k and "reduce" not in k]
+    assert len(tw) == 3 and all(v.get("scratch", 0) == 0 for v in tw), tw
 
 
 def test_split_kernels_evaluate_their_step_tables_at_compile_time():
