@@ -333,3 +333,6 @@ static __device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned lds_byte, 
                  : "=&s"(keep) : "v"(voff), "s"(lds_byte), "s"(rsrc) : "memory");
 }
 
+
+// (mlp_split.hip) the current device's registered range flag of the split-fp16 forward kernels, or NULL
+unsigned *esr_split_range_flag_ptr();

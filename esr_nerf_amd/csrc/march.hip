@@ -452,10 +452,14 @@ __device__ __forceinline__ int2 block_scan2(int2 v, int2 *wave_tot, int tid)   /
 __global__ void __launch_bounds__(1024) plan_kernel(const int32_t *__restrict__ cnt3,
                                                     const int64_t *__restrict__ em_modes,
                                                     const int32_t *__restrict__ stats, int n_rays,
-                                                    int32_t *__restrict__ off3, esr_plan_t *plan)
+                                                    int32_t *__restrict__ off3, esr_plan_t *plan,
+                                                    const unsigned *__restrict__ range_flag)
 {
     __shared__ int2 wave_tot[17];
     const int tid = threadIdx.x;
+    // the split-fp16 forward kernels' sticky range flag (mlp_split.hip: esr_mlp_split_range_flag) rides to the host in bit 1
+    // of the header's overflow word: no dispatch and no copy of its own
+    if (tid == 0 && range_flag && *range_flag) atomicOr(&plan->overflow, 2);
     {   // survivor statistics m0, m1, m2 = sums of the per-ray counts (element j of stats is of class j % 3)
         int s[3] = {0, 0, 0};
         // 16-byte loads, unrolled: one workgroup has nobody to hide a load behind -- 75 dependent dword round trips for the
@@ -579,7 +583,7 @@ ESR_API int esr_fine_plan(const int32_t *cnt3, const int64_t *em_modes, const in
 {
     if (n_rays < 0 || !plan) return ESR_EINVAL;
     if (n_rays && (!cnt3 || !em_modes || !ray_stats || !off3)) return ESR_EINVAL;
-    plan_kernel<<<1, 1024, 0, esr_stream(stream)>>>(cnt3, em_modes, ray_stats, n_rays, off3, plan);
+    plan_kernel<<<1, 1024, 0, esr_stream(stream)>>>(cnt3, em_modes, ray_stats, n_rays, off3, plan, esr_split_range_flag_ptr());
     ESR_CHECK_LAUNCH();
     return 0;
 }

@@ -809,6 +809,12 @@ ESR_API int esr_mlp_fwd_split(int kind, const float *packed32, const void *plane
     return launch_split(kind, B, esr_stream(stream));
 }
 
+unsigned *esr_split_range_flag_ptr()
+{
+    int dev = 0;
+    return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) ? g_range_flag[dev].load() : nullptr;
+}
+
 // Registers (NULL: removes) the CURRENT device's range flag: a device uint32 that every later split forward launch on this
 // device ORs with 1 when a hidden activation reaches 60000 (or is inf / NaN): the products' first plane is fp16.
 ESR_API int esr_mlp_split_range_flag(uint32_t *flag)

@@ -167,7 +167,6 @@ class FineEngine:
             if key not in _RANGE_FLAGS:
                 _RANGE_FLAGS[key] = torch.zeros(1, dtype=torch.int32, device=self.device)
             self.range_flag = _RANGE_FLAGS[key]
-            self.range_host = torch.zeros(1, dtype=torch.int32).pin_memory()
             with torch.cuda.device(self.device):
                 _lib.check(self.L.esr_mlp_split_range_flag(_lib.ptr(self.range_flag)), "esr_mlp_split_range_flag")
         # ... and the weight gradients of the 192-wide nets (csrc/mlp.hip: wgrad_dma_body<..., SPLIT>); their gradient
@@ -195,13 +194,13 @@ class FineEngine:
             raise RuntimeError("a ray exceeded scene.max_steps; the LDS bound of the march kernel is wrong")
         self.overflow_seen = True
 
-    def _range_readback(self):
-        """Enqueue the copy of the split kernels' range flag beside the plan header's (same host wait)."""
-        if self.range_flag is not None:
-            self.range_host.copy_(self.range_flag, non_blocking=True)
-
-    def _range_check(self):
-        if self.range_flag is not None and int(self.range_host[0]) != 0:
+    def _range_check(self, overflow_word=None):
+        """The split kernels' sticky range flag: bit 1 of the plan header's overflow word (esr_fine_plan puts it there), or --
+        without a header at hand (step.close()) -- a read of the flag itself."""
+        if self.range_flag is None:
+            return
+        hit = (overflow_word & 2) != 0 if overflow_word is not None else int(self.range_flag) != 0
+        if hit:
             self.range_flag.zero_()
             raise RuntimeError("a hidden activation of an MLP left fp16's range (|x| >= 60000, or inf / NaN) in a split-fp16 forward "
                                "kernel (csrc/mlp_split.hip): its results since the previous step are not valid.  Set "
@@ -415,7 +414,6 @@ class FineEngine:
         self._run("plan", L.esr_fine_plan, _lib.ptr(rb["cnt3"]), _lib.ptr(em_modes), _lib.ptr(rb["stats"]), n, _lib.ptr(rb["off3"]),
                                    _lib.ptr(plan_dev), s)
         self.plan_host.copy_(plan_dev, non_blocking=True)
-        self._range_readback()
         landed = torch.cuda.Event()
         landed.record()
         e_pre = None
@@ -429,9 +427,9 @@ class FineEngine:
                 e_pre = torch.cuda.Event()
                 e_pre.record(side)
         landed.synchronize()                                        # the one host wait of the step
-        self._range_check()                                         # (the PREVIOUS steps' forward launches)
         n_on, n_off, tiles_on, tiles_all, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
-        if overflow:
+        self._range_check(overflow)                                 # (the PREVIOUS steps' split forward launches)
+        if overflow & 1:
             self._overflow()
         ctx = FineCtx(scene=scene, n_rays=n, tiles_on=tiles_on, tiles_all=tiles_all,
                       counts=dict(m0=m0, m1=m1, m2=m2, m3=n_on + n_off, n_on=n_on, n_off=n_off),
@@ -520,7 +518,8 @@ class FineEngine:
         self.plan_host.copy_(self.plan_dev, non_blocking=True)
         torch.cuda.current_stream(dev).synchronize()
         _, _, _, T, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
-        if overflow:
+        self._range_check(overflow)
+        if overflow & 1:
             raise RuntimeError("a ray exceeded scene.max_steps; the LDS bound of the march kernel is wrong")
         z3 = lambda: torch.zeros(n, 3, dtype=torch.float32, device=dev)
         out = {f"{sp_}/{v}_rgb": z3() for v in ("off", "on", "emo") for sp_ in ("srgb", "lin")}

@@ -245,7 +245,6 @@ class LtsEngine(FineEngine):
         self._run("plan", L.esr_fine_plan, _lib.ptr(cnt3), _lib.ptr(em_modes), _lib.ptr(stats), n, _lib.ptr(off3),
                   _lib.ptr(self.plan_dev), s)
         self.plan_host.copy_(self.plan_dev, non_blocking=True)
-        self._range_readback()
         P.e_pre = None
         landed = torch.cuda.Event()
         landed.record()
@@ -259,9 +258,9 @@ class LtsEngine(FineEngine):
                 P.e_pre = torch.cuda.Event()
                 P.e_pre.record(side)
         landed.synchronize()
-        self._range_check()
         n_on, n_off, tiles_on, tiles_all, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
-        if overflow:
+        self._range_check(overflow)
+        if overflow & 1:
             self._overflow()
         P.tiles_on, P.tiles_all = tiles_on, tiles_all
         P.counts = dict(m0=m0, m1=m1, m2=m2, m3=n_on + n_off, n_on=n_on, n_off=n_off)

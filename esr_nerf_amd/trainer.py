@@ -185,7 +185,6 @@ def _finish(step):
         _check_overflow(step)
     eng = getattr(step.model, "_engine", None)          # the split-fp16 kernels' range flag of the last step(s): a device read
     if eng is not None and getattr(eng, "range_flag", None) is not None:
-        eng.range_host.copy_(eng.range_flag)
         eng._range_check()
 
 

@@ -87,7 +87,7 @@ class CoarseEngine(FineEngine):
         self.plan_host.copy_(self.plan_dev, non_blocking=True)
         torch.cuda.current_stream(dev).synchronize()
         n_on, n_off, tiles_on, tiles_all, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
-        if overflow:
+        if overflow & 1:                                   # (bit 1: the fine stage's split-fp16 range flag, not this renderer's)
             raise RuntimeError("a ray exceeded scene.max_steps; the LDS bound of the march kernel is wrong")
         ctx = dict(scene=scene, batch=batch, n=n, T=tiles_all, Ton=tiles_on, sm=sm, gg=gg, off3=off3, dims=dims,
                    mask_density=mask_density, kernel_w=kernel_w, ksize=ksize, voxel=voxel_size,

@@ -131,7 +131,8 @@ typedef struct esr_plan {
     int32_t tiles_on;    /* ceil(n_on / 32)                         */
     int32_t tiles_all;   /* tiles_on + ceil(n_off / 32)             */
     int32_t m0, m1, m2;  /* survivors after in-box / mask-cache / alpha>thres */
-    int32_t overflow;    /* !=0: a ray exceeded scene.max_steps     */
+    int32_t overflow;    /* bit 0: a ray exceeded scene.max_steps; bit 1 (esr_fine_plan): the registered range flag of the
+                            split-fp16 forward kernels is set (esr_mlp_split_range_flag) */
 } esr_plan_t;
 
 /*
@@ -330,7 +331,8 @@ int64_t esr_mlp_packed_split_elems(int kind);
 /* The split kernels' range: a first plane is fp16, so a hidden activation (or input, or 64 x weight) beyond 65504 would become
  * inf.  flag (device uint32, owned by the caller, sticky; NULL unregisters) is registered for the CURRENT device; every later
  * esr_mlp_fwd_split / esr_mlp_fwd_fine_split launch on it ORs the flag with 1 when a hidden activation reaches 60000 or is
- * inf / NaN.  The engines read it back with the step's plan header and raise (fine_engine.py). */
+ * inf / NaN.  esr_fine_plan copies it into bit 1 of the plan header's overflow word, so it reaches the host with the read-back the
+ * step makes anyway (fine_engine.py raises). */
 int esr_mlp_split_range_flag(uint32_t *flag);
 int esr_mlp_fwd_split(int kind, const float *packed32, const void *planes, const float *X, int32_t t0, int32_t t1,
                       float *const *H, uint32_t *const *M, int save, int color_row0, float *zout, void *stream);

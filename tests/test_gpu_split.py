@@ -532,7 +532,13 @@ def test_split_forward_raises_its_range_flag_and_the_engine_reports_it():
     H = fwd(3.0e4)
     assert float(H[0].max()) > 6.0e4                                   # (the fp32 epilogue still shows the magnitude)
     assert int(eng.range_flag) == 1
-    eng.range_host.copy_(eng.range_flag)
+    # esr_fine_plan carries the flag to the host in bit 1 of the plan header's overflow word
+    plan = torch.zeros(8, dtype=torch.int32, device="cuda")
+    cnt3, em, stats, off3 = (torch.zeros(3, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda"),
+                             torch.zeros(3, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda"))
+    _lib.check(L.esr_fine_plan(_lib.ptr(cnt3), _lib.ptr(em), _lib.ptr(stats), 1, _lib.ptr(off3), _lib.ptr(plan), s), "plan")
+    torch.cuda.synchronize()
+    assert int(plan[7]) == 2
     with pytest.raises(RuntimeError, match="fp16's range"):
-        eng._range_check()
+        eng._range_check(int(plan[7]))
     assert int(eng.range_flag) == 0                                    # reported once, then cleared
