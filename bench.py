@@ -739,6 +739,7 @@ def main():
                    and not (split_fwd and k == "mlp_fwd(rad)") and not (split_fwd and split_bwd and k == "mlp_dgrad(rad)")
                    and not (split_wg and k == "mlp_wgrad(all)")
                    and not (split_fwd and k == "mlp_fwd(tone)" and 1 in getattr(eng, "split_kinds", ()))
+                   and not (split_bwd and k == "mlp_dgrad(tone)" and 1 in getattr(eng, "split_kinds_bwd", ()))
                    and not (split_wg and k == "tone_wgrad" and getattr(eng, "split_tone_wgrad", False))}
             # (f32-pipe launches only: the split forward / input gradients are priced apart)
             if mlp:

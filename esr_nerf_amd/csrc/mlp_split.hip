@@ -151,7 +151,12 @@ template <int KIND, bool BWD = false> struct SplitSteps {
     }
     static constexpr int BUF = max_chunks() * 1024;
     static constexpr int BIAS_FLOATS = 32 * MAX_HID_TILES;
-    static constexpr int LDS_BYTES = 2 * BUF + NL * BIAS_FLOATS * 4;
+    // a net whose planes fit 64 KB (the tone mapper: 60 chunks each way) keeps them RESIDENT in LDS for the kernel's whole
+    // life: no per-step staging, no step barriers -- a two-layer net's steps are a handful of MFMAs each, far shorter than
+    // the global -> register -> LDS round trip that used to sit between them
+    static constexpr bool RES = L.total_chunks <= 64;
+    static constexpr int WBYTES = RES ? L.total_chunks * 1024 : 2 * BUF;
+    static constexpr int LDS_BYTES = WBYTES + NL * BIAS_FLOATS * 4;
     static constexpr int PRE = (max_chunks() * 64 + 64 * SPW - 1) / (64 * SPW);     // 16-byte pieces per thread and step
 };
 
@@ -204,7 +209,7 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_fwd_split_kerne
         if (k < AB.nseg && (int)blockIdx.x >= AB.seg[k].b0) A = AB.seg[k];
     const int blk0 = A.b0, nblk = A.nb;
     extern __shared__ __attribute__((aligned(16))) unsigned char wl[];          // buffer 0 | buffer 1 | biases
-    float *bias_l = reinterpret_cast<float *>(wl + 2 * S::BUF);
+    float *bias_l = reinterpret_cast<float *>(wl + S::WBYTES);
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, s_ = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntiles = A.t1 - A.t0, ngroups = (ntiles + SPW - 1) / SPW;
@@ -237,8 +242,13 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_fwd_split_kerne
         if constexpr (k * 64 * SPW < pieces)
             if (tid + 64 * SPW * k < pieces) *reinterpret_cast<u32x4 *>(dst + (size_t)(tid + 64 * SPW * k) * 16) = pre[k];
     };
-    stage_load(std::integral_constant<int, 0>{});
-    stage_store(std::integral_constant<int, 0>{}, wl);
+    if constexpr (S::RES) {
+        for (int i = tid; i < L.total_chunks * 64; i += 64 * SPW)
+            *reinterpret_cast<u32x4 *>(wl + (size_t)i * 16) = __builtin_amdgcn_raw_buffer_load_b128(WP, i * 16, S::BASE_CHUNK * 1024, 0);
+    } else {
+        stage_load(std::integral_constant<int, 0>{});
+        stage_store(std::integral_constant<int, 0>{}, wl);
+    }
     step_barrier();
 
     // the group's input rows: lane (h, s) needs rows 16 j + 8 h + i of its sample s (first layer's k order)
@@ -376,9 +386,9 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_fwd_split_kerne
             f32x16 zm;                                             // (output layer: its single tile's sums)
             sfor<0, NP>([&](auto PC) {
                 constexpr int p = decltype(PC)::value, st = s0 + p, tin = S::tiles_in(st), nxt_st = (st + 1) % NS;
-                const unsigned char *wsrc = wl + ((st + par) & 1) * S::BUF;
+                const unsigned char *wsrc = S::RES ? wl + (S::chunk0(st) - S::BASE_CHUNK) * 1024 : wl + ((st + par) & 1) * S::BUF;
                 const u32x4 *mine = reinterpret_cast<const u32x4 *>(wsrc) + lane;
-                stage_load(std::integral_constant<int, nxt_st>{});
+                if constexpr (!S::RES) stage_load(std::integral_constant<int, nxt_st>{});
                 // flat k-step index n = tt_ * KS + j; chunk of (tile tt_, plane q, k-step j) = (tt_ * 2 + q) * KS + j
                 constexpr int NTOT = tin * KS;
                 // weight operands: a ring of three k-steps (requested two k-steps = ~190 clocks ahead)
@@ -423,7 +433,7 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_fwd_split_kerne
                             else pending(std::integral_constant<int, pl>{}, std::integral_constant<int, pit>{}, U,
                                          std::integral_constant<int, 3 * (KS - 2)>{}, am[pit & 1], in1, in2);
                         }
-                        if constexpr (tt_ == tin - 1) {            // the next step's weights: one piece per slot, last slots of the step
+                        if constexpr (tt_ == tin - 1 && !S::RES) { // the next step's weights: one piece per slot, last slots of the step
                             constexpr int u_ = decltype(U)::value, first = 3 * KS - S::PRE;
                             static_assert(first >= 0, "a tile has a slot for every staged piece");
                             if constexpr (u_ >= first) stage_piece(std::integral_constant<int, nxt_st>{}, std::integral_constant<int, u_ - first>{},
@@ -461,7 +471,7 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_fwd_split_kerne
                 }
                 ESR_SPLIT_STAMP(1 + 3 * st);
                 ESR_SPLIT_STAMP(2 + 3 * st);
-                step_barrier();
+                if constexpr (!S::RES) step_barrier();
                 ESR_SPLIT_STAMP(3 + 3 * st);
             });
         };
@@ -540,8 +550,13 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_dgrad_split_ker
         if constexpr (k * 64 * SPW < pieces)
             if (tid + 64 * SPW * k < pieces) *reinterpret_cast<u32x4 *>(dst + (size_t)(tid + 64 * SPW * k) * 16) = pre[k];
     };
-    stage_load(std::integral_constant<int, 0>{});
-    stage_store(std::integral_constant<int, 0>{}, wl);
+    if constexpr (S::RES) {
+        for (int i = tid; i < L.total_chunks * 64; i += 64 * SPW)
+            *reinterpret_cast<u32x4 *>(wl + (size_t)i * 16) = __builtin_amdgcn_raw_buffer_load_b128(WP, i * 16, S::BASE_CHUNK * 1024, 0);
+    } else {
+        stage_load(std::integral_constant<int, 0>{});
+        stage_store(std::integral_constant<int, 0>{}, wl);
+    }
     step_barrier();
 
     // the group's output gradients (rows 0..3 of the 4-row tile: half 0's slots 0..3, everything else of the k-step is zero)
@@ -561,6 +576,7 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_dgrad_split_ker
     if ((int)blockIdx.x - blk0 < ngroups) fetch((int)blockIdx.x - blk0);
     const int hvoff = tile_voff(lane);
 
+    float wmax = 0.f;                                       // largest |dz| of this wave's tiles (AB.amax)
     // LDS buffer of step st = (st + par) & 1: a net with an odd number of steps per group (the 128-wide nets: 7) starts every
     // other group in buffer 1
     for (int tg = (int)blockIdx.x - blk0, trip = 0; tg < ngroups; tg += nblk, ++trip) {
@@ -576,8 +592,7 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_dgrad_split_ker
         for (int i = 0; i < D.out_dim; ++i) zmax = fmaxf(zmax, fabsf(zn[i]));
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, o));
-        if (AB.amax && live && lane == 0)                                     // (non-negative floats order like their bit patterns)
-            atomicMax(reinterpret_cast<unsigned *>(AB.amax), __float_as_uint(zmax));
+        if (live) wmax = fmaxf(wmax, zmax);                                   // (the launch's maximum: one atomic per wave, at the end)
         const int ez = (__float_as_int(zmax) >> 23) & 0xff;                   // biased exponent of the maximum
         const int ks = ez == 0 ? 0 : 131 - ez;                                // scale exponent: max lands in [16, 32)
         const int kc = ks < -100 ? -100 : (ks > 100 ? 100 : ks);
@@ -653,9 +668,9 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_dgrad_split_ker
             constexpr int s0 = [] { int s = 0; for (int k = 0; k < q; ++k) s += L.pairs[k]; return s; }();
             sfor<0, NP>([&](auto PC) {
                 constexpr int p = decltype(PC)::value, st = s0 + p, tin = S::tiles_in(st), nxt_st = (st + 1) % NS;
-                const unsigned char *wsrc = wl + ((st + par) & 1) * S::BUF;
+                const unsigned char *wsrc = S::RES ? wl + (S::chunk0(st) - S::BASE_CHUNK) * 1024 : wl + ((st + par) & 1) * S::BUF;
                 const u32x4 *mine = reinterpret_cast<const u32x4 *>(wsrc) + lane;
-                stage_load(std::integral_constant<int, nxt_st>{});
+                if constexpr (!S::RES) stage_load(std::integral_constant<int, nxt_st>{});
                 constexpr int NTOT = tin * KS;
                 u32x4 wb[WRING][2];
                 sfor<0, (WRING - 1 < NTOT ? WRING - 1 : NTOT)>([&](auto NC) {
@@ -681,7 +696,7 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_dgrad_split_ker
                             else pending(std::integral_constant<int, pq>{}, std::integral_constant<int, pit>{}, U,
                                          std::integral_constant<int, 3 * (KS - 2)>{}, am[pit & 1], in1, in2);
                         }
-                        if constexpr (tt_ == tin - 1 && 3 * KS >= S::PRE) {
+                        if constexpr (tt_ == tin - 1 && 3 * KS >= S::PRE && !S::RES) {
                             constexpr int u_ = decltype(U)::value, first = 3 * KS - S::PRE;
                             if constexpr (u_ >= first) stage_piece(std::integral_constant<int, nxt_st>{}, std::integral_constant<int, u_ - first>{},
                                                                    wl + ((st + 1 + par) & 1) * S::BUF);
@@ -700,9 +715,9 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_dgrad_split_ker
                         micro(QC, std::integral_constant<int, NT - 1>{}, MC, am[(NT - 1) & 1], o1, o2);
                     });
                 }
-                if constexpr (3 * KS < S::PRE)                     // (the one-k-step first layer: too few slots, all pieces here)
+                if constexpr (3 * KS < S::PRE && !S::RES)          // (the one-k-step first layer: too few slots, all pieces here)
                     stage_store(std::integral_constant<int, nxt_st>{}, wl + ((st + 1 + par) & 1) * S::BUF);
-                step_barrier();
+                if constexpr (!S::RES) step_barrier();
             });
         };
         run_layer(std::integral_constant<int, 0>{}, xi1, xi2, pa1, pa2);      // W3ᵀ dz -> dZ[2]   (tone mapper: W1ᵀ dz -> dZ[0])
@@ -712,6 +727,11 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_dgrad_split_ker
         }
         run_layer(std::integral_constant<int, NL - 1>{}, pa1, pa2, pb1, pb2);      // -> dX (pb unused)
     }
+    // max |dz| of the launch: one atomic per wave, and only from a wave that would raise the value (non-negative floats order
+    // like their bit patterns).  One atomic per TILE -- 16 384 on one address at C2 -- took 0.14 ms to drain: twice the tone
+    // mapper's whole launch.
+    if (AB.amax && lane == 0 && wmax > *reinterpret_cast<volatile float *>(AB.amax))
+        atomicMax(reinterpret_cast<unsigned *>(AB.amax), __float_as_uint(wmax));
 }
 
 // workgroups per segment proportional to its tile groups (every non-empty segment >= 1); returns the grid
@@ -867,8 +887,8 @@ int launch_dsplit_k(DSplitBatch &B, hipStream_t s)
         B.seg[0].b0 = 0; B.seg[0].nb = n0; B.seg[1].b0 = n0; B.seg[1].nb = grid - n0;
     }
     static std::atomic<uint64_t> optin{0};
-    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_dgrad_split_kernel<KIND>), 2 * S::BUF, optin)) return rc;
-    mlp_dgrad_split_kernel<KIND><<<grid, 64 * SPW, 2 * S::BUF, s>>>(B);
+    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_dgrad_split_kernel<KIND>), S::WBYTES, optin)) return rc;
+    mlp_dgrad_split_kernel<KIND><<<grid, 64 * SPW, S::WBYTES, s>>>(B);
     ESR_CHECK_LAUNCH();
     return 0;
 }

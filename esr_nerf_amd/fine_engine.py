@@ -152,12 +152,12 @@ class FineEngine:
         self.packed_split: Dict[str, torch.Tensor] = {}
         # ... and the radiance input-gradient chain the same way (per-tile power-of-two scaling); ESR_SPLIT_BWD=0: f32 MFMA
         self.split_bwd = self.split_fwd and os.environ.get("ESR_SPLIT_BWD", "1") != "0"
-        # net kinds that run on the split kernels: radiance (0), tone mapper (1, forward only), BRDF (2), emission (3).
-        # Measured (one box each): BRDF + emission, two waves per SIMD: C4 lts 4.58 -> 4.22 ms; tone mapper at C2: forward
-        # 0.099 -> 0.074 ms, input gradients 0.088 -> 0.097 ms (its one-k-step first layer has three slots per tile for 24
-        # epilogue slices), so those stay on the f32 MFMA kernel.  ESR_SPLIT_KINDS / ESR_SPLIT_KINDS_BWD override.
+        # net kinds that run on the split kernels: radiance (0), tone mapper (1), BRDF (2), emission (3) -- every MLP launch of
+        # the f32 engine.  Measured (same box each): BRDF + emission, two waves per SIMD: C4 lts 4.58 -> 4.22 ms; tone mapper
+        # at C2 with its planes resident in LDS: forward 0.099 -> 0.070 ms, input gradients 0.088 -> 0.070 ms (0.097 while its
+        # 60 KB of planes were re-staged per tile group).  ESR_SPLIT_KINDS / ESR_SPLIT_KINDS_BWD override ("0" = radiance only).
         self.split_kinds = {int(k) for k in os.environ.get("ESR_SPLIT_KINDS", "0,1,2,3").split(",") if k.strip() != ""}
-        self.split_kinds_bwd = {int(k) for k in os.environ.get("ESR_SPLIT_KINDS_BWD", "0,2,3").split(",") if k.strip() != ""} & self.split_kinds
+        self.split_kinds_bwd = {int(k) for k in os.environ.get("ESR_SPLIT_KINDS_BWD", "0,1,2,3").split(",") if k.strip() != ""} & self.split_kinds
         self._psplit = {}
         # the split kernels' first planes are fp16: a hidden activation beyond fp16's range would become inf.  One sticky
         # device flag per device (never freed: the library keeps its address), read back with every step's plan header
@@ -454,7 +454,7 @@ class FineEngine:
         x16 = self.x16 and self.merge_rad and all(0.0 <= float(r) <= 2.0 for r in scene.grad_feat)
         ctx.x16 = x16
         ctx.amax, ctx.amax_set = self._amax, False
-        ctx.amax_t = self._amax_t
+        ctx.amax_t, ctx.amax_t_set = self._amax_t, False
         if x16:
             self._run("feat_fwd", L.esr_fine_feat_fwd_x16, sp, C.byref(fa), _lib.ptr(ws["X"]), _lib.ptr(ws["gnorm"]),
                       _lib.ptr(ws["X16"]), s)
@@ -644,7 +644,8 @@ class FineEngine:
             (w0, w1), (b0, _) = self._raw["tone"]
             if self.split_tone_wgrad and getattr(ctx, "amax_t", None) is not None:
                 # f32 engine: the products on the 16-bit matrix cores; the gradient operand's scale from max |dzt|
-                self._run("absmax(dzt)", L.esr_absmax, _lib.ptr(ws["dzt"]), C.c_int64(ta * 4 * 32), _lib.ptr(ctx.amax_t), s_)
+                if not getattr(ctx, "amax_t_set", False):          # (the f32 input-gradient kernel ran: one small reduction over dzt)
+                    self._run("absmax(dzt)", L.esr_absmax, _lib.ptr(ws["dzt"]), C.c_int64(ta * 4 * 32), _lib.ptr(ctx.amax_t), s_)
                 self._run("tone_wgrad", L.esr_tone_wgrad_recompute_split, _lib.ptr(ws["Xt"]), _lib.ptr(ws["dzt"]), _lib.ptr(w0.detach()),
                           _lib.ptr(b0.detach()), _lib.ptr(w1.detach()), _lib.ptr(ctx.amax_t), 0, ta, _lib.ptr(grads["tone_w"][0]),
                           _lib.ptr(grads["tone_b"][0]), _lib.ptr(grads["tone_w"][1]), _lib.ptr(grads["tone_b"][1]),
@@ -713,8 +714,17 @@ class FineEngine:
         e_scat = on(scat, mark(), march_bwd) if scat is not None else None
         if fold:
             march_bwd(s)
-        dgrad("mlp_dgrad(tone)", KIND_TONEMAP, self.packed["tone"], ws["dzt"], 0, ta, self._H(["Mt"]),
-              _lib.ptr_array([None]) if self.tone_recompute else self._H(["dZt"]), ws["dXt"])
+        dZt_arg = _lib.ptr_array([None]) if self.tone_recompute else self._H(["dZt"])
+        tone_planes = self._psplit.get(self.packed["tone"].data_ptr()) if (self.split_fwd and self.split_bwd and not self.bf16
+                                                                          and KIND_TONEMAP in self.split_kinds_bwd and cap == 0) else None
+        if tone_planes is not None:
+            # the split kernel leaves max |dzt| behind: the scale of the tone mapper's split weight gradients (no absmax launch)
+            amax_t = getattr(ctx, "amax_t", None)
+            self._run("mlp_dgrad(tone)", L.esr_mlp_dgrad_split, KIND_TONEMAP, tone_planes, _lib.ptr(ws["dzt"]), 0, ta, self._H(["Mt"]),
+                      dZt_arg, _lib.ptr(ws["dXt"]), _lib.ptr(amax_t) if amax_t is not None else None, s)
+            ctx.amax_t_set = amax_t is not None
+        else:
+            dgrad("mlp_dgrad(tone)", KIND_TONEMAP, self.packed["tone"], ws["dzt"], 0, ta, self._H(["Mt"]), dZt_arg, ws["dXt"])
         self._run("tone_in_bwd", L.esr_fine_tone_in_bwd, _lib.ptr(ws["dXt"]), _lib.ptr(ws["Xt"]), _lib.ptr(g_lin), _lib.ptr(ws["lin"]),
                   _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), to, ta,
                   _lib.ptr(ws["dz"]), s)

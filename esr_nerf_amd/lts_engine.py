@@ -369,8 +369,10 @@ class LtsEngine(FineEngine):
                 # (radiance, BRDF, emission nets.)  max |dz| of this net and pass, left behind by the input-gradient kernel:
                 # the scale of the split-fp16 weight-gradient job (esr_wgrad_job_t::amax)
                 amax = self._z(1) if (self.split_wgrad and self._wgrad_jobs is not None) else None
+                if recompute and self.split_tone_wgrad:
+                    amax = self._z(1)                      # max |dzt|: the scale of the tone mapper's split weight gradients
                 self._run(f"mlp_dgrad({net})[{P.name}]", self.L.esr_mlp_dgrad_split, kind, _lib.ptr(self.packed_split[net]),
-                          _lib.ptr(dz), t0, t1, _lib.ptr_array(M), _lib.ptr_array(dZ), _lib.ptr(dX),
+                          _lib.ptr(dz), t0, t1, _lib.ptr_array(M), _lib.ptr_array([None] * nh if recompute else dZ), _lib.ptr(dX),
                           _lib.ptr(amax) if amax is not None else None, s)
             else:
                 self._run(f"mlp_dgrad({net})[{P.name}]", self.mlp_dgrad, kind, _lib.ptr(self.packed[net]),
@@ -378,11 +380,12 @@ class LtsEngine(FineEngine):
             if recompute:
                 (w0, w1), (b0, _) = self._raw[net]
 
-                def tone_wgrad():
+                def tone_wgrad(amax_t=amax):
                     if self.split_tone_wgrad:
-                        amax_t = self._z(1)
-                        self._run(f"absmax(dzt)[{P.name}]", self.L.esr_absmax, C.c_void_p(dz.data_ptr() + t0 * 4 * 32 * 4),
-                                  C.c_int64((t1 - t0) * 4 * 32), _lib.ptr(amax_t), self._s())
+                        if amax_t is None:                 # (the f32 input-gradient kernel ran)
+                            amax_t = self._z(1)
+                            self._run(f"absmax(dzt)[{P.name}]", self.L.esr_absmax, C.c_void_p(dz.data_ptr() + t0 * 4 * 32 * 4),
+                                      C.c_int64((t1 - t0) * 4 * 32), _lib.ptr(amax_t), self._s())
                         self._run(f"tone_wgrad[{P.name}]", self.L.esr_tone_wgrad_recompute_split, _lib.ptr(x), _lib.ptr(dz),
                                   _lib.ptr(w0.detach()), _lib.ptr(b0.detach()), _lib.ptr(w1.detach()), _lib.ptr(amax_t), t0, t1,
                                   _lib.ptr(gw[0]), _lib.ptr(gb[0]), _lib.ptr(gw[1]), _lib.ptr(gb[1]), _lib.ptr(self.tone_scratch),
