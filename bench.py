@@ -742,16 +742,21 @@ def main():
                    and not (split_bwd and k == "mlp_dgrad(tone)" and 1 in getattr(eng, "split_kinds_bwd", ()))
                    and not (split_wg and k == "tone_wgrad" and getattr(eng, "split_tone_wgrad", False))}
             # (f32-pipe launches only: the split forward / input gradients are priced apart)
+            peak = MFMA_BF16_PEAK_TF if a.dtype == "bf16" else MFMA_F32_PEAK_TF
             if mlp:
                 mf = sum(algorithmic_flops(k, counts) * v[0] for k, v in mlp.items())
                 mt = sum(v[1] for v in mlp.values()) * 1e-3
-                peak = MFMA_BF16_PEAK_TF if a.dtype == "bf16" else MFMA_F32_PEAK_TF
                 out["roofline"]["all_mlp_kernels"] = {"achieved": mf / mt / 1e12, "frac": mf / mt / 1e12 / peak, "peak": peak,
                                                       "share_of_kernel_time": mt * 1e3 / total_ms,
                                                       "launches": sorted(mlp)}
                 if a.dtype == "bf16":
                     mb = sum((algorithmic_bytes(k, counts, True) or 0) * v[0] for k, v in mlp.items())
                     out["roofline"]["all_mlp_kernels"].update(hbm_gbs=mb / mt / 1e9, hbm_frac=mb / mt / 1e9 / HBM_PEAK_GBS)
+            elif split_fwd:
+                out["roofline"]["all_mlp_kernels"] = {"launches": [], "note": "no launch of this step multiplies on the f32 MFMA pipe: every "
+                                                      "net runs on the split-fp16 kernels (roofline.split_forward / split_dgrad / "
+                                                      "split_wgrad price the three largest)"}
+            if mlp or split_fwd:
                 # the whole step against the path's roof: algorithmic FLOPs of the step / wall time
                 # every net pass counted at the forward's MACs x 3 (fwd, dgrad, wgrad); an on-ray sample runs
                 # the emo net x3, the off net x1 (detached) and the tone mapper x3, an off-ray sample the off net x3
