@@ -843,10 +843,9 @@ def main():
                       achieved=pick["achieved"], peak=pick["peak"], unit=pick["unit"], frac=pick["frac"],
                       hbm_frac=rl["hbm"]["frac"], mfma_frac=rl["mfma"]["frac"])
             if not bf and getattr(eng, "split_fwd", False):
-                rl["note"] = ("f32 engine, round 4: the radiance nets' forward / input-gradient / weight-gradient launches run on the "
-                              "16-bit matrix cores from split fp16 planes (fp32 results); `mfma` is still the step's ALGORITHMIC "
-                              "FLOP rate over the f32 matrix peak, kept for comparison with earlier rounds -- the brdf / emission "
-                              "/ tone-mapper launches are the ones left on that pipe")
+                rl["note"] = ("f32 engine, round 4: every net's forward / input-gradient / weight-gradient launches run on the 16-bit "
+                              "matrix cores from split fp16 planes (fp32 results); `mfma` is still the step's ALGORITHMIC FLOP rate "
+                              "over the f32 matrix peak, kept for comparison with earlier rounds -- it is not bounded by 1")
             out["roofline"] = rl
         if pg is not None:
             # how many ranks the collective library actually saw, and which exchange ran (trainer._grid_sync)
