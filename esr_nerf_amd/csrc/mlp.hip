@@ -250,6 +250,11 @@ struct WgradArgs {
     int wg0, nwg;                // workgroups [wg0, wg0 + nwg) of the launch work on this job
     int cfg;                     // kernel shape of this job (layer_cfg) -- read by the unified launch (mlp_wgrad_uni192_kernel)
     const float *amax;           // split-fp16 kernel: max |dz| of the step (device), the source of the gradient operand's scale
+    // last hidden layer, gradient operand NOT read from memory but synthesised per tile: A = mask (.) (W_last^T dz)
+    const float *syn_dz;         // [tiles][zrows][32] output gradients
+    const unsigned *syn_m;       // [tiles][hid/64][64] ReLU masks of the last hidden layer
+    const float *syn_w;          // [out_dim][hid] the output layer's weights (reference layout)
+    int syn_zrows;
 };
 
 // One launch can carry up to MAX_JOBS jobs of the same kernel shape (the same layer of the emissive and the non-emissive
@@ -291,16 +296,24 @@ constexpr int LDS_STRIDE = 36;        // floats per staged row (32 samples + 4 p
 // [row][32] bf16 and a 16-B read IS an 8-sample operand) while the
 // network input X and the output gradient dz are fp32 (rounded on the way from LDS to the operand registers):
 //   1 = output layer (A = dz fp32, B = H bf16), 2 = hidden layer (both bf16), 3 = first layer (A = dZ bf16, B = X fp32).
-template <int MI, int NJ, int WM, int WN, int WK, int MODE>
+// SYN (bf16 hidden layer, the LAST hidden layer of a net): the gradient operand dZ = mask (.) (W_out^T dz) is not read from
+// memory -- the input-gradient pass does not store it -- but synthesised per tile from the 3-row output gradient, the
+// layer's ReLU mask and the output layer's weights, in the arithmetic of the input-gradient kernel's first step (operands
+// rounded to bf16, fp32 sum, result rounded to bf16): 1.3 KB instead of 12 KB per tile read here, 12 KB per tile not
+// written there (-0.6 GB per C3 step).  Each wave makes one or two 32-row blocks of the tile with one
+// MFMA each (a first form computed the values on the vector lanes, 300 instructions per thread and tile: the launch went
+// from 0.36 to 0.41 ms).
+template <int MI, int NJ, int WM, int WN, int WK, int MODE, bool SYN = false>
 __device__ __forceinline__ void wgrad_reg_body(const WgradArgs &W)
 {
     static_assert(MODE >= 1 && MODE <= 3, "f32 operands: mlp_wgrad_dma_kernel");
+    static_assert(!SYN || MODE == 2, "synthesis: the hidden-layer shape of the bf16 engine");
     constexpr bool A16 = MODE == 2 || MODE == 3, B16 = MODE == 1 || MODE == 2;
     constexpr int NW = WM * WN * WK, NT = 64 * NW;
     constexpr int RAP = WM * MI * 32, RBP = WN * NJ * 32;          // staged rows (padded to tiles)
     constexpr int BUF = (RAP + RBP) * LDS_STRIDE;                  // floats per LDS buffer
     constexpr int STRIDE16 = 20;                                   // floats per staged bf16 row (64 B + 16 B pad)
-    constexpr int LA = A16 ? 4 : RAP * 8 / NT, LB = B16 ? 4 : RBP * 8 / NT;       // 16-B loads per thread (bf16: one 64-B unit)
+    constexpr int LA = SYN ? 9 : A16 ? 4 : RAP * 8 / NT, LB = B16 ? 4 : RBP * 8 / NT;       // 16-B loads per thread (bf16: one 64-B unit)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, rl = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -318,6 +331,18 @@ __device__ __forceinline__ void wgrad_reg_body(const WgradArgs &W)
     // to be committed and tile t+2's HBM loads are in flight (two register sets, static names).  With
     // one tile of prefetch the 192x96 and 4x192 layers were latency-bound: their MFMA work per tile
     // (<= 4.6k cycles) is shorter than an HBM round trip under load.
+    // SYN: the B operand of the synthesis MFMA for the wave's two 32-row blocks: the output layer's weights of hidden row
+    // 32 (w + 4 j) + lane % 32 in slots 0..2 of lane half 0
+    bf16x8 syn_b[2];
+    if constexpr (SYN) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = 32 * (w + 4 * j) + rl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                syn_b[j][e] = (__bf16)((h == 0 && e < 3 && row < W.RA) ? W.syn_w[e * W.RA + row] : 0.f);
+        }
+    }
     float4 ga[2][LA], gb[2][LB];
     // Staging loads are range-checked BUFFER loads (out-of-range rows of a short operand read as
     // zero): no per-load branches, so the whole step is one basic block and hipcc keeps a COUNTED
@@ -338,9 +363,25 @@ __device__ __forceinline__ void wgrad_reg_body(const WgradArgs &W)
         // bf16 operand (row-quad layout, mlp_common.h: store_tiles_bf16): thread u < rows takes quad u / 4, samples
         // 8 (u % 4) .. + 7 -- four 16-B pieces of 2 samples x 4 rows each, piece k at + 64 k (so that four neighbouring
         // threads read a full 64-byte run per load)
+        if constexpr (SYN) {
+            const rsrc_t SZ = make_rsrc(W.syn_dz + (size_t)tc * W.syn_zrows * 32, live ? (unsigned)W.syn_zrows * 128u : 0u);
+            const rsrc_t SM = make_rsrc(W.syn_m + (size_t)tc * (RAP / 64) * 64, live ? (unsigned)(RAP / 64) * 256u : 0u);
+            // this lane's sample (lane % 32): dz rows 0..2 -- the A operand of the synthesis MFMA
+            ra[0] = make_float4(bload1(SZ, rl * 4, 0), bload1(SZ, rl * 4, 128), bload1(SZ, rl * 4, 256), 0.f);
+            // mask words of this lane's hidden row in the wave's 32-row blocks w and w + 4, at the 16 samples its accumulator
+            // registers hold (four runs of four consecutive samples: word [it >> 1][32 hh + s], csrc/mlp_bf16.hip)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int it = w + 4 * j, hh = (rl >> 2) & 1;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    ra[1 + 4 * j + g] = bload4(SM, (((it >> 1) * 64 + 32 * hh + 8 * g + 4 * h) * 4), 0);   // (block 6, 7: past the tile, zeros)
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < LA; ++k)
             ra[k] = A16 ? bload4(SA, (tid >> 2) * 256 + k * 64 + (tid & 3) * 16, 0) : bload4(SA, (tid + k * NT) * 16, 0);
+        }
 #pragma unroll
         for (int k = 0; k < LB; ++k) {
             if (B16) {
@@ -374,7 +415,46 @@ __device__ __forceinline__ void wgrad_reg_body(const WgradArgs &W)
     };
     auto commit = [&](int buf, const float4 (&ra)[LA], const float4 (&rb_)[LB]) {
         float *La = lds + buf * BUF, *Lb = La + RAP * (A16 ? STRIDE16 : LDS_STRIDE);
-        if (A16) {
+        if constexpr (SYN) {
+            // dZ^T[s][u] = sum_c dz[c][s] W_out[c][u] as ONE bf16 MFMA per 32-row block (k = the output channel, slots 0..2 of
+            // lane half 0): accumulator register r of lane (u, h) holds sample acc_row(r, h) of hidden row u -- masked, rounded
+            // to bf16 and written as four 8-byte runs of that row's staged line
+            bf16x8 a8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a8[e] = (__bf16)0.f;
+            if (h == 0) { a8[0] = (__bf16)ra[0].x; a8[1] = (__bf16)ra[0].y; a8[2] = (__bf16)ra[0].z; }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int it = w + 4 * j;
+                if (it < RAP / 32) {
+                    f32x16 d;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) d[r] = 0.f;
+                    d = mfma16(a8, syn_b[j], d);
+                    const int rr = (rl & 3) + 4 * (rl >> 3);
+                    const int bit = 8 * (it & 1) + (rr >> 1) + 16 * (rr & 1);                 // mask_bit16(it, rr)
+                    float *row = La + (32 * it + rl) * STRIDE16 + 2 * h;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 m4 = ra[1 + 4 * j + g];
+                        const unsigned mw[4] = {__float_as_uint(m4.x), __float_as_uint(m4.y), __float_as_uint(m4.z), __float_as_uint(m4.w)};
+                        unsigned pk[2];
+#pragma unroll
+                        for (int e2 = 0; e2 < 2; ++e2) {
+                            float v2[2];
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const int i4 = 2 * e2 + e;
+                                const int keep = ((int)(mw[i4] << (31 - bit))) >> 31;
+                                v2[e] = __int_as_float(__float_as_int(d[4 * g + i4]) & keep);
+                            }
+                            pk[e2] = __builtin_bit_cast(unsigned short, (__bf16)v2[0]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v2[1]) << 16);
+                        }
+                        *reinterpret_cast<float2 *>(row + 4 * g) = make_float2(__uint_as_float(pk[0]), __uint_as_float(pk[1]));
+                    }
+                }
+            }
+        } else if (A16) {
             quad_rows(La, RAP, ra);
         } else {
 #pragma unroll
@@ -753,11 +833,12 @@ __global__ void __launch_bounds__(320, 1) mlp_wgrad_uni192_kernel(WgradBatch WB)
 }
 // the bf16 engine's 192-wide jobs the same way (register-staged bodies, four waves each; UNI_FIRST192_X16: the first layer
 // reading the bf16 input tile).  Three launches + their fill / drain became one.
-enum { UNI_FIRST192_X16 = 3 };
+enum { UNI_FIRST192_X16 = 3, UNI_HID192_SYN = 4 };
 __global__ void __launch_bounds__(256, 1) mlp_wgrad_uni192b_kernel(WgradBatch WB)
 {
     const WgradArgs W = pick_job(WB);
     if (W.cfg == UNI_HID192) wgrad_reg_body<3, 3, 2, 2, 1, 2>(W);
+    else if (W.cfg == UNI_HID192_SYN) wgrad_reg_body<3, 3, 2, 2, 1, 2, true>(W);
     else if (W.cfg == UNI_FIRST192) wgrad_reg_body<3, 3, 2, 1, 2, 3>(W);
     else if (W.cfg == UNI_FIRST192_X16) wgrad_reg_body<3, 3, 2, 1, 2, 2>(W);
     else wgrad_reg_body<1, 3, 1, 2, 2, 1>(W);
@@ -967,7 +1048,7 @@ int launch_wgrad_any(WgradBatch &B, SlabPool &P)
 // output layer 12.8 KB); the fourth entry is the bf16 first layer on the bf16 input tile
 const double *uni_cost(int variant)
 {
-    static double c[3][4] = {{1.0, 0.5, 0.2, 0.5}, {1.0, 0.8, 0.6, 0.8}, {1.0, 1.0, 0.7, 0.9}};
+    static double c[3][5] = {{1.0, 0.5, 0.2, 0.5, 1.0}, {1.0, 0.8, 0.6, 0.8, 1.0}, {1.0, 1.0, 0.7, 0.9, 1.2}};      // (fifth: bf16 hidden layer with a synthesised dZ: half the bytes, but 1.2x the time per tile)
     static std::atomic<int> done{0};
     if (!done.load()) {
         const char *names[3] = {"ESR_WGRAD_COST", "ESR_WGRAD_COST_SPLIT", "ESR_WGRAD_COST_BF16"};
@@ -975,12 +1056,14 @@ const double *uni_cost(int variant)
             if (const char *e = std::getenv(names[k])) {
                 double a, b, d;
                 if (std::sscanf(e, "%lf,%lf,%lf", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0) { c[k][0] = a; c[k][1] = b; c[k][2] = d; c[k][3] = b; }
+
             }
+        if (const char *e5 = std::getenv("ESR_WGRAD_COST_SYN")) { const double v = std::atof(e5); if (v > 0) c[2][4] = v; }
         done.store(1);
     }
     return c[variant];
 }
-constexpr int uni_wk(int cfg) { return cfg == UNI_HID192 ? 1 : 2; }      // (both first-layer forms and the output layer: k split in two)
+constexpr int uni_wk(int cfg) { return (cfg == UNI_HID192 || cfg == 4 /* UNI_HID192_SYN */) ? 1 : 2; }      // (both first-layer forms and the output layer: k split in two)
 
 // workgroups per job proportional to tiles x cost (every job >= 1, none more than its tiles); slab regions back to back
 int plan_uni(WgradBatch &B, float *scratch, int64_t slab_floats, ReduceArgs &R, int64_t &used_out, int variant)
@@ -1381,7 +1464,12 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
             W.t0 = J.t0; W.t1 = J.t1;
             W.gw = J.gw[l]; W.ld = first ? D.in_dim : hid; W.out_rows = last ? D.out_dim : hid;
             W.kind = J.kind; W.first = first ? 1 : 0; W.gb = J.gb[l];
-            if (!W.A || !W.B || !W.gw || !W.gb) return ESR_EINVAL;
+            // the last hidden layer's gradient operand synthesised in the kernel (bf16 engine, 192-wide nets): dZ[l] is not read
+            const bool syn = BF && !first && !last && l == D.n_layers - 2 && hid == 192 && J.M_last && J.W_last && uni_on();
+            if (syn) {
+                W.A = nullptr; W.syn_dz = J.dz; W.syn_m = J.M_last; W.syn_w = J.W_last; W.syn_zrows = D.zrows;
+            }
+            if ((!W.A && !syn) || !W.B || !W.gw || !W.gb) return ESR_EINVAL;
             int c = layer_cfg(D, first, last, W.RB);
             if (BF && first && J.X16 && J.kind == ESR_MLP_RADIANCE) {
                 if (J.color_row0 != 0) return ESR_EINVAL;          // (the bf16 tile's alternate colour rows are the forward's only)
@@ -1390,7 +1478,7 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
                 c = CFG_FIRST192_X16;
             }
             if (uni_on() && (c == CFG_HID192 || c == CFG_FIRST192 || c == CFG_OUT192 || (BF && c == CFG_FIRST192_X16))) {
-                W.cfg = c == CFG_HID192 ? UNI_HID192 : c == CFG_FIRST192 ? UNI_FIRST192 : c == CFG_OUT192 ? UNI_OUT192 : UNI_FIRST192_X16;
+                W.cfg = c == CFG_HID192 ? (syn ? UNI_HID192_SYN : UNI_HID192) : c == CFG_FIRST192 ? UNI_FIRST192 : c == CFG_OUT192 ? UNI_OUT192 : UNI_FIRST192_X16;
                 W.amax = BF ? nullptr : J.amax;                    // non-NULL: the split-fp16 kernel (esr_hip.h)
                 const bool sp = !BF && J.amax != nullptr;
                 if (n_uni == 0 || uni[n_uni - 1].n == MAX_JOBS || uni_split[n_uni - 1] != sp) {

@@ -126,6 +126,12 @@ class FineEngine:
         self._events = []
         self.n_calls = 0
         self.overlap_wgrad = os.environ.get("ESR_OVERLAP_WGRAD", "1") != "0"
+        # ESR_SYN_DZ=1 (bf16 engine, radiance nets; OFF by default, measured): the last hidden layer's dZ tile is neither stored
+        # nor read -- synthesised in the unified weight-gradient launch (csrc/mlp.hip: wgrad_reg_body<..., SYN>; needs
+        # ESR_WGRAD_UNI).  C3 bf16: -0.59 GB of HBM traffic per step, input gradients 0.205 -> 0.175 ms, but a synthesised tile
+        # costs the weight-gradient launch 1.2x a stored one (its MFMA + mask + pack chain sits in the staging step, in front
+        # of the tile's barrier): 0.36 -> 0.41 ms with the best workgroup shares -- the step does not get faster.
+        self.syn_dz = (self.bf16 and os.environ.get("ESR_SYN_DZ", "0") != "0" and os.environ.get("ESR_WGRAD_UNI", "1") != "0")
         self.tone_wgrad_early = os.environ.get("ESR_TONE_WGRAD_EARLY", "0") != "0"       # (A/B switch, OFF: backward())
         # f32 engine: the three radiance forward passes of a step as ONE launch (esr_mlp_fwd_fine) and the two radiance
         # input-gradient passes as one (esr_mlp_dgrad_fine); ESR_MERGE_RAD=0 keeps the separate launches (A/B timing)
@@ -684,6 +690,9 @@ class FineEngine:
                 jb.gw, jb.gb = C.addressof(gwa), C.addressof(gba)
                 if getattr(ctx, "x16", False) and kind == KIND_RADIANCE:
                     jb.X16 = ws["X16"].data_ptr()
+                if self.syn_dz and kind == KIND_RADIANCE:
+                    jb.M_last = ws["M2"].data_ptr()
+                    jb.W_last = self._raw["emo" if gwk == "emo_w" else "off"][0][3].data_ptr()
                 if self.split_wgrad and kind == KIND_RADIANCE and getattr(ctx, "amax", None) is not None:
                     if not ctx.amax_set:        # (the f32 input-gradient kernels ran: one small reduction over dz)
                         self._run("absmax(dz)", L.esr_absmax, _lib.ptr(ws["dz"]), C.c_int64(ta * 4 * 32), _lib.ptr(ctx.amax), s_)
@@ -728,7 +737,10 @@ class FineEngine:
         self._run("tone_in_bwd", L.esr_fine_tone_in_bwd, _lib.ptr(ws["dXt"]), _lib.ptr(ws["Xt"]), _lib.ptr(g_lin), _lib.ptr(ws["lin"]),
                   _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), to, ta,
                   _lib.ptr(ws["dz"]), s)
-        M, dZ = self._H(["M0", "M1", "M2"]), self._H(["dZ0", "dZ1", "dZ2"])
+        M = self._H(["M0", "M1", "M2"])
+        # bf16 engine: the last hidden layer's dZ is synthesised inside the weight-gradient kernel (esr_wgrad_job_t::M_last /
+        # W_last), so the input-gradient pass does not store it
+        dZ = _lib.ptr_array([ws["dZ0"], ws["dZ1"], None]) if self.syn_dz else self._H(["dZ0", "dZ1", "dZ2"])
         if self.merge_rad and scat is None:                        # both radiance nets' input gradients: one launch
             if self.bf16:
                 pe, po = _lib.ptr(self.packed["emo"]), _lib.ptr(self.packed["off"])

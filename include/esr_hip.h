@@ -443,6 +443,12 @@ typedef struct esr_wgrad_job {
      * the same fp32 operands, every value cut into two fp16 planes on its way into the 16-bit matrix cores, fp32
      * accumulation; the gradient operand is scaled by a power of two derived from *amax (csrc/mlp.hip, SPLIT). */
     const float *amax;
+    /* optional (bf16 operands, ESR_MLP_RADIANCE): the ReLU masks of the LAST hidden layer [tiles][3][64] and the output layer's
+     * weights [3][192] (reference layout).  With both set, that layer's gradient operand is synthesised per tile inside the
+     * kernel (mask (.) W_out^T dz, the input-gradient kernel's arithmetic) and dZ[n_layers - 2] is not read: it may be NULL,
+     * and the input-gradient pass may skip storing it (a NULL dZ[l] there). */
+    const uint32_t *M_last;
+    const float *W_last;
 } esr_wgrad_job_t;
 int esr_mlp_wgrad_batch(const esr_wgrad_job_t *jobs, int32_t n_jobs, int bf16_operands, float *scratch,
                         int64_t scratch_floats, void *stream);
