@@ -599,8 +599,23 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradBa
 // Accuracy: tests/test_gpu_split.py (vs float64: as the f32 MFMA kernel).  Cost: 8 samples per lane and operand row are
 // converted by ~4 VALU instructions each -- the kernel is HBM-bound with them.
 typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+// two values -> one register of each plane in four instructions: the pair's first halves (v_cvt_pk_f16_f32), the two residuals
+// v - (float)h1 by v_fma_mix_f32 straight from the packed half (exact), their halves.  (hipcc's own code for the C form
+// unpacks the first halves with two more conversions; one asm statement: between two of them it puts an s_nop.)  Used by
+// the synthesising kernel, whose loop has more VALU work than the stored-operand kernels'.
+__device__ __forceinline__ void wg_split2(float v0, float v1, unsigned &p1, unsigned &p2)
+{
+    float d0, d1;
+    asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+        "v_fma_mix_f32 %2, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %3, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_cvt_pk_f16_f32 %1, %2, %3"
+        : "=&v"(p1), "=v"(p2), "=&v"(d0), "=&v"(d1) : "v"(v0), "v"(v1));
+}
 __device__ __forceinline__ void wg_split8(const float4 &lo, const float4 &hi, float s, wg_f16x8 &p1, wg_f16x8 &p2)
 {
+    // (C form: with wg_split2 here the loop has 13 % fewer instructions and the launch takes the same time -- it waits for HBM)
     const float v[8] = {lo.x * s, lo.y * s, lo.z * s, lo.w * s, hi.x * s, hi.y * s, hi.z * s, hi.w * s};
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -624,12 +639,19 @@ __device__ __forceinline__ float wg_scale(float amax)
     return ldexpf(1.f, e);
 }
 
-template <int MI, int NJ, int WM, int WN, int WK, bool SPLIT = false>
+// SYN (with SPLIT, the hidden shape, the LAST hidden layer of a 192-wide net): the gradient operand dZ = mask (.) (W_out^T dz)
+// is not read from memory -- the input-gradient pass does not store it -- but made by the compute waves from the tile's
+// output gradient (512 B), the layer's ReLU mask (768 B; both staged by the loader as two 1-KiB pieces in the A region) and
+// the output layer's weights (fp16 planes in LDS): one split-fp16 MFMA per 32 hidden rows and k-step, whose accumulator
+// layout IS the layout of the weight-gradient MFMA's A operand.  24 KB per tile less to read here and to write there.
+template <int MI, int NJ, int WM, int WN, int WK, bool SPLIT = false, bool SYN = false>
 __device__ __forceinline__ void wgrad_dma_body(const WgradArgs &W)
 {
+    static_assert(!SYN || (SPLIT && WK == 1), "synthesis: the split hidden-layer shape");
     constexpr int NW = WM * WN * WK;                 // compute waves (one per SIMD); wave NW is the loader
     constexpr int RAP = WM * MI * 32, RBP = WN * NJ * 32, ROWS = RAP + RBP;
     constexpr int PIECES = ROWS / 8;                 // 1-KiB pieces (8 rows x 128 B) per tile
+    constexpr int NPIECE = SYN ? 2 + RBP / 8 : PIECES;       // pieces the loader actually issues per tile
     static_assert(PIECES <= 60, "the loader counts a whole tile on vmcnt");
     constexpr int BUF = ROWS * 32;                   // floats per LDS buffer
     constexpr int NU = 4 / WK;                       // 8-sample groups per compute wave per tile
@@ -642,6 +664,18 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs &W)
 
     // rows that no DMA ever fills (operands shorter than the staged block) must not hold NaN patterns
     for (int i = tid; i < 3 * BUF; i += 64 * (NW + 1)) lds[i] = 0.f;
+    if constexpr (SYN) {
+        // the output layer's weights as (64 w) fp16 planes behind the tile buffers: [hidden row][plane][8 k-slots, 0..2 used]
+        _Float16 *wp = reinterpret_cast<_Float16 *>(lds + 3 * BUF);
+        for (int i = tid; i < RAP * 16; i += 64 * (NW + 1)) {
+            // lane half 0: k-slots (w1 | w1), half 1: (w2 | 0) -- against the dz operand's (z1 | z2) and (z1 | 0): ONE MFMA
+            // sums z1 w1 + z2 w1 + z1 w2
+            const int row = i >> 4, pl = (i >> 3) & 1, k = i & 7, c = k < 3 ? k : k - 3;
+            const float wv = (k < (pl ? 3 : 6) && row < W.RA) ? 64.f * W.syn_w[c * W.RA + row] : 0.f;
+            const _Float16 h1 = (_Float16)wv;
+            wp[i] = pl == 0 ? h1 : (_Float16)(wv - (float)h1);
+        }
+    }
     __syncthreads();
 
     // Barrier schedule, identical in every wave: one before the first tile, then one in the MIDDLE of every tile.
@@ -661,19 +695,30 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs &W)
                                       live ? (unsigned)W.RA * 128u : 0u);
             const u32x4 SB = raw_rsrc(reinterpret_cast<const char *>(W.B) + (size_t)tc * W.b_tile_rows * 128u,
                                       live ? (unsigned)W.b_tile_rows * 128u : 0u);
+            // SYN: image rows 0..7 = the dz tile (rows past zrows: zeros), rows 8..15 = the mask tile (6 rows of 128 B)
+            const u32x4 SZ = raw_rsrc(reinterpret_cast<const char *>(W.syn_dz) + (size_t)tc * W.syn_zrows * 128u,
+                                      (SYN && live) ? (unsigned)W.syn_zrows * 128u : 0u);
+            const u32x4 SM = raw_rsrc(reinterpret_cast<const char *>(W.syn_m) + (size_t)tc * (RAP / 64) * 256u,
+                                      (SYN && live) ? (unsigned)(RAP / 64) * 256u : 0u);
 #pragma unroll
             for (int p = 0; p < PIECES; ++p) {
                 const int R = 8 * p + (lane >> 3);                       // row of the staged image
                 const int c = (lane & 7) ^ ((R >> 1) & 7);               // source chunk of this LDS slot
                 int row = R;                                             // A rows >= RA fail the range check
                 if (8 * p >= RAP) row = (R - RAP < cw) ? R - RAP + W.crow : R - RAP;   // first layer: colour rows
-                lds_dma16(8 * p < RAP ? SA : SB, lds0 + (unsigned)(fb * BUF + p * 256) * 4u, row * 128 + c * 16);
+                if constexpr (SYN) {
+                    if (p == 0) lds_dma16(SZ, lds0 + (unsigned)(fb * BUF + p * 256) * 4u, R * 128 + c * 16);
+                    else if (p == 1) lds_dma16(SM, lds0 + (unsigned)(fb * BUF + p * 256) * 4u, (R - 8) * 128 + c * 16);
+                    else if (8 * p >= RAP) lds_dma16(SB, lds0 + (unsigned)(fb * BUF + p * 256) * 4u, row * 128 + c * 16);
+                } else {
+                    lds_dma16(8 * p < RAP ? SA : SB, lds0 + (unsigned)(fb * BUF + p * 256) * 4u, row * 128 + c * 16);
+                }
             }
         };
         int t = W.t0 + split;
         load_tile(t, 0);
         load_tile(t + nsplit, 1);
-        __builtin_amdgcn_s_waitcnt(wait_vm(PIECES));
+        __builtin_amdgcn_s_waitcnt(wait_vm(NPIECE));
         __builtin_amdgcn_s_barrier();
         for (int fb = 2; t < W.t1; t += nsplit) {
             __builtin_amdgcn_s_waitcnt(wait_vm(0));
@@ -719,25 +764,91 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs &W)
             hi = *reinterpret_cast<const float4 *>(lds + buf * BUF + row0 + c1);
         };
         float4 ral[MI], rah[MI], rbl[2], rbh[2];
-        __builtin_amdgcn_s_barrier();
+        // SYN: dZ^T[s][u] = sum_c dz[c][s] W_out[c][u] as split-fp16 MFMAs with k = the output channel (slots 0..2 of lane
+        // half 0): accumulator register r of lane (u, h) holds sample acc_row(r, h) = 4 (2 (r >> 2) + h) + (r & 3) of hidden row
+        // u -- EXACTLY the eight samples per k-step this lane feeds into the weight-gradient MFMAs (k-step ks: registers
+        // 8 ks .. 8 ks + 7).  Operands: (sc dz) planes from the staged dz tile, (64 W_out) planes from LDS (written once at the
+        // kernel's start), both planes in the 16 k-slots of ONE instruction; the result 64 sc dZ is masked with the staged
+        // mask words and cut into the A planes.
+        const int mbit0 = (rl & 3) + 4 * (rl >> 3), mrow0 = 32 * ((rl >> 2) & 1);          // lane part of the mask bit / word index
+        const _Float16 *w3p = reinterpret_cast<const _Float16 *>(lds + 3 * BUF);           // [RAP rows][2 planes][8]
+        float bsum_s[MI];                                      // bias gradients of the synthesised operand, scaled by 64 sc
 #pragma unroll
-        for (int i = 0; i < MI; ++i) read2(0, 0, a_row + i * 32 * 32, ral[i], rah[i]);
+        for (int i = 0; i < MI; ++i) bsum_s[i] = 0.f;
+        __builtin_amdgcn_s_barrier();
+        if constexpr (!SYN) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) read2(0, 0, a_row + i * 32 * 32, ral[i], rah[i]);
+        }
         read2(0, 0, b_row, rbl[0], rbh[0]);
         int t = W.t0 + split;
         for (int buf = 0; t < W.t1; t += nsplit) {
             const int nb = buf == 2 ? 0 : buf + 1;
+            wg_f16x8 za;                                       // SYN: (sc dz)^T of sample rl of this tile: k-slots (z1 | z2) / (z1 | 0)
+            if constexpr (SYN) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) za[e] = (_Float16)0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float z = sc * lds[buf * BUF + c * 32 + (((rl >> 2) ^ ((c >> 1) & 7)) * 4) + (rl & 3)];
+                    const _Float16 h1 = (_Float16)z;
+                    za[c] = h1;
+                    za[3 + c] = h == 0 ? (_Float16)(z - (float)h1) : (_Float16)0.f;
+                }
+            }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (ks == KS - 1) __builtin_amdgcn_s_barrier();          // the next tile has landed (see the schedule above)
                 const int nbuf = ks + 1 < KS ? buf : nb, nks = ks + 1 < KS ? ks + 1 : 0;
+                // (SYN: the operand is made here, from the tile in work, not a k-step ahead: the kernel sits at 256 registers)
                 wg_f16x8 a1[MI], a2[MI];
+                if constexpr (SYN) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        const int it = wm * MI + i, mbit = (it & 1) * 16 + mbit0;
+                        // (read here, a latency before their use: fetched one block ahead they cost 12 registers the kernel does not
+                        //  have -- 15 spills, 0.56 -> 0.63 ms)
+                        const wg_f16x8 wb = __builtin_bit_cast(wg_f16x8, *reinterpret_cast<const float4 *>(w3p + ((it * 32 + rl) * 2 + h) * 8));
+                        f32x16 d;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) d[r] = 0.f;
+                        d = wg_mfma_f16(za, wb, d);
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            const int sb = 4 * (4 * ks + 2 * g + h);
+                            const int widx = (it >> 1) * 64 + mrow0 + sb, Rsl = 8 + (widx >> 5);
+                            const float4 m4 = *reinterpret_cast<const float4 *>(lds + buf * BUF + Rsl * 32 + ((((widx >> 2) & 7) ^ ((Rsl >> 1) & 7)) * 4));
+                            const unsigned mw[4] = {__float_as_uint(m4.x), __float_as_uint(m4.y), __float_as_uint(m4.z), __float_as_uint(m4.w)};
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int keep = ((int)(mw[e] << (31 - mbit))) >> 31;
+                                v[e] = __int_as_float(__float_as_int(d[8 * ks + 4 * g + e]) & keep);                // 64 sc dZ
+                                bsum_s[i] += v[e];
+                                v[e] *= 1.f / 64.f;
+                            }
+                            unsigned q1[2], q2[2];
+                            wg_split2(v[0], v[1], q1[0], q2[0]);
+                            wg_split2(v[2], v[3], q1[1], q2[1]);
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const f16x2_t x1 = __builtin_bit_cast(f16x2_t, q1[e]), x2 = __builtin_bit_cast(f16x2_t, q2[e]);
+                                a1[i][4 * g + 2 * e] = x1[0]; a1[i][4 * g + 2 * e + 1] = x1[1];
+                                a2[i][4 * g + 2 * e] = x2[0]; a2[i][4 * g + 2 * e + 1] = x2[1];
+                            }
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     bsum[i] += ((ral[i].x + ral[i].y) + (ral[i].z + ral[i].w)) + ((rah[i].x + rah[i].y) + (rah[i].z + rah[i].w));
                     wg_split8(ral[i], rah[i], sc, a1[i], a2[i]);
                 }
+                }
+                if constexpr (!SYN) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i) read2(nbuf, nks, a_row + i * 32 * 32, ral[i], rah[i]);     // (stale but unused after the last tile)
+                    for (int i = 0; i < MI; ++i) read2(nbuf, nks, a_row + i * 32 * 32, ral[i], rah[i]); // (stale but unused after the last tile)
+                }
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     wg_f16x8 b1, b2;
@@ -754,6 +865,10 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs &W)
                 }
             }
             buf = nb;
+        }
+        if constexpr (SYN) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) bsum[i] = bsum_s[i] * (osc * (1.f / 64.f));
         }
     } else {
     float4 a0[MI], b0[NJ], a1[MI], b1[NJ];
@@ -850,6 +965,13 @@ __global__ void __launch_bounds__(320, 1) mlp_wgrad_uni192s_kernel(WgradBatch WB
     if (W.cfg == UNI_HID192) wgrad_dma_body<3, 3, 2, 2, 1, true>(W);
     else if (W.cfg == UNI_FIRST192) wgrad_dma_body<3, 3, 2, 1, 2, true>(W);
     else wgrad_dma_body<1, 3, 1, 2, 2, true>(W);
+}
+
+// The hidden-layer jobs whose gradient operand is synthesised (wgrad_dma_body<..., SYN>) get a launch of their own: inside the
+// unified kernel their register need (beside the loader wave: 256 per wave) spilled 19 registers and slowed every job of it.
+__global__ void __launch_bounds__(320, 1) mlp_wgrad_syn192s_kernel(WgradBatch WB)
+{
+    wgrad_dma_body<3, 3, 2, 2, 1, true, true>(pick_job(WB));
 }
 
 // gw[e] += sum over the partial slabs of every job of a launch; 32 slabs per thread, groups combined with one atomic
@@ -1048,7 +1170,7 @@ int launch_wgrad_any(WgradBatch &B, SlabPool &P)
 // output layer 12.8 KB); the fourth entry is the bf16 first layer on the bf16 input tile
 const double *uni_cost(int variant)
 {
-    static double c[3][5] = {{1.0, 0.5, 0.2, 0.5, 1.0}, {1.0, 0.8, 0.6, 0.8, 1.0}, {1.0, 1.0, 0.7, 0.9, 1.2}};      // (fifth: bf16 hidden layer with a synthesised dZ: half the bytes, but 1.2x the time per tile)
+    static double c[3][5] = {{1.0, 0.5, 0.2, 0.5, 1.0}, {1.0, 0.8, 0.6, 0.8, 0.75}, {1.0, 1.0, 0.7, 0.9, 1.2}};      // (fifth: bf16 hidden layer with a synthesised dZ: half the bytes, but 1.2x the time per tile)
     static std::atomic<int> done{0};
     if (!done.load()) {
         const char *names[3] = {"ESR_WGRAD_COST", "ESR_WGRAD_COST_SPLIT", "ESR_WGRAD_COST_BF16"};
@@ -1151,6 +1273,23 @@ int launch_wgrad_uni(WgradBatch &B, SlabPool &P)
     if (V == 1) mlp_wgrad_uni192s_kernel<<<grid, 320, lds_bytes, s>>>(B);
     else if (V == 2) mlp_wgrad_uni192b_kernel<<<grid, 256, lds_bytes, s>>>(B);
     else mlp_wgrad_uni192_kernel<<<grid, 320, lds_bytes, s>>>(B);
+    ESR_CHECK_LAUNCH();
+    return P.launched(R, n);
+}
+
+int launch_wgrad_syn(WgradBatch &B, SlabPool &P)
+{
+    hipStream_t s = P.s;
+    for (int j = 0; j < B.n; ++j)
+        if (B.job[j].RA > 192 || B.job[j].RB > 192) return ESR_ECAP;
+    constexpr size_t lds_bytes = 3 * (size_t)(192 + 192) * 32 * sizeof(float) + 192 * 16 * sizeof(_Float16);   // + the W_out planes
+    static std::atomic<uint64_t> optin{0};
+    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_wgrad_syn192s_kernel), lds_bytes, optin)) return rc;
+    ReduceArgs R;
+    int64_t n = 0;
+    const int grid = P.place([&](float *sc, int64_t fl, ReduceArgs &R_, int64_t &n_) { return plan_batch<1>(B, sc, fl, R_, n_); }, R, n);
+    if (grid < 0) return grid;
+    mlp_wgrad_syn192s_kernel<<<grid, 320, lds_bytes, s>>>(B);
     ESR_CHECK_LAUNCH();
     return P.launched(R, n);
 }
@@ -1442,6 +1581,8 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
     WgradBatch uni[MAX_UNI];
     bool uni_split[MAX_UNI];
     int n_uni = 0;
+    WgradBatch synb;
+    synb.n = 0;
     for (int v = 0; v < 2; ++v)
         for (int c = 0; c < N_CFG; ++c)
             for (int g = 0; g < 4; ++g) group[v][c][g].n = 0;
@@ -1465,7 +1606,7 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
             W.gw = J.gw[l]; W.ld = first ? D.in_dim : hid; W.out_rows = last ? D.out_dim : hid;
             W.kind = J.kind; W.first = first ? 1 : 0; W.gb = J.gb[l];
             // the last hidden layer's gradient operand synthesised in the kernel (bf16 engine, 192-wide nets): dZ[l] is not read
-            const bool syn = BF && !first && !last && l == D.n_layers - 2 && hid == 192 && J.M_last && J.W_last && uni_on();
+            const bool syn = (BF || J.amax) && !first && !last && l == D.n_layers - 2 && hid == 192 && J.M_last && J.W_last && uni_on();
             if (syn) {
                 W.A = nullptr; W.syn_dz = J.dz; W.syn_m = J.M_last; W.syn_w = J.W_last; W.syn_zrows = D.zrows;
             }
@@ -1480,6 +1621,11 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
             if (uni_on() && (c == CFG_HID192 || c == CFG_FIRST192 || c == CFG_OUT192 || (BF && c == CFG_FIRST192_X16))) {
                 W.cfg = c == CFG_HID192 ? (syn ? UNI_HID192_SYN : UNI_HID192) : c == CFG_FIRST192 ? UNI_FIRST192 : c == CFG_OUT192 ? UNI_OUT192 : UNI_FIRST192_X16;
                 W.amax = BF ? nullptr : J.amax;                    // non-NULL: the split-fp16 kernel (esr_hip.h)
+                if (syn && !BF) {                                  // f32 operands: a launch of its own (mlp_wgrad_syn192s_kernel)
+                    if (synb.n == MAX_JOBS) return ESR_ECAP;
+                    synb.job[synb.n++] = W;
+                    continue;
+                }
                 const bool sp = !BF && J.amax != nullptr;
                 if (n_uni == 0 || uni[n_uni - 1].n == MAX_JOBS || uni_split[n_uni - 1] != sp) {
                     if (n_uni == MAX_UNI) return ESR_ECAP;
@@ -1504,6 +1650,8 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
     SlabPool P(scratch, scratch_floats, esr_stream(stream));
     for (int u = 0; u < n_uni; ++u)
         if (int rc = BF ? launch_wgrad_uni<2>(uni[u], P) : uni_split[u] ? launch_wgrad_uni<1>(uni[u], P) : launch_wgrad_uni<0>(uni[u], P)) return rc;
+    if (synb.n)
+        if (int rc = launch_wgrad_syn(synb, P)) return rc;
     for (int c = 0; c < N_CFG; ++c) {
         for (int g = 0; g < n_group[0][c]; ++g)
             if (int rc = launch_cfg<BF ? 1 : 0>(c, group[0][c][g], P)) return rc;

@@ -132,6 +132,9 @@ class FineEngine:
         # costs the weight-gradient launch 1.2x a stored one (its MFMA + mask + pack chain sits in the staging step, in front
         # of the tile's barrier): 0.36 -> 0.41 ms with the best workgroup shares -- the step does not get faster.
         self.syn_dz = (self.bf16 and os.environ.get("ESR_SYN_DZ", "0") != "0" and os.environ.get("ESR_WGRAD_UNI", "1") != "0")
+        # (f32 engine with split weight gradients: the same switch, mlp_wgrad_syn192s_kernel; C2: input gradients 0.39 -> 0.34 ms,
+        #  weight gradients 0.47 -> 0.56 ms, step 2.03 -> 2.06 ms -- OFF)
+        self._syn_dz32_env = os.environ.get("ESR_SYN_DZ", "0") != "0" and os.environ.get("ESR_WGRAD_UNI", "1") != "0"
         self.tone_wgrad_early = os.environ.get("ESR_TONE_WGRAD_EARLY", "0") != "0"       # (A/B switch, OFF: backward())
         # f32 engine: the three radiance forward passes of a step as ONE launch (esr_mlp_fwd_fine) and the two radiance
         # input-gradient passes as one (esr_mlp_dgrad_fine); ESR_MERGE_RAD=0 keeps the separate launches (A/B timing)
@@ -180,6 +183,8 @@ class FineEngine:
         self.split_wgrad = self.split_bwd and os.environ.get("ESR_SPLIT_WGRAD", "1") != "0"
         # ... and the tone mapper's weight gradients by recomputation (csrc/tone_wgrad.hip: tone_wgrad_split_t_kernel)
         self.split_tone_wgrad = self.split_wgrad and os.environ.get("ESR_SPLIT_TONE_WGRAD", "1") != "0"
+        if self.split_wgrad and self._syn_dz32_env:        # (f32 engine: the same switch, the split weight-gradient launch's form)
+            self.syn_dz = True
         self.tone_scratch = torch.empty(self.L.esr_tone_wgrad_scratch_floats() if self.tone_recompute else 1,
                                         dtype=torch.float32, device=self.device)
         self.neus_grad = False          # cfg neus_alpha: "grad" (set by the renderer)
