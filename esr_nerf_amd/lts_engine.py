@@ -163,6 +163,8 @@ class LtsEngine(FineEngine):
         self.sec = Pass(self.device, "secondary")
         self.epsp = Pass(self.device, "eps")
         self._wgrad_jobs = None
+        # ESR_LTS_WGRAD_EARLY: flush points of the batched weight gradients inside the backward (_flush_wgrad); "" = all at the end
+        self.wgrad_early = {int(v) for v in os.environ.get("ESR_LTS_WGRAD_EARLY", "1,2").split(",") if v.strip()}
         for k, kind in (("brdf", KIND_BRDF), ("emit", KIND_EMIT)):
             self.packed[k] = torch.empty(self.L.esr_mlp_packed_floats(kind), dtype=torch.float32,
                                          device=self.device)
@@ -974,17 +976,19 @@ class LtsEngine(FineEngine):
         a second stream (or, without ``overlap_wgrad``, after it) and are joined at the end."""
         main = torch.cuda.current_stream(self.device)
         self._wgrad_jobs, self._wgrad_extra = [], []
+        self._wgrad_flushed = False
         try:
             self._lts_backward(ctx, g, grads)
             jobs_done = None
-            if self._wgrad_jobs:
+            if self._wgrad_jobs or self._wgrad_extra or self._wgrad_flushed:
                 if self.overlap_wgrad:          # beside the dense-grid exchange / whatever follows on the main stream
                     side = self._side_stream()
                     ev = torch.cuda.Event()
                     ev.record(main)
                     side.wait_event(ev)
                     with torch.cuda.stream(side):
-                        self._launch_wgrad_jobs()
+                        if self._wgrad_jobs or self._wgrad_extra:
+                            self._launch_wgrad_jobs()
                         jobs_done = torch.cuda.Event()
                         jobs_done.record(side)
                 else:
@@ -998,6 +1002,21 @@ class LtsEngine(FineEngine):
                 main.wait_event(jobs_done)
         finally:
             self._wgrad_jobs = None
+
+    def _flush_wgrad(self, point):
+        """Inside ``_lts_backward``: send the weight-gradient jobs collected so far to the second stream NOW, so that they run
+        beside the grid scatters that follow on the main stream (march_bwd + feat_bwd: LDS / L2 atomics, the matrix cores idle)
+        instead of after them.  ``point``: 1 = behind the secondary pass's input gradients, 2 = behind the primary pass's."""
+        if not (self.overlap_wgrad and point in self.wgrad_early and (self._wgrad_jobs or self._wgrad_extra)):
+            return
+        main, side = torch.cuda.current_stream(self.device), self._side_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            self._launch_wgrad_jobs()
+        self._wgrad_jobs, self._wgrad_extra = [], []
+        self._wgrad_flushed = True
 
     def _launch_wgrad_jobs(self):
         jobs = self._wgrad_jobs
@@ -1014,8 +1033,9 @@ class LtsEngine(FineEngine):
             jb.X, jb.dz = x.data_ptr(), dz.data_ptr()
             jb.H, jb.dZ, jb.gw, jb.gb = (C.addressof(p) for p in ptrs)
             dz.record_stream(torch.cuda.current_stream(self.device))      # may be a transient allocation of the main stream
-        self._run("mlp_wgrad(all)", self.L.esr_mlp_wgrad_batch, arr, len(jobs), 1 if self.bf16 else 0,
-                  _lib.ptr(self.wgrad_scratch), C.c_int64(self.wgrad_scratch.numel()), self._s())
+        if jobs:
+            self._run("mlp_wgrad(all)", self.L.esr_mlp_wgrad_batch, arr, len(jobs), 1 if self.bf16 else 0,
+                      _lib.ptr(self.wgrad_scratch), C.c_int64(self.wgrad_scratch.numel()), self._s())
         for fn, dz in self._wgrad_extra:
             dz.record_stream(torch.cuda.current_stream(self.device))
             fn()
@@ -1058,6 +1078,7 @@ class LtsEngine(FineEngine):
             for (nm, crow, gon), dz in zip((("off", 0, grads["off"]), ("emo", 88, grads["emo"])), dzs):
                 dX = self._net_bwd(P2, nm, KIND_RADIANCE, crow, 0, T2, dz, grads[f"{nm}_w"], grads[f"{nm}_b"])
                 src.append((dX, None, gon, 0, T2))
+            self._flush_wgrad(1)
             # the secondary march's value-tap gradients of the recorded samples ride on the feature backward's window
             ds2 = P2.buf("dsdf")
             wrote = self._march_bwd("march_bwd[secondary]", P2, sp2, ctx.t["o2"], ctx.t["d2"], Pn * R, ctx.t["off3_2"], dw2,
@@ -1115,6 +1136,7 @@ class LtsEngine(FineEngine):
                     grads["brdf"], grads["brdf"], 0, T))
         src.append((self._net_bwd(P0, "emit", KIND_EMIT, 88, 0, T, dze, grads["emit_w"], grads["emit_b"]),
                     grads["emo"], grads["emo"], 0, T))
+        self._flush_wgrad(2)
         self._march_bwd("march_bwd", P0, sp, b["rays_o"], b["rays_d"], P0.n_rays, ctx.t["off3"], dweight, g_last,
                         grads["sdf"], dsdf_extra, 1)
         # exact normals (linear in the grid): the gradient of etc/normal is scattered inside the feature backward (same

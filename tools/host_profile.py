@@ -40,13 +40,23 @@ for _ in range(5):
     run()
 torch.cuda.synchronize()
 import gc; gc.collect(); gc.freeze(); gc.disable()
+# time the host spends WAITING for the device inside a step (the plan read-backs): the rest of `host returned after` is work
+_wait = [0.0]
+_sync = torch.cuda.Event.synchronize
+def _timed_sync(self):
+    t = time.perf_counter()
+    _sync(self)
+    _wait[0] += time.perf_counter() - t
+torch.cuda.Event.synchronize = _timed_sync
 t0 = time.perf_counter()
 for _ in range(a.steps):
     run()
 t_host = time.perf_counter() - t0
 torch.cuda.synchronize()
 t_all = time.perf_counter() - t0
-print(f"{a.config}: {t_all / a.steps * 1e3:.3f} ms per step, host returned after {t_host / a.steps * 1e3:.3f} ms per step")
+torch.cuda.Event.synchronize = _sync
+print(f"{a.config}: {t_all / a.steps * 1e3:.3f} ms per step, host returned after {t_host / a.steps * 1e3:.3f} ms per step, "
+      f"of which {_wait[0] / a.steps * 1e3:.3f} ms waiting in Event.synchronize (host work: {(t_host - _wait[0]) / a.steps * 1e3:.3f} ms)")
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(a.steps):
