@@ -163,8 +163,10 @@ class LtsEngine(FineEngine):
         self.sec = Pass(self.device, "secondary")
         self.epsp = Pass(self.device, "eps")
         self._wgrad_jobs = None
-        # ESR_LTS_WGRAD_EARLY: flush points of the batched weight gradients inside the backward (_flush_wgrad); "" = all at the end
-        self.wgrad_early = {int(v) for v in os.environ.get("ESR_LTS_WGRAD_EARLY", "1,2").split(",") if v.strip()}
+        # ESR_LTS_WGRAD_EARLY: flush points of the batched weight gradients inside the backward (_flush_wgrad; "" = all at the
+        # end).  C5 pdra bf16, 100 steps x 3 on one box: none 3.45 ms, "1,2" 3.39, "1,2,3" 3.33; with 4 and 5 too: -0.6 %,
+        # inside the noise, for two more batched calls per step -- not taken.
+        self.wgrad_early = {int(v) for v in os.environ.get("ESR_LTS_WGRAD_EARLY", "1,2,3").split(",") if v.strip()}
         for k, kind in (("brdf", KIND_BRDF), ("emit", KIND_EMIT)):
             self.packed[k] = torch.empty(self.L.esr_mlp_packed_floats(kind), dtype=torch.float32,
                                          device=self.device)
@@ -1006,7 +1008,8 @@ class LtsEngine(FineEngine):
     def _flush_wgrad(self, point):
         """Inside ``_lts_backward``: send the weight-gradient jobs collected so far to the second stream NOW, so that they run
         beside the grid scatters that follow on the main stream (march_bwd + feat_bwd: LDS / L2 atomics, the matrix cores idle)
-        instead of after them.  ``point``: 1 = behind the secondary pass's input gradients, 2 = behind the primary pass's."""
+        instead of after them.  ``point``: 1 = behind the secondary pass's input gradients, 3 = behind the primary pass's
+        radiance nets', 2 = behind its material heads' (4: the points' pass, 5: the perturbed heads' -- off by default)."""
         if not (self.overlap_wgrad and point in self.wgrad_early and (self._wgrad_jobs or self._wgrad_extra)):
             return
         main, side = torch.cuda.current_stream(self.device), self._side_stream()
@@ -1098,6 +1101,7 @@ class LtsEngine(FineEngine):
             dX = self._net_bwd(P1, nm, KIND_RADIANCE, crow, 0, T1, dz, grads[f"{nm}_w"], grads[f"{nm}_b"])
             src.append((dX, None, gon, 0, T1))
         dsdf_pts = self._z(T1 * 32, device=dev)
+        self._flush_wgrad(4)
         self._feat_bwd(P1, ctx.scene, src, grads["sdf"], dsdf_out=dsdf_pts)
 
         # ---- primary pass: assemble per-sample head gradients in compact order
@@ -1126,6 +1130,7 @@ class LtsEngine(FineEngine):
                 grads["off"], grads["off"], 0, T),
                (self._net_bwd(P0, "emo", KIND_RADIANCE, 88, 0, Ton, P0.bufs["emo.dz"], grads["emo_w"], grads["emo_b"]),
                 grads["emo"], grads["emo"], 0, Ton)]
+        self._flush_wgrad(3)
         inv, pt1 = ctx.t["inv"], ctx.t["pt1"]
         dzb, dze = self._act_batch("act_bwd", [
             dict(P=P0, z="brdf.z", out="brdf.dz", rows=8, n_ch=5, act=ACT_SIGMOID, src=g.get("etc/brdf"), inv=inv, pt1=pt1,
@@ -1169,6 +1174,7 @@ class LtsEngine(FineEngine):
             dX = self._net_bwd(P3, nm, kind, crow, 0, T3, dz, grads[f"{nm}_w"], grads[f"{nm}_b"])
             src.append((dX, None, ggrid, 0, T3))
         if src:
+            self._flush_wgrad(5)
             # the points' SDF values came from esr_expgrad_fwd(pts_e, zero padding): their gradient goes back through the
             # same interpolant, inside the feature backward (grad4_mode 3 = zero_pad | own SDF-value gradient)
             self._feat_bwd(P3, ctx.scene, src, grads["sdf"], grad4_mode=3)
