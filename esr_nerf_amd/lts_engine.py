@@ -167,6 +167,9 @@ class LtsEngine(FineEngine):
         # end).  C5 pdra bf16, 100 steps x 3 on one box: none 3.45 ms, "1,2" 3.39, "1,2,3" 3.33; with 4 and 5 too: -0.6 %,
         # inside the noise, for two more batched calls per step -- not taken.
         self.wgrad_early = {int(v) for v in os.environ.get("ESR_LTS_WGRAD_EARLY", "1,2,3").split(",") if v.strip()}
+        # ESR_LTS_SCATTER_STREAM: the passes whose grid scatters leave the main stream (_on_scatter_stream; "0" = none).  C5 pdra
+        # bf16, 100 steps x 3 on one box: none 3.29 ms, "1" 3.18; C4 lts f32: 3.99 -> 3.84.  "1,2": inside the noise of "1".
+        self.scatter_streamed = {int(v) for v in os.environ.get("ESR_LTS_SCATTER_STREAM", "1").split(",") if v.strip() and v != "0"}
         for k, kind in (("brdf", KIND_BRDF), ("emit", KIND_EMIT)):
             self.packed[k] = torch.empty(self.L.esr_mlp_packed_floats(kind), dtype=torch.float32,
                                          device=self.device)
@@ -979,8 +982,12 @@ class LtsEngine(FineEngine):
         main = torch.cuda.current_stream(self.device)
         self._wgrad_jobs, self._wgrad_extra = [], []
         self._wgrad_flushed = False
+        self._scatter_done = None
         try:
             self._lts_backward(ctx, g, grads)
+            if self._scatter_done is not None:          # (before the grid gradients' exchange and anything else that reads them)
+                main.wait_event(self._scatter_done)
+                self._scatter_done = None
             jobs_done = None
             if self._wgrad_jobs or self._wgrad_extra or self._wgrad_flushed:
                 if self.overlap_wgrad:          # beside the dense-grid exchange / whatever follows on the main stream
@@ -1004,6 +1011,23 @@ class LtsEngine(FineEngine):
                 main.wait_event(jobs_done)
         finally:
             self._wgrad_jobs = None
+
+    def _on_scatter_stream(self, which, fn):
+        """Inside ``_lts_backward``: run the grid scatters ``fn`` (march_bwd + feat_bwd of one pass) on the scatter stream, behind
+        everything enqueued on the main stream so far.  Nothing on the main stream reads what they write (atomic sums into the
+        grid gradients) before ``lts_backward`` joins the stream.  ``which``: 1 = secondary pass, 2 = primary pass
+        (ESR_LTS_SCATTER_STREAM lists the ones that leave the main stream)."""
+        if not (self.overlap_wgrad and which in self.scatter_streamed):
+            fn()
+            return
+        main, scat = torch.cuda.current_stream(self.device), self._side_stream(1)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        scat.wait_event(ev)
+        with torch.cuda.stream(scat):
+            fn()
+            self._scatter_done = torch.cuda.Event()
+            self._scatter_done.record(scat)
 
     def _flush_wgrad(self, point):
         """Inside ``_lts_backward``: send the weight-gradient jobs collected so far to the second stream NOW, so that they run
@@ -1084,9 +1108,14 @@ class LtsEngine(FineEngine):
             self._flush_wgrad(1)
             # the secondary march's value-tap gradients of the recorded samples ride on the feature backward's window
             ds2 = P2.buf("dsdf")
-            wrote = self._march_bwd("march_bwd[secondary]", P2, sp2, ctx.t["o2"], ctx.t["d2"], Pn * R, ctx.t["off3_2"], dw2,
-                                    d["d_last2"], grads["sdf"], ds2, 0)
-            self._feat_bwd(P2, ctx.scene2, src, grads["sdf"], dsdf_extra=ds2 if wrote else None)
+
+            def scatter2():
+                wrote = self._march_bwd("march_bwd[secondary]", P2, sp2, ctx.t["o2"], ctx.t["d2"], Pn * R, ctx.t["off3_2"], dw2,
+                                        d["d_last2"], grads["sdf"], ds2, 0)
+                self._feat_bwd(P2, ctx.scene2, src, grads["sdf"], dsdf_extra=ds2 if wrote else None)
+            # the secondary pass's grid scatters (incoherent rays: L2 atomics, ~0.4 ms with the matrix cores idle) on a stream of
+            # their own, beside the input-gradient chains of the points' and the primary pass that follow on the main stream
+            self._on_scatter_stream(1, scatter2)
         else:
             self._march_bwd("march_bwd[secondary]", P2, sp2, ctx.t["o2"], ctx.t["d2"], Pn * R, ctx.t["off3_2"], z(32),
                             d["d_last2"], grads["sdf"], None, 0)
@@ -1142,15 +1171,19 @@ class LtsEngine(FineEngine):
         src.append((self._net_bwd(P0, "emit", KIND_EMIT, 88, 0, T, dze, grads["emit_w"], grads["emit_b"]),
                     grads["emo"], grads["emo"], 0, T))
         self._flush_wgrad(2)
-        self._march_bwd("march_bwd", P0, sp, b["rays_o"], b["rays_d"], P0.n_rays, ctx.t["off3"], dweight, g_last,
-                        grads["sdf"], dsdf_extra, 1)
         # exact normals (linear in the grid): the gradient of etc/normal is scattered inside the feature backward (same
         # samples, esr_fine_feat_bwd's grad4); etc/normal_eps sits up to several voxels away and keeps its own launch
         g4n = None
         if g.get("etc/normal") is not None:
             g4n = self._z(T * 32, 4, device=dev)
             g4n[perm, 1:4] = g["etc/normal"]
-        self._feat_bwd(P0, ctx.scene, src, grads["sdf"], dsdf_extra=dsdf_extra, grad4=g4n)
+
+        def scatter0(src=src):
+            self._march_bwd("march_bwd", P0, sp, b["rays_o"], b["rays_d"], P0.n_rays, ctx.t["off3"], dweight, g_last,
+                            grads["sdf"], dsdf_extra, 1)
+            self._feat_bwd(P0, ctx.scene, src, grads["sdf"], dsdf_extra=dsdf_extra, grad4=g4n)
+        # (beside the perturbed heads' chain below, which does not depend on them)
+        self._on_scatter_stream(2, scatter0)
         for key, noise, eps in (("etc/normal_eps", ctx.t["noise_n"], ctx.eps["normal"]),):
             if g.get(key) is None:
                 continue
