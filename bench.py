@@ -829,7 +829,8 @@ def main():
             total_ms = sum(ms_ for _, ms_ in breakdown.values()) / max(n_prof, 1)
             tf, gbs = fl / (ms_mlp * 1e-3) / 1e12, by / (ms_mlp * 1e-3) / 1e9
             peak = MFMA_BF16_PEAK_TF if bf else MFMA_F32_PEAK_TF
-            rl = {"kernel": "all mlp_fwd/dgrad/wgrad launches of the step (HIP events, instrumented warm-up steps)",
+            rl = {"kernel": "all mlp_fwd/dgrad/wgrad launches of the step (HIP events, instrumented warm-up steps: every launch alone on "
+                            "one stream; the timed steps run the backward on three streams)",
                   "traffic": pmc_traffic(a, stage, ["__step__"]), "mlp_ms_per_step": ms_mlp,
                   "share_of_kernel_time": ms_mlp / total_ms, "kernel_ms_per_step": total_ms,
                   "mfma": {"achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak},

@@ -983,6 +983,7 @@ class LtsEngine(FineEngine):
         self._wgrad_jobs, self._wgrad_extra = [], []
         self._wgrad_flushed = False
         self._scatter_done = None
+        self.last_wgrad_jobs = []
         try:
             self._lts_backward(ctx, g, grads)
             if self._scatter_done is not None:          # (before the grid gradients' exchange and anything else that reads them)
@@ -1047,7 +1048,7 @@ class LtsEngine(FineEngine):
 
     def _launch_wgrad_jobs(self):
         jobs = self._wgrad_jobs
-        self.last_wgrad_jobs = [(name, t1 - t0) for name, _, _, _, _, _, _, t0, t1, _, _, _ in jobs]     # (net[pass], tiles)
+        self.last_wgrad_jobs += [(name, t1 - t0) for name, _, _, _, _, _, _, t0, t1, _, _, _ in jobs]    # (net[pass], tiles) of the step
         arr = (_lib.EsrWgradJob * len(jobs))()
         keep = []
         for jb, (_, kind, x, crow, H, dZ, dz, t0, t1, gw, gb, amax) in zip(arr, jobs):

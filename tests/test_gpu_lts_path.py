@@ -268,6 +268,44 @@ def test_lts_step_equals_autograd_route(stage):
     assert not bad, str(bad)
 
 
+@pytest.mark.parametrize("stage,dtype", [("lts", "f32"), ("pdra", "f32"), ("pdra", "bf16")])
+def test_lts_backward_on_three_streams_equals_the_one_stream_order(stage, dtype):
+    """The backward's stream schedule (weight-gradient jobs flushed to the second stream at points inside the backward,
+    the secondary pass's grid scatters on a third: lts_engine._flush_wgrad / _on_scatter_stream) against the same step with
+    everything in program order on one stream: same loss, gradients equal up to the order of the atomic sums."""
+    from esr_nerf_amd.synthetic import init_slab_model, slab_scene
+    from esr_nerf_amd.trainer import LtsStep
+    s_val, n_rays, R, Pn = 70.0, 256, 16, 24
+    sc = slab_scene("small", s_val=s_val, oblique=True, n_rays=n_rays, seed=2)
+    m, cfg = build_lts_model(sc, num_2ndrays=R, num_ltspts=Pn)
+    init_slab_model(m, sc, seed=3)
+    with torch.no_grad():
+        m.brdf.grid.normal_(0.0, 0.3)
+    m.pdra_mode = stage == "pdra"
+    m.mlp_dtype = dtype
+    b = {k: v.cuda() for k, v in sc.batch.items()}
+    g = torch.Generator().manual_seed(1)
+    b["uncert_masks"] = (torch.rand(n_rays, generator=g) < 0.5).cuda()
+    step = LtsStep(m, cfg.app.trainer, stage=stage)
+    step.forward_loss_backward(b, s_val)
+    m3 = m.last_counts["m3"]
+    draws = dict(idx=torch.randperm(m3, generator=g)[:Pn].cuda(), dirs=torch.randn(Pn, R + 1, 3, generator=g).cuda(),
+                 noise_normal=torch.randn(m3, 3, generator=g).cuda(), noise_emit=torch.randn(m3, 3, generator=g).cuda())
+    eng = m.engine
+    assert eng.overlap_wgrad and eng.wgrad_early and eng.scatter_streamed, "the defaults this test is about"
+    res = {}
+    for name, (overlap, early, scat) in dict(streams=(True, {1, 2, 3, 4, 5}, {1, 2}), serial=(False, set(), set())).items():
+        eng.overlap_wgrad, eng.wgrad_early, eng.scatter_streamed = overlap, early, scat
+        loss, G, _ = step.forward_loss_backward(b, s_val, draws=draws)
+        torch.cuda.synchronize()
+        res[name] = (float(loss), {k: v.clone() for k, v in G.items()})
+    assert abs(res["streams"][0] - res["serial"][0]) <= 1e-6 * abs(res["serial"][0])      # (same forward; atomic sums in the loss)
+    tol = 2e-5 if dtype == "f32" else 2e-4        # (summation order of atomics / of the weight-gradient workgroups' slabs)
+    bad = {k: rel_err(v, res["serial"][1][k]) for k, v in res["streams"][1].items()}
+    bad = {k: e for k, e in bad.items() if not e < tol}
+    assert not bad, str(bad)
+
+
 @pytest.mark.parametrize("mask", MASKS)
 def test_finetune_golden_reference_vectors(mask):
     """ESRNeRF.forward_finetune (A16) on the HIP path against the reference-generated fixture: both outputs,
