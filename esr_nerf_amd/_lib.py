@@ -117,7 +117,7 @@ EXPORTS = [
     "esr_adam_step", "esr_eval_aux", "esr_eval_disp",
     "esr_mlp_packed_bf16_elems", "esr_mlp_pack_bf16", "esr_mlp_fwd_bf16", "esr_mlp_dgrad_bf16", "esr_mlp_wgrad_bf16",
     "esr_brick_floats", "esr_brick_flags", "esr_brick_pack", "esr_brick_unpack", "esr_brick_list", "esr_brick_list_scratch_ints",
-    "esr_smooth_grad_tv_fwd", "esr_smooth_grad_tv_bwd", "esr_host_choice_noreplace",
+    "esr_smooth_grad_tv_fwd", "esr_smooth_grad_tv_bwd", "esr_host_choice_noreplace", "esr_host_choice_start", "esr_host_choice_wait",
 ]
 
 

@@ -6,7 +6,11 @@
 // is the same algorithm on the same generator state, bit for bit, callable without the GIL so that it runs on a
 // worker thread beside the enqueueing of the primary pass (the count M3 is known right after the plan sync).
 // The caller checks numpy's global state out (np.random.get_state) and back in (set_state) around the call.
+#include <condition_variable>
 #include <cstdint>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "esr_common.h"
@@ -125,4 +129,86 @@ ESR_API int esr_host_choice_noreplace(uint32_t *key, int32_t *pos, int64_t n, in
     for (int64_t t = 0; t < k; ++t) out[t] = (int64_t)a[(size_t)t];
     *pos = g.pos;
     return 0;
+}
+
+// ---- the same draw on a worker thread of this library ------------------------------------------------------------------
+// The Python side used to hand the call above to a concurrent.futures worker: submitting it, and the worker taking the
+// interpreter lock to start the call, cost the enqueueing thread ~0.1 ms right after the plan read-back -- in the one
+// segment of the LTS step where the device waits for the host (tools/host_gaps.py).  Here: one detached thread that sleeps
+// on a condition variable; start = push a job and notify (microseconds, no interpreter involved), wait = block until that
+// job is done (ctypes releases the interpreter lock around it).  Jobs run in submission order.
+namespace {
+struct DrawJob {
+    uint32_t *key;
+    int32_t *pos;
+    int64_t n, k;
+    int64_t *out;
+    int rc = 0;
+    bool done = false;
+};
+struct DrawQueue {
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    std::deque<DrawJob *> q;
+    bool started = false;
+    void loop()
+    {
+        for (;;) {
+            DrawJob *j;
+            {
+                std::unique_lock<std::mutex> l(m);
+                cv_job.wait(l, [&] { return !q.empty(); });
+                j = q.front();
+                q.pop_front();
+            }
+            const int rc = esr_host_choice_noreplace(j->key, j->pos, j->n, j->k, j->out);
+            {
+                std::lock_guard<std::mutex> l(m);
+                j->rc = rc;
+                j->done = true;
+            }
+            cv_done.notify_all();
+        }
+    }
+};
+DrawQueue &draw_queue()
+{
+    static DrawQueue *dq = new DrawQueue;      // never destroyed: the detached worker may outlive static destruction
+    return *dq;
+}
+}  // namespace
+
+ESR_API int esr_host_choice_start(uint32_t *key, int32_t *pos, int64_t n, int64_t k, int64_t *out, void **job)
+{
+    if (!job) return ESR_EINVAL;
+    *job = nullptr;
+    if (!key || !pos || !out || n < 0 || k < 0 || k > n || *pos < 0 || *pos > 624) return ESR_EINVAL;
+    DrawJob *j = new DrawJob{key, pos, n, k, out};
+    DrawQueue &Q = draw_queue();
+    {
+        std::lock_guard<std::mutex> l(Q.m);
+        if (!Q.started) {
+            std::thread([&Q] { Q.loop(); }).detach();
+            Q.started = true;
+        }
+        Q.q.push_back(j);
+    }
+    Q.cv_job.notify_one();
+    *job = j;
+    return 0;
+}
+
+ESR_API int esr_host_choice_wait(void *job)
+{
+    if (!job) return ESR_EINVAL;
+    DrawJob *j = static_cast<DrawJob *>(job);
+    DrawQueue &Q = draw_queue();
+    int rc;
+    {
+        std::unique_lock<std::mutex> l(Q.m);
+        Q.cv_done.wait(l, [&] { return j->done; });
+        rc = j->rc;
+    }
+    delete j;
+    return rc;
 }

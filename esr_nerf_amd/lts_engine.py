@@ -94,24 +94,18 @@ class _PointDraw:
     the reference draws it.  The draw is a full shuffle of range(n) on the host (1.3-1.6 ms at C4, 12 ms at 600 k
     survivors) and the light-transport pass cannot be enqueued without it; beside the enqueueing of the primary pass
     it is free.  ``esr_host_choice_noreplace`` is numpy's algorithm on numpy's state, bit for bit, called through
-    ctypes (no GIL).  The global state is checked out here and written back in ``result()``: nothing else may draw
-    from ``np.random`` in between (nothing on this path does)."""
-
-    _pool = None           # one persistent worker: creating a thread per step costs ~0.1 ms of host time
+    a worker thread of the library (no GIL).  It advances numpy's global state IN PLACE between the constructor and
+    ``result()``: nothing else may draw from ``np.random`` in between (nothing on this path does)."""
 
     def __init__(self, n: int, k: int, ring: list):
         """``ring``: the calling engine's [buffer, buffer, last slot, capacity] -- two alternating pinned buffers sized
         for the engine's LARGEST draw and sliced to k (one ring per engine: a class-level dict keyed by k grew by two
-        pinned buffers for every distinct survivor-limited k and was shared by every engine of the process)."""
-        from concurrent.futures import ThreadPoolExecutor
-        if _PointDraw._pool is None:
-            _PointDraw._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="esr-point-draw")
-        st = np.random.get_state()
-        if st[0] != "MT19937":
-            raise RuntimeError("numpy's global generator is not the legacy MT19937")
-        self._st = st
-        self._key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
-        self._pos = C.c_int32(int(st[2]))
+        pinned buffers for every distinct survivor-limited k and was shared by every engine of the process).
+        The worker is a thread of the library (esr_host_choice_start / _wait): handing the call to a concurrent.futures
+        worker cost this thread ~0.1 ms (submit + the worker taking the interpreter lock) in the one segment of the step
+        where the device waits for the host."""
+        # numpy's state is used IN PLACE (np.random.get_state / set_state cost this thread 33 + 35 us per step)
+        key_addr, pos_addr = _np_global_mt19937()
         # pinned: the upload in lts_forward must not block the host (a pageable copy waits for the stream to drain,
         # after which every small launch of the light-transport glue shows its full launch latency: ~0.5 ms idle per step)
         # (two alternating buffers, allocated once: a pinned allocation per step cost the host ~60 us right after
@@ -123,20 +117,47 @@ class _PointDraw:
         if ring[slot] is None:
             ring[slot] = torch.empty(ring[3], dtype=torch.int64, pin_memory=torch.cuda.is_available())
         self._out_t = ring[slot][:k]
-        self._out = self._out_t.numpy()
-        self._rc = None
-        L = _lib.lib()
-
-        def run():
-            self._rc = L.esr_host_choice_noreplace(self._key.ctypes.data_as(C.c_void_p), C.byref(self._pos),
-                                                   C.c_int64(n), C.c_int64(k), self._out.ctypes.data_as(C.c_void_p))
-        self._fut = _PointDraw._pool.submit(run)
+        self._job = C.c_void_p(0)
+        _lib.check(_lib.lib().esr_host_choice_start(C.c_void_p(key_addr), C.c_void_p(pos_addr), C.c_int64(n), C.c_int64(k),
+                                                    C.c_void_p(self._out_t.data_ptr()), C.byref(self._job)), "esr_host_choice_start")
 
     def result(self) -> torch.Tensor:
-        self._fut.result()
-        _lib.check(self._rc, "esr_host_choice_noreplace")
-        np.random.set_state((self._st[0], self._key, int(self._pos.value), self._st[3], self._st[4]))
+        job, self._job = self._job, None
+        _lib.check(_lib.lib().esr_host_choice_wait(job), "esr_host_choice_noreplace")
         return self._out_t
+
+
+_NP_MT = None
+
+
+def _np_global_mt19937():
+    """(address of key[624], address of pos) inside numpy's GLOBAL legacy generator (``np.random.seed`` / ``set_state`` rewrite
+    that state in place, so the addresses hold for the life of the process).  numpy publishes the address of its
+    ``mt19937_state {uint32_t key[624]; int pos;}`` through the bit generator's ctypes interface; the layout is verified
+    against ``get_state()`` the first time (and once more after a perturbation of the state)."""
+    global _NP_MT
+    if _NP_MT is None:
+        bg = np.random.mtrand._rand._bit_generator
+        if type(bg).__name__ != "MT19937":
+            raise RuntimeError("numpy's global generator is not the legacy MT19937")
+        addr = bg.ctypes.state_address
+        addr = int(getattr(addr, "value", addr))
+
+        def same():
+            st = np.random.get_state()
+            key = np.frombuffer((C.c_uint32 * 624).from_address(addr), dtype=np.uint32)
+            return st[0] == "MT19937" and np.array_equal(key, st[1]) and C.c_int.from_address(addr + 624 * 4).value == int(st[2])
+        ok = same()
+        st0 = np.random.get_state()
+        np.random.random(3)                    # (moves pos, or refills the block)
+        ok = ok and same()
+        np.random.set_state(st0)
+        if not (ok and same()):
+            raise RuntimeError("numpy's MT19937 state is not laid out as {uint32 key[624]; int pos;} at its published address")
+        _NP_MT = (bg, addr, addr + 624 * 4)
+    if np.random.mtrand._rand._bit_generator is not _NP_MT[0]:
+        raise RuntimeError("numpy's global generator object was replaced")
+    return _NP_MT[1], _NP_MT[2]
 
 
 def fibonacci_hemisphere(count: int) -> torch.Tensor:

@@ -908,6 +908,13 @@ int esr_smooth_grad_tv_bwd(const float *work6, int32_t gx, int32_t gy, int32_t g
  * without the GIL while the primary pass is being enqueued.
  */
 int esr_host_choice_noreplace(uint32_t *key, int32_t *pos, int64_t n, int64_t k, int64_t *out);
+/*
+ * The same draw on a worker thread owned by the library (one thread, jobs in submission order): _start returns at once with a
+ * job handle, _wait blocks until that job is done, returns its code and releases the handle (exactly one _wait per _start;
+ * key / pos / out must stay valid until then).  No interpreter involvement on the worker: starting it costs microseconds.
+ */
+int esr_host_choice_start(uint32_t *key, int32_t *pos, int64_t n, int64_t k, int64_t *out, void **job);
+int esr_host_choice_wait(void *job);
 
 /* ------------------------------------------------------------------------- *
  * F. Data-parallel gradient exchange (no reference counterpart: the reference is single-process,

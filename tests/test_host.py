@@ -385,6 +385,38 @@ def test_host_point_draw_equals_numpy_choice():
     assert L.esr_host_choice_noreplace(None, None, C.c_int64(3), C.c_int64(5), None) < 0
 
 
+def test_point_draw_on_the_library_worker_equals_numpy_choice():
+    """lts_engine._PointDraw (esr_host_choice_start / _wait: the draw on the library's worker thread, numpy's state checked
+    out and back in) == np.random.choice of the legacy global generator, draw after draw; jobs queued behind one another
+    come back in submission order with their own results."""
+    import ctypes as C
+    from esr_nerf_amd import _lib
+    from esr_nerf_amd.lts_engine import _PointDraw
+    ring = [None, None, 0, 0]
+    for seed in range(3):
+        for n, k in [(1, 1), (1000, 100), (80000, 100), (70001, 64), (5, 3)]:
+            np.random.seed(seed); np.random.random(seed * 5)
+            a = np.random.choice(n, k, replace=False); ra = np.random.random()
+            np.random.seed(seed); np.random.random(seed * 5)
+            b = _PointDraw(n, k, ring).result().numpy().copy(); rb = np.random.random()
+            assert np.array_equal(a, b) and ra == rb, (seed, n, k)
+    # two jobs in flight on separate states (the raw entry points): each handle returns its own draw
+    L = _lib.lib()
+    jobs = []
+    for seed, (n, k) in enumerate([(50000, 10), (300, 300)]):
+        st = np.random.RandomState(seed).get_state()
+        key, pos, out, h = np.ascontiguousarray(st[1], dtype=np.uint32).copy(), C.c_int32(int(st[2])), np.empty(k, np.int64), C.c_void_p(0)
+        assert L.esr_host_choice_start(C.c_void_p(key.ctypes.data), C.byref(pos), C.c_int64(n), C.c_int64(k),
+                                       C.c_void_p(out.ctypes.data), C.byref(h)) == 0 and h.value
+        jobs.append((seed, n, k, key, pos, out, h))
+    for seed, n, k, key, pos, out, h in jobs:
+        assert L.esr_host_choice_wait(h) == 0
+        assert np.array_equal(out, np.random.RandomState(seed).choice(n, k, replace=False))
+    h = C.c_void_p(0)
+    assert L.esr_host_choice_start(None, None, C.c_int64(3), C.c_int64(5), None, C.byref(h)) < 0 and not h.value
+    assert L.esr_host_choice_wait(None) < 0
+
+
 def test_deferred_march_overflow_raises_on_the_next_step():
     """Data-parallel steps do not raise inside the step when a ray exceeded the march bound (the other ranks would hang in
     the exchange): the flag is reduced with the loss and every rank raises at the start of its next step."""
