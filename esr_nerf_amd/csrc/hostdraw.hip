@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <deque>
 #include <mutex>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 
@@ -171,10 +172,17 @@ struct DrawQueue {
         }
     }
 };
+DrawQueue *g_draw_queue = nullptr;              // never destroyed: the detached worker may outlive static destruction
+std::once_flag g_draw_once;
 DrawQueue &draw_queue()
 {
-    static DrawQueue *dq = new DrawQueue;      // never destroyed: the detached worker may outlive static destruction
-    return *dq;
+    std::call_once(g_draw_once, [] {
+        g_draw_queue = new DrawQueue;
+        // a fork()ed child has this library's state but not its worker thread (and possibly a locked mutex): fresh queue,
+        // the worker starts again with the child's first job
+        pthread_atfork(nullptr, nullptr, [] { g_draw_queue = new DrawQueue; });
+    });
+    return *g_draw_queue;
 }
 }  // namespace
 

@@ -415,6 +415,19 @@ def test_point_draw_on_the_library_worker_equals_numpy_choice():
     h = C.c_void_p(0)
     assert L.esr_host_choice_start(None, None, C.c_int64(3), C.c_int64(5), None, C.byref(h)) < 0 and not h.value
     assert L.esr_host_choice_wait(None) < 0
+    # a fork()ed child has the library's state but not its worker thread: the child's first job starts a new one
+    import os
+    np.random.seed(1)
+    a = _PointDraw(1000, 10, ring).result().numpy().copy()
+    pid = os.fork()
+    if pid == 0:
+        try:
+            np.random.seed(1)
+            b = _PointDraw(1000, 10, [None, None, 0, 0]).result().numpy().copy()
+            os._exit(0 if np.array_equal(a, b) else 3)
+        finally:
+            os._exit(4)
+    assert os.WEXITSTATUS(os.waitpid(pid, 0)[1]) == 0
 
 
 def test_deferred_march_overflow_raises_on_the_next_step():
