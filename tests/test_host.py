@@ -422,6 +422,8 @@ def test_point_draw_on_the_library_worker_equals_numpy_choice():
     pid = os.fork()
     if pid == 0:
         try:
+            import signal
+            signal.alarm(30)                   # (a stuck child ends itself: the parent sees a non-zero status)
             np.random.seed(1)
             b = _PointDraw(1000, 10, [None, None, 0, 0]).result().numpy().copy()
             os._exit(0 if np.array_equal(a, b) else 3)
