@@ -938,17 +938,22 @@ __global__ void __launch_bounds__(64 * (WM * WN * WK + 1), 1) mlp_wgrad_dma_kern
 // wave; a workgroup works on exactly one job, so the switch is workgroup-uniform) and get a share of the 256 workgroups
 // proportional to tiles x cost per tile.  Why: every launch pays a fixed 25-35 us (slab round trip, ring fill and
 // drain, tail) whatever its tile count -- three launches + three reductions per step became one + one.
-enum { UNI_HID192 = 0, UNI_FIRST192 = 1, UNI_OUT192 = 2 };
+// (round 4, end: the 128-wide nets' shapes -- the BRDF / emission jobs of an LTS step -- ride in the same launches: three more
+//  launches + their fill / drain per flush gone)
+enum { UNI_HID192 = 0, UNI_FIRST192 = 1, UNI_OUT192 = 2, UNI_FIRST192_X16 = 3, UNI_HID192_SYN = 4, UNI_HID128 = 5, UNI_FIRST128 = 6,
+       UNI_OUT128 = 7, N_UNI_CFG = 8 };
 __global__ void __launch_bounds__(320, 1) mlp_wgrad_uni192_kernel(WgradBatch WB)
 {
     const WgradArgs W = pick_job(WB);
     if (W.cfg == UNI_HID192) wgrad_dma_body<3, 3, 2, 2, 1>(W);
     else if (W.cfg == UNI_FIRST192) wgrad_dma_body<3, 3, 2, 1, 2>(W);
+    else if (W.cfg == UNI_HID128) wgrad_dma_body<2, 2, 2, 2, 1>(W);
+    else if (W.cfg == UNI_FIRST128) wgrad_dma_body<2, 3, 2, 1, 2>(W);
+    else if (W.cfg == UNI_OUT128) wgrad_dma_body<1, 2, 1, 2, 2>(W);
     else wgrad_dma_body<1, 3, 1, 2, 2>(W);
 }
 // the bf16 engine's 192-wide jobs the same way (register-staged bodies, four waves each; UNI_FIRST192_X16: the first layer
 // reading the bf16 input tile).  Three launches + their fill / drain became one.
-enum { UNI_FIRST192_X16 = 3, UNI_HID192_SYN = 4 };
 __global__ void __launch_bounds__(256, 1) mlp_wgrad_uni192b_kernel(WgradBatch WB)
 {
     const WgradArgs W = pick_job(WB);
@@ -956,6 +961,9 @@ __global__ void __launch_bounds__(256, 1) mlp_wgrad_uni192b_kernel(WgradBatch WB
     else if (W.cfg == UNI_HID192_SYN) wgrad_reg_body<3, 3, 2, 2, 1, 2, true>(W);
     else if (W.cfg == UNI_FIRST192) wgrad_reg_body<3, 3, 2, 1, 2, 3>(W);
     else if (W.cfg == UNI_FIRST192_X16) wgrad_reg_body<3, 3, 2, 1, 2, 2>(W);
+    else if (W.cfg == UNI_HID128) wgrad_reg_body<2, 2, 2, 2, 1, 2>(W);
+    else if (W.cfg == UNI_FIRST128) wgrad_reg_body<2, 3, 2, 1, 2, 3>(W);
+    else if (W.cfg == UNI_OUT128) wgrad_reg_body<1, 2, 1, 2, 2, 1>(W);
     else wgrad_reg_body<1, 3, 1, 2, 2, 1>(W);
 }
 // the same launch with the products on the 16-bit matrix cores (wgrad_dma_body<..., SPLIT>)
@@ -964,6 +972,9 @@ __global__ void __launch_bounds__(320, 1) mlp_wgrad_uni192s_kernel(WgradBatch WB
     const WgradArgs W = pick_job(WB);
     if (W.cfg == UNI_HID192) wgrad_dma_body<3, 3, 2, 2, 1, true>(W);
     else if (W.cfg == UNI_FIRST192) wgrad_dma_body<3, 3, 2, 1, 2, true>(W);
+    else if (W.cfg == UNI_HID128) wgrad_dma_body<2, 2, 2, 2, 1, true>(W);
+    else if (W.cfg == UNI_FIRST128) wgrad_dma_body<2, 3, 2, 1, 2, true>(W);
+    else if (W.cfg == UNI_OUT128) wgrad_dma_body<1, 2, 1, 2, 2, true>(W);
     else wgrad_dma_body<1, 3, 1, 2, 2, true>(W);
 }
 
@@ -1170,7 +1181,10 @@ int launch_wgrad_any(WgradBatch &B, SlabPool &P)
 // output layer 12.8 KB); the fourth entry is the bf16 first layer on the bf16 input tile
 const double *uni_cost(int variant)
 {
-    static double c[3][5] = {{1.0, 0.5, 0.2, 0.5, 1.0}, {1.0, 0.8, 0.6, 0.8, 0.75}, {1.0, 1.0, 0.7, 0.9, 1.2}};      // (fifth: bf16 hidden layer with a synthesised dZ: half the bytes, but 1.2x the time per tile)
+    // (fifth: bf16 hidden layer with a synthesised dZ: half the bytes, but 1.2x the time per tile; sixth to eighth: the 128-wide
+    //  nets' hidden / first / output shapes -- bytes per tile 0.67 / 0.58 / 0.35 of the 192-wide hidden shape's, MACs 0.44 / 0.33 / 0.03)
+    static double c[3][N_UNI_CFG] = {{1.0, 0.5, 0.2, 0.5, 1.0, 0.45, 0.35, 0.15}, {1.0, 0.8, 0.6, 0.8, 0.75, 0.65, 0.55, 0.4},
+                                     {1.0, 1.0, 0.7, 0.9, 1.2, 0.65, 0.6, 0.45}};
     static std::atomic<int> done{0};
     if (!done.load()) {
         const char *names[3] = {"ESR_WGRAD_COST", "ESR_WGRAD_COST_SPLIT", "ESR_WGRAD_COST_BF16"};
@@ -1181,11 +1195,16 @@ const double *uni_cost(int variant)
 
             }
         if (const char *e5 = std::getenv("ESR_WGRAD_COST_SYN")) { const double v = std::atof(e5); if (v > 0) c[2][4] = v; }
+        if (const char *e8 = std::getenv("ESR_WGRAD_COST_128")) {          // hidden,first,output of the 128-wide nets, every variant
+            double a, b, d;
+            if (std::sscanf(e8, "%lf,%lf,%lf", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0)
+                for (int k = 0; k < 3; ++k) { c[k][UNI_HID128] = a; c[k][UNI_FIRST128] = b; c[k][UNI_OUT128] = d; }
+        }
         done.store(1);
     }
     return c[variant];
 }
-constexpr int uni_wk(int cfg) { return (cfg == UNI_HID192 || cfg == 4 /* UNI_HID192_SYN */) ? 1 : 2; }      // (both first-layer forms and the output layer: k split in two)
+constexpr int uni_wk(int cfg) { return (cfg == UNI_HID192 || cfg == UNI_HID192_SYN || cfg == UNI_HID128) ? 1 : 2; }      // (both first-layer forms and the output layer: k split in two)
 
 // workgroups per job proportional to tiles x cost (every job >= 1, none more than its tiles); slab regions back to back
 int plan_uni(WgradBatch &B, float *scratch, int64_t slab_floats, ReduceArgs &R, int64_t &used_out, int variant)
@@ -1259,7 +1278,9 @@ int launch_wgrad_uni(WgradBatch &B, SlabPool &P)
                               : reinterpret_cast<const void *>(&mlp_wgrad_uni192_kernel);
     for (int j = 0; j < B.n; ++j) {
         const WgradArgs &W = B.job[j];
-        const int rap = W.cfg == UNI_OUT192 ? 32 : 192, rbp = (W.cfg == UNI_FIRST192 || W.cfg == UNI_FIRST192_X16) ? 96 : 192;
+        const bool w128 = W.cfg == UNI_HID128 || W.cfg == UNI_FIRST128 || W.cfg == UNI_OUT128;
+        const int rap = (W.cfg == UNI_OUT192 || W.cfg == UNI_OUT128) ? 32 : w128 ? 128 : 192;
+        const int rbp = (W.cfg == UNI_FIRST192 || W.cfg == UNI_FIRST192_X16 || W.cfg == UNI_FIRST128) ? 96 : w128 ? 128 : 192;
         if (W.RA > rap || W.RB > rbp) return ESR_ECAP;
     }
     constexpr size_t lds_bytes = V == 2 ? 2 * (size_t)(192 + 192) * LDS_STRIDE * sizeof(float)       // two register-staged buffers
@@ -1309,6 +1330,13 @@ int layer_cfg(const NetDesc &D, bool first, bool last, int RB)
 bool uni_on()
 {
     static const bool on = [] { const char *e = std::getenv("ESR_WGRAD_UNI"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+// ESR_WGRAD_UNI128=0: the 128-wide nets' jobs keep their per-shape launches (A/B timing)
+bool uni128_on()
+{
+    static const bool on = [] { const char *e = std::getenv("ESR_WGRAD_UNI128"); return !(e && e[0] == '0'); }();
     return on;
 }
 
@@ -1618,8 +1646,10 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
                 W.RB = 96; W.b_tile_rows = 104;                    // 24 row quads of operand rows, 26 quads (6656 B) per tile
                 c = CFG_FIRST192_X16;
             }
-            if (uni_on() && (c == CFG_HID192 || c == CFG_FIRST192 || c == CFG_OUT192 || (BF && c == CFG_FIRST192_X16))) {
-                W.cfg = c == CFG_HID192 ? (syn ? UNI_HID192_SYN : UNI_HID192) : c == CFG_FIRST192 ? UNI_FIRST192 : c == CFG_OUT192 ? UNI_OUT192 : UNI_FIRST192_X16;
+            const bool uni128 = uni128_on() && (c == CFG_HID128 || c == CFG_FIRST128 || c == CFG_OUT128);
+            if (uni_on() && (c == CFG_HID192 || c == CFG_FIRST192 || c == CFG_OUT192 || (BF && c == CFG_FIRST192_X16) || uni128)) {
+                W.cfg = c == CFG_HID192 ? (syn ? UNI_HID192_SYN : UNI_HID192) : c == CFG_FIRST192 ? UNI_FIRST192 : c == CFG_OUT192 ? UNI_OUT192
+                      : c == CFG_HID128 ? UNI_HID128 : c == CFG_FIRST128 ? UNI_FIRST128 : c == CFG_OUT128 ? UNI_OUT128 : UNI_FIRST192_X16;
                 W.amax = BF ? nullptr : J.amax;                    // non-NULL: the split-fp16 kernel (esr_hip.h)
                 if (syn && !BF) {                                  // f32 operands: a launch of its own (mlp_wgrad_syn192s_kernel)
                     if (synb.n == MAX_JOBS) return ESR_ECAP;
