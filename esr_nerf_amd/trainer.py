@@ -230,7 +230,8 @@ class FineStep:
         """One flat zero buffer holding every gradient (a single memset; grids first, then the MLP tensors)."""
         m = self.model
         X, Y, Z = m._world_size_l                   # host copy: int(device scalar) is a sync each
-        hit = _cached_views(self, (X, Y, Z))
+        vkey = (X, Y, Z, id(getattr(self, "sharded", None)))      # (a ShardedGrids attached later changes the padding)
+        hit = _cached_views(self, vkey)
         if hit is not None:
             return hit
         shapes = [("sdf.grid", (1, 1, X, Y, Z)), ("off_color.grid", (1, X, Y, Z, 6)),
@@ -251,7 +252,7 @@ class FineStep:
                 self._n_grid = o          # [0, _n_grid): the three dense grids; [_n_grid, _n_grid_pad): zero padding
                 o += pad                  # (shard mode); the rest: MLP tensors
                 self._n_grid_pad = o
-        self._views = ((X, Y, Z), self._flat, dict(out))
+        self._views = (vkey, self._flat, dict(out))
         return out
 
     @torch.no_grad()
@@ -418,7 +419,8 @@ class LtsStep:
     def _alloc_grads(self, dev):
         m = self.model
         X, Y, Z = m._world_size_l                   # host copy: int(device scalar) is a sync each
-        hit = _cached_views(self, (X, Y, Z))
+        vkey = (X, Y, Z, id(getattr(self, "sharded", None)))      # (a ShardedGrids attached later changes the padding)
+        hit = _cached_views(self, vkey)
         if hit is not None:
             return hit
         J = m.envmap.mus.shape[0]
@@ -441,7 +443,7 @@ class LtsStep:
                 self._n_grid = o          # [0, _n_grid): the four dense grids; [_n_grid, _n_grid_pad): zero padding
                 o += pad                  # (shard mode); the rest: MLP + env-map tensors
                 self._n_grid_pad = o
-        self._views = ((X, Y, Z), self._flat, dict(out))
+        self._views = (vkey, self._flat, dict(out))
         return out
 
     def _pair(self, eng, loss, a, b, kind, w_value, w_a, w_b, scale, want_gb=True, row_mask=None, mask_value=0,
