@@ -190,6 +190,7 @@ class LtsEngine(FineEngine):
         self.wgrad_early = {int(v) for v in os.environ.get("ESR_LTS_WGRAD_EARLY", "1,2,3").split(",") if v.strip()}
         # ESR_LTS_SCATTER_STREAM: the passes whose grid scatters leave the main stream (_on_scatter_stream; "0" = none).  C5 pdra
         # bf16, 100 steps x 3 on one box: none 3.29 ms, "1" 3.18; C4 lts f32: 3.99 -> 3.84.  "1,2": inside the noise of "1".
+        self.eps_stream = os.environ.get("ESR_LTS_EPS_STREAM", "1") != "0"      # (lts_forward: the perturbed heads' pass)
         self.scatter_streamed = {int(v) for v in os.environ.get("ESR_LTS_SCATTER_STREAM", "1").split(",") if v.strip() and v != "0"}
         for k, kind in (("brdf", KIND_BRDF), ("emit", KIND_EMIT)):
             self.packed[k] = torch.empty(self.L.esr_mlp_packed_floats(kind), dtype=torch.float32,
@@ -882,20 +883,41 @@ class LtsEngine(FineEngine):
         # emit_eps / brdf_eps: forward only (explicit points in reference order)
         P3 = self.epsp
         sv = torch.empty(m3, 4, device=dev)
-        self._run("expgrad_fwd(pts)", L.esr_expgrad_fwd, sp, None, None, None, None, _lib.ptr(pts_e), None, C.c_float(0.0),
-                  _lib.ptr(sdf), m3, 1, _lib.ptr(sv), s)
-        sdf_e = sv[:, 0].contiguous()
+        sdf_e = torch.empty(m3, device=dev)
         vd_e = self._z(m3, 3, device=dev)
-        self._feat_args_points(P3, pts_e, vd_e, sdf_e, sdf, (None, emog, brdfg))
-        self._features(P3, scene)
-        T3 = P3.tiles_all
         eps_grads = bool(cfg.get("eps_grads", True))      # keep activations for d/d(emit_eps, brdf_eps)
-        self._net_fwd(P3, "emit", KIND_EMIT, 88, 0, T3, save=eps_grads)
-        self._net_fwd(P3, "brdf", KIND_BRDF, 96, 0, T3, save=eps_grads)
-        self._act_batch("act_fwd", [dict(P=P3, z="emit.z", out="emit.a", rows=4, n_ch=3, act=ACT_SOFTPLUS),
-                                    dict(P=P3, z="brdf.z", out="brdf.a", rows=8, n_ch=5, act=ACT_SIGMOID)])
-        emit_eps, brdf_eps = self._gather_batch([(P3.bufs["emit.a"], 4, 0, 0, 3, None, m3),
-                                                 (P3.bufs["brdf.a"], 8, 0, 0, 5, None, m3)])
+        eps_out = {}
+
+        def eps_pass():
+            self._run("expgrad_fwd(pts)", L.esr_expgrad_fwd, sp, None, None, None, None, _lib.ptr(pts_e), None, C.c_float(0.0),
+                      _lib.ptr(sdf), m3, 1, _lib.ptr(sv), self._s())
+            sdf_e.copy_(sv[:, 0])
+            self._feat_args_points(P3, pts_e, vd_e, sdf_e, sdf, (None, emog, brdfg))
+            self._features(P3, scene)
+            T3 = P3.tiles_all
+            self._net_fwd(P3, "emit", KIND_EMIT, 88, 0, T3, save=eps_grads)
+            self._net_fwd(P3, "brdf", KIND_BRDF, 96, 0, T3, save=eps_grads)
+            self._act_batch("act_fwd", [dict(P=P3, z="emit.z", out="emit.a", rows=4, n_ch=3, act=ACT_SOFTPLUS),
+                                        dict(P=P3, z="brdf.z", out="brdf.a", rows=8, n_ch=5, act=ACT_SIGMOID)])
+            eps_out["emit"], eps_out["brdf"] = self._gather_batch([(P3.bufs["emit.a"], 4, 0, 0, 3, None, m3),
+                                                                   (P3.bufs["brdf.a"], 8, 0, 0, 5, None, m3)])
+        eps_done = None
+        if self.overlap_wgrad and self.eps_stream:
+            # this pass feeds nothing before the loss: on a stream of its own it runs beside the light-transport segment's
+            # gathers and the secondary march (latency-bound kernels) instead of in front of them
+            main_, side_ = torch.cuda.current_stream(dev), self._side_stream(1)
+            ev_ = torch.cuda.Event()
+            ev_.record(main_)
+            side_.wait_event(ev_)
+            with torch.cuda.stream(side_):
+                eps_pass()
+                eps_done = torch.cuda.Event()
+                eps_done.record(side_)
+            for t_ in eps_out.values():
+                t_.record_stream(main_)
+        else:
+            eps_pass()
+        emit_eps, brdf_eps = eps_out["emit"], eps_out["brdf"]
 
 
         # ---- light-transport segment
@@ -991,6 +1013,8 @@ class LtsEngine(FineEngine):
             "etc/brdf": r_brdf, "etc/brdf_eps": brdf_eps,
         }
         ctx.t.update(um=um, pts_e=pts_e, eps_grads=eps_grads, m3=m3, inv=self.inv_order)
+        if eps_done is not None:
+            torch.cuda.current_stream(dev).wait_event(eps_done)
         return ctx, out
 
     # ------------------------------------------------------------------ backward

@@ -270,9 +270,10 @@ def test_lts_step_equals_autograd_route(stage):
 
 @pytest.mark.parametrize("stage,dtype", [("lts", "f32"), ("pdra", "f32"), ("pdra", "bf16")])
 def test_lts_backward_on_three_streams_equals_the_one_stream_order(stage, dtype):
-    """The backward's stream schedule (weight-gradient jobs flushed to the second stream at points inside the backward,
-    the secondary pass's grid scatters on a third: lts_engine._flush_wgrad / _on_scatter_stream) against the same step with
-    everything in program order on one stream: same loss, gradients equal up to the order of the atomic sums."""
+    """The step's stream schedule (weight-gradient jobs flushed to the second stream at points inside the backward, the
+    secondary pass's grid scatters on a third: lts_engine._flush_wgrad / _on_scatter_stream; the forward's perturbed-heads
+    pass beside the light-transport segment) against the same step with everything in program order on one stream: same
+    loss, gradients equal up to the order of the atomic sums."""
     from esr_nerf_amd.synthetic import init_slab_model, slab_scene
     from esr_nerf_amd.trainer import LtsStep
     s_val, n_rays, R, Pn = 70.0, 256, 16, 24
@@ -292,10 +293,11 @@ def test_lts_backward_on_three_streams_equals_the_one_stream_order(stage, dtype)
     draws = dict(idx=torch.randperm(m3, generator=g)[:Pn].cuda(), dirs=torch.randn(Pn, R + 1, 3, generator=g).cuda(),
                  noise_normal=torch.randn(m3, 3, generator=g).cuda(), noise_emit=torch.randn(m3, 3, generator=g).cuda())
     eng = m.engine
-    assert eng.overlap_wgrad and eng.wgrad_early and eng.scatter_streamed, "the defaults this test is about"
+    assert eng.overlap_wgrad and eng.wgrad_early and eng.scatter_streamed and eng.eps_stream, "the defaults this test is about"
     res = {}
     for name, (overlap, early, scat) in dict(streams=(True, {1, 2, 3, 4, 5}, {1, 2}), serial=(False, set(), set())).items():
         eng.overlap_wgrad, eng.wgrad_early, eng.scatter_streamed = overlap, early, scat
+        eng.eps_stream = overlap                  # (the forward's perturbed-heads pass on its own stream: lts_forward)
         loss, G, _ = step.forward_loss_backward(b, s_val, draws=draws)
         torch.cuda.synchronize()
         res[name] = (float(loss), {k: v.clone() for k, v in G.items()})
