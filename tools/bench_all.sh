@@ -12,10 +12,10 @@ python3 bench.py --s-val 220 --steps 50 --warmup 10 --no-cpu-baseline > "$OUT/${
 python3 bench.py --dtype bf16 --steps 50 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_c2_bf16.json" 2>/dev/null
 python3 bench.py --config C3 --dtype f32 --steps 30 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_c3_f32.json" 2>/dev/null
 python3 bench.py --config C3 --dtype bf16 --steps 30 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_c3_bf16.json" 2>/dev/null
-python3 bench.py --config C4 --steps 20 --warmup 5 --cpu-rays 256 --cpu-iters 1 > "$OUT/${TAG}_bench_c4_lts_f32.json" 2>/dev/null
-python3 bench.py --config C4 --stage pdra --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/${TAG}_bench_c4_pdra_f32.json" 2>/dev/null
-python3 bench.py --config C5 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/${TAG}_bench_c5_pdra_bf16.json" 2>/dev/null
-python3 bench.py --config C5 --stage finetune --steps 30 --warmup 5 --no-cpu-baseline > "$OUT/${TAG}_bench_c5_finetune_bf16.json" 2>/dev/null
+python3 bench.py --config C4 --steps 30 --warmup 10 --cpu-rays 256 --cpu-iters 1 > "$OUT/${TAG}_bench_c4_lts_f32.json" 2>/dev/null
+python3 bench.py --config C4 --stage pdra --steps 30 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_c4_pdra_f32.json" 2>/dev/null
+python3 bench.py --config C5 --steps 30 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_c5_pdra_bf16.json" 2>/dev/null
+python3 bench.py --config C5 --stage finetune --steps 30 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_c5_finetune_bf16.json" 2>/dev/null
 python3 bench.py --grid 256 --steps 30 --warmup 8 --no-cpu-baseline > "$OUT/${TAG}_bench_c2_g256_f32.json" 2>/dev/null
 python3 bench.py --oblique --steps 50 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_c2_oblique_f32.json" 2>/dev/null
 python3 bench.py --grid 256 --oblique --steps 30 --warmup 8 --no-cpu-baseline > "$OUT/${TAG}_bench_c2_g256_oblique_f32.json" 2>/dev/null
