@@ -449,6 +449,9 @@ __device__ __forceinline__ int2 block_scan2(int2 v, int2 *wave_tot, int tid)   /
     return make_int2(wb.x + inc.x - v.x, wb.y + inc.y - v.y);
 }
 
+// TOTALS = false: the offsets only (the statistics and the range flag came from plan_totals_kernel; n_on / n_off / tiles are
+// written again, with the same values)
+template <bool TOTALS>
 __global__ void __launch_bounds__(1024) plan_kernel(const int32_t *__restrict__ cnt3,
                                                     const int64_t *__restrict__ em_modes,
                                                     const int32_t *__restrict__ stats, int n_rays,
@@ -459,8 +462,8 @@ __global__ void __launch_bounds__(1024) plan_kernel(const int32_t *__restrict__ 
     const int tid = threadIdx.x;
     // the split-fp16 forward kernels' sticky range flag (mlp_split.hip: esr_mlp_split_range_flag) rides to the host in bit 1
     // of the header's overflow word: no dispatch and no copy of its own
-    if (tid == 0 && range_flag && *range_flag) atomicOr(&plan->overflow, 2);
-    {   // survivor statistics m0, m1, m2 = sums of the per-ray counts (element j of stats is of class j % 3)
+    if (TOTALS && tid == 0 && range_flag && *range_flag) atomicOr(&plan->overflow, 2);
+    if constexpr (TOTALS) {   // survivor statistics m0, m1, m2 = sums of the per-ray counts (element j of stats is of class j % 3)
         int s[3] = {0, 0, 0};
         // 16-byte loads, unrolled: one workgroup has nobody to hide a load behind -- 75 dependent dword round trips for the
         // 25.6 k secondary rays were most of this kernel's 58 us, which sit right in front of the host's read of the plan
@@ -536,6 +539,42 @@ __global__ void __launch_bounds__(1024) plan_kernel(const int32_t *__restrict__ 
     }
 }
 
+// The numbers the HOST waits for (n_on, n_off, m0..m2, the overflow word) are plain sums: many workgroups, five atomics each,
+// ~5 us where the one-workgroup scan above takes 17 (8 k rays) to 48 us (25.6 k secondary rays).  The caller reads the header
+// back right behind this kernel and enqueues the scan (plan_kernel<false>: the offsets, which only the NEXT launches need)
+// behind the copy: it runs while the host wakes up and enqueues.  tiles_on / tiles_all are the host's to derive.
+__global__ void __launch_bounds__(1024) plan_totals_kernel(const int32_t *__restrict__ cnt3, const int64_t *__restrict__ em_modes,
+                                                           const int32_t *__restrict__ stats, int n_rays, esr_plan_t *plan,
+                                                           const unsigned *__restrict__ range_flag)
+{
+    __shared__ int part[16][5];
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0 && range_flag && *range_flag) atomicOr(&plan->overflow, 2);
+    int v[5] = {0, 0, 0, 0, 0};                         // on, off, m0, m1, m2
+#pragma unroll 2
+    for (int i = blockIdx.x * 1024 + tid; i < n_rays; i += gridDim.x * 1024) {
+        const int c = cnt3[i];
+        const bool on = em_modes[i] == 1;
+        v[0] += on ? c : 0; v[1] += on ? 0 : c;
+        v[2] += stats[3 * i]; v[3] += stats[3 * i + 1]; v[4] += stats[3 * i + 2];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] += __shfl_xor(v[k], off);
+    if ((tid & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) part[tid >> 6][k] = v[k];
+    __syncthreads();
+    if (tid < 5) {
+        int t = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += part[w][tid];
+        int32_t *dst = tid == 0 ? &plan->n_on : tid == 1 ? &plan->n_off : tid == 2 ? &plan->m0 : tid == 3 ? &plan->m1 : &plan->m2;
+        if (t) atomicAdd(dst, t);
+    }
+}
+
 int march_cap(const esr_scene_t *sc) { return ((sc->max_steps + 63) / 64) * 64; }
 
 template <int MODE, bool COARSE = false, bool GA = false>
@@ -583,7 +622,28 @@ ESR_API int esr_fine_plan(const int32_t *cnt3, const int64_t *em_modes, const in
 {
     if (n_rays < 0 || !plan) return ESR_EINVAL;
     if (n_rays && (!cnt3 || !em_modes || !ray_stats || !off3)) return ESR_EINVAL;
-    plan_kernel<<<1, 1024, 0, esr_stream(stream)>>>(cnt3, em_modes, ray_stats, n_rays, off3, plan, esr_split_range_flag_ptr());
+    plan_kernel<true><<<1, 1024, 0, esr_stream(stream)>>>(cnt3, em_modes, ray_stats, n_rays, off3, plan, esr_split_range_flag_ptr());
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_fine_plan_totals(const int32_t *cnt3, const int64_t *em_modes, const int32_t *ray_stats, int32_t n_rays,
+                                 esr_plan_t *plan, void *stream)
+{
+    if (n_rays < 0 || !plan) return ESR_EINVAL;
+    if (n_rays && (!cnt3 || !em_modes || !ray_stats)) return ESR_EINVAL;
+    const int grid = n_rays < 2048 ? 1 : (n_rays + 2047) / 2048 < 64 ? (n_rays + 2047) / 2048 : 64;
+    plan_totals_kernel<<<grid, 1024, 0, esr_stream(stream)>>>(cnt3, em_modes, ray_stats, n_rays, plan, esr_split_range_flag_ptr());
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_fine_plan_offsets(const int32_t *cnt3, const int64_t *em_modes, int32_t n_rays, int32_t *off3, esr_plan_t *plan,
+                                  void *stream)
+{
+    if (n_rays < 0 || !plan) return ESR_EINVAL;
+    if (n_rays && (!cnt3 || !em_modes || !off3)) return ESR_EINVAL;
+    plan_kernel<false><<<1, 1024, 0, esr_stream(stream)>>>(cnt3, em_modes, nullptr, n_rays, off3, plan, nullptr);
     ESR_CHECK_LAUNCH();
     return 0;
 }

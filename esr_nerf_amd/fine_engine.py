@@ -422,11 +422,14 @@ class FineEngine:
         else:
             self._march("march_count", "count", sp, rays_o, rays_d, viewdirs, _lib.ptr(mask_density),
                         _lib.ptr(sdf), n, _lib.ptr(rb["cnt3"]), _lib.ptr(last), _lib.ptr(rb["stats"]), _lib.ptr(plan_dev), s)
-        self._run("plan", L.esr_fine_plan, _lib.ptr(rb["cnt3"]), _lib.ptr(em_modes), _lib.ptr(rb["stats"]), n, _lib.ptr(rb["off3"]),
-                                   _lib.ptr(plan_dev), s)
+        # the counts the host waits for first (a many-workgroup sum), their copy, THEN the one-workgroup scan of the offsets,
+        # which runs while the host reads the header and enqueues
+        self._run("plan_totals", L.esr_fine_plan_totals, _lib.ptr(rb["cnt3"]), _lib.ptr(em_modes), _lib.ptr(rb["stats"]), n,
+                  _lib.ptr(plan_dev), s)
         self.plan_host.copy_(plan_dev, non_blocking=True)
         landed = torch.cuda.Event()
         landed.record()
+        self._run("plan", L.esr_fine_plan_offsets, _lib.ptr(rb["cnt3"]), _lib.ptr(em_modes), n, _lib.ptr(rb["off3"]), _lib.ptr(plan_dev), s)
         e_pre = None
         if prelude is not None:
             # on a side stream: the packing / zeroing kernels are bandwidth-bound and run beside the march and feature
@@ -438,7 +441,9 @@ class FineEngine:
                 e_pre = torch.cuda.Event()
                 e_pre.record(side)
         landed.synchronize()                                        # the one host wait of the step
-        n_on, n_off, tiles_on, tiles_all, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
+        n_on, n_off, _, _, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
+        tiles_on = (n_on + 31) // 32                                # (esr_fine_plan_totals leaves the tile counts to the host)
+        tiles_all = tiles_on + (n_off + 31) // 32
         self._range_check(overflow)                                 # (the PREVIOUS steps' split forward launches)
         if overflow & 1:
             self._overflow()

@@ -271,12 +271,15 @@ class LtsEngine(FineEngine):
                       _lib.ptr(mask_density), _lib.ptr(sdf), n, _lib.ptr(cnt3), _lib.ptr(last), _lib.ptr(stats),
                       _lib.ptr(self.plan_dev), _lib.ptr(P.cache), s)
             P.march = (stats, last, P.cache)
-        self._run("plan", L.esr_fine_plan, _lib.ptr(cnt3), _lib.ptr(em_modes), _lib.ptr(stats), n, _lib.ptr(off3),
+        # the counts the host waits for first (a many-workgroup sum), their copy, THEN the one-workgroup scan of the offsets:
+        # it runs while the host reads the header and enqueues (17 / 48 us off the path to the read-back)
+        self._run("plan_totals", L.esr_fine_plan_totals, _lib.ptr(cnt3), _lib.ptr(em_modes), _lib.ptr(stats), n,
                   _lib.ptr(self.plan_dev), s)
         self.plan_host.copy_(self.plan_dev, non_blocking=True)
         P.e_pre = None
         landed = torch.cuda.Event()
         landed.record()
+        self._run("plan", L.esr_fine_plan_offsets, _lib.ptr(cnt3), _lib.ptr(em_modes), n, _lib.ptr(off3), _lib.ptr(self.plan_dev), s)
         if between is not None:
             between()
         if prelude is not None:
@@ -287,7 +290,9 @@ class LtsEngine(FineEngine):
                 P.e_pre = torch.cuda.Event()
                 P.e_pre.record(side)
         landed.synchronize()
-        n_on, n_off, tiles_on, tiles_all, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
+        n_on, n_off, _, _, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
+        tiles_on = (n_on + 31) // 32                                 # (esr_fine_plan_totals leaves the tile counts to the host)
+        tiles_all = tiles_on + (n_off + 31) // 32
         self._range_check(overflow)
         if overflow & 1:
             self._overflow()

@@ -159,6 +159,16 @@ int esr_fine_plan_begin(esr_plan_t *plan, void *stream);
  */
 int esr_fine_plan(const int32_t *cnt3, const int64_t *em_modes, const int32_t *ray_stats,
                   int32_t n_rays, int32_t *off3, esr_plan_t *plan, void *stream);
+/*
+ * The same in two launches, for a caller that reads the header back: _totals leaves n_on, n_off, m0, m1, m2 and the overflow
+ * word in the header (many workgroups; tiles_on / tiles_all are NOT written: ceil(n_on / 32), tiles_on + ceil(n_off / 32)),
+ * _offsets computes off3 (and writes all four counts).  Copy the header between the two: the one-workgroup scan of _offsets
+ * then runs while the host reads it.  Header zeroed by esr_fine_plan_begin as for esr_fine_plan.
+ */
+int esr_fine_plan_totals(const int32_t *cnt3, const int64_t *em_modes, const int32_t *ray_stats, int32_t n_rays,
+                         esr_plan_t *plan, void *stream);
+int esr_fine_plan_offsets(const int32_t *cnt3, const int64_t *em_modes, int32_t n_rays, int32_t *off3, esr_plan_t *plan,
+                          void *stream);
 
 /*
  * march, fill pass: recomputes the march and writes one record per surviving

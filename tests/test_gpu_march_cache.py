@@ -81,3 +81,43 @@ def test_cached_march_equals_uncached(mask, s_val, oblique):
     assert torch.equal(a["dsdf"][valid], b["dsdf"][valid])
     scale = float(a["grad"].abs().max().clamp_min(1e-30))
     assert float((a["grad"] - b["grad"]).abs().max()) <= 1e-6 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 31, 1000, 2049, 8192, 25600, 70001])
+def test_plan_in_two_launches_equals_the_one_launch_plan(n):
+    """esr_fine_plan_totals (the counts the host reads back: many workgroups) + esr_fine_plan_offsets (the scan) against
+    esr_fine_plan on random per-ray counts and emissive modes: same offsets, same header (tiles as the host derives them),
+    including the registered range flag in bit 1 of the overflow word and a pre-set bit 0."""
+    from esr_nerf_amd import _lib
+    from esr_nerf_amd.fine_engine import FineEngine
+    L = _lib.lib()
+    dev = "cuda:0"
+    s = _lib.stream_ptr(dev)
+    eng = FineEngine(dev)                     # (registers the device's range flag)
+    g = torch.Generator().manual_seed(n)
+    cnt3 = torch.randint(0, 40, (n,), generator=g, dtype=torch.int32).to(dev)
+    em = torch.randint(0, 3, (n,), generator=g, dtype=torch.int64).to(dev)
+    stats = torch.randint(0, 200, (3 * n,), generator=g, dtype=torch.int32).to(dev)
+    for flag in (0, 1):
+        if eng.range_flag is not None:
+            eng.range_flag.fill_(flag)
+        off_a, off_b = torch.zeros(n, dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.int32, device=dev)
+        plan_a, plan_b = torch.zeros(8, dtype=torch.int32, device=dev), torch.zeros(8, dtype=torch.int32, device=dev)
+        plan_a[7] = plan_b[7] = 1             # (as the march leaves it after an overflow)
+        _lib.check(L.esr_fine_plan(_lib.ptr(cnt3), _lib.ptr(em), _lib.ptr(stats), n, _lib.ptr(off_a), _lib.ptr(plan_a), s), "plan")
+        _lib.check(L.esr_fine_plan_totals(_lib.ptr(cnt3), _lib.ptr(em), _lib.ptr(stats), n, _lib.ptr(plan_b), s), "totals")
+        torch.cuda.synchronize()
+        hdr = plan_b.tolist()                 # what the host sees between the two launches
+        _lib.check(L.esr_fine_plan_offsets(_lib.ptr(cnt3), _lib.ptr(em), n, _lib.ptr(off_b), _lib.ptr(plan_b), s), "offsets")
+        torch.cuda.synchronize()
+        ref = plan_a.tolist()
+        assert hdr[0:2] == ref[0:2] and hdr[4:8] == ref[4:8], (hdr, ref)
+        assert [(hdr[0] + 31) // 32, (hdr[0] + 31) // 32 + (hdr[1] + 31) // 32] == ref[2:4]
+        assert plan_b.tolist() == ref
+        assert torch.equal(off_a, off_b)
+        on = em.cpu() == 1
+        assert ref[0] == int(cnt3.cpu()[on].sum()) and ref[1] == int(cnt3.cpu()[~on].sum())
+        assert ref[7] == 1 | (2 if (flag and eng.range_flag is not None) else 0)
+    if eng.range_flag is not None:
+        eng.range_flag.zero_()
