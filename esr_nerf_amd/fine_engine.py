@@ -440,6 +440,11 @@ class FineEngine:
                 prelude()
                 e_pre = torch.cuda.Event()
                 e_pre.record(side)
+        # padding lanes of the record arrays carry ray -1: filled BEFORE the wait (whole buffer of the previous step's size),
+        # one dispatch less between the read-back and the first kernel that depends on it
+        pre_rec = ws.buf.get("rec_ray")
+        if pre_rec is not None:
+            pre_rec.fill_(-1)
         landed.synchronize()                                        # the one host wait of the step
         n_on, n_off, _, _, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
         tiles_on = (n_on + 31) // 32                                # (esr_fine_plan_totals leaves the tile counts to the host)
@@ -455,7 +460,8 @@ class FineEngine:
                 main.wait_event(e_pre)
             return ctx, last, srgb, lin
         ws.ensure(tiles_all)
-        ws["rec_ray"][: tiles_all * 32].fill_(-1)
+        if ws["rec_ray"] is not pre_rec:                            # (the workspace grew: a new, unfilled buffer)
+            ws["rec_ray"][: tiles_all * 32].fill_(-1)
         if cached:
             self._run("march_fill", L.esr_fine_march_fill_cached, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), n, _lib.ptr(rb["off3"]),
                       _lib.ptr(rb["stats"]), _lib.ptr(rb["cache"]), _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_step"]),

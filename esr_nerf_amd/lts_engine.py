@@ -289,6 +289,9 @@ class LtsEngine(FineEngine):
                 prelude()
                 P.e_pre = torch.cuda.Event()
                 P.e_pre.record(side)
+        pre_rec = P.bufs.get("rec_ray")       # padding lanes carry ray -1: filled before the wait (fine_engine.forward)
+        if pre_rec is not None:
+            pre_rec.fill_(-1)
         landed.synchronize()
         n_on, n_off, _, _, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
         tiles_on = (n_on + 31) // 32                                 # (esr_fine_plan_totals leaves the tile counts to the host)
@@ -300,7 +303,8 @@ class LtsEngine(FineEngine):
         P.counts = dict(m0=m0, m1=m1, m2=m2, m3=n_on + n_off, n_on=n_on, n_off=n_off)
         P.ensure(max(tiles_all, 1))
         rec_ray = P.buf("rec_ray", 1, torch.int32)
-        rec_ray[: max(tiles_all, 1) * 32].fill_(-1)
+        if rec_ray is not pre_rec:                # (the pass's buffers grew: a new, unfilled one)
+            rec_ray[: max(tiles_all, 1) * 32].fill_(-1)
         if tiles_all and ga:
             self._run(f"march_fill[{P.name}]", L.esr_fine_march_fill_ga, sp, _lib.ptr(rays_o), _lib.ptr(rays_d),
                       _lib.ptr(viewdirs), _lib.ptr(mask_density), _lib.ptr(sdf), n, _lib.ptr(off3), _lib.ptr(rec_ray),
