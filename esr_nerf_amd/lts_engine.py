@@ -835,9 +835,8 @@ class LtsEngine(FineEngine):
         sp = C.byref(scene)
         self._feat_args_records(P0, rays_o, rays_d, viewdirs, sdf, (offg, emog, brdfg), (offg, emog, brdfg))
         self._features(P0, scene)
-        # (started behind the first large launch: checking out numpy's state and waking the worker is ~50 us of host time
-        # the device would otherwise spend idle right after the plan read; the draw itself is 0.4 ms against ~0.8 ms of
-        # primary-pass work queued in front of its consumer)
+        # (handing the draw to the library's worker thread is ~7 us of host time; the draw itself is 0.2-0.4 ms against
+        # ~0.6 ms of primary-pass work queued in front of its consumer)
         point_draw = _PointDraw(m3, min(int(cfg["num_ltspts"]), m3), self._draw_ring) if draws is None else None
         # exact normals (+ positions) of every surviving sample
         eg = torch.empty(T * 32, 4, device=dev)
