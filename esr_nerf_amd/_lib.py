@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libesr_hip.so")
 # developer experiments only (tools/variant.sh builds alternative libraries; tools/ab_env.sh times them side by side on one box)
 LIB_PATH = os.environ.get("ESR_LIB_PATH", LIB_PATH)
-ABI_VERSION = 22
+ABI_VERSION = 23
 _lib = None
 
 
