@@ -263,7 +263,13 @@ struct WgradArgs {
 // tile count (tools/wgrad_scaling.py: 135 us per 4-layer net) -- the partial dW of every workgroup goes to a slab
 // (256 x 147 KB written, then read by the reduction) and the ring has to fill and drain.  With J jobs per launch each
 // job runs on 256/J workgroups: J times fewer, J times longer launches, and J times less slab traffic per layer.
-constexpr int MAX_JOBS = 8;
+// (16 since the end of round 4: the sixteen radiance jobs of an LTS flush -- two nets x four layers x two passes -- are one
+//  launch; C5 2.97 -> 2.91 ms, C4 unchanged, A/B on one box with tools/variant.sh -DESR_MAX_JOBS=8.  The batch is a kernel
+//  argument: 16 x 152 B, inside the 4 KB limit.)
+#ifndef ESR_MAX_JOBS
+#define ESR_MAX_JOBS 16
+#endif
+constexpr int MAX_JOBS = ESR_MAX_JOBS;
 struct WgradBatch {
     int n;
     WgradArgs job[MAX_JOBS];
