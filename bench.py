@@ -362,6 +362,31 @@ def other_workloads(budget_s=170.0):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N ...` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` as a child, pass its output through (rank 0 prints
+    the ONE JSON line last) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:                   # a free port for the rendezvous
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8")),
+                       capture_output=True, text=True)
+    sys.stderr.write(r.stderr)
+    lines = r.stdout.splitlines()
+    js = [l for l in lines if l.startswith("{")]
+    for l in lines:
+        if not js or l is not js[-1]:
+            print(l)
+    if js:
+        sys.stdout.flush()
+        print(js[-1], flush=True)                 # the ONE JSON line, last on stdout
+    return r.returncode if (r.returncode != 0 or js) else 1
+
+
 def main():
     a = parse()
     bad_ranks = None
@@ -380,9 +405,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+            # plain `python bench.py --gpus N`: start the N ranks ourselves, as a CHILD process (this process has not touched
+            # the GPU and must not be replaced by exec on this pool), relay rank 0's JSON line and the launcher's exit code
+            raise SystemExit(self_launch(a.gpus))
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
@@ -554,7 +580,7 @@ def main():
         split_bwd = split_fwd and bool(getattr(eng, "split_bwd", False))
         split_wg = split_bwd and bool(getattr(eng, "split_wgrad", False))
         dominant, dom_calls = ((SPLIT_KERNELS["mlp_fwd(rad)"], ["mlp_fwd(rad)"]) if split_fwd else
-                               ("mlp_fwd_kernel<0>", ["mlp_fwd(rad)" if getattr(eng, "merge_rad", False) else "mlp_fwd(emo)"]))
+                               ("mlp_fwd_kernel<0>", ["mlp_fwd(rad)"]))
     # timed region: exactly K steps, events only around the dominant kernel's launches (on their stream)
     eng.enable_timing(dominant is not None, only=dom_calls if dominant else None)
     if pg is not None:
@@ -659,6 +685,9 @@ def main():
             # launches of this library's kernels per step (C-ABI calls; torch's own fills / copies / gathers come on top:
             # tools/dispatches.sh counts every device dispatch from a rocprofv3 trace)
             "c_abi_launches_per_step": calls_per_step,
+            # steps that the split-fp16 kernels' range flag sent to the f32 MFMA kernels (fine_engine.py: same-step fallback);
+            # a timed step among them would have run twice
+            "split_fallback_steps": int(getattr(eng, "split_fallback_steps", 0)),
         }
         if opt_ms is not None:
             out["optimizer_step"] = {"ms": opt_ms, "parameters": n_params, "kernel": "esr_adam_step (fused Adam, 28 B/param)",

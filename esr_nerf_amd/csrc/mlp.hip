@@ -1398,7 +1398,68 @@ ESR_API int esr_mlp_pack(int kind, const esr_mlp_weights_t *w, float *packed, vo
 ESR_API int64_t esr_mlp_packed_split_elems(int kind)
 {
     if (!kind_ok(kind)) return ESR_EINVAL;
-    return ((int64_t)split_layout(kind).total_chunks + split_layout_t(kind).total_chunks) * 512;      // forward | transposed planes
+    return split_gain_offset(kind) + SPLIT_GAIN_PAD;      // forward | transposed planes | the gradient gain bound (one fp32)
+}
+
+// The split input-gradient chain carries dz and every hidden gradient as fp16 planes of ONE power-of-two scale per tile.  How
+// far a hidden gradient can exceed the output gradient is bounded by the weights alone: dZ[l-1] = mask (.) (W_l^T dZ[l]), so
+// max |dZ[l-1]| <= (largest column sum of |W_l|) max |dZ[l]|.  One block per net: G = max over the hidden layers of the
+// running product of those column sums (and 1), written behind the net's planes.  mlp_dgrad_split_kernel scales a tile so
+// that G max |dz| stays inside fp16's range -- no overflow in the chain BY CONSTRUCTION -- and hands the weight-gradient
+// kernels max |dz| max(1, G / 16) as their scale source (their headroom above it is >= 32x), so neither needs a run-time check.
+// A net whose bound is beyond 2^18 (or not finite) raises the range flag: the step runs on the f32 MFMA kernels.
+template <int KIND>
+__device__ __forceinline__ void split_gain_job(const PackArgs &A)
+{
+    constexpr NetDesc D = net_desc(KIND);
+    constexpr int NL = D.n_layers, hid = 32 * D.hid_tiles, RG = 4;         // 1024 threads = RG row groups x 256 columns
+    static_assert(hid <= 256, "one thread per hidden unit and row group");
+    __shared__ float red[RG * 256];
+    const int tid = threadIdx.x, col = tid & 255, rg = tid >> 8;
+    float cum = 1.f, worst = 1.f;
+    for (int l = NL - 1; l >= 1; --l) {
+        const int outd = l == NL - 1 ? D.out_dim : hid;
+        float s = 0.f;
+        if (col < hid) {
+            const float *w = A.w[l] + col;
+            int o = rg;
+            for (; o + 7 * RG < outd; o += 8 * RG) {               // eight independent loads in flight per thread
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = w[(int64_t)(o + k * RG) * hid];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += fabsf(v[k]);
+            }
+            for (; o < outd; o += RG) s += fabsf(w[(int64_t)o * hid]);
+        }
+        red[tid] = s;
+        __syncthreads();
+        if (tid < 256) red[tid] = (red[tid] + red[tid + 256]) + (red[tid + 512] + red[tid + 768]);     // the column's sum
+        __syncthreads();
+        for (int k = 128; k > 0; k >>= 1) {
+            if (tid < k) { const float a = red[tid], b = red[tid + k]; red[tid] = (a != a || b != b) ? a + b : fmaxf(a, b); }   // (a NaN stays)
+            __syncthreads();
+        }
+        cum *= red[0];
+        if (!(worst >= cum)) worst = cum;                    // (also takes a NaN)
+        __syncthreads();
+    }
+    if (tid == 0) {
+        *reinterpret_cast<float *>(A.outs + split_gain_offset(KIND)) = worst;
+        if (A.range && !(worst <= SPLIT_GAIN_MAX)) atomicOr(A.range, 1u);
+    }
+}
+__global__ void __launch_bounds__(1024) split_gain_kernel(PackBatch B)
+{
+    const PackArgs &A = B.job[blockIdx.x];
+    if (!A.outs) return;
+    switch (A.kind) {                                    // (block-uniform)
+    case ESR_MLP_RADIANCE: split_gain_job<ESR_MLP_RADIANCE>(A); break;
+    case ESR_MLP_TONEMAP:  split_gain_job<ESR_MLP_TONEMAP>(A); break;
+    case ESR_MLP_BRDF:     split_gain_job<ESR_MLP_BRDF>(A); break;
+    case ESR_MLP_EMIT:     split_gain_job<ESR_MLP_EMIT>(A); break;
+    default: break;
+    }
 }
 
 ESR_API int esr_mlp_pack_batch(int n, const int32_t *kinds, const esr_mlp_weights_t *const *w, float *const *packed32,
@@ -1409,6 +1470,7 @@ ESR_API int esr_mlp_pack_batch(int n, const int32_t *kinds, const esr_mlp_weight
     PackBatch B = {};
     B.n = n;
     int64_t most = 0;
+    bool any_split = false;
     for (int i = 0; i < n; ++i) {
         const int kind = kinds[i];
         if (!kind_ok(kind) || !w[i] || !packed32[i]) return ESR_EINVAL;
@@ -1422,12 +1484,18 @@ ESR_API int esr_mlp_pack_batch(int n, const int32_t *kinds, const esr_mlp_weight
         A.out = packed32[i];
         A.out16 = packed16 ? static_cast<__bf16 *>(packed16[i]) : nullptr;
         A.outs = packed_split ? static_cast<_Float16 *>(packed_split[i]) : nullptr;
-        const int64_t tot = pack_layout(kind).total + pack16_layout(kind).total +
-                            (A.outs ? ((int64_t)split_layout(kind).total_chunks + split_layout_t(kind).total_chunks) * 512 : 0);
+        if (A.outs && !(kind == ESR_MLP_RADIANCE || kind == ESR_MLP_TONEMAP || kind == ESR_MLP_BRDF || kind == ESR_MLP_EMIT)) return ESR_EINVAL;
+        A.range = A.outs ? esr_split_range_flag_ptr() : nullptr;
+        any_split = any_split || A.outs;
+        const int64_t tot = pack_layout(kind).total + pack16_layout(kind).total + (A.outs ? split_gain_offset(kind) : 0);
         most = tot > most ? tot : most;
     }
     pack_kernel<<<dim3(esr_grid_for(most, 256, 256), n), 256, 0, esr_stream(stream)>>>(B);
     ESR_CHECK_LAUNCH();
+    if (any_split) {                                     // the nets' gradient gain bounds, behind their planes
+        split_gain_kernel<<<n, 1024, 0, esr_stream(stream)>>>(B);
+        ESR_CHECK_LAUNCH();
+    }
     return 0;
 }
 

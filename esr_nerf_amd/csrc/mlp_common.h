@@ -137,6 +137,7 @@ struct PackArgs {
     float *out;
     __bf16 *out16;          // bf16 twin (pack16_body), or NULL
     _Float16 *outs;         // split-fp16 planes of the forward weights (packs_body; mlp_split.hip), or NULL
+    unsigned *range;        // the split kernels' range flag (mlp_split.hip), or NULL: ORed with 1 when 64 w leaves fp16's range
 };
 
 // One element of the packed fp32 buffer.  KIND is a template argument so that the layout table is a set of immediates:
@@ -333,6 +334,20 @@ __host__ __device__ constexpr SplitLayout split_layout_t(int kind)
     L.total_chunks = o;
     return L;
 }
+// A weight whose first plane fp16(64 w) is not finite (|w| >= 1023.5, inf, NaN) cannot be carried by the planes: the sticky
+// range flag tells the host, which runs the step on the f32 MFMA kernels instead (fine_engine.py: same-step fallback).
+__device__ __forceinline__ void split_weight_range(const PackArgs &A, float v64)
+{
+    if (A.range && !(fabsf(v64) < 65504.f)) atomicOr(A.range, 1u);
+}
+// The planes buffer ends with one fp32 slot: the net's GRADIENT GAIN BOUND (split_gain_kernel, mlp.hip), read by the split
+// input-gradient kernel.  Offset in fp16 elements:
+__host__ __device__ constexpr int64_t split_gain_offset(int kind)
+{
+    return ((int64_t)split_layout(kind).total_chunks + split_layout_t(kind).total_chunks) * 512;
+}
+constexpr int SPLIT_GAIN_PAD = 8;                       // fp16 elements reserved for the slot (16 bytes)
+constexpr float SPLIT_GAIN_MAX = 262144.f;              // 2^18: beyond it the scaled chain would lose bits -> range flag
 template <int KIND>
 __device__ __forceinline__ void packst_body(const PackArgs &A, int64_t e)
 {
@@ -360,6 +375,7 @@ __device__ __forceinline__ void packst_body(const PackArgs &A, int64_t e)
         if (orow < L.out_dim[q] && col >= 0 && col < L.in_dim[q]) v = A.w[l][(int64_t)orow * L.in_dim[q] + col];
     }
     v *= SPLIT_W_SCALE;
+    split_weight_range(A, v);
     const _Float16 w1 = (_Float16)v;
     A.outs[BASE + e] = plane == 0 ? w1 : (_Float16)(v - (float)w1);
 }
@@ -387,6 +403,7 @@ __device__ __forceinline__ void packs_body(const PackArgs &A, int64_t e)
         if (row < L.out_dim[l] && col >= 0 && col < L.in_dim[l]) v = A.w[l][(int64_t)row * L.in_dim[l] + col];
     }
     v *= SPLIT_W_SCALE;
+    split_weight_range(A, v);
     const _Float16 w1 = (_Float16)v;
     A.outs[e] = plane == 0 ? w1 : (_Float16)(v - (float)w1);
 }

@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_fwd_split_kerne
     if (PREFETCH_X && (int)blockIdx.x - blk0 < ngroups) fetch((int)blockIdx.x - blk0);
     const int hvoff = tile_voff(lane);
 
-    int rmax = 0;                                           // largest hidden activation of this wave, as bits (all >= 0 after the ReLU)
+    int rmax = 0;                                           // largest |input| / hidden activation of this wave, as bits (all >= 0)
     // LDS buffer of step st = (st + par) & 1: a net with an odd number of steps per group (the 128-wide nets: 7) starts every
     // other group in buffer 1
     for (int tg = (int)blockIdx.x - blk0, trip = 0; tg < ngroups; tg += nblk, ++trip) {
@@ -290,13 +290,17 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_fwd_split_kerne
         // planes: first layer's input (from X) | set A | set B; layer 0 writes A, 1 reads A writes B, 2 reads B writes A, 3 reads A
         f16x8 xi1[KS1], xi2[KS1], pa1[2 * HT], pa2[2 * HT], pb1[2 * HT], pb2[2 * HT];
         if constexpr (!PREFETCH_X) fetch(tg);
+        float xmax = 0.f;                                  // largest |input| of the tile: its first plane is fp16 too
 #pragma unroll
         for (int j = 0; j < KS1; ++j) {
             float v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = xn[j * 8 + i];
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) xmax = fmaxf(xmax, fmaxf(fabsf(v[i]), fabsf(v[i + 1])));      // (v_max3_f32 with |.| modifiers)
             split8(v, xi1[j], xi2[j]);
         }
+        rmax = max(rmax, __float_as_int(xmax));            // (non-negative floats order like their bits; dead before the planes are live)
         ESR_SPLIT_STAMP(0);
         if constexpr (PREFETCH_X) fetch(tg + nblk < ngroups ? tg + nblk : tg);       // the next group's rows (past the end: this group again, never used)
         // one accumulator per tile (two tiles alternate: the one in flight and the one in its epilogue); bz: a tile's biases,
@@ -482,17 +486,19 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_fwd_split_kerne
         }
         run_layer(std::integral_constant<int, NL - 1>{}, pa1, pa2, pb1, pb2);      // output layer (pb: unused)
     }
-    // a first plane holds |x| < 65504: a hidden activation at or above SPLIT_RANGE (or inf / NaN, which an overflowing input or
-    // weight turns into) raises the caller's sticky flag -- the host reports it instead of training on inf (fine_engine.py)
+    // a first plane holds |x| < 65504: an input or a hidden activation at or above SPLIT_RANGE (or inf; a +NaN activation) raises
+    // the caller's sticky flag -- the host re-runs the step on the f32 MFMA kernels (fine_engine.py).  The OUTPUT layer's results
+    // are fp32 sums that never become planes: nothing to check.  (A NaN input is NaN in both engines' results.)
     if (AB.range && rmax >= __float_as_int(SPLIT_RANGE)) atomicOr(AB.range, 1u);
 }
 
 // ---- the input-gradient chain on the same scheme ---------------------------------------------------------------------
 // dZ[2] = mask ⊙ (W3ᵀ dz), dZ[1] = mask ⊙ (W2ᵀ dZ[2]), dZ[0] = mask ⊙ (W1ᵀ dZ[1]), dX = W0ᵀ dZ[0] (rows 0 .. 43: the rows that
 // lead back to a grid) -- mlp.hip's mlp_dgrad_kernel<0> with the products on the 16-bit matrix cores.  Gradients are small
-// (1e-3 .. 1e-9) where fp16's normal range ends at 6e-5, so a tile's chain runs SCALED: s = 2^k with max |dz| of the tile
-// brought to ~16 (the multiplications by s and 1 / s are exact, the ReLU masks do not care, and the chain is linear); a
-// layer can grow a value by at most its row-sum of |W| -- a few units -- against fp16's ceiling of 65504.  What counts for
+// (1e-3 .. 1e-9) where fp16's normal range ends at 6e-5, so a tile's chain runs SCALED: s = 2^k (the multiplications by s
+// and 1 / s are exact, the ReLU masks do not care, and the chain is linear).  A layer can grow a value by at most the largest
+// column sum of its |W|; the running product of those sums, G, comes with the planes (split_gain_kernel), and s puts
+// G max |dz| of the tile into [2^14, 2^15): no plane of the chain can reach fp16's ceiling of 65504.  What counts for
 // the consumers (weight gradients and grid scatters sum over samples) is the error relative to the tile's LARGEST
 // gradients: 2^-22 of them, as in the forward; a sample whose gradient is 2^-20 of its tile's largest loses relative
 // precision, as it does in any sum with the large ones.
@@ -577,6 +583,11 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_dgrad_split_ker
     const int hvoff = tile_voff(lane);
 
     float wmax = 0.f;                                       // largest |dz| of this wave's tiles (AB.amax)
+    // the net's gradient gain bound G >= 1 (mlp.hip: split_gain_kernel, behind the planes): no hidden gradient of a tile exceeds
+    // G max |dz|.  ge = ceil(log2 G)
+    const float *gainp = reinterpret_cast<const float *>(A.planes + (size_t)(S::BASE_CHUNK + L.total_chunks) * 512);
+    const int gbits = __builtin_amdgcn_readfirstlane(__float_as_int(*gainp));
+    const int kbase = __builtin_amdgcn_readfirstlane(141 + 127 - ((gbits >> 23) & 0xff) - ((gbits & 0x7fffff) ? 1 : 0));   // 141 - ge (scalar)
     // LDS buffer of step st = (st + par) & 1: a net with an odd number of steps per group (the 128-wide nets: 7) starts every
     // other group in buffer 1
     for (int tg = (int)blockIdx.x - blk0, trip = 0; tg < ngroups; tg += nblk, ++trip) {
@@ -586,7 +597,8 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_dgrad_split_ker
         const int t = live ? tt : A.t1 - 1;
         int hv = hvoff;                                                       // (opaque per group: see the forward)
         asm volatile("" : "+v"(hv));
-        // the tile's scale: 2^k with the largest |dz| of its 32 samples at ~16 (exponent arithmetic; an all-zero tile: 1)
+        // the tile's scale: 2^k with G x (the largest |dz| of its 32 samples) in [2^14, 2^15) (exponent arithmetic; an all-zero
+        // tile: 1): every plane of the chain stays below fp16's 65504 whatever the masks and signs do
         float zmax = 0.f;
 #pragma unroll
         for (int i = 0; i < D.out_dim; ++i) zmax = fmaxf(zmax, fabsf(zn[i]));
@@ -594,7 +606,7 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_dgrad_split_ker
         for (int o = 16; o > 0; o >>= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, o));
         if (live) wmax = fmaxf(wmax, zmax);                                   // (the launch's maximum: one atomic per wave, at the end)
         const int ez = (__float_as_int(zmax) >> 23) & 0xff;                   // biased exponent of the maximum
-        const int ks = ez == 0 ? 0 : 131 - ez;                                // scale exponent: max lands in [16, 32)
+        const int ks = ez == 0 ? 0 : kbase - ez;                              // scale exponent: G max lands in [2^14, 2^15)
         const int kc = ks < -100 ? -100 : (ks > 100 ? 100 : ks);
         const float sc = __int_as_float((127 + kc) << 23), isc = __int_as_float((127 - kc) << 23);
         f16x8 xi1[1], xi2[1];
@@ -730,6 +742,9 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_dgrad_split_ker
     // max |dz| of the launch: one atomic per wave, and only from a wave that would raise the value (non-negative floats order
     // like their bit patterns).  One atomic per TILE -- 16 384 on one address at C2 -- took 0.14 ms to drain: twice the tone
     // mapper's whole launch.
+    // (what the weight-gradient kernels scale by: max |dz| x max(1, G / 16) -- their headroom above the scale source is >= 32x, so
+    //  G max |dz|, the bound of every hidden gradient, fits their planes as well)
+    wmax *= fmaxf(1.f, *gainp * 0.0625f);
     if (AB.amax && lane == 0 && wmax > *reinterpret_cast<volatile float *>(AB.amax))
         atomicMax(reinterpret_cast<unsigned *>(AB.amax), __float_as_uint(wmax));
 }

@@ -90,12 +90,14 @@ class _LtsRender(torch.autograd.Function):
         eng: LtsEngine = model.engine
         nets = (("off", KIND_RADIANCE, 8), ("emo", KIND_RADIANCE, 8), ("tone", KIND_TONEMAP, 4),
                 ("brdf", KIND_BRDF, 8), ("emit", KIND_EMIT, 8))
-        o = 0
-        with eng.packing():
-            for name, kind, n in nets:
-                ps = mlp_params[o:o + n]
-                eng.pack(name, kind, list(ps[0::2]), list(ps[1::2]))
-                o += n
+        def pack():
+            o = 0
+            with eng.packing():
+                for name, kind, n in nets:
+                    ps = mlp_params[o:o + n]
+                    eng.pack(name, kind, list(ps[0::2]), list(ps[1::2]))
+                    o += n
+        pack()
         scene = model.scene_struct()
         scene2 = model.scene_struct(near=model.lts_near)
         grids = dict(sdf=model.sdf.device_view(), off=model.off_color.device_view(),
@@ -105,6 +107,10 @@ class _LtsRender(torch.autograd.Function):
         cfg = dict(num_2ndrays=model.num_2ndrays, num_ltspts=model.num_ltspts, normal_eps=batch["normal_eps"],
                    emit_eps=batch["emit_eps"], pdra=model.pdra_mode)
         lctx, out = eng.lts_forward(scene, scene2, batch, grids, env, cfg, draws)
+        if eng.range_hit():       # a split-fp16 kernel's range flag: again on the f32 MFMA kernels, same draws (fine_engine.py)
+            with eng.f32_only():
+                pack()
+                lctx, out = eng.lts_forward(scene, scene2, batch, grids, env, cfg, eng.last_draws)
         ctx.lctx, ctx.model = lctx, model
         ctx.set_materialize_grads(False)         # unused result tensors arrive as None and cost nothing
         ctx.shapes = [tuple(p.shape) for p in mlp_params]
@@ -137,17 +143,24 @@ class _FinetuneRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, batch, draws, emo_color, *emo_params):
         eng: LtsEngine = model.engine
-        with eng.packing():
-            eng.pack("emo", KIND_RADIANCE, list(emo_params[0::2]), list(emo_params[1::2]))
-            for name, kind, net in (("brdf", KIND_BRDF, model.brdfnet), ("emit", KIND_EMIT, model.emitnet)):
-                lins = net.layers()
-                eng.pack(name, kind, [l.weight.detach() for l in lins], [l.bias.detach() for l in lins])
+        def pack():
+            with eng.packing():
+                eng.pack("emo", KIND_RADIANCE, list(emo_params[0::2]), list(emo_params[1::2]))
+                for name, kind, net in (("brdf", KIND_BRDF, model.brdfnet), ("emit", KIND_EMIT, model.emitnet)):
+                    lins = net.layers()
+                    eng.pack(name, kind, [l.weight.detach() for l in lins], [l.bias.detach() for l in lins])
+        pack()
         grids = dict(sdf=model.sdf.device_view(), emo=model.emo_color.device_view(), brdf=model.brdf.device_view(),
                      emit=model.emit_color.device_view(),
                      mask=model.mask_cache.density.view(*model.mask_cache.density.shape[2:]))
         cfg = dict(num_2ndrays=model.num_2ndrays, num_ltspts=model.num_ltspts)
         fctx, out = eng.finetune_forward(model.scene_struct(), model.scene_struct(near=model.lts_near), batch, grids,
                                          cfg, draws)
+        if eng.range_hit():       # (the range fallback, as in _LtsRender)
+            with eng.f32_only():
+                pack()
+                fctx, out = eng.finetune_forward(model.scene_struct(), model.scene_struct(near=model.lts_near), batch, grids,
+                                                 cfg, eng.last_draws)
         ctx.fctx, ctx.model = fctx, model
         ctx.shapes = [tuple(p.shape) for p in emo_params]
         ctx.set_materialize_grads(False)

@@ -70,6 +70,7 @@ class FineCtx:
     feat_args: object = None
     march_cache: object = None        # (ray_stats, alphainv_last, cache) of the count pass, for the backward
     x16: bool = False                 # the features of this step are the bf16 tile (ws["X16"]), not the fp32 one
+    f32_only: bool = False            # the forward ran on the f32 MFMA kernels (range fallback): so must the backward
 
 
 class _Workspace:
@@ -125,68 +126,44 @@ class FineEngine:
         self._only = None
         self._events = []
         self.n_calls = 0
-        self.overlap_wgrad = os.environ.get("ESR_OVERLAP_WGRAD", "1") != "0"
-        # ESR_SYN_DZ=1 (bf16 engine, radiance nets; OFF by default, measured): the last hidden layer's dZ tile is neither stored
-        # nor read -- synthesised in the unified weight-gradient launch (csrc/mlp.hip: wgrad_reg_body<..., SYN>; needs
-        # ESR_WGRAD_UNI).  C3 bf16: -0.59 GB of HBM traffic per step, input gradients 0.205 -> 0.175 ms, but a synthesised tile
-        # costs the weight-gradient launch 1.2x a stored one (its MFMA + mask + pack chain sits in the staging step, in front
-        # of the tile's barrier): 0.36 -> 0.41 ms with the best workgroup shares -- the step does not get faster.
-        self.syn_dz = (self.bf16 and os.environ.get("ESR_SYN_DZ", "0") != "0" and os.environ.get("ESR_WGRAD_UNI", "1") != "0")
-        # (f32 engine with split weight gradients: the same switch, mlp_wgrad_syn192s_kernel; C2: input gradients 0.39 -> 0.34 ms,
-        #  weight gradients 0.47 -> 0.56 ms, step 2.03 -> 2.06 ms -- OFF)
-        self._syn_dz32_env = os.environ.get("ESR_SYN_DZ", "0") != "0" and os.environ.get("ESR_WGRAD_UNI", "1") != "0"
-        self.tone_wgrad_early = os.environ.get("ESR_TONE_WGRAD_EARLY", "0") != "0"       # (A/B switch, OFF: backward())
-        # f32 engine: the three radiance forward passes of a step as ONE launch (esr_mlp_fwd_fine) and the two radiance
-        # input-gradient passes as one (esr_mlp_dgrad_fine); ESR_MERGE_RAD=0 keeps the separate launches (A/B timing)
-        self.merge_rad = os.environ.get("ESR_MERGE_RAD", "1") != "0"
-        # measured NEGATIVE on MI355X (C2: 4.08 ms without, 4.19 / 4.32 / 4.47 ms with the input-gradient kernels capped at
-        # 256 / 384 / uncapped workgroups): the atomics-heavy scatters slow the matrix kernels more than they hide
-        self.overlap_scatter = os.environ.get("ESR_OVERLAP_SCATTER", "0") != "0"
-        self.dgrad_cap = int(os.environ.get("ESR_DGRAD_CAP", "256"))
+        self.overlap_wgrad = True         # the weight gradients on a second stream beside the grid scatters (bench.py turns it off
+        #                                   while it times kernels one at a time)
         self._side = None
         self._raw: Dict[str, tuple] = {}
         self._pack_cache: Dict[str, tuple] = {}
         self._pack_pending = None         # inside `with self.packing():` the jobs of one esr_mlp_pack_batch launch
         self._pack_batch_cache = None
-        # the tone mapper's weight gradients recompute its hidden layer (csrc/tone_wgrad.hip; round 3: also with bf16
-        # operands), so its forward keeps only the ReLU masks and its input-gradient pass stores no dZt;
-        # ESR_TONE_RECOMPUTE16=0: the bf16 engine's saved-tile path of round 2 (A/B timing)
-        self.tone_recompute = (not self.bf16) or os.environ.get("ESR_TONE_RECOMPUTE16", "1") != "0"
-        # bf16 engine, merged radiance launches: the features are written as a bf16 tile in the operand layout of the
-        # first layer (esr_fine_feat_fwd_x16); ESR_X16=0: the fp32 tile, converted on load (A/B timing)
-        self.x16 = self.bf16 and os.environ.get("ESR_X16", "1") != "0"
-        # f32 engine: the radiance forward's products on the 16-bit matrix cores from split fp16 planes, fp32 results
-        # (csrc/mlp_split.hip); ESR_SPLIT_FWD=0: the f32 MFMA forward (A/B timing, and for inputs beyond fp16's range)
+        # bf16 engine: the features are written as a bf16 tile in the operand layout of the first layer (esr_fine_feat_fwd_x16)
+        # whenever the stencil radii allow it (forward())
+        self.x16 = self.bf16
+        # f32 engine: every MLP product on the 16-bit matrix cores from split fp16 planes, fp32 results (csrc/mlp_split.hip):
+        # forward, input gradients (per-tile power-of-two scaling) and weight gradients of every net kind.  ESR_SPLIT_FWD=0:
+        # the f32 MFMA kernels instead (A/B timing).  The planes' first halves are fp16: an input, a hidden activation or a
+        # weight (x 64) beyond fp16's range cannot be carried.  Every split launch of a FORWARD raises a sticky device flag then
+        # (the backward cannot overflow by construction: csrc/mlp.hip: split_gain_kernel), and the step that set it is RE-RUN
+        # on the f32 MFMA kernels before anything leaves it (`range_probe` / `range_hit` / `f32_only`; trainer.py,
+        # voxurff.py); ESR_SPLIT_STRICT=1 raises instead.
         self.split_fwd = (not self.bf16) and os.environ.get("ESR_SPLIT_FWD", "1") != "0"
+        self.split_bwd = self.split_wgrad = self.split_tone_wgrad = self.split_fwd
+        self.split_strict = os.environ.get("ESR_SPLIT_STRICT", "0") == "1"
+        self.split_fallback_steps = 0     # steps (or image chunks) that were re-run on the f32 MFMA kernels
         self.packed_split: Dict[str, torch.Tensor] = {}
-        # ... and the radiance input-gradient chain the same way (per-tile power-of-two scaling); ESR_SPLIT_BWD=0: f32 MFMA
-        self.split_bwd = self.split_fwd and os.environ.get("ESR_SPLIT_BWD", "1") != "0"
-        # net kinds that run on the split kernels: radiance (0), tone mapper (1), BRDF (2), emission (3) -- every MLP launch of
-        # the f32 engine.  Measured (same box each): BRDF + emission, two waves per SIMD: C4 lts 4.58 -> 4.22 ms; tone mapper
-        # at C2 with its planes resident in LDS: forward 0.099 -> 0.070 ms, input gradients 0.088 -> 0.070 ms (0.097 while its
-        # 60 KB of planes were re-staged per tile group).  ESR_SPLIT_KINDS / ESR_SPLIT_KINDS_BWD override ("0" = radiance only).
-        self.split_kinds = {int(k) for k in os.environ.get("ESR_SPLIT_KINDS", "0,1,2,3").split(",") if k.strip() != ""}
-        self.split_kinds_bwd = {int(k) for k in os.environ.get("ESR_SPLIT_KINDS_BWD", "0,1,2,3").split(",") if k.strip() != ""} & self.split_kinds
+        # net kinds on the split kernels: radiance (0), tone mapper (1), BRDF (2), emission (3)
+        self.split_kinds = {0, 1, 2, 3}
+        self.split_kinds_bwd = set(self.split_kinds)
         self._psplit = {}
-        # the split kernels' first planes are fp16: a hidden activation beyond fp16's range would become inf.  One sticky
-        # device flag per device (never freed: the library keeps its address), read back with every step's plan header
         self.range_flag = None
+        self._range_host = None
+        self._range_event = None
         if self.split_fwd:
             key = str(self.device)
-            if key not in _RANGE_FLAGS:
+            if key not in _RANGE_FLAGS:       # one flag per device (never freed: the library keeps its address)
                 _RANGE_FLAGS[key] = torch.zeros(1, dtype=torch.int32, device=self.device)
             self.range_flag = _RANGE_FLAGS[key]
+            self._range_host = torch.zeros(1, dtype=torch.int32).pin_memory()
             with torch.cuda.device(self.device):
                 _lib.check(self.L.esr_mlp_split_range_flag(_lib.ptr(self.range_flag)), "esr_mlp_split_range_flag")
-        # ... and the weight gradients of the 192-wide nets (csrc/mlp.hip: wgrad_dma_body<..., SPLIT>); their gradient
-        # operand's scale comes from max |dz|, which the split input-gradient kernel leaves behind (else esr_absmax)
-        self.split_wgrad = self.split_bwd and os.environ.get("ESR_SPLIT_WGRAD", "1") != "0"
-        # ... and the tone mapper's weight gradients by recomputation (csrc/tone_wgrad.hip: tone_wgrad_split_t_kernel)
-        self.split_tone_wgrad = self.split_wgrad and os.environ.get("ESR_SPLIT_TONE_WGRAD", "1") != "0"
-        if self.split_wgrad and self._syn_dz32_env:        # (f32 engine: the same switch, the split weight-gradient launch's form)
-            self.syn_dz = True
-        self.tone_scratch = torch.empty(self.L.esr_tone_wgrad_scratch_floats() if self.tone_recompute else 1,
-                                        dtype=torch.float32, device=self.device)
+        self.tone_scratch = torch.empty(self.L.esr_tone_wgrad_scratch_floats(), dtype=torch.float32, device=self.device)
         self.neus_grad = False          # cfg neus_alpha: "grad" (set by the renderer)
 
     # -- helpers ---------------------------------------------------------------
@@ -205,17 +182,53 @@ class FineEngine:
             raise RuntimeError("a ray exceeded scene.max_steps; the LDS bound of the march kernel is wrong")
         self.overflow_seen = True
 
-    def _range_check(self, overflow_word=None):
-        """The split kernels' sticky range flag: bit 1 of the plan header's overflow word (esr_fine_plan puts it there), or --
-        without a header at hand (step.close()) -- a read of the flag itself."""
-        if self.range_flag is None:
+    # -- the split-fp16 kernels' range flag: same-step fallback to the f32 MFMA kernels -------------------------------------
+    _RANGE_MSG = ("an input, a hidden activation or a weight of an MLP left fp16's range (|x| >= 60000, |w| >= 1023, inf / NaN) in a "
+                  "split-fp16 kernel (csrc/mlp_split.hip)")
+
+    def range_probe(self):
+        """Enqueue, on the current stream, the flag's copy to pinned host memory + an event: call it behind the LAST split
+        launch of a forward.  No-op for the bf16 / f32-MFMA engines."""
+        if self.range_flag is None or not self.split_fwd:
+            self._range_event = None
             return
-        hit = (overflow_word & 2) != 0 if overflow_word is not None else int(self.range_flag) != 0
-        if hit:
-            self.range_flag.zero_()
-            raise RuntimeError("a hidden activation of an MLP left fp16's range (|x| >= 60000, or inf / NaN) in a split-fp16 forward "
-                               "kernel (csrc/mlp_split.hip): its results since the previous step are not valid.  Set "
-                               "ESR_SPLIT_FWD=0 to run every product on the f32 MFMA pipe, which has no such limit.")
+        self._range_host.copy_(self.range_flag, non_blocking=True)
+        self._range_event = torch.cuda.Event()
+        self._range_event.record()
+
+    def range_hit(self) -> bool:
+        """Wait for the probe (the host normally arrives here long after the device has passed it: trainer.py calls this
+        with the input-gradient chain and the grid scatters queued behind the forward) and tell whether a split launch of
+        this step raised the flag.  The flag is cleared; the caller re-runs the step inside ``with eng.f32_only():``."""
+        ev, self._range_event = self._range_event, None
+        if ev is None:
+            return False
+        ev.synchronize()
+        if int(self._range_host[0]) == 0:
+            return False
+        self.range_flag.zero_()
+        if self.split_strict:
+            raise RuntimeError(self._RANGE_MSG + " (ESR_SPLIT_STRICT=1: no fallback)")
+        if self.split_fallback_steps == 0:
+            import warnings
+            warnings.warn(self._RANGE_MSG + ": the step is re-run on the f32 MFMA kernels (slower; counted in "
+                          "engine.split_fallback_steps)", RuntimeWarning, stacklevel=3)
+        self.split_fallback_steps += 1
+        return True
+
+    def f32_only(self):
+        """Context manager: every MLP launch inside runs on the f32 MFMA kernels (no range limit), on the same buffers."""
+        eng = self
+
+        class _F32:
+            def __enter__(self_):
+                self_.keep = (eng.split_fwd, eng.split_bwd, eng.split_wgrad, eng.split_tone_wgrad)
+                eng.split_fwd = eng.split_bwd = eng.split_wgrad = eng.split_tone_wgrad = False
+
+            def __exit__(self_, *exc):
+                eng.split_fwd, eng.split_bwd, eng.split_wgrad, eng.split_tone_wgrad = self_.keep
+                return False
+        return _F32()
 
     def _run(self, name, fn, *args):
         """Enqueue one C-ABI call; with timing on, bracket it with HIP events recorded on the
@@ -386,7 +399,19 @@ class FineEngine:
         return fa
 
     # -- forward -----------------------------------------------------------------
-    def forward(self, scene, rays_o, rays_d, viewdirs, em_modes, mask_density, sdf, off_color, emo_color, prelude=None):
+    def forward(self, scene, rays_o, rays_d, viewdirs, em_modes, mask_density, sdf, off_color, emo_color, prelude=None,
+                heal: bool = True):
+        """``_forward`` + the split kernels' range fallback.  ``heal=True`` (the autograd route: the results go to arbitrary torch
+        code): wait for the forward's range probe and, when a split launch raised the flag, run the forward again on the f32
+        MFMA kernels.  ``heal=False`` (trainer.FineStep): the caller examines the probe itself (``range_hit``) where the wait
+        is free -- with the backward's input-gradient chain queued -- and re-runs its whole step."""
+        out = self._forward(scene, rays_o, rays_d, viewdirs, em_modes, mask_density, sdf, off_color, emo_color, prelude)
+        if heal and self.range_hit():
+            with self.f32_only():
+                out = self._forward(scene, rays_o, rays_d, viewdirs, em_modes, mask_density, sdf, off_color, emo_color, prelude)
+        return out
+
+    def _forward(self, scene, rays_o, rays_d, viewdirs, em_modes, mask_density, sdf, off_color, emo_color, prelude=None):
         """-> (ctx, alphainv_last [N], srgb_marched [N,3], lin_marched [N,3]).
         sdf [X,Y,Z], off_color/emo_color [X,Y,Z,6], mask_density [mx,my,mz]: contiguous fp32.
         ``prelude()``: enqueues work that does not depend on the march (weight packing, zeroing the gradient buffer).
@@ -449,15 +474,17 @@ class FineEngine:
         n_on, n_off, _, _, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
         tiles_on = (n_on + 31) // 32                                # (esr_fine_plan_totals leaves the tile counts to the host)
         tiles_all = tiles_on + (n_off + 31) // 32
-        self._range_check(overflow)                                 # (the PREVIOUS steps' split forward launches)
-        if overflow & 1:
+        if overflow & 1:                                            # (bit 1: the split kernels' range flag, informational)
             self._overflow()
+        self._range_event = None
         ctx = FineCtx(scene=scene, n_rays=n, tiles_on=tiles_on, tiles_all=tiles_all,
                       counts=dict(m0=m0, m1=m1, m2=m2, m3=n_on + n_off, n_on=n_on, n_off=n_off),
-                      rays_o=rays_o, rays_d=rays_d, viewdirs=viewdirs, off3=rb["off3"], mask_density=mask_density, sdf=sdf)
+                      rays_o=rays_o, rays_d=rays_d, viewdirs=viewdirs, off3=rb["off3"], mask_density=mask_density, sdf=sdf,
+                      f32_only=not self.bf16 and not self.split_fwd)
         if tiles_all == 0:
             if e_pre is not None:
                 main.wait_event(e_pre)
+            self.range_probe()                                      # (the weight packing may have raised the flag)
             return ctx, last, srgb, lin
         ws.ensure(tiles_all)
         if ws["rec_ray"] is not pre_rec:                            # (the workspace grew: a new, unfilled buffer)
@@ -473,10 +500,9 @@ class FineEngine:
                         _lib.ptr(ws["rec_w"]), _lib.ptr(ws["rec_sdf"]), s)
         fa = self.feat_args(rays_o, rays_d, viewdirs, sdf, tiles_on, tiles_all,
                             color_on=(emo_color, off_color, None), color_off=(off_color, None, None))
-        x16 = self.x16 and self.merge_rad and all(0.0 <= float(r) <= 2.0 for r in scene.grad_feat)
+        x16 = self.x16 and all(0.0 <= float(r) <= 2.0 for r in scene.grad_feat)
         ctx.x16 = x16
-        ctx.amax, ctx.amax_set = self._amax, False
-        ctx.amax_t, ctx.amax_t_set = self._amax_t, False
+        ctx.amax, ctx.amax_t = self._amax, self._amax_t             # the split weight gradients' scale sources (backward)
         if x16:
             self._run("feat_fwd", L.esr_fine_feat_fwd_x16, sp, C.byref(fa), _lib.ptr(ws["X"]), _lib.ptr(ws["gnorm"]),
                       _lib.ptr(ws["X16"]), s)
@@ -486,35 +512,26 @@ class FineEngine:
         H, M = self._H(["H0", "H1", "H2"]), self._H(["M0", "M1", "M2"])
         if e_pre is not None:
             main.wait_event(e_pre)
-        # off net: detached pass on the on-tiles (alt colour rows, nothing saved), saved pass on the off-tiles
-        if not self.bf16 and self.merge_rad and self.split_fwd and "off" in self.packed_split and "emo" in self.packed_split:
-            # the same three passes, products from split fp16 planes on the 16-bit matrix cores (fp32 results)
+        # the step's three radiance passes as ONE launch: the off net detached on the on-tiles (alt colour rows, nothing saved)
+        # and saved on the off-tiles, the emo net on the on-tiles
+        if not self.bf16 and self.split_fwd and "off" in self.packed_split and "emo" in self.packed_split:
+            # products from split fp16 planes on the 16-bit matrix cores (fp32 results)
             self._run("mlp_fwd(rad)", L.esr_mlp_fwd_fine_split, _lib.ptr(self.packed["off"]), _lib.ptr(self.packed_split["off"]),
                       _lib.ptr(self.packed["emo"]), _lib.ptr(self.packed_split["emo"]), _lib.ptr(ws["X"]), tiles_on, tiles_all,
                       H, M, 88, _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), s)
-        elif not self.bf16 and self.merge_rad:     # off net (detached on-tiles + saved off-tiles) and emo net: one launch
+        elif not self.bf16:
             self._run("mlp_fwd(rad)", L.esr_mlp_fwd_fine, _lib.ptr(self.packed["off"]), _lib.ptr(self.packed["emo"]),
                       _lib.ptr(ws["X"]), tiles_on, tiles_all, H, M, 88, _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), s)
-        elif not self.bf16:       # one launch, same weights (no launch seam, one ramp-up / tail instead of two)
-                self._run("mlp_fwd(off)", L.esr_mlp_fwd_mixed, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]),
-                      0, tiles_on, tiles_all, H, M, 88, _lib.ptr(ws["z_off"]), s)
-        elif self.merge_rad:        # bf16 engine: the same three passes as one launch (a workgroup = one pass's weights in LDS)
+        else:                       # bf16 engine (a workgroup = one pass's weights in LDS)
             po, pe = _lib.ptr(self.packed["off"]), _lib.ptr(self.packed["emo"])
             self._run("mlp_fwd(rad)", L.esr_mlp_fwd_fine_bf16, po, self._p16[po.value], pe, self._p16[pe.value], _lib.ptr(ws["X"]),
                       _lib.ptr(ws["X16"]) if x16 else None, tiles_on, tiles_all, H, M, 88, _lib.ptr(ws["z_off"]),
                       _lib.ptr(ws["z_emo"]), s)
-        else:
-            self._run("mlp_fwd(off|on-tiles)", self.mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), 0, tiles_on,
-                                     H, M, 0, 88, _lib.ptr(ws["z_off"]), s)
-            self._run("mlp_fwd(off)", self.mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["off"]), _lib.ptr(ws["X"]), tiles_on,
-                                     tiles_all, H, M, 1, 0, _lib.ptr(ws["z_off"]), s)
-        if not self.merge_rad:
-            self._run("mlp_fwd(emo)", self.mlp_fwd, KIND_RADIANCE, _lib.ptr(self.packed["emo"]), _lib.ptr(ws["X"]), 0, tiles_on,
-                                     H, M, 1, 0, _lib.ptr(ws["z_emo"]), s)
         self._run("tone_in_fwd", L.esr_fine_tone_in_fwd, _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), tiles_on, tiles_all,
                                           _lib.ptr(ws["lin"]), _lib.ptr(ws["Xt"]), s)
         self._run("mlp_fwd(tone)", self.mlp_fwd, KIND_TONEMAP, _lib.ptr(self.packed["tone"]), _lib.ptr(ws["Xt"]), 0, tiles_all,
-                                 self._H(["Ht"]), self._H(["Mt"]), 2 if self.tone_recompute else 1, 0, _lib.ptr(ws["zt"]), s)
+                                 self._H(["Ht"]), self._H(["Mt"]), 2, 0, _lib.ptr(ws["zt"]), s)      # (masks only: tone_wgrad.hip recomputes Ht)
+        self.range_probe()                                          # behind the forward's last split launch
         self._run("composite_fwd", L.esr_fine_composite_fwd, _lib.ptr(ws["zt"]), _lib.ptr(ws["lin"]), _lib.ptr(ws["rec_ray"]),
                                             _lib.ptr(ws["rec_w"]), tiles_all, _lib.ptr(ws["rgb"]),
                                             _lib.ptr(srgb), _lib.ptr(lin), s)
@@ -522,8 +539,16 @@ class FineEngine:
 
     # -- image rendering ---------------------------------------------------------
     @torch.no_grad()
-    def evaluate(self, scene, rays_o, rays_d, viewdirs, mask_density, sdf, off_color, emo_color, pos_rt, far,
-                 em_mode: int):
+    def evaluate(self, *args):
+        """``_evaluate`` + the split kernels' range fallback (one more run on the f32 MFMA kernels when the flag was raised)."""
+        out = self._evaluate(*args)
+        if self.range_hit():
+            with self.f32_only():
+                out = self._evaluate(*args)
+        return out
+
+    def _evaluate(self, scene, rays_o, rays_d, viewdirs, mask_density, sdf, off_color, emo_color, pos_rt, far,
+                  em_mode: int):
         """``VoxurfF.forward_evaluate`` (voxurff.py:280-461), forward only: the off / emo / on radiance variants
         tone-mapped separately, depth, disparity and camera-space normals.  Returns the reference's 12 keys."""
         L, s, ws, dev = self.L, self._s(), self.ws, self.device
@@ -540,7 +565,7 @@ class FineEngine:
         self.plan_host.copy_(self.plan_dev, non_blocking=True)
         torch.cuda.current_stream(dev).synchronize()
         _, _, _, T, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
-        self._range_check(overflow)
+        self._range_event = None
         if overflow & 1:
             raise RuntimeError("a ray exceeded scene.max_steps; the LDS bound of the march kernel is wrong")
         z3 = lambda: torch.zeros(n, 3, dtype=torch.float32, device=dev)
@@ -579,6 +604,7 @@ class FineEngine:
                       _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), T, _lib.ptr(depth3), s)
         self._run("eval_disp", L.esr_eval_disp, _lib.ptr(depth3), _lib.ptr(last), C.c_float(far), n, _lib.ptr(depth),
                   _lib.ptr(disp), s)
+        self.range_probe()
         out.update({"etc/depth": depth, "etc/disp": disp, "etc/normal": normal_m, "etc/white_bg": last.unsqueeze(-1)})
         pick = "off" if int(em_mode) == 0 else "on"
         out["srgb/rgb"], out["lin/rgb"] = out[f"srgb/{pick}_rgb"], out[f"lin/{pick}_rgb"]
@@ -596,7 +622,14 @@ class FineEngine:
         march_bwd: LDS / L2 atomics) and the weight gradients (matrix cores).  With ``overlap_wgrad``
         the weight gradients run on a second HIP stream beside the scatters and are joined at the end.
         ``after_grids()`` is called once the grid gradients are complete in stream order: the
-        data-parallel step starts the (large) grid all-reduce there, underneath the wgrad kernels."""
+        data-parallel step starts the (large) grid all-reduce there, underneath the wgrad kernels.
+        A forward that ran on the f32 MFMA kernels (the range fallback) gets an f32 backward."""
+        if ctx.f32_only and self.split_fwd:
+            with self.f32_only():
+                return self._backward(ctx, g_last, g_srgb, g_lin, grads, after_grids)
+        return self._backward(ctx, g_last, g_srgb, g_lin, grads, after_grids)
+
+    def _backward(self, ctx: FineCtx, g_last, g_srgb, g_lin, grads, after_grids=None):
         L, ws = self.L, self.ws
         sp = C.byref(ctx.scene)
         to, ta = ctx.tiles_on, ctx.tiles_all
@@ -605,33 +638,16 @@ class FineEngine:
         s = self._s()
         dweight = ws["dweight"] if ta > 0 else torch.zeros(32, dtype=torch.float32, device=self.device)
         # Queues (HIP streams of this device):
-        #   main     composite_bwd -> dgrad(tone) -> tone_in_bwd -> dgrad(emo) -> dgrad(off) -> feat_bwd -> march_bwd
-        #   wgrad    (overlap_wgrad) the weight gradients, after dgrad(off), beside the grid scatters
-        #   scatter  (overlap_scatter, OFF by default: measured slower) march_bwd as soon as composite_bwd has produced
-        #            d/d weight, feat_bwd(on-tiles) after dgrad(emo), feat_bwd(off-tiles) after dgrad(off), with the
-        #            input-gradient kernels capped at one workgroup per CU so that both fit a CU
+        #   main     composite_bwd -> march_bwd -> dgrad(tone) -> tone_in_bwd -> dgrad(rad) -> feat_bwd
+        #   wgrad    (overlap_wgrad) the weight gradients, after dgrad(rad), beside the feature scatter
+        # (a third stream for the scatters was measured slower on MI355X -- C2: 4.08 ms without, 4.19-4.47 ms with: the
+        #  atomics-heavy scatters slow the matrix kernels more than they hide -- and is gone)
         overlap = self.overlap_wgrad and ta > 0
-        cap = self.dgrad_cap if overlap and self.overlap_scatter else 0
-        scat = self._side_stream(1) if overlap and self.overlap_scatter else None
-
-        def on(stream, after, fn):
-            """run fn on `stream` once `after` (an event) has happened; returns an event marking fn's end"""
-            stream.wait_event(after)
-            with torch.cuda.stream(stream):
-                fn(_lib.stream_ptr(self.device))
-                e = torch.cuda.Event()
-                e.record(stream)
-            return e
-
-        def mark():
-            e = torch.cuda.Event()
-            e.record(main)
-            return e
+        split = not self.bf16 and self.split_fwd and self.split_bwd
 
         # the march backward's value-tap gradients of the recorded samples ride on the feature backward's SDF window
-        # (ws["dsdf"]) instead of 8 L2 atomics each; not with neus_alpha "grad" (its gradient taps scatter anyway) and
-        # not on the scatter-stream variant (its feature backward runs in two windows)
-        fold = ta > 0 and not self.neus_grad and scat is None and grads.get("sdf") is not None
+        # (ws["dsdf"]) instead of 8 L2 atomics each; not with neus_alpha "grad" (its gradient taps scatter anyway)
+        fold = ta > 0 and not self.neus_grad and grads.get("sdf") is not None
 
         def march_bwd(s_):
             if fold and ctx.march_cache is not None:
@@ -649,25 +665,22 @@ class FineEngine:
                         _lib.ptr(ctx.sdf), ctx.n_rays, _lib.ptr(ctx.off3), _lib.ptr(dweight), _lib.ptr(g_last),
                         _lib.ptr(grads["sdf"]), s_)
 
-        def feat_bwd(t0, t1):
-            def run(s_):
-                src = (_lib.EsrFeatBwdSrc * 1)()
-                src[0].dX = ws["dX"].data_ptr()
-                src[0].grad_color_on = grads["emo_color"].data_ptr()      # on-tiles carry the emo net's gradient
-                src[0].grad_color_off = grads["off_color"].data_ptr()
-                src[0].t0, src[0].t1 = t0, t1
-                self._run("feat_bwd", L.esr_fine_feat_bwd, sp, C.byref(ctx.feat_args), _lib.ptr(ws["X"]),
-                          _lib.ptr(ws["gnorm"]), src, 1, _lib.ptr(ws["dsdf"]) if fold else None, _lib.ptr(grads["sdf"]),
-                          None, None, 0, s_)
-            return run
+        def feat_bwd(s_):
+            src = (_lib.EsrFeatBwdSrc * 1)()
+            src[0].dX = ws["dX"].data_ptr()
+            src[0].grad_color_on = grads["emo_color"].data_ptr()      # on-tiles carry the emo net's gradient
+            src[0].grad_color_off = grads["off_color"].data_ptr()
+            src[0].t0, src[0].t1 = 0, ta
+            self._run("feat_bwd", L.esr_fine_feat_bwd, sp, C.byref(ctx.feat_args), _lib.ptr(ws["X"]),
+                      _lib.ptr(ws["gnorm"]), src, 1, _lib.ptr(ws["dsdf"]) if fold else None, _lib.ptr(grads["sdf"]),
+                      None, None, 0, s_)
 
         def tone_wgrad(s_):
             # from Xt and dzt alone: the hidden layer is recomputed inside (tone_wgrad.hip)
             (w0, w1), (b0, _) = self._raw["tone"]
-            if self.split_tone_wgrad and getattr(ctx, "amax_t", None) is not None:
-                # f32 engine: the products on the 16-bit matrix cores; the gradient operand's scale from max |dzt|
-                if not getattr(ctx, "amax_t_set", False):          # (the f32 input-gradient kernel ran: one small reduction over dzt)
-                    self._run("absmax(dzt)", L.esr_absmax, _lib.ptr(ws["dzt"]), C.c_int64(ta * 4 * 32), _lib.ptr(ctx.amax_t), s_)
+            if split and self.split_tone_wgrad:
+                # products on the 16-bit matrix cores; the gradient operand's scale: ctx.amax_t, left behind by the split
+                # input-gradient kernel (max |dzt| x the net's gain bound: no overflow by construction)
                 self._run("tone_wgrad", L.esr_tone_wgrad_recompute_split, _lib.ptr(ws["Xt"]), _lib.ptr(ws["dzt"]), _lib.ptr(w0.detach()),
                           _lib.ptr(b0.detach()), _lib.ptr(w1.detach()), _lib.ptr(ctx.amax_t), 0, ta, _lib.ptr(grads["tone_w"][0]),
                           _lib.ptr(grads["tone_b"][0]), _lib.ptr(grads["tone_w"][1]), _lib.ptr(grads["tone_b"][1]),
@@ -678,23 +691,15 @@ class FineEngine:
                       _lib.ptr(b0.detach()), _lib.ptr(w1.detach()), 0, ta, _lib.ptr(grads["tone_w"][0]),
                       _lib.ptr(grads["tone_b"][0]), _lib.ptr(grads["tone_w"][1]), _lib.ptr(grads["tone_b"][1]),
                       _lib.ptr(self.tone_scratch), C.c_int64(self.tone_scratch.numel()), s_)
-        # ESR_TONE_WGRAD_EARLY=1 (OFF by default, measured): the tone mapper's weight gradients need composite_bwd's dzt only
-        # and could run on the weight-gradient stream BESIDE the input-gradient chain instead of in front of the radiance
-        # weight gradients at the end of the step.  C2 f32: 2.13 -> 2.18 ms (the issue-bound split kernels lose more than the
-        # overlap gains), C3 bf16: 1.689 -> 1.671 ms (inside the run-to-run spread).
-        tone_early = overlap and self.tone_recompute and self.tone_wgrad_early and scat is None
 
         def wgrads(s_):
-            # one call for the three nets: layers of the same kernel shape share a launch (esr_mlp_wgrad_batch)
-            Hh, dZh, Hth, dZth = self._H(["H0", "H1", "H2"]), self._H(["dZ0", "dZ1", "dZ2"]), self._H(["Ht"]), self._H(["dZt"])
-            keep = [Hh, dZh, Hth, dZth]
+            # the tone mapper's by recomputation, then one call for the two radiance nets: layers of the same kernel shape
+            # share a launch (esr_mlp_wgrad_batch)
+            tone_wgrad(s_)
+            Hh, dZh = self._H(["H0", "H1", "H2"]), self._H(["dZ0", "dZ1", "dZ2"])
+            keep = [Hh, dZh]
             todo = [(KIND_RADIANCE, ws["X"], Hh, dZh, ws["dz"], 0, to, "emo_w", "emo_b"),
                     (KIND_RADIANCE, ws["X"], Hh, dZh, ws["dz"], to, ta, "off_w", "off_b")]
-            if self.tone_recompute:
-                if not tone_early:
-                    tone_wgrad(s_)
-            else:
-                todo.append((KIND_TONEMAP, ws["Xt"], Hth, dZth, ws["dzt"], 0, ta, "tone_w", "tone_b"))
             jobs = (_lib.EsrWgradJob * len(todo))()
             for j, (kind, X, Hs, dZs, dzs, r0, r1, gwk, gbk) in enumerate(todo):
                 gwa, gba = _lib.ptr_array(grads[gwk]), _lib.ptr_array(grads[gbk])
@@ -704,27 +709,12 @@ class FineEngine:
                 jb.X, jb.dz = X.data_ptr(), dzs.data_ptr()
                 jb.H, jb.dZ = C.addressof(Hs), C.addressof(dZs)
                 jb.gw, jb.gb = C.addressof(gwa), C.addressof(gba)
-                if getattr(ctx, "x16", False) and kind == KIND_RADIANCE:
+                if ctx.x16:
                     jb.X16 = ws["X16"].data_ptr()
-                if self.syn_dz and kind == KIND_RADIANCE:
-                    jb.M_last = ws["M2"].data_ptr()
-                    jb.W_last = self._raw["emo" if gwk == "emo_w" else "off"][0][3].data_ptr()
-                if self.split_wgrad and kind == KIND_RADIANCE and getattr(ctx, "amax", None) is not None:
-                    if not ctx.amax_set:        # (the f32 input-gradient kernels ran: one small reduction over dz)
-                        self._run("absmax(dz)", L.esr_absmax, _lib.ptr(ws["dz"]), C.c_int64(ta * 4 * 32), _lib.ptr(ctx.amax), s_)
-                        ctx.amax_set = True
+                if split and self.split_wgrad:          # (non-NULL amax selects the split-fp16 weight-gradient kernel)
                     jb.amax = ctx.amax.data_ptr()
             self._run("mlp_wgrad(all)", L.esr_mlp_wgrad_batch, jobs, len(todo), 1 if self.bf16 else 0,
                       _lib.ptr(self.wgrad_scratch), C.c_int64(self.wgrad_scratch.numel()), s_)
-
-        def dgrad(name, kind, packed, dz, t0, t1, Ms, dZs, dX):
-            if self.bf16:
-                self._run(name, self.mlp_dgrad, kind, _lib.ptr(packed), _lib.ptr(dz), t0, t1, Ms, dZs, _lib.ptr(dX), s)
-            else:
-                if cap == 0:                    # (no workgroup cap: the dispatcher, i.e. the split kernel where planes exist)
-                    self._run(name, self.mlp_dgrad, kind, _lib.ptr(packed), _lib.ptr(dz), t0, t1, Ms, dZs, _lib.ptr(dX), s)
-                else:
-                    self._run(name, L.esr_mlp_dgrad_wg, kind, _lib.ptr(packed), _lib.ptr(dz), t0, t1, Ms, dZs, _lib.ptr(dX), cap, s)
 
         if ta == 0:
             march_bwd(s)
@@ -734,64 +724,55 @@ class FineEngine:
         self._run("composite_bwd", L.esr_fine_composite_bwd, _lib.ptr(g_srgb), _lib.ptr(g_lin), _lib.ptr(ws["rgb"]),
                   _lib.ptr(ws["lin"]), _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), ta, _lib.ptr(ws["dweight"]),
                   _lib.ptr(ws["dzt"]), s)
-        if tone_early:
-            on(self._side_stream(0), mark(), tone_wgrad)          # (the stream's later work -- wgrads -- is ordered behind it)
-        e_scat = on(scat, mark(), march_bwd) if scat is not None else None
         if fold:
             march_bwd(s)
-        dZt_arg = _lib.ptr_array([None]) if self.tone_recompute else self._H(["dZt"])
-        tone_planes = self._psplit.get(self.packed["tone"].data_ptr()) if (self.split_fwd and self.split_bwd and not self.bf16
-                                                                          and KIND_TONEMAP in self.split_kinds_bwd and cap == 0) else None
-        if tone_planes is not None:
-            # the split kernel leaves max |dzt| behind: the scale of the tone mapper's split weight gradients (no absmax launch)
-            amax_t = getattr(ctx, "amax_t", None)
-            self._run("mlp_dgrad(tone)", L.esr_mlp_dgrad_split, KIND_TONEMAP, tone_planes, _lib.ptr(ws["dzt"]), 0, ta, self._H(["Mt"]),
-                      dZt_arg, _lib.ptr(ws["dXt"]), _lib.ptr(amax_t) if amax_t is not None else None, s)
-            ctx.amax_t_set = amax_t is not None
+        dZt_arg = _lib.ptr_array([None])            # (the tone mapper's hidden gradient is recomputed, not stored)
+        M = self._H(["M0", "M1", "M2"])
+        dZ = self._H(["dZ0", "dZ1", "dZ2"])
+        if self.bf16:
+            self._run("mlp_dgrad(tone)", L.esr_mlp_dgrad_bf16, KIND_TONEMAP, self._p16[self.packed["tone"].data_ptr()],
+                      _lib.ptr(ws["dzt"]), 0, ta, self._H(["Mt"]), dZt_arg, _lib.ptr(ws["dXt"]), s)
+        elif split:
+            # (the split kernels leave max |dzt| / max |dz| x the nets' gain bounds behind: the weight gradients' scales)
+            self._run("mlp_dgrad(tone)", L.esr_mlp_dgrad_split, KIND_TONEMAP, _lib.ptr(self.packed_split["tone"]), _lib.ptr(ws["dzt"]),
+                      0, ta, self._H(["Mt"]), dZt_arg, _lib.ptr(ws["dXt"]), _lib.ptr(ctx.amax_t), s)
         else:
-            dgrad("mlp_dgrad(tone)", KIND_TONEMAP, self.packed["tone"], ws["dzt"], 0, ta, self._H(["Mt"]), dZt_arg, ws["dXt"])
+            self._run("mlp_dgrad(tone)", L.esr_mlp_dgrad, KIND_TONEMAP, _lib.ptr(self.packed["tone"]), _lib.ptr(ws["dzt"]), 0, ta,
+                      self._H(["Mt"]), dZt_arg, _lib.ptr(ws["dXt"]), s)
         self._run("tone_in_bwd", L.esr_fine_tone_in_bwd, _lib.ptr(ws["dXt"]), _lib.ptr(ws["Xt"]), _lib.ptr(g_lin), _lib.ptr(ws["lin"]),
                   _lib.ptr(ws["z_off"]), _lib.ptr(ws["z_emo"]), _lib.ptr(ws["rec_ray"]), _lib.ptr(ws["rec_w"]), to, ta,
                   _lib.ptr(ws["dz"]), s)
-        M = self._H(["M0", "M1", "M2"])
-        # bf16 engine: the last hidden layer's dZ is synthesised inside the weight-gradient kernel (esr_wgrad_job_t::M_last /
-        # W_last), so the input-gradient pass does not store it
-        dZ = _lib.ptr_array([ws["dZ0"], ws["dZ1"], None]) if self.syn_dz else self._H(["dZ0", "dZ1", "dZ2"])
-        if self.merge_rad and scat is None:                        # both radiance nets' input gradients: one launch
-            if self.bf16:
-                pe, po = _lib.ptr(self.packed["emo"]), _lib.ptr(self.packed["off"])
-                self._run("mlp_dgrad(rad)", L.esr_mlp_dgrad_fine_bf16, self._p16[pe.value], self._p16[po.value],
-                          _lib.ptr(ws["dz"]), to, ta, M, dZ, _lib.ptr(ws["dX"]), s)
-            elif self.split_fwd and self.split_bwd and "off" in self.packed_split and "emo" in self.packed_split:
-                self._run("mlp_dgrad(rad)", L.esr_mlp_dgrad_fine_split, _lib.ptr(self.packed_split["emo"]),
-                          _lib.ptr(self.packed_split["off"]), _lib.ptr(ws["dz"]), to, ta, M, dZ, _lib.ptr(ws["dX"]),
-                          _lib.ptr(ctx.amax) if getattr(ctx, "amax", None) is not None else None, s)
-                ctx.amax_set = getattr(ctx, "amax", None) is not None
-            else:
-                self._run("mlp_dgrad(rad)", L.esr_mlp_dgrad_fine, _lib.ptr(self.packed["emo"]), _lib.ptr(self.packed["off"]),
-                          _lib.ptr(ws["dz"]), to, ta, M, dZ, _lib.ptr(ws["dX"]), s)
+        # both radiance nets' input gradients: one launch
+        if self.bf16:
+            pe, po = self.packed["emo"].data_ptr(), self.packed["off"].data_ptr()
+            self._run("mlp_dgrad(rad)", L.esr_mlp_dgrad_fine_bf16, self._p16[pe], self._p16[po],
+                      _lib.ptr(ws["dz"]), to, ta, M, dZ, _lib.ptr(ws["dX"]), s)
+        elif split:
+            self._run("mlp_dgrad(rad)", L.esr_mlp_dgrad_fine_split, _lib.ptr(self.packed_split["emo"]),
+                      _lib.ptr(self.packed_split["off"]), _lib.ptr(ws["dz"]), to, ta, M, dZ, _lib.ptr(ws["dX"]),
+                      _lib.ptr(ctx.amax), s)
         else:
-            dgrad("mlp_dgrad(emo)", KIND_RADIANCE, self.packed["emo"], ws["dz"], 0, to, M, dZ, ws["dX"])
-            if scat is not None and to > 0:
-                e_scat = on(scat, mark(), feat_bwd(0, to))
-            dgrad("mlp_dgrad(off)", KIND_RADIANCE, self.packed["off"], ws["dz"], to, ta, M, dZ, ws["dX"])
+            self._run("mlp_dgrad(rad)", L.esr_mlp_dgrad_fine, _lib.ptr(self.packed["emo"]), _lib.ptr(self.packed["off"]),
+                      _lib.ptr(ws["dz"]), to, ta, M, dZ, _lib.ptr(ws["dX"]), s)
         if not overlap:
-            feat_bwd(0, ta)(s)
+            feat_bwd(s)
             if not fold:
                 march_bwd(s)
             if after_grids is not None:
                 after_grids()
             wgrads(s)
             return
-        e_dgrad = mark()
-        e_w = on(self._side_stream(0), e_dgrad, wgrads)
-        if scat is not None:
-            e_scat = on(scat, e_dgrad, feat_bwd(to, ta))
-            main.wait_event(e_scat)
-        else:
-            feat_bwd(0, ta)(s)
-            if not fold:
-                march_bwd(s)
+        e_dgrad = torch.cuda.Event()
+        e_dgrad.record(main)
+        side = self._side_stream(0)
+        side.wait_event(e_dgrad)
+        with torch.cuda.stream(side):
+            wgrads(_lib.stream_ptr(self.device))
+            e_w = torch.cuda.Event()
+            e_w.record(side)
+        feat_bwd(s)
+        if not fold:
+            march_bwd(s)
         if after_grids is not None:
             after_grids()
         main.wait_event(e_w)

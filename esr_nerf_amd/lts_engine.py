@@ -86,6 +86,7 @@ class LtsCtx:
     pdra: bool
     t: Dict[str, torch.Tensor] = field(default_factory=dict)
     eps: Dict[str, float] = field(default_factory=dict)
+    f32_only: bool = False             # the forward ran on the f32 MFMA kernels (range fallback): so must the backward
 
 
 class _PointDraw:
@@ -178,20 +179,21 @@ class LtsEngine(FineEngine):
         super().__init__(device, mlp_dtype)
         self.ray_sampling = "random"        # or "fib" (cfg.app.model.ray_sampling; esrnerf.py:188-192)
         self._draw_ring = [None, None, 0, 0]   # pinned buffers of the surface-point draw (_PointDraw)
-        self.zero_arena = os.environ.get("ESR_ZERO_ARENA", "1") != "0"      # (read once, here; A/B switch of tools/ab.sh)
+        self.zero_arena = True
         self.prim = Pass(self.device, "primary")
         self.pts = Pass(self.device, "points")
         self.sec = Pass(self.device, "secondary")
         self.epsp = Pass(self.device, "eps")
         self._wgrad_jobs = None
-        # ESR_LTS_WGRAD_EARLY: flush points of the batched weight gradients inside the backward (_flush_wgrad; "" = all at the
-        # end).  C5 pdra bf16, 100 steps x 3 on one box: none 3.45 ms, "1,2" 3.39, "1,2,3" 3.33; with 4 and 5 too: -0.6 %,
-        # inside the noise, for two more batched calls per step -- not taken.
-        self.wgrad_early = {int(v) for v in os.environ.get("ESR_LTS_WGRAD_EARLY", "1,2,3").split(",") if v.strip()}
-        # ESR_LTS_SCATTER_STREAM: the passes whose grid scatters leave the main stream (_on_scatter_stream; "0" = none).  C5 pdra
-        # bf16, 100 steps x 3 on one box: none 3.29 ms, "1" 3.18; C4 lts f32: 3.99 -> 3.84.  "1,2": inside the noise of "1".
-        self.eps_stream = os.environ.get("ESR_LTS_EPS_STREAM", "1") != "0"      # (lts_forward: the perturbed heads' pass)
-        self.scatter_streamed = {int(v) for v in os.environ.get("ESR_LTS_SCATTER_STREAM", "1").split(",") if v.strip() and v != "0"}
+        # flush points of the batched weight gradients inside the backward (_flush_wgrad; empty = all at the end).  C5 pdra
+        # bf16, 100 steps x 3 on one box: none 3.45 ms, {1,2} 3.39, {1,2,3} 3.33; with 4 and 5 too: -0.6 %, inside the noise,
+        # for two more batched calls per step -- not taken.
+        self.wgrad_early = {1, 2, 3}
+        # the passes whose grid scatters leave the main stream (_on_scatter_stream; empty = none).  C5 pdra bf16, 100 steps x 3
+        # on one box: none 3.29 ms, {1} 3.18; C4 lts f32: 3.99 -> 3.84.  {1,2}: inside the noise of {1}.
+        self.eps_stream = True              # (lts_forward: the perturbed heads' pass on a stream of its own)
+        self.scatter_streamed = {1}
+        self.last_draws = None              # the random draws of the last lts_forward (the range fallback replays them)
         for k, kind in (("brdf", KIND_BRDF), ("emit", KIND_EMIT)):
             self.packed[k] = torch.empty(self.L.esr_mlp_packed_floats(kind), dtype=torch.float32,
                                          device=self.device)
@@ -296,7 +298,6 @@ class LtsEngine(FineEngine):
         n_on, n_off, _, _, m0, m1, m2, overflow = [int(v) for v in self.plan_host.tolist()]
         tiles_on = (n_on + 31) // 32                                 # (esr_fine_plan_totals leaves the tile counts to the host)
         tiles_all = tiles_on + (n_off + 31) // 32
-        self._range_check(overflow)
         if overflow & 1:
             self._overflow()
         P.tiles_on, P.tiles_all = tiles_on, tiles_all
@@ -379,7 +380,7 @@ class LtsEngine(FineEngine):
         x = P.bufs["Xt"] if kind == KIND_TONEMAP else P.bufs["X"]
         if t1 > t0:
             # tone mapper: masks only, its weight gradient recomputes the hidden layer (tone_wgrad.hip, f32 and bf16 operands)
-            mode = 0 if not save else 2 if (kind == KIND_TONEMAP and self.tone_recompute) else 1
+            mode = 0 if not save else 2 if kind == KIND_TONEMAP else 1
             if kind == KIND_RADIANCE and self.split_fwd and net in self.packed_split:
                 # f32 engine: the radiance forward's products on the 16-bit matrix cores, fp32 results (csrc/mlp_split.hip)
                 self._run(f"mlp_fwd({net})[{P.name}]", self.L.esr_mlp_fwd_split, kind, _lib.ptr(self.packed[net]),
@@ -401,7 +402,7 @@ class LtsEngine(FineEngine):
         x = P.bufs["Xt"] if kind == KIND_TONEMAP else P.bufs["X"]
         if t1 > t0:
             s = self._s()
-            recompute = kind == KIND_TONEMAP and self.tone_recompute
+            recompute = kind == KIND_TONEMAP
             amax = None
             if kind in self.split_kinds_bwd and self.split_fwd and self.split_bwd and net in self.packed_split:
                 # (radiance, BRDF, emission nets.)  max |dz| of this net and pass, left behind by the input-gradient kernel:
@@ -419,11 +420,7 @@ class LtsEngine(FineEngine):
                 (w0, w1), (b0, _) = self._raw[net]
 
                 def tone_wgrad(amax_t=amax):
-                    if self.split_tone_wgrad:
-                        if amax_t is None:                 # (the f32 input-gradient kernel ran)
-                            amax_t = self._z(1)
-                            self._run(f"absmax(dzt)[{P.name}]", self.L.esr_absmax, C.c_void_p(dz.data_ptr() + t0 * 4 * 32 * 4),
-                                      C.c_int64((t1 - t0) * 4 * 32), _lib.ptr(amax_t), self._s())
+                    if self.split_tone_wgrad and amax_t is not None:       # (the scale source comes from the split input-gradient kernel)
                         self._run(f"tone_wgrad[{P.name}]", self.L.esr_tone_wgrad_recompute_split, _lib.ptr(x), _lib.ptr(dz),
                                   _lib.ptr(w0.detach()), _lib.ptr(b0.detach()), _lib.ptr(w1.detach()), _lib.ptr(amax_t), t0, t1,
                                   _lib.ptr(gw[0]), _lib.ptr(gb[0]), _lib.ptr(gw[1]), _lib.ptr(gb[1]), _lib.ptr(self.tone_scratch),
@@ -552,6 +549,17 @@ class LtsEngine(FineEngine):
     @torch.no_grad()
     def evaluate(self, scene, scene2, rays_o, rays_d, viewdirs, grids, envmap, pos_rt, far, em_mode, render_pbr, chunk_sz,
                  num_2ndrays, draws=None):
+        """``_evaluate_lts`` + the split kernels' range fallback: one more run on the f32 MFMA kernels, with the same
+        scattering draws, when a split launch raised the flag."""
+        args = (scene, scene2, rays_o, rays_d, viewdirs, grids, envmap, pos_rt, far, em_mode, render_pbr, chunk_sz, num_2ndrays)
+        out = self._evaluate_lts(*args, draws)
+        if self.range_hit():
+            with self.f32_only():
+                out = self._evaluate_lts(*args, self._eval_draws)
+        return out
+
+    def _evaluate_lts(self, scene, scene2, rays_o, rays_d, viewdirs, grids, envmap, pos_rt, far, em_mode, render_pbr, chunk_sz,
+                      num_2ndrays, draws=None):
         """``ESRNeRF.forward_evaluate`` (esrnerf.py:853-1297), forward only: the 12 image keys of the fine renderer,
         the composited material heads (lin/emit, lin/basecolor, lin/roughness, lin/metallic) and, with ``render_pbr``,
         the light-transport decomposition of EVERY surviving sample (lin/env_dir, lin/env_indir, lin/env_effects,
@@ -561,6 +569,8 @@ class LtsEngine(FineEngine):
         sdf, offg, emog, brdfg, emitg = grids["sdf"], grids["off"], grids["emo"], grids["brdf"], grids["emit"]
         n = rays_o.shape[0]
         P0 = self.prim
+        self._eval_draws = []                     # the chunks' scattering draws (replayed by the range fallback)
+        self._range_event = None
         cnt3, off3, last = self._march(P0, scene, rays_o, rays_d, torch.zeros(n, dtype=torch.int64, device=dev),
                                        grids["mask"], sdf, viewdirs=viewdirs)
         T, m3 = P0.tiles_all, P0.counts["m3"]
@@ -636,6 +646,7 @@ class LtsEngine(FineEngine):
                 base_c, rough_c, metal_c = brdf_rm[jc, 0:3].contiguous(), brdf_rm[jc, 3].contiguous(), brdf_rm[jc, 4].contiguous()
                 emit_c = emit_rm[jc, 0:3].contiguous()
                 raw = self._scatter_draws(nc, R) if draws is None else draws[ci].to(dev).contiguous()
+                self._eval_draws.append(raw)
                 raw1 = torch.cat([raw, torch.ones(nc, 1, 3, device=dev)], 1).contiguous()       # slot R: unused second view
                 dirs_all = torch.empty(nc, R + 1, 3, device=dev)
                 self._run("lts_dirs", L.esr_lts_dirs, _lib.ptr(raw1), _lib.ptr(normal_c), nc, R + 1, _lib.ptr(dirs_all), s)
@@ -679,16 +690,25 @@ class LtsEngine(FineEngine):
                 comp(_lib.ptr(P0.from_rowmajor("pbr.t", 4, per[k])), 4, out[k], k)
         pick = "off" if int(em_mode) == 0 else "on"
         out["srgb/rgb"], out["lin/rgb"] = out[f"srgb/{pick}_rgb"], out[f"lin/{pick}_rgb"]
+        self.range_probe()
         return out
 
     # ------------------------------------------------------------------ PDRA regrouping queries
     @torch.no_grad()
-    def eval_query(self, scene, rays_o, rays_d, viewdirs, mask_density, sdf, emit_grid, what: str):
+    def eval_query(self, *args):
+        out = self._eval_query(*args)
+        if self.range_hit():
+            with self.f32_only():
+                out = self._eval_query(*args)
+        return out
+
+    def _eval_query(self, scene, rays_o, rays_d, viewdirs, mask_density, sdf, emit_grid, what: str):
         """``ESRNeRF.eval_emit`` (what="emit", esrnerf.py:1299-1358: composited emission) or ``eval_esp``
         (what="esp", :1360-1407: composited sample position) per ray, forward only -> [N,3]."""
         L, s, dev = self.L, self._s(), self.device
         n = rays_o.shape[0]
         P0 = self.prim
+        self._range_event = None
         self._march(P0, scene, rays_o, rays_d, torch.zeros(n, dtype=torch.int64, device=dev), mask_density, sdf,
                     viewdirs=viewdirs)
         T = P0.tiles_all
@@ -708,6 +728,7 @@ class LtsEngine(FineEngine):
             v = P0.from_rowmajor("pts.t", 4, pts)
         self._run(f"composite3_fwd({what})", L.esr_composite3_fwd, _lib.ptr(v), 4, _lib.ptr(P0.bufs["rec_ray"]),
                   _lib.ptr(P0.bufs["rec_w"]), T, _lib.ptr(out), s)
+        self.range_probe()
         return out
 
     # ------------------------------------------------------------------ re-lighting fine-tune (A16)
@@ -717,6 +738,7 @@ class LtsEngine(FineEngine):
         ``num_2ndrays`` secondary rays.  grids: sdf, emo, brdf, emit (the frozen copy feeding the emission head),
         mask.  Only the emo colour grid and the emo net receive gradients (finetune_backward)."""
         L, s, dev = self.L, self._s(), self.device
+        self._range_event = None
         sdf, emog, brdfg, emitg = grids["sdf"], grids["emo"], grids["brdf"], grids["emit"]
         rays_o, rays_d, viewdirs = batch["rays_o"], batch["rays_d"], batch["viewdirs"]
         N = rays_o.shape[0]
@@ -794,11 +816,16 @@ class LtsEngine(FineEngine):
         off_hat = torch.empty(2 * Pn, 3, device=dev)          # the off half of the combine is unused here
         emo_hat = torch.empty(2 * Pn, 3, device=dev)
         self._run("lts_combine_fwd", L.esr_lts_combine_fwd, C.byref(a), _lib.ptr(off_hat), _lib.ptr(emo_hat), s)
-        ctx = dict(scene=scene, n_pts=Pn, held=held, keep=(pts2, vd2, sdf2, last2))
+        ctx = dict(scene=scene, n_pts=Pn, held=held, keep=(pts2, vd2, sdf2, last2), f32_only=not self.bf16 and not self.split_fwd)
+        self.last_draws = dict(idx=idx_ref, dirs=raw)
+        self.range_probe()
         return ctx, {"lin/pbr/emo": emo_pt, "lin/pbr/emo_hat": emo_hat}
 
     def finetune_backward(self, ctx, g_emo, grads):
         """g_emo [2*P,3] -> grads["emo"] (colour grid, channels-last), grads["emo_w"], grads["emo_b"]."""
+        if ctx.get("f32_only") and self.split_fwd:
+            with self.f32_only():
+                return self.finetune_backward(ctx, g_emo, grads)
         P1, dev = self.pts, self.device
         T1, Pn = P1.tiles_all, ctx["n_pts"]
         ga = torch.zeros(T1 * 32, 3, device=dev)
@@ -815,6 +842,7 @@ class LtsEngine(FineEngine):
         absent they are drawn exactly where the reference draws them."""
         L, s, dev = self.L, self._s(), self.device
         sdf, offg, emog, brdfg = grids["sdf"], grids["off"], grids["emo"], grids["brdf"]
+        self._range_event = None
         self._zero_arena_begin()
         rays_o, rays_d, viewdirs = batch["rays_o"], batch["rays_d"], batch["viewdirs"]
         N = rays_o.shape[0]
@@ -827,6 +855,7 @@ class LtsEngine(FineEngine):
         emit_m = self._z(N, 3, device=dev)
         ctx = LtsCtx(scene=scene, scene2=scene2, batch=batch, perm=None, jp=None, n_pts=0,
                      n_2nd=int(cfg["num_2ndrays"]), pdra=bool(cfg["pdra"]))
+        ctx.f32_only = not self.bf16 and not self.split_fwd
         ctx.t.update(cnt3=cnt3, off3=off3, last=last, grids=grids, envmap=envmap)
         ctx.eps = dict(normal=float(cfg["normal_eps"]), emit=float(cfg["emit_eps"]))
         m3 = P0.counts["m3"]
@@ -1023,6 +1052,8 @@ class LtsEngine(FineEngine):
         ctx.t.update(um=um, pts_e=pts_e, eps_grads=eps_grads, m3=m3, inv=self.inv_order)
         if eps_done is not None:
             torch.cuda.current_stream(dev).wait_event(eps_done)
+        self.last_draws = dict(idx=idx_host, dirs=raw, noise_normal=nn_, noise_emit=ne_)
+        self.range_probe()                        # behind the forward's last split launch (every stream is joined here)
         return ctx, out
 
     # ------------------------------------------------------------------ backward
@@ -1032,6 +1063,9 @@ class LtsEngine(FineEngine):
         Order on the main stream: every input-gradient chain and grid scatter, then ``after_grids()`` (the
         data-parallel step exchanges the dense-grid gradients there); the weight-gradient launches run beside it on
         a second stream (or, without ``overlap_wgrad``, after it) and are joined at the end."""
+        if ctx.f32_only and self.split_fwd:         # (the range fallback's forward: fine_engine.FineEngine.backward)
+            with self.f32_only():
+                return self.lts_backward(ctx, g, grads, after_grids)
         main = torch.cuda.current_stream(self.device)
         self._wgrad_jobs, self._wgrad_extra = [], []
         self._wgrad_flushed = False

@@ -177,15 +177,30 @@ class _OverflowScope:
         return False
 
 
+class _RangeGuard:
+    """The ``after_grids`` callback of a trainer step, with the split-fp16 kernels' range fallback in front of it.  The engine
+    calls it when the input-gradient chain and the grid scatters are enqueued and BEFORE anything leaves the rank (the
+    data-parallel exchange starts inside the wrapped callback): the best place for the one host wait the check needs -- the
+    device has ~0.7 ms of queued work behind the forward the host waits for, so it never idles.  ``hit``: a split launch of
+    this step's forward raised the flag; the exchange was not started and the step object runs the step again."""
+
+    def __init__(self, eng, after_grids):
+        self.eng, self.after_grids, self.hit = eng, after_grids, False
+
+    def __call__(self):
+        if self.eng.range_hit():
+            self.hit = True
+            return
+        if self.after_grids is not None:
+            self.after_grids()
+
+
 def _finish(step):
     """After the LAST step: the march-overflow flag of a data-parallel step is examined by the next step's
-    ``_check_overflow``, the split-fp16 kernels' range flag by the next step's plan read-back; this examines the final ones
-    (data parallel: every rank raises together)."""
+    ``_check_overflow``; this examines the final one (data parallel: every rank raises together).  (The split-fp16 kernels'
+    range flag needs nothing here: every step examines and heals its own, _RangeGuard.)"""
     if step.pg is not None:
         _check_overflow(step)
-    eng = getattr(step.model, "_engine", None)          # the split-fp16 kernels' range flag of the last step(s): a device read
-    if eng is not None and getattr(eng, "range_flag", None) is not None:
-        eng._range_check()
 
 
 def _cached_views(step, key):
@@ -287,6 +302,17 @@ class FineStep:
         return False
 
     def _step(self, batch, s_val, global_rays, entropy_owner, m, eng, ps):
+        res = self._attempt(batch, s_val, global_rays, entropy_owner, m, eng, ps)
+        if res is None:
+            # a split-fp16 kernel of the forward raised the range flag (fine_engine.py): nothing has left the step -- no
+            # exchange was started, no gradient handed out -- so the whole step runs again on the f32 MFMA kernels.  The
+            # second attempt's launches are ordered behind the first's on every stream they share, and its prelude zeroes
+            # the gradient buffer again.
+            with eng.f32_only():
+                res = self._attempt(batch, s_val, global_rays, entropy_owner, m, eng, ps)
+        return res
+
+    def _attempt(self, batch, s_val, global_rays, entropy_owner, m, eng, ps):
         g = None
 
         def prelude():        # independent of the march: runs on the device while the host waits for the plan header
@@ -300,7 +326,7 @@ class FineStep:
         ctx, last, srgb, lin = eng.forward(
             m.scene_struct(), batch["rays_o"], batch["rays_d"], batch["viewdirs"], batch["em_modes"],
             m.mask_cache.density.view(*m.mask_cache.density.shape[2:]),
-            m.sdf.device_view(), m.off_color.device_view(), m.emo_color.device_view(), prelude=prelude)
+            m.sdf.device_view(), m.off_color.device_view(), m.emo_color.device_view(), prelude=prelude, heal=False)
         m.last_counts = ctx.counts
         if self.pg is not None:
             _check_overflow(self)         # (after the forward's host wait: see _check_overflow)
@@ -320,7 +346,10 @@ class FineStep:
             after_grids, works = _grid_sync(self, eng)
         else:
             after_grids = None
-        eng.backward(ctx, g_last, g_srgb, g_lin, grads, after_grids=after_grids)
+        guard = _RangeGuard(eng, after_grids)
+        eng.backward(ctx, g_last, g_srgb, g_lin, grads, after_grids=guard)
+        if guard.hit:
+            return None
         if self.pg is not None:
             works.append(dist.all_reduce(self._flat[self._n_grid_pad:], group=self.pg, async_op=True))
             lf = _reduce_loss_and_overflow(self, eng, loss, works)
@@ -490,6 +519,14 @@ class LtsStep:
             return self._step(batch, s_val, global_rays, entropy_owner, draws, m, t, eng, ps)
 
     def _step(self, batch, s_val, global_rays, entropy_owner, draws, m, t, eng, ps):
+        res = self._attempt(batch, s_val, global_rays, entropy_owner, draws, m, t, eng, ps)
+        if res is None:
+            # the range fallback (FineStep._step): again on the f32 MFMA kernels, with the SAME random draws
+            with eng.f32_only():
+                res = self._attempt(batch, s_val, global_rays, entropy_owner, eng.last_draws, m, t, eng, ps)
+        return res
+
+    def _attempt(self, batch, s_val, global_rays, entropy_owner, draws, m, t, eng, ps):
         from .fine_engine import KIND_RADIANCE as KR, KIND_TONEMAP as KT
         from .lts_engine import KIND_BRDF as KB, KIND_EMIT as KE
         G = None
@@ -557,7 +594,11 @@ class LtsStep:
             after_grids, works = _grid_sync(self, eng)
         else:
             after_grids = None
-        eng.lts_backward(ctx, g, grads, after_grids=after_grids)
+        guard = _RangeGuard(eng, after_grids)
+        eng.lts_backward(ctx, g, grads, after_grids=guard)
+        if guard.hit:
+            self._pair_jobs = []
+            return None
         if self.pg is not None:
             works.append(dist.all_reduce(self._flat[self._n_grid_pad:], group=self.pg, async_op=True))
             lf = _reduce_loss_and_overflow(self, eng, loss, works)

@@ -338,11 +338,18 @@ int esr_mlp_pack_batch(int n, const int32_t *kinds, const esr_mlp_weights_t *con
  * net: ESR_EINVAL).  The reference evaluates these layers with fp32 nn.Linear (app/utils/pbr/module.py:6-83).
  */
 int64_t esr_mlp_packed_split_elems(int kind);
-/* The split kernels' range: a first plane is fp16, so a hidden activation (or input, or 64 x weight) beyond 65504 would become
- * inf.  flag (device uint32, owned by the caller, sticky; NULL unregisters) is registered for the CURRENT device; every later
- * esr_mlp_fwd_split / esr_mlp_fwd_fine_split launch on it ORs the flag with 1 when a hidden activation reaches 60000 or is
- * inf / NaN.  esr_fine_plan copies it into bit 1 of the plan header's overflow word, so it reaches the host with the read-back the
- * step makes anyway (fine_engine.py raises). */
+/* The split kernels' range: a first plane is fp16, so an input, a hidden activation or 64 x a weight beyond 65504 would become
+ * inf.  flag (device uint32, owned by the caller, sticky; NULL unregisters) is registered for the CURRENT device and ORed with 1
+ * by every later (a) esr_mlp_fwd_split / esr_mlp_fwd_fine_split launch on it when an input or a hidden activation reaches
+ * 60000 (or is inf; a +NaN activation) -- the output layer's results are fp32 sums that never become planes --, (b)
+ * esr_mlp_pack_batch launch when fp16(64 w) of a weight is not finite (|w| >= 1023.5), or when the net's gradient gain bound
+ * (below) exceeds 2^18.  The BACKWARD needs no flag: esr_mlp_pack_batch writes, behind a net's planes, the bound
+ * G = max over the hidden layers of the running product of the layers' largest column sums of |W| (and 1): no hidden
+ * gradient of a tile can exceed G max |dz|; esr_mlp_dgrad_split scales each tile so that G max |dz| is in [2^14, 2^15), and its
+ * `amax` output (the weight-gradient kernels' scale source) is max |dz| x max(1, G / 16).  The host side
+ * (esr_nerf_amd/fine_engine.py: range_probe / range_hit / f32_only) reads the flag behind the forward of every step and
+ * re-runs a step that raised it on the f32 MFMA entry points, which share every buffer format.  esr_fine_plan also copies the
+ * flag into bit 1 of the plan header's overflow word (informational). */
 int esr_mlp_split_range_flag(uint32_t *flag);
 int esr_mlp_fwd_split(int kind, const float *packed32, const void *planes, const float *X, int32_t t0, int32_t t1,
                       float *const *H, uint32_t *const *M, int save, int color_row0, float *zout, void *stream);
@@ -352,14 +359,15 @@ int esr_mlp_fwd_fine_split(const float *packed32_off, const void *planes_off, co
 /* The input-gradient chain the same way (contracts of esr_mlp_dgrad / esr_mlp_dgrad_fine; the same four kinds): the split
  * buffer also holds the TRANSPOSED weights' planes.  Gradients are far below fp16's normal range, so each 32-sample tile's
  * chain runs scaled by a power of two chosen from its largest |dz| (exact), and dZ / dX are written unscaled in fp32. */
-/* amax (optional, device, one float, >= 0 on entry -- normally zero): raised to the largest |dz| of the launch's tiles with an
- * atomic maximum; esr_wgrad_job_t::amax reads it (the scale of the split-fp16 weight-gradient kernel). */
+/* amax (optional, device, one float, >= 0 on entry -- normally zero): raised, with an atomic maximum, to the largest |dz| of the
+ * launch's tiles x max(1, G / 16) (G: the net's gain bound, above) -- a value B with |dz| <= B and every hidden |dZ| <= 16 B;
+ * esr_wgrad_job_t::amax and esr_tone_wgrad_recompute_split read it (their planes hold >= 32 B). */
 int esr_mlp_dgrad_split(int kind, const void *planes, const float *dz, int32_t t0, int32_t t1, const uint32_t *const *M,
                         float *const *dZ, float *dX, float *amax, void *stream);
 int esr_mlp_dgrad_fine_split(const void *planes_emo, const void *planes_off, const float *dz, int32_t t_on, int32_t t_all,
                              const uint32_t *const *M, float *const *dZ, float *dX, float *amax, void *stream);
-/* out[0] = max(out[0], max |x[i]|, i < n) (device; out >= 0 on entry): the same quantity for callers that do not run the
- * split input-gradient kernel. */
+/* out[0] = max(out[0], max |x[i]|, i < n) (device; out >= 0 on entry).  As a scale source of the split weight-gradient
+ * kernels it is safe only where the caller knows its hidden gradients stay below 32 x that value (tests). */
 int esr_absmax(const float *x, int64_t n, float *out, void *stream);
 
 /*
@@ -448,8 +456,9 @@ typedef struct esr_wgrad_job {
     /* optional (bf16 operands, ESR_MLP_RADIANCE, color_row0 == 0): the net's input tile as written by
      * esr_fine_feat_fwd_x16 -- the first-layer job then stages it like a hidden layer's tile and X is not read. */
     const void *X16;
-    /* optional (f32 operands; every net kind and layer shape): device pointer to max |dz| over the step's output gradients
-     * (esr_absmax, or esr_mlp_dgrad_fine_split's amax output).  Non-NULL selects the split-fp16 weight-gradient kernel:
+    /* optional (f32 operands; every net kind and layer shape): device pointer to the scale source B left by
+     * esr_mlp_dgrad_split / esr_mlp_dgrad_fine_split (|dz| <= B, hidden |dZ| <= 16 B; the planes hold 128 B).  Non-NULL
+     * selects the split-fp16 weight-gradient kernel:
      * the same fp32 operands, every value cut into two fp16 planes on its way into the 16-bit matrix cores, fp32
      * accumulation; the gradient operand is scaled by a power of two derived from *amax (csrc/mlp.hip, SPLIT). */
     const float *amax;
@@ -481,7 +490,7 @@ int esr_tone_wgrad_recompute_bf16(const float *Xt, const float *dzt, const float
                                   int32_t t0, int32_t t1, float *gw0, float *gb0, float *gw1, float *gb1,
                                   float *scratch, int64_t scratch_floats, void *stream);
 /* The same with the products on the 16-bit matrix cores from split fp16 planes, fp32 results (round 4; csrc/tone_wgrad.hip):
- * amax = device pointer to max |dzt| over the tiles (esr_absmax), the source of the gradient operand's power-of-two scale. */
+ * amax = device pointer to esr_mlp_dgrad_split's scale source of the tone mapper's pass (|dzt| <= B, |dZt| <= 16 B). */
 int esr_tone_wgrad_recompute_split(const float *Xt, const float *dzt, const float *W0, const float *b0, const float *W1,
                                    const float *amax, int32_t t0, int32_t t1, float *gw0, float *gb0, float *gw1,
                                    float *gb1, float *scratch, int64_t scratch_floats, void *stream);

@@ -170,3 +170,18 @@ def test_bench_flow_with_two_ranks_rehearsal(scaling):
     assert d["config"]["rays_per_gpu"] == (512 if scaling == "weak" else 256)      # strong: the config's rays in total
     assert d["grad_exchange"]["mode"] == "sparse" and d["grad_exchange"]["bricks"] > 0      # 2 ranks -> sparse
     assert "REHEARSAL" in d["data"]
+
+
+def test_plain_bench_command_with_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` WITHOUT a launcher (the shape of the driver's single-GPU command): bench.py starts
+    `torch.distributed.run` itself as a child process and relays rank 0's JSON line as the last line of stdout, exit code 0."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(ESR_BENCH_REHEARSAL="1", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2",
+                          "--config", "small"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    last = out.stdout.strip().splitlines()[-1]
+    d = json.loads(last)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["dist"]["rccl_ranks"] == 2
+    assert d["split_fallback_steps"] == 0
