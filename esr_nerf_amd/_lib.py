@@ -103,7 +103,7 @@ EXPORTS = [
     "esr_fine_march_bwd", "esr_fine_march_bwd_rec", "esr_fine_march_cache_floats", "esr_fine_march_count_cached",
     "esr_fine_march_fill_cached", "esr_fine_march_bwd_cached", "esr_fine_march_count_ga", "esr_fine_march_fill_ga", "esr_fine_march_bwd_ga",
     "esr_fine_feat_fwd", "esr_fine_feat_fwd_x16", "esr_fine_feat_x16_bytes", "esr_fine_feat_bwd",
-    "esr_mlp_packed_floats", "esr_mlp_pack", "esr_mlp_pack_batch", "esr_mlp_packed_split_elems", "esr_mlp_split_range_flag", "esr_mlp_fwd_split", "esr_mlp_fwd_fine_split", "esr_mlp_dgrad_split", "esr_mlp_dgrad_fine_split", "esr_absmax", "esr_mlp_fwd", "esr_mlp_fwd_mixed", "esr_mlp_fwd_fine", "esr_mlp_dgrad_fine", "esr_mlp_fwd_fine_bf16", "esr_mlp_dgrad_fine_bf16", "esr_mlp_dgrad", "esr_mlp_dgrad_wg", "esr_mlp_wgrad", "esr_mlp_wgrad_batch", "esr_tone_wgrad_scratch_floats", "esr_tone_wgrad_recompute", "esr_tone_wgrad_recompute_bf16", "esr_tone_wgrad_recompute_split",
+    "esr_mlp_packed_floats", "esr_mlp_pack", "esr_mlp_pack_batch", "esr_mlp_packed_split_elems", "esr_mlp_split_gain_offset", "esr_mlp_split_range_flag", "esr_mlp_split_variant", "esr_mlp_fwd_split", "esr_mlp_fwd_fine_split", "esr_mlp_dgrad_split", "esr_mlp_dgrad_fine_split", "esr_absmax", "esr_mlp_fwd", "esr_mlp_fwd_mixed", "esr_mlp_fwd_fine", "esr_mlp_dgrad_fine", "esr_mlp_fwd_fine_bf16", "esr_mlp_dgrad_fine_bf16", "esr_mlp_dgrad", "esr_mlp_dgrad_wg", "esr_mlp_wgrad", "esr_mlp_wgrad_batch", "esr_tone_wgrad_scratch_floats", "esr_tone_wgrad_recompute", "esr_tone_wgrad_recompute_bf16", "esr_tone_wgrad_recompute_split",
     "esr_mlp_wgrad_scratch_floats",
     "esr_fine_tone_in_fwd", "esr_fine_composite_fwd", "esr_fine_composite_bwd",
     "esr_fine_tone_in_bwd", "esr_fine_loss_fwd_bwd", "esr_fine_loss_fwd_bwd_dp",
@@ -145,6 +145,8 @@ def lib() -> C.CDLL:
             L.esr_mlp_packed_bf16_elems.restype = C.c_int64
         if hasattr(L, "esr_mlp_packed_split_elems"):
             L.esr_mlp_packed_split_elems.restype = C.c_int64
+        if hasattr(L, "esr_mlp_split_gain_offset"):
+            L.esr_mlp_split_gain_offset.restype = C.c_int64
         if L.esr_abi_version() != ABI_VERSION:
             raise RuntimeError("libesr_hip.so ABI version mismatch: rebuild")
         _lib = L

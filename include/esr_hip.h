@@ -338,6 +338,8 @@ int esr_mlp_pack_batch(int n, const int32_t *kinds, const esr_mlp_weights_t *con
  * net: ESR_EINVAL).  The reference evaluates these layers with fp32 nn.Linear (app/utils/pbr/module.py:6-83).
  */
 int64_t esr_mlp_packed_split_elems(int kind);
+/* fp16-element offset, inside a net's planes buffer, of its gradient gain bound G (one fp32; see esr_mlp_split_range_flag) */
+int64_t esr_mlp_split_gain_offset(int kind);
 /* The split kernels' range: a first plane is fp16, so an input, a hidden activation or 64 x a weight beyond 65504 would become
  * inf.  flag (device uint32, owned by the caller, sticky; NULL unregisters) is registered for the CURRENT device and ORed with 1
  * by every later (a) esr_mlp_fwd_split / esr_mlp_fwd_fine_split launch on it when an input or a hidden activation reaches
@@ -351,6 +353,10 @@ int64_t esr_mlp_packed_split_elems(int kind);
  * re-runs a step that raised it on the f32 MFMA entry points, which share every buffer format.  esr_fine_plan also copies the
  * flag into bit 1 of the plan header's overflow word (informational). */
 int esr_mlp_split_range_flag(uint32_t *flag);
+/* Test / timing hook.  Which kernels run the RADIANCE net's split launches: 0 (default) the one-wave-per-SIMD kernels, 1 the
+ * wave-pair kernels (csrc/mlp_pair.h: two waves share a 32-sample tile, K split by k-step parity, partial sums through LDS;
+ * two waves per SIMD).  Same contracts, same buffers; results equal to fp32 rounding.  Returns the previous value. */
+int esr_mlp_split_variant(int pair);
 int esr_mlp_fwd_split(int kind, const float *packed32, const void *planes, const float *X, int32_t t0, int32_t t1,
                       float *const *H, uint32_t *const *M, int save, int color_row0, float *zout, void *stream);
 int esr_mlp_fwd_fine_split(const float *packed32_off, const void *planes_off, const float *packed32_emo,

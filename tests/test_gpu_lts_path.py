@@ -455,3 +455,67 @@ def test_evaluate_reads_the_frozen_emit_color_after_finetune():
     for k in ro:
         assert rel_err(res[k], ro[k]) < TOL, (k, rel_err(res[k], ro[k]))
     assert rel_err(m.eval_emit(**b), lp.eval_emit(P, c, sc.batch, 60.0, emit_grid_key="emit_color.grid")) < TOL
+
+
+@pytest.mark.parametrize("stage,which", [("lts", "brdf_hidden"), ("pdra", "emo_weight")])
+def test_lts_step_heals_a_range_overflow_in_the_same_step_with_the_same_draws(stage, which):
+    """The split-fp16 kernels' range fallback in the light-transport steps (trainer.LtsStep, INTERNAL random draws): a BRDF-net
+    bias that pushes a hidden activation beyond fp16's range / an emo-net weight beyond 1023 in the middle of a run.  The
+    step object re-runs the step on the f32 MFMA kernels with the draws of the first attempt (surface points, directions,
+    both noises) -- so its loss and its 43 gradients equal those of an engine that is f32-only from the start and is fed
+    the same draws -- without an exception, before anything leaves the step."""
+    import warnings
+    from esr_nerf_amd.synthetic import init_slab_model, slab_scene
+    from esr_nerf_amd.trainer import LtsStep
+    n_rays, R, Pn, s_val = 384, 16, 48, 60.0
+    sc = slab_scene("small", s_val=s_val, oblique=True, n_rays=n_rays, seed=2)
+    b = {k: v.cuda() for k, v in sc.batch.items()}
+    g = torch.Generator().manual_seed(1)
+    b["uncert_masks"] = (torch.rand(n_rays, generator=g) < 0.5).cuda()
+
+    def build():
+        m, cfg = build_lts_model(sc, num_2ndrays=R, num_ltspts=Pn)
+        init_slab_model(m, sc, seed=3)
+        with torch.no_grad():
+            m.brdf.grid.normal_(0.0, 0.3)
+        m.pdra_mode = stage == "pdra"
+        return m, LtsStep(m, cfg.app.trainer, stage=stage)
+
+    def poke(m):
+        if which == "brdf_hidden":
+            m.brdfnet.layers()[0].bias.data[5] = 9.0e4
+        else:
+            m.emo_rgbnet.layers()[2].weight.data[3, 4] = 2500.0
+    m, step = build()
+    eng = m.engine
+    assert eng.split_fwd
+    eng.range_flag.zero_()
+    step.forward_loss_backward(b, s_val)
+    assert eng.split_fallback_steps == 0
+    poke(m)
+    torch.manual_seed(11)
+    np.random.seed(11)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        loss, G, _ = step.forward_loss_backward(b, s_val)
+    torch.cuda.synchronize()
+    assert eng.split_fallback_steps == 1 and eng.split_fwd and int(eng.range_flag) == 0
+    draws = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in eng.last_draws.items()}
+    got = (float(loss), {k: v.clone() for k, v in G.items()})
+    step.close()
+    m2, step2 = build()
+    e2 = m2.engine
+    e2.split_fwd = e2.split_bwd = e2.split_wgrad = e2.split_tone_wgrad = False
+    step2.forward_loss_backward(b, s_val)
+    poke(m2)
+    loss2, G2, _ = step2.forward_loss_backward(b, s_val, draws=draws)
+    torch.cuda.synchronize()
+    assert abs(got[0] - float(loss2)) <= 2e-6 * abs(float(loss2)), (got[0], float(loss2))
+    assert len(G2) >= 43
+    bad = {}
+    for k, v in G2.items():
+        assert bool(torch.isfinite(got[1][k]).all()), k
+        e = rel_err(got[1][k], v)
+        if not e < 3e-5:                      # (the same f32 kernels on the same data; float-atomic order differs)
+            bad[k] = e
+    assert not bad, str(bad)
