@@ -106,6 +106,10 @@ def parse():
                          "the timed steps (they are inside by default: the metric is forward A1-A12 + loss + backward)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not bracket kernels with HIP events (drops the roofline object)")
+    ap.add_argument("--sync-sweep", action="store_true",
+                    help="N > 1: after the timed steps, time 10 more steps under each gradient-exchange form (sparse / dense / "
+                         "shard is left out: it needs the sharded optimizer) and print grad_sync_sweep_ms, so that ONE multi-GPU "
+                         "record is enough to pick the default of trainer._grid_sync")
     ap.add_argument("--no-other", action="store_true",
                     help="headline run only: skip the `other_workloads` key (C3 bf16, C4 lts f32, C5 pdra bf16; 30 steps each, "
                          "one child process per workload after the headline has been measured)")
@@ -477,12 +481,13 @@ def main():
             p_.requires_grad_(True)
         model.s_val = a.s_val
         model.train(True, finetune=True)
+        from esr_nerf_amd.trainer import FinetuneStep
         g_ = torch.Generator().manual_seed(21)
         batch = dict(rays_o=batch["rays_o"], rays_d=batch["rays_d"], viewdirs=batch["viewdirs"],
                      em_modes=(torch.arange(n_rays, device=dev) % 5).long(),
                      em_intensities=(0.25 + 2.0 * torch.rand(n_rays, generator=g_)).to(dev),
                      em_colors=torch.rand(n_rays, 2, generator=g_).to(dev))
-        step = None
+        step = FinetuneStep(model)              # (the direct driver; ESRNeRF.forward_finetune + autograd is the drop-in route)
     else:
         model.pdra_mode = stage == "pdra"
         with torch.no_grad():
@@ -502,12 +507,8 @@ def main():
                                                 entropy_owner=(rank == world - 1))[:2]
             step.add_regularisers(l_, g_, n_rays * world, W_TV, TVS, True)
             return l_, g_
-        if stage == "finetune":
-            model.zero_grad(set_to_none=True)
-            res = model(**batch)
-            loss_ = 0.5 * torch.nn.functional.mse_loss(res["lin/pbr/emo"], res["lin/pbr/emo_hat"])   # pdra.py:1090-1093
-            loss_.backward()
-            return loss_.detach(), None
+        if stage == "finetune":                 # loss: 0.5 * mse(lin/pbr/emo, lin/pbr/emo_hat), pdra.py:1090-1093
+            return step.forward_loss_backward(batch, a.s_val)
         # N > 1: this rank's rays are one shard of a global batch of n_rays * N rays
         return step.forward_loss_backward(batch, a.s_val, global_rays=n_rays * world if pg is not None else None,
                                           entropy_owner=(rank == world - 1))[:2]
@@ -657,6 +658,25 @@ def main():
         prof = getattr(step, "_sync", None) or GridGradSync(pg)
         phases = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in prof.profile(step._flat[: step._n_grid]).items()}
 
+    sweep = None
+    if pg is not None and a.sync_sweep and stage != "finetune":
+        sweep = {}
+        keep_mode = step._sync_mode
+        for mode in ("sparse", "dense"):
+            step._sync_mode, step._sync = mode, None
+            for _ in range(3):
+                one()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i_ in range(10):
+                one(i_)
+            torch.cuda.synchronize()
+            dist.barrier()
+            tt_ = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            sweep[mode] = float(tt_.item()) / 10 * 1e3
+        step._sync_mode, step._sync = keep_mode, None
     if rank == 0:
         value = n_rays * world * a.steps / dt
         c = CONFIGS[a.config]
@@ -802,8 +822,8 @@ def main():
                     ms_ = t_ / n_
                     out["roofline"]["split_forward"] = {
                         "kernel": "mlp_fwd_split_kernel<0>", "avg_launch_ms": ms_,
-                        "what": "the step's three radiance forward passes; every product as 3 fp16 MFMAs on split planes "
-                                "(x = x1 + x2/2048), fp32 accumulation and fp32 results (csrc/mlp_split.hip)",
+                        "what": "the step's three radiance forward passes; every product as 3 fp16 MFMAs on two fp16 planes per "
+                                "operand (x = x1 + x2), fp32 accumulation and fp32 results (csrc/mlp_split.hip)",
                         "algorithmic_gflop": fl_ / 1e9, "issued_16bit_gflop": 3 * fl_ / 1e9,
                         "mfma16_tflops_issued": 3 * fl_ / (ms_ * 1e-3) / 1e12,
                         "mfma16_frac": 3 * fl_ / (ms_ * 1e-3) / 1e12 / MFMA_F16_PEAK_TF,
@@ -841,6 +861,26 @@ def main():
                                                  "frac": step_fl / (dt / a.steps) / 1e12 / peak,
                                                  "exact_mac_gflop": exact / 1e9,
                                                  "frac_exact_mac": exact / (dt / a.steps) / 1e12 / peak}
+                step_traffic = pmc_traffic(a, stage, ["__step__"])
+                if split_fwd:
+                    # the step against the roofs of the pipes it runs on: issued 16-bit MFMA FLOPs (3 per algorithmic FLOP of
+                    # the exact MAC count) over the fp16 matrix peak, and the step's HBM bytes (PMC) over its wall time
+                    ws = out["roofline"]["whole_step"]
+                    ws["mfma16_issued_tflops"] = 3 * exact / (dt / a.steps) / 1e12
+                    ws["mfma16_frac"] = ws["mfma16_issued_tflops"] / MFMA_F16_PEAK_TF
+                    ws["mfma16_frac_algorithmic"] = exact / (dt / a.steps) / 1e12 / MFMA_F16_PEAK_TF
+                if step_traffic:
+                    ws = out["roofline"]["whole_step"]
+                    # compulsory bytes per iteration = rays, grids touched once, activations written once and read
+                    # once by the backward: 1.31 KB per surviving sample + 80 B per ray = 0.69 GB at C2
+                    compulsory = 1310.0 * counts["m3"] + 80.0 * n_rays
+                    ws["hbm_bytes_pmc"] = step_traffic
+                    ws["hbm_gbs"] = step_traffic / (dt / a.steps) / 1e9
+                    ws["hbm_frac"] = ws["hbm_gbs"] / HBM_PEAK_GBS
+                    ws["compulsory_bytes_survey_8d"] = compulsory
+                    ws["traffic_over_compulsory"] = step_traffic / compulsory
+                    ws["bound"] = ("hbm" if ws["hbm_frac"] >= 0.6 else
+                                   "mfma" if ws.get("mfma16_frac", ws["frac"]) >= 0.6 else "latency")
                 if split_fwd:
                     out["roofline"]["whole_step"]["note"] = (
                         "the radiance nets' FLOPs (forward, input and weight gradients; algorithmic, counted once) run on the 16-bit matrix cores since round 4: "
@@ -865,17 +905,20 @@ def main():
                   "mfma": {"achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak},
                   "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                           "note": "algorithmic bytes of the MLP launches (inputs + saved activations / gradients)"}}
-            # f32 operands: the f32 matrix rate binds; bf16 operands: the matrix work is 16x cheaper and the saved
-            # activation traffic binds -- each line is priced against the roof of ITS operand type
-            pick = rl["hbm"] if bf else rl["mfma"]
-            rl.update(bound=("hbm" if bf else "mfma") if pick["frac"] >= 0.6 or (not bf) else
-                      ("mfma" if rl["mfma"]["frac"] >= 0.6 else "latency"),
+            # each line is priced against the roofs of the pipe its products RUN on: bf16 operands -> the bf16 matrix peak; f32
+            # operands on the split-fp16 kernels -> three ISSUED 16-bit MFMA FLOPs per algorithmic FLOP against the fp16 matrix
+            # peak; f32 operands on the f32 MFMA kernels (ESR_SPLIT_FWD=0) -> the f32 matrix peak.  Beside it the algorithmic
+            # bytes against HBM.  Neither fraction at 0.6 = bound by launch / issue latency: labelled so, the NEARER roof quoted.
+            split_lts = (not bf) and bool(getattr(eng, "split_fwd", False))
+            if split_lts:
+                rl["mfma"] = {"achieved": 3.0 * tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": 3.0 * tf / MFMA_F16_PEAK_TF,
+                              "note": "issued 16-bit MFMA FLOPs (3 per algorithmic FLOP: split fp16 planes, fp32 results)",
+                              "fp32_equivalent_tflops": tf}
+            hf, mf_ = rl["hbm"]["frac"], rl["mfma"]["frac"]
+            pick = rl["hbm"] if hf >= mf_ else rl["mfma"]
+            rl.update(bound="hbm" if hf >= 0.6 else "mfma" if mf_ >= 0.6 else "latency",
                       achieved=pick["achieved"], peak=pick["peak"], unit=pick["unit"], frac=pick["frac"],
-                      hbm_frac=rl["hbm"]["frac"], mfma_frac=rl["mfma"]["frac"])
-            if not bf and getattr(eng, "split_fwd", False):
-                rl["note"] = ("f32 engine, round 4: every net's forward / input-gradient / weight-gradient launches run on the 16-bit "
-                              "matrix cores from split fp16 planes (fp32 results); `mfma` is still the step's ALGORITHMIC FLOP rate "
-                              "over the f32 matrix peak, kept for comparison with earlier rounds -- it is not bounded by 1")
+                      hbm_frac=hf, mfma_frac=mf_)
             out["roofline"] = rl
         if pg is not None:
             # how many ranks the collective library actually saw, and which exchange ran (trainer._grid_sync)
@@ -887,6 +930,8 @@ def main():
         sync = getattr(step, "_sync", None)
         if phases is not None:
             out["grad_exchange_phases_ms"] = phases
+        if sweep is not None:
+            out["grad_sync_sweep_ms"] = dict(sweep, note="ms per step (10 steps after 3 warm-up steps) under each exchange form, same ranks")
         if sync is not None:
             # data-parallel exchange of the dense-grid gradients (esr_nerf_amd/grad_sync.py), last step of rank 0
             out["grad_exchange"] = dict(sync.last, brick_bytes=sync.brick * 4,

@@ -616,3 +616,88 @@ class LtsStep:
         for n, p in self.model.named_parameters():
             if n in grads:
                 p.grad = grads[n]
+
+
+class FinetuneStep:
+    """One step of the re-lighting fine-tune (app/fine/pdra.py:1047-1109: ``forward_finetune`` + ``0.5 * mse(emo, emo_hat)`` +
+    backward) on the HIP path without autograd in the loop: ``LtsEngine.finetune_forward`` -> one ``esr_pair_loss_batch``
+    launch -> ``LtsEngine.finetune_backward``.  Only ``emo_color.grid`` and the emo radiance net receive gradients (the
+    reference freezes everything else, pdra.py:1060-1066); the model must be in fine-tune mode (``model.train(True,
+    finetune=True)``: the frozen ``emit_color`` copy exists).  The drop-in route -- ``ESRNeRF.forward_finetune`` + a torch loss +
+    ``loss.backward()`` -- enqueues the same kernels and is tested to give the same numbers; this driver spares the step
+    autograd's bookkeeping and a dozen torch launches (it was the most host-bound step of the path)."""
+
+    def __init__(self, model, weight: float = 0.5):
+        if not hasattr(model, "emit_color"):
+            raise RuntimeError("FinetuneStep needs the model in fine-tune mode: model.train(True, finetune=True)")
+        self.model, self.weight = model, float(weight)
+        self._flat = None
+        self._names = [f"emo_rgbnet.linear.{k}.{p}" for k, sub in model.emo_rgbnet.linear.named_modules()
+                       if isinstance(sub, torch.nn.Linear) for p in ("weight", "bias")]
+        self._pair = LtsStep._pair.__get__(self)          # (the two-operand loss helpers of LtsStep, on this object)
+        self._pair_flush = LtsStep._pair_flush.__get__(self)
+        self._pair_jobs = []
+
+    def _alloc_grads(self, dev):
+        m = self.model
+        X, Y, Z = m._world_size_l
+        ps = [t for lin in m.emo_rgbnet.layers() for t in (lin.weight, lin.bias)]
+        shapes = [("emo_color.grid", (1, X, Y, Z, 6))] + [(n, tuple(p.shape)) for n, p in zip(self._names, ps)]
+        total = sum(int(torch.Size(s).numel()) for _, s in shapes)
+        if self._flat is None or self._flat.numel() != total:
+            self._flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self._flat.zero_()
+        out, o = {}, 0
+        for n, s in shapes:
+            k = int(torch.Size(s).numel())
+            out[n] = self._flat[o:o + k].view(s)
+            o += k
+        return out
+
+    @torch.no_grad()
+    def forward_loss_backward(self, batch: Dict[str, torch.Tensor], s_val: float, draws=None):
+        """batch: rays_o, rays_d, viewdirs, em_modes, em_intensities, em_colors.  -> (loss [1], gradients by parameter name)."""
+        m = self.model
+        eng = m.engine
+        m.s_val = s_val
+        res = self._attempt(batch, draws, m, eng)
+        if res is None:                   # the split-fp16 kernels' range fallback (FineStep._step): again, same draws
+            with eng.f32_only():
+                res = self._attempt(batch, eng.last_draws, m, eng)
+        return res
+
+    def _attempt(self, batch, draws, m, eng):
+        from .fine_engine import KIND_RADIANCE as KR
+        from .lts_engine import KIND_BRDF as KB, KIND_EMIT as KE
+        dev = batch["rays_o"].device
+        emo = m.emo_rgbnet.layers()
+        with eng.packing():
+            eng.pack("emo", KR, [l.weight.detach() for l in emo], [l.bias.detach() for l in emo])
+            for name, kind, net in (("brdf", KB, m.brdfnet), ("emit", KE, m.emitnet)):
+                lins = net.layers()
+                eng.pack(name, kind, [l.weight.detach() for l in lins], [l.bias.detach() for l in lins])
+        G = self._alloc_grads(dev)
+        grids = dict(sdf=m.sdf.device_view(), emo=m.emo_color.device_view(), brdf=m.brdf.device_view(),
+                     emit=m.emit_color.device_view(), mask=m.mask_cache.density.view(*m.mask_cache.density.shape[2:]))
+        cfg = dict(num_2ndrays=m.num_2ndrays, num_ltspts=m.num_ltspts)
+        b = {k: batch[k].contiguous() for k in ("rays_o", "rays_d", "viewdirs", "em_modes", "em_intensities", "em_colors")}
+        ctx, out = eng.finetune_forward(m.scene_struct(), m.scene_struct(near=m.lts_near), b, grids, cfg, draws)
+        m.last_counts = dict(eng.prim.counts)
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        g_emo, _ = self._pair(eng, loss, out["lin/pbr/emo"], out["lin/pbr/emo_hat"], 0, self.weight, self.weight, 0.0, 1.0,
+                              want_gb=False)
+        self._pair_flush(eng, loss)
+        eng.finetune_backward(ctx, g_emo, dict(emo=G["emo_color.grid"], emo_w=[G[n] for n in self._names[0::2]],
+                                               emo_b=[G[n] for n in self._names[1::2]]))
+        if eng.range_hit():               # (with the backward queued: the wait is free; nothing has left the step -- _RangeGuard)
+            return None
+        G["emo_color.grid"] = G["emo_color.grid"].permute(0, 4, 1, 2, 3)       # logical [1,6,X,Y,Z]
+        return loss, G
+
+    def assign_grads(self, grads: Dict[str, torch.Tensor]):
+        for n, p in self.model.named_parameters():
+            if n in grads:
+                p.grad = grads[n]
+
+    def close(self):
+        pass

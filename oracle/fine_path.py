@@ -220,12 +220,24 @@ class _Composite(torch.autograd.Function):
 KNIFE_LOG: Optional[list] = None      # tests may set a list: receives (weight key, unit indices) of hidden units with |z| < 2e-6
 
 
-def mlp(P: Dict[str, Tensor], keys, x: Tensor, knife: Optional[Tensor] = None) -> Tensor:
+FLIP_LOG: Optional[list] = None       # tests may set a list: receives one record per forced ReLU layer (see mlp)
+
+
+def mlp(P: Dict[str, Tensor], keys, x: Tensor, knife: Optional[Tensor] = None, force=None) -> Tensor:
     """Linear+ReLU chain; the last layer is linear.  ``knife`` ([rows] float, optional) is lowered in place to the
     smallest |hidden pre-activation| of every row: a ReLU unit that close to its kink can take the other branch under
     a different fp32 summation order, which changes that row's GRADIENT discontinuously (tests use it to tell such
-    rows apart; it does not enter the arithmetic)."""
+    rows apart; it does not enter the arithmetic).
+
+    ``force`` (optional): one bool tensor [rows, width] per hidden layer -- the ReLU BRANCHES another implementation of
+    the same net took (the HIP kernels' saved sign bits).  The layer's output is then ``pre-activation * mask`` instead
+    of ``relu(pre-activation)``: the same piecewise-linear function on the same piece, so the two implementations can
+    be compared at the tolerance of their arithmetic with no sample set aside.  Every unit whose forced branch differs
+    from this evaluation's own is ARBITRATED in float64: FLIP_LOG receives (layer key, number of flipped units,
+    largest |float64 pre-activation| among them) -- a flip is legitimate only where the exact value is within fp32
+    summation noise of the kink (the tests assert the bound)."""
     for i, k in enumerate(keys):
+        xin = x
         x = F.linear(x, P[k + ".weight"], P[k + ".bias"])
         if i + 1 < len(keys):
             if knife is not None:
@@ -233,7 +245,21 @@ def mlp(P: Dict[str, Tensor], keys, x: Tensor, knife: Optional[Tensor] = None) -
                     torch.minimum(knife, x.detach().abs().amin(-1), out=knife)
                     if KNIFE_LOG is not None:
                         KNIFE_LOG.append((k, (x.detach().abs() < 2e-6).nonzero()[:, 1].unique()))
-            x = F.relu(x)
+            if force is not None:
+                mask = force[i]
+                with torch.no_grad():
+                    flip = mask != (x.detach() > 0)
+                    if FLIP_LOG is not None:
+                        worst = 0.0
+                        if bool(flip.any()):
+                            rows = flip.any(-1).nonzero()[:, 0]
+                            x64 = F.linear(xin.detach()[rows].double(), P[k + ".weight"].detach().double(),
+                                           P[k + ".bias"].detach().double())
+                            worst = float(x64[flip[rows]].abs().max())
+                        FLIP_LOG.append((k, int(flip.sum()), worst))
+                x = x * mask.to(x.dtype)
+            else:
+                x = F.relu(x)
     return x
 
 
@@ -241,21 +267,29 @@ RADIANCE_KEYS = ("linear.0", "linear.2.0", "linear.3.0", "linear.4")
 TONEMAP_KEYS = ("srgb.0", "srgb.2")
 
 
-def radiance(P, prefix, x, knife: Optional[Tensor] = None):
-    return F.softplus(mlp(P, [f"{prefix}.{k}" for k in RADIANCE_KEYS], x, knife))
+def radiance(P, prefix, x, knife: Optional[Tensor] = None, force=None):
+    return F.softplus(mlp(P, [f"{prefix}.{k}" for k in RADIANCE_KEYS], x, knife, force))
 
 
-def tonemap(P, c: FineConsts, lin: Tensor, knife: Optional[Tensor] = None) -> Tensor:
+def tonemap(P, c: FineConsts, lin: Tensor, knife: Optional[Tensor] = None, force=None) -> Tensor:
     freq = torch.tensor([2.0 ** i for i in range(c.colorbase_pe)])
     emb = (lin.unsqueeze(-1) * freq).flatten(-2)
     x = torch.cat([lin, emb.sin(), emb.cos()], -1)
-    return torch.sigmoid(mlp(P, [f"tonemapper.{k}" for k in TONEMAP_KEYS], x, knife))
+    return torch.sigmoid(mlp(P, [f"tonemapper.{k}" for k in TONEMAP_KEYS], x, knife, force))
 
 
 def forward_training(P: Dict[str, Tensor], c: FineConsts, batch: Dict[str, Tensor], s_val: float,
-                     keep: Optional[dict] = None) -> Dict[str, Tensor]:
+                     keep: Optional[dict] = None, force: Optional[dict] = None) -> Dict[str, Tensor]:
     """P: tensors under the reference's state_dict names (sdf.grid, off_color.grid,
-    emo_color.grid, off_rgbnet.*, emo_rgbnet.*, tonemapper.*)."""
+    emo_color.grid, off_rgbnet.*, emo_rgbnet.*, tonemapper.*).
+
+    ``force`` (tests only): the DISCRETE decisions of another implementation of this path, taken over so that the two
+    can be compared with nothing set aside --
+      "survivors": int64 keys ``ray * 2**20 + step`` of ITS final survivor set: replaces this evaluation's
+                   ``weights > fastcolor_thres`` test (``keep["threshold_flips"]``: the weights of the samples whose
+                   membership changed -- legitimate only ON the threshold, which the tests assert);
+      "relu":      callable (ray_id, step_id, on) -> dict(emo=[3 masks], off=[3 masks], tone=[1 mask]), bool tensors in
+                   THIS evaluation's sample order (emo: the on-samples, off: the off-samples, tone: all): see ``mlp``."""
     rays_o, rays_d = batch["rays_o"].contiguous(), batch["rays_d"].contiguous()
     viewdirs, em_modes = batch["viewdirs"], batch["em_modes"]
     N = rays_o.shape[0]
@@ -278,6 +312,11 @@ def forward_training(P: Dict[str, Tensor], c: FineConsts, batch: Dict[str, Tenso
 
     weights, alphainv_last = _Composite.apply(alpha, ray_id, N)
     m = weights > c.fastcolor_thres
+    if force is not None and force.get("survivors") is not None:
+        m_forced = torch.isin(ray_id * (1 << 20) + step_id, force["survivors"])
+        if keep is not None:
+            keep["threshold_flips"] = weights.detach()[m_forced != m]
+        m = m_forced
     weights, pts, ray_id, step_id, sdf = weights[m], pts[m], ray_id[m], step_id[m], sdf[m]
     n3 = pts.shape[0]
 
@@ -296,13 +335,15 @@ def forward_training(P: Dict[str, Tensor], c: FineConsts, batch: Dict[str, Tenso
     lin = torch.zeros_like(pts)
     knife = torch.full((n3,), float("inf")) if keep is not None else None
     k_on, k_off = (knife[on], knife[off]) if knife is not None else (None, None)
+    fr = force["relu"](ray_id, step_id, on) if (force is not None and force.get("relu") is not None) else {}
     x_on_emo = torch.cat([sample_grid(P["emo_color.grid"], norm_pts[on]), common[on]], -1)
     x_on_off = torch.cat([sample_grid(P["off_color.grid"], norm_pts[on]), common[on]], -1)
-    lin[on] = radiance(P, "emo_rgbnet", x_on_emo, k_on) + radiance(P, "off_rgbnet", x_on_off).detach()
+    # (the detached off-net pass on the on-samples carries no gradient: its branches are not forced)
+    lin[on] = radiance(P, "emo_rgbnet", x_on_emo, k_on, fr.get("emo")) + radiance(P, "off_rgbnet", x_on_off).detach()
     x_off = torch.cat([sample_grid(P["off_color.grid"], norm_pts[off]), common[off]], -1)
-    lin[off] = radiance(P, "off_rgbnet", x_off, k_off)
+    lin[off] = radiance(P, "off_rgbnet", x_off, k_off, fr.get("off"))
 
-    rgb = tonemap(P, c, lin, knife)
+    rgb = tonemap(P, c, lin, knife, fr.get("tone"))
     if knife is not None:
         knife[on] = torch.minimum(knife[on], k_on)
         knife[off] = torch.minimum(knife[off], k_off)

@@ -183,8 +183,35 @@ def _run_fine(m, sc, s_val, white_bg=True):
     return float(loss), {k: v.clone() for k, v in grads.items()}
 
 
-def _oracle_fine(fp, c, P, sc, s_val, white_bg=True):
+def _compare_all(grads, P, n_expected):
+    """Every gradient at 1e-4 rel-to-max-norm, nothing set aside: for oracle runs that took over the HIP step's discrete
+    decisions (tests/decisions.py) -- both sides then evaluate the same piecewise-linear function on the same piece."""
+    bad, n = {}, 0
+    for k, v in P.items():
+        if v.grad is None:
+            continue
+        n += 1
+        e = rel_err(grads[k].detach().cpu(), v.grad)
+        if not e < TOL:
+            bad[k] = e
+    assert n == n_expected and not bad, str(bad)
+
+
+def _oracle_fine(fp, c, P, sc, s_val, white_bg=True, force=None, what=""):
+    """``force``: tests/decisions.hip_decisions(model) of the HIP step this oracle run is compared with -- the float64
+    arbitration of every decision taken over is asserted here."""
     keep = {}
+    if force is not None:
+        from decisions import assert_legitimate
+        fp.FLIP_LOG = []
+        try:
+            res = fp.forward_training(P, c, sc.batch, s_val, keep=keep, force=force)
+            assert_legitimate(keep, fp.FLIP_LOG, what=what)
+        finally:
+            fp.FLIP_LOG = None
+        loss, _ = fp.fine_loss(res, sc.batch["rgbs"], white_bg=white_bg)
+        loss.backward()
+        return {k: v.detach() for k, v in res.items()}, float(loss), keep
     res = fp.forward_training(P, c, sc.batch, s_val, keep=keep)
     loss, _ = fp.fine_loss(res, sc.batch["rgbs"], white_bg=white_bg)
     loss.backward()
@@ -196,21 +223,23 @@ def test_c2_full_batch_forward_backward_vs_oracle():
     from esr_nerf_amd.synthetic import slab_scene
     sc = slab_scene("C2", s_val=20.0)
     m = _fine_model(sc)
+    from decisions import hip_decisions
     loss, grads = _run_fine(m, sc, 20.0)
+    dec = hip_decisions(m)                # the step's survivor set and ReLU branches (before another forward reuses the workspace)
     lc = m.last_counts
     assert lc["m0"] == lc["m1"] == lc["m2"] == lc["m3"] == 4096 * 128
     fp, c, P = _fine_oracle(m, sc)
-    res, o_loss, keep = _oracle_fine(fp, c, P, sc, 20.0)
+    # round 4 set aside the grid cells of samples on a ReLU kink (up to 6 / 12 % of the touched cells, bounded by 5e-2);
+    # now the oracle takes over the step's decisions, each arbitrated in float64, and EVERYTHING compares at 1e-4
+    res, o_loss, keep = _oracle_fine(fp, c, P, sc, 20.0, force=dec, what="C2")
     assert keep["counts"] == (lc["m0"], lc["m1"], lc["m2"], lc["m3"])
-    odd = _check_survivor_sets(_survivors(m), keep["ray_id"], keep["step_id"], keep["weights"], sc.batch["rays_o"],
-                               sc.batch["rays_d"], c, sc.near)
-    assert len(odd) == 0
+    assert keep.get("threshold_flips") is None or keep["threshold_flips"].numel() == 0
     assert abs(loss - o_loss) < 1e-5 * max(1.0, abs(o_loss))
     b = {k: v.cuda() for k, v in sc.batch.items()}
     out = m(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=b["em_modes"], s_val=20.0)
     for k in res:
         assert rel_err(out[k], res[k]) < TOL, (k, rel_err(out[k], res[k]))
-    _compare_grads(grads, P, [(keep["pts"], keep["knife"])], c, 23)
+    _compare_all(grads, P, 23)
 
 
 def test_c3_full_size_fp32_no_white_bg_and_bf16_psnr():
@@ -219,20 +248,21 @@ def test_c3_full_size_fp32_no_white_bg_and_bf16_psnr():
     from esr_nerf_amd.synthetic import slab_scene
     sc = slab_scene("C3", s_val=20.0)
     m = _fine_model(sc)
+    from decisions import hip_decisions
     loss, grads = _run_fine(m, sc, 20.0, white_bg=False)
+    dec = hip_decisions(m)
     lc = m.last_counts
     assert lc["m0"] == lc["m1"] == 4096 * 192
     fp, c, P = _fine_oracle(m, sc)
-    res, o_loss, keep = _oracle_fine(fp, c, P, sc, 20.0, white_bg=False)
+    # round 1 recorded 702 430 survivors here against the oracle's 702 431: a sample whose weight sits ON the threshold.
+    # The oracle takes over the step's survivor set (and ReLU branches); a sample whose membership it changes must have
+    # its weight within 2e-3 relative of the threshold (decisions.assert_legitimate), at most 3 of them
+    res, o_loss, keep = _oracle_fine(fp, c, P, sc, 20.0, white_bg=False, force=dec, what="C3")
     n0, n1, n2, n3 = keep["counts"]
-    assert (lc["m0"], lc["m1"], lc["m2"]) == (n0, n1, n2)
-    # round 1 recorded 702 430 survivors here against the oracle's 702 431: the sets are compared sample by sample and
-    # every sample that is in one set only must have its weight on the threshold
-    odd = _check_survivor_sets(_survivors(m), keep["ray_id"], keep["step_id"], keep["weights"], sc.batch["rays_o"],
-                               sc.batch["rays_d"], c, sc.near)
-    assert abs(lc["m3"] - n3) <= len(odd) <= 3, (lc["m3"], n3, len(odd))
+    assert (lc["m0"], lc["m1"], lc["m2"], lc["m3"]) == (n0, n1, n2, n3)
+    assert keep.get("threshold_flips") is None or keep["threshold_flips"].numel() <= 3
     assert abs(loss - o_loss) < 1e-5 * max(1.0, abs(o_loss))
-    _compare_grads(grads, P, [(keep["pts"], keep["knife"]), (odd, torch.zeros(len(odd)))], c, 23)
+    _compare_all(grads, P, 23)
 
     # bf16 MLP operands at the same size: rendered image (forward_evaluate) against the fp32 render
     m16 = _fine_model(sc, "bf16")
@@ -445,23 +475,22 @@ def test_production_size_grid_256_ray_subset_vs_oracle():
     loss, grads = step.forward_loss_backward(b, 40.0)
     torch.cuda.synchronize()
     loss, grads = float(loss), {k: v.clone() for k, v in grads.items()}
+    from decisions import hip_decisions
+    dec = hip_decisions(m)
     lc = m.last_counts
     assert lc["m0"] > 2.5 * lc["m1"] > 0 and lc["m1"] >= lc["m2"] >= lc["m3"] > 0           # the slab mask prunes ~3/4
     fp, c, P = _fine_oracle(m, sc)
-    fp.KNIFE_LOG = []                     # hidden units with a sample on their ReLU kink (65 k samples: a single sample is
-    res, o_loss, keep = _oracle_fine(fp, c, P, sc, 40.0)     # 1.5e-4 of a weight-gradient row, see _compare_grads)
-    fp_log, fp.KNIFE_LOG = fp.KNIFE_LOG, None
+    # (65 k samples: ONE sample on a ReLU kink is 1.5e-4 of a weight-gradient row -- the oracle takes over the step's
+    #  decisions, arbitrated in float64, and nothing is set aside: _oracle_fine / tests/decisions.py)
+    res, o_loss, keep = _oracle_fine(fp, c, P, sc, 40.0, force=dec, what="256^3")
     n0, n1, n2, n3 = keep["counts"]
-    assert (lc["m0"], lc["m1"], lc["m2"]) == (n0, n1, n2)
-    odd = _check_survivor_sets(_survivors(m), keep["ray_id"], keep["step_id"], keep["weights"], sc.batch["rays_o"],
-                               sc.batch["rays_d"], c, sc.near)
-    assert abs(lc["m3"] - n3) <= len(odd) <= 3, (lc["m3"], n3, len(odd))
+    assert (lc["m0"], lc["m1"], lc["m2"], lc["m3"]) == (n0, n1, n2, n3)
+    assert keep.get("threshold_flips") is None or keep["threshold_flips"].numel() <= 3
     assert abs(loss - o_loss) < 1e-5 * max(1.0, abs(o_loss))
     out = m(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=b["em_modes"], s_val=40.0)
     for k in res:
         assert rel_err(out[k], res[k]) < TOL, (k, rel_err(out[k], res[k]))
-    # (measured marked shares: SDF 0.043, colour 0.033 / 0.023 -- inside the default caps)
-    _compare_grads(grads, P, [(keep["pts"], keep["knife"]), (odd, torch.zeros(len(odd)))], c, 23, fp_log=fp_log)
+    _compare_all(grads, P, 23)
     # one fused Adam step at this size (first step from zero moments: update = -lr * g / (|g| + eps) where g != 0)
     lrs = dict(off_color=0.1, off_rgbnet=0.003, emo_color=0.1, emo_rgbnet=0.003, sdf=0.005, tonemapper=0.003)
     opt = create_optimizer_or_freeze_model(m, **lrs)

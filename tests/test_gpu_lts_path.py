@@ -342,6 +342,15 @@ def test_finetune_golden_reference_vectors(mask):
     assert got == want
     bad = {k: rel_err(dict(m.named_parameters())[k].grad, z["grad/" + k]) for k in want}
     assert all(e < TOL for e in bad.values()), str(bad)
+    # the direct driver (trainer.FinetuneStep: no autograd in the loop) against the same reference vectors
+    from esr_nerf_amd.trainer import FinetuneStep
+    step = FinetuneStep(m, weight=float(z["in/weight_lts"]))
+    loss2, G = step.forward_loss_backward(b, 60.0, draws=dict(idx=z["draw/idx"].cuda(), dirs=z["draw/dirs"].cuda()))
+    torch.cuda.synchronize()
+    assert abs(float(loss2) - float(z["loss"])) < 1e-6
+    assert set(G) == want
+    bad = {k: rel_err(G[k], z["grad/" + k]) for k in want}
+    assert all(e < TOL for e in bad.values()), str(bad)
     m.train(True)                      # leaving fine-tune mode drops the frozen copy (esrnerf.py:222-223)
     assert not hasattr(m, "emit_color")
 
