@@ -107,9 +107,17 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not bracket kernels with HIP events (drops the roofline object)")
     ap.add_argument("--sync-sweep", action="store_true",
-                    help="N > 1: after the timed steps, time 10 more steps under each gradient-exchange form (sparse / dense / "
+                    help="N > 1: after the timed steps, time 10 more steps under each gradient-exchange form (sparse / dense; "
                          "shard is left out: it needs the sharded optimizer) and print grad_sync_sweep_ms, so that ONE multi-GPU "
-                         "record is enough to pick the default of trainer._grid_sync")
+                         "record is enough to pick the default of trainer._grid_sync.  On by itself for N = 2..4 (outside the timed "
+                         "region, ~0.1 s); for N >= 5 only with this flag: there the non-default form is the one no real node has run yet")
+    ap.add_argument("--no-sync-sweep", action="store_true", help="N = 2..4: leave the sweep out")
+    ap.add_argument("--split-variant", type=int, default=0,
+                    help="esr_mlp_split_variant: 0 = the one-wave-per-SIMD radiance kernels (the product), 1 = wave-pair kernels in both "
+                         "directions, 2 = in the input gradients only (A/B timing of the round-5 experiment, DESIGN.md section 4)")
+    ap.add_argument("--serial", action="store_true",
+                    help="every kernel on ONE stream (no weight gradients beside the scatters, no side streams in the LTS steps): "
+                         "for rocprofv3 kernel statistics, whose per-kernel times should not include what ran beside them")
     ap.add_argument("--no-other", action="store_true",
                     help="headline run only: skip the `other_workloads` key (C3 bf16, C4 lts f32, C5 pdra bf16; 30 steps each, "
                          "one child process per workload after the headline has been measured)")
@@ -495,6 +503,12 @@ def main():
         batch["uncert_masks"] = (torch.arange(n_rays, device=dev) % 3 == 0)
         step = LtsStep(model, cfg.app.trainer, stage=stage, process_group=pg, split_points=(a.scaling == "strong"))
     eng = model.engine
+    if a.split_variant:
+        eng.L.esr_mlp_split_variant(int(a.split_variant))
+    if a.serial:
+        eng.overlap_wgrad = False
+        if hasattr(eng, "wgrad_early"):
+            eng.wgrad_early, eng.scatter_streamed, eng.eps_stream = set(), set(), False
 
     tv_in_step = stage == "fine" and not a.no_tv
     TVS, W_TV, TV_EVERY = dict(sdf=0.1, smooth_grad=0.05), 0.01, 3        # cfg/app/fine.yaml:73-83
@@ -659,9 +673,9 @@ def main():
         phases = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in prof.profile(step._flat[: step._n_grid]).items()}
 
     sweep = None
-    if pg is not None and a.sync_sweep and stage != "finetune":
+    if pg is not None and (a.sync_sweep or (2 <= world <= 4 and not a.no_sync_sweep)) and stage != "finetune":
         sweep = {}
-        keep_mode = step._sync_mode
+        keep_mode, keep_sync, keep_used = step._sync_mode, step._sync, getattr(step, "sync_mode_used", None)
         for mode in ("sparse", "dense"):
             step._sync_mode, step._sync = mode, None
             for _ in range(3):
@@ -676,7 +690,7 @@ def main():
             tt_ = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
             dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
             sweep[mode] = float(tt_.item()) / 10 * 1e3
-        step._sync_mode, step._sync = keep_mode, None
+        step._sync_mode, step._sync, step.sync_mode_used = keep_mode, keep_sync, keep_used      # (what the line reports: the timed steps')
     if rank == 0:
         value = n_rays * world * a.steps / dt
         c = CONFIGS[a.config]
@@ -709,6 +723,8 @@ def main():
             # a timed step among them would have run twice
             "split_fallback_steps": int(getattr(eng, "split_fallback_steps", 0)),
         }
+        if a.split_variant:
+            out["config"]["split_variant"] = int(a.split_variant)      # an A/B line of the wave-pair experiment, not the product
         if opt_ms is not None:
             out["optimizer_step"] = {"ms": opt_ms, "parameters": n_params, "kernel": "esr_adam_step (fused Adam, 28 B/param)",
                                      "hbm_gbs": n_params * 28 / (opt_ms * 1e-3) / 1e9,

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libesr_hip.so")
 # developer experiments only (tools/variant.sh builds alternative libraries; tools/ab_env.sh times them side by side on one box)
 LIB_PATH = os.environ.get("ESR_LIB_PATH", LIB_PATH)
-ABI_VERSION = 23
+ABI_VERSION = 24
 _lib = None
 
 
@@ -90,8 +90,7 @@ class EsrWgradJob(C.Structure):
     """esr_wgrad_job_t"""
     _fields_ = [("kind", C.c_int32), ("color_row0", C.c_int32), ("t0", C.c_int32), ("t1", C.c_int32),
                 ("X", C.c_void_p), ("H", C.c_void_p), ("dZ", C.c_void_p), ("dz", C.c_void_p),
-                ("gw", C.c_void_p), ("gb", C.c_void_p), ("X16", C.c_void_p), ("amax", C.c_void_p),
-                ("M_last", C.c_void_p), ("W_last", C.c_void_p)]
+                ("gw", C.c_void_p), ("gb", C.c_void_p), ("X16", C.c_void_p), ("amax", C.c_void_p)]
 
 
 # every exported symbol of include/esr_hip.h (checked by tests/test_host.py::test_library_loads_and_exports_every_header_symbol)

@@ -250,11 +250,6 @@ struct WgradArgs {
     int wg0, nwg;                // workgroups [wg0, wg0 + nwg) of the launch work on this job
     int cfg;                     // kernel shape of this job (layer_cfg) -- read by the unified launch (mlp_wgrad_uni192_kernel)
     const float *amax;           // split-fp16 kernel: max |dz| of the step (device), the source of the gradient operand's scale
-    // last hidden layer, gradient operand NOT read from memory but synthesised per tile: A = mask (.) (W_last^T dz)
-    const float *syn_dz;         // [tiles][zrows][32] output gradients
-    const unsigned *syn_m;       // [tiles][hid/64][64] ReLU masks of the last hidden layer
-    const float *syn_w;          // [out_dim][hid] the output layer's weights (reference layout)
-    int syn_zrows;
 };
 
 // One launch can carry up to MAX_JOBS jobs of the same kernel shape (the same layer of the emissive and the non-emissive
@@ -302,24 +297,16 @@ constexpr int LDS_STRIDE = 36;        // floats per staged row (32 samples + 4 p
 // [row][32] bf16 and a 16-B read IS an 8-sample operand) while the
 // network input X and the output gradient dz are fp32 (rounded on the way from LDS to the operand registers):
 //   1 = output layer (A = dz fp32, B = H bf16), 2 = hidden layer (both bf16), 3 = first layer (A = dZ bf16, B = X fp32).
-// SYN (bf16 hidden layer, the LAST hidden layer of a net): the gradient operand dZ = mask (.) (W_out^T dz) is not read from
-// memory -- the input-gradient pass does not store it -- but synthesised per tile from the 3-row output gradient, the
-// layer's ReLU mask and the output layer's weights, in the arithmetic of the input-gradient kernel's first step (operands
-// rounded to bf16, fp32 sum, result rounded to bf16): 1.3 KB instead of 12 KB per tile read here, 12 KB per tile not
-// written there (-0.6 GB per C3 step).  Each wave makes one or two 32-row blocks of the tile with one
-// MFMA each (a first form computed the values on the vector lanes, 300 instructions per thread and tile: the launch went
-// from 0.36 to 0.41 ms).
-template <int MI, int NJ, int WM, int WN, int WK, int MODE, bool SYN = false>
+template <int MI, int NJ, int WM, int WN, int WK, int MODE>
 __device__ __forceinline__ void wgrad_reg_body(const WgradArgs &W)
 {
     static_assert(MODE >= 1 && MODE <= 3, "f32 operands: mlp_wgrad_dma_kernel");
-    static_assert(!SYN || MODE == 2, "synthesis: the hidden-layer shape of the bf16 engine");
     constexpr bool A16 = MODE == 2 || MODE == 3, B16 = MODE == 1 || MODE == 2;
     constexpr int NW = WM * WN * WK, NT = 64 * NW;
     constexpr int RAP = WM * MI * 32, RBP = WN * NJ * 32;          // staged rows (padded to tiles)
     constexpr int BUF = (RAP + RBP) * LDS_STRIDE;                  // floats per LDS buffer
     constexpr int STRIDE16 = 20;                                   // floats per staged bf16 row (64 B + 16 B pad)
-    constexpr int LA = SYN ? 9 : A16 ? 4 : RAP * 8 / NT, LB = B16 ? 4 : RBP * 8 / NT;       // 16-B loads per thread (bf16: one 64-B unit)
+    constexpr int LA = A16 ? 4 : RAP * 8 / NT, LB = B16 ? 4 : RBP * 8 / NT;       // 16-B loads per thread (bf16: one 64-B unit)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, rl = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -337,18 +324,6 @@ __device__ __forceinline__ void wgrad_reg_body(const WgradArgs &W)
     // to be committed and tile t+2's HBM loads are in flight (two register sets, static names).  With
     // one tile of prefetch the 192x96 and 4x192 layers were latency-bound: their MFMA work per tile
     // (<= 4.6k cycles) is shorter than an HBM round trip under load.
-    // SYN: the B operand of the synthesis MFMA for the wave's two 32-row blocks: the output layer's weights of hidden row
-    // 32 (w + 4 j) + lane % 32 in slots 0..2 of lane half 0
-    bf16x8 syn_b[2];
-    if constexpr (SYN) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = 32 * (w + 4 * j) + rl;
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                syn_b[j][e] = (__bf16)((h == 0 && e < 3 && row < W.RA) ? W.syn_w[e * W.RA + row] : 0.f);
-        }
-    }
     float4 ga[2][LA], gb[2][LB];
     // Staging loads are range-checked BUFFER loads (out-of-range rows of a short operand read as
     // zero): no per-load branches, so the whole step is one basic block and hipcc keeps a COUNTED
@@ -369,25 +344,9 @@ __device__ __forceinline__ void wgrad_reg_body(const WgradArgs &W)
         // bf16 operand (row-quad layout, mlp_common.h: store_tiles_bf16): thread u < rows takes quad u / 4, samples
         // 8 (u % 4) .. + 7 -- four 16-B pieces of 2 samples x 4 rows each, piece k at + 64 k (so that four neighbouring
         // threads read a full 64-byte run per load)
-        if constexpr (SYN) {
-            const rsrc_t SZ = make_rsrc(W.syn_dz + (size_t)tc * W.syn_zrows * 32, live ? (unsigned)W.syn_zrows * 128u : 0u);
-            const rsrc_t SM = make_rsrc(W.syn_m + (size_t)tc * (RAP / 64) * 64, live ? (unsigned)(RAP / 64) * 256u : 0u);
-            // this lane's sample (lane % 32): dz rows 0..2 -- the A operand of the synthesis MFMA
-            ra[0] = make_float4(bload1(SZ, rl * 4, 0), bload1(SZ, rl * 4, 128), bload1(SZ, rl * 4, 256), 0.f);
-            // mask words of this lane's hidden row in the wave's 32-row blocks w and w + 4, at the 16 samples its accumulator
-            // registers hold (four runs of four consecutive samples: word [it >> 1][32 hh + s], csrc/mlp_bf16.hip)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int it = w + 4 * j, hh = (rl >> 2) & 1;
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    ra[1 + 4 * j + g] = bload4(SM, (((it >> 1) * 64 + 32 * hh + 8 * g + 4 * h) * 4), 0);   // (block 6, 7: past the tile, zeros)
-            }
-        } else {
 #pragma unroll
         for (int k = 0; k < LA; ++k)
             ra[k] = A16 ? bload4(SA, (tid >> 2) * 256 + k * 64 + (tid & 3) * 16, 0) : bload4(SA, (tid + k * NT) * 16, 0);
-        }
 #pragma unroll
         for (int k = 0; k < LB; ++k) {
             if (B16) {
@@ -421,46 +380,7 @@ __device__ __forceinline__ void wgrad_reg_body(const WgradArgs &W)
     };
     auto commit = [&](int buf, const float4 (&ra)[LA], const float4 (&rb_)[LB]) {
         float *La = lds + buf * BUF, *Lb = La + RAP * (A16 ? STRIDE16 : LDS_STRIDE);
-        if constexpr (SYN) {
-            // dZ^T[s][u] = sum_c dz[c][s] W_out[c][u] as ONE bf16 MFMA per 32-row block (k = the output channel, slots 0..2 of
-            // lane half 0): accumulator register r of lane (u, h) holds sample acc_row(r, h) of hidden row u -- masked, rounded
-            // to bf16 and written as four 8-byte runs of that row's staged line
-            bf16x8 a8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a8[e] = (__bf16)0.f;
-            if (h == 0) { a8[0] = (__bf16)ra[0].x; a8[1] = (__bf16)ra[0].y; a8[2] = (__bf16)ra[0].z; }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int it = w + 4 * j;
-                if (it < RAP / 32) {
-                    f32x16 d;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) d[r] = 0.f;
-                    d = mfma16(a8, syn_b[j], d);
-                    const int rr = (rl & 3) + 4 * (rl >> 3);
-                    const int bit = 8 * (it & 1) + (rr >> 1) + 16 * (rr & 1);                 // mask_bit16(it, rr)
-                    float *row = La + (32 * it + rl) * STRIDE16 + 2 * h;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 m4 = ra[1 + 4 * j + g];
-                        const unsigned mw[4] = {__float_as_uint(m4.x), __float_as_uint(m4.y), __float_as_uint(m4.z), __float_as_uint(m4.w)};
-                        unsigned pk[2];
-#pragma unroll
-                        for (int e2 = 0; e2 < 2; ++e2) {
-                            float v2[2];
-#pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                const int i4 = 2 * e2 + e;
-                                const int keep = ((int)(mw[i4] << (31 - bit))) >> 31;
-                                v2[e] = __int_as_float(__float_as_int(d[4 * g + i4]) & keep);
-                            }
-                            pk[e2] = __builtin_bit_cast(unsigned short, (__bf16)v2[0]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v2[1]) << 16);
-                        }
-                        *reinterpret_cast<float2 *>(row + 4 * g) = make_float2(__uint_as_float(pk[0]), __uint_as_float(pk[1]));
-                    }
-                }
-            }
-        } else if (A16) {
+        if (A16) {
             quad_rows(La, RAP, ra);
         } else {
 #pragma unroll
@@ -606,22 +526,9 @@ __global__ void __launch_bounds__(64 * WM * WN * WK, 1) mlp_wgrad_kernel(WgradBa
 // converted by ~4 VALU instructions each -- the kernel is HBM-bound with them.
 typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-// two values -> one register of each plane in four instructions: the pair's first halves (v_cvt_pk_f16_f32), the two residuals
-// v - (float)h1 by v_fma_mix_f32 straight from the packed half (exact), their halves.  (hipcc's own code for the C form
-// unpacks the first halves with two more conversions; one asm statement: between two of them it puts an s_nop.)  Used by
-// the synthesising kernel, whose loop has more VALU work than the stored-operand kernels'.
-__device__ __forceinline__ void wg_split2(float v0, float v1, unsigned &p1, unsigned &p2)
-{
-    float d0, d1;
-    asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
-        "v_fma_mix_f32 %2, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %3, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_cvt_pk_f16_f32 %1, %2, %3"
-        : "=&v"(p1), "=v"(p2), "=&v"(d0), "=&v"(d1) : "v"(v0), "v"(v1));
-}
 __device__ __forceinline__ void wg_split8(const float4 &lo, const float4 &hi, float s, wg_f16x8 &p1, wg_f16x8 &p2)
 {
-    // (C form: with wg_split2 here the loop has 13 % fewer instructions and the launch takes the same time -- it waits for HBM)
+    // (C form: an asm form of four instructions per value pair made the loop 13 % shorter and the launch no faster -- it waits for HBM)
     const float v[8] = {lo.x * s, lo.y * s, lo.z * s, lo.w * s, hi.x * s, hi.y * s, hi.z * s, hi.w * s};
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -645,19 +552,12 @@ __device__ __forceinline__ float wg_scale(float amax)
     return ldexpf(1.f, e);
 }
 
-// SYN (with SPLIT, the hidden shape, the LAST hidden layer of a 192-wide net): the gradient operand dZ = mask (.) (W_out^T dz)
-// is not read from memory -- the input-gradient pass does not store it -- but made by the compute waves from the tile's
-// output gradient (512 B), the layer's ReLU mask (768 B; both staged by the loader as two 1-KiB pieces in the A region) and
-// the output layer's weights (fp16 planes in LDS): one split-fp16 MFMA per 32 hidden rows and k-step, whose accumulator
-// layout IS the layout of the weight-gradient MFMA's A operand.  24 KB per tile less to read here and to write there.
-template <int MI, int NJ, int WM, int WN, int WK, bool SPLIT = false, bool SYN = false>
+template <int MI, int NJ, int WM, int WN, int WK, bool SPLIT = false>
 __device__ __forceinline__ void wgrad_dma_body(const WgradArgs &W)
 {
-    static_assert(!SYN || (SPLIT && WK == 1), "synthesis: the split hidden-layer shape");
     constexpr int NW = WM * WN * WK;                 // compute waves (one per SIMD); wave NW is the loader
     constexpr int RAP = WM * MI * 32, RBP = WN * NJ * 32, ROWS = RAP + RBP;
     constexpr int PIECES = ROWS / 8;                 // 1-KiB pieces (8 rows x 128 B) per tile
-    constexpr int NPIECE = SYN ? 2 + RBP / 8 : PIECES;       // pieces the loader actually issues per tile
     static_assert(PIECES <= 60, "the loader counts a whole tile on vmcnt");
     constexpr int BUF = ROWS * 32;                   // floats per LDS buffer
     constexpr int NU = 4 / WK;                       // 8-sample groups per compute wave per tile
@@ -670,18 +570,6 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs &W)
 
     // rows that no DMA ever fills (operands shorter than the staged block) must not hold NaN patterns
     for (int i = tid; i < 3 * BUF; i += 64 * (NW + 1)) lds[i] = 0.f;
-    if constexpr (SYN) {
-        // the output layer's weights as (64 w) fp16 planes behind the tile buffers: [hidden row][plane][8 k-slots, 0..2 used]
-        _Float16 *wp = reinterpret_cast<_Float16 *>(lds + 3 * BUF);
-        for (int i = tid; i < RAP * 16; i += 64 * (NW + 1)) {
-            // lane half 0: k-slots (w1 | w1), half 1: (w2 | 0) -- against the dz operand's (z1 | z2) and (z1 | 0): ONE MFMA
-            // sums z1 w1 + z2 w1 + z1 w2
-            const int row = i >> 4, pl = (i >> 3) & 1, k = i & 7, c = k < 3 ? k : k - 3;
-            const float wv = (k < (pl ? 3 : 6) && row < W.RA) ? 64.f * W.syn_w[c * W.RA + row] : 0.f;
-            const _Float16 h1 = (_Float16)wv;
-            wp[i] = pl == 0 ? h1 : (_Float16)(wv - (float)h1);
-        }
-    }
     __syncthreads();
 
     // Barrier schedule, identical in every wave: one before the first tile, then one in the MIDDLE of every tile.
@@ -701,30 +589,19 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs &W)
                                       live ? (unsigned)W.RA * 128u : 0u);
             const u32x4 SB = raw_rsrc(reinterpret_cast<const char *>(W.B) + (size_t)tc * W.b_tile_rows * 128u,
                                       live ? (unsigned)W.b_tile_rows * 128u : 0u);
-            // SYN: image rows 0..7 = the dz tile (rows past zrows: zeros), rows 8..15 = the mask tile (6 rows of 128 B)
-            const u32x4 SZ = raw_rsrc(reinterpret_cast<const char *>(W.syn_dz) + (size_t)tc * W.syn_zrows * 128u,
-                                      (SYN && live) ? (unsigned)W.syn_zrows * 128u : 0u);
-            const u32x4 SM = raw_rsrc(reinterpret_cast<const char *>(W.syn_m) + (size_t)tc * (RAP / 64) * 256u,
-                                      (SYN && live) ? (unsigned)(RAP / 64) * 256u : 0u);
 #pragma unroll
             for (int p = 0; p < PIECES; ++p) {
                 const int R = 8 * p + (lane >> 3);                       // row of the staged image
                 const int c = (lane & 7) ^ ((R >> 1) & 7);               // source chunk of this LDS slot
                 int row = R;                                             // A rows >= RA fail the range check
                 if (8 * p >= RAP) row = (R - RAP < cw) ? R - RAP + W.crow : R - RAP;   // first layer: colour rows
-                if constexpr (SYN) {
-                    if (p == 0) lds_dma16(SZ, lds0 + (unsigned)(fb * BUF + p * 256) * 4u, R * 128 + c * 16);
-                    else if (p == 1) lds_dma16(SM, lds0 + (unsigned)(fb * BUF + p * 256) * 4u, (R - 8) * 128 + c * 16);
-                    else if (8 * p >= RAP) lds_dma16(SB, lds0 + (unsigned)(fb * BUF + p * 256) * 4u, row * 128 + c * 16);
-                } else {
-                    lds_dma16(8 * p < RAP ? SA : SB, lds0 + (unsigned)(fb * BUF + p * 256) * 4u, row * 128 + c * 16);
-                }
+                lds_dma16(8 * p < RAP ? SA : SB, lds0 + (unsigned)(fb * BUF + p * 256) * 4u, row * 128 + c * 16);
             }
         };
         int t = W.t0 + split;
         load_tile(t, 0);
         load_tile(t + nsplit, 1);
-        __builtin_amdgcn_s_waitcnt(wait_vm(NPIECE));
+        __builtin_amdgcn_s_waitcnt(wait_vm(PIECES));
         __builtin_amdgcn_s_barrier();
         for (int fb = 2; t < W.t1; t += nsplit) {
             __builtin_amdgcn_s_waitcnt(wait_vm(0));
@@ -770,91 +647,25 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs &W)
             hi = *reinterpret_cast<const float4 *>(lds + buf * BUF + row0 + c1);
         };
         float4 ral[MI], rah[MI], rbl[2], rbh[2];
-        // SYN: dZ^T[s][u] = sum_c dz[c][s] W_out[c][u] as split-fp16 MFMAs with k = the output channel (slots 0..2 of lane
-        // half 0): accumulator register r of lane (u, h) holds sample acc_row(r, h) = 4 (2 (r >> 2) + h) + (r & 3) of hidden row
-        // u -- EXACTLY the eight samples per k-step this lane feeds into the weight-gradient MFMAs (k-step ks: registers
-        // 8 ks .. 8 ks + 7).  Operands: (sc dz) planes from the staged dz tile, (64 W_out) planes from LDS (written once at the
-        // kernel's start), both planes in the 16 k-slots of ONE instruction; the result 64 sc dZ is masked with the staged
-        // mask words and cut into the A planes.
-        const int mbit0 = (rl & 3) + 4 * (rl >> 3), mrow0 = 32 * ((rl >> 2) & 1);          // lane part of the mask bit / word index
-        const _Float16 *w3p = reinterpret_cast<const _Float16 *>(lds + 3 * BUF);           // [RAP rows][2 planes][8]
-        float bsum_s[MI];                                      // bias gradients of the synthesised operand, scaled by 64 sc
-#pragma unroll
-        for (int i = 0; i < MI; ++i) bsum_s[i] = 0.f;
         __builtin_amdgcn_s_barrier();
-        if constexpr (!SYN) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) read2(0, 0, a_row + i * 32 * 32, ral[i], rah[i]);
-        }
+        for (int i = 0; i < MI; ++i) read2(0, 0, a_row + i * 32 * 32, ral[i], rah[i]);
         read2(0, 0, b_row, rbl[0], rbh[0]);
         int t = W.t0 + split;
         for (int buf = 0; t < W.t1; t += nsplit) {
             const int nb = buf == 2 ? 0 : buf + 1;
-            wg_f16x8 za;                                       // SYN: (sc dz)^T of sample rl of this tile: k-slots (z1 | z2) / (z1 | 0)
-            if constexpr (SYN) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) za[e] = (_Float16)0.f;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float z = sc * lds[buf * BUF + c * 32 + (((rl >> 2) ^ ((c >> 1) & 7)) * 4) + (rl & 3)];
-                    const _Float16 h1 = (_Float16)z;
-                    za[c] = h1;
-                    za[3 + c] = h == 0 ? (_Float16)(z - (float)h1) : (_Float16)0.f;
-                }
-            }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (ks == KS - 1) __builtin_amdgcn_s_barrier();          // the next tile has landed (see the schedule above)
                 const int nbuf = ks + 1 < KS ? buf : nb, nks = ks + 1 < KS ? ks + 1 : 0;
-                // (SYN: the operand is made here, from the tile in work, not a k-step ahead: the kernel sits at 256 registers)
                 wg_f16x8 a1[MI], a2[MI];
-                if constexpr (SYN) {
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) {
-                        const int it = wm * MI + i, mbit = (it & 1) * 16 + mbit0;
-                        // (read here, a latency before their use: fetched one block ahead they cost 12 registers the kernel does not
-                        //  have -- 15 spills, 0.56 -> 0.63 ms)
-                        const wg_f16x8 wb = __builtin_bit_cast(wg_f16x8, *reinterpret_cast<const float4 *>(w3p + ((it * 32 + rl) * 2 + h) * 8));
-                        f32x16 d;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) d[r] = 0.f;
-                        d = wg_mfma_f16(za, wb, d);
-#pragma unroll
-                        for (int g = 0; g < 2; ++g) {
-                            const int sb = 4 * (4 * ks + 2 * g + h);
-                            const int widx = (it >> 1) * 64 + mrow0 + sb, Rsl = 8 + (widx >> 5);
-                            const float4 m4 = *reinterpret_cast<const float4 *>(lds + buf * BUF + Rsl * 32 + ((((widx >> 2) & 7) ^ ((Rsl >> 1) & 7)) * 4));
-                            const unsigned mw[4] = {__float_as_uint(m4.x), __float_as_uint(m4.y), __float_as_uint(m4.z), __float_as_uint(m4.w)};
-                            float v[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const int keep = ((int)(mw[e] << (31 - mbit))) >> 31;
-                                v[e] = __int_as_float(__float_as_int(d[8 * ks + 4 * g + e]) & keep);                // 64 sc dZ
-                                bsum_s[i] += v[e];
-                                v[e] *= 1.f / 64.f;
-                            }
-                            unsigned q1[2], q2[2];
-                            wg_split2(v[0], v[1], q1[0], q2[0]);
-                            wg_split2(v[2], v[3], q1[1], q2[1]);
-#pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                const f16x2_t x1 = __builtin_bit_cast(f16x2_t, q1[e]), x2 = __builtin_bit_cast(f16x2_t, q2[e]);
-                                a1[i][4 * g + 2 * e] = x1[0]; a1[i][4 * g + 2 * e + 1] = x1[1];
-                                a2[i][4 * g + 2 * e] = x2[0]; a2[i][4 * g + 2 * e + 1] = x2[1];
-                            }
-                        }
-                    }
-                } else {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     bsum[i] += ((ral[i].x + ral[i].y) + (ral[i].z + ral[i].w)) + ((rah[i].x + rah[i].y) + (rah[i].z + rah[i].w));
                     wg_split8(ral[i], rah[i], sc, a1[i], a2[i]);
                 }
-                }
-                if constexpr (!SYN) {
 #pragma unroll
-                    for (int i = 0; i < MI; ++i) read2(nbuf, nks, a_row + i * 32 * 32, ral[i], rah[i]); // (stale but unused after the last tile)
-                }
+                for (int i = 0; i < MI; ++i) read2(nbuf, nks, a_row + i * 32 * 32, ral[i], rah[i]); // (stale but unused after the last tile)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     wg_f16x8 b1, b2;
@@ -871,10 +682,6 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs &W)
                 }
             }
             buf = nb;
-        }
-        if constexpr (SYN) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) bsum[i] = bsum_s[i] * (osc * (1.f / 64.f));
         }
     } else {
     float4 a0[MI], b0[NJ], a1[MI], b1[NJ];
@@ -946,8 +753,8 @@ __global__ void __launch_bounds__(64 * (WM * WN * WK + 1), 1) mlp_wgrad_dma_kern
 // drain, tail) whatever its tile count -- three launches + three reductions per step became one + one.
 // (round 4, end: the 128-wide nets' shapes -- the BRDF / emission jobs of an LTS step -- ride in the same launches: three more
 //  launches + their fill / drain per flush gone)
-enum { UNI_HID192 = 0, UNI_FIRST192 = 1, UNI_OUT192 = 2, UNI_FIRST192_X16 = 3, UNI_HID192_SYN = 4, UNI_HID128 = 5, UNI_FIRST128 = 6,
-       UNI_OUT128 = 7, N_UNI_CFG = 8 };
+enum { UNI_HID192 = 0, UNI_FIRST192 = 1, UNI_OUT192 = 2, UNI_FIRST192_X16 = 3, UNI_HID128 = 4, UNI_FIRST128 = 5, UNI_OUT128 = 6,
+       N_UNI_CFG = 7 };
 __global__ void __launch_bounds__(320, 1) mlp_wgrad_uni192_kernel(WgradBatch WB)
 {
     const WgradArgs W = pick_job(WB);
@@ -964,7 +771,6 @@ __global__ void __launch_bounds__(256, 1) mlp_wgrad_uni192b_kernel(WgradBatch WB
 {
     const WgradArgs W = pick_job(WB);
     if (W.cfg == UNI_HID192) wgrad_reg_body<3, 3, 2, 2, 1, 2>(W);
-    else if (W.cfg == UNI_HID192_SYN) wgrad_reg_body<3, 3, 2, 2, 1, 2, true>(W);
     else if (W.cfg == UNI_FIRST192) wgrad_reg_body<3, 3, 2, 1, 2, 3>(W);
     else if (W.cfg == UNI_FIRST192_X16) wgrad_reg_body<3, 3, 2, 1, 2, 2>(W);
     else if (W.cfg == UNI_HID128) wgrad_reg_body<2, 2, 2, 2, 1, 2>(W);
@@ -982,13 +788,6 @@ __global__ void __launch_bounds__(320, 1) mlp_wgrad_uni192s_kernel(WgradBatch WB
     else if (W.cfg == UNI_FIRST128) wgrad_dma_body<2, 3, 2, 1, 2, true>(W);
     else if (W.cfg == UNI_OUT128) wgrad_dma_body<1, 2, 1, 2, 2, true>(W);
     else wgrad_dma_body<1, 3, 1, 2, 2, true>(W);
-}
-
-// The hidden-layer jobs whose gradient operand is synthesised (wgrad_dma_body<..., SYN>) get a launch of their own: inside the
-// unified kernel their register need (beside the loader wave: 256 per wave) spilled 19 registers and slowed every job of it.
-__global__ void __launch_bounds__(320, 1) mlp_wgrad_syn192s_kernel(WgradBatch WB)
-{
-    wgrad_dma_body<3, 3, 2, 2, 1, true, true>(pick_job(WB));
 }
 
 // gw[e] += sum over the partial slabs of every job of a launch; 32 slabs per thread, groups combined with one atomic
@@ -1179,38 +978,19 @@ int launch_wgrad_any(WgradBatch &B, SlabPool &P)
 // ---- unified launch of the 192-wide f32 jobs --------------------------------------------------------------
 // relative cost of one sample tile per job shape (hidden : first : output), from the per-shape launches' times at C2
 // (4.4 : 2.2 : 0.8 us per tile per workgroup; the output shape is bound by its loader wave, not by matrix work);
-// ESR_WGRAD_COST="h,f,o" overrides (developer knob, read once)
 // The split-fp16 launch is bound by the bytes it streams, not by matrix work: the shares follow the tile sizes
 // (48 : 36 : 25 KB per sample tile; measured at C2: "1,0.85,0.6" 0.466 ms, "1,1,0.6" 0.480-0.489, the f32 table 0.850; C4: 0.954 / 0.986 / -).
-// ESR_WGRAD_COST_SPLIT overrides.
 // variant: 0 = f32 MFMA, 1 = split fp16 planes, 2 = bf16 operands (bytes per tile: hidden 24.6 KB, first layer 18-24 KB,
 // output layer 12.8 KB); the fourth entry is the bf16 first layer on the bf16 input tile
 const double *uni_cost(int variant)
 {
-    // (fifth: bf16 hidden layer with a synthesised dZ: half the bytes, but 1.2x the time per tile; sixth to eighth: the 128-wide
-    //  nets' hidden / first / output shapes -- bytes per tile 0.67 / 0.58 / 0.35 of the 192-wide hidden shape's, MACs 0.44 / 0.33 / 0.03)
-    static double c[3][N_UNI_CFG] = {{1.0, 0.5, 0.2, 0.5, 1.0, 0.45, 0.35, 0.15}, {1.0, 0.8, 0.6, 0.8, 0.75, 0.65, 0.55, 0.4},
-                                     {1.0, 1.0, 0.7, 0.9, 1.2, 0.65, 0.6, 0.45}};
-    static std::atomic<int> done{0};
-    if (!done.load()) {
-        const char *names[3] = {"ESR_WGRAD_COST", "ESR_WGRAD_COST_SPLIT", "ESR_WGRAD_COST_BF16"};
-        for (int k = 0; k < 3; ++k)
-            if (const char *e = std::getenv(names[k])) {
-                double a, b, d;
-                if (std::sscanf(e, "%lf,%lf,%lf", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0) { c[k][0] = a; c[k][1] = b; c[k][2] = d; c[k][3] = b; }
-
-            }
-        if (const char *e5 = std::getenv("ESR_WGRAD_COST_SYN")) { const double v = std::atof(e5); if (v > 0) c[2][4] = v; }
-        if (const char *e8 = std::getenv("ESR_WGRAD_COST_128")) {          // hidden,first,output of the 128-wide nets, every variant
-            double a, b, d;
-            if (std::sscanf(e8, "%lf,%lf,%lf", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0)
-                for (int k = 0; k < 3; ++k) { c[k][UNI_HID128] = a; c[k][UNI_FIRST128] = b; c[k][UNI_OUT128] = d; }
-        }
-        done.store(1);
-    }
+    // (fifth to seventh: the 128-wide nets' hidden / first / output shapes -- bytes per tile 0.67 / 0.58 / 0.35 of the 192-wide
+    //  hidden shape's, MACs 0.44 / 0.33 / 0.03)
+    static const double c[3][N_UNI_CFG] = {{1.0, 0.5, 0.2, 0.5, 0.45, 0.35, 0.15}, {1.0, 0.8, 0.6, 0.8, 0.65, 0.55, 0.4},
+                                     {1.0, 1.0, 0.7, 0.9, 0.65, 0.6, 0.45}};
     return c[variant];
 }
-constexpr int uni_wk(int cfg) { return (cfg == UNI_HID192 || cfg == UNI_HID192_SYN || cfg == UNI_HID128) ? 1 : 2; }      // (both first-layer forms and the output layer: k split in two)
+constexpr int uni_wk(int cfg) { return (cfg == UNI_HID192 || cfg == UNI_HID128) ? 1 : 2; }      // (both first-layer forms and the output layer: k split in two)
 
 // workgroups per job proportional to tiles x cost (every job >= 1, none more than its tiles); slab regions back to back
 int plan_uni(WgradBatch &B, float *scratch, int64_t slab_floats, ReduceArgs &R, int64_t &used_out, int variant)
@@ -1304,23 +1084,6 @@ int launch_wgrad_uni(WgradBatch &B, SlabPool &P)
     return P.launched(R, n);
 }
 
-int launch_wgrad_syn(WgradBatch &B, SlabPool &P)
-{
-    hipStream_t s = P.s;
-    for (int j = 0; j < B.n; ++j)
-        if (B.job[j].RA > 192 || B.job[j].RB > 192) return ESR_ECAP;
-    constexpr size_t lds_bytes = 3 * (size_t)(192 + 192) * 32 * sizeof(float) + 192 * 16 * sizeof(_Float16);   // + the W_out planes
-    static std::atomic<uint64_t> optin{0};
-    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_wgrad_syn192s_kernel), lds_bytes, optin)) return rc;
-    ReduceArgs R;
-    int64_t n = 0;
-    const int grid = P.place([&](float *sc, int64_t fl, ReduceArgs &R_, int64_t &n_) { return plan_batch<1>(B, sc, fl, R_, n_); }, R, n);
-    if (grid < 0) return grid;
-    mlp_wgrad_syn192s_kernel<<<grid, 320, lds_bytes, s>>>(B);
-    ESR_CHECK_LAUNCH();
-    return P.launched(R, n);
-}
-
 // kernel shapes (waves per workgroup wm x wn x wk, always 4 compute waves = 1 per SIMD):
 //   192-wide nets: 192x192 -> 2x2x1, 192x<=96 (first layer) -> 2x1x2, 192x<=64 (tone mapper's first) , zrows x 192 (output) -> 1x2x2
 //   128-wide nets: 128x128 -> 2x2x1, 128x96 -> 2x1x2, 8x128 -> 1x2x2
@@ -1332,38 +1095,13 @@ int layer_cfg(const NetDesc &D, bool first, bool last, int RB)
     return last ? CFG_OUT128 : first ? CFG_FIRST128 : CFG_HID128;
 }
 
-// ESR_WGRAD_UNI=0: one launch per kernel shape as in round 2 (A/B timing)
-bool uni_on()
-{
-    static const bool on = [] { const char *e = std::getenv("ESR_WGRAD_UNI"); return !(e && e[0] == '0'); }();
-    return on;
-}
-
-// ESR_WGRAD_UNI128=0: the 128-wide nets' jobs keep their per-shape launches (A/B timing)
-bool uni128_on()
-{
-    static const bool on = [] { const char *e = std::getenv("ESR_WGRAD_UNI128"); return !(e && e[0] == '0'); }();
-    return on;
-}
-
-// F: 0 = f32 MFMA, 1 = bf16 operands, 2 = f32 operands as split fp16 planes (jobs with esr_wgrad_job_t::amax)
+// Every shape but the tone mapper's narrow first layer (192 x <= 64) rides in the unified launches above (rounds 2-4 kept one
+// launch per shape beside them, behind environment switches).  F: 0 = f32 MFMA, 1 = bf16 operands, 2 = f32 operands as split
+// fp16 planes (jobs with esr_wgrad_job_t::amax)
 template <int F>
-int launch_cfg(int cfg, WgradBatch &B, SlabPool &P)
+int launch_first64(WgradBatch &B, SlabPool &P)
 {
-    constexpr bool BF = F == 1;
-    constexpr int M0 = F == 2 ? 4 : 0;
-    switch (cfg) {
-    case CFG_HID192:      return launch_wgrad_any<3, 3, 2, 2, 1, BF ? 2 : M0>(B, P);
-    case CFG_FIRST192:    return launch_wgrad_any<3, 3, 2, 1, 2, BF ? 3 : M0>(B, P);
-    case CFG_FIRST192_64: return launch_wgrad_any<3, 2, 2, 1, 2, BF ? 3 : M0>(B, P);
-    case CFG_OUT192:      return launch_wgrad_any<1, 3, 1, 2, 2, BF ? 1 : M0>(B, P);
-    case CFG_HID128:      return launch_wgrad_any<2, 2, 2, 2, 1, BF ? 2 : M0>(B, P);
-    case CFG_FIRST128:    return launch_wgrad_any<2, 3, 2, 1, 2, BF ? 3 : M0>(B, P);
-    case CFG_FIRST192_X16:  // first layer of a radiance net whose input tile is bf16 in the row-quad layout: staged like a hidden layer's
-        if constexpr (BF) return launch_wgrad_any<3, 3, 2, 1, 2, 2>(B, P);
-        else return ESR_EINVAL;
-    default:              return launch_wgrad_any<1, 2, 1, 2, 2, BF ? 1 : M0>(B, P);
-    }
+    return launch_wgrad_any<3, 2, 2, 1, 2, F == 1 ? 3 : F == 2 ? 4 : 0>(B, P);
 }
 
 }  // namespace
@@ -1685,17 +1423,14 @@ template <bool BF>
 static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, int64_t scratch_floats, void *stream)
 {
     if (!jobs || n_jobs < 0 || !scratch) return ESR_EINVAL;
-    WgradBatch group[2][N_CFG][4];          // [0]: this call's operand type, [1]: f32 operands as split planes (jobs with amax)
-    int n_group[2][N_CFG] = {};
+    WgradBatch group[2][4];                 // the tone mapper's first layers; [0]: this call's operand type, [1]: f32 operands as split planes (jobs with amax)
+    int n_group[2] = {};
     constexpr int MAX_UNI = 8;
     WgradBatch uni[MAX_UNI];
     bool uni_split[MAX_UNI];
     int n_uni = 0;
-    WgradBatch synb;
-    synb.n = 0;
     for (int v = 0; v < 2; ++v)
-        for (int c = 0; c < N_CFG; ++c)
-            for (int g = 0; g < 4; ++g) group[v][c][g].n = 0;
+        for (int g = 0; g < 4; ++g) group[v][g].n = 0;
     for (int q = 0; q < n_jobs; ++q) {
         const esr_wgrad_job_t &J = jobs[q];
         if (!kind_ok(J.kind) || J.t0 < 0 || J.t1 < J.t0) return ESR_EINVAL;
@@ -1715,12 +1450,7 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
             W.t0 = J.t0; W.t1 = J.t1;
             W.gw = J.gw[l]; W.ld = first ? D.in_dim : hid; W.out_rows = last ? D.out_dim : hid;
             W.kind = J.kind; W.first = first ? 1 : 0; W.gb = J.gb[l];
-            // the last hidden layer's gradient operand synthesised in the kernel (bf16 engine, 192-wide nets): dZ[l] is not read
-            const bool syn = (BF || J.amax) && !first && !last && l == D.n_layers - 2 && hid == 192 && J.M_last && J.W_last && uni_on();
-            if (syn) {
-                W.A = nullptr; W.syn_dz = J.dz; W.syn_m = J.M_last; W.syn_w = J.W_last; W.syn_zrows = D.zrows;
-            }
-            if ((!W.A && !syn) || !W.B || !W.gw || !W.gb) return ESR_EINVAL;
+            if (!W.A || !W.B || !W.gw || !W.gb) return ESR_EINVAL;
             int c = layer_cfg(D, first, last, W.RB);
             if (BF && first && J.X16 && J.kind == ESR_MLP_RADIANCE) {
                 if (J.color_row0 != 0) return ESR_EINVAL;          // (the bf16 tile's alternate colour rows are the forward's only)
@@ -1728,16 +1458,10 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
                 W.RB = 96; W.b_tile_rows = 104;                    // 24 row quads of operand rows, 26 quads (6656 B) per tile
                 c = CFG_FIRST192_X16;
             }
-            const bool uni128 = uni128_on() && (c == CFG_HID128 || c == CFG_FIRST128 || c == CFG_OUT128);
-            if (uni_on() && (c == CFG_HID192 || c == CFG_FIRST192 || c == CFG_OUT192 || (BF && c == CFG_FIRST192_X16) || uni128)) {
-                W.cfg = c == CFG_HID192 ? (syn ? UNI_HID192_SYN : UNI_HID192) : c == CFG_FIRST192 ? UNI_FIRST192 : c == CFG_OUT192 ? UNI_OUT192
+            if (c != CFG_FIRST192_64) {
+                W.cfg = c == CFG_HID192 ? UNI_HID192 : c == CFG_FIRST192 ? UNI_FIRST192 : c == CFG_OUT192 ? UNI_OUT192
                       : c == CFG_HID128 ? UNI_HID128 : c == CFG_FIRST128 ? UNI_FIRST128 : c == CFG_OUT128 ? UNI_OUT128 : UNI_FIRST192_X16;
                 W.amax = BF ? nullptr : J.amax;                    // non-NULL: the split-fp16 kernel (esr_hip.h)
-                if (syn && !BF) {                                  // f32 operands: a launch of its own (mlp_wgrad_syn192s_kernel)
-                    if (synb.n == MAX_JOBS) return ESR_ECAP;
-                    synb.job[synb.n++] = W;
-                    continue;
-                }
                 const bool sp = !BF && J.amax != nullptr;
                 if (n_uni == 0 || uni[n_uni - 1].n == MAX_JOBS || uni_split[n_uni - 1] != sp) {
                     if (n_uni == MAX_UNI) return ESR_ECAP;
@@ -1750,26 +1474,22 @@ static int wgrad_jobs(const esr_wgrad_job_t *jobs, int n_jobs, float *scratch, i
             }
             const int v = (!BF && J.amax) ? 1 : 0;
             W.amax = J.amax;
-            int g = n_group[v][c];
-            if (g == 0 || group[v][c][g - 1].n == MAX_JOBS) {
+            int g = n_group[v];
+            if (g == 0 || group[v][g - 1].n == MAX_JOBS) {
                 if (g == 4) return ESR_ECAP;
-                g = ++n_group[v][c];
+                g = ++n_group[v];
             }
-            WgradBatch &B = group[v][c][g - 1];
+            WgradBatch &B = group[v][g - 1];
             B.job[B.n++] = W;
         }
     }
     SlabPool P(scratch, scratch_floats, esr_stream(stream));
     for (int u = 0; u < n_uni; ++u)
         if (int rc = BF ? launch_wgrad_uni<2>(uni[u], P) : uni_split[u] ? launch_wgrad_uni<1>(uni[u], P) : launch_wgrad_uni<0>(uni[u], P)) return rc;
-    if (synb.n)
-        if (int rc = launch_wgrad_syn(synb, P)) return rc;
-    for (int c = 0; c < N_CFG; ++c) {
-        for (int g = 0; g < n_group[0][c]; ++g)
-            if (int rc = launch_cfg<BF ? 1 : 0>(c, group[0][c][g], P)) return rc;
-        for (int g = 0; g < n_group[1][c]; ++g)
-            if (int rc = launch_cfg<2>(c, group[1][c][g], P)) return rc;
-    }
+    for (int g = 0; g < n_group[0]; ++g)
+        if (int rc = launch_first64<BF ? 1 : 0>(group[0][g], P)) return rc;
+    for (int g = 0; g < n_group[1]; ++g)
+        if (int rc = launch_first64<2>(group[1][g], P)) return rc;
     return P.flush();
 }
 

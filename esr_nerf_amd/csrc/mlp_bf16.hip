@@ -289,17 +289,13 @@ __device__ __forceinline__ void layer_barrier()
 // tile's MFMAs (taking turns on the matrix pipe), then both in a tile's epilogue (taking turns on the vector lanes) -- and
 // the per-SIMD time is the SUM of matrix and vector time.  Holding back the second wave of every SIMD (waves 4-7) by
 // about one tile's products after each barrier puts its MFMAs under the first wave's epilogues and vice versa.
-// skew: units of 64 clocks (s_sleep 1); ESR_SKEW16 overrides (0 = off; A/B timing).
+// skew: units of 64 clocks (s_sleep 1); skew16() below (6 measured best at C3 / C5; 0 = off).
 __device__ __forceinline__ void layer_skew(int wv, int skew)
 {
     if (wv >= SHW / 2)
         for (int i = 0; i < skew; ++i) __builtin_amdgcn_s_sleep(1);
 }
-int skew16()
-{
-    static const int v = [] { const char *e = getenv("ESR_SKEW16"); return e ? atoi(e) : 6; }();
-    return v;
-}
+constexpr int skew16() { return 6; }
 
 template <int KIND>
 __global__ void __launch_bounds__(64 * SHW, 1) mlp_fwd16s_kernel(Fwd16Batch AB)

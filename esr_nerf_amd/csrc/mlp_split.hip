@@ -805,7 +805,7 @@ int launch_split_k(SplitBatch &B, hipStream_t s)
     int dev = 0;
     B.range = (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) ? g_range_flag[dev].load() : nullptr;
     if constexpr (pair_kind(KIND)) {
-        if (g_pair_variant.load()) {
+        if (g_pair_variant.load() & 1) {
             using P = PairSteps<KIND, false>;
             const int grid = share_blocks_split(B.seg, B.nseg, 256);                   // one workgroup of eight waves per CU
             static std::atomic<uint64_t> optin_p{0};
@@ -881,9 +881,10 @@ ESR_API int esr_mlp_split_range_flag(uint32_t *flag)
 }
 
 // Test / timing hook: which kernels run the radiance net's split launches (see g_pair_variant).  Returns the previous value.
+// bit 0: the forward, bit 1: the input gradients on the wave-pair kernels (1 as an argument means both, as before the bits)
 ESR_API int esr_mlp_split_variant(int pair)
 {
-    return g_pair_variant.exchange(pair ? 1 : 0);
+    return g_pair_variant.exchange(pair == 1 ? 3 : (pair & 3));
 }
 
 // The fine stage's three radiance forward passes of a step as ONE launch (esr_mlp_fwd_fine's contract and argument meaning).
@@ -916,7 +917,7 @@ int launch_dsplit_k(DSplitBatch &B, hipStream_t s)
     using S = SplitSteps<KIND, true>;
     int groups[2], total = 0;
     for (int k = 0; k < B.nseg; ++k) { groups[k] = (B.seg[k].t1 - B.seg[k].t0 + SPW - 1) / SPW; total += groups[k]; }
-    const bool pair = pair_kind(KIND) && g_pair_variant.load();                 // (one workgroup of eight waves per CU)
+    const bool pair = pair_kind(KIND) && (g_pair_variant.load() & 2);           // (one workgroup of eight waves per CU)
     const int cap = pair ? 256 : 256 * split_occ(KIND);
     const int grid = total < cap ? total : cap;
     if (B.nseg == 1) { B.seg[0].b0 = 0; B.seg[0].nb = grid; }

@@ -115,7 +115,8 @@ class _LtsRender(torch.autograd.Function):
         ctx.set_materialize_grads(False)         # unused result tensors arrive as None and cost nothing
         ctx.shapes = [tuple(p.shape) for p in mlp_params]
         model.last_counts = dict(eng.prim.counts)
-        return tuple(out[k] for k in OUT_KEYS)
+        # (fresh tensor objects: voxurff._FineRender.forward)
+        return tuple(out[k].detach() for k in OUT_KEYS)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -164,9 +165,10 @@ class _FinetuneRender(torch.autograd.Function):
         ctx.fctx, ctx.model = fctx, model
         ctx.shapes = [tuple(p.shape) for p in emo_params]
         ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(out["lin/pbr/emo_hat"])
         model.last_counts = dict(eng.prim.counts)
-        return out["lin/pbr/emo"], out["lin/pbr/emo_hat"]
+        emo, emo_hat = out["lin/pbr/emo"].detach(), out["lin/pbr/emo_hat"].detach()    # (fresh objects: voxurff._FineRender.forward)
+        ctx.mark_non_differentiable(emo_hat)
+        return emo, emo_hat
 
     @staticmethod
     @torch.autograd.function.once_differentiable

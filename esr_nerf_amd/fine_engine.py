@@ -102,6 +102,39 @@ class _Workspace:
         return self.buf[k]
 
 
+# (module-level classes: a class defined inside the method that returns it is a new TYPE per call -- a type is a reference
+#  cycle of its own, its methods' closures held the engine, and the engine's workspaces then lived until Python's cycle
+#  collector ran: tools/debug/cycle_probe.py)
+class _F32Only:
+    def __init__(self, eng):
+        self.eng = eng
+
+    def __enter__(self):
+        e = self.eng
+        self.keep = (e.split_fwd, e.split_bwd, e.split_wgrad, e.split_tone_wgrad)
+        e.split_fwd = e.split_bwd = e.split_wgrad = e.split_tone_wgrad = False
+
+    def __exit__(self, *exc):
+        e = self.eng
+        e.split_fwd, e.split_bwd, e.split_wgrad, e.split_tone_wgrad = self.keep
+        return False
+
+
+class _PackGroup:
+    def __init__(self, eng):
+        self.eng = eng
+
+    def __enter__(self):
+        self.eng._pack_pending = []
+
+    def __exit__(self, et, ev, tb):
+        eng = self.eng
+        jobs, eng._pack_pending = eng._pack_pending, None
+        if et is None and jobs:
+            eng._pack_flush(jobs)
+        return False
+
+
 class FineEngine:
     def __init__(self, device, mlp_dtype: str = "f32"):
         """``mlp_dtype``: "f32" (f32 matrix cores; BASELINE configs C2, C4) or "bf16" (bf16 MFMA operands with fp32
@@ -218,17 +251,7 @@ class FineEngine:
 
     def f32_only(self):
         """Context manager: every MLP launch inside runs on the f32 MFMA kernels (no range limit), on the same buffers."""
-        eng = self
-
-        class _F32:
-            def __enter__(self_):
-                self_.keep = (eng.split_fwd, eng.split_bwd, eng.split_wgrad, eng.split_tone_wgrad)
-                eng.split_fwd = eng.split_bwd = eng.split_wgrad = eng.split_tone_wgrad = False
-
-            def __exit__(self_, *exc):
-                eng.split_fwd, eng.split_bwd, eng.split_wgrad, eng.split_tone_wgrad = self_.keep
-                return False
-        return _F32()
+        return _F32Only(self)
 
     def _run(self, name, fn, *args):
         """Enqueue one C-ABI call; with timing on, bracket it with HIP events recorded on the
@@ -330,18 +353,7 @@ class FineEngine:
 
     def packing(self):
         """Context manager: the ``pack`` calls inside go out as one launch at exit."""
-        eng = self
-
-        class _Group:
-            def __enter__(self_):
-                eng._pack_pending = []
-
-            def __exit__(self_, et, ev, tb):
-                jobs, eng._pack_pending = eng._pack_pending, None
-                if et is None and jobs:
-                    eng._pack_flush(jobs)
-                return False
-        return _Group()
+        return _PackGroup(self)
 
     def _pack_flush(self, jobs):
         split = [(self.packed_split[which].data_ptr() if (self.split_fwd and kind in self.split_kinds) else 0)

@@ -119,13 +119,39 @@ class _PointDraw:
             ring[slot] = torch.empty(ring[3], dtype=torch.int64, pin_memory=torch.cuda.is_available())
         self._out_t = ring[slot][:k]
         self._job = C.c_void_p(0)
-        _lib.check(_lib.lib().esr_host_choice_start(C.c_void_p(key_addr), C.c_void_p(pos_addr), C.c_int64(n), C.c_int64(k),
-                                                    C.c_void_p(self._out_t.data_ptr()), C.byref(self._job)), "esr_host_choice_start")
+        # numpy's own lock on the generator for the whole start-to-wait window: the worker mutates the MT19937 state in place,
+        # and any other Python thread that draws from np.random meanwhile (a data loader) would race on raw memory
+        self._lock = np.random.mtrand._rand._bit_generator.lock
+        self._lock.acquire()
+        try:
+            _lib.check(_lib.lib().esr_host_choice_start(C.c_void_p(key_addr), C.c_void_p(pos_addr), C.c_int64(n), C.c_int64(k),
+                                                        C.c_void_p(self._out_t.data_ptr()), C.byref(self._job)), "esr_host_choice_start")
+        except Exception:
+            self._job = None
+            self._lock.release()
+            raise
 
     def result(self) -> torch.Tensor:
-        job, self._job = self._job, None
-        _lib.check(_lib.lib().esr_host_choice_wait(job), "esr_host_choice_noreplace")
+        self.close()
         return self._out_t
+
+    def close(self):
+        """Wait for the worker and release numpy's lock (idempotent; also from __del__: an exception between the
+        constructor and result() -- a march overflow in the secondary pass -- must not leave the worker writing numpy's
+        state and the pinned ring buffer behind a dropped object)."""
+        job, self._job = self._job, None
+        if job is None:
+            return
+        try:
+            _lib.check(_lib.lib().esr_host_choice_wait(job), "esr_host_choice_noreplace")
+        finally:
+            self._lock.release()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 _NP_MT = None
@@ -732,7 +758,21 @@ class LtsEngine(FineEngine):
         return out
 
     # ------------------------------------------------------------------ re-lighting fine-tune (A16)
+    def _with_draw_closed(self, fn, *args, **kw):
+        """Run a forward that may start a surface-point draw (self._pd); whatever happens, the draw's worker is waited for
+        and numpy's generator lock released before control leaves the engine (_PointDraw.close)."""
+        self._pd = None
+        try:
+            return fn(*args, **kw)
+        finally:
+            pd, self._pd = self._pd, None
+            if pd is not None:
+                pd.close()
+
     def finetune_forward(self, scene, scene2, batch, grids, cfg, draws=None):
+        return self._with_draw_closed(self._finetune_forward, scene, scene2, batch, grids, cfg, draws)
+
+    def _finetune_forward(self, scene, scene2, batch, grids, cfg, draws=None):
         """``ESRNeRF.forward_finetune`` (esrnerf.py:241-484): the emo net's prediction at ``num_ltspts`` surface
         points (camera + one random direction) against edited emission + reflected emo radiance gathered over
         ``num_2ndrays`` secondary rays.  grids: sdf, emo, brdf, emit (the frozen copy feeding the emission head),
@@ -749,7 +789,7 @@ class LtsEngine(FineEngine):
         if T == 0:
             raise RuntimeError("fine-tune step with no surviving sample (degenerate batch)")
         # the surface-point draw (a full host-side shuffle of range(m3): 1.5 ms at C5) on the worker thread, collected below
-        point_draw = _PointDraw(m3, min(int(cfg["num_ltspts"]), m3), self._draw_ring) if draws is None else None
+        point_draw = self._pd = _PointDraw(m3, min(int(cfg["num_ltspts"]), m3), self._draw_ring) if draws is None else None
         sp = C.byref(scene)
         eg = torch.empty(T * 32, 4, device=dev)
         self._run("expgrad_fwd", L.esr_expgrad_fwd, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(P0.bufs["rec_ray"]),
@@ -837,6 +877,9 @@ class LtsEngine(FineEngine):
 
     # ------------------------------------------------------------------ forward
     def lts_forward(self, scene, scene2, batch, grids, envmap, cfg, draws=None, prelude=None):
+        return self._with_draw_closed(self._lts_forward, scene, scene2, batch, grids, envmap, cfg, draws, prelude)
+
+    def _lts_forward(self, scene, scene2, batch, grids, envmap, cfg, draws=None, prelude=None):
         """grids: dict sdf [X,Y,Z], off/emo/brdf [X,Y,Z,6], mask [mx,my,mz].  cfg: num_2ndrays, num_ltspts,
         normal_eps, emit_eps, pdra.  draws (optional): dict idx, dirs, noise_normal, noise_emit -- when
         absent they are drawn exactly where the reference draws them."""
@@ -866,7 +909,7 @@ class LtsEngine(FineEngine):
         self._features(P0, scene)
         # (handing the draw to the library's worker thread is ~7 us of host time; the draw itself is 0.2-0.4 ms against
         # ~0.6 ms of primary-pass work queued in front of its consumer)
-        point_draw = _PointDraw(m3, min(int(cfg["num_ltspts"]), m3), self._draw_ring) if draws is None else None
+        point_draw = self._pd = _PointDraw(m3, min(int(cfg["num_ltspts"]), m3), self._draw_ring) if draws is None else None
         # exact normals (+ positions) of every surviving sample
         eg = torch.empty(T * 32, 4, device=dev)
         self._run("expgrad_fwd", L.esr_expgrad_fwd, sp, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(P0.bufs["rec_ray"]),
@@ -1104,7 +1147,7 @@ class LtsEngine(FineEngine):
         """Inside ``_lts_backward``: run the grid scatters ``fn`` (march_bwd + feat_bwd of one pass) on the scatter stream, behind
         everything enqueued on the main stream so far.  Nothing on the main stream reads what they write (atomic sums into the
         grid gradients) before ``lts_backward`` joins the stream.  ``which``: 1 = secondary pass, 2 = primary pass
-        (ESR_LTS_SCATTER_STREAM lists the ones that leave the main stream)."""
+        (``self.scatter_streamed`` lists the ones that leave the main stream)."""
         if not (self.overlap_wgrad and which in self.scatter_streamed):
             fn()
             return

@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import _lib, render_utils
 from .fine_engine import DX_ROWS, FineEngine, make_scene
-from .modules import DenseGrid, Gaussian3DConv, GradientConv, MaskCache, _linears, _mlp_stack
+from .modules import DenseGrid, ForwardSwitch, Gaussian3DConv, GradientConv, MaskCache, _linears, _mlp_stack
 
 KIND_COARSE = 4
 XC_ROWS, HID = 72, 128
@@ -219,7 +219,7 @@ class _CoarseRender(torch.autograd.Function):
         ctx.shapes = [tuple(p.shape) for p in mlp_params]
         ctx.set_materialize_grads(False)
         model.last_counts = fctx["counts"]
-        return last, wbg, srgb
+        return last.detach(), wbg.detach(), srgb.detach()      # (fresh objects: voxurff._FineRender.forward)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -236,7 +236,7 @@ class _CoarseRender(torch.autograd.Function):
         return (None, None, g_sdf, g_off.permute(0, 4, 1, 2, 3), g_emo.permute(0, 4, 1, 2, 3), *mg)
 
 
-class VoxurfC(nn.Module):
+class VoxurfC(ForwardSwitch, nn.Module):
     def __init__(self, cfg, near: float, far: float, xyz_min: torch.Tensor, xyz_max: torch.Tensor,
                  mask_xyz_min: torch.Tensor, mask_xyz_max: torch.Tensor, mask_alpha_init: float,
                  mask_density: torch.Tensor, s_val: float):

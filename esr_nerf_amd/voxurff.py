@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from . import render_utils
 from .fine_engine import KIND_RADIANCE, KIND_TONEMAP, FineEngine, make_scene
-from .modules import DenseGrid, GradientConv, MaskCache, RadianceNet, TonemapNet
+from .modules import DenseGrid, ForwardSwitch, GradientConv, MaskCache, RadianceNet, TonemapNet
 
 
 class _FineRender(torch.autograd.Function):
@@ -46,7 +46,10 @@ class _FineRender(torch.autograd.Function):
         ctx.model = model
         ctx.shapes = [tuple(p.shape) for p in mlp_params]
         model.last_counts = fctx.counts
-        return last, srgb, lin
+        # (fresh tensor objects: the engine's context keeps some of these results for the backward, and a result that left
+        #  forward() carries this node as its grad_fn -- node -> ctx -> context -> result -> node would keep the step's buffers alive
+        #  until Python's cycle collector runs)
+        return last.detach(), srgb.detach(), lin.detach()
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -88,7 +91,7 @@ class _SmoothGradTV(torch.autograd.Function):
         return None, grad, None
 
 
-class VoxurfF(nn.Module):
+class VoxurfF(ForwardSwitch, nn.Module):
     def __init__(self, cfg, near: float, far: float, xyz_min: torch.Tensor, xyz_max: torch.Tensor,
                  mask_xyz_min: torch.Tensor, mask_xyz_max: torch.Tensor, mask_alpha_init: float,
                  mask_density: torch.Tensor, s_val: float, num_voxles: int):

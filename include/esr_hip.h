@@ -355,7 +355,9 @@ int64_t esr_mlp_split_gain_offset(int kind);
 int esr_mlp_split_range_flag(uint32_t *flag);
 /* Test / timing hook.  Which kernels run the RADIANCE net's split launches: 0 (default) the one-wave-per-SIMD kernels, 1 the
  * wave-pair kernels (csrc/mlp_pair.h: two waves share a 32-sample tile, K split by k-step parity, partial sums through LDS;
- * two waves per SIMD).  Same contracts, same buffers; results equal to fp32 rounding.  Returns the previous value. */
+ * two waves per SIMD) in both directions, 2 in the input gradients only, 3 (what 1 is stored as) both again -- bit 0 the
+ * forward, bit 1 the input gradients.  Same contracts, same buffers; results equal to fp32 rounding.  Returns the previous
+ * value (0..3). */
 int esr_mlp_split_variant(int pair);
 int esr_mlp_fwd_split(int kind, const float *packed32, const void *planes, const float *X, int32_t t0, int32_t t1,
                       float *const *H, uint32_t *const *M, int save, int color_row0, float *zout, void *stream);
@@ -468,12 +470,6 @@ typedef struct esr_wgrad_job {
      * the same fp32 operands, every value cut into two fp16 planes on its way into the 16-bit matrix cores, fp32
      * accumulation; the gradient operand is scaled by a power of two derived from *amax (csrc/mlp.hip, SPLIT). */
     const float *amax;
-    /* optional (bf16 operands, ESR_MLP_RADIANCE): the ReLU masks of the LAST hidden layer [tiles][3][64] and the output layer's
-     * weights [3][192] (reference layout).  With both set, that layer's gradient operand is synthesised per tile inside the
-     * kernel (mask (.) W_out^T dz, the input-gradient kernel's arithmetic) and dZ[n_layers - 2] is not read: it may be NULL,
-     * and the input-gradient pass may skip storing it (a NULL dZ[l] there). */
-    const uint32_t *M_last;
-    const float *W_last;
 } esr_wgrad_job_t;
 int esr_mlp_wgrad_batch(const esr_wgrad_job_t *jobs, int32_t n_jobs, int bf16_operands, float *scratch,
                         int64_t scratch_floats, void *stream);

@@ -198,6 +198,17 @@ def alpha_of(c: FineConsts, P, pts: Tensor, ray_id: Tensor, viewdirs: Tensor, s_
     return sdf, neus_alpha_interp(sdf, ray_id, s_val)
 
 
+def admit_survivors(m: Tensor, alpha: Tensor, key: Tensor, survivors: Tensor, keep: Optional[dict], name: str) -> Tensor:
+    """Forced decisions, first threshold (``alpha > fastcolor_thres``): a sample the other implementation kept to the END is
+    a candidate here too, whatever this evaluation's alpha says (``keep[name]``: the alphas of the samples admitted that
+    way -- legitimate only ON the threshold, which the tests assert).  The other implementation's candidates that did NOT
+    survive its second threshold are not known; this evaluation's own stay (each changes a transmittance by < 1e-4)."""
+    admitted = torch.isin(key, survivors) & ~m
+    if keep is not None:
+        keep[name] = alpha.detach()[admitted]
+    return m | admitted
+
+
 class _Composite(torch.autograd.Function):
     """alpha -> (weights, alphainv_last) with the reference's early stop, through
     the C oracle (module.py:117-143 semantics)."""
@@ -221,6 +232,10 @@ KNIFE_LOG: Optional[list] = None      # tests may set a list: receives (weight k
 
 
 FLIP_LOG: Optional[list] = None       # tests may set a list: receives one record per forced ReLU layer (see mlp)
+
+
+RECOMPUTE_LOG: Optional[list] = None         # tests: see mlp()
+RECOMPUTE_KINK = 4e-6
 
 
 def mlp(P: Dict[str, Tensor], keys, x: Tensor, knife: Optional[Tensor] = None, force=None) -> Tensor:
@@ -247,6 +262,7 @@ def mlp(P: Dict[str, Tensor], keys, x: Tensor, knife: Optional[Tensor] = None, f
                         KNIFE_LOG.append((k, (x.detach().abs() < 2e-6).nonzero()[:, 1].unique()))
             if force is not None:
                 mask = force[i]
+                pre = x.detach()
                 with torch.no_grad():
                     flip = mask != (x.detach() > 0)
                     if FLIP_LOG is not None:
@@ -258,6 +274,16 @@ def mlp(P: Dict[str, Tensor], keys, x: Tensor, knife: Optional[Tensor] = None, f
                             worst = float(x64[flip[rows]].abs().max())
                         FLIP_LOG.append((k, int(flip.sum()), worst))
                 x = x * mask.to(x.dtype)
+                if RECOMPUTE_LOG is not None and k.startswith("tonemapper."):
+                    # The HIP tone mapper's WEIGHT gradients recompute this layer (csrc/tone_wgrad.hip) instead of reading
+                    # the forward's branches: at a unit within summation noise of its kink the recomputation may take the
+                    # other one.  Logged for the tests: those (row, unit) pairs, their inputs, and (by a hook) the gradient
+                    # arriving at the unit's OUTPUT -- what the row's weight gradient can differ by, exactly.
+                    near = (pre.abs() < RECOMPUTE_KINK).nonzero()
+                    entry = dict(key=k, units=near[:, 1], xin=xin.detach()[near[:, 0]], gh=None)
+                    RECOMPUTE_LOG.append(entry)
+                    if x.requires_grad and near.numel():
+                        x.register_hook(lambda g, e=entry, n=near: e.__setitem__("gh", g[n[:, 0], n[:, 1]].clone()))
             else:
                 x = F.relu(x)
     return x
@@ -307,6 +333,8 @@ def forward_training(P: Dict[str, Tensor], c: FineConsts, batch: Dict[str, Tenso
     sdf, alpha = alpha_of(c, P, pts, ray_id, viewdirs, s_val)
 
     m = alpha > c.fastcolor_thres
+    if force is not None and force.get("survivors") is not None:
+        m = admit_survivors(m, alpha, ray_id * (1 << 20) + step_id, force["survivors"], keep, "alpha_flips")
     alpha, pts, ray_id, step_id, sdf = alpha[m], pts[m], ray_id[m], step_id[m], sdf[m]
     n2 = pts.shape[0]
 

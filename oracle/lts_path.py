@@ -125,13 +125,13 @@ def sg_envmap(P: Dict[str, Tensor], dirs: Tensor) -> Tensor:
     return F.softplus((P["envmap.mus"] * e).sum(-2))
 
 
-def brdf_net(P, x, knife=None):
-    o = torch.sigmoid(fp.mlp(P, [f"brdfnet.{k}" for k in BRDF_KEYS], x, knife))
+def brdf_net(P, x, knife=None, force=None):
+    o = torch.sigmoid(fp.mlp(P, [f"brdfnet.{k}" for k in BRDF_KEYS], x, knife, force))
     return o[:, 0:3], o[:, 3:4], o[:, 4:5]
 
 
-def emit_net(P, x, knife=None):
-    return F.softplus(fp.mlp(P, [f"emitnet.{k}" for k in BRDF_KEYS], x, knife))
+def emit_net(P, x, knife=None, force=None):
+    return F.softplus(fp.mlp(P, [f"emitnet.{k}" for k in BRDF_KEYS], x, knife, force))
 
 
 def _knife(keep, pts):
@@ -189,20 +189,33 @@ def _stencil(c, grid, pts):
 
 def forward_training(P: Dict[str, Tensor], c: fp.FineConsts, batch: Dict[str, Tensor], s_val: float,
                      draws: Draws, normal_eps: float, emit_eps: float, num_2ndrays: int, lts_near: float,
-                     pdra_mode: bool = False, keep: Optional[dict] = None) -> Dict[str, Tensor]:
+                     pdra_mode: bool = False, keep: Optional[dict] = None, force: Optional[dict] = None) -> Dict[str, Tensor]:
+    """``force`` (tests only; oracle/fine_path.py: forward_training): the discrete decisions of another implementation, taken
+    over pass by pass -- "prim_survivors" / "sec_survivors": int64 keys ``ray * 2**20 + step`` of its final survivor sets;
+    "prim": callable (ray_id, step_id, on) -> dict(emo, off, tone, brdf, emit) of ReLU-branch masks in this evaluation's
+    sample order (emo: the on-samples); "pts": dict(off, emo) for the 2 P point rows; "sec": callable (ray_id, step_id) ->
+    dict(off, emo); "eps": dict(emit, brdf) for the perturbed heads' rows."""
+    force = force or {}
     rays_o, rays_d, viewdirs = batch["rays_o"], batch["rays_d"], batch["viewdirs"]
     em_modes, uncert = batch["em_modes"], batch["uncert_masks"]
     prim_counts: list = []
     N, pts, ray_id = _march(P, c, rays_o, rays_d, c.near, s_val, prim_counts)
-    prim_counts.pop()
+    step_id = prim_counts.pop()                               # step ids of the mask-cache survivors
     sdf, expg = sdf_expgrad(c, P["sdf.grid"], pts)
     alpha = _alpha(c, P, pts, ray_id, viewdirs, sdf, s_val)
     m = alpha > c.fastcolor_thres
-    alpha, pts, ray_id, sdf, expg = alpha[m], pts[m], ray_id[m], sdf[m], expg[m]
+    if force.get("prim_survivors") is not None:
+        m = fp.admit_survivors(m, alpha, ray_id * (1 << 20) + step_id, force["prim_survivors"], keep, "alpha_flips")
+    alpha, pts, ray_id, sdf, expg, step_id = alpha[m], pts[m], ray_id[m], sdf[m], expg[m], step_id[m]
     prim_counts.append(int(pts.shape[0]))
     weights, alphainv_last = fp._Composite.apply(alpha, ray_id, N)
     m = weights > c.fastcolor_thres
-    weights, pts, ray_id, sdf, expg = weights[m], pts[m], ray_id[m], sdf[m], expg[m]
+    if force.get("prim_survivors") is not None:
+        m_forced = torch.isin(ray_id * (1 << 20) + step_id, force["prim_survivors"])
+        if keep is not None:
+            keep["threshold_flips"] = weights.detach()[m_forced != m]
+        m = m_forced
+    weights, pts, ray_id, sdf, expg, step_id = weights[m], pts[m], ray_id[m], sdf[m], expg[m], step_id[m]
 
     on = em_modes[ray_id] == 1
     feat, _, nrm = _stencil(c, P["sdf.grid"], pts)
@@ -213,14 +226,16 @@ def forward_training(P: Dict[str, Tensor], c: fp.FineConsts, batch: Dict[str, Te
     lin = torch.zeros_like(pts)
     kn = _knife(keep, pts)
     kn_on = kn[on] if kn is not None else None
-    lin[on] = fp.radiance(P, "emo_rgbnet", torch.cat([fp.sample_grid(P["emo_color.grid"], gpts[on]), common[on]], -1), kn_on)
+    fr = force["prim"](ray_id, step_id, on) if force.get("prim") is not None else {}
+    lin[on] = fp.radiance(P, "emo_rgbnet", torch.cat([fp.sample_grid(P["emo_color.grid"], gpts[on]), common[on]], -1), kn_on,
+                          fr.get("emo"))
     if kn is not None:
         kn[on] = kn_on
-    lin = lin + fp.radiance(P, "off_rgbnet", torch.cat([fp.sample_grid(P["off_color.grid"], gpts), common], -1), kn)
-    rgb = fp.tonemap(P, c, lin, kn)
+    lin = lin + fp.radiance(P, "off_rgbnet", torch.cat([fp.sample_grid(P["off_color.grid"], gpts), common], -1), kn, fr.get("off"))
+    rgb = fp.tonemap(P, c, lin, kn, fr.get("tone"))
     bfeat = torch.cat([xyz_pe, sdf[:, None], feat, nrm], -1)
-    base, rough, metal = brdf_net(P, torch.cat([fp.sample_grid(P["brdf.grid"], gpts), bfeat], -1), kn)
-    emit = emit_net(P, torch.cat([fp.sample_grid(P["emo_color.grid"], gpts), bfeat], -1), kn)
+    base, rough, metal = brdf_net(P, torch.cat([fp.sample_grid(P["brdf.grid"], gpts), bfeat], -1), kn, fr.get("brdf"))
+    emit = emit_net(P, torch.cat([fp.sample_grid(P["emo_color.grid"], gpts), bfeat], -1), kn, fr.get("emit"))
     w = weights.unsqueeze(-1)
     zeros = lambda: torch.zeros(N, 3)
     rgb_m = zeros().index_add(0, ray_id, w * rgb)
@@ -231,7 +246,7 @@ def forward_training(P: Dict[str, Tensor], c: fp.FineConsts, batch: Dict[str, Te
     idx = draws.idx
     lts = light_transport_segment(P, c, pts[idx], viewdirs[ray_id][idx], normal[idx], sdf[idx], base[idx],
                                   rough[idx], metal[idx], emit[idx], uncert[ray_id][idx], draws.dirs,
-                                  s_val, num_2ndrays, lts_near, pdra_mode, keep=keep)
+                                  s_val, num_2ndrays, lts_near, pdra_mode, keep=keep, force=force)
     _, expg_eps = sdf_expgrad(c, P["sdf.grid"], pts + draws.noise_normal * normal_eps)
     pts2 = pts + draws.noise_emit * emit_eps
     gp2 = fp.to_norm(pts2, c.xyz_min, c.xyz_max)
@@ -239,10 +254,11 @@ def forward_training(P: Dict[str, Tensor], c: fp.FineConsts, batch: Dict[str, Te
     feat2, _, nrm2 = _stencil(c, P["sdf.grid"], pts2)
     bfeat2 = torch.cat([_pe(c, pts2), sdf2[:, None], feat2, nrm2], -1)
     kn2 = _knife(keep, pts2)
-    emit2 = emit_net(P, torch.cat([fp.sample_grid(P["emo_color.grid"], gp2), bfeat2], -1), kn2)
-    base2, rough2, metal2 = brdf_net(P, torch.cat([fp.sample_grid(P["brdf.grid"], gp2), bfeat2], -1), kn2)
+    fe = force.get("eps") or {}
+    emit2 = emit_net(P, torch.cat([fp.sample_grid(P["emo_color.grid"], gp2), bfeat2], -1), kn2, fe.get("emit"))
+    base2, rough2, metal2 = brdf_net(P, torch.cat([fp.sample_grid(P["brdf.grid"], gp2), bfeat2], -1), kn2, fe.get("brdf"))
     if keep is not None:
-        keep.update(m3=pts.shape[0], ray_id=ray_id, pts=pts, counts=tuple(prim_counts + [int(pts.shape[0])]))
+        keep.update(m3=pts.shape[0], ray_id=ray_id, step_id=step_id, pts=pts, counts=tuple(prim_counts + [int(pts.shape[0])]))
     return {
         "etc/alphainv_cum": alphainv_last, "etc/white_bg": alphainv_last[..., None],
         "srgb/rgb": rgb_m, "lin/rgb": lin_m,
@@ -255,7 +271,7 @@ def forward_training(P: Dict[str, Tensor], c: fp.FineConsts, batch: Dict[str, Te
 
 
 def light_transport_segment(P, c, pts, viewdirs, normal, sdf, base, rough, metal, emission, umask, raw_dirs,
-                            s_val, R, lts_near, pdra_mode, keep: Optional[dict] = None):
+                            s_val, R, lts_near, pdra_mode, keep: Optional[dict] = None, force: Optional[dict] = None):
     """Outgoing radiance of P surface points predicted by the radiance nets ("off", "emo", for the
     camera direction and one random direction) against the rendering equation evaluated with R
     secondary rays per point ("off_hat", "emo_hat")."""
@@ -270,8 +286,10 @@ def light_transport_segment(P, c, pts, viewdirs, normal, sdf, base, rough, metal
     common = torch.cat([rep(xyz_pe), vpe, rep(sdf[:, None]), rep(feat), rep(nrm)], -1)
     gp = fp.to_norm(pts, c.xyz_min, c.xyz_max)
     knp = _knife(keep, rep(pts))
-    off = fp.radiance(P, "off_rgbnet", torch.cat([rep(fp.sample_grid(P["off_color.grid"], gp)), common], -1), knp)
-    emo = fp.radiance(P, "emo_rgbnet", torch.cat([rep(fp.sample_grid(P["emo_color.grid"], gp)), common], -1), knp)
+    force = force or {}
+    fpt = force.get("pts") or {}
+    off = fp.radiance(P, "off_rgbnet", torch.cat([rep(fp.sample_grid(P["off_color.grid"], gp)), common], -1), knp, fpt.get("off"))
+    emo = fp.radiance(P, "emo_rgbnet", torch.cat([rep(fp.sample_grid(P["emo_color.grid"], gp)), common], -1), knp, fpt.get("emo"))
 
     ex = lambda t: t.view(Pn, 1, -1).expand(Pn, R, t.shape[-1]).flatten(0, 1)
     o2, v2, vr2, n2 = ex(pts), ex(viewdirs), ex(v_rand), ex(normal)
@@ -285,10 +303,18 @@ def light_transport_segment(P, c, pts, viewdirs, normal, sdf, base, rough, metal
     s2 = fp.sample_grid(P["sdf.grid"], fp.to_norm(p2, c.xyz_min, c.xyz_max))[:, 0]
     a2 = _alpha(c, P, p2, rid, d2, s2, s_val) if s2.numel() > 1 else s2.new_zeros(s2.shape)
     m = a2 > c.fastcolor_thres
+    force = force or {}
+    if force.get("sec_survivors") is not None:
+        m = fp.admit_survivors(m, a2, rid * (1 << 20) + sid2, force["sec_survivors"], keep, "sec_alpha_flips")
     a2, p2, rid, s2, sid2 = a2[m], p2[m], rid[m], s2[m], sid2[m]
     sec_counts.append(int(p2.shape[0]))
     w2, last2 = fp._Composite.apply(a2, rid, N2)
     m = w2 > c.fastcolor_thres
+    if force.get("sec_survivors") is not None:
+        m_forced = torch.isin(rid * (1 << 20) + sid2, force["sec_survivors"])
+        if keep is not None:
+            keep["sec_threshold_flips"] = w2.detach()[m_forced != m]
+        m = m_forced
     w2, p2, rid, s2, sid2 = w2[m], p2[m], rid[m], s2[m], sid2[m]
     if keep is not None:
         keep["sec_counts"] = tuple(sec_counts + [int(p2.shape[0])])
@@ -297,8 +323,9 @@ def light_transport_segment(P, c, pts, viewdirs, normal, sdf, base, rough, metal
     feat2 = torch.cat([_pe(c, p2), _view_pe(c, d2)[rid], s2[:, None], f2, nr2], -1)
     g2 = fp.to_norm(p2, c.xyz_min, c.xyz_max)
     kns = _knife(keep, p2)
-    loff = fp.radiance(P, "off_rgbnet", torch.cat([fp.sample_grid(P["off_color.grid"], g2), feat2], -1), kns)
-    lemo = fp.radiance(P, "emo_rgbnet", torch.cat([fp.sample_grid(P["emo_color.grid"], g2), feat2], -1), kns)
+    fs = force["sec"](rid, sid2) if force.get("sec") is not None else {}
+    loff = fp.radiance(P, "off_rgbnet", torch.cat([fp.sample_grid(P["off_color.grid"], g2), feat2], -1), kns, fs.get("off"))
+    lemo = fp.radiance(P, "emo_rgbnet", torch.cat([fp.sample_grid(P["emo_color.grid"], g2), feat2], -1), kns, fs.get("emo"))
     off_m = torch.zeros(N2, 3).index_add(0, rid, w2[:, None] * loff)
     emo_m = torch.zeros(N2, 3).index_add(0, rid, w2[:, None] * lemo)
     env = sg_envmap(P, d2) * last2.unsqueeze(-1)

@@ -682,29 +682,12 @@ def test_mlp_engine_bf16_vs_emulation(kind, tiles, crow):
         assert rel_err(gw[i], gW[i]) < T16, ("gw", i, rel_err(gw[i], gW[i]))
         assert rel_err(gb[i], gB[i]) < T16, ("gb", i, rel_err(gb[i], gB[i]))
     if kind == 0:
-        # round 4: the last hidden layer's dZ synthesised inside the weight-gradient kernel (esr_wgrad_job_t::M_last / W_last)
-        # from dz, that layer's ReLU mask and the output layer's weights -- the tile is neither stored by the input-gradient
-        # pass (a NULL dZ[2]) nor read here; same emulation, same tolerance, and close to the stored-tile launch's result
+        # a NULL dZ[l] in the input-gradient pass: that layer's tile is computed but not stored, everything else is unchanged
         dZn = [torch.zeros(tiles, hid, 32, device="cuda") for _ in range(nl - 1)]
         dXn = torch.full((tiles, 64, 32), 3.0, device="cuda")
         _lib.check(L.esr_mlp_dgrad_bf16(kind, _lib.ptr(packed16), _lib.ptr(dzd), 0, tiles, _lib.ptr_array(Md),
                                         _lib.ptr_array([dZn[0], dZn[1], None]), _lib.ptr(dXn), s), "dgrad16 without dZ[2]")
         assert torch.equal(dXn, dXd) and torch.equal(dZn[0], dZd[0]) and torch.equal(dZn[1], dZd[1])
-        gw2 = [torch.zeros_like(w_).cuda() for w_ in Ws]
-        gb2 = [torch.zeros_like(b_).cuda() for b_ in Bs]
-        Wlast = Ws[nl - 1].detach().cuda().contiguous()
-        jobs = (_lib.EsrWgradJob * 1)()
-        ptrs = [_lib.ptr_array(Hd), _lib.ptr_array([dZn[0], dZn[1], None]), _lib.ptr_array(gw2), _lib.ptr_array(gb2)]
-        jb = jobs[0]
-        jb.kind, jb.color_row0, jb.t0, jb.t1 = kind, crow, 0, tiles
-        jb.X, jb.dz = Xd.data_ptr(), dzd.data_ptr()
-        jb.H, jb.dZ, jb.gw, jb.gb = (C.addressof(p_) for p_ in ptrs)
-        jb.M_last, jb.W_last = Md[nl - 2].data_ptr(), Wlast.data_ptr()
-        _lib.check(L.esr_mlp_wgrad_batch(jobs, 1, 1, _lib.ptr(eng.wgrad_scratch), C.c_int64(eng.wgrad_scratch.numel()), s), "wgrad16 syn")
-        for i in range(nl):
-            assert rel_err(gw2[i], gW[i]) < T16, ("gw syn", i, rel_err(gw2[i], gW[i]))
-            assert rel_err(gb2[i], gB[i]) < T16, ("gb syn", i, rel_err(gb2[i], gB[i]))
-            assert rel_err(gw2[i], gw[i]) < 2e-3, ("gw syn vs stored", i, rel_err(gw2[i], gw[i]))
 
 
 def test_bf16_mode_end_to_end_close_to_fp32_and_psnr():

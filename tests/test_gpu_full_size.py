@@ -46,135 +46,6 @@ def _fine_oracle(m, sc):
     return fp, c, P
 
 
-def _records(counts, rec_ray, rec_step, rec_w):
-    """(ray, step, weight) of the samples a march kept, from its records (padding lanes have ray -1)."""
-    n = (-(-counts["n_on"] // 32) + -(-counts["n_off"] // 32)) * 32
-    ray = rec_ray[:n]
-    ok = ray >= 0
-    return ray[ok].cpu().long(), rec_step[:n][ok].cpu().long(), rec_w[:n][ok].cpu()
-
-
-def _survivors(m):
-    ws = m.engine.ws
-    return _records(m.last_counts, ws["rec_ray"], ws["rec_step"], ws["rec_w"])
-
-
-def _check_survivor_sets(gpu, ray_id, step_id, weights, rays_o, rays_d, c, near, thres=1e-4):
-    """A march's survivor set against the oracle's, sample by sample.  A sample may be in one set only if its weight
-    sits ON the ``> thres`` test.  How close is "on": alpha = (relu(pc - nc) + 1e-5) / (pc + 1e-5) with pc, nc two
-    sigmoids of O(1) -- at alpha ~ 1e-4 the difference pc - nc cancels four digits, so one ulp of expf (device vs
-    glibc) moves alpha, and w = T alpha, by up to ~1e-3 relative: |w - 1e-4| < 2e-7.  Such a sample carries 1e-4 of a
-    ray's colour (invisible at the 1e-4 tolerance of the outputs) but its presence switches its own gradient
-    contribution on or off.  Returns the positions of those samples (their cells are set aside by _compare_grads)."""
-    ray, step, w = gpu
-    key_g, key_o = ray * 100000 + step, ray_id * 100000 + step_id
-    kg, ko = set(key_g.tolist()), set(key_o.tolist())
-    w_gpu = dict(zip(key_g.tolist(), w.tolist()))
-    w_orc = dict(zip(key_o.tolist(), weights.detach().tolist()))
-    odd = sorted(kg ^ ko)
-    for k in odd:
-        wk = w_gpu.get(k, w_orc.get(k))
-        assert abs(wk - thres) < 2e-3 * thres, (k, wk)
-    r = torch.tensor([k // 100000 for k in odd], dtype=torch.long)
-    st = torch.tensor([k % 100000 for k in odd], dtype=torch.float32)
-    # position of (ray, step) with the sampler's formulas (render_utils_kernel.cu:12-35, 58-79, 167-194)
-    o, d = rays_o[r], rays_d[r]
-    v = torch.where(d == 0, torch.full_like(d, 1e-6), d)
-    ta, tb = (c.xyz_max - o) / v, (c.xyz_min - o) / v
-    t_min = torch.minimum(ta, tb).amax(-1).clamp(min=near)
-    pos = o + d * t_min[:, None] + d / d.norm(dim=-1, keepdim=True) * (float(c.stepsize * c.voxel_size) * st)[:, None]
-    return pos
-
-
-KNIFE = 2e-6      # |hidden pre-activation| below which the two summation orders can disagree on a ReLU's branch
-                  # (192 fmaf steps on partial sums of O(0.5): a random walk of ~4e-7; measured flips up to 6e-7)
-
-
-def _mark(mark, i0, dims, offsets):
-    for d in offsets:
-        q = torch.minimum(torch.maximum(i0 + torch.tensor(d), torch.zeros(3, dtype=torch.long)), dims - 1)
-        mark[q[:, 0], q[:, 1], q[:, 2]] = True
-
-
-CORNERS = [(x, y, z) for x in (0, 1) for y in (0, 1) for z in (0, 1)]
-# cells of the SDF grid a sample's 24-tap stencil reads: taps at +-0.5..2 voxels along ONE axis, 8 corners each
-CROSS = sorted({tuple(c[a] + (t if a == ax else 0) for a in range(3)) for ax in range(3) for t in range(-2, 3) for c in CORNERS})
-CUBE1 = [(x, y, z) for x in range(-1, 3) for y in range(-1, 3) for z in range(-1, 3)]      # + the NeuS neighbours' taps
-
-
-def _knife_cells(sets, c, sdf_grid):
-    """Grid cells that receive gradient from a sample with a ReLU unit on its kink (oracle/fine_path.py::mlp records
-    the smallest |hidden pre-activation| of every sample) or from a sample on a survivor threshold (record 0).
-    Colour grids: the 8 corners of the sample's cell; SDF grid: the cells of its 24-tap stencil (+ for threshold
-    samples, whose alpha also reads the neighbouring samples' SDF taps, the surrounding cube)."""
-    dims = torch.tensor([int(v) for v in c.world_size])
-    mark = torch.zeros(tuple(dims.tolist()), dtype=torch.bool)
-    n_knife = n_all = 0
-    for pts, knife in sets:
-        ks = knife < KNIFE
-        n_knife, n_all = n_knife + int(ks.sum()), n_all + knife.numel()
-        i0 = ((pts[ks] - c.xyz_min) / (c.xyz_max - c.xyz_min) * (dims - 1)).floor().long()
-        _mark(mark, i0, dims, CROSS if sdf_grid else CORNERS)
-        thr = knife[ks] == 0
-        if sdf_grid and bool(thr.any()):
-            _mark(mark, i0[thr], dims, CUBE1)
-    return mark, n_knife, n_all
-
-
-def _compare_grads(grads, P, sets, c, n_expected, max_marked=(0.06, 0.12), fp_log=None):
-    """Every gradient against the oracle at 1e-4 rel-to-max-norm.  Network weights are means over ~10^5-10^6 samples
-    and compare as they are.  A DENSE-GRID cell sums the contributions of the one or two samples that touch it, so a
-    sample whose ReLU unit sits on its kink (|pre-activation| < 2e-6, where the MFMA's k-ordered fmaf chain and the
-    oracle's BLAS can land on different sides of 0: ~100 actual flips per step at this size) moves that cell by up to
-    ~1e-2 of the max-norm although every forward value agrees to 1e-6.  Three checks per grid:
-      (a) ALL touched cells, nothing set aside: fewer than 2 in 1000 are beyond 1e-4;
-      (b) cell by cell outside the cells such samples touch (found from the ORACLE's pre-activations, and from the
-          threshold samples of _check_survivor_sets): 1e-4, and those cells must be a small share of the touched ones;
-      (c) the cells set aside stay within 5e-2.
-    ``max_marked`` = (colour grids, SDF grid): measured share of marked cells + 50 % -- C2 / C3: 0.037-0.040 colour,
-    0.080-0.081 SDF; the measured values of every run are printed (pytest -s)."""
-    bad, n = {}, 0
-    for k, v in P.items():
-        if v.grad is None:
-            continue
-        n += 1
-        g, o = grads[k].detach().cpu(), v.grad
-        if not k.endswith(".grid"):
-            e = rel_err(g, o)
-            if not e < TOL:
-                # a hidden unit with a sample on its ReLU kink (fp.KNIFE_LOG, from the ORACLE's pre-activations): that
-                # sample's whole contribution to the unit's weight row / bias switches on or off.  At s_val = 220 a
-                # weight-gradient row is a sum of ~10^5 terms of both signs, one term can be 1e-4 of the max-norm.
-                # Rows beyond 1e-4 must all be such units, and stay within 2e-3.
-                rows = (g - o).abs().reshape(g.shape[0], -1).amax(1) / float(o.abs().max())
-                beyond = set((rows > TOL).nonzero()[:, 0].tolist())
-                kinks = set()
-                for kk, u in (fp_log or []):
-                    if k.startswith(kk + "."):
-                        kinks |= set(u.tolist())
-                if not (beyond and beyond <= kinks and float(rows.max()) < 2e-3):
-                    bad[k] = (e, sorted(beyond), sorted(kinks))
-            continue
-        mark, n_knife, n_all = _knife_cells(sets, c, k == "sdf.grid")
-        assert n_knife < 0.02 * n_all, (n_knife, n_all)
-        err = (g - o).abs().amax(1)[0] / float(o.abs().max())
-        touched = o.abs().amax(1)[0] > 0
-        n_touched = max(1, int(touched.sum()))
-        share = int((mark & touched).sum()) / n_touched
-        # (the BRDF grid only gets gradient at the ~100 surface points of the light-transport estimate: too few cells
-        # for a share to mean anything)
-        assert share < max_marked[k == "sdf.grid"] or n_touched < 5000, (k, share)
-        frac_bad = int((err > TOL).sum()) / n_touched
-        e_out, e_in = float(err[~mark].max()), float(err[mark].max()) if bool(mark.any()) else 0.0
-        # measured values, one line per grid (pytest -s / the captured log): the caps above are these + 50 %
-        print(f"[full-size grads] {k}: touched {n_touched}, marked share {share:.4f} (cap {max_marked[k == 'sdf.grid']}), "
-              f"beyond 1e-4 {frac_bad:.2e} (cap 2e-3), max err outside marks {e_out:.2e}, inside {e_in:.2e}, "
-              f"knife samples {n_knife}/{n_all}")
-        if not (frac_bad < 2e-3 and e_out < TOL and e_in < 5e-2):
-            bad[k] = dict(beyond_tol=frac_bad, outside=e_out, set_aside=e_in, share=share)
-    assert n == n_expected and not bad, str(bad)
-
-
 def _run_fine(m, sc, s_val, white_bg=True):
     from esr_nerf_amd.trainer import FineStep
     b = {k: v.cuda() for k, v in sc.batch.items()}
@@ -183,16 +54,34 @@ def _run_fine(m, sc, s_val, white_bg=True):
     return float(loss), {k: v.clone() for k, v in grads.items()}
 
 
-def _compare_all(grads, P, n_expected):
+def _allowance(log, P):
+    from decisions import recompute_allowance
+    allow, pairs = recompute_allowance(log, {k: v.shape for k, v in P.items()})
+    print(f"[recompute allowance] tone-mapper (sample, unit) pairs within 4e-6 of the kink: {pairs}")
+    return allow
+
+
+def _compare_all(grads, P, n_expected, allow=None):
     """Every gradient at 1e-4 rel-to-max-norm, nothing set aside: for oracle runs that took over the HIP step's discrete
-    decisions (tests/decisions.py) -- both sides then evaluate the same piecewise-linear function on the same piece."""
+    decisions (tests/decisions.py) -- both sides then evaluate the same piecewise-linear function on the same piece.
+    ``allow`` (decisions.recompute_allowance): per-element extra room of the tone mapper's first layer, whose weight
+    gradients the HIP step takes from a RECOMPUTED hidden layer (its branches at a kink need not be the forward's)."""
     bad, n = {}, 0
     for k, v in P.items():
         if v.grad is None:
             continue
         n += 1
-        e = rel_err(grads[k].detach().cpu(), v.grad)
+        g = grads[k].detach().cpu()
+        e = rel_err(g, v.grad)
         if not e < TOL:
+            if allow is not None and k in allow:
+                room = TOL * float(v.grad.abs().max()) + allow[k].reshape(v.grad.shape)
+                over = (g.double() - v.grad.double()).abs() - room
+                rows = sorted(set((over > 0).nonzero()[:, 0].tolist()))
+                print(f"[recompute allowance] {k}: err {e:.2e} before the allowance; elements of {int((allow[k] > 0).sum())} "
+                      f"carry one (largest {float(allow[k].max()):.2e} of max |g| {float(v.grad.abs().max()):.2e}); rows still beyond: {rows}")
+                if not rows:
+                    continue
             bad[k] = e
     assert n == n_expected and not bad, str(bad)
 
@@ -203,14 +92,15 @@ def _oracle_fine(fp, c, P, sc, s_val, white_bg=True, force=None, what=""):
     keep = {}
     if force is not None:
         from decisions import assert_legitimate
-        fp.FLIP_LOG = []
+        fp.FLIP_LOG, fp.RECOMPUTE_LOG = [], []
         try:
             res = fp.forward_training(P, c, sc.batch, s_val, keep=keep, force=force)
             assert_legitimate(keep, fp.FLIP_LOG, what=what)
+            loss, _ = fp.fine_loss(res, sc.batch["rgbs"], white_bg=white_bg)
+            loss.backward()
+            keep["recompute"] = fp.RECOMPUTE_LOG
         finally:
-            fp.FLIP_LOG = None
-        loss, _ = fp.fine_loss(res, sc.batch["rgbs"], white_bg=white_bg)
-        loss.backward()
+            fp.FLIP_LOG = fp.RECOMPUTE_LOG = None
         return {k: v.detach() for k, v in res.items()}, float(loss), keep
     res = fp.forward_training(P, c, sc.batch, s_val, keep=keep)
     loss, _ = fp.fine_loss(res, sc.batch["rgbs"], white_bg=white_bg)
@@ -239,7 +129,7 @@ def test_c2_full_batch_forward_backward_vs_oracle():
     out = m(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=b["em_modes"], s_val=20.0)
     for k in res:
         assert rel_err(out[k], res[k]) < TOL, (k, rel_err(out[k], res[k]))
-    _compare_all(grads, P, 23)
+    _compare_all(grads, P, 23, _allowance(keep["recompute"], P))
 
 
 def test_c3_full_size_fp32_no_white_bg_and_bf16_psnr():
@@ -262,7 +152,7 @@ def test_c3_full_size_fp32_no_white_bg_and_bf16_psnr():
     assert (lc["m0"], lc["m1"], lc["m2"], lc["m3"]) == (n0, n1, n2, n3)
     assert keep.get("threshold_flips") is None or keep["threshold_flips"].numel() <= 3
     assert abs(loss - o_loss) < 1e-5 * max(1.0, abs(o_loss))
-    _compare_all(grads, P, 23)
+    _compare_all(grads, P, 23, _allowance(keep["recompute"], P))
 
     # bf16 MLP operands at the same size: rendered image (forward_evaluate) against the fp32 render
     m16 = _fine_model(sc, "bf16")
@@ -333,28 +223,38 @@ def test_c4_full_size_lts_step_vs_oracle():
     draws = _lts_draws(m3, 100, 256)
     batch = dict(sc.batch, uncert_masks=torch.arange(sc.n_rays) % 3 == 0)
     tr = cfg.app.trainer
-    keep = {}
-    fp.KNIFE_LOG = []
-    ro = lp.forward_training(P, c, batch, s_val, lp.Draws(**draws), tr.normal_eps, tr.emit_eps, 256,
-                             ccfg.app.model.lts_near, pdra_mode=False, keep=keep)
-    fp_log, fp.KNIFE_LOG = fp.KNIFE_LOG, None
-    lo, _ = lp.lts_loss(ro, batch["rgbs"], True, tr.weight_linear, tr.weight_lts, tr.weight_entropy_last,
-                        tr.weight_normal_smooth)
     b = {k: v.cuda() for k, v in batch.items()}
     rg = m(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=b["em_modes"],
            uncert_masks=b["uncert_masks"], s_val=s_val, normal_eps=tr.normal_eps, emit_eps=tr.emit_eps,
            draws={k: v.cuda() for k, v in draws.items()})
+    torch.cuda.synchronize()
+    # The oracle takes over the HIP step's discrete decisions -- the survivor sets of BOTH marches (3.6 M secondary samples:
+    # a sample in one set only sits on the threshold: first sample of a ray, T = 1, alpha = w = 1e-4 (1 +- 1e-5)) and the ReLU
+    # branches of every net in every pass -- each arbitrated in float64 (tests/decisions.py), and EVERYTHING compares at 1e-4.
+    # Round 4 set aside up to 14 % of the colour cells and 36 % of the SDF cells of this case (bounded by 5e-2) and let
+    # weight-gradient rows of kink units pass at 2e-3.
+    from decisions import assert_legitimate, hip_decisions_lts
+    dec = hip_decisions_lts(m)
+    keep = {}
+    fp.FLIP_LOG, fp.RECOMPUTE_LOG = [], []
+    try:
+        ro = lp.forward_training(P, c, batch, s_val, lp.Draws(**draws), tr.normal_eps, tr.emit_eps, 256,
+                                 ccfg.app.model.lts_near, pdra_mode=False, keep=keep, force=dec)
+        n_thr, _ = assert_legitimate(keep, fp.FLIP_LOG, what="C4")
+        recompute_log = fp.RECOMPUTE_LOG
+    finally:
+        fp.FLIP_LOG = fp.RECOMPUTE_LOG = None
+    assert n_thr <= 6
+    lo, _ = lp.lts_loss(ro, batch["rgbs"], True, tr.weight_linear, tr.weight_lts, tr.weight_entropy_last,
+                        tr.weight_normal_smooth)
     # exact survivor counts of BOTH marches
     lc, sec = m.last_counts, m.engine.sec.counts
-    assert (lc["m0"], lc["m1"], lc["m2"], lc["m3"]) == keep["counts"] == k0["counts"]
-    assert (sec["m0"], sec["m1"]) == keep["sec_counts"][:2]
-    # 3.6 M secondary samples: the alpha > 1e-4 / weight > 1e-4 survivors are compared as SETS; a sample in one set
-    # only must sit on the threshold (first sample of a ray, T = 1, alpha = w = 1e-4 (1 +- 1e-5))
-    pb = m.engine.sec.bufs
-    ks = keep["sec"]
-    odd = _check_survivor_sets(_records(sec, pb["rec_ray"], pb["rec_step"], pb["rec_w"]), ks["ray_id"], ks["step_id"],
-                               ks["weights"], ks["rays_o"], ks["rays_d"], c, ccfg.app.model.lts_near)
-    assert abs(sec["m3"] - keep["sec_counts"][3]) <= len(odd) <= 3 and abs(sec["m2"] - keep["sec_counts"][2]) <= len(odd)
+    # (m2, the count behind the FIRST threshold, is the one set the HIP step does not hand over: within the samples taken over)
+    assert (lc["m0"], lc["m1"], lc["m3"]) == (keep["counts"][0], keep["counts"][1], keep["counts"][3])
+    assert abs(lc["m2"] - keep["counts"][2]) <= n_thr
+    assert (lc["m0"], lc["m1"]) == k0["counts"][:2] and abs(lc["m2"] - k0["counts"][2]) <= 3 and abs(lc["m3"] - k0["counts"][3]) <= 3
+    assert (sec["m0"], sec["m1"]) == keep["sec_counts"][:2] and sec["m3"] == keep["sec_counts"][3]
+    assert abs(sec["m2"] - keep["sec_counts"][2]) <= 3
     assert lc["m0"] == 8192 * 128 and lc["m2"] < lc["m1"] and lc["m3"] < lc["m2"] and sec["m0"] > 3_000_000
     bad = {}
     for k in sorted(ro):
@@ -375,9 +275,7 @@ def test_c4_full_size_lts_step_vs_oracle():
 
     with_fixed_subgradient(ro, lo, sgn).backward()
     with_fixed_subgradient(rg, lg, sgn.cuda()).backward()
-    _compare_grads({k: p.grad for k, p in m.named_parameters() if p.grad is not None}, P,
-                   keep["knife_sets"] + [(odd, torch.zeros(len(odd)))], c, 43, max_marked=(0.20, 0.45), fp_log=fp_log)    # C4 at s_val = 220, measured: colour 0.136 / 0.142, SDF 0.362 (few survivors per ray:
-                   # the 24-tap crosses of the kink samples cover a third of the touched cells)
+    _compare_all({k: p.grad for k, p in m.named_parameters() if p.grad is not None}, P, 43, _allowance(recompute_log, P))
 
 
 def test_c5_full_size_pdra_bf16_tracks_fp32_and_finetune_vs_oracle():
@@ -490,7 +388,7 @@ def test_production_size_grid_256_ray_subset_vs_oracle():
     out = m(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=b["em_modes"], s_val=40.0)
     for k in res:
         assert rel_err(out[k], res[k]) < TOL, (k, rel_err(out[k], res[k]))
-    _compare_all(grads, P, 23)
+    _compare_all(grads, P, 23, _allowance(keep["recompute"], P))
     # one fused Adam step at this size (first step from zero moments: update = -lr * g / (|g| + eps) where g != 0)
     lrs = dict(off_color=0.1, off_rgbnet=0.003, emo_color=0.1, emo_rgbnet=0.003, sdf=0.005, tonemapper=0.003)
     opt = create_optimizer_or_freeze_model(m, **lrs)

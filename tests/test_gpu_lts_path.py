@@ -155,8 +155,10 @@ def test_lts_path_vs_oracle_linear_functional(mode, scene_name, n_rays, s_val, m
     hidden-layer gradients.  At ~1000 samples the expected number of such units is ~0.2 per case.
     Round 4: the BRDF / emission nets moved to the split-fp16 kernels (another summation order); the case
     lts-tiny-160-45.0-prune then had such a unit in the emission net (1.8e-3 on that net's first-layer gradients and
-    2.8e-3 on the colour grid feeding it, every result tensor and every other gradient inside the tolerance; with the
-    f32-MFMA kernels, ESR_SPLIT_KINDS=0, the same case passes) and draws its rays with another seed."""
+    2.8e-3 on the colour grid feeding it, every result tensor and every other gradient inside the tolerance) and got another
+    ray seed.  Round 5: every case keeps the same seed and NOTHING is set aside -- the oracle takes over the HIP step's
+    discrete decisions (tests/decisions.py: survivor sets of both marches, ReLU branches of every net in every pass), each
+    decision it would have taken differently is arbitrated in float64, and all results and gradients compare at 1e-4."""
     from esr_nerf_amd.config import lts_cfg
     from esr_nerf_amd.synthetic import init_slab_model, slab_scene
     from oracle import fine_path as fp
@@ -164,8 +166,7 @@ def test_lts_path_vs_oracle_linear_functional(mode, scene_name, n_rays, s_val, m
     R, Pn = 16, 20
     ga, mask = mask.endswith("+ga"), mask.replace("+ga", "")          # +ga: cfg neus_alpha "grad" in both marches
     alpha_mode = "grad" if ga else "interp"
-    ray_seed = 12 if (mode, scene_name, n_rays, mask) == ("lts", "tiny", 160, "prune") else 11
-    sc = slab_scene(scene_name, s_val=s_val, oblique=True, n_rays=n_rays, seed=ray_seed, mask=mask)
+    sc = slab_scene(scene_name, s_val=s_val, oblique=True, n_rays=n_rays, seed=11, mask=mask)
     m, cfg = build_lts_model(sc, num_2ndrays=R, num_ltspts=Pn, neus_alpha=alpha_mode)
     init_slab_model(m, sc, seed=4)
     with torch.no_grad():
@@ -176,24 +177,34 @@ def test_lts_path_vs_oracle_linear_functional(mode, scene_name, n_rays, s_val, m
                        sc.mask_density, sc.near, sc.num_voxels)
     sd = {k: v.detach().cpu().contiguous() for k, v in m.state_dict().items()}
     P = fp.params_from_state_dict(sd)
-    keep = {}
-    fp.forward_training(fp.params_from_state_dict(sd), c, sc.batch, s_val, keep=keep)
-    m3 = keep["counts"][3]
+    keep0 = {}
+    fp.forward_training(fp.params_from_state_dict(sd), c, sc.batch, s_val, keep=keep0)
+    m3 = keep0["counts"][3]
     g = torch.Generator().manual_seed(7)
     draws = dict(idx=torch.randperm(m3, generator=g)[:Pn], dirs=torch.randn(Pn, R + 1, 3, generator=g),
                  noise_normal=torch.randn(m3, 3, generator=g), noise_emit=torch.randn(m3, 3, generator=g))
     um = torch.rand(n_rays, generator=g) < 0.4
     batch = dict(sc.batch, uncert_masks=um)
     tr = cfg.app.trainer
-    ro = lp.forward_training(P, c, batch, s_val, lp.Draws(**draws), tr.normal_eps, tr.emit_eps, R,
-                             ccfg.app.model.lts_near, pdra_mode=(mode == "pdra"))
     b = {k: v.cuda() for k, v in batch.items()}
     rg = m(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=b["em_modes"],
            uncert_masks=b["uncert_masks"], s_val=s_val, normal_eps=tr.normal_eps, emit_eps=tr.emit_eps,
            draws={k: v.cuda() for k, v in draws.items()})
+    torch.cuda.synchronize()
     assert m.last_counts["m3"] == m3
+    from decisions import assert_legitimate, hip_decisions_lts
+    keep = {}
+    fp.FLIP_LOG = []
+    try:
+        ro = lp.forward_training(P, c, batch, s_val, lp.Draws(**draws), tr.normal_eps, tr.emit_eps, R,
+                                 ccfg.app.model.lts_near, pdra_mode=(mode == "pdra"), keep=keep, force=hip_decisions_lts(m))
+        n_thr, _ = assert_legitimate(keep, fp.FLIP_LOG, what=f"lts {mode}/{n_rays}/{mask}")
+    finally:
+        fp.FLIP_LOG = None
     lc = m.last_counts
-    assert (lc["m0"], lc["m1"], lc["m2"], lc["m3"]) == tuple(keep["counts"])
+    assert (lc["m0"], lc["m1"], lc["m3"]) == (keep["counts"][0], keep["counts"][1], keep["counts"][3])
+    assert abs(lc["m2"] - keep["counts"][2]) <= n_thr and abs(lc["m2"] - keep0["counts"][2]) <= n_thr
+    assert tuple(keep0["counts"][:2]) == tuple(keep["counts"][:2]) and abs(keep0["counts"][3] - lc["m3"]) <= n_thr
     if mask == "prune":
         assert lc["m0"] > lc["m1"] > lc["m2"] > lc["m3"] and lc["m1"] < 0.7 * lc["m0"]
     bad = {}
@@ -528,3 +539,50 @@ def test_lts_step_heals_a_range_overflow_in_the_same_step_with_the_same_draws(st
         if not e < 3e-5:                      # (the same f32 kernels on the same data; float-atomic order differs)
             bad[k] = e
     assert not bad, str(bad)
+
+
+@pytest.mark.parametrize("route", ["step", "autograd"])
+def test_a_dropped_model_gives_its_device_memory_back_without_the_cycle_collector(route):
+    """A model + step object that go out of scope free their workspaces at once, by reference count: device memory pressure
+    does not trigger Python's cycle collector, so anything that needs it accumulates (a 140-experiment statistics run of round
+    5 ended in an out-of-memory error with 285 GB held by dead models: ``self.forward = self.forward_training`` stored a
+    bound method on its own instance, and the engine's context managers were classes defined -- a new type, i.e. a new
+    cycle, holding the engine in its methods' closures -- on every call).  With the collector switched off: two steps through
+    the trainer's step object / through the renderer's autograd route (also one in evaluation mode), drop everything, and the
+    allocator is back where it started."""
+    import gc
+    from esr_nerf_amd.synthetic import init_slab_model, slab_scene
+    from esr_nerf_amd.trainer import LtsStep
+    n_rays, s_val = 256, 60.0
+    sc = slab_scene("small", s_val=s_val, oblique=True, n_rays=n_rays, seed=2)
+    b = {k: v.cuda() for k, v in sc.batch.items()}
+    b["uncert_masks"] = (torch.arange(n_rays) % 2 == 0).cuda()
+
+    def run():
+        m, cfg = build_lts_model(sc, num_2ndrays=8, num_ltspts=16)
+        init_slab_model(m, sc, seed=3)
+        tr = cfg.app.trainer
+        if route == "step":
+            with LtsStep(m, tr, stage="lts") as step:
+                for _ in range(2):
+                    step.forward_loss_backward(b, s_val)
+        else:
+            for _ in range(2):
+                res = m(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=b["em_modes"],
+                        uncert_masks=b["uncert_masks"], s_val=s_val, normal_eps=tr.normal_eps, emit_eps=tr.emit_eps)
+                sum(v.sum() for v in res.values() if v.requires_grad).backward()
+            m.s_val = s_val
+            m.eval()
+            m(em_modes=1, pos_rt=torch.eye(3).cuda(), render_pbr=False, chunk_sz=64,
+              **{k: b[k][:64].contiguous() for k in ("rays_o", "rays_d", "viewdirs")})
+        torch.cuda.synchronize()
+    run()                                        # (first use: lazily created per-device objects stay)
+    gc.collect()
+    gc.disable()
+    try:
+        base = torch.cuda.memory_allocated()
+        run()
+        left = torch.cuda.memory_allocated() - base
+    finally:
+        gc.enable()
+    assert left <= 1 << 20, f"{left / 2**20:.1f} MiB still allocated after the model went out of scope"

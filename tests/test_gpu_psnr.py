@@ -81,29 +81,42 @@ def test_pdra_stage_bf16_minus_f32_paired_statistics():
       * tools/psnr_teacher_student.py --stage pdra --seeds-range 64 --noise-floor (profiles/r04_psnr_pdra_64seeds.json):
         bf16 - f32 = +0.042 dB, 95 % CI [-0.152, +0.235]; f32 rerun - f32 = -0.018 dB, CI [-0.155, +0.119];
         256 seeds (profiles/r04_psnr_pdra_256seeds.json): see DESIGN.md section 5.
-      * here, on every GPU test run, 12 seeds x (f32, f32 rerun, bf16): every trained student scores > 27 dB and the mean gain is > 3 dB;
-        the 99.9 % confidence interval of the mean paired difference bf16 - f32 CONTAINS 0 (no systematic loss of quality); the scatter of bf16 - f32 is
-        no more than 2.5x the scatter of two f32 runs of the same seed (measured ratio over 64 seeds: 1.41 -- the operand
-        rounding is a larger initial perturbation than an atomic's summation order, in a system that amplifies both to
-        the same attractor-sized spread); and the mean difference is inside 0.1 dB plus its own standard error band.
-    A bf16 kernel that lost precision costs several dB (the score moves by ~5 dB over training) and fails all three."""
+      * round 5, 512 seeds on the final build (profiles/r05_psnr_pdra.json, asserted by tests/test_psnr_statistics.py on
+        every CPU run): the 95 % CI of the mean paired difference lies inside [-0.1, +0.1] dB.
+      * here, on every GPU test run, 12 seeds x (f32, f32 rerun, bf16), what twelve seeds CAN decide:
+          - per run: every trained student ends above 28 dB (random students start between 21 and 37 dB and the trained
+            ones end between 28.5 and 35 dB: the minimum over the 2 x 256 runs of round 4 is 28.53), and a student that
+            starts below 26 dB gains more than 3 dB (minimum over those 2 x 112 runs: 3.60; a student that happens to
+            start at 35 dB cannot gain, which is why "start + 4 dB" is not a per-run property of this objective);
+          - the mean gain is > 3 dB and mean(bf16) > mean(f32) - 1.5 dB;
+          - the mean paired difference bf16 - f32 is inside 0.1 dB plus the half width of its own 99.9 % interval (the
+            interval meets the bar's [-0.1, +0.1]; with 12 seeds that half width is ~1 dB -- the 512-seed file is what
+            shrinks it to under 0.1), and the interval contains 0 (no systematic loss);
+          - the scatter of bf16 - f32 is no more than 2.5x the scatter of two f32 runs of the same seed (measured ratio
+            over 64 seeds: 1.41 -- the operand rounding is a larger initial perturbation than an atomic's summation
+            order, in a system that amplifies both to the same attractor-sized spread).
+    A bf16 kernel that lost precision costs several dB (the score moves by ~5 dB over training) and fails all of them."""
     steps, seeds = 200, range(12)
-    d16, d32, gains = [], [], []
+    d16, d32, gains, f32s, b16s = [], [], [], [], []
     for seed in seeds:
         ra, _, _ = ts.pdra_experiment("f32", steps=steps, seed=seed)
         rb, _, _ = ts.pdra_experiment("f32", steps=steps, seed=seed)
         rh, _, _ = ts.pdra_experiment("bf16", steps=steps, seed=seed)
         print(f"pdra seed {seed}: f32 {ra[0]:.2f} -> {ra[steps]:.3f} / rerun {rb[steps]:.3f} dB, bf16 -> {rh[steps]:.3f} dB")
         for r in (ra, rb, rh):
-            assert r[steps] > 27.0, r              # (random students START between 24 and 35 dB; trained ones end at 29.5 - 34.5)
+            assert r[steps] > 28.0, r
+            assert r[0] >= 26.0 or r[steps] > r[0] + 3.0, r
         gains.append(ra[steps] - ra[0])
+        f32s.append(ra[steps]); b16s.append(rh[steps])
         d16.append(rh[steps] - ra[steps])
         d32.append(rb[steps] - ra[steps])
     assert float(np.mean(gains)) > 3.0, gains       # the score is sensitive: training moves it by ~5 dB on average
+    assert float(np.mean(b16s)) > float(np.mean(f32s)) - 1.5
     # 99.9 % intervals: with the true mean difference at 0 a 95 % interval would fail one run in twenty by construction
     s16, s32 = ts.paired_stats(d16, conf=0.999), ts.paired_stats(d32, conf=0.999)
     print(f"pdra: bf16 - f32 mean {s16['mean']:+.3f} dB (99.9 % CI {s16['ci95'][0]:+.3f} .. {s16['ci95'][1]:+.3f}, sd {s16['sd']:.3f}); "
           f"f32 rerun - f32 mean {s32['mean']:+.3f} dB (CI {s32['ci95'][0]:+.3f} .. {s32['ci95'][1]:+.3f}, sd {s32['sd']:.3f})")
+    assert abs(s16["mean"]) < BAR_DB + s16["ci95_half_width"], s16
     assert s16["ci95"][0] <= 0.0 <= s16["ci95"][1], s16
     assert s16["sd"] <= 2.5 * max(s32["sd"], 0.3), (s16, s32)
 

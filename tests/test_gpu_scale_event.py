@@ -12,7 +12,7 @@ import pytest
 import torch
 
 from conftest import rel_err
-from test_gpu_fine_path import KNIFE, build_gpu_model, gpu_batch, oracle_for, run_oracle
+from test_gpu_fine_path import build_gpu_model, gpu_batch, oracle_for, run_oracle
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4      # BASELINE.json north_star: 1e-4 rel (to max-norm) fp32
@@ -63,22 +63,17 @@ def test_fine_step_through_scale_volume_grid_event(dtype):
     assert tuple(g_w["sdf.grid"].shape[2:]) == (256, 256, 64) and tuple(g_w["off_color.grid"].shape[1:]) == (6, 256, 256, 64)
     assert step._flat.numel() >= 13 * scaled                         # the flat gradient buffer followed the new grids
     if dtype == "f32":
+        # the oracle takes over the step's discrete decisions (survivor set, ReLU branches), each arbitrated in float64
+        # (tests/decisions.py); rounds 3-4 dropped the rays with a sample on a ReLU kink and re-ran both sides
+        from decisions import assert_legitimate, hip_decisions
+        dec = hip_decisions(m)
         fp, c, P = oracle_for(m, sc2)
-        o_out, o_loss, o_grads, keep = run_oracle(fp, c, P, sc2, s_val)
-        kr = torch.unique(keep["ray_id"][keep["knife"] < KNIFE])      # rays with a sample on a ReLU kink: dropped, both sides re-run
-        if len(kr):
-            n_all = sc2.batch["rays_o"].shape[0]
-            assert len(kr) < 0.2 * n_all, (len(kr), n_all)
-            sel = torch.ones(n_all, dtype=torch.bool)
-            sel[kr] = False
-            sc2.batch = {k: v[sel].contiguous() for k, v in sc2.batch.items()}
-            b2 = gpu_batch(sc2)
-            loss_w, g2 = step.forward_loss_backward(b2, s_val)
-            torch.cuda.synchronize()
-            loss_w, g_w = float(loss_w), {k: v.clone() for k, v in g2.items()}
-            for v in P.values():
-                v.grad = None
-            o_out, o_loss, o_grads, keep = run_oracle(fp, c, P, sc2, s_val)
+        fp.FLIP_LOG = []
+        try:
+            o_out, o_loss, o_grads, keep = run_oracle(fp, c, P, sc2, s_val, force=dec)
+            assert_legitimate(keep, fp.FLIP_LOG, what="scale event")
+        finally:
+            fp.FLIP_LOG = None
         lc = m.last_counts
         assert (lc["m0"], lc["m1"], lc["m2"], lc["m3"]) == tuple(keep["counts"])
         assert lc["m0"] > lc["m1"] >= lc["m2"] >= lc["m3"] > 0

@@ -6,11 +6,10 @@ TAG=${1:-d}; shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
-export ESR_OVERLAP_WGRAD=0
 export GPU_MAX_HW_QUEUES=8
 STEPS=10; WARM=3
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d "$OUT/${TAG}_trace" -o run -- python3 "$ROOT/bench.py" --steps $STEPS --warmup $WARM --no-cpu-baseline --no-optimizer --no-kernel-timing --no-other "$@" > "$OUT/${TAG}_trace.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/${TAG}_trace" -o run -- python3 "$ROOT/bench.py" --steps $STEPS --warmup $WARM --no-cpu-baseline --no-optimizer --no-kernel-timing --serial --no-other "$@" > "$OUT/${TAG}_trace.log" 2>&1
 cd "$ROOT"
 TR=$(find "$OUT/${TAG}_trace" -name "*kernel_trace.csv" | head -1)
 python3 tools/kstats_by_grid.py "$TR" "$OUT/${TAG}_kernel_by_grid.csv" $((STEPS + WARM))

@@ -28,13 +28,67 @@ ap.add_argument("--other", default="bf16", choices=["bf16", "f32mfma"],
                 help="the arithmetic compared with the f32 engine: bf16 MLP operands (default), or f32mfma = the f32 engine with "
                      "every product on the f32 MFMA pipe (ESR_SPLIT_FWD=0) -- then 'f32' is the split-fp16 engine under test")
 ap.add_argument("--seeds-range", type=int, default=None, help="seeds 0 .. N-1 (overrides --seeds)")
+ap.add_argument("--seed-start", type=int, default=0, help="with --seeds-range: seeds START .. N-1 (a long run in several calls)")
+ap.add_argument("--from-log", default=None,
+                help="no runs: rebuild --summary from the per-run lines of this tool's own output (a call that was cut at its time limit)")
+ap.add_argument("--merge", nargs="+", default=None,
+                help="no runs: merge the per-seed scores of these summary files (same stage / steps / other; a seed counted once) "
+                     "into --summary, with the statistics recomputed")
 ap.add_argument("--summary", default=None,
                 help="write paired statistics (bf16 - f32 and, with --noise-floor, f32 rerun - f32: mean, sd, 95 %% CI of the "
                      "mean) and the per-seed scores to this JSON file")
 a = ap.parse_args()
 if a.seeds_range:
-    a.seeds = list(range(a.seeds_range))
+    a.seeds = list(range(a.seed_start, a.seeds_range))
 per_seed = []
+
+
+def summarise(per_seed):
+    out = dict(stage=a.stage, steps=a.steps, seeds=len(per_seed), other=a.other,
+               bf16_minus_f32=ts.paired_stats(r["bf16"] - r["f32"] for r in per_seed),
+               mean_f32=sum(r["f32"] for r in per_seed) / len(per_seed), mean_bf16=sum(r["bf16"] for r in per_seed) / len(per_seed),
+               mean_gain_f32=sum(r["f32"] - r["start"] for r in per_seed) / len(per_seed))
+    if all(r.get("f32_rerun") is not None for r in per_seed):
+        out["f32rerun_minus_f32"] = ts.paired_stats(r["f32_rerun"] - r["f32"] for r in per_seed)
+    return out
+
+
+def write_summary(per_seed, quiet=False):
+    out = summarise(per_seed)
+    if not quiet:
+        print(json.dumps(out), flush=True)
+    if a.summary:
+        out["per_seed"] = per_seed
+        with open(a.summary + ".tmp", "w") as f:
+            json.dump(out, f, indent=1)
+        os.replace(a.summary + ".tmp", a.summary)
+
+
+if a.from_log:
+    # the per-run lines this tool prints ({"stage", "seed", "dtype", "psnr": {step: dB}}; scores rounded to 0.001 dB)
+    runs = {}
+    for line in open(a.from_log):
+        if line.startswith("{") and '"dtype"' in line:
+            r = json.loads(line)
+            a.stage = r["stage"]
+            runs.setdefault(r["seed"], {})[r["dtype"]] = {int(k): v for k, v in r["psnr"].items()}
+    a.steps = max(max(v) for rr in runs.values() for v in rr.values())
+    rows = [dict(seed=k, f32=rr["f32"][a.steps], bf16=rr["bf16"][a.steps],
+                 f32_rerun=rr["f32b"][a.steps] if "f32b" in rr else None, start=rr["f32"][0])
+            for k, rr in sorted(runs.items()) if "f32" in rr and "bf16" in rr]
+    write_summary(rows)
+    sys.exit(0)
+
+if a.merge:
+    seen = {}
+    for path in a.merge:
+        part = json.load(open(path))
+        a.stage, a.steps, a.other = part["stage"], part["steps"], part.get("other", "bf16")
+        for r in part["per_seed"]:
+            seen.setdefault(r["seed"], r)
+    write_summary([seen[k] for k in sorted(seen)])
+    sys.exit(0)
+
 run = dict(fine=ts.fine_experiment, pdra=ts.pdra_experiment, finetune=ts.finetune_experiment)[a.stage]
 ev = sorted({0, a.steps // 4, a.steps // 2, 3 * a.steps // 4, a.steps})
 for seed in a.seeds:
@@ -63,15 +117,5 @@ for seed in a.seeds:
     print(line, flush=True)
     per_seed.append(dict(seed=seed, f32=res["f32"][a.steps], bf16=res["bf16"][a.steps],
                          f32_rerun=res["f32b"][a.steps] if a.noise_floor else None, start=res["f32"][0]))
-if len(per_seed) > 1:
-    out = dict(stage=a.stage, steps=a.steps, seeds=len(per_seed), other=a.other,
-               bf16_minus_f32=ts.paired_stats(r["bf16"] - r["f32"] for r in per_seed),
-               mean_f32=sum(r["f32"] for r in per_seed) / len(per_seed), mean_bf16=sum(r["bf16"] for r in per_seed) / len(per_seed),
-               mean_gain_f32=sum(r["f32"] - r["start"] for r in per_seed) / len(per_seed))
-    if a.noise_floor:
-        out["f32rerun_minus_f32"] = ts.paired_stats(r["f32_rerun"] - r["f32"] for r in per_seed)
-    print(json.dumps({k: v for k, v in out.items()}), flush=True)
-    if a.summary:
-        out["per_seed"] = per_seed
-        with open(a.summary, "w") as f:
-            json.dump(out, f, indent=1)
+    if len(per_seed) > 1:
+        write_summary(per_seed, quiet=seed != a.seeds[-1])      # after every seed: a call cut short keeps what it measured
