@@ -35,3 +35,42 @@ def test_bf16_minus_f32_psnr_is_resolved_inside_the_bar(name, min_seeds):
     # the statistics are those of the per-seed scores in the file
     diffs = [r["bf16"] - r["f32"] for r in d["per_seed"]]
     assert len(diffs) == st["n"] and abs(sum(diffs) / len(diffs) - st["mean"]) < 1e-9
+
+
+def test_statistics_tool_merges_parts_and_rebuilds_a_summary_from_a_cut_call(tmp_path):
+    """tools/psnr_teacher_student.py --merge (several calls' seeds into one file, a seed counted once, statistics recomputed)
+    and --from-log (a call cut at its time limit: the per-run lines it printed) -- how profiles/r05_psnr_*.json were put
+    together from calls that each fit the GPU box's time limit."""
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, "tools", "psnr_teacher_student.py")
+
+    def part(seeds, path):
+        rows = [dict(seed=s, f32=30.0 + 0.1 * s, bf16=30.0 + 0.1 * s + (0.05 if s % 2 else -0.03), f32_rerun=None, start=25.0)
+                for s in seeds]
+        with open(path, "w") as f:
+            json.dump(dict(stage="pdra", steps=200, seeds=len(rows), other="bf16", per_seed=rows), f)
+    a, b, out = tmp_path / "a.json", tmp_path / "b.json", tmp_path / "m.json"
+    part(range(0, 6), a)
+    part(range(4, 10), b)                                   # seeds 4, 5 in both: counted once
+    r = subprocess.run([sys.executable, tool, "--merge", str(a), str(b), "--summary", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.load(open(out))
+    assert d["seeds"] == 10 and [p["seed"] for p in d["per_seed"]] == list(range(10)) and d["stage"] == "pdra" and d["steps"] == 200
+    st = d["bf16_minus_f32"]
+    assert st["n"] == 10 and abs(st["mean"] - 0.01) < 1e-12 and st["ci95"][0] < st["mean"] < st["ci95"][1]
+    assert abs(d["mean_gain_f32"] - (5.0 + 0.45)) < 1e-9
+    log = tmp_path / "run.log"
+    with open(log, "w") as f:
+        f.write("voxel_size 0.1\n")
+        for s in range(3):
+            for tag, v in (("f32", 31.0 + s), ("bf16", 31.25 + s)):
+                f.write(json.dumps(dict(stage="fine", seed=s, dtype=tag, psnr={"0": 24.5, "50": 30.0, "100": v})) + "\n")
+            f.write(f"seed {s}: final PSNR ...\n")
+        f.write(json.dumps(dict(stage="fine", seed=3, dtype="f32", psnr={"0": 24.5, "100": 35.0})) + "\n")     # cut mid-seed
+    out2 = tmp_path / "l.json"
+    r = subprocess.run([sys.executable, tool, "--from-log", str(log), "--summary", str(out2)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.load(open(out2))
+    assert d["stage"] == "fine" and d["steps"] == 100 and d["seeds"] == 3
+    assert abs(d["bf16_minus_f32"]["mean"] - 0.25) < 1e-12 and all(p["start"] == 24.5 for p in d["per_seed"])
