@@ -57,6 +57,29 @@ for dense_above, mode in ((2.0, "sparse"), (0.0, "dense")):
         assert step._sync.last["sent"] >= step._sync.last["union"] > 0 and "overflow" not in step._sync.last
     step.close()                                     # the last step's deferred march-overflow flag: nothing flagged
 
+# the split-fp16 kernels' range fallback is RANK-LOCAL and decided before the exchange: rank 1's flag is raised (as a forward
+# launch of its shard would raise it), rank 1 re-runs its step on the f32 MFMA kernels, rank 0 does not -- both join ONE
+# exchange, and every rank ends with the full-batch gradients
+import warnings
+for mode in ("sparse", "dense"):
+    step = FineStep(m, process_group=dist.group.WORLD)
+    step._sync_mode = mode
+    step.forward_loss_backward(local, sc.s_val, global_rays=n, entropy_owner=(rank == world - 1))
+    before = m.engine.split_fallback_steps
+    if rank == 1:
+        m.engine.range_flag.fill_(1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        loss, g = step.forward_loss_backward(local, sc.s_val, global_rays=n, entropy_owner=(rank == world - 1))
+    torch.cuda.synchronize()
+    assert m.engine.split_fallback_steps - before == (1 if rank == 1 else 0), (rank, m.engine.split_fallback_steps, before)
+    assert int(m.engine.range_flag) == 0 and m.engine.split_fwd
+    assert abs(float(loss) - float(ref_loss)) < 1e-5, (float(loss), float(ref_loss))
+    for k, v in ref.items():
+        e = float((g[k] - v).abs().max() / v.abs().max().clamp_min(1e-30))
+        assert e < 2e-5, ("range fallback on one rank", mode, k, e)
+    step.close()
+
 # a march overflow in the LAST step of a data-parallel run must not be dropped: only rank 1's rays overflow (its scene
 # gets a step bound of 4 -> an LDS capacity of 64 steps, the tilted rays of this scene take up to ~68), the flag travels
 # with the loss all-reduce, and close() raises on EVERY rank
