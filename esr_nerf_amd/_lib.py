@@ -98,6 +98,8 @@ EXPORTS = [
     "esr_abi_version", "esr_build_info",
     "esr_sample_count", "esr_sample_fill", "esr_alpha2weight_fwd", "esr_alpha2weight_bwd",
     "esr_tv_add_grad", "esr_segment_sum",
+    "esr_infer_t_minmax", "esr_infer_n_samples", "esr_infer_ray_start_dir", "esr_sample_ndc_pts", "esr_sample_bg_pts",
+    "esr_maskcache_lookup", "esr_raw2alpha", "esr_raw2alpha_bwd", "esr_tv_add_grad_masked",
     "esr_fine_march_count", "esr_fine_plan_begin", "esr_fine_plan", "esr_fine_plan_totals", "esr_fine_plan_offsets", "esr_fine_march_fill",
     "esr_fine_march_bwd", "esr_fine_march_bwd_rec", "esr_fine_march_cache_floats", "esr_fine_march_count_cached",
     "esr_fine_march_fill_cached", "esr_fine_march_bwd_cached", "esr_fine_march_count_ga", "esr_fine_march_fill_ga", "esr_fine_march_bwd_ga",

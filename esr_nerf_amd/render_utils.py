@@ -122,15 +122,124 @@ def segment_coo(src, index, out=None, dim_size=None, reduce="sum"):
     return out
 
 
-# Exported by the reference's extensions but never called from its Python: asking for one of them
-# gets a message instead of a bare AttributeError.
-_REFERENCE_DEAD_OPS = ("infer_t_minmax", "infer_n_samples", "infer_ray_start_dir", "sample_ndc_pts_on_rays",
-                       "sample_bg_pts_on_rays", "maskcache_lookup", "raw2alpha", "raw2alpha_backward",
-                       "raw2alpha_nonuni", "raw2alpha_nonuni_backward", "total_variation_add_grad_new")
+# ---- exported by the reference's extensions but never called from its Python: same names, argument order
+# and return lists (render_utils.cpp:171-173,175-181, total_variation.cpp:31); elementwise launches of csrc/legacy_ops.hip
+def infer_t_minmax(rays_o, rays_d, xyz_min, xyz_max, near, far):
+    """-> [t_min, t_max]."""
+    for t, n in ((rays_o, "rays_o"), (rays_d, "rays_d"), (xyz_min, "xyz_min"), (xyz_max, "xyz_max")):
+        _chk(t, n, _f32)
+    n = rays_o.shape[0]
+    t_min, t_max = torch.empty(n, dtype=_f32, device=rays_o.device), torch.empty(n, dtype=_f32, device=rays_o.device)
+    _lib.check(_lib.lib().esr_infer_t_minmax(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(xyz_min), _lib.ptr(xyz_max),
+                                             C.c_float(float(near)), C.c_float(float(far)), C.c_int64(n), _lib.ptr(t_min),
+                                             _lib.ptr(t_max), _lib.stream_ptr(rays_o.device)), "esr_infer_t_minmax")
+    return [t_min, t_max]
 
 
-def __getattr__(name):
-    if name in _REFERENCE_DEAD_OPS:
-        raise NotImplementedError(f"{name}: exported by the reference's CUDA extension but never called from its Python "
-                                  "(app/utils/base/functions.py, module.py); not part of the accelerated path")
-    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+def infer_n_samples(rays_d, t_min, t_max, stepdist):
+    for t, n in ((rays_d, "rays_d"), (t_min, "t_min"), (t_max, "t_max")):
+        _chk(t, n, _f32)
+    n = t_min.shape[0]
+    out = torch.empty(n, dtype=_i64, device=t_min.device)
+    _lib.check(_lib.lib().esr_infer_n_samples(_lib.ptr(rays_d), _lib.ptr(t_min), _lib.ptr(t_max), C.c_float(float(stepdist)),
+                                              C.c_int64(n), _lib.ptr(out), _lib.stream_ptr(t_min.device)), "esr_infer_n_samples")
+    return out
+
+
+def infer_ray_start_dir(rays_o, rays_d, t_min):
+    """-> [rays_start, rays_dir]."""
+    for t, n in ((rays_o, "rays_o"), (rays_d, "rays_d"), (t_min, "t_min")):
+        _chk(t, n, _f32)
+    start, dirs = torch.empty_like(rays_o), torch.empty_like(rays_o)
+    _lib.check(_lib.lib().esr_infer_ray_start_dir(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t_min), C.c_int64(rays_o.shape[0]),
+                                                  _lib.ptr(start), _lib.ptr(dirs), _lib.stream_ptr(rays_o.device)),
+               "esr_infer_ray_start_dir")
+    return [start, dirs]
+
+
+def sample_ndc_pts_on_rays(rays_o, rays_d, xyz_min, xyz_max, N_samples):
+    """-> [rays_pts [n, N, 3], mask_outbbox [n, N]]."""
+    for t, n in ((rays_o, "rays_o"), (rays_d, "rays_d"), (xyz_min, "xyz_min"), (xyz_max, "xyz_max")):
+        _chk(t, n, _f32)
+    n, S = rays_o.shape[0], int(N_samples)
+    pts = torch.empty(n, S, 3, dtype=_f32, device=rays_o.device)
+    mask = torch.empty(n, S, dtype=torch.bool, device=rays_o.device)
+    _lib.check(_lib.lib().esr_sample_ndc_pts(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(xyz_min), _lib.ptr(xyz_max),
+                                             C.c_int32(S), C.c_int64(n), _lib.ptr(pts), _lib.ptr(mask),
+                                             _lib.stream_ptr(rays_o.device)), "esr_sample_ndc_pts")
+    return [pts, mask]
+
+
+def sample_bg_pts_on_rays(rays_o, rays_d, t_max, bg_preserve, N_samples):
+    for t, n in ((rays_o, "rays_o"), (rays_d, "rays_d"), (t_max, "t_max")):
+        _chk(t, n, _f32)
+    n, S = rays_o.shape[0], int(N_samples)
+    pts = torch.empty(n, S, 3, dtype=_f32, device=rays_o.device)
+    _lib.check(_lib.lib().esr_sample_bg_pts(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t_max), C.c_float(float(bg_preserve)),
+                                            C.c_int32(S), C.c_int64(n), _lib.ptr(pts), _lib.stream_ptr(rays_o.device)),
+               "esr_sample_bg_pts")
+    return pts
+
+
+def maskcache_lookup(world, xyz, xyz2ijk_scale, xyz2ijk_shift):
+    """world: bool [I, J, K]; xyz [n, 3] -> bool [n] (False outside the volume)."""
+    _chk(world, "world", torch.bool)
+    for t, n in ((xyz, "xyz"), (xyz2ijk_scale, "xyz2ijk_scale"), (xyz2ijk_shift, "xyz2ijk_shift")):
+        _chk(t, n, _f32)
+    out = torch.zeros(xyz.shape[0], dtype=torch.bool, device=xyz.device)
+    _lib.check(_lib.lib().esr_maskcache_lookup(_lib.ptr(world), _lib.ptr(xyz), _lib.ptr(xyz2ijk_scale), _lib.ptr(xyz2ijk_shift),
+                                               C.c_int32(world.shape[0]), C.c_int32(world.shape[1]), C.c_int32(world.shape[2]),
+                                               C.c_int64(xyz.shape[0]), _lib.ptr(out), _lib.stream_ptr(xyz.device)),
+               "esr_maskcache_lookup")
+    return out
+
+
+def _raw2alpha(density, shift, interval, per_point):
+    _chk(density, "density", _f32)
+    if per_point is not None:
+        _chk(per_point, "interval", _f32)
+    e, a = torch.empty_like(density), torch.empty_like(density)
+    _lib.check(_lib.lib().esr_raw2alpha(_lib.ptr(density), C.c_float(float(shift)), C.c_float(float(interval)),
+                                        _lib.ptr(per_point) if per_point is not None else None, C.c_int64(density.shape[0]),
+                                        _lib.ptr(e), _lib.ptr(a), _lib.stream_ptr(density.device)), "esr_raw2alpha")
+    return [e, a]
+
+
+def _raw2alpha_bwd(exp, grad_back, interval, per_point):
+    _chk(exp, "exp", _f32)
+    _chk(grad_back, "grad_back", _f32)
+    if per_point is not None:
+        _chk(per_point, "interval", _f32)
+    g = torch.empty_like(exp)
+    _lib.check(_lib.lib().esr_raw2alpha_bwd(_lib.ptr(exp), _lib.ptr(grad_back), C.c_float(float(interval)),
+                                            _lib.ptr(per_point) if per_point is not None else None, C.c_int64(exp.shape[0]),
+                                            _lib.ptr(g), _lib.stream_ptr(exp.device)), "esr_raw2alpha_bwd")
+    return g
+
+
+def raw2alpha(density, shift, interval):
+    """-> [exp, alpha]."""
+    return _raw2alpha(density, shift, interval, None)
+
+
+def raw2alpha_nonuni(density, shift, interval):
+    """``interval``: a tensor, one value per point."""
+    return _raw2alpha(density, shift, 0.0, interval)
+
+
+def raw2alpha_backward(exp, grad_back, interval):
+    return _raw2alpha_bwd(exp, grad_back, interval, None)
+
+
+def raw2alpha_nonuni_backward(exp, grad_back, interval):
+    return _raw2alpha_bwd(exp, grad_back, 0.0, interval)
+
+
+def total_variation_add_grad_new(param, grad, mask, wx, wy, wz, dense_mode):
+    """In place on ``grad``; ``mask``: a float tensor shaped like ``param``."""
+    for t, n in ((param, "param"), (grad, "grad"), (mask, "mask")):
+        _chk(t, n, _f32)
+    _lib.check(_lib.lib().esr_tv_add_grad_masked(
+        _lib.ptr(param), _lib.ptr(grad), _lib.ptr(mask), C.c_float(float(wx)), C.c_float(float(wy)), C.c_float(float(wz)),
+        C.c_int64(param.shape[2]), C.c_int64(param.shape[3]), C.c_int64(param.shape[4]), C.c_int64(param.numel()),
+        C.c_int(1 if dense_mode else 0), _lib.stream_ptr(param.device)), "esr_tv_add_grad_masked")

@@ -103,6 +103,42 @@ int esr_tv_add_grad(const float *param, float *grad, float wx, float wy, float w
 int esr_segment_sum(const float *src, const int64_t *index, int64_t n, int64_t c,
                     float *out, int64_t n_seg, void *stream);
 
+/*
+ * The ops the two pybind modules EXPORT but the reference's own Python never calls (render_utils.cpp:171-173,175-181,
+ * total_variation.cpp:31).  Not on the accelerated path: one thread per ray / point / cell, the fp32
+ * instantiation of the reference's templates statement by statement (csrc/legacy_ops.hip; float / double mixing where the
+ * reference's literals put it).  Caller-allocated outputs; bool tensors are bytes.
+ */
+/* infer_t_minmax -- render_utils_kernel.cu:12-35,82-103: ray / box range clamped into [near, far] -> t_min, t_max [n_rays]. */
+int esr_infer_t_minmax(const float *rays_o, const float *rays_d, const float *xyz_min, const float *xyz_max,
+                       float near_, float far_, int64_t n_rays, float *t_min, float *t_max, void *stream);
+/* infer_n_samples -- :38-55,105-121: max(ceil((t_max - t_min) |d| / stepdist), 1) -> int64 [n_rays]. */
+int esr_infer_n_samples(const float *rays_d, const float *t_min, const float *t_max, float stepdist, int64_t n_rays,
+                        int64_t *n_samples, void *stream);
+/* infer_ray_start_dir -- :58-79,123-140: o + d t_min and d / |d| -> [n_rays,3] each. */
+int esr_infer_ray_start_dir(const float *rays_o, const float *rays_d, const float *t_min, int64_t n_rays,
+                            float *rays_start, float *rays_dir, void *stream);
+/* sample_ndc_pts_on_rays -- :243-292: o + d step / (N - 1) -> rays_pts [n_rays,N,3], mask_outbbox [n_rays,N]. */
+int esr_sample_ndc_pts(const float *rays_o, const float *rays_d, const float *xyz_min, const float *xyz_max,
+                       int32_t n_samples, int64_t n_rays, float *rays_pts, uint8_t *mask_outbbox, void *stream);
+/* sample_bg_pts_on_rays -- :294-360: inverted-sphere background points -> rays_pts [n_rays,N,3]. */
+int esr_sample_bg_pts(const float *rays_o, const float *rays_d, const float *t_max, float bg_preserve, int32_t n_samples,
+                      int64_t n_rays, float *rays_pts, void *stream);
+/* maskcache_lookup -- :366-423: nearest voxel of a bool volume [sz_i,sz_j,sz_k]; outside reads 0 -> out [n_pts]. */
+int esr_maskcache_lookup(const uint8_t *world, const float *xyz, const float *xyz2ijk_scale, const float *xyz2ijk_shift,
+                         int32_t sz_i, int32_t sz_j, int32_t sz_k, int64_t n_pts, uint8_t *out, void *stream);
+/* raw2alpha / raw2alpha_nonuni -- :431-502: e = exp(density + shift), alpha = 1 - (1 + e)^(-interval) -> exp_d, alpha [n_pts].
+ * interval_per_point != NULL: the _nonuni form (one interval per point; `interval` is ignored). */
+int esr_raw2alpha(const float *density, float shift, float interval, const float *interval_per_point, int64_t n_pts,
+                  float *exp_d, float *alpha, void *stream);
+/* raw2alpha_backward / raw2alpha_nonuni_backward -- :504-575: min(e, 1e10) (1 + e)^(-interval - 1) interval grad_back. */
+int esr_raw2alpha_bwd(const float *exp_d, const float *grad_back, float interval, const float *interval_per_point,
+                      int64_t n_pts, float *grad, void *stream);
+/* total_variation_add_grad_new -- total_variation_kernel.cu:38-66,101-131: every term x mask[cell] mask[neighbour] (mask is a
+ * float tensor like param); wx on the fastest axis, wy, wz on the slowest (the live kernel's wz-twice quirk is NOT in this one). */
+int esr_tv_add_grad_masked(const float *param, float *grad, const float *mask, float wx, float wy, float wz,
+                           int64_t sz_i, int64_t sz_j, int64_t sz_k, int64_t n, int dense_mode, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * B. Fused fine-stage path (VoxurfF.forward_training and its backward).
  * ------------------------------------------------------------------------- */

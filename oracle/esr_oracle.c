@@ -17,6 +17,11 @@
  *   TV add-grad ............. app/utils/base/cuda/total_variation_kernel.cu:13-35,68-98
  *   segment_coo(sum) ........ torch_scatter (third party, not vendored, unpinned);
  *                             call sites app/fine/model/voxurff.py:260-272
+ *   exported but never called by the reference's Python (bottom of this file):
+ *   NDC / background points . app/utils/base/cuda/render_utils_kernel.cu:243-269,301-340
+ *   mask-cache lookup ....... app/utils/base/cuda/render_utils_kernel.cu:366-392
+ *   raw2alpha (+ backward) .. app/utils/base/cuda/render_utils_kernel.cu:431-460,504-530
+ *   masked TV add-grad ...... app/utils/base/cuda/total_variation_kernel.cu:38-66,101-131
  *
  * Pinning: the reference has no tests or golden vectors.  This
  * file is pinned by plugging it into the *imported* reference Python models in
@@ -219,4 +224,123 @@ ESR_API void esr_oracle_segment_sum(const float *src, const int64_t *index, int6
 {
     for (int64_t i = 0; i < n; ++i)
         for (int64_t a = 0; a < c; ++a) out[index[i] * c + a] += src[i * c + a];
+}
+
+/* ---- the exported-but-dead ops of the two pybind modules ----------------
+ * fp32 instantiations, statement by statement; float / double mixing exactly where the reference's literals put it.
+ * No reference caller, test or golden vector exists for these: pinned by independent torch restatements of the formulas
+ * (tests/test_oracle_native.py), incl. the "original pytorch implementation" the background sampler's source quotes. */
+
+ESR_API void esr_oracle_infer_n_samples(const float *rays_d, const float *t_min, const float *t_max, float stepdist,
+                                        int64_t n_rays, int64_t *n_samples)
+{
+    for (int64_t r = 0; r < n_rays; ++r) {
+        float len = (t_max[r] - t_min[r]) * ray_norm(rays_d + 3 * r) / stepdist;
+        double c = (double)ceilf(len);
+        n_samples[r] = (int64_t)(c > 1.0 ? c : 1.0);
+    }
+}
+
+ESR_API void esr_oracle_infer_ray_start_dir(const float *rays_o, const float *rays_d, const float *t_min, int64_t n_rays,
+                                            float *rays_start, float *rays_dir)
+{
+    for (int64_t r = 0; r < n_rays; ++r) {
+        const float *o = rays_o + 3 * r, *d = rays_d + 3 * r;
+        const float nrm = ray_norm(d);
+        for (int a = 0; a < 3; ++a) {
+            rays_start[3 * r + a] = o[a] + d[a] * t_min[r];
+            rays_dir[3 * r + a] = d[a] / nrm;
+        }
+    }
+}
+
+ESR_API void esr_oracle_sample_ndc_pts(const float *rays_o, const float *rays_d, const float *xyz_min, const float *xyz_max,
+                                       int n_samples, int64_t n_rays, float *rays_pts, uint8_t *mask_outbbox)
+{
+    for (int64_t r = 0; r < n_rays; ++r)
+        for (int s = 0; s < n_samples; ++s) {
+            const int64_t idx = r * n_samples + s;
+            const float dist = ((float)s) / (float)(n_samples - 1);
+            int out = 0;
+            for (int a = 0; a < 3; ++a) {
+                const float p = rays_o[3 * r + a] + rays_d[3 * r + a] * dist;
+                rays_pts[3 * idx + a] = p;
+                out |= (xyz_min[a] > p) | (xyz_max[a] < p);
+            }
+            mask_outbbox[idx] = (uint8_t)out;
+        }
+}
+
+ESR_API void esr_oracle_sample_bg_pts(const float *rays_o, const float *rays_d, const float *t_max, float bg_preserve,
+                                      int n_samples, int64_t n_rays, float *rays_pts)
+{
+    for (int64_t r = 0; r < n_rays; ++r)
+        for (int s = 0; s < n_samples; ++s) {
+            const int64_t idx = r * n_samples + s;
+            const float frac = ((float)s) / (float)n_samples;
+            const float t_o = (float)(((double)t_max[r] - 1.) + 1. / (1. - (double)frac));
+            float q[3];
+            for (int a = 0; a < 3; ++a) q[a] = rays_o[3 * r + a] + rays_d[3 * r + a] * t_o;
+            const float t_outer = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+            const float m = fmaxf(fabsf(q[0]), fmaxf(fabsf(q[1]), fabsf(q[2])));
+            const float R = t_outer / m;
+            const float a1 = R * R / (t_outer * t_outer), a2 = R / t_outer * bg_preserve;
+            const float o2i = (float)((double)a1 * (1. - (double)bg_preserve) + (double)a2);
+            for (int a = 0; a < 3; ++a) rays_pts[3 * idx + a] = q[a] * o2i;
+        }
+}
+
+ESR_API void esr_oracle_maskcache_lookup(const uint8_t *world, const float *xyz, const float *scale, const float *shift,
+                                         int sz_i, int sz_j, int sz_k, int64_t n_pts, uint8_t *out)
+{
+    for (int64_t p = 0; p < n_pts; ++p) {
+        const int i = (int)roundf(xyz[3 * p] * scale[0] + shift[0]);
+        const int j = (int)roundf(xyz[3 * p + 1] * scale[1] + shift[1]);
+        const int k = (int)roundf(xyz[3 * p + 2] * scale[2] + shift[2]);
+        const int in = 0 <= i && i < sz_i && 0 <= j && j < sz_j && 0 <= k && k < sz_k;
+        out[p] = in ? world[((int64_t)i * sz_j + j) * sz_k + k] : 0;      /* (the reference's output starts as zeros) */
+    }
+}
+
+/* interval_t != NULL: one interval per point (raw2alpha_nonuni) */
+ESR_API void esr_oracle_raw2alpha(const float *density, float shift, float interval, const float *interval_t, int64_t n_pts,
+                                  float *exp_d, float *alpha)
+{
+    for (int64_t p = 0; p < n_pts; ++p) {
+        const float e = expf(density[p] + shift);
+        const float iv = interval_t ? interval_t[p] : interval;
+        exp_d[p] = e;
+        alpha[p] = 1.f - powf(1.f + e, -iv);
+    }
+}
+
+ESR_API void esr_oracle_raw2alpha_bwd(const float *exp_d, const float *grad_back, float interval, const float *interval_t,
+                                      int64_t n_pts, float *grad)
+{
+    for (int64_t p = 0; p < n_pts; ++p) {
+        const float e = exp_d[p];
+        const float iv = interval_t ? interval_t[p] : interval;
+        const double lim = (double)e < 1e10 ? (double)e : 1e10;          /* min(float, 1e10): the double overload */
+        grad[p] = (float)(lim * (double)powf(1.f + e, -iv - 1.f) * (double)iv * (double)grad_back[p]);
+    }
+}
+
+/* total_variation_add_grad_new: wx on the fastest axis (the live kernel uses wz there), every term x mask[cell] mask[nbr] */
+ESR_API void esr_oracle_tv_add_grad_masked(const float *param, float *grad, const float *mask, float wx, float wy, float wz,
+                                           int64_t sz_i, int64_t sz_j, int64_t sz_k, int64_t n, int dense_mode)
+{
+    wx /= 6; wy /= 6; wz /= 6;
+    for (int64_t idx = 0; idx < n; ++idx) {
+        if (!dense_mode && grad[idx] == 0.f) continue;
+        const int64_t k = idx % sz_k, j = idx / sz_k % sz_j, i = idx / sz_k / sz_j % sz_i;
+        const float p = param[idx], m = mask[idx];
+        float g = 0.f;
+        g += (k == 0)        ? 0.f : wx * clamp1(p - param[idx - 1]) * m * mask[idx - 1];
+        g += (k == sz_k - 1) ? 0.f : wx * clamp1(p - param[idx + 1]) * m * mask[idx + 1];
+        g += (j == 0)        ? 0.f : wy * clamp1(p - param[idx - sz_k]) * m * mask[idx - sz_k];
+        g += (j == sz_j - 1) ? 0.f : wy * clamp1(p - param[idx + sz_k]) * m * mask[idx + sz_k];
+        g += (i == 0)        ? 0.f : wz * clamp1(p - param[idx - sz_k * sz_j]) * m * mask[idx - sz_k * sz_j];
+        g += (i == sz_i - 1) ? 0.f : wz * clamp1(p - param[idx + sz_k * sz_j]) * m * mask[idx + sz_k * sz_j];
+        grad[idx] += g;
+    }
 }

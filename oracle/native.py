@@ -132,6 +132,114 @@ def segment_sum(src, index, out):
     return out
 
 
+# ---- the exported-but-never-called ops of the two modules (render_utils.cpp:171-173,175-181, total_variation.cpp:31) ----
+def infer_t_minmax(rays_o, rays_d, xyz_min, xyz_max, near, far):
+    """-> [t_min, t_max] (render_utils_kernel.cu:12-35,82-103)."""
+    rays_o, rays_d, xyz_min, xyz_max = _f32(rays_o), _f32(rays_d), _f32(xyz_min), _f32(xyz_max)
+    n = rays_o.shape[0]
+    t_min, t_max = torch.empty(n, dtype=torch.float32), torch.empty(n, dtype=torch.float32)
+    unused = torch.empty(n, dtype=torch.int64)             # (the step counts of that statement, at stepdist 1: not returned)
+    lib().esr_oracle_sample_count(_p(rays_o), _p(rays_d), _p(xyz_min), _p(xyz_max), ctypes.c_float(float(near)),
+                                  ctypes.c_float(float(far)), ctypes.c_float(1.0), ctypes.c_int64(n), _p(t_min), _p(t_max),
+                                  _p(unused))
+    return [t_min, t_max]
+
+
+def infer_n_samples(rays_d, t_min, t_max, stepdist):
+    """-> int64 [n_rays] (render_utils_kernel.cu:38-55,105-121)."""
+    rays_d, t_min, t_max = _f32(rays_d), _f32(t_min), _f32(t_max)
+    n = torch.empty(t_min.shape[0], dtype=torch.int64)
+    lib().esr_oracle_infer_n_samples(_p(rays_d), _p(t_min), _p(t_max), ctypes.c_float(float(stepdist)),
+                                     ctypes.c_int64(t_min.shape[0]), _p(n))
+    return n
+
+
+def infer_ray_start_dir(rays_o, rays_d, t_min):
+    """-> [rays_start, rays_dir] (render_utils_kernel.cu:58-79)."""
+    rays_o, rays_d, t_min = _f32(rays_o), _f32(rays_d), _f32(t_min)
+    start, dirs = torch.empty_like(rays_o), torch.empty_like(rays_o)
+    lib().esr_oracle_infer_ray_start_dir(_p(rays_o), _p(rays_d), _p(t_min), ctypes.c_int64(rays_o.shape[0]), _p(start), _p(dirs))
+    return [start, dirs]
+
+
+def sample_ndc_pts_on_rays(rays_o, rays_d, xyz_min, xyz_max, n_samples):
+    """-> [rays_pts [n, S, 3], mask_outbbox [n, S]] (render_utils_kernel.cu:243-292)."""
+    rays_o, rays_d, xyz_min, xyz_max = _f32(rays_o), _f32(rays_d), _f32(xyz_min), _f32(xyz_max)
+    n, S = rays_o.shape[0], int(n_samples)
+    pts = torch.empty(n, S, 3, dtype=torch.float32)
+    mask = torch.empty(n, S, dtype=torch.uint8)
+    lib().esr_oracle_sample_ndc_pts(_p(rays_o), _p(rays_d), _p(xyz_min), _p(xyz_max), ctypes.c_int(S), ctypes.c_int64(n),
+                                    _p(pts), _p(mask))
+    return [pts, mask.bool()]
+
+
+def sample_bg_pts_on_rays(rays_o, rays_d, t_max, bg_preserve, n_samples):
+    """-> rays_pts [n, S, 3] (render_utils_kernel.cu:294-360)."""
+    rays_o, rays_d, t_max = _f32(rays_o), _f32(rays_d), _f32(t_max)
+    n, S = rays_o.shape[0], int(n_samples)
+    pts = torch.empty(n, S, 3, dtype=torch.float32)
+    lib().esr_oracle_sample_bg_pts(_p(rays_o), _p(rays_d), _p(t_max), ctypes.c_float(float(bg_preserve)), ctypes.c_int(S),
+                                   ctypes.c_int64(n), _p(pts))
+    return pts
+
+
+def maskcache_lookup(world, xyz, xyz2ijk_scale, xyz2ijk_shift):
+    """-> bool [n_pts] (render_utils_kernel.cu:366-423)."""
+    w = world.to(torch.uint8).contiguous()
+    xyz, sc, sh = _f32(xyz), _f32(xyz2ijk_scale), _f32(xyz2ijk_shift)
+    out = torch.zeros(xyz.shape[0], dtype=torch.uint8)
+    lib().esr_oracle_maskcache_lookup(_p(w), _p(xyz), _p(sc), _p(sh), ctypes.c_int(w.shape[0]), ctypes.c_int(w.shape[1]),
+                                      ctypes.c_int(w.shape[2]), ctypes.c_int64(xyz.shape[0]), _p(out))
+    return out.bool()
+
+
+def _raw2alpha(density, shift, interval, interval_t):
+    density = _f32(density)
+    e, a = torch.empty_like(density), torch.empty_like(density)
+    it = _f32(interval_t) if interval_t is not None else None
+    lib().esr_oracle_raw2alpha(_p(density), ctypes.c_float(float(shift)), ctypes.c_float(float(interval)),
+                               _p(it) if it is not None else None, ctypes.c_int64(density.shape[0]), _p(e), _p(a))
+    return [e, a]
+
+
+def _raw2alpha_bwd(exp_d, grad_back, interval, interval_t):
+    exp_d, grad_back = _f32(exp_d), _f32(grad_back)
+    g = torch.empty_like(exp_d)
+    it = _f32(interval_t) if interval_t is not None else None
+    lib().esr_oracle_raw2alpha_bwd(_p(exp_d), _p(grad_back), ctypes.c_float(float(interval)), _p(it) if it is not None else None,
+                                   ctypes.c_int64(exp_d.shape[0]), _p(g))
+    return g
+
+
+def raw2alpha(density, shift, interval):
+    """-> [exp, alpha] (render_utils_kernel.cu:431-443,462-482)."""
+    return _raw2alpha(density, shift, interval, None)
+
+
+def raw2alpha_nonuni(density, shift, interval):
+    return _raw2alpha(density, shift, 0.0, interval)
+
+
+def raw2alpha_backward(exp_d, grad_back, interval):
+    """-> grad (render_utils_kernel.cu:504-515,532-552)."""
+    return _raw2alpha_bwd(exp_d, grad_back, interval, None)
+
+
+def raw2alpha_nonuni_backward(exp_d, grad_back, interval):
+    return _raw2alpha_bwd(exp_d, grad_back, 0.0, interval)
+
+
+def total_variation_add_grad_new(param, grad, mask, wx, wy, wz, dense_mode):
+    """In-place on `grad` (total_variation_kernel.cu:38-66,101-131)."""
+    assert param.is_contiguous() and grad.is_contiguous() and mask.is_contiguous()
+    assert param.dtype == grad.dtype == mask.dtype == torch.float32
+    lib().esr_oracle_tv_add_grad_masked(
+        _p(param.detach()), _p(grad), _p(mask),
+        ctypes.c_float(float(wx)), ctypes.c_float(float(wy)), ctypes.c_float(float(wz)),
+        ctypes.c_int64(param.shape[2]), ctypes.c_int64(param.shape[3]), ctypes.c_int64(param.shape[4]),
+        ctypes.c_int64(param.numel()), ctypes.c_int(1 if dense_mode else 0))
+
+
 class _Namespace:
     """Stand-in for the pybind module object the reference imports."""
 
@@ -141,12 +249,16 @@ def as_render_utils_module():
     m.sample_pts_on_rays = sample_pts_on_rays
     m.alpha2weight = alpha2weight
     m.alpha2weight_backward = alpha2weight_backward
+    for f in (infer_t_minmax, infer_n_samples, infer_ray_start_dir, sample_ndc_pts_on_rays, sample_bg_pts_on_rays,
+              maskcache_lookup, raw2alpha, raw2alpha_backward, raw2alpha_nonuni, raw2alpha_nonuni_backward):
+        setattr(m, f.__name__, f)               # (exported by the reference's module, never called by its Python)
     return m
 
 
 def as_total_variation_module():
     m = _Namespace()
     m.total_variation_add_grad = total_variation_add_grad
+    m.total_variation_add_grad_new = total_variation_add_grad_new
     return m
 
 

@@ -180,3 +180,99 @@ def test_smooth_gradient_tv_term_matches_torch_chain():
     (tv * 0.01).backward()
     assert rel_err(g.grad, ref_in.grad) < 1e-5
     assert float(ref_in.grad.abs().max()) > 0
+
+
+# ---- the ops the two pybind modules export but the reference's Python never calls (csrc/legacy_ops.hip) vs the C oracle:
+# everything made of +, *, /, sqrt, ceil, round and comparisons is BIT-EXACT (separately rounded operations on both sides);
+# exp / pow come from two math libraries (ocml on the device, glibc on the host): 2 ulp
+@pytest.mark.parametrize("n,seed", [(1, 0), (300, 2), (20000, 4)])
+def test_dead_ray_helpers_bit_exact(ru, native, n, seed):
+    o, d = _rays(n, seed)
+    bmin, bmax = torch.tensor([-1, -0.8, -0.5]), torch.tensor([1, 0.9, 0.25])
+    near, far, sd = 0.05, 7.5, 0.0123
+    t_ref = native.infer_t_minmax(o, d, bmin, bmax, near, far)
+    t_got = ru.infer_t_minmax(o.cuda(), d.cuda(), bmin.cuda(), bmax.cuda(), near, far)
+    for r, g in zip(t_ref, t_got):
+        assert torch.equal(r, g.cpu())
+    n_ref = native.infer_n_samples(d, t_ref[0], t_ref[1], sd)
+    n_got = ru.infer_n_samples(d.cuda(), t_got[0], t_got[1], sd)
+    assert n_got.dtype == torch.int64 and torch.equal(n_ref, n_got.cpu())
+    s_ref = native.infer_ray_start_dir(o, d, t_ref[0])
+    s_got = ru.infer_ray_start_dir(o.cuda(), d.cuda(), t_got[0])
+    for r, g in zip(s_ref, s_got):
+        assert torch.equal(r, g.cpu())
+    # and they are the three steps of the live sampler
+    live = ru.sample_pts_on_rays(o.cuda(), d.cuda(), bmin.cuda(), bmax.cuda(), near, far, sd)
+    assert torch.equal(live[4], n_got) and torch.equal(live[5], t_got[0]) and torch.equal(live[6], t_got[1])
+
+
+@pytest.mark.parametrize("n,S", [(1, 2), (37, 17), (4096, 64)])
+def test_dead_ndc_and_background_samplers_bit_exact(ru, native, n, S):
+    g = torch.Generator().manual_seed(n)
+    o = torch.rand(n, 3, generator=g) * 0.6 - 0.3
+    d = torch.randn(n, 3, generator=g)
+    bmin, bmax = torch.tensor([-1.0, -1.0, -1.0]), torch.tensor([1.0, 1.0, 0.5])
+    p_ref, m_ref = native.sample_ndc_pts_on_rays(o, d, bmin, bmax, S)
+    p_got, m_got = ru.sample_ndc_pts_on_rays(o.cuda(), d.cuda(), bmin.cuda(), bmax.cuda(), S)
+    assert p_got.shape == (n, S, 3) and m_got.dtype == torch.bool
+    assert torch.equal(p_ref, p_got.cpu()) and torch.equal(m_ref, m_got.cpu())
+    t_max = torch.rand(n, generator=g) + 1.0
+    for bg in (0.0, 0.3, 1.0):
+        b_ref = native.sample_bg_pts_on_rays(o, d, t_max, bg, S)
+        b_got = ru.sample_bg_pts_on_rays(o.cuda(), d.cuda(), t_max.cuda(), bg, S)
+        assert torch.equal(b_ref, b_got.cpu()), bg
+
+
+def test_dead_maskcache_lookup_bit_exact(ru, native):
+    g = torch.Generator().manual_seed(1)
+    world = torch.rand(33, 20, 17, generator=g) < 0.5
+    xyz = torch.rand(100000, 3, generator=g) * 3.0 - 1.0
+    scale, shift = torch.tensor([16.0, 9.5, 8.0]), torch.tensor([0.0, 0.5, 1.0])
+    ref = native.maskcache_lookup(world, xyz, scale, shift)
+    got = ru.maskcache_lookup(world.cuda(), xyz.cuda(), scale.cuda(), shift.cuda())
+    assert got.dtype == torch.bool and torch.equal(ref, got.cpu())
+    assert bool(ref.any()) and not bool(ref.all())
+    assert ru.maskcache_lookup(world.cuda(), xyz[:0].cuda(), scale.cuda(), shift.cuda()).shape == (0,)
+
+
+@pytest.mark.parametrize("nonuni", [False, True])
+def test_dead_raw2alpha_and_backward(ru, native, nonuni):
+    g = torch.Generator().manual_seed(2)
+    n = 200000
+    dens = torch.randn(n, generator=g) * 6.0
+    dens[:3] = torch.tensor([95.0, -95.0, 0.0])
+    shift = -1.5
+    iv_t = torch.rand(n, generator=g) * 0.9 + 0.1
+    iv = iv_t if nonuni else 0.37
+    ivd = iv_t.cuda() if nonuni else 0.37
+    f_ref = (native.raw2alpha_nonuni if nonuni else native.raw2alpha)(dens, shift, iv)
+    f_got = (ru.raw2alpha_nonuni if nonuni else ru.raw2alpha)(dens.cuda(), shift, ivd)
+    e_ref, a_ref = f_ref
+    e_got, a_got = (t.cpu() for t in f_got)
+    fin = torch.isfinite(e_ref)
+    assert torch.equal(fin, torch.isfinite(e_got)) and bool((~fin).any())
+    assert float(((e_got[fin] - e_ref[fin]).abs() / e_ref[fin].clamp_min(1e-30)).max()) < 3e-7        # 2 ulp
+    assert float((a_got - a_ref).abs().max()) < 3e-7
+    gb = torch.randn(n, generator=g)
+    b_ref = (native.raw2alpha_nonuni_backward if nonuni else native.raw2alpha_backward)(e_ref, gb, iv)
+    b_got = (ru.raw2alpha_nonuni_backward if nonuni else ru.raw2alpha_backward)(e_ref.cuda(), gb.cuda(), ivd).cpu()
+    assert bool(torch.isfinite(b_got).all())
+    assert float((b_got - b_ref).abs().max() / b_ref.abs().max()) < 3e-7
+    assert float(b_got[~fin].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dense", [True, False])
+@pytest.mark.parametrize("shape", [(1, 1, 7, 6, 5), (1, 3, 16, 8, 9), (1, 1, 64, 48, 33)])
+def test_dead_masked_tv_add_grad_bit_exact(ru, native, dense, shape):
+    g = torch.Generator().manual_seed(5)
+    param = torch.randn(shape, generator=g) * 1.5
+    mask = (torch.rand(shape, generator=g) < 0.7).float() * (torch.rand(shape, generator=g) + 0.5)
+    grad = torch.randn(shape, generator=g)
+    grad[torch.rand(shape, generator=g) < 0.4] = 0
+    exp = grad.clone()
+    native.total_variation_add_grad_new(param, exp, mask, 9.0, 0.3, 0.7, dense)
+    got = grad.clone().cuda()
+    ru.total_variation_add_grad_new(param.cuda(), got, mask.cuda(), 9.0, 0.3, 0.7, dense)
+    assert torch.equal(got.cpu(), exp)
+    if not dense:
+        assert torch.equal(got.cpu()[grad == 0], grad[grad == 0])

@@ -448,9 +448,21 @@ def test_deferred_march_overflow_raises_on_the_next_step():
     trainer._check_overflow(step)                                   # raised once, then cleared
 
 
-def test_render_utils_shim_names_dead_reference_ops():
+def test_render_utils_shim_has_every_name_of_the_two_pybind_modules():
+    """render_utils.cpp:170-184 (13 names) + total_variation.cpp:29-32 (2): the shim answers all of them -- also the ones the
+    reference's own Python never calls (round 5: real launches, csrc/legacy_ops.hip; rounds 1-4 raised NotImplementedError) --
+    and refuses CPU tensors the way the reference's CHECK_CUDA does."""
+    import torch
     from esr_nerf_amd import render_utils
-    with pytest.raises(NotImplementedError, match="never called"):
-        render_utils.maskcache_lookup
+    names = ("infer_t_minmax", "infer_n_samples", "infer_ray_start_dir", "sample_pts_on_rays", "sample_ndc_pts_on_rays",
+             "sample_bg_pts_on_rays", "maskcache_lookup", "raw2alpha", "raw2alpha_backward", "raw2alpha_nonuni",
+             "raw2alpha_nonuni_backward", "alpha2weight", "alpha2weight_backward", "total_variation_add_grad",
+             "total_variation_add_grad_new")
+    for n in names:
+        assert callable(getattr(render_utils, n)), n
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        render_utils.raw2alpha(torch.zeros(4), 0.0, 0.5)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        render_utils.maskcache_lookup(torch.zeros(2, 2, 2, dtype=torch.bool), torch.zeros(3, 3), torch.ones(3), torch.zeros(3))
     with pytest.raises(AttributeError):
         render_utils.no_such_op

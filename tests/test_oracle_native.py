@@ -187,3 +187,131 @@ def test_native_ops_reproduce_recorded_reference_traffic(golden_case):
     g = native.alpha2weight_backward(z["native/a2w/alpha"], *out, z["in/rays_o"].shape[0],
                                      z["native/a2wb/grad_weights"], z["native/a2wb/grad_last"])
     assert torch.equal(g, z["native/a2wb/grad"])
+
+
+# ---- the ops the reference's modules export but its Python never calls (no reference traffic, no golden vectors exist for
+# them): the C restatements against independent numpy / torch statements of the kernels' formulas
+def test_dead_ray_helpers_match_the_sampler_statement():
+    """infer_t_minmax / infer_n_samples / infer_ray_start_dir (render_utils_kernel.cu:12-79) are the three steps
+    sample_pts_on_rays runs internally: same numbers as np_sample's, bit for bit."""
+    o, d = rand_rays(300, 4)
+    bmin, bmax = np.array([-1, -1, -0.25], np.float32), np.array([1, 1, 0.25], np.float32)
+    _, _, _, _, n_ref, tmin_ref, tmax_ref = np_sample(o, d, bmin, bmax, 0.2, 6.0, 0.01)
+    to = torch.from_numpy
+    t_min, t_max = native.infer_t_minmax(to(o), to(d), to(bmin), to(bmax), 0.2, 6.0)
+    assert np.array_equal(t_min.numpy(), tmin_ref) and np.array_equal(t_max.numpy(), tmax_ref)
+    n = native.infer_n_samples(to(d), t_min, t_max, 0.01)
+    assert n.dtype == torch.int64 and np.array_equal(n.numpy(), n_ref)
+    start, dirs = native.infer_ray_start_dir(to(o), to(d), t_min)
+    f = np.float32
+    sq = ((d[:, 0] * d[:, 0]).astype(f) + (d[:, 1] * d[:, 1]).astype(f)).astype(f)
+    nrm = np.sqrt((sq + (d[:, 2] * d[:, 2]).astype(f)).astype(f)).astype(f)
+    assert np.array_equal(start.numpy(), (o + (d * tmin_ref[:, None]).astype(f)).astype(f))
+    assert np.array_equal(dirs.numpy(), (d / nrm[:, None]).astype(f))
+
+
+def test_dead_ndc_and_background_samplers():
+    """sample_ndc_pts_on_rays (render_utils_kernel.cu:243-269): o + d step / (N - 1), exact in numpy float32.
+    sample_bg_pts_on_rays (:301-340) against the torch lines its source quotes as the original implementation."""
+    g = np.random.default_rng(3)
+    o = g.uniform(-0.3, 0.3, (40, 3)).astype(np.float32)
+    d = g.normal(size=(40, 3)).astype(np.float32)
+    bmin, bmax = np.array([-1, -1, -1], np.float32), np.array([1, 1, 0.5], np.float32)
+    to = torch.from_numpy
+    S = 17
+    pts, mask = native.sample_ndc_pts_on_rays(to(o), to(d), to(bmin), to(bmax), S)
+    dist = (np.arange(S, dtype=np.float32) / np.float32(S - 1)).astype(np.float32)
+    ref = (o[:, None, :] + (d[:, None, :] * dist[None, :, None]).astype(np.float32)).astype(np.float32)
+    assert pts.shape == (40, S, 3) and np.array_equal(pts.numpy(), ref)
+    assert mask.dtype == torch.bool and np.array_equal(mask.numpy(), ((bmin > ref) | (bmax < ref)).any(-1))
+    assert mask.any() and not mask.all()
+    # background: the quoted torch implementation, in float64 (the kernel mixes float and double; it agrees to fp32 rounding)
+    t_max = torch.from_numpy(g.uniform(1.0, 2.0, 40).astype(np.float32))
+    N, bg = 12, 0.3
+    got = native.sample_bg_pts_on_rays(to(o), to(d), t_max, bg, N)
+    ro, rd, tm = to(o).double(), to(d).double(), t_max.double()
+    ori_t_outer = tm[:, None] - 1 + 1 / torch.linspace(1, 0, N + 1, dtype=torch.float64)[:-1]
+    ori = (ro[:, None, :] + rd[:, None, :] * ori_t_outer[:, :, None]).reshape(-1, 3)
+    t_outer = ori.norm(dim=-1)
+    R_outer = t_outer / ori.abs().amax(1)
+    o2i = R_outer.pow(2) / t_outer.pow(2) * (1 - bg) + R_outer / t_outer * bg
+    ref = (ori * o2i[:, None]).reshape(40, N, 3)
+    assert got.shape == (40, N, 3)
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
+def test_dead_maskcache_lookup():
+    """render_utils_kernel.cu:366-392: nearest voxel (round half away from zero) of a bool volume; outside reads False."""
+    g = torch.Generator().manual_seed(1)
+    world = torch.rand(5, 6, 7, generator=g) < 0.5
+    xyz = torch.rand(500, 3, generator=g) * 3.0 - 1.0
+    xyz[0] = torch.tensor([0.5 / 2.0, 0.0, 0.0])           # a tie: 0.5 rounds to 1, not to 0
+    scale, shift = torch.tensor([2.0, 2.5, 3.0]), torch.tensor([0.0, 0.5, 1.0])
+    got = native.maskcache_lookup(world, xyz, scale, shift)
+    ijk = (xyz * scale + shift)
+    r = torch.where(ijk >= 0, torch.floor(ijk + 0.5), torch.ceil(ijk - 0.5)).long()
+    inside = ((r >= 0) & (r < torch.tensor([5, 6, 7]))).all(-1)
+    ref = torch.zeros(500, dtype=torch.bool)
+    ref[inside] = world[r[inside, 0], r[inside, 1], r[inside, 2]]
+    assert got.dtype == torch.bool and torch.equal(got, ref)
+    assert bool(inside.any()) and not bool(inside.all()) and bool(got.any())
+
+
+@pytest.mark.parametrize("nonuni", [False, True])
+def test_dead_raw2alpha_and_its_backward(nonuni):
+    """render_utils_kernel.cu:431-460,504-530: alpha = 1 - (1 + exp(d + shift))^(-interval) and the gradient the kernel
+    states, min(e, 1e10) (1 + e)^(-interval - 1) interval g -- which is autograd's gradient of that alpha where e is finite."""
+    g = torch.Generator().manual_seed(2)
+    n = 4000
+    dens = torch.randn(n, generator=g) * 6.0
+    dens[:3] = torch.tensor([95.0, -95.0, 0.0])            # e = inf (fp32 exp overflows at 88.7), e = 0+, e = e^shift
+    shift = -1.5
+    iv_t = torch.rand(n, generator=g) * 0.9 + 0.1
+    iv = iv_t if nonuni else 0.37
+    fwd = native.raw2alpha_nonuni if nonuni else native.raw2alpha
+    bwd = native.raw2alpha_nonuni_backward if nonuni else native.raw2alpha_backward
+    e, a = fwd(dens, shift, iv)
+    d64 = (dens + shift).double().requires_grad_(True)        # the kernel rounds density + shift to fp32 before the exponential
+    e64 = torch.exp(d64)
+    iv64 = iv_t.double() if nonuni else iv
+    a64 = 1 - (1 + e64) ** (-iv64)
+    fin = torch.isfinite(e)
+    assert bool((~fin).any()) and float(a[~fin].min()) == 1.0                    # (1 + inf)^(-interval) = 0
+    assert float((e[fin].double() - e64.detach()[fin]).abs().div(e64.detach()[fin].clamp_min(1e-30)).max()) < 5e-7    # (e^-96.5 is a denormal)
+    assert float((a.double() - a64.detach()).abs().max()) < 3e-7
+    gb = torch.randn(n, generator=g)
+    got = bwd(e, gb, iv)
+    a64.backward(gb.double())
+    ok = fin & (e < 1e10)
+    assert float((got[ok].double() - d64.grad[ok]).abs().max() / d64.grad[ok].abs().max()) < 1e-6
+    assert bool(torch.isfinite(got[fin]).all())
+    # e = inf: min(e, 1e10) * (1 + inf)^(..) = 1e10 * 0 = 0 -- the kernel's clamp is what keeps inf * 0 = NaN out
+    assert float(got[~fin].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dense", [True, False])
+def test_dead_masked_tv_add_grad(dense):
+    """total_variation_kernel.cu:38-66: the live kernel's stencil with every term times mask[cell] mask[neighbour], wx on the
+    fastest axis (the live one uses wz there) -- against a torch statement with shifted slices."""
+    g = torch.Generator().manual_seed(7)
+    p = torch.randn(1, 2, 5, 6, 7, generator=g) * 1.5
+    m = (torch.rand(1, 2, 5, 6, 7, generator=g) < 0.7).float()
+    grad = torch.randn(1, 2, 5, 6, 7, generator=g)
+    if not dense:
+        grad[torch.rand(grad.shape, generator=g) < 0.5] = 0.0
+    g0 = grad.clone()
+    wx, wy, wz = 0.6, 1.2, 2.4
+    native.total_variation_add_grad_new(p, grad, m, wx, wy, wz, dense)
+    add = torch.zeros_like(p, dtype=torch.float64)
+    for axis, w in ((4, wx), (3, wy), (2, wz)):
+        for sgn in (-1, 1):
+            nb, mb = torch.roll(p, sgn, axis).double(), torch.roll(m, sgn, axis).double()
+            term = (w / 6) * (p.double() - nb).clamp(-1, 1) * m.double() * mb
+            idx = torch.arange(p.shape[axis])
+            edge = (idx == 0) if sgn == 1 else (idx == p.shape[axis] - 1)       # roll(+1) brings index-1: no left neighbour at 0
+            shape = [1] * 5
+            shape[axis] = -1
+            add += torch.where(edge.view(shape), torch.zeros_like(term), term)
+    ref = g0.double() + (add if dense else add * (g0 != 0))
+    assert float((grad.double() - ref).abs().max()) < 1e-6
+    assert bool(((grad - g0) != 0).any())
