@@ -98,6 +98,7 @@ EXPORTS = [
     "esr_abi_version", "esr_build_info",
     "esr_sample_count", "esr_sample_fill", "esr_alpha2weight_fwd", "esr_alpha2weight_bwd",
     "esr_tv_add_grad", "esr_segment_sum",
+    "esr_sample_count_f64", "esr_sample_fill_f64", "esr_alpha2weight_fwd_f64", "esr_alpha2weight_bwd_f64",
     "esr_infer_t_minmax", "esr_infer_n_samples", "esr_infer_ray_start_dir", "esr_sample_ndc_pts", "esr_sample_bg_pts",
     "esr_maskcache_lookup", "esr_raw2alpha", "esr_raw2alpha_bwd", "esr_tv_add_grad_masked",
     "esr_fine_march_count", "esr_fine_plan_begin", "esr_fine_plan", "esr_fine_plan_totals", "esr_fine_plan_offsets", "esr_fine_march_fill",

@@ -108,6 +108,60 @@ __global__ void __launch_bounds__(256) a2w_bwd_kernel(
     }
 }
 
+// ---- the reference's DOUBLE instantiation (render_utils_kernel.cu:639,692): `float T_cum` / `float back_cum` stay float
+// locals, everything else is double.  One thread per ray, the reference's own loop (nothing on the path calls it).
+__global__ void __launch_bounds__(256) a2w_init_f64_kernel(int64_t n_pts, int64_t n_rays, double *__restrict__ weight,
+                                                           double *__restrict__ T, double *__restrict__ last,
+                                                           int64_t *__restrict__ i_start, int64_t *__restrict__ i_end)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (int64_t i = t0; i < n_pts; i += stride) { weight[i] = 0.0; T[i] = 1.0; }
+    for (int64_t r = t0; r < n_rays; r += stride) { last[r] = 1.0; i_start[r] = 0; i_end[r] = 0; }
+}
+
+__global__ void __launch_bounds__(256) a2w_fwd_f64_kernel(const double *__restrict__ alpha, int64_t n_rays,
+                                                          double *__restrict__ weight, double *__restrict__ T,
+                                                          double *__restrict__ last, const int64_t *__restrict__ i_start,
+                                                          int64_t *__restrict__ i_end)
+{
+#pragma clang fp contract(off)
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i = i_start[r];
+        const int64_t e = i_end[r];
+        float tc = 1.f;
+        while (i < e) {
+            T[i] = (double)tc;
+            weight[i] = (double)tc * alpha[i];
+            tc = (float)((double)tc * (1.0 - alpha[i]));
+            ++i;
+            if ((double)tc < 1e-3) break;
+        }
+        i_end[r] = i;
+        last[r] = (double)tc;
+    }
+}
+
+__global__ void __launch_bounds__(256) a2w_bwd_f64_kernel(
+    const double *__restrict__ alpha, const double *__restrict__ weight, const double *__restrict__ T,
+    const double *__restrict__ last, const int64_t *__restrict__ i_start, const int64_t *__restrict__ i_end, int64_t n_rays,
+    const double *__restrict__ gw, const double *__restrict__ gl, double *__restrict__ grad)
+{
+#pragma clang fp contract(off)
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)gridDim.x * blockDim.x) {
+        float back = (float)(gl[r] * last[r]);
+        for (int64_t i = i_end[r] - 1; i >= i_start[r]; --i) {
+            grad[i] = gw[i] * T[i] - (double)back / ((1.0 - alpha[i]) + 1e-10);
+            back = (float)((double)back + gw[i] * weight[i]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) zero_f64_kernel(double *__restrict__ p, int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.0;
+}
+
 __global__ void __launch_bounds__(256) zero_f32_kernel(float *__restrict__ p, int64_t n)
 {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
@@ -155,6 +209,43 @@ ESR_API int esr_alpha2weight_bwd(const float *alpha, const float *weight, const 
     if (n_rays == 0) return 0;
     a2w_bwd_kernel<<<esr_grid_for(n_rays * 64, 256), 256, 0, s>>>(
         alpha, weight, T, alphainv_last, i_start, i_end, n_rays, grad_weights, grad_last, grad);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_alpha2weight_fwd_f64(const double *alpha, const int64_t *ray_id, int64_t n_pts, int64_t n_rays, double *weight,
+                                     double *T, double *alphainv_last, int64_t *i_start, int64_t *i_end, void *stream)
+{
+    if (n_pts < 0 || n_rays < 0) return ESR_EINVAL;
+    if (n_rays > 0 && (!alphainv_last || !i_start || !i_end)) return ESR_EINVAL;
+    if (n_pts > 0 && (!alpha || !ray_id || !weight || !T)) return ESR_EINVAL;
+    hipStream_t s = esr_stream(stream);
+    if (n_pts + n_rays == 0) return 0;
+    a2w_init_f64_kernel<<<esr_grid_for(n_pts > n_rays ? n_pts : n_rays, 256), 256, 0, s>>>(n_pts, n_rays, weight, T,
+                                                                                             alphainv_last, i_start, i_end);
+    ESR_CHECK_LAUNCH();
+    if (n_pts == 0) return 0;
+    a2w_bounds_kernel<<<esr_grid_for(n_pts, 256), 256, 0, s>>>(ray_id, n_pts, i_start, i_end);
+    ESR_CHECK_LAUNCH();
+    a2w_fwd_f64_kernel<<<esr_grid_for(n_rays, 256), 256, 0, s>>>(alpha, n_rays, weight, T, alphainv_last, i_start, i_end);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_alpha2weight_bwd_f64(const double *alpha, const double *weight, const double *T, const double *alphainv_last,
+                                     const int64_t *i_start, const int64_t *i_end, int64_t n_pts, int64_t n_rays,
+                                     const double *grad_weights, const double *grad_last, double *grad, void *stream)
+{
+    if (n_pts < 0 || n_rays < 0) return ESR_EINVAL;
+    if (n_pts == 0) return 0;
+    if (!alpha || !weight || !T || !alphainv_last || !i_start || !i_end || !grad_weights || !grad_last || !grad)
+        return ESR_EINVAL;
+    hipStream_t s = esr_stream(stream);
+    zero_f64_kernel<<<esr_grid_for(n_pts, 256), 256, 0, s>>>(grad, n_pts);
+    ESR_CHECK_LAUNCH();
+    if (n_rays == 0) return 0;
+    a2w_bwd_f64_kernel<<<esr_grid_for(n_rays, 256), 256, 0, s>>>(alpha, weight, T, alphainv_last, i_start, i_end, n_rays,
+                                                                 grad_weights, grad_last, grad);
     ESR_CHECK_LAUNCH();
     return 0;
 }

@@ -92,6 +92,82 @@ __global__ void __launch_bounds__(256) sample_fill_kernel(
     }
 }
 
+// ---- the reference's DOUBLE instantiation of the same op (AT_DISPATCH_FLOATING_TYPES, render_utils_kernel.cu:93-101,113-120,
+// 130-138,229): its kernels keep `float` LOCALS, so with double tensors the t-range, the ray length and every sample point are
+// computed in double and ROUNDED TO FLOAT before they are stored as doubles; only rays_start / rays_dir carry double precision.
+// Restated literally (one thread per ray / sample, no tuning: nothing on the path calls it); oracle/esr_oracle.c has the twin.
+__device__ __forceinline__ void ray_trange_f64(const double *o, const double *d, const double *bmin, const double *bmax,
+                                               float near_, float far_, float &tmin, float &tmax)
+{
+    float lo = 0.f, hi = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float v = (float)((d[a] == 0.0) ? 1e-6 : d[a]);
+        const float ta = (float)((bmax[a] - o[a]) / (double)v);
+        const float tb = (float)((bmin[a] - o[a]) / (double)v);
+        const float mn = fminf(ta, tb), mx = fmaxf(ta, tb);
+        if (a == 0) { lo = mn; hi = mx; }
+        else        { lo = fmaxf(lo, mn); hi = fminf(hi, mx); }
+    }
+    tmin = fmaxf(fminf(lo, far_), near_);
+    tmax = fmaxf(fminf(hi, far_), near_);
+}
+
+__device__ __forceinline__ float ray_norm_f64(const double *d)
+{
+#pragma clang fp contract(off)
+    return (float)sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+}
+
+__global__ void __launch_bounds__(256) ray_count_f64_kernel(
+    const double *__restrict__ rays_o, const double *__restrict__ rays_d, const double *__restrict__ xyz_min,
+    const double *__restrict__ xyz_max, float near_, float far_, float stepdist, int64_t n_rays,
+    double *__restrict__ t_min, double *__restrict__ t_max, int64_t *__restrict__ n_steps)
+{
+#pragma clang fp contract(off)
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)gridDim.x * blockDim.x) {
+        float lo, hi;
+        ray_trange_f64(rays_o + 3 * r, rays_d + 3 * r, xyz_min, xyz_max, near_, far_, lo, hi);
+        t_min[r] = (double)lo;
+        t_max[r] = (double)hi;
+        const double len = ((double)hi - (double)lo) * (double)ray_norm_f64(rays_d + 3 * r) / (double)stepdist;
+        const double c = ceil(len);
+        n_steps[r] = (int64_t)(c > 1.0 ? c : 1.0);
+    }
+}
+
+__global__ void __launch_bounds__(256) sample_fill_f64_kernel(
+    const double *__restrict__ rays_o, const double *__restrict__ rays_d, const double *__restrict__ xyz_min,
+    const double *__restrict__ xyz_max, const double *__restrict__ t_min, const int64_t *__restrict__ cumsum, float stepdist,
+    int64_t n_rays, int64_t total, double *__restrict__ ray_pts, uint8_t *__restrict__ mask_outbbox,
+    int64_t *__restrict__ ray_id, int64_t *__restrict__ step_id)
+{
+#pragma clang fp contract(off)
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t lo = 0, hi = n_rays - 1;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (cumsum[mid] > i) hi = mid; else lo = mid + 1;
+        }
+        const int64_t r = lo;
+        const int step = (int)(i - (r ? cumsum[r - 1] : 0));
+        const float nrm = ray_norm_f64(rays_d + 3 * r);
+        const float dist = stepdist * (float)step;
+        bool out = false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double start = rays_o[3 * r + a] + rays_d[3 * r + a] * t_min[r];
+            const double dir = rays_d[3 * r + a] / (double)nrm;
+            const float p = (float)(start + dir * (double)dist);
+            ray_pts[3 * i + a] = (double)p;
+            out |= (xyz_min[a] > (double)p) | (xyz_max[a] < (double)p);
+        }
+        mask_outbbox[i] = out ? 1 : 0;
+        ray_id[i] = r;
+        step_id[i] = step;
+    }
+}
+
 // out[index[i], :] += src[i, :] for a sorted index: a wave walks 64 consecutive
 // rows, does a segmented inclusive scan with shuffles and issues ONE atomic per
 // (segment, channel) instead of one per row.
@@ -158,6 +234,36 @@ ESR_API int esr_sample_fill(const float *rays_o, const float *rays_d, const floa
     sample_fill_kernel<<<esr_grid_for(total, 256, 256 * 16), 256, 0, esr_stream(stream)>>>(
         rays_o, rays_d, xyz_min, xyz_max, t_min, cumsum, stepdist, n_rays, total, ray_pts,
         mask_outbbox, ray_id, step_id);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_sample_count_f64(const double *rays_o, const double *rays_d, const double *xyz_min, const double *xyz_max,
+                                 float near_, float far_, float stepdist, int64_t n_rays, double *t_min, double *t_max,
+                                 int64_t *n_steps, int64_t *cumsum, int64_t *total, void *stream)
+{
+    if (n_rays < 0 || !total) return ESR_EINVAL;
+    hipStream_t s = esr_stream(stream);
+    if (n_rays == 0) return (int)hipMemsetAsync(total, 0, sizeof(int64_t), s);
+    if (!rays_o || !rays_d || !xyz_min || !xyz_max || !t_min || !t_max || !n_steps || !cumsum) return ESR_EINVAL;
+    ray_count_f64_kernel<<<esr_grid_for(n_rays, 256), 256, 0, s>>>(rays_o, rays_d, xyz_min, xyz_max, near_, far_, stepdist,
+                                                                   n_rays, t_min, t_max, n_steps);
+    ESR_CHECK_LAUNCH();
+    scan_i64_kernel<<<1, 1024, 0, s>>>(n_steps, n_rays, cumsum, total);
+    ESR_CHECK_LAUNCH();
+    return 0;
+}
+
+ESR_API int esr_sample_fill_f64(const double *rays_o, const double *rays_d, const double *xyz_min, const double *xyz_max,
+                                const double *t_min, const int64_t *cumsum, float stepdist, int64_t n_rays, int64_t total,
+                                double *ray_pts, uint8_t *mask_outbbox, int64_t *ray_id, int64_t *step_id, void *stream)
+{
+    if (n_rays < 0 || total < 0) return ESR_EINVAL;
+    if (total == 0 || n_rays == 0) return 0;
+    if (!rays_o || !rays_d || !xyz_min || !xyz_max || !t_min || !cumsum || !ray_pts || !mask_outbbox || !ray_id || !step_id)
+        return ESR_EINVAL;
+    sample_fill_f64_kernel<<<esr_grid_for(total, 256, 256 * 16), 256, 0, esr_stream(stream)>>>(
+        rays_o, rays_d, xyz_min, xyz_max, t_min, cumsum, stepdist, n_rays, total, ray_pts, mask_outbbox, ray_id, step_id);
     ESR_CHECK_LAUNCH();
     return 0;
 }

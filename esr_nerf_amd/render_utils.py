@@ -28,30 +28,40 @@ def _chk(t: torch.Tensor, name: str, dtype=None):
         raise RuntimeError(f"{name} must be {dtype}")
 
 
+def _float_type(t: torch.Tensor, name: str):
+    """The reference dispatches its three live ops over float AND double (AT_DISPATCH_FLOATING_TYPES): fp32 runs the tuned
+    kernels, fp64 the literal restatement of the double instantiation (entry points *_f64); anything else is an error."""
+    if t.dtype not in (_f32, torch.float64):
+        raise RuntimeError(f"{name} must be float32 or float64")
+    return t.dtype
+
+
 def sample_pts_on_rays(rays_o, rays_d, xyz_min, xyz_max, near, far, stepdist):
     """-> [ray_pts, mask_outbbox, ray_id, step_id, N_steps, t_min, t_max]."""
+    ft = _float_type(rays_o, "rays_o")
     for t, n in ((rays_o, "rays_o"), (rays_d, "rays_d"), (xyz_min, "xyz_min"), (xyz_max, "xyz_max")):
-        _chk(t, n, _f32)
+        _chk(t, n, ft)
     L = _lib.lib()
+    count, fill = (L.esr_sample_count, L.esr_sample_fill) if ft == _f32 else (L.esr_sample_count_f64, L.esr_sample_fill_f64)
     dev = rays_o.device
     n = rays_o.shape[0]
-    t_min = torch.empty(n, dtype=_f32, device=dev)
-    t_max = torch.empty(n, dtype=_f32, device=dev)
+    t_min = torch.empty(n, dtype=ft, device=dev)
+    t_max = torch.empty(n, dtype=ft, device=dev)
     n_steps = torch.empty(n, dtype=_i64, device=dev)
     cumsum = torch.empty(n, dtype=_i64, device=dev)
     total = torch.empty(1, dtype=_i64, device=dev)
     s = _lib.stream_ptr(dev)
-    _lib.check(L.esr_sample_count(
+    _lib.check(count(
         _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(xyz_min), _lib.ptr(xyz_max),
         C.c_float(float(near)), C.c_float(float(far)), C.c_float(float(stepdist)), C.c_int64(n),
         _lib.ptr(t_min), _lib.ptr(t_max), _lib.ptr(n_steps), _lib.ptr(cumsum), _lib.ptr(total), s),
         "esr_sample_count")
     m = int(total.item())          # same device->host sync as the reference (kernel.cu:212)
-    ray_pts = torch.empty(m, 3, dtype=_f32, device=dev)
+    ray_pts = torch.empty(m, 3, dtype=ft, device=dev)
     mask = torch.empty(m, dtype=torch.bool, device=dev)
     ray_id = torch.empty(m, dtype=_i64, device=dev)
     step_id = torch.empty(m, dtype=_i64, device=dev)
-    _lib.check(L.esr_sample_fill(
+    _lib.check(fill(
         _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(xyz_min), _lib.ptr(xyz_max), _lib.ptr(t_min),
         _lib.ptr(cumsum), C.c_float(float(stepdist)), C.c_int64(n), C.c_int64(m),
         _lib.ptr(ray_pts), _lib.ptr(mask), _lib.ptr(ray_id), _lib.ptr(step_id), s),
@@ -61,17 +71,18 @@ def sample_pts_on_rays(rays_o, rays_d, xyz_min, xyz_max, near, far, stepdist):
 
 def alpha2weight(alpha, ray_id, n_rays):
     """-> [weight, T, alphainv_last, i_start, i_end]."""
-    _chk(alpha, "alpha", _f32)
+    ft = _float_type(alpha, "alpha")
+    _chk(alpha, "alpha", ft)
     _chk(ray_id, "ray_id", _i64)
     L = _lib.lib()
     dev = alpha.device
     m, n_rays = alpha.shape[0], int(n_rays)
     weight = torch.empty_like(alpha)
     T = torch.empty_like(alpha)
-    last = torch.empty(n_rays, dtype=_f32, device=dev)
+    last = torch.empty(n_rays, dtype=ft, device=dev)
     i_s = torch.empty(n_rays, dtype=_i64, device=dev)
     i_e = torch.empty(n_rays, dtype=_i64, device=dev)
-    _lib.check(L.esr_alpha2weight_fwd(
+    _lib.check((L.esr_alpha2weight_fwd if ft == _f32 else L.esr_alpha2weight_fwd_f64)(
         _lib.ptr(alpha), _lib.ptr(ray_id), C.c_int64(m), C.c_int64(n_rays), _lib.ptr(weight),
         _lib.ptr(T), _lib.ptr(last), _lib.ptr(i_s), _lib.ptr(i_e), _lib.stream_ptr(dev)),
         "esr_alpha2weight_fwd")
@@ -80,12 +91,13 @@ def alpha2weight(alpha, ray_id, n_rays):
 
 def alpha2weight_backward(alpha, weight, T, alphainv_last, i_start, i_end, n_rays,
                           grad_weights, grad_last):
+    ft = _float_type(alpha, "alpha")
     for t, n in ((alpha, "alpha"), (weight, "weight"), (T, "T"), (alphainv_last, "alphainv_last"),
                  (grad_weights, "grad_weights"), (grad_last, "grad_last")):
-        _chk(t, n, _f32)
+        _chk(t, n, ft)
     L = _lib.lib()
     grad = torch.empty_like(alpha)
-    _lib.check(L.esr_alpha2weight_bwd(
+    _lib.check((L.esr_alpha2weight_bwd if ft == _f32 else L.esr_alpha2weight_bwd_f64)(
         _lib.ptr(alpha), _lib.ptr(weight), _lib.ptr(T), _lib.ptr(alphainv_last), _lib.ptr(i_start),
         _lib.ptr(i_end), C.c_int64(alpha.shape[0]), C.c_int64(int(n_rays)), _lib.ptr(grad_weights),
         _lib.ptr(grad_last), _lib.ptr(grad), _lib.stream_ptr(alpha.device)),

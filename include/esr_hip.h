@@ -104,6 +104,25 @@ int esr_segment_sum(const float *src, const int64_t *index, int64_t n, int64_t c
                     float *out, int64_t n_seg, void *stream);
 
 /*
+ * The reference's DOUBLE instantiation of its three live ops (AT_DISPATCH_FLOATING_TYPES, render_utils_kernel.cu:229,639,692;
+ * nothing in the reference's Python produces double tensors, the shim dispatches on dtype like the reference does).  Same
+ * contracts as the fp32 entry points with double tensors.  The reference's kernels keep `float` locals whatever the tensor
+ * type: t_min / t_max, the sample points, the running transmittance and the backward's running sum are rounded to float on
+ * the way (stored as doubles) -- restated literally, one thread per ray / sample (csrc/sampler.hip, composite.hip).
+ */
+int esr_sample_count_f64(const double *rays_o, const double *rays_d, const double *xyz_min, const double *xyz_max,
+                         float near_, float far_, float stepdist, int64_t n_rays, double *t_min, double *t_max,
+                         int64_t *n_steps, int64_t *cumsum, int64_t *total, void *stream);
+int esr_sample_fill_f64(const double *rays_o, const double *rays_d, const double *xyz_min, const double *xyz_max,
+                        const double *t_min, const int64_t *cumsum, float stepdist, int64_t n_rays, int64_t total,
+                        double *ray_pts, uint8_t *mask_outbbox, int64_t *ray_id, int64_t *step_id, void *stream);
+int esr_alpha2weight_fwd_f64(const double *alpha, const int64_t *ray_id, int64_t n_pts, int64_t n_rays, double *weight,
+                             double *T, double *alphainv_last, int64_t *i_start, int64_t *i_end, void *stream);
+int esr_alpha2weight_bwd_f64(const double *alpha, const double *weight, const double *T, const double *alphainv_last,
+                             const int64_t *i_start, const int64_t *i_end, int64_t n_pts, int64_t n_rays,
+                             const double *grad_weights, const double *grad_last, double *grad, void *stream);
+
+/*
  * The ops the two pybind modules EXPORT but the reference's own Python never calls (render_utils.cpp:171-173,175-181,
  * total_variation.cpp:31).  Not on the accelerated path: one thread per ray / point / cell, the fp32
  * instantiation of the reference's templates statement by statement (csrc/legacy_ops.hip; float / double mixing where the

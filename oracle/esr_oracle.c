@@ -344,3 +344,106 @@ ESR_API void esr_oracle_tv_add_grad_masked(const float *param, float *grad, cons
         grad[idx] += g;
     }
 }
+
+/* ---- the DOUBLE instantiations of the three live ops (AT_DISPATCH_FLOATING_TYPES; render_utils_kernel.cu:93-101,113-120,
+ * 130-138,229,639,692).  The reference's kernels keep `float` LOCALS whatever scalar_t is: with double tensors the t-range,
+ * the ray length, every sample point, the running transmittance and the backward's running sum are rounded to float on the
+ * way; restated literally.  Pinned by an independent numpy statement (tests/test_oracle_native.py). */
+
+static void ray_t_range_f64(const double *o, const double *d, const double *bmin, const double *bmax, float near_, float far_,
+                            float *tmin, float *tmax)
+{
+    float lo = 0.f, hi = 0.f;
+    for (int a = 0; a < 3; ++a) {
+        const float v = (float)((d[a] == 0.0) ? 1e-6 : d[a]);
+        const float ta = (float)((bmax[a] - o[a]) / (double)v);
+        const float tb = (float)((bmin[a] - o[a]) / (double)v);
+        const float mn = fminf(ta, tb), mx = fmaxf(ta, tb);
+        if (a == 0) { lo = mn; hi = mx; }
+        else        { lo = fmaxf(lo, mn); hi = fminf(hi, mx); }
+    }
+    *tmin = fmaxf(fminf(lo, far_), near_);
+    *tmax = fmaxf(fminf(hi, far_), near_);
+}
+
+static inline float ray_norm_f64(const double *d) { return (float)sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]); }
+
+ESR_API void esr_oracle_sample_count_f64(const double *rays_o, const double *rays_d, const double *xyz_min, const double *xyz_max,
+                                         float near_, float far_, float stepdist, int64_t n_rays, double *t_min, double *t_max,
+                                         int64_t *n_steps)
+{
+    for (int64_t r = 0; r < n_rays; ++r) {
+        float lo, hi;
+        ray_t_range_f64(rays_o + 3 * r, rays_d + 3 * r, xyz_min, xyz_max, near_, far_, &lo, &hi);
+        t_min[r] = (double)lo;
+        t_max[r] = (double)hi;
+        const double len = ((double)hi - (double)lo) * (double)ray_norm_f64(rays_d + 3 * r) / (double)stepdist;
+        const double c = ceil(len);
+        n_steps[r] = (int64_t)(c > 1.0 ? c : 1.0);
+    }
+}
+
+ESR_API void esr_oracle_sample_fill_f64(const double *rays_o, const double *rays_d, const double *xyz_min, const double *xyz_max,
+                                        const double *t_min, const int64_t *n_steps, float stepdist, int64_t n_rays,
+                                        double *ray_pts, uint8_t *mask_outbbox, int64_t *ray_id, int64_t *step_id)
+{
+    int64_t at = 0;
+    for (int64_t r = 0; r < n_rays; ++r) {
+        const double *o = rays_o + 3 * r, *d = rays_d + 3 * r;
+        const float nrm = ray_norm_f64(d);
+        for (int64_t s = 0; s < n_steps[r]; ++s, ++at) {
+            const float dist = stepdist * (float)(int)s;
+            int out = 0;
+            for (int a = 0; a < 3; ++a) {
+                const double start = o[a] + d[a] * t_min[r];
+                const double dir = d[a] / (double)nrm;
+                const float p = (float)(start + dir * (double)dist);
+                ray_pts[3 * at + a] = (double)p;
+                out |= (xyz_min[a] > (double)p) | (xyz_max[a] < (double)p);
+            }
+            mask_outbbox[at] = (uint8_t)out;
+            ray_id[at] = r;
+            step_id[at] = s;
+        }
+    }
+}
+
+ESR_API void esr_oracle_alpha2weight_f64(const double *alpha, const int64_t *ray_id, int64_t n_pts, int64_t n_rays,
+                                         double *weight, double *T, double *alphainv_last, int64_t *i_start, int64_t *i_end)
+{
+    for (int64_t i = 0; i < n_pts; ++i) { weight[i] = 0.0; T[i] = 1.0; }
+    for (int64_t r = 0; r < n_rays; ++r) { alphainv_last[r] = 1.0; i_start[r] = 0; i_end[r] = 0; }
+    if (n_pts == 0) return;
+    for (int64_t i = 1; i < n_pts; ++i)
+        if (ray_id[i] != ray_id[i - 1]) { i_start[ray_id[i]] = i; i_end[ray_id[i - 1]] = i; }
+    i_end[ray_id[n_pts - 1]] = n_pts;
+    for (int64_t r = 0; r < n_rays; ++r) {
+        int64_t i = i_start[r];
+        const int64_t e = i_end[r];
+        float tc = 1.f;
+        while (i < e) {
+            T[i] = (double)tc;
+            weight[i] = (double)tc * alpha[i];
+            tc = (float)((double)tc * (1.0 - alpha[i]));
+            ++i;
+            if ((double)tc < 1e-3) break;
+        }
+        i_end[r] = i;
+        alphainv_last[r] = (double)tc;
+    }
+}
+
+ESR_API void esr_oracle_alpha2weight_backward_f64(const double *alpha, const double *weight, const double *T,
+                                                  const double *alphainv_last, const int64_t *i_start, const int64_t *i_end,
+                                                  int64_t n_pts, int64_t n_rays, const double *grad_weights,
+                                                  const double *grad_last, double *grad)
+{
+    for (int64_t i = 0; i < n_pts; ++i) grad[i] = 0.0;
+    for (int64_t r = 0; r < n_rays; ++r) {
+        float back = (float)(grad_last[r] * alphainv_last[r]);
+        for (int64_t i = i_end[r] - 1; i >= i_start[r]; --i) {
+            grad[i] = grad_weights[i] * T[i] - (double)back / ((1.0 - alpha[i]) + 1e-10);
+            back = (float)((double)back + grad_weights[i] * weight[i]);
+        }
+    }
+}

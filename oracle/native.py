@@ -45,9 +45,31 @@ def _f32(t):
     return t.detach().to(torch.float32).contiguous()
 
 
+def _sample_pts_on_rays_f64(rays_o, rays_d, xyz_min, xyz_max, near, far, stepdist):
+    """The reference's double instantiation (float locals inside: esr_oracle.c)."""
+    c = lambda t: t.detach().to(torch.float64).contiguous()
+    rays_o, rays_d, xyz_min, xyz_max = c(rays_o), c(rays_d), c(xyz_min), c(xyz_max)
+    n = rays_o.shape[0]
+    t_min, t_max = torch.empty(n, dtype=torch.float64), torch.empty(n, dtype=torch.float64)
+    n_steps = torch.empty(n, dtype=torch.int64)
+    L = lib()
+    L.esr_oracle_sample_count_f64(_p(rays_o), _p(rays_d), _p(xyz_min), _p(xyz_max), ctypes.c_float(float(near)),
+                                  ctypes.c_float(float(far)), ctypes.c_float(float(stepdist)), ctypes.c_int64(n),
+                                  _p(t_min), _p(t_max), _p(n_steps))
+    total = int(n_steps.sum().item())
+    ray_pts = torch.empty(total, 3, dtype=torch.float64)
+    mask = torch.empty(total, dtype=torch.uint8)
+    ray_id, step_id = torch.empty(total, dtype=torch.int64), torch.empty(total, dtype=torch.int64)
+    L.esr_oracle_sample_fill_f64(_p(rays_o), _p(rays_d), _p(xyz_min), _p(xyz_max), _p(t_min), _p(n_steps),
+                                 ctypes.c_float(float(stepdist)), ctypes.c_int64(n), _p(ray_pts), _p(mask), _p(ray_id), _p(step_id))
+    return [ray_pts, mask.bool(), ray_id, step_id, n_steps, t_min, t_max]
+
+
 def sample_pts_on_rays(rays_o, rays_d, xyz_min, xyz_max, near, far, stepdist):
     """-> [ray_pts, mask_outbbox, ray_id, step_id, N_steps, t_min, t_max]
     (render_utils_kernel.cu:196-242)."""
+    if rays_o.dtype == torch.float64:
+        return _sample_pts_on_rays_f64(rays_o, rays_d, xyz_min, xyz_max, near, far, stepdist)
     rays_o, rays_d = _f32(rays_o), _f32(rays_d)
     xyz_min, xyz_max = _f32(xyz_min), _f32(xyz_max)
     n = rays_o.shape[0]
@@ -76,6 +98,16 @@ def sample_pts_on_rays(rays_o, rays_d, xyz_min, xyz_max, near, far, stepdist):
 
 def alpha2weight(alpha, ray_id, n_rays):
     """-> [weight, T, alphainv_last, i_start, i_end] (render_utils_kernel.cu:619-651)."""
+    if alpha.dtype == torch.float64:
+        alpha = alpha.detach().contiguous()
+        ray_id = ray_id.to(torch.int64).contiguous()
+        m = alpha.shape[0]
+        weight, T = torch.empty(m, dtype=torch.float64), torch.empty(m, dtype=torch.float64)
+        last = torch.empty(n_rays, dtype=torch.float64)
+        i_s, i_e = torch.empty(n_rays, dtype=torch.int64), torch.empty(n_rays, dtype=torch.int64)
+        lib().esr_oracle_alpha2weight_f64(_p(alpha), _p(ray_id), ctypes.c_int64(m), ctypes.c_int64(int(n_rays)),
+                                          _p(weight), _p(T), _p(last), _p(i_s), _p(i_e))
+        return [weight, T, last, i_s, i_e]
     alpha = _f32(alpha)
     ray_id = ray_id.to(torch.int64).contiguous()
     m = alpha.shape[0]
@@ -94,6 +126,14 @@ def alpha2weight(alpha, ray_id, n_rays):
 def alpha2weight_backward(alpha, weight, T, alphainv_last, i_start, i_end, n_rays,
                           grad_weights, grad_last):
     """-> grad wrt alpha (render_utils_kernel.cu:679-707)."""
+    if alpha.dtype == torch.float64:
+        c = lambda t: t.detach().to(torch.float64).contiguous()
+        alpha, weight, T, alphainv_last, gw, gl = (c(t) for t in (alpha, weight, T, alphainv_last, grad_weights, grad_last))
+        grad = torch.empty(alpha.shape[0], dtype=torch.float64)
+        lib().esr_oracle_alpha2weight_backward_f64(_p(alpha), _p(weight), _p(T), _p(alphainv_last), _p(i_start.contiguous()),
+                                                   _p(i_end.contiguous()), ctypes.c_int64(alpha.shape[0]), ctypes.c_int64(int(n_rays)),
+                                                   _p(gw), _p(gl), _p(grad))
+        return grad
     alpha, weight, T = _f32(alpha), _f32(weight), _f32(T)
     alphainv_last = _f32(alphainv_last)
     gw, gl = _f32(grad_weights), _f32(grad_last)

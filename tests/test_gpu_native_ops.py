@@ -276,3 +276,43 @@ def test_dead_masked_tv_add_grad_bit_exact(ru, native, dense, shape):
     assert torch.equal(got.cpu(), exp)
     if not dense:
         assert torch.equal(got.cpu()[grad == 0], grad[grad == 0])
+
+
+# ---- the reference's DOUBLE instantiation of its three live ops (AT_DISPATCH_FLOATING_TYPES): the shim dispatches on dtype,
+# the *_f64 entry points restate the double kernels (float locals inside) -- bit-exact vs the C oracle's twins
+@pytest.mark.parametrize("n,seed", [(1, 0), (300, 2), (20000, 4)])
+def test_sampler_double_instantiation_bit_exact(ru, native, n, seed):
+    o, d = _rays(n, seed)
+    g = torch.Generator().manual_seed(seed)
+    o = o.double() + torch.randn(n, 3, generator=g, dtype=torch.float64) * 1e-9
+    d = d.double() * (1 + torch.randn(n, 3, generator=g, dtype=torch.float64) * 1e-9)
+    bmin, bmax = torch.tensor([-1, -0.8, -0.5], dtype=torch.float64), torch.tensor([1, 0.9, 0.25], dtype=torch.float64)
+    near, far, sd = 0.05, 1e9, 0.0123 if n < 10000 else 0.03
+    ref = native.sample_pts_on_rays(o, d, bmin, bmax, near, far, sd)
+    got = ru.sample_pts_on_rays(o.cuda(), d.cuda(), bmin.cuda(), bmax.cuda(), near, far, sd)
+    for nm, r, t in zip(["pts", "mask", "ray_id", "step_id", "n_steps", "t_min", "t_max"], ref, got):
+        assert r.dtype == t.dtype, nm
+        assert torch.equal(r, t.cpu()), nm
+    assert got[0].dtype == torch.float64
+    with pytest.raises(RuntimeError):
+        ru.sample_pts_on_rays(o.cuda().half(), d.cuda().half(), bmin.cuda().half(), bmax.cuda().half(), near, far, sd)
+    with pytest.raises(RuntimeError):
+        ru.sample_pts_on_rays(o.cuda(), d.cuda().float(), bmin.cuda(), bmax.cuda(), near, far, sd)     # mixed types
+
+
+@pytest.mark.parametrize("seed,n_rays,maxc", [(0, 40, 30), (2, 4096, 128)])
+def test_alpha2weight_double_instantiation_bit_exact(ru, native, seed, n_rays, maxc):
+    g = np.random.default_rng(seed)
+    counts = g.integers(0, maxc, n_rays)
+    counts[min(3, n_rays - 1)] = 0
+    ray_id = torch.from_numpy(np.repeat(np.arange(n_rays), counts))
+    alpha = torch.from_numpy(g.uniform(0, 1, len(ray_id)) ** 3)
+    alpha[torch.from_numpy(g.uniform(size=len(alpha)) < 0.1)] = 0.9999
+    ref = native.alpha2weight(alpha, ray_id, n_rays)
+    got = ru.alpha2weight(alpha.cuda(), ray_id.cuda(), n_rays)
+    for r, t in zip(ref, got):
+        assert r.dtype == t.dtype and torch.equal(r, t.cpu())
+    gw, gl = torch.from_numpy(g.normal(size=len(alpha))), torch.from_numpy(g.normal(size=n_rays))
+    b_ref = native.alpha2weight_backward(alpha, *ref, n_rays, gw, gl)
+    b_got = ru.alpha2weight_backward(alpha.cuda(), *got, n_rays, gw.cuda(), gl.cuda())
+    assert b_got.dtype == torch.float64 and torch.equal(b_ref, b_got.cpu())

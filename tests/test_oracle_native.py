@@ -315,3 +315,92 @@ def test_dead_masked_tv_add_grad(dense):
     ref = g0.double() + (add if dense else add * (g0 != 0))
     assert float((grad.double() - ref).abs().max()) < 1e-6
     assert bool(((grad - g0) != 0).any())
+
+
+# ---- the reference's DOUBLE instantiation of the three live ops: float locals inside double kernels
+def np_sample_f64(o, d, bmin, bmax, near, far, stepdist):
+    """numpy statement of render_utils_kernel.cu:12-79,167-194 with scalar_t = double: every `float` local of the kernels is an
+    explicit astype(float32), everything else float64."""
+    f, D = np.float32, np.float64
+    o, d, bmin, bmax = o.astype(D), d.astype(D), bmin.astype(D), bmax.astype(D)
+    v = np.where(d == 0, D(1e-6), d).astype(f)
+    a = ((bmax - o) / v.astype(D)).astype(f)
+    b = ((bmin - o) / v.astype(D)).astype(f)
+    tmin = np.maximum(np.minimum(np.minimum(a, b).max(-1), f(far)), f(near)).astype(f)
+    tmax = np.maximum(np.minimum(np.maximum(a, b).min(-1), f(far)), f(near)).astype(f)
+    nrm = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]).astype(f)
+    ln = (tmax.astype(D) - tmin.astype(D)) * nrm.astype(D) / D(f(stepdist))
+    n = np.maximum(np.ceil(ln), 1.0).astype(np.int64)
+    start = o + d * tmin.astype(D)[:, None]
+    dr = d / nrm.astype(D)[:, None]
+    ray_id = np.repeat(np.arange(len(n)), n)
+    step = np.concatenate([np.arange(k) for k in n]) if len(n) else np.zeros(0, np.int64)
+    dist = (f(stepdist) * step.astype(f)).astype(f)
+    pts = (start[ray_id] + dr[ray_id] * dist.astype(D)[:, None]).astype(f)
+    out = ((bmin > pts.astype(D)) | (bmax < pts.astype(D))).any(-1)
+    return pts.astype(D), out, ray_id, step, n, tmin.astype(D), tmax.astype(D)
+
+
+@pytest.mark.parametrize("n,seed", [(1, 0), (300, 2), (3000, 5)])
+def test_sampler_double_instantiation(n, seed):
+    o, d = rand_rays(n, seed)
+    g = np.random.default_rng(seed + 100)
+    o = o.astype(np.float64) + g.normal(size=o.shape) * 1e-9          # values that are NOT floats: the roundings matter
+    d = d.astype(np.float64) * (1 + g.normal(size=d.shape) * 1e-9)
+    bmin, bmax = np.array([-1, -0.8, -0.5]), np.array([1, 0.9, 0.25])
+    ref = np_sample_f64(o, d, bmin, bmax, 0.05, 1e9, 0.0123)
+    to = torch.from_numpy
+    got = native.sample_pts_on_rays(to(o), to(d), to(bmin), to(bmax), 0.05, 1e9, 0.0123)
+    assert got[0].dtype == torch.float64 and got[5].dtype == torch.float64 and got[4].dtype == torch.int64
+    for nm, r, t in zip(["pts", "mask", "ray_id", "step_id", "n_steps", "t_min", "t_max"], ref, got):
+        assert np.array_equal(np.asarray(r), t.numpy()), nm
+    # float-valued although stored as doubles (the kernels' float locals)
+    assert np.array_equal(got[0].numpy(), got[0].numpy().astype(np.float32).astype(np.float64))
+    # and close to, but not the same as, the fp32 instantiation on the rounded inputs
+    f32 = native.sample_pts_on_rays(to(o).float(), to(d).float(), to(bmin).float(), to(bmax).float(), 0.05, 1e9, 0.0123)
+    assert abs(int(f32[4].sum()) - int(got[4].sum())) <= max(2, n // 100)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_alpha2weight_double_instantiation(seed):
+    g = np.random.default_rng(seed)
+    n_rays = 60
+    counts = g.integers(0, 40, n_rays)
+    counts[3] = 0
+    ray_id = np.repeat(np.arange(n_rays), counts)
+    alpha = g.uniform(0, 1, len(ray_id)) ** 3
+    alpha[g.uniform(size=len(alpha)) < 0.1] = 0.9999
+    f, D = np.float32, np.float64
+    w, T = np.zeros(len(alpha)), np.ones(len(alpha))
+    last, i_s, i_e = np.ones(n_rays), np.zeros(n_rays, np.int64), np.zeros(n_rays, np.int64)
+    for r in range(n_rays):
+        seg = np.nonzero(ray_id == r)[0]
+        if len(seg):
+            i_s[r], i_e[r] = seg[0], seg[-1] + 1
+    # (rays without samples keep 0 / 0; a ray FOLLOWING an empty one still starts where its samples do)
+    for r in range(n_rays):
+        tc, i = f(1.0), i_s[r]
+        while i < i_e[r]:
+            T[i] = D(tc)
+            w[i] = D(tc) * alpha[i]
+            tc = f(D(tc) * (1.0 - alpha[i]))                     # `float T_cum` in a double kernel
+            i += 1
+            if D(tc) < 1e-3:
+                break
+        if len(np.nonzero(ray_id == r)[0]):
+            i_e[r] = i
+        last[r] = D(tc)
+    to = torch.from_numpy
+    got = native.alpha2weight(to(alpha), to(ray_id), n_rays)
+    assert got[0].dtype == torch.float64
+    assert np.array_equal(got[0].numpy(), w) and np.array_equal(got[1].numpy(), T) and np.array_equal(got[2].numpy(), last)
+    assert np.array_equal(got[4].numpy(), i_e)
+    gw, gl = g.normal(size=len(alpha)), g.normal(size=n_rays)
+    grad = native.alpha2weight_backward(to(alpha), *got, n_rays, to(gw), to(gl)).numpy()
+    exp = np.zeros(len(alpha))
+    for r in range(n_rays):
+        back = f(gl[r] * last[r])                                 # `float back_cum`
+        for i in range(i_e[r] - 1, i_s[r] - 1, -1):
+            exp[i] = gw[i] * T[i] - D(back) / ((1.0 - alpha[i]) + 1e-10)
+            back = f(D(back) + gw[i] * w[i])
+    assert grad.dtype == np.float64 and np.array_equal(grad, exp)
