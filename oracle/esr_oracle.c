@@ -447,3 +447,45 @@ ESR_API void esr_oracle_alpha2weight_backward_f64(const double *alpha, const dou
         }
     }
 }
+
+/* ---- what-if: the sampler with the contractions nvcc's default -fmad=true would most plausibly make -----------------
+ * The reference JIT-builds its kernels with torch's default nvcc flags (app/utils/base/functions.py:14-31), so a*b+c patterns
+ * of the real binary are fused; which ones is the compiler's choice and cannot be observed here (no nvcc).  This variant fuses
+ * every multiply-add of the sampler's statements (sum of squares, start = o + d t_min, point = start + dir dist) and exists only
+ * to MEASURE how far such a build can be from the separately rounded statement above (tests/test_oracle_native.py,
+ * DESIGN.md section 3); nothing compares the HIP kernels with it. */
+ESR_API void esr_oracle_sample_count_fma(const float *rays_o, const float *rays_d, const float *xyz_min, const float *xyz_max,
+                                         float near_, float far_, float stepdist, int64_t n_rays, float *t_min, float *t_max,
+                                         int64_t *n_steps)
+{
+    for (int64_t r = 0; r < n_rays; ++r) {
+        const float *o = rays_o + 3 * r, *d = rays_d + 3 * r;
+        ray_t_range(o, d, xyz_min, xyz_max, near_, far_, &t_min[r], &t_max[r]);
+        const float nrm = sqrtf(fmaf(d[2], d[2], fmaf(d[1], d[1], d[0] * d[0])));
+        float len = (t_max[r] - t_min[r]) * nrm / stepdist;
+        double c = (double)ceilf(len);
+        n_steps[r] = (int64_t)(c > 1.0 ? c : 1.0);
+    }
+}
+
+ESR_API void esr_oracle_sample_fill_fma(const float *rays_o, const float *rays_d, const float *xyz_min, const float *xyz_max,
+                                        const float *t_min, const int64_t *n_steps, float stepdist, int64_t n_rays,
+                                        float *ray_pts, uint8_t *mask_outbbox)
+{
+    int64_t at = 0;
+    for (int64_t r = 0; r < n_rays; ++r) {
+        const float *o = rays_o + 3 * r, *d = rays_d + 3 * r;
+        const float nrm = sqrtf(fmaf(d[2], d[2], fmaf(d[1], d[1], d[0] * d[0])));
+        for (int64_t s = 0; s < n_steps[r]; ++s, ++at) {
+            const float dist = stepdist * (float)(int)s;
+            int out = 0;
+            for (int a = 0; a < 3; ++a) {
+                const float start = fmaf(d[a], t_min[r], o[a]);
+                const float p = fmaf(d[a] / nrm, dist, start);
+                ray_pts[3 * at + a] = p;
+                out |= (xyz_min[a] > p) | (xyz_max[a] < p);
+            }
+            mask_outbbox[at] = (uint8_t)out;
+        }
+    }
+}

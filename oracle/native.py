@@ -280,6 +280,24 @@ def total_variation_add_grad_new(param, grad, mask, wx, wy, wz, dense_mode):
         ctypes.c_int64(param.numel()), ctypes.c_int(1 if dense_mode else 0))
 
 
+def sample_pts_on_rays_fma(rays_o, rays_d, xyz_min, xyz_max, near, far, stepdist):
+    """WHAT-IF variant of the fp32 sampler with every multiply-add fused (esr_oracle.c: what nvcc's default contraction could
+    make of the reference's statements) -> [ray_pts, mask_outbbox, N_steps, t_min, t_max].  Measurement only."""
+    rays_o, rays_d, xyz_min, xyz_max = _f32(rays_o), _f32(rays_d), _f32(xyz_min), _f32(xyz_max)
+    n = rays_o.shape[0]
+    t_min, t_max = torch.empty(n, dtype=torch.float32), torch.empty(n, dtype=torch.float32)
+    n_steps = torch.empty(n, dtype=torch.int64)
+    L = lib()
+    L.esr_oracle_sample_count_fma(_p(rays_o), _p(rays_d), _p(xyz_min), _p(xyz_max), ctypes.c_float(float(near)),
+                                  ctypes.c_float(float(far)), ctypes.c_float(float(stepdist)), ctypes.c_int64(n),
+                                  _p(t_min), _p(t_max), _p(n_steps))
+    total = int(n_steps.sum().item())
+    pts, mask = torch.empty(total, 3, dtype=torch.float32), torch.empty(total, dtype=torch.uint8)
+    L.esr_oracle_sample_fill_fma(_p(rays_o), _p(rays_d), _p(xyz_min), _p(xyz_max), _p(t_min), _p(n_steps),
+                                 ctypes.c_float(float(stepdist)), ctypes.c_int64(n), _p(pts), _p(mask))
+    return [pts, mask.bool(), n_steps, t_min, t_max]
+
+
 class _Namespace:
     """Stand-in for the pybind module object the reference imports."""
 

@@ -404,3 +404,35 @@ def test_alpha2weight_double_instantiation(seed):
             exp[i] = gw[i] * T[i] - D(back) / ((1.0 - alpha[i]) + 1e-10)
             back = f(D(back) + gw[i] * w[i])
     assert grad.dtype == np.float64 and np.array_equal(grad, exp)
+
+
+def test_what_if_the_reference_binary_contracts_multiply_adds():
+    """DESIGN.md section 3, stated limit (ii): the reference's kernels are built with nvcc's default contraction, the oracle (and
+    sampler.hip) round every operation separately, and the real binary cannot be run here.  The oracle's what-if variant fuses
+    EVERY multiply-add of the sampler's statements; on the ray sets of the BASELINE configurations this is how far such a build
+    can be: NO ray changes its step count, a sample point moves by at most an ulp of its box coordinate, and the only discrete
+    output that changes is the out-of-box flag of a ray's ENTRY sample, which lies ON the box face (distance exactly 0) -- a
+    sample in empty space in front of the mask cache, so nothing behind the sampler sees it."""
+    from esr_nerf_amd.config import fine_cfg
+    from esr_nerf_amd.synthetic import slab_scene
+    from oracle import fine_path as fp
+    seen_flip = False
+    for name, kw in (("C2", dict(s_val=20.0)), ("C2", dict(s_val=20.0, oblique=True)), ("C4", dict(s_val=220.0))):
+        sc = slab_scene(name, **kw)
+        c = fp.make_consts(fine_cfg("cpu").app.model, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max,
+                           sc.mask_alpha_init, sc.mask_density, sc.near, sc.num_voxels)
+        sd = float(c.stepsize * c.voxel_size)
+        b = sc.batch
+        a = native.sample_pts_on_rays(b["rays_o"], b["rays_d"], sc.xyz_min, sc.xyz_max, sc.near, 1e9, sd)
+        f = native.sample_pts_on_rays_fma(b["rays_o"], b["rays_d"], sc.xyz_min, sc.xyz_max, sc.near, 1e9, sd)
+        assert torch.equal(a[4], f[2]), name                                  # step counts: identical
+        assert float((a[0] - f[0]).abs().max()) <= 2.4e-7                     # <= one ulp of a coordinate of size <= 2
+        flip = (a[1] != f[1]).nonzero()[:, 0]
+        if flip.numel():
+            seen_flip = True
+            assert bool((a[3][flip] == 0).all())                              # entry samples only
+            p = a[0][flip]
+            on_face = torch.minimum((p - sc.xyz_min).abs(), (p - sc.xyz_max).abs()).min(-1).values
+            assert float(on_face.max()) == 0.0
+            assert flip.numel() < 0.003 * a[1].numel()
+    assert seen_flip                                                          # (the oblique set: ~1000 of 406 k samples)
