@@ -316,3 +316,31 @@ def test_alpha2weight_double_instantiation_bit_exact(ru, native, seed, n_rays, m
     b_ref = native.alpha2weight_backward(alpha, *ref, n_rays, gw, gl)
     b_got = ru.alpha2weight_backward(alpha.cuda(), *got, n_rays, gw.cuda(), gl.cuda())
     assert b_got.dtype == torch.float64 and torch.equal(b_ref, b_got.cpu())
+
+
+def test_dead_ops_empty_inputs_and_type_errors(ru):
+    """Zero rays / points / samples launch nothing and return tensors of the reference's shapes and dtypes; a CPU or fp64 tensor
+    is refused (these ops are fp32 only)."""
+    dev = "cuda"
+    e3, e1 = torch.zeros(0, 3, device=dev), torch.zeros(0, device=dev)
+    b = torch.tensor([-1.0, -1.0, -1.0], device=dev)
+    t = ru.infer_t_minmax(e3, e3, b, -b, 0.1, 5.0)
+    assert t[0].shape == (0,) and t[1].dtype == torch.float32
+    assert ru.infer_n_samples(e3, e1, e1, 0.01).dtype == torch.int64
+    assert ru.infer_ray_start_dir(e3, e3, e1)[1].shape == (0, 3)
+    p, m = ru.sample_ndc_pts_on_rays(e3, e3, b, -b, 8)
+    assert p.shape == (0, 8, 3) and m.shape == (0, 8) and m.dtype == torch.bool
+    o = torch.rand(5, 3, device=dev)
+    p, m = ru.sample_ndc_pts_on_rays(o, o, b, -b, 0)
+    assert p.shape == (5, 0, 3)
+    assert ru.sample_bg_pts_on_rays(e3, e3, e1, 0.5, 4).shape == (0, 4, 3)
+    ex, al = ru.raw2alpha(e1, 0.0, 0.5)
+    assert ex.shape == al.shape == (0,)
+    assert ru.raw2alpha_backward(e1, e1, 0.5).shape == (0,)
+    g = torch.zeros(1, 1, 2, 2, 2, device=dev)
+    ru.total_variation_add_grad_new(torch.ones_like(g), g, torch.ones_like(g), 1.0, 1.0, 1.0, True)
+    assert float(g.abs().max()) == 0.0                                   # a constant field has no variation
+    with pytest.raises(RuntimeError, match="float32"):
+        ru.raw2alpha(torch.zeros(4, device=dev, dtype=torch.float64), 0.0, 0.5)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        ru.infer_n_samples(torch.zeros(3, 3), torch.zeros(3), torch.zeros(3), 0.1)

@@ -37,6 +37,20 @@ def test_bf16_minus_f32_psnr_is_resolved_inside_the_bar(name, min_seeds):
     assert len(diffs) == st["n"] and abs(sum(diffs) / len(diffs) - st["mean"]) < 1e-9
 
 
+def test_split_fp16_engine_trains_like_the_f32_mfma_engine():
+    """The f32 engine's arithmetic (split fp16 planes, fp32 results) against every product on the f32 MFMA pipe, same training
+    experiments: fine stage resolved to a hundredth of the bar; the PDRA stage is chaotic per run (two runs of ONE engine end
+    0.55 dB apart, one sigma), so the file is a noise-floor record: the interval contains 0 and the scatter is the rerun scatter."""
+    d = _load("r05_psnr_fine_split_vs_mfma.json")
+    st = d["bf16_minus_f32"]                              # (the tool's key; here: f32mfma - split, d["other"] says so)
+    assert d["other"] == "f32mfma" and st["n"] >= 200
+    assert -0.01 < st["ci95"][0] and st["ci95"][1] < 0.01 and st["sd"] < 0.05, st
+    p = _load("r05_psnr_pdra_split_vs_mfma.json")
+    sp = p["bf16_minus_f32"]
+    assert p["other"] == "f32mfma" and sp["n"] >= 300
+    assert sp["ci95"][0] <= 0.0 <= sp["ci95"][1] and sp["ci95_half_width"] < 0.1 and sp["sd"] < 0.9, sp
+
+
 def test_statistics_tool_merges_parts_and_rebuilds_a_summary_from_a_cut_call(tmp_path):
     """tools/psnr_teacher_student.py --merge (several calls' seeds into one file, a seed counted once, statistics recomputed)
     and --from-log (a call cut at its time limit: the per-run lines it printed) -- how profiles/r05_psnr_*.json were put
