@@ -13,14 +13,14 @@ node over the kernels of libesr_hip.so (esr_nerf_amd/lts_engine.py).
 """
 from __future__ import annotations
 
-from typing import Dict, List
+from typing import List
 
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fine_engine import KIND_RADIANCE, KIND_TONEMAP, make_scene
+from .fine_engine import KIND_RADIANCE, KIND_TONEMAP
 from .lts_engine import KIND_BRDF, KIND_EMIT, LtsEngine
 from .modules import DenseGrid, _mlp_stack, _linears
 from .voxurff import VoxurfF

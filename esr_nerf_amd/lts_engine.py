@@ -14,7 +14,6 @@ where the reference draws them) and for the autograd edge.
 """
 from __future__ import annotations
 
-import os
 
 import ctypes as C
 import math

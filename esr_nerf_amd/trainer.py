@@ -477,8 +477,6 @@ class LtsStep:
 
     def _pair(self, eng, loss, a, b, kind, w_value, w_a, w_b, scale, want_gb=True, row_mask=None, mask_value=0,
               count=None):
-        import ctypes as C
-        from . import _lib
         a = a.contiguous()
         ga = torch.empty_like(a)
         gb = torch.empty_like(a) if (b is not None and want_gb) else None
