@@ -632,9 +632,12 @@ class FinetuneStep:
         self._flat = None
         self._names = [f"emo_rgbnet.linear.{k}.{p}" for k, sub in model.emo_rgbnet.linear.named_modules()
                        if isinstance(sub, torch.nn.Linear) for p in ("weight", "bias")]
-        self._pair = LtsStep._pair.__get__(self)          # (the two-operand loss helpers of LtsStep, on this object)
-        self._pair_flush = LtsStep._pair_flush.__get__(self)
         self._pair_jobs = []
+
+    # the two-operand loss helpers of LtsStep, as methods of this class (class attributes, not bound methods stored on the
+    # instance: that would make every step object a reference cycle holding its gradient buffer -- modules.ForwardSwitch)
+    _pair = LtsStep._pair
+    _pair_flush = LtsStep._pair_flush
 
     def _alloc_grads(self, dev):
         m = self.model

@@ -541,7 +541,7 @@ def test_lts_step_heals_a_range_overflow_in_the_same_step_with_the_same_draws(st
     assert not bad, str(bad)
 
 
-@pytest.mark.parametrize("route", ["step", "autograd"])
+@pytest.mark.parametrize("route", ["step", "autograd", "finetune_step", "fine_step"])
 def test_a_dropped_model_gives_its_device_memory_back_without_the_cycle_collector(route):
     """A model + step object that go out of scope free their workspaces at once, by reference count: device memory pressure
     does not trigger Python's cycle collector, so anything that needs it accumulates (a 140-experiment statistics run of round
@@ -559,6 +559,14 @@ def test_a_dropped_model_gives_its_device_memory_back_without_the_cycle_collecto
     b["uncert_masks"] = (torch.arange(n_rays) % 2 == 0).cuda()
 
     def run():
+        if route == "fine_step":
+            from esr_nerf_amd.trainer import FineStep
+            from test_gpu_fine_path import build_gpu_model
+            with FineStep(build_gpu_model(sc, seed=1, grid_seed=2)) as step:
+                for _ in range(2):
+                    step.forward_loss_backward(b, s_val)
+            torch.cuda.synchronize()
+            return
         m, cfg = build_lts_model(sc, num_2ndrays=8, num_ltspts=16)
         init_slab_model(m, sc, seed=3)
         tr = cfg.app.trainer
@@ -566,6 +574,13 @@ def test_a_dropped_model_gives_its_device_memory_back_without_the_cycle_collecto
             with LtsStep(m, tr, stage="lts") as step:
                 for _ in range(2):
                     step.forward_loss_backward(b, s_val)
+        elif route == "finetune_step":
+            from esr_nerf_amd.trainer import FinetuneStep
+            m.train(True, finetune=True)
+            fb = dict(b, em_intensities=torch.ones(n_rays, device="cuda"), em_colors=torch.full((n_rays, 2), 0.5, device="cuda"))
+            step = FinetuneStep(m)
+            for _ in range(2):
+                step.forward_loss_backward(fb, s_val)
         else:
             for _ in range(2):
                 res = m(rays_o=b["rays_o"], rays_d=b["rays_d"], viewdirs=b["viewdirs"], em_modes=b["em_modes"],
