@@ -12,8 +12,23 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def pytest_addoption(parser):
+    parser.addoption("--runslow", action="store_true", default=False,
+                     help="also run the tests marked slow (minutes of GPU time: regeneration of the committed PSNR statistics)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if config.getoption("--runslow"):
+        return
+    skip = pytest.mark.skip(reason="slow: needs --runslow")
+    for item in items:
+        if "slow" in item.keywords:
+            item.add_marker(skip)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes of GPU time; skipped unless --runslow is given")
     # the CPU oracle is the checker of the GPU tests; a GPU box hands one GPU's share of its host cores (16) to this
     # process while os.cpu_count() reports all of them -- torch's default thread count oversubscribes 8x there
     if torch.cuda.device_count() > 0:

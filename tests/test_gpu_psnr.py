@@ -135,3 +135,32 @@ def test_fine_stage_split_fp16_engine_trains_like_the_f32_mfma_engine():
         print(f"fine seed {seed}: split-fp16 engine {rs[steps]:.4f} dB, f32-MFMA engine {rm[steps]:.4f} dB")
         assert rs[steps] > rs[0] + 8.0 and rm[steps] > rm[0] + 8.0
         assert abs(rs[steps] - rm[steps]) < 0.02, (seed, rs[steps], rm[steps])
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("stage,steps,seeds,name", [("fine", 100, 96, "r05_psnr_fine.json"), ("finetune", 80, 12, "r05_psnr_finetune.json"),
+                                                    ("pdra", 200, 96, "r05_psnr_pdra.json")])
+def test_committed_psnr_statistics_regenerate(stage, steps, seeds, name):
+    """The statistics tests/test_psnr_statistics.py asserts come from profiles/r05_psnr_*.json; this regenerates a slice of each
+    on the current build (--runslow: ~1 / 0.5 / 4 minutes of GPU time) and checks that the slice is a sample of the same
+    distribution: its per-seed scores for the committed seeds agree where the stage is reproducible (fine-tune: to 0.05 dB),
+    and its mean paired difference lies within three standard errors of the committed mean."""
+    import json
+    import math
+    import os
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", name)))
+    assert ref["stage"] == stage and ref["steps"] == steps
+    run = dict(fine=ts.fine_experiment, finetune=ts.finetune_experiment, pdra=ts.pdra_experiment)[stage]
+    by_seed = {r["seed"]: r for r in ref["per_seed"]}
+    diffs = []
+    for seed in range(seeds):
+        r32 = run("f32", steps=steps, seed=seed)[0]
+        r16 = run("bf16", steps=steps, seed=seed)[0]
+        diffs.append(r16[steps] - r32[steps])
+        if stage == "finetune" and seed in by_seed:
+            assert abs(r32[steps] - by_seed[seed]["f32"]) < 0.05 and abs(r16[steps] - by_seed[seed]["bf16"]) < 0.05
+    st = ts.paired_stats(diffs)
+    se = max(ref["bf16_minus_f32"]["sd"], st["sd"]) / math.sqrt(seeds)
+    print(f"{stage}: regenerated mean {st['mean']:+.4f} dB over {seeds} seeds (committed {ref['bf16_minus_f32']['mean']:+.4f} over "
+          f"{ref['bf16_minus_f32']['n']}), standard error {se:.4f}")
+    assert abs(st["mean"] - ref["bf16_minus_f32"]["mean"]) < 3.0 * se + 1e-3
