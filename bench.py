@@ -115,6 +115,9 @@ def parse():
     ap.add_argument("--split-variant", type=int, default=0,
                     help="esr_mlp_split_variant: 0 = the one-wave-per-SIMD radiance kernels (the product), 1 = wave-pair kernels in both "
                          "directions, 2 = in the input gradients only (A/B timing of the round-5 experiment, DESIGN.md section 4)")
+    ap.add_argument("--step-times", action="store_true",
+                    help="diagnostic: record a HIP event behind every timed step and print the per-step times (ms) to stderr -- how "
+                         "long the step takes to reach its steady state after the warm-up (clocks, caches)")
     ap.add_argument("--serial", action="store_true",
                     help="every kernel on ONE stream (no weight gradients beside the scatters, no side streams in the LTS steps): "
                          "for rocprofv3 kernel statistics, whose per-kernel times should not include what ran beside them")
@@ -527,10 +530,11 @@ def main():
         return step.forward_loss_backward(batch, a.s_val, global_rays=n_rays * world if pg is not None else None,
                                           entropy_owner=(rank == world - 1))[:2]
 
-    # Warm-up = W steps.  Up to three of them (after the first, which allocates the workspace) carry HIP events
-    # around EVERY kernel: the full breakdown and which kernel dominates.  Bracketing everything costs ~2 ms/step and
-    # reading the events back idles the GPU, so these steps come FIRST and the plain warm-up steps run last, right
-    # before the timed region.
+    # Warm-up = W PLAIN steps, exactly the steps that are timed afterwards (round 5: until then up to three of them were the
+    # instrumented ones below -- serialised kernels, events around every launch -- which left the device in another state
+    # than the timed steps find it in: with the driver's short warm-up the first ~10 timed steps ran 5-20 % slower,
+    # `--step-times`).  The per-kernel breakdown (HIP events around EVERY launch, kernels serialised: ~2 ms per step and a
+    # read-back that idles the GPU) is taken in up to three EXTRA steps AFTER the timed region, like the optimizer and TV timings.
     # A generation-2 pass of Python's cyclic GC over this process (torch modules, thousands of tensors) takes
     # 50-110 ms -- twenty steps' worth of GPU idle when it lands inside a launch sequence (seen as a "112 ms
     # feat_bwd").  Collect now, park the survivors, and keep the collector off while kernels are being timed.
@@ -538,22 +542,57 @@ def main():
     gc.collect()
     gc.freeze()
     gc.disable()
-    n_prof = 0 if a.no_kernel_timing else max(0, min(3, a.warmup - 1))
-    n_lead = 1 if a.warmup > n_prof else 0
-    for _ in range(n_lead):
-        one()
+    n_prof = 0 if a.no_kernel_timing else 3
+    for i_ in range(a.warmup):
+        one(i_)
+    # timed region: exactly K steps; the fine stage's three large launches carry one event pair each (on their stream) -- which
+    # of them dominates is decided from the breakdown afterwards
+    in_region = ["mlp_fwd(rad)", "mlp_dgrad(rad)", "mlp_wgrad(all)"] if (n_prof and stage == "fine") else None
+    eng.enable_timing(in_region is not None, only=in_region)
+    if pg is not None:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    calls0 = getattr(eng, "n_calls", 0)
+    marks = []
+    if a.step_times:
+        marks.append(torch.cuda.Event(enable_timing=True))
+        marks[0].record()
+    t0 = time.perf_counter()
+    for i_ in range(a.steps):
+        loss, _ = one(i_)
+        if a.step_times:
+            marks.append(torch.cuda.Event(enable_timing=True))
+            marks[-1].record()
+    torch.cuda.synchronize()
+    if marks and rank == 0:
+        print("step times (ms, device):", [round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(len(marks) - 1)], file=sys.stderr)
+    if pg is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    calls_per_step = (getattr(eng, "n_calls", 0) - calls0) / max(a.steps, 1)
+    if pg is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern = eng.timing_summary() if in_region else {}     # the bracketed launches: name -> (launches, total ms)
+    eng.enable_timing(False)
+    # the instrumented steps (outside W and K; every rank runs them: a step is collective when N > 1)
     breakdown, dominant = {}, None
     if n_prof:
         torch.cuda.synchronize()
         eng.enable_timing(True)
         overlap, eng.overlap_wgrad = eng.overlap_wgrad, False    # one kernel at a time while each is being timed
-        for _ in range(n_prof):
-            one()
+        for i_ in range(n_prof):
+            one(i_)
         breakdown = {k: (n, ms) for k, (n, ms) in eng.timing_summary().items()}
         eng.overlap_wgrad = overlap
         eng.enable_timing(False)
-    for i_ in range(a.warmup - n_prof - n_lead):
-        one(i_)
+    if step is not None and hasattr(step, "close"):
+        step.close()                                     # data parallel: the last step's deferred march-overflow flag (every rank raises)
+    gc.enable()
+    counts = dict(model.last_counts, merged_off_pass=(stage == "fine"))
     if n_prof:
         counts = dict(model.last_counts, merged_off_pass=(stage == "fine"))
         by_kernel = {}
@@ -596,32 +635,8 @@ def main():
         split_wg = split_bwd and bool(getattr(eng, "split_wgrad", False))
         dominant, dom_calls = ((SPLIT_KERNELS["mlp_fwd(rad)"], ["mlp_fwd(rad)"]) if split_fwd else
                                ("mlp_fwd_kernel<0>", ["mlp_fwd(rad)"]))
-    # timed region: exactly K steps, events only around the dominant kernel's launches (on their stream)
-    eng.enable_timing(dominant is not None, only=dom_calls if dominant else None)
-    if pg is not None:
-        import torch.distributed as dist
-        dist.barrier()
-    torch.cuda.synchronize()
-    calls0 = getattr(eng, "n_calls", 0)
-    t0 = time.perf_counter()
-    for i_ in range(a.steps):
-        loss, _ = one(i_)
-    torch.cuda.synchronize()
-    if pg is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    calls_per_step = (getattr(eng, "n_calls", 0) - calls0) / max(a.steps, 1)
-    if pg is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    if step is not None and hasattr(step, "close"):
-        step.close()                                     # data parallel: the last step's deferred march-overflow flag (every rank raises)
-    kern = eng.timing_summary() if dominant else {}      # dominant kernel only: name -> (launches, total ms)
-    eng.enable_timing(False)
-    gc.enable()
-    counts = dict(model.last_counts, merged_off_pass=(stage == "fine"))
+    if dominant and not all(c in kern for c in dom_calls):
+        dominant, dom_calls = None, []                     # (not one of the bracketed launches: no in-region figure for it)
 
     # optimizer step, reported separately (outside the named path, never part of `value`)
     opt_ms = None
@@ -799,7 +814,7 @@ def main():
                                         "hbm_frac": hf, "mfma_frac": mf_,
                                         "algorithmic_mb_per_launch": bytes_total / launches / 1e6,
                                         "mfma_tflops": ach, "mfma_frac_of_bf16_peak": mf_})
-            # the whole MLP engine (all 10 calls per step), from the instrumented warm-up steps
+            # the whole MLP engine (all 10 calls per step), from the instrumented steps behind the timed region
             mlp = {k: v for k, v in breakdown.items() if algorithmic_flops(k, counts)
                    and not (split_fwd and k == "mlp_fwd(rad)") and not (split_fwd and split_bwd and k == "mlp_dgrad(rad)")
                    and not (split_wg and k == "mlp_wgrad(all)")
@@ -903,10 +918,10 @@ def main():
                         "`frac` is the step's algorithmic FLOP rate over the f32 matrix peak, kept for comparison with earlier "
                         "rounds -- it is no longer bounded by 1 in principle; the f32-pipe launches are priced one by one in "
                         "roofline / all_mlp_kernels")
-                out["kernel_ms_per_step_warmup"] = {k: round(v[1] / v[0], 4) for k, v in
+                out["kernel_ms_per_step_instrumented"] = {k: round(v[1] / v[0], 4) for k, v in
                                                     sorted(breakdown.items(), key=lambda kv: -kv[1][1])}
-        if breakdown and "kernel_ms_per_step_warmup" not in out:
-            out["kernel_ms_per_step_warmup"] = {k: round(v[1] / max(n_prof, 1), 4) for k, v in
+        if breakdown and "kernel_ms_per_step_instrumented" not in out:
+            out["kernel_ms_per_step_instrumented"] = {k: round(v[1] / max(n_prof, 1), 4) for k, v in
                                                 sorted(breakdown.items(), key=lambda kv: -kv[1][1])}
         if breakdown and stage != "fine":
             bf = a.dtype == "bf16"
@@ -914,7 +929,7 @@ def main():
             total_ms = sum(ms_ for _, ms_ in breakdown.values()) / max(n_prof, 1)
             tf, gbs = fl / (ms_mlp * 1e-3) / 1e12, by / (ms_mlp * 1e-3) / 1e9
             peak = MFMA_BF16_PEAK_TF if bf else MFMA_F32_PEAK_TF
-            rl = {"kernel": "all mlp_fwd/dgrad/wgrad launches of the step (HIP events, instrumented warm-up steps: every launch alone on "
+            rl = {"kernel": "all mlp_fwd/dgrad/wgrad launches of the step (HIP events, instrumented steps behind the timed region: every launch alone on "
                             "one stream; the timed steps run the backward on three streams)",
                   "traffic": pmc_traffic(a, stage, ["__step__"]), "mlp_ms_per_step": ms_mlp,
                   "share_of_kernel_time": ms_mlp / total_ms, "kernel_ms_per_step": total_ms,

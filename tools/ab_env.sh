@@ -15,7 +15,7 @@ for v in "${VARS[@]}"; do
 import json, sys
 try:
     d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
-    k = d.get("kernel_ms_per_step_warmup", {})
+    k = (d.get("kernel_ms_per_step_instrumented") or d.get("kernel_ms_per_step_warmup", {}))
     top = ", ".join(f"{a} {b:.3f}" for a, b in list(k.items())[:12])
     print(f"[{sys.argv[1]}] ms/step {d['ms_per_step']:.4f}  rays/s {d['value']:.0f}  loss {d.get('loss')}\n    {top}")
 except Exception as e:

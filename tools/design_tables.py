@@ -24,7 +24,7 @@ for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{tag}_bench_*.json"))
           f"{(r.get('kernel') or '')[:26]} frac {r.get('frac') or 0:.2f} hbm {r.get('hbm_frac') or 0:.2f} mfma {r.get('mfma_frac') or 0:.2f}"
           + (f" whole-step {ws:.2f}" if ws else ""))
     if name == "c2_f32":
-        for k, v in d.get("kernel_ms_per_step_warmup", {}).items():
+        for k, v in (d.get("kernel_ms_per_step_instrumented") or d.get("kernel_ms_per_step_warmup", {})).items():
             print(f"      {k:18s} {v:.3f}")
         for k in ("split_forward", "split_dgrad", "split_wgrad"):
             b = r.get(k) or {}
