@@ -160,6 +160,85 @@ dist.destroy_process_group()
 '''
 
 
+LTS_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import torch
+import torch.distributed as dist
+from esr_nerf_amd.config import lts_cfg
+from esr_nerf_amd.esrnerf import ESRNeRF
+from esr_nerf_amd.synthetic import init_slab_model, slab_scene
+from esr_nerf_amd.trainer import LtsStep, shard_batch
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+torch.cuda.set_device(0)
+s_val = 60.0
+sc = slab_scene("small", s_val=s_val, oblique=True, n_rays=384, seed=2)
+torch.manual_seed(0); np.random.seed(0)
+cfg = lts_cfg("cuda:0", num_2ndrays=16, num_ltspts=24)
+m = ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max, sc.mask_alpha_init,
+            sc.mask_density, sc.s_val, sc.num_voxels)
+init_slab_model(m, sc, seed=3)
+with torch.no_grad():
+    m.brdf.grid.normal_(0.0, 0.3, generator=torch.Generator(device="cuda").manual_seed(5))
+m.train()
+full = {k: v.cuda() for k, v in sc.batch.items()}
+full["uncert_masks"] = (torch.arange(384, device="cuda") % 3 == 0)
+n = 384
+worst = 0.0
+for stage in ("lts", "pdra"):
+    m.pdra_mode = stage == "pdra"
+    for split_points in (False, True):
+        # the data-parallel step: every rank its ray shard and its own draws (seeded per rank)
+        step = LtsStep(m, cfg.app.trainer, stage=stage, process_group=dist.group.WORLD, split_points=split_points)
+        torch.manual_seed(100 + rank); np.random.seed(100 + rank)
+        loss, G, _ = step.forward_loss_backward(shard_batch(full, rank, world), s_val, global_rays=n, entropy_owner=(rank == world - 1))
+        torch.cuda.synchronize()
+        loss, G = float(loss), {k: v.clone() for k, v in G.items()}
+        step.close()
+        # what it must equal: the SUM over the shards of the single-process steps on each shard with the same draws and the
+        # same global normalisation (every rank computes all of them locally)
+        ref_loss, ref = 0.0, None
+        for r in range(world):
+            one = LtsStep(m, cfg.app.trainer, stage=stage)
+            one.ltspts = step.ltspts
+            torch.manual_seed(100 + r); np.random.seed(100 + r)
+            l_r, G_r, _ = one.forward_loss_backward(shard_batch(full, r, world), s_val, global_rays=n, entropy_owner=(r == world - 1))
+            torch.cuda.synchronize()
+            ref_loss += float(l_r)
+            ref = {k: v.clone() for k, v in G_r.items()} if ref is None else {k: ref[k] + G_r[k] for k in ref}
+        assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss)), (stage, split_points, loss, ref_loss)
+        assert set(G) == set(ref) and len(G) == 43
+        for k, v in ref.items():
+            e = float((G[k] - v).abs().max() / v.abs().max().clamp_min(1e-30))
+            worst = max(worst, e)
+            assert e < 2e-5, (stage, split_points, k, e)
+dist.barrier()
+if rank == 0:
+    print("DPLTS", worst)
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_lts_step_equals_the_sum_of_its_shards():
+    """LtsStep / PDRA under data parallelism (SURVEY 8(e)): two real ranks on the one GPU over gloo, each with its ray shard and
+    its own random draws (surface points, directions, noises: seeded per rank), with and without ``split_points``.  The
+    all-reduced loss and all 43 gradients equal the sum over the shards of the single-process steps on each shard with the same
+    draws and the same global normalisation -- the exchange adds nothing and loses nothing."""
+    with tempfile.TemporaryDirectory() as d:
+        w = os.path.join(d, "w.py")
+        open(w, "w").write(LTS_WORKER)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+        out = subprocess.run(
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+             "--master-addr", "127.0.0.1", "--master-port", "29541", w, ROOT],
+            env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    line = [l for l in out.stdout.splitlines() if l.startswith("DPLTS")][0].split()
+    assert float(line[1]) < 2e-5
+
+
 def test_two_rank_step_equals_full_batch_step():
     with tempfile.TemporaryDirectory() as d:
         w = os.path.join(d, "w.py")
