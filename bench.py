@@ -112,9 +112,6 @@ def parse():
                          "record is enough to pick the default of trainer._grid_sync.  On by itself for N = 2..4 (outside the timed "
                          "region, ~0.1 s); for N >= 5 only with this flag: there the non-default form is the one no real node has run yet")
     ap.add_argument("--no-sync-sweep", action="store_true", help="N = 2..4: leave the sweep out")
-    ap.add_argument("--split-variant", type=int, default=0,
-                    help="esr_mlp_split_variant: 0 = the one-wave-per-SIMD radiance kernels (the product), 1 = wave-pair kernels in both "
-                         "directions, 2 = in the input gradients only (A/B timing of the round-5 experiment, DESIGN.md section 4)")
     ap.add_argument("--step-times", action="store_true",
                     help="diagnostic: record a HIP event behind every timed step and print the per-step times (ms) to stderr -- how "
                          "long the step takes to reach its steady state after the warm-up (clocks, caches)")
@@ -506,8 +503,6 @@ def main():
         batch["uncert_masks"] = (torch.arange(n_rays, device=dev) % 3 == 0)
         step = LtsStep(model, cfg.app.trainer, stage=stage, process_group=pg, split_points=(a.scaling == "strong"))
     eng = model.engine
-    if a.split_variant:
-        eng.L.esr_mlp_split_variant(int(a.split_variant))
     if a.serial:
         eng.overlap_wgrad = False
         if hasattr(eng, "wgrad_early"):
@@ -738,8 +733,6 @@ def main():
             # a timed step among them would have run twice
             "split_fallback_steps": int(getattr(eng, "split_fallback_steps", 0)),
         }
-        if a.split_variant:
-            out["config"]["split_variant"] = int(a.split_variant)      # an A/B line of the wave-pair experiment, not the product
         if opt_ms is not None:
             out["optimizer_step"] = {"ms": opt_ms, "parameters": n_params, "kernel": "esr_adam_step (fused Adam, 28 B/param)",
                                      "hbm_gbs": n_params * 28 / (opt_ms * 1e-3) / 1e9,

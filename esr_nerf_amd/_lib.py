@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libesr_hip.so")
 # developer experiments only (tools/variant.sh builds alternative libraries; tools/ab_env.sh times them side by side on one box)
 LIB_PATH = os.environ.get("ESR_LIB_PATH", LIB_PATH)
-ABI_VERSION = 24
+ABI_VERSION = 25
 _lib = None
 
 
@@ -105,7 +105,7 @@ EXPORTS = [
     "esr_fine_march_bwd", "esr_fine_march_bwd_rec", "esr_fine_march_cache_floats", "esr_fine_march_count_cached",
     "esr_fine_march_fill_cached", "esr_fine_march_bwd_cached", "esr_fine_march_count_ga", "esr_fine_march_fill_ga", "esr_fine_march_bwd_ga",
     "esr_fine_feat_fwd", "esr_fine_feat_fwd_x16", "esr_fine_feat_x16_bytes", "esr_fine_feat_bwd",
-    "esr_mlp_packed_floats", "esr_mlp_pack", "esr_mlp_pack_batch", "esr_mlp_packed_split_elems", "esr_mlp_split_gain_offset", "esr_mlp_split_range_flag", "esr_mlp_split_variant", "esr_mlp_fwd_split", "esr_mlp_fwd_fine_split", "esr_mlp_dgrad_split", "esr_mlp_dgrad_fine_split", "esr_absmax", "esr_mlp_fwd", "esr_mlp_fwd_mixed", "esr_mlp_fwd_fine", "esr_mlp_dgrad_fine", "esr_mlp_fwd_fine_bf16", "esr_mlp_dgrad_fine_bf16", "esr_mlp_dgrad", "esr_mlp_dgrad_wg", "esr_mlp_wgrad", "esr_mlp_wgrad_batch", "esr_tone_wgrad_scratch_floats", "esr_tone_wgrad_recompute", "esr_tone_wgrad_recompute_bf16", "esr_tone_wgrad_recompute_split",
+    "esr_mlp_packed_floats", "esr_mlp_pack", "esr_mlp_pack_batch", "esr_mlp_packed_split_elems", "esr_mlp_split_gain_offset", "esr_mlp_split_range_flag", "esr_mlp_fwd_split", "esr_mlp_fwd_fine_split", "esr_mlp_dgrad_split", "esr_mlp_dgrad_fine_split", "esr_absmax", "esr_mlp_fwd", "esr_mlp_fwd_mixed", "esr_mlp_fwd_fine", "esr_mlp_dgrad_fine", "esr_mlp_fwd_fine_bf16", "esr_mlp_dgrad_fine_bf16", "esr_mlp_dgrad", "esr_mlp_dgrad_wg", "esr_mlp_wgrad", "esr_mlp_wgrad_batch", "esr_tone_wgrad_scratch_floats", "esr_tone_wgrad_recompute", "esr_tone_wgrad_recompute_bf16", "esr_tone_wgrad_recompute_split",
     "esr_mlp_wgrad_scratch_floats",
     "esr_fine_tone_in_fwd", "esr_fine_composite_fwd", "esr_fine_composite_bwd",
     "esr_fine_tone_in_bwd", "esr_fine_loss_fwd_bwd", "esr_fine_loss_fwd_bwd_dp",

@@ -1136,8 +1136,8 @@ ESR_API int esr_mlp_pack(int kind, const esr_mlp_weights_t *w, float *packed, vo
 ESR_API int64_t esr_mlp_packed_split_elems(int kind)
 {
     if (!kind_ok(kind)) return ESR_EINVAL;
-    // forward | transposed planes | the gradient gain bound (one fp32) | the radiance net's planes in wave-pair order
-    return split_gain_offset(kind) + SPLIT_GAIN_PAD + pair_elems(kind);
+    // forward | transposed planes | the gradient gain bound (one fp32)
+    return split_gain_offset(kind) + SPLIT_GAIN_PAD;
 }
 
 // element (fp16) offset of the net's gradient gain bound (one fp32) inside its planes buffer
@@ -1233,7 +1233,7 @@ ESR_API int esr_mlp_pack_batch(int n, const int32_t *kinds, const esr_mlp_weight
         if (A.outs && !(kind == ESR_MLP_RADIANCE || kind == ESR_MLP_TONEMAP || kind == ESR_MLP_BRDF || kind == ESR_MLP_EMIT)) return ESR_EINVAL;
         A.range = A.outs ? esr_split_range_flag_ptr() : nullptr;
         any_split = any_split || A.outs;
-        const int64_t tot = pack_layout(kind).total + pack16_layout(kind).total + (A.outs ? split_gain_offset(kind) + pair_elems(kind) : 0);
+        const int64_t tot = pack_layout(kind).total + pack16_layout(kind).total + (A.outs ? split_gain_offset(kind) : 0);
         most = tot > most ? tot : most;
     }
     pack_kernel<<<dim3(esr_grid_for(most, 256, 256), n), 256, 0, esr_stream(stream)>>>(B);

@@ -408,97 +408,6 @@ __device__ __forceinline__ void packs_body(const PackArgs &A, int64_t e)
     A.outs[e] = plane == 0 ? w1 : (_Float16)(v - (float)w1);
 }
 
-// ---- split-fp16 planes in WAVE-PAIR order (mlp_pair.h: the 192-wide radiance net at two waves per SIMD) -----------------
-// Two waves share one 32-sample tile and split every product along K by k-step PARITY: wave A (w = 0) holds the planes of
-// the even k-steps of a layer's input, wave B (w = 1) those of the odd ones, each multiplies its half of K into every output
-// tile.  Of a tile's 16 accumulator registers a wave FINISHES eight and hands the other eight to its partner (fp32, through
-// LDS).  The registers a wave finishes are always its registers 0..7: B's weight rows are rotated by 16 inside a tile (the
-// A operand of lane r holds output row r ^ 16), so that the rows B finishes -- 16..31 of the tile, the next layer's ODD
-// k-step -- land in its registers 0..7 and both waves run the same code.  A step = one output tile, staged as
-//   [wave A: plane 0 k-steps | plane 1 k-steps][wave B: plane 0 k-steps | plane 1 k-steps]          (2 KS chunks of 1 KB)
-// A layer with ONE k-step (the input-gradient chain's first: K = the 3 output rows) cannot be split along K: it is a single
-// step in which both waves multiply all tiles (B with rotated rows) and each finishes its eight registers of every tile,
-// [wave][tile][plane] chunks.
-struct PairLayout {
-    int n_layers;
-    int ks[4], kw[4], tiles[4], in_dim[4], out_dim[4];
-    int rowsplit[4];           // the layer is one step over all tiles, K not split (ks == 1)
-    int step0[4], nsteps[4];   // steps of the layer
-    int n_steps;
-    int layer_of[20], tile_of[20], chunk0[20], chunks[20];
-    int total_chunks, max_chunks;
-};
-__host__ __device__ constexpr PairLayout pair_layout_from(const SplitLayout S)
-{
-    PairLayout L = {};
-    L.n_layers = S.n_layers;
-    int s = 0, o = 0, mx = 0;
-    for (int l = 0; l < S.n_layers; ++l) {
-        L.ks[l] = S.ks[l]; L.tiles[l] = S.tiles_out[l];
-        L.in_dim[l] = S.in_dim[l]; L.out_dim[l] = S.out_dim[l];
-        L.rowsplit[l] = S.ks[l] == 1 ? 1 : 0;
-        L.kw[l] = L.rowsplit[l] ? 1 : S.ks[l] / 2;           // k-steps per wave (ks is even where K is split)
-        L.step0[l] = s;
-        L.nsteps[l] = L.rowsplit[l] ? 1 : S.tiles_out[l];
-        for (int n = 0; n < L.nsteps[l]; ++n, ++s) {
-            L.layer_of[s] = l; L.tile_of[s] = n; L.chunk0[s] = o;
-            L.chunks[s] = L.rowsplit[l] ? 2 * S.tiles_out[l] * 2 : 2 * S.ks[l];
-            o += L.chunks[s];
-            mx = L.chunks[s] > mx ? L.chunks[s] : mx;
-        }
-    }
-    L.n_steps = s; L.total_chunks = o; L.max_chunks = mx;
-    return L;
-}
-__host__ __device__ constexpr PairLayout pair_layout(int kind) { return pair_layout_from(split_layout(kind)); }
-__host__ __device__ constexpr PairLayout pair_layout_t(int kind) { return pair_layout_from(split_layout_t(kind)); }
-__host__ __device__ constexpr bool pair_kind(int kind) { return kind == ESR_MLP_RADIANCE; }
-// element offsets inside the planes buffer: ... | gain slot (8) | pair forward planes | pair transposed planes
-__host__ __device__ constexpr int64_t pair_offset(int kind) { return split_gain_offset(kind) + SPLIT_GAIN_PAD; }
-__host__ __device__ constexpr int64_t pair_elems(int kind)
-{
-    return pair_kind(kind) ? ((int64_t)pair_layout(kind).total_chunks + pair_layout_t(kind).total_chunks) * 512 : 0;
-}
-// one element of the pair-ordered planes; BWD: the transposed weights (packst_body's feature maps)
-template <int KIND, bool BWD>
-__device__ __forceinline__ void packp_body(const PackArgs &A, int64_t e)
-{
-    constexpr PairLayout L = BWD ? pair_layout_t(KIND) : pair_layout(KIND);
-    constexpr int NL = L.n_layers;
-    const int chunk = (int)(e >> 9), slot = (int)(e & 7), lane = (int)((e >> 3) & 63), h = lane >> 5;
-    int s = 0;
-#pragma unroll
-    for (int k = 1; k < L.n_steps; ++k)
-        if (chunk >= L.chunk0[k]) s = k;
-    const int l = L.layer_of[s], kw = L.kw[l];
-    int c = chunk - L.chunk0[s], tile, plane, j, w;
-    if (L.rowsplit[l]) {                                  // [wave][tile][plane], the single k-step
-        w = c / (2 * L.tiles[l]); c %= 2 * L.tiles[l]; tile = c >> 1; plane = c & 1; j = 0;
-    } else {                                             // [wave][plane][its k-steps: 2 jl + w]
-        tile = L.tile_of[s];
-        w = c / (2 * kw); c %= 2 * kw;
-        plane = c / kw; j = 2 * (c % kw) + w;
-    }
-    const int r = (lane & 31) ^ (16 * w);                 // (B: rows rotated by 16 inside the tile)
-    float v = 0.f;
-    if (!BWD) {
-        const int row = 32 * tile + r;
-        const int col = l == 0 ? in_colmap(KIND, 16 * j + 8 * h + slot) : kfeat16(j, h, slot);
-        if (row < L.out_dim[l] && col >= 0 && col < L.in_dim[l]) v = A.w[l][(int64_t)row * L.in_dim[l] + col];
-    } else {
-        const int nl = NL - 1 - l;                        // network layer of transposed layer l
-        const bool first = nl == 0, last = nl == NL - 1;
-        const int orow = last ? (8 * h + slot) : kfeat16(j, h, slot);
-        const int irow = 32 * tile + r;
-        const int col = first ? in_colmap(KIND, irow) : irow;
-        if (orow < L.out_dim[l] && col >= 0 && col < L.in_dim[l]) v = A.w[nl][(int64_t)orow * L.in_dim[l] + col];
-    }
-    v *= SPLIT_W_SCALE;
-    const _Float16 w1 = (_Float16)v;
-    const int64_t base = pair_offset(KIND) + (BWD ? (int64_t)pair_layout(KIND).total_chunks * 512 : 0);
-    A.outs[base + e] = plane == 0 ? w1 : (_Float16)(v - (float)w1);
-}
-
 // Every net of a step in ONE launch (esr_mlp_pack_batch): blockIdx.y = job; fp32 elements first, then the bf16 twin's.
 constexpr int MAX_PACK_JOBS = 8;
 struct PackBatch {
@@ -510,17 +419,12 @@ __device__ __forceinline__ void pack_job(const PackArgs &A)
 {
     constexpr int64_t N32 = pack_layout(KIND).total, N16 = pack16_layout(KIND).total;
     constexpr int64_t NS = (int64_t)split_layout(KIND).total_chunks * 512, NST = (int64_t)split_layout_t(KIND).total_chunks * 512;
-    constexpr int64_t NPF = pair_kind(KIND) ? (int64_t)pair_layout(KIND).total_chunks * 512 : 0, NPB = pair_elems(KIND) - NPF;
-    const int64_t n = N32 + N16 + (A.outs ? NS + NST + NPF + NPB : 0);
+    const int64_t n = N32 + N16 + (A.outs ? NS + NST : 0);
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         if (e < N32) { if (A.out) pack_body<KIND>(A, e); }
         else if (e < N32 + N16) { if (A.out16) pack16_body<KIND>(A, e - N32); }
         else if (e < N32 + N16 + NS) packs_body<KIND>(A, e - N32 - N16);
-        else if (e < N32 + N16 + NS + NST) packst_body<KIND>(A, e - N32 - N16 - NS);
-        else if constexpr (pair_kind(KIND)) {
-            if (e < N32 + N16 + NS + NST + NPF) packp_body<KIND, false>(A, e - N32 - N16 - NS - NST);
-            else packp_body<KIND, true>(A, e - N32 - N16 - NS - NST - NPF);
-        }
+        else packst_body<KIND>(A, e - N32 - N16 - NS);
     }
 }
 __global__ void __launch_bounds__(256) pack_kernel(PackBatch B)

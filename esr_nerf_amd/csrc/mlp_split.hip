@@ -50,7 +50,10 @@ constexpr float SPLIT_RANGE = 60000.f;                      // hidden activation
 #ifndef ESR_SPLIT_WRING
 #define ESR_SPLIT_WRING 3
 #endif
-constexpr int WRING = ESR_SPLIT_WRING;                      // k-steps of weight operands in flight per wave (tools/ubench/split_stamps.hip: 3 / 4 / 5 / 6)
+constexpr int WRING = ESR_SPLIT_WRING;
+#ifndef ESR_NS_DEFAULT
+#define ESR_NS_DEFAULT 0                                    // esr_mlp_split_variant's initial value
+#endif                      // k-steps of weight operands in flight per wave (tools/ubench/split_stamps.hip: 3 / 4 / 5 / 6)
 
 __device__ __forceinline__ f32x16 mfma_h(f16x8 a, f16x8 b, f32x16 c)
 {
@@ -749,9 +752,6 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_dgrad_split_ker
         atomicMax(reinterpret_cast<unsigned *>(AB.amax), __float_as_uint(wmax));
 }
 
-#include "mlp_pair.h"
-#include "mlp_pair_dgrad.h"
-
 // workgroups per segment proportional to its tile groups (every non-empty segment >= 1); returns the grid
 int share_blocks_split(SplitSeg *seg, int nseg, int cap = 256)
 {
@@ -792,29 +792,12 @@ int share_blocks_split(SplitSeg *seg, int nseg, int cap = 256)
 // per-device sticky flag registered by the caller (esr_mlp_split_range_flag); NULL: no check
 std::atomic<unsigned *> g_range_flag[16];
 
-// 0 (default): the radiance net on the one-wave-per-SIMD kernels above; 1: on the wave-pair kernels (mlp_pair.h, two waves per
-// SIMD) -- round 5's experiment: correct (tests/test_gpu_split.py runs both variants against float64) and NOT faster: forward
-// 0.58 vs 0.54 ms, input gradients 0.33 vs 0.35 ms at C2's shape (tools/ubench/pair_bench.hip, profiles/r05_pair_bench.txt;
-// DESIGN.md section 4 has the stamps).  esr_mlp_split_variant selects.
-std::atomic<int> g_pair_variant{0};
-
 template <int KIND>
 int launch_split_k(SplitBatch &B, hipStream_t s)
 {
     using S = SplitSteps<KIND>;
     int dev = 0;
     B.range = (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) ? g_range_flag[dev].load() : nullptr;
-    if constexpr (pair_kind(KIND)) {
-        if (g_pair_variant.load() & 1) {
-            using P = PairSteps<KIND, false>;
-            const int grid = share_blocks_split(B.seg, B.nseg, 256);                   // one workgroup of eight waves per CU
-            static std::atomic<uint64_t> optin_p{0};
-            if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_fwd_pair_kernel<KIND>), P::LDS_BYTES, optin_p)) return rc;
-            mlp_fwd_pair_kernel<KIND><<<grid, 64 * PW, P::LDS_BYTES, s>>>(B);
-            ESR_CHECK_LAUNCH();
-            return 0;
-        }
-    }
     const int grid = share_blocks_split(B.seg, B.nseg, 256 * split_occ(KIND));       // resident workgroups: one or two per CU
     static std::atomic<uint64_t> optin{0};
     if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_fwd_split_kernel<KIND>), S::LDS_BYTES, optin)) return rc;
@@ -880,13 +863,6 @@ ESR_API int esr_mlp_split_range_flag(uint32_t *flag)
     return 0;
 }
 
-// Test / timing hook: which kernels run the radiance net's split launches (see g_pair_variant).  Returns the previous value.
-// bit 0: the forward, bit 1: the input gradients on the wave-pair kernels (1 as an argument means both, as before the bits)
-ESR_API int esr_mlp_split_variant(int pair)
-{
-    return g_pair_variant.exchange(pair == 1 ? 3 : (pair & 3));
-}
-
 // The fine stage's three radiance forward passes of a step as ONE launch (esr_mlp_fwd_fine's contract and argument meaning).
 ESR_API int esr_mlp_fwd_fine_split(const float *packed32_off, const void *planes_off, const float *packed32_emo,
                                    const void *planes_emo, const float *X, int32_t t_on, int32_t t_all, float *const *H,
@@ -917,8 +893,7 @@ int launch_dsplit_k(DSplitBatch &B, hipStream_t s)
     using S = SplitSteps<KIND, true>;
     int groups[2], total = 0;
     for (int k = 0; k < B.nseg; ++k) { groups[k] = (B.seg[k].t1 - B.seg[k].t0 + SPW - 1) / SPW; total += groups[k]; }
-    const bool pair = pair_kind(KIND) && (g_pair_variant.load() & 2);           // (one workgroup of eight waves per CU)
-    const int cap = pair ? 256 : 256 * split_occ(KIND);
+    const int cap = 256 * split_occ(KIND);
     const int grid = total < cap ? total : cap;
     if (B.nseg == 1) { B.seg[0].b0 = 0; B.seg[0].nb = grid; }
     else {
@@ -928,16 +903,6 @@ int launch_dsplit_k(DSplitBatch &B, hipStream_t s)
         if (grid - n0 > groups[1]) n0 = grid - groups[1];
         if (grid - n0 < 1) n0 = grid - 1;
         B.seg[0].b0 = 0; B.seg[0].nb = n0; B.seg[1].b0 = n0; B.seg[1].nb = grid - n0;
-    }
-    if constexpr (pair_kind(KIND)) {
-        if (pair) {
-            using P = PairSteps<KIND, true>;
-            static std::atomic<uint64_t> optin_p{0};
-            if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_dgrad_pair_kernel<KIND>), P::LDS_BYTES, optin_p)) return rc;
-            mlp_dgrad_pair_kernel<KIND><<<grid, 64 * PW, P::LDS_BYTES, s>>>(B);
-            ESR_CHECK_LAUNCH();
-            return 0;
-        }
     }
     static std::atomic<uint64_t> optin{0};
     if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_dgrad_split_kernel<KIND>), S::WBYTES, optin)) return rc;

@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256) segment_sum_kernel(const float *__restric
 
 }  // namespace
 
-ESR_API int esr_abi_version(void) { return 24; }
+ESR_API int esr_abi_version(void) { return 25; }
 ESR_API const char *esr_build_info(void) { return "libesr_hip gfx950 " __DATE__ " " __TIME__; }
 
 ESR_API int esr_sample_count(const float *rays_o, const float *rays_d, const float *xyz_min,

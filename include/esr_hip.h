@@ -408,12 +408,6 @@ int64_t esr_mlp_split_gain_offset(int kind);
  * re-runs a step that raised it on the f32 MFMA entry points, which share every buffer format.  esr_fine_plan also copies the
  * flag into bit 1 of the plan header's overflow word (informational). */
 int esr_mlp_split_range_flag(uint32_t *flag);
-/* Test / timing hook.  Which kernels run the RADIANCE net's split launches: 0 (default) the one-wave-per-SIMD kernels, 1 the
- * wave-pair kernels (csrc/mlp_pair.h: two waves share a 32-sample tile, K split by k-step parity, partial sums through LDS;
- * two waves per SIMD) in both directions, 2 in the input gradients only, 3 (what 1 is stored as) both again -- bit 0 the
- * forward, bit 1 the input gradients.  Same contracts, same buffers; results equal to fp32 rounding.  Returns the previous
- * value (0..3). */
-int esr_mlp_split_variant(int pair);
 int esr_mlp_fwd_split(int kind, const float *packed32, const void *planes, const float *X, int32_t t0, int32_t t1,
                       float *const *H, uint32_t *const *M, int save, int color_row0, float *zout, void *stream);
 int esr_mlp_fwd_fine_split(const float *packed32_off, const void *planes_off, const float *packed32_emo,

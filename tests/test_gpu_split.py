@@ -787,113 +787,3 @@ def test_autograd_route_heals_in_the_forward():
         assert rel_err(res["split"][1][k], v) < 2e-5, k
 
 
-@pytest.mark.parametrize("tiles,t0,crow,save", [(1, 0, 0, 1), (5, 2, 88, 1), (131, 3, 96, 2), (1030, 0, 0, 1), (64, 0, 88, 0)])
-def test_wave_pair_kernels_vs_double_precision_and_vs_the_one_wave_kernels(tiles, t0, crow, save):
-    """esr_mlp_split_variant(1): the radiance net's split launches on the WAVE-PAIR kernels (csrc/mlp_pair.h: two waves share a
-    32-sample tile, K split by k-step parity, partial sums through LDS, B's weight rows rotated) -- forward (outputs, saved
-    tiles, masks; ragged ranges, every colour-row group, save modes) and the input-gradient chain (dZ[0..2], dX, the
-    weight-gradient scale source) against float64 and beside the one-wave-per-SIMD kernels on the same buffers.  The pair
-    kernels sum the same products in a different order: equal to fp32 rounding, masks equal except within rounding of zero."""
-    from esr_nerf_amd import _lib
-    from esr_nerf_amd.fine_engine import FineEngine
-    eng = FineEngine("cuda:0")
-    L, s = eng.L, _lib.stream_ptr("cuda:0")
-    g = torch.Generator().manual_seed(tiles * 13 + crow)
-    Ws, Bs = _net(g)
-    _pack(L, eng, "off", Ws, Bs)
-    X = torch.randn(tiles, 104, 32, generator=g)
-    X[:, 7:31] *= 5.0
-    rows = [r for r in range(96) if _in_colmap(0, r) >= 0]
-    cols = [_in_colmap(0, r) for r in rows]
-    src_rows = [r + crow if r < 6 else r for r in rows]
-    n = tiles - t0
-    x_ref = torch.zeros(n * 32, 85, dtype=torch.float64)
-    x_ref[:, cols] = X[t0:, src_rows, :].permute(0, 2, 1).reshape(n * 32, len(rows)).double()
-    h, hs = x_ref, []
-    for i in range(4):
-        h = torch.nn.functional.linear(h, Ws[i].double(), Bs[i].double())
-        if i < 3:
-            h = torch.relu(h)
-            hs.append(h)
-    tm = lambda t, r: t.reshape(n, 32, r).permute(0, 2, 1).contiguous()
-    Xd = X.cuda().contiguous()
-    dz = torch.randn(tiles, 4, 32, generator=g) * 1e-3 * 10.0 ** (-4.0 * torch.rand(tiles, 1, 32, generator=g))
-    dz[:, 3] = 0.0
-    dzd = dz.cuda().contiguous()
-    out = {}
-    prev = L.esr_mlp_split_variant(0)
-    try:
-        for v in (0, 1):
-            L.esr_mlp_split_variant(v)
-            H = [torch.full((tiles, 192, 32), -3.0, device="cuda") for _ in range(3)]
-            M = [torch.full((tiles, 3, 64), -3, dtype=torch.int32, device="cuda") for _ in range(3)]
-            z = torch.full((tiles, 4, 32), 7.0, device="cuda")
-            _lib.check(L.esr_mlp_fwd_split(0, _lib.ptr(eng.packed["off"]), _lib.ptr(eng.packed_split["off"]), _lib.ptr(Xd), t0, tiles,
-                                           _lib.ptr_array(H), _lib.ptr_array(M), save, crow, _lib.ptr(z), s), "fwd")
-            dZ = [torch.full((tiles, 192, 32), -3.0, device="cuda") for _ in range(3)]
-            dX = torch.full((tiles, 64, 32), 3.0, device="cuda")
-            amax = torch.zeros(1, device="cuda")
-            Mb = out[0][2] if v == 1 else M                              # (both chains on the SAME masks)
-            if save:
-                _lib.check(L.esr_mlp_dgrad_split(0, _lib.ptr(eng.packed_split["off"]), _lib.ptr(dzd), t0, tiles, _lib.ptr_array(Mb),
-                                                 _lib.ptr_array(dZ), _lib.ptr(dX), _lib.ptr(amax), s), "dgrad")
-            torch.cuda.synchronize()
-            out[v] = (z, H, M, dZ, dX, float(amax))
-    finally:
-        L.esr_mlp_split_variant(prev)
-    z0, H0, M0, dZ0, dX0, a0 = out[0]
-    z1, H1, M1, dZ1, dX1, a1 = out[1]
-    zr = tm(h, 3)
-    e1, e0 = rel_err(z1[t0:, :3], zr), rel_err(z0[t0:, :3], zr)
-    print(f"z vs double: pair {e1:.2e}, one-wave {e0:.2e}")
-    assert e1 < 3e-6 and e1 < 4 * e0 + 5e-7
-    assert float(z1[t0:, 3].abs().max()) == 0.0
-    if t0:
-        assert float((z1[:t0] - 7.0).abs().max()) == 0.0 and all(float((H1[l][:t0] + 3.0).abs().max()) == 0.0 for l in range(3))
-    for l in range(3):
-        if save == 1:
-            assert rel_err(H1[l][t0:], tm(hs[l], 192)) < 3e-6, l
-        else:
-            assert float((H1[l] + 3.0).abs().max()) == 0.0
-        if save:
-            diff = (M1[l][t0:] ^ M0[l][t0:])
-            nd = int(sum(bin(int(x) & 0xffffffff).count("1") for x in diff.flatten().tolist())) if diff.any() else 0
-            assert nd <= max(2, n * 32 * 192 // 20000), (l, nd)
-            if t0:
-                assert int((M1[l][:t0] + 3).abs().max()) == 0
-        else:
-            assert int((M1[l] + 3).abs().max()) == 0
-    if not save:
-        return
-    assert a0 == a1
-    for name, a, b in [(f"dZ{l}", dZ1[l][t0:], dZ0[l][t0:]) for l in range(3)] + [("dX", dX1[t0:, :44], dX0[t0:, :44])]:
-        a_, b_ = a.cpu().double(), b.cpu().double()
-        scale_t = b_.abs().amax(dim=(1, 2)).clamp_min(1e-300)
-        e = float(((a_ - b_).abs().amax(dim=(1, 2)) / scale_t).max())
-        print(f"{name}: pair vs one-wave {e:.2e} (per-tile max-norm)")
-        assert e < 4e-6, (name, e)
-    assert float((dX1[:, 44:] - 3.0).abs().max()) == 0.0 and (t0 == 0 or float((dX1[:t0] - 3.0).abs().max()) == 0.0)
-
-
-def test_trainer_step_on_the_wave_pair_kernels_equals_the_default_step():
-    """FineStep with esr_mlp_split_variant(1): loss and all 23 gradients as on the default (one-wave) split kernels."""
-    from esr_nerf_amd.synthetic import slab_scene
-    from esr_nerf_amd.trainer import FineStep
-    from test_gpu_fine_path import build_gpu_model, gpu_batch
-    sc = slab_scene("small", s_val=60.0, oblique=True, n_rays=384, seed=9, mask="prune")
-    m = build_gpu_model(sc, seed=1, grid_seed=2)
-    b = gpu_batch(sc)
-    L = m.engine.L
-    res = {}
-    prev = L.esr_mlp_split_variant(0)
-    try:
-        for v in (0, 1):
-            L.esr_mlp_split_variant(v)
-            loss, gr = FineStep(m).forward_loss_backward(b, 60.0)
-            torch.cuda.synchronize()
-            res[v] = (float(loss), {k: x.clone() for k, x in gr.items()})
-    finally:
-        L.esr_mlp_split_variant(prev)
-    assert abs(res[0][0] - res[1][0]) < 2e-6 * max(1.0, abs(res[0][0]))
-    for k in res[0][1]:
-        assert rel_err(res[1][1][k], res[0][1][k]) < 5e-4, (k, rel_err(res[1][1][k], res[0][1][k]))

@@ -43,9 +43,9 @@ def asm_reads_behind_mfma(path, every_reader_in=None, hazard=None):
     """[(kernel, line number, instruction, distance)] of inline-asm instructions whose sources an MFMA wrote < HAZARD
     wait states before (linear scan per function: conservative across branches).  ``every_reader_in``: a substring of
     kernel names in which EVERY vector / LDS-write / buffer-store instruction is held to the bound, not only the hand-written
-    ones -- the wave-pair kernels pin their MFMAs with empty asm statements, behind which hipcc no longer provides the wait
-    states (mlp_pair_dgrad.h: a third of the tiles came out wrong when a tile's sums were read a few instructions behind
-    its last pinned MFMA).  ``hazard``: the bound for those kernels (their MFMAs are 8-pass: 11 wait states)."""
+    ones -- for kernels that pin their MFMAs with empty asm statements, behind which hipcc no longer provides the wait
+    states (round 5's wave-pair kernels, since removed: a third of the tiles came out wrong when a tile's sums were read a
+    few instructions behind its last pinned MFMA).  ``hazard``: the bound for those kernels (8-pass MFMAs: 11 wait states)."""
     HZ = hazard or HAZARD
     bad, recent, in_asm, func, slot = [], [], False, None, 0
     for ln, line in enumerate(open(path), 1):
@@ -86,17 +86,6 @@ def asm_reads_behind_mfma(path, every_reader_in=None, hazard=None):
 @pytest.mark.parametrize("src", ["mlp.hip", "mlp_bf16.hip", "tone_wgrad.hip", "mlp_split.hip"])
 def test_no_inline_asm_reads_a_fresh_mfma_result(src):
     bad = asm_reads_behind_mfma(_asm(src))
-    assert not bad, bad[:5]
-
-
-@pytest.mark.parametrize("kernel", ["mlp_fwd_pair_kernel", "mlp_dgrad_pair_kernel"])
-def test_pair_kernels_read_no_pinned_mfma_result_early(kernel):
-    """The wave-pair kernels pin every MFMA of a K-split step to its slot with an empty asm on the accumulator; hipcc stops
-    counting wait states behind such a pin.  Every reader of an MFMA result in these kernels -- the epilogue's vector
-    instructions, the exchange's LDS writes -- must therefore be at least 11 wait states (8-pass MFMA on gfx950) behind the
-    MFMA by the kernels' own construction (accumulating MFMAs read srcC = their predecessor's destination: no wait)."""
-    bad = asm_reads_behind_mfma(_asm("mlp_split.hip"), every_reader_in=kernel, hazard=11)
-    bad = [b for b in bad if kernel in b[0]]
     assert not bad, bad[:5]
 
 

@@ -15,3 +15,9 @@ for v in NO_MFMA NO_HSTORE NO_WREAD; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-fast-math -DESR_SPLIT_$v -I../../include -I../../esr_nerf_amd/csrc \
       -o split_stamps_$(echo $v | tr 'A-Z' 'a-z') split_stamps.hip 2>&1 | grep -E "error"
 done
+# round 6's prototype of the radiance kernels at two waves per SIMD (nsplit_proto.h) beside the product kernels, and its timing variants
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-fast-math -I../../include -I../../esr_nerf_amd/csrc -o nsplit_bench nsplit_bench.hip 2>&1 | grep -E "error"
+for v in NO_MFMA NO_HSTORE NO_WREAD NO_STAGE; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-fast-math -DESR_NS_$v -I../../include -I../../esr_nerf_amd/csrc \
+      -o nsplit_bench_$(echo $v | tr 'A-Z' 'a-z') nsplit_bench.hip 2>&1 | grep -E "error"
+done

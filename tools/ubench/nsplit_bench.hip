@@ -1,27 +1,114 @@
-// The wave-pair radiance kernels (csrc/mlp_pair.h) beside the one-wave-per-SIMD split kernels they replace: same packed
-// weights, same inputs; differences of outputs / saved tiles / masks (the two sum the same products in a different order)
-// and launch times at C2's shape (8192 on-tiles + 8192 off-tiles).
-//   gpurun -- './tools/ubench/pair_bench'
+// The N-split radiance kernels (csrc/mlp_nsplit.h: two waves per SIMD, a pair of waves splits a tile's OUTPUT tiles) beside
+// the one-wave-per-SIMD split kernels: same packed weights, same inputs; differences of outputs / saved tiles / masks (the
+// two sum the same products in the same order: expected 0) and launch times at C2's shape (8192 on-tiles + 8192 off-tiles).
+//   gpurun -- './tools/ubench/nsplit_bench'
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <vector>
-// stamps of waves 0 (type A) and 4 (type B) of every workgroup, first three tile groups: [wg][type][trip][step][4]
-constexpr int NST_ = 19;
+// stamps of waves 0 (w = 0) and 4 (w = 1) of every workgroup, first three tile groups: [wg][w][trip][unit][4]
+constexpr int NST_ = 17;
 __device__ unsigned long long g_stamps[256 * 2 * 3 * NST_ * 4];
-#define ESR_PAIR_STAMP(st_, i_)                                                                                   \
+#define ESR_NS_STAMP(u_, i_)                                                                                      \
     do {                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
-        if (lane == 0 && pr == 0) {                                                                               \
-            const int trip_ = (tg - ((int)blockIdx.x - blk0)) / nblk;                                             \
-            if (trip_ < 3 && blockIdx.x < 256)                                                                    \
-                g_stamps[(((blockIdx.x * 2 + w) * 3 + trip_) * NST_ + (st_)) * 4 + (i_)] = __builtin_amdgcn_s_memtime(); \
+        if (lane == 0 && pr == 0 && trip < 3 && blockIdx.x < 256 && (u_) < NST_)                                  \
+        {                                                                                                         \
+            g_stamps[(((blockIdx.x * 2 + w) * 3 + trip) * NST_ + (u_)) * 4 + (i_)] = __builtin_amdgcn_s_memtime(); \
+            if ((i_) == 0) g_stamps[(((blockIdx.x * 2 + w) * 3 + trip) * NST_ + (u_)) * 4 + 3] = __builtin_amdgcn_s_memrealtime(); \
         }                                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     } while (0)
+__device__ unsigned long long g_stamps2[256 * 2 * 3 * NST_ * 2];
+#define ESR_NS_STAMP2(u_, i_)                                                                                     \
+    do {                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        if (lane == 0 && pr == 0 && trip < 3 && blockIdx.x < 256 && (u_) < NST_)                                  \
+            g_stamps2[(((blockIdx.x * 2 + w) * 3 + trip) * NST_ + (u_)) * 2 + (i_)] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+// the product's one-wave forward: shader ticks and wall ticks at the start of each tile group (wave 0), for its clock
+__device__ unsigned long long g_ow[256 * 4 * 2];
+#define ESR_SPLIT_STAMP(i)                                                                                        \
+    do {                                                                                                          \
+        if ((i) == 0 && tid == 0 && blockIdx.x < 256) {                                                           \
+            const int trip_ = (tg - ((int)blockIdx.x - blk0)) / nblk;                                             \
+            if (trip_ < 4) {                                                                                      \
+                g_ow[(blockIdx.x * 4 + trip_) * 2] = __builtin_amdgcn_s_memtime();                                \
+                g_ow[(blockIdx.x * 4 + trip_) * 2 + 1] = __builtin_amdgcn_s_memrealtime();                        \
+            }                                                                                                     \
+        }                                                                                                         \
+    } while (0)
 #include "../../esr_nerf_amd/csrc/mlp_split.hip"
 #include "../../esr_nerf_amd/csrc/mlp.hip"
+#include "nsplit_proto.h"
+// the prototype's launches: esr_mlp_fwd_split / esr_mlp_fwd_fine_split / esr_mlp_dgrad_fine_split on the N-split kernels
+static int g_variant = 0;
+static int esr_mlp_split_variant(int v) { const int p = g_variant; g_variant = v; return p; }
+static const _Float16 *g_nsplanes = nullptr;               // N-split forward | transposed | gain
+static int ns_launch_fwd(SplitBatch &B)
+{
+    using P = NsSteps<ESR_MLP_RADIANCE, false>;
+    for (int k = 0; k < B.nseg; ++k) B.seg[k].planes = g_nsplanes;         // (one net in this harness)
+    const int grid = share_blocks_split(B.seg, B.nseg, 256);
+    static std::atomic<uint64_t> optin{0};
+    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_fwd_ns_kernel<ESR_MLP_RADIANCE>), P::LDS_BYTES, optin)) return rc;
+    mlp_fwd_ns_kernel<ESR_MLP_RADIANCE><<<grid, 64 * NW, P::LDS_BYTES, 0>>>(B);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+static int fwd_split(int kind, const float *packed32, const void *planes, const float *X, int32_t t0, int32_t t1, float *const *H,
+                     uint32_t *const *M, int save, int crow, float *zout)
+{
+    if (!g_variant) return esr_mlp_fwd_split(kind, packed32, planes, X, t0, t1, H, M, save, crow, zout, nullptr);
+    SplitBatch B = {};
+    B.X = X;
+    for (int l = 0; l < 3; ++l) { B.H[l] = save == 1 ? H[l] : nullptr; B.M[l] = M[l]; }
+    B.nseg = 1;
+    B.seg[0] = SplitSeg{packed32, nullptr, t0, t1, save == 2 ? 2 : save ? 1 : 0, crow, zout, 0, 0};
+    return ns_launch_fwd(B);
+}
+static int fwd_fine_split(const float *p32, const void *planes, const float *X, int32_t t_on, int32_t t_all, float *const *H,
+                          uint32_t *const *M, int crow, float *z_off, float *z_emo)
+{
+    if (!g_variant) return esr_mlp_fwd_fine_split(p32, planes, p32, planes, X, t_on, t_all, H, M, crow, z_off, z_emo, nullptr);
+    SplitBatch B = {};
+    B.X = X;
+    for (int l = 0; l < 3; ++l) { B.H[l] = H[l]; B.M[l] = M[l]; }
+    int n = 0;
+    if (t_on > 0) B.seg[n++] = SplitSeg{p32, nullptr, 0, t_on, 0, crow, z_off, 0, 0};
+    if (t_all > t_on) B.seg[n++] = SplitSeg{p32, nullptr, t_on, t_all, 1, 0, z_off, 0, 0};
+    if (t_on > 0) B.seg[n++] = SplitSeg{p32, nullptr, 0, t_on, 1, 0, z_emo, 0, 0};
+    B.nseg = n;
+    return ns_launch_fwd(B);
+}
+static int dgrad_fine_split(const void *planes, const float *dz, int32_t t_on, int32_t t_all, const uint32_t *const *M, float *const *dZ,
+                            float *dX, float *amax)
+{
+    if (!g_variant) return esr_mlp_dgrad_fine_split(planes, planes, dz, t_on, t_all, M, dZ, dX, amax, nullptr);
+    using P = NsSteps<ESR_MLP_RADIANCE, true>;
+    DSplitBatch B = {};
+    B.dz = dz; B.dX = dX; B.amax = amax;
+    for (int l = 0; l < 3; ++l) { B.M[l] = M[l]; B.dZ[l] = dZ[l]; }
+    int n = 0;
+    if (t_on > 0) B.seg[n++] = DSplitSeg{g_nsplanes, 0, t_on, 0, 0};
+    if (t_all > t_on) B.seg[n++] = DSplitSeg{g_nsplanes, t_on, t_all, 0, 0};
+    B.nseg = n;
+    int groups[2], total = 0;
+    for (int k = 0; k < n; ++k) { groups[k] = (B.seg[k].t1 - B.seg[k].t0 + 3) / 4; total += groups[k]; }
+    const int grid = total < 256 ? total : 256;
+    if (n == 1) { B.seg[0].b0 = 0; B.seg[0].nb = grid; }
+    else {
+        int n0 = (int)((int64_t)grid * groups[0] / total);
+        n0 = n0 < 1 ? 1 : n0;
+        B.seg[0].b0 = 0; B.seg[0].nb = n0; B.seg[1].b0 = n0; B.seg[1].nb = grid - n0;
+    }
+    static std::atomic<uint64_t> optin{0};
+    if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&mlp_dgrad_ns_kernel<ESR_MLP_RADIANCE>), P::LDS_BYTES, optin)) return rc;
+    mlp_dgrad_ns_kernel<ESR_MLP_RADIANCE><<<grid, 64 * NW, P::LDS_BYTES, 0>>>(B);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 
 template <typename T> static T *dalloc(size_t n) { T *p; (void)hipMalloc(&p, n * sizeof(T)); return p; }
 static double maxrel(const std::vector<float> &a, const std::vector<float> &b)
@@ -54,6 +141,16 @@ int main(int argc, char **argv)
     float *p32[1] = {packed};
     void *psp[1] = {planes};
     if (esr_mlp_pack_batch(1, kinds, ws, p32, nullptr, psp, nullptr)) { printf("pack failed\n"); return 1; }
+    {
+        _Float16 *nsp = dalloc<_Float16>(ns_elems(kind) + 8);
+        NsPackArgs P = {};
+        for (int l = 0; l < 4; ++l) P.w[l] = w.w[l];
+        P.outs = nsp;
+        ns_pack_kernel<ESR_MLP_RADIANCE><<<256, 256>>>(P);
+        (void)hipMemcpy(nsp + ns_elems(kind), planes + esr_mlp_split_gain_offset(kind), 4, hipMemcpyDeviceToDevice);
+        (void)hipDeviceSynchronize();
+        g_nsplanes = nsp;
+    }
     std::vector<float> hx((size_t)T * 104 * 32);
     for (auto &v : hx) v = (rand() / (float)RAND_MAX - 0.5f) * 2.f;
     float *X = dalloc<float>(hx.size());
@@ -68,7 +165,7 @@ int main(int argc, char **argv)
     for (int v = 0; v < 2; ++v) {
         esr_mlp_split_variant(v);
         // single pass, ragged range, colour rows 88
-        if (int rc = esr_mlp_fwd_split(kind, packed, planes, X, 3, std::min(T, 1003), H[v], M[v], 1, 88, z[v], nullptr)) { printf("rc %d\n", rc); return 1; }
+        if (int rc = fwd_split(kind, packed, planes, X, 3, std::min(T, 1003), H[v], M[v], 1, 88, z[v])) { printf("rc %d\n", rc); return 1; }
         (void)hipDeviceSynchronize();
         hipError_t err = hipGetLastError();
         if (err != hipSuccess) { printf("variant %d: %s\n", v, hipGetErrorString(err)); return 1; }
@@ -77,7 +174,7 @@ int main(int argc, char **argv)
         const size_t nz = (size_t)std::min(T, 1003) * 128, nh = (size_t)std::min(T, 1003) * 192 * 32, nm = (size_t)std::min(T, 1003) * 192;
         std::vector<float> a(nz), b(nz);
         (void)hipMemcpy(a.data(), z[1], nz * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(b.data(), z[0], nz * 4, hipMemcpyDeviceToHost);
-        printf("single pass [3, 1003): z pair vs one-wave %.2e\n", maxrel(std::vector<float>(a.begin() + 3 * 128, a.end()), std::vector<float>(b.begin() + 3 * 128, b.end())));
+        printf("single pass [3, 1003): z N-split vs one-wave %.2e\n", maxrel(std::vector<float>(a.begin() + 3 * 128, a.end()), std::vector<float>(b.begin() + 3 * 128, b.end())));
         for (int l = 0; l < 3; ++l) {
             std::vector<float> ha(nh), hb_(nh);
             (void)hipMemcpy(ha.data(), H[1][l], nh * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(hb_.data(), H[0][l], nh * 4, hipMemcpyDeviceToHost);
@@ -95,13 +192,13 @@ int main(int argc, char **argv)
     for (int v = 0; v < 2; ++v) {
         esr_mlp_split_variant(v);
         for (int rep = 0; rep < (round ? 20 : 150); ++rep)
-            esr_mlp_fwd_fine_split(packed, planes, packed, planes, X, Ton, T, H[v], M[v], 88, z[v], ze[v], nullptr);
+            fwd_fine_split(packed, planes, X, Ton, T, H[v], M[v], 88, z[v], ze[v]);
         (void)hipEventRecord(e0);
         for (int rep = 0; rep < 20; ++rep)
-            esr_mlp_fwd_fine_split(packed, planes, packed, planes, X, Ton, T, H[v], M[v], 88, z[v], ze[v], nullptr);
+            fwd_fine_split(packed, planes, X, Ton, T, H[v], M[v], 88, z[v], ze[v]);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-        printf("merged fine launch (%d on + %d off tiles), variant %d (%s): %.3f ms\n", Ton, T - Ton, v, v ? "wave pairs, 2 waves/SIMD" : "1 wave/SIMD", ms / 20);
+        printf("merged fine launch (%d on + %d off tiles), variant %d (%s): %.3f ms\n", Ton, T - Ton, v, v ? "N-split, 2 waves/SIMD" : "1 wave/SIMD", ms / 20);
     }
     {
         std::vector<unsigned long long> st(256 * 2 * 3 * NST_ * 4);
@@ -116,20 +213,51 @@ int main(int argc, char **argv)
             std::sort(d.begin(), d.end());
             return d[d.size() / 2];
         };
-        printf("stamps (s_memtime ticks, median over workgroups x 2 groups): step: A work / write / barrier | B work / write / barrier\n");
+        std::vector<unsigned long long> st2(256 * 2 * 3 * NST_ * 2);
+        (void)hipMemcpyFromSymbol(st2.data(), HIP_SYMBOL(g_stamps2), st2.size() * 8);
+        // unit start -> second k-step | second -> last k-step | last k-step -> unit end (before the barrier)
+        auto med2 = [&](int w_, int s_, int which) {
+            std::vector<long long> d;
+            for (int wg = 0; wg < 256; ++wg)
+                for (int trip = 1; trip < 3; ++trip) {
+                    const unsigned long long *p = &st[((wg * 2 + w_) * 3 + trip) * NST_ * 4 + s_ * 4];
+                    const unsigned long long *q = &st2[((wg * 2 + w_) * 3 + trip) * NST_ * 2 + s_ * 2];
+                    d.push_back(which == 0 ? (long long)(q[0] - p[0]) : which == 1 ? (long long)(q[1] - q[0]) : (long long)(p[1] - q[1]));
+                }
+            std::sort(d.begin(), d.end());
+            return d[d.size() / 2];
+        };
+        printf("inside a unit (start -> k-step 1 | k-step 1 -> last k-step | last k-step -> end):\n");
         for (int s_ = 0; s_ < NST_; ++s_)
-            printf("  step %2d: A %5lld %4lld %5lld | B %5lld %4lld %5lld\n", s_, med(0, s_, 0, 1), med(0, s_, 1, 2), med(0, s_, 2, 3),
-                   med(1, s_, 0, 1), med(1, s_, 1, 2), med(1, s_, 2, 3));
-        printf("  group total: A %lld  B %lld ticks\n", med(0, 0, 0, 3, NST_ - 1), med(1, 0, 0, 3, NST_ - 1));
+            printf("  unit %2d: w0 %5lld %5lld %5lld | w1 %5lld %5lld %5lld\n", s_, med2(0, s_, 0), med2(0, s_, 1), med2(0, s_, 2), med2(1, s_, 0), med2(1, s_, 1), med2(1, s_, 2));
+        printf("stamps (s_memtime ticks, median over workgroups x 2 groups): unit: w0 work / barrier | w1 work / barrier\n");
+        for (int s_ = 0; s_ < NST_; ++s_)
+            printf("  unit %2d: w0 %5lld %5lld | w1 %5lld %5lld\n", s_, med(0, s_, 0, 1), med(0, s_, 1, 2), med(1, s_, 0, 1), med(1, s_, 1, 2));
+        printf("  group total: w0 %lld  w1 %lld ticks\n", med(0, 0, 0, 2, NST_ - 1), med(1, 0, 0, 2, NST_ - 1));
+        {
+            std::vector<unsigned long long> ow(256 * 4 * 2);
+            (void)hipMemcpyFromSymbol(ow.data(), HIP_SYMBOL(g_ow), ow.size() * 8);
+            std::vector<long long> dt, dr;
+            for (int wg = 0; wg < 256; ++wg)
+                for (int trip = 1; trip < 3; ++trip) {
+                    dt.push_back((long long)(ow[(wg * 4 + trip + 1) * 2] - ow[(wg * 4 + trip) * 2]));
+                    dr.push_back((long long)(ow[(wg * 4 + trip + 1) * 2 + 1] - ow[(wg * 4 + trip) * 2 + 1]));
+                }
+            std::sort(dt.begin(), dt.end()); std::sort(dr.begin(), dr.end());
+            printf("  one-wave kernel, one tile group: %lld ticks in %lld x 10 ns: %.0f MHz\n", dt[dt.size() / 2], dr[dr.size() / 2],
+                   100.0 * dt[dt.size() / 2] / dr[dr.size() / 2]);
+        }
+        printf("  units 0 -> 16 start: %lld ticks in %lld x 10 ns: %.0f MHz\n", med(0, 0, 0, 0, NST_ - 1), med(0, 0, 3, 3, NST_ - 1),
+               100.0 * med(0, 0, 0, 0, NST_ - 1) / med(0, 0, 3, 3, NST_ - 1));
     }
     {
         const size_t nz = (size_t)T * 128;
         std::vector<float> a(nz), b(nz);
         (void)hipMemcpy(a.data(), z[1], nz * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(b.data(), z[0], nz * 4, hipMemcpyDeviceToHost);
-        printf("merged: z_off pair vs one-wave %.2e\n", maxrel(a, b));
+        printf("merged: z_off N-split vs one-wave %.2e\n", maxrel(a, b));
         (void)hipMemcpy(a.data(), ze[1], nz / 2 * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(b.data(), ze[0], nz / 2 * 4, hipMemcpyDeviceToHost);
         a.resize(nz / 2); b.resize(nz / 2);
-        printf("merged: z_emo pair vs one-wave %.2e\n", maxrel(a, b));
+        printf("merged: z_emo N-split vs one-wave %.2e\n", maxrel(a, b));
     }
     // ---- the input-gradient chain: both variants on the masks the forward left, per-sample gradients over five decades
     {
@@ -149,14 +277,14 @@ int main(int argc, char **argv)
         (void)hipMemset(amax, 0, 8);
         for (int v = 0; v < 2; ++v) {
             esr_mlp_split_variant(v);
-            if (int rc = esr_mlp_dgrad_fine_split(planes, planes, dz, Ton, T, M[0], dZ[v], dX[v], amax + v, nullptr)) { printf("dgrad rc %d\n", rc); return 1; }
+            if (int rc = dgrad_fine_split(planes, dz, Ton, T, M[0], dZ[v], dX[v], amax + v)) { printf("dgrad rc %d\n", rc); return 1; }
             (void)hipDeviceSynchronize();
             hipError_t err = hipGetLastError();
             if (err != hipSuccess) { printf("dgrad variant %d: %s\n", v, hipGetErrorString(err)); return 1; }
         }
         float ha[2];
         (void)hipMemcpy(ha, amax, 8, hipMemcpyDeviceToHost);
-        printf("dgrad: amax one-wave %.6e pair %.6e\n", ha[0], ha[1]);
+        printf("dgrad: amax one-wave %.6e N-split %.6e\n", ha[0], ha[1]);
         auto tile_err = [&](float *a_, float *b_, size_t rows, size_t use_rows) {       // worst per-tile max-norm error
             std::vector<float> a((size_t)T * rows * 32), b(a.size());
             (void)hipMemcpy(a.data(), a_, a.size() * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(b.data(), b_, b.size() * 4, hipMemcpyDeviceToHost);
@@ -171,7 +299,7 @@ int main(int argc, char **argv)
             }
             return worst;
         };
-        for (int l = 0; l < 3; ++l) printf("  dZ[%d] pair vs one-wave (worst tile, max-norm) %.2e\n", l, tile_err(dZ[1][l], dZ[0][l], 192, 192));
+        for (int l = 0; l < 3; ++l) printf("  dZ[%d] N-split vs one-wave (worst tile, max-norm) %.2e\n", l, tile_err(dZ[1][l], dZ[0][l], 192, 192));
         {
             std::vector<float> a((size_t)T * 6144), b(a.size());
             (void)hipMemcpy(a.data(), dZ[1][1], a.size() * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(b.data(), dZ[0][1], b.size() * 4, hipMemcpyDeviceToHost);
@@ -217,13 +345,13 @@ int main(int argc, char **argv)
                 }
             }
         }
-        printf("  dX    pair vs one-wave (rows 0..43)               %.2e\n", tile_err(dX[1], dX[0], 64, 44));
+        printf("  dX    N-split vs one-wave (rows 0..43)               %.2e\n", tile_err(dX[1], dX[0], 64, 44));
         for (int round = 0; round < 2; ++round)
         for (int v = 0; v < 2; ++v) {
             esr_mlp_split_variant(v);
-            for (int rep = 0; rep < 20; ++rep) esr_mlp_dgrad_fine_split(planes, planes, dz, Ton, T, M[0], dZ[v], dX[v], amax + v, nullptr);
+            for (int rep = 0; rep < 20; ++rep) dgrad_fine_split(planes, dz, Ton, T, M[0], dZ[v], dX[v], amax + v);
             (void)hipEventRecord(e0);
-            for (int rep = 0; rep < 20; ++rep) esr_mlp_dgrad_fine_split(planes, planes, dz, Ton, T, M[0], dZ[v], dX[v], amax + v, nullptr);
+            for (int rep = 0; rep < 20; ++rep) dgrad_fine_split(planes, dz, Ton, T, M[0], dZ[v], dX[v], amax + v);
             (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
             float ms; (void)hipEventElapsedTime(&ms, e0, e1);
             printf("merged dgrad launch (%d tiles), variant %d: %.3f ms\n", T, v, ms / 20);
