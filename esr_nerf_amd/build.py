@@ -40,7 +40,10 @@ def _stamp(paths):
 # per-source flags (none at present).  Tried for mlp_split.hip, which runs ONE wave per SIMD on ~460 registers:
 # `-mllvm -amdgpu-mfma-vgpr-form=1` keeps the MFMA accumulators in the VGPR half (1163 -> 477 v_accvgpr_read per tile group,
 # 6.6 k -> 6.1 k instructions in the loop body) but moves the planes' traffic to v_accvgpr_write: 0.705 -> 0.72 ms at C2.
-EXTRA = {}
+# tone_wgrad.hip: the SLP vectoriser packs the per-lane fp32 sums of the weight-gradient kernels into v_pk_fma_f32 / v_pk_add_f32 on
+# register PAIRS -- 150 register moves per tile and 100+ more live registers in tone_wgrad_split_t_kernel (367 registers, or
+# 320 bytes of scratch at two waves per SIMD; 194 registers and no moves without it: round 6).
+EXTRA = {"tone_wgrad.hip": ["-fno-slp-vectorize"]}
 
 
 def _compile(src):

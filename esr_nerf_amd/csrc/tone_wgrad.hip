@@ -436,7 +436,8 @@ __global__ void __launch_bounds__(256, 1) tone_wgrad16_t_kernel(ToneWgArgs A)
 // a scale where the largest value is ~1e3) -- in a sum over all tiles that is 2^-35 of the dominant terms.
 typedef _Float16 tf16x8 __attribute__((ext_vector_type(8)));
 constexpr float TW_SCALE = 64.f;
-constexpr int WAVE_LDSS = 2 * 32 * XS16 * 2 + (4 + 1) * XS * 4;  // bytes per wave: Xt rows 0..31 as two fp16 planes | dzt rows 0..3 + Xt row 32 (f32)
+constexpr int WAVE_LDSS = (4 + 1) * XS * 4;                     // bytes per wave: dzt rows 0..3 + Xt row 32 (f32)
+constexpr int W1S_BYTES = 2 * THID * 8 * 2;                     // 64 W1 as two fp16 planes [192][8] (B of dHt^T: k = output channel)
 constexpr int W0S_BYTES = 2 * THID * W0B_U * 2;                 // W0 as two fp16 planes [192][W0B_U]
 
 __device__ __forceinline__ void tsplit8(const float (&v)[8], tf16x8 &hi, tf16x8 &lo)
@@ -465,23 +466,66 @@ struct ToneWgSplitArgs {
     const float *amax;                      // max |dzt| of the step (device)
 };
 
-__global__ void __launch_bounds__(256, 1) tone_wgrad_split_t_kernel(ToneWgSplitArgs AS)
+// x -> (fp16(x), fp16(x - fp16(x))) for two values into slots I0, I0 + 1 of the plane registers: mlp_split.hip's put_pair /
+// put_residual_pair (one v_cvt_pk + two v_fma_mix + one v_cvt_pk per pair; the C form -- tsplit8 -- costs ~5 instructions per
+// value).  The operands must be VALU results or loaded values, never a fresh MFMA result (tests/test_isa.py).
+typedef _Float16 tf16x2 __attribute__((ext_vector_type(2)));
+template <int I0>
+__device__ __forceinline__ void tsplit_pair(tf16x8 &hi, tf16x8 &lo, float v0, float v1)
+{
+    const tf16x2 hh = {(_Float16)v0, (_Float16)v1};
+    const unsigned u = __builtin_bit_cast(unsigned, hh);
+    unsigned r;
+    float d0, d1;
+    asm volatile("v_fma_mix_f32 %1, %3, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+                 "v_fma_mix_f32 %2, %3, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                 "v_cvt_pk_f16_f32 %0, %1, %2"
+                 : "=v"(r), "=&v"(d0), "=&v"(d1) : "v"(u), "v"(v0), "v"(v1));
+    const tf16x2 ll = __builtin_bit_cast(tf16x2, r);
+    hi[I0] = hh[0]; hi[I0 + 1] = hh[1];
+    lo[I0] = ll[0]; lo[I0 + 1] = ll[1];
+}
+__device__ __forceinline__ void tsplit8f(const float (&v)[8], tf16x8 &hi, tf16x8 &lo)
+{
+    tsplit_pair<0>(hi, lo, v[0], v[1]);
+    tsplit_pair<2>(hi, lo, v[2], v[3]);
+    tsplit_pair<4>(hi, lo, v[4], v[5]);
+    tsplit_pair<6>(hi, lo, v[6], v[7]);
+}
+
+// Round 6.  (i) The recomputed hidden layer is the FORWARD's, bit for bit: mlp_fwd_split_kernel<1> forms a pre-activation as
+// fma(acc, 1/64, bias) with acc = the k-steps' products w1.x2, w1.x1, w2.x1 in that order from a zero accumulator; here the
+// same products (A and B exchanged: the sample is on the lane's row) in the same order, the same fma, the same integer ReLU --
+// so the branch this kernel takes at a unit is the branch the forward saved in its mask, and the step is self-consistent at
+// kink units without reading the masks back (tests/test_gpu_split.py::test_tone_wgrad_takes_the_forwards_branches; until round
+// 6 the accumulator started from 64 b and the products came in another order: a unit within summation noise of its kink could
+// take the other branch, the one allowance the oracle comparison had to make).  (ii) The kernel's instruction count: the
+// planes by mlp_split.hip's pair conversions, the B operand of dW0 (X rows over permuted samples) straight from global memory
+// as two planes -- no transposition through LDS (32 two-byte writes + 12 reads per tile) --, everything inside 256 registers:
+// no accumulation-register moves (176 per tile before) and two waves per SIMD.
+__global__ void __launch_bounds__(256, 2) tone_wgrad_split_t_kernel(ToneWgSplitArgs AS)
 {
     const ToneWgArgs &A = AS.a;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldss[];
     _Float16 *w0h = reinterpret_cast<_Float16 *>(ldss), *w0l = w0h + THID * W0B_U;      // [192][W0B_U] each: 64 W0[u][x]
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, ul = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned char *mine = ldss + W0S_BYTES + wv * WAVE_LDSS;
-    _Float16 *xh = reinterpret_cast<_Float16 *>(mine), *xl = xh + 32 * XS16;            // [32][XS16] each
-    float *lz = reinterpret_cast<float *>(mine + 2 * 32 * XS16 * 2);                   // dzt rows 0..3, [4][XS]
-    float *lx32 = lz + 4 * XS;                                                          // Xt row 32, [XS]
+    _Float16 *w1hp = reinterpret_cast<_Float16 *>(ldss + W0S_BYTES), *w1lp = w1hp + THID * 8;   // [192][8] each: 64 W1[c][u], c < 3
+    float *lz = reinterpret_cast<float *>(ldss + W0S_BYTES + W1S_BYTES) + wv * (5 * XS);          // this wave's dzt rows 0..3 and Xt row 32, [5][XS]
+    float *lx32 = lz + 4 * XS;
     for (int i = tid; i < THID * W0B_U; i += 256) {
         const int u = i / W0B_U, x = i % W0B_U;
         const float w = x < TIN ? TW_SCALE * A.W0[u * TIN + x] : 0.f;
         const _Float16 hh = (_Float16)w;
         w0h[i] = hh;
         w0l[i] = (_Float16)(w - (float)hh);
+    }
+    for (int i = tid; i < THID * 8; i += 256) {
+        const int u = i >> 3, c = i & 7;
+        const float w = c < TOUT ? TW_SCALE * A.W1[c * THID + u] : 0.f;
+        const _Float16 hh = (_Float16)w;
+        w1hp[i] = hh;
+        w1lp[i] = (_Float16)(w - (float)hh);
     }
     __syncthreads();
     // the step's gradient scale: 2^k with max |dzt| 2^k in [16, 32) (1 for an all-zero or non-finite maximum)
@@ -497,17 +541,9 @@ __global__ void __launch_bounds__(256, 1) tone_wgrad_split_t_kernel(ToneWgSplitA
     }
 
     const int g = wv & 1;                                                   // this wave's hidden units [96 g, 96 g + 96)
-    tf16x8 w1h[3], w1l[3];
     float b0r[3];
 #pragma unroll
-    for (int i3 = 0; i3 < 3; ++i3) {
-        const int u = 96 * g + 32 * i3 + ul;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (h == 0 && e < TOUT) ? TW_SCALE * A.W1[e * THID + u] : 0.f;
-        tsplit8(v, w1h[i3], w1l[i3]);
-        b0r[i3] = TW_SCALE * A.b0[u];
-    }
+    for (int i3 = 0; i3 < 3; ++i3) b0r[i3] = A.b0[96 * g + 32 * i3 + ul];
     f32x16 dW0[3];
     zero_tiles<3>(dW0);
     float dW0c[3], dW1r[3][3], db0r[3], db1r[2] = {0.f, 0.f};
@@ -517,77 +553,76 @@ __global__ void __launch_bounds__(256, 1) tone_wgrad_split_t_kernel(ToneWgSplitA
         dW1r[i3][0] = dW1r[i3][1] = dW1r[i3][2] = 0.f;
     }
     const int pair = blockIdx.x * 2 + (wv >> 1), npairs = gridDim.x * 2;
+    // a tile's rows as this lane needs them: A of Ht^T (sample ul: input rows 16 q + 8 h + e and 32), B of dW0 (input row ul:
+    // the samples of k-slots (q, h, e) = acc_row(8 q + e, h): two runs of four), dzt (rows h and 2)
     float xn[17], zn[2];
     auto fetch = [&](int t) {
         const bool live = t < A.t1;
-        const float *X = A.Xt + (size_t)(live ? t : A.t0) * XT_ROWS * 32 + ul;
+        const float *X = A.Xt + (size_t)(live ? t : A.t0) * XT_ROWS * 32;
         const float *Zt = A.dzt + (size_t)(live ? t : A.t0) * 4 * 32 + ul;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) xn[j] = X[(16 * (j >> 3) + 8 * h + (j & 7)) * 32];
-        xn[16] = X[(32 + 8 * h) * 32];
+        for (int j = 0; j < 16; ++j) xn[j] = X[(16 * (j >> 3) + 8 * h + (j & 7)) * 32 + ul];
+        xn[16] = X[(32 + 8 * h) * 32 + ul];
         zn[0] = Zt[h * 32];
         zn[1] = h == 0 ? Zt[2 * 32] : 0.f;
     };
-    const int xp = xperm(ul);
     if (A.t0 + pair < A.t1) fetch(A.t0 + pair);
     for (int t = A.t0 + pair; t < A.t1; t += npairs) {
-        float xa[17], za[2];
+        // the B operand of dW0: this tile's row ul over the permuted samples (second read of the tile: L2), used a block from now
+        float4 bn[4];
+        {
+            const float *X = A.Xt + (size_t)t * XT_ROWS * 32 + ul * 32 + 4 * h;
 #pragma unroll
-        for (int j = 0; j < 17; ++j) xa[j] = xn[j];
-        za[0] = zn[0]; za[1] = zn[1];
-        fetch(t + npairs);                              // one wave per SIMD: the next tile's rows a tile ahead
-        db1r[0] += za[0]; db1r[1] += za[1];
-        // the A operands of Ht^T (this lane's 8 input rows per k-step) as planes; the same values, permuted, staged for dW0's B
-        tf16x8 a8h[3], a8l[3];
+            for (int k = 0; k < 4; ++k) bn[k] = *reinterpret_cast<const float4 *>(X + 16 * (k >> 1) + 8 * (k & 1));
+        }
+        // this tile's A operands as planes, then the next tile's loads
+        tf16x8 a8h[3], a8l[3], xqh[2], xql[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = xa[8 * q + e];
-            tsplit8(v, a8h[q], a8l[q]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                xh[(16 * q + 8 * h + e) * XS16 + xp] = a8h[q][e];
-                xl[(16 * q + 8 * h + e) * XS16 + xp] = a8l[q][e];
-            }
+            for (int e = 0; e < 8; ++e) v[e] = xn[8 * q + e];
+            tsplit8f(v, a8h[q], a8l[q]);
         }
         {
-            const float v[8] = {xa[16], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const float v[8] = {xn[16], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             tsplit8(v, a8h[2], a8l[2]);
         }
-        lz[h * XS + ul] = za[0];
-        if (h == 0) { lz[2 * XS + ul] = za[1]; lx32[ul] = xa[16]; }
-        float x32[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 d4 = *reinterpret_cast<const float4 *>(lx32 + 8 * q + 4 * h);
-            x32[4 * q] = d4.x; x32[4 * q + 1] = d4.y; x32[4 * q + 2] = d4.z; x32[4 * q + 3] = d4.w;
-        }
+        const float za0 = zn[0], za1 = zn[1];
+        lz[h * XS + ul] = za0;
+        if (h == 0) { lz[2 * XS + ul] = za1; lx32[ul] = xn[16]; }
+        db1r[0] += za0; db1r[1] += za1;
         // (S dzt)^T as the A operand of dHt^T: slots 0..2 of half 0 = dzt rows 0..2 of this lane's sample
-        const float z1 = __shfl_xor(za[0], 32);
+        const float z1 = __shfl_xor(za0, 32);
         tf16x8 zah, zal;
         {
-            const float v[8] = {h == 0 ? S * za[0] : 0.f, h == 0 ? S * z1 : 0.f, h == 0 ? S * za[1] : 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const float v[8] = {h == 0 ? S * za0 : 0.f, h == 0 ? S * z1 : 0.f, h == 0 ? S * za1 : 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             tsplit8(v, zah, zal);
         }
-        // one 32-unit block at a time (one Ht tile live instead of three)
+        fetch(t + npairs);                              // (past the range: re-reads tile t0, never used)
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // one 32-unit block at a time
 #pragma unroll
         for (int i3 = 0; i3 < 3; ++i3) {
-            // ---- 64 Ht^T[s][u]
-            f32x16 ht;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ht[r] = b0r[i3];
+            // ---- the forward's pre-activation, bit for bit: acc = sum over the k-steps of w1.x2 + w1.x1 + w2.x1 (64 w planes)
+            f32x16 acc = zero16;
             const int wrow = (96 * g + 32 * i3 + ul) * W0B_U + 8 * h;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const tf16x8 bh = *reinterpret_cast<const tf16x8 *>(w0h + wrow + 16 * q);
                 const tf16x8 bl = *reinterpret_cast<const tf16x8 *>(w0l + wrow + 16 * q);
-                ht = tmfma3(a8h[q], a8l[q], bh, bl, ht);
+                acc = tmfma(a8l[q], bh, acc);
+                acc = tmfma(a8h[q], bh, acc);
+                acc = tmfma(a8h[q], bl, acc);
             }
-            // (ReLU in C: the compiler's hazard recogniser must see the read of the MFMA result -- see the bf16 twin)
+            // value = acc / 64 + bias, ReLU as max((int) bits, 0): mlp_split.hip's epilogue (compiler-visible reads of the MFMA result)
+            float ht[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ht[r] = fmaxf(ht[r], 0.f);
-            // ---- 64 dW1[c][u] += sum_s dzt[c][s] (64 Ht[u][s]): fp32 vector sums
+            for (int r = 0; r < 16; ++r) {
+                const int bits = __float_as_int(fmaf(acc[r], 1.f / TW_SCALE, b0r[i3]));
+                ht[r] = __int_as_float(bits > 0 ? bits : 0);
+            }
+            // ---- dW1[c][u] += sum_s dzt[c][s] Ht[u][s]: fp32 vector sums
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 a = *reinterpret_cast<const float4 *>(lz + 0 * XS + 8 * q + 4 * h);
@@ -602,37 +637,47 @@ __global__ void __launch_bounds__(256, 1) tone_wgrad_split_t_kernel(ToneWgSplitA
                     dW1r[i3][2] = fmaf(zc4[i], hv, dW1r[i3][2]);
                 }
             }
-            // ---- 64 S dHt^T = (S dzt)^T (64 W1), masked by the recomputed activation; then 64 S dW0 += (64 S dZt) Xt^T
-            f32x16 d;
+            // ---- 64 S dHt^T = (S dzt)^T (64 W1), masked by the forward's branch; then 64 S dW0 += (64 S dZt) Xt^T
+            const int w1row = (96 * g + 32 * i3 + ul) * 8;
+            const tf16x8 w1h = *reinterpret_cast<const tf16x8 *>(w1hp + w1row), w1l = *reinterpret_cast<const tf16x8 *>(w1lp + w1row);
+            f32x16 d = tmfma3(zah, zal, w1h, w1l, zero16);      // (half 1's k-slots: zah / zal are zero there)
+            float sb = 0.f, sc = 0.f, dv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d[r] = 0.f;
-            d = tmfma3(zah, zal, w1h[i3], w1l[i3], d);
-            float sb = 0.f, sc = 0.f;
+            for (int q = 0; q < 4; ++q) {
+                const float4 x4 = *reinterpret_cast<const float4 *>(lx32 + 8 * q + 4 * h);       // Xt row 32 at this half-wave's samples
+                const float x32[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = ht[r] > 0.f ? d[r] : 0.f;
-                d[r] = v;
-                sb += v;
-                sc = fmaf(v, x32[r], sc);
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * q + i;
+                    const float v = __float_as_int(ht[r]) > 0 ? d[r] : 0.f;
+                    dv[r] = v;
+                    sb += v;
+                    sc = fmaf(v, x32[i], sc);
+                }
             }
             db0r[i3] += sb;
             dW0c[i3] += sc;
+            if (i3 == 0) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float b[8] = {bn[2 * q].x, bn[2 * q].y, bn[2 * q].z, bn[2 * q].w, bn[2 * q + 1].x, bn[2 * q + 1].y, bn[2 * q + 1].z, bn[2 * q + 1].w};
+                    tsplit8f(b, xqh[q], xql[q]);
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = d[8 * q + e];
+                for (int e = 0; e < 8; ++e) v[e] = dv[8 * q + e];
                 tf16x8 aqh, aql;
-                tsplit8(v, aqh, aql);
-                const tf16x8 xqh = *reinterpret_cast<const tf16x8 *>(xh + ul * XS16 + (2 * q + h) * 8);
-                const tf16x8 xql = *reinterpret_cast<const tf16x8 *>(xl + ul * XS16 + (2 * q + h) * 8);
-                dW0[i3] = tmfma3(aqh, aql, xqh, xql, dW0[i3]);
+                tsplit8f(v, aqh, aql);
+                dW0[i3] = tmfma3(aqh, aql, xqh[q], xql[q], dW0[i3]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     // ---- flush (same slab layout as the f32 kernel), scales removed
-    const float iw = 1.f / TW_SCALE, ig = 1.f / (TW_SCALE * S);
+    const float ig = 1.f / (TW_SCALE * S);
     float *Sl = A.slab + (size_t)pair * SLAB;
 #pragma unroll
     for (int i3 = 0; i3 < 3; ++i3) {
@@ -649,7 +694,7 @@ __global__ void __launch_bounds__(256, 1) tone_wgrad_split_t_kernel(ToneWgSplitA
             Sl[u * TIN + 32] = c32 * ig;
             Sl[N_DW0 + N_DW1 + u] = b * ig;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) Sl[N_DW0 + c * THID + u] = w1[c] * iw;
+            for (int c = 0; c < 3; ++c) Sl[N_DW0 + c * THID + u] = w1[c];
         }
     }
     float d0 = db1r[0], d1 = db1r[1];
@@ -746,7 +791,7 @@ ESR_API int esr_tone_wgrad_recompute_split(const float *Xt, const float *dzt, co
     int grid = (n_tiles + 1) / 2;
     if (grid > 512) grid = 512;                                        // two workgroups (8 waves) per CU
     if ((int64_t)grid * 2 * SLAB > scratch_floats) return ESR_ECAP;
-    constexpr size_t lds_bytes = (size_t)W0S_BYTES + 4 * WAVE_LDSS;
+    constexpr size_t lds_bytes = (size_t)W0S_BYTES + W1S_BYTES + 4 * WAVE_LDSS;
     static std::atomic<uint64_t> optin{0};
     if (int rc = esr_lds_optin(reinterpret_cast<const void *>(&tone_wgrad_split_t_kernel), lds_bytes, optin)) return rc;
     ToneWgSplitArgs A = {{Xt, dzt, W0, b0, W1, t0, t1, scratch}, amax};

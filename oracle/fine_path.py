@@ -234,10 +234,6 @@ KNIFE_LOG: Optional[list] = None      # tests may set a list: receives (weight k
 FLIP_LOG: Optional[list] = None       # tests may set a list: receives one record per forced ReLU layer (see mlp)
 
 
-RECOMPUTE_LOG: Optional[list] = None         # tests: see mlp()
-RECOMPUTE_KINK = 4e-6
-
-
 def mlp(P: Dict[str, Tensor], keys, x: Tensor, knife: Optional[Tensor] = None, force=None) -> Tensor:
     """Linear+ReLU chain; the last layer is linear.  ``knife`` ([rows] float, optional) is lowered in place to the
     smallest |hidden pre-activation| of every row: a ReLU unit that close to its kink can take the other branch under
@@ -262,7 +258,6 @@ def mlp(P: Dict[str, Tensor], keys, x: Tensor, knife: Optional[Tensor] = None, f
                         KNIFE_LOG.append((k, (x.detach().abs() < 2e-6).nonzero()[:, 1].unique()))
             if force is not None:
                 mask = force[i]
-                pre = x.detach()
                 with torch.no_grad():
                     flip = mask != (x.detach() > 0)
                     if FLIP_LOG is not None:
@@ -274,16 +269,6 @@ def mlp(P: Dict[str, Tensor], keys, x: Tensor, knife: Optional[Tensor] = None, f
                             worst = float(x64[flip[rows]].abs().max())
                         FLIP_LOG.append((k, int(flip.sum()), worst))
                 x = x * mask.to(x.dtype)
-                if RECOMPUTE_LOG is not None and k.startswith("tonemapper."):
-                    # The HIP tone mapper's WEIGHT gradients recompute this layer (csrc/tone_wgrad.hip) instead of reading
-                    # the forward's branches: at a unit within summation noise of its kink the recomputation may take the
-                    # other one.  Logged for the tests: those (row, unit) pairs, their inputs, and (by a hook) the gradient
-                    # arriving at the unit's OUTPUT -- what the row's weight gradient can differ by, exactly.
-                    near = (pre.abs() < RECOMPUTE_KINK).nonzero()
-                    entry = dict(key=k, units=near[:, 1], xin=xin.detach()[near[:, 0]], gh=None)
-                    RECOMPUTE_LOG.append(entry)
-                    if x.requires_grad and near.numel():
-                        x.register_hook(lambda g, e=entry, n=near: e.__setitem__("gh", g[n[:, 0], n[:, 1]].clone()))
             else:
                 x = F.relu(x)
     return x

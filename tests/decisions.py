@@ -74,26 +74,6 @@ def assert_legitimate(keep, flip_log, thres=1e-4, what=""):
     return n_thr, n_flip
 
 
-def recompute_allowance(log, shapes):
-    """What the tone mapper's first-layer weight gradients may differ by because csrc/tone_wgrad.hip RECOMPUTES the hidden
-    layer instead of reading the forward's ReLU branches (oracle.fine_path.mlp: RECOMPUTE_LOG): for every (sample, unit)
-    whose pre-activation is within 4e-6 of the kink, |gradient at the unit's output| x |that sample's inputs| on the unit's
-    row (and |gradient| on its bias) -- the exact size of that sample's contribution, not a blanket tolerance.  Everything
-    outside those pairs still compares at the tests' 1e-4.  -> {tensor name: allowance tensor}, number of pairs."""
-    out, pairs = {}, 0
-    for e in log:
-        if e["gh"] is None:
-            continue
-        w, b = e["key"] + ".weight", e["key"] + ".bias"
-        aw = out.setdefault(w, torch.zeros(shapes[w], dtype=torch.float64))
-        ab = out.setdefault(b, torch.zeros(shapes[b], dtype=torch.float64))
-        g = e["gh"].abs().double()
-        aw.index_add_(0, e["units"], g[:, None] * e["xin"].abs().double())
-        ab.index_add_(0, e["units"], g)
-        pairs += int(g.numel())
-    return out, pairs
-
-
 # ---- the light-transport steps (esr_nerf_amd/lts_engine.py: four sampling passes) ------------------------------------
 def _pass_masks(P, net, n_hidden, hid_tiles):
     T = P.tiles_all

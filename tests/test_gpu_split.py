@@ -787,3 +787,86 @@ def test_autograd_route_heals_in_the_forward():
         assert rel_err(res["split"][1][k], v) < 2e-5, k
 
 
+
+
+@pytest.mark.parametrize("engine", ["split", "f32"])
+def test_tone_wgrad_takes_the_forwards_branches(engine):
+    """The tone mapper's weight gradients RECOMPUTE the hidden layer (csrc/tone_wgrad.hip) instead of reading what the forward
+    saved.  The step is self-consistent only if the recomputation takes, at every (sample, unit), the ReLU branch the forward
+    took -- also at a unit within summation noise of its kink, where any other order of the same sum may land on the other
+    side.  Round 6 made the recomputation the forward's arithmetic bit for bit (same products, same order, same fma, same integer
+    ReLU).  Adversarial data: every sample is one of eight vectors and every unit's bias cancels its pre-activation on one of
+    them, so an eighth of ALL (sample, unit) pairs sit within rounding of zero; the reference is a float64 evaluation ON THE
+    BRANCHES THE FORWARD SAVED in its masks.  One disagreeing pair would show as that sample's whole contribution to the
+    unit's row (|dz W1| |x| ~ 1e-3 of the row's largest entry, against the 2e-6 asserted)."""
+    from esr_nerf_amd import _lib
+    from decisions import _decode_masks
+    L = _lib.lib()
+    s = _lib.stream_ptr("cuda:0")
+    tiles, kind = 96, 1
+    g = torch.Generator().manual_seed(5)
+    W0 = torch.randn(192, 33, generator=g) / 33 ** 0.5
+    W1 = torch.randn(3, 192, generator=g) / 192 ** 0.5
+    b1 = torch.randn(3, generator=g) * 0.1
+    proto = torch.randn(8, 33, generator=g)
+    which = torch.randint(0, 8, (tiles * 32,), generator=g)
+    x = proto[which]                                                    # [samples, 33]
+    # b0[u] = -fp32(W0[u] . proto[u % 8]): summed in fp32 in yet another order than either kernel
+    b0 = -(W0 * proto[torch.arange(192) % 8]).sum(1)
+    X = torch.zeros(tiles, 48, 32)
+    X[:, :33] = x.reshape(tiles, 32, 33).permute(0, 2, 1)
+    pre = torch.nn.functional.linear(x.double(), W0.double(), b0.double())        # [samples, 192]
+    on_edge = pre.abs() < 1e-6
+    assert int(on_edge.sum()) > tiles * 32 * 192 // 10
+    keep = [(W0.cuda().contiguous(), b0.cuda().contiguous()), (W1.cuda().contiguous(), b1.cuda().contiguous())]
+    w = _lib.EsrMlpWeights()
+    for i, (a, b) in enumerate(keep):
+        w.w[i], w.b[i] = a.data_ptr(), b.data_ptr()
+    packed = torch.empty(L.esr_mlp_packed_floats(kind), device="cuda")
+    planes = torch.empty(L.esr_mlp_packed_split_elems(kind), dtype=torch.float16, device="cuda")
+    _lib.check(L.esr_mlp_pack_batch(1, (C.c_int32 * 1)(kind), (C.c_void_p * 1)(C.addressof(w)), (C.c_void_p * 1)(packed.data_ptr()), None,
+                                    (C.c_void_p * 1)(planes.data_ptr()), s), "pack")
+    Xd = X.cuda().contiguous()
+    M = [torch.zeros(tiles, 3, 64, dtype=torch.int32, device="cuda")]
+    H = [torch.zeros(tiles, 192, 32, device="cuda")]
+    z = torch.zeros(tiles, 4, 32, device="cuda")
+    if engine == "split":
+        rc = L.esr_mlp_fwd_split(kind, _lib.ptr(packed), _lib.ptr(planes), _lib.ptr(Xd), 0, tiles, _lib.ptr_array(H), _lib.ptr_array(M), 2, 0,
+                                 _lib.ptr(z), s)
+    else:
+        rc = L.esr_mlp_fwd(kind, _lib.ptr(packed), _lib.ptr(Xd), 0, tiles, _lib.ptr_array(H), _lib.ptr_array(M), 2, 0, _lib.ptr(z), s)
+    _lib.check(rc, "fwd")
+    torch.cuda.synchronize()
+    mask = _decode_masks(M[0].cpu(), 6).permute(0, 2, 1).reshape(tiles * 32, 192)              # the forward's branches
+    frac_on = float(mask[on_edge].double().mean())
+    print(f"{engine}: {int(on_edge.sum())} (sample, unit) pairs within 1e-6 of the kink, the forward kept {frac_on:.2f} of them")
+    assert 0.1 < frac_on < 0.9                                          # (noise decides there: the test has teeth)
+    dz = torch.randn(tiles, 4, 32, generator=g) * 1e-3
+    dz[:, 3] = 0.0
+    dzd = dz.cuda().contiguous()
+    gw0, gb0 = torch.zeros(192, 33, device="cuda"), torch.zeros(192, device="cuda")
+    gw1, gb1 = torch.zeros(3, 192, device="cuda"), torch.zeros(3, device="cuda")
+    scratch = torch.empty(L.esr_tone_wgrad_scratch_floats(), device="cuda")
+    amax = dzd.abs().max().reshape(1).contiguous()
+    if engine == "split":
+        rc = L.esr_tone_wgrad_recompute_split(_lib.ptr(Xd), _lib.ptr(dzd), _lib.ptr(keep[0][0]), _lib.ptr(keep[0][1]), _lib.ptr(keep[1][0]),
+                                              _lib.ptr(amax), 0, tiles, _lib.ptr(gw0), _lib.ptr(gb0), _lib.ptr(gw1), _lib.ptr(gb1),
+                                              _lib.ptr(scratch), C.c_int64(scratch.numel()), s)
+    else:
+        rc = L.esr_tone_wgrad_recompute(_lib.ptr(Xd), _lib.ptr(dzd), _lib.ptr(keep[0][0]), _lib.ptr(keep[0][1]), _lib.ptr(keep[1][0]),
+                                        0, tiles, _lib.ptr(gw0), _lib.ptr(gb0), _lib.ptr(gw1), _lib.ptr(gb1),
+                                        _lib.ptr(scratch), C.c_int64(scratch.numel()), s)
+    _lib.check(rc, "tone_wgrad")
+    torch.cuda.synchronize()
+    dzs = dz[:, :3].permute(0, 2, 1).reshape(tiles * 32, 3).double()
+    md = mask.double()
+    h = pre * md
+    dH = (dzs @ W1.double()) * md
+    ref = {"gw1": dzs.t() @ h, "gb1": dzs.sum(0), "gw0": dH.t() @ x.double(), "gb0": dH.sum(0)}
+    got = {"gw1": gw1, "gb1": gb1, "gw0": gw0, "gb0": gb0}
+    # what ONE wrong branch would cost: the largest single-pair contribution to a first-layer row, relative to the tensor's largest entry
+    one = float(((dzs @ W1.double()).abs().max(0).values[:, None] * x.double().abs().max(0).values[None, :]).max() / ref["gw0"].abs().max())
+    for k in ("gw0", "gb0", "gw1", "gb1"):
+        e = rel_err(got[k], ref[k])
+        print(f"{engine} {k}: {e:.2e} (one wrong branch on the worst pair: {one:.1e} of gw0's largest entry)")
+        assert e < 2e-6, (k, e)
