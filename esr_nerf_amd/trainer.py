@@ -48,6 +48,15 @@ def dp_loss_weights(n_local: int, global_rays, entropy_owner: bool, weight_entro
     return scale, w_ent
 
 
+def lts_point_share(num_ltspts: int, world: int, rank: int):
+    """(points, weight) of one rank when ``LtsStep(split_points=True)`` splits the reference's ``num_ltspts`` surface points
+    over ``world`` ranks: the remainder goes to the first ranks one point each (the counts add up to ``num_ltspts``), and a
+    rank's per-point loss terms -- means over ITS points -- enter the global mean with ``points / num_ltspts``."""
+    base, rem = divmod(int(num_ltspts), int(world))
+    n = base + (1 if rank < rem else 0)
+    return n, n / float(num_ltspts)
+
+
 def _grid_sync(step, eng):
     """after_grids callback of a data-parallel step: how the dense-grid gradients are summed over ranks.
 
@@ -403,16 +412,20 @@ class LtsStep:
 
     def __init__(self, model, trainer_cfg, stage: str = "lts", white_bg: bool = True, process_group=None,
                  split_points: bool = False):
-        """``split_points``: under data parallelism draw ``num_ltspts / G`` surface points per rank instead of
-        ``num_ltspts`` on each (the reference's setting is per process): the GLOBAL light-transport estimate then uses
-        the reference's number of points and secondary rays, and the per-rank secondary work shrinks with G."""
+        """``split_points``: under data parallelism split the reference's ``num_ltspts`` surface points over the ranks
+        (``lts_point_share``: the remainder one point each to the first ranks, so the counts add up to ``num_ltspts``; the
+        per-point loss terms are weighted by a rank's actual share) instead of drawing ``num_ltspts`` on each (the
+        reference's setting is per process): the GLOBAL light-transport estimate then uses the reference's number of points
+        and secondary rays, and the per-rank secondary work shrinks with G."""
         if stage not in ("lts", "pdra"):
             raise ValueError("stage must be 'lts' or 'pdra'")
         self.model, self.t, self.stage, self.white_bg, self.pg = model, trainer_cfg, stage, white_bg, process_group
         self.ltspts = int(model.num_ltspts)
+        self.pt_scale = None                 # weight of this rank's per-point terms in the global mean (None: the ray share)
         if split_points and process_group is not None:
             import torch.distributed as dist
-            self.ltspts = max(1, self.ltspts // dist.get_world_size(process_group))
+            self.ltspts, self.pt_scale = lts_point_share(self.ltspts, dist.get_world_size(process_group),
+                                                         dist.get_rank(process_group))
         self._names = None
         self._flat = None
         self._sync = None
@@ -554,17 +567,18 @@ class LtsStep:
                                                        self.white_bg, t.weight_linear, w_ent, scale=scale)
         g = {"etc/alphainv_cum": g_last, "srgb/rgb": g_srgb, "lin/rgb": g_lin}
         wl = t.weight_lts
+        pscale = scale if self.pt_scale is None else self.pt_scale       # the terms that are means over the surface POINTS
         if not pdra:
             g["lin/pbr/off"], g["lin/pbr/off_hat"] = self._pair(eng, loss, out["lin/pbr/off"], out["lin/pbr/off_hat"],
-                                                                0, wl, wl, wl, scale)
+                                                                0, wl, wl, wl, pscale)
             g["lin/pbr/emo"], g["lin/pbr/emo_hat"] = self._pair(eng, loss, out["lin/pbr/emo"], out["lin/pbr/emo_hat"],
-                                                                0, wl, wl, wl, scale)
+                                                                0, wl, wl, wl, pscale)
         else:
             g["lin/pbr/off"], g["lin/pbr/off_hat"] = self._pair(eng, loss, out["lin/pbr/off"], out["lin/pbr/off_hat"],
-                                                                1, wl, wl, wl, scale)
+                                                                1, wl, wl, wl, pscale)
             wL, wR = t.weight_lts_l, t.weight_lts_r
             g["lin/pbr/emo"], g["lin/pbr/emo_hat"] = self._pair(eng, loss, out["lin/pbr/emo"], out["lin/pbr/emo_hat"],
-                                                                1, wl * (wL + wR), wl * wR, wl * wL, scale)
+                                                                1, wl * (wL + wR), wl * wR, wl * wL, pscale)
             um8 = batch["uncert_masks"].view(torch.uint8)
             n_cert = (um8 == 0).sum(dtype=torch.int32).view(1)
             g["emit_marched"], _ = self._pair(eng, loss, out["emit_marched"], None, 0, t.weight_emit_supp,

@@ -169,14 +169,14 @@ import torch.distributed as dist
 from esr_nerf_amd.config import lts_cfg
 from esr_nerf_amd.esrnerf import ESRNeRF
 from esr_nerf_amd.synthetic import init_slab_model, slab_scene
-from esr_nerf_amd.trainer import LtsStep, shard_batch
+from esr_nerf_amd.trainer import LtsStep, lts_point_share, shard_batch
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 torch.cuda.set_device(0)
 s_val = 60.0
 sc = slab_scene("small", s_val=s_val, oblique=True, n_rays=384, seed=2)
 torch.manual_seed(0); np.random.seed(0)
-cfg = lts_cfg("cuda:0", num_2ndrays=16, num_ltspts=24)
+cfg = lts_cfg("cuda:0", num_2ndrays=16, num_ltspts=25)      # (odd: the split leaves a remainder)
 m = ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max, sc.mask_alpha_init,
             sc.mask_density, sc.s_val, sc.num_voxels)
 init_slab_model(m, sc, seed=3)
@@ -192,6 +192,10 @@ for stage in ("lts", "pdra"):
     for split_points in (False, True):
         # the data-parallel step: every rank its ray shard and its own draws (seeded per rank)
         step = LtsStep(m, cfg.app.trainer, stage=stage, process_group=dist.group.WORLD, split_points=split_points)
+        if split_points:                                 # the ranks' shares add up to the reference's number of points
+            cnt = torch.tensor([step.ltspts])
+            dist.all_reduce(cnt)
+            assert int(cnt) == m.num_ltspts == 25 and step.ltspts == (13 if rank == 0 else 12)
         torch.manual_seed(100 + rank); np.random.seed(100 + rank)
         loss, G, _ = step.forward_loss_backward(shard_batch(full, rank, world), s_val, global_rays=n, entropy_owner=(rank == world - 1))
         torch.cuda.synchronize()
@@ -202,7 +206,8 @@ for stage in ("lts", "pdra"):
         ref_loss, ref = 0.0, None
         for r in range(world):
             one = LtsStep(m, cfg.app.trainer, stage=stage)
-            one.ltspts = step.ltspts
+            if split_points:
+                one.ltspts, one.pt_scale = lts_point_share(m.num_ltspts, world, r)
             torch.manual_seed(100 + r); np.random.seed(100 + r)
             l_r, G_r, _ = one.forward_loss_backward(shard_batch(full, r, world), s_val, global_rays=n, entropy_owner=(r == world - 1))
             torch.cuda.synchronize()

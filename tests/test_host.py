@@ -466,3 +466,17 @@ def test_render_utils_shim_has_every_name_of_the_two_pybind_modules():
         render_utils.maskcache_lookup(torch.zeros(2, 2, 2, dtype=torch.bool), torch.zeros(3, 3), torch.ones(3), torch.zeros(3))
     with pytest.raises(AttributeError):
         render_utils.no_such_op
+
+
+def test_lts_point_share_adds_up_to_the_references_point_count():
+    """``LtsStep(split_points=True)``: the ranks' surface-point counts add up to ``num_ltspts`` (lts.yaml: 100; 8 ranks used to
+    get 12 each = 96) and their weights to 1, for every world size a node can have."""
+    from esr_nerf_amd.trainer import lts_point_share
+    for P in (100, 25, 7, 64):
+        for world in (1, 2, 3, 4, 5, 6, 7, 8):
+            if world > P:
+                continue
+            shares = [lts_point_share(P, world, r) for r in range(world)]
+            assert sum(n for n, _ in shares) == P and abs(sum(w for _, w in shares) - 1.0) < 1e-12
+            assert max(n for n, _ in shares) - min(n for n, _ in shares) <= 1
+            assert all(abs(w - n / P) < 1e-15 for n, w in shares)
