@@ -317,6 +317,20 @@ def cpu_baseline_lts(model, scene, s_val, n_rays, iters, stage, tr):
                        f"torch {torch.__version__} CPU ops + oracle/esr_oracle.c")
 
 
+SCENE_OF = {"C2": "giftbox_w", "C3": "dtu scan97", "C4": "giftbox_w", "C5": "book_w"}
+
+
+def pmc_tag(a, stage):
+    """Which committed counter pass roofline.traffic / whole_step quote for this workload (profiles/pmc_traffic.json)."""
+    side = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(side):
+        return None
+    with open(side) as f:
+        wl = json.load(f).get("workloads", {}).get(f"{a.config}/{stage}/{a.dtype}/{float(a.s_val):g}")
+    return {"source": "profiles/pmc_traffic.json", "tag": wl.get("_tag"), "passes": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+            "passes; FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE"} if wl else None
+
+
 def pmc_traffic(a, stage, calls):
     """HBM bytes per launch of the named calls from the committed counter passes (profiles/pmc_traffic.json, one entry
     per workload: tools/pmc_summary.py), or None when no pass was taken on THIS workload.  ``__step__`` = all kernels
@@ -367,7 +381,8 @@ def other_workloads(budget_s=170.0):
             out[name] = {"rays_per_s": d["value"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "steps": d["steps"],
                          "warmup": d["warmup"], "workload": d["config"]["workload"],
                          "roofline": {k: rl.get(k) for k in ("bound", "kernel", "frac", "mfma_frac", "hbm_frac") if k in rl},
-                         "whole_step_frac": (rl.get("whole_step") or {}).get("frac"),
+                         "whole_step": {k: v for k, v in (rl.get("whole_step") or {}).items()
+                                        if k in ("mfma16_frac_issued", "mfma16_frac_algorithmic", "hbm_frac", "traffic_over_compulsory", "frac", "bound")},
                          "c_abi_launches_per_step": d.get("c_abi_launches_per_step")}
         except subprocess.TimeoutExpired:
             out[name] = {"failed": f"timeout after {left:.0f} s"}
@@ -385,24 +400,30 @@ def self_launch(n):
         port = so.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
-    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8")),
-                       capture_output=True, text=True)
-    sys.stderr.write(r.stderr)
-    lines = r.stdout.splitlines()
-    js = [l for l in lines if l.startswith("{")]
-    for l in lines:
-        if not js or l is not js[-1]:
-            print(l)
-    if js:
-        sys.stdout.flush()
-        print(js[-1], flush=True)                 # the ONE JSON line, last on stdout
-    return r.returncode if (r.returncode != 0 or js) else 1
+    # stderr goes straight through; stdout is relayed line by line as it comes (a hung run shows how far it got), the JSON
+    # line held back so that it is the LAST line of this process
+    p = subprocess.Popen(cmd, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8")),
+                         stdout=subprocess.PIPE, text=True, bufsize=1)
+    js = None
+    for l in p.stdout:
+        l = l.rstrip("\n")
+        if l.startswith("{"):
+            if js is not None:
+                print(js, flush=True)
+            js = l
+        else:
+            print(l, flush=True)
+    rc = p.wait()
+    if js is not None:
+        print(js, flush=True)                     # the ONE JSON line, last on stdout
+    return rc if (rc != 0 or js is not None) else 1
 
 
 def main():
     a = parse()
     bad_ranks = None
     headline = (a.config, a.stage, a.dtype, a.s_val, a.oblique, a.grid, a.gpus) == ("C2", None, None, None, False, None, 1)
+    a.baseline_config = a.config                  # the label of the line (C5 runs on C4's scene objects)
     if a.config == "C5":
         a.config, a.stage, a.dtype = "C4", a.stage or "pdra", a.dtype or "bf16"
     a.dtype = a.dtype or "f32"
@@ -559,13 +580,13 @@ def main():
         if a.step_times:
             marks.append(torch.cuda.Event(enable_timing=True))
             marks[-1].record()
-    torch.cuda.synchronize()
-    if marks and rank == 0:
-        print("step times (ms, device):", [round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(len(marks) - 1)], file=sys.stderr)
     if pg is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if marks and rank == 0:       # (read back behind the clock: the line's value does not contain the read-backs; the per-step
+        #  event records inside the loop remain -- config.step_times marks such a line)
+        print("step times (ms, device):", [round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(len(marks) - 1)], file=sys.stderr)
     calls_per_step = (getattr(eng, "n_calls", 0) - calls0) / max(a.steps, 1)
     if pg is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -683,7 +704,8 @@ def main():
         phases = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in prof.profile(step._flat[: step._n_grid]).items()}
 
     sweep = None
-    if pg is not None and (a.sync_sweep or (2 <= world <= 4 and not a.no_sync_sweep)) and stage != "finetune":
+    if (pg is not None and (a.sync_sweep or (2 <= world <= 4 and not a.no_sync_sweep)) and stage != "finetune"
+            and getattr(step, "sharded", None) is None):      # (a sharded optimizer forces the shard form: nothing to compare)
         sweep = {}
         keep_mode, keep_sync, keep_used = step._sync_mode, step._sync, getattr(step, "sync_mode_used", None)
         for mode in ("sparse", "dense"):
@@ -714,7 +736,9 @@ def main():
             "vs_baseline": None, "dtype": a.dtype,
             "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)",
             "config": {
-                "workload": f"{a.config}: giftbox_w {stage} stage on the slab scene, {n_rays} rays x {samples} "
+                # BASELINE.json's names: C2 / C4 giftbox_w, C3 dtu scan97, C5 book_w (pdra stage + the re-lighting fine-tune); the
+                # data are the synthetic slab scene of that shape in every case (`data`)
+                "workload": f"{a.baseline_config}: {SCENE_OF.get(a.baseline_config, 'giftbox_w')} {stage} stage on the slab scene, {n_rays} rays x {samples} "
                             f"samples per GPU, grid {'x'.join(str(int(v)) for v in model.world_size.tolist())}, "
                             f"s_val={a.s_val:g}, forward + trainer loss + backward"
                             + (" + the TV lines on every third step" if tv_in_step else "") + " (no optimizer step)"
@@ -724,6 +748,7 @@ def main():
                                "train" if stage == "finetune" else ""),
                 "rays_per_gpu": n_rays, "samples_per_ray": samples if not a.grid else 128, "surviving_samples": counts.get("m3"),
                 "parallelism": f"dp{world}",
+                **({"step_times": True} if a.step_times else {}),      # (events recorded inside the timed loop: a diagnostic line)
             },
             "loss": float(loss),
             # launches of this library's kernels per step (C-ABI calls; torch's own fills / copies / gathers come on top:
@@ -792,11 +817,11 @@ def main():
                     "hbm_frac": hf, "mfma_frac": mf_, "hbm_gbs_algorithmic": gbs,
                     "algorithmic_mb_per_launch": bytes_total / launches / 1e6,
                     "mfma16_tflops_issued": issued, "issued_16bit_gflop_per_launch": 3.0 * flops_total / launches / 1e9,
-                    "fp32_equivalent_tflops": ach, "fp32_equivalent_over_f32_matrix_peak": ach / MFMA_F32_PEAK_TF,
+                    "fp32_equivalent_tflops": ach,
                     "pipe": "v_mfma_f32_32x32x16_f16 on two fp16 planes per fp32 operand (x = x1 + x2), three products per "
                             "algorithmic product, fp32 accumulation and fp32 results; error vs float64 as the f32 MFMA "
                             "kernels' (tests/test_gpu_split.py)",
-                    "pmc": None})
+                    "pmc": dict(pmc_tag(a, stage) or {}, **({"mfma_util": pmc_mfma} if pmc_mfma else {})) or None})
             elif a.dtype == "bf16":                # bf16 operands: the activation traffic, not the MFMA pipe, binds
                 gbs = bytes_total / (ms * 1e-3) / 1e9
                 hf, mf_ = gbs / HBM_PEAK_GBS, ach / MFMA_BF16_PEAK_TF
@@ -880,37 +905,29 @@ def main():
                         "hbm_gbs_algorithmic": by_ / (ms_ * 1e-3) / 1e9, "hbm_frac": by_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "mfma16_frac": 3 * fl_ / (ms_ * 1e-3) / 1e12 / MFMA_F16_PEAK_TF,
                         "fp32_equivalent_tflops": fl_ / (ms_ * 1e-3) / 1e12}
-                out["roofline"]["whole_step"] = {"algorithmic_gflop": step_fl / 1e9,
-                                                 "achieved": step_fl / (dt / a.steps) / 1e12, "peak": peak,
-                                                 "frac": step_fl / (dt / a.steps) / 1e12 / peak,
-                                                 "exact_mac_gflop": exact / 1e9,
-                                                 "frac_exact_mac": exact / (dt / a.steps) / 1e12 / peak}
-                step_traffic = pmc_traffic(a, stage, ["__step__"])
+                ws = out["roofline"]["whole_step"] = {"algorithmic_gflop": step_fl / 1e9, "exact_mac_gflop": exact / 1e9}
                 if split_fwd:
                     # the step against the roofs of the pipes it runs on: issued 16-bit MFMA FLOPs (3 per algorithmic FLOP of
-                    # the exact MAC count) over the fp16 matrix peak, and the step's HBM bytes (PMC) over its wall time
-                    ws = out["roofline"]["whole_step"]
-                    ws["mfma16_issued_tflops"] = 3 * exact / (dt / a.steps) / 1e12
-                    ws["mfma16_frac"] = ws["mfma16_issued_tflops"] / MFMA_F16_PEAK_TF
+                    # the exact MAC count) over the fp16 matrix peak, and the step's HBM bytes (PMC) over its wall time.  (Until
+                    # round 6 the line also carried the algorithmic rate over the F32 matrix peak -- 1.05-1.12, a pipe the
+                    # step does not run on: not a roofline.)
+                    ws["mfma16_frac_issued"] = 3 * exact / (dt / a.steps) / 1e12 / MFMA_F16_PEAK_TF
                     ws["mfma16_frac_algorithmic"] = exact / (dt / a.steps) / 1e12 / MFMA_F16_PEAK_TF
+                else:
+                    ws.update(achieved=step_fl / (dt / a.steps) / 1e12, peak=peak, frac=step_fl / (dt / a.steps) / 1e12 / peak,
+                              frac_exact_mac=exact / (dt / a.steps) / 1e12 / peak)
+                step_traffic = pmc_traffic(a, stage, ["__step__"])
                 if step_traffic:
-                    ws = out["roofline"]["whole_step"]
                     # compulsory bytes per iteration = rays, grids touched once, activations written once and read
                     # once by the backward: 1.31 KB per surviving sample + 80 B per ray = 0.69 GB at C2
                     compulsory = 1310.0 * counts["m3"] + 80.0 * n_rays
-                    ws["hbm_bytes_pmc"] = step_traffic
-                    ws["hbm_gbs"] = step_traffic / (dt / a.steps) / 1e9
-                    ws["hbm_frac"] = ws["hbm_gbs"] / HBM_PEAK_GBS
-                    ws["compulsory_bytes_survey_8d"] = compulsory
+                    ws["hbm_frac"] = step_traffic / (dt / a.steps) / 1e9 / HBM_PEAK_GBS
                     ws["traffic_over_compulsory"] = step_traffic / compulsory
+                    ws["hbm_bytes_pmc"] = step_traffic
+                    ws["compulsory_bytes_survey_8d"] = compulsory
+                    ws["pmc"] = pmc_tag(a, stage)
                     ws["bound"] = ("hbm" if ws["hbm_frac"] >= 0.6 else
-                                   "mfma" if ws.get("mfma16_frac", ws["frac"]) >= 0.6 else "latency")
-                if split_fwd:
-                    out["roofline"]["whole_step"]["note"] = (
-                        "the radiance nets' FLOPs (forward, input and weight gradients; algorithmic, counted once) run on the 16-bit matrix cores since round 4: "
-                        "`frac` is the step's algorithmic FLOP rate over the f32 matrix peak, kept for comparison with earlier "
-                        "rounds -- it is no longer bounded by 1 in principle; the f32-pipe launches are priced one by one in "
-                        "roofline / all_mlp_kernels")
+                                   "mfma" if ws.get("mfma16_frac_issued", ws.get("frac", 0.0)) >= 0.6 else "latency")
                 out["kernel_ms_per_step_instrumented"] = {k: round(v[1] / v[0], 4) for k, v in
                                                     sorted(breakdown.items(), key=lambda kv: -kv[1][1])}
         if breakdown and "kernel_ms_per_step_instrumented" not in out:

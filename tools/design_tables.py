@@ -18,11 +18,11 @@ for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{tag}_bench_*.json"))
     name = os.path.basename(f)[len(tag) + 7:-5]
     d, o = load(tag, name), load(old, name)
     r = d.get("roofline") or {}
-    ws = (r.get("whole_step") or {}).get("frac")
+    ws = (r.get("whole_step") or {}).get("mfma16_frac_issued") or (r.get("whole_step") or {}).get("frac")
     was = f"{o['ms_per_step']:.2f} ms, {o['value'] / 1e6:.2f} M" if o else "-"
     print(f"{name:24s} {d['ms_per_step']:.2f} ms  {d['value'] / 1e6:.2f} M rays/s | start {was} | {r.get('bound')} "
           f"{(r.get('kernel') or '')[:26]} frac {r.get('frac') or 0:.2f} hbm {r.get('hbm_frac') or 0:.2f} mfma {r.get('mfma_frac') or 0:.2f}"
-          + (f" whole-step {ws:.2f}" if ws else ""))
+          + (f" whole-step (issued 16-bit MFMA or own pipe) {ws:.2f}" if ws else ""))
     if name == "c2_f32":
         for k, v in (d.get("kernel_ms_per_step_instrumented") or d.get("kernel_ms_per_step_warmup", {})).items():
             print(f"      {k:18s} {v:.3f}")
