@@ -238,16 +238,34 @@ class FineEngine:
             return False
         ev.synchronize()
         if int(self._range_host[0]) == 0:
+            self._range_streak = 0
             return False
         self.range_flag.zero_()
         if self.split_strict:
+            if self.defer_overflow:
+                # data parallel: raising here would leave the other ranks waiting in the gradient exchange.  The hit travels
+                # with the march-overflow word (summed over the ranks with the loss) and EVERY rank raises at its next check
+                # (trainer._check_overflow / step.close()); this step's gradients must not be used.
+                self.overflow_seen = True
+                self.range_strict_seen = True
+                return False
             raise RuntimeError(self._RANGE_MSG + " (ESR_SPLIT_STRICT=1: no fallback)")
+        import warnings
         if self.split_fallback_steps == 0:
-            import warnings
             warnings.warn(self._RANGE_MSG + ": the step is re-run on the f32 MFMA kernels (slower; counted in "
                           "engine.split_fallback_steps)", RuntimeWarning, stacklevel=3)
         self.split_fallback_steps += 1
+        self._range_streak = getattr(self, "_range_streak", 0) + 1
+        if self._range_streak >= self.RANGE_STREAK_MAX and self.split_fwd:
+            # the cause persists (a weight beyond 1023, a gain bound beyond 2^18): every further step would run the split attempt,
+            # wait on the host and then run again on the f32 MFMA kernels -- more than twice the work.  From here on the engine
+            # IS the f32-MFMA engine (what ESR_SPLIT_FWD=0 selects), and says so once.
+            self.split_fwd = self.split_bwd = self.split_wgrad = self.split_tone_wgrad = False
+            warnings.warn(f"{self.RANGE_STREAK_MAX} consecutive steps left fp16's range: this engine now runs every MLP launch on the "
+                          "f32 MFMA kernels (as with ESR_SPLIT_FWD=0)", RuntimeWarning, stacklevel=3)
         return True
+
+    RANGE_STREAK_MAX = 3
 
     def f32_only(self):
         """Context manager: every MLP launch inside runs on the f32 MFMA kernels (no range limit), on the same buffers."""

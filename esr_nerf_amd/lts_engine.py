@@ -119,8 +119,15 @@ class _PointDraw:
         self._out_t = ring[slot][:k]
         self._job = C.c_void_p(0)
         # numpy's own lock on the generator for the whole start-to-wait window: the worker mutates the MT19937 state in place,
-        # and any other Python thread that draws from np.random meanwhile (a data loader) would race on raw memory
-        self._lock = np.random.mtrand._rand._bit_generator.lock
+        # and any other Python thread that draws from np.random meanwhile (a data loader) would race on raw memory.
+        # RULE for callers (lts_forward / finetune_forward hold this object from the point draw to its result()): the lock is
+        # NOT re-entrant -- no np.random.* call on the calling thread inside that window (it would deadlock; a `prelude`
+        # callback runs before the window opens); other threads' np.random calls stall for the ~0.3 ms of the draw.
+        bg = getattr(getattr(np.random.mtrand, "_rand", None), "_bit_generator", None)
+        if bg is None or not hasattr(bg, "lock"):
+            raise RuntimeError("numpy's global MT19937 exposes no lock (np.random.mtrand._rand._bit_generator.lock): this numpy "
+                               "version is not supported by the in-place point draw")
+        self._lock = bg.lock
         self._lock.acquire()
         try:
             _lib.check(_lib.lib().esr_host_choice_start(C.c_void_p(key_addr), C.c_void_p(pos_addr), C.c_int64(n), C.c_int64(k),

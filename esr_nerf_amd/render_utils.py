@@ -135,7 +135,10 @@ def segment_coo(src, index, out=None, dim_size=None, reduce="sum"):
 
 
 # ---- exported by the reference's extensions but never called from its Python: same names, argument order
-# and return lists (render_utils.cpp:171-173,175-181, total_variation.cpp:31); elementwise launches of csrc/legacy_ops.hip
+# and return lists (render_utils.cpp:171-173,175-181, total_variation.cpp:31); elementwise launches of csrc/legacy_ops.hip.
+# FLOAT32 ONLY: the reference dispatches these over float and double (AT_DISPATCH_FLOATING_TYPES); here a float64 tensor
+# raises RuntimeError (what TORCH_CHECK raises) -- only the three ops the reference actually calls (sample_pts_on_rays,
+# alpha2weight, alpha2weight_backward) carry its double instantiation (the *_f64 entry points).  INTEGRATION.md says the same.
 def infer_t_minmax(rays_o, rays_d, xyz_min, xyz_max, near, far):
     """-> [t_min, t_max]."""
     for t, n in ((rays_o, "rays_o"), (rays_d, "rays_d"), (xyz_min, "xyz_min"), (xyz_max, "xyz_max")):

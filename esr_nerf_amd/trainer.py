@@ -139,8 +139,9 @@ def _check_overflow(step):
         ev.synchronize()
     if float(step._ovf_host[0]) > 0:
         step._ovf_host.zero_()
-        raise RuntimeError("a ray exceeded scene.max_steps on at least one rank in the previous step; the LDS bound of "
-                           "the march kernel is wrong (its rays were skipped)")
+        raise RuntimeError("on at least one rank in the previous step: a ray exceeded scene.max_steps (the LDS bound of the march "
+                           "kernel is wrong, its rays were skipped) or, with ESR_SPLIT_STRICT=1, an MLP operand left fp16's range "
+                           "in a split-fp16 kernel (that step's gradients are not those of the f32 engine)")
 
 
 def _grid_pad(step, n_grid: int) -> int:

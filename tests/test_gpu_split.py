@@ -754,6 +754,48 @@ def test_strict_mode_raises_instead_of_falling_back():
     assert int(eng.range_flag) == 0
 
 
+def test_a_persistent_cause_switches_the_engine_to_the_f32_kernels_and_strict_mode_defers_under_data_parallelism():
+    """(i) a cause that persists (a weight of 1500) would make EVERY step run the split attempt, wait, and run again on
+    the f32 MFMA kernels; after three consecutive fallbacks the engine switches to those kernels for good and warns a second
+    time -- the following steps run once.  (ii) ESR_SPLIT_STRICT=1 under data parallelism (``defer_overflow``): raising inside
+    one rank's step would leave the others waiting in the gradient exchange; the hit is carried by the overflow word
+    instead (every rank raises together at its next check)."""
+    import warnings
+    from esr_nerf_amd.synthetic import slab_scene
+    from esr_nerf_amd.trainer import FineStep
+    from test_gpu_fine_path import build_gpu_model, gpu_batch
+    sc = slab_scene("small", s_val=60.0, oblique=True, n_rays=128, seed=3)
+    b = gpu_batch(sc)
+    m = build_gpu_model(sc, seed=1, grid_seed=2)
+    eng = m.engine
+    eng.range_flag.zero_()
+    m.off_rgbnet.layers()[3].weight.data[1, 7] = 1500.0
+    step = FineStep(m)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always", RuntimeWarning)
+        for i in range(5):
+            calls0 = eng.n_calls
+            loss, grads = step.forward_loss_backward(b, 60.0)
+            torch.cuda.synchronize()
+            assert all(bool(torch.isfinite(v).all()) for v in grads.values())
+            if i == 0:
+                twice = eng.n_calls - calls0
+            if i >= 3:                                                     # one pass over the step's launches, not two
+                assert eng.n_calls - calls0 < 0.7 * twice, (i, eng.n_calls - calls0, twice)
+    assert eng.split_fallback_steps == 3 and not (eng.split_fwd or eng.split_bwd or eng.split_wgrad or eng.split_tone_wgrad)
+    msgs = [str(w.message) for w in rec if issubclass(w.category, RuntimeWarning)]
+    assert len(msgs) == 2 and "now runs every MLP launch on the f32 MFMA kernels" in msgs[1], msgs
+    # (ii)
+    m2 = build_gpu_model(sc, seed=1, grid_seed=2)
+    e2 = m2.engine
+    e2.range_flag.zero_()
+    e2.split_strict, e2.defer_overflow = True, True
+    m2.emo_rgbnet.layers()[0].bias.data[3] = 7.0e4
+    FineStep(m2).forward_loss_backward(b, 60.0)                            # no exception on this rank ...
+    torch.cuda.synchronize()
+    assert e2.overflow_seen and getattr(e2, "range_strict_seen", False)     # ... the hit rides on the overflow word
+
+
 def test_autograd_route_heals_in_the_forward():
     """VoxurfF.forward (the drop-in route: results go to the caller's torch code) waits for the range probe at the end of the
     forward and re-runs it on the f32 MFMA kernels; the backward of that call follows on the f32 kernels."""
