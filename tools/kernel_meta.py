@@ -6,7 +6,15 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fvisibility=hi
          "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only"]
 
 
-EXTRA = {}     # per-source flags, as esr_nerf_amd/build.py
+def _build_extra():
+    """The per-source flags of the product build (esr_nerf_amd/build.py: EXTRA), read from that file so the two cannot drift."""
+    src = open(os.path.join(ROOT, "esr_nerf_amd", "build.py")).read()
+    m = re.search(r"^EXTRA\s*=\s*(\{.*?\})\s*$", src, re.M | re.S)
+    import ast
+    return {k: tuple(v) for k, v in ast.literal_eval(m.group(1)).items()} if m else {}
+
+
+EXTRA = _build_extra()     # per-source flags, as esr_nerf_amd/build.py
 
 
 def asm_of(src, out=None, extra=()):
