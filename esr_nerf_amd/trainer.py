@@ -57,6 +57,12 @@ def lts_point_share(num_ltspts: int, world: int, rank: int):
     return n, n / float(num_ltspts)
 
 
+def default_grid_sync(world: int) -> str:
+    """The exchange form when ``ESR_GRAD_SYNC`` does not force one: ``sparse`` for 2-4 ranks (few usable xGMI links: the wire
+    time dominates), ``dense`` otherwise (link arithmetic, to be replaced by the driver's multi-GPU measurements)."""
+    return "sparse" if 2 <= int(world) <= 4 else "dense"
+
+
 def _grid_sync(step, eng):
     """after_grids callback of a data-parallel step: how the dense-grid gradients are summed over ranks.
 
@@ -82,7 +88,7 @@ def _grid_sync(step, eng):
         raise RuntimeError("ESR_GRAD_SYNC=shard needs step.sharded = grad_sync.ShardedGrids(model, names, group) "
                            "(and optimizer.ShardedGridAdam for the update)")
     if mode == "auto":
-        mode = "sparse" if 2 <= dist.get_world_size(step.pg) <= 4 else "dense"
+        mode = default_grid_sync(dist.get_world_size(step.pg))
     step.sync_mode_used = mode            # what bench.py reports (grad_exchange.mode)
     if mode == "shard":
         def after_grids():

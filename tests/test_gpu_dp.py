@@ -280,25 +280,26 @@ def test_bench_flow_with_two_ranks_rehearsal(scaling):
 
 
 @pytest.mark.parametrize("scaling,stage", [("weak", "fine"), ("strong", "lts")])
-def test_bench_flow_with_five_ranks_rehearsal(scaling, stage):
-    """The >= 5-rank flow before a real node sees it: five real ranks on the test box's one GPU over gloo
-    (ESR_BENCH_REHEARSAL=1) -- five, not eight: this pool kills a run with more than six processes on a card, and the test
-    runner itself is one of them; the rank arithmetic of eight (point shares, shard sizes) is covered on the CPU
-    (tests/test_host.py).  From five ranks on the gradient exchange defaults to the `dense` form (trainer._grid_sync) and
-    the exchange sweep runs only with --sync-sweep: both branches run here, weak (fine stage) and strong (lts stage: rays AND
-    surface points split)."""
+def test_bench_flow_with_the_dense_exchange_rehearsal(scaling, stage):
+    """What a node with >= 5 GPUs runs, before a real node sees it: the `dense` exchange form (one asynchronous
+    all-reduce under the weight-gradient kernels; the default from five ranks on: trainer.default_grid_sync, asserted for every
+    world size on the CPU) and the forced exchange sweep, in bench.py's flow -- weak (fine stage) and strong (lts stage: rays AND
+    surface points split) -- with FOUR real ranks on the test box's one GPU over gloo and ESR_GRAD_SYNC=dense.  Four, not eight
+    or five: this pool kills a run with more than six processes on a card, the test runner is one of them, and a five-rank run
+    inside the full suite was killed with seven counted; the rank arithmetic of eight (point shares, shard sizes, the default's
+    choice) is covered on the CPU (tests/test_host.py)."""
     import json
-    env = dict(os.environ, ESR_BENCH_REHEARSAL="1", OMP_NUM_THREADS="2")
+    env = dict(os.environ, ESR_BENCH_REHEARSAL="1", OMP_NUM_THREADS="2", ESR_GRAD_SYNC="dense")
     out = subprocess.run(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=5", "--master-addr", "127.0.0.1",
-         "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "5", "--steps", "2", "--warmup", "1",
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1",
+         "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
          "--config", "small", "--stage", stage, "--scaling", scaling, "--sync-sweep", "--no-cpu-baseline", "--no-other"],
         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["n_gpus"] == 5 and d["scaling"] == scaling and d["value"] > 0 and "REHEARSAL" in d["data"]
-    assert d["grad_exchange"]["mode"].startswith("dense")                          # >= 5 ranks: one asynchronous all-reduce
-    assert set(d["grad_sync_sweep_ms"]) >= {"sparse", "dense"}                     # the forced sweep ran both forms
+    assert d["n_gpus"] == 4 and d["scaling"] == scaling and d["value"] > 0 and "REHEARSAL" in d["data"]
+    assert d["grad_exchange"]["mode"].startswith("dense")                          # one asynchronous all-reduce
+    assert set(d["grad_sync_sweep_ms"]) >= {"sparse", "dense"}                     # the sweep ran both forms
     assert d["split_fallback_steps"] == 0
 
 

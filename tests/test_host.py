@@ -480,3 +480,10 @@ def test_lts_point_share_adds_up_to_the_references_point_count():
             assert sum(n for n, _ in shares) == P and abs(sum(w for _, w in shares) - 1.0) < 1e-12
             assert max(n for n, _ in shares) - min(n for n, _ in shares) <= 1
             assert all(abs(w - n / P) < 1e-15 for n, w in shares)
+
+
+def test_default_exchange_form_by_world_size():
+    """trainer.default_grid_sync: sparse for 2-4 ranks, dense from five on (and for one rank: nothing to exchange sparsely) -- the
+    branch a node with 8 GPUs takes, which no GPU test can take here (this pool allows six processes per card)."""
+    from esr_nerf_amd.trainer import default_grid_sync
+    assert [default_grid_sync(w) for w in range(1, 9)] == ["dense", "sparse", "sparse", "sparse", "dense", "dense", "dense", "dense"]
