@@ -248,9 +248,9 @@ __device__ __forceinline__ int xperm(int s)                    // position of sa
     return (2 * (r >> 3) + hh) * 8 + (r & 7);
 }
 
-// (launch bound 1, not 2: asked for two waves per SIMD the compiler squeezes into 256 registers with 46 spills -- 0.19 ms at
-// C3; left alone it takes 230 without spills, which still lets two workgroups share a CU -- 0.14 ms)
-__global__ void __launch_bounds__(256, 1) tone_wgrad16_t_kernel(ToneWgArgs A)
+// (two waves per SIMD since round 6: 252 registers, no accumulation-register moves -- 144 per tile before -- and no spills, once
+// the file is built without the SLP vectoriser (esr_nerf_amd/build.py); with it the same bound gave 46 spills, 0.19 ms at C3)
+__global__ void __launch_bounds__(256, 2) tone_wgrad16_t_kernel(ToneWgArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
     __bf16 *w0b = reinterpret_cast<__bf16 *>(lds16);                       // [192][W0B_U]: w0b[u * W0B_U + x] = bf16(W0[u][x])
@@ -338,7 +338,10 @@ __global__ void __launch_bounds__(256, 1) tone_wgrad16_t_kernel(ToneWgArgs A)
 #pragma unroll
         for (int i3 = 0; i3 < 3; ++i3)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ht[i3][r] = fmaxf(ht[i3][r], 0.f);
+            for (int r = 0; r < 16; ++r) {                               // (integer form: one v_max_i32 per value, compiler-visible)
+                const int bits = __float_as_int(ht[i3][r]);
+                ht[i3][r] = __int_as_float(bits > 0 ? bits : 0);
+            }
         // ---- dW1[c][u] += sum_s dzt[c][s] Ht[u][s]: fp32 sums of UNROUNDED values (the saved-tile path rounded both to
         // bf16 on their way to its MFMA; here they are vector operands, and rounding them would only add ~100 vector
         // instructions per tile to a kernel that is bound by its vector work)
