@@ -18,8 +18,21 @@ OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libesr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
+# NO packed-fp32 arithmetic (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 / v_pk_mov_b32) in any product kernel: the target feature is
+# switched off (`-target-feature -packed-fp32-ops`: whatever builds <2 x float> operations -- the SLP vectoriser, the loop vectoriser, a
+# sum of two f32x4 accumulators in the source -- is scalarised by the backend), and the SLP vectoriser with it.
+# Why (round 6, DESIGN 5 "packed fp32"): on this hardware a packed-fp32 instruction whose op_sel reads a HIGH half for the low result
+# (v_pk_add_f32 / v_pk_mul_f32 ... op_sel:[0,1]) returns wrong results in lanes 48-63 while ANOTHER wave of the same SIMD alternates
+# MFMAs with op_sel'd v_fma_mix_f32 -- which is what the split-fp16 kernels do.  tools/ubench/pk_beside_mfma.hip shows it with nothing
+# of this library involved (6.9 M wrong results in 3000 launches, none in any other lane quarter, none beside any other load);
+# esr_expgrad_fwd, whose x / y interpolation weights the SLP vectoriser had packed exactly so, returned wrong rows in 44 % of its
+# launches beside the C2 step and in 1.5 % of the light-transport steps of two ranks sharing a card (profiles/r06_packed_fp32_lanes.txt).
+# Cost: nothing measurable (profiles/r06_ab_noslp_whole_library.txt; the instruction streams of mlp_split / tone_wgrad / feat are
+# unchanged by the feature switch); in tone_wgrad.hip the SLP switch saves 170 registers.  tests/test_isa.py asserts that no kernel
+# of the library holds a packed-fp32 instruction.
+NO_PACKED_FP32 = ["-fno-slp-vectorize", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden",
-         "-Wall", "-Wno-unused-function", "-fno-fast-math"]
+         "-Wall", "-Wno-unused-function", "-fno-fast-math", *NO_PACKED_FP32]
 FLAGS += os.environ.get("ESR_EXTRA_HIPCC_FLAGS", "").split()      # developer experiments (-DESR_EXP_...), build time only
 
 
@@ -37,13 +50,17 @@ def _stamp(paths):
     return h.hexdigest()
 
 
-# per-source flags (none at present).  Tried for mlp_split.hip, which runs ONE wave per SIMD on ~460 registers:
-# `-mllvm -amdgpu-mfma-vgpr-form=1` keeps the MFMA accumulators in the VGPR half (1163 -> 477 v_accvgpr_read per tile group,
-# 6.6 k -> 6.1 k instructions in the loop body) but moves the planes' traffic to v_accvgpr_write: 0.705 -> 0.72 ms at C2.
-# tone_wgrad.hip: the SLP vectoriser packs the per-lane fp32 sums of the weight-gradient kernels into v_pk_fma_f32 / v_pk_add_f32 on
-# register PAIRS -- 150 register moves per tile and 100+ more live registers in tone_wgrad_split_t_kernel (367 registers, or
-# 320 bytes of scratch at two waves per SIMD; 194 registers and no moves without it: round 6).
-EXTRA = {"tone_wgrad.hip": ["-fno-slp-vectorize"]}
+# per-source flags.
+# mlp_split.hip, which runs ONE wave per SIMD on ~430 registers: `-mllvm -amdgpu-mfma-vgpr-form=1` keeps the MFMA accumulators in
+# the VGPR half -- the epilogue's vector instructions read them there instead of through v_accvgpr_read: 600 -> 367 accumulation-
+# register moves per tile group in the radiance forward (5441 -> 5198 instructions), 466 -> 234 in the input gradients (4556 ->
+# 4321).  Round 4 measured the flag slower on that round's kernel (three accumulator sets: the planes' traffic moved to
+# v_accvgpr_write, 0.705 -> 0.72 ms); on today's kernels, three alternating rounds on one box: radiance forward 0.491-0.495 ->
+# 0.479-0.483 ms, C2 step 1.981-1.994 -> 1.972-1.983 ms (round 6; the same flag on mlp.hip moves nothing at C3 / C4 / C5).
+# (tone_wgrad.hip was the first file built without the SLP vectoriser, for registers: packed into v_pk_fma_f32 / v_pk_add_f32 on register
+# PAIRS, the per-lane fp32 sums of tone_wgrad_split_t_kernel cost 150 register moves per tile and 367 registers -- or 320 bytes of
+# scratch at two waves per SIMD -- against 194 registers without.  The flag is library-wide now: FLAGS above.)
+EXTRA = {"mlp_split.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _compile(src):
@@ -58,8 +75,11 @@ def _compile(src):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
-    if r.stderr.strip():
-        sys.stderr.write(r.stderr)
+    # (the host pass of the same command does not know the device feature: "'-packed-fp32-ops' is not a recognized feature for
+    #  this target (ignoring feature)", once per function -- dropped; everything else the compiler says is passed on)
+    err = "\n".join(l for l in r.stderr.splitlines() if "'-packed-fp32-ops' is not a recognized feature" not in l)
+    if err.strip():
+        sys.stderr.write(err + "\n")
     with open(sfile, "w") as f:
         f.write(stamp)
     return obj, True

@@ -160,6 +160,14 @@ dist.destroy_process_group()
 '''
 
 
+def _why(out):
+    """The lines of a failed worker's output that say why (pytest cuts long assertion messages in the middle)."""
+    keep = [l for l in (out.stdout + "\n" + out.stderr).splitlines()
+            if any(k in l for k in ("Error", "error", "assert", "Traceback", "File \"", "DPLTS", "DPGPU", "killed", "Signal", "exitcode"))
+            and "elastic/errors" not in l]
+    return "\n".join(keep[-40:])
+
+
 LTS_WORKER = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1])
@@ -239,7 +247,7 @@ def test_two_rank_lts_step_equals_the_sum_of_its_shards():
             [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
              "--master-addr", "127.0.0.1", "--master-port", "29541", w, ROOT],
             env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    assert out.returncode == 0, _why(out)
     line = [l for l in out.stdout.splitlines() if l.startswith("DPLTS")][0].split()
     assert float(line[1]) < 2e-5
 

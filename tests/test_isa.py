@@ -80,6 +80,16 @@ def asm_reads_behind_mfma(path, every_reader_in=None, hazard=None):
             for s, dst in recent:
                 if slot - s < (HZ if everyone else HAZARD) and srcs & dst:
                     bad.append((func, ln, t, slot - s))
+        # A register that a later NON-MFMA instruction has written no longer holds the MFMA's result: its next reader reads that
+        # instruction's value (vector -> vector needs no wait state, and the write itself -- if compiler-generated -- was placed
+        # behind the MFMA by the compiler's own hazard recogniser).  Matters since round 6: with the accumulators in the
+        # architected half of the register file (mlp_split.hip is built with -amdgpu-mfma-vgpr-form=1) an accumulator register
+        # and a vector temporary can carry the same NUMBER within 19 slots.
+        if not in_asm and ops and (op.startswith("v_") and not op.startswith(("v_cmp", "v_cmpx"))
+                                   or op.startswith(("ds_read", "ds_load", "buffer_load", "global_load", "scratch_load"))):
+            wr = _regs(ops[0])
+            if wr:
+                recent = [(s, dst - wr) for s, dst in recent]
     return bad
 
 
@@ -145,3 +155,17 @@ def test_split_kernels_evaluate_their_step_tables_at_compile_time():
         body = body[: body.index(".Lfunc_end")]
         n_sload, n_branch = len(re.findall(r"\bs_load_dword", body)), len(re.findall(r"\bs_cbranch", body))
         assert n_sload < 40 and n_branch < 80, (name, n_sload, n_branch)
+
+
+def test_no_kernel_of_the_library_holds_a_packed_fp32_instruction():
+    """Round 6 (DESIGN 5 "packed fp32", tools/ubench/pk_beside_mfma.hip): v_pk_add_f32 / v_pk_mul_f32 with an op_sel that reads a
+    high half return wrong results in lanes 48-63 while another wave of the SIMD alternates MFMAs with op_sel'd v_fma_mix_f32 -- the
+    split-fp16 kernels' instruction mix.  The compiler wrote such instructions into esr_expgrad_fwd by itself (SLP vectoriser); the
+    library is built with the packed-fp32 target feature off (esr_nerf_amd/build.py: NO_PACKED_FP32) and every source is checked."""
+    import glob
+    found = {}
+    for src in sorted(glob.glob(os.path.join(ROOT, "esr_nerf_amd", "csrc", "*.hip"))):
+        ops = re.findall(r"^\s+(v_pk_(?:add|mul|fma)_f32|v_pk_mov_b32)\b", open(_asm(os.path.basename(src))).read(), re.M)
+        if ops:
+            found[os.path.basename(src)] = len(ops)
+    assert not found, found

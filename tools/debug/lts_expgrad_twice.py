@@ -1,0 +1,77 @@
+"""tools/debug/lts_repeat.py found rare wrong rows (lanes 48-63 of single waves) in the outputs of esr_expgrad_fwd inside an
+LtsStep when two processes share the GPU.  Here every esr_expgrad_fwd launch of the step is followed, on the same stream, by
+snapshots of its per-slot inputs and TWO more launches with the same arguments into fresh buffers; after the step (device
+idle) a fourth launch gives the settled answer.  Which of the four differ says whether the inputs were in flux.
+   python tools/debug/lts_expgrad_twice.py [steps] & python tools/debug/lts_expgrad_twice.py [steps]; wait"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from esr_nerf_amd import _lib                                             # noqa: E402
+from esr_nerf_amd.config import lts_cfg                                   # noqa: E402
+from esr_nerf_amd.esrnerf import ESRNeRF                                  # noqa: E402
+from esr_nerf_amd.synthetic import init_slab_model, slab_scene            # noqa: E402
+from esr_nerf_amd.trainer import LtsStep                                  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+s_val = 60.0
+sc = slab_scene("small", s_val=s_val, oblique=True, n_rays=192, seed=2)
+torch.manual_seed(0); np.random.seed(0)
+cfg = lts_cfg("cuda:0", num_2ndrays=16, num_ltspts=25)
+m = ESRNeRF(cfg, sc.near, sc.far, sc.xyz_min, sc.xyz_max, sc.mask_xyz_min, sc.mask_xyz_max, sc.mask_alpha_init,
+            sc.mask_density, sc.s_val, sc.num_voxels)
+init_slab_model(m, sc, seed=3)
+m.train()
+eng = m.engine
+eng.overlap_wgrad = False
+b = {k: v.cuda() for k, v in sc.batch.items()}
+b["uncert_masks"] = (torch.arange(192, device="cuda") % 3 == 0)
+step = LtsStep(m, cfg.app.trainer, stage="lts")
+L = eng.L
+log = []
+_run = eng._run
+
+
+def spy(name, fn, *args):
+    _run(name, fn, *args)
+    if not name.startswith("expgrad_fwd"):
+        return
+    n = int(args[9])
+    extra = []
+    for _ in range(2):
+        o = torch.empty(n, 4, device="cuda")
+        a = list(args)
+        a[11] = _lib.ptr(o)
+        _lib.check(fn(*a), name)
+        extra.append(o)
+    log.append((name, args, extra))
+
+
+eng._run = spy
+bad = 0
+for it in range(steps):
+    log.clear()
+    torch.manual_seed(100); np.random.seed(100)
+    step.forward_loss_backward(b, s_val)
+    torch.cuda.synchronize()
+    for name, args, (o2, o3) in log:
+        n = int(args[9])
+        o4 = torch.empty(n, 4, device="cuda")
+        a = list(args)
+        a[11] = _lib.ptr(o4)
+        _lib.check(L.esr_expgrad_fwd(*a), name)
+        torch.cuda.synchronize()
+        valid = slice(None)
+        if args[3] is not None and args[3].value:           # ray/step mode: padding slots are written as zeros, all rows defined
+            pass
+        d2, d3 = (o2 != o4).any(1), (o3 != o4).any(1)
+        if bool(d2.any()) or bool(d3.any()):
+            bad += 1
+            r2, r3 = d2.nonzero().flatten().tolist(), d3.nonzero().flatten().tolist()
+            print(f"[pid {os.getpid()}] step {it} {name}: second launch differs from the settled one in rows {r2[:3]}..({len(r2)}), third in {r3[:3]}..({len(r3)})", flush=True)
+print(f"[pid {os.getpid()}] {bad} launches differed from the settled result in {steps} steps", flush=True)

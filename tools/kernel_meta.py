@@ -3,6 +3,7 @@
 import glob, os, re, subprocess, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fvisibility=hidden", "-fno-fast-math",
+         "-fno-slp-vectorize", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",        # = build.py: NO_PACKED_FP32
          "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only"]
 
 

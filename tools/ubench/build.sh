@@ -2,7 +2,7 @@
 # Build the micro-benchmarks for gfx950 (hipcc cross-compiles without a GPU); run them with
 #   gpurun -- './tools/ubench/lds_atomic'   etc.
 cd "$(dirname "$0")"
-for f in lds_atomic lds_dma_m0 mfma_f32_loop mfma_vmem_mix mfma4_loop mfma_mix permlane_swap mfma_f32_shapes mfma_valu_overlap issue_cost asm_behind_mfma; do
+for f in lds_atomic lds_dma_m0 mfma_f32_loop mfma_vmem_mix mfma4_loop mfma_mix permlane_swap mfma_f32_shapes mfma_valu_overlap issue_cost asm_behind_mfma pk_beside_mfma reg_canary; do
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o $f $f.hip 2>&1 | grep -E "error" 
 done
 ls -la
