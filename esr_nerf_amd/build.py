@@ -19,18 +19,19 @@ LIB = os.path.join(HERE, "libesr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 # NO packed-fp32 arithmetic (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 / v_pk_mov_b32) in any product kernel: the target feature is
-# switched off (`-target-feature -packed-fp32-ops`: whatever builds <2 x float> operations -- the SLP vectoriser, the loop vectoriser, a
-# sum of two f32x4 accumulators in the source -- is scalarised by the backend), and the SLP vectoriser with it.
+# switched off (`-target-feature -packed-fp32-ops`): whatever builds <2 x float> operations -- the SLP vectoriser, the loop
+# vectoriser, a sum of two f32x4 accumulators in the source -- is scalarised by the backend.
 # Why (round 6, DESIGN 5 "packed fp32"): on this hardware a packed-fp32 instruction whose op_sel reads a HIGH half for the low result
 # (v_pk_add_f32 / v_pk_mul_f32 ... op_sel:[0,1]) returns wrong results in lanes 48-63 while ANOTHER wave of the same SIMD alternates
 # MFMAs with op_sel'd v_fma_mix_f32 -- which is what the split-fp16 kernels do.  tools/ubench/pk_beside_mfma.hip shows it with nothing
 # of this library involved (6.9 M wrong results in 3000 launches, none in any other lane quarter, none beside any other load);
 # esr_expgrad_fwd, whose x / y interpolation weights the SLP vectoriser had packed exactly so, returned wrong rows in 44 % of its
 # launches beside the C2 step and in 1.5 % of the light-transport steps of two ranks sharing a card (profiles/r06_packed_fp32_lanes.txt).
-# Cost: nothing measurable (profiles/r06_ab_noslp_whole_library.txt; the instruction streams of mlp_split / tone_wgrad / feat are
-# unchanged by the feature switch); in tone_wgrad.hip the SLP switch saves 170 registers.  tests/test_isa.py asserts that no kernel
-# of the library holds a packed-fp32 instruction.
-NO_PACKED_FP32 = ["-fno-slp-vectorize", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+# Cost: none -- three builds alternating on one box, C2 step: packed 2.066-2.083 ms, this build 2.053-2.070 ms, this build without
+# the SLP vectoriser as well 2.091-2.110 ms (the vectoriser's merged loads and stores are worth keeping; C4 / C3 bf16: within 1 %
+# of each other: profiles/r06_ab_packed_fp32_builds.txt).  tests/test_isa.py asserts that no kernel of the library holds a
+# packed-fp32 instruction.
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-fno-fast-math", *NO_PACKED_FP32]
 FLAGS += os.environ.get("ESR_EXTRA_HIPCC_FLAGS", "").split()      # developer experiments (-DESR_EXP_...), build time only
@@ -57,10 +58,10 @@ def _stamp(paths):
 # 4321).  Round 4 measured the flag slower on that round's kernel (three accumulator sets: the planes' traffic moved to
 # v_accvgpr_write, 0.705 -> 0.72 ms); on today's kernels, three alternating rounds on one box: radiance forward 0.491-0.495 ->
 # 0.479-0.483 ms, C2 step 1.981-1.994 -> 1.972-1.983 ms (round 6; the same flag on mlp.hip moves nothing at C3 / C4 / C5).
-# (tone_wgrad.hip was the first file built without the SLP vectoriser, for registers: packed into v_pk_fma_f32 / v_pk_add_f32 on register
-# PAIRS, the per-lane fp32 sums of tone_wgrad_split_t_kernel cost 150 register moves per tile and 367 registers -- or 320 bytes of
-# scratch at two waves per SIMD -- against 194 registers without.  The flag is library-wide now: FLAGS above.)
-EXTRA = {"mlp_split.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# tone_wgrad.hip: the SLP vectoriser pairs the per-lane fp32 sums of the weight-gradient kernels up in register PAIRS -- 150 register
+# moves per tile and 100+ more live registers in tone_wgrad_split_t_kernel (367 registers, or 320 bytes of scratch at two waves per
+# SIMD; 194 registers and no moves without it: round 6).
+EXTRA = {"tone_wgrad.hip": ["-fno-slp-vectorize"], "mlp_split.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _compile(src):

@@ -3,7 +3,7 @@
 import glob, os, re, subprocess, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fvisibility=hidden", "-fno-fast-math",
-         "-fno-slp-vectorize", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",        # = build.py: NO_PACKED_FP32
+         "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",        # = build.py: NO_PACKED_FP32
          "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only"]
 
 
@@ -23,7 +23,7 @@ def asm_of(src, out=None, extra=()):
     out = out or os.path.join("/tmp", "esr_asm_" + os.path.basename(src) + ".s")
     stamp = out + ".stamp"
     deps = [src] + glob.glob(os.path.join(os.path.dirname(src), "*.h")) + [os.path.join(ROOT, "include", "esr_hip.h")]
-    key = str([(d, os.path.getmtime(d)) for d in deps]) + str(extra)
+    key = str([(d, os.path.getmtime(d)) for d in deps]) + str(extra) + str(FLAGS)
     if not (os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == key):
         subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *extra, "-o", out, src], check=True, stderr=subprocess.DEVNULL)
         open(stamp, "w").write(key)
