@@ -67,6 +67,44 @@ __global__ void __launch_bounds__(256) victim(const float *in, unsigned *bad, in
                 asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(hf) : "v"(u & 0xffffu));
                 asm volatile("v_sub_f32 %0, %1, %2" : "=v"(want[0]) : "v"(x[1]), "v"(hf));
                 got[1] = want[1] = 0.f;
+            } else if (V == 10) {    // mlp.hip's form: the HIGH fp16 half as the ADDEND (third operand)
+                const unsigned u = (__float_as_uint(x[0]) & 0xffff0000u) | 0x3c00u;
+                asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(got[0]) : "v"(x[1]), "v"(fl[1]), "v"(u));
+                float hf;
+                asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(hf) : "v"(u >> 16));
+                asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(want[0]) : "v"(x[1]), "v"(fl[1]), "v"(hf));
+                got[1] = want[1] = 0.f;
+            } else if (V == 11) {    // v_fma_mixlo_f16 / v_fma_mixhi_f16 (fp16 results into the two halves of one register), against v_cvt_f16_f32 of the fp32 fma
+                const unsigned u = 0x3c003c00u;        // (1.0, 1.0): x * 1.0 + fl, rounded once to fp16 -- the fp32 fma below is exact in fp32 only
+                unsigned p = 0;                        // for small integers, so compare the packed register of two identical computations instead
+                unsigned q = 0;
+                asm volatile("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %4, %2, %3 op_sel_hi:[0,0,1]" : "+v"(p) : "v"(x[0]), "v"(fl[1]), "v"(u), "v"(x[1]));
+                asm volatile("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[0,0,1]" : "+v"(q) : "v"(x[0]), "v"(fl[1]), "v"(u));
+                unsigned q2 = 0;
+                asm volatile("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[0,0,1]" : "+v"(q2) : "v"(x[1]), "v"(fl[1]), "v"(u));
+                got[0] = __uint_as_float(p);  want[0] = __uint_as_float((q & 0xffffu) | (q2 << 16));
+                got[1] = want[1] = 0.f;
+            } else if (V == 12) {    // v_cvt_pk_f16_f32 against two v_cvt_f16_f32
+                unsigned p, a, b;
+                asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p) : "v"(x[0]), "v"(x[1]));
+                asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(a) : "v"(x[0]));
+                asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(b) : "v"(x[1]));
+                got[0] = __uint_as_float(p);  want[0] = __uint_as_float((a & 0xffffu) | (b << 16));
+                got[1] = want[1] = 0.f;
+            } else if (V == 13) {    // v_pk_min_u16 (mlp_bf16.hip) against v_min_u32 on the halves
+                const unsigned a = __float_as_uint(x[0]), b = __float_as_uint(x[1]);
+                unsigned p;
+                asm volatile("v_pk_min_u16 %0, %1, %2" : "=v"(p) : "v"(a), "v"(b));
+                const unsigned lo = min(a & 0xffffu, b & 0xffffu), hi = min(a >> 16, b >> 16);
+                got[0] = __uint_as_float(p);  want[0] = __uint_as_float(lo | (hi << 16));
+                got[1] = want[1] = 0.f;
+            } else if (V == 14) {    // v_pk_min_u16 with crossed halves
+                const unsigned a = __float_as_uint(x[0]), b = __float_as_uint(x[1]);
+                unsigned p;
+                asm volatile("v_pk_min_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(p) : "v"(a), "v"(b));
+                const unsigned lo = min(a & 0xffffu, b >> 16), hi = min(a >> 16, b & 0xffffu);
+                got[0] = __uint_as_float(p);  want[0] = __uint_as_float(lo | (hi << 16));
+                got[1] = want[1] = 0.f;
             } else {                 // control: no packed instruction at all
                 asm volatile("v_sub_f32 %0, %1, %2" : "=v"(got[0]) : "v"(x[0]), "v"(fl[0]));
                 asm volatile("v_sub_f32 %0, %1, %2" : "=v"(got[1]) : "v"(x[1]), "v"(fl[1]));
@@ -190,10 +228,11 @@ int main(int argc, char **argv)
     hipStream_t sa, sb;
     CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));  CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
     const char *an[] = {"nothing", "v_mfma_f32_32x32x16_f16", "v_mfma_f32_32x32x2_f32", "v_mfma_f32_4x4x1_f32", "v_fma_f32", "LDS reads/writes", "v_pk_fma_f32", "v_fma_mix_f32 op_sel", "v_cvt_pk_f16_f32", "MFMA + v_fma_mix op_sel"};
-    const char *vn[] = {"v_pk_add_f32", "v_pk_add_f32 neg", "v_pk_add_f32 op_sel neg", "v_pk_mul_f32 op_sel_hi", "v_pk_fma_f32", "scalar only", "v_pk_mul_f32 op_sel", "v_pk_add_f32 op_sel", "v_fma_mix_f32 hi half", "v_fma_mix_f32 lo half"};
+    const char *vn[] = {"v_pk_add_f32", "v_pk_add_f32 neg", "v_pk_add_f32 op_sel neg", "v_pk_mul_f32 op_sel_hi", "v_pk_fma_f32", "scalar only", "v_pk_mul_f32 op_sel", "v_pk_add_f32 op_sel", "v_fma_mix_f32 hi half", "v_fma_mix_f32 lo half",
+                        "v_fma_mix_f32 hi addend", "v_fma_mixlo/hi_f16", "v_cvt_pk_f16_f32", "v_pk_min_u16", "v_pk_min_u16 op_sel"};
     printf("victim: %d launches of %d lanes x %d repetitions per cell; wrong results by lane quarter [0-15, 16-31, 32-47, 48-63]\n", launches, n, reps);
     for (int a = (only_a >= 0 ? only_a : 0); a < (only_a >= 0 ? only_a + 1 : 10); ++a)
-        for (int v = 0; v < 10; ++v) {
+        for (int v = 0; v < 15; ++v) {
             CK(hipMemset(bad, 0, 16));
             CK(hipDeviceSynchronize());
             for (int l = 0; l < launches; ++l) {
@@ -213,6 +252,9 @@ int main(int argc, char **argv)
                 case 4: launch_victim<4>(in, bad, n, reps, sa); break;   case 5: launch_victim<5>(in, bad, n, reps, sa); break;
                 case 6: launch_victim<6>(in, bad, n, reps, sa); break;   case 7: launch_victim<7>(in, bad, n, reps, sa); break;
                 case 8: launch_victim<8>(in, bad, n, reps, sa); break;   case 9: launch_victim<9>(in, bad, n, reps, sa); break;
+                case 10: launch_victim<10>(in, bad, n, reps, sa); break; case 11: launch_victim<11>(in, bad, n, reps, sa); break;
+                case 12: launch_victim<12>(in, bad, n, reps, sa); break; case 13: launch_victim<13>(in, bad, n, reps, sa); break;
+                case 14: launch_victim<14>(in, bad, n, reps, sa); break;
                 }
                 if (l % 50 == 49) CK(hipStreamSynchronize(sa));
             }
