@@ -88,7 +88,7 @@ class _Workspace:
     def ensure(self, tiles: int):
         if tiles <= self.cap_tiles:
             return
-        cap = max(tiles, int(self.cap_tiles * 1.25) + 64)
+        cap = int(max(tiles, self.cap_tiles) * 1.25) + 64          # (headroom from the first allocation on: lts_engine.Pass.ensure)
         self.buf = {k: torch.empty(cap * r * 32, dtype=torch.float32, device=self.device)
                     for k, r in self.ROWS.items()}
         for k in ("M0", "M1", "M2", "Mt"):          # ReLU sign bits, [tiles, 3, 64] u32

@@ -45,8 +45,11 @@ class Pass:
         self.keep: List[torch.Tensor] = []   # tensors referenced by raw pointers
 
     def ensure(self, tiles):
+        # headroom from the FIRST allocation on: the tile counts of the light-transport passes move by +-15 % from step to step
+        # (random surface points and directions), and a step that exceeds the capacity reallocates every buffer of the pass --
+        # 12 hipMalloc calls, 82 ms, once (tools/debug/alloc_per_step.py: step 6 of a C5 run, in the middle of a short bench run)
         if tiles > self.cap:
-            self.cap = max(tiles, int(self.cap * 1.25) + 16)
+            self.cap = int(max(tiles, self.cap) * 1.25) + 16
             self.bufs = {}
 
     def buf(self, name, rows=1, dtype=torch.float32):
