@@ -729,7 +729,7 @@ def main():
         samples = int(round(c["res"] * c["z"] * 2))
         out = {
             "metric": "training rays/sec at 4096 rays x 128 samples (fine stage)" if (a.config, stage, a.dtype, float(a.s_val), a.oblique) == ("C2", "fine", "f32", 20.0, False)
-                      else f"training rays/sec, config {a.config}, {stage} stage, {a.dtype} MLPs, s_val {a.s_val:g}" + (", OBLIQUE rays (not BASELINE's workload)" if a.oblique else "")
+                      else f"training rays/sec, config {a.config if a.grid else a.baseline_config}, {stage} stage, {a.dtype} MLPs, s_val {a.s_val:g}" + (", OBLIQUE rays (not BASELINE's workload)" if a.oblique else "")
                            + (", PRODUCTION-SIZE GRID 256^3 (not BASELINE's workload)" if a.grid else ""),
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling if world > 1 else "weak",
