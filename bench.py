@@ -463,7 +463,20 @@ def main():
         if rehearsal:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device(dev))     # nccl == RCCL on ROCm
+            # RCCL prints a five-line banner (version, HIP / ROCm version, host name, library path) to STDOUT when its
+            # communicator comes up; stdout is for rank 0's one JSON line, so the descriptor points at stderr meanwhile
+            sys.stdout.flush()
+            keep = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("nccl", device_id=torch.device(dev))     # nccl == RCCL on ROCm
+                one = torch.ones(1, device=dev)
+                dist.all_reduce(one)                 # (the communicator is created here at the latest)
+                torch.cuda.synchronize()
+            finally:
+                sys.stdout.flush()
+                os.dup2(keep, 1)
+                os.close(keep)
         pg = dist.group.WORLD
 
     import numpy as np

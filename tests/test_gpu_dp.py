@@ -324,3 +324,20 @@ def test_plain_bench_command_with_gpus_2_launches_its_own_ranks():
     d = json.loads(last)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["dist"]["rccl_ranks"] == 2
     assert d["split_fallback_steps"] == 0
+
+
+def test_bench_under_rccl_prints_one_json_line_and_nothing_else_on_stdout():
+    """The driver's launcher line with ONE rank on the real backend (`nccl` = RCCL; two ranks on one card are refused by it):
+    process-group set-up with `device_id`, the exchange code with a world of one -- and stdout holds rank 0's JSON line only
+    (RCCL prints a banner to stdout when its communicator comes up; bench.py points the descriptor at stderr meanwhile)."""
+    import json
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+         "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+         "--config", "small", "--force-dist", "--no-cpu-baseline", "--no-other", "--no-optimizer"],
+        env=dict(os.environ, OMP_NUM_THREADS="2"), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, _why(out)
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0
