@@ -100,8 +100,6 @@ for name, fn in (("esr_expgrad_fwd", expgrad), ("torch elementwise", plain)):
     bad, lanes = 0, {}
     for it in range(launches):
         o = fn()
-        if it % 8 == 7:           # (a short queue: the host stays ahead, the device changes hands in the middle of kernels)
-            pass
         d = (o != first).any(1)
         if bool(d.any()):
             bad += 1
