@@ -549,10 +549,10 @@ def main():
         """One step; ``it``: iteration number of a timed / warm-up step -- on every TV_EVERY-th the trainer's do_tv
         lines (fine.py:383-400: smoothed-gradient TV value + gradient, in-place 6-neighbour TV gradient) run too."""
         if stage == "fine" and tv_in_step and it is not None and it % TV_EVERY == 0:
-            l_, g_ = step.forward_loss_backward(batch, a.s_val, global_rays=n_rays * world if pg is not None else None,
-                                                entropy_owner=(rank == world - 1))[:2]
-            step.add_regularisers(l_, g_, n_rays * world, W_TV, TVS, True)
-            return l_, g_
+            return step.forward_loss_backward(batch, a.s_val, global_rays=n_rays * world if pg is not None else None,
+                                              entropy_owner=(rank == world - 1),
+                                              regularisers=dict(n_rays_global=n_rays * world, weight_tv_density=W_TV, tvs=TVS,
+                                                                dense_mode=True))[:2]
         if stage == "finetune":                 # loss: 0.5 * mse(lin/pbr/emo, lin/pbr/emo_hat), pdra.py:1090-1093
             return step.forward_loss_backward(batch, a.s_val)
         # N > 1: this rank's rays are one shard of a global batch of n_rays * N rays

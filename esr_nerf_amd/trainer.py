@@ -289,18 +289,25 @@ class FineStep:
     @torch.no_grad()
     def forward_loss_backward(self, batch: Dict[str, torch.Tensor], s_val: float,
                               global_rays: Optional[int] = None,
-                              entropy_owner: bool = True) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+                              entropy_owner: bool = True,
+                              regularisers: Optional[dict] = None) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
         """``global_rays``: size of the whole batch when ``batch`` is one rank's shard.
         ``entropy_owner``: the reference's entropy term looks at the LAST ray of the batch only
         (fine.py:378), so under sharding exactly one rank -- the one holding the global last ray --
-        must add it."""
+        must add it.
+        ``regularisers``: the arguments of ``add_regularisers`` (dict n_rays_global, weight_tv_density, tvs, dense_mode) on an
+        iteration whose ``do_tv`` lines run (fine.py:383-400).  The step then adds them itself, in the reference's order
+        (after the backward's sums into ``sdf.grid``'s gradient), but as soon as the grid scatters are enqueued: the three
+        dense-grid launches (0.13 ms at C2, no LDS, few registers) run BESIDE the weight-gradient kernels of the second
+        stream instead of behind them.  Same launches, same order of additions: results are those of calling
+        ``add_regularisers`` on the returned gradients, bit for bit.  (Data parallel: after the exchange, as before.)"""
         m = self.model
         eng = m.engine
         m.s_val = s_val
         ps = m._mlp_params()
         g = None
         with _OverflowScope(eng, self.pg is not None):
-            return self._step(batch, s_val, global_rays, entropy_owner, m, eng, ps)
+            return self._step(batch, s_val, global_rays, entropy_owner, m, eng, ps, regularisers)
 
     def close(self):
         """Call once after the final step (data parallel): reports a march overflow flagged by that step."""
@@ -317,18 +324,18 @@ class FineStep:
             self.close()
         return False
 
-    def _step(self, batch, s_val, global_rays, entropy_owner, m, eng, ps):
-        res = self._attempt(batch, s_val, global_rays, entropy_owner, m, eng, ps)
+    def _step(self, batch, s_val, global_rays, entropy_owner, m, eng, ps, regularisers=None):
+        res = self._attempt(batch, s_val, global_rays, entropy_owner, m, eng, ps, regularisers)
         if res is None:
             # a split-fp16 kernel of the forward raised the range flag (fine_engine.py): nothing has left the step -- no
             # exchange was started, no gradient handed out -- so the whole step runs again on the f32 MFMA kernels.  The
             # second attempt's launches are ordered behind the first's on every stream they share, and its prelude zeroes
             # the gradient buffer again.
             with eng.f32_only():
-                res = self._attempt(batch, s_val, global_rays, entropy_owner, m, eng, ps)
+                res = self._attempt(batch, s_val, global_rays, entropy_owner, m, eng, ps, regularisers)
         return res
 
-    def _attempt(self, batch, s_val, global_rays, entropy_owner, m, eng, ps):
+    def _attempt(self, batch, s_val, global_rays, entropy_owner, m, eng, ps, regularisers=None):
         g = None
 
         def prelude():        # independent of the march: runs on the device while the host waits for the plan header
@@ -360,6 +367,10 @@ class FineStep:
             # grid gradients (218 MB at C2, >99 % of the payload) are final when the engine calls this:
             # their exchange runs underneath the wgrad kernels
             after_grids, works = _grid_sync(self, eng)
+        elif regularisers is not None:
+            # the do_tv lines, behind the grid scatters on the main stream and beside the weight gradients of the second one
+            # (a range fallback returns before this is called: _RangeGuard)
+            after_grids = lambda: self.add_regularisers(loss, g, **regularisers)
         else:
             after_grids = None
         guard = _RangeGuard(eng, after_grids)
@@ -375,6 +386,8 @@ class FineStep:
             _publish_overflow(self, lf)
             if self._sync is not None:
                 self._sync.verify()       # everything of the step is enqueued: close the brick exchange
+            if regularisers is not None:
+                self.add_regularisers(loss, g, **regularisers)
         g["off_color.grid"] = g["off_color.grid"].permute(0, 4, 1, 2, 3)     # logical [1,6,X,Y,Z]
         g["emo_color.grid"] = g["emo_color.grid"].permute(0, 4, 1, 2, 3)
         return loss, g

@@ -136,3 +136,30 @@ def test_pdra_loop_with_ray_groups():
         assert np.isfinite(float(loss))
     assert float((m.emitnet.brdfnet[0].weight.detach() - before).abs().max()) > 0
     assert groups.stats()["total"] == 1536
+
+
+def test_regularisers_inside_the_step_equal_the_call_after_it():
+    """``FineStep.forward_loss_backward(regularisers=...)`` launches the do_tv lines itself -- behind the grid scatters, beside the
+    weight gradients of the second stream -- instead of the caller after the step: same launches on the same data in the same
+    order, so loss and gradients agree to the scatter atomics' run-to-run noise, and the TV share is there (fine.py:383-400)."""
+    from esr_nerf_amd.trainer import FineStep
+    m, sc = _fresh()
+    with torch.no_grad():            # a rough SDF grid: the TV terms are not negligible beside the image loss
+        m.sdf.grid.add_(0.02 * torch.randn(m.sdf.grid.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4)))
+    batch = {k: v.cuda() for k, v in sc.batch.items()}
+    step = FineStep(m)
+    args = dict(n_rays_global=batch["rgbs"].shape[0], weight_tv_density=0.01, tvs=TVS, dense_mode=True)
+    loss0, g0 = step.forward_loss_backward(batch, 40.0)
+    loss0, g0 = float(loss0), {k: v.clone() for k, v in g0.items()}
+    loss1, g1 = step.forward_loss_backward(batch, 40.0)
+    step.add_regularisers(loss1, g1, **args)
+    loss1, g1 = float(loss1), {k: v.clone() for k, v in g1.items()}
+    for overlap in (True, False):
+        m.engine.overlap_wgrad = overlap
+        loss2, g2 = step.forward_loss_backward(batch, 40.0, regularisers=args)
+        assert abs(float(loss2) - loss1) < 1e-6 * abs(loss1), (float(loss2), loss1)
+        assert set(g2) == set(g1)
+        for k in g1:
+            assert rel_err(g2[k], g1[k]) < 2e-6, (overlap, k, rel_err(g2[k], g1[k]))
+    m.engine.overlap_wgrad = True
+    assert loss1 > loss0 and rel_err(g1["sdf.grid"], g0["sdf.grid"]) > 1e-4          # the regularisers do something here (noise: 1e-7)
