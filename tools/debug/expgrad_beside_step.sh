@@ -1,7 +1,7 @@
 #!/bin/bash
 # esr_expgrad_fwd (tools/debug/two_process_lanes.py: the same launch 30000 times, every result compared with the first) while ANOTHER
 # process runs the C4 light-transport step on the same card: packed build of lts.hip / in-tree library / packed build again.
-#   gpurun -- 'bash tools/debug/expgrad_beside_step.sh'        (tools/_variants/lts_slp.so: lts.hip compiled WITHOUT build.py's NO_PACKED_FP32)
+#   bash tools/debug/build_lts_slp_variant.sh && gpurun -- "bash tools/debug/expgrad_beside_step.sh"
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 B="--no-cpu-baseline --no-other --no-optimizer --no-kernel-timing --warmup 5"
 python bench.py --config C4 --steps 9000 $B > gpurun_out/agg.txt 2>&1 &
