@@ -344,7 +344,17 @@ __global__ void __launch_bounds__(64 * SPW, split_occ(KIND)) mlp_fwd_split_kerne
                 // sank to the kernel's end and kept every value alive; operands are the integer max's VALU results)
                 asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(rmax) : "v"(__float_as_int(v0)), "v"(__float_as_int(v1)));
                 const rsrc_t RH = make_rsrc(AB.H[l] + (size_t)t * (HBYTES / 4), hrec);      // fp32 tile, mlp.hip's store_tiles order
-#ifndef ESR_SPLIT_NO_HSTORE
+#if defined(ESR_SPLIT_H24)
+                // timing variant (tools/ubench/split_stamps_h24: what would a 3-byte tile format cost / return in THIS kernel?):
+                // the top 24 bits of a row pair's two values as one dword + one short store (wrong layout, right byte count)
+                asm volatile("" : "+v"(hv));
+                {
+                    const unsigned u0 = __float_as_uint(v0), u1 = __float_as_uint(v1);
+                    const unsigned hi2 = __builtin_amdgcn_perm(u1, u0, 0x07060302u), mid2 = __builtin_amdgcn_perm(u1, u0, 0x0c0c0501u);
+                    bstore1_nt(RH, __uint_as_float(hi2), hv + tile_soff(0, r0), it * 4096);
+                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)mid2, RH, hv + tile_soff(0, r0 + 1), it * 4096, ESR_NT_AUX);
+                }
+#elif !defined(ESR_SPLIT_NO_HSTORE)
                 asm volatile("" : "+v"(hv));                       // (opaque per slice: a shared `hv + row offset` is kept in a
                 bstore1_nt(RH, v0, hv + tile_soff(0, r0), it * 4096);       //  register of its own instead of the store's immediate)
                 bstore1_nt(RH, v1, hv + tile_soff(0, r0 + 1), it * 4096);

@@ -11,7 +11,7 @@ for f in fwd_stamps dgrad_stamps fwd16_stamps tone_stamps split_stamps ldsread_s
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-fast-math -I../../include -I../../esr_nerf_amd/csrc -o $f $f.hip 2>&1 | grep -E "error"
 done
 # timing variants of the split forward's stamps (wrong results, one ingredient removed each)
-for v in NO_MFMA NO_HSTORE NO_WREAD; do
+for v in NO_MFMA NO_HSTORE NO_WREAD H24; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-fast-math -DESR_SPLIT_$v -I../../include -I../../esr_nerf_amd/csrc \
       -o split_stamps_$(echo $v | tr 'A-Z' 'a-z') split_stamps.hip 2>&1 | grep -E "error"
 done
