@@ -487,3 +487,24 @@ def test_default_exchange_form_by_world_size():
     branch a node with 8 GPUs takes, which no GPU test can take here (this pool allows six processes per card)."""
     from esr_nerf_amd.trainer import default_grid_sync
     assert [default_grid_sync(w) for w in range(1, 9)] == ["dense", "sparse", "sparse", "sparse", "dense", "dense", "dense", "dense"]
+
+
+def test_workspace_capacity_has_headroom_from_the_first_allocation():
+    """lts_engine.Pass / fine_engine._Workspace: grow-only, 25 % headroom from the FIRST allocation on (round 6: a step that
+    exceeded the first step's tile count by 1 % reallocated every buffer of a pass -- 12 hipMalloc calls, 82 ms)."""
+    from esr_nerf_amd.lts_engine import Pass
+    p = Pass("cpu", "t")
+    p.ensure(1000)
+    assert p.cap == 1266
+    b = p.buf("x", rows=2)
+    p.ensure(1200)                                   # within the headroom: the same buffers
+    assert p.cap == 1266 and p.buf("x", rows=2) is b
+    p.ensure(1300)                                   # beyond: larger, the old buffers dropped
+    assert p.cap == int(1300 * 1.25) + 16 and p.buf("x", rows=2) is not b
+    from esr_nerf_amd.fine_engine import _Workspace
+    w = _Workspace("cpu")
+    w.ensure(100)
+    assert w.cap_tiles == 189
+    x = w["X"]
+    w.ensure(150)
+    assert w.cap_tiles == 189 and w["X"] is x
