@@ -102,7 +102,7 @@ def parse():
                     help="initialise the process group and run the gradient all-reduces even with one rank (self-test)")
     ap.add_argument("--no-optimizer", action="store_true", help="skip the separately reported fused-Adam timing")
     ap.add_argument("--no-tv", action="store_true",
-                    help="fine stage: leave the trainer's every-third-iteration TV lines (SURVEY A12, fine.py:383-400) out of "
+                    help="leave the trainers' every-third-iteration TV lines (SURVEY A12; fine.py:383-400, lts.py:381-398, pdra.py:459-476) out of "
                          "the timed steps (they are inside by default: the metric is forward A1-A12 + loss + backward)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not bracket kernels with HIP events (drops the roofline object)")
@@ -542,13 +542,16 @@ def main():
         if hasattr(eng, "wgrad_early"):
             eng.wgrad_early, eng.scatter_streamed, eng.eps_stream = set(), set(), False
 
-    tv_in_step = stage == "fine" and not a.no_tv
-    TVS, W_TV, TV_EVERY = dict(sdf=0.1, smooth_grad=0.05), 0.01, 3        # cfg/app/fine.yaml:73-83
+    # the trainers' do_tv lines: the same block, with the same weights and period, in all three training loops
+    # (fine.py:383-400, lts.py:381-398, pdra.py:459-476; cfg/app/fine.yaml:73-83, lts.yaml:91-98, pdra.yaml:100-107);
+    # the re-lighting fine-tune has none (pdra.py:1047-1109)
+    tv_in_step = stage in ("fine", "lts", "pdra") and not a.no_tv
+    TVS, W_TV, TV_EVERY = dict(sdf=0.1, smooth_grad=0.05), 0.01, 3
 
     def one(it=None):
         """One step; ``it``: iteration number of a timed / warm-up step -- on every TV_EVERY-th the trainer's do_tv
         lines (fine.py:383-400: smoothed-gradient TV value + gradient, in-place 6-neighbour TV gradient) run too."""
-        if stage == "fine" and tv_in_step and it is not None and it % TV_EVERY == 0:
+        if tv_in_step and it is not None and it % TV_EVERY == 0:
             return step.forward_loss_backward(batch, a.s_val, global_rays=n_rays * world if pg is not None else None,
                                               entropy_owner=(rank == world - 1),
                                               regularisers=dict(n_rays_global=n_rays * world, weight_tv_density=W_TV, tvs=TVS,
@@ -697,7 +700,7 @@ def main():
         zero_ms = (time.perf_counter() - t1) / 5 * 1e3
     # the trainer's every-third-iteration TV lines (fine.py:383-400), reported separately like the optimizer
     tv_ms = None
-    if not a.no_optimizer and stage == "fine":
+    if not a.no_optimizer and stage in ("fine", "lts", "pdra"):
         l_tv, g_tv = one()
         for _ in range(2):
             step.add_regularisers(l_tv, g_tv, n_rays * world, W_TV, TVS, True)
@@ -781,7 +784,7 @@ def main():
         if tv_ms is not None:
             out["tv_terms"] = {"ms": tv_ms, "every": TV_EVERY, "kernels": "esr_smooth_grad_tv_fwd/bwd + esr_tv_add_grad",
                                "in_timed_steps": tv_in_step,
-                               "note": "do_tv lines of the trainer (fine.py:383-400): run on every third TIMED step (part of "
+                               "note": "do_tv lines of the trainer (fine.py:383-400, lts.py:381-398, pdra.py:459-476): run on every third TIMED step (part of "
                                        "value / ms_per_step) and timed alone here" if tv_in_step else
                                        "do_tv lines of the trainer (fine.py:383-400), timed alone; NOT in the timed steps (--no-tv)"}
         if dominant:

@@ -211,6 +211,18 @@ class _RangeGuard:
             self.after_grids()
 
 
+def _add_regularisers(m, loss, grads, n_rays_global, weight_tv_density, tvs, dense_mode):
+    """The trainers' ``do_tv`` lines (fine.py:383-400, lts.py:381-398, pdra.py:459-476: the same block in all three)."""
+    from . import render_utils
+    w = weight_tv_density * tvs["smooth_grad"]
+    loss1 = loss.reshape(1)
+    m.smooth_grad_tv_fwd(w, loss1)
+    m.smooth_grad_tv_bwd(w, grads["sdf.grid"])
+    wt = weight_tv_density * tvs["sdf"] / n_rays_global * max(m._world_size_l) / 128
+    render_utils.total_variation_add_grad(m.sdf.grid.detach(), grads["sdf.grid"], wt, wt, wt, dense_mode)
+    return loss
+
+
 def _finish(step):
     """After the LAST step: the march-overflow flag of a data-parallel step is examined by the next step's
     ``_check_overflow``; this examines the final one (data parallel: every rank raises together).  (The split-fp16 kernels'
@@ -399,15 +411,7 @@ class FineStep:
         ``loss += w * smoothed-gradient TV`` with its SDF gradient (csrc/tv.hip, fused forward + backward), then the
         in-place 6-neighbour TV gradient (``sdf_total_variation_add_grad``).  Dense-grid work on replicated
         parameters: under data parallelism call it AFTER the exchange, identically on every rank."""
-        from . import render_utils
-        m = self.model
-        w = weight_tv_density * tvs["smooth_grad"]
-        loss1 = loss.reshape(1)
-        m.smooth_grad_tv_fwd(w, loss1)
-        m.smooth_grad_tv_bwd(w, grads["sdf.grid"])
-        wt = weight_tv_density * tvs["sdf"] / n_rays_global * max(m._world_size_l) / 128
-        render_utils.total_variation_add_grad(m.sdf.grid.detach(), grads["sdf.grid"], wt, wt, wt, dense_mode)
-        return loss
+        return _add_regularisers(self.model, loss, grads, n_rays_global, weight_tv_density, tvs, dense_mode)
 
     def assign_grads(self, grads: Dict[str, torch.Tensor]):
         """Expose the step's gradients as ``param.grad`` (for a torch optimizer)."""
@@ -541,23 +545,31 @@ class LtsStep:
 
     @torch.no_grad()
     def forward_loss_backward(self, batch: Dict[str, torch.Tensor], s_val: float, global_rays: Optional[int] = None,
-                              entropy_owner: bool = True, draws=None):
+                              entropy_owner: bool = True, draws=None, regularisers: Optional[dict] = None):
+        """``regularisers``: as ``FineStep.forward_loss_backward`` -- the arguments of ``add_regularisers`` on an iteration whose
+        ``do_tv`` lines run (lts.py:381-398, pdra.py:459-476); launched behind the grid scatters, beside the last
+        weight-gradient jobs."""
         m, t = self.model, self.t
         eng = m.engine
         m.s_val = s_val
         ps = m._mlp_params()
         with _OverflowScope(eng, self.pg is not None):
-            return self._step(batch, s_val, global_rays, entropy_owner, draws, m, t, eng, ps)
+            return self._step(batch, s_val, global_rays, entropy_owner, draws, m, t, eng, ps, regularisers)
 
-    def _step(self, batch, s_val, global_rays, entropy_owner, draws, m, t, eng, ps):
-        res = self._attempt(batch, s_val, global_rays, entropy_owner, draws, m, t, eng, ps)
+    def add_regularisers(self, loss: torch.Tensor, grads: Dict[str, torch.Tensor], n_rays_global: int,
+                         weight_tv_density: float, tvs: Dict[str, float], dense_mode: bool):
+        """The ``do_tv`` lines of the LTS / PDRA trainers (lts.py:381-398, pdra.py:459-476): ``FineStep.add_regularisers``."""
+        return _add_regularisers(self.model, loss, grads, n_rays_global, weight_tv_density, tvs, dense_mode)
+
+    def _step(self, batch, s_val, global_rays, entropy_owner, draws, m, t, eng, ps, regularisers=None):
+        res = self._attempt(batch, s_val, global_rays, entropy_owner, draws, m, t, eng, ps, regularisers)
         if res is None:
             # the range fallback (FineStep._step): again on the f32 MFMA kernels, with the SAME random draws
             with eng.f32_only():
-                res = self._attempt(batch, s_val, global_rays, entropy_owner, eng.last_draws, m, t, eng, ps)
+                res = self._attempt(batch, s_val, global_rays, entropy_owner, eng.last_draws, m, t, eng, ps, regularisers)
         return res
 
-    def _attempt(self, batch, s_val, global_rays, entropy_owner, draws, m, t, eng, ps):
+    def _attempt(self, batch, s_val, global_rays, entropy_owner, draws, m, t, eng, ps, regularisers=None):
         from .fine_engine import KIND_RADIANCE as KR, KIND_TONEMAP as KT
         from .lts_engine import KIND_BRDF as KB, KIND_EMIT as KE
         G = None
@@ -624,6 +636,8 @@ class LtsStep:
             # the four grid gradients (> 99 % of the payload) are final when the engine calls this: their exchange
             # runs underneath the weight-gradient kernels
             after_grids, works = _grid_sync(self, eng)
+        elif regularisers is not None:
+            after_grids = lambda: self.add_regularisers(loss, G, **regularisers)      # (FineStep._attempt)
         else:
             after_grids = None
         guard = _RangeGuard(eng, after_grids)
@@ -640,6 +654,8 @@ class LtsStep:
             _publish_overflow(self, lf)
             if self._sync is not None:
                 self._sync.verify()       # everything of the step is enqueued: close the brick exchange
+            if regularisers is not None:
+                self.add_regularisers(loss, G, **regularisers)
         for k in ("off_color.grid", "emo_color.grid", "brdf.grid"):
             G[k] = G[k].permute(0, 4, 1, 2, 3)
         return loss, G, out

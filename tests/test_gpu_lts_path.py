@@ -279,6 +279,40 @@ def test_lts_step_equals_autograd_route(stage):
     assert not bad, str(bad)
 
 
+@pytest.mark.parametrize("stage", ["lts", "pdra"])
+def test_lts_step_regularisers_inside_the_step_equal_the_call_after_it(stage):
+    """The do_tv lines of the LTS / PDRA trainers (lts.py:381-398, pdra.py:459-476) launched by the step itself -- behind the grid
+    scatters, beside the last weight-gradient jobs -- against ``add_regularisers`` on the returned gradients, on identical draws."""
+    from esr_nerf_amd.synthetic import init_slab_model, slab_scene
+    from esr_nerf_amd.trainer import LtsStep
+    s_val, n_rays, R, Pn = 70.0, 256, 16, 24
+    sc = slab_scene("small", s_val=s_val, oblique=True, n_rays=n_rays, seed=2)
+    m, cfg = build_lts_model(sc, num_2ndrays=R, num_ltspts=Pn)
+    init_slab_model(m, sc, seed=3)
+    with torch.no_grad():
+        m.brdf.grid.normal_(0.0, 0.3)
+        m.sdf.grid.add_(0.02 * torch.randn(m.sdf.grid.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4)))
+    m.pdra_mode = stage == "pdra"
+    b = {k: v.cuda() for k, v in sc.batch.items()}
+    b["uncert_masks"] = (torch.arange(n_rays, device="cuda") % 3 == 0)
+    step = LtsStep(m, cfg.app.trainer, stage=stage)
+    step.forward_loss_backward(b, s_val)
+    draws = dict(m.engine.last_draws)
+    # (ten times the trainers' weight_tv_density: the lines' share of sdf.grid's gradient stands well clear of the atomics' noise)
+    args = dict(n_rays_global=n_rays, weight_tv_density=0.1, tvs=dict(sdf=0.1, smooth_grad=0.05), dense_mode=True)
+    loss0, G0, _ = step.forward_loss_backward(b, s_val, draws=draws)
+    loss0, G0 = float(loss0), {k: v.clone() for k, v in G0.items()}
+    loss1, G1, _ = step.forward_loss_backward(b, s_val, draws=draws)
+    step.add_regularisers(loss1, G1, **args)
+    loss1, G1 = float(loss1), {k: v.clone() for k, v in G1.items()}
+    loss2, G2, _ = step.forward_loss_backward(b, s_val, draws=draws, regularisers=args)
+    assert abs(float(loss2) - loss1) < 1e-6 * abs(loss1), (float(loss2), loss1)
+    assert set(G2) == set(G1) and len(G1) == 43
+    for k in G1:
+        assert rel_err(G2[k], G1[k]) < 5e-6, (k, rel_err(G2[k], G1[k]))
+    assert loss1 > loss0 and rel_err(G1["sdf.grid"], G0["sdf.grid"]) > 5e-5          # (the lines do something on this grid)
+
+
 @pytest.mark.parametrize("stage,dtype", [("lts", "f32"), ("pdra", "f32"), ("pdra", "bf16")])
 def test_lts_backward_on_three_streams_equals_the_one_stream_order(stage, dtype):
     """The step's stream schedule (weight-gradient jobs flushed to the second stream at points inside the backward, the
