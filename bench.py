@@ -231,39 +231,49 @@ def cpu_baseline(model, scene, s_val, n_rays, iters):
                        f"(host has {os.cpu_count()} logical cores), torch {torch.__version__} CPU ops + oracle/esr_oracle.c")
 
 
-def lts_mlp_work(breakdown, eng, n_prof, bf16):
+def lts_counts(eng):
+    """The sizes ``lts_mlp_work`` prices one step with: taken right behind THAT step (survivor counts and the secondary pass
+    change from step to step with the random surface points and directions)."""
+    return dict(prim=dict(eng.prim.counts), pts_tiles=eng.pts.tiles_all, sec_m3=eng.sec.counts.get("m3", 0),
+                wgrad_jobs=list(getattr(eng, "last_wgrad_jobs", [])))
+
+
+def lts_mlp_work(breakdown, snaps, n_prof, bf16):
     """Algorithmic FLOPs, algorithmic HBM bytes and milliseconds per step of every MLP launch of an LTS / PDRA /
-    fine-tune step.  Call names: ``mlp_<op>(<net>)[<pass>]`` (samples per pass from the engine's survivor counts) and
-    ``mlp_wgrad(all)`` = the batched weight gradients (jobs listed by the engine as (net[pass], tiles))."""
-    pc = eng.prim.counts
-    n_of = {"primary": {"off": pc["m3"], "emo": pc["n_on"], "tone": pc["m3"], "brdf": pc["m3"], "emit": pc["m3"]},
-            "points": dict.fromkeys(NETS, eng.pts.tiles_all * 32),
-            "secondary": dict.fromkeys(NETS, eng.sec.counts.get("m3", 0)),
-            "eps": dict.fromkeys(NETS, pc["m3"])}
+    fine-tune step, averaged over the instrumented steps (``snaps``: ``lts_counts`` behind each of them -- the times in
+    ``breakdown`` are those steps' totals).  Call names: ``mlp_<op>(<net>)[<pass>]`` (samples per pass from the engine's
+    survivor counts) and ``mlp_wgrad(all)`` = the batched weight gradients (jobs listed by the engine as (net[pass], tiles))."""
     fl = by = ms = 0.0
     for name, (n, t) in breakdown.items():
-        if name.startswith("tone_wgrad["):                       # f32 engine: tone weight gradients by recomputation
-            k = n_of[name[len("tone_wgrad["):-1]]["tone"]
+        if name.startswith("tone_wgrad[") or (name.startswith("mlp_") and "pack" not in name):
             ms += t / max(n_prof, 1)
-            fl += 2.0 * net_macs("tone", "wgrad") * k
-            by += (NETS["tone"][0] * 4 + 16) * k
-            continue
-        if not name.startswith("mlp_") or "pack" in name:
-            continue
-        ms += t / max(n_prof, 1)
-        if name == "mlp_wgrad(all)":
-            for job, tiles in getattr(eng, "last_wgrad_jobs", []):
-                net, pas = job.rstrip("]").split("[")
-                k = min(tiles * 32, n_of[pas][net])
-                fl += 2.0 * net_macs(net, "wgrad") * k
-                by += net_bytes(net, "wgrad", bf16) * k
-            continue
-        op, rest = name[4:].split("(", 1)
-        net, pas = rest.split(")[")
-        pas = pas.rstrip("]")
-        fl += 2.0 * net_macs(net, op) * n_of[pas][net]
-        by += net_bytes(net, op, bf16) * n_of[pas][net]
-    return fl, by, ms
+    for c in snaps:
+        pc = c["prim"]
+        n_of = {"primary": {"off": pc["m3"], "emo": pc["n_on"], "tone": pc["m3"], "brdf": pc["m3"], "emit": pc["m3"]},
+                "points": dict.fromkeys(NETS, c["pts_tiles"] * 32),
+                "secondary": dict.fromkeys(NETS, c["sec_m3"]),
+                "eps": dict.fromkeys(NETS, pc["m3"])}
+        for name in breakdown:
+            if name.startswith("tone_wgrad["):                       # f32 engine: tone weight gradients by recomputation
+                k = n_of[name[len("tone_wgrad["):-1]]["tone"]
+                fl += 2.0 * net_macs("tone", "wgrad") * k
+                by += (NETS["tone"][0] * 4 + 16) * k
+                continue
+            if not name.startswith("mlp_") or "pack" in name:
+                continue
+            if name == "mlp_wgrad(all)":
+                for job, tiles in c["wgrad_jobs"]:
+                    net, pas = job.rstrip("]").split("[")
+                    k = min(tiles * 32, n_of[pas][net])
+                    fl += 2.0 * net_macs(net, "wgrad") * k
+                    by += net_bytes(net, "wgrad", bf16) * k
+                continue
+            op, rest = name[4:].split("(", 1)
+            net, pas = rest.split(")[")
+            pas = pas.rstrip("]")
+            fl += 2.0 * net_macs(net, op) * n_of[pas][net]
+            by += net_bytes(net, op, bf16) * n_of[pas][net]
+    return fl / max(len(snaps), 1), by / max(len(snaps), 1), ms
 
 
 def cpu_baseline_lts(model, scene, s_val, n_rays, iters, stage, tr):
@@ -611,13 +621,15 @@ def main():
     kern = eng.timing_summary() if in_region else {}     # the bracketed launches: name -> (launches, total ms)
     eng.enable_timing(False)
     # the instrumented steps (outside W and K; every rank runs them: a step is collective when N > 1)
-    breakdown, dominant = {}, None
+    breakdown, dominant, prof_counts = {}, None, []
     if n_prof:
         torch.cuda.synchronize()
         eng.enable_timing(True)
         overlap, eng.overlap_wgrad = eng.overlap_wgrad, False    # one kernel at a time while each is being timed
         for i_ in range(n_prof):
             one(i_)
+            if stage != "fine":
+                prof_counts.append(lts_counts(eng))
         breakdown = {k: (n, ms) for k, (n, ms) in eng.timing_summary().items()}
         eng.overlap_wgrad = overlap
         eng.enable_timing(False)
@@ -759,7 +771,8 @@ def main():
                             f"s_val={a.s_val:g}, forward + trainer loss + backward"
                             + (" + the TV lines on every third step" if tv_in_step else "") + " (no optimizer step)"
                             + ("" if stage == "fine" else f"; + {getattr(step, 'ltspts', model.num_ltspts)} surface points x {model.num_2ndrays} "
-                               f"secondary rays per GPU ({eng.sec.counts.get('m3')} surviving secondary samples)")
+                               f"secondary rays per GPU ({round(sum(c['sec_m3'] for c in prof_counts) / len(prof_counts)) if prof_counts else eng.sec.counts.get('m3')} "
+                               f"surviving secondary samples, mean of the instrumented steps: the draws are random)")
                             + ("; fine-tune target: edited emission + its light transport, only emo_color / emo_rgbnet "
                                "train" if stage == "finetune" else ""),
                 "rays_per_gpu": n_rays, "samples_per_ray": samples if not a.grid else 128, "surviving_samples": counts.get("m3"),
@@ -951,7 +964,7 @@ def main():
                                                 sorted(breakdown.items(), key=lambda kv: -kv[1][1])}
         if breakdown and stage != "fine":
             bf = a.dtype == "bf16"
-            fl, by, ms_mlp = lts_mlp_work(breakdown, eng, n_prof, bf)
+            fl, by, ms_mlp = lts_mlp_work(breakdown, prof_counts, n_prof, bf)
             total_ms = sum(ms_ for _, ms_ in breakdown.values()) / max(n_prof, 1)
             tf, gbs = fl / (ms_mlp * 1e-3) / 1e12, by / (ms_mlp * 1e-3) / 1e9
             peak = MFMA_BF16_PEAK_TF if bf else MFMA_F32_PEAK_TF
