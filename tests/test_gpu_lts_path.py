@@ -306,7 +306,7 @@ def test_lts_step_regularisers_inside_the_step_equal_the_call_after_it(stage):
     step.add_regularisers(loss1, G1, **args)
     loss1, G1 = float(loss1), {k: v.clone() for k, v in G1.items()}
     loss2, G2, _ = step.forward_loss_backward(b, s_val, draws=draws, regularisers=args)
-    assert abs(float(loss2) - loss1) < 1e-6 * abs(loss1), (float(loss2), loss1)
+    assert abs(float(loss2) - loss1) < 1e-5 * abs(loss1), (float(loss2), loss1)
     assert set(G2) == set(G1) and len(G1) == 43
     for k in G1:
         assert rel_err(G2[k], G1[k]) < 2e-5, (k, rel_err(G2[k], G1[k]))          # (the atomics' run-to-run noise: ~1e-6)

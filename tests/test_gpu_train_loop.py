@@ -157,7 +157,7 @@ def test_regularisers_inside_the_step_equal_the_call_after_it():
     for overlap in (True, False):
         m.engine.overlap_wgrad = overlap
         loss2, g2 = step.forward_loss_backward(batch, 40.0, regularisers=args)
-        assert abs(float(loss2) - loss1) < 1e-6 * abs(loss1), (float(loss2), loss1)
+        assert abs(float(loss2) - loss1) < 1e-5 * abs(loss1), (float(loss2), loss1)
         assert set(g2) == set(g1)
         for k in g1:
             assert rel_err(g2[k], g1[k]) < 1e-5, (overlap, k, rel_err(g2[k], g1[k]))      # (the atomics' run-to-run noise: ~1e-7)
